@@ -1,0 +1,76 @@
+"""The oracle (oracle/eemflow_oracle.py) against vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from eemflow_amd.weights import CORR_TAPS_53, seeded_state_dict, synthetic_voxel_pair
+from oracle import eemflow_oracle as O
+
+
+def test_pad_table(golden):
+    g = golden("pad.npz")
+    for h, w, rate, mode, *pad in g["table"].tolist():
+        assert O.input_padder_pad(h, w, "chairs" if mode == 0 else "sintel", rate) == pad
+    x = torch.from_numpy(g["x"])
+    xp = O.replicate_pad(x, g["x_pad"].tolist())
+    assert np.array_equal(xp.numpy(), g["x_padded"])
+    assert np.array_equal(O.unpad(xp, g["x_pad"].tolist()).numpy(), g["x_unpadded"])
+
+
+def test_known_pads():
+    # SURVEY.md Appendix B (probe-verified on the reference)
+    assert O.input_padder_pad(260, 346) == [19, 19, 0, 60]
+    assert O.input_padder_pad(720, 1280) == [0, 0, 0, 48]
+    assert O.input_padder_pad(512, 960) == [0, 0, 0, 0]
+
+
+def test_local_corr(golden):
+    g = golden("local_corr.npz")
+    x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"])
+    np.testing.assert_allclose(O.local_corr81(x, y).numpy(), g["cv81"], atol=1e-6)
+    np.testing.assert_allclose(O.local_corr53(x, y).numpy(), g["cv53"], atol=1e-6)
+    assert tuple(O.CORR_TAPS_53) == tuple(CORR_TAPS_53) and len(CORR_TAPS_53) == 53
+
+
+def test_decoder(golden):
+    g = golden("decoder.npz")
+    sd = O.to_torch_sd(seeded_state_dict(int(g["seed"])))
+    x = torch.from_numpy(g["x"])
+    perm = O.channel_shuffle(torch.arange(100.0).view(1, 100, 1, 1), 5).flatten().numpy().astype(np.int64)
+    assert np.array_equal(perm, g["shuffle_perm"])
+    np.testing.assert_allclose(O.decoder(sd, "decoder_2.", x).numpy(), g["y"], atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["128x192", "260x346", "100x150"])
+def test_eemflow_forward(golden, tag):
+    g = golden(f"eemflow_fwd_{tag}.npz")
+    h, w = g["hw"].tolist()
+    sd = O.to_torch_sd(seeded_state_dict(int(g["seed"])))
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(int(g["input_seed"]), int(g["batch"]), h, w))
+    with torch.no_grad():
+        flow, st = O.eemflow_forward(sd, e1, e2, keep=True)
+    assert st["pad"] == g["pad"].tolist()
+    for k in g.files:
+        if k in st and k != "pad":
+            np.testing.assert_allclose(st[k].numpy(), g[k], atol=2e-6, rtol=1e-5, err_msg=k)
+    np.testing.assert_allclose(flow.numpy(), g["flow"], atol=2e-6, rtol=1e-5)
+
+
+VOX_CASES = ["n20k", "n20k_pol01", "n1", "n2_dt0", "n3_dt0", "n500_raw", "n300_bins3", "n400_unsorted", "n64_const"]
+
+
+@pytest.mark.parametrize("name", VOX_CASES)
+def test_voxelizer(golden, name):
+    g = golden("voxel.npz")
+    h, w, bins, norm = g[f"{name}_hwb"].tolist()
+    feats = O.event_sequence(g[f"{name}_events"], 1e6, True)
+    il, _, ir, _ = O.voxel_indices(feats, bins, h, w)
+    assert np.array_equal(il, g[f"{name}_idx_left"])        # integer indices: bit-exact
+    assert np.array_equal(ir, g[f"{name}_idx_right"])
+    grid = O.voxelize(feats, bins, h, w, bool(norm))
+    ref = g[f"{name}_grid"]
+    assert np.array_equal(np.isnan(grid), np.isnan(ref))
+    np.testing.assert_allclose(np.nan_to_num(grid), np.nan_to_num(ref), atol=1e-6, rtol=1e-6)
+    if not norm:
+        assert np.array_equal(grid, ref)                    # same accumulation order => same bits

@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""EEMFlow hot-path benchmark on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step is one EEMFlow inference forward (libeemflow_hip.so, HIP-graph replay) over one batch of
+synthetic event-voxel pairs already resident in HBM: BASELINE.json configs[1], 1280x720, batch 1.
+Ranks are independent replicas (frames shard over GPUs, no data-path collective): weak scaling.
+Rank 0 prints ONE JSON line with the whole-job frames/s, the roofline of the dominant kernel
+(per-kernel HIP-event timing via eemflow_time_kernels) and the CPU baseline (the oracle - the
+reference's PyTorch-CPU path restated - timed on this host's cores).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+PEAK_MFMA_F32_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix peak
+PEAK_HBM_GBS = 8000.0            # HBM3E spec peak
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=300)
+    p.add_argument("--warmup", type=int, default=30)
+    p.add_argument("--batch", type=int, default=1)
+    p.add_argument("--height", type=int, default=720)
+    p.add_argument("--width", type=int, default=1280)
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
+    p.add_argument("--kernel-reps", type=int, default=20)
+    p.add_argument("--no-graph", action="store_true")
+    return p.parse_args()
+
+
+def cpu_baseline(sd_np, e1, e2, budget_s):
+    """The oracle (PyTorch-CPU restatement of the reference path) on the host cores, bounded sample."""
+    from oracle import eemflow_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = O.to_torch_sd(sd_np)
+    with torch.no_grad():
+        ref = None
+        for _ in range(2):
+            ref, _ = O.eemflow_forward(sd, e1, e2)
+        times = []
+        t_start = time.perf_counter()
+        while (time.perf_counter() - t_start < budget_s and len(times) < 50) or len(times) < 3:
+            t0 = time.perf_counter()
+            O.eemflow_forward(sd, e1, e2)
+            times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return ref, {"value": e1.shape[0] / med, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                 "sample": f"{len(times)} forwards of the same {e1.shape[0]}x5x{e1.shape[2]}x{e1.shape[3]} pair, "
+                           f"median {med * 1e3:.1f} ms, 2 warm-up, torch {torch.__version__} CPU fp32",
+                 "ms_per_frame": med * 1e3 / e1.shape[0]}
+
+
+def load_traffic():
+    path = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    if os.path.exists(path):
+        try:
+            return json.load(open(path))
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    args = parse()
+    from eemflow_amd import _lib, parallel
+    from eemflow_amd.weights import seeded_state_dict, synthetic_voxel_pair
+
+    rank, local_rank, world = parallel.init_distributed()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    B, H, W = args.batch, args.height, args.width
+    L = _lib.lib()
+    sd_np = seeded_state_dict(0)
+    e1_np, e2_np = synthetic_voxel_pair(1 + rank, B, H, W)          # each rank its own frames
+    e1, e2 = torch.from_numpy(e1_np).to(dev), torch.from_numpy(e2_np).to(dev)
+    flow = torch.empty(B, 2, H, W, device=dev)
+    flat = torch.cat([torch.from_numpy(v).reshape(-1) for v in sd_np.values()]).contiguous()
+
+    ctx = ctypes.c_void_p()
+    _lib.check(L.eemflow_create(local_rank, ctypes.byref(ctx)))
+    _lib.check(L.eemflow_load_weights(ctx, flat.data_ptr(), flat.numel(), 5, 5))
+    _lib.check(L.eemflow_set_image_size(ctx, H, W, None))
+    _lib.check(L.eemflow_use_graph(ctx, 0 if args.no_graph else 1))
+    stream = torch.cuda.Stream(device=dev)
+    sp = ctypes.c_void_p(stream.cuda_stream)
+
+    def step():
+        _lib.check(L.eemflow_forward(ctx, e1.data_ptr(), e2.data_ptr(), B, H, W, flow.data_ptr(), H, W, sp))
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    parallel.barrier(dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    parallel.barrier(dev)
+    gpu_ms = ev0.elapsed_time(ev1)
+    value, slowest = parallel.aggregate_throughput(args.steps * B, elapsed, dev)
+
+    if rank == 0:
+        # ---- per-kernel roofline, measured live with HIP events on the launch stream
+        stats = (_lib.KernelStat * 64)()
+        n = ctypes.c_int(0)
+        _lib.check(L.eemflow_time_kernels(ctx, e1.data_ptr(), e2.data_ptr(), B, H, W, flow.data_ptr(), H, W,
+                                          args.kernel_reps, stats, 64, ctypes.byref(n), sp))
+        torch.cuda.synchronize(dev)
+        kernels = []
+        for i in range(n.value):
+            k = stats[i]
+            sec = k.ms * 1e-3
+            ai = k.flops / max(k.bytes, 1.0)
+            bound = "mfma" if ai >= PEAK_MFMA_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9) else "hbm"
+            kernels.append({"name": k.name.decode(), "us": round(k.ms * 1e3, 2), "gflop": round(k.flops / 1e9, 4),
+                            "mbytes": round(k.bytes / 1e6, 3), "bound": bound,
+                            "tflops": round(k.flops / sec / 1e12, 2), "gbs": round(k.bytes / sec / 1e9, 1)})
+        dom = max(kernels, key=lambda k: k["us"])
+        if dom["bound"] == "mfma":
+            roof = {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(dom["tflops"] / PEAK_MFMA_F32_TFLOPS, 4)}
+        else:
+            roof = {"bound": "hbm", "achieved": dom["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(dom["gbs"] / PEAK_HBM_GBS, 4)}
+        traffic = load_traffic()
+        roof["traffic"] = (traffic or {}).get(dom["name"])
+        roof["kernel"] = dom["name"]
+        roof["kernel_us"] = dom["us"]
+        sum_us = sum(k["us"] for k in kernels)
+        enc = [k for k in kernels if k["name"].startswith("enc.")]
+        enc_tflops = sum(k["gflop"] for k in enc) / max(sum(k["us"] for k in enc), 1e-9) * 1e-3
+        total_gflop = sum(k["gflop"] for k in kernels)
+
+        # ---- CPU baseline + EPE agreement on this rank's frames
+        cpu = None
+        extra = {}
+        if args.cpu_seconds > 0:
+            from oracle import eemflow_oracle as O
+            ref, cpu = cpu_baseline(sd_np, torch.from_numpy(e1_np), torch.from_numpy(e2_np), args.cpu_seconds)
+            step()
+            torch.cuda.synchronize(dev)
+            got = flow.cpu()
+            yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+            gt = np.stack([3 * np.sin(2 * np.pi * xx / W), 3 * np.cos(2 * np.pi * yy / H)])
+            extra = {"flow_max_abs_err_vs_oracle": float((got - ref).abs().max()),
+                     "epe_hip": O.flow_error_dense(gt, got[0].numpy())[0],
+                     "epe_oracle": O.flow_error_dense(gt, ref[0].numpy())[0]}
+            extra["speedup_vs_cpu_baseline"] = round(value / world / cpu["value"], 1)
+
+        ms_per_step = slowest * 1e3 / args.steps
+        line = {
+            "metric": "frames/sec + EPE, EEMFlow 1280x720 dt1, 1/2/4/8 MI355X",
+            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"EEMFlow inference, HREM {W}x{H} dt1, batch={B} per GPU (BASELINE configs[1]); "
+                                   "synthetic 20%-dense voxel pairs resident in HBM, seeded Kaiming weights",
+                       "height": H, "width": W, "batch_per_gpu": B, "hip_graph": not args.no_graph,
+                       "parallelism": f"replicas x{world}: frames sharded over ranks, no data-path collective"},
+            "roofline": roof, "cpu_baseline": cpu,
+            "gpu_ms_per_step_hip_events": round(gpu_ms / args.steps, 4),
+            "schedule_sum_us": round(sum_us, 1), "frame_gflop": round(total_gflop, 3),
+            "frame_tflops": round(total_gflop / (ms_per_step / B) * 1e-3, 2),
+            "encoder_tflops_in_kernel": round(enc_tflops, 2),
+            "kernels": kernels, **extra,
+        }
+        print(json.dumps(line), flush=True)
+    parallel.barrier(dev)
+    L.eemflow_destroy(ctx)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

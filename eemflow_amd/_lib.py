@@ -1,0 +1,76 @@
+"""ctypes binding of libeemflow_hip.so (C ABI: include/eemflow_hip.h).
+
+There is no fallback: if the library is missing or a call fails this raises.  The product path
+never computes on the CPU and never imports oracle/.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libeemflow_hip.so")
+
+_c_float_p = ctypes.c_void_p          # device/host pointers travel as integers
+
+
+class KernelStat(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 48), ("flops", ctypes.c_double), ("bytes", ctypes.c_double),
+                ("ms", ctypes.c_float), ("reserved", ctypes.c_int)]
+
+
+_SIGNATURES = {
+    "eemflow_abi_version": (ctypes.c_int, []),
+    "eemflow_last_error": (ctypes.c_char_p, []),
+    "eemflow_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "eemflow_destroy": (None, [ctypes.c_void_p]),
+    "eemflow_load_weights": (ctypes.c_int, [ctypes.c_void_p, _c_float_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int]),
+    "eemflow_set_image_size": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int * 4)]),
+    "eemflow_use_graph": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "eemflow_forward": (ctypes.c_int, [ctypes.c_void_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "eemflow_time_kernels": (ctypes.c_int, [ctypes.c_void_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(KernelStat),
+                                            ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
+    "eemflow_get_stage": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, _c_float_p, ctypes.c_size_t,
+                                         ctypes.POINTER(ctypes.c_int * 4), ctypes.c_void_p]),
+    "eemflow_decoder": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       _c_float_p, ctypes.c_void_p]),
+    "eemflow_local_corr53": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            _c_float_p, ctypes.c_void_p]),
+    "eemflow_upsample_bilinear": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "eemflow_voxelize": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int, _c_float_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+}
+EXPORTS = tuple(_SIGNATURES)
+_lib = None
+
+
+class EEMFlowHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EEMFlowHipError(
+                f"{LIB_PATH} is missing: build it with `python -m eemflow_amd.build` (needs hipcc). "
+                "There is no CPU fallback for the EEMFlow hot path.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise EEMFlowHipError(lib().eemflow_last_error().decode("utf-8", "replace"))
+
+
+def current_stream_ptr(device):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

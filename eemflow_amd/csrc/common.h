@@ -1,0 +1,110 @@
+// Shared declarations for the EEMFlow MI355X (gfx950) hot-path library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define EEM_OK 0
+#define EEM_ERR_ARG 1
+#define EEM_ERR_HIP 2
+#define EEM_ERR_STATE 3
+
+void eem_set_error(const char* fmt, ...);
+
+#define EEM_HIP_CHECK(expr)                                                            \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess) {                                                        \
+            eem_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),       \
+                          __FILE__, __LINE__);                                         \
+            return EEM_ERR_HIP;                                                        \
+        }                                                                              \
+    } while (0)
+
+#define EEM_REQUIRE(cond, ...)                                                         \
+    do {                                                                               \
+        if (!(cond)) {                                                                 \
+            eem_set_error(__VA_ARGS__);                                                \
+            return EEM_ERR_ARG;                                                        \
+        }                                                                              \
+    } while (0)
+
+__host__ __device__ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ----------------------------------------------------------------------------- encoder conv
+// Identifies one of the eight encoder layers (EEMFlow.py:75-82).
+enum EncLayer { ENC_1_1 = 0, ENC_1_2, ENC_2_1, ENC_2_2, ENC_2_3, ENC_3_1, ENC_3_2, ENC_3_3, ENC_NUM };
+
+struct EncLayerDesc {
+    int cin, cout, stride;
+};
+static const EncLayerDesc kEncLayers[ENC_NUM] = {
+    {5, 16, 2}, {16, 16, 1}, {16, 32, 2}, {32, 32, 1}, {32, 32, 1}, {32, 64, 2}, {64, 64, 1}, {64, 64, 1}};
+
+// Number of packed floats for an encoder layer's MFMA A-fragments (see conv_enc.hip).
+size_t enc_packed_floats(int cin, int cout);
+// Pack OIHW weights [cout][cin][3][3] into MFMA A-fragment order (host).
+void enc_pack_weights(const float* w, int cin, int cout, float* packed);
+
+// Launch a fused {replicate-pad (first layer only)} + conv3x3 + bias + LeakyReLU(0.1).
+//  in : layer ENC_1_1: two raw tensors ev1, ev2 of shape [B][cin][hraw][wraw] (images 0..B-1, B..2B-1)
+//       other layers : [nimg][cin][hin][win]
+//  out: [nimg][cout][hout][wout], hout = (hin-1)/stride+1 (pad 1, k 3)
+struct EncConvArgs {
+    const float* in0;
+    const float* in1;      // only ENC_1_1 (second event volume), else unused
+    const float* wpk;      // packed weights
+    const float* bias;
+    float* out;
+    int nimg;              // images in this launch (2B)
+    int nimg0;             // images taken from in0 (B) - rest from in1
+    int hin, win;          // conv input extent (after the fused replicate pad for ENC_1_1)
+    int hout, wout;
+    int hraw, wraw;        // raw extent for ENC_1_1 (== hin, win elsewhere)
+    int pad_top, pad_left; // replicate-pad offsets for ENC_1_1 (0 elsewhere)
+    int act;               // 1: LeakyReLU(0.1)
+};
+int enc_conv_launch(int cin, int cout, int stride, const EncConvArgs& a, hipStream_t stream);
+
+// ----------------------------------------------------------------------------- tail kernels
+// Generic small-grid 3x3 (or 1x1) conv on MFMA 16x16x4, K split over the 4 waves of a block.
+struct TailConvJob {
+    const float* in;       // [B][in_ctotal][h][w]; this job reads channels [in_coff, in_coff+cin)
+    const float* wpk;      // packed A fragments for this job
+    const float* bias;     // [cout]
+    float* out;            // [B][out_ctotal][h][w]; writes channel co*out_cmul + out_coff
+    int cin, cout;
+    int in_ctotal, in_coff;
+    int out_ctotal, out_coff, out_cmul;
+    int act;
+};
+#define TAIL_MAX_JOBS 16
+struct TailConvLaunch {
+    TailConvJob job[TAIL_MAX_JOBS];
+    int njobs;
+    int batch, h, w;
+    int ksize;             // 3 or 1
+};
+size_t tail_packed_floats(int cin, int cout, int ksize);
+void tail_pack_weights(const float* w, int cin, int cout, int ksize, float* packed);
+int tail_conv_launch(const TailConvLaunch& l, hipStream_t stream);
+
+// avg-pool k x k (stride k, floor) of [n][c][h][w] -> [n][c][h/k][w/k]
+struct PoolJob { const float* in; float* out; int c, h, w, k; };
+int pool_launch(const PoolJob* jobs, int njobs, int nimg, hipStream_t stream);
+
+// 9x9 local correlation, selected taps, scaled by 1/C; writes channels [0,ntaps) of out
+struct CorrJob { const float* f1; const float* f2; float* out; int c, out_ctotal; };
+int corr_launch(const CorrJob* jobs, int njobs, int batch, int h, int w, const int* taps_dev, int ntaps,
+                hipStream_t stream);
+
+// plain bilinear resize (align_corners False) of [n][c][h][w] -> [n][c][oh][ow]
+int upsample_launch(const float* in, float* out, int nc, int h, int w, int oh, int ow, hipStream_t stream);
+
+// ----------------------------------------------------------------------------- voxelizer
+int voxel_launch(const double* events, int64_t n, int bins, int h, int w, int normalize, float* grid,
+                 int64_t* idx_left, int64_t* idx_right, void* scratch, hipStream_t stream);
+size_t voxel_scratch_bytes();

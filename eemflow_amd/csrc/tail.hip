@@ -1,0 +1,238 @@
+// Everything that runs on EEMFlow's 1/64-resolution grid (reference: model/EEMFlow/EEMFlow.py):
+//   stage pooling (:144-154), 9x9 local correlation + tap select (:14-23,160), rconv_k and the
+//   three decoders with grouped convs + channel shuffle (:37-69,96-102,161-176), out_conv (:104,180)
+//   and the bilinear upsample back to the input size (:118-120,181).
+// The grid is tiny (12x20 at 1280x720) so these kernels are latency-, not throughput-bound: each
+// conv layer is one launch that covers all decoders/groups/samples ("jobs"), spreads 16x16 MFMA
+// tiles over the chip and splits K over the four waves of a block.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------- pooling
+struct PoolArgs {
+    PoolJob job[3];
+    int first_wave[4];      // prefix of output counts per job
+    int njobs, nimg;
+};
+
+__global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);      // one wave per pooled output value
+    if (gw >= a.first_wave[a.njobs]) return;
+    int ji = 0;
+    while (ji + 1 < a.njobs && gw >= a.first_wave[ji + 1]) ++ji;
+    const PoolJob jb = a.job[ji];
+    const int oh = jb.h / jb.k, ow = jb.w / jb.k;
+    int o = gw - a.first_wave[ji];
+    const int ox = o % ow; o /= ow;
+    const int oy = o % oh; o /= oh;                          // o = n*c + channel
+    const float* src = jb.in + ((size_t)o * jb.h + (size_t)oy * jb.k) * jb.w + (size_t)ox * jb.k;
+    const int kk = jb.k * jb.k;
+    float s = 0.f;
+    for (int i = lane; i < kk; i += 64) {
+        const int ry = i / jb.k, rx = i - ry * jb.k;
+        s += src[(size_t)ry * jb.w + rx];
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
+    if (lane == 0) jb.out[((size_t)o * oh + oy) * ow + ox] = s / (float)kk;
+}
+
+// ------------------------------------------------------------------------------- local correlation
+struct CorrArgs {
+    CorrJob job[3];
+    int njobs, batch, h, w, ntaps;
+    const int* taps;
+};
+
+__global__ __launch_bounds__(256) void corr_kernel(CorrArgs a) {
+    const int hw = a.h * a.w;
+    const int per_job = a.batch * a.ntaps * hw;
+    int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= per_job * a.njobs) return;
+    const int ji = idx / per_job;
+    idx -= ji * per_job;
+    const CorrJob jb = a.job[ji];
+    const int p = idx % hw; idx /= hw;
+    const int ti = idx % a.ntaps;
+    const int b = idx / a.ntaps;
+    const int y = p / a.w, x = p - y * a.w;
+    const int tap = a.taps[ti];                 // dy-major index into the 9x9 window
+    const int yy = y + tap / 9 - 4, xx = x + tap % 9 - 4;
+    float s = 0.f;
+    if (yy >= 0 && yy < a.h && xx >= 0 && xx < a.w) {
+        const float* p1 = jb.f1 + (size_t)b * jb.c * hw + p;
+        const float* p2 = jb.f2 + (size_t)b * jb.c * hw + yy * a.w + xx;
+        for (int c = 0; c < jb.c; ++c) s = fmaf(p1[(size_t)c * hw], p2[(size_t)c * hw], s);
+    }
+    jb.out[((size_t)b * jb.out_ctotal + ti) * hw + p] = s / (float)jb.c;
+}
+
+// ------------------------------------------------------------------------------- small-grid conv
+// D[cout 16][pixel 16] tiles on v_mfma_f32_16x16x4_f32; pixels are the flattened (y*w+x) index.
+// block = 4 waves; wave v takes k-steps v, v+4, ...; partial tiles are summed through LDS.
+template <int KS>
+__global__ __launch_bounds__(256) void tail_conv_kernel(TailConvLaunch L) {
+    __shared__ f32x4 part[3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ji = blockIdx.z / L.batch, b = blockIdx.z % L.batch;
+    const TailConvJob jb = L.job[ji];
+    const int cot = blockIdx.y;
+    if (cot * 16 >= jb.cout) return;
+    const int hw = L.h * L.w;
+    const int j = lane & 15, g = lane >> 4;
+    const int p = blockIdx.x * 16 + j;
+    const bool pvalid = p < hw;
+    const int y = p / L.w, x = p - y * L.w;
+    const int cg = (jb.cin + 3) >> 2;
+    const int ksteps = KS * KS * cg;
+    const float* in = jb.in + ((size_t)b * jb.in_ctotal + jb.in_coff) * hw;
+    const float* wp = jb.wpk + (size_t)cot * ksteps * 64 + lane;
+
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int s = wave; s < ksteps; s += 4) {
+        const int t = s / cg, c = (s - t * cg) * 4 + g;
+        const int yy = y + (KS == 3 ? t / 3 - 1 : 0), xx = x + (KS == 3 ? t % 3 - 1 : 0);
+        float bv = 0.f;
+        if (pvalid && c < jb.cin && yy >= 0 && yy < L.h && xx >= 0 && xx < L.w)
+            bv = in[(size_t)c * hw + yy * L.w + xx];
+        const float av = wp[(size_t)s * 64];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+    }
+    if (wave > 0) part[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+        acc += part[0][lane] + part[1][lane] + part[2][lane];
+        if (pvalid) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = cot * 16 + g * 4 + r;
+                if (co < jb.cout) {
+                    float v = acc[r] + jb.bias[co];
+                    if (jb.act) v = v > 0.f ? v : 0.1f * v;
+                    jb.out[((size_t)b * jb.out_ctotal + co * jb.out_cmul + jb.out_coff) * hw + p] = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------- bilinear resize
+// F.interpolate(mode='bilinear', align_corners=False): src = max(scale*(dst+0.5)-0.5, 0)
+__device__ __forceinline__ void src_index(float scale, int dst, int in_size, int& i0, int& i1, float& l1) {
+    float s = scale * ((float)dst + 0.5f) - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    i0 = (int)s;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                       int nc, int h, int w, int oh, int ow) {
+    const int xq = ceil_div(ow, 4);
+    const long total = (long)nc * oh * xq;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int q = idx % xq;
+    const int oy = (idx / xq) % oh;
+    const int c = idx / ((long)xq * oh);
+    const float sy = (float)h / (float)oh, sx = (float)w / (float)ow;
+    int y0, y1; float ly;
+    src_index(sy, oy, h, y0, y1, ly);
+    const float* r0 = in + ((size_t)c * h + y0) * w;
+    const float* r1 = in + ((size_t)c * h + y1) * w;
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ox = q * 4 + i;
+        int x0, x1; float lx;
+        src_index(sx, ox < ow ? ox : ow - 1, w, x0, x1, lx);
+        const float top = (1.f - lx) * r0[x0] + lx * r0[x1];
+        const float bot = (1.f - lx) * r1[x0] + lx * r1[x1];
+        v[i] = (1.f - ly) * top + ly * bot;
+    }
+    float* dst = out + ((size_t)c * oh + oy) * ow + q * 4;
+    if ((ow & 3) == 0) {
+        *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (q * 4 + i < ow) dst[i] = v[i];
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------- host side
+int pool_launch(const PoolJob* jobs, int njobs, int nimg, hipStream_t stream) {
+    EEM_REQUIRE(njobs >= 1 && njobs <= 3, "pool_launch: njobs=%d", njobs);
+    PoolArgs a;
+    a.njobs = njobs;
+    a.nimg = nimg;
+    int total = 0;
+    for (int i = 0; i < njobs; ++i) {
+        a.job[i] = jobs[i];
+        a.first_wave[i] = total;
+        total += nimg * jobs[i].c * (jobs[i].h / jobs[i].k) * (jobs[i].w / jobs[i].k);
+    }
+    for (int i = njobs; i < 4; ++i) a.first_wave[i] = total;
+    if (total == 0) return EEM_OK;
+    hipLaunchKernelGGL(pool_kernel, dim3(ceil_div(total, 4)), dim3(256), 0, stream, a);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int corr_launch(const CorrJob* jobs, int njobs, int batch, int h, int w, const int* taps_dev, int ntaps,
+                hipStream_t stream) {
+    EEM_REQUIRE(njobs >= 1 && njobs <= 3, "corr_launch: njobs=%d", njobs);
+    CorrArgs a;
+    for (int i = 0; i < njobs; ++i) a.job[i] = jobs[i];
+    a.njobs = njobs; a.batch = batch; a.h = h; a.w = w; a.ntaps = ntaps; a.taps = taps_dev;
+    const long total = (long)njobs * batch * ntaps * h * w;
+    if (total == 0) return EEM_OK;
+    hipLaunchKernelGGL(corr_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+size_t tail_packed_floats(int cin, int cout, int ksize) {
+    return (size_t)ceil_div(cout, 16) * ksize * ksize * ceil_div(cin, 4) * 64;
+}
+
+void tail_pack_weights(const float* w, int cin, int cout, int ksize, float* packed) {
+    const int cg = ceil_div(cin, 4), kk = ksize * ksize, ksteps = kk * cg;
+    for (int cot = 0; cot < ceil_div(cout, 16); ++cot)
+        for (int s = 0; s < ksteps; ++s)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int co = cot * 16 + (lane & 15);
+                const int t = s / cg, c = (s % cg) * 4 + (lane >> 4);
+                float v = 0.f;
+                if (co < cout && c < cin) v = w[((size_t)co * cin + c) * kk + t];
+                packed[((size_t)cot * ksteps + s) * 64 + lane] = v;
+            }
+}
+
+int tail_conv_launch(const TailConvLaunch& l, hipStream_t stream) {
+    EEM_REQUIRE(l.njobs >= 1 && l.njobs <= TAIL_MAX_JOBS, "tail_conv_launch: njobs=%d", l.njobs);
+    EEM_REQUIRE(l.ksize == 3 || l.ksize == 1, "tail_conv_launch: ksize=%d", l.ksize);
+    int max_cout = 0;
+    for (int i = 0; i < l.njobs; ++i) max_cout = l.job[i].cout > max_cout ? l.job[i].cout : max_cout;
+    dim3 grid(ceil_div(l.h * l.w, 16), ceil_div(max_cout, 16), l.njobs * l.batch);
+    if (l.ksize == 3)
+        hipLaunchKernelGGL(tail_conv_kernel<3>, grid, dim3(256), 0, stream, l);
+    else
+        hipLaunchKernelGGL(tail_conv_kernel<1>, grid, dim3(256), 0, stream, l);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int upsample_launch(const float* in, float* out, int nc, int h, int w, int oh, int ow, hipStream_t stream) {
+    const long total = (long)nc * oh * ceil_div(ow, 4);
+    if (total == 0) return EEM_OK;
+    hipLaunchKernelGGL(upsample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, in, out, nc,
+                       h, w, oh, ow);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}

@@ -1,0 +1,171 @@
+"""EEMFlow with the reference's nn.Module interface, computed by libeemflow_hip.so on MI355X.
+
+Drop-in for `model.EEMFlow.EEMFlow.EEMFlow` (reference: model/EEMFlow/EEMFlow.py:71-183):
+same constructor, `change_imagesize`, `forward(events1, events2) -> ((events1, events2), [flow])`,
+`upsample_flow`, and the same 66-tensor state_dict, so test_EEMFlow_HREM.py / train_mvsec.py's
+run_network call it unchanged.  The parameters are ordinary nn.Parameters (checkpoint layout and
+optimizers keep working); the forward hands them, flattened, to the HIP library, which packs them
+into MFMA fragment order once per weight version.
+
+Inference only in this round: forward() requires CUDA (ROCm) tensors and runs under no_grad
+semantics - a forward that needs autograd raises instead of silently using another path.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .padder import InputPadder
+from .weights import CORR_TAPS_53, eemflow_param_shapes
+
+
+def convrelu(in_channels, out_channels, kernel_size=3, stride=1, padding=1, dilation=1, groups=1, bias=True):
+    # parameter container only (keys '<name>.0.weight' / '<name>.0.bias' as in EEMFlow.py:26-30)
+    return nn.Sequential(
+        nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias=bias),
+        nn.LeakyReLU(0.1, inplace=True))
+
+
+class Decoder(nn.Module):
+    """Parameter container mirroring EEMFlow.py:37-46."""
+
+    def __init__(self, in_channels, groups):
+        super().__init__()
+        self.in_channels = in_channels
+        self.groups = groups
+        self.conv1 = convrelu(in_channels, 100, 3, 1)
+        self.conv2 = convrelu(100, 100, 3, 1, groups=groups)
+        self.conv3 = convrelu(100, 100, 3, 1, groups=groups)
+        self.conv4 = convrelu(100, 100, 3, 1, groups=groups)
+        self.conv5 = convrelu(100, 64, 3, 1)
+        self.conv6 = convrelu(64, 32, 3, 1)
+        self.conv7 = nn.Conv2d(32, 2, 3, 1, 1)
+
+
+class EEMFlow(nn.Module):
+    def __init__(self, config, groups=5, n_first_channels=5, out_mesh_size=False):
+        super().__init__()
+        self.groups = groups
+        self.n_first_channels = n_first_channels
+        self.pconv1_1 = convrelu(n_first_channels, 16, 3, 2)
+        self.pconv1_2 = convrelu(16, 16, 3, 1)
+        self.pconv2_1 = convrelu(16, 32, 3, 2)
+        self.pconv2_2 = convrelu(32, 32, 3, 1)
+        self.pconv2_3 = convrelu(32, 32, 3, 1)
+        self.pconv3_1 = convrelu(32, 64, 3, 2)
+        self.pconv3_2 = convrelu(64, 64, 3, 1)
+        self.pconv3_3 = convrelu(64, 64, 3, 1)
+        # 53-tap diamond (EEMFlow+.py:89-97); the 49-entry list of EEMFlow.py:85-94 cannot feed
+        # Decoder(69).  Plain attribute, not a buffer: it is not part of the checkpoint.
+        self.index = torch.tensor(CORR_TAPS_53)
+        self.rconv_1 = convrelu(16, 16, 3, 1)
+        self.rconv_2 = convrelu(32, 16, 3, 1)
+        self.rconv_3 = convrelu(64, 16, 3, 1)
+        self.decoder_1 = Decoder(69, groups)
+        self.decoder_2 = Decoder(69, groups)
+        self.decoder_3 = Decoder(69, groups)
+        self.out_conv = nn.Conv2d(6, 2, 1, 1)
+        self.out_mesh_size = out_mesh_size
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                nn.init.kaiming_normal_(m.weight)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+        assert list(self.state_dict().keys()) == list(eemflow_param_shapes(n_first_channels, groups).keys())
+        self._ctx = None
+        self._ctx_device = None
+        self._weights_version = None
+        self.use_graph = True
+
+    # ------------------------------------------------------------------ reference interface
+    def change_imagesize(self, img_size):
+        self.image_size = img_size
+        self.image_padder = InputPadder(img_size, mode='chairs', eval_pad_rate=64)
+
+    def upsample_flow(self, flow, orig_size):
+        if not flow.is_cuda:
+            raise _lib.EEMFlowHipError("EEMFlow.upsample_flow: the HIP path needs a CUDA (ROCm) tensor")
+        flow = flow.contiguous().float()
+        b, c, h, w = flow.shape
+        out = torch.empty(b, c, int(orig_size[0]), int(orig_size[1]), device=flow.device, dtype=torch.float32)
+        with torch.cuda.device(flow.device):
+            _lib.check(_lib.lib().eemflow_upsample_bilinear(
+                flow.data_ptr(), out.data_ptr(), b * c, h, w, out.shape[2], out.shape[3],
+                _lib.current_stream_ptr(flow.device)))
+        return out
+
+    def forward(self, events1, events2):
+        if not (events1.is_cuda and events2.is_cuda):
+            raise _lib.EEMFlowHipError(
+                "EEMFlow.forward: inputs must be CUDA (ROCm) tensors - this implementation has no CPU path")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+            raise _lib.EEMFlowHipError(
+                "EEMFlow.forward: the HIP backward pass is not built yet (round 1 covers inference); "
+                "call under torch.no_grad() / model.eval()")
+        if not hasattr(self, "image_padder"):
+            raise AttributeError("call change_imagesize(img_size) before forward (as the reference requires)")
+        input_size = events1.shape[-2:]
+        if self.training and self.out_mesh_size:
+            out_size = (16, 16)                                  # EEMFlow.py:126-130
+        else:
+            out_size = tuple(int(v) for v in input_size)
+        e1 = events1.contiguous().float()
+        e2 = events2.contiguous().float()
+        if e1.shape != e2.shape or e1.dim() != 4 or e1.shape[1] != self.n_first_channels:
+            raise ValueError(f"expected two (B,{self.n_first_channels},H,W) tensors, got {tuple(e1.shape)} and {tuple(e2.shape)}")
+        ctx = self._context(e1.device)
+        b, _, h, w = e1.shape
+        flow = torch.empty(b, 2, out_size[0], out_size[1], device=e1.device, dtype=torch.float32)
+        with torch.cuda.device(e1.device):
+            _lib.check(_lib.lib().eemflow_forward(ctx, e1.data_ptr(), e2.data_ptr(), b, h, w, flow.data_ptr(),
+                                                  out_size[0], out_size[1], _lib.current_stream_ptr(e1.device)))
+        return (events1, events2), [flow]
+
+    # ------------------------------------------------------------------ HIP context plumbing
+    def _flat_weights(self):
+        return torch.cat([v.detach().reshape(-1).to(torch.float32).cpu() for v in self.state_dict().values()])
+
+    def _weights_fingerprint(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def _context(self, device):
+        L = _lib.lib()
+        if self._ctx is None or self._ctx_device != device:
+            self._release()
+            handle = ctypes.c_void_p()
+            _lib.check(L.eemflow_create(device.index if device.index is not None else torch.cuda.current_device(),
+                                        ctypes.byref(handle)))
+            self._ctx, self._ctx_device, self._weights_version = handle, device, None
+        fp = self._weights_fingerprint()
+        if fp != self._weights_version:
+            flat = self._flat_weights().contiguous()
+            _lib.check(L.eemflow_load_weights(self._ctx, flat.data_ptr(), flat.numel(), self.n_first_channels, self.groups))
+            self._weights_version = fp
+        pad = (ctypes.c_int * 4)()
+        _lib.check(L.eemflow_set_image_size(self._ctx, int(self.image_size[0]), int(self.image_size[1]), ctypes.byref(pad)))
+        assert list(pad) == self.image_padder._pad
+        _lib.check(L.eemflow_use_graph(self._ctx, 1 if self.use_graph else 0))
+        return self._ctx
+
+    def stage(self, name):
+        """Intermediate tensor of the last forward (parity tests): see eemflow_get_stage."""
+        L = _lib.lib()
+        dims = (ctypes.c_int * 4)()
+        _lib.check(L.eemflow_get_stage(self._ctx, name.encode(), None, 0, ctypes.byref(dims), None))
+        out = torch.empty(*list(dims), device=self._ctx_device, dtype=torch.float32)
+        with torch.cuda.device(self._ctx_device):
+            _lib.check(L.eemflow_get_stage(self._ctx, name.encode(), out.data_ptr(), out.numel(), ctypes.byref(dims),
+                                           _lib.current_stream_ptr(self._ctx_device)))
+        return out
+
+    def _release(self):
+        if self._ctx is not None:
+            _lib.lib().eemflow_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass

@@ -1,0 +1,72 @@
+"""One-process-per-GPU plumbing for the EEMFlow hot path.
+
+Inference shards along the batch/frame dimension with no data-path exchange (the reference's only
+strategy is nn.DataParallel's batch scatter, train_EEMFlow_HREM.py:116-118): every rank owns a
+replica and a disjoint slice of the frames; the only collectives are a barrier and a MAX-reduction
+of the elapsed time for reporting.  Backend "nccl" is RCCL on ROCm; tests use "gloo" on CPU.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    """(rank, local_rank, world_size) from the torchrun environment (1 process if unset)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_distributed(backend=None):
+    """Join the process group when launched with WORLD_SIZE > 1; returns (rank, local_rank, world)."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kwargs = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            kwargs["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+    return rank, local_rank, world
+
+
+def shard_frames(n_frames, rank, world):
+    """Contiguous, disjoint, near-equal slice [start, stop) of n_frames for this rank."""
+    base, extra = divmod(n_frames, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def barrier(device=None):
+    if dist.is_initialized():
+        if device is not None and device.type == "cuda":
+            dist.barrier(device_ids=[device.index])
+        else:
+            dist.barrier()
+
+
+def max_over_ranks(value, device=None):
+    """MAX of a python float over all ranks (identity without a process group)."""
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device=None):
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def aggregate_throughput(units_this_rank, seconds_this_rank, device=None):
+    """Whole-job rate: units processed by ALL ranks / the slowest rank's time."""
+    total = sum_over_ranks(units_this_rank, device)
+    slowest = max_over_ranks(seconds_this_rank, device)
+    return total / slowest, slowest

@@ -1,0 +1,95 @@
+"""Event voxelization on MI355X behind the reference's loader interface.
+
+`EventSequence` and `EventSequenceToVoxelGrid_Pytorch` keep the constructor arguments and call
+convention of loader/loader_utils.py:352-397 and :429-537, so HREM/MVSEC dataset code
+(loader/HREM.py:140-144,226-232) can use them unchanged.  The host side only orders, scales and
+shifts the timestamps (float64 numpy, as the reference does); the voting and the normalisation
+run in libeemflow_hip.so.  There is no CPU voting path: without a GPU this raises.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class EventSequence(object):
+    """(N,4) float64 events [t, x, y, p]; sorted by time on construction (loader_utils.py:352-397)."""
+
+    def __init__(self, dataframe, params, features=None, timestamp_multiplier=None, convert_to_relative=False):
+        if dataframe is not None and hasattr(dataframe, "to_numpy"):
+            self.feature_names = dataframe.columns.values
+            self.features = dataframe.to_numpy()
+        else:
+            self.feature_names = np.array(['ts', 'x', 'y', 'p'], dtype=object)
+            self.features = np.zeros([1, 4]) if features is None else features
+        self.image_height = params['height']
+        self.image_width = params['width']
+        if not self.is_sorted():
+            self.sort_by_timestamp()
+        if timestamp_multiplier is not None:
+            self.features[:, 0] *= timestamp_multiplier          # in place, like the reference
+        if convert_to_relative:
+            self.absolute_time_to_relative()
+
+    def get_sequence_only(self):
+        return self.features
+
+    def __len__(self):
+        return len(self.features)
+
+    def __add__(self, sequence):
+        return EventSequence(dataframe=None, features=np.concatenate([self.features, sequence.features]),
+                             params={'height': self.image_height, 'width': self.image_width})
+
+    def is_sorted(self):
+        t = self.features[:, 0]
+        return bool(np.all(t[:-1] <= t[1:]))
+
+    def sort_by_timestamp(self):
+        if len(self.features[:, 0]) > 0:
+            self.features = self.features[np.argsort(self.features[:, 0])]
+
+    def absolute_time_to_relative(self):
+        start_ts = self.features[:, 0].min()
+        assert start_ts == self.features[0, 0]
+        self.features[:, 0] -= start_ts
+
+
+class EventSequenceToVoxelGrid_Pytorch(object):
+    def __init__(self, num_bins, gpu=False, gpu_nr=0, normalize=True, forkserver=True):
+        if forkserver:
+            try:
+                torch.multiprocessing.set_start_method('forkserver')
+            except RuntimeError:
+                pass
+        self.num_bins = num_bins
+        self.normalize = normalize
+        self.return_on_gpu = bool(gpu)          # the reference returns a CPU tensor when gpu=False
+        self.device = torch.device('cuda:' + str(gpu_nr))
+
+    def __call__(self, event_sequence, return_indices=False):
+        events = np.ascontiguousarray(event_sequence.features.astype('float'))
+        width, height = event_sequence.image_width, event_sequence.image_height
+        assert events.shape[1] == 4
+        assert self.num_bins > 0 and width > 0 and height > 0
+        if not torch.cuda.is_available():
+            raise _lib.EEMFlowHipError("EventSequenceToVoxelGrid_Pytorch: no GPU - the voxelizer has no CPU path here")
+        n = events.shape[0]
+        with torch.no_grad(), torch.cuda.device(self.device):
+            ev = torch.from_numpy(events).to(self.device)
+            grid = torch.empty(self.num_bins, height, width, dtype=torch.float32, device=self.device)
+            il = ir = None
+            if return_indices:
+                il = torch.empty(n, dtype=torch.int64, device=self.device)
+                ir = torch.empty(n, dtype=torch.int64, device=self.device)
+            _lib.check(_lib.lib().eemflow_voxelize(
+                ev.data_ptr(), n, self.num_bins, height, width, 1 if self.normalize else 0, grid.data_ptr(),
+                il.data_ptr() if return_indices else None, ir.data_ptr() if return_indices else None,
+                _lib.current_stream_ptr(self.device)))
+        if not self.return_on_gpu:
+            grid = grid.cpu()
+        if return_indices:
+            return grid, il, ir
+        return grid

@@ -1,7 +1,7 @@
 """Checkpoint layout of the EEMFlow dense-flow path and a seeded weight generator.
 
 The layout (key names, shapes, order) is the reference's ``state_dict()`` for
-``EEMFlow(config, groups=5, n_first_channels=5)``: 58 tensors, 714 352 parameters
+``EEMFlow(config, groups=5, n_first_channels=5)``: 66 tensors (SURVEY.md says 58; the reference module registers 33 convs x {weight,bias}), 714 352 parameters
 (reference: model/EEMFlow/EEMFlow.py:72-112; Decoder :37-46).  Keys may carry the
 ``module.`` prefix that ``nn.DataParallel`` adds (test_EEMFlow_HREM.py:62-66).
 

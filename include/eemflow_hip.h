@@ -1,0 +1,115 @@
+/*
+ * eemflow_hip.h - C ABI of libeemflow_hip.so: the MI355X (gfx950) implementation of EEMFlow's
+ * dense-flow hot path.  Plain pointers and sizes only; every device pointer is a HIP device
+ * address on the context's device, every `stream` is a hipStream_t passed as void* (NULL = the
+ * default stream).  All functions return 0 on success; on failure they return non-zero and
+ * eemflow_last_error() describes the problem (thread-local, valid until the next failing call).
+ *
+ * The reference (boomluo02/EEMFlow) has no FFI of its own on this path: its boundary is the
+ * nn.Module interface plus two third-party torch extensions.  Each entry point below names the
+ * reference interface it replaces (paths relative to the reference repo root).
+ *
+ * Tensors are dense NCHW fp32 unless stated.  Ownership: the caller owns every buffer it passes;
+ * the context owns its weights and workspaces and never retains caller pointers beyond a call
+ * (except inside a cached HIP graph, which is keyed on those pointers and rebuilt when they change).
+ * Threading: one context per host thread/stream; calls on one context must not overlap.
+ */
+#ifndef EEMFLOW_HIP_H
+#define EEMFLOW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct eemflow_ctx eemflow_ctx;
+
+/* ABI version of this header (bumped on incompatible change). */
+int eemflow_abi_version(void);
+
+/* Last error message of the calling thread ("" if none). */
+const char* eemflow_last_error(void);
+
+/* Create / destroy a model context on HIP device `device`.
+ * Replaces: EEMFlow.__init__ + model.to(device)  (model/EEMFlow/EEMFlow.py:72-112,
+ * test_EEMFlow_HREM.py:53-55,113). */
+int eemflow_create(int device, eemflow_ctx** out);
+void eemflow_destroy(eemflow_ctx* ctx);
+
+/* Load all parameters from one flat host fp32 vector holding the 66 tensors of the reference
+ * state_dict() back to back in registration order (pconv1_1.0.weight, pconv1_1.0.bias, ...,
+ * out_conv.bias; 714 352 floats for n_first_channels=5, groups=5).
+ * Replaces: model.load_state_dict(checkpoint['state_dict'])  (test_EEMFlow_HREM.py:62-66). */
+int eemflow_load_weights(eemflow_ctx* ctx, const float* flat_host, size_t nfloats, int n_first_channels,
+                         int groups);
+
+/* Configure the replicate padder for images of `height` x `width` (pad to a multiple of 64, 'chairs'
+ * mode: width split left/right, height bottom only).  pad_out = [left, right, top, bottom].
+ * Replaces: EEMFlow.change_imagesize -> InputPadder(img_size, 'chairs', 64)
+ * (model/EEMFlow/EEMFlow.py:114-116, utils/image_utils.py:129-137). */
+int eemflow_set_image_size(eemflow_ctx* ctx, int height, int width, int pad_out[4]);
+
+/* Replay the forward pass through a cached HIP graph (1, default) or launch kernels eagerly (0). */
+int eemflow_use_graph(eemflow_ctx* ctx, int enable);
+
+/* Inference forward: events1/events2 [batch][C][in_h][in_w] -> flow_out [batch][2][out_h][out_w].
+ * The reference upsamples the 1/64 grid straight to the *input* size (out_h,out_w = in_h,in_w) or,
+ * in training with out_mesh_size, to 16x16.
+ * Replaces: EEMFlow.forward(events1, events2)[1][0]  (model/EEMFlow/EEMFlow.py:122-183), i.e. the
+ * call made by TestRaftEvents.run_network (test_mvsec.py:1444-1455). */
+int eemflow_forward(eemflow_ctx* ctx, const float* events1, const float* events2, int batch, int in_h,
+                    int in_w, float* flow_out, int out_h, int out_w, void* stream);
+
+/* Per-kernel timing of the forward schedule: each kernel of the schedule is launched `reps` times back
+ * to back between two HIP events recorded on `stream` (the stream the kernels run on); `ms` is the
+ * average per launch.  `flops` / `bytes` are the ALGORITHMIC work of one launch (conv MACs x 2; compulsory
+ * input + output + weight bytes).  The schedule still produces the correct flow in flow_out.
+ * Replaces: the reference's time_eval() wall-clock loop (model/EEMFlow/EEMFlow.py:201-225), per kernel. */
+typedef struct eemflow_kernel_stat {
+    char name[48];
+    double flops;
+    double bytes;
+    float ms;
+    int reserved;
+} eemflow_kernel_stat;
+int eemflow_time_kernels(eemflow_ctx* ctx, const float* events1, const float* events2, int batch, int in_h,
+                         int in_w, float* flow_out, int out_h, int out_w, int reps, eemflow_kernel_stat* stats,
+                         int max_stats, int* nstats, void* stream);
+
+/* Copy an intermediate of the LAST forward into dst (device).  Names: "f11","f12","f13" (stage
+ * outputs, images 0..B-1 = events1, B..2B-1 = events2), "pool_1".."pool_3", "cat_1".."cat_3"
+ * ([cv(53) | r(16)]), "flow_1".."flow_3" (as channels 0-1, 2-3, 4-5 of "flowcat"), "flowcat",
+ * "coarse".  dims_out = [n, c, h, w].  For parity tests against the oracle's stage tensors. */
+int eemflow_get_stage(eemflow_ctx* ctx, const char* name, float* dst, size_t dst_capacity_floats,
+                      int dims_out[4], void* stream);
+
+/* One decoder (k = 1..3) on a caller-supplied [batch][69][h][w] input -> [batch][2][h][w].
+ * Replaces: Decoder.forward  (model/EEMFlow/EEMFlow.py:59-69). */
+int eemflow_decoder(eemflow_ctx* ctx, int k, const float* x, int batch, int h, int w, float* out, void* stream);
+
+/* 9x9 local correlation of two [batch][c][h][w] maps, 53 selected taps, scaled by 1/c
+ * -> out [batch][53][h][w].
+ * Replaces: Correlation.forward + torch.index_select  (model/EEMFlow/EEMFlow.py:14-23,160), i.e.
+ * spatial_correlation_sampler.SpatialCorrelationSampler(1, 9, 1, 0, 1) (requirements.txt:131). */
+int eemflow_local_corr53(const float* f1, const float* f2, int batch, int c, int h, int w, float* out,
+                         void* stream);
+
+/* Bilinear resize, align_corners=False: in [nc][h][w] -> out [nc][oh][ow].
+ * Replaces: EEMFlow.upsample_flow = F.interpolate(..., mode='bilinear', align_corners=False)
+ * (model/EEMFlow/EEMFlow.py:118-120). */
+int eemflow_upsample_bilinear(const float* in, float* out, int nc, int h, int w, int oh, int ow, void* stream);
+
+/* Event voxelization: events [n][4] f64 (t, x, y, p) on the device, time-sorted, as held by the
+ * reference's EventSequence -> grid [bins][h][w] fp32.  idx_left / idx_right (optional, may be NULL)
+ * receive, per event, the int64 flat index x + y*w + bin*w*h of the left / right temporal vote, or -1
+ * where the reference masks the vote out.
+ * Replaces: EventSequenceToVoxelGrid_Pytorch.__call__  (loader/loader_utils.py:447-537). */
+int eemflow_voxelize(const double* events, int64_t n, int bins, int h, int w, int normalize, float* grid,
+                     int64_t* idx_left, int64_t* idx_right, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EEMFLOW_HIP_H */

@@ -174,6 +174,17 @@ def gen_eemflow(mod, tag, seed, batch, h, w, keep_stages):
     save(f"eemflow_fwd_{tag}.npz", **arrays)
 
 
+def gen_layout(mod):
+    """Key names, order and shapes of the reference module's state_dict (EEMFlow.py:72-112)."""
+    net = mod.EEMFlow(config="", groups=5, n_first_channels=5)
+    sd = net.state_dict()
+    shapes = np.full((len(sd), 4), -1, dtype=np.int64)
+    for i, v in enumerate(sd.values()):
+        shapes[i, :v.dim()] = list(v.shape)
+    save("state_dict_layout.npz", keys=np.array(list(sd.keys())), shapes=shapes,
+         nparams=np.int64(sum(v.numel() for v in sd.values())))
+
+
 def gen_corr(mod):
     rng = np.random.default_rng(7)
     x = rng.standard_normal((2, 8, 7, 9), dtype=np.float32)
@@ -263,6 +274,7 @@ def main():
     torch.set_num_threads(4)
     mod, lu, InputPadder = load_reference()
     gen_pad(InputPadder)
+    gen_layout(mod)
     gen_corr(mod)
     gen_decoder(mod)
     gen_eemflow(mod, "128x192", seed=1, batch=2, h=128, w=192, keep_stages=True)

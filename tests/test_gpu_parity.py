@@ -1,0 +1,244 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the reference-generated golden
+vectors.  Needs a real MI355X: run with `pytest -m gpu`.
+
+Tolerances (SURVEY.md 8c / BASELINE.json north_star): flow max-abs <= 1e-3 (we assert 1e-4, the path
+is exact fp32), intermediate features <= 1e-4, integer event-bin indices bit-exact."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from eemflow_amd import EEMFlow, EventSequence, EventSequenceToVoxelGrid_Pytorch, _lib
+from eemflow_amd.weights import seeded_state_dict, synthetic_voxel_pair
+from oracle import eemflow_oracle as O
+
+pytestmark = pytest.mark.gpu
+FLOW_TOL = 1e-4      # north star allows 1e-3
+FEAT_TOL = 1e-4
+DEV = "cuda:0"
+
+
+def make_net(seed, graph=True):
+    sd = seeded_state_dict(seed)
+    net = EEMFlow("", groups=5, n_first_channels=5).eval()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.use_graph = graph
+    return net.to(DEV), sd
+
+
+def maxerr(a, b):
+    return float((torch.as_tensor(a).cpu().float() - torch.as_tensor(b).cpu().float()).abs().max())
+
+
+def test_library_is_the_loaded_code():
+    _lib.lib()
+    assert any("libeemflow_hip.so" in ln for ln in open("/proc/self/maps"))
+
+
+@pytest.mark.parametrize("tag", ["128x192", "260x346", "100x150"])
+def test_forward_vs_golden(golden, tag):
+    g = golden(f"eemflow_fwd_{tag}.npz")
+    h, w = g["hw"].tolist()
+    net, _ = make_net(int(g["seed"]))
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(int(g["input_seed"]), int(g["batch"]), h, w))
+    with torch.no_grad():
+        (r1, r2), preds = net(e1, e2)
+    assert r1 is e1 and r2 is e2 and len(preds) == 1
+    flow = preds[0]
+    assert flow.shape == (int(g["batch"]), 2, h, w)
+    b = int(g["batch"])
+    if "f11" in g.files:        # stage tensors of the first event volume
+        for name in ("f11", "f12", "f13"):
+            assert maxerr(net.stage(name)[:b], g[name]) < FEAT_TOL, name
+        assert maxerr(net.stage("f13")[b:], g["f23"]) < FEAT_TOL
+    for k in (1, 2, 3):
+        pool = net.stage(f"pool_{k}")
+        assert maxerr(pool[:b], g[f"pool1_{k}"]) < FEAT_TOL
+        assert maxerr(pool[b:], g[f"pool2_{k}"]) < FEAT_TOL
+        cat = net.stage(f"cat_{k}")
+        assert maxerr(cat[:, :53], g[f"cv_{k}"]) < FEAT_TOL
+        assert maxerr(cat[:, 53:], g[f"r_{k}"]) < FEAT_TOL
+        assert maxerr(net.stage("flowcat")[:, 2 * (k - 1):2 * k], g[f"flow_{k}"]) < FEAT_TOL
+    assert maxerr(net.stage("coarse"), g["coarse"]) < FEAT_TOL
+    assert maxerr(flow, g["flow"]) < FLOW_TOL
+
+
+@pytest.mark.parametrize("b,h,w", [(1, 64, 64), (3, 72, 200), (2, 130, 70), (1, 200, 333)])
+def test_forward_vs_oracle_ragged(b, h, w):
+    net, sd = make_net(11)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(12, b, h, w))
+    with torch.no_grad():
+        flow = net(e1.to(DEV), e2.to(DEV))[1][0]
+        ref, _ = O.eemflow_forward(O.to_torch_sd(sd), e1, e2)
+    assert maxerr(flow, ref) < FLOW_TOL
+
+
+def test_forward_full_size_1280x720():
+    """BASELINE config[1]: 1x5x720x1280, checked directly against the oracle (a few seconds of CPU)."""
+    h, w = 720, 1280
+    net, sd = make_net(21)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(22, 1, h, w))
+    with torch.no_grad():
+        flow = net(e1.to(DEV), e2.to(DEV))[1][0]
+        ref, st = O.eemflow_forward(O.to_torch_sd(sd), e1, e2, keep=True)
+    assert maxerr(net.stage("f13")[:1], st["f13"]) < FEAT_TOL
+    assert maxerr(flow, ref) < FLOW_TOL
+    # EPE against a smooth synthetic ground truth agrees with the oracle's (north star: within 1e-3)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    gt = np.stack([3 * np.sin(2 * np.pi * xx / w), 3 * np.cos(2 * np.pi * yy / h)])
+    epe_hip = O.flow_error_dense(gt, flow[0].cpu().numpy())[0]
+    epe_ref = O.flow_error_dense(gt, ref[0].numpy())[0]
+    assert abs(epe_hip - epe_ref) < 1e-3
+
+
+def test_padder_mismatch_quirk():
+    """change_imagesize for one size, forward on another (train_mvsec.py:230 does this)."""
+    net, sd = make_net(31)
+    net.change_imagesize((260, 346))             # pad [19,19,0,60]
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(32, 1, 196, 282))   # padded 256x320
+    with torch.no_grad():
+        flow = net(e1.to(DEV), e2.to(DEV))[1][0]
+        ref, _ = O.eemflow_forward(O.to_torch_sd(sd), e1, e2, image_size=(260, 346))
+    assert maxerr(flow, ref) < FLOW_TOL
+
+
+def test_graph_equals_eager_and_is_repeatable():
+    h, w = 128, 192
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(42, 2, h, w))
+    outs = []
+    for graph in (True, False):
+        net, _ = make_net(41, graph=graph)
+        net.change_imagesize((h, w))
+        with torch.no_grad():
+            a = net(e1, e2)[1][0].clone()
+            b = net(e1, e2)[1][0].clone()
+        assert torch.equal(a, b)                 # no atomics on this path: bitwise repeatable
+        outs.append(a)
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_weights_reload_after_update():
+    h, w = 64, 128
+    net, sd = make_net(51)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(52, 1, h, w))
+    with torch.no_grad():
+        f0 = net(e1.to(DEV), e2.to(DEV))[1][0].clone()
+        sd2 = seeded_state_dict(53)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd2.items()})
+        f1 = net(e1.to(DEV), e2.to(DEV))[1][0]
+        ref, _ = O.eemflow_forward(O.to_torch_sd(sd2), e1, e2)
+    assert maxerr(f1, ref) < FLOW_TOL and maxerr(f0, f1) > 1e-3
+
+
+def test_out_mesh_size_training_shape():
+    net, sd = make_net(61)
+    net.out_mesh_size = True
+    net.change_imagesize((128, 128))
+    for p in net.parameters():
+        p.requires_grad_(False)
+    net.train()
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(62, 1, 128, 128))
+    with torch.no_grad():
+        flow = net(e1.to(DEV), e2.to(DEV))[1][0]
+        ref, _ = O.eemflow_forward(O.to_torch_sd(sd), e1, e2, out_size=(16, 16))
+    assert flow.shape == (1, 2, 16, 16) and maxerr(flow, ref) < FLOW_TOL
+
+
+def test_decoder_golden(golden):
+    g = golden("decoder.npz")
+    net, _ = make_net(int(g["seed"]))
+    net.change_imagesize((64, 64))
+    ctx = net._context(torch.device(DEV))
+    x = torch.from_numpy(g["x"]).to(DEV)
+    out = torch.empty(x.shape[0], 2, x.shape[2], x.shape[3], device=DEV)
+    _lib.check(_lib.lib().eemflow_decoder(ctx, 2, x.data_ptr(), x.shape[0], x.shape[2], x.shape[3], out.data_ptr(),
+                                          _lib.current_stream_ptr(torch.device(DEV))))
+    assert maxerr(out, g["y"]) < FEAT_TOL
+
+
+def test_local_corr_golden(golden):
+    g = golden("local_corr.npz")
+    x, y = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["y"]).to(DEV)
+    b, c, h, w = x.shape
+    out = torch.empty(b, 53, h, w, device=DEV)
+    _lib.check(_lib.lib().eemflow_local_corr53(x.data_ptr(), y.data_ptr(), b, c, h, w, out.data_ptr(),
+                                               _lib.current_stream_ptr(torch.device(DEV))))
+    assert maxerr(out, g["cv53"]) < 1e-5
+
+
+@pytest.mark.parametrize("shape,size", [((2, 2, 12, 20), (720, 1280)), ((1, 2, 5, 6), (260, 346)),
+                                        ((3, 2, 4, 7), (16, 16)), ((1, 2, 9, 9), (5, 31))])
+def test_upsample_vs_torch(shape, size):
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(3))
+    net, _ = make_net(1)
+    got = net.upsample_flow(x.to(DEV), size)
+    ref = O.upsample_flow(x, size)
+    assert maxerr(got, ref) < 1e-5
+
+
+VOX_CASES = ["n20k", "n20k_pol01", "n1", "n2_dt0", "n3_dt0", "n500_raw", "n300_bins3", "n400_unsorted", "n64_const"]
+
+
+@pytest.mark.parametrize("name", VOX_CASES)
+def test_voxelizer_golden(golden, name):
+    g = golden("voxel.npz")
+    h, w, bins, norm = g[f"{name}_hwb"].tolist()
+    seq = EventSequence(None, {"height": h, "width": w}, features=g[f"{name}_events"].copy(),
+                        timestamp_multiplier=1e6, convert_to_relative=True)
+    vox = EventSequenceToVoxelGrid_Pytorch(num_bins=bins, normalize=bool(norm), gpu=True, forkserver=False)
+    grid, il, ir = vox(seq, return_indices=True)
+    il, ir = il.cpu().numpy(), ir.cpu().numpy()
+    assert np.array_equal(il[il >= 0], g[f"{name}_idx_left"])      # int64 indices: bit-exact
+    assert np.array_equal(ir[ir >= 0], g[f"{name}_idx_right"])
+    ref = g[f"{name}_grid"]
+    got = grid.cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    np.testing.assert_allclose(np.nan_to_num(got), np.nan_to_num(ref), atol=2e-5, rtol=1e-5)
+    assert np.array_equal(got != 0, ref != 0) or not norm       # same support
+
+
+def test_voxelizer_full_size_properties():
+    """1280x720, N=2e6: indices against the oracle bit-exact; raw grid sums to the vote sum;
+    normalised grid has zero mean / unit unbiased std over its non-zero voxels."""
+    rng = np.random.default_rng(0)
+    n, h, w = 2_000_000, 720, 1280
+    ev = np.stack([np.sort(rng.uniform(0, 0.05, n)), rng.integers(0, w, n).astype(np.float64),
+                   rng.integers(0, h, n).astype(np.float64), rng.integers(0, 2, n) * 2.0 - 1.0], 1)
+    seq = EventSequence(None, {"height": h, "width": w}, features=ev.copy(), timestamp_multiplier=1e6,
+                        convert_to_relative=True)
+    feats = O.event_sequence(ev, 1e6, True)
+    assert np.array_equal(seq.features, feats)
+    il_ref, vl, ir_ref, vr = O.voxel_indices(feats, 5, h, w)
+    raw, il, ir = EventSequenceToVoxelGrid_Pytorch(5, gpu=True, normalize=False, forkserver=False)(seq, True)
+    il, ir = il.cpu().numpy(), ir.cpu().numpy()
+    assert np.array_equal(il[il >= 0], il_ref) and np.array_equal(ir[ir >= 0], ir_ref)
+    total = float(vl.astype(np.float64).sum() + vr.astype(np.float64).sum())
+    assert abs(float(raw.double().sum()) - total) < 1e-2
+    ref = O.voxelize(feats, 5, h, w, normalize=False)
+    np.testing.assert_allclose(raw.cpu().numpy(), ref, atol=1e-5)
+    norm = EventSequenceToVoxelGrid_Pytorch(5, gpu=True, normalize=True, forkserver=False)(seq)
+    nz = norm[norm != 0].double()
+    assert abs(float(nz.mean())) < 1e-4 and abs(float(nz.std()) - 1.0) < 1e-4
+
+
+def test_errors_are_loud():
+    net, _ = make_net(1)
+    with pytest.raises(AttributeError):
+        net(torch.zeros(1, 5, 64, 64, device=DEV), torch.zeros(1, 5, 64, 64, device=DEV))
+    net.change_imagesize((64, 64))
+    with pytest.raises(_lib.EEMFlowHipError):
+        net(torch.zeros(1, 5, 64, 64), torch.zeros(1, 5, 64, 64))
+    with pytest.raises(_lib.EEMFlowHipError):      # padded 64x64 -> grid 1x1 ok; 16x16 raw pads to 64: ok; use bad ctx arg
+        _lib.check(_lib.lib().eemflow_forward(net._context(torch.device(DEV)), None, None, 1, 64, 64, None, 64, 64, None))
+    handle = ctypes.c_void_p()
+    _lib.check(_lib.lib().eemflow_create(0, ctypes.byref(handle)))
+    with pytest.raises(_lib.EEMFlowHipError, match="no weights"):
+        x = torch.zeros(1, 5, 64, 64, device=DEV)
+        o = torch.zeros(1, 2, 64, 64, device=DEV)
+        _lib.check(_lib.lib().eemflow_forward(handle, x.data_ptr(), x.data_ptr(), 1, 64, 64, o.data_ptr(), 64, 64, None))
+    _lib.lib().eemflow_destroy(handle)

@@ -1,0 +1,98 @@
+"""CPU-side checks: the C-ABI library loads and exports every declared symbol, the host mirrors of the
+reference interfaces behave like the reference (against golden vectors), nothing falls back to CPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from eemflow_amd import EEMFlow, EventSequence, InputPadder, _lib
+from eemflow_amd.weights import eemflow_param_shapes, seeded_state_dict, strip_module_prefix
+from oracle import eemflow_oracle as O
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(REPO, "include", "eemflow_hip.h")).read()
+    declared = set(re.findall(r"\b(eemflow_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    handle = _lib.lib()                      # resolves every symbol or raises
+    assert handle.eemflow_abi_version() == 1
+    assert handle.eemflow_last_error() is not None
+
+
+def test_header_cites_reference_interfaces():
+    header = open(os.path.join(REPO, "include", "eemflow_hip.h")).read()
+    assert header.count("Replaces:") >= 8 and "EEMFlow.py:122-183" in header and "loader_utils.py:447-537" in header
+
+
+def test_state_dict_layout(golden):
+    g = golden("state_dict_layout.npz")
+    net = EEMFlow("", groups=5, n_first_channels=5)
+    sd = net.state_dict()
+    assert list(sd.keys()) == g["keys"].tolist()
+    assert [list(v.shape) for v in sd.values()] == [s[s >= 0].tolist() for s in g["shapes"]]
+    assert sum(v.numel() for v in sd.values()) == 714352 == int(g["nparams"])
+    assert list(eemflow_param_shapes().keys()) == list(sd.keys())
+    # DataParallel-prefixed checkpoints load after stripping, as test_EEMFlow_HREM.py:62-66 does
+    pref = {"module." + k: torch.from_numpy(v) for k, v in seeded_state_dict(0).items()}
+    net.load_state_dict(strip_module_prefix(pref))
+    flat = net._flat_weights()
+    assert flat.numel() == 714352 and torch.equal(flat[:720], torch.from_numpy(seeded_state_dict(0)["pconv1_1.0.weight"]).flatten())
+
+
+def test_init_matches_reference_scheme():
+    torch.manual_seed(0)
+    net = EEMFlow("", groups=5, n_first_channels=5)
+    assert all(float(p.abs().max()) == 0 for n, p in net.named_parameters() if n.endswith("bias"))
+    w = net.decoder_1.conv1[0].weight
+    assert abs(float(w.std()) - (2.0 / (69 * 9)) ** 0.5) < 2e-3           # kaiming_normal_, fan_in
+
+
+def test_padder_matches_reference(golden):
+    g = golden("pad.npz")
+    for h, w, rate, mode, *pad in g["table"].tolist():
+        assert InputPadder((h, w), mode="chairs" if mode == 0 else "sintel", eval_pad_rate=rate)._pad == pad
+    p = InputPadder((5, 7), mode="chairs", eval_pad_rate=4)
+    xp = p.pad(torch.from_numpy(g["x"]))[0]
+    assert np.array_equal(xp.numpy(), g["x_padded"]) and np.array_equal(p.unpad(xp).numpy(), g["x_unpadded"])
+
+
+def test_event_sequence_host_logic(golden):
+    g = golden("voxel.npz")
+    for name in ("n400_unsorted", "n20k", "n2_dt0"):
+        ev = g[f"{name}_events"]
+        seq = EventSequence(None, {"height": 48, "width": 64}, features=ev.copy(), timestamp_multiplier=1e6,
+                            convert_to_relative=True)
+        assert np.array_equal(seq.features, O.event_sequence(ev, 1e6, True))
+        assert seq.is_sorted() and len(seq) == len(ev) and seq.features[0, 0] == 0
+    a = EventSequence(None, {"height": 4, "width": 4}, features=np.array([[1.0, 0, 0, 1], [2.0, 1, 1, -1]]))
+    assert len(a + a) == 4 and (a + a).is_sorted()
+    assert EventSequence(None, {"height": 4, "width": 4}).features.shape == (1, 4)
+
+
+def test_no_cpu_fallback():
+    net = EEMFlow("", groups=5, n_first_channels=5).eval()
+    net.change_imagesize((64, 64))
+    with pytest.raises(_lib.EEMFlowHipError, match="no CPU path"):
+        net(torch.zeros(1, 5, 64, 64), torch.zeros(1, 5, 64, 64))
+    with pytest.raises(_lib.EEMFlowHipError):
+        net.upsample_flow(torch.zeros(1, 2, 4, 4), (8, 8))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(REPO, "eemflow_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(root, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libeemflow_hip.so")
+    with pytest.raises(_lib.EEMFlowHipError, match="no CPU fallback"):
+        _lib.lib()

@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libeemflow_hip.so")
-SOURCES = ["api.hip", "conv_enc.hip", "tail.hip", "voxel.hip"]
+SOURCES = ["api.hip", "conv_enc.hip", "conv_enc2.hip", "tail.hip", "voxel.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 EXTRA = {"voxel.hip": ["-ffp-contract=off"]}      # bit-exact f64 time scaling
 

@@ -60,7 +60,9 @@ struct eemflow_ctx {
     int pad[4] = {0, 0, 0, 0};
     // weights
     float* arena = nullptr;
-    size_t enc_w[ENC_NUM], enc_b[ENC_NUM];
+    size_t enc_w[ENC_NUM], enc_w2[ENC_NUM], enc_b[ENC_NUM];
+    bool enc_has2[ENC_NUM];
+    float* zero_page = nullptr;
     TailW rconv[3], dconv1[3], dgroup[3][3][5], dconv5[3], dconv6[3], dconv7[3], outc;
     int* taps = nullptr;
     // workspaces
@@ -256,6 +258,8 @@ int run_forward(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2
         a.in0 = sp.layer == ENC_1_1 ? e1 : sp.in;
         a.in1 = sp.layer == ENC_1_1 ? e2 : nullptr;
         a.wpk = c->arena + c->enc_w[sp.layer];
+        a.wpk2 = c->enc_has2[sp.layer] ? c->arena + c->enc_w2[sp.layer] : nullptr;
+        a.zero_page = c->zero_page;
         a.bias = c->arena + c->enc_b[sp.layer];
         a.out = sp.out;
         a.nimg = n2; a.nimg0 = sp.layer == ENC_1_1 ? s.batch : n2;
@@ -326,6 +330,8 @@ extern "C" int eemflow_create(int device, eemflow_ctx** out) {
     hipError_t e = hipMalloc(&c->taps, sizeof(kTaps53));
     if (e == hipSuccess) e = hipMemcpy(c->taps, kTaps53, sizeof(kTaps53), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&c->vox_scratch, voxel_scratch_bytes());
+    if (e == hipSuccess) e = hipMalloc(&c->zero_page, 256);
+    if (e == hipSuccess) e = hipMemset(c->zero_page, 0, 256);
     if (e != hipSuccess) {
         eem_set_error("eemflow_create: %s", hipGetErrorString(e));
         delete c;
@@ -347,6 +353,7 @@ extern "C" void eemflow_destroy(eemflow_ctx* c) {
     }
     if (c->arena) (void)hipFree(c->arena);
     if (c->taps) (void)hipFree(c->taps);
+    if (c->zero_page) (void)hipFree(c->zero_page);
     if (c->vox_scratch) (void)hipFree(c->vox_scratch);
     delete c;
 }
@@ -381,6 +388,11 @@ extern "C" int eemflow_load_weights(eemflow_ctx* c, const float* flat, size_t nf
         const int cin = l == 0 ? n_first_channels : kEncLayers[l].cin, cout = kEncLayers[l].cout;
         c->enc_w[l] = push(enc_packed_floats(cin, cout));
         enc_pack_weights(p, cin, cout, host.data() + c->enc_w[l]);
+        c->enc_has2[l] = enc2_supported(cin, cout, kEncLayers[l].stride, 4);
+        if (c->enc_has2[l]) {
+            c->enc_w2[l] = push(enc2_packed_floats(cin, cout));
+            enc2_pack_weights(p, cin, cout, host.data() + c->enc_w2[l]);
+        }
         p += (size_t)cout * cin * 9;
         c->enc_b[l] = push(cout);
         memcpy(host.data() + c->enc_b[l], p, cout * sizeof(float));

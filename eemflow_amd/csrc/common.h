@@ -56,7 +56,9 @@ void enc_pack_weights(const float* w, int cin, int cout, float* packed);
 struct EncConvArgs {
     const float* in0;
     const float* in1;      // only ENC_1_1 (second event volume), else unused
-    const float* wpk;      // packed weights
+    const float* wpk;      // packed weights, generic kernel (conv_enc.hip)
+    const float* wpk2;     // packed weights, LDS-DMA fast path (conv_enc2.hip); may be NULL
+    const float* zero_page;// >= 16 zero bytes in device memory (source of out-of-image pieces)
     const float* bias;
     float* out;
     int nimg;              // images in this launch (2B)
@@ -68,6 +70,11 @@ struct EncConvArgs {
     int act;               // 1: LeakyReLU(0.1)
 };
 int enc_conv_launch(int cin, int cout, int stride, const EncConvArgs& a, hipStream_t stream);
+// fast path (feature width % 4 == 0, layers 2..8)
+bool enc2_supported(int cin, int cout, int stride, int win);
+size_t enc2_packed_floats(int cin, int cout);
+void enc2_pack_weights(const float* w, int cin, int cout, float* packed);
+int enc_conv2_launch(int cin, int cout, int stride, const EncConvArgs& a, hipStream_t stream);
 
 // ----------------------------------------------------------------------------- tail kernels
 // Generic small-grid 3x3 (or 1x1) conv on MFMA 16x16x4, K split over the 4 waves of a block.

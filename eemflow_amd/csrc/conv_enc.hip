@@ -73,16 +73,19 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(EncConvArgs a) {
             const int ry = rem / C::IN_COLS;
             const int rx = rem - ry * C::IN_COLS;
             const int gy = gy0 + ry, gx = gx0 + rx;
-            float v = 0.f;
-            if (gy >= 0 && gy < a.hin && gx >= 0 && gx < a.win) {
-                if (PADIN) {
-                    int sy = min(max(gy - a.pad_top, 0), a.hraw - 1);
-                    int sx = min(max(gx - a.pad_left, 0), a.wraw - 1);
-                    v = src[((size_t)c * a.hraw + sy) * a.wraw + sx];
-                } else {
-                    v = src[((size_t)c * a.hin + gy) * a.win + gx];
-                }
+            // branch-free: always load from a clamped (valid) address, then select
+            const bool ok = gy >= 0 && gy < a.hin && gx >= 0 && gx < a.win;
+            float v;
+            if (PADIN) {
+                const int sy = min(max(gy - a.pad_top, 0), a.hraw - 1);
+                const int sx = min(max(gx - a.pad_left, 0), a.wraw - 1);
+                v = src[((size_t)c * a.hraw + sy) * a.wraw + sx];
+            } else {
+                const int sy = min(max(gy, 0), a.hin - 1);
+                const int sx = min(max(gx, 0), a.win - 1);
+                v = src[((size_t)c * a.hin + sy) * a.win + sx];
             }
+            v = ok ? v : 0.f;
             tile[e] = v;
         }
     }
@@ -239,6 +242,7 @@ void enc_pack_weights(const float* w, int cin, int cout, float* packed) {
 }
 
 int enc_conv_launch(int cin, int cout, int stride, const EncConvArgs& a, hipStream_t stream) {
+    if (a.wpk2 && a.zero_page && enc2_supported(cin, cout, stride, a.win)) return enc_conv2_launch(cin, cout, stride, a, stream);
     //                                   CIN COUT S  TH TWT PADIN
     if (cin == 5 && cout == 16 && stride == 2) return launch<5, 16, 2, 8, 4, true>(a, stream);
     if (cin == 16 && cout == 16 && stride == 1) return launch<16, 16, 1, 8, 4, false>(a, stream);

@@ -1,0 +1,234 @@
+// Fast path of the encoder convolutions (layers 2..8 of EEMFlow.py:75-82) for feature maps whose
+// width is a multiple of 4 (always true for inputs padded to a multiple of 64).
+//
+// Same implicit GEMM as conv_enc.hip (D[cout][pixel] on the fp32 matrix cores), but the operands
+// are streamed through LDS by the DMA path instead of through registers:
+//   * the input is consumed in chunks of CK channels; a chunk's input tile [CK][rows][ROWP] (16-byte
+//     aligned row segments incl. halo) AND its packed weight fragments are copied HBM/L2 -> LDS with
+//     global_load_lds_dwordx4 (1 KiB per wave-instruction, per-lane source address, out-of-image
+//     pieces read a zero page);
+//   * two LDS stages: chunk c+1 is in flight while chunk c feeds the MFMAs (counted vmcnt + raw
+//     s_barrier, one __shared__ array - see cdna_hip_programming.md "Pipelining across barriers");
+//   * weights are read back as ds_read_b128 (4 k-steps per lane), input taps as ds_read_b32 with
+//     compile-time immediates for every (tap, channel) displacement.
+#include "common.h"
+
+namespace {
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+template <int CIN, int COUT, int STRIDE, int TH, int TWT, int WAVES, int WM, int CK>
+struct Cfg2 {
+    static constexpr bool M16 = (COUT == 16);
+    static constexpr int NPIX = M16 ? 16 : 32;
+    static constexpr int KPS = M16 ? 4 : 2;
+    static constexpr int MT = M16 ? 1 : COUT / 32;
+    static constexpr int ACC = M16 ? 4 : 16;
+    static constexpr int TW = TWT * NPIX;
+    static constexpr int IN_ROWS = (TH - 1) * STRIDE + 3;
+    static constexpr int ROWP = ((TW - 1) * STRIDE + 6 + 3) / 4 * 4;     // floats per staged row (starts at x0*S-4)
+    static constexpr int PPR = ROWP / 4;                                   // 16-byte pieces per row
+    static constexpr int PLANE = IN_ROWS * ROWP;
+    static constexpr int NCHUNK = CIN / CK;
+    static constexpr int CG = CK / KPS;                                    // k-steps per tap in a chunk
+    static constexpr int STEPS = 9 * CG;                                   // k-steps per chunk
+    static constexpr int B_PIECES = CK * IN_ROWS * PPR;
+    static constexpr int NB = (B_PIECES + 63) / 64;                        // wave-instructions for the input tile
+    static constexpr int NA = MT * STEPS / 4;                              // wave-instructions for the weights
+    static constexpr int NI = (NB + NA + WAVES - 1) / WAVES;               // per wave, per chunk (incl. dummies)
+    static constexpr int STAGE = (NI * WAVES) * 256;                       // floats per LDS stage
+    static constexpr int NSTAGE = NCHUNK > 1 ? 2 : 1;
+    static constexpr int WP = WAVES / WM;                                  // wave groups along pixels
+    static constexpr int UPW = TH * TWT / WP;                              // pixel tiles per wave
+    static constexpr int MTW = MT / WM;                                    // cout tiles per wave
+    static_assert(CIN % CK == 0 && CK % KPS == 0 && STEPS % 4 == 0, "chunking");
+    static_assert((TH * TWT) % WP == 0 && MT % WM == 0 && WAVES % WM == 0, "wave split");
+    static_assert(NSTAGE * STAGE * 4 <= 160 * 1024, "LDS budget");
+};
+
+template <bool M16> struct AccT2 { using type = f32x16; };
+template <> struct AccT2<true> { using type = f32x4; };
+
+template <int CIN, int COUT, int STRIDE, int TH, int TWT, int WAVES, int WM, int CK>
+__global__ __launch_bounds__(WAVES * 64) void enc_conv2_kernel(EncConvArgs a) {
+    using C = Cfg2<CIN, COUT, STRIDE, TH, TWT, WAVES, WM, CK>;
+    using acc_t = typename AccT2<C::M16>::type;
+    __shared__ __attribute__((aligned(16))) float lds[C::NSTAGE * C::STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int n = blockIdx.z;
+    const int oy0 = blockIdx.y * TH;
+    const int ox0 = blockIdx.x * C::TW;
+    const int gy0 = oy0 * STRIDE - 1;
+    const int gxa = ox0 * STRIDE - 4;                       // 16-byte aligned start column
+    const float* src = a.in0 + (size_t)n * CIN * a.hin * a.win;
+    const float* zero_page = a.zero_page;
+
+    // ---- issue the DMA of chunk `ch` into LDS stage `stage`: NI wave-instructions per wave
+    auto issue = [&](int ch, int stage) {
+        float* sbase = lds + stage * C::STAGE;
+#pragma unroll
+        for (int k = 0; k < C::NI; ++k) {
+            const int i = wave + k * WAVES;                 // wave-uniform instruction index
+            const float* g;
+            if (i < C::NB) {
+                const int p = i * 64 + lane;
+                const int c = p / (C::IN_ROWS * C::PPR);
+                const int rem = p - c * (C::IN_ROWS * C::PPR);
+                const int ry = rem / C::PPR;
+                const int q = rem - ry * C::PPR;
+                const int gy = gy0 + ry, gx = gxa + q * 4;
+                const bool ok = (p < C::B_PIECES) && gy >= 0 && gy < a.hin && gx >= 0 && gx < a.win;
+                g = ok ? src + ((size_t)(ch * CK + c) * a.hin + gy) * a.win + gx : zero_page;
+            } else if (i < C::NB + C::NA) {
+                g = a.wpk2 + ((size_t)ch * C::NA + (i - C::NB)) * 256 + lane * 4;
+            } else {
+                g = zero_page;                              // padding instruction keeps vmcnt uniform
+            }
+            __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(sbase + i * 256), 16, 0, 0);
+        }
+    };
+
+    // ---- per-lane constants
+    const int j = lane & (C::NPIX - 1);
+    const int g = lane / C::NPIX;
+    const int wm = wave % WM, wp = wave / WM;
+
+    acc_t acc[C::UPW][C::MTW];
+#pragma unroll
+    for (int u = 0; u < C::UPW; ++u)
+#pragma unroll
+        for (int m = 0; m < C::MTW; ++m)
+#pragma unroll
+            for (int r = 0; r < C::ACC; ++r) {
+                const int mt = wm * C::MTW + m;
+                const int co = C::M16 ? (g * 4 + r) : (mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g);
+                acc[u][m][r] = a.bias[co];
+            }
+
+    int ubase[C::UPW];
+#pragma unroll
+    for (int u = 0; u < C::UPW; ++u) {
+        const int unit = wp * C::UPW + u;
+        const int row = unit / TWT, ct = unit % TWT;
+        ubase[u] = g * C::PLANE + row * STRIDE * C::ROWP + (ct * C::NPIX + j) * STRIDE + 3;
+    }
+
+    issue(0, 0);
+#pragma unroll 1
+    for (int ch = 0; ch < C::NCHUNK; ++ch) {
+        const int cur = (C::NSTAGE == 2) ? (ch & 1) : 0;
+        if (C::NSTAGE == 2 && ch + 1 < C::NCHUNK) {
+            issue(ch + 1, cur ^ 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NI) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+
+        const float* tb = lds + cur * C::STAGE;
+        const f32x4* ta = reinterpret_cast<const f32x4*>(tb + C::NB * 256) + lane;
+#pragma unroll
+        for (int s4 = 0; s4 < C::STEPS / 4; ++s4) {
+            f32x4 av[C::MTW];
+#pragma unroll
+            for (int m = 0; m < C::MTW; ++m) av[m] = ta[((wm * C::MTW + m) * (C::STEPS / 4) + s4) * 64];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int s = s4 * 4 + q;
+                const int t = s / C::CG, cg = s % C::CG;
+                const int off = cg * C::KPS * C::PLANE + (t / 3) * C::ROWP + (t % 3);
+#pragma unroll
+                for (int u = 0; u < C::UPW; ++u) {
+                    const float b = tb[ubase[u] + off];
+#pragma unroll
+                    for (int m = 0; m < C::MTW; ++m) {
+                        if constexpr (C::M16)
+                            acc[u][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][q], b, acc[u][m], 0, 0, 0);
+                        else
+                            acc[u][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][q], b, acc[u][m], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (C::NSTAGE == 2 && ch + 2 < C::NCHUNK) __builtin_amdgcn_s_barrier();   // stage `cur` is refilled next
+    }
+
+    // ---- epilogue: LeakyReLU + NCHW store
+    float* dst = a.out + (size_t)n * COUT * a.hout * a.wout;
+#pragma unroll
+    for (int u = 0; u < C::UPW; ++u) {
+        const int unit = wp * C::UPW + u;
+        const int row = unit / TWT, ct = unit % TWT;
+        const int oy = oy0 + row;
+        const int ox = ox0 + ct * C::NPIX + j;
+        if (oy < a.hout && ox < a.wout) {
+#pragma unroll
+            for (int m = 0; m < C::MTW; ++m)
+#pragma unroll
+                for (int r = 0; r < C::ACC; ++r) {
+                    const int mt = wm * C::MTW + m;
+                    const int co = C::M16 ? (g * 4 + r) : (mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g);
+                    float v = acc[u][m][r];
+                    if (a.act) v = v > 0.f ? v : 0.1f * v;
+                    dst[((size_t)co * a.hout + oy) * a.wout + ox] = v;
+                }
+        }
+    }
+}
+
+template <int CIN, int COUT, int STRIDE, int TH, int TWT, int WAVES, int WM, int CK>
+int launch2(const EncConvArgs& a, hipStream_t stream) {
+    using C = Cfg2<CIN, COUT, STRIDE, TH, TWT, WAVES, WM, CK>;
+    dim3 grid(ceil_div(a.wout, C::TW), ceil_div(a.hout, TH), a.nimg);
+    hipLaunchKernelGGL((enc_conv2_kernel<CIN, COUT, STRIDE, TH, TWT, WAVES, WM, CK>), grid, dim3(WAVES * 64), 0,
+                       stream, a);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------- host side
+// Weight layout of the fast path: [chunk][cout tile][k-step/4][lane][4], k-step s of a chunk = tap-major
+// (t = s / CG), then channel group (cg = s % CG); lane supplies channel cg*KPS + lane/NPIX.
+static int enc2_ck(int cin, int cout) { return cout == 64 ? 8 : 16; }
+
+bool enc2_supported(int cin, int cout, int stride, int win) {
+    if ((win & 3) != 0 || cin < 16) return false;
+    return (cin == 16 && cout == 16 && stride == 1) || (cin == 16 && cout == 32 && stride == 2) ||
+           (cin == 32 && cout == 32 && stride == 1) || (cin == 32 && cout == 64 && stride == 2) ||
+           (cin == 64 && cout == 64 && stride == 1);
+}
+
+size_t enc2_packed_floats(int cin, int cout) { return (size_t)cout * cin * 9; }
+
+void enc2_pack_weights(const float* w, int cin, int cout, float* packed) {
+    const bool m16 = cout == 16;
+    const int npix = m16 ? 16 : 32, kps = m16 ? 4 : 2, mt = m16 ? 1 : cout / 32;
+    const int ck = enc2_ck(cin, cout), cg = ck / kps, steps = 9 * cg, nchunk = cin / ck;
+    for (int ch = 0; ch < nchunk; ++ch)
+        for (int m = 0; m < mt; ++m)
+            for (int s = 0; s < steps; ++s)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int co = m * 32 + (lane & (npix - 1));
+                    const int c = ch * ck + (s % cg) * kps + lane / npix;
+                    const int t = s / cg;
+                    const size_t idx = ((((size_t)ch * mt + m) * (steps / 4) + s / 4) * 64 + lane) * 4 + (s & 3);
+                    packed[idx] = w[((size_t)co * cin + c) * 9 + t];
+                }
+}
+
+int enc_conv2_launch(int cin, int cout, int stride, const EncConvArgs& a, hipStream_t stream) {
+    //                                            CIN COUT S TH TWT WAVES WM CK
+    if (cin == 16 && cout == 16) return launch2<16, 16, 1, 8, 4, 4, 1, 16>(a, stream);
+    if (cin == 16 && cout == 32) return launch2<16, 32, 2, 4, 1, 4, 1, 16>(a, stream);
+    if (cin == 32 && cout == 32) return launch2<32, 32, 1, 4, 2, 8, 1, 16>(a, stream);
+    if (cin == 32 && cout == 64) return launch2<32, 64, 2, 4, 1, 8, 2, 8>(a, stream);
+    if (cin == 64 && cout == 64) return launch2<64, 64, 1, 4, 1, 8, 2, 8>(a, stream);
+    eem_set_error("enc_conv2_launch: unsupported layer cin=%d cout=%d stride=%d", cin, cout, stride);
+    return EEM_ERR_ARG;
+}

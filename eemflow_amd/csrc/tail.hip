@@ -71,11 +71,15 @@ __global__ __launch_bounds__(256) void corr_kernel(CorrArgs a) {
 
 // ------------------------------------------------------------------------------- small-grid conv
 // D[cout 16][pixel 16] tiles on v_mfma_f32_16x16x4_f32; pixels are the flattened (y*w+x) index.
-// block = 4 waves; wave v takes k-steps v, v+4, ...; partial tiles are summed through LDS.
-template <int KS>
-__global__ __launch_bounds__(256) void tail_conv_kernel(TailConvLaunch L) {
-    __shared__ f32x4 part[3][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// One wave per filter tap (9 waves for 3x3): a wave's K range is its tap x all channel groups, so the
+// tap displacement and the bounds test are per-wave constants and ALL of its operand loads (<= MAXCG
+// weight fragments + MAXCG input gathers) are issued before the first MFMA - the grid is tiny and
+// L2-resident, so the kernel is one memory round trip + <= 25 MFMAs + a 9-way LDS reduction.
+template <int KS, int MAXCG>
+__global__ __launch_bounds__(64 * KS * KS) void tail_conv_kernel(TailConvLaunch L) {
+    constexpr int KK = KS * KS;
+    __shared__ f32x4 part[KK][64];
+    const int lane = threadIdx.x & 63, t = threadIdx.x >> 6;
     const int ji = blockIdx.z / L.batch, b = blockIdx.z % L.batch;
     const TailConvJob jb = L.job[ji];
     const int cot = blockIdx.y;
@@ -85,35 +89,42 @@ __global__ __launch_bounds__(256) void tail_conv_kernel(TailConvLaunch L) {
     const int p = blockIdx.x * 16 + j;
     const bool pvalid = p < hw;
     const int y = p / L.w, x = p - y * L.w;
+    const int yy = y + (KS == 3 ? t / 3 - 1 : 0), xx = x + (KS == 3 ? t % 3 - 1 : 0);
+    const bool valid = pvalid && yy >= 0 && yy < L.h && xx >= 0 && xx < L.w;
     const int cg = (jb.cin + 3) >> 2;
-    const int ksteps = KS * KS * cg;
-    const float* in = jb.in + ((size_t)b * jb.in_ctotal + jb.in_coff) * hw;
-    const float* wp = jb.wpk + (size_t)cot * ksteps * 64 + lane;
+    const float* in = jb.in + ((size_t)b * jb.in_ctotal + jb.in_coff) * hw + (valid ? yy * L.w + xx : 0);
+    const float* wp = jb.wpk + ((size_t)cot * KK + t) * cg * 64 + lane;
 
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int s = wave; s < ksteps; s += 4) {
-        const int t = s / cg, c = (s - t * cg) * 4 + g;
-        const int yy = y + (KS == 3 ? t / 3 - 1 : 0), xx = x + (KS == 3 ? t % 3 - 1 : 0);
-        float bv = 0.f;
-        if (pvalid && c < jb.cin && yy >= 0 && yy < L.h && xx >= 0 && xx < L.w)
-            bv = in[(size_t)c * hw + yy * L.w + xx];
-        const float av = wp[(size_t)s * 64];
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-    }
-    if (wave > 0) part[wave - 1][lane] = acc;
-    __syncthreads();
-    if (wave == 0) {
-        acc += part[0][lane] + part[1][lane] + part[2][lane];
-        if (pvalid) {
+    float av[MAXCG], bv[MAXCG];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = cot * 16 + g * 4 + r;
-                if (co < jb.cout) {
-                    float v = acc[r] + jb.bias[co];
-                    if (jb.act) v = v > 0.f ? v : 0.1f * v;
-                    jb.out[((size_t)b * jb.out_ctotal + co * jb.out_cmul + jb.out_coff) * hw + p] = v;
-                }
+    for (int q = 0; q < MAXCG; ++q) {
+        const int qc = q < cg ? q : cg - 1;
+        const int c = qc * 4 + g;
+        const float a0 = wp[(size_t)qc * 64];
+        const float b0 = in[(size_t)(c < jb.cin ? c : jb.cin - 1) * hw];
+        av[q] = q < cg ? a0 : 0.f;                       // weights of padded channels are packed as zeros
+        bv[q] = (valid && c < jb.cin) ? b0 : 0.f;
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < MAXCG; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q], acc, 0, 0, 0);
+
+    if (KK > 1) {
+        part[t][lane] = acc;
+        __syncthreads();
+        if (t != 0) return;
+        acc = part[0][lane];
+#pragma unroll
+        for (int k = 1; k < KK; ++k) acc += part[k][lane];          // fixed order: bitwise repeatable
+    }
+    if (pvalid) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = cot * 16 + g * 4 + r;
+            if (co < jb.cout) {
+                float v = acc[r] + jb.bias[co];
+                if (jb.act) v = v > 0.f ? v : 0.1f * v;
+                jb.out[((size_t)b * jb.out_ctotal + co * jb.out_cmul + jb.out_coff) * hw + p] = v;
             }
         }
     }
@@ -214,16 +225,30 @@ void tail_pack_weights(const float* w, int cin, int cout, int ksize, float* pack
             }
 }
 
+template <int KS, int MAXCG>
+static void tail_launch_t(const TailConvLaunch& l, dim3 grid, hipStream_t stream) {
+    hipLaunchKernelGGL((tail_conv_kernel<KS, MAXCG>), grid, dim3(64 * KS * KS), 0, stream, l);
+}
+
 int tail_conv_launch(const TailConvLaunch& l, hipStream_t stream) {
     EEM_REQUIRE(l.njobs >= 1 && l.njobs <= TAIL_MAX_JOBS, "tail_conv_launch: njobs=%d", l.njobs);
     EEM_REQUIRE(l.ksize == 3 || l.ksize == 1, "tail_conv_launch: ksize=%d", l.ksize);
-    int max_cout = 0;
-    for (int i = 0; i < l.njobs; ++i) max_cout = l.job[i].cout > max_cout ? l.job[i].cout : max_cout;
+    int max_cout = 0, max_cg = 0;
+    for (int i = 0; i < l.njobs; ++i) {
+        max_cout = l.job[i].cout > max_cout ? l.job[i].cout : max_cout;
+        const int cg = ceil_div(l.job[i].cin, 4);
+        max_cg = cg > max_cg ? cg : max_cg;
+    }
+    EEM_REQUIRE(max_cg <= 25, "tail_conv_launch: cin > 100 is not built");
     dim3 grid(ceil_div(l.h * l.w, 16), ceil_div(max_cout, 16), l.njobs * l.batch);
-    if (l.ksize == 3)
-        hipLaunchKernelGGL(tail_conv_kernel<3>, grid, dim3(256), 0, stream, l);
-    else
-        hipLaunchKernelGGL(tail_conv_kernel<1>, grid, dim3(256), 0, stream, l);
+    if (l.ksize == 1) {
+        if (max_cg <= 2) tail_launch_t<1, 2>(l, grid, stream);
+        else tail_launch_t<1, 25>(l, grid, stream);
+    } else if (max_cg <= 5) tail_launch_t<3, 5>(l, grid, stream);
+    else if (max_cg <= 8) tail_launch_t<3, 8>(l, grid, stream);
+    else if (max_cg <= 16) tail_launch_t<3, 16>(l, grid, stream);
+    else if (max_cg <= 18) tail_launch_t<3, 18>(l, grid, stream);
+    else tail_launch_t<3, 25>(l, grid, stream);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

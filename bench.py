@@ -39,6 +39,8 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
     p.add_argument("--kernel-reps", type=int, default=20)
     p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--streams", type=int, default=1,
+                   help="frames in flight per GPU: independent contexts on separate HIP streams, steps alternate")
     return p.parse_args()
 
 
@@ -119,29 +121,41 @@ def main():
     sd_np = seeded_state_dict(0)
     e1_np, e2_np = synthetic_voxel_pair(1 + rank, B, H, W)          # each rank its own frames
     e1, e2 = torch.from_numpy(e1_np).to(dev), torch.from_numpy(e2_np).to(dev)
-    flow = torch.empty(B, 2, H, W, device=dev)
     flat = torch.cat([torch.from_numpy(v).reshape(-1) for v in sd_np.values()]).contiguous()
 
-    ctx = ctypes.c_void_p()
-    _lib.check(L.eemflow_create(local_rank, ctypes.byref(ctx)))
-    _lib.check(L.eemflow_load_weights(ctx, flat.data_ptr(), flat.numel(), 5, 5))
-    _lib.check(L.eemflow_set_image_size(ctx, H, W, None))
-    _lib.check(L.eemflow_use_graph(ctx, 0 if args.no_graph else 1))
-    stream = torch.cuda.Stream(device=dev)
+    NS = max(1, args.streams)
+    ctxs, streams, flows = [], [], []
+    for _ in range(NS):
+        c = ctypes.c_void_p()
+        _lib.check(L.eemflow_create(local_rank, ctypes.byref(c)))
+        _lib.check(L.eemflow_load_weights(c, flat.data_ptr(), flat.numel(), 5, 5))
+        _lib.check(L.eemflow_set_image_size(c, H, W, None))
+        _lib.check(L.eemflow_use_graph(c, 0 if args.no_graph else 1))
+        ctxs.append(c)
+        streams.append(torch.cuda.Stream(device=dev))
+        flows.append(torch.empty(B, 2, H, W, device=dev))
+    ctx, stream, flow = ctxs[0], streams[0], flows[0]
     sp = ctypes.c_void_p(stream.cuda_stream)
+    sps = [ctypes.c_void_p(st.cuda_stream) for st in streams]
+    counter = [0]
 
     def step():
-        _lib.check(L.eemflow_forward(ctx, e1.data_ptr(), e2.data_ptr(), B, H, W, flow.data_ptr(), H, W, sp))
+        i = counter[0] % NS
+        counter[0] += 1
+        _lib.check(L.eemflow_forward(ctxs[i], e1.data_ptr(), e2.data_ptr(), B, H, W, flows[i].data_ptr(), H, W, sps[i]))
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
     parallel.barrier(dev)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    counter[0] = 0
     t0 = time.perf_counter()
     ev0.record(stream)
     for _ in range(args.steps):
         step()
+    for st in streams[1:]:
+        stream.wait_stream(st)
     ev1.record(stream)
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
@@ -187,6 +201,7 @@ def main():
         if args.cpu_seconds > 0:
             from oracle import eemflow_oracle as O
             ref, cpu = cpu_baseline(sd_np, torch.from_numpy(e1_np), torch.from_numpy(e2_np), args.cpu_seconds)
+            counter[0] = 0
             step()
             torch.cuda.synchronize(dev)
             got = flow.cpu()
@@ -205,7 +220,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"EEMFlow inference, HREM {W}x{H} dt1, batch={B} per GPU (BASELINE configs[1]); "
                                    "synthetic 20%-dense voxel pairs resident in HBM, seeded Kaiming weights",
-                       "height": H, "width": W, "batch_per_gpu": B, "hip_graph": not args.no_graph,
+                       "height": H, "width": W, "batch_per_gpu": B, "hip_graph": not args.no_graph, "streams_per_gpu": NS,
                        "parallelism": f"replicas x{world}: frames sharded over ranks, no data-path collective"},
             "roofline": roof, "cpu_baseline": cpu,
             "gpu_ms_per_step_hip_events": round(gpu_ms / args.steps, 4),
@@ -216,7 +231,8 @@ def main():
         }
         print(json.dumps(line), flush=True)
     parallel.barrier(dev)
-    L.eemflow_destroy(ctx)
+    for c in ctxs:
+        L.eemflow_destroy(c)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 

@@ -47,6 +47,9 @@ struct Shape {
     int hp = 0, wp = 0;                // padded extent
     int h1 = 0, w1 = 0, h2 = 0, w2 = 0, h3 = 0, w3 = 0;
     int gh = 0, gw = 0;                // 1/64 grid
+    // fused stage pooling (fast path): partial-sum buffer dims per stage, fuse[k] = conv epilogue pools stage k
+    bool fuse[3] = {false, false, false};
+    int prow[3] = {0, 0, 0}, pcol[3] = {0, 0, 0}, th[3] = {0, 0, 0};
 };
 
 }  // namespace
@@ -66,7 +69,7 @@ struct eemflow_ctx {
     TailW rconv[3], dconv1[3], dgroup[3][3][5], dconv5[3], dconv6[3], dconv7[3], outc;
     int* taps = nullptr;
     // workspaces
-    DevBuf a1, f11, a2, b2, f12, a3, b3, f13, pool[3], cat[3], ta[3], tb[3], t64[3], t32[3], flowcat, coarse;
+    DevBuf a1, f11, a2, b2, f12, a3, b3, f13, pool[3], ppart[3], cat[3], ta[3], tb[3], t64[3], t32[3], flowcat, coarse;
     void* vox_scratch = nullptr;
     Shape last;
     bool have_last = false;
@@ -118,6 +121,18 @@ int compute_shape(eemflow_ctx* c, int batch, int in_h, int in_w, int out_h, int 
     EEM_REQUIRE(s->h2 / 16 == s->gh && s->h3 / 8 == s->gh && s->w2 / 16 == s->gw && s->w3 / 8 == s->gw,
                 "pooled grids of the three stages differ for padded size %dx%d (the reference's torch.cat "
                 "fails too)", s->hp, s->wp);
+    // stage pooling can ride in the epilogue of pconv1_2 / pconv2_3 / pconv3_3 when those run the fast path
+    const int last[3] = {ENC_1_2, ENC_2_3, ENC_3_3};
+    const int hs[3] = {s->h1, s->h2, s->h3}, ws[3] = {s->w1, s->w2, s->w3}, ks[3] = {32, 16, 8};
+    for (int k = 0; k < 3; ++k) {
+        const EncLayerDesc& d = kEncLayers[last[k]];
+        int th, tw, pk;
+        enc2_tile(d.cin, d.cout, &th, &tw, &pk);
+        s->fuse[k] = c->enc_has2[last[k]] && enc2_supported(d.cin, d.cout, d.stride, ws[k]) && pk == ks[k];
+        s->th[k] = th;
+        s->prow[k] = ceil_div(hs[k], th);
+        s->pcol[k] = ceil_div(ws[k], tw) * (tw / ks[k]);
+    }
     return EEM_OK;
 }
 
@@ -131,6 +146,7 @@ int alloc_workspace(eemflow_ctx* c, const Shape& s) {
     const int pc[3] = {16, 32, 64};
     for (int k = 0; k < 3; ++k) {
         ENS(c->pool[k], n2 * pc[k] * g);
+        if (s.fuse[k]) ENS(c->ppart[k], n2 * pc[k] * (size_t)s.prow[k] * s.pcol[k]);
         ENS(c->cat[k], B * kDecIn * g);
         ENS(c->ta[k], B * kDecW * g);   ENS(c->tb[k], B * kDecW * g);
         ENS(c->t64[k], B * 64 * g);     ENS(c->t32[k], B * 32 * g);
@@ -269,6 +285,13 @@ int run_forward(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2
         a.pad_top = sp.layer == ENC_1_1 ? c->pad[2] : 0;
         a.pad_left = sp.layer == ENC_1_1 ? c->pad[0] : 0;
         a.act = 1;
+        a.pool_partial = nullptr;
+        a.pool_k = 0;
+        for (int k = 0; k < 3; ++k)
+            if (s.fuse[k] && sp.layer == (k == 0 ? ENC_1_2 : k == 1 ? ENC_2_3 : ENC_3_3)) {
+                a.pool_partial = c->ppart[k].p;
+                a.pool_k = k == 0 ? 32 : k == 1 ? 16 : 8;
+            }
         const double opix = (double)n2 * sp.hout * sp.wout;
         const double flops = 2.0 * opix * d.cout * d.cin * 9;
         const double ipix = sp.layer == ENC_1_1 ? (double)n2 * s.in_h * s.in_w : (double)n2 * sp.hin * sp.win;
@@ -277,14 +300,36 @@ int run_forward(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2
                     [&](hipStream_t st) { return enc_conv_launch(d.cin, d.cout, d.stride, a, st); });
         if (rc != EEM_OK) return rc;
     }
-    // ---- stage pooling to the common 1/64 grid (EEMFlow.py:144-154)
-    const PoolJob pj[3] = {{c->f11.p, c->pool[0].p, 16, s.h1, s.w1, 32},
-                           {c->f12.p, c->pool[1].p, 32, s.h2, s.w2, 16},
-                           {c->f13.p, c->pool[2].p, 64, s.h3, s.w3, 8}};
-    const double pool_elems = (double)n2 * (16.0 * s.h1 * s.w1 + 32.0 * s.h2 * s.w2 + 64.0 * s.h3 * s.w3);
-    rc = hk.run("pool 32/16/8", pool_elems, 4.0 * pool_elems,
-                [&](hipStream_t st) { return pool_launch(pj, 3, n2, st); });
-    if (rc != EEM_OK) return rc;
+    // ---- stage pooling to the common 1/64 grid (EEMFlow.py:144-154): finish the partial sums the conv
+    // epilogues wrote; stages whose conv ran the generic kernel are pooled from the stored feature map
+    {
+        const float* feat[3] = {c->f11.p, c->f12.p, c->f13.p};
+        const int pcs[3] = {16, 32, 64}, hs[3] = {s.h1, s.h2, s.h3}, ws[3] = {s.w1, s.w2, s.w3}, ks[3] = {32, 16, 8};
+        PoolFinJob fj[3];
+        PoolJob pj[3];
+        int nf = 0, np = 0;
+        double fin_elems = 0, pool_elems = 0;
+        for (int k = 0; k < 3; ++k) {
+            if (s.fuse[k]) {
+                fj[nf++] = {c->ppart[k].p, c->pool[k].p, pcs[k], s.prow[k], s.pcol[k], ks[k] / s.th[k], ks[k]};
+                fin_elems += (double)n2 * pcs[k] * s.gh * s.gw * (ks[k] / s.th[k] + 1);
+            } else {
+                pj[np++] = {feat[k], c->pool[k].p, pcs[k], hs[k], ws[k], ks[k]};
+                pool_elems += (double)n2 * pcs[k] * hs[k] * ws[k];
+            }
+        }
+        if (nf) {
+            rc = hk.run("pool finalize (fused partials)", fin_elems, 4.0 * fin_elems, [&](hipStream_t st) {
+                return pool_finalize_launch(fj, nf, n2, s.gh, s.gw, st);
+            });
+            if (rc != EEM_OK) return rc;
+        }
+        if (np) {
+            rc = hk.run("pool 32/16/8", pool_elems, 4.0 * pool_elems,
+                        [&](hipStream_t st) { return pool_launch(pj, np, n2, st); });
+            if (rc != EEM_OK) return rc;
+        }
+    }
     // ---- correlation (53 taps) and rconv into the decoders' input [cv | r] (EEMFlow.py:160-163)
     const size_t g = (size_t)s.gh * s.gw;
     const int pc[3] = {16, 32, 64};
@@ -348,6 +393,7 @@ extern "C" void eemflow_destroy(eemflow_ctx* c) {
     DevBuf* bufs[] = {&c->a1, &c->f11, &c->a2, &c->b2, &c->f12, &c->a3, &c->b3, &c->f13, &c->flowcat, &c->coarse};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     for (int k = 0; k < 3; ++k) {
+        if (c->ppart[k].p) (void)hipFree(c->ppart[k].p);
         DevBuf* kb[] = {&c->pool[k], &c->cat[k], &c->ta[k], &c->tb[k], &c->t64[k], &c->t32[k]};
         for (DevBuf* b : kb) if (b->p) (void)hipFree(b->p);
     }

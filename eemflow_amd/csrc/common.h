@@ -68,6 +68,8 @@ struct EncConvArgs {
     int hraw, wraw;        // raw extent for ENC_1_1 (== hin, win elsewhere)
     int pad_top, pad_left; // replicate-pad offsets for ENC_1_1 (0 elsewhere)
     int act;               // 1: LeakyReLU(0.1)
+    float* pool_partial;   // fast path only: per-block partial sums of the k x k stage pooling, or NULL
+    int pool_k;
 };
 int enc_conv_launch(int cin, int cout, int stride, const EncConvArgs& a, hipStream_t stream);
 // fast path (feature width % 4 == 0, layers 2..8)
@@ -75,6 +77,7 @@ bool enc2_supported(int cin, int cout, int stride, int win);
 size_t enc2_packed_floats(int cin, int cout);
 void enc2_pack_weights(const float* w, int cin, int cout, float* packed);
 int enc_conv2_launch(int cin, int cout, int stride, const EncConvArgs& a, hipStream_t stream);
+void enc2_tile(int cin, int cout, int* th, int* tw, int* poolk);
 
 // ----------------------------------------------------------------------------- tail kernels
 // Generic small-grid 3x3 (or 1x1) conv on MFMA 16x16x4, K split over the 4 waves of a block.
@@ -102,6 +105,10 @@ int tail_conv_launch(const TailConvLaunch& l, hipStream_t stream);
 // avg-pool k x k (stride k, floor) of [n][c][h][w] -> [n][c][h/k][w/k]
 struct PoolJob { const float* in; float* out; int c, h, w, k; };
 int pool_launch(const PoolJob* jobs, int njobs, int nimg, hipStream_t stream);
+// sums the per-block partial sums written by the fused conv epilogue: out[n][c][gy][gx] =
+// (1/k^2) * sum_{i < rows} partial[n][c][gy*rows + i][gx], partial is [n][c][prows][pcols]
+struct PoolFinJob { const float* partial; float* out; int c, prows, pcols, rows, k; };
+int pool_finalize_launch(const PoolFinJob* jobs, int njobs, int nimg, int gh, int gw, hipStream_t stream);
 
 // 9x9 local correlation, selected taps, scaled by 1/C; writes channels [0,ntaps) of out
 struct CorrJob { const float* f1; const float* f2; float* out; int c, out_ctotal; };

@@ -18,6 +18,22 @@ namespace {
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
+// Sum over groups of SW (4, 8 or 16) adjacent lanes with DPP row operations (VALU cross-lane moves - no
+// LDS traffic, unlike __shfl_xor's ds_bpermute): every lane of a group ends up holding the group sum.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int SW>
+__device__ __forceinline__ float lane_group_sum(float v) {
+    static_assert(SW == 4 || SW == 8 || SW == 16, "group width");
+    v = dpp_add<0xB1>(v);                       // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);                       // quad_perm [2,3,0,1]
+    if (SW >= 8) v = dpp_add<0x141>(v);         // row_half_mirror: lane i <-> 7-i
+    if (SW >= 16) v = dpp_add<0x140>(v);        // row_mirror: lane i <-> 15-i
+    return v;
+}
+
 template <int CIN, int COUT, int STRIDE, int TH, int TWT, int WAVES, int WM, int CK>
 struct Cfg2 {
     static constexpr bool M16 = (COUT == 16);
@@ -50,7 +66,7 @@ struct Cfg2 {
 template <bool M16> struct AccT2 { using type = f32x16; };
 template <> struct AccT2<true> { using type = f32x4; };
 
-template <int CIN, int COUT, int STRIDE, int TH, int TWT, int WAVES, int WM, int CK>
+template <int CIN, int COUT, int STRIDE, int TH, int TWT, int WAVES, int WM, int CK, int POOLK>
 __global__ __launch_bounds__(WAVES * 64) void enc_conv2_kernel(EncConvArgs a) {
     using C = Cfg2<CIN, COUT, STRIDE, TH, TWT, WAVES, WM, CK>;
     using acc_t = typename AccT2<C::M16>::type;
@@ -157,7 +173,55 @@ __global__ __launch_bounds__(WAVES * 64) void enc_conv2_kernel(EncConvArgs a) {
         if (C::NSTAGE == 2 && ch + 2 < C::NCHUNK) __builtin_amdgcn_s_barrier();   // stage `cur` is refilled next
     }
 
-    // ---- epilogue: LeakyReLU + NCHW store
+    // ---- epilogue: LeakyReLU, [pooling], NCHW store; with POOLK also the stage pooling (EEMFlow.py:144-154) as
+    // per-block partial sums: lanes reduce their pixels inside a window by shuffles, rows / tiles of the
+    // block are summed through LDS in a fixed order (bitwise repeatable, no atomics), and one value per
+    // (channel, window) and block row-group goes to a small buffer that pool_finalize sums.
+    constexpr int SW = (POOLK > 0 && POOLK < C::NPIX) ? POOLK : C::NPIX;   // pixels per reduction slot
+    constexpr int SLOTS = C::TW / SW;                                       // slots per block row
+    float* red = lds;                                                       // [TH][COUT][SLOTS]
+#pragma unroll
+    for (int u = 0; u < C::UPW; ++u)
+#pragma unroll
+        for (int m = 0; m < C::MTW; ++m)
+#pragma unroll
+            for (int r = 0; r < C::ACC; ++r) {
+                const float v = acc[u][m][r];
+                if (a.act) acc[u][m][r] = v > 0.f ? v : 0.1f * v;
+            }
+    if constexpr (POOLK > 0) {
+        // pooling goes first so that its barriers never wait for the feature-map stores below
+        constexpr int NWX = C::TW / POOLK, SPW = POOLK / SW;
+        static_assert(C::TW % POOLK == 0 && POOLK % TH == 0 && POOLK % SW == 0, "pool windows must tile the block");
+        static_assert(TH * COUT * SLOTS <= C::NSTAGE * C::STAGE, "reduction scratch fits the staging LDS");
+        __builtin_amdgcn_s_barrier();                                       // staged operands are dead now
+#pragma unroll
+        for (int u = 0; u < C::UPW; ++u) {
+            const int unit = wp * C::UPW + u;
+            const int row = unit / TWT, ct = unit % TWT;
+#pragma unroll
+            for (int m = 0; m < C::MTW; ++m)
+#pragma unroll
+                for (int r = 0; r < C::ACC; ++r) {
+                    const int mt = wm * C::MTW + m;
+                    const int co = C::M16 ? (g * 4 + r) : (mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g);
+                    // windows that leave the image are never read back
+                    const float sred = lane_group_sum<SW>(acc[u][m][r]);
+                    if ((j & (SW - 1)) == 0) red[(row * COUT + co) * SLOTS + ct * (C::NPIX / SW) + j / SW] = sred;
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int idx = tid; idx < COUT * NWX; idx += WAVES * 64) {
+            const int co = idx / NWX, wx = idx - co * NWX;
+            float s = 0.f;
+#pragma unroll
+            for (int row = 0; row < TH; ++row)
+#pragma unroll
+                for (int q = 0; q < SPW; ++q) s += red[(row * COUT + co) * SLOTS + wx * SPW + q];
+            a.pool_partial[(((size_t)n * COUT + co) * gridDim.y + blockIdx.y) * (gridDim.x * NWX) + blockIdx.x * NWX + wx] = s;
+        }
+    }
     float* dst = a.out + (size_t)n * COUT * a.hout * a.wout;
 #pragma unroll
     for (int u = 0; u < C::UPW; ++u) {
@@ -172,20 +236,26 @@ __global__ __launch_bounds__(WAVES * 64) void enc_conv2_kernel(EncConvArgs a) {
                 for (int r = 0; r < C::ACC; ++r) {
                     const int mt = wm * C::MTW + m;
                     const int co = C::M16 ? (g * 4 + r) : (mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g);
-                    float v = acc[u][m][r];
-                    if (a.act) v = v > 0.f ? v : 0.1f * v;
-                    dst[((size_t)co * a.hout + oy) * a.wout + ox] = v;
+                    dst[((size_t)co * a.hout + oy) * a.wout + ox] = acc[u][m][r];
                 }
         }
     }
 }
 
-template <int CIN, int COUT, int STRIDE, int TH, int TWT, int WAVES, int WM, int CK>
+template <int CIN, int COUT, int STRIDE, int TH, int TWT, int WAVES, int WM, int CK, int POOLK>
 int launch2(const EncConvArgs& a, hipStream_t stream) {
     using C = Cfg2<CIN, COUT, STRIDE, TH, TWT, WAVES, WM, CK>;
     dim3 grid(ceil_div(a.wout, C::TW), ceil_div(a.hout, TH), a.nimg);
-    hipLaunchKernelGGL((enc_conv2_kernel<CIN, COUT, STRIDE, TH, TWT, WAVES, WM, CK>), grid, dim3(WAVES * 64), 0,
-                       stream, a);
+    if (POOLK > 0 && a.pool_partial != nullptr && a.pool_k == POOLK)
+        hipLaunchKernelGGL((enc_conv2_kernel<CIN, COUT, STRIDE, TH, TWT, WAVES, WM, CK, POOLK>), grid, dim3(WAVES * 64),
+                           0, stream, a);
+    else if (a.pool_partial == nullptr)
+        hipLaunchKernelGGL((enc_conv2_kernel<CIN, COUT, STRIDE, TH, TWT, WAVES, WM, CK, 0>), grid, dim3(WAVES * 64), 0,
+                           stream, a);
+    else {
+        eem_set_error("enc_conv2: fused pooling with k=%d is not built for this layer", a.pool_k);
+        return EEM_ERR_ARG;
+    }
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }
@@ -222,13 +292,22 @@ void enc2_pack_weights(const float* w, int cin, int cout, float* packed) {
                 }
 }
 
+// Block tile (rows, cols) of the fast path and the pooling window it can fuse (0 = none), per layer.
+void enc2_tile(int cin, int cout, int* th, int* tw, int* poolk) {
+    if (cin == 16 && cout == 16) { *th = 8; *tw = 64; *poolk = 32; }
+    else if (cin == 16 && cout == 32) { *th = 4; *tw = 32; *poolk = 0; }
+    else if (cin == 32 && cout == 32) { *th = 4; *tw = 64; *poolk = 16; }
+    else if (cin == 32 && cout == 64) { *th = 4; *tw = 32; *poolk = 0; }
+    else { *th = 4; *tw = 32; *poolk = 8; }
+}
+
 int enc_conv2_launch(int cin, int cout, int stride, const EncConvArgs& a, hipStream_t stream) {
-    //                                            CIN COUT S TH TWT WAVES WM CK
-    if (cin == 16 && cout == 16) return launch2<16, 16, 1, 8, 4, 4, 1, 16>(a, stream);
-    if (cin == 16 && cout == 32) return launch2<16, 32, 2, 4, 1, 4, 1, 16>(a, stream);
-    if (cin == 32 && cout == 32) return launch2<32, 32, 1, 4, 2, 8, 1, 16>(a, stream);
-    if (cin == 32 && cout == 64) return launch2<32, 64, 2, 4, 1, 8, 2, 8>(a, stream);
-    if (cin == 64 && cout == 64) return launch2<64, 64, 1, 4, 1, 8, 2, 8>(a, stream);
+    //                                            CIN COUT S TH TWT WAVES WM CK POOLK
+    if (cin == 16 && cout == 16) return launch2<16, 16, 1, 8, 4, 4, 1, 16, 32>(a, stream);
+    if (cin == 16 && cout == 32) return launch2<16, 32, 2, 4, 1, 4, 1, 16, 0>(a, stream);
+    if (cin == 32 && cout == 32) return launch2<32, 32, 1, 4, 2, 8, 1, 16, 16>(a, stream);
+    if (cin == 32 && cout == 64) return launch2<32, 64, 2, 4, 1, 8, 2, 8, 0>(a, stream);
+    if (cin == 64 && cout == 64) return launch2<64, 64, 1, 4, 1, 8, 2, 8, 8>(a, stream);
     eem_set_error("enc_conv2_launch: unsupported layer cin=%d cout=%d stride=%d", cin, cout, stride);
     return EEM_ERR_ARG;
 }

@@ -39,6 +39,29 @@ __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
     if (lane == 0) jb.out[((size_t)o * oh + oy) * ow + ox] = s / (float)kk;
 }
 
+struct PoolFinArgs {
+    PoolFinJob job[3];
+    int njobs, nimg, gh, gw;
+};
+
+__global__ __launch_bounds__(256) void pool_finalize_kernel(PoolFinArgs a) {
+    int idx = blockIdx.x * 256 + threadIdx.x;
+    const int g = a.gh * a.gw;
+    for (int ji = 0; ji < a.njobs; ++ji) {
+        const PoolFinJob jb = a.job[ji];
+        const int total = a.nimg * jb.c * g;
+        if (idx < total) {
+            const int gx = idx % a.gw, gy = (idx / a.gw) % a.gh, nc = idx / g;
+            const float* src = jb.partial + ((size_t)nc * jb.prows + (size_t)gy * jb.rows) * jb.pcols + gx;
+            float s = 0.f;
+            for (int i = 0; i < jb.rows; ++i) s += src[(size_t)i * jb.pcols];
+            jb.out[idx] = s / (float)(jb.k * jb.k);
+            return;
+        }
+        idx -= total;
+    }
+}
+
 // ------------------------------------------------------------------------------- local correlation
 struct CorrArgs {
     CorrJob job[3];
@@ -191,6 +214,18 @@ int pool_launch(const PoolJob* jobs, int njobs, int nimg, hipStream_t stream) {
     for (int i = njobs; i < 4; ++i) a.first_wave[i] = total;
     if (total == 0) return EEM_OK;
     hipLaunchKernelGGL(pool_kernel, dim3(ceil_div(total, 4)), dim3(256), 0, stream, a);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int pool_finalize_launch(const PoolFinJob* jobs, int njobs, int nimg, int gh, int gw, hipStream_t stream) {
+    EEM_REQUIRE(njobs >= 1 && njobs <= 3, "pool_finalize_launch: njobs=%d", njobs);
+    PoolFinArgs a;
+    a.njobs = njobs; a.nimg = nimg; a.gh = gh; a.gw = gw;
+    int total = 0;
+    for (int i = 0; i < njobs; ++i) { a.job[i] = jobs[i]; total += nimg * jobs[i].c * gh * gw; }
+    if (total == 0) return EEM_OK;
+    hipLaunchKernelGGL(pool_finalize_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, a);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

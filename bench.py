@@ -39,7 +39,7 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
     p.add_argument("--kernel-reps", type=int, default=20)
     p.add_argument("--no-graph", action="store_true")
-    p.add_argument("--streams", type=int, default=1,
+    p.add_argument("--streams", type=int, default=3,
                    help="frames in flight per GPU: independent contexts on separate HIP streams, steps alternate")
     return p.parse_args()
 

@@ -265,7 +265,7 @@ int launch2(const EncConvArgs& a, hipStream_t stream) {
 // ------------------------------------------------------------------------------- host side
 // Weight layout of the fast path: [chunk][cout tile][k-step/4][lane][4], k-step s of a chunk = tap-major
 // (t = s / CG), then channel group (cg = s % CG); lane supplies channel cg*KPS + lane/NPIX.
-static int enc2_ck(int cin, int cout) { return cout == 64 ? 8 : 16; }
+static int enc2_ck(int cin, int cout);
 
 bool enc2_supported(int cin, int cout, int stride, int win) {
     if ((win & 3) != 0 || cin < 16) return false;
@@ -292,22 +292,64 @@ void enc2_pack_weights(const float* w, int cin, int cout, float* packed) {
                 }
 }
 
+// ---- variant table.  Each layer shape has a few tilings; index 0 is the production choice, the others are
+// kept for tuning on hardware (EEM_V<cin>_<cout>=<index> in the environment selects one - a tuning knob,
+// read once).
+struct Variant {
+    int th, tw, poolk, ck;
+    int (*launch)(const EncConvArgs&, hipStream_t);
+};
+
+//                      CIN COUT S TH TWT WAVES WM CK POOLK
+#define V(CIN, COUT, S, TH, TWT, WAVES, WM, CK, POOLK) \
+    Variant{TH, TWT * (COUT == 16 ? 16 : 32), POOLK, CK, &launch2<CIN, COUT, S, TH, TWT, WAVES, WM, CK, POOLK>}
+
+// (measured at 1280x720 b1, profiles/r01_variant_sweep.txt: index 0 is the fastest of each family)
+static const Variant kV16_16[] = {V(16, 16, 1, 4, 4, 8, 1, 16, 32), V(16, 16, 1, 4, 4, 4, 1, 16, 32),
+                                  V(16, 16, 1, 8, 4, 4, 1, 16, 32), V(16, 16, 1, 8, 4, 8, 1, 16, 32)};
+static const Variant kV16_32[] = {V(16, 32, 2, 4, 1, 4, 1, 8, 0), V(16, 32, 2, 2, 1, 2, 1, 16, 0),
+                                  V(16, 32, 2, 4, 1, 4, 1, 16, 0), V(16, 32, 2, 8, 1, 8, 1, 8, 0)};
+static const Variant kV32_32[] = {V(32, 32, 1, 4, 2, 8, 1, 8, 16), V(32, 32, 1, 4, 2, 8, 1, 16, 16),
+                                  V(32, 32, 1, 4, 1, 4, 1, 8, 16), V(32, 32, 1, 2, 2, 4, 1, 8, 16)};
+static const Variant kV32_64[] = {V(32, 64, 2, 4, 1, 8, 2, 8, 0), V(32, 64, 2, 2, 1, 4, 2, 8, 0),
+                                  V(32, 64, 2, 4, 1, 4, 1, 8, 0)};
+static const Variant kV64_64[] = {V(64, 64, 1, 4, 1, 8, 2, 8, 8), V(64, 64, 1, 2, 1, 4, 2, 8, 8),
+                                  V(64, 64, 1, 4, 1, 8, 2, 16, 8), V(64, 64, 1, 4, 1, 4, 1, 8, 8)};
+#undef V
+
+static const Variant* pick_variant(int cin, int cout) {
+    const Variant* tab = nullptr;
+    int n = 0;
+    if (cin == 16 && cout == 16) { tab = kV16_16; n = sizeof(kV16_16) / sizeof(Variant); }
+    else if (cin == 16 && cout == 32) { tab = kV16_32; n = sizeof(kV16_32) / sizeof(Variant); }
+    else if (cin == 32 && cout == 32) { tab = kV32_32; n = sizeof(kV32_32) / sizeof(Variant); }
+    else if (cin == 32 && cout == 64) { tab = kV32_64; n = sizeof(kV32_64) / sizeof(Variant); }
+    else if (cin == 64 && cout == 64) { tab = kV64_64; n = sizeof(kV64_64) / sizeof(Variant); }
+    if (!tab) return nullptr;
+    char name[32];
+    snprintf(name, sizeof(name), "EEM_V%d_%d", cin, cout);
+    const char* e = getenv(name);
+    int idx = e ? atoi(e) : 0;
+    if (idx < 0 || idx >= n) idx = 0;
+    return tab + idx;
+}
+
+static int enc2_ck(int cin, int cout) {
+    const Variant* v = pick_variant(cin, cout);
+    return v ? v->ck : 16;
+}
+
 // Block tile (rows, cols) of the fast path and the pooling window it can fuse (0 = none), per layer.
 void enc2_tile(int cin, int cout, int* th, int* tw, int* poolk) {
-    if (cin == 16 && cout == 16) { *th = 8; *tw = 64; *poolk = 32; }
-    else if (cin == 16 && cout == 32) { *th = 4; *tw = 32; *poolk = 0; }
-    else if (cin == 32 && cout == 32) { *th = 4; *tw = 64; *poolk = 16; }
-    else if (cin == 32 && cout == 64) { *th = 4; *tw = 32; *poolk = 0; }
-    else { *th = 4; *tw = 32; *poolk = 8; }
+    const Variant* v = pick_variant(cin, cout);
+    *th = v ? v->th : 4; *tw = v ? v->tw : 32; *poolk = v ? v->poolk : 0;
 }
 
 int enc_conv2_launch(int cin, int cout, int stride, const EncConvArgs& a, hipStream_t stream) {
-    //                                            CIN COUT S TH TWT WAVES WM CK POOLK
-    if (cin == 16 && cout == 16) return launch2<16, 16, 1, 8, 4, 4, 1, 16, 32>(a, stream);
-    if (cin == 16 && cout == 32) return launch2<16, 32, 2, 4, 1, 4, 1, 16, 0>(a, stream);
-    if (cin == 32 && cout == 32) return launch2<32, 32, 1, 4, 2, 8, 1, 16, 16>(a, stream);
-    if (cin == 32 && cout == 64) return launch2<32, 64, 2, 4, 1, 8, 2, 8, 0>(a, stream);
-    if (cin == 64 && cout == 64) return launch2<64, 64, 1, 4, 1, 8, 2, 8, 8>(a, stream);
-    eem_set_error("enc_conv2_launch: unsupported layer cin=%d cout=%d stride=%d", cin, cout, stride);
-    return EEM_ERR_ARG;
+    const Variant* v = pick_variant(cin, cout);
+    if (!v) {
+        eem_set_error("enc_conv2_launch: unsupported layer cin=%d cout=%d stride=%d", cin, cout, stride);
+        return EEM_ERR_ARG;
+    }
+    return v->launch(a, stream);
 }

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/pmc_traffic.json (read by bench.py).
+
+HBM bytes per launch = FETCH_SIZE(KB) * 1024 * 2 + WRITE_SIZE(KB) * 1024: on gfx950 FETCH_SIZE reports half
+of the bytes of a wide (16 B/lane) coalesced read (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact
+for 16-B-per-lane stores... our stores are dword-per-lane 128-B segments, counted as reported.
+Usage: python tools/pmc_traffic.py <dir with FETCH_SIZE/ and WRITE_SIZE/ subdirs> <out.json>
+"""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+ENC_NAMES = {("5", "16"): ["enc.pconv1_1 5->16 s2 +pad"], ("16", "16"): ["enc.pconv1_2 16->16"],
+             ("16", "32"): ["enc.pconv2_1 16->32 s2"], ("32", "32"): ["enc.pconv2_2 32->32", "enc.pconv2_3 32->32"],
+             ("32", "64"): ["enc.pconv3_1 32->64 s2"], ("64", "64"): ["enc.pconv3_2 64->64", "enc.pconv3_3 64->64"]}
+
+
+def load(d, counter):
+    f = glob.glob(f"{d}/{counter}/**/*_counter_collection.csv", recursive=True)[0]
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        m = re.search(r"enc_conv2?_kernel<(\d+), (\d+),", r["Kernel_Name"])
+        if m:
+            agg[(m.group(1), m.group(2))].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+
+
+def main():
+    d, out = sys.argv[1], sys.argv[2]
+    fetch, write = load(d, "FETCH_SIZE"), load(d, "WRITE_SIZE")
+    res = {}
+    for key, names in ENC_NAMES.items():
+        if key in fetch and key in write:
+            hbm = fetch[key] * 1024 * 2 + write[key] * 1024
+            for n in names:
+                res[n] = {"hbm_bytes": round(hbm), "fetch_size_kb_raw": round(fetch[key], 1),
+                          "write_size_kb_raw": round(write[key], 1), "fetch_correction": 2.0}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -34,6 +34,15 @@ void eem_set_error(const char* fmt, ...);
 
 __host__ __device__ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// XCD-aware block remap: the dispatcher deals consecutive block ids round-robin over the 8 XCDs (each with
+// its own L2), so id b and b+8 share an L2.  Giving XCD x the contiguous range [x*cpx, (x+1)*cpx) of
+// logical tiles makes spatially adjacent tiles (which share halo rows/columns) hit the same L2.  Placement
+// is a speed matter only; the grid is padded to a multiple of 8 and surplus blocks exit.
+__device__ static inline unsigned xcd_logical_block(unsigned bid, unsigned nblocks_padded) {
+    const unsigned cpx = nblocks_padded >> 3;
+    return (bid & 7u) * cpx + (bid >> 3);
+}
+
 // ----------------------------------------------------------------------------- encoder conv
 // Identifies one of the eight encoder layers (EEMFlow.py:75-82).
 enum EncLayer { ENC_1_1 = 0, ENC_1_2, ENC_2_1, ENC_2_2, ENC_2_3, ENC_3_1, ENC_3_2, ENC_3_3, ENC_NUM };
@@ -68,6 +77,7 @@ struct EncConvArgs {
     int hraw, wraw;        // raw extent for ENC_1_1 (== hin, win elsewhere)
     int pad_top, pad_left; // replicate-pad offsets for ENC_1_1 (0 elsewhere)
     int act;               // 1: LeakyReLU(0.1)
+    int tiles_x, tiles_y;  // filled by the launcher: block tiles per image (blocks are remapped XCD-aware)
     float* pool_partial;   // fast path only: per-block partial sums of the k x k stage pooling, or NULL
     int pool_k;
 };

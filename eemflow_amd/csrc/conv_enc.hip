@@ -52,9 +52,12 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(EncConvArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int n = blockIdx.z;
-    const int oy0 = blockIdx.y * TH;
-    const int ox0 = blockIdx.x * C::TW;
+    const unsigned lid = xcd_logical_block(blockIdx.x, gridDim.x);
+    if (lid >= (unsigned)(a.tiles_x * a.tiles_y * a.nimg)) return;
+    const int bx = lid % a.tiles_x, by = (lid / a.tiles_x) % a.tiles_y;
+    const int n = lid / (a.tiles_x * a.tiles_y);
+    const int oy0 = by * TH;
+    const int ox0 = bx * C::TW;
 
     // ---- stage the input tile (zero outside the conv input; replicate inside the pad band)
     {
@@ -191,9 +194,12 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(EncConvArgs a) {
 }
 
 template <int CIN, int COUT, int STRIDE, int TH, int TWT, bool PADIN>
-int launch(const EncConvArgs& a, hipStream_t stream) {
+int launch(const EncConvArgs& a0, hipStream_t stream) {
     using C = Cfg<CIN, COUT, STRIDE, TH, TWT>;
-    dim3 grid(ceil_div(a.wout, C::TW), ceil_div(a.hout, TH), a.nimg);
+    EncConvArgs a = a0;
+    a.tiles_x = ceil_div(a.wout, C::TW);
+    a.tiles_y = ceil_div(a.hout, TH);
+    dim3 grid((unsigned)ceil_div(a.tiles_x * a.tiles_y * a.nimg, 8) * 8);
     hipLaunchKernelGGL((enc_conv_kernel<CIN, COUT, STRIDE, TH, TWT, PADIN>), grid, dim3(256), 0, stream, a);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;

@@ -75,9 +75,12 @@ __global__ __launch_bounds__(WAVES * 64) void enc_conv2_kernel(EncConvArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int n = blockIdx.z;
-    const int oy0 = blockIdx.y * TH;
-    const int ox0 = blockIdx.x * C::TW;
+    const unsigned lid = xcd_logical_block(blockIdx.x, gridDim.x);
+    if (lid >= (unsigned)(a.tiles_x * a.tiles_y * a.nimg)) return;
+    const int bx = lid % a.tiles_x, by = (lid / a.tiles_x) % a.tiles_y;
+    const int n = lid / (a.tiles_x * a.tiles_y);
+    const int oy0 = by * TH;
+    const int ox0 = bx * C::TW;
     const int gy0 = oy0 * STRIDE - 1;
     const int gxa = ox0 * STRIDE - 4;                       // 16-byte aligned start column
     const float* src = a.in0 + (size_t)n * CIN * a.hin * a.win;
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(WAVES * 64) void enc_conv2_kernel(EncConvArgs a) {
             for (int row = 0; row < TH; ++row)
 #pragma unroll
                 for (int q = 0; q < SPW; ++q) s += red[(row * COUT + co) * SLOTS + wx * SPW + q];
-            a.pool_partial[(((size_t)n * COUT + co) * gridDim.y + blockIdx.y) * (gridDim.x * NWX) + blockIdx.x * NWX + wx] = s;
+            a.pool_partial[(((size_t)n * COUT + co) * a.tiles_y + by) * (a.tiles_x * NWX) + bx * NWX + wx] = s;
         }
     }
     float* dst = a.out + (size_t)n * COUT * a.hout * a.wout;
@@ -243,9 +246,12 @@ __global__ __launch_bounds__(WAVES * 64) void enc_conv2_kernel(EncConvArgs a) {
 }
 
 template <int CIN, int COUT, int STRIDE, int TH, int TWT, int WAVES, int WM, int CK, int POOLK>
-int launch2(const EncConvArgs& a, hipStream_t stream) {
+int launch2(const EncConvArgs& a0, hipStream_t stream) {
     using C = Cfg2<CIN, COUT, STRIDE, TH, TWT, WAVES, WM, CK>;
-    dim3 grid(ceil_div(a.wout, C::TW), ceil_div(a.hout, TH), a.nimg);
+    EncConvArgs a = a0;
+    a.tiles_x = ceil_div(a.wout, C::TW);
+    a.tiles_y = ceil_div(a.hout, TH);
+    dim3 grid((unsigned)ceil_div(a.tiles_x * a.tiles_y * a.nimg, 8) * 8);
     if (POOLK > 0 && a.pool_partial != nullptr && a.pool_k == POOLK)
         hipLaunchKernelGGL((enc_conv2_kernel<CIN, COUT, STRIDE, TH, TWT, WAVES, WM, CK, POOLK>), grid, dim3(WAVES * 64),
                            0, stream, a);

@@ -276,6 +276,7 @@ int run_forward(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2
         a.wpk = c->arena + c->enc_w[sp.layer];
         a.wpk2 = c->enc_has2[sp.layer] ? c->arena + c->enc_w2[sp.layer] : nullptr;
         a.zero_page = c->zero_page;
+        a.trash = c->zero_page + 64;
         a.bias = c->arena + c->enc_b[sp.layer];
         a.out = sp.out;
         a.nimg = n2; a.nimg0 = sp.layer == ENC_1_1 ? s.batch : n2;
@@ -375,8 +376,8 @@ extern "C" int eemflow_create(int device, eemflow_ctx** out) {
     hipError_t e = hipMalloc(&c->taps, sizeof(kTaps53));
     if (e == hipSuccess) e = hipMemcpy(c->taps, kTaps53, sizeof(kTaps53), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&c->vox_scratch, voxel_scratch_bytes());
-    if (e == hipSuccess) e = hipMalloc(&c->zero_page, 256);
-    if (e == hipSuccess) e = hipMemset(c->zero_page, 0, 256);
+    if (e == hipSuccess) e = hipMalloc(&c->zero_page, 1024);
+    if (e == hipSuccess) e = hipMemset(c->zero_page, 0, 1024);
     if (e != hipSuccess) {
         eem_set_error("eemflow_create: %s", hipGetErrorString(e));
         delete c;

@@ -68,6 +68,7 @@ struct EncConvArgs {
     const float* wpk;      // packed weights, generic kernel (conv_enc.hip)
     const float* wpk2;     // packed weights, LDS-DMA fast path (conv_enc2.hip); may be NULL
     const float* zero_page;// >= 16 zero bytes in device memory (source of out-of-image pieces)
+    float* trash;          // >= 256 writable bytes: sink for the stores of out-of-image lanes
     const float* bias;
     float* out;
     int nimg;              // images in this launch (2B)

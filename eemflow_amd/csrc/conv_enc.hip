@@ -47,7 +47,7 @@ template <int CIN, int COUT, int STRIDE, int TH, int TWT, bool PADIN>
 __global__ __launch_bounds__(256) void enc_conv_kernel(EncConvArgs a) {
     using C = Cfg<CIN, COUT, STRIDE, TH, TWT>;
     using acc_t = typename AccT<C::M16>::type;
-    __shared__ float tile[C::TILE];
+    __shared__ float tile[(C::TILE + 63) / 64 * 64];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -59,7 +59,9 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(EncConvArgs a) {
     const int oy0 = by * TH;
     const int ox0 = bx * C::TW;
 
-    // ---- stage the input tile (zero outside the conv input; replicate inside the pad band)
+    // ---- stage the input tile (zero outside the conv input; replicate inside the pad band) with 4-byte
+    // LDS-DMA copies: each lane's source address is clamped (replicate) or the zero page (conv padding),
+    // all of a wave's copies are in flight at once and no VGPR holds the data.
     {
         const float* src;
         if (PADIN)
@@ -69,28 +71,28 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(EncConvArgs a) {
             src = a.in0 + (size_t)n * CIN * a.hin * a.win;
         const int gy0 = oy0 * STRIDE - 1;
         const int gx0 = ox0 * STRIDE - 1;
-#pragma unroll 8
-        for (int e = tid; e < C::TILE; e += 256) {
+#pragma unroll 4
+        for (int e0 = wave * 64; e0 < C::TILE; e0 += 256) {
+            const int e = e0 + lane;
             const int c = e / C::PLANE;
             const int rem = e - c * C::PLANE;
             const int ry = rem / C::IN_COLS;
             const int rx = rem - ry * C::IN_COLS;
             const int gy = gy0 + ry, gx = gx0 + rx;
-            // branch-free: always load from a clamped (valid) address, then select
-            const bool ok = gy >= 0 && gy < a.hin && gx >= 0 && gx < a.win;
-            float v;
+            const bool ok = e < C::TILE && gy >= 0 && gy < a.hin && gx >= 0 && gx < a.win;
+            const float* g;
             if (PADIN) {
                 const int sy = min(max(gy - a.pad_top, 0), a.hraw - 1);
                 const int sx = min(max(gx - a.pad_left, 0), a.wraw - 1);
-                v = src[((size_t)c * a.hraw + sy) * a.wraw + sx];
+                g = src + ((size_t)c * a.hraw + sy) * a.wraw + sx;
             } else {
-                const int sy = min(max(gy, 0), a.hin - 1);
-                const int sx = min(max(gx, 0), a.win - 1);
-                v = src[((size_t)c * a.hin + sy) * a.win + sx];
+                g = src + ((size_t)c * a.hin + gy) * a.win + gx;
             }
-            v = ok ? v : 0.f;
-            tile[e] = v;
+            g = ok ? g : a.zero_page;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(tile + e0), 4, 0, 0);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
 
@@ -248,7 +250,11 @@ void enc_pack_weights(const float* w, int cin, int cout, float* packed) {
 }
 
 int enc_conv_launch(int cin, int cout, int stride, const EncConvArgs& a, hipStream_t stream) {
-    if (a.wpk2 && a.zero_page && enc2_supported(cin, cout, stride, a.win)) return enc_conv2_launch(cin, cout, stride, a, stream);
+    if (!a.zero_page) {
+        eem_set_error("enc_conv_launch: zero_page is NULL");
+        return EEM_ERR_ARG;
+    }
+    if (a.wpk2 && enc2_supported(cin, cout, stride, a.win)) return enc_conv2_launch(cin, cout, stride, a, stream);
     //                                   CIN COUT S  TH TWT PADIN
     if (cin == 5 && cout == 16 && stride == 2) return launch<5, 16, 2, 8, 4, true>(a, stream);
     if (cin == 16 && cout == 16 && stride == 1) return launch<16, 16, 1, 8, 4, false>(a, stream);

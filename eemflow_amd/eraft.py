@@ -1,0 +1,223 @@
+"""E-RAFT on MI355X behind the reference's nn.Module interfaces.
+
+Mirrors model/eraft.py (ERAFT), model/extractor.py (BasicEncoder, ResidualBlock), model/update.py
+(BasicUpdateBlock and parts) and model/corr.py (CorrBlock): same constructors, forward signatures and
+state_dict keys (179 tensors).  The modules only hold parameters; all arithmetic happens in
+libeemflow_hip.so (include/eemflow_hip.h, eraft_* entry points).  Inference only; CUDA tensors only.
+"""
+import ctypes
+from argparse import Namespace
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .padder import InputPadder
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, in_planes, planes, norm_fn='group', stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_planes, planes, kernel_size=3, padding=1, stride=stride)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, padding=1)
+        self.relu = nn.ReLU(inplace=True)
+        if norm_fn == 'batch':
+            mk = lambda: nn.BatchNorm2d(planes)
+        elif norm_fn == 'instance':
+            mk = lambda: nn.InstanceNorm2d(planes)
+        else:
+            raise ValueError("only norm_fn 'batch' and 'instance' are built (the two E-RAFT uses, eraft.py:57-60)")
+        self.norm1, self.norm2 = mk(), mk()
+        if not stride == 1:
+            self.norm3 = mk()
+        if stride == 1:
+            self.downsample = None
+        else:
+            self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride), self.norm3)
+        self.stride = stride
+
+
+class BasicEncoder(nn.Module):
+    def __init__(self, output_dim=128, norm_fn='batch', dropout=0.0, n_first_channels=1):
+        super().__init__()
+        self.norm_fn = norm_fn
+        if norm_fn == 'batch':
+            self.norm1 = nn.BatchNorm2d(64)
+        elif norm_fn == 'instance':
+            self.norm1 = nn.InstanceNorm2d(64)
+        else:
+            raise ValueError("only norm_fn 'batch' and 'instance' are built")
+        self.conv1 = nn.Conv2d(n_first_channels, 64, kernel_size=7, stride=2, padding=3)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.in_planes = 64
+        self.layer1 = self._make_layer(64, stride=1)
+        self.layer2 = self._make_layer(96, stride=2)
+        self.layer3 = self._make_layer(128, stride=2)
+        self.conv2 = nn.Conv2d(128, output_dim, kernel_size=1)
+        self.dropout = None
+        if dropout > 0:
+            raise ValueError("dropout > 0 is not built (E-RAFT uses 0, eraft.py:57-60)")
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, (nn.BatchNorm2d, nn.InstanceNorm2d, nn.GroupNorm)):
+                if m.weight is not None:
+                    nn.init.constant_(m.weight, 1)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, dim, stride=1):
+        layers = (ResidualBlock(self.in_planes, dim, self.norm_fn, stride=stride),
+                  ResidualBlock(dim, dim, self.norm_fn, stride=1))
+        self.in_planes = dim
+        return nn.Sequential(*layers)
+
+
+class FlowHead(nn.Module):
+    def __init__(self, input_dim=128, hidden_dim=256):
+        super().__init__()
+        self.conv1 = nn.Conv2d(input_dim, hidden_dim, 3, padding=1)
+        self.conv2 = nn.Conv2d(hidden_dim, 2, 3, padding=1)
+        self.relu = nn.ReLU(inplace=True)
+
+
+class SepConvGRU(nn.Module):
+    def __init__(self, hidden_dim=128, input_dim=192 + 128):
+        super().__init__()
+        self.convz1 = nn.Conv2d(hidden_dim + input_dim, hidden_dim, (1, 5), padding=(0, 2))
+        self.convr1 = nn.Conv2d(hidden_dim + input_dim, hidden_dim, (1, 5), padding=(0, 2))
+        self.convq1 = nn.Conv2d(hidden_dim + input_dim, hidden_dim, (1, 5), padding=(0, 2))
+        self.convz2 = nn.Conv2d(hidden_dim + input_dim, hidden_dim, (5, 1), padding=(2, 0))
+        self.convr2 = nn.Conv2d(hidden_dim + input_dim, hidden_dim, (5, 1), padding=(2, 0))
+        self.convq2 = nn.Conv2d(hidden_dim + input_dim, hidden_dim, (5, 1), padding=(2, 0))
+
+
+class BasicMotionEncoder(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        cor_planes = args.corr_levels * (2 * args.corr_radius + 1) ** 2
+        self.convc1 = nn.Conv2d(cor_planes, 256, 1, padding=0)
+        self.convc2 = nn.Conv2d(256, 192, 3, padding=1)
+        self.convf1 = nn.Conv2d(2, 128, 7, padding=3)
+        self.convf2 = nn.Conv2d(128, 64, 3, padding=1)
+        self.conv = nn.Conv2d(64 + 192, 128 - 2, 3, padding=1)
+
+
+class BasicUpdateBlock(nn.Module):
+    def __init__(self, args, hidden_dim=128, input_dim=128):
+        super().__init__()
+        self.args = args
+        self.encoder = BasicMotionEncoder(args)
+        self.gru = SepConvGRU(hidden_dim=hidden_dim, input_dim=128 + hidden_dim)
+        self.flow_head = FlowHead(hidden_dim, hidden_dim=256)
+        self.mask = nn.Sequential(
+            nn.Conv2d(hidden_dim, hidden_dim * 2, 3, padding=1),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(hidden_dim * 2, 64 * 9, 1, padding=0))
+
+
+def get_args():
+    return Namespace(small=False, dropout=False, mixed_precision=False, clip=1.0)
+
+
+class ERAFT(nn.Module):
+    def __init__(self, config, n_first_channels=5):
+        super().__init__()
+        args = get_args()
+        self.args = args
+        self.hidden_dim = hdim = 128
+        self.context_dim = cdim = 128
+        args.corr_levels = 4
+        args.corr_radius = 4
+        self.n_first_channels = n_first_channels
+        self.fnet = BasicEncoder(output_dim=256, norm_fn='instance', dropout=0, n_first_channels=n_first_channels)
+        self.cnet = BasicEncoder(output_dim=hdim + cdim, norm_fn='batch', dropout=0, n_first_channels=n_first_channels)
+        self.update_block = BasicUpdateBlock(self.args, hidden_dim=hdim)
+        self._ctx = None
+        self._ctx_device = None
+        self._weights_version = None
+
+    def change_imagesize(self, img_size):
+        self.image_size = img_size
+        self.image_padder = InputPadder(img_size, mode='chairs')
+
+    def freeze_bn(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.eval()
+
+    # ------------------------------------------------------------------ HIP plumbing
+    def _flat_weights(self):
+        """All float tensors of the state_dict in registration order (num_batches_tracked skipped)."""
+        return torch.cat([v.detach().reshape(-1).to(torch.float32).cpu()
+                          for k, v in self.state_dict().items() if not k.endswith("num_batches_tracked")])
+
+    def _fingerprint(self):
+        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    def _context(self, device):
+        L = _lib.lib()
+        if self._ctx is None or self._ctx_device != device:
+            self._release()
+            handle = ctypes.c_void_p()
+            _lib.check(L.eraft_create(device.index if device.index is not None else torch.cuda.current_device(),
+                                      ctypes.byref(handle)))
+            self._ctx, self._ctx_device, self._weights_version = handle, device, None
+        fp = self._fingerprint()
+        if fp != self._weights_version:
+            flat = self._flat_weights().contiguous()
+            _lib.check(L.eraft_load_weights(self._ctx, flat.data_ptr(), flat.numel(), self.n_first_channels))
+            self._weights_version = fp
+        return self._ctx
+
+    def forward(self, events1, events2, iters=12, flow_init=None, upsample=True, normal=False):
+        if not (events1.is_cuda and events2.is_cuda):
+            raise _lib.EEMFlowHipError("ERAFT.forward: inputs must be CUDA (ROCm) tensors - there is no CPU path")
+        if self.training and torch.is_grad_enabled():
+            raise _lib.EEMFlowHipError("ERAFT.forward: inference only in this round (eval()/no_grad required; "
+                                       "train-mode BatchNorm batch statistics are not built)")
+        if self.training:
+            raise _lib.EEMFlowHipError("ERAFT.forward: call .eval() - cnet's BatchNorm uses running statistics here")
+        if not hasattr(self, "image_padder"):
+            raise AttributeError("call change_imagesize(img_size) before forward (as the reference requires)")
+        e1, e2 = events1.contiguous().float(), events2.contiguous().float()
+        if e1.shape != e2.shape or e1.dim() != 4 or e1.shape[1] != self.n_first_channels:
+            raise ValueError(f"expected two (B,{self.n_first_channels},H,W) tensors")
+        b, _, h, w = e1.shape
+        pad = self.image_padder._pad
+        hp, wp = h + pad[2] + pad[3], w + pad[0] + pad[1]
+        if hp % 8 or wp % 8:
+            raise ValueError(f"padded size {hp}x{wp} is not a multiple of 8: the reference's convex upsampling "
+                             "(eraft.py:83-94) cannot be unpadded consistently")
+        ctx = self._context(e1.device)
+        out = torch.empty(iters, b, 2, h, w, device=e1.device, dtype=torch.float32)
+        fi = None
+        if flow_init is not None:
+            fi = flow_init.contiguous().float()
+        padc = (ctypes.c_int * 4)(*pad)
+        with torch.cuda.device(e1.device):
+            _lib.check(_lib.lib().eraft_forward(ctx, e1.data_ptr(), e2.data_ptr(), b, h, w, padc, iters,
+                                                fi.data_ptr() if fi is not None else None, out.data_ptr(),
+                                                _lib.current_stream_ptr(e1.device)))
+        return (events1, events2), [out[i] for i in range(iters)]
+
+    def stage(self, name):
+        L = _lib.lib()
+        dims = (ctypes.c_int * 4)()
+        _lib.check(L.eraft_get_stage(self._ctx, name.encode(), None, 0, ctypes.byref(dims), None))
+        out = torch.empty(*list(dims), device=self._ctx_device, dtype=torch.float32)
+        with torch.cuda.device(self._ctx_device):
+            _lib.check(L.eraft_get_stage(self._ctx, name.encode(), out.data_ptr(), out.numel(), ctypes.byref(dims),
+                                         _lib.current_stream_ptr(self._ctx_device)))
+        return out
+
+    def _release(self):
+        if self._ctx is not None:
+            _lib.lib().eraft_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass

@@ -269,6 +269,85 @@ def gen_voxel(lu):
     save("voxel.npz", **cases)
 
 
+def ref_eraft(seed):
+    """Reference ERAFT loaded (strict) with the product's seeded weights (eemflow_amd/eraft_weights.py)."""
+    from model.eraft import ERAFT
+    from eemflow_amd.eraft import ERAFT as Mirror
+    from eemflow_amd.eraft_weights import seeded_from_shapes
+    shapes = {k: tuple(v.shape) for k, v in Mirror("", 5).state_dict().items()}
+    sd = seeded_from_shapes(shapes, seed)
+    net = ERAFT(config="", n_first_channels=5).eval()
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return net
+
+
+def gen_eraft_layout():
+    from model.eraft import ERAFT
+    sd = ERAFT(config="", n_first_channels=5).state_dict()
+    shapes = np.full((len(sd), 4), -1, dtype=np.int64)
+    for i, v in enumerate(sd.values()):
+        shapes[i, :v.dim()] = list(v.shape)
+    save("eraft_layout.npz", keys=np.array(list(sd.keys())), shapes=shapes,
+         nparams=np.int64(sum(v.numel() for k, v in sd.items() if "running" not in k and "num_batches" not in k)))
+
+
+def gen_eraft(tag, seed, batch, h, w, iters, keep):
+    net = ref_eraft(seed)
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(seed + 2000, batch, h, w))
+    net.change_imagesize((h, w))
+    arrays = dict(seed=np.int64(seed), input_seed=np.int64(seed + 2000), batch=np.int64(batch), hw=np.array([h, w]),
+                  iters=np.int64(iters))
+    with torch.no_grad():
+        (_, _), preds = net(e1, e2, iters=iters)
+        arrays["pad"] = np.array(net.image_padder._pad)
+        arrays["preds"] = torch.stack(preds).numpy()
+        if keep:
+            from model.corr import CorrBlock
+            from model.model_utils import coords_grid
+            im1, im2 = net.image_padder.pad(e1, e2)
+            fmap1, fmap2 = net.fnet([im1.contiguous(), im2.contiguous()])
+            cnet = net.cnet(im1.contiguous())
+            n0, inp = torch.split(cnet, [128, 128], dim=1)
+            n0, inp = torch.tanh(n0), torch.relu(inp)
+            cb = CorrBlock(fmap1.float(), fmap2.float(), radius=4)
+            n, _, hh, ww = fmap1.shape
+            c0 = coords_grid(n, hh, ww)
+            corr0 = cb(c0)
+            net1, mask1, delta1 = net.update_block(n0, inp, corr0, c0 - c0)
+            arrays.update(fmap1=fmap1.numpy(), fmap2=fmap2.numpy(), net0=n0.numpy(), inp=inp.numpy(), corr0=corr0.numpy(),
+                          net1=net1.numpy(), mask1=mask1.numpy(), delta1=delta1.numpy(),
+                          pyr1=cb.corr_pyramid[1].numpy(), pyr3=cb.corr_pyramid[3].numpy())
+    save(f"eraft_fwd_{tag}.npz", **arrays)
+
+
+def gen_eraft_lookup():
+    """CorrBlock on small random maps with fractional, negative and out-of-range coordinates (model/corr.py)."""
+    from model.corr import CorrBlock
+    rng = np.random.default_rng(31)
+    f1 = rng.standard_normal((2, 16, 9, 11), dtype=np.float32)
+    f2 = rng.standard_normal((2, 16, 9, 11), dtype=np.float32)
+    coords = rng.uniform(-6, 16, size=(2, 2, 9, 11)).astype(np.float32)
+    coords[0, :, 0, 0] = [3.0, 4.0]                        # exactly on a grid point
+    coords[0, :, 0, 1] = [10.0, 8.0]                       # exactly on the last column / row
+    with torch.no_grad():
+        cb = CorrBlock(torch.from_numpy(f1), torch.from_numpy(f2), radius=4)
+        out = cb(torch.from_numpy(coords))
+    save("eraft_lookup.npz", f1=f1, f2=f2, coords=coords, out=out.numpy(),
+         **{f"pyr{i}": p.numpy() for i, p in enumerate(cb.corr_pyramid)})
+
+
+def gen_eraft_upsample():
+    from model.eraft import ERAFT
+    rng = np.random.default_rng(41)
+    flow = rng.standard_normal((2, 2, 5, 7), dtype=np.float32) * 3
+    mask = rng.standard_normal((2, 576, 5, 7), dtype=np.float32)
+    net = ERAFT(config="", n_first_channels=5)
+    with torch.no_grad():
+        up = net.upsample_flow(torch.from_numpy(flow), torch.from_numpy(mask))
+    save("eraft_upsample.npz", flow=flow, mask=mask, up=up.numpy())
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(4)
@@ -281,6 +360,11 @@ def main():
     gen_eemflow(mod, "260x346", seed=2, batch=1, h=260, w=346, keep_stages=False)
     gen_eemflow(mod, "100x150", seed=4, batch=1, h=100, w=150, keep_stages=False)
     gen_voxel(lu)
+    gen_eraft_layout()
+    gen_eraft_lookup()
+    gen_eraft_upsample()
+    gen_eraft("96x128", seed=7, batch=1, h=96, w=128, iters=3, keep=True)
+    gen_eraft("100x150", seed=8, batch=2, h=100, w=150, iters=2, keep=False)
 
 
 if __name__ == "__main__":

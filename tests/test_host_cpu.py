@@ -96,3 +96,12 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libeemflow_hip.so")
     with pytest.raises(_lib.EEMFlowHipError, match="no CPU fallback"):
         _lib.lib()
+
+
+def test_eraft_state_dict_layout(golden):
+    from eemflow_amd.eraft import ERAFT
+    g = golden("eraft_layout.npz")
+    sd = ERAFT("", 5).state_dict()
+    assert list(sd.keys()) == g["keys"].tolist() and len(sd) == 179
+    assert [list(v.shape) for v in sd.values()] == [s[s >= 0].tolist() for s in g["shapes"]]
+    assert sum(v.numel() for k, v in sd.items() if "running" not in k and "num_batches" not in k) == int(g["nparams"])

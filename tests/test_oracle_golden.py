@@ -74,3 +74,47 @@ def test_voxelizer(golden, name):
     np.testing.assert_allclose(np.nan_to_num(grid), np.nan_to_num(ref), atol=1e-6, rtol=1e-6)
     if not norm:
         assert np.array_equal(grid, ref)                    # same accumulation order => same bits
+
+
+# ----------------------------------------------------------------------------- E-RAFT
+from oracle import eraft_oracle as R   # noqa: E402
+
+
+def eraft_sd(seed):
+    from eemflow_amd.eraft import ERAFT
+    from eemflow_amd.eraft_weights import seeded_from_shapes
+    shapes = {k: tuple(v.shape) for k, v in ERAFT("", 5).state_dict().items()}
+    return O.to_torch_sd(seeded_from_shapes(shapes, seed))
+
+
+def test_eraft_lookup_and_pyramid(golden):
+    g = golden("eraft_lookup.npz")
+    pyr = R.corr_pyramid(torch.from_numpy(g["f1"]), torch.from_numpy(g["f2"]))
+    for i, p in enumerate(pyr):
+        np.testing.assert_allclose(p.numpy(), g[f"pyr{i}"], atol=1e-6)
+    out = R.corr_lookup(pyr, torch.from_numpy(g["coords"]))
+    np.testing.assert_allclose(out.numpy(), g["out"], atol=1e-6)
+
+
+def test_eraft_convex_upsample(golden):
+    g = golden("eraft_upsample.npz")
+    up = R.convex_upsample(torch.from_numpy(g["flow"]), torch.from_numpy(g["mask"]))
+    np.testing.assert_allclose(up.numpy(), g["up"], atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["96x128", "100x150"])
+def test_eraft_forward(golden, tag):
+    g = golden(f"eraft_fwd_{tag}.npz")
+    h, w = g["hw"].tolist()
+    sd = eraft_sd(int(g["seed"]))
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(int(g["input_seed"]), int(g["batch"]), h, w))
+    with torch.no_grad():
+        preds, st = R.eraft_forward(sd, e1, e2, iters=int(g["iters"]), keep=True)
+    assert st["pad"] == g["pad"].tolist()
+    for k in ("fmap1", "fmap2", "net0", "inp", "corr0", "net1", "mask1", "delta1"):
+        if k in g.files:
+            np.testing.assert_allclose(st[k].numpy(), g[k], atol=2e-5, rtol=1e-5, err_msg=k)
+    if "pyr1" in g.files:
+        np.testing.assert_allclose(st["pyr"][1].numpy(), g["pyr1"], atol=1e-5)
+        np.testing.assert_allclose(st["pyr"][3].numpy(), g["pyr3"], atol=1e-5)
+    np.testing.assert_allclose(torch.stack(preds).numpy(), g["preds"], atol=1e-4, rtol=1e-5)

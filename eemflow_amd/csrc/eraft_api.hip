@@ -1,0 +1,491 @@
+// C ABI for the E-RAFT part of the path (declared in include/eemflow_hip.h): context, weight parsing with
+// eval-mode BatchNorm folding, packing, workspace and the forward schedule of model/eraft.py:97-159.
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/eemflow_hip.h"
+#include "eraft_kernels.h"
+#include "gconv.h"
+
+namespace {
+
+struct Buf {
+    float* p = nullptr;
+    size_t cap = 0;
+};
+
+int ensure(Buf& b, size_t floats) {
+    if (floats <= b.cap) return EEM_OK;
+    if (b.p) EEM_HIP_CHECK(hipFree(b.p));
+    b.p = nullptr; b.cap = 0;
+    EEM_HIP_CHECK(hipMalloc(&b.p, floats * sizeof(float)));
+    b.cap = floats;
+    return EEM_OK;
+}
+
+struct Layer {                    // one convolution, weights packed for gconv
+    size_t wpk = 0, scale = 0, shift = 0;
+    bool has_scale = false;
+    int cout = 0, kh = 1, kw = 1, stride = 1, ph = 0, pw = 0;
+    int cs[3] = {0, 0, 0}, nseg = 1;
+};
+
+struct Block {                    // ResidualBlock (model/extractor.py:7-57)
+    Layer conv1, conv2, down;
+    bool has_down = false;
+};
+
+struct Encoder {                  // BasicEncoder (model/extractor.py:119-190)
+    Layer conv1, conv2a, conv2b;  // conv2b: second half of the output conv (cnet: net | inp split)
+    Block blk[6];
+    bool batch_norm = false;
+};
+
+}  // namespace
+
+struct eraft_ctx {
+    int device = 0;
+    bool loaded = false;
+    int cin0 = 5;
+    float* arena = nullptr;
+    Encoder fnet, cnet;
+    Layer convc1, convc2, convf1, convf2, conv, gz[2], gr[2], gq[2], fh1, fh2, mk0, mk2;
+    // workspace
+    Buf padded, s[5], fmap, net[2], inp, pyr[4], c0, c1, corr, cor1, corflo, flo1, motion, z, rh, fhid, delta, mhid, mask;
+    Buf st_corr0, st_net1, st_mask1, st_delta1, zeros;
+    int B = 0, h8 = 0, w8 = 0, ph[4] = {0, 0, 0, 0}, pw[4] = {0, 0, 0, 0};
+    bool have_last = false;
+};
+
+namespace {
+
+struct Cursor {
+    const float* p;
+    const float* end;
+    const float* take(size_t n) { const float* r = p; p += n; return r; }
+};
+
+struct Packer {
+    std::vector<float> host;
+    size_t push(size_t n) { size_t off = host.size(); host.resize(off + ((n + 3) & ~(size_t)3), 0.f); return off; }
+};
+
+struct BN { const float *w, *b, *rm, *rv; };
+
+BN take_bn(Cursor& c, int ch) {
+    BN bn;
+    bn.w = c.take(ch); bn.b = c.take(ch); bn.rm = c.take(ch); bn.rv = c.take(ch);
+    return bn;
+}
+
+// conv [cout][cin][kh][kw] + bias, optional eval-mode BatchNorm folded into (scale, shift); `co0, con` select an
+// output-channel slice (cnet.conv2 is applied as two convs: tanh half and relu half)
+void make_layer(Packer& pk, Layer& L, const float* w, const float* bias, int cout_all, int co0, int con, const int* cs, int nseg,
+                int kh, int kw, int stride, int ph, int pw, const BN* bn) {
+    int cin = 0;
+    for (int s = 0; s < nseg; ++s) { cin += cs[s]; L.cs[s] = cs[s]; }
+    L.nseg = nseg; L.cout = con; L.kh = kh; L.kw = kw; L.stride = stride; L.ph = ph; L.pw = pw;
+    const float* wsl = w + (size_t)co0 * cin * kh * kw;
+    L.wpk = pk.push(gconv_packed_floats(con, cs, nseg, kh, kw));
+    gconv_pack(wsl, con, cs, nseg, kh, kw, pk.host.data() + L.wpk);
+    L.shift = pk.push(con);
+    if (bn) {
+        L.has_scale = true;
+        L.scale = pk.push(con);
+        for (int i = 0; i < con; ++i) {
+            const int co = co0 + i;
+            const float sc = bn->w[co] / sqrtf(bn->rv[co] + 1e-5f);
+            pk.host[L.scale + i] = sc;
+            pk.host[L.shift + i] = (bias[co] - bn->rm[co]) * sc + bn->b[co];
+        }
+    } else {
+        for (int i = 0; i < con; ++i) pk.host[L.shift + i] = bias[co0 + i];
+    }
+    (void)cout_all;
+}
+
+void parse_encoder(Cursor& c, Packer& pk, Encoder& E, bool batch_norm, int cin0, int out_dim, bool split_out) {
+    E.batch_norm = batch_norm;
+    BN bn1{};
+    if (batch_norm) bn1 = take_bn(c, 64);                         // norm1 is registered before conv1
+    {
+        const float* w = c.take((size_t)64 * cin0 * 49);
+        const float* b = c.take(64);
+        const int cs[1] = {cin0};
+        make_layer(pk, E.conv1, w, b, 64, 0, 64, cs, 1, 7, 7, 2, 3, 3, batch_norm ? &bn1 : nullptr);
+    }
+    const int dims[3] = {64, 96, 128};
+    int in_planes = 64, bi = 0;
+    for (int l = 0; l < 3; ++l)
+        for (int r = 0; r < 2; ++r, ++bi) {
+            Block& bk = E.blk[bi];
+            const int planes = dims[l];
+            const int stride = (r == 0 && l > 0) ? 2 : 1;
+            const int cin = r == 0 ? in_planes : planes;
+            const float* w1 = c.take((size_t)planes * cin * 9);
+            const float* b1 = c.take(planes);
+            const float* w2 = c.take((size_t)planes * planes * 9);
+            const float* b2 = c.take(planes);
+            BN n1{}, n2{}, n3{};
+            if (batch_norm) { n1 = take_bn(c, planes); n2 = take_bn(c, planes); }
+            bk.has_down = stride != 1;
+            const int cs1[1] = {cin}, cs2[1] = {planes};
+            make_layer(pk, bk.conv1, w1, b1, planes, 0, planes, cs1, 1, 3, 3, stride, 1, 1, batch_norm ? &n1 : nullptr);
+            make_layer(pk, bk.conv2, w2, b2, planes, 0, planes, cs2, 1, 3, 3, 1, 1, 1, batch_norm ? &n2 : nullptr);
+            if (bk.has_down) {
+                if (batch_norm) n3 = take_bn(c, planes);           // norm3, then downsample.0, then its alias downsample.1
+                const float* wd = c.take((size_t)planes * cin);
+                const float* bd = c.take(planes);
+                if (batch_norm) (void)take_bn(c, planes);
+                make_layer(pk, bk.down, wd, bd, planes, 0, planes, cs1, 1, 1, 1, stride, 0, 0, batch_norm ? &n3 : nullptr);
+            }
+            if (r == 0) in_planes = planes;
+        }
+    const float* w = c.take((size_t)out_dim * 128);
+    const float* b = c.take(out_dim);
+    const int cs[1] = {128};
+    if (split_out) {
+        make_layer(pk, E.conv2a, w, b, out_dim, 0, out_dim / 2, cs, 1, 1, 1, 1, 0, 0, nullptr);
+        make_layer(pk, E.conv2b, w, b, out_dim, out_dim / 2, out_dim / 2, cs, 1, 1, 1, 1, 0, 0, nullptr);
+    } else {
+        make_layer(pk, E.conv2a, w, b, out_dim, 0, out_dim, cs, 1, 1, 1, 1, 0, 0, nullptr);
+    }
+}
+
+GConvArgs conv_args(const eraft_ctx* c, const Layer& L, int n, int hin, int win, float* out, int out_ctotal, int out_coff, int act) {
+    GConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nseg = L.nseg;
+    a.wpk = c->arena + L.wpk;
+    a.scale = L.has_scale ? c->arena + L.scale : nullptr;
+    a.shift = c->arena + L.shift;
+    a.out = out; a.out_ctotal = out_ctotal; a.out_coff = out_coff;
+    a.n = n; a.hin = hin; a.win = win;
+    a.hout = (hin + 2 * L.ph - L.kh) / L.stride + 1;
+    a.wout = (win + 2 * L.pw - L.kw) / L.stride + 1;
+    a.cout = L.cout; a.kh = L.kh; a.kw = L.kw; a.stride = L.stride; a.pad_h = L.ph; a.pad_w = L.pw;
+    a.act = act; a.epi = GEPI_PLAIN; a.out_scale = 1.f;
+    return a;
+}
+
+void set_seg(GConvArgs& a, int i, const float* ptr, int cch, int ctotal, int coff) {
+    a.seg[i].ptr = ptr; a.seg[i].c = cch; a.seg[i].ctotal = ctotal; a.seg[i].coff = coff;
+}
+
+// BasicEncoder forward on `n` images [n][cin0][hp][wp]; result of the residual stack in *feat ([n][128][hp/8][wp/8]).
+int run_encoder(eraft_ctx* c, const Encoder& E, const float* x, int n, int cin0, int hp, int wp, float** feat, hipStream_t st) {
+    int rc;
+    float* X = c->s[0].p; float* R = c->s[1].p; float* Y = c->s[2].p; float* D = c->s[3].p; float* O = c->s[4].p;
+    int h = hp, w = wp;
+    {   // conv1 7x7 s2 + norm1 + relu
+        GConvArgs a = conv_args(c, E.conv1, n, h, w, E.batch_norm ? X : R, 64, 0, E.batch_norm ? GACT_RELU : GACT_NONE);
+        set_seg(a, 0, x, cin0, cin0, 0);
+        if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+        h = a.hout; w = a.wout;
+        if (!E.batch_norm && (rc = er_instnorm_launch(R, X, nullptr, n * 64, h * w, 1, st)) != EEM_OK) return rc;
+    }
+    const int dims[3] = {64, 96, 128};
+    int in_planes = 64, bi = 0;
+    for (int l = 0; l < 3; ++l)
+        for (int r = 0; r < 2; ++r, ++bi) {
+            const Block& bk = E.blk[bi];
+            const int planes = dims[l], cin = r == 0 ? in_planes : planes;
+            // y = relu(norm1(conv1(x)))
+            GConvArgs a1 = conv_args(c, bk.conv1, n, h, w, E.batch_norm ? Y : R, planes, 0, E.batch_norm ? GACT_RELU : GACT_NONE);
+            set_seg(a1, 0, X, cin, cin, 0);
+            if ((rc = gconv_launch(a1, st)) != EEM_OK) return rc;
+            const int ho = a1.hout, wo = a1.wout;
+            if (!E.batch_norm && (rc = er_instnorm_launch(R, Y, nullptr, n * planes, ho * wo, 1, st)) != EEM_OK) return rc;
+            // shortcut
+            const float* res = X;
+            if (bk.has_down) {
+                GConvArgs ad = conv_args(c, bk.down, n, h, w, E.batch_norm ? D : R, planes, 0, GACT_NONE);
+                set_seg(ad, 0, X, cin, cin, 0);
+                if ((rc = gconv_launch(ad, st)) != EEM_OK) return rc;
+                if (!E.batch_norm && (rc = er_instnorm_launch(R, D, nullptr, n * planes, ho * wo, 0, st)) != EEM_OK) return rc;
+                res = D;
+            }
+            // out = relu(res + relu(norm2(conv2(y))))
+            GConvArgs a2 = conv_args(c, bk.conv2, n, ho, wo, E.batch_norm ? O : R, planes, 0, E.batch_norm ? GACT_RELU : GACT_NONE);
+            set_seg(a2, 0, Y, planes, planes, 0);
+            if (E.batch_norm) { a2.epi = GEPI_ADD_RELU; a2.e0 = res; a2.e0_ctotal = planes; a2.e0_coff = 0; }
+            if ((rc = gconv_launch(a2, st)) != EEM_OK) return rc;
+            if (!E.batch_norm && (rc = er_instnorm_launch(R, O, res, n * planes, ho * wo, 1, st)) != EEM_OK) return rc;
+            float* t = X; X = O; O = t;
+            h = ho; w = wo;
+            if (r == 0) in_planes = planes;
+        }
+    *feat = X;
+    return EEM_OK;
+}
+
+int build_pyramid(eraft_ctx* c, const float* f1, const float* f2, int batch, int ch, int h, int w, hipStream_t st) {
+    int rc;
+    const size_t hw = (size_t)h * w;
+    c->ph[0] = h; c->pw[0] = w;
+    for (int l = 1; l < 4; ++l) { c->ph[l] = c->ph[l - 1] / 2; c->pw[l] = c->pw[l - 1] / 2; }
+    for (int l = 0; l < 4; ++l) {
+        EEM_REQUIRE(c->ph[l] >= 1 && c->pw[l] >= 1, "correlation pyramid level %d is empty for a %dx%d feature map", l, h, w);
+        if ((rc = ensure(c->pyr[l], (size_t)batch * hw * c->ph[l] * c->pw[l])) != EEM_OK) return rc;
+    }
+    if ((rc = er_allpairs_launch(f1, f2, c->pyr[0].p, batch, ch, (int)hw, st)) != EEM_OK) return rc;
+    for (int l = 1; l < 4; ++l)
+        if ((rc = er_pool2_launch(c->pyr[l - 1].p, c->pyr[l].p, (long)batch * hw, c->ph[l - 1], c->pw[l - 1], st)) != EEM_OK) return rc;
+    return EEM_OK;
+}
+
+int run_lookup(eraft_ctx* c, const float* coords, float* out, int batch, int h, int w, hipStream_t st) {
+    LookupArgs la;
+    for (int l = 0; l < 4; ++l) { la.pyr[l] = c->pyr[l].p; la.ph[l] = c->ph[l]; la.pw[l] = c->pw[l]; }
+    la.coords = coords; la.out = out; la.batch = batch; la.h = h; la.w = w;
+    return er_lookup_launch(la, st);
+}
+
+}  // namespace
+
+extern "C" int eraft_create(int device, eraft_ctx** out) {
+    EEM_REQUIRE(out != nullptr, "eraft_create: out is NULL");
+    int ndev = 0;
+    EEM_HIP_CHECK(hipGetDeviceCount(&ndev));
+    EEM_REQUIRE(device >= 0 && device < ndev, "eraft_create: device %d of %d", device, ndev);
+    EEM_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    EEM_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    EEM_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, "built for gfx950 (MI355X) only; device %d is %s", device,
+                prop.gcnArchName);
+    eraft_ctx* c = new eraft_ctx();
+    c->device = device;
+    *out = c;
+    return EEM_OK;
+}
+
+extern "C" void eraft_destroy(eraft_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    Buf* all[] = {&c->padded, &c->s[0], &c->s[1], &c->s[2], &c->s[3], &c->s[4], &c->fmap, &c->net[0], &c->net[1], &c->inp,
+                  &c->pyr[0], &c->pyr[1], &c->pyr[2], &c->pyr[3], &c->c0, &c->c1, &c->corr, &c->cor1, &c->corflo, &c->flo1,
+                  &c->motion, &c->z, &c->rh, &c->fhid, &c->delta, &c->mhid, &c->mask, &c->st_corr0, &c->st_net1, &c->st_mask1,
+                  &c->st_delta1, &c->zeros};
+    for (Buf* b : all) if (b->p) (void)hipFree(b->p);
+    if (c->arena) (void)hipFree(c->arena);
+    delete c;
+}
+
+extern "C" int eraft_load_weights(eraft_ctx* c, const float* flat, size_t nfloats, int n_first_channels) {
+    EEM_REQUIRE(c && flat, "eraft_load_weights: NULL argument");
+    EEM_REQUIRE(n_first_channels >= 1 && n_first_channels <= 64, "eraft_load_weights: n_first_channels=%d", n_first_channels);
+    EEM_HIP_CHECK(hipSetDevice(c->device));
+    Cursor cur{flat, flat + nfloats};
+    Packer pk;
+    parse_encoder(cur, pk, c->fnet, false, n_first_channels, 256, false);
+    parse_encoder(cur, pk, c->cnet, true, n_first_channels, 256, true);
+    auto plain = [&](Layer& L, int cout, const int* cs, int nseg, int kh, int kw, int ph, int pw) {
+        int cin = 0;
+        for (int s = 0; s < nseg; ++s) cin += cs[s];
+        const float* w = cur.take((size_t)cout * cin * kh * kw);
+        const float* b = cur.take(cout);
+        make_layer(pk, L, w, b, cout, 0, cout, cs, nseg, kh, kw, 1, ph, pw, nullptr);
+    };
+    const int c324[1] = {324}, c256[1] = {256}, c2[1] = {2}, c128[1] = {128}, c3x128[3] = {128, 128, 128};
+    plain(c->convc1, 256, c324, 1, 1, 1, 0, 0);          // model/update.py:63-71
+    plain(c->convc2, 192, c256, 1, 3, 3, 1, 1);
+    plain(c->convf1, 128, c2, 1, 7, 7, 3, 3);
+    plain(c->convf2, 64, c128, 1, 3, 3, 1, 1);
+    plain(c->conv, 126, c256, 1, 3, 3, 1, 1);
+    plain(c->gz[0], 128, c3x128, 3, 1, 5, 0, 2);         // model/update.py:33-44: hx = [h | inp | motion]
+    plain(c->gr[0], 128, c3x128, 3, 1, 5, 0, 2);
+    plain(c->gq[0], 128, c3x128, 3, 1, 5, 0, 2);
+    plain(c->gz[1], 128, c3x128, 3, 5, 1, 2, 0);
+    plain(c->gr[1], 128, c3x128, 3, 5, 1, 2, 0);
+    plain(c->gq[1], 128, c3x128, 3, 5, 1, 2, 0);
+    plain(c->fh1, 256, c128, 1, 3, 3, 1, 1);             // model/update.py:6-14
+    plain(c->fh2, 2, c256, 1, 3, 3, 1, 1);
+    plain(c->mk0, 256, c128, 1, 3, 3, 1, 1);             // model/update.py:92-95
+    plain(c->mk2, 576, c256, 1, 1, 1, 0, 0);
+    EEM_REQUIRE(cur.p == cur.end, "eraft_load_weights: the 179-tensor layout needs %zu floats (num_batches_tracked "
+                                  "excluded), got %zu", (size_t)(cur.p - flat), nfloats);
+    if (c->arena) EEM_HIP_CHECK(hipFree(c->arena));
+    c->arena = nullptr;
+    EEM_HIP_CHECK(hipMalloc(&c->arena, pk.host.size() * sizeof(float)));
+    EEM_HIP_CHECK(hipMemcpy(c->arena, pk.host.data(), pk.host.size() * sizeof(float), hipMemcpyHostToDevice));
+    c->cin0 = n_first_channels;
+    c->loaded = true;
+    return EEM_OK;
+}
+
+extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int batch, int in_h, int in_w, const int pad[4],
+                             int iters, const float* flow_init, float* out, void* stream) {
+    EEM_REQUIRE(c && e1 && e2 && out && pad, "eraft_forward: NULL argument");
+    EEM_REQUIRE(c->loaded, "eraft_forward: no weights loaded");
+    EEM_REQUIRE(batch >= 1 && in_h >= 1 && in_w >= 1 && iters >= 1, "eraft_forward: bad sizes");
+    EEM_HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int B = batch, hp = in_h + pad[2] + pad[3], wp = in_w + pad[0] + pad[1];
+    EEM_REQUIRE(hp % 8 == 0 && wp % 8 == 0, "eraft_forward: padded size %dx%d must be a multiple of 8", hp, wp);
+    const int h8 = hp / 8, w8 = wp / 8;
+    const size_t g = (size_t)h8 * w8;
+    int rc;
+    // ---- workspace
+    const size_t big = (size_t)2 * B * 64 * ((hp + 1) / 2) * ((wp + 1) / 2);
+#define ENS(b, n) if ((rc = ensure(b, n)) != EEM_OK) return rc
+    ENS(c->padded, (size_t)2 * B * c->cin0 * hp * wp);
+    for (int i = 0; i < 5; ++i) ENS(c->s[i], big);
+    ENS(c->fmap, (size_t)2 * B * 256 * g);
+    ENS(c->net[0], B * 128 * g); ENS(c->net[1], B * 128 * g); ENS(c->inp, B * 128 * g);
+    ENS(c->c0, B * 2 * g); ENS(c->c1, B * 2 * g); ENS(c->corr, B * 324 * g); ENS(c->cor1, B * 256 * g);
+    ENS(c->corflo, B * 256 * g); ENS(c->flo1, B * 128 * g); ENS(c->motion, B * 128 * g); ENS(c->z, B * 128 * g);
+    ENS(c->rh, B * 128 * g); ENS(c->fhid, B * 256 * g); ENS(c->delta, B * 2 * g); ENS(c->mhid, B * 256 * g);
+    ENS(c->mask, B * 576 * g);
+    ENS(c->st_corr0, B * 324 * g); ENS(c->st_net1, B * 128 * g); ENS(c->st_mask1, B * 576 * g); ENS(c->st_delta1, B * 2 * g);
+#undef ENS
+    const int cin0 = c->cin0;
+    // ---- pad both event volumes into one batch (model/eraft.py:106-109)
+    float* pad1 = c->padded.p;
+    float* pad2 = c->padded.p + (size_t)B * cin0 * hp * wp;
+    if ((rc = er_pad_launch(e1, pad1, B * cin0, in_h, in_w, pad[0], pad[1], pad[2], pad[3], st)) != EEM_OK) return rc;
+    if ((rc = er_pad_launch(e2, pad2, B * cin0, in_h, in_w, pad[0], pad[1], pad[2], pad[3], st)) != EEM_OK) return rc;
+    // ---- feature network on [image1; image2] (:116), then its 1x1 output conv
+    float* feat = nullptr;
+    if ((rc = run_encoder(c, c->fnet, c->padded.p, 2 * B, cin0, hp, wp, &feat, st)) != EEM_OK) return rc;
+    {
+        GConvArgs a = conv_args(c, c->fnet.conv2a, 2 * B, h8, w8, c->fmap.p, 256, 0, GACT_NONE);
+        set_seg(a, 0, feat, 128, 128, 0);
+        if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+    }
+    // ---- all-pairs correlation pyramid (:121)
+    if ((rc = build_pyramid(c, c->fmap.p, c->fmap.p + (size_t)B * 256 * g, B, 256, h8, w8, st)) != EEM_OK) return rc;
+    // ---- context network on image1 (:126-131): net = tanh(first half), inp = relu(second half)
+    if ((rc = run_encoder(c, c->cnet, pad1, B, cin0, hp, wp, &feat, st)) != EEM_OK) return rc;
+    {
+        GConvArgs a = conv_args(c, c->cnet.conv2a, B, h8, w8, c->net[0].p, 128, 0, GACT_TANH);
+        set_seg(a, 0, feat, 128, 128, 0);
+        if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+        GConvArgs b2 = conv_args(c, c->cnet.conv2b, B, h8, w8, c->inp.p, 128, 0, GACT_RELU);
+        set_seg(b2, 0, feat, 128, 128, 0);
+        if ((rc = gconv_launch(b2, st)) != EEM_OK) return rc;
+    }
+    if ((rc = er_coords_init_launch(c->c0.p, c->c1.p, flow_init, B, h8, w8, st)) != EEM_OK) return rc;
+
+    int cur = 0;
+    for (int it = 0; it < iters; ++it) {
+        float* net = c->net[cur].p;
+        float* netn = c->net[cur ^ 1].p;
+        if ((rc = run_lookup(c, c->c1.p, c->corr.p, B, h8, w8, st)) != EEM_OK) return rc;                    // :142
+        if ((rc = er_flow_launch(c->c0.p, c->c1.p, c->motion.p, 128, 126, B, (int)g, st)) != EEM_OK) return rc;  // :144, update.py:81
+        // motion encoder (model/update.py:73-81)
+        GConvArgs a = conv_args(c, c->convc1, B, h8, w8, c->cor1.p, 256, 0, GACT_RELU);
+        set_seg(a, 0, c->corr.p, 324, 324, 0);
+        if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+        a = conv_args(c, c->convc2, B, h8, w8, c->corflo.p, 256, 0, GACT_RELU);
+        set_seg(a, 0, c->cor1.p, 256, 256, 0);
+        if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+        a = conv_args(c, c->convf1, B, h8, w8, c->flo1.p, 128, 0, GACT_RELU);
+        set_seg(a, 0, c->motion.p, 2, 128, 126);
+        if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+        a = conv_args(c, c->convf2, B, h8, w8, c->corflo.p, 256, 192, GACT_RELU);
+        set_seg(a, 0, c->flo1.p, 128, 128, 0);
+        if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+        a = conv_args(c, c->conv, B, h8, w8, c->motion.p, 128, 0, GACT_RELU);
+        set_seg(a, 0, c->corflo.p, 256, 256, 0);
+        if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+        // SepConvGRU (model/update.py:43-60): horizontal then vertical pass
+        float* hcur = net;
+        float* hnext = netn;
+        for (int pass = 0; pass < 2; ++pass) {
+            a = conv_args(c, c->gz[pass], B, h8, w8, c->z.p, 128, 0, GACT_SIGMOID);
+            set_seg(a, 0, hcur, 128, 128, 0); set_seg(a, 1, c->inp.p, 128, 128, 0); set_seg(a, 2, c->motion.p, 128, 128, 0);
+            if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+            a = conv_args(c, c->gr[pass], B, h8, w8, c->rh.p, 128, 0, GACT_SIGMOID);
+            set_seg(a, 0, hcur, 128, 128, 0); set_seg(a, 1, c->inp.p, 128, 128, 0); set_seg(a, 2, c->motion.p, 128, 128, 0);
+            a.epi = GEPI_MUL; a.e0 = hcur; a.e0_ctotal = 128; a.e0_coff = 0;
+            if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+            a = conv_args(c, c->gq[pass], B, h8, w8, hnext, 128, 0, GACT_TANH);
+            set_seg(a, 0, c->rh.p, 128, 128, 0); set_seg(a, 1, c->inp.p, 128, 128, 0); set_seg(a, 2, c->motion.p, 128, 128, 0);
+            a.epi = GEPI_GRU; a.e0 = hcur; a.e0_ctotal = 128; a.e0_coff = 0; a.e1 = c->z.p; a.e1_ctotal = 128; a.e1_coff = 0;
+            if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+            float* t = hcur; hcur = hnext; hnext = t;
+        }
+        // after two passes the new hidden state is back in `net`
+        // flow head and mask head (model/update.py:102-105)
+        a = conv_args(c, c->fh1, B, h8, w8, c->fhid.p, 256, 0, GACT_RELU);
+        set_seg(a, 0, net, 128, 128, 0);
+        if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+        a = conv_args(c, c->fh2, B, h8, w8, c->delta.p, 2, 0, GACT_NONE);
+        set_seg(a, 0, c->fhid.p, 256, 256, 0);
+        if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+        a = conv_args(c, c->mk0, B, h8, w8, c->mhid.p, 256, 0, GACT_RELU);
+        set_seg(a, 0, net, 128, 128, 0);
+        if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+        a = conv_args(c, c->mk2, B, h8, w8, c->mask.p, 576, 0, GACT_NONE);
+        set_seg(a, 0, c->mhid.p, 256, 256, 0);
+        a.out_scale = 0.25f;
+        if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+        if ((rc = er_axpy_launch(c->c1.p, c->delta.p, (long)B * 2 * g, st)) != EEM_OK) return rc;              // :149
+        if ((rc = er_convex_up_launch(c->c0.p, c->c1.p, c->mask.p, out + (size_t)it * B * 2 * in_h * in_w, B, h8, w8, pad[2],
+                                      pad[0], in_h, in_w, st)) != EEM_OK) return rc;                          // :155-157
+        if (it == 0) {
+            EEM_HIP_CHECK(hipMemcpyAsync(c->st_corr0.p, c->corr.p, B * 324 * g * 4, hipMemcpyDeviceToDevice, st));
+            EEM_HIP_CHECK(hipMemcpyAsync(c->st_net1.p, net, B * 128 * g * 4, hipMemcpyDeviceToDevice, st));
+            EEM_HIP_CHECK(hipMemcpyAsync(c->st_mask1.p, c->mask.p, B * 576 * g * 4, hipMemcpyDeviceToDevice, st));
+            EEM_HIP_CHECK(hipMemcpyAsync(c->st_delta1.p, c->delta.p, B * 2 * g * 4, hipMemcpyDeviceToDevice, st));
+        }
+        (void)cur;
+    }
+    c->B = B; c->h8 = h8; c->w8 = w8; c->have_last = true;
+    return EEM_OK;
+}
+
+extern "C" int eraft_get_stage(eraft_ctx* c, const char* name, float* dst, size_t cap, int dims[4], void* stream) {
+    EEM_REQUIRE(c && name && dims, "eraft_get_stage: NULL argument");
+    EEM_REQUIRE(c->have_last, "eraft_get_stage: no forward has run");
+    const std::string nm(name);
+    const float* src = nullptr;
+    dims[2] = c->h8; dims[3] = c->w8;
+    if (nm == "fmap") { src = c->fmap.p; dims[0] = 2 * c->B; dims[1] = 256; }
+    else if (nm == "inp") { src = c->inp.p; dims[0] = c->B; dims[1] = 128; }
+    else if (nm == "corr0") { src = c->st_corr0.p; dims[0] = c->B; dims[1] = 324; }
+    else if (nm == "net1") { src = c->st_net1.p; dims[0] = c->B; dims[1] = 128; }
+    else if (nm == "mask1") { src = c->st_mask1.p; dims[0] = c->B; dims[1] = 576; }
+    else if (nm == "delta1") { src = c->st_delta1.p; dims[0] = c->B; dims[1] = 2; }
+    else if (nm == "flow_low") { src = nullptr; dims[0] = c->B; dims[1] = 2; }
+    else if (nm.size() == 4 && nm.compare(0, 3, "pyr") == 0 && nm[3] >= '0' && nm[3] <= '3') {
+        const int l = nm[3] - '0';
+        src = c->pyr[l].p; dims[0] = c->B * c->h8 * c->w8; dims[1] = 1; dims[2] = c->ph[l]; dims[3] = c->pw[l];
+    } else {
+        eem_set_error("eraft_get_stage: unknown stage '%s'", name);
+        return EEM_ERR_ARG;
+    }
+    const size_t n = (size_t)dims[0] * dims[1] * dims[2] * dims[3];
+    if (dst == nullptr) return EEM_OK;
+    EEM_REQUIRE(cap >= n, "eraft_get_stage: '%s' needs %zu floats, buffer holds %zu", name, n, cap);
+    if (nm == "flow_low") {
+        int rc = er_flow_launch(c->c0.p, c->c1.p, dst, 2, 0, c->B, c->h8 * c->w8, (hipStream_t)stream);
+        return rc;
+    }
+    EEM_HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return EEM_OK;
+}
+
+// CorrBlock as a standalone op (model/corr.py:13-50): pyramid of (fmap1, fmap2), then one lookup at `coords`
+extern "C" int eraft_corr_lookup(eraft_ctx* c, const float* fmap1, const float* fmap2, const float* coords, int batch, int ch,
+                                 int h, int w, float* out, void* stream) {
+    EEM_REQUIRE(c && fmap1 && fmap2 && coords && out, "eraft_corr_lookup: NULL argument");
+    EEM_HIP_CHECK(hipSetDevice(c->device));
+    int rc = build_pyramid(c, fmap1, fmap2, batch, ch, h, w, (hipStream_t)stream);
+    if (rc != EEM_OK) return rc;
+    c->B = batch; c->h8 = h; c->w8 = w; c->have_last = true;
+    return run_lookup(c, coords, out, batch, h, w, (hipStream_t)stream);
+}
+
+// ERAFT.upsample_flow (model/eraft.py:83-94): flow [B][2][h][w], mask [B][576][h][w] -> out [B][2][8h][8w]
+extern "C" int eraft_convex_upsample(eraft_ctx* c, const float* flow, const float* mask, int batch, int h, int w, float* out,
+                                     void* stream) {
+    EEM_REQUIRE(c && flow && mask && out, "eraft_convex_upsample: NULL argument");
+    EEM_HIP_CHECK(hipSetDevice(c->device));
+    int rc = ensure(c->zeros, (size_t)batch * 2 * h * w);
+    if (rc != EEM_OK) return rc;
+    EEM_HIP_CHECK(hipMemsetAsync(c->zeros.p, 0, (size_t)batch * 2 * h * w * 4, (hipStream_t)stream));
+    return er_convex_up_launch(c->zeros.p, flow, mask, out, batch, h, w, 0, 0, 8 * h, 8 * w, (hipStream_t)stream);
+}

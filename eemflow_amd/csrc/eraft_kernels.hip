@@ -1,0 +1,269 @@
+#include "eraft_kernels.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void pad_kernel(const float* __restrict__ in, float* __restrict__ out, int nc, int h, int w,
+                                                  int left, int top, int oh, int ow) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)nc * oh * ow) return;
+    const int x = idx % ow, y = (idx / ow) % oh;
+    const long c = idx / ((long)ow * oh);
+    const int sy = min(max(y - top, 0), h - 1), sx = min(max(x - left, 0), w - 1);
+    out[idx] = in[(c * h + sy) * w + sx];
+}
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// one block per (n, c) plane; mean, then biased variance around the mean, then apply
+__global__ __launch_bounds__(256) void instnorm_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                       const float* __restrict__ res, int hw, int relu_inner) {
+    __shared__ float sh[4];
+    const float* p = x + (size_t)blockIdx.x * hw;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < hw; i += 256) s += p[i];
+    const float mean = block_sum(s, sh) / (float)hw;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < hw; i += 256) { const float d = p[i] - mean; q += d * d; }
+    const float var = block_sum(q, sh) / (float)hw;
+    const float rstd = 1.f / sqrtf(var + 1e-5f);
+    float* o = out + (size_t)blockIdx.x * hw;
+    const float* r = res ? res + (size_t)blockIdx.x * hw : nullptr;
+    for (int i = threadIdx.x; i < hw; i += 256) {
+        float v = (p[i] - mean) * rstd;
+        if (relu_inner) v = v > 0.f ? v : 0.f;
+        if (r) { v += r[i]; v = v > 0.f ? v : 0.f; }
+        o[i] = v;
+    }
+}
+
+// D[p1][p2] tiles of 64x64 per wave on v_mfma_f32_32x32x2_f32; both operands are read with unit stride along
+// the pixel index (A[i=p1][k=c] = f1[c][p1], B[k=c][j=p2] = f2[c][p2]) and each accumulator register is a
+// 128-B run of p2 for one p1 row.
+__global__ __launch_bounds__(256) void allpairs_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                       float* __restrict__ out, int c, int hw, float scale) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z;
+    const int m0 = blockIdx.y * 128 + (wave >> 1) * 64;      // p1 tile origin
+    const int n0 = blockIdx.x * 128 + (wave & 1) * 64;       // p2 tile origin
+    if (m0 >= hw || n0 >= hw) return;
+    const float* a = f1 + (size_t)b * c * hw;
+    const float* bb = f2 + (size_t)b * c * hw;
+    int ma[2], nb[2];
+    bool mv[2], nv[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        ma[t] = m0 + t * 32 + j; mv[t] = ma[t] < hw; ma[t] = mv[t] ? ma[t] : 0;
+        nb[t] = n0 + t * 32 + j; nv[t] = nb[t] < hw; nb[t] = nv[t] ? nb[t] : 0;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[s][t][r] = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < c; k += 2) {
+        const int kk = k + h;
+        const bool kv = kk < c;
+        const size_t ko = (size_t)(kv ? kk : 0) * hw;
+        float av[2], bv[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float x = a[ko + ma[t]], y = bb[ko + nb[t]];
+            av[t] = (kv && mv[t]) ? x : 0.f;
+            bv[t] = (kv && nv[t]) ? y : 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[t], acc[s][t], 0, 0, 0);
+    }
+    float* o = out + (size_t)b * hw * hw;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int p2 = n0 + t * 32 + j;
+            if (p2 >= hw) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p1 = m0 + s * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (p1 < hw) o[(size_t)p1 * hw + p2] = acc[s][t][r] * scale;
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void pool2_kernel(const float* __restrict__ in, float* __restrict__ out, long planes, int h,
+                                                    int w) {
+    const int oh = h / 2, ow = w / 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= planes * oh * ow) return;
+    const int x = idx % ow, y = (idx / ow) % oh;
+    const long p = idx / ((long)ow * oh);
+    const float* s = in + (p * h + 2 * y) * w + 2 * x;
+    out[idx] = (s[0] + s[1] + s[w] + s[w + 1]) * 0.25f;
+}
+
+// grid_sample(align_corners=True, zeros) at pixel coordinates, computed like the reference: normalise with
+// (size-1), un-normalise again, floor, 4 taps (model/model_utils.py:7-21)
+__device__ __forceinline__ float sample_bilinear(const float* __restrict__ img, int h, int w, float x, float y) {
+    const float xn = 2.f * x / (float)(w - 1) - 1.f, yn = 2.f * y / (float)(h - 1) - 1.f;
+    const float ix = ((xn + 1.f) * 0.5f) * (float)(w - 1), iy = ((yn + 1.f) * 0.5f) * (float)(h - 1);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float tx = ix - fx, ty = iy - fy;
+    auto at = [&](int yy, int xx) -> float {
+        return (yy >= 0 && yy < h && xx >= 0 && xx < w) ? img[(size_t)yy * w + xx] : 0.f;
+    };
+    return at(y0, x0) * (1.f - tx) * (1.f - ty) + at(y0, x0 + 1) * tx * (1.f - ty) + at(y0 + 1, x0) * (1.f - tx) * ty +
+           at(y0 + 1, x0 + 1) * tx * ty;
+}
+
+__global__ __launch_bounds__(256) void lookup_kernel(LookupArgs a) {
+    const int hw = a.h * a.w;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)a.batch * 324 * hw) return;
+    const int p = idx % hw;
+    const int ch = (idx / hw) % 324;
+    const int b = idx / ((long)hw * 324);
+    const int lvl = ch / 81, k = ch - lvl * 81;
+    const int i = k / 9, jj = k - i * 9;
+    const float cx = a.coords[((size_t)b * 2 + 0) * hw + p], cy = a.coords[((size_t)b * 2 + 1) * hw + p];
+    const float sc = (float)(1 << lvl);
+    const float x = cx / sc + (float)(i - 4);          // the reference adds (dy[i], dx[j]) to (x, y)
+    const float y = cy / sc + (float)(jj - 4);
+    const float* img = a.pyr[lvl] + ((size_t)b * hw + p) * a.ph[lvl] * a.pw[lvl];
+    a.out[idx] = sample_bilinear(img, a.ph[lvl], a.pw[lvl], x, y);
+}
+
+__global__ __launch_bounds__(256) void coords_init_kernel(float* c0, float* c1, const float* init, int batch, int h, int w) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int hw = h * w;
+    if (idx >= (long)batch * 2 * hw) return;
+    const int p = idx % hw, ch = (idx / hw) % 2;
+    const float v = ch == 0 ? (float)(p % w) : (float)(p / w);
+    c0[idx] = v;
+    c1[idx] = init ? v + init[idx] : v;
+}
+
+__global__ __launch_bounds__(256) void flow_kernel(const float* c0, const float* c1, float* dst, int dst_ctotal, int dst_coff,
+                                                   int batch, int hw) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)batch * 2 * hw) return;
+    const int p = idx % hw, ch = (idx / hw) % 2, b = idx / (2L * hw);
+    dst[((size_t)b * dst_ctotal + dst_coff + ch) * hw + p] = c1[idx] - c0[idx];
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(float* y, const float* x, long n) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx < n) y[idx] += x[idx];
+}
+
+// one thread per output pixel (both flow channels): softmax over the 9 mask logits of its (sub-pixel, cell),
+// convex combination of the 3x3 neighbourhood of 8*flow (zero outside, F.unfold padding=1)
+__global__ __launch_bounds__(256) void convex_up_kernel(const float* __restrict__ c0, const float* __restrict__ c1,
+                                                        const float* __restrict__ mask, float* __restrict__ out, int batch,
+                                                        int h, int w, int top, int left, int oh, int ow) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)batch * oh * ow) return;
+    const int X = idx % ow + left, Y = (idx / ow) % oh + top;
+    const int b = idx / ((long)ow * oh);
+    const int x = X >> 3, y = Y >> 3, sx = X & 7, sy = Y & 7;
+    const int hw = h * w;
+    const float* m = mask + ((size_t)b * 576 + sy * 8 + sx) * hw + y * w + x;
+    float lg[9], mx = -3.4e38f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { lg[k] = m[(size_t)k * 64 * hw]; mx = fmaxf(mx, lg[k]); }
+    float den = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { lg[k] = expf(lg[k] - mx); den += lg[k]; }
+    float u = 0.f, v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+        if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
+            const size_t q = (size_t)b * 2 * hw + yy * w + xx;
+            const float wgt = lg[k] / den;
+            u += wgt * (8.f * (c1[q] - c0[q]));
+            v += wgt * (8.f * (c1[q + hw] - c0[q + hw]));
+        }
+    }
+    const size_t o = (size_t)b * 2 * oh * ow + (size_t)(Y - top) * ow + (X - left);
+    out[o] = u;
+    out[o + (size_t)oh * ow] = v;
+}
+
+inline unsigned blocks(long n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+int er_pad_launch(const float* in, float* out, int nc, int h, int w, int left, int right, int top, int bottom, hipStream_t st) {
+    const int oh = h + top + bottom, ow = w + left + right;
+    hipLaunchKernelGGL(pad_kernel, dim3(blocks((long)nc * oh * ow)), dim3(256), 0, st, in, out, nc, h, w, left, top, oh, ow);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int er_instnorm_launch(const float* x, float* out, const float* res, int planes, int hw, int relu_inner, hipStream_t st) {
+    hipLaunchKernelGGL(instnorm_kernel, dim3(planes), dim3(256), 0, st, x, out, res, hw, relu_inner);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int er_allpairs_launch(const float* f1, const float* f2, float* out, int batch, int c, int hw, hipStream_t st) {
+    dim3 grid(ceil_div(hw, 128), ceil_div(hw, 128), batch);
+    hipLaunchKernelGGL(allpairs_kernel, grid, dim3(256), 0, st, f1, f2, out, c, hw, 1.0f / sqrtf((float)c));
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int er_pool2_launch(const float* in, float* out, long planes, int h, int w, hipStream_t st) {
+    const long n = planes * (h / 2) * (w / 2);
+    if (n == 0) return EEM_OK;
+    hipLaunchKernelGGL(pool2_kernel, dim3(blocks(n)), dim3(256), 0, st, in, out, planes, h, w);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int er_lookup_launch(const LookupArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(lookup_kernel, dim3(blocks((long)a.batch * 324 * a.h * a.w)), dim3(256), 0, st, a);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int er_coords_init_launch(float* c0, float* c1, const float* init, int batch, int h, int w, hipStream_t st) {
+    hipLaunchKernelGGL(coords_init_kernel, dim3(blocks((long)batch * 2 * h * w)), dim3(256), 0, st, c0, c1, init, batch, h, w);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int er_flow_launch(const float* c0, const float* c1, float* dst, int dst_ctotal, int dst_coff, int batch, int hw, hipStream_t st) {
+    hipLaunchKernelGGL(flow_kernel, dim3(blocks((long)batch * 2 * hw)), dim3(256), 0, st, c0, c1, dst, dst_ctotal, dst_coff, batch, hw);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int er_axpy_launch(float* y, const float* x, long n, hipStream_t st) {
+    hipLaunchKernelGGL(axpy_kernel, dim3(blocks(n)), dim3(256), 0, st, y, x, n);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int er_convex_up_launch(const float* c0, const float* c1, const float* mask, float* out, int batch, int h, int w, int top,
+                        int left, int oh, int ow, hipStream_t st) {
+    hipLaunchKernelGGL(convex_up_kernel, dim3(blocks((long)batch * oh * ow)), dim3(256), 0, st, c0, c1, mask, out, batch, h, w, top,
+                       left, oh, ow);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}

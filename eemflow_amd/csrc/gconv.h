@@ -1,0 +1,39 @@
+// Generic NCHW fp32 convolution on the fp32 matrix cores (used by the E-RAFT / EEMFlow+ parts of the path,
+// where kernel sizes, strides and channel counts vary per layer: 7x7 s2, 3x3, 1x1, 1x5, 5x1; 2..384 -> 2..576).
+#pragma once
+#include "common.h"
+
+struct GConvSeg {
+    const float* ptr;      // [N][ctotal][hin][win]
+    int c, ctotal, coff;   // this segment = channels [coff, coff + c)
+};
+
+enum { GACT_NONE = 0, GACT_RELU = 1, GACT_SIGMOID = 2, GACT_TANH = 3, GACT_LEAKY = 4 };
+// epilogue modes: v = act(acc * scale[co] + shift[co]) then
+enum {
+    GEPI_PLAIN = 0,        // out = v
+    GEPI_MUL = 1,          // out = v * e0                      (r * h of the GRU)
+    GEPI_GRU = 2,          // out = (1 - e1) * e0 + e1 * v      (e0 = h, e1 = z)
+    GEPI_ADD_RELU = 3      // out = relu(v + e0)                (residual block tail)
+};
+
+struct GConvArgs {
+    GConvSeg seg[3];
+    int nseg;
+    const float* wpk;      // packed by gconv_pack
+    const float* scale;    // [cout] or NULL (= 1)
+    const float* shift;    // [cout] or NULL (= 0)
+    float* out;            // [N][out_ctotal][hout][wout], channel co goes to out_coff + co
+    int out_ctotal, out_coff;
+    int n, hin, win, hout, wout, cout;
+    int kh, kw, stride, pad_h, pad_w;
+    int act, epi;
+    const float* e0; int e0_ctotal, e0_coff;
+    const float* e1; int e1_ctotal, e1_coff;
+    float out_scale;       // final multiplier (1 = none)
+};
+
+// number of packed floats / packing for weights [cout][sum(c_s)][kh][kw] read as segments of sizes cs[0..nseg)
+size_t gconv_packed_floats(int cout, const int* cs, int nseg, int kh, int kw);
+void gconv_pack(const float* w, int cout, const int* cs, int nseg, int kh, int kw, float* packed);
+int gconv_launch(const GConvArgs& a, hipStream_t stream);

@@ -1,0 +1,171 @@
+// Generic convolution as implicit GEMM on v_mfma_f32_32x32x2_f32:  D[cout][pixel] = sum_k A[cout][k] B[k][pixel],
+// k = (tap, segment, channel).  Pixels are the flattened output index (any width works); a wave owns NPW
+// pixel tiles of 32 and MTW cout tiles of 32.  Operands come straight from global memory (the maps of this
+// part of the path are small and L2-resident): A fragments from the host-packed weight stream (one coalesced
+// 256-B load per k-step), B gathered with the tap displacement and the zero-padding test per lane.
+// Inputs may be the concatenation of up to three tensors (segments) - the reference's torch.cat's
+// (model/update.py:44,51,79,99) are never materialised.  The epilogue applies a per-channel scale/shift
+// (bias, folded eval-mode BatchNorm), the activation and the GRU / residual combinations.
+#include "gconv.h"
+
+namespace {
+
+__device__ __forceinline__ float g_act(float v, int act) {
+    switch (act) {
+        case GACT_RELU: return v > 0.f ? v : 0.f;
+        case GACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        case GACT_TANH: return tanhf(v);
+        case GACT_LEAKY: return v > 0.f ? v : 0.1f * v;
+        default: return v;
+    }
+}
+
+template <int NPW, int MTW>
+__global__ __launch_bounds__(256) void gconv_kernel(GConvArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int n = blockIdx.z;
+    const int cot0 = blockIdx.y * MTW;
+    const int hwo = a.hout * a.wout, hwi = a.hin * a.win;
+    const int p0 = (blockIdx.x * 4 + wave) * (NPW * 32);
+    if (p0 >= hwo) return;
+
+    int oy[NPW], ox[NPW];
+    bool pv[NPW];
+#pragma unroll
+    for (int t = 0; t < NPW; ++t) {
+        const int p = p0 + t * 32 + j;
+        pv[t] = p < hwo;
+        const int pc = pv[t] ? p : 0;
+        oy[t] = pc / a.wout;
+        ox[t] = pc - oy[t] * a.wout;
+    }
+    int ksteps = 0;
+    for (int s = 0; s < a.nseg; ++s) ksteps += (a.seg[s].c + 1) >> 1;
+    ksteps *= a.kh * a.kw;
+
+    f32x16 acc[NPW][MTW];
+#pragma unroll
+    for (int t = 0; t < NPW; ++t)
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][m][r] = 0.f;
+
+    const float* wp = a.wpk + (size_t)cot0 * ksteps * 64 + lane;
+    int ks = 0;
+    for (int ty = 0; ty < a.kh; ++ty)
+        for (int tx = 0; tx < a.kw; ++tx) {
+            int off[NPW];
+            bool tv[NPW];
+#pragma unroll
+            for (int t = 0; t < NPW; ++t) {
+                const int iy = oy[t] * a.stride - a.pad_h + ty, ix = ox[t] * a.stride - a.pad_w + tx;
+                tv[t] = pv[t] && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
+                off[t] = tv[t] ? iy * a.win + ix : 0;
+            }
+            for (int s = 0; s < a.nseg; ++s) {
+                const GConvSeg sg = a.seg[s];
+                const float* base = sg.ptr + ((size_t)n * sg.ctotal + sg.coff) * hwi;
+                const int cp_n = (sg.c + 1) >> 1;
+#pragma unroll 4
+                for (int cp = 0; cp < cp_n; ++cp, ++ks) {
+                    const int c = cp * 2 + h;
+                    const bool cv = c < sg.c;
+                    const float* bp = base + (size_t)(cv ? c : 0) * hwi;
+                    float av[MTW], bv[NPW];
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m) av[m] = wp[((size_t)m * ksteps + ks) * 64];
+#pragma unroll
+                    for (int t = 0; t < NPW; ++t) {
+                        const float x = bp[off[t]];
+                        bv[t] = (tv[t] && cv) ? x : 0.f;
+                    }
+#pragma unroll
+                    for (int t = 0; t < NPW; ++t)
+#pragma unroll
+                        for (int m = 0; m < MTW; ++m)
+                            acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[t], acc[t][m], 0, 0, 0);
+                }
+            }
+        }
+
+    // ---- epilogue
+#pragma unroll
+    for (int t = 0; t < NPW; ++t) {
+        if (!pv[t]) continue;
+        const int p = p0 + t * 32 + j;
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = (cot0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (co >= a.cout) continue;
+                float v = acc[t][m][r];
+                if (a.scale) v *= a.scale[co];
+                if (a.shift) v += a.shift[co];
+                v = g_act(v, a.act);
+                if (a.epi == GEPI_MUL) {
+                    v *= a.e0[((size_t)n * a.e0_ctotal + a.e0_coff + co) * hwo + p];
+                } else if (a.epi == GEPI_GRU) {
+                    const float hh = a.e0[((size_t)n * a.e0_ctotal + a.e0_coff + co) * hwo + p];
+                    const float z = a.e1[((size_t)n * a.e1_ctotal + a.e1_coff + co) * hwo + p];
+                    v = (1.f - z) * hh + z * v;
+                } else if (a.epi == GEPI_ADD_RELU) {
+                    v += a.e0[((size_t)n * a.e0_ctotal + a.e0_coff + co) * hwo + p];
+                    v = v > 0.f ? v : 0.f;
+                }
+                a.out[((size_t)n * a.out_ctotal + a.out_coff + co) * hwo + p] = v * a.out_scale;
+            }
+    }
+}
+
+}  // namespace
+
+size_t gconv_packed_floats(int cout, const int* cs, int nseg, int kh, int kw) {
+    int cps = 0;
+    for (int s = 0; s < nseg; ++s) cps += (cs[s] + 1) / 2;
+    return (size_t)ceil_div(cout, 32) * kh * kw * cps * 64;
+}
+
+void gconv_pack(const float* w, int cout, const int* cs, int nseg, int kh, int kw, float* packed) {
+    int cin = 0, cps = 0;
+    for (int s = 0; s < nseg; ++s) { cin += cs[s]; cps += (cs[s] + 1) / 2; }
+    const int taps = kh * kw, ksteps = taps * cps;
+    for (int cot = 0; cot < ceil_div(cout, 32); ++cot) {
+        int ks = 0;
+        for (int tap = 0; tap < taps; ++tap) {
+            int cbase = 0;
+            for (int s = 0; s < nseg; ++s) {
+                for (int cp = 0; cp < (cs[s] + 1) / 2; ++cp, ++ks)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int co = cot * 32 + (lane & 31), c = cp * 2 + (lane >> 5);
+                        float v = 0.f;
+                        if (co < cout && c < cs[s]) v = w[((size_t)co * cin + cbase + c) * taps + tap];
+                        packed[((size_t)cot * ksteps + ks) * 64 + lane] = v;
+                    }
+                cbase += cs[s];
+            }
+        }
+    }
+}
+
+int gconv_launch(const GConvArgs& a, hipStream_t stream) {
+    EEM_REQUIRE(a.nseg >= 1 && a.nseg <= 3 && a.n >= 1 && a.cout >= 1, "gconv_launch: bad arguments");
+    const int hwo = a.hout * a.wout;
+    const int cot = ceil_div(a.cout, 32);
+    // big problems: 2x2 tiles per wave (half the operand traffic per MFMA); small ones: 1x1 for parallelism
+    const long waves22 = (long)ceil_div(hwo, 64) * ceil_div(cot, 2) * a.n;
+    if (waves22 >= 2048 && cot >= 2) {
+        dim3 grid(ceil_div(hwo, 256), ceil_div(cot, 2), a.n);
+        hipLaunchKernelGGL((gconv_kernel<2, 2>), grid, dim3(256), 0, stream, a);
+    } else if ((long)ceil_div(hwo, 64) * cot * a.n >= 2048) {
+        dim3 grid(ceil_div(hwo, 256), cot, a.n);
+        hipLaunchKernelGGL((gconv_kernel<2, 1>), grid, dim3(256), 0, stream, a);
+    } else {
+        dim3 grid(ceil_div(hwo, 128), cot, a.n);
+        hipLaunchKernelGGL((gconv_kernel<1, 1>), grid, dim3(256), 0, stream, a);
+    }
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}

@@ -196,7 +196,7 @@ class ERAFT(nn.Module):
             fi = flow_init.contiguous().float()
         padc = (ctypes.c_int * 4)(*pad)
         with torch.cuda.device(e1.device):
-            _lib.check(_lib.lib().eraft_forward(ctx, e1.data_ptr(), e2.data_ptr(), b, h, w, padc, iters,
+            _lib.check(_lib.lib().eraft_forward(ctx, e1.data_ptr(), e2.data_ptr(), b, h, w, ctypes.byref(padc), iters,
                                                 fi.data_ptr() if fi is not None else None, out.data_ptr(),
                                                 _lib.current_stream_ptr(e1.device)))
         return (events1, events2), [out[i] for i in range(iters)]

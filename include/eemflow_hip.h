@@ -109,6 +109,44 @@ int eemflow_upsample_bilinear(const float* in, float* out, int nc, int h, int w,
 int eemflow_voxelize(const double* events, int64_t n, int bins, int h, int w, int normalize, float* grid,
                      int64_t* idx_left, int64_t* idx_right, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * E-RAFT (model/eraft.py): feature / context encoders, all-pairs correlation pyramid, 9x9 x 4-level
+ * lookup, SepConvGRU update block, convex upsampling.  Inference (eval-mode BatchNorm).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct eraft_ctx eraft_ctx;
+
+/* Replaces: ERAFT.__init__ + .to(device)  (model/eraft.py:40-62). */
+int eraft_create(int device, eraft_ctx** out);
+void eraft_destroy(eraft_ctx* ctx);
+
+/* All float tensors of the reference state_dict() (179 entries; the integer num_batches_tracked buffers are
+ * skipped) back to back in registration order: fnet.*, cnet.* (BatchNorm weight, bias, running_mean,
+ * running_var; the aliased downsample.1.* entries are present, as in the checkpoint), update_block.*.
+ * Replaces: load_state_dict for model/eraft.py:57-62 modules. */
+int eraft_load_weights(eraft_ctx* ctx, const float* flat_host, size_t nfloats, int n_first_channels);
+
+/* events1/2 [batch][C][in_h][in_w]; pad = [left, right, top, bottom] from InputPadder(img_size, 'chairs', 32)
+ * (model/eraft.py:65-67); flow_init [batch][2][H/8][W/8] of the padded size or NULL.
+ * flow_out [iters][batch][2][in_h][in_w]: every iteration's convex-upsampled, unpadded flow.
+ * Replaces: ERAFT.forward(events1, events2, iters, flow_init)[1]  (model/eraft.py:97-159). */
+int eraft_forward(eraft_ctx* ctx, const float* events1, const float* events2, int batch, int in_h, int in_w,
+                  const int pad[4], int iters, const float* flow_init, float* flow_out, void* stream);
+
+/* Intermediates of the LAST forward: "fmap" ([2B,256,h,w]: fmap1 then fmap2), "inp", "corr0" (first lookup),
+ * "net1", "mask1", "delta1" (after the first update), "flow_low", "pyr0".."pyr3". */
+int eraft_get_stage(eraft_ctx* ctx, const char* name, float* dst, size_t dst_capacity_floats, int dims_out[4],
+                    void* stream);
+
+/* CorrBlock(fmap1, fmap2, num_levels=4, radius=4)(coords): fmaps [batch][c][h][w], coords [batch][2][h][w]
+ * -> out [batch][324][h][w].  Replaces: model/corr.py:13-60 (+ model/model_utils.py:7-21). */
+int eraft_corr_lookup(eraft_ctx* ctx, const float* fmap1, const float* fmap2, const float* coords, int batch, int c,
+                      int h, int w, float* out, void* stream);
+
+/* Convex upsampling: flow [batch][2][h][w], mask [batch][576][h][w] -> out [batch][2][8h][8w].
+ * Replaces: ERAFT.upsample_flow  (model/eraft.py:83-94). */
+int eraft_convex_upsample(eraft_ctx* ctx, const float* flow, const float* mask, int batch, int h, int w, float* out,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

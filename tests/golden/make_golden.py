@@ -325,11 +325,11 @@ def gen_eraft_lookup():
     """CorrBlock on small random maps with fractional, negative and out-of-range coordinates (model/corr.py)."""
     from model.corr import CorrBlock
     rng = np.random.default_rng(31)
-    f1 = rng.standard_normal((2, 16, 9, 11), dtype=np.float32)
-    f2 = rng.standard_normal((2, 16, 9, 11), dtype=np.float32)
-    coords = rng.uniform(-6, 16, size=(2, 2, 9, 11)).astype(np.float32)
+    f1 = rng.standard_normal((2, 16, 17, 19), dtype=np.float32)
+    f2 = rng.standard_normal((2, 16, 17, 19), dtype=np.float32)
+    coords = rng.uniform(-6, 25, size=(2, 2, 17, 19)).astype(np.float32)
     coords[0, :, 0, 0] = [3.0, 4.0]                        # exactly on a grid point
-    coords[0, :, 0, 1] = [10.0, 8.0]                       # exactly on the last column / row
+    coords[0, :, 0, 1] = [18.0, 16.0]                      # exactly on the last column / row
     with torch.no_grad():
         cb = CorrBlock(torch.from_numpy(f1), torch.from_numpy(f2), radius=4)
         out = cb(torch.from_numpy(coords))
@@ -363,8 +363,10 @@ def main():
     gen_eraft_layout()
     gen_eraft_lookup()
     gen_eraft_upsample()
-    gen_eraft("96x128", seed=7, batch=1, h=96, w=128, iters=3, keep=True)
-    gen_eraft("100x150", seed=8, batch=2, h=100, w=150, iters=2, keep=False)
+    # the reference's bilinear_sampler divides by (W-1), (H-1): the 1/64-scale pyramid level must be >= 2x2,
+    # i.e. the padded input >= 128x128, or every output is NaN
+    gen_eraft("128x160", seed=7, batch=1, h=128, w=160, iters=3, keep=True)
+    gen_eraft("136x200", seed=8, batch=2, h=136, w=200, iters=2, keep=False)
 
 
 if __name__ == "__main__":

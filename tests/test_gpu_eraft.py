@@ -1,0 +1,122 @@
+"""E-RAFT on the GPU (through the C ABI) against reference-generated goldens and the oracle.  `pytest -m gpu`."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from eemflow_amd import _lib
+from eemflow_amd.eraft import ERAFT
+from eemflow_amd.eraft_weights import seeded_from_shapes
+from eemflow_amd.weights import synthetic_voxel_pair
+from oracle import eemflow_oracle as O
+from oracle import eraft_oracle as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+FLOW_TOL = 1e-3      # north star tolerance on flow (12 recurrent fp32 iterations amplify reordering noise)
+FEAT_TOL = 2e-4
+
+
+def make_net(seed):
+    net = ERAFT("", 5).eval()
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = seeded_from_shapes(shapes, seed)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return net.to(DEV), O.to_torch_sd(sd)
+
+
+def maxerr(a, b):
+    """max |a-b| over the positions where the reference b is finite (a 1x1 pyramid level divides by W-1 = 0 in
+    the reference's bilinear_sampler and yields NaN there); a must be finite wherever b is."""
+    a, b = torch.as_tensor(a).cpu().float(), torch.as_tensor(b).cpu().float()
+    ok = torch.isfinite(b)
+    assert bool(torch.isfinite(a[ok]).all())
+    return float((a[ok] - b[ok]).abs().max())
+
+
+def stream():
+    return _lib.current_stream_ptr(torch.device(DEV))
+
+
+def test_corr_lookup_golden(golden):
+    g = golden("eraft_lookup.npz")
+    net, _ = make_net(1)
+    ctx = net._context(torch.device(DEV))
+    f1, f2, co = (torch.from_numpy(g[k]).to(DEV) for k in ("f1", "f2", "coords"))
+    b, c, h, w = f1.shape
+    out = torch.empty(b, 324, h, w, device=DEV)
+    _lib.check(_lib.lib().eraft_corr_lookup(ctx, f1.data_ptr(), f2.data_ptr(), co.data_ptr(), b, c, h, w, out.data_ptr(), stream()))
+    for l in range(4):
+        assert maxerr(net.stage(f"pyr{l}"), g[f"pyr{l}"]) < 1e-5
+    assert maxerr(out, g["out"]) < 1e-5
+
+
+def test_convex_upsample_golden(golden):
+    g = golden("eraft_upsample.npz")
+    net, _ = make_net(1)
+    ctx = net._context(torch.device(DEV))
+    flow, mask = torch.from_numpy(g["flow"]).to(DEV), torch.from_numpy(g["mask"]).to(DEV)
+    b, _, h, w = flow.shape
+    out = torch.empty(b, 2, 8 * h, 8 * w, device=DEV)
+    _lib.check(_lib.lib().eraft_convex_upsample(ctx, flow.data_ptr(), mask.data_ptr(), b, h, w, out.data_ptr(), stream()))
+    assert maxerr(out, g["up"]) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["128x160", "136x200"])
+def test_forward_vs_golden(golden, tag):
+    g = golden(f"eraft_fwd_{tag}.npz")
+    h, w = g["hw"].tolist()
+    net, _ = make_net(int(g["seed"]))
+    net.change_imagesize((h, w))
+    assert net.image_padder._pad == g["pad"].tolist()
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(int(g["input_seed"]), int(g["batch"]), h, w))
+    with torch.no_grad():
+        (r1, r2), preds = net(e1, e2, iters=int(g["iters"]))
+    assert r1 is e1 and len(preds) == int(g["iters"]) and preds[0].shape == (int(g["batch"]), 2, h, w)
+    b = int(g["batch"])
+    if "fmap1" in g.files:
+        fm = net.stage("fmap")
+        assert maxerr(fm[:b], g["fmap1"]) < FEAT_TOL and maxerr(fm[b:], g["fmap2"]) < FEAT_TOL
+        assert maxerr(net.stage("inp"), g["inp"]) < FEAT_TOL
+        assert maxerr(net.stage("pyr1"), g["pyr1"]) < FEAT_TOL and maxerr(net.stage("pyr3"), g["pyr3"]) < FEAT_TOL
+        assert maxerr(net.stage("corr0"), g["corr0"]) < FEAT_TOL
+        assert maxerr(net.stage("net1"), g["net1"]) < FEAT_TOL
+        assert maxerr(net.stage("delta1"), g["delta1"]) < FEAT_TOL
+        assert maxerr(net.stage("mask1"), g["mask1"]) < FEAT_TOL
+    assert maxerr(torch.stack(preds), g["preds"]) < FLOW_TOL
+
+
+@pytest.mark.parametrize("b,h,w,iters", [(1, 128, 160, 2), (3, 136, 200, 4)])
+def test_forward_vs_oracle(b, h, w, iters):
+    net, sd = make_net(17)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(18, b, h, w))
+    with torch.no_grad():
+        preds = net(e1.to(DEV), e2.to(DEV), iters=iters)[1]
+        ref, _ = R.eraft_forward(sd, e1, e2, iters=iters)
+    assert maxerr(torch.stack(preds), torch.stack(ref)) < FLOW_TOL
+
+
+def test_flow_init_and_twelve_iterations():
+    h, w = 128, 128
+    net, sd = make_net(19)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(20, 1, h, w))
+    init = torch.randn(1, 2, 16, 16, generator=torch.Generator().manual_seed(2)) * 0.5
+    with torch.no_grad():
+        preds = net(e1.to(DEV), e2.to(DEV), iters=12, flow_init=init.to(DEV))[1]
+        ref, _ = R.eraft_forward(sd, e1, e2, iters=12, flow_init=init)
+    assert len(preds) == 12 and maxerr(preds[-1], ref[-1]) < FLOW_TOL
+
+
+def test_errors():
+    net, _ = make_net(1)
+    with pytest.raises(AttributeError):
+        net(torch.zeros(1, 5, 64, 64, device=DEV), torch.zeros(1, 5, 64, 64, device=DEV))
+    net.change_imagesize((64, 64))
+    with pytest.raises(_lib.EEMFlowHipError):
+        net(torch.zeros(1, 5, 64, 64), torch.zeros(1, 5, 64, 64))
+    net.train()
+    with pytest.raises(_lib.EEMFlowHipError):
+        net(torch.zeros(1, 5, 64, 64, device=DEV), torch.zeros(1, 5, 64, 64, device=DEV))

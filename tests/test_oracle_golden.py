@@ -102,7 +102,7 @@ def test_eraft_convex_upsample(golden):
     np.testing.assert_allclose(up.numpy(), g["up"], atol=1e-6)
 
 
-@pytest.mark.parametrize("tag", ["96x128", "100x150"])
+@pytest.mark.parametrize("tag", ["128x160", "136x200"])
 def test_eraft_forward(golden, tag):
     g = golden(f"eraft_fwd_{tag}.npz")
     h, w = g["hw"].tolist()
@@ -117,4 +117,5 @@ def test_eraft_forward(golden, tag):
     if "pyr1" in g.files:
         np.testing.assert_allclose(st["pyr"][1].numpy(), g["pyr1"], atol=1e-5)
         np.testing.assert_allclose(st["pyr"][3].numpy(), g["pyr3"], atol=1e-5)
+    assert np.isfinite(g["preds"]).all()
     np.testing.assert_allclose(torch.stack(preds).numpy(), g["preds"], atol=1e-4, rtol=1e-5)

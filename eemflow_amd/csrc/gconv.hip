@@ -68,24 +68,35 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvArgs a) {
                 const GConvSeg sg = a.seg[s];
                 const float* base = sg.ptr + ((size_t)n * sg.ctotal + sg.coff) * hwi;
                 const int cp_n = (sg.c + 1) >> 1;
-#pragma unroll 4
-                for (int cp = 0; cp < cp_n; ++cp, ++ks) {
-                    const int c = cp * 2 + h;
-                    const bool cv = c < sg.c;
-                    const float* bp = base + (size_t)(cv ? c : 0) * hwi;
-                    float av[MTW], bv[NPW];
+                // operands of U k-steps are requested before the first of their MFMAs: the loop is bound by
+                // L2 latency, not bandwidth, so memory-level parallelism is what counts
+                constexpr int U = (NPW * MTW == 1) ? 16 : 8;
+                for (int cp0 = 0; cp0 < cp_n; cp0 += U) {
+                    float av[U][MTW], bv[U][NPW];
 #pragma unroll
-                    for (int m = 0; m < MTW; ++m) av[m] = wp[((size_t)m * ksteps + ks) * 64];
+                    for (int u = 0; u < U; ++u) {
+                        const int cp = cp0 + u;
+                        const bool ok = cp < cp_n;
+                        const int c = cp * 2 + h;
+                        const bool cv = ok && c < sg.c;
+                        const float* bp = base + (size_t)(cv ? c : 0) * hwi;
+                        const int kk = ok ? ks + u : ks;
 #pragma unroll
-                    for (int t = 0; t < NPW; ++t) {
-                        const float x = bp[off[t]];
-                        bv[t] = (tv[t] && cv) ? x : 0.f;
+                        for (int m = 0; m < MTW; ++m) av[u][m] = wp[((size_t)m * ksteps + kk) * 64];
+#pragma unroll
+                        for (int t = 0; t < NPW; ++t) {
+                            const float x = bp[off[t]];
+                            bv[u][t] = (tv[t] && cv) ? x : 0.f;
+                        }
                     }
 #pragma unroll
-                    for (int t = 0; t < NPW; ++t)
+                    for (int u = 0; u < U; ++u)
 #pragma unroll
-                        for (int m = 0; m < MTW; ++m)
-                            acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[t], acc[t][m], 0, 0, 0);
+                        for (int t = 0; t < NPW; ++t)
+#pragma unroll
+                            for (int m = 0; m < MTW; ++m)
+                                acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][m], bv[u][t], acc[t][m], 0, 0, 0);
+                    ks += min(U, cp_n - cp0);
                 }
             }
         }

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""E-RAFT timing on the GPU box (BASELINE configs[4] shape: 640x480, 12 iterations)."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from eemflow_amd.eraft import ERAFT
+from eemflow_amd.eraft_weights import seeded_from_shapes
+from eemflow_amd.weights import synthetic_voxel_pair
+
+b = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+h, w, iters = 480, 640, 12
+net = ERAFT("", 5).eval()
+sd = seeded_from_shapes({k: tuple(v.shape) for k, v in net.state_dict().items()}, 0)
+net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+net = net.cuda(); net.change_imagesize((h, w))
+e1, e2 = (torch.from_numpy(a).cuda() for a in synthetic_voxel_pair(1, b, h, w))
+with torch.no_grad():
+    for _ in range(2): net(e1, e2, iters=iters)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    n = 5
+    for _ in range(n): net(e1, e2, iters=iters)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+print(f"E-RAFT {w}x{h} iters={iters} batch={b}: {dt*1e3:.2f} ms/forward, {b/dt:.2f} frames/s, {499.2*b/dt/1e3:.1f} TFLOP/s")

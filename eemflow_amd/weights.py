@@ -104,3 +104,15 @@ def synthetic_voxel_pair(seed, batch, height, width, bins=5, density=0.2):
         m = rng.random((batch, bins, height, width), dtype=np.float32) < density
         out.append((v * m).astype(np.float32))
     return out
+
+
+def synthetic_gt(seed, batch, h, w):
+    """Smooth ground-truth flow + validity mask with holes and a few |gt| > 400 pixels (numpy PCG64);
+    the same generator tests/golden/make_golden.py used for train_step.npz."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    gt = np.stack([3 * np.sin(2 * np.pi * xx / w + 0.3), 2 * np.cos(2 * np.pi * yy / h)])[None].repeat(batch, 0)
+    gt = (gt + rng.normal(0, 0.5, gt.shape)).astype(np.float32)
+    gt[:, :, 0, :3] = 500.0                                  # excluded by mag < MAX_FLOW
+    valid = (rng.random((batch, h, w)) < 0.8).astype(np.float32)
+    return gt, valid

@@ -348,6 +348,73 @@ def gen_eraft_upsample():
     save("eraft_upsample.npz", flow=flow, mask=mask, up=up.numpy())
 
 
+def synthetic_gt(seed, batch, h, w):
+    """Smooth ground-truth flow + validity mask with holes and a few |gt| > 400 pixels (numpy PCG64)."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    gt = np.stack([3 * np.sin(2 * np.pi * xx / w + 0.3), 2 * np.cos(2 * np.pi * yy / h)])[None].repeat(batch, 0)
+    gt = (gt + rng.normal(0, 0.5, gt.shape)).astype(np.float32)
+    gt[:, :, 0, :3] = 500.0                                  # excluded by mag < MAX_FLOW
+    valid = (rng.random((batch, h, w)) < 0.8).astype(np.float32)
+    return gt, valid
+
+
+def gen_train(mod):
+    """Reference module in train mode + the reference's own sequence_loss (train_mvsec.py:201-227, exec'd from
+    source) + torch AdamW / OneCycleLR / clip_grad_norm_ as train_mvsec.py:178-183,241-258 order them."""
+    import textwrap
+    src = open(f"{REF}/train_mvsec.py").read().splitlines()[200:227]
+    ns = {"torch": torch, "MAX_FLOW": 400}
+    exec(textwrap.dedent("\n".join(src)), ns)
+    ref_loss = ns["sequence_loss"]
+    seed, batch, h, w = 9, 2, 64, 96
+    sd = seeded_state_dict(seed)
+    net = ref_eemflow(mod, sd).train()
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(seed + 3000, batch, h, w))
+    gt, valid = (torch.from_numpy(a) for a in synthetic_gt(seed + 3001, batch, h, w))
+    (_, _), preds = net(e1, e2)
+    loss, metrics = ref_loss(None, preds, gt, valid, 0.8)
+    loss.backward()
+    grads = {k: p.grad.detach().numpy() for k, p in net.named_parameters()}
+    arrays = dict(seed=np.int64(seed), input_seed=np.int64(seed + 3000), gt_seed=np.int64(seed + 3001), batch=np.int64(batch),
+                  hw=np.array([h, w]), loss=np.float64(loss.item()), epe=np.float64(metrics["epe"]),
+                  px1=np.float64(metrics["1px"]), flow=preds[0].detach().numpy(),
+                  grad_keys=np.array(list(grads.keys())),
+                  grad_norms=np.array([np.sqrt((g.astype(np.float64) ** 2).sum()) for g in grads.values()]),
+                  grad_sums=np.array([g.astype(np.float64).sum() for g in grads.values()]))
+    for k in ("pconv1_1.0.weight", "pconv1_1.0.bias", "pconv2_2.0.weight", "pconv3_3.0.bias", "rconv_2.0.weight",
+              "decoder_1.conv1.0.weight", "decoder_2.conv3.0.weight", "decoder_3.conv7.weight", "decoder_3.conv7.bias",
+              "out_conv.weight", "out_conv.bias"):
+        arrays["g:" + k] = grads[k]
+    # 3 optimisation steps on 3 different batches (lr 1e-3 so the trajectory is visible in fp32)
+    net = ref_eemflow(mod, sd).train()
+    net.change_imagesize((h, w))
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=5e-5, eps=1e-8)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, 1e-3, 20 + 100, pct_start=0.05, cycle_momentum=False,
+                                                anneal_strategy="linear")
+    losses, lrs = [], []
+    for step in range(3):
+        e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(seed + 3100 + step, batch, h, w))
+        gt, valid = (torch.from_numpy(a) for a in synthetic_gt(seed + 3200 + step, batch, h, w))
+        opt.zero_grad()
+        (_, _), preds = net(e1, e2)
+        loss, _ = ref_loss(None, preds, gt, valid, 0.8)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sched.step()
+        losses.append(loss.item())
+    final = net.state_dict()
+    arrays.update(step_losses=np.array(losses), step_lrs=np.array(lrs),
+                  final_sums=np.array([v.double().sum().item() for v in final.values()]),
+                  final_norms=np.array([v.double().norm().item() for v in final.values()]))
+    for k in ("pconv1_1.0.weight", "decoder_2.conv3.0.weight", "out_conv.weight", "out_conv.bias"):
+        arrays["p3:" + k] = final[k].numpy()
+    save("train_step.npz", **arrays)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(4)
@@ -360,6 +427,7 @@ def main():
     gen_eemflow(mod, "260x346", seed=2, batch=1, h=260, w=346, keep_stages=False)
     gen_eemflow(mod, "100x150", seed=4, batch=1, h=100, w=150, keep_stages=False)
     gen_voxel(lu)
+    gen_train(mod)
     gen_eraft_layout()
     gen_eraft_lookup()
     gen_eraft_upsample()

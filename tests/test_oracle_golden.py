@@ -119,3 +119,46 @@ def test_eraft_forward(golden, tag):
         np.testing.assert_allclose(st["pyr"][3].numpy(), g["pyr3"], atol=1e-5)
     assert np.isfinite(g["preds"]).all()
     np.testing.assert_allclose(torch.stack(preds).numpy(), g["preds"], atol=1e-4, rtol=1e-5)
+
+
+# ----------------------------------------------------------------------------- training step (A14)
+from oracle import train_oracle as T   # noqa: E402
+
+
+def test_train_loss_and_grads(golden):
+    from eemflow_amd.weights import synthetic_gt
+    g = golden("train_step.npz")
+    h, w = g["hw"].tolist()
+    b = int(g["batch"])
+    sd = O.to_torch_sd(seeded_state_dict(int(g["seed"])))
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(int(g["input_seed"]), b, h, w))
+    gt, valid = (torch.from_numpy(a) for a in synthetic_gt(int(g["gt_seed"]), b, h, w))
+    loss, metrics, grads, flow = T.loss_and_grads(sd, e1, e2, gt, valid)
+    assert abs(loss - float(g["loss"])) < 1e-6 and abs(metrics["epe"] - float(g["epe"])) < 1e-5
+    np.testing.assert_allclose(flow.numpy(), g["flow"], atol=2e-6)
+    assert list(grads.keys()) == g["grad_keys"].tolist()
+    norms = np.array([float(v.double().norm()) for v in grads.values()])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-4, atol=1e-7)
+    for k in g.files:
+        if k.startswith("g:"):
+            np.testing.assert_allclose(grads[k[2:]].numpy(), g[k], rtol=1e-3, atol=2e-6, err_msg=k)
+
+
+def test_train_three_steps(golden):
+    from eemflow_amd.weights import synthetic_gt
+    g = golden("train_step.npz")
+    h, w = g["hw"].tolist()
+    b, seed = int(g["batch"]), int(g["seed"])
+    sd = O.to_torch_sd(seeded_state_dict(seed))
+    batches = []
+    for step in range(3):
+        e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(seed + 3100 + step, b, h, w))
+        gt, valid = (torch.from_numpy(a) for a in synthetic_gt(seed + 3200 + step, b, h, w))
+        batches.append((e1, e2, gt, valid))
+    losses, lrs, final = T.train_steps(sd, batches, lr=1e-3, num_steps=20)
+    np.testing.assert_allclose(losses, g["step_losses"], rtol=1e-5)
+    np.testing.assert_allclose(lrs, g["step_lrs"], rtol=1e-7)
+    np.testing.assert_allclose([float(v.double().norm()) for v in final.values()], g["final_norms"], rtol=1e-5)
+    for k in g.files:
+        if k.startswith("p3:"):
+            np.testing.assert_allclose(final[k[3:]].numpy(), g[k], atol=2e-5, err_msg=k)

@@ -6,8 +6,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/eemflow_hip.h"
-#include "common.h"
+#include "api_internal.h"
 
 // ------------------------------------------------------------------------------- errors
 static thread_local char g_err[512] = "";
@@ -21,344 +20,6 @@ void eem_set_error(const char* fmt, ...) {
 
 extern "C" const char* eemflow_last_error(void) { return g_err; }
 extern "C" int eemflow_abi_version(void) { return 1; }
-
-// ------------------------------------------------------------------------------- context
-namespace {
-
-const int kTaps53[53] = {0,  2,  4,  6,  8,  10, 12, 14, 16, 18, 20, 21, 22, 23, 24, 26, 28, 29,
-                         30, 31, 32, 33, 34, 36, 38, 39, 40, 41, 42, 44, 46, 47, 48, 49, 50, 51,
-                         52, 54, 56, 57, 58, 59, 60, 62, 64, 66, 68, 70, 72, 74, 76, 78, 80};
-constexpr int kNTaps = 53;
-constexpr int kDecIn = kNTaps + 16;   // 69
-constexpr int kDecW = 100;
-
-struct TailW {                         // one packed small-grid conv
-    size_t wpk = 0, bias = 0;          // float offsets into the weight arena
-    int cin = 0, cout = 0, ksize = 3;
-};
-
-struct DevBuf {
-    float* p = nullptr;
-    size_t cap = 0;                    // floats
-};
-
-struct Shape {
-    int batch = 0, in_h = 0, in_w = 0, out_h = 0, out_w = 0;
-    int hp = 0, wp = 0;                // padded extent
-    int h1 = 0, w1 = 0, h2 = 0, w2 = 0, h3 = 0, w3 = 0;
-    int gh = 0, gw = 0;                // 1/64 grid
-    // fused stage pooling (fast path): partial-sum buffer dims per stage, fuse[k] = conv epilogue pools stage k
-    bool fuse[3] = {false, false, false};
-    int prow[3] = {0, 0, 0}, pcol[3] = {0, 0, 0}, th[3] = {0, 0, 0};
-};
-
-}  // namespace
-
-struct eemflow_ctx {
-    int device = 0;
-    bool weights_loaded = false;
-    int cin0 = 5, groups = 5;
-    // padder
-    bool have_pad = false;
-    int pad[4] = {0, 0, 0, 0};
-    // weights
-    float* arena = nullptr;
-    size_t enc_w[ENC_NUM], enc_w2[ENC_NUM], enc_b[ENC_NUM];
-    bool enc_has2[ENC_NUM];
-    float* zero_page = nullptr;
-    TailW rconv[3], dconv1[3], dgroup[3][3][5], dconv5[3], dconv6[3], dconv7[3], outc;
-    int* taps = nullptr;
-    // workspaces
-    DevBuf a1, f11, a2, b2, f12, a3, b3, f13, pool[3], ppart[3], cat[3], ta[3], tb[3], t64[3], t32[3], flowcat, coarse;
-    void* vox_scratch = nullptr;
-    Shape last;
-    bool have_last = false;
-    // graph cache
-    bool use_graph = true;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-    struct Key {
-        const float *e1, *e2;
-        float* out;
-        int batch, in_h, in_w, out_h, out_w, pad[4];
-    } graph_key;
-    bool have_graph = false;
-};
-
-namespace {
-
-int ensure(DevBuf& b, size_t floats) {
-    if (floats <= b.cap) return EEM_OK;
-    if (b.p) EEM_HIP_CHECK(hipFree(b.p));
-    b.p = nullptr;
-    b.cap = 0;
-    EEM_HIP_CHECK(hipMalloc(&b.p, floats * sizeof(float)));
-    b.cap = floats;
-    return EEM_OK;
-}
-
-void drop_graph(eemflow_ctx* c) {
-    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
-    if (c->graph) (void)hipGraphDestroy(c->graph);
-    c->graph_exec = nullptr;
-    c->graph = nullptr;
-    c->have_graph = false;
-}
-
-int compute_shape(eemflow_ctx* c, int batch, int in_h, int in_w, int out_h, int out_w, Shape* s) {
-    s->batch = batch; s->in_h = in_h; s->in_w = in_w; s->out_h = out_h; s->out_w = out_w;
-    s->hp = in_h + c->pad[2] + c->pad[3];
-    s->wp = in_w + c->pad[0] + c->pad[1];
-    auto half = [](int v) { return (v - 1) / 2 + 1; };          // conv k3 s2 p1
-    s->h1 = half(s->hp); s->w1 = half(s->wp);
-    s->h2 = half(s->h1); s->w2 = half(s->w1);
-    s->h3 = half(s->h2); s->w3 = half(s->w2);
-    s->gh = s->h1 / 32; s->gw = s->w1 / 32;
-    EEM_REQUIRE(s->gh >= 1 && s->gw >= 1, "input %dx%d (padded %dx%d) is too small for the 1/64 grid", in_h, in_w,
-                s->hp, s->wp);
-    // the reference concatenates the three decoders' flows (EEMFlow.py:179): the three pooled grids
-    // must agree or torch.cat raises
-    EEM_REQUIRE(s->h2 / 16 == s->gh && s->h3 / 8 == s->gh && s->w2 / 16 == s->gw && s->w3 / 8 == s->gw,
-                "pooled grids of the three stages differ for padded size %dx%d (the reference's torch.cat "
-                "fails too)", s->hp, s->wp);
-    // stage pooling can ride in the epilogue of pconv1_2 / pconv2_3 / pconv3_3 when those run the fast path
-    const int last[3] = {ENC_1_2, ENC_2_3, ENC_3_3};
-    const int hs[3] = {s->h1, s->h2, s->h3}, ws[3] = {s->w1, s->w2, s->w3}, ks[3] = {32, 16, 8};
-    for (int k = 0; k < 3; ++k) {
-        const EncLayerDesc& d = kEncLayers[last[k]];
-        int th, tw, pk;
-        enc2_tile(d.cin, d.cout, &th, &tw, &pk);
-        s->fuse[k] = c->enc_has2[last[k]] && enc2_supported(d.cin, d.cout, d.stride, ws[k]) && pk == ks[k];
-        s->th[k] = th;
-        s->prow[k] = ceil_div(hs[k], th);
-        s->pcol[k] = ceil_div(ws[k], tw) * (tw / ks[k]);
-    }
-    return EEM_OK;
-}
-
-int alloc_workspace(eemflow_ctx* c, const Shape& s) {
-    const size_t n2 = 2 * (size_t)s.batch, B = s.batch, g = (size_t)s.gh * s.gw;
-    int rc;
-#define ENS(buf, n) if ((rc = ensure(buf, n)) != EEM_OK) return rc
-    ENS(c->a1, n2 * 16 * s.h1 * s.w1);  ENS(c->f11, n2 * 16 * s.h1 * s.w1);
-    ENS(c->a2, n2 * 32 * s.h2 * s.w2);  ENS(c->b2, n2 * 32 * s.h2 * s.w2);  ENS(c->f12, n2 * 32 * s.h2 * s.w2);
-    ENS(c->a3, n2 * 64 * s.h3 * s.w3);  ENS(c->b3, n2 * 64 * s.h3 * s.w3);  ENS(c->f13, n2 * 64 * s.h3 * s.w3);
-    const int pc[3] = {16, 32, 64};
-    for (int k = 0; k < 3; ++k) {
-        ENS(c->pool[k], n2 * pc[k] * g);
-        if (s.fuse[k]) ENS(c->ppart[k], n2 * pc[k] * (size_t)s.prow[k] * s.pcol[k]);
-        ENS(c->cat[k], B * kDecIn * g);
-        ENS(c->ta[k], B * kDecW * g);   ENS(c->tb[k], B * kDecW * g);
-        ENS(c->t64[k], B * 64 * g);     ENS(c->t32[k], B * 32 * g);
-    }
-    ENS(c->flowcat, B * 6 * g);  ENS(c->coarse, B * 2 * g);
-#undef ENS
-    return EEM_OK;
-}
-
-TailConvJob make_job(const eemflow_ctx* c, const TailW& w, const float* in, int in_ctotal, int in_coff, float* out,
-                     int out_ctotal, int out_coff, int out_cmul, int act) {
-    TailConvJob j;
-    j.in = in; j.wpk = c->arena + w.wpk; j.bias = c->arena + w.bias; j.out = out;
-    j.cin = w.cin; j.cout = w.cout;
-    j.in_ctotal = in_ctotal; j.in_coff = in_coff;
-    j.out_ctotal = out_ctotal; j.out_coff = out_coff; j.out_cmul = out_cmul; j.act = act;
-    return j;
-}
-
-// Every kernel launch of the schedule goes through a Hook: normally it just launches; in timing mode
-// (eemflow_time_kernels) it launches the same kernel `reps` times back to back between two HIP
-// events on the launch stream and records the average duration with its algorithmic FLOPs / bytes.
-struct Hook {
-    hipStream_t st = nullptr;
-    bool timing = false;
-    int reps = 1;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::vector<eemflow_kernel_stat> stats;
-
-    template <class F>
-    int run(const char* name, double flops, double bytes, F&& launch) {
-        if (!timing) return launch(st);
-        int rc = launch(st);                                  // warm (also keeps data flowing downstream)
-        if (rc != EEM_OK) return rc;
-        EEM_HIP_CHECK(hipEventRecord(ev0, st));
-        for (int i = 0; i < reps; ++i)
-            if ((rc = launch(st)) != EEM_OK) return rc;
-        EEM_HIP_CHECK(hipEventRecord(ev1, st));
-        EEM_HIP_CHECK(hipEventSynchronize(ev1));
-        float ms = 0.f;
-        EEM_HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
-        eemflow_kernel_stat ks;
-        memset(&ks, 0, sizeof(ks));
-        strncpy(ks.name, name, sizeof(ks.name) - 1);
-        ks.flops = flops; ks.bytes = bytes; ks.ms = ms / (float)reps;
-        stats.push_back(ks);
-        return EEM_OK;
-    }
-};
-
-double tail_flops(const TailConvLaunch& L) {
-    double f = 0;
-    for (int i = 0; i < L.njobs; ++i)
-        f += 2.0 * L.batch * L.h * L.w * (double)L.job[i].cout * L.job[i].cin * L.ksize * L.ksize;
-    return f;
-}
-double tail_bytes(const TailConvLaunch& L) {
-    double b = 0;
-    for (int i = 0; i < L.njobs; ++i)
-        b += 4.0 * ((double)L.batch * L.h * L.w * (L.job[i].cin + L.job[i].cout) +
-                    (double)L.job[i].cout * L.job[i].cin * L.ksize * L.ksize + L.job[i].cout);
-    return b;
-}
-int run_tail(Hook& hk, const char* name, const TailConvLaunch& L) {
-    return hk.run(name, tail_flops(L), tail_bytes(L), [&](hipStream_t st) { return tail_conv_launch(L, st); });
-}
-
-// decoder convs 1..7 for decoders [k0,k1); input cat buffers `cat[k]`, final 2-ch flow of decoder k goes to
-// channels [2*(k-kbase), +2) of `flow_dst` (which has flow_ctotal channels)
-int run_decoders(eemflow_ctx* c, int k0, int k1, const float* const cat[3], int batch, int h, int w, float* flow_dst,
-                 int flow_ctotal, int kbase, Hook& hk) {
-    int rc;
-    TailConvLaunch L;
-    L.batch = batch; L.h = h; L.w = w; L.ksize = 3;
-    // conv1: 69 -> 100
-    L.njobs = 0;
-    for (int k = k0; k < k1; ++k) L.job[L.njobs++] = make_job(c, c->dconv1[k], cat[k], kDecIn, 0, c->ta[k].p, kDecW, 0, 1, 1);
-    if ((rc = run_tail(hk, "dec.conv1 69->100", L)) != EEM_OK) return rc;
-    // conv2..4: grouped 100 -> 100, each followed by channel_shuffle (EEMFlow.py:51-57):
-    // group g, in-group channel j lands in channel j*groups + g
-    const int G = c->groups, per = kDecW / G;
-    const char* gname[3] = {"dec.conv2 grouped+shuffle", "dec.conv3 grouped+shuffle", "dec.conv4 grouped+shuffle"};
-    for (int layer = 0; layer < 3; ++layer) {
-        L.njobs = 0;
-        for (int k = k0; k < k1; ++k) {
-            float* src = (layer & 1) ? c->tb[k].p : c->ta[k].p;
-            float* dst = (layer & 1) ? c->ta[k].p : c->tb[k].p;
-            for (int g = 0; g < G; ++g) {
-                if (G == 1) L.job[L.njobs++] = make_job(c, c->dgroup[k][layer][g], src, kDecW, 0, dst, kDecW, 0, 1, 1);
-                else L.job[L.njobs++] = make_job(c, c->dgroup[k][layer][g], src, kDecW, g * per, dst, kDecW, g, G, 1);
-            }
-        }
-        if ((rc = run_tail(hk, gname[layer], L)) != EEM_OK) return rc;
-    }
-    // after three layers the result sits in tb
-    L.njobs = 0;
-    for (int k = k0; k < k1; ++k) L.job[L.njobs++] = make_job(c, c->dconv5[k], c->tb[k].p, kDecW, 0, c->t64[k].p, 64, 0, 1, 1);
-    if ((rc = run_tail(hk, "dec.conv5 100->64", L)) != EEM_OK) return rc;
-    L.njobs = 0;
-    for (int k = k0; k < k1; ++k) L.job[L.njobs++] = make_job(c, c->dconv6[k], c->t64[k].p, 64, 0, c->t32[k].p, 32, 0, 1, 1);
-    if ((rc = run_tail(hk, "dec.conv6 64->32", L)) != EEM_OK) return rc;
-    L.njobs = 0;
-    for (int k = k0; k < k1; ++k)
-        L.job[L.njobs++] = make_job(c, c->dconv7[k], c->t32[k].p, 32, 0, flow_dst, flow_ctotal, 2 * (k - kbase), 1, 0);
-    return run_tail(hk, "dec.conv7 32->2", L);
-}
-
-int run_forward(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2, float* out, Hook& hk) {
-    int rc;
-    const int n2 = 2 * s.batch;
-    // ---- encoder (both event volumes as one batch; shared weights, EEMFlow.py:135-140)
-    struct Step { int layer; const char* name; const float* in; float* out; int hin, win, hout, wout; };
-    const Step steps[ENC_NUM] = {
-        {ENC_1_1, "enc.pconv1_1 5->16 s2 +pad", nullptr, c->a1.p, s.hp, s.wp, s.h1, s.w1},
-        {ENC_1_2, "enc.pconv1_2 16->16", c->a1.p, c->f11.p, s.h1, s.w1, s.h1, s.w1},
-        {ENC_2_1, "enc.pconv2_1 16->32 s2", c->f11.p, c->a2.p, s.h1, s.w1, s.h2, s.w2},
-        {ENC_2_2, "enc.pconv2_2 32->32", c->a2.p, c->b2.p, s.h2, s.w2, s.h2, s.w2},
-        {ENC_2_3, "enc.pconv2_3 32->32", c->b2.p, c->f12.p, s.h2, s.w2, s.h2, s.w2},
-        {ENC_3_1, "enc.pconv3_1 32->64 s2", c->f12.p, c->a3.p, s.h2, s.w2, s.h3, s.w3},
-        {ENC_3_2, "enc.pconv3_2 64->64", c->a3.p, c->b3.p, s.h3, s.w3, s.h3, s.w3},
-        {ENC_3_3, "enc.pconv3_3 64->64", c->b3.p, c->f13.p, s.h3, s.w3, s.h3, s.w3}};
-    for (const Step& sp : steps) {
-        EncConvArgs a;
-        const EncLayerDesc& d = kEncLayers[sp.layer];
-        a.in0 = sp.layer == ENC_1_1 ? e1 : sp.in;
-        a.in1 = sp.layer == ENC_1_1 ? e2 : nullptr;
-        a.wpk = c->arena + c->enc_w[sp.layer];
-        a.wpk2 = c->enc_has2[sp.layer] ? c->arena + c->enc_w2[sp.layer] : nullptr;
-        a.zero_page = c->zero_page;
-        a.trash = c->zero_page + 64;
-        a.bias = c->arena + c->enc_b[sp.layer];
-        a.out = sp.out;
-        a.nimg = n2; a.nimg0 = sp.layer == ENC_1_1 ? s.batch : n2;
-        a.hin = sp.hin; a.win = sp.win; a.hout = sp.hout; a.wout = sp.wout;
-        a.hraw = sp.layer == ENC_1_1 ? s.in_h : sp.hin;
-        a.wraw = sp.layer == ENC_1_1 ? s.in_w : sp.win;
-        a.pad_top = sp.layer == ENC_1_1 ? c->pad[2] : 0;
-        a.pad_left = sp.layer == ENC_1_1 ? c->pad[0] : 0;
-        a.act = 1;
-        a.pool_partial = nullptr;
-        a.pool_k = 0;
-        for (int k = 0; k < 3; ++k)
-            if (s.fuse[k] && sp.layer == (k == 0 ? ENC_1_2 : k == 1 ? ENC_2_3 : ENC_3_3)) {
-                a.pool_partial = c->ppart[k].p;
-                a.pool_k = k == 0 ? 32 : k == 1 ? 16 : 8;
-            }
-        const double opix = (double)n2 * sp.hout * sp.wout;
-        const double flops = 2.0 * opix * d.cout * d.cin * 9;
-        const double ipix = sp.layer == ENC_1_1 ? (double)n2 * s.in_h * s.in_w : (double)n2 * sp.hin * sp.win;
-        const double bytes = 4.0 * (ipix * d.cin + opix * d.cout + (double)d.cout * d.cin * 9 + d.cout);
-        rc = hk.run(sp.name, flops, bytes,
-                    [&](hipStream_t st) { return enc_conv_launch(d.cin, d.cout, d.stride, a, st); });
-        if (rc != EEM_OK) return rc;
-    }
-    // ---- stage pooling to the common 1/64 grid (EEMFlow.py:144-154): finish the partial sums the conv
-    // epilogues wrote; stages whose conv ran the generic kernel are pooled from the stored feature map
-    {
-        const float* feat[3] = {c->f11.p, c->f12.p, c->f13.p};
-        const int pcs[3] = {16, 32, 64}, hs[3] = {s.h1, s.h2, s.h3}, ws[3] = {s.w1, s.w2, s.w3}, ks[3] = {32, 16, 8};
-        PoolFinJob fj[3];
-        PoolJob pj[3];
-        int nf = 0, np = 0;
-        double fin_elems = 0, pool_elems = 0;
-        for (int k = 0; k < 3; ++k) {
-            if (s.fuse[k]) {
-                fj[nf++] = {c->ppart[k].p, c->pool[k].p, pcs[k], s.prow[k], s.pcol[k], ks[k] / s.th[k], ks[k]};
-                fin_elems += (double)n2 * pcs[k] * s.gh * s.gw * (ks[k] / s.th[k] + 1);
-            } else {
-                pj[np++] = {feat[k], c->pool[k].p, pcs[k], hs[k], ws[k], ks[k]};
-                pool_elems += (double)n2 * pcs[k] * hs[k] * ws[k];
-            }
-        }
-        if (nf) {
-            rc = hk.run("pool finalize (fused partials)", fin_elems, 4.0 * fin_elems, [&](hipStream_t st) {
-                return pool_finalize_launch(fj, nf, n2, s.gh, s.gw, st);
-            });
-            if (rc != EEM_OK) return rc;
-        }
-        if (np) {
-            rc = hk.run("pool 32/16/8", pool_elems, 4.0 * pool_elems,
-                        [&](hipStream_t st) { return pool_launch(pj, np, n2, st); });
-            if (rc != EEM_OK) return rc;
-        }
-    }
-    // ---- correlation (53 taps) and rconv into the decoders' input [cv | r] (EEMFlow.py:160-163)
-    const size_t g = (size_t)s.gh * s.gw;
-    const int pc[3] = {16, 32, 64};
-    CorrJob cj[3];
-    for (int k = 0; k < 3; ++k)
-        cj[k] = {c->pool[k].p, c->pool[k].p + (size_t)s.batch * pc[k] * g, c->cat[k].p, pc[k], kDecIn};
-    rc = hk.run("local_corr 9x9 (53 taps)", 2.0 * s.batch * g * kNTaps * (16 + 32 + 64),
-                4.0 * s.batch * g * (2.0 * (16 + 32 + 64) + 3.0 * kNTaps),
-                [&](hipStream_t st) { return corr_launch(cj, 3, s.batch, s.gh, s.gw, c->taps, kNTaps, st); });
-    if (rc != EEM_OK) return rc;
-    TailConvLaunch L;
-    L.batch = s.batch; L.h = s.gh; L.w = s.gw; L.ksize = 3; L.njobs = 0;
-    for (int k = 0; k < 3; ++k)
-        L.job[L.njobs++] = make_job(c, c->rconv[k], c->pool[k].p, pc[k], 0, c->cat[k].p, kDecIn, kNTaps, 1, 1);
-    if ((rc = run_tail(hk, "rconv {16,32,64}->16", L)) != EEM_OK) return rc;
-    // ---- decoders, out_conv, upsample (EEMFlow.py:164-181)
-    const float* cats[3] = {c->cat[0].p, c->cat[1].p, c->cat[2].p};
-    if ((rc = run_decoders(c, 0, 3, cats, s.batch, s.gh, s.gw, c->flowcat.p, 6, 0, hk)) != EEM_OK) return rc;
-    L.ksize = 1; L.njobs = 1;
-    L.job[0] = make_job(c, c->outc, c->flowcat.p, 6, 0, c->coarse.p, 2, 0, 1, 0);
-    if ((rc = run_tail(hk, "out_conv 1x1 6->2", L)) != EEM_OK) return rc;
-    const double opix = (double)s.batch * 2 * s.out_h * s.out_w;
-    return hk.run("upsample bilinear", 8.0 * opix, 4.0 * (opix + (double)s.batch * 2 * g), [&](hipStream_t st) {
-        return upsample_launch(c->coarse.p, out, s.batch * 2, s.gh, s.gw, s.out_h, s.out_w, st);
-    });
-}
-
-}  // namespace
 
 // ------------------------------------------------------------------------------- C ABI
 extern "C" int eemflow_create(int device, eemflow_ctx** out) {
@@ -391,14 +52,19 @@ extern "C" void eemflow_destroy(eemflow_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     drop_graph(c);
-    DevBuf* bufs[] = {&c->a1, &c->f11, &c->a2, &c->b2, &c->f12, &c->a3, &c->b3, &c->f13, &c->flowcat, &c->coarse};
+    DevBuf* bufs[] = {&c->a1, &c->f11, &c->a2, &c->b2, &c->f12, &c->a3, &c->b3, &c->f13, &c->flowcat, &c->coarse,
+                      &c->padded, &c->g_a1, &c->g_f11, &c->g_a2, &c->g_b2, &c->g_f12, &c->g_a3, &c->g_b3, &c->g_f13,
+                      &c->g_flowcat, &c->g_coarse, &c->g_flow, &c->ups_tmp, &c->grad_flat, &c->adam_m, &c->adam_v, &c->scalars};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     for (int k = 0; k < 3; ++k) {
         if (c->ppart[k].p) (void)hipFree(c->ppart[k].p);
-        DevBuf* kb[] = {&c->pool[k], &c->cat[k], &c->ta[k], &c->tb[k], &c->t64[k], &c->t32[k]};
+        DevBuf* kb[] = {&c->pool[k], &c->cat[k], &c->ta[k], &c->tb[k], &c->tc[k], &c->td[k], &c->t64[k], &c->t32[k],
+                        &c->g_pool[k], &c->g_cat[k], &c->g_ta[k], &c->g_tb[k], &c->g_tc[k], &c->g_td[k], &c->g_t64[k], &c->g_t32[k]};
         for (DevBuf* b : kb) if (b->p) (void)hipFree(b->p);
     }
     if (c->arena) (void)hipFree(c->arena);
+    if (c->flat) (void)hipFree(c->flat);
+    if (c->pack_idx) (void)hipFree(c->pack_idx);
     if (c->taps) (void)hipFree(c->taps);
     if (c->zero_page) (void)hipFree(c->zero_page);
     if (c->vox_scratch) (void)hipFree(c->vox_scratch);
@@ -427,10 +93,30 @@ extern "C" int eemflow_load_weights(eemflow_ctx* c, const float* flat, size_t nf
     EEM_REQUIRE(nfloats == expect, "eemflow_load_weights: expected %zu floats for the 66-tensor layout, got %zu",
                 expect, nfloats);
 
-    // ---- pack everything into one host arena, then upload once
+    // ---- build the pack table: run the host packers on an "index-valued" copy of the flat vector (element i
+    // holds i+1, exactly representable in fp32; 0 marks zero padding).  The arena is then a pure gather of the
+    // device-resident flat weights, so an optimizer step re-packs on the device without touching the host.
+    std::vector<float> idxflat(nfloats);
+    for (size_t i = 0; i < nfloats; ++i) idxflat[i] = (float)(i + 1);
+    const float* const base = idxflat.data();
     std::vector<float> host;
     auto push = [&host](size_t n) { size_t off = host.size(); host.resize(off + ((n + 3) & ~(size_t)3), 0.f); return off; };
-    const float* p = flat;
+    // transposed + flipped weights T[ci][co][k-1-ky][k-1-kx] packed for gconv: the data gradient of a conv is a
+    // conv of the output gradient with T (transposed-stride for stride 2)
+    auto pack_T = [&](eemflow_ctx::ConvRef& r, const float* w, const float* b, int cin, int cout, int k, int stride) {
+        r.w = (size_t)(w - base); r.b = (size_t)(b - base); r.cin = cin; r.cout = cout; r.k = k; r.stride = stride;
+        std::vector<float> T((size_t)cin * cout * k * k);
+        for (int co = 0; co < cout; ++co)
+            for (int ci = 0; ci < cin; ++ci)
+                for (int ky = 0; ky < k; ++ky)
+                    for (int kx = 0; kx < k; ++kx)
+                        T[(((size_t)ci * cout + co) * k + (k - 1 - ky)) * k + (k - 1 - kx)] =
+                            w[(((size_t)co * cin + ci) * k + ky) * k + kx];
+        const int cs[1] = {cout};
+        r.wT = push(gconv_packed_floats(cin, cs, 1, k, k));
+        gconv_pack(T.data(), cin, cs, 1, k, k, host.data() + r.wT);
+    };
+    const float* p = base;
     for (int l = 0; l < ENC_NUM; ++l) {
         const int cin = l == 0 ? n_first_channels : kEncLayers[l].cin, cout = kEncLayers[l].cout;
         c->enc_w[l] = push(enc_packed_floats(cin, cout));
@@ -440,50 +126,65 @@ extern "C" int eemflow_load_weights(eemflow_ctx* c, const float* flat, size_t nf
             c->enc_w2[l] = push(enc2_packed_floats(cin, cout));
             enc2_pack_weights(p, cin, cout, host.data() + c->enc_w2[l]);
         }
+        pack_T(c->t_enc[l], p, p + (size_t)cout * cin * 9, cin, cout, 3, kEncLayers[l].stride);
         p += (size_t)cout * cin * 9;
         c->enc_b[l] = push(cout);
         memcpy(host.data() + c->enc_b[l], p, cout * sizeof(float));
         p += cout;
     }
-    auto tail = [&](TailW& t, int cin, int cout, int ksize, const float* w, const float* b) {
+    auto tail = [&](TailW& t, eemflow_ctx::ConvRef& r, int cin, int cout, int ksize, const float* w, const float* b) {
         t.cin = cin; t.cout = cout; t.ksize = ksize;
         t.wpk = push(tail_packed_floats(cin, cout, ksize));
         tail_pack_weights(w, cin, cout, ksize, host.data() + t.wpk);
         t.bias = push(cout);
         memcpy(host.data() + t.bias, b, cout * sizeof(float));
+        pack_T(r, w, b, cin, cout, ksize, 1);
     };
     for (int k = 0; k < 3; ++k) {
-        tail(c->rconv[k], rc_in[k], 16, 3, p, p + (size_t)16 * rc_in[k] * 9);
+        tail(c->rconv[k], c->t_rconv[k], rc_in[k], 16, 3, p, p + (size_t)16 * rc_in[k] * 9);
         p += (size_t)16 * rc_in[k] * 9 + 16;
     }
     for (int k = 0; k < 3; ++k) {
-        tail(c->dconv1[k], kDecIn, kDecW, 3, p, p + (size_t)kDecW * kDecIn * 9);
+        tail(c->dconv1[k], c->t_dconv1[k], kDecIn, kDecW, 3, p, p + (size_t)kDecW * kDecIn * 9);
         p += (size_t)kDecW * kDecIn * 9 + kDecW;
         for (int layer = 0; layer < 3; ++layer) {
             const float* w = p;
             const float* b = p + (size_t)kDecW * per * 9;
             for (int g = 0; g < groups; ++g)     // group g = output channels [g*per, (g+1)*per), its own `per` inputs
-                tail(c->dgroup[k][layer][g], per, per, 3, w + (size_t)g * per * per * 9, b + g * per);
+                tail(c->dgroup[k][layer][g], c->t_dgroup[k][layer][g], per, per, 3, w + (size_t)g * per * per * 9, b + g * per);
             p += (size_t)kDecW * per * 9 + kDecW;
         }
-        tail(c->dconv5[k], kDecW, 64, 3, p, p + (size_t)64 * kDecW * 9);  p += (size_t)64 * kDecW * 9 + 64;
-        tail(c->dconv6[k], 64, 32, 3, p, p + (size_t)32 * 64 * 9);        p += (size_t)32 * 64 * 9 + 32;
-        tail(c->dconv7[k], 32, 2, 3, p, p + (size_t)2 * 32 * 9);          p += (size_t)2 * 32 * 9 + 2;
+        tail(c->dconv5[k], c->t_dconv5[k], kDecW, 64, 3, p, p + (size_t)64 * kDecW * 9);  p += (size_t)64 * kDecW * 9 + 64;
+        tail(c->dconv6[k], c->t_dconv6[k], 64, 32, 3, p, p + (size_t)32 * 64 * 9);        p += (size_t)32 * 64 * 9 + 32;
+        tail(c->dconv7[k], c->t_dconv7[k], 32, 2, 3, p, p + (size_t)2 * 32 * 9);          p += (size_t)2 * 32 * 9 + 2;
     }
-    tail(c->outc, 6, 2, 1, p, p + 12);
+    tail(c->outc, c->t_outc, 6, 2, 1, p, p + 12);
     p += 14;
-    if ((size_t)(p - flat) != nfloats) {
-        eem_set_error("eemflow_load_weights: internal layout walk consumed %zu of %zu floats", (size_t)(p - flat), nfloats);
+    if ((size_t)(p - base) != nfloats) {
+        eem_set_error("eemflow_load_weights: internal layout walk consumed %zu of %zu floats", (size_t)(p - base), nfloats);
         return EEM_ERR_STATE;
     }
+    std::vector<int> idx(host.size());
+    for (size_t i = 0; i < host.size(); ++i) idx[i] = (int)host[i];
     drop_graph(c);
     if (c->arena) EEM_HIP_CHECK(hipFree(c->arena));
-    c->arena = nullptr;
+    if (c->pack_idx) EEM_HIP_CHECK(hipFree(c->pack_idx));
+    if (c->flat) EEM_HIP_CHECK(hipFree(c->flat));
+    c->arena = nullptr; c->pack_idx = nullptr; c->flat = nullptr;
+    c->arena_floats = host.size();
+    c->nflat = nfloats;
     EEM_HIP_CHECK(hipMalloc(&c->arena, host.size() * sizeof(float)));
-    EEM_HIP_CHECK(hipMemcpy(c->arena, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    EEM_HIP_CHECK(hipMalloc(&c->pack_idx, host.size() * sizeof(int)));
+    EEM_HIP_CHECK(hipMalloc(&c->flat, nfloats * sizeof(float)));
+    EEM_HIP_CHECK(hipMemcpy(c->pack_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
+    EEM_HIP_CHECK(hipMemcpy(c->flat, flat, nfloats * sizeof(float), hipMemcpyHostToDevice));
+    int rc = repack_launch(c->flat, c->pack_idx, c->arena, (long)c->arena_floats, nullptr);
+    if (rc != EEM_OK) return rc;
+    EEM_HIP_CHECK(hipDeviceSynchronize());
     c->cin0 = n_first_channels;
     c->groups = groups;
     c->weights_loaded = true;
+    c->opt_step = 0;
     return EEM_OK;
 }
 
@@ -625,6 +326,7 @@ extern "C" int eemflow_decoder(eemflow_ctx* c, int k, const float* x, int batch,
     int rc;
     const int i = k - 1;
     if ((rc = ensure(c->ta[i], B * kDecW * g)) || (rc = ensure(c->tb[i], B * kDecW * g)) ||
+        (rc = ensure(c->tc[i], B * kDecW * g)) || (rc = ensure(c->td[i], B * kDecW * g)) ||
         (rc = ensure(c->t64[i], B * 64 * g)) || (rc = ensure(c->t32[i], B * 32 * g)))
         return rc;
     const float* cats[3] = {x, x, x};

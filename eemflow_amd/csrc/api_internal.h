@@ -1,0 +1,366 @@
+// Internals shared by api.hip (inference C ABI) and train_api.hip (training step): the context, workspace
+// management and the forward schedule.  Everything here has internal linkage.
+#pragma once
+#include <stdarg.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/eemflow_hip.h"
+#include "common.h"
+#include "gconv.h"
+
+// ------------------------------------------------------------------------------- context
+namespace {
+
+const int kTaps53[53] = {0,  2,  4,  6,  8,  10, 12, 14, 16, 18, 20, 21, 22, 23, 24, 26, 28, 29,
+                         30, 31, 32, 33, 34, 36, 38, 39, 40, 41, 42, 44, 46, 47, 48, 49, 50, 51,
+                         52, 54, 56, 57, 58, 59, 60, 62, 64, 66, 68, 70, 72, 74, 76, 78, 80};
+constexpr int kNTaps = 53;
+constexpr int kDecIn = kNTaps + 16;   // 69
+constexpr int kDecW = 100;
+
+struct TailW {                         // one packed small-grid conv
+    size_t wpk = 0, bias = 0;          // float offsets into the weight arena
+    int cin = 0, cout = 0, ksize = 3;
+};
+
+struct DevBuf {
+    float* p = nullptr;
+    size_t cap = 0;                    // floats
+};
+
+struct Shape {
+    int batch = 0, in_h = 0, in_w = 0, out_h = 0, out_w = 0;
+    int hp = 0, wp = 0;                // padded extent
+    int h1 = 0, w1 = 0, h2 = 0, w2 = 0, h3 = 0, w3 = 0;
+    int gh = 0, gw = 0;                // 1/64 grid
+    // fused stage pooling (fast path): partial-sum buffer dims per stage, fuse[k] = conv epilogue pools stage k
+    bool fuse[3] = {false, false, false};
+    int prow[3] = {0, 0, 0}, pcol[3] = {0, 0, 0}, th[3] = {0, 0, 0};
+};
+
+}  // namespace
+
+struct eemflow_ctx {
+    int device = 0;
+    bool weights_loaded = false;
+    int cin0 = 5, groups = 5;
+    // padder
+    bool have_pad = false;
+    int pad[4] = {0, 0, 0, 0};
+    // weights: `flat` is the device-resident master copy in state_dict order; `arena` holds every packed
+    // form the kernels read (MFMA fragment orders, biases, transposed weights for the data gradients) and is
+    // rebuilt from `flat` by one gather kernel driven by `pack_idx` (arena[i] = flat[pack_idx[i]-1], 0 -> 0.f)
+    float* flat = nullptr;
+    size_t nflat = 0;
+    int* pack_idx = nullptr;
+    size_t arena_floats = 0;
+    float* arena = nullptr;
+    size_t enc_w[ENC_NUM], enc_w2[ENC_NUM], enc_b[ENC_NUM];
+    bool enc_has2[ENC_NUM];
+    float* zero_page = nullptr;
+    TailW rconv[3], dconv1[3], dgroup[3][3][5], dconv5[3], dconv6[3], dconv7[3], outc;
+    // training: per-conv descriptors (flat offsets of weight/bias, packed transposed weights for gconv dgrad)
+    struct ConvRef { size_t w = 0, b = 0, wT = 0; int cin = 0, cout = 0, k = 3, stride = 1; };
+    ConvRef t_enc[ENC_NUM], t_rconv[3], t_dconv1[3], t_dgroup[3][3][5], t_dconv5[3], t_dconv6[3], t_dconv7[3], t_outc;
+    // training workspace + optimizer state
+    DevBuf padded, g_a1, g_f11, g_a2, g_b2, g_f12, g_a3, g_b3, g_f13, g_pool[3], g_cat[3], g_ta[3], g_tb[3], g_tc[3], g_td[3],
+        g_t64[3], g_t32[3], g_flowcat, g_coarse, g_flow, ups_tmp, grad_flat, adam_m, adam_v, scalars;
+    long opt_step = 0;
+    int* taps = nullptr;
+    // workspaces
+    DevBuf a1, f11, a2, b2, f12, a3, b3, f13, pool[3], ppart[3], cat[3], ta[3], tb[3], tc[3], td[3], t64[3], t32[3], flowcat, coarse;
+    void* vox_scratch = nullptr;
+    Shape last;
+    bool have_last = false;
+    // graph cache
+    bool use_graph = true;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    struct Key {
+        const float *e1, *e2;
+        float* out;
+        int batch, in_h, in_w, out_h, out_w, pad[4];
+    } graph_key;
+    bool have_graph = false;
+};
+
+namespace {
+
+int ensure(DevBuf& b, size_t floats) {
+    if (floats <= b.cap) return EEM_OK;
+    if (b.p) EEM_HIP_CHECK(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    EEM_HIP_CHECK(hipMalloc(&b.p, floats * sizeof(float)));
+    b.cap = floats;
+    return EEM_OK;
+}
+
+void drop_graph(eemflow_ctx* c) {
+    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+    if (c->graph) (void)hipGraphDestroy(c->graph);
+    c->graph_exec = nullptr;
+    c->graph = nullptr;
+    c->have_graph = false;
+}
+
+int compute_shape(eemflow_ctx* c, int batch, int in_h, int in_w, int out_h, int out_w, Shape* s) {
+    s->batch = batch; s->in_h = in_h; s->in_w = in_w; s->out_h = out_h; s->out_w = out_w;
+    s->hp = in_h + c->pad[2] + c->pad[3];
+    s->wp = in_w + c->pad[0] + c->pad[1];
+    auto half = [](int v) { return (v - 1) / 2 + 1; };          // conv k3 s2 p1
+    s->h1 = half(s->hp); s->w1 = half(s->wp);
+    s->h2 = half(s->h1); s->w2 = half(s->w1);
+    s->h3 = half(s->h2); s->w3 = half(s->w2);
+    s->gh = s->h1 / 32; s->gw = s->w1 / 32;
+    EEM_REQUIRE(s->gh >= 1 && s->gw >= 1, "input %dx%d (padded %dx%d) is too small for the 1/64 grid", in_h, in_w,
+                s->hp, s->wp);
+    // the reference concatenates the three decoders' flows (EEMFlow.py:179): the three pooled grids
+    // must agree or torch.cat raises
+    EEM_REQUIRE(s->h2 / 16 == s->gh && s->h3 / 8 == s->gh && s->w2 / 16 == s->gw && s->w3 / 8 == s->gw,
+                "pooled grids of the three stages differ for padded size %dx%d (the reference's torch.cat "
+                "fails too)", s->hp, s->wp);
+    // stage pooling can ride in the epilogue of pconv1_2 / pconv2_3 / pconv3_3 when those run the fast path
+    const int last[3] = {ENC_1_2, ENC_2_3, ENC_3_3};
+    const int hs[3] = {s->h1, s->h2, s->h3}, ws[3] = {s->w1, s->w2, s->w3}, ks[3] = {32, 16, 8};
+    for (int k = 0; k < 3; ++k) {
+        const EncLayerDesc& d = kEncLayers[last[k]];
+        int th, tw, pk;
+        enc2_tile(d.cin, d.cout, &th, &tw, &pk);
+        s->fuse[k] = c->enc_has2[last[k]] && enc2_supported(d.cin, d.cout, d.stride, ws[k]) && pk == ks[k];
+        s->th[k] = th;
+        s->prow[k] = ceil_div(hs[k], th);
+        s->pcol[k] = ceil_div(ws[k], tw) * (tw / ks[k]);
+    }
+    return EEM_OK;
+}
+
+int alloc_workspace(eemflow_ctx* c, const Shape& s) {
+    const size_t n2 = 2 * (size_t)s.batch, B = s.batch, g = (size_t)s.gh * s.gw;
+    int rc;
+#define ENS(buf, n) if ((rc = ensure(buf, n)) != EEM_OK) return rc
+    ENS(c->a1, n2 * 16 * s.h1 * s.w1);  ENS(c->f11, n2 * 16 * s.h1 * s.w1);
+    ENS(c->a2, n2 * 32 * s.h2 * s.w2);  ENS(c->b2, n2 * 32 * s.h2 * s.w2);  ENS(c->f12, n2 * 32 * s.h2 * s.w2);
+    ENS(c->a3, n2 * 64 * s.h3 * s.w3);  ENS(c->b3, n2 * 64 * s.h3 * s.w3);  ENS(c->f13, n2 * 64 * s.h3 * s.w3);
+    const int pc[3] = {16, 32, 64};
+    for (int k = 0; k < 3; ++k) {
+        ENS(c->pool[k], n2 * pc[k] * g);
+        if (s.fuse[k]) ENS(c->ppart[k], n2 * pc[k] * (size_t)s.prow[k] * s.pcol[k]);
+        ENS(c->cat[k], B * kDecIn * g);
+        ENS(c->ta[k], B * kDecW * g);   ENS(c->tb[k], B * kDecW * g);
+        ENS(c->tc[k], B * kDecW * g);   ENS(c->td[k], B * kDecW * g);
+        ENS(c->t64[k], B * 64 * g);     ENS(c->t32[k], B * 32 * g);
+    }
+    ENS(c->flowcat, B * 6 * g);  ENS(c->coarse, B * 2 * g);
+#undef ENS
+    return EEM_OK;
+}
+
+TailConvJob make_job(const eemflow_ctx* c, const TailW& w, const float* in, int in_ctotal, int in_coff, float* out,
+                     int out_ctotal, int out_coff, int out_cmul, int act) {
+    TailConvJob j;
+    j.in = in; j.wpk = c->arena + w.wpk; j.bias = c->arena + w.bias; j.out = out;
+    j.cin = w.cin; j.cout = w.cout;
+    j.in_ctotal = in_ctotal; j.in_coff = in_coff;
+    j.out_ctotal = out_ctotal; j.out_coff = out_coff; j.out_cmul = out_cmul; j.act = act;
+    return j;
+}
+
+// Every kernel launch of the schedule goes through a Hook: normally it just launches; in timing mode
+// (eemflow_time_kernels) it launches the same kernel `reps` times back to back between two HIP
+// events on the launch stream and records the average duration with its algorithmic FLOPs / bytes.
+struct Hook {
+    hipStream_t st = nullptr;
+    bool timing = false;
+    int reps = 1;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<eemflow_kernel_stat> stats;
+
+    template <class F>
+    int run(const char* name, double flops, double bytes, F&& launch) {
+        if (!timing) return launch(st);
+        int rc = launch(st);                                  // warm (also keeps data flowing downstream)
+        if (rc != EEM_OK) return rc;
+        EEM_HIP_CHECK(hipEventRecord(ev0, st));
+        for (int i = 0; i < reps; ++i)
+            if ((rc = launch(st)) != EEM_OK) return rc;
+        EEM_HIP_CHECK(hipEventRecord(ev1, st));
+        EEM_HIP_CHECK(hipEventSynchronize(ev1));
+        float ms = 0.f;
+        EEM_HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
+        eemflow_kernel_stat ks;
+        memset(&ks, 0, sizeof(ks));
+        strncpy(ks.name, name, sizeof(ks.name) - 1);
+        ks.flops = flops; ks.bytes = bytes; ks.ms = ms / (float)reps;
+        stats.push_back(ks);
+        return EEM_OK;
+    }
+};
+
+double tail_flops(const TailConvLaunch& L) {
+    double f = 0;
+    for (int i = 0; i < L.njobs; ++i)
+        f += 2.0 * L.batch * L.h * L.w * (double)L.job[i].cout * L.job[i].cin * L.ksize * L.ksize;
+    return f;
+}
+double tail_bytes(const TailConvLaunch& L) {
+    double b = 0;
+    for (int i = 0; i < L.njobs; ++i)
+        b += 4.0 * ((double)L.batch * L.h * L.w * (L.job[i].cin + L.job[i].cout) +
+                    (double)L.job[i].cout * L.job[i].cin * L.ksize * L.ksize + L.job[i].cout);
+    return b;
+}
+int run_tail(Hook& hk, const char* name, const TailConvLaunch& L) {
+    return hk.run(name, tail_flops(L), tail_bytes(L), [&](hipStream_t st) { return tail_conv_launch(L, st); });
+}
+
+// decoder convs 1..7 for decoders [k0,k1); input cat buffers `cat[k]`, final 2-ch flow of decoder k goes to
+// channels [2*(k-kbase), +2) of `flow_dst` (which has flow_ctotal channels)
+int run_decoders(eemflow_ctx* c, int k0, int k1, const float* const cat[3], int batch, int h, int w, float* flow_dst,
+                 int flow_ctotal, int kbase, Hook& hk) {
+    int rc;
+    TailConvLaunch L;
+    L.batch = batch; L.h = h; L.w = w; L.ksize = 3;
+    // conv1: 69 -> 100
+    L.njobs = 0;
+    for (int k = k0; k < k1; ++k) L.job[L.njobs++] = make_job(c, c->dconv1[k], cat[k], kDecIn, 0, c->ta[k].p, kDecW, 0, 1, 1);
+    if ((rc = run_tail(hk, "dec.conv1 69->100", L)) != EEM_OK) return rc;
+    // conv2..4: grouped 100 -> 100, each followed by channel_shuffle (EEMFlow.py:51-57):
+    // group g, in-group channel j lands in channel j*groups + g
+    const int G = c->groups, per = kDecW / G;
+    const char* gname[3] = {"dec.conv2 grouped+shuffle", "dec.conv3 grouped+shuffle", "dec.conv4 grouped+shuffle"};
+    for (int layer = 0; layer < 3; ++layer) {
+        L.njobs = 0;
+        for (int k = k0; k < k1; ++k) {
+            // every activation keeps its own buffer (the training step reads them back): ta -> tb -> tc -> td
+            float* chain[4] = {c->ta[k].p, c->tb[k].p, c->tc[k].p, c->td[k].p};
+            float* src = chain[layer];
+            float* dst = chain[layer + 1];
+            for (int g = 0; g < G; ++g) {
+                if (G == 1) L.job[L.njobs++] = make_job(c, c->dgroup[k][layer][g], src, kDecW, 0, dst, kDecW, 0, 1, 1);
+                else L.job[L.njobs++] = make_job(c, c->dgroup[k][layer][g], src, kDecW, g * per, dst, kDecW, g, G, 1);
+            }
+        }
+        if ((rc = run_tail(hk, gname[layer], L)) != EEM_OK) return rc;
+    }
+    L.njobs = 0;
+    for (int k = k0; k < k1; ++k) L.job[L.njobs++] = make_job(c, c->dconv5[k], c->td[k].p, kDecW, 0, c->t64[k].p, 64, 0, 1, 1);
+    if ((rc = run_tail(hk, "dec.conv5 100->64", L)) != EEM_OK) return rc;
+    L.njobs = 0;
+    for (int k = k0; k < k1; ++k) L.job[L.njobs++] = make_job(c, c->dconv6[k], c->t64[k].p, 64, 0, c->t32[k].p, 32, 0, 1, 1);
+    if ((rc = run_tail(hk, "dec.conv6 64->32", L)) != EEM_OK) return rc;
+    L.njobs = 0;
+    for (int k = k0; k < k1; ++k)
+        L.job[L.njobs++] = make_job(c, c->dconv7[k], c->t32[k].p, 32, 0, flow_dst, flow_ctotal, 2 * (k - kbase), 1, 0);
+    return run_tail(hk, "dec.conv7 32->2", L);
+}
+
+int run_forward(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2, float* out, Hook& hk) {
+    int rc;
+    const int n2 = 2 * s.batch;
+    // ---- encoder (both event volumes as one batch; shared weights, EEMFlow.py:135-140)
+    struct Step { int layer; const char* name; const float* in; float* out; int hin, win, hout, wout; };
+    const Step steps[ENC_NUM] = {
+        {ENC_1_1, "enc.pconv1_1 5->16 s2 +pad", nullptr, c->a1.p, s.hp, s.wp, s.h1, s.w1},
+        {ENC_1_2, "enc.pconv1_2 16->16", c->a1.p, c->f11.p, s.h1, s.w1, s.h1, s.w1},
+        {ENC_2_1, "enc.pconv2_1 16->32 s2", c->f11.p, c->a2.p, s.h1, s.w1, s.h2, s.w2},
+        {ENC_2_2, "enc.pconv2_2 32->32", c->a2.p, c->b2.p, s.h2, s.w2, s.h2, s.w2},
+        {ENC_2_3, "enc.pconv2_3 32->32", c->b2.p, c->f12.p, s.h2, s.w2, s.h2, s.w2},
+        {ENC_3_1, "enc.pconv3_1 32->64 s2", c->f12.p, c->a3.p, s.h2, s.w2, s.h3, s.w3},
+        {ENC_3_2, "enc.pconv3_2 64->64", c->a3.p, c->b3.p, s.h3, s.w3, s.h3, s.w3},
+        {ENC_3_3, "enc.pconv3_3 64->64", c->b3.p, c->f13.p, s.h3, s.w3, s.h3, s.w3}};
+    for (const Step& sp : steps) {
+        EncConvArgs a;
+        const EncLayerDesc& d = kEncLayers[sp.layer];
+        a.in0 = sp.layer == ENC_1_1 ? e1 : sp.in;
+        a.in1 = sp.layer == ENC_1_1 ? e2 : nullptr;
+        a.wpk = c->arena + c->enc_w[sp.layer];
+        a.wpk2 = c->enc_has2[sp.layer] ? c->arena + c->enc_w2[sp.layer] : nullptr;
+        a.zero_page = c->zero_page;
+        a.trash = c->zero_page + 64;
+        a.bias = c->arena + c->enc_b[sp.layer];
+        a.out = sp.out;
+        a.nimg = n2; a.nimg0 = sp.layer == ENC_1_1 ? s.batch : n2;
+        a.hin = sp.hin; a.win = sp.win; a.hout = sp.hout; a.wout = sp.wout;
+        a.hraw = sp.layer == ENC_1_1 ? s.in_h : sp.hin;
+        a.wraw = sp.layer == ENC_1_1 ? s.in_w : sp.win;
+        a.pad_top = sp.layer == ENC_1_1 ? c->pad[2] : 0;
+        a.pad_left = sp.layer == ENC_1_1 ? c->pad[0] : 0;
+        a.act = 1;
+        a.pool_partial = nullptr;
+        a.pool_k = 0;
+        for (int k = 0; k < 3; ++k)
+            if (s.fuse[k] && sp.layer == (k == 0 ? ENC_1_2 : k == 1 ? ENC_2_3 : ENC_3_3)) {
+                a.pool_partial = c->ppart[k].p;
+                a.pool_k = k == 0 ? 32 : k == 1 ? 16 : 8;
+            }
+        const double opix = (double)n2 * sp.hout * sp.wout;
+        const double flops = 2.0 * opix * d.cout * d.cin * 9;
+        const double ipix = sp.layer == ENC_1_1 ? (double)n2 * s.in_h * s.in_w : (double)n2 * sp.hin * sp.win;
+        const double bytes = 4.0 * (ipix * d.cin + opix * d.cout + (double)d.cout * d.cin * 9 + d.cout);
+        rc = hk.run(sp.name, flops, bytes,
+                    [&](hipStream_t st) { return enc_conv_launch(d.cin, d.cout, d.stride, a, st); });
+        if (rc != EEM_OK) return rc;
+    }
+    // ---- stage pooling to the common 1/64 grid (EEMFlow.py:144-154): finish the partial sums the conv
+    // epilogues wrote; stages whose conv ran the generic kernel are pooled from the stored feature map
+    {
+        const float* feat[3] = {c->f11.p, c->f12.p, c->f13.p};
+        const int pcs[3] = {16, 32, 64}, hs[3] = {s.h1, s.h2, s.h3}, ws[3] = {s.w1, s.w2, s.w3}, ks[3] = {32, 16, 8};
+        PoolFinJob fj[3];
+        PoolJob pj[3];
+        int nf = 0, np = 0;
+        double fin_elems = 0, pool_elems = 0;
+        for (int k = 0; k < 3; ++k) {
+            if (s.fuse[k]) {
+                fj[nf++] = {c->ppart[k].p, c->pool[k].p, pcs[k], s.prow[k], s.pcol[k], ks[k] / s.th[k], ks[k]};
+                fin_elems += (double)n2 * pcs[k] * s.gh * s.gw * (ks[k] / s.th[k] + 1);
+            } else {
+                pj[np++] = {feat[k], c->pool[k].p, pcs[k], hs[k], ws[k], ks[k]};
+                pool_elems += (double)n2 * pcs[k] * hs[k] * ws[k];
+            }
+        }
+        if (nf) {
+            rc = hk.run("pool finalize (fused partials)", fin_elems, 4.0 * fin_elems, [&](hipStream_t st) {
+                return pool_finalize_launch(fj, nf, n2, s.gh, s.gw, st);
+            });
+            if (rc != EEM_OK) return rc;
+        }
+        if (np) {
+            rc = hk.run("pool 32/16/8", pool_elems, 4.0 * pool_elems,
+                        [&](hipStream_t st) { return pool_launch(pj, np, n2, st); });
+            if (rc != EEM_OK) return rc;
+        }
+    }
+    // ---- correlation (53 taps) and rconv into the decoders' input [cv | r] (EEMFlow.py:160-163)
+    const size_t g = (size_t)s.gh * s.gw;
+    const int pc[3] = {16, 32, 64};
+    CorrJob cj[3];
+    for (int k = 0; k < 3; ++k)
+        cj[k] = {c->pool[k].p, c->pool[k].p + (size_t)s.batch * pc[k] * g, c->cat[k].p, pc[k], kDecIn};
+    rc = hk.run("local_corr 9x9 (53 taps)", 2.0 * s.batch * g * kNTaps * (16 + 32 + 64),
+                4.0 * s.batch * g * (2.0 * (16 + 32 + 64) + 3.0 * kNTaps),
+                [&](hipStream_t st) { return corr_launch(cj, 3, s.batch, s.gh, s.gw, c->taps, kNTaps, st); });
+    if (rc != EEM_OK) return rc;
+    TailConvLaunch L;
+    L.batch = s.batch; L.h = s.gh; L.w = s.gw; L.ksize = 3; L.njobs = 0;
+    for (int k = 0; k < 3; ++k)
+        L.job[L.njobs++] = make_job(c, c->rconv[k], c->pool[k].p, pc[k], 0, c->cat[k].p, kDecIn, kNTaps, 1, 1);
+    if ((rc = run_tail(hk, "rconv {16,32,64}->16", L)) != EEM_OK) return rc;
+    // ---- decoders, out_conv, upsample (EEMFlow.py:164-181)
+    const float* cats[3] = {c->cat[0].p, c->cat[1].p, c->cat[2].p};
+    if ((rc = run_decoders(c, 0, 3, cats, s.batch, s.gh, s.gw, c->flowcat.p, 6, 0, hk)) != EEM_OK) return rc;
+    L.ksize = 1; L.njobs = 1;
+    L.job[0] = make_job(c, c->outc, c->flowcat.p, 6, 0, c->coarse.p, 2, 0, 1, 0);
+    if ((rc = run_tail(hk, "out_conv 1x1 6->2", L)) != EEM_OK) return rc;
+    const double opix = (double)s.batch * 2 * s.out_h * s.out_w;
+    return hk.run("upsample bilinear", 8.0 * opix, 4.0 * (opix + (double)s.batch * 2 * g), [&](hipStream_t st) {
+        return upsample_launch(c->coarse.p, out, s.batch * 2, s.gh, s.gw, s.out_h, s.out_w, st);
+    });
+}
+
+}  // namespace
+

@@ -129,6 +129,9 @@ int corr_launch(const CorrJob* jobs, int njobs, int batch, int h, int w, const i
 // plain bilinear resize (align_corners False) of [n][c][h][w] -> [n][c][oh][ow]
 int upsample_launch(const float* in, float* out, int nc, int h, int w, int oh, int ow, hipStream_t stream);
 
+// arena[i] = idx[i] ? flat[idx[i] - 1] : 0  (weight re-packing after an optimizer step, see api.hip)
+int repack_launch(const float* flat, const int* idx, float* arena, long n, hipStream_t stream);
+
 // ----------------------------------------------------------------------------- voxelizer
 int voxel_launch(const double* events, int64_t n, int bins, int h, int w, int normalize, float* grid,
                  int64_t* idx_left, int64_t* idx_right, void* scratch, hipStream_t stream);

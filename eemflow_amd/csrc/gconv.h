@@ -5,7 +5,10 @@
 
 struct GConvSeg {
     const float* ptr;      // [N][ctotal][hin][win]
-    int c, ctotal, coff;   // this segment = channels [coff, coff + c)
+    int c, ctotal, coff;   // this segment = channels coff + i*cmul, i in [0, c)
+    int cmul;              // channel stride (0 is read as 1); >1 undoes a channel shuffle in backward passes
+    const float* gate;     // optional, same shape/indexing as ptr: the value is multiplied by LeakyReLU'(gate)
+                           // (1 if gate > 0 else 0.1) - backward through convrelu without a separate pass
 };
 
 enum { GACT_NONE = 0, GACT_RELU = 1, GACT_SIGMOID = 2, GACT_TANH = 3, GACT_LEAKY = 4 };
@@ -27,6 +30,8 @@ struct GConvArgs {
     int out_ctotal, out_coff;
     int n, hin, win, hout, wout, cout;
     int kh, kw, stride, pad_h, pad_w;
+    int tstride;           // 0/1: ordinary conv.  2: transposed conv (data gradient of a stride-2 conv): the
+                           // source position (o - pad + tap) must be a multiple of tstride and is divided by it
     int act, epi;
     const float* e0; int e0_ctotal, e0_coff;
     const float* e1; int e1_ctotal, e1_coff;

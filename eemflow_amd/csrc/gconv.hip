@@ -60,13 +60,21 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvArgs a) {
             bool tv[NPW];
 #pragma unroll
             for (int t = 0; t < NPW; ++t) {
-                const int iy = oy[t] * a.stride - a.pad_h + ty, ix = ox[t] * a.stride - a.pad_w + tx;
-                tv[t] = pv[t] && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
+                int iy = oy[t] * a.stride - a.pad_h + ty, ix = ox[t] * a.stride - a.pad_w + tx;
+                bool par = true;
+                if (a.tstride > 1) {
+                    par = iy >= 0 && ix >= 0 && (iy % a.tstride) == 0 && (ix % a.tstride) == 0;
+                    iy /= a.tstride; ix /= a.tstride;
+                }
+                tv[t] = pv[t] && par && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
                 off[t] = tv[t] ? iy * a.win + ix : 0;
             }
             for (int s = 0; s < a.nseg; ++s) {
                 const GConvSeg sg = a.seg[s];
-                const float* base = sg.ptr + ((size_t)n * sg.ctotal + sg.coff) * hwi;
+                const int cmul = sg.cmul > 1 ? sg.cmul : 1;
+                const size_t seg_off = ((size_t)n * sg.ctotal + sg.coff) * hwi;
+                const float* base = sg.ptr + seg_off;
+                const float* gbase = sg.gate ? sg.gate + seg_off : nullptr;
                 const int cp_n = (sg.c + 1) >> 1;
                 // operands of U k-steps are requested before the first of their MFMAs: the loop is bound by
                 // L2 latency, not bandwidth, so memory-level parallelism is what counts
@@ -79,13 +87,15 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvArgs a) {
                         const bool ok = cp < cp_n;
                         const int c = cp * 2 + h;
                         const bool cv = ok && c < sg.c;
-                        const float* bp = base + (size_t)(cv ? c : 0) * hwi;
+                        const size_t coffs = (size_t)(cv ? c : 0) * cmul * hwi;
+                        const float* bp = base + coffs;
                         const int kk = ok ? ks + u : ks;
 #pragma unroll
                         for (int m = 0; m < MTW; ++m) av[u][m] = wp[((size_t)m * ksteps + kk) * 64];
 #pragma unroll
                         for (int t = 0; t < NPW; ++t) {
-                            const float x = bp[off[t]];
+                            float x = bp[off[t]];
+                            if (gbase) x *= (gbase[coffs + off[t]] > 0.f) ? 1.f : 0.1f;
                             bv[u][t] = (tv[t] && cv) ? x : 0.f;
                         }
                     }

@@ -1,0 +1,26 @@
+// Training-step kernels (see train.hip).
+#pragma once
+#include "common.h"
+
+struct WgradArgs {
+    const float* x;        // forward input  [N][x_ctotal][hin][win], channels [x_coff, x_coff + cin)
+    int x_ctotal, x_coff, cin;
+    const float* g;        // output gradient [N][g_ctotal][hout][wout], channel co -> g_coff + co * g_cmul
+    const float* gate;     // forward output (same indexing as g) for LeakyReLU', or NULL
+    int g_ctotal, g_coff, g_cmul, cout;
+    float* dw;             // [cout][cin][k][k], accumulated with atomics (zero it first)
+    int n, hin, win, hout, wout, k, stride, pad;
+};
+
+int tr_loss_launch(const float* flow, const float* gt, const float* valid, float* dflow, int batch, int hw, float weight,
+                   double* stats, hipStream_t st);
+int tr_upsample_bwd_launch(const float* d, float* tmp, float* out, int nc, int oh, int ow, int h, int w, hipStream_t st);
+int tr_pool_bwd_launch(const float* dpool, float* g, long nc, int h, int w, int k, int gh, int gw, int accumulate, hipStream_t st);
+int tr_corr_bwd_launch(const float* dcv, int dcv_ctotal, const float* f1, const float* f2, float* d1, float* d2, int batch, int c,
+                       int h, int w, const int* taps, int ntaps, hipStream_t st);
+int tr_bias_grad_launch(const float* g, const float* gate, int g_ctotal, int g_coff, int g_cmul, int cout, int n, int hw, float* db,
+                        hipStream_t st);
+int tr_wgrad_launch(const WgradArgs& a, hipStream_t st);
+int tr_sumsq_launch(const float* g, long n, double* out, hipStream_t st);
+int tr_adamw_launch(float* p, const float* g, float* m, float* v, long n, const double* sumsq, float clip, float lr, float wd,
+                    float eps, float b1, float b2, long step, hipStream_t st);

@@ -1,0 +1,361 @@
+// Kernels of the EEMFlow training step (reference: train_mvsec.py:178-183,201-227,241-258 and the autograd
+// transposes of model/EEMFlow/EEMFlow.py): loss + its gradient, bilinear-upsample / pooling / local-correlation
+// backward, weight and bias gradients, gradient clipping + AdamW, weight re-packing.
+// Data gradients of the convolutions reuse gconv (transposed weights, transposed stride, LeakyReLU' gate).
+#include "train.h"
+
+namespace {
+
+inline unsigned nblocks(long n) { return (unsigned)((n + 255) / 256); }
+
+__global__ __launch_bounds__(256) void repack_kernel(const float* __restrict__ flat, const int* __restrict__ idx,
+                                                     float* __restrict__ arena, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const int k = idx[i]; arena[i] = k ? flat[k - 1] : 0.f; }
+}
+
+// ---- sequence_loss for one prediction (train_mvsec.py:201-227): loss = mean(valid * |flow - gt|) over B*2*H*W,
+// valid = (valid >= 0.5) & (|gt| < 400); dflow = sign(flow - gt) * valid / (B*2*H*W); epe statistics of :218-226.
+__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ flow, const float* __restrict__ gt,
+                                                   const float* __restrict__ valid, float* __restrict__ dflow, int batch, int hw,
+                                                   float weight, double* __restrict__ stats) {
+    __shared__ double sh[4][5];
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    double l = 0, e = 0, cnt = 0, c1 = 0, c3 = 0;
+    if (idx < (long)batch * hw) {
+        const int b = idx / hw, p = idx - (long)b * hw;
+        const size_t o = (size_t)b * 2 * hw + p;
+        const float gx = gt[o], gy = gt[o + hw], fx = flow[o], fy = flow[o + hw];
+        const bool ok = (valid[idx] >= 0.5f) && (sqrtf(gx * gx + gy * gy) < 400.f);
+        const float dx = fx - gx, dy = fy - gy;
+        const float s = ok ? weight / ((float)batch * 2.f * (float)hw) : 0.f;
+        dflow[o] = dx > 0.f ? s : (dx < 0.f ? -s : 0.f);
+        dflow[o + hw] = dy > 0.f ? s : (dy < 0.f ? -s : 0.f);
+        if (ok) {
+            l = (double)fabsf(dx) + (double)fabsf(dy);
+            const float ep = sqrtf(dx * dx + dy * dy);
+            e = ep; cnt = 1; c1 = ep < 1.f; c3 = ep < 3.f;
+        }
+    }
+    double v[5] = {l, e, cnt, c1, c3};
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v[k] += __shfl_xor(v[k], d);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+        for (int k = 0; k < 5; ++k) sh[wave][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x < 5) atomicAdd(&stats[threadIdx.x], sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+// ---- adjoint of F.interpolate(bilinear, align_corners=False), separable and deterministic:
+// pass X: tmp[nc][Y][xc] = sum_X wx(X, xc) * d[nc][Y][X];  pass Y: out[nc][yc][xc] = sum_Y wy(Y, yc) * tmp[nc][Y][xc]
+__device__ __forceinline__ float up_weight(float scale, int dst, int in_size, int c) {
+    float s = scale * ((float)dst + 0.5f) - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    const int i0 = (int)s;
+    const int i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    const float l1 = s - (float)i0;
+    return (i0 == c ? 1.f - l1 : 0.f) + (i1 == c ? l1 : 0.f);
+}
+
+__global__ __launch_bounds__(256) void upbwd_x_kernel(const float* __restrict__ d, float* __restrict__ tmp, long nc_oh, int ow, int w) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nc_oh * w) return;
+    const int xc = idx % w;
+    const long row = idx / w;
+    const float scale = (float)w / (float)ow, inv = (float)ow / (float)w;
+    int lo = (int)floorf(((float)xc - 1.f + 0.5f) * inv - 0.5f) - 1, hi = (int)ceilf(((float)xc + 1.f + 0.5f) * inv - 0.5f) + 1;
+    lo = lo < 0 ? 0 : lo; hi = hi > ow - 1 ? ow - 1 : hi;
+    if (xc == 0) lo = 0;                                      // negative source positions clamp to column 0
+    const float* r = d + row * ow;
+    float s = 0.f;
+    for (int X = lo; X <= hi; ++X) s += up_weight(scale, X, w, xc) * r[X];
+    tmp[idx] = s;
+}
+
+__global__ __launch_bounds__(256) void upbwd_y_kernel(const float* __restrict__ tmp, float* __restrict__ out, int nc, int oh, int h, int w) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)nc * h * w) return;
+    const int xc = idx % w, yc = (idx / w) % h;
+    const int c = idx / ((long)w * h);
+    const float scale = (float)h / (float)oh, inv = (float)oh / (float)h;
+    int lo = (int)floorf(((float)yc - 1.f + 0.5f) * inv - 0.5f) - 1, hi = (int)ceilf(((float)yc + 1.f + 0.5f) * inv - 0.5f) + 1;
+    lo = lo < 0 ? 0 : lo; hi = hi > oh - 1 ? oh - 1 : hi;
+    if (yc == 0) lo = 0;
+    float s = 0.f;
+    for (int Y = lo; Y <= hi; ++Y) s += up_weight(scale, Y, h, yc) * tmp[((size_t)c * oh + Y) * w + xc];
+    out[idx] = s;
+}
+
+// ---- avg_pool2d(k) backward: g[nc][y][x] (+)= dpool[nc][y/k][x/k] / k^2 inside the pooled region
+__global__ __launch_bounds__(256) void poolbwd_kernel(const float* __restrict__ dpool, float* __restrict__ g, long nc, int h, int w,
+                                                      int k, int gh, int gw, int accumulate) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nc * h * w) return;
+    const int x = idx % w, y = (idx / w) % h;
+    const long c = idx / ((long)w * h);
+    const int py = y / k, px = x / k;
+    const float v = (py < gh && px < gw) ? dpool[(c * gh + py) * gw + px] / (float)(k * k) : 0.f;
+    g[idx] = accumulate ? g[idx] + v : v;
+}
+
+// ---- local correlation backward (the transpose of corr_kernel in tail.hip):
+// dx[b][c][p] += (1/C) sum_t dcv[b][t][p] * y[b][c][p + d_t];   dy[b][c][q] = (1/C) sum_t dcv[b][t][q - d_t] * x[b][c][q - d_t]
+__global__ __launch_bounds__(256) void corrbwd_kernel(const float* __restrict__ dcv, int dcv_ctotal, const float* __restrict__ f1,
+                                                      const float* __restrict__ f2, float* __restrict__ d1, float* __restrict__ d2,
+                                                      int batch, int c, int h, int w, const int* __restrict__ taps, int ntaps) {
+    const int hw = h * w;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)batch * c * hw) return;
+    const int p = idx % hw, ch = (idx / hw) % c, b = idx / ((long)hw * c);
+    const int y = p / w, x = p - y * w;
+    const float* dc = dcv + (size_t)b * dcv_ctotal * hw;
+    const float* a1 = f1 + ((size_t)b * c + ch) * hw;
+    const float* a2 = f2 + ((size_t)b * c + ch) * hw;
+    float s1 = 0.f, s2 = 0.f;
+    for (int t = 0; t < ntaps; ++t) {
+        const int dy = taps[t] / 9 - 4, dx = taps[t] % 9 - 4;
+        const int yy = y + dy, xx = x + dx;
+        if (yy >= 0 && yy < h && xx >= 0 && xx < w) s1 = fmaf(dc[(size_t)t * hw + p], a2[yy * w + xx], s1);
+        const int y2 = y - dy, x2 = x - dx;
+        if (y2 >= 0 && y2 < h && x2 >= 0 && x2 < w) s2 = fmaf(dc[(size_t)t * hw + y2 * w + x2], a1[y2 * w + x2], s2);
+    }
+    d1[idx] += s1 / (float)c;
+    d2[idx] = s2 / (float)c;
+}
+
+// ---- bias gradient: db[co] = sum_{n,p} g[n][co'][p] * LeakyReLU'(gate); grid (chunks, cout)
+__global__ __launch_bounds__(256) void biasgrad_kernel(const float* __restrict__ g, const float* __restrict__ gate, int g_ctotal,
+                                                       int g_coff, int g_cmul, int n, int hw, float* __restrict__ db) {
+    __shared__ float sh[4];
+    const int co = blockIdx.y;
+    const int ch = g_coff + co * g_cmul;
+    const long total = (long)n * hw;
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int b = i / hw, p = i - (long)b * hw;
+        const size_t o = ((size_t)b * g_ctotal + ch) * hw + p;
+        float v = g[o];
+        if (gate) v *= gate[o] > 0.f ? 1.f : 0.1f;
+        s += v;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&db[co], sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+// ---- weight gradient on v_mfma_f32_32x32x2_f32: dW[co][(ci,tap)] = sum_pixels G[co][pixel] * X[(ci,tap)][pixel].
+// M = cout tiles, N = (32 input channels of this block's chunk) x taps, K = output pixels.  A block walks 4x32
+// pixel tiles; per tile G (with the LeakyReLU' gate folded in) and the haloed X tile go to LDS (G rows with an
+// odd pitch -> conflict-free column reads), each wave owns up to MAXT (cout-tile, tap-tile) accumulators and adds
+// them to dW with fp32 atomics at the end (one atomic per weight and block).
+constexpr int WG_TH = 4, WG_TW = 32, WG_PX = WG_TH * WG_TW, WG_GP = WG_PX + 1, WG_CI = 32, WG_MAXT = 9;
+
+template <int K>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+    constexpr int KK = K * K;
+    __shared__ float lds[4 * 32 * WG_GP + WG_CI * 9 * 65];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int ci0 = blockIdx.y * WG_CI;
+    const int cin_here = min(WG_CI, a.cin - ci0);
+    const int MT = (a.cout + 31) >> 5;
+    const int NT = (cin_here * KK + 31) >> 5;
+    const int XR = (WG_TH - 1) * a.stride + K, XC = (WG_TW - 1) * a.stride + K;
+    float* Gs = lds;
+    float* Xs = lds + MT * 32 * WG_GP;
+
+    // this wave's tiles
+    int tmt[WG_MAXT], boff[WG_MAXT];
+    bool tok[WG_MAXT];
+    int ntile = 0;
+#pragma unroll
+    for (int i = 0; i < WG_MAXT; ++i) {
+        const int t = wave + i * 4;
+        tok[i] = t < MT * NT;
+        const int mt = tok[i] ? t / NT : 0, nt = tok[i] ? t - mt * NT : 0;
+        tmt[i] = mt;
+        const int nidx = nt * 32 + j;
+        const int ci_l = nidx / KK, tap = nidx - ci_l * KK;
+        const bool nv = nidx < cin_here * KK;
+        boff[i] = nv ? ci_l * XR * XC + (tap / K) * XC + (tap % K) : 0;
+        if (tok[i]) ntile = i + 1;
+    }
+    f32x16 acc[WG_MAXT];
+#pragma unroll
+    for (int i = 0; i < WG_MAXT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    const int tiles_x = (a.wout + WG_TW - 1) / WG_TW, tiles_y = (a.hout + WG_TH - 1) / WG_TH;
+    const int total = tiles_x * tiles_y * a.n;
+    const size_t ghw = (size_t)a.hout * a.wout, xhw = (size_t)a.hin * a.win;
+    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        const int bx = tile % tiles_x, by = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        const int oy0 = by * WG_TH, ox0 = bx * WG_TW;
+        __syncthreads();
+        for (int e = threadIdx.x; e < MT * 32 * WG_PX; e += 256) {
+            const int co = e / WG_PX, p = e - co * WG_PX;
+            const int oy = oy0 + (p >> 5), ox = ox0 + (p & 31);
+            float v = 0.f;
+            if (co < a.cout && oy < a.hout && ox < a.wout) {
+                const size_t o = ((size_t)n * a.g_ctotal + a.g_coff + (size_t)co * a.g_cmul) * ghw + (size_t)oy * a.wout + ox;
+                v = a.g[o];
+                if (a.gate) v *= a.gate[o] > 0.f ? 1.f : 0.1f;
+            }
+            Gs[co * WG_GP + p] = v;
+        }
+        const int gy0 = oy0 * a.stride - a.pad, gx0 = ox0 * a.stride - a.pad;
+        for (int e = threadIdx.x; e < cin_here * XR * XC; e += 256) {
+            const int ci_l = e / (XR * XC), rem = e - ci_l * (XR * XC);
+            const int ry = rem / XC, rx = rem - ry * XC;
+            const int iy = gy0 + ry, ix = gx0 + rx;
+            float v = 0.f;
+            if (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win)
+                v = a.x[((size_t)n * a.x_ctotal + a.x_coff + ci0 + ci_l) * xhw + (size_t)iy * a.win + ix];
+            Xs[e] = v;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int p = 0; p < WG_PX; p += 2) {
+            const int pp = p + h;
+            const int xoff = ((pp >> 5) * a.stride) * XC + (pp & 31) * a.stride;
+#pragma unroll
+            for (int i = 0; i < WG_MAXT; ++i) {
+                if (i < ntile) {
+                    const float av = Gs[(tmt[i] * 32 + j) * WG_GP + pp];
+                    const float bv = Xs[boff[i] + xoff];
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < WG_MAXT; ++i) {
+        if (!tok[i]) continue;
+        const int t = wave + i * 4;
+        const int mt = t / NT, nt = t - mt * NT;
+        const int nidx = nt * 32 + j;
+        if (nidx >= cin_here * KK) continue;
+        const int ci_l = nidx / KK, tap = nidx - ci_l * KK;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (co < a.cout) atomicAdd(&a.dw[((size_t)co * a.cin + ci0 + ci_l) * KK + tap], acc[i][r]);
+        }
+    }
+}
+
+// ---- clip_grad_norm_ + AdamW (train_mvsec.py:178-183,255-256): sum of squares, then the fused update
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, double* __restrict__ out) {
+    __shared__ double sh[4];
+    double s = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += (double)g[i] * (double)g[i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long n, const double* __restrict__ sumsq, float clip,
+                                                    float lr, float wd, float eps, float b1, float b2, float bc1, float bc2) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float coef = 1.f;
+    if (clip > 0.f) {
+        const float norm = (float)sqrt(*sumsq);
+        coef = fminf(clip / (norm + 1e-6f), 1.f);            // torch.nn.utils.clip_grad_norm_
+    }
+    const float gi = g[i] * coef;
+    float pi = p[i] * (1.f - lr * wd);                        // decoupled weight decay
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    p[i] = pi;
+}
+
+}  // namespace
+
+int repack_launch(const float* flat, const int* idx, float* arena, long n, hipStream_t st) {
+    hipLaunchKernelGGL(repack_kernel, dim3(nblocks(n)), dim3(256), 0, st, flat, idx, arena, n);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int tr_loss_launch(const float* flow, const float* gt, const float* valid, float* dflow, int batch, int hw, float weight,
+                   double* stats, hipStream_t st) {
+    hipLaunchKernelGGL(loss_kernel, dim3(nblocks((long)batch * hw)), dim3(256), 0, st, flow, gt, valid, dflow, batch, hw, weight, stats);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int tr_upsample_bwd_launch(const float* d, float* tmp, float* out, int nc, int oh, int ow, int h, int w, hipStream_t st) {
+    hipLaunchKernelGGL(upbwd_x_kernel, dim3(nblocks((long)nc * oh * w)), dim3(256), 0, st, d, tmp, (long)nc * oh, ow, w);
+    hipLaunchKernelGGL(upbwd_y_kernel, dim3(nblocks((long)nc * h * w)), dim3(256), 0, st, tmp, out, nc, oh, h, w);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int tr_pool_bwd_launch(const float* dpool, float* g, long nc, int h, int w, int k, int gh, int gw, int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(poolbwd_kernel, dim3(nblocks(nc * h * w)), dim3(256), 0, st, dpool, g, nc, h, w, k, gh, gw, accumulate);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int tr_corr_bwd_launch(const float* dcv, int dcv_ctotal, const float* f1, const float* f2, float* d1, float* d2, int batch, int c,
+                       int h, int w, const int* taps, int ntaps, hipStream_t st) {
+    hipLaunchKernelGGL(corrbwd_kernel, dim3(nblocks((long)batch * c * h * w)), dim3(256), 0, st, dcv, dcv_ctotal, f1, f2, d1, d2, batch,
+                       c, h, w, taps, ntaps);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int tr_bias_grad_launch(const float* g, const float* gate, int g_ctotal, int g_coff, int g_cmul, int cout, int n, int hw, float* db,
+                        hipStream_t st) {
+    const long total = (long)n * hw;
+    int chunks = (int)((total + 256 * 64 - 1) / (256 * 64));
+    chunks = chunks < 1 ? 1 : (chunks > 256 ? 256 : chunks);
+    hipLaunchKernelGGL(biasgrad_kernel, dim3(chunks, cout), dim3(256), 0, st, g, gate, g_ctotal, g_coff, g_cmul, n, hw, db);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int tr_wgrad_launch(const WgradArgs& a, hipStream_t st) {
+    EEM_REQUIRE((a.k == 3 || a.k == 1) && a.cout >= 1 && a.cout <= 128 && a.cin >= 1, "tr_wgrad_launch: unsupported conv");
+    EEM_REQUIRE(a.stride == 1 || a.stride == 2, "tr_wgrad_launch: stride %d", a.stride);
+    const int nchunk = (a.cin + WG_CI - 1) / WG_CI;
+    const int mt = (a.cout + 31) / 32;
+    const int nt = ((a.cin < WG_CI ? a.cin : WG_CI) * a.k * a.k + 31) / 32;
+    EEM_REQUIRE((mt * nt + 3) / 4 <= WG_MAXT, "tr_wgrad_launch: %d x %d tiles exceed the per-wave budget", mt, nt);
+    const int tiles = ((a.wout + WG_TW - 1) / WG_TW) * ((a.hout + WG_TH - 1) / WG_TH) * a.n;
+    int workers = 1024 / nchunk;
+    workers = workers < 1 ? 1 : workers;
+    workers = tiles < workers ? tiles : workers;
+    dim3 grid(workers, nchunk);
+    if (a.k == 3) hipLaunchKernelGGL(wgrad_kernel<3>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(256), 0, st, a);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int tr_sumsq_launch(const float* g, long n, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(sumsq_kernel, dim3(512), dim3(256), 0, st, g, n, out);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int tr_adamw_launch(float* p, const float* g, float* m, float* v, long n, const double* sumsq, float clip, float lr, float wd,
+                    float eps, float b1, float b2, long step, hipStream_t st) {
+    const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(nblocks(n)), dim3(256), 0, st, p, g, m, v, n, sumsq, clip, lr, wd, eps, b1, b2, bc1, bc2);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}

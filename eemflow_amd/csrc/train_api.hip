@@ -1,0 +1,217 @@
+// Training step of EEMFlow on the C ABI (train_mvsec.py:229-258 for one iteration): forward with every
+// activation kept, sequence loss, the full backward pass into one flat gradient buffer (state_dict order - the
+// buffer a data-parallel job all-reduces over RCCL), then gradient clipping + AdamW on the device-resident
+// weights and the re-pack of every MFMA weight layout.
+#include "api_internal.h"
+#include "eraft_kernels.h"
+#include "train.h"
+
+namespace {
+
+typedef eemflow_ctx::ConvRef ConvRef;
+
+struct Bwd {
+    eemflow_ctx* c;
+    hipStream_t st;
+    float* grad;           // flat gradient buffer
+
+    // data gradient of a conv layer through gconv: dX = convT(dY * act'(Y), W)
+    int dgrad(const ConvRef& r, const float* dy, const float* y_gate, int g_ctotal, int g_coff, int g_cmul, int n, int hout,
+              int wout, int hin, int win, float* dx, int dx_ctotal, int dx_coff) {
+        GConvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.nseg = 1;
+        a.seg[0].ptr = dy; a.seg[0].c = r.cout; a.seg[0].ctotal = g_ctotal; a.seg[0].coff = g_coff; a.seg[0].cmul = g_cmul;
+        a.seg[0].gate = y_gate;
+        a.wpk = c->arena + r.wT;
+        a.out = dx; a.out_ctotal = dx_ctotal; a.out_coff = dx_coff;
+        a.n = n; a.hin = hout; a.win = wout; a.hout = hin; a.wout = win; a.cout = r.cin;
+        a.kh = r.k; a.kw = r.k; a.stride = 1;
+        a.pad_h = a.pad_w = r.k - 1 - (r.k == 3 ? 1 : 0);      // k - 1 - pad
+        a.tstride = r.stride;
+        a.act = GACT_NONE; a.epi = GEPI_PLAIN; a.out_scale = 1.f;
+        return gconv_launch(a, st);
+    }
+    // weight + bias gradient of a conv layer into the flat buffer
+    int wgrad(const ConvRef& r, const float* x, int x_ctotal, int x_coff, const float* dy, const float* y_gate, int g_ctotal,
+              int g_coff, int g_cmul, int n, int hin, int win, int hout, int wout) {
+        WgradArgs w;
+        w.x = x; w.x_ctotal = x_ctotal; w.x_coff = x_coff; w.cin = r.cin;
+        w.g = dy; w.gate = y_gate; w.g_ctotal = g_ctotal; w.g_coff = g_coff; w.g_cmul = g_cmul; w.cout = r.cout;
+        w.dw = grad + r.w;
+        w.n = n; w.hin = hin; w.win = win; w.hout = hout; w.wout = wout; w.k = r.k; w.stride = r.stride; w.pad = r.k == 3 ? 1 : 0;
+        int rc = tr_wgrad_launch(w, st);
+        if (rc != EEM_OK) return rc;
+        return tr_bias_grad_launch(dy, y_gate, g_ctotal, g_coff, g_cmul, r.cout, n, hout * wout, grad + r.b, st);
+    }
+};
+
+int alloc_train(eemflow_ctx* c, const Shape& s) {
+    const size_t n2 = 2 * (size_t)s.batch, B = s.batch, g = (size_t)s.gh * s.gw;
+    int rc;
+#define ENS(buf, n) if ((rc = ensure(buf, n)) != EEM_OK) return rc
+    ENS(c->padded, n2 * c->cin0 * s.hp * s.wp);
+    ENS(c->g_a1, n2 * 16 * s.h1 * s.w1);  ENS(c->g_f11, n2 * 16 * s.h1 * s.w1);
+    ENS(c->g_a2, n2 * 32 * s.h2 * s.w2);  ENS(c->g_b2, n2 * 32 * s.h2 * s.w2);  ENS(c->g_f12, n2 * 32 * s.h2 * s.w2);
+    ENS(c->g_a3, n2 * 64 * s.h3 * s.w3);  ENS(c->g_b3, n2 * 64 * s.h3 * s.w3);  ENS(c->g_f13, n2 * 64 * s.h3 * s.w3);
+    const int pc[3] = {16, 32, 64};
+    for (int k = 0; k < 3; ++k) {
+        ENS(c->g_pool[k], n2 * pc[k] * g);  ENS(c->g_cat[k], B * kDecIn * g);
+        ENS(c->g_ta[k], B * kDecW * g);  ENS(c->g_tb[k], B * kDecW * g);  ENS(c->g_tc[k], B * kDecW * g);  ENS(c->g_td[k], B * kDecW * g);
+        ENS(c->g_t64[k], B * 64 * g);  ENS(c->g_t32[k], B * 32 * g);
+    }
+    ENS(c->g_flowcat, B * 6 * g);  ENS(c->g_coarse, B * 2 * g);
+    ENS(c->g_flow, B * 2 * (size_t)s.out_h * s.out_w);
+    ENS(c->ups_tmp, B * 2 * (size_t)s.out_h * s.gw);
+    ENS(c->grad_flat, c->nflat);
+    ENS(c->scalars, 16);
+#undef ENS
+    return EEM_OK;
+}
+
+}  // namespace
+
+// Forward + loss + backward.  grad_out (device, nflat floats, state_dict order) receives d loss / d parameter;
+// stats_out (host, 5 doubles): loss, mean epe, valid count, fraction < 1 px, fraction < 3 px.
+extern "C" int eemflow_forward_backward(eemflow_ctx* c, const float* e1, const float* e2, const float* flow_gt, const float* valid,
+                                        int batch, int in_h, int in_w, int out_h, int out_w, float gamma_weight, float* flow_out,
+                                        float* grad_out, double* stats_out, void* stream) {
+    EEM_REQUIRE(c && e1 && e2 && flow_gt && valid && grad_out && flow_out, "eemflow_forward_backward: NULL argument");
+    EEM_REQUIRE(c->weights_loaded && c->have_pad, "eemflow_forward_backward: load weights and set the image size first");
+    EEM_REQUIRE(c->groups == 5, "eemflow_forward_backward: only groups == 5 is built for training");
+    EEM_HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    Shape s;
+    int rc = compute_shape(c, batch, in_h, in_w, out_h, out_w, &s);
+    if (rc != EEM_OK) return rc;
+    drop_graph(c);
+    if ((rc = alloc_workspace(c, s)) != EEM_OK) return rc;
+    if ((rc = alloc_train(c, s)) != EEM_OK) return rc;
+    c->last = s;
+    c->have_last = true;
+    const int B = batch, n2 = 2 * batch;
+    const size_t g = (size_t)s.gh * s.gw;
+
+    // ---- forward (eager: every activation stays in its workspace buffer)
+    float* flow = flow_out;
+    Hook hk;
+    hk.st = st;
+    if ((rc = run_forward(c, s, e1, e2, flow, hk)) != EEM_OK) return rc;
+
+    Bwd bw{c, st, grad_out};
+    EEM_HIP_CHECK(hipMemsetAsync(grad_out, 0, c->nflat * sizeof(float), st));
+    double* stats = (double*)c->scalars.p;
+    EEM_HIP_CHECK(hipMemsetAsync(stats, 0, 8 * sizeof(double), st));
+    // ---- loss and d loss / d flow (train_mvsec.py:201-227)
+    if ((rc = tr_loss_launch(flow, flow_gt, valid, c->g_flow.p, B, s.out_h * s.out_w, gamma_weight, stats, st)) != EEM_OK) return rc;
+    // ---- upsample backward (EEMFlow.py:118-120)
+    if ((rc = tr_upsample_bwd_launch(c->g_flow.p, c->ups_tmp.p, c->g_coarse.p, B * 2, s.out_h, s.out_w, s.gh, s.gw, st)) != EEM_OK) return rc;
+    // ---- out_conv (1x1, no activation)
+    if ((rc = bw.wgrad(c->t_outc, c->flowcat.p, 6, 0, c->g_coarse.p, nullptr, 2, 0, 1, B, s.gh, s.gw, s.gh, s.gw)) != EEM_OK) return rc;
+    if ((rc = bw.dgrad(c->t_outc, c->g_coarse.p, nullptr, 2, 0, 1, B, s.gh, s.gw, s.gh, s.gw, c->g_flowcat.p, 6, 0)) != EEM_OK) return rc;
+    // ---- decoders (EEMFlow.py:59-69), last layer first
+    const int G = c->groups, per = kDecW / G;
+    const int pc[3] = {16, 32, 64};
+    for (int k = 0; k < 3; ++k) {
+        const int gh = s.gh, gw = s.gw;
+        // conv7: 32 -> 2, no activation; its output gradient is channels [2k, 2k+2) of g_flowcat
+        if ((rc = bw.wgrad(c->t_dconv7[k], c->t32[k].p, 32, 0, c->g_flowcat.p, nullptr, 6, 2 * k, 1, B, gh, gw, gh, gw)) != EEM_OK) return rc;
+        if ((rc = bw.dgrad(c->t_dconv7[k], c->g_flowcat.p, nullptr, 6, 2 * k, 1, B, gh, gw, gh, gw, c->g_t32[k].p, 32, 0)) != EEM_OK) return rc;
+        // conv6: 64 -> 32 (gate = its output t32)
+        if ((rc = bw.wgrad(c->t_dconv6[k], c->t64[k].p, 64, 0, c->g_t32[k].p, c->t32[k].p, 32, 0, 1, B, gh, gw, gh, gw)) != EEM_OK) return rc;
+        if ((rc = bw.dgrad(c->t_dconv6[k], c->g_t32[k].p, c->t32[k].p, 32, 0, 1, B, gh, gw, gh, gw, c->g_t64[k].p, 64, 0)) != EEM_OK) return rc;
+        // conv5: 100 -> 64, input = td (shuffled output of conv4)
+        if ((rc = bw.wgrad(c->t_dconv5[k], c->td[k].p, kDecW, 0, c->g_t64[k].p, c->t64[k].p, 64, 0, 1, B, gh, gw, gh, gw)) != EEM_OK) return rc;
+        if ((rc = bw.dgrad(c->t_dconv5[k], c->g_t64[k].p, c->t64[k].p, 64, 0, 1, B, gh, gw, gh, gw, c->g_td[k].p, kDecW, 0)) != EEM_OK) return rc;
+        // conv4, conv3, conv2: grouped + channel shuffle; group g's output channel j lives at j*G + g of the
+        // shuffled tensor, its inputs are channels [g*per, (g+1)*per) of the previous activation
+        float* act[4] = {c->ta[k].p, c->tb[k].p, c->tc[k].p, c->td[k].p};
+        float* gact[4] = {c->g_ta[k].p, c->g_tb[k].p, c->g_tc[k].p, c->g_td[k].p};
+        for (int layer = 2; layer >= 0; --layer)
+            for (int gi = 0; gi < G; ++gi) {
+                const ConvRef& r = c->t_dgroup[k][layer][gi];
+                if ((rc = bw.wgrad(r, act[layer], kDecW, gi * per, gact[layer + 1], act[layer + 1], kDecW, gi, G, B, gh, gw, gh, gw)) != EEM_OK) return rc;
+                if ((rc = bw.dgrad(r, gact[layer + 1], act[layer + 1], kDecW, gi, G, B, gh, gw, gh, gw, gact[layer], kDecW, gi * per)) != EEM_OK) return rc;
+            }
+        // conv1: 69 -> 100, input = cat_k
+        if ((rc = bw.wgrad(c->t_dconv1[k], c->cat[k].p, kDecIn, 0, c->g_ta[k].p, c->ta[k].p, kDecW, 0, 1, B, gh, gw, gh, gw)) != EEM_OK) return rc;
+        if ((rc = bw.dgrad(c->t_dconv1[k], c->g_ta[k].p, c->ta[k].p, kDecW, 0, 1, B, gh, gw, gh, gw, c->g_cat[k].p, kDecIn, 0)) != EEM_OK) return rc;
+        // rconv_k: pooled features of events1 -> channels [53, 69) of cat_k (gate = those channels)
+        const float* pool1 = c->pool[k].p;
+        const float* pool2 = c->pool[k].p + (size_t)B * pc[k] * g;
+        float* gp1 = c->g_pool[k].p;
+        float* gp2 = c->g_pool[k].p + (size_t)B * pc[k] * g;
+        if ((rc = bw.wgrad(c->t_rconv[k], pool1, pc[k], 0, c->g_cat[k].p, c->cat[k].p, kDecIn, kNTaps, 1, B, gh, gw, gh, gw)) != EEM_OK) return rc;
+        if ((rc = bw.dgrad(c->t_rconv[k], c->g_cat[k].p, c->cat[k].p, kDecIn, kNTaps, 1, B, gh, gw, gh, gw, gp1, pc[k], 0)) != EEM_OK) return rc;
+        // correlation: adds to d pool1, writes d pool2
+        if ((rc = tr_corr_bwd_launch(c->g_cat[k].p, kDecIn, pool1, pool2, gp1, gp2, B, pc[k], gh, gw, c->taps, kNTaps, st)) != EEM_OK) return rc;
+    }
+    // ---- encoder (EEMFlow.py:135-154): both event volumes as one batch of 2B images
+    if ((rc = er_pad_launch(e1, c->padded.p, B * c->cin0, in_h, in_w, c->pad[0], c->pad[1], c->pad[2], c->pad[3], st)) != EEM_OK) return rc;
+    if ((rc = er_pad_launch(e2, c->padded.p + (size_t)B * c->cin0 * s.hp * s.wp, B * c->cin0, in_h, in_w, c->pad[0], c->pad[1], c->pad[2],
+                            c->pad[3], st)) != EEM_OK) return rc;
+    struct L { int layer; const float* x; int xc, hin, win; const float* y; float* gy; int hout, wout; float* gx; };
+    const L ls[ENC_NUM] = {
+        {ENC_3_3, c->b3.p, 64, s.h3, s.w3, c->f13.p, c->g_f13.p, s.h3, s.w3, c->g_b3.p},
+        {ENC_3_2, c->a3.p, 64, s.h3, s.w3, c->b3.p, c->g_b3.p, s.h3, s.w3, c->g_a3.p},
+        {ENC_3_1, c->f12.p, 32, s.h2, s.w2, c->a3.p, c->g_a3.p, s.h3, s.w3, c->g_f12.p},
+        {ENC_2_3, c->b2.p, 32, s.h2, s.w2, c->f12.p, c->g_f12.p, s.h2, s.w2, c->g_b2.p},
+        {ENC_2_2, c->a2.p, 32, s.h2, s.w2, c->b2.p, c->g_b2.p, s.h2, s.w2, c->g_a2.p},
+        {ENC_2_1, c->f11.p, 16, s.h1, s.w1, c->a2.p, c->g_a2.p, s.h2, s.w2, c->g_f11.p},
+        {ENC_1_2, c->a1.p, 16, s.h1, s.w1, c->f11.p, c->g_f11.p, s.h1, s.w1, c->g_a1.p},
+        {ENC_1_1, c->padded.p, c->cin0, s.hp, s.wp, c->a1.p, c->g_a1.p, s.h1, s.w1, nullptr}};
+    // the stage outputs feed the pooling: start each stage's gradient with the pooling backward
+    if ((rc = tr_pool_bwd_launch(c->g_pool[2].p, c->g_f13.p, (long)n2 * 64, s.h3, s.w3, 8, s.gh, s.gw, 0, st)) != EEM_OK) return rc;
+    for (const L& l : ls) {
+        const ConvRef& r = c->t_enc[l.layer];
+        if ((rc = bw.wgrad(r, l.x, l.xc, 0, l.gy, l.y, r.cout, 0, 1, n2, l.hin, l.win, l.hout, l.wout)) != EEM_OK) return rc;
+        if (l.gx) {
+            if ((rc = bw.dgrad(r, l.gy, l.y, r.cout, 0, 1, n2, l.hout, l.wout, l.hin, l.win, l.gx, r.cin, 0)) != EEM_OK) return rc;
+            if (l.layer == ENC_3_1 && (rc = tr_pool_bwd_launch(c->g_pool[1].p, c->g_f12.p, (long)n2 * 32, s.h2, s.w2, 16, s.gh, s.gw, 1, st)) != EEM_OK) return rc;
+            if (l.layer == ENC_2_1 && (rc = tr_pool_bwd_launch(c->g_pool[0].p, c->g_f11.p, (long)n2 * 16, s.h1, s.w1, 32, s.gh, s.gw, 1, st)) != EEM_OK) return rc;
+        }
+    }
+    if (stats_out) {
+        double hst[5];
+        EEM_HIP_CHECK(hipMemcpyAsync(hst, stats, sizeof(hst), hipMemcpyDeviceToHost, st));
+        EEM_HIP_CHECK(hipStreamSynchronize(st));
+        const double cnt = hst[2] > 0 ? hst[2] : 1.0;
+        stats_out[0] = hst[0] * gamma_weight / ((double)B * 2.0 * s.out_h * s.out_w);
+        stats_out[1] = hst[1] / cnt; stats_out[2] = hst[2]; stats_out[3] = hst[3] / cnt; stats_out[4] = hst[4] / cnt;
+    }
+    return EEM_OK;
+}
+
+// clip_grad_norm_(max_norm = clip) + AdamW on the device-resident weights, then re-pack (train_mvsec.py:178-183,255-257).
+// `grad` is the (already all-reduced, in data-parallel jobs) flat gradient; lr comes from the host-side OneCycle schedule.
+extern "C" int eemflow_optimizer_step(eemflow_ctx* c, const float* grad, float lr, float weight_decay, float eps, float clip,
+                                      void* stream) {
+    EEM_REQUIRE(c && grad, "eemflow_optimizer_step: NULL argument");
+    EEM_REQUIRE(c->weights_loaded, "eemflow_optimizer_step: no weights loaded");
+    EEM_HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (c->adam_m.cap < c->nflat) {
+        if ((rc = ensure(c->adam_m, c->nflat)) != EEM_OK || (rc = ensure(c->adam_v, c->nflat)) != EEM_OK) return rc;
+        EEM_HIP_CHECK(hipMemsetAsync(c->adam_m.p, 0, c->nflat * sizeof(float), st));
+        EEM_HIP_CHECK(hipMemsetAsync(c->adam_v.p, 0, c->nflat * sizeof(float), st));
+        c->opt_step = 0;
+    }
+    if ((rc = ensure(c->scalars, 16)) != EEM_OK) return rc;
+    double* sumsq = (double*)c->scalars.p + 6;
+    EEM_HIP_CHECK(hipMemsetAsync(sumsq, 0, sizeof(double), st));
+    if ((rc = tr_sumsq_launch(grad, (long)c->nflat, sumsq, st)) != EEM_OK) return rc;
+    c->opt_step += 1;
+    if ((rc = tr_adamw_launch(c->flat, grad, c->adam_m.p, c->adam_v.p, (long)c->nflat, sumsq, clip, lr, weight_decay, eps, 0.9f,
+                              0.999f, c->opt_step, st)) != EEM_OK) return rc;
+    drop_graph(c);
+    return repack_launch(c->flat, c->pack_idx, c->arena, (long)c->arena_floats, st);
+}
+
+// Copy the device-resident weights (state_dict order) to `dst` (device) - checkpointing / syncing nn.Parameters.
+extern "C" int eemflow_get_weights(eemflow_ctx* c, float* dst, size_t nfloats, void* stream) {
+    EEM_REQUIRE(c && dst && c->weights_loaded, "eemflow_get_weights: bad arguments");
+    EEM_REQUIRE(nfloats == c->nflat, "eemflow_get_weights: expected %zu floats, got %zu", c->nflat, nfloats);
+    EEM_HIP_CHECK(hipMemcpyAsync(dst, c->flat, nfloats * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return EEM_OK;
+}

@@ -110,6 +110,32 @@ int eemflow_voxelize(const double* events, int64_t n, int bins, int h, int w, in
                      int64_t* idx_left, int64_t* idx_right, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Training step of EEMFlow (train_mvsec.py:229-258).  Weights live on the device in state_dict order; one
+ * flat gradient buffer in the same order is what a data-parallel job all-reduces (RCCL) between the two calls.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Forward (train-mode output size), sequence loss for the single prediction (weight = gamma^0 = 1 unless the
+ * caller scales it), and the full backward pass.  flow_gt [batch][2][out_h][out_w], valid [batch][out_h][out_w];
+ * flow_out [batch][2][out_h][out_w] receives the prediction; grad_out (device, 714 352 floats) receives
+ * d loss / d parameter; stats_out (host, 5 doubles, may be NULL): loss, mean EPE over valid pixels, valid
+ * count, fraction < 1 px, fraction < 3 px.
+ * Replaces: run_network + sequence_loss + scaler.scale(loss).backward()
+ * (train_mvsec.py:245-253,201-227; autograd of model/EEMFlow/EEMFlow.py:122-183). */
+int eemflow_forward_backward(eemflow_ctx* ctx, const float* events1, const float* events2, const float* flow_gt,
+                             const float* valid, int batch, int in_h, int in_w, int out_h, int out_w,
+                             float loss_weight, float* flow_out, float* grad_out, double* stats_out, void* stream);
+
+/* clip_grad_norm_(clip) + AdamW(lr, weight_decay, eps, betas 0.9/0.999) on the device-resident weights, then the
+ * re-pack of every kernel-side weight layout.  lr is the caller's OneCycleLR value for this step.
+ * Replaces: scaler.unscale_ + clip_grad_norm_ + scaler.step(optimizer)  (train_mvsec.py:254-258,178-183). */
+int eemflow_optimizer_step(eemflow_ctx* ctx, const float* grad, float lr, float weight_decay, float eps, float clip,
+                           void* stream);
+
+/* Copy the current weights (state_dict order, 714 352 floats) to a device buffer - checkpointing
+ * (train_EEMFlow_HREM.py:127-130 saves model.module.state_dict()). */
+int eemflow_get_weights(eemflow_ctx* ctx, float* dst, size_t nfloats, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * E-RAFT (model/eraft.py): feature / context encoders, all-pairs correlation pyramid, 9x9 x 4-level
  * lookup, SepConvGRU update block, convex upsampling.  Inference (eval-mode BatchNorm).
  * ---------------------------------------------------------------------------------------------- */

@@ -1,0 +1,117 @@
+"""EEMFlow training step on the GPU (C ABI) against the training oracle (torch autograd through the functional
+oracle) and the reference-generated golden.  `pytest -m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+from eemflow_amd import EEMFlow
+from eemflow_amd.train import EEMFlowTrainer
+from eemflow_amd.weights import seeded_state_dict, synthetic_gt, synthetic_voxel_pair
+from oracle import eemflow_oracle as O
+from oracle import train_oracle as T
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def make_net(seed, **kw):
+    sd = seeded_state_dict(seed)
+    net = EEMFlow("", groups=5, n_first_channels=5, **kw)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return net.to(DEV).train(), O.to_torch_sd(sd)
+
+
+def split_flat(flat, sd):
+    out, off = {}, 0
+    for k, v in sd.items():
+        out[k] = flat[off:off + v.numel()].view_as(v)
+        off += v.numel()
+    return out
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def run_grads(net, e1, e2, gt, valid):
+    tr = EEMFlowTrainer(net, lr=0.0, wdecay=0.0, clip=0.0)       # lr 0: the step leaves the weights unchanged
+    loss, metrics, flow = tr.step(e1.to(DEV), e2.to(DEV), gt.to(DEV), valid.to(DEV))
+    return loss, metrics, flow.cpu(), tr.grad.clone().cpu()
+
+
+def test_loss_and_gradients_vs_golden(golden):
+    g = golden("train_step.npz")
+    h, w = g["hw"].tolist()
+    b = int(g["batch"])
+    net, sd = make_net(int(g["seed"]))
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(int(g["input_seed"]), b, h, w))
+    gt, valid = (torch.from_numpy(a) for a in synthetic_gt(int(g["gt_seed"]), b, h, w))
+    loss, metrics, flow, flat = run_grads(net, e1, e2, gt, valid)
+    assert abs(loss - float(g["loss"])) < 1e-5 and abs(metrics["epe"] - float(g["epe"])) < 1e-4
+    assert float((flow - torch.from_numpy(g["flow"])).abs().max()) < 1e-4
+    grads = split_flat(flat, sd)
+    norms = np.array([float(v.double().norm()) for v in grads.values()])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-3, atol=1e-7)
+    for k in g.files:
+        if k.startswith("g:"):
+            assert rel_err(grads[k[2:]], torch.from_numpy(g[k])) < 2e-3, k
+
+
+@pytest.mark.parametrize("b,h,w,size", [(3, 70, 100, (70, 100)), (1, 128, 192, (128, 192)), (2, 64, 64, (100, 120))])
+def test_gradients_vs_oracle_autograd(b, h, w, size):
+    net, sd = make_net(23)
+    net.change_imagesize(size)                                   # (the third case: padder built for another size)
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(24, b, h, w))
+    gt, valid = (torch.from_numpy(a) for a in synthetic_gt(25, b, h, w))
+    loss, _, flow, flat = run_grads(net, e1, e2, gt, valid)
+    rloss, _, rgrads, rflow = T.loss_and_grads(sd, e1, e2, gt, valid, image_size=size)
+    assert abs(loss - rloss) < 1e-5 and float((flow - rflow).abs().max()) < 1e-4
+    grads = split_flat(flat, sd)
+    worst = max((rel_err(grads[k], rgrads[k]), k) for k in sd)
+    assert worst[0] < 3e-3, worst
+
+
+def test_three_optimizer_steps_vs_golden(golden):
+    g = golden("train_step.npz")
+    h, w = g["hw"].tolist()
+    b, seed = int(g["batch"]), int(g["seed"])
+    net, sd = make_net(seed)
+    net.change_imagesize((h, w))
+    tr = EEMFlowTrainer(net, lr=1e-3, wdecay=5e-5, epsilon=1e-8, num_steps=20, clip=1.0)
+    losses, lrs = [], []
+    for step in range(3):
+        e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(seed + 3100 + step, b, h, w))
+        gt, valid = (torch.from_numpy(a).to(DEV) for a in synthetic_gt(seed + 3200 + step, b, h, w))
+        loss, m, _ = tr.step(e1, e2, gt, valid)
+        losses.append(loss)
+        lrs.append(m["lr"])
+    np.testing.assert_allclose(lrs, g["step_lrs"], rtol=1e-6)
+    np.testing.assert_allclose(losses, g["step_losses"], rtol=2e-4)
+    tr.sync_parameters()
+    final = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    np.testing.assert_allclose([float(v.double().norm()) for v in final.values()], g["final_norms"], rtol=1e-4)
+    for k in g.files:
+        if k.startswith("p3:"):
+            assert float((final[k[3:]] - torch.from_numpy(g[k])).abs().max()) < 2e-4, k
+    # the updated weights are the ones inference now uses
+    net.eval()
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(77, 1, h, w))
+    with torch.no_grad():
+        flow = net(e1.to(DEV), e2.to(DEV))[1][0].cpu()
+        ref, _ = O.eemflow_forward({k: v for k, v in final.items()}, e1, e2)
+    assert float((flow - ref).abs().max()) < 1e-4
+
+
+def test_out_mesh_size_training():
+    net, sd = make_net(29, out_mesh_size=True)
+    net.change_imagesize((128, 128))
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(30, 2, 128, 128))
+    gt, valid = (torch.from_numpy(a) for a in synthetic_gt(31, 2, 16, 16))
+    loss, _, flow, flat = run_grads(net, e1, e2, gt, valid)
+    rloss, _, rgrads, rflow = T.loss_and_grads(sd, e1, e2, gt, valid, out_size=(16, 16))
+    assert flow.shape == (2, 2, 16, 16) and abs(loss - rloss) < 1e-5
+    grads = split_flat(flat, sd)
+    worst = max((rel_err(grads[k], rgrads[k]), k) for k in sd)
+    assert worst[0] < 3e-3, worst

@@ -105,3 +105,17 @@ def test_eraft_state_dict_layout(golden):
     assert list(sd.keys()) == g["keys"].tolist() and len(sd) == 179
     assert [list(v.shape) for v in sd.values()] == [s[s >= 0].tolist() for s in g["shapes"]]
     assert sum(v.numel() for k, v in sd.items() if "running" not in k and "num_batches" not in k) == int(g["nparams"])
+
+
+def test_onecycle_schedule_matches_torch():
+    from eemflow_amd.train import OneCycleLinear
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=1e-4)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, 1e-4, 300 + 100, pct_start=0.05, cycle_momentum=False,
+                                                anneal_strategy='linear')           # train_mvsec.py:182-183
+    mine = OneCycleLinear(1e-4, 300 + 100)
+    for step in range(400):
+        assert abs(opt.param_groups[0]["lr"] - mine.lr(step)) < 1e-12 * 1e4, step
+        opt.step()
+        if step < 399:
+            sched.step()

@@ -70,3 +70,21 @@ def aggregate_throughput(units_this_rank, seconds_this_rank, device=None):
     total = sum_over_ranks(units_this_rank, device)
     slowest = max_over_ranks(seconds_this_rank, device)
     return total / slowest, slowest
+
+
+def average_gradients(flat_grad):
+    """Data-parallel gradient exchange: ONE all-reduce (RCCL on GPUs) of the flat fp32 gradient buffer, then
+    divide by the world size - the mean over the global batch when every rank holds an equal shard, which is
+    what the reference's single-process nn.DataParallel computes (train_mvsec.py:215 means over the whole
+    scattered batch).  No-op without a process group."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+        flat_grad.div_(dist.get_world_size())
+    return flat_grad
+
+
+def broadcast_weights(flat_weights, src=0):
+    """Replicas start from rank `src`'s weights (replaces DataParallel's per-step re-broadcast by one at start)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(flat_weights, src=src)
+    return flat_weights

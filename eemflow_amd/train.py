@@ -13,9 +13,8 @@ scale/unscale is exact and is not reproduced.
 import ctypes
 
 import torch
-import torch.distributed as dist
 
-from . import _lib
+from . import _lib, parallel
 
 
 class OneCycleLinear:
@@ -73,9 +72,7 @@ class EEMFlowTrainer:
             s = _lib.current_stream_ptr(dev)
             _lib.check(L.eemflow_forward_backward(ctx, e1.data_ptr(), e2.data_ptr(), gt.data_ptr(), va.data_ptr(), b, h, w, oh, ow,
                                                   1.0, flow.data_ptr(), self.grad.data_ptr(), ctypes.byref(stats), s))
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                dist.all_reduce(self.grad)                       # RCCL; mean over the global batch = equal shards averaged
-                self.grad.div_(dist.get_world_size())
+            parallel.average_gradients(self.grad)                # one RCCL all-reduce of 2.86 MB per step
             lr = self.schedule.lr(self.iteration)
             _lib.check(L.eemflow_optimizer_step(ctx, self.grad.data_ptr(), lr, self.wdecay, self.eps, self.clip, s))
         self.iteration += 1

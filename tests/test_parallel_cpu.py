@@ -24,6 +24,14 @@ def _worker(rank, world, port, q):
     parallel.barrier()
     seconds = 1.0 + rank            # rank 1 is the slow one
     rate, slowest = parallel.aggregate_throughput(hi - lo, seconds)
+    import torch
+    # data-parallel gradient exchange: per-rank gradients of equal shards -> mean over the global batch
+    g = torch.full((1000,), float(rank + 1))
+    parallel.average_gradients(g)
+    assert torch.allclose(g, torch.full((1000,), 1.5))
+    wts = torch.arange(10.0) * (rank + 1)
+    parallel.broadcast_weights(wts, src=0)
+    assert torch.equal(wts, torch.arange(10.0))
     q.put((rank, lo, hi, rate, slowest, parallel.max_over_ranks(rank * 10.0)))
     parallel.barrier()
     import torch.distributed as dist

@@ -39,6 +39,7 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
     p.add_argument("--kernel-reps", type=int, default=20)
     p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--no-other-rows", action="store_true", help="skip the E-RAFT / training-step side timings")
     p.add_argument("--streams", type=int, default=3,
                    help="frames in flight per GPU: independent contexts on separate HIP streams, steps alternate")
     return p.parse_args()
@@ -91,6 +92,55 @@ def cpu_baseline(sd_np, e1, e2, budget_s):
                            f"(fastest of sweep {{{', '.join(f'{k}: {v * 1e3:.0f} ms' for k, v in sweep.items())}}}; "
                            f"host has {os.cpu_count()} logical CPUs, {ncpu} usable)",
                  "ms_per_frame": med * 1e3 / e1.shape[0]}
+
+
+def other_rows(dev):
+    """Short timings of the other built rows of the scope table (not the headline metric): E-RAFT inference at
+    BASELINE configs[4]'s shape and the EEMFlow training step at configs[2]'s shape.  Never fatal."""
+    out = {}
+    try:
+        from eemflow_amd.eraft import ERAFT
+        from eemflow_amd.eraft_weights import seeded_from_shapes
+        from eemflow_amd.weights import synthetic_voxel_pair
+        net = ERAFT("", 5).eval()
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in
+                             seeded_from_shapes({k: tuple(v.shape) for k, v in net.state_dict().items()}, 0).items()})
+        net = net.to(dev)
+        net.change_imagesize((480, 640))
+        e1, e2 = (torch.from_numpy(a).to(dev) for a in synthetic_voxel_pair(1, 1, 480, 640))
+        with torch.no_grad():
+            net(e1, e2, iters=12)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                net(e1, e2, iters=12)
+            torch.cuda.synchronize(dev)
+        out["eraft_640x480_12it_b1_frames_per_s"] = round(3 / (time.perf_counter() - t0), 2)
+        del net
+    except Exception as e:                                   # noqa: BLE001
+        out["eraft_error"] = repr(e)[:200]
+    try:
+        from eemflow_amd import EEMFlow
+        from eemflow_amd.train import EEMFlowTrainer
+        from eemflow_amd.weights import seeded_state_dict, synthetic_gt, synthetic_voxel_pair
+        b, h, w = 32, 260, 346
+        net = EEMFlow("", 5, 5)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(0).items()})
+        net = net.to(dev).train()
+        net.change_imagesize((h, w))
+        tr = EEMFlowTrainer(net, lr=1e-4, num_steps=1000)
+        e1, e2 = (torch.from_numpy(a).to(dev) for a in synthetic_voxel_pair(1, b, h, w))
+        gt, va = (torch.from_numpy(a).to(dev) for a in synthetic_gt(2, b, h, w))
+        tr.step(e1, e2, gt, va)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            tr.step(e1, e2, gt, va)
+        torch.cuda.synchronize(dev)
+        out["train_step_346x260_b32_ms"] = round((time.perf_counter() - t0) / 5 * 1e3, 2)
+    except Exception as e:                                   # noqa: BLE001
+        out["train_error"] = repr(e)[:200]
+    return out
 
 
 def load_traffic():
@@ -229,6 +279,8 @@ def main():
             "encoder_tflops_in_kernel": round(enc_tflops, 2),
             "kernels": kernels, **extra,
         }
+        if not args.no_other_rows:
+            line["other_rows"] = other_rows(dev)
         print(json.dumps(line), flush=True)
     parallel.barrier(dev)
     for c in ctxs:

@@ -103,6 +103,11 @@ extern "C" int eemflow_load_weights(eemflow_ctx* c, const float* flat, size_t nf
     auto push = [&host](size_t n) { size_t off = host.size(); host.resize(off + ((n + 3) & ~(size_t)3), 0.f); return off; };
     // transposed + flipped weights T[ci][co][k-1-ky][k-1-kx] packed for gconv: the data gradient of a conv is a
     // conv of the output gradient with T (transposed-stride for stride 2)
+    size_t enc_floats = 0;
+    for (int l = 0; l < ENC_NUM; ++l) {
+        const int cin = l == 0 ? n_first_channels : kEncLayers[l].cin;
+        enc_floats += (size_t)kEncLayers[l].cout * cin * 9 + kEncLayers[l].cout;
+    }
     auto pack_T = [&](eemflow_ctx::ConvRef& r, const float* w, const float* b, int cin, int cout, int k, int stride) {
         r.w = (size_t)(w - base); r.b = (size_t)(b - base); r.cin = cin; r.cout = cout; r.k = k; r.stride = stride;
         std::vector<float> T((size_t)cin * cout * k * k);
@@ -115,7 +120,18 @@ extern "C" int eemflow_load_weights(eemflow_ctx* c, const float* flat, size_t nf
         const int cs[1] = {cout};
         r.wT = push(gconv_packed_floats(cin, cs, 1, k, k));
         gconv_pack(T.data(), cin, cs, 1, k, k, host.data() + r.wT);
+        // stride-1 encoder layers: the data gradient is itself one of the encoder's conv shapes (cin <-> cout),
+        // so it runs on the same fast kernels with W^T
+        r.fast_dgrad = (k == 3 && stride == 1 && cin == cout && (cin == 16 || cin == 32 || cin == 64) && w < base + enc_floats);
+        if (r.fast_dgrad) {
+            r.wT_enc = push(enc_packed_floats(cout, cin));
+            enc_pack_weights(T.data(), cout, cin, host.data() + r.wT_enc);
+            r.wT_enc2 = push(enc2_packed_floats(cout, cin));
+            enc2_pack_weights(T.data(), cout, cin, host.data() + r.wT_enc2);
+            r.zero_bias = push(cin);
+        }
     };
+
     const float* p = base;
     for (int l = 0; l < ENC_NUM; ++l) {
         const int cin = l == 0 ? n_first_channels : kEncLayers[l].cin, cout = kEncLayers[l].cout;

@@ -63,7 +63,12 @@ struct eemflow_ctx {
     float* zero_page = nullptr;
     TailW rconv[3], dconv1[3], dgroup[3][3][5], dconv5[3], dconv6[3], dconv7[3], outc;
     // training: per-conv descriptors (flat offsets of weight/bias, packed transposed weights for gconv dgrad)
-    struct ConvRef { size_t w = 0, b = 0, wT = 0; int cin = 0, cout = 0, k = 3, stride = 1; };
+    struct ConvRef {
+        size_t w = 0, b = 0, wT = 0;                 // flat offsets of weight / bias; arena offset of gconv-packed W^T
+        size_t wT_enc = 0, wT_enc2 = 0, zero_bias = 0;   // stride-1 encoder layers: W^T packed for the encoder kernels
+        bool fast_dgrad = false;
+        int cin = 0, cout = 0, k = 3, stride = 1;
+    };
     ConvRef t_enc[ENC_NUM], t_rconv[3], t_dconv1[3], t_dgroup[3][3][5], t_dconv5[3], t_dconv6[3], t_dconv7[3], t_outc;
     // training workspace + optimizer state
     DevBuf padded, g_a1, g_f11, g_a2, g_b2, g_f12, g_a3, g_b3, g_f13, g_pool[3], g_cat[3], g_ta[3], g_tb[3], g_tc[3], g_td[3],
@@ -290,6 +295,7 @@ int run_forward(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2
         a.pad_top = sp.layer == ENC_1_1 ? c->pad[2] : 0;
         a.pad_left = sp.layer == ENC_1_1 ? c->pad[0] : 0;
         a.act = 1;
+        a.gate = nullptr;
         a.pool_partial = nullptr;
         a.pool_k = 0;
         for (int k = 0; k < 3; ++k)

@@ -78,6 +78,7 @@ struct EncConvArgs {
     int hraw, wraw;        // raw extent for ENC_1_1 (== hin, win elsewhere)
     int pad_top, pad_left; // replicate-pad offsets for ENC_1_1 (0 elsewhere)
     int act;               // 1: LeakyReLU(0.1)
+    const float* gate;     // backward use: [nimg][cout][hout][wout]; the result is multiplied by LeakyReLU'(gate)
     int tiles_x, tiles_y;  // filled by the launcher: block tiles per image (blocks are remapped XCD-aware)
     float* pool_partial;   // fast path only: per-block partial sums of the k x k stage pooling, or NULL
     int pool_k;

@@ -189,7 +189,9 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(EncConvArgs a) {
                     const int co = C::M16 ? (g * 4 + r) : (mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g);
                     float v = acc[u][mt][r];
                     if (a.act) v = v > 0.f ? v : 0.1f * v;
-                    dst[((size_t)co * a.hout + oy) * a.wout + ox] = v;
+                    const size_t o = ((size_t)co * a.hout + oy) * a.wout + ox;
+                    if (a.gate) v *= a.gate[(size_t)n * COUT * a.hout * a.wout + o] > 0.f ? 1.f : 0.1f;
+                    dst[o] = v;
                 }
         }
     }

@@ -245,7 +245,10 @@ __global__ __launch_bounds__(WAVES * 64) void enc_conv2_kernel(EncConvArgs a) {
                 for (int r = 0; r < C::ACC; ++r) {
                     const int mt = wm * C::MTW + m;
                     const int co = C::M16 ? (g * 4 + r) : (mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g);
-                    dst[((size_t)co * a.hout + oy) * a.wout + ox] = acc[u][m][r];
+                    const size_t o = ((size_t)co * a.hout + oy) * a.wout + ox;
+                    float v = acc[u][m][r];
+                    if (a.gate) v *= a.gate[(size_t)n * COUT * a.hout * a.wout + o] > 0.f ? 1.f : 0.1f;
+                    dst[o] = v;
                 }
         }
     }

@@ -15,7 +15,8 @@ struct WgradArgs {
 int tr_loss_launch(const float* flow, const float* gt, const float* valid, float* dflow, int batch, int hw, float weight,
                    double* stats, hipStream_t st);
 int tr_upsample_bwd_launch(const float* d, float* tmp, float* out, int nc, int oh, int ow, int h, int w, hipStream_t st);
-int tr_pool_bwd_launch(const float* dpool, float* g, long nc, int h, int w, int k, int gh, int gw, int accumulate, hipStream_t st);
+int tr_pool_bwd_launch(const float* dpool, float* g, long nc, int h, int w, int k, int gh, int gw, int accumulate, const float* gate,
+                       hipStream_t st);
 int tr_corr_bwd_launch(const float* dcv, int dcv_ctotal, const float* f1, const float* f2, float* d1, float* d2, int batch, int c,
                        int h, int w, const int* taps, int ntaps, hipStream_t st);
 int tr_bias_grad_launch(const float* g, const float* gate, int g_ctotal, int g_coff, int g_cmul, int cout, int n, int hw, float* db,

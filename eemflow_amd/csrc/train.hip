@@ -91,14 +91,16 @@ __global__ __launch_bounds__(256) void upbwd_y_kernel(const float* __restrict__ 
 
 // ---- avg_pool2d(k) backward: g[nc][y][x] (+)= dpool[nc][y/k][x/k] / k^2 inside the pooled region
 __global__ __launch_bounds__(256) void poolbwd_kernel(const float* __restrict__ dpool, float* __restrict__ g, long nc, int h, int w,
-                                                      int k, int gh, int gw, int accumulate) {
+                                                      int k, int gh, int gw, int accumulate, const float* __restrict__ gate) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= nc * h * w) return;
     const int x = idx % w, y = (idx / w) % h;
     const long c = idx / ((long)w * h);
     const int py = y / k, px = x / k;
     const float v = (py < gh && px < gw) ? dpool[(c * gh + py) * gw + px] / (float)(k * k) : 0.f;
-    g[idx] = accumulate ? g[idx] + v : v;
+    float r = accumulate ? g[idx] + v : v;
+    if (gate) r *= gate[idx] > 0.f ? 1.f : 0.1f;               // gradient w.r.t. the producing conv's pre-activation
+    g[idx] = r;
 }
 
 // ---- local correlation backward (the transpose of corr_kernel in tail.hip):
@@ -155,17 +157,17 @@ __global__ __launch_bounds__(256) void biasgrad_kernel(const float* __restrict__
 // them to dW with fp32 atomics at the end (one atomic per weight and block).
 constexpr int WG_TH = 4, WG_TW = 32, WG_PX = WG_TH * WG_TW, WG_GP = WG_PX + 1, WG_CI = 32, WG_MAXT = 9;
 
-template <int K>
+template <int K, int S>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     constexpr int KK = K * K;
-    __shared__ float lds[4 * 32 * WG_GP + WG_CI * 9 * 65];
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // MT*32*WG_GP + cin_here*XR*XC floats
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int ci0 = blockIdx.y * WG_CI;
     const int cin_here = min(WG_CI, a.cin - ci0);
     const int MT = (a.cout + 31) >> 5;
     const int NT = (cin_here * KK + 31) >> 5;
-    const int XR = (WG_TH - 1) * a.stride + K, XC = (WG_TW - 1) * a.stride + K;
+    constexpr int XR = (WG_TH - 1) * S + K, XC = (WG_TW - 1) * S + K;   // compile-time: the staging index math is mul/shift
     float* Gs = lds;
     float* Xs = lds + MT * 32 * WG_GP;
 
@@ -198,32 +200,34 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         const int bx = tile % tiles_x, by = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
         const int oy0 = by * WG_TH, ox0 = bx * WG_TW;
         __syncthreads();
+        // staging is branch-free (clamped addresses + select) so that the unrolled loads are all in flight together
+#pragma unroll 8
         for (int e = threadIdx.x; e < MT * 32 * WG_PX; e += 256) {
             const int co = e / WG_PX, p = e - co * WG_PX;
             const int oy = oy0 + (p >> 5), ox = ox0 + (p & 31);
-            float v = 0.f;
-            if (co < a.cout && oy < a.hout && ox < a.wout) {
-                const size_t o = ((size_t)n * a.g_ctotal + a.g_coff + (size_t)co * a.g_cmul) * ghw + (size_t)oy * a.wout + ox;
-                v = a.g[o];
-                if (a.gate) v *= a.gate[o] > 0.f ? 1.f : 0.1f;
-            }
-            Gs[co * WG_GP + p] = v;
+            const bool ok = co < a.cout && oy < a.hout && ox < a.wout;
+            const int coc = min(co, a.cout - 1), oyc = min(oy, a.hout - 1), oxc = min(ox, a.wout - 1);
+            const size_t o = ((size_t)n * a.g_ctotal + a.g_coff + (size_t)coc * a.g_cmul) * ghw + (size_t)oyc * a.wout + oxc;
+            float v = a.g[o];
+            if (a.gate) v *= a.gate[o] > 0.f ? 1.f : 0.1f;
+            Gs[co * WG_GP + p] = ok ? v : 0.f;
         }
-        const int gy0 = oy0 * a.stride - a.pad, gx0 = ox0 * a.stride - a.pad;
+        const int gy0 = oy0 * S - a.pad, gx0 = ox0 * S - a.pad;
+#pragma unroll 8
         for (int e = threadIdx.x; e < cin_here * XR * XC; e += 256) {
             const int ci_l = e / (XR * XC), rem = e - ci_l * (XR * XC);
             const int ry = rem / XC, rx = rem - ry * XC;
             const int iy = gy0 + ry, ix = gx0 + rx;
-            float v = 0.f;
-            if (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win)
-                v = a.x[((size_t)n * a.x_ctotal + a.x_coff + ci0 + ci_l) * xhw + (size_t)iy * a.win + ix];
-            Xs[e] = v;
+            const bool ok = iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
+            const int iyc = min(max(iy, 0), a.hin - 1), ixc = min(max(ix, 0), a.win - 1);
+            const float v = a.x[((size_t)n * a.x_ctotal + a.x_coff + ci0 + ci_l) * xhw + (size_t)iyc * a.win + ixc];
+            Xs[e] = ok ? v : 0.f;
         }
         __syncthreads();
 #pragma unroll 2
         for (int p = 0; p < WG_PX; p += 2) {
             const int pp = p + h;
-            const int xoff = ((pp >> 5) * a.stride) * XC + (pp & 31) * a.stride;
+            const int xoff = ((pp >> 5) * S) * XC + (pp & 31) * S;
 #pragma unroll
             for (int i = 0; i < WG_MAXT; ++i) {
                 if (i < ntile) {
@@ -304,8 +308,9 @@ int tr_upsample_bwd_launch(const float* d, float* tmp, float* out, int nc, int o
     return EEM_OK;
 }
 
-int tr_pool_bwd_launch(const float* dpool, float* g, long nc, int h, int w, int k, int gh, int gw, int accumulate, hipStream_t st) {
-    hipLaunchKernelGGL(poolbwd_kernel, dim3(nblocks(nc * h * w)), dim3(256), 0, st, dpool, g, nc, h, w, k, gh, gw, accumulate);
+int tr_pool_bwd_launch(const float* dpool, float* g, long nc, int h, int w, int k, int gh, int gw, int accumulate, const float* gate,
+                       hipStream_t st) {
+    hipLaunchKernelGGL(poolbwd_kernel, dim3(nblocks(nc * h * w)), dim3(256), 0, st, dpool, g, nc, h, w, k, gh, gw, accumulate, gate);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }
@@ -340,8 +345,19 @@ int tr_wgrad_launch(const WgradArgs& a, hipStream_t st) {
     workers = workers < 1 ? 1 : workers;
     workers = tiles < workers ? tiles : workers;
     dim3 grid(workers, nchunk);
-    if (a.k == 3) hipLaunchKernelGGL(wgrad_kernel<3>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(256), 0, st, a);
+    const int xr = (WG_TH - 1) * a.stride + a.k, xc = (WG_TW - 1) * a.stride + a.k;
+    const size_t lds_bytes = ((size_t)mt * 32 * WG_GP + (size_t)(a.cin < WG_CI ? a.cin : WG_CI) * xr * xc) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        EEM_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EEM_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EEM_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    EEM_REQUIRE(!(a.k == 1 && a.stride != 1), "tr_wgrad_launch: strided 1x1 convs are not built");
+    if (a.k == 3 && a.stride == 1) hipLaunchKernelGGL((wgrad_kernel<3, 1>), grid, dim3(256), lds_bytes, st, a);
+    else if (a.k == 3) hipLaunchKernelGGL((wgrad_kernel<3, 2>), grid, dim3(256), lds_bytes, st, a);
+    else hipLaunchKernelGGL((wgrad_kernel<1, 1>), grid, dim3(256), lds_bytes, st, a);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

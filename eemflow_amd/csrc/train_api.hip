@@ -160,15 +160,31 @@ extern "C" int eemflow_forward_backward(eemflow_ctx* c, const float* e1, const f
         {ENC_2_1, c->f11.p, 16, s.h1, s.w1, c->a2.p, c->g_a2.p, s.h2, s.w2, c->g_f11.p},
         {ENC_1_2, c->a1.p, 16, s.h1, s.w1, c->f11.p, c->g_f11.p, s.h1, s.w1, c->g_a1.p},
         {ENC_1_1, c->padded.p, c->cin0, s.hp, s.wp, c->a1.p, c->g_a1.p, s.h1, s.w1, nullptr}};
-    // the stage outputs feed the pooling: start each stage's gradient with the pooling backward
-    if ((rc = tr_pool_bwd_launch(c->g_pool[2].p, c->g_f13.p, (long)n2 * 64, s.h3, s.w3, 8, s.gh, s.gw, 0, st)) != EEM_OK) return rc;
+    // Encoder gradients are stored "pre-gated": g_* = dL/dY (.) LeakyReLU'(Y), the gradient w.r.t. the conv's
+    // pre-activation, so weight/bias gradients read them as they are and the stride-1 data gradients run on the
+    // encoder's own fast conv kernels (W^T, zero bias, no activation, epilogue gate = the next layer's output).
+    if ((rc = tr_pool_bwd_launch(c->g_pool[2].p, c->g_f13.p, (long)n2 * 64, s.h3, s.w3, 8, s.gh, s.gw, 0, c->f13.p, st)) != EEM_OK) return rc;
     for (const L& l : ls) {
         const ConvRef& r = c->t_enc[l.layer];
-        if ((rc = bw.wgrad(r, l.x, l.xc, 0, l.gy, l.y, r.cout, 0, 1, n2, l.hin, l.win, l.hout, l.wout)) != EEM_OK) return rc;
-        if (l.gx) {
-            if ((rc = bw.dgrad(r, l.gy, l.y, r.cout, 0, 1, n2, l.hout, l.wout, l.hin, l.win, l.gx, r.cin, 0)) != EEM_OK) return rc;
-            if (l.layer == ENC_3_1 && (rc = tr_pool_bwd_launch(c->g_pool[1].p, c->g_f12.p, (long)n2 * 32, s.h2, s.w2, 16, s.gh, s.gw, 1, st)) != EEM_OK) return rc;
-            if (l.layer == ENC_2_1 && (rc = tr_pool_bwd_launch(c->g_pool[0].p, c->g_f11.p, (long)n2 * 16, s.h1, s.w1, 32, s.gh, s.gw, 1, st)) != EEM_OK) return rc;
+        if ((rc = bw.wgrad(r, l.x, l.xc, 0, l.gy, nullptr, r.cout, 0, 1, n2, l.hin, l.win, l.hout, l.wout)) != EEM_OK) return rc;
+        if (!l.gx) continue;
+        if (r.fast_dgrad) {
+            EncConvArgs a;
+            memset(&a, 0, sizeof(a));
+            a.in0 = l.gy;
+            a.wpk = c->arena + r.wT_enc; a.wpk2 = c->arena + r.wT_enc2; a.bias = c->arena + r.zero_bias;
+            a.zero_page = c->zero_page; a.trash = c->zero_page + 64;
+            a.out = l.gx;
+            a.nimg = n2; a.nimg0 = n2;
+            a.hin = l.hout; a.win = l.wout; a.hout = l.hin; a.wout = l.win; a.hraw = l.hout; a.wraw = l.wout;
+            a.act = 0;
+            a.gate = l.x;                                        // -> gradient w.r.t. the previous conv's pre-activation
+            if ((rc = enc_conv_launch(r.cout, r.cin, 1, a, st)) != EEM_OK) return rc;
+        } else {
+            if ((rc = bw.dgrad(r, l.gy, nullptr, r.cout, 0, 1, n2, l.hout, l.wout, l.hin, l.win, l.gx, r.cin, 0)) != EEM_OK) return rc;
+            // stride-2 layers read a stage output, which also feeds the pooling: add that branch, then gate
+            if (l.layer == ENC_3_1 && (rc = tr_pool_bwd_launch(c->g_pool[1].p, c->g_f12.p, (long)n2 * 32, s.h2, s.w2, 16, s.gh, s.gw, 1, c->f12.p, st)) != EEM_OK) return rc;
+            if (l.layer == ENC_2_1 && (rc = tr_pool_bwd_launch(c->g_pool[0].p, c->g_f11.p, (long)n2 * 16, s.h1, s.w1, 32, s.gh, s.gw, 1, c->f11.p, st)) != EEM_OK) return rc;
         }
     }
     if (stats_out) {

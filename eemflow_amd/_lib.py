@@ -57,6 +57,17 @@ _SIGNATURES = {
                                          ctypes.c_int, ctypes.c_int, _c_float_p, ctypes.c_void_p]),
     "eraft_convex_upsample": (ctypes.c_int, [ctypes.c_void_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                              _c_float_p, ctypes.c_void_p]),
+    "eemplus_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "eemplus_destroy": (None, [ctypes.c_void_p]),
+    "eemplus_load_weights": (ctypes.c_int, [ctypes.c_void_p, _c_float_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int]),
+    "eemplus_forward": (ctypes.c_int, [ctypes.c_void_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       ctypes.POINTER(ctypes.c_int * 4), _c_float_p, ctypes.c_void_p]),
+    "eemplus_get_stage": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, _c_float_p, ctypes.c_size_t,
+                                         ctypes.POINTER(ctypes.c_int * 4), ctypes.c_void_p]),
+    "eemplus_warp": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                    _c_float_p, ctypes.c_void_p]),
+    "eemplus_upsample_flow_as": (ctypes.c_int, [_c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int, _c_float_p, ctypes.c_void_p]),
 }
 EXPORTS = tuple(_SIGNATURES)
 _lib = None

@@ -13,9 +13,10 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libeemflow_hip.so")
 SOURCES = ["api.hip", "conv_enc.hip", "conv_enc2.hip", "tail.hip", "voxel.hip", "gconv.hip", "eraft_kernels.hip",
-           "eraft_api.hip", "train.hip", "train_api.hip"]
+           "eraft_api.hip", "train.hip", "train_api.hip", "plus_kernels.hip", "plus_api.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
-EXTRA = {"voxel.hip": ["-ffp-contract=off"]}      # bit-exact f64 time scaling
+EXTRA = {"voxel.hip": ["-ffp-contract=off"],      # bit-exact f64 time scaling
+         "plus_kernels.hip": ["-ffp-contract=off"]}   # the warp mask depends on the last bit of the weight sum
 
 
 def _hipcc():
@@ -36,7 +37,7 @@ def build_library(force=False, verbose=True):
     hipcc = _hipcc()
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gconv.h"), os.path.join(CSRC, "eraft_kernels.h"), os.path.join(CSRC, "api_internal.h"), os.path.join(CSRC, "train.h"), os.path.join(PKG, "..", "include", "eemflow_hip.h"),
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gconv.h"), os.path.join(CSRC, "eraft_kernels.h"), os.path.join(CSRC, "api_internal.h"), os.path.join(CSRC, "train.h"), os.path.join(CSRC, "plus_kernels.h"), os.path.join(PKG, "..", "include", "eemflow_hip.h"),
                os.path.abspath(__file__)]
     jobs = []
     objs = []

@@ -17,7 +17,8 @@ enum {
     GEPI_PLAIN = 0,        // out = v
     GEPI_MUL = 1,          // out = v * e0                      (r * h of the GRU)
     GEPI_GRU = 2,          // out = (1 - e1) * e0 + e1 * v      (e0 = h, e1 = z)
-    GEPI_ADD_RELU = 3      // out = relu(v + e0)                (residual block tail)
+    GEPI_ADD_RELU = 3,     // out = relu(v + e0)                (residual block tail)
+    GEPI_ADD = 4           // out = v + e0                      (EEMFlow+ decoder: flow residual)
 };
 
 struct GConvArgs {
@@ -28,6 +29,7 @@ struct GConvArgs {
     const float* shift;    // [cout] or NULL (= 0)
     float* out;            // [N][out_ctotal][hout][wout], channel co goes to out_coff + co
     int out_ctotal, out_coff;
+    int out_cmul;          // channel co goes to out_coff + co * out_cmul (0 is read as 1): channel shuffle of grouped convs
     int n, hin, win, hout, wout, cout;
     int kh, kw, stride, pad_h, pad_w;
     int tstride;           // 0/1: ordinary conv.  2: transposed conv (data gradient of a stride-2 conv): the

@@ -135,8 +135,11 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvArgs a) {
                 } else if (a.epi == GEPI_ADD_RELU) {
                     v += a.e0[((size_t)n * a.e0_ctotal + a.e0_coff + co) * hwo + p];
                     v = v > 0.f ? v : 0.f;
+                } else if (a.epi == GEPI_ADD) {
+                    v += a.e0[((size_t)n * a.e0_ctotal + a.e0_coff + co) * hwo + p];
                 }
-                a.out[((size_t)n * a.out_ctotal + a.out_coff + co) * hwo + p] = v * a.out_scale;
+                const int oc = a.out_coff + co * (a.out_cmul > 1 ? a.out_cmul : 1);
+                a.out[((size_t)n * a.out_ctotal + oc) * hwo + p] = v * a.out_scale;
             }
     }
 }

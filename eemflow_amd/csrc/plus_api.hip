@@ -1,0 +1,309 @@
+// C ABI of EEMFlow+ (EEMFlow_cdc, model/EEMFlow/EEMFlow+.py:74-234): encoder, 6-level feature pyramid, and the
+// coarse-to-fine loop {cdc_model self-guided upsampling (warp, dense estimator, mask blend) -> warp -> 9x9
+// correlation -> decoder + residual}.  Convolutions run on gconv; the torch.cat's are channel offsets.
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/eemflow_hip.h"
+#include "eraft_kernels.h"
+#include "gconv.h"
+#include "plus_kernels.h"
+
+namespace {
+
+struct PBuf { float* p = nullptr; size_t cap = 0; };
+
+int pensure(PBuf& b, size_t floats) {
+    if (floats <= b.cap) return EEM_OK;
+    if (b.p) EEM_HIP_CHECK(hipFree(b.p));
+    b.p = nullptr; b.cap = 0;
+    EEM_HIP_CHECK(hipMalloc(&b.p, floats * sizeof(float)));
+    b.cap = floats;
+    return EEM_OK;
+}
+
+struct PLayer { size_t wpk = 0, bias = 0; int cin = 0, cout = 0, k = 3, stride = 1; };
+
+const int kTaps[53] = {0,  2,  4,  6,  8,  10, 12, 14, 16, 18, 20, 21, 22, 23, 24, 26, 28, 29, 30, 31, 32, 33, 34, 36, 38, 39, 40,
+                       41, 42, 44, 46, 47, 48, 49, 50, 51, 52, 54, 56, 57, 58, 59, 60, 62, 64, 66, 68, 70, 72, 74, 76, 78, 80};
+constexpr int kDW = 96, kDIn = 87, kDense = 184;
+
+}  // namespace
+
+struct eemplus_ctx {
+    int device = 0, cin0 = 15, groups = 3;
+    bool loaded = false;
+    float* arena = nullptr;
+    int* taps = nullptr;
+    PLayer enc[8], rconv[7], dec1[7], decg[7][3][3], dec5[7], dec6[7], dec7[7], de[6], c1x1[6];
+    PBuf padded, f[7], a2, dense, xout, fi, tw, fup[7], fw, cat, d[4], t64, t32, flow[7];
+    int B = 0, hl[7] = {0}, wl[7] = {0};
+    bool have_last = false;
+};
+
+namespace {
+
+struct Cur { const float* p; const float* end; const float* take(size_t n) { const float* r = p; p += n; return r; } };
+struct Pk {
+    std::vector<float> host;
+    size_t push(size_t n) { size_t off = host.size(); host.resize(off + ((n + 3) & ~(size_t)3), 0.f); return off; }
+};
+
+void mk(Pk& pk, PLayer& L, const float* w, const float* b, int cin, int cout, int k, int stride) {
+    L.cin = cin; L.cout = cout; L.k = k; L.stride = stride;
+    const int cs[1] = {cin};
+    L.wpk = pk.push(gconv_packed_floats(cout, cs, 1, k, k));
+    gconv_pack(w, cout, cs, 1, k, k, pk.host.data() + L.wpk);
+    L.bias = pk.push(cout);
+    memcpy(pk.host.data() + L.bias, b, cout * sizeof(float));
+}
+
+int conv(eemplus_ctx* c, const PLayer& L, const float* in, int in_ctotal, int in_coff, int n, int hin, int win, float* out,
+         int out_ctotal, int out_coff, int out_cmul, int act, const float* add, hipStream_t st) {
+    GConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nseg = 1;
+    a.seg[0].ptr = in; a.seg[0].c = L.cin; a.seg[0].ctotal = in_ctotal; a.seg[0].coff = in_coff;
+    a.wpk = c->arena + L.wpk; a.shift = c->arena + L.bias;
+    a.out = out; a.out_ctotal = out_ctotal; a.out_coff = out_coff; a.out_cmul = out_cmul;
+    const int pad = (L.k - 1) / 2;
+    a.n = n; a.hin = hin; a.win = win; a.hout = (hin + 2 * pad - L.k) / L.stride + 1; a.wout = (win + 2 * pad - L.k) / L.stride + 1;
+    a.cout = L.cout; a.kh = a.kw = L.k; a.stride = L.stride; a.pad_h = a.pad_w = pad;
+    a.act = act; a.out_scale = 1.f;
+    if (add) { a.epi = GEPI_ADD; a.e0 = add; a.e0_ctotal = L.cout; a.e0_coff = 0; }
+    return gconv_launch(a, st);
+}
+
+// Decoder (EEMFlow+.py:38-71): cat [B][87] -> flow [B][2] (+ residual)
+int run_decoder(eemplus_ctx* c, int l, int B, int h, int w, const float* residual, hipStream_t st) {
+    int rc;
+    const size_t g = (size_t)h * w;
+    for (int i = 0; i < 4; ++i)
+        if ((rc = pensure(c->d[i], B * kDW * g)) != EEM_OK) return rc;
+    if ((rc = pensure(c->t64, B * 64 * g)) != EEM_OK || (rc = pensure(c->t32, B * 32 * g)) != EEM_OK ||
+        (rc = pensure(c->flow[l], B * 2 * g)) != EEM_OK)
+        return rc;
+    if ((rc = conv(c, c->dec1[l], c->cat.p, kDIn, 0, B, h, w, c->d[0].p, kDW, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+    const int G = c->groups, per = kDW / G;
+    for (int layer = 0; layer < 3; ++layer)
+        for (int gi = 0; gi < G; ++gi) {
+            // group gi reads channels [gi*per, (gi+1)*per); channel_shuffle puts its output j at j*G + gi
+            const int oc = G == 1 ? 0 : gi, om = G == 1 ? 1 : G;
+            if ((rc = conv(c, c->decg[l][layer][gi], c->d[layer].p, kDW, gi * per, B, h, w, c->d[layer + 1].p, kDW, oc, om, GACT_LEAKY,
+                           nullptr, st)) != EEM_OK) return rc;
+        }
+    if ((rc = conv(c, c->dec5[l], c->d[3].p, kDW, 0, B, h, w, c->t64.p, 64, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+    if ((rc = conv(c, c->dec6[l], c->t64.p, 64, 0, B, h, w, c->t32.p, 32, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+    return conv(c, c->dec7[l], c->t32.p, 32, 0, B, h, w, c->flow[l].p, 2, 0, 1, GACT_NONE, residual, st);
+}
+
+}  // namespace
+
+extern "C" int eemplus_create(int device, eemplus_ctx** out) {
+    EEM_REQUIRE(out != nullptr, "eemplus_create: out is NULL");
+    int ndev = 0;
+    EEM_HIP_CHECK(hipGetDeviceCount(&ndev));
+    EEM_REQUIRE(device >= 0 && device < ndev, "eemplus_create: device %d of %d", device, ndev);
+    EEM_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    EEM_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    EEM_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, "built for gfx950 (MI355X) only; device %d is %s", device, prop.gcnArchName);
+    eemplus_ctx* c = new eemplus_ctx();
+    c->device = device;
+    hipError_t e = hipMalloc(&c->taps, sizeof(kTaps));
+    if (e == hipSuccess) e = hipMemcpy(c->taps, kTaps, sizeof(kTaps), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { eem_set_error("eemplus_create: %s", hipGetErrorString(e)); delete c; return EEM_ERR_HIP; }
+    *out = c;
+    return EEM_OK;
+}
+
+extern "C" void eemplus_destroy(eemplus_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    PBuf* one[] = {&c->padded, &c->a2, &c->dense, &c->xout, &c->fi, &c->tw, &c->fw, &c->cat, &c->t64, &c->t32,
+                   &c->d[0], &c->d[1], &c->d[2], &c->d[3]};
+    for (PBuf* b : one) if (b->p) (void)hipFree(b->p);
+    for (int l = 0; l < 7; ++l) {
+        if (c->f[l].p) (void)hipFree(c->f[l].p);
+        if (c->fup[l].p) (void)hipFree(c->fup[l].p);
+        if (c->flow[l].p) (void)hipFree(c->flow[l].p);
+    }
+    if (c->arena) (void)hipFree(c->arena);
+    if (c->taps) (void)hipFree(c->taps);
+    delete c;
+}
+
+extern "C" int eemplus_load_weights(eemplus_ctx* c, const float* flat, size_t nfloats, int n_first_channels, int groups) {
+    EEM_REQUIRE(c && flat, "eemplus_load_weights: NULL argument");
+    EEM_REQUIRE(n_first_channels >= 1 && n_first_channels <= 64, "eemplus_load_weights: n_first_channels=%d", n_first_channels);
+    EEM_REQUIRE(groups == 3 || groups == 1, "eemplus_load_weights: groups must be 3 (reference default) or 1, got %d", groups);
+    EEM_HIP_CHECK(hipSetDevice(c->device));
+    Cur cur{flat, flat + nfloats};
+    Pk pk;
+    auto layer = [&](PLayer& L, int cin, int cout, int k, int stride) {
+        const float* w = cur.take((size_t)cout * cin * k * k);
+        const float* b = cur.take(cout);
+        mk(pk, L, w, b, cin, cout, k, stride);
+    };
+    const int ec[8][3] = {{n_first_channels, 16, 2}, {16, 16, 1}, {16, 32, 2}, {32, 32, 1}, {32, 32, 1}, {32, 64, 2}, {64, 64, 1}, {64, 64, 1}};
+    for (int i = 0; i < 8; ++i) layer(c->enc[i], ec[i][0], ec[i][1], 3, ec[i][2]);
+    const int rc_in[7] = {0, 0, 32, 64, 64, 64, 64};
+    for (int l = 2; l <= 6; ++l) layer(c->rconv[l], rc_in[l], 32, 3, 1);
+    for (int i = 0; i < 4; ++i) (void)cur.take(2 * 2 * 4 * 4 + 2);                     // up3..up6: registered, never used
+    const int per = kDW / groups;
+    for (int l = 2; l <= 6; ++l) {
+        layer(c->dec1[l], kDIn, kDW, 3, 1);
+        for (int j = 0; j < 3; ++j) {
+            const float* w = cur.take((size_t)kDW * per * 9);
+            const float* b = cur.take(kDW);
+            for (int g = 0; g < groups; ++g) mk(pk, c->decg[l][j][g], w + (size_t)g * per * per * 9, b + g * per, per, per, 3, 1);
+        }
+        layer(c->dec5[l], kDW, 64, 3, 1);
+        layer(c->dec6[l], 64, 32, 3, 1);
+        layer(c->dec7[l], 32, 2, 3, 1);
+    }
+    const int de_in[6] = {64, 96, 128, 160, 176, 184}, de_out[6] = {32, 32, 32, 16, 8, 3};
+    for (int i = 0; i < 6; ++i) layer(c->de[i], de_in[i], de_out[i], 3, 1);
+    (void)cur.take((size_t)16 * 3 * 9 + 16 + 16 * 16 * 9 + 16 + 32 * 16 * 9 + 32 + 32 * 32 * 9 + 32);   // upsample_output_conv: unused
+    const int c1_in[6] = {15, 16, 32, 64, 64, 64};
+    for (int i = 0; i < 6; ++i) layer(c->c1x1[i], c1_in[i], 32, 1, 1);
+    EEM_REQUIRE(cur.p == cur.end, "eemplus_load_weights: the 136-tensor layout needs %zu floats, got %zu", (size_t)(cur.p - flat), nfloats);
+    if (c->arena) EEM_HIP_CHECK(hipFree(c->arena));
+    c->arena = nullptr;
+    EEM_HIP_CHECK(hipMalloc(&c->arena, pk.host.size() * sizeof(float)));
+    EEM_HIP_CHECK(hipMemcpy(c->arena, pk.host.data(), pk.host.size() * sizeof(float), hipMemcpyHostToDevice));
+    c->cin0 = n_first_channels; c->groups = groups; c->loaded = true;
+    return EEM_OK;
+}
+
+extern "C" int eemplus_forward(eemplus_ctx* c, const float* e1, const float* e2, int batch, int in_h, int in_w, const int pad[4],
+                               float* out, void* stream) {
+    EEM_REQUIRE(c && e1 && e2 && out && pad, "eemplus_forward: NULL argument");
+    EEM_REQUIRE(c->loaded, "eemplus_forward: no weights loaded");
+    EEM_REQUIRE(batch >= 1 && in_h >= 1 && in_w >= 1, "eemplus_forward: bad sizes");
+    EEM_HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int B = batch, n2 = 2 * batch, hp = in_h + pad[2] + pad[3], wp = in_w + pad[0] + pad[1];
+    int rc;
+    // ---- pad, encoder on both volumes (EEMFlow+.py:162-169)
+    if ((rc = pensure(c->padded, (size_t)n2 * c->cin0 * hp * wp)) != EEM_OK) return rc;
+    if ((rc = er_pad_launch(e1, c->padded.p, B * c->cin0, in_h, in_w, pad[0], pad[1], pad[2], pad[3], st)) != EEM_OK) return rc;
+    if ((rc = er_pad_launch(e2, c->padded.p + (size_t)B * c->cin0 * hp * wp, B * c->cin0, in_h, in_w, pad[0], pad[1], pad[2], pad[3], st)) != EEM_OK) return rc;
+    auto half = [](int v) { return (v - 1) / 2 + 1; };
+    int* hl = c->hl; int* wl = c->wl;
+    hl[1] = half(hp); wl[1] = half(wp); hl[2] = half(hl[1]); wl[2] = half(wl[1]); hl[3] = half(hl[2]); wl[3] = half(wl[2]);
+    for (int l = 4; l <= 6; ++l) { hl[l] = hl[l - 1] / 2; wl[l] = wl[l - 1] / 2; }
+    EEM_REQUIRE(hl[6] >= 1 && wl[6] >= 1, "eemplus_forward: padded input %dx%d is too small for the 6-level pyramid", hp, wp);
+    const int C[7] = {0, 16, 32, 64, 64, 64, 64};
+    for (int l = 1; l <= 6; ++l)
+        if ((rc = pensure(c->f[l], (size_t)n2 * C[l] * hl[l] * wl[l])) != EEM_OK) return rc;
+    // scratch for the two-conv stages: reuse `dense` (large) and `cat`
+    {
+        const size_t s1 = (size_t)n2 * 16 * hl[1] * wl[1], s2 = (size_t)n2 * 32 * hl[2] * wl[2], s3 = (size_t)n2 * 64 * hl[3] * wl[3];
+        size_t big = s1 > s2 ? s1 : s2; big = big > s3 ? big : s3;
+        if ((rc = pensure(c->dense, big)) != EEM_OK || (rc = pensure(c->fw, big)) != EEM_OK) return rc;
+        float* t0 = c->dense.p; float* t1 = c->fw.p;
+        if ((rc = conv(c, c->enc[0], c->padded.p, c->cin0, 0, n2, hp, wp, t0, 16, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+        if ((rc = conv(c, c->enc[1], t0, 16, 0, n2, hl[1], wl[1], c->f[1].p, 16, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+        if ((rc = conv(c, c->enc[2], c->f[1].p, 16, 0, n2, hl[1], wl[1], t0, 32, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+        if ((rc = conv(c, c->enc[3], t0, 32, 0, n2, hl[2], wl[2], t1, 32, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+        if ((rc = conv(c, c->enc[4], t1, 32, 0, n2, hl[2], wl[2], c->f[2].p, 32, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+        if ((rc = conv(c, c->enc[5], c->f[2].p, 32, 0, n2, hl[2], wl[2], t0, 64, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+        if ((rc = conv(c, c->enc[6], t0, 64, 0, n2, hl[3], wl[3], t1, 64, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+        if ((rc = conv(c, c->enc[7], t1, 64, 0, n2, hl[3], wl[3], c->f[3].p, 64, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+    }
+    for (int l = 4; l <= 6; ++l)                                                       // avg_pool2d(2,2) x3 (:170-175)
+        if ((rc = er_pool2_launch(c->f[l - 1].p, c->f[l].p, (long)n2 * 64, hl[l - 1], wl[l - 1], st)) != EEM_OK) return rc;
+
+    auto f1 = [&](int l) { return c->f[l].p; };
+    auto f2 = [&](int l) { return c->f[l].p + (size_t)B * C[l] * hl[l] * wl[l]; };
+    // ---- level 6 (:177-181)
+    {
+        const int h = hl[6], w = wl[6];
+        const size_t g = (size_t)h * w;
+        if ((rc = pensure(c->cat, B * kDIn * g)) != EEM_OK) return rc;
+        CorrJob cj = {f1(6), f2(6), c->cat.p, 64, kDIn};
+        if ((rc = corr_launch(&cj, 1, B, h, w, c->taps, 53, st)) != EEM_OK) return rc;
+        if ((rc = conv(c, c->rconv[6], f1(6), 64, 0, B, h, w, c->cat.p, kDIn, 53, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+        if ((rc = pl_copy_channels_launch(nullptr, 0, 0, c->cat.p, kDIn, 85, 2, B, (int)g, st)) != EEM_OK) return rc;
+        if ((rc = run_decoder(c, 6, B, h, w, nullptr, st)) != EEM_OK) return rc;
+    }
+    // ---- levels 5..2 (:183-229)
+    for (int l = 5; l >= 2; --l) {
+        const int h = hl[l], w = wl[l], hc = hl[l + 1], wc = wl[l + 1];
+        const size_t g = (size_t)h * w;
+        if ((rc = pensure(c->dense, B * kDense * g)) != EEM_OK || (rc = pensure(c->a2, B * 32 * g)) != EEM_OK ||
+            (rc = pensure(c->xout, B * 3 * g)) != EEM_OK || (rc = pensure(c->fi, B * 2 * g)) != EEM_OK ||
+            (rc = pensure(c->tw, B * 2 * g)) != EEM_OK || (rc = pensure(c->fup[l], B * 2 * g)) != EEM_OK ||
+            (rc = pensure(c->fw, B * C[l] * g)) != EEM_OK || (rc = pensure(c->cat, B * kDIn * g)) != EEM_OK)
+            return rc;
+        // 1x1 projections of both feature maps (:184-185); feature_1 goes straight into the dense buffer's x slot
+        if ((rc = conv(c, c->c1x1[l], f1(l), C[l], 0, B, h, w, c->dense.p, kDense, 120, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+        if ((rc = conv(c, c->c1x1[l], f2(l), C[l], 0, B, h, w, c->a2.p, 32, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+        // cdc_model.forward (cdc_utils.py:156-174)
+        if (hc != h || wc != w) {
+            if ((rc = pl_upflow_launch(c->flow[l + 1].p, c->fi.p, B, hc, wc, h, w, 1, st)) != EEM_OK) return rc;
+            // in-place side effect of upsample2d_flow_as(if_rate=True) on the coarser flow (cdc_utils.py:85-86)
+            if ((rc = pl_scale_flow_launch(c->flow[l + 1].p, B, hc * wc, (float)w / (float)wc, (float)h / (float)hc, st)) != EEM_OK) return rc;
+        } else {
+            EEM_HIP_CHECK(hipMemcpyAsync(c->fi.p, c->flow[l + 1].p, B * 2 * g * 4, hipMemcpyDeviceToDevice, st));
+        }
+        if ((rc = pl_warp_launch(c->a2.p, c->fi.p, 2, c->dense.p, kDense, 152, B, 32, h, w, 2, st)) != EEM_OK) return rc;
+        const int din[6] = {64, 96, 128, 160, 176, 184}, dout_off[5] = {88, 56, 24, 8, 0};
+        for (int i = 0; i < 5; ++i)
+            if ((rc = conv(c, c->de[i], c->dense.p, kDense, kDense - din[i], B, h, w, c->dense.p, kDense, dout_off[i], 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+        if ((rc = conv(c, c->de[5], c->dense.p, kDense, 0, B, h, w, c->xout.p, 3, 0, 1, GACT_NONE, nullptr, st)) != EEM_OK) return rc;
+        if ((rc = pl_warp_launch(c->fi.p, c->xout.p, 3, c->tw.p, 2, 0, B, 2, h, w, 1, st)) != EEM_OK) return rc;
+        if ((rc = pl_blend_launch(c->tw.p, c->fi.p, c->xout.p, c->fup[l].p, B, (int)g, st)) != EEM_OK) return rc;
+        // warp, correlate, decode (:189-193)
+        if ((rc = pl_warp_launch(f2(l), c->fup[l].p, 2, c->fw.p, C[l], 0, B, C[l], h, w, 0, st)) != EEM_OK) return rc;
+        CorrJob cj = {f1(l), c->fw.p, c->cat.p, C[l], kDIn};
+        if ((rc = corr_launch(&cj, 1, B, h, w, c->taps, 53, st)) != EEM_OK) return rc;
+        if ((rc = conv(c, c->rconv[l], f1(l), C[l], 0, B, h, w, c->cat.p, kDIn, 53, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+        if ((rc = pl_copy_channels_launch(c->fup[l].p, 2, 0, c->cat.p, kDIn, 85, 2, B, (int)g, st)) != EEM_OK) return rc;
+        if ((rc = run_decoder(c, l, B, h, w, c->fup[l].p, st)) != EEM_OK) return rc;
+    }
+    // ---- five full-resolution predictions, coarse to fine (:231-232); flow6..flow3 carry the doubling above
+    for (int i = 0, l = 6; l >= 2; --l, ++i)
+        if ((rc = pl_upflow_launch(c->flow[l].p, out + (size_t)i * B * 2 * in_h * in_w, B, hl[l], wl[l], in_h, in_w, 1, st)) != EEM_OK) return rc;
+    c->B = B; c->have_last = true;
+    return EEM_OK;
+}
+
+extern "C" int eemplus_get_stage(eemplus_ctx* c, const char* name, float* dst, size_t cap, int dims[4], void* stream) {
+    EEM_REQUIRE(c && name && dims, "eemplus_get_stage: NULL argument");
+    EEM_REQUIRE(c->have_last, "eemplus_get_stage: no forward has run");
+    const std::string nm(name);
+    const float* src = nullptr;
+    if (nm.size() == 5 && nm.compare(0, 4, "flow") == 0 && nm[4] >= '2' && nm[4] <= '6') {
+        const int l = nm[4] - '0';
+        src = c->flow[l].p; dims[0] = c->B; dims[1] = 2; dims[2] = c->hl[l]; dims[3] = c->wl[l];
+    } else if (nm.size() == 8 && nm.compare(0, 7, "flow_up") == 0 && nm[7] >= '2' && nm[7] <= '5') {
+        const int l = nm[7] - '0';
+        src = c->fup[l].p; dims[0] = c->B; dims[1] = 2; dims[2] = c->hl[l]; dims[3] = c->wl[l];
+    } else {
+        eem_set_error("eemplus_get_stage: unknown stage '%s'", name);
+        return EEM_ERR_ARG;
+    }
+    const size_t n = (size_t)dims[0] * dims[1] * dims[2] * dims[3];
+    if (dst == nullptr) return EEM_OK;
+    EEM_REQUIRE(cap >= n, "eemplus_get_stage: '%s' needs %zu floats, buffer holds %zu", name, n, cap);
+    EEM_HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return EEM_OK;
+}
+
+// The three warps as standalone ops: mode 0 EEMFlow_cdc.warp, 1 torch_warp, 2 WarpingLayer_no_div
+extern "C" int eemplus_warp(const float* x, const float* flow, int batch, int ch, int h, int w, int mode, float* out, void* stream) {
+    EEM_REQUIRE(x && flow && out && mode >= 0 && mode <= 2, "eemplus_warp: bad arguments");
+    return pl_warp_launch(x, flow, 2, out, ch, 0, batch, ch, h, w, mode, (hipStream_t)stream);
+}
+
+// upsample2d_flow_as(inputs, target, 'bilinear', if_rate): out [b][2][oh][ow]; with if_rate the INPUT is scaled in place afterwards
+extern "C" int eemplus_upsample_flow_as(float* inputs, int batch, int h, int w, int oh, int ow, int if_rate, float* out, void* stream) {
+    EEM_REQUIRE(inputs && out, "eemplus_upsample_flow_as: NULL argument");
+    int rc = pl_upflow_launch(inputs, out, batch, h, w, oh, ow, if_rate, (hipStream_t)stream);
+    if (rc != EEM_OK || !if_rate) return rc;
+    return pl_scale_flow_launch(inputs, batch, h * w, (float)ow / (float)w, (float)oh / (float)h, (hipStream_t)stream);
+}

@@ -1,0 +1,14 @@
+// Warp / resampling kernels of EEMFlow+ (see plus_kernels.hip).
+#pragma once
+#include "common.h"
+
+// mode 0: EEMFlow_cdc.warp (align_corners=True); 1: torch_warp (align False); 2: WarpingLayer_no_div (align False + mask)
+// x [b][c][h][w]; flow = channels 0,1 of a [b][flow_ctotal][h][w] tensor; out channels [out_coff, out_coff+c) of [b][out_ctotal][h][w]
+int pl_warp_launch(const float* x, const float* flow, int flow_ctotal, float* out, int out_ctotal, int out_coff, int batch, int c, int h,
+                   int w, int mode, hipStream_t st);
+int pl_upflow_launch(const float* in, float* out, int batch, int h, int w, int oh, int ow, int rate, hipStream_t st);
+int pl_scale_flow_launch(float* f, int batch, int hw, float su, float sv, hipStream_t st);
+int pl_blend_launch(const float* warped, const float* flow_init, const float* xout, float* out, int batch, int hw, hipStream_t st);
+// dst[:, d_coff : d_coff + c] = src[:, s_coff : s_coff + c]   (src NULL: zeros)
+int pl_copy_channels_launch(const float* src, int s_ctotal, int s_coff, float* dst, int d_ctotal, int d_coff, int c, int batch, int hw,
+                            hipStream_t st);

@@ -1,0 +1,137 @@
+// Warp family and flow resampling of EEMFlow+ (reference: model/EEMFlow/EEMFlow+.py:137-149,
+// model/EEMFlow/cdc_utils.py:50-103,156-174, utils_luo/tools.py:2262-2306).
+// Built with -ffp-contract=off: the reference's `grid_sample(ones) >= 1.0` mask depends on the last bit of
+// nw + ne + sw + se, so the coordinate and weight arithmetic follows ATen's CPU grid sampler operation by
+// operation (separate multiplies and adds, same association).
+#include "plus_kernels.h"
+
+namespace {
+
+inline unsigned nblocks(long n) { return (unsigned)((n + 255) / 256); }
+
+// mode 0: align_corners=True (EEMFlow_cdc.warp); 1: align_corners=False (torch_warp);
+// 2: align_corners=False + `grid_sample(ones) >= 1` mask (WarpingLayer_no_div)
+__global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ x, const float* __restrict__ flow, int flow_ctotal,
+                                                   float* __restrict__ out, int out_ctotal, int out_coff, int batch, int c, int h, int w,
+                                                   int mode) {
+    const int hw = h * w;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)batch * hw) return;
+    const int p = idx % hw, b = idx / hw;
+    const int py = p / w, px = p - py * w;
+    const float vx = (float)px + flow[((size_t)b * flow_ctotal + 0) * hw + p];
+    const float vy = (float)py + flow[((size_t)b * flow_ctotal + 1) * hw + p];
+    const float xn = 2.0f * vx / (float)max(w - 1, 1) - 1.0f;
+    const float yn = 2.0f * vy / (float)max(h - 1, 1) - 1.0f;
+    float ix, iy;
+    if (mode == 0) {
+        ix = (xn + 1.f) * ((float)(w - 1) / 2.f);
+        iy = (yn + 1.f) * ((float)(h - 1) / 2.f);
+    } else {
+        ix = (xn + 1.f) * ((float)w / 2.f) - 0.5f;
+        iy = (yn + 1.f) * ((float)h / 2.f) - 0.5f;
+    }
+    const float xw = floorf(ix), yn0 = floorf(iy);
+    const float wgt_w = ix - xw, wgt_e = 1.f - wgt_w, wgt_n = iy - yn0, wgt_s = 1.f - wgt_n;
+    const float nw = wgt_s * wgt_e, ne = wgt_s * wgt_w, sw = wgt_n * wgt_e, se = wgt_n * wgt_w;
+    // the float -> int conversion must not overflow for wild flows
+    const float cx = fminf(fmaxf(xw, -2.f), (float)w + 1.f), cy = fminf(fmaxf(yn0, -2.f), (float)h + 1.f);
+    const int x0 = (int)cx, y0 = (int)cy;
+    const bool in_w = x0 >= 0 && x0 < w, in_e = x0 + 1 >= 0 && x0 + 1 < w;
+    const bool in_n = y0 >= 0 && y0 < h, in_s = y0 + 1 >= 0 && y0 + 1 < h;
+    float m = 1.f;
+    if (mode == 2) {
+        const float ones = (((in_n && in_w ? 1.f : 0.f) * nw + (in_n && in_e ? 1.f : 0.f) * ne) + (in_s && in_w ? 1.f : 0.f) * sw) +
+                           (in_s && in_e ? 1.f : 0.f) * se;
+        m = ones >= 1.0f ? 1.f : 0.f;
+    }
+    for (int ch = 0; ch < c; ++ch) {
+        const float* s = x + ((size_t)b * c + ch) * hw;
+        const float v_nw = (in_n && in_w) ? s[y0 * w + x0] : 0.f;
+        const float v_ne = (in_n && in_e) ? s[y0 * w + x0 + 1] : 0.f;
+        const float v_sw = (in_s && in_w) ? s[(y0 + 1) * w + x0] : 0.f;
+        const float v_se = (in_s && in_e) ? s[(y0 + 1) * w + x0 + 1] : 0.f;
+        const float r = ((v_nw * nw + v_ne * ne) + v_sw * sw) + v_se * se;
+        out[((size_t)b * out_ctotal + out_coff + ch) * hw + p] = r * m;
+    }
+}
+
+// F.interpolate(bilinear, align_corners=True) of a flow [b][2][h][w] -> [b][2][oh][ow], optionally scaled by
+// (ow/w, oh/h) per channel (upsample2d_flow_as, if_rate=True; cdc_utils.py:80-103)
+__global__ __launch_bounds__(256) void upflow_kernel(const float* __restrict__ in, float* __restrict__ out, int batch, int h, int w,
+                                                     int oh, int ow, int rate) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)batch * 2 * oh * ow) return;
+    const int X = idx % ow, Y = (idx / ow) % oh;
+    const int bc = idx / ((long)ow * oh);
+    const float sy = oh > 1 ? (float)(h - 1) / (float)(oh - 1) : 0.f, sx = ow > 1 ? (float)(w - 1) / (float)(ow - 1) : 0.f;
+    const float fy = sy * (float)Y, fx = sx * (float)X;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float* s = in + (size_t)bc * h * w;
+    float v = (1.f - ly) * ((1.f - lx) * s[y0 * w + x0] + lx * s[y0 * w + x1]) + ly * ((1.f - lx) * s[y1 * w + x0] + lx * s[y1 * w + x1]);
+    if (rate) v *= (bc & 1) ? ((float)oh / (float)h) : ((float)ow / (float)w);
+    out[idx] = v;
+}
+
+// the in-place side effect of upsample2d_flow_as(if_rate=True): inputs[:,0] *= ow/w; inputs[:,1] *= oh/h
+__global__ __launch_bounds__(256) void scale_flow_kernel(float* __restrict__ f, int batch, int hw, float su, float sv) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)batch * 2 * hw) return;
+    f[idx] *= ((idx / hw) & 1) ? sv : su;
+}
+
+// flow_up = torch_warp(flow_init, inter_flow) * (1 - sigmoid(m)) + flow_init * sigmoid(m)   (cdc_utils.py:163-173)
+__global__ __launch_bounds__(256) void blend_kernel(const float* __restrict__ warped, const float* __restrict__ flow_init,
+                                                    const float* __restrict__ xout, float* __restrict__ out, int batch, int hw) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)batch * 2 * hw) return;
+    const int p = idx % hw, b = idx / (2L * hw);
+    const float mk = 1.f / (1.f + expf(-xout[((size_t)b * 3 + 2) * hw + p]));
+    out[idx] = warped[idx] * (1.f - mk) + flow_init[idx] * mk;
+}
+
+__global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restrict__ src, int s_ctotal, int s_coff, float* __restrict__ dst,
+                                                            int d_ctotal, int d_coff, int c, int batch, int hw) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)batch * c * hw) return;
+    const int p = idx % hw, ch = (idx / hw) % c, b = idx / ((long)hw * c);
+    dst[((size_t)b * d_ctotal + d_coff + ch) * hw + p] = src ? src[((size_t)b * s_ctotal + s_coff + ch) * hw + p] : 0.f;
+}
+
+}  // namespace
+
+int pl_warp_launch(const float* x, const float* flow, int flow_ctotal, float* out, int out_ctotal, int out_coff, int batch, int c, int h,
+                   int w, int mode, hipStream_t st) {
+    hipLaunchKernelGGL(warp_kernel, dim3(nblocks((long)batch * h * w)), dim3(256), 0, st, x, flow, flow_ctotal, out, out_ctotal, out_coff,
+                       batch, c, h, w, mode);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int pl_upflow_launch(const float* in, float* out, int batch, int h, int w, int oh, int ow, int rate, hipStream_t st) {
+    hipLaunchKernelGGL(upflow_kernel, dim3(nblocks((long)batch * 2 * oh * ow)), dim3(256), 0, st, in, out, batch, h, w, oh, ow, rate);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int pl_scale_flow_launch(float* f, int batch, int hw, float su, float sv, hipStream_t st) {
+    hipLaunchKernelGGL(scale_flow_kernel, dim3(nblocks((long)batch * 2 * hw)), dim3(256), 0, st, f, batch, hw, su, sv);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int pl_blend_launch(const float* warped, const float* flow_init, const float* xout, float* out, int batch, int hw, hipStream_t st) {
+    hipLaunchKernelGGL(blend_kernel, dim3(nblocks((long)batch * 2 * hw)), dim3(256), 0, st, warped, flow_init, xout, out, batch, hw);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int pl_copy_channels_launch(const float* src, int s_ctotal, int s_coff, float* dst, int d_ctotal, int d_coff, int c, int batch, int hw,
+                            hipStream_t st) {
+    hipLaunchKernelGGL(copy_channels_kernel, dim3(nblocks((long)batch * c * hw)), dim3(256), 0, st, src, s_ctotal, s_coff, dst, d_ctotal,
+                       d_coff, c, batch, hw);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}

@@ -173,6 +173,42 @@ int eraft_corr_lookup(eraft_ctx* ctx, const float* fmap1, const float* fmap2, co
 int eraft_convex_upsample(eraft_ctx* ctx, const float* flow, const float* mask, int batch, int h, int w, float* out,
                           void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * EEMFlow+ (EEMFlow_cdc, model/EEMFlow/EEMFlow+.py + cdc_utils.py): the coarse-to-fine bilinear flow-warp loop.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct eemplus_ctx eemplus_ctx;
+
+/* Replaces: EEMFlow_cdc.__init__ + .to(device)  (model/EEMFlow/EEMFlow+.py:75-135). */
+int eemplus_create(int device, eemplus_ctx** out);
+void eemplus_destroy(eemplus_ctx* ctx);
+
+/* The 136 tensors of the reference state_dict() back to back in registration order (the parameters the
+ * reference registers but never uses - up3..up6, cdc_model.upsample_output_conv - are present and skipped).
+ * Replaces: load_state_dict of EEMFlow_cdc. */
+int eemplus_load_weights(eemplus_ctx* ctx, const float* flat_host, size_t nfloats, int n_first_channels, int groups);
+
+/* events1/2 [batch][C][in_h][in_w], pad = [left, right, top, bottom] of InputPadder(img_size, 'chairs', 64);
+ * flow_out [5][batch][2][in_h][in_w]: the predictions of levels 6, 5, 4, 3, 2 at full resolution.
+ * Replaces: EEMFlow_cdc.forward(events1, events2)[1]  (model/EEMFlow/EEMFlow+.py:158-234). */
+int eemplus_forward(eemplus_ctx* ctx, const float* events1, const float* events2, int batch, int in_h, int in_w,
+                    const int pad[4], float* flow_out, void* stream);
+
+/* Intermediates of the LAST forward: "flow2".."flow6" (low-resolution level flows, incl. the in-place doubling
+ * the reference applies to flow3..flow6) and "flow_up2".."flow_up5". */
+int eemplus_get_stage(eemplus_ctx* ctx, const char* name, float* dst, size_t dst_capacity_floats, int dims_out[4],
+                      void* stream);
+
+/* Backward bilinear warp of x [batch][c][h][w] by flow [batch][2][h][w].  mode 0: EEMFlow_cdc.warp
+ * (EEMFlow+.py:137-149, align_corners=True); 1: tensor_tools.torch_warp (utils_luo/tools.py:2262-2306,
+ * align_corners=False); 2: WarpingLayer_no_div (cdc_utils.py:50-78, align_corners=False and the
+ * grid_sample(ones) >= 1 mask). */
+int eemplus_warp(const float* x, const float* flow, int batch, int c, int h, int w, int mode, float* out, void* stream);
+
+/* upsample2d_flow_as(inputs, target, 'bilinear', if_rate)  (cdc_utils.py:80-103): out [batch][2][oh][ow];
+ * with if_rate != 0 `inputs` is scaled in place afterwards, as the reference does. */
+int eemplus_upsample_flow_as(float* inputs, int batch, int h, int w, int oh, int ow, int if_rate, float* out,
+                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

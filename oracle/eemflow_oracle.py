@@ -50,6 +50,11 @@ def unpad(x, pad):
     return x[..., pad[2]:ht - pad[3], pad[0]:wd - pad[1]]
 
 
+def unpad_none(x):
+    """EEMFlow / EEMFlow+ never crop: predictions are interpolated from the padded grid to the input size."""
+    return x
+
+
 # ----------------------------------------------------------------------------- A3 encoder
 def convrelu(x, w, b, stride=1, groups=1):
     """3x3 conv, zero pad 1, bias, LeakyReLU(0.1) - model/EEMFlow/EEMFlow.py:26-30."""

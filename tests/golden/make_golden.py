@@ -415,6 +415,64 @@ def gen_train(mod):
     save("train_step.npz", **arrays)
 
 
+def load_reference_plus():
+    """model/EEMFlow/EEMFlow+.py with utils_luo.tools.tensor_tools.torch_warp restated from
+    utils_luo/tools.py:2262-2306 (that file itself cannot be imported - SURVEY.md Appendix A)."""
+    tt = sys.modules["utils_luo.tools"].tensor_tools
+
+    def torch_warp(cls, x, flo):
+        b, c, h, w = x.size()
+        xx = torch.arange(0, w).view(1, -1).repeat(h, 1).view(1, 1, h, w).repeat(b, 1, 1, 1)
+        yy = torch.arange(0, h).view(-1, 1).repeat(1, w).view(1, 1, h, w).repeat(b, 1, 1, 1)
+        vgrid = torch.cat((xx, yy), 1).float() + flo
+        vgrid[:, 0, :, :] = 2.0 * vgrid[:, 0, :, :] / max(w - 1, 1) - 1.0
+        vgrid[:, 1, :, :] = 2.0 * vgrid[:, 1, :, :] / max(h - 1, 1) - 1.0
+        return F.grid_sample(x, vgrid.permute(0, 2, 3, 1), padding_mode="zeros")
+
+    tt.torch_warp = classmethod(torch_warp)
+    spec = importlib.util.spec_from_file_location("EEMFlowP_ref", f"{REF}/model/EEMFlow/EEMFlow+.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def gen_plus(modp, tag, seed, batch, h, w, cin, keep):
+    from eemflow_amd.eemflow_plus import EEMFlow_cdc as Mirror
+    from eemflow_amd.plus_weights import seeded_from_shapes
+    shapes = {k: tuple(v.shape) for k, v in Mirror("", 3, cin).state_dict().items()}
+    sd = seeded_from_shapes(shapes, seed)
+    net = modp.EEMFlow_cdc(config="", groups=3, n_first_channels=cin).eval()
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(seed + 4000, batch, h, w, bins=cin))
+    with torch.no_grad():
+        (_, _), preds = net(e1, e2)
+    arrays = dict(seed=np.int64(seed), input_seed=np.int64(seed + 4000), batch=np.int64(batch), hw=np.array([h, w]),
+                  cin=np.int64(cin), pad=np.array(net.image_padder._pad), preds=torch.stack(preds).numpy())
+    if keep:
+        keys = list(net.state_dict().keys())
+        shp = np.full((len(keys), 4), -1, dtype=np.int64)
+        for i, v in enumerate(net.state_dict().values()):
+            shp[i, :v.dim()] = list(v.shape)
+        arrays.update(keys=np.array(keys), shapes=shp)
+        # warp family on small tensors (cdc_utils.py:50-103, EEMFlow+.py:137-149)
+        rng = np.random.default_rng(seed + 1)
+        x = rng.standard_normal((2, 4, 9, 11), dtype=np.float32)
+        flo = (rng.standard_normal((2, 2, 9, 11)) * 3).astype(np.float32)
+        from model.EEMFlow.cdc_utils import WarpingLayer_no_div, upsample2d_flow_as
+        tt = sys.modules["utils_luo.tools"].tensor_tools
+        with torch.no_grad():
+            small = torch.from_numpy((rng.standard_normal((2, 2, 5, 6)) * 2).astype(np.float32))
+            small_in = small.clone()
+            up = upsample2d_flow_as(small_in, torch.zeros(2, 1, 10, 12), mode="bilinear", if_rate=True)
+            arrays.update(w_x=x, w_flo=flo, w_no_div=WarpingLayer_no_div()(torch.from_numpy(x), torch.from_numpy(flo)).numpy(),
+                          w_torch_warp=tt.torch_warp(torch.from_numpy(x), torch.from_numpy(flo)).numpy(),
+                          w_align_true=net.warp(torch.from_numpy(x), torch.from_numpy(flo)).numpy(),
+                          up_in=small.numpy(), up_out=up.numpy(), up_in_after=small_in.numpy())
+    save(f"eemflow_plus_{tag}.npz", **arrays)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(4)
@@ -428,6 +486,9 @@ def main():
     gen_eemflow(mod, "100x150", seed=4, batch=1, h=100, w=150, keep_stages=False)
     gen_voxel(lu)
     gen_train(mod)
+    modp = load_reference_plus()
+    gen_plus(modp, "128x192", seed=12, batch=1, h=128, w=192, cin=5, keep=True)
+    gen_plus(modp, "100x150_c15", seed=13, batch=2, h=100, w=150, cin=15, keep=False)
     gen_eraft_layout()
     gen_eraft_lookup()
     gen_eraft_upsample()

@@ -1,0 +1,86 @@
+"""EEMFlow+ (EEMFlow_cdc) on the GPU against reference-generated goldens.  `pytest -m gpu`.
+
+The reference's WarpingLayer_no_div masks with `grid_sample(ones) >= 1.0`; that test flips on 1-ulp changes of
+the flow, so past the first warped level the REFERENCE ITSELF moves by up to ~0.1 px on a third of the pixels
+when only its CPU thread count changes (tests/test_oracle_golden.py::test_plus_forward).  Hence: the warp /
+resampling ops are checked bit-for-bit on fixed inputs, the coarse levels tightly, and the fine levels with the
+same robust statistics the reference satisfies against itself."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from eemflow_amd import _lib
+from eemflow_amd.eemflow_plus import EEMFlow_cdc
+from eemflow_amd.plus_weights import seeded_from_shapes
+from eemflow_amd.weights import synthetic_voxel_pair
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def stream():
+    return _lib.current_stream_ptr(torch.device(DEV))
+
+
+def make_net(seed, cin):
+    net = EEMFlow_cdc("", 3, cin).eval()
+    sd = seeded_from_shapes({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return net.to(DEV)
+
+
+@pytest.mark.parametrize("mode,key", [(2, "w_no_div"), (1, "w_torch_warp"), (0, "w_align_true")])
+def test_warp_family_same_mask(golden, mode, key):
+    g = golden("eemflow_plus_128x192.npz")
+    x, flo = torch.from_numpy(g["w_x"]).to(DEV), torch.from_numpy(g["w_flo"]).to(DEV)
+    b, c, h, w = x.shape
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().eemplus_warp(x.data_ptr(), flo.data_ptr(), b, c, h, w, mode, out.data_ptr(), stream()))
+    got, ref = out.cpu().numpy(), g[key]
+    assert np.array_equal(got == 0, ref == 0)                  # the >= 1.0 mask and the zero padding: identical support
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=2e-6)    # values: few-ulp differences in the 4-tap sum only
+
+
+def test_upsample_flow_as_and_its_side_effect(golden):
+    g = golden("eemflow_plus_128x192.npz")
+    inp = torch.from_numpy(g["up_in"]).to(DEV).clone()
+    b, _, h, w = inp.shape
+    out = torch.empty(b, 2, 10, 12, device=DEV)
+    _lib.check(_lib.lib().eemplus_upsample_flow_as(inp.data_ptr(), b, h, w, 10, 12, 1, out.data_ptr(), stream()))
+    np.testing.assert_allclose(out.cpu().numpy(), g["up_out"], atol=1e-5)
+    np.testing.assert_allclose(inp.cpu().numpy(), g["up_in_after"], rtol=1e-7)     # inputs scaled in place (cdc_utils.py:85-86)
+
+
+@pytest.mark.parametrize("tag", ["128x192", "100x150_c15"])
+def test_forward_vs_golden(golden, tag):
+    g = golden(f"eemflow_plus_{tag}.npz")
+    h, w = g["hw"].tolist()
+    cin, b = int(g["cin"]), int(g["batch"])
+    net = make_net(int(g["seed"]), cin)
+    assert len(net.state_dict()) == 136
+    net.change_imagesize((h, w))
+    assert net.image_padder._pad == g["pad"].tolist()
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(int(g["input_seed"]), b, h, w, bins=cin))
+    with torch.no_grad():
+        (r1, _), preds = net(e1, e2)
+    assert r1 is e1 and len(preds) == 5 and preds[0].shape == (b, 2, h, w)
+    got, ref = torch.stack(preds).cpu().numpy(), g["preds"]
+    assert np.isfinite(got).all()
+    err = np.abs(got - ref)
+    assert err[0].max() < 1e-3                                  # level 6: no warp upstream
+    for i in range(1, 5):                                       # levels 5..2: mask flips allowed, bounded like the reference's own
+        e = err[i].ravel()
+        assert np.median(e) < 2e-3, (i, float(np.median(e)))
+        assert (e > 0.25).mean() < 0.02, (i, float((e > 0.25).mean()))
+        assert e.max() < 2.0, (i, float(e.max()))
+
+
+def test_errors():
+    net = make_net(1, 5)
+    with pytest.raises(AttributeError):
+        net(torch.zeros(1, 5, 64, 64, device=DEV), torch.zeros(1, 5, 64, 64, device=DEV))
+    net.change_imagesize((64, 64))
+    with pytest.raises(_lib.EEMFlowHipError):
+        net(torch.zeros(1, 5, 64, 64), torch.zeros(1, 5, 64, 64))

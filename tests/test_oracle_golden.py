@@ -1,5 +1,7 @@
 """The oracle (oracle/eemflow_oracle.py) against vectors produced by the reference itself
 (tests/golden/make_golden.py).  CPU only."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -162,3 +164,51 @@ def test_train_three_steps(golden):
     for k in g.files:
         if k.startswith("p3:"):
             np.testing.assert_allclose(final[k[3:]].numpy(), g[k], atol=2e-5, err_msg=k)
+
+
+# ----------------------------------------------------------------------------- EEMFlow+ (A8)
+from oracle import eemflow_plus_oracle as P   # noqa: E402
+
+
+def plus_sd(seed, cin):
+    from eemflow_amd.eemflow_plus import EEMFlow_cdc
+    from eemflow_amd.plus_weights import seeded_from_shapes
+    shapes = {k: tuple(v.shape) for k, v in EEMFlow_cdc("", 3, cin).state_dict().items()}
+    return O.to_torch_sd(seeded_from_shapes(shapes, seed))
+
+
+def test_plus_warp_family(golden):
+    g = golden("eemflow_plus_128x192.npz")
+    x, flo = torch.from_numpy(g["w_x"]), torch.from_numpy(g["w_flo"])
+    assert np.array_equal(P.warping_layer_no_div(x, flo).numpy(), g["w_no_div"])       # incl. the >= 1.0 mask: bit-exact
+    assert np.array_equal(P.torch_warp(x, flo).numpy(), g["w_torch_warp"])
+    assert np.array_equal(P.warp_align_true(x, flo).numpy(), g["w_align_true"])
+    inp = torch.from_numpy(g["up_in"]).clone()
+    up = P.upsample2d_flow_as(inp, (10, 12), if_rate=True)
+    assert np.array_equal(up.numpy(), g["up_out"]) and np.array_equal(inp.numpy(), g["up_in_after"])   # in-place quirk
+
+
+@pytest.mark.parametrize("tag", ["128x192", "100x150_c15"])
+def test_plus_forward(golden, tag):
+    g = golden(f"eemflow_plus_{tag}.npz")
+    h, w = g["hw"].tolist()
+    cin = int(g["cin"])
+    sd = plus_sd(int(g["seed"]), cin)
+    if "keys" in g.files:
+        assert list(sd.keys()) == g["keys"].tolist() and len(sd) == 136
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(int(g["input_seed"]), int(g["batch"]), h, w, bins=cin))
+    # The reference's `grid_sample(ones) >= 1.0` warp mask flips on 1-ulp differences, and oneDNN's conv rounding
+    # depends on the thread count: with the generator's 4 threads the oracle is BIT-IDENTICAL to the reference; with
+    # another thread count the reference ITSELF moves by up to ~0.1 px on a third of the fine-level pixels.
+    nt = torch.get_num_threads()
+    torch.set_num_threads(4)
+    try:
+        with torch.no_grad():
+            preds, st = P.eemflow_plus_forward(sd, e1, e2)
+    finally:
+        torch.set_num_threads(nt)
+    assert st["pad"] == g["pad"].tolist()
+    got = torch.stack(preds).numpy()
+    np.testing.assert_allclose(got[:3], g["preds"][:3], atol=1e-5)          # levels 6, 5, 4: before the flips matter
+    if os.cpu_count() and os.cpu_count() >= 4:
+        assert np.array_equal(got, g["preds"])

@@ -12,10 +12,11 @@ from concurrent.futures import ThreadPoolExecutor
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libeemflow_hip.so")
-SOURCES = ["api.hip", "conv_enc.hip", "conv_enc2.hip", "tail.hip", "voxel.hip", "gconv.hip", "eraft_kernels.hip",
+SOURCES = ["api.hip", "conv_enc.hip", "conv_enc2.hip", "conv_wino.hip", "conv_wino32.hip", "tail.hip", "voxel.hip", "gconv.hip", "eraft_kernels.hip",
            "eraft_api.hip", "train.hip", "train_api.hip", "plus_kernels.hip", "plus_api.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
-EXTRA = {"voxel.hip": ["-ffp-contract=off"],      # bit-exact f64 time scaling
+EXTRA = {"voxel.hip": ["-ffp-contract=off"],
+         "conv_wino.hip": ["-fno-slp-vectorize"], "conv_wino32.hip": ["-fno-slp-vectorize"],     # packed f32 VALU beside MFMAs is slower than scalar (guide: anti-lever)      # bit-exact f64 time scaling
          "plus_kernels.hip": ["-ffp-contract=off"]}   # the warp mask depends on the last bit of the weight sum
 
 
@@ -46,7 +47,7 @@ def build_library(force=False, verbose=True):
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc, *FLAGS, *EXTRA.get(src, []), "-c", s, "-o", o])
+            jobs.append([hipcc, *FLAGS, *EXTRA.get(src, []), *os.environ.get("EEM_EXTRA_FLAGS", "").split(), "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

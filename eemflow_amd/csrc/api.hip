@@ -1,6 +1,7 @@
 // C ABI of libeemflow_hip.so (declared in include/eemflow_hip.h): context, weight packing,
 // workspace management, the forward schedule and its HIP-graph cache.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -63,6 +64,7 @@ extern "C" void eemflow_destroy(eemflow_ctx* c) {
         for (DevBuf* b : kb) if (b->p) (void)hipFree(b->p);
     }
     if (c->arena) (void)hipFree(c->arena);
+    if (c->wino) (void)hipFree(c->wino);
     if (c->flat) (void)hipFree(c->flat);
     if (c->pack_idx) (void)hipFree(c->pack_idx);
     if (c->taps) (void)hipFree(c->taps);
@@ -196,6 +198,22 @@ extern "C" int eemflow_load_weights(eemflow_ctx* c, const float* flat, size_t nf
     EEM_HIP_CHECK(hipMemcpy(c->flat, flat, nfloats * sizeof(float), hipMemcpyHostToDevice));
     int rc = repack_launch(c->flat, c->pack_idx, c->arena, (long)c->arena_floats, nullptr);
     if (rc != EEM_OK) return rc;
+    {   // Winograd-domain weights for the stride-1 C->C layers
+        const char* e = getenv("EEM_WINO");
+        c->use_wino = !(e && atoi(e) == 0);
+        size_t off = 0;
+        for (int l = 0; l < ENC_NUM; ++l) {
+            const EncLayerDesc& d = kEncLayers[l];
+            c->enc_wino[l] = l > 0 && wino_supported(d.cin, d.cout, d.stride, 4);
+            if (!c->enc_wino[l]) continue;
+            c->wino_off[l] = off;            off += wino_packed_floats(d.cin);
+            c->wino_off[ENC_NUM + l] = off;  off += wino_packed_floats(d.cin);
+        }
+        if (c->wino) EEM_HIP_CHECK(hipFree(c->wino));
+        c->wino = nullptr;
+        EEM_HIP_CHECK(hipMalloc(&c->wino, off * sizeof(float)));
+        if ((rc = refresh_wino(c, nullptr)) != EEM_OK) return rc;
+    }
     EEM_HIP_CHECK(hipDeviceSynchronize());
     c->cin0 = n_first_channels;
     c->groups = groups;

@@ -60,6 +60,12 @@ struct eemflow_ctx {
     float* arena = nullptr;
     size_t enc_w[ENC_NUM], enc_w2[ENC_NUM], enc_b[ENC_NUM];
     bool enc_has2[ENC_NUM];
+    // Winograd-domain weights of the stride-1 C->C encoder layers (conv_wino.hip): computed from `flat` by
+    // wino_transform_launch after every (re)pack; [l] forward weights, [ENC_NUM + l] W^T flipped (data gradient)
+    float* wino = nullptr;
+    size_t wino_off[2 * ENC_NUM];
+    bool enc_wino[ENC_NUM];
+    bool use_wino = true;              // EEM_WINO=0 in the environment keeps the direct-convolution kernels
     float* zero_page = nullptr;
     TailW rconv[3], dconv1[3], dgroup[3][3][5], dconv5[3], dconv6[3], dconv7[3], outc;
     // training: per-conv descriptors (flat offsets of weight/bias, packed transposed weights for gconv dgrad)
@@ -104,6 +110,18 @@ int ensure(DevBuf& b, size_t floats) {
     return EEM_OK;
 }
 
+// Recompute the Winograd-domain weights from the device-resident flat weights (after load / optimizer step).
+int refresh_wino(eemflow_ctx* c, hipStream_t st) {
+    for (int l = 0; l < ENC_NUM; ++l) {
+        if (!c->enc_wino[l]) continue;
+        const int ch = kEncLayers[l].cin;
+        int rc = wino_transform_launch(c->flat + c->t_enc[l].w, ch, 0, c->wino + c->wino_off[l], st);
+        if (rc != EEM_OK) return rc;
+        if ((rc = wino_transform_launch(c->flat + c->t_enc[l].w, ch, 1, c->wino + c->wino_off[ENC_NUM + l], st)) != EEM_OK) return rc;
+    }
+    return EEM_OK;
+}
+
 void drop_graph(eemflow_ctx* c) {
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     if (c->graph) (void)hipGraphDestroy(c->graph);
@@ -134,8 +152,10 @@ int compute_shape(eemflow_ctx* c, int batch, int in_h, int in_w, int out_h, int 
     for (int k = 0; k < 3; ++k) {
         const EncLayerDesc& d = kEncLayers[last[k]];
         int th, tw, pk;
-        enc2_tile(d.cin, d.cout, &th, &tw, &pk);
-        s->fuse[k] = c->enc_has2[last[k]] && enc2_supported(d.cin, d.cout, d.stride, ws[k]) && pk == ks[k];
+        const bool wino = c->use_wino && c->enc_wino[last[k]] && wino_supported(d.cin, d.cout, d.stride, ws[k]);
+        if (wino) wino_tile(d.cin, &th, &tw, &pk);
+        else enc2_tile(d.cin, d.cout, &th, &tw, &pk);
+        s->fuse[k] = (wino || (c->enc_has2[last[k]] && enc2_supported(d.cin, d.cout, d.stride, ws[k]))) && pk == ks[k];
         s->th[k] = th;
         s->prow[k] = ceil_div(hs[k], th);
         s->pcol[k] = ceil_div(ws[k], tw) * (tw / ks[k]);
@@ -284,6 +304,7 @@ int run_forward(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2
         a.in1 = sp.layer == ENC_1_1 ? e2 : nullptr;
         a.wpk = c->arena + c->enc_w[sp.layer];
         a.wpk2 = c->enc_has2[sp.layer] ? c->arena + c->enc_w2[sp.layer] : nullptr;
+        a.wwino = (c->use_wino && c->enc_wino[sp.layer]) ? c->wino + c->wino_off[sp.layer] : nullptr;
         a.zero_page = c->zero_page;
         a.trash = c->zero_page + 64;
         a.bias = c->arena + c->enc_b[sp.layer];

@@ -4,6 +4,9 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <type_traits>
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -34,6 +37,18 @@ void eem_set_error(const char* fmt, ...);
 
 __host__ __device__ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N) - the index is usable as a template /
+// inline-asm immediate inside f
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 // XCD-aware block remap: the dispatcher deals consecutive block ids round-robin over the 8 XCDs (each with
 // its own L2), so id b and b+8 share an L2.  Giving XCD x the contiguous range [x*cpx, (x+1)*cpx) of
 // logical tiles makes spatially adjacent tiles (which share halo rows/columns) hit the same L2.  Placement
@@ -41,6 +56,22 @@ __host__ __device__ static inline int ceil_div(int a, int b) { return (a + b - 1
 __device__ static inline unsigned xcd_logical_block(unsigned bid, unsigned nblocks_padded) {
     const unsigned cpx = nblocks_padded >> 3;
     return (bid & 7u) * cpx + (bid >> 3);
+}
+
+// Sum over groups of SW (4, 8 or 16) adjacent lanes with DPP row operations (VALU cross-lane moves - no
+// LDS traffic, unlike __shfl_xor's ds_bpermute): every lane of a group ends up holding the group sum.
+template <int CTRL>
+__device__ static __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int SW>
+__device__ static __forceinline__ float lane_group_sum(float v) {
+    static_assert(SW == 4 || SW == 8 || SW == 16, "group width");
+    v = dpp_add<0xB1>(v);                       // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);                       // quad_perm [2,3,0,1]
+    if (SW >= 8) v = dpp_add<0x141>(v);         // row_half_mirror: lane i <-> 7-i
+    if (SW >= 16) v = dpp_add<0x140>(v);        // row_mirror: lane i <-> 15-i
+    return v;
 }
 
 // ----------------------------------------------------------------------------- encoder conv
@@ -67,6 +98,7 @@ struct EncConvArgs {
     const float* in1;      // only ENC_1_1 (second event volume), else unused
     const float* wpk;      // packed weights, generic kernel (conv_enc.hip)
     const float* wpk2;     // packed weights, LDS-DMA fast path (conv_enc2.hip); may be NULL
+    const float* wwino;    // Winograd-domain weights (conv_wino.hip) for the stride-1 C->C layers; may be NULL
     const float* zero_page;// >= 16 zero bytes in device memory (source of out-of-image pieces)
     float* trash;          // >= 256 writable bytes: sink for the stores of out-of-image lanes
     const float* bias;
@@ -90,6 +122,18 @@ size_t enc2_packed_floats(int cin, int cout);
 void enc2_pack_weights(const float* w, int cin, int cout, float* packed);
 int enc_conv2_launch(int cin, int cout, int stride, const EncConvArgs& a, hipStream_t stream);
 void enc2_tile(int cin, int cout, int* th, int* tw, int* poolk);
+// Winograd F(2x2,3x3) path for the stride-1 C -> C layers (C = 16, 32, 64), conv_wino.hip
+bool wino_supported(int cin, int cout, int stride, int win);
+size_t wino_packed_floats(int c);
+// U = G g G^T of OIHW weights w [c][c][3][3] (device pointers), written in the register-fragment order of
+// wino_kernel; transpose_flip = 1 transforms W^T with flipped taps (the data gradient's weights)
+int wino_transform_launch(const float* w, int c, int transpose_flip, float* packed, hipStream_t stream);
+int wino_launch(int c, const EncConvArgs& a, hipStream_t stream);
+void wino_tile(int c, int* th, int* tw, int* poolk);
+// C = 32 / 64 on 32x32x2 MFMA with the Winograd rows split over 4 waves (conv_wino32.hip); reached through wino_*
+int wino32_transform_launch(const float* w, int c, int transpose_flip, float* packed, hipStream_t stream);
+int wino32_launch(int c, const EncConvArgs& a, hipStream_t stream);
+void wino32_tile(int c, int* th, int* tw, int* poolk);
 
 // ----------------------------------------------------------------------------- tail kernels
 // Generic small-grid 3x3 (or 1x1) conv on MFMA 16x16x4, K split over the 4 waves of a block.

@@ -18,22 +18,6 @@ namespace {
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
-// Sum over groups of SW (4, 8 or 16) adjacent lanes with DPP row operations (VALU cross-lane moves - no
-// LDS traffic, unlike __shfl_xor's ds_bpermute): every lane of a group ends up holding the group sum.
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float v) {
-    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-template <int SW>
-__device__ __forceinline__ float lane_group_sum(float v) {
-    static_assert(SW == 4 || SW == 8 || SW == 16, "group width");
-    v = dpp_add<0xB1>(v);                       // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E>(v);                       // quad_perm [2,3,0,1]
-    if (SW >= 8) v = dpp_add<0x141>(v);         // row_half_mirror: lane i <-> 7-i
-    if (SW >= 16) v = dpp_add<0x140>(v);        // row_mirror: lane i <-> 15-i
-    return v;
-}
-
 template <int CIN, int COUT, int STRIDE, int TH, int TWT, int WAVES, int WM, int CK>
 struct Cfg2 {
     static constexpr bool M16 = (COUT == 16);

@@ -173,6 +173,7 @@ extern "C" int eemflow_forward_backward(eemflow_ctx* c, const float* e1, const f
             memset(&a, 0, sizeof(a));
             a.in0 = l.gy;
             a.wpk = c->arena + r.wT_enc; a.wpk2 = c->arena + r.wT_enc2; a.bias = c->arena + r.zero_bias;
+            a.wwino = (c->use_wino && c->enc_wino[l.layer]) ? c->wino + c->wino_off[ENC_NUM + l.layer] : nullptr;
             a.zero_page = c->zero_page; a.trash = c->zero_page + 64;
             a.out = l.gx;
             a.nimg = n2; a.nimg0 = n2;
@@ -221,7 +222,8 @@ extern "C" int eemflow_optimizer_step(eemflow_ctx* c, const float* grad, float l
     if ((rc = tr_adamw_launch(c->flat, grad, c->adam_m.p, c->adam_v.p, (long)c->nflat, sumsq, clip, lr, weight_decay, eps, 0.9f,
                               0.999f, c->opt_step, st)) != EEM_OK) return rc;
     drop_graph(c);
-    return repack_launch(c->flat, c->pack_idx, c->arena, (long)c->arena_floats, st);
+    if ((rc = repack_launch(c->flat, c->pack_idx, c->arena, (long)c->arena_floats, st)) != EEM_OK) return rc;
+    return refresh_wino(c, st);
 }
 
 // Copy the device-resident weights (state_dict order) to `dst` (device) - checkpointing / syncing nn.Parameters.

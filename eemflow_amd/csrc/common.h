@@ -47,7 +47,10 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_vmcnt() {
+    // counts above the 6-bit field are clamped: waiting for more than asked is always safe
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N > 63 ? 63 : N) : "memory");
+}
 
 // XCD-aware block remap: the dispatcher deals consecutive block ids round-robin over the 8 XCDs (each with
 // its own L2), so id b and b+8 share an L2.  Giving XCD x the contiguous range [x*cpx, (x+1)*cpx) of

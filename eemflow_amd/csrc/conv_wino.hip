@@ -172,6 +172,7 @@ __global__ __launch_bounds__(WAVES * 64) void wino_kernel(EncConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { d[r][0] = dn[r][0][1]; d[r][1] = dn[r][1][0]; d[r][2] = dn[r][1][1]; d[r][3] = dn[r][2][0]; }
                 if (s + 1 < K::KS) load_patch(s + 1);
+                __builtin_amdgcn_sched_barrier(0);   // keep the next k-step's LDS reads ahead of this k-step's work
                 float t[4][4];
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(WAVES * 64) void wino_kernel(EncConvArgs a) {
                         acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[q >> 2][q & 3], v[nu], acc[p], 0, 0, 0);
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
 
             // ---- output transform, bias, LeakyReLU, [gate], stores, pooling partial sums

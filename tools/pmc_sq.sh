@@ -4,7 +4,9 @@ tag=${1:-sq}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS SQ_INSTS_WAVE32_LDS SQ_WAVES SQ_INSTS_SMEM"; do
+PASSES=${PMC_PASSES:-}
+if [ -n "$PASSES" ]; then IFS=";" read -ra PL <<< "$PASSES"; else PL=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS SQ_INSTS_WAVE32_LDS SQ_WAVES SQ_INSTS_SMEM"); fi
+for pass in "${PL[@]}"; do
   t=$(echo $pass | cut -d" " -f1)
   timeout 300 rocprofv3 --pmc $pass --output-format csv -d $out/$t -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-graph --streams 1 --kernel-reps 2 --no-other-rows > /dev/null 2> $out/$t.err
 done

@@ -27,7 +27,7 @@ s = np.frombuffer(buf, dtype=np.uint64).reshape(2048, 8, 8).astype(np.int64)
 nb = int((s[:, 0, 0] > 0).sum())
 s = s[:nb]
 print("blocks", nb)
-names = ["start->dma landed", "barrier", "k loop", "barrier+u write", "finish+stores(tile0)", "remaining tiles"]
+names = ["start->poff done", "bias+issue(0)", "k loop(+landing)", "barrier+u write", "finish+stores(tile0)", "remaining tiles"]
 for w in (0, 7):
     d = np.diff(s[:, w, :7], axis=1)
     print(f"wave {w}: " + "  ".join(f"{nm}: med {int(np.median(d[:, i]))} max {int(d[:, i].max())}" for i, nm in enumerate(names)))

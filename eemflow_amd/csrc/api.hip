@@ -38,8 +38,8 @@ extern "C" int eemflow_create(int device, eemflow_ctx** out) {
     hipError_t e = hipMalloc(&c->taps, sizeof(kTaps53));
     if (e == hipSuccess) e = hipMemcpy(c->taps, kTaps53, sizeof(kTaps53), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&c->vox_scratch, voxel_scratch_bytes());
-    if (e == hipSuccess) e = hipMalloc(&c->zero_page, 1024);
-    if (e == hipSuccess) e = hipMemset(c->zero_page, 0, 1024);
+    if (e == hipSuccess) e = hipMalloc(&c->zero_page, 4096);
+    if (e == hipSuccess) e = hipMemset(c->zero_page, 0, 4096);
     if (e != hipSuccess) {
         eem_set_error("eemflow_create: %s", hipGetErrorString(e));
         delete c;

@@ -306,7 +306,7 @@ int run_forward(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2
         a.wpk2 = c->enc_has2[sp.layer] ? c->arena + c->enc_w2[sp.layer] : nullptr;
         a.wwino = (c->use_wino && c->enc_wino[sp.layer]) ? c->wino + c->wino_off[sp.layer] : nullptr;
         a.zero_page = c->zero_page;
-        a.trash = c->zero_page + 64;
+        a.trash = c->zero_page + 256;
         a.bias = c->arena + c->enc_b[sp.layer];
         a.out = sp.out;
         a.nimg = n2; a.nimg0 = sp.layer == ENC_1_1 ? s.batch : n2;

@@ -77,6 +77,31 @@ __device__ static __forceinline__ float lane_group_sum(float v) {
     return v;
 }
 
+// Persistent blocks walk a CONTIGUOUS range of logical tiles (x fastest, then y, then image): XCD x owns tiles
+// [x*cpx, (x+1)*cpx) and its resident blocks split that range evenly.  Consecutive tiles of a block are
+// neighbours in x, so the coordinates advance without integer divisions - the CU's single scalar unit is shared
+// by all its waves, and three divisions per tile and wave were ~20 % of a tile's time in the Winograd kernels.
+struct TileCoord { int bx, by, n; };
+struct TileRange { int first, count; };
+__device__ static inline TileRange block_tile_range(int T, unsigned bid, unsigned nblocks) {
+    const int cpx = (T + 7) >> 3;
+    const int xcd = bid & 7, kb = bid >> 3, gb = nblocks >> 3;
+    const int r0 = xcd * cpx, r1 = min(r0 + cpx, T);
+    const int per = (cpx + gb - 1) / gb;
+    const int f = r0 + kb * per;
+    const int cnt = min(per, r1 - f);
+    return TileRange{f, cnt > 0 ? cnt : 0};
+}
+__device__ static inline TileCoord tile_coord(int lt, int tiles_x, int tiles_y) {
+    return TileCoord{lt % tiles_x, (lt / tiles_x) % tiles_y, lt / (tiles_x * tiles_y)};
+}
+__device__ static inline void tile_advance(TileCoord& t, int tiles_x, int tiles_y) {
+    if (++t.bx == tiles_x) {
+        t.bx = 0;
+        if (++t.by == tiles_y) { t.by = 0; ++t.n; }
+    }
+}
+
 // ----------------------------------------------------------------------------- encoder conv
 // Identifies one of the eight encoder layers (EEMFlow.py:75-82).
 enum EncLayer { ENC_1_1 = 0, ENC_1_2, ENC_2_1, ENC_2_2, ENC_2_3, ENC_3_1, ENC_3_2, ENC_3_3, ENC_NUM };
@@ -103,7 +128,7 @@ struct EncConvArgs {
     const float* wpk2;     // packed weights, LDS-DMA fast path (conv_enc2.hip); may be NULL
     const float* wwino;    // Winograd-domain weights (conv_wino.hip) for the stride-1 C->C layers; may be NULL
     const float* zero_page;// >= 16 zero bytes in device memory (source of out-of-image pieces)
-    float* trash;          // >= 256 writable bytes: sink for the stores of out-of-image lanes
+    float* trash;          // >= 1024 writable bytes: sink for the stores of out-of-image lanes (up to 16 B per lane)
     const float* bias;
     float* out;
     int nimg;              // images in this launch (2B)
@@ -119,6 +144,9 @@ struct EncConvArgs {
     int pool_k;
 };
 int enc_conv_launch(int cin, int cout, int stride, const EncConvArgs& a, hipStream_t stream);
+// first layer with 16-byte LDS-DMA staging (conv_enc1.hip): raw width % 4 == 0, no horizontal padding
+bool enc1_supported(const EncConvArgs& a);
+int enc1_launch(const EncConvArgs& a, hipStream_t stream);
 // fast path (feature width % 4 == 0, layers 2..8)
 bool enc2_supported(int cin, int cout, int stride, int win);
 size_t enc2_packed_floats(int cin, int cout);

@@ -15,6 +15,8 @@
 // * the first layer folds the reference's replicate padding (utils/image_utils.py:139-140)
 //   into the tile loader; bias is the accumulator's initial value; LeakyReLU(0.1) in the
 //   epilogue.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -259,6 +261,7 @@ int enc_conv_launch(int cin, int cout, int stride, const EncConvArgs& a, hipStre
     if (a.wwino && wino_supported(cin, cout, stride, a.win)) return wino_launch(cin, a, stream);
     if (a.wpk2 && enc2_supported(cin, cout, stride, a.win)) return enc_conv2_launch(cin, cout, stride, a, stream);
     //                                   CIN COUT S  TH TWT PADIN
+    if (cin == 5 && cout == 16 && stride == 2 && enc1_supported(a) && !getenv("EEM_NO_ENC1")) return enc1_launch(a, stream);
     if (cin == 5 && cout == 16 && stride == 2) return launch<5, 16, 2, 8, 4, true>(a, stream);
     if (cin == 16 && cout == 16 && stride == 1) return launch<16, 16, 1, 8, 4, false>(a, stream);
     if (cin == 16 && cout == 32 && stride == 2) return launch<16, 32, 2, 4, 1, false>(a, stream);

@@ -54,8 +54,21 @@ struct WCfg {
 // channel of k-step slot g (lane / 16): slots 0,1 (one half-wave) take channels 0 and 2 of the step
 __device__ __forceinline__ int cperm(int g) { return ((g & 1) << 1) | (g >> 1); }
 
+#ifdef EEM_STAMPS
+// diagnostic build only: per-wave s_memtime stamps of the block's SECOND tile (steady state), written at the end
+__device__ unsigned long long g_stamps16[2048 * 8 * 8];
+#define STAMP16(i) if (it == 1) st[i] = __builtin_amdgcn_s_memtime()
+#else
+#define STAMP16(i)
+#endif
+
 template <int C, int TH, int TW, int WAVES, int POOLK>
 __global__ __launch_bounds__(WAVES * 64) void wino_kernel(EncConvArgs a) {
+#ifdef EEM_STAMPS
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    st[6] = __builtin_amdgcn_s_memtime();
+    st[7] = __builtin_amdgcn_s_memrealtime();
+#endif
     using K = WCfg<C, TH, TW, WAVES>;
     constexpr int NWX = POOLK > 0 ? TW / POOLK : 1;                      // pooling windows per block tile (x)
     constexpr int RED = POOLK > 0 ? K::NGY * C * NWX : 0;                // pooling scratch (floats)
@@ -74,13 +87,10 @@ __global__ __launch_bounds__(WAVES * 64) void wino_kernel(EncConvArgs a) {
     const int slot = wave / K::COG;
     const int cog = wave % K::COG;
 
-    // ---- this block's tiles (same XCD-contiguous sweep as enc_conv3_kernel)
-    const int T = a.tiles_x * a.tiles_y * a.nimg;
-    const int cpx = (T + 7) >> 3;
-    const int xcd = blockIdx.x & 7, kb = blockIdx.x >> 3, gb = gridDim.x >> 3;
-    const int r0 = xcd * cpx, r1 = min(r0 + cpx, T);
-    const int ntile = (r0 + kb < r1) ? (r1 - r0 - kb + gb - 1) / gb : 0;
+    const TileRange tr_ = block_tile_range(a.tiles_x * a.tiles_y * a.nimg, blockIdx.x, gridDim.x);
+    const int ntile = tr_.count;
     if (ntile == 0) return;
+    TileCoord cur = tile_coord(tr_.first, a.tiles_x, a.tiles_y), nxt = cur;      // tile being computed / next to request
     const float* zero_page = a.zero_page;
 
     // ---- DMA plan: the piece a lane moves in wave-instruction k never changes; its offset from the tile's first
@@ -96,9 +106,8 @@ __global__ __launch_bounds__(WAVES * 64) void wino_kernel(EncConvArgs a) {
         const int q = rem - ry * K::PPR;
         poff[k] = (c * a.hin + ry) * a.win + q * 4;
     }
-    auto issue = [&](int it) {
-        const int lt = r0 + kb + it * gb;
-        const int bx = lt % a.tiles_x, by = (lt / a.tiles_x) % a.tiles_y, n = lt / (a.tiles_x * a.tiles_y);
+    auto issue = [&](int it, const TileCoord& tc) {
+        const int bx = tc.bx, by = tc.by, n = tc.n;
         const int gy0 = by * TH - 1, gxa = bx * TW - 4;
         const float* src = a.in0 + (size_t)n * C * a.hin * a.win + (gy0 * a.win + gxa);
         float* sbase = lds + (it & 1) * K::STAGE;
@@ -126,20 +135,24 @@ __global__ __launch_bounds__(WAVES * 64) void wino_kernel(EncConvArgs a) {
     float biasv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) biasv[r] = a.bias[cog * 16 + g * 4 + r];
-    issue(0);
+    issue(0, nxt);
     // stationary weights (k-step-major float4s); requested only after tile 0's input has landed - see conv_wino32.hip
     f32x4 wr[K::NW4];
     const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wwino) + (size_t)cog * K::NW4 * 64 + lane;
 
     auto tile = [&](int it, auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
-        if (it + 1 < ntile) issue(it + 1);           // its stage was last read by tile it-1: free since the barrier
+        STAMP16(1);
+        if (it + 1 < ntile) {                        // its stage was last read by tile it-1: free since the barrier
+            tile_advance(nxt, a.tiles_x, a.tiles_y);
+            issue(it + 1, nxt);
+        }
+        STAMP16(2);
         if constexpr (FIRST) {
 #pragma unroll
             for (int q = 0; q < K::NW4; ++q) wr[q] = wsrc[q * 64];
         }
-        const int lt = r0 + kb + it * gb;
-        const int bx = lt % a.tiles_x, by = (lt / a.tiles_x) % a.tiles_y, n = lt / (a.tiles_x * a.tiles_y);
+        const int bx = cur.bx, by = cur.by, n = cur.n;
         const float* tb = lds + (it & 1) * K::STAGE;
         const int hw = a.hout * a.wout;
         float* dst = a.out + (size_t)n * C * hw;
@@ -194,6 +207,7 @@ __global__ __launch_bounds__(WAVES * 64) void wino_kernel(EncConvArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
 
+            STAMP16(3);
             // ---- output transform, bias, LeakyReLU, [gate], stores, pooling partial sums
             const int oy = by * TH + 2 * tr, ox = bx * TW + 2 * (xg * 16 + j);
             const bool in0 = oy < a.hout && ox < a.wout, in1 = oy + 1 < a.hout && ox < a.wout;
@@ -241,6 +255,7 @@ __global__ __launch_bounds__(WAVES * 64) void wino_kernel(EncConvArgs a) {
                 }
             }
         }
+        STAMP16(4);
         if constexpr (POOLK > 0) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -260,15 +275,27 @@ __global__ __launch_bounds__(WAVES * 64) void wino_kernel(EncConvArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // tile 0's input has landed
     __builtin_amdgcn_s_barrier();
     tile(0, std::true_type{});
+    tile_advance(cur, a.tiles_x, a.tiles_y);
     // from here on the weights are plain register values for the compiler (no vmcnt bookkeeping in the loop)
 #pragma unroll
     for (int q = 0; q < K::NW4; ++q) asm volatile("" : "+v"(wr[q]));
 #pragma unroll 1
     for (int it = 1; it < ntile; ++it) {
+        STAMP16(0);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS) : "memory");           // all but the previous tile's stores
         __builtin_amdgcn_s_barrier();
         tile(it, std::false_type{});
+        tile_advance(cur, a.tiles_x, a.tiles_y);
+        STAMP16(5);
     }
+#ifdef EEM_STAMPS
+    st[6] = __builtin_amdgcn_s_memtime() - st[6];
+    st[7] = __builtin_amdgcn_s_memrealtime() - st[7];
+    if (lane == 0 && blockIdx.x < 2048) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int i = 0; i < 8; ++i) g_stamps16[(blockIdx.x * 8 + wave) * 8 + i] = st[i];
+    }
+#endif
 }
 
 // ---- weight transform U = G g G^T into the fragment order read above:
@@ -337,6 +364,12 @@ bool wino_supported(int cin, int cout, int stride, int win) {
 }
 
 size_t wino_packed_floats(int c) { return (size_t)16 * c * c; }
+
+#ifdef EEM_STAMPS
+extern "C" int eemflow_debug_read_stamps16(unsigned long long* dst, size_t n) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps16), n * sizeof(unsigned long long)) == hipSuccess ? 0 : 2;
+}
+#endif
 
 int wino_transform_launch(const float* w, int c, int transpose_flip, float* packed, hipStream_t stream) {
     EEM_REQUIRE(c == 16 || c == 32 || c == 64, "wino_transform_launch: C=%d", c);

@@ -59,7 +59,7 @@ __device__ unsigned long long g_stamps[2048 * 8 * 8];
 #define STAMP(i)
 #endif
 
-template <int C, int TH, int TW, int NGH, int WAVES, int POOLK>
+template <int C, int TH, int TW, int NGH, int WAVES, bool STREAM, int POOLK>
 __global__ __launch_bounds__(WAVES * 64) void wino32_kernel(EncConvArgs a) {
 #ifdef EEM_STAMPS
     unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -86,51 +86,33 @@ __global__ __launch_bounds__(WAVES * 64) void wino32_kernel(EncConvArgs a) {
     const int tr = (slot / K::NGX) * NGH + ty;                           // tile row inside the block tile
     const int txb = (slot % K::NGX) * (K::NGW / 2) + tx;                 // tile column inside the block tile
 
-    const int T = a.tiles_x * a.tiles_y * a.nimg;
-    const int cpx = (T + 7) >> 3;
-    const int xcd = blockIdx.x & 7, kb = blockIdx.x >> 3, gb = gridDim.x >> 3;
-    const int r0 = xcd * cpx, r1 = min(r0 + cpx, T);
-    const int ntile = (r0 + kb < r1) ? (r1 - r0 - kb + gb - 1) / gb : 0;
+    const TileRange tr_ = block_tile_range(a.tiles_x * a.tiles_y * a.nimg, blockIdx.x, gridDim.x);
+    const int ntile = tr_.count;
     if (ntile == 0) return;
+    TileCoord cur = tile_coord(tr_.first, a.tiles_x, a.tiles_y), nxt = cur;      // tile being computed / next to request
     const float* zero_page = a.zero_page;
 
-    // ---- DMA plan: the piece a lane moves in wave-instruction k never changes; its offset from the tile's
-    // first staged element is kept, tiles that lie inside the image skip the per-piece bounds tests
-    int poff[K::NI];
-#pragma unroll
-    for (int k = 0; k < K::NI; ++k) {
-        int p = (wave + k * WAVES) * 64 + lane;
-        p = p < K::PIECES ? p : K::PIECES - 1;                           // padding lanes re-copy the last piece
-        const int c = p / (K::IN_ROWS * K::PPR);
-        const int rem = p - c * (K::IN_ROWS * K::PPR);
-        const int ry = rem / K::PPR;
-        const int q = rem - ry * K::PPR;
-        poff[k] = (c * a.hin + ry) * a.win + q * 4;
-    }
-    auto issue = [&](int it) {
-        const int lt = r0 + kb + it * gb;
-        const int bx = lt % a.tiles_x, by = (lt / a.tiles_x) % a.tiles_y, n = lt / (a.tiles_x * a.tiles_y);
+    // ---- DMA: wave-instruction k of a wave always moves the same piece (channel c, tile row ry, 16-byte column
+    // q) per lane; the decomposition is recomputed per tile (a dozen VALU per piece) rather than kept in registers -
+    // the k-loop needs every VGPR it can get
+    auto issue = [&](int it, const TileCoord& tc) {
+        const int bx = tc.bx, by = tc.by, n = tc.n;
         const int gy0 = by * TH - 1, gxa = bx * TW - 4;
         const float* src = a.in0 + (size_t)n * C * a.hin * a.win + (gy0 * a.win + gxa);
         float* sbase = lds + (it & 1) * K::STAGE;
         const bool interior = gy0 >= 0 && gy0 + K::IN_ROWS <= a.hin && gxa >= 0 && gxa + K::ROWP <= a.win;
-        if (interior) {
 #pragma unroll
-            for (int k = 0; k < K::NI; ++k)
-                __builtin_amdgcn_global_load_lds(GLB_PTR(src + poff[k]), LDS_PTR(sbase + (wave + k * WAVES) * 256), 16, 0, 0);
-        } else {
-#pragma unroll
-            for (int k = 0; k < K::NI; ++k) {
-                int p = (wave + k * WAVES) * 64 + lane;
-                p = p < K::PIECES ? p : K::PIECES - 1;
-                const int rem = p % (K::IN_ROWS * K::PPR);
-                const int ry = rem / K::PPR;
-                const int q = rem - ry * K::PPR;
-                const int gy = gy0 + ry, gx = gxa + q * 4;
-                const bool ok = gy >= 0 && gy < a.hin && gx >= 0 && gx < a.win;
-                const float* gp = ok ? src + poff[k] : zero_page;
-                __builtin_amdgcn_global_load_lds(GLB_PTR(gp), LDS_PTR(sbase + (wave + k * WAVES) * 256), 16, 0, 0);
-            }
+        for (int k = 0; k < K::NI; ++k) {
+            int p = (wave + k * WAVES) * 64 + lane;
+            p = p < K::PIECES ? p : K::PIECES - 1;                       // padding lanes re-copy the last piece
+            const int c = p / (K::IN_ROWS * K::PPR);
+            const int rem = p - c * (K::IN_ROWS * K::PPR);
+            const int ry = rem / K::PPR;
+            const int q = rem - ry * K::PPR;
+            const int gy = gy0 + ry, gx = gxa + q * 4;
+            const bool ok = interior || (gy >= 0 && gy < a.hin && gx >= 0 && gx < a.win);
+            const float* gp = ok ? src + ((c * a.hin + ry) * a.win + q * 4) : zero_page;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(gp), LDS_PTR(sbase + (wave + k * WAVES) * 256), 16, 0, 0);
         }
     };
 
@@ -138,13 +120,18 @@ __global__ __launch_bounds__(WAVES * 64) void wino32_kernel(EncConvArgs a) {
     float biasv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) biasv[r] = a.bias[cog * 32 + r + 8 * xi + 4 * kk];
-    issue(0);
-    // Stationary weights, one float4 (nu = 0..3) per k-step.  They are NOT requested here: a CU serves its waves'
-    // requests in issue order, so 8 x 32 KB of weight loads queued behind the first waves' DMA would hold back the
-    // other waves' input pieces (measured: tile 0 landed after 10-13k cycles).  Tile 0 requests them WD k-steps
-    // ahead of use inside its k-loop instead; the compiler counts vmcnt for them.
+    issue(0, nxt);
+    // Weights: one float4 (nu = 0..3) per k-step.  They are NOT requested here: a CU serves its waves' requests in
+    // issue order, so 8 x 32 KB of weight loads queued behind the first waves' DMA would hold back the other waves'
+    // input pieces (measured: tile 0 landed after 10-13k cycles).  They are requested inside the k-loop, H k-steps
+    // ahead of use; the compiler counts vmcnt for them.
+    //   STREAM = false (C = 32): H = WD for tile 0 only; the KS registers then stay stationary for the block's life.
+    //   STREAM = true  (C = 64): a ring of H = KS/2 k-steps, refilled in every tile - 128 stationary registers would
+    //   leave the k-loop no room (spills, LDS reads serialised against their use).
     constexpr int WD = 8;
-    f32x4 wr[K::KS];
+    constexpr int H = STREAM ? K::KS / 2 : WD;       // request distance in k-steps
+    constexpr int NWR = STREAM ? H : K::KS;          // weight registers (float4)
+    f32x4 wr[NWR];
     const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wwino) + (size_t)(cog * 4 + xi) * K::KS * 64 + lane;
     // patch rows of this wave: t_xi = e_a + sgn * e_b with (a, b, sgn) = (0,2,-) (1,2,+) (2,1,-) (1,3,-)
     const int ra = xi == 0 ? 0 : (xi == 2 ? 2 : 1);
@@ -155,10 +142,12 @@ __global__ __launch_bounds__(WAVES * 64) void wino32_kernel(EncConvArgs a) {
     auto tile = [&](int it, auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
         if constexpr (!FIRST) {
-            if (it + 1 < ntile) issue(it + 1);       // its stage was last read by tile it-1: free since the barrier
+            if (it + 1 < ntile) {                    // its stage was last read by tile it-1: free since the barrier
+                tile_advance(nxt, a.tiles_x, a.tiles_y);
+                issue(it + 1, nxt);
+            }
         }
-        const int lt = r0 + kb + it * gb;
-        const int bx = lt % a.tiles_x, by = (lt / a.tiles_x) % a.tiles_y, n = lt / (a.tiles_x * a.tiles_y);
+        const int bx = cur.bx, by = cur.by, n = cur.n;
         float* stage = lds + (it & 1) * K::STAGE;
         const float* pa = stage + lbase + ra * K::ROWP;
         const float* pb = stage + lbase + rb * K::ROWP;
@@ -184,35 +173,40 @@ __global__ __launch_bounds__(WAVES * 64) void wino32_kernel(EncConvArgs a) {
             __builtin_amdgcn_s_barrier();
         }
         load_patch(0);
-        if constexpr (FIRST) {
+        constexpr bool LOADW = FIRST || STREAM;      // this tile requests weights
+        if constexpr (LOADW) {
 #pragma unroll
-            for (int s = 0; s < WD && s < K::KS; ++s) wr[s] = wsrc[s * 64];
+            for (int s = 0; s < H && s < K::KS; ++s) wr[s % NWR] = wsrc[s * 64];
         }
         static_for<0, K::KS>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            if constexpr (FIRST) {
-                if constexpr (s + WD < K::KS) wr[s + WD] = wsrc[(s + WD) * 64];
-            }
             const float ea[4] = {na[0][1], na[1][0], na[1][1], na[2][0]};
             const float eb[4] = {nb[0][1], nb[1][0], nb[1][1], nb[2][0]};
             if constexpr (s + 1 < K::KS) {
                 if constexpr (FIRST && K::kq(s + 1) > K::kq(s)) {
                     // the next k-step's channels are in a later DMA group: younger ops = remaining DMA + weights so far
-                    constexpr int WL = s + 1 + WD < K::KS ? s + 1 + WD : K::KS;
+                    constexpr int WL = s + H < K::KS ? s + H : K::KS;       // weight loads requested so far
                     wait_vmcnt<K::NI - 1 - K::kq(s + 1) + WL>();
                     __builtin_amdgcn_s_barrier();
                 }
                 load_patch(s + 1);
+                // keep these reads ahead of this k-step's transform and MFMAs (the scheduler otherwise sinks them
+                // next to their use and exposes the LDS latency)
+                __builtin_amdgcn_sched_barrier(0);
             }
             float t[4];
 #pragma unroll
             for (int b = 0; b < 4; ++b) t[b] = __builtin_fmaf(sgn, eb[b], ea[b]);
             const float v[4] = {t[0] - t[2], t[1] + t[2], t[2] - t[1], t[1] - t[3]};
 #pragma unroll
-            for (int nu = 0; nu < 4; ++nu) acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[s][nu], v[nu], acc[nu], 0, 0, 0);
+            for (int nu = 0; nu < 4; ++nu) acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[s % NWR][nu], v[nu], acc[nu], 0, 0, 0);
+            if constexpr (LOADW && s + H < K::KS) wr[(s + H) % NWR] = wsrc[(s + H) * 64];   // slot free: its MFMAs have issued
         });
         if constexpr (FIRST) {
-            if (ntile > 1) issue(1);                 // after tile 0's last counted wait (keeps those counts exact)
+            if (ntile > 1) {                         // after tile 0's last counted wait (keeps those counts exact)
+                tile_advance(nxt, a.tiles_x, a.tiles_y);
+                issue(1, nxt);
+            }
         }
 
         if constexpr (FIRST) STAMP(3);
@@ -289,14 +283,18 @@ __global__ __launch_bounds__(WAVES * 64) void wino32_kernel(EncConvArgs a) {
     STAMP(1);
     STAMP(2);
     tile(0, std::true_type{});
+    tile_advance(cur, a.tiles_x, a.tiles_y);
     STAMP(5);
+    if constexpr (!STREAM) {                         // from here on the weights are plain register values
 #pragma unroll
-    for (int s = 0; s < K::KS; ++s) asm volatile("" : "+v"(wr[s]));
+        for (int s = 0; s < K::KS; ++s) asm volatile("" : "+v"(wr[s]));
+    }
 #pragma unroll 1
     for (int it = 1; it < ntile; ++it) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS) : "memory");
         __builtin_amdgcn_s_barrier();
         tile(it, std::false_type{});
+        tile_advance(cur, a.tiles_x, a.tiles_y);
     }
 #ifdef EEM_STAMPS
     STAMP(6);
@@ -338,8 +336,8 @@ __global__ void wino32_wt_kernel(const float* __restrict__ w, int c, int transpo
 
 template <int C> struct W32Tile;
 //                                             TH  TW  NGH WAVES POOLK
-template <> struct W32Tile<32> { static constexpr int TH = 4, TW = 64, NGH = 1, WAVES = 8, POOLK = 16; };
-template <> struct W32Tile<64> { static constexpr int TH = 4, TW = 32, NGH = 2, WAVES = 8, POOLK = 8; };
+template <> struct W32Tile<32> { static constexpr int TH = 4, TW = 64, NGH = 1, WAVES = 8, POOLK = 16; static constexpr bool STREAM = false; };
+template <> struct W32Tile<64> { static constexpr int TH = 4, TW = 32, NGH = 2, WAVES = 8, POOLK = 8; static constexpr bool STREAM = true; };
 
 template <int C>
 int launch_c(const EncConvArgs& a0, hipStream_t stream) {
@@ -355,10 +353,10 @@ int launch_c(const EncConvArgs& a0, hipStream_t stream) {
         return EEM_ERR_ARG;
     }
     if (a.pool_partial != nullptr)
-        hipLaunchKernelGGL((wino32_kernel<C, W::TH, W::TW, W::NGH, W::WAVES, W::POOLK>), dim3(per_xcd * 8), dim3(W::WAVES * 64),
+        hipLaunchKernelGGL((wino32_kernel<C, W::TH, W::TW, W::NGH, W::WAVES, W::STREAM, W::POOLK>), dim3(per_xcd * 8), dim3(W::WAVES * 64),
                            0, stream, a);
     else
-        hipLaunchKernelGGL((wino32_kernel<C, W::TH, W::TW, W::NGH, W::WAVES, 0>), dim3(per_xcd * 8), dim3(W::WAVES * 64), 0,
+        hipLaunchKernelGGL((wino32_kernel<C, W::TH, W::TW, W::NGH, W::WAVES, W::STREAM, 0>), dim3(per_xcd * 8), dim3(W::WAVES * 64), 0,
                            stream, a);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;

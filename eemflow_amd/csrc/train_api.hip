@@ -174,7 +174,7 @@ extern "C" int eemflow_forward_backward(eemflow_ctx* c, const float* e1, const f
             a.in0 = l.gy;
             a.wpk = c->arena + r.wT_enc; a.wpk2 = c->arena + r.wT_enc2; a.bias = c->arena + r.zero_bias;
             a.wwino = (c->use_wino && c->enc_wino[l.layer]) ? c->wino + c->wino_off[ENC_NUM + l.layer] : nullptr;
-            a.zero_page = c->zero_page; a.trash = c->zero_page + 64;
+            a.zero_page = c->zero_page; a.trash = c->zero_page + 256;
             a.out = l.gx;
             a.nimg = n2; a.nimg0 = n2;
             a.hin = l.hout; a.win = l.wout; a.hout = l.hin; a.wout = l.win; a.hraw = l.hout; a.wraw = l.wout;

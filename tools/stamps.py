@@ -37,3 +37,18 @@ print("total cycles med", int(np.median(tot)), "max", int(tot.max()), " realtime
       " -> clock GHz", round(float(np.median(tot) / np.median(rt) / 10), 3))
 t0 = s[:, 0, 0].min()
 print("block start spread (cycles)", int(s[:, 0, 0].max() - t0), " last end - first start", int(s[:, :, 6].max() - t0))
+
+# ---- C = 16 kernel (pconv1_2): phases of each block's second tile
+fn = getattr(L, "eemflow_debug_read_stamps16", None)
+if fn is not None:
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    assert fn(buf, n) == 0
+    s = np.frombuffer(buf, dtype=np.uint64).reshape(2048, 8, 8).astype(np.int64)
+    nb = int((s[:, 0, 1] > 0).sum())
+    s = s[:nb]
+    names = ["wait+barrier", "issue next DMA", "k loop", "transform+stores", "pool", ]
+    for w in (0, 7):
+        d = np.diff(s[:, w, :6], axis=1)
+        print(f"C16 wave {w}: " + "  ".join(f"{nm}: med {int(np.median(d[:, i]))} max {int(d[:, i].max())}" for i, nm in enumerate(names)))
+    print("C16 kernel cycles med", int(np.median(s[:, 0, 6])), "ticks", int(np.median(s[:, 0, 7])), "GHz",
+          round(float(np.median(s[:, 0, 6]) / np.median(s[:, 0, 7]) / 10), 3), "blocks", nb)

@@ -73,12 +73,12 @@ __global__ __launch_bounds__(WAVES * 64) void wino_kernel(EncConvArgs a) {
     constexpr int NWX = POOLK > 0 ? TW / POOLK : 1;                      // pooling windows per block tile (x)
     constexpr int RED = POOLK > 0 ? K::NGY * C * NWX : 0;                // pooling scratch (floats)
     constexpr int NSF = K::NGW * 8;                                      // feature-map stores per wave per tile
-    constexpr int NS = NSF + (POOLK > 0 ? 1 : 0);
-    static_assert((2 * K::STAGE + RED) * 4 <= 160 * 1024, "LDS budget");
+    constexpr int NS = NSF;                                              // younger than the next tile's DMA
+    static_assert((2 * K::STAGE + 2 * RED) * 4 <= 160 * 1024, "LDS budget");
     static_assert(NS <= 63, "vmcnt immediate");
     static_assert(POOLK == 0 || (POOLK % TH == 0 && TW % POOLK == 0 && C * NWX <= WAVES * 64), "pool windows");
-    __shared__ __attribute__((aligned(16))) float lds[2 * K::STAGE + RED];
-    float* red = lds + 2 * K::STAGE;
+    __shared__ __attribute__((aligned(16))) float lds[2 * K::STAGE + 2 * RED];
+    float* red0 = lds + 2 * K::STAGE;          // pooling scratch, double-buffered by tile parity
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(WAVES * 64) void wino_kernel(EncConvArgs a) {
     const TileRange tr_ = block_tile_range(a.tiles_x * a.tiles_y * a.nimg, blockIdx.x, gridDim.x);
     const int ntile = tr_.count;
     if (ntile == 0) return;
-    TileCoord cur = tile_coord(tr_.first, a.tiles_x, a.tiles_y), nxt = cur;      // tile being computed / next to request
+    TileCoord cur = tile_coord(tr_.first, a.tiles_x, a.tiles_y), nxt = cur, prv = cur;   // computed / next to request / previous
     const float* zero_page = a.zero_page;
 
     // ---- DMA plan: the piece a lane moves in wave-instruction k never changes; its offset from the tile's first
@@ -106,36 +106,37 @@ __global__ __launch_bounds__(WAVES * 64) void wino_kernel(EncConvArgs a) {
         const int q = rem - ry * K::PPR;
         poff[k] = (c * a.hin + ry) * a.win + q * 4;
     }
-    auto issue = [&](int it, const TileCoord& tc) {
-        const int bx = tc.bx, by = tc.by, n = tc.n;
-        const int gy0 = by * TH - 1, gxa = bx * TW - 4;
-        const float* src = a.in0 + (size_t)n * C * a.hin * a.win + (gy0 * a.win + gxa);
-        float* sbase = lds + (it & 1) * K::STAGE;
-        const bool interior = gy0 >= 0 && gy0 + K::IN_ROWS <= a.hin && gxa >= 0 && gxa + K::ROWP <= a.win;
-        if (interior) {
-#pragma unroll
-            for (int k = 0; k < K::NI; ++k)
-                __builtin_amdgcn_global_load_lds(GLB_PTR(src + poff[k]), LDS_PTR(sbase + (wave + k * WAVES) * 256), 16, 0, 0);
-        } else {
-#pragma unroll
-            for (int k = 0; k < K::NI; ++k) {
-                int p = (wave + k * WAVES) * 64 + lane;
-                p = p < K::PIECES ? p : K::PIECES - 1;
-                const int rem = p % (K::IN_ROWS * K::PPR);
-                const int ry = rem / K::PPR;
-                const int q = rem - ry * K::PPR;
-                const int gy = gy0 + ry, gx = gxa + q * 4;
-                const bool ok = gy >= 0 && gy < a.hin && gx >= 0 && gx < a.win;
-                const float* gp = ok ? src + poff[k] : zero_page;
-                __builtin_amdgcn_global_load_lds(GLB_PTR(gp), LDS_PTR(sbase + (wave + k * WAVES) * 256), 16, 0, 0);
-            }
+    struct DmaTile { const float* src; float* sbase; int gy0, gxa; bool interior; };
+    auto dma_prep = [&](int it, const TileCoord& tc) {
+        DmaTile d;
+        d.gy0 = tc.by * TH - 1; d.gxa = tc.bx * TW - 4;
+        d.src = a.in0 + (size_t)tc.n * C * a.hin * a.win + (d.gy0 * a.win + d.gxa);
+        d.sbase = lds + (it & 1) * K::STAGE;
+        d.interior = d.gy0 >= 0 && d.gy0 + K::IN_ROWS <= a.hin && d.gxa >= 0 && d.gxa + K::ROWP <= a.win;
+        return d;
+    };
+    auto dma_piece = [&](const DmaTile& d, int k) {
+        const float* gp = d.src + poff[k];
+        if (!d.interior) {
+            int p = (wave + k * WAVES) * 64 + lane;
+            p = p < K::PIECES ? p : K::PIECES - 1;
+            const int rem = p % (K::IN_ROWS * K::PPR);
+            const int ry = rem / K::PPR;
+            const int q = rem - ry * K::PPR;
+            const int gy = d.gy0 + ry, gx = d.gxa + q * 4;
+            gp = (gy >= 0 && gy < a.hin && gx >= 0 && gx < a.win) ? gp : zero_page;
         }
+        __builtin_amdgcn_global_load_lds(GLB_PTR(gp), LDS_PTR(d.sbase + (wave + k * WAVES) * 256), 16, 0, 0);
     };
 
     float biasv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) biasv[r] = a.bias[cog * 16 + g * 4 + r];
-    issue(0, nxt);
+    {
+        const DmaTile d0 = dma_prep(0, nxt);
+#pragma unroll
+        for (int k = 0; k < K::NI; ++k) dma_piece(d0, k);
+    }
     // stationary weights (k-step-major float4s); requested only after tile 0's input has landed - see conv_wino32.hip
     f32x4 wr[K::NW4];
     const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wwino) + (size_t)cog * K::NW4 * 64 + lane;
@@ -143,10 +144,33 @@ __global__ __launch_bounds__(WAVES * 64) void wino_kernel(EncConvArgs a) {
     auto tile = [&](int it, auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
         STAMP16(1);
-        if (it + 1 < ntile) {                        // its stage was last read by tile it-1: free since the barrier
+        // The next tile's DMA (its stage was last read by tile it-1: free since the barrier) is issued piecewise
+        // inside the k-loop, behind each k-step's MFMAs: an LDS-DMA instruction costs the issuing wave 100-200
+        // cycles, which then overlap MFMAs in flight instead of stalling every wave of the block at once.
+        const bool have_next = it + 1 < ntile;
+        DmaTile dnext = {};
+        if (have_next) {
             tile_advance(nxt, a.tiles_x, a.tiles_y);
-            issue(it + 1, nxt);
+            dnext = dma_prep(it + 1, nxt);
+#ifdef EEM_DMA_AT_TOP
+#pragma unroll
+            for (int k = 0; k < K::NI; ++k) dma_piece(dnext, k);
+#endif
         }
+        if constexpr (POOLK > 0 && !FIRST) {
+            // finish the previous tile's pooling partial sums (its barrier is the ring barrier just passed);
+            // one store per lane (idle lanes into the scratch page)
+            const float* redp = red0 + ((it - 1) & 1) * RED;
+            float s = 0.f;
+            const bool act = tid < C * NWX;
+            const int co = act ? tid / NWX : 0, wx = act ? tid - co * NWX : 0;
+#pragma unroll
+            for (int q = 0; q < K::NGY; ++q) s += redp[(q * C + co) * NWX + wx];
+            float* p = act ? a.pool_partial + (((size_t)prv.n * C + co) * a.tiles_y + prv.by) * (a.tiles_x * NWX) + prv.bx * NWX + wx
+                           : a.trash + lane * 2;
+            *p = s;
+        }
+        float* red = red0 + (it & 1) * RED;
         STAMP16(2);
         if constexpr (FIRST) {
 #pragma unroll
@@ -205,6 +229,16 @@ __global__ __launch_bounds__(WAVES * 64) void wino_kernel(EncConvArgs a) {
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef EEM_DMA_AT_TOP
+                {   // this k-step's share of the next tile's DMA
+                    constexpr int STEPS = K::KS * K::NGW, PER = (K::NI + STEPS - 1) / STEPS;
+                    if (have_next) {
+#pragma unroll
+                        for (int q = 0; q < PER; ++q)
+                            if ((e * K::KS + s) * PER + q < K::NI) dma_piece(dnext, (e * K::KS + s) * PER + q);
+                    }
+                }
+#endif
             }
 
             STAMP16(3);
@@ -256,25 +290,14 @@ __global__ __launch_bounds__(WAVES * 64) void wino_kernel(EncConvArgs a) {
             }
         }
         STAMP16(4);
-        if constexpr (POOLK > 0) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            // one store per lane and tile (idle lanes into the scratch page) keeps the store count uniform
-            float s = 0.f;
-            const bool act = tid < C * NWX;
-            const int co = act ? tid / NWX : 0, wx = act ? tid - co * NWX : 0;
-#pragma unroll
-            for (int q = 0; q < K::NGY; ++q) s += red[(q * C + co) * NWX + wx];
-            float* p = act ? a.pool_partial + (((size_t)n * C + co) * a.tiles_y + by) * (a.tiles_x * NWX) + bx * NWX + wx
-                           : a.trash + lane * 2;
-            *p = s;
-            // `red` is rewritten one tile later at the earliest: every wave passes the ring barrier before that
-        }
+        // the pooling partial sums in `red` are finished after the next ring barrier (top of the next tile / after
+        // the loop): one barrier per tile instead of two
     };
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // tile 0's input has landed
     __builtin_amdgcn_s_barrier();
     tile(0, std::true_type{});
+    prv = cur;
     tile_advance(cur, a.tiles_x, a.tiles_y);
     // from here on the weights are plain register values for the compiler (no vmcnt bookkeeping in the loop)
 #pragma unroll
@@ -282,11 +305,29 @@ __global__ __launch_bounds__(WAVES * 64) void wino_kernel(EncConvArgs a) {
 #pragma unroll 1
     for (int it = 1; it < ntile; ++it) {
         STAMP16(0);
+#ifdef EEM_WAIT0
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS) : "memory");           // all but the previous tile's stores
+#endif
+        if constexpr (POOLK > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // its pooling sums are in LDS
         __builtin_amdgcn_s_barrier();
         tile(it, std::false_type{});
+        prv = cur;
         tile_advance(cur, a.tiles_x, a.tiles_y);
         STAMP16(5);
+    }
+    if constexpr (POOLK > 0) {                       // last tile's pooling partial sums
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const float* redp = red0 + ((ntile - 1) & 1) * RED;
+        if (tid < C * NWX) {
+            const int co = tid / NWX, wx = tid - co * NWX;
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < K::NGY; ++q) s += redp[(q * C + co) * NWX + wx];
+            a.pool_partial[(((size_t)prv.n * C + co) * a.tiles_y + prv.by) * (a.tiles_x * NWX) + prv.bx * NWX + wx] = s;
+        }
     }
 #ifdef EEM_STAMPS
     st[6] = __builtin_amdgcn_s_memtime() - st[6];

@@ -24,9 +24,16 @@ def load(d, counter):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
             continue
-        m = re.search(r"enc_conv2?_kernel<(\d+), (\d+),", r["Kernel_Name"])
+        k = r["Kernel_Name"]
+        m = re.search(r"enc_conv2?_kernel<(\d+), (\d+),", k)
         if m:
             agg[(m.group(1), m.group(2))].append(float(r["Counter_Value"]))
+            continue
+        m = re.search(r"wino(?:32)?_kernel<(\d+),", k)          # Winograd C -> C layers
+        if m:
+            agg[(m.group(1), m.group(1))].append(float(r["Counter_Value"]))
+        elif "enc1_kernel" in k:                                 # pconv1_1 with 16-byte DMA
+            agg[("5", "16")].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
 

@@ -1,0 +1,54 @@
+// Evaluation metrics on the device: Test.flow_error of the reference
+// (test_mvsec.py:291-346) - AEE, %EE<1px, %(EE<3px or EE<10% of |gt|) over the pixels where the ground truth is
+// finite and non-zero (and, for the 'sparse' evaluation, where the event-count image is positive; rows >= 190 are
+// dropped for the MVSEC 'is_car' crop).  One pass over 5 planes (HBM-bound: 20 B per pixel); per-block partial sums
+// in double, combined with double atomics (5 per block).
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void flow_error_kernel(const float* __restrict__ gt, const float* __restrict__ pred,
+                                                         const float* __restrict__ ev, int h, int w, int max_row,
+                                                         double* __restrict__ out) {
+    const long plane = (long)h * w, npix = (long)min(max_row, h) * w;
+    double s_ee = 0, s_gt = 0, n = 0, n1 = 0, n3 = 0;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < npix; i += (long)gridDim.x * 256L) {
+        const float gx = gt[i], gy = gt[plane + i];
+        // numpy: ~isinf(gx) & ~isinf(gy) & (norm > 0); a NaN ground truth passes the reference's mask as well
+        const float ng = sqrtf(gx * gx + gy * gy);
+        bool m = !isinf(gx) && !isinf(gy) && (ng > 0.f);
+        if (ev) m = m && ev[i] > 0.f;
+        if (!m) continue;
+        const float dx = gx - pred[i], dy = gy - pred[plane + i];
+        const float ee = sqrtf(dx * dx + dy * dy);
+        s_ee += ee; s_gt += ng; n += 1.0;
+        n1 += ee < 1.0f ? 1.0 : 0.0;
+        n3 += (ee < 3.0f || ee < 0.1f * ng) ? 1.0 : 0.0;
+    }
+    __shared__ double red[5][4];
+    double v[5] = {s_ee, s_gt, n, n1, n3};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) atomicAdd(out + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+}  // namespace
+
+// out5 (device, 5 doubles): sum EE, sum |gt|, n_points, count(EE < 1), count(EE < 3 or EE < 0.1 |gt|)
+extern "C" int eemflow_flow_error(const float* flow_gt, const float* flow_pred, const float* event_img, int h, int w,
+                                  int max_row, double* out5, void* stream) {
+    EEM_REQUIRE(flow_gt && flow_pred && out5 && h >= 1 && w >= 1 && max_row >= 1, "eemflow_flow_error: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    EEM_HIP_CHECK(hipMemsetAsync(out5, 0, 5 * sizeof(double), st));
+    const long npix = (long)(max_row < h ? max_row : h) * w;
+    int blocks = (int)((npix + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(flow_error_kernel, dim3(blocks), dim3(256), 0, st, flow_gt, flow_pred, event_img, h, w, max_row, out5);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}

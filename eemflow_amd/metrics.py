@@ -1,0 +1,32 @@
+"""Evaluation metrics on the GPU: the reference's Test.flow_error (test_mvsec.py:291-346) behind its call shape.
+
+`flow_error(flow_gt, flow_pred, event_img, is_car=False, evaluation_type='dense')` takes the (1,2,H,W) CUDA tensors the
+harness holds and returns the reference's 7-tuple (AEE, percent_1_AEE, percent_3_AEE, n_points, AEE_sum, AEE_gt,
+AEE_gt_sum); the reduction runs in libeemflow_hip.so (eemflow_flow_error).  CUDA tensors only."""
+import torch
+
+from . import _lib
+
+
+def flow_error(flow_gt, flow_pred, event_img=None, is_car=False, evaluation_type="dense"):
+    if not (flow_gt.is_cuda and flow_pred.is_cuda):
+        raise _lib.EEMFlowHipError("flow_error: inputs must be CUDA (ROCm) tensors - there is no CPU path")
+    gt = flow_gt[0].contiguous().float()
+    pr = flow_pred[0].contiguous().float()
+    _, h, w = gt.shape
+    max_row = 190 if is_car else w                         # the reference crops rows with shape[1] = the WIDTH (:296)
+    ev = None
+    if evaluation_type == "sparse":
+        ev = event_img.to(gt.device).reshape(h, w).contiguous().float()
+    elif evaluation_type != "dense":
+        raise ValueError(f"evaluation_type {evaluation_type!r}")
+    out = torch.empty(5, dtype=torch.float64, device=gt.device)
+    with torch.cuda.device(gt.device):
+        _lib.check(_lib.lib().eemflow_flow_error(gt.data_ptr(), pr.data_ptr(), ev.data_ptr() if ev is not None else None, h, w,
+                                                 max_row, out.data_ptr(), _lib.current_stream_ptr(gt.device)))
+    s_ee, s_gt, n, n1, n3 = out.cpu().tolist()
+    p1 = n1 / (n + 1e-5)
+    p3 = n3 / (n + 1e-5)
+    if s_ee == 0:
+        return 0.0, p1, p3, int(n), 0.0, 0.0, 0.0
+    return s_ee / n, p1, p3, int(n), s_ee, s_gt / n, s_gt

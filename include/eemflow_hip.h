@@ -101,6 +101,14 @@ int eemflow_local_corr53(const float* f1, const float* f2, int batch, int c, int
  * (model/EEMFlow/EEMFlow.py:118-120). */
 int eemflow_upsample_bilinear(const float* in, float* out, int nc, int h, int w, int oh, int ow, void* stream);
 
+/* Evaluation statistics of one flow field against its ground truth, on the device.
+ * Replaces: Test.flow_error (test_mvsec.py:291-346).  flow_gt, flow_pred: [2][h][w]; event_img: [h][w] event counts for the
+ * 'sparse' evaluation or NULL ('dense'); max_row: rows >= max_row are ignored (190 for the MVSEC is_car crop, else >= h -
+ * note the reference passes the WIDTH there, test_mvsec.py:296).  out5 (device, 5 doubles): sum EE, sum |gt|, n_points,
+ * count(EE < 1), count(EE < 3 or EE < 0.1 |gt|) over the pixels with finite non-zero ground truth (and event_img > 0). */
+int eemflow_flow_error(const float* flow_gt, const float* flow_pred, const float* event_img, int h, int w, int max_row,
+                       double* out5, void* stream);
+
 /* Event voxelization: events [n][4] f64 (t, x, y, p) on the device, time-sorted, as held by the
  * reference's EventSequence -> grid [bins][h][w] fp32.  idx_left / idx_right (optional, may be NULL)
  * receive, per event, the int64 flat index x + y*w + bin*w*h of the left / right temporal vote, or -1

@@ -1,0 +1,74 @@
+"""Dataset front-end rows and A15: the oracle against goldens produced by executing the reference's
+own function sources (tests/golden/make_golden_data.py), and the product's host code against the oracle.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from eemflow_amd import hrem
+from oracle import data_oracle as D
+
+
+def test_event_npz_reader(golden, tmp_path):
+    g = golden("data_rows.npz")
+    ev = hrem.synthetic_hrem_events(int(g["ev_seed"]), int(g["ev_n"]), 720, 1280)
+    p = os.path.join(tmp_path, "events1.npz")
+    hrem.write_events_npz(p, ev)
+    assert np.array_equal(D.get_compressed_events(p), g["ev_ref"])           # oracle == reference
+    got = hrem.get_compressed_events(p)
+    assert got.dtype == np.float64 and np.array_equal(got, g["ev_ref"])      # product == reference
+    assert set(np.unique(got[:, 3])) <= {-1.0, 1.0}
+
+
+def test_flo_reader(golden, tmp_path):
+    g = golden("data_rows.npz")
+    h, w = g["flo_hw"]
+    fl = hrem.synthetic_flow(int(g["flo_seed"]), h, w)
+    p = os.path.join(tmp_path, "flow.flo")
+    hrem.write_flo(p, fl)
+    assert np.array_equal(D.read_flo(p), g["flo_ref"]) and np.array_equal(hrem.read_flo(p), g["flo_ref"])
+    assert np.array_equal(g["flo_ref"], fl)                                   # round trip
+    with open(p, "r+b") as f:
+        f.write(b"\0\0\0\0")
+    assert hrem.read_flo(p) is None and D.read_flo(p) is None                 # wrong magic: the reference returns None
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_motion_propagate(golden, tag):
+    g = golden("data_rows.npz")
+    h, w = g[f"mp_{tag}_hw"]
+    f = hrem.synthetic_flow(int(g[f"mp_{tag}_seed"]), h, w)
+    ox, oy = D.motion_propagate(f, h, w)
+    assert np.array_equal(ox, g[f"mp_{tag}_x"]) and np.array_equal(oy, g[f"mp_{tag}_y"])     # oracle == reference, bit-exact
+    px, py = hrem.motion_propagate(f, h, w)
+    assert px.shape == (16, 16) and np.array_equal(px, ox) and np.array_equal(py, oy)       # vectorised product == oracle
+
+
+def test_flow_error_oracle(golden):
+    g = golden("data_rows.npz")
+    h, w = g["fe_hw"]
+    gt, pred, ev = hrem.flow_error_inputs(int(g["fe_seed"]), h, w)
+    i = 0
+    for et in ("dense", "sparse"):
+        for car in (False, True):
+            np.testing.assert_allclose(D.flow_error(gt, pred, ev, is_car=car, evaluation_type=et), g["fe_cases"][i], rtol=1e-6)
+            i += 1
+    gz = np.nan_to_num(gt, posinf=1.0)
+    np.testing.assert_allclose(D.flow_error(gz, gz.copy(), ev), g["fe_cases"][4], rtol=1e-12)
+
+
+def test_dataset_needs_gpu_and_layout(tmp_path):
+    """Directory walk of HREM.py:154-190 (no GPU needed to list samples)."""
+    for split, sub in (("train", "dt1/s0"), ("train", "dt1/s1"), ("test", "dt1/seqA/s0")):
+        d = os.path.join(tmp_path, "dataset/HREM", split, sub)
+        os.makedirs(d)
+        for k in ("events1.npz", "events2.npz"):
+            hrem.write_events_npz(os.path.join(d, k), hrem.synthetic_hrem_events(1, 10, 720, 1280))
+    os.makedirs(os.path.join(tmp_path, "dataset/HREM/train/dt1/incomplete"))
+    args = {"eval_type": "dense", "event_interval": "dt1", "num_voxel_bins": 5}
+    tr = hrem.HREMEventFlow(args, train=True, root=str(tmp_path))
+    assert len(tr) == 2 and [s["names"] for s in tr.data_ls] == ["s0", "s1"]
+    te = hrem.HREMEventFlow(args, train=False, root=str(tmp_path))
+    assert list(te.nori_list) == ["seqA"]
+    te.change_test_sequence("seqA")
+    assert len(te) == 1

@@ -1,0 +1,160 @@
+"""Slim evaluation / training harness around the GPU path.
+
+Keeps what the reference's harness does ON the path and its log lines, drops cv2 / pandas / imageio / git:
+
+  load_checkpoint / save_checkpoint   test_EEMFlow_HREM.py:59-66, train_EEMFlow_HREM.py:127-130:
+                                      torch.save({'epoch', 'state_dict'}) '.pth.tar', keys optionally 'module.'-prefixed
+  TestRaftEvents.test_multi_sequence  test_mvsec.py:538-671: per sequence, every `stride`-th sample: change_imagesize,
+                                      model(events1, events2), flow_error on the last prediction, the reference's summary
+                                      lines; returns the mean AEE over the sequences
+  TrainRaftEvents.train_iters         train_mvsec.py:229-286: model.change_imagesize, one optimisation step per batch
+                                      (EEMFlowTrainer: loss, backward, [RCCL all-reduce], clip + AdamW + OneCycle)
+
+Samples come from a dataset with the reference's dict keys ('event_volume_old', 'event_volume_new', 'flow', 'valid',
+'event_valid'); tensors are moved to the model's device.  One process per GPU (eemflow_amd.parallel), not
+nn.DataParallel.  Unlike the reference, save_checkpoint can also store the step count of the schedule.
+"""
+import collections
+import sys
+
+import torch
+
+from .metrics import flow_error
+from .train import EEMFlowTrainer
+
+
+class Logger:
+    """write_line(text, also_print) as the reference's logger is used; lines are kept in `.lines`."""
+
+    def __init__(self, path=None):
+        self.path, self.lines = path, []
+
+    def write_line(self, text, verbose=True):
+        self.lines.append(text)
+        if self.path:
+            with open(self.path, "a") as f:
+                f.write(text + "\n")
+        if verbose:
+            print(text)
+            sys.stdout.flush()
+
+
+def load_checkpoint(path, model, map_location="cpu"):
+    """Load {'epoch', 'state_dict'}; 'module.' prefixes of nn.DataParallel checkpoints are stripped. Returns the epoch."""
+    states = torch.load(path, map_location=map_location, weights_only=False)
+    sd = collections.OrderedDict((k.replace('module.', ''), v) for k, v in states['state_dict'].items())
+    model.load_state_dict(sd)
+    return states.get('epoch', 0)
+
+
+def save_checkpoint(path, model, epoch, trainer=None, module_prefix=False):
+    """Write the reference's checkpoint layout.  With a trainer, the device-resident weights are synced into the
+    module first and the schedule position is stored under 'iteration' (the reference does not keep it)."""
+    if trainer is not None:
+        trainer.sync_parameters()
+    sd = model.state_dict()
+    if module_prefix:
+        sd = collections.OrderedDict(('module.' + k, v) for k, v in sd.items())
+    out = {'epoch': epoch, 'state_dict': collections.OrderedDict((k, v.detach().cpu()) for k, v in sd.items())}
+    if trainer is not None:
+        out['iteration'] = trainer.iteration
+    torch.save(out, path)
+
+
+def _device_of(model):
+    return next(model.parameters()).device
+
+
+class TestRaftEvents:
+    """Evaluation loop of test_mvsec.py:538-671 on a dataset object (HREMEventFlow-like: change_test_sequence, __len__,
+    __getitem__ -> sample dict)."""
+    __test__ = False                      # not a pytest class
+
+    def __init__(self, dataset, image_size, logger=None, is_car=False):
+        self.dataset = dataset
+        self.image_size = image_size
+        self.logger = logger or Logger()
+        self.is_car = is_car
+
+    def run_network(self, model, sample, dev):
+        e1 = sample['event_volume_old'].to(dev)[None].float()
+        e2 = sample['event_volume_new'].to(dev)[None].float()
+        _, preds = model(events1=e1, events2=e2)
+        return preds[-1]
+
+    def test_multi_sequence(self, model, epoch=0, sequence_list=(), stride=10):
+        model.change_imagesize(self.image_size)
+        model.eval()
+        dev = _device_of(model)
+        self.logger.write_line("test in stride {:d}".format(stride), True)
+        sparse = getattr(self.dataset, "evaluation_type", "dense") == "sparse"
+        mean_aee, mean_out, aee_list, out_list = 0., 0., [], []
+        with torch.no_grad():
+            for sequence in sequence_list:
+                acc = collections.defaultdict(float)
+                iters, n_points = 0, 0
+                self.dataset.change_test_sequence(sequence)
+                for idx in range(len(self.dataset)):
+                    if idx % stride:
+                        continue
+                    sample = self.dataset[idx]
+                    f_est = self.run_network(model, sample, dev)
+                    f_gt = sample['flow'].to(dev)[None].float()
+                    ev = sample['event_valid'].to(dev).sum(0) if ('event_valid' in sample and sparse) else None
+                    aee, p1, p3, n_points, s_ee, aee_gt, s_gt = flow_error(f_gt, f_est, ev, is_car=self.is_car,
+                                                                          evaluation_type="sparse" if ev is not None else "dense")
+                    for k, v in (("aee", aee), ("sum", s_ee), ("aee_gt", aee_gt), ("sum_gt", s_gt), ("p1", p1), ("p3", p3)):
+                        acc[k] += v
+                    iters += 1
+                    print('{:05d} / {:05d}  AEE: {:2.6f}  meanAEE:{:2.6f} 3 - mean %AEE: {:.6f}'.format(
+                        idx + 1, len(self.dataset), aee, acc["aee"] / iters, 1. - acc["p3"] / iters))
+                iters = max(iters, 1)
+                self.logger.write_line("-------------------test_sequence_{:s}------------------".format(sequence), True)
+                self.logger.write_line(
+                    "Mean AEE: {:.6f}, sum AEE: {:.6f}, Mean AEE_gt: {:.6f}, sum AEE_gt: {:.6f}, 1 - mean %AEE: {:.6f}, "
+                    "3 - mean %AEE: {:.6f}, # pts: {:.6f}".format(acc["aee"] / iters, acc["sum"] / iters, acc["aee_gt"] / iters,
+                                                                  acc["sum_gt"] / iters, 1. - acc["p1"] / iters,
+                                                                  1. - acc["p3"] / iters, n_points), True)
+                mean_aee += acc["aee"] / iters
+                mean_out += 1. - acc["p3"] / iters
+                aee_list.append(acc["aee"] / iters)
+                out_list.append(1. - acc["p3"] / iters)
+        self.logger.write_line("-------------------------------------------------------", True)
+        self.logger.write_line("-----------------Test after {:d} epoch-----------------".format(epoch), True)
+        for name, a, o in zip(sequence_list, aee_list, out_list):
+            self.logger.write_line("{:s}: Mean AEE: {:.6f},  3 - mean %AEE: {:.6f}".format(name, a, o), True)
+        self.logger.write_line("-------------------------------------------------------", True)
+        n = max(len(sequence_list), 1)
+        self.logger.write_line("Average points: Mean AEE: {:.6f},  3 - mean %AEE: {:.6f}".format(mean_aee / n, mean_out / n), True)
+        return mean_aee / n
+
+
+class TrainRaftEvents:
+    """Training loop of train_mvsec.py:229-286 (one process per GPU; batches are this rank's shard)."""
+
+    def __init__(self, loader, image_size, lr=1e-4, wdecay=5e-5, epsilon=1e-8, num_steps=1000000, clip=1.0, gamma=0.8,
+                 logger=None, print_freq=100):
+        self.loader, self.image_size = loader, image_size
+        self.opt = dict(lr=lr, wdecay=wdecay, epsilon=epsilon, num_steps=num_steps, clip=clip, gamma=gamma)
+        self.logger = logger or Logger()
+        self.print_freq = print_freq
+        self.trainer = None
+
+    def train_iters(self, model, start_epoch=0, val_iters=None):
+        model.change_imagesize(self.image_size)
+        model.train()
+        dev = _device_of(model)
+        if self.trainer is None:
+            self.trainer = EEMFlowTrainer(model, **self.opt)
+        done = 0
+        for batch in self.loader:
+            e1 = batch['event_volume_old'].to(dev).float()
+            e2 = batch['event_volume_new'].to(dev).float()
+            loss, metrics, _ = self.trainer.step(e1, e2, batch['flow'].to(dev).float(), batch['valid'].to(dev).float())
+            done += 1
+            if done % self.print_freq == 0 or done == 1:
+                self.logger.write_line("[epoch {:d}, {:6d}] loss {:.6f} epe {:.4f} lr {:.3e}".format(
+                    start_epoch, self.trainer.iteration, loss, metrics["epe"], metrics["lr"]), True)
+            if val_iters is not None and done >= val_iters:
+                break
+        return model

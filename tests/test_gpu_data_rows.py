@@ -74,3 +74,50 @@ def test_hrem_dataset_end_to_end(tmp_path):
     assert float((s["flow"].cpu() - up).abs().max()) < 1e-5
     assert tuple(s["valid"].shape) == (720, 1280) and float(s["valid"].min()) >= 0
     assert torch.equal(s["fflow"], torch.from_numpy(fl.transpose(2, 0, 1).copy()))
+
+
+def test_harness_eval_and_train_on_synthetic_hrem(tmp_path):
+    """test_multi_sequence / train_iters over a two-sample synthetic HREM tree: runs the whole row chain
+    (files -> GPU voxelizer -> model -> flow_error / optimisation step) and the checkpoint writer."""
+    from eemflow_amd import EEMFlow
+    from eemflow_amd.harness import TestRaftEvents, TrainRaftEvents, load_checkpoint, save_checkpoint
+    from eemflow_amd.weights import seeded_state_dict
+    root = str(tmp_path)
+    for split, sub in (("test", "dt1/seqA/000001"), ("test", "dt1/seqA/000002"), ("train", "dt1/000001"), ("train", "dt1/000002")):
+        d = os.path.join(root, "dataset/HREM", split, sub)
+        os.makedirs(d)
+        seed = hash(sub) % 1000
+        hrem.write_events_npz(os.path.join(d, "events1.npz"), hrem.synthetic_hrem_events(seed, 20000, 720, 1280))
+        hrem.write_events_npz(os.path.join(d, "events2.npz"), hrem.synthetic_hrem_events(seed + 1, 20000, 720, 1280))
+        hrem.write_flo(os.path.join(d, "flow.flo"), hrem.synthetic_flow(seed + 2, 720, 1280))
+    args = {"eval_type": "dense", "event_interval": "dt1", "num_voxel_bins": 5}
+    net = EEMFlow("", 5, 5)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(3).items()})
+    net = net.to(DEV)
+    # ---- evaluation: mean AEE equals the oracle's flow_error on the same prediction
+    ds = hrem.HREMEventFlow(args, train=False, root=root)
+    ev = TestRaftEvents(ds, (720, 1280))
+    mean_aee = ev.test_multi_sequence(net, epoch=0, sequence_list=["seqA"], stride=1)
+    ds.change_test_sequence("seqA")
+    ref = []
+    with torch.no_grad():
+        for i in range(2):
+            s = ds[i]
+            pred = net(s["event_volume_old"][None], s["event_volume_new"][None])[1][-1]
+            ref.append(D.flow_error(s["flow"].cpu().numpy(), pred[0].cpu().numpy())[0])
+    assert abs(mean_aee - float(np.mean(ref))) < 1e-4
+    assert any(line.startswith("seqA: Mean AEE") for line in ev.logger.lines)
+    # ---- training on the 16x16 mesh-flow target (out_mesh_size=True, EEMFlow.py:126-132)
+    tnet = EEMFlow("", 5, 5, out_mesh_size=True)
+    tnet.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(3).items()})
+    tnet = tnet.to(DEV)
+    tds = hrem.HREMEventFlow(args, train=True, root=root)
+    loader = torch.utils.data.DataLoader(tds, batch_size=2, shuffle=False, num_workers=0)
+    tr = TrainRaftEvents(loader, (720, 1280), lr=1e-4, num_steps=100)
+    w0 = tnet.state_dict()["out_conv.weight"].clone()
+    tr.train_iters(tnet, start_epoch=0, val_iters=1)
+    p = os.path.join(root, "lasted_ckpt.pth.tar")
+    save_checkpoint(p, tnet, epoch=0, trainer=tr.trainer)
+    fresh = EEMFlow("", 5, 5, out_mesh_size=True)
+    assert load_checkpoint(p, fresh) == 0
+    assert not torch.equal(fresh.state_dict()["out_conv.weight"], w0.cpu())          # the step changed the weights

@@ -119,3 +119,19 @@ def test_onecycle_schedule_matches_torch():
         opt.step()
         if step < 399:
             sched.step()
+
+
+def test_checkpoint_layout_round_trip(tmp_path):
+    """{'epoch', 'state_dict'} '.pth.tar' files, 'module.' prefixes accepted (test_EEMFlow_HREM.py:59-66)."""
+    import os
+    import torch
+    from eemflow_amd import EEMFlow
+    from eemflow_amd.harness import load_checkpoint, save_checkpoint
+    a, b = EEMFlow("", 5, 5), EEMFlow("", 5, 5)
+    p = os.path.join(tmp_path, "ckpt.pth.tar")
+    save_checkpoint(p, a, epoch=7, module_prefix=True)
+    raw = torch.load(p, weights_only=False)
+    assert raw["epoch"] == 7 and all(k.startswith("module.") for k in raw["state_dict"]) and len(raw["state_dict"]) == 66
+    assert load_checkpoint(p, b) == 7
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)

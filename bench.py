@@ -97,6 +97,7 @@ def cpu_baseline(sd_np, e1, e2, budget_s):
 def other_rows(dev):
     """Short timings of the other built rows of the scope table (not the headline metric): E-RAFT inference at
     BASELINE configs[4]'s shape and the EEMFlow training step at configs[2]'s shape.  Never fatal."""
+    from eemflow_amd import _lib as _lib_mod
     out = {}
     try:
         from eemflow_amd.eraft import ERAFT
@@ -119,6 +120,48 @@ def other_rows(dev):
         del net
     except Exception as e:                                   # noqa: BLE001
         out["eraft_error"] = repr(e)[:200]
+    try:
+        from eemflow_amd.eemflow_plus import EEMFlow_cdc
+        from eemflow_amd.plus_weights import seeded_from_shapes as plus_seeded
+        from eemflow_amd.weights import synthetic_voxel_pair
+        net = EEMFlow_cdc("", 3, 5).eval()
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in
+                             plus_seeded({k: tuple(v.shape) for k, v in net.state_dict().items()}, 0).items()})
+        net = net.to(dev)
+        net.change_imagesize((720, 1280))
+        e1, e2 = (torch.from_numpy(a).to(dev) for a in synthetic_voxel_pair(1, 1, 720, 1280))
+        with torch.no_grad():
+            net(e1, e2)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                net(e1, e2)
+            torch.cuda.synchronize(dev)
+        out["eemflow_plus_1280x720_b1_frames_per_s"] = round(5 / (time.perf_counter() - t0), 2)
+        del net
+    except Exception as e:                                   # noqa: BLE001
+        out["eemflow_plus_error"] = repr(e)[:200]
+    try:
+        from eemflow_amd.hrem import synthetic_hrem_events
+        from eemflow_amd.voxelizer import EventSequence, EventSequenceToVoxelGrid_Pytorch
+        ev = synthetic_hrem_events(1, 2000000, 720, 1280)
+        seq = EventSequence(None, {"height": 720, "width": 1280}, features=ev, timestamp_multiplier=1e6, convert_to_relative=True)
+        feats = torch.from_numpy(np.ascontiguousarray(seq.features)).to(dev)
+        grid = torch.empty(5, 720, 1280, device=dev)
+        L = _lib_mod.lib()
+        sp = _lib_mod.current_stream_ptr(dev)
+        for _ in range(3):
+            _lib_mod.check(L.eemflow_voxelize(feats.data_ptr(), feats.shape[0], 5, 720, 1280, 1, grid.data_ptr(), None, None, sp))
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            _lib_mod.check(L.eemflow_voxelize(feats.data_ptr(), feats.shape[0], 5, 720, 1280, 1, grid.data_ptr(), None, None, sp))
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / 20
+        out["voxelize_2M_events_1280x720_ms"] = round(dt * 1e3, 3)
+        out["voxelize_Mevents_per_s"] = round(2.0 / dt, 1)
+    except Exception as e:                                   # noqa: BLE001
+        out["voxelize_error"] = repr(e)[:200]
     try:
         from eemflow_amd import EEMFlow
         from eemflow_amd.train import EEMFlowTrainer

@@ -291,7 +291,7 @@ def main():
         # ---- CPU baseline + EPE agreement on this rank's frames
         cpu = None
         extra = {}
-        if args.cpu_seconds > 0:
+        if args.cpu_seconds > 0 and world == 1:              # the CPU baseline is timed at N=1 only
             from oracle import eemflow_oracle as O
             ref, cpu = cpu_baseline(sd_np, torch.from_numpy(e1_np), torch.from_numpy(e2_np), args.cpu_seconds)
             counter[0] = 0
@@ -322,7 +322,7 @@ def main():
             "encoder_tflops_in_kernel": round(enc_tflops, 2),
             "kernels": kernels, **extra,
         }
-        if not args.no_other_rows:
+        if not args.no_other_rows and world == 1:
             line["other_rows"] = other_rows(dev)
         print(json.dumps(line), flush=True)
     parallel.barrier(dev)

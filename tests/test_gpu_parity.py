@@ -242,3 +242,25 @@ def test_errors_are_loud():
         o = torch.zeros(1, 2, 64, 64, device=DEV)
         _lib.check(_lib.lib().eemflow_forward(handle, x.data_ptr(), x.data_ptr(), 1, 64, 64, o.data_ptr(), 64, 64, None))
     _lib.lib().eemflow_destroy(handle)
+
+
+@pytest.mark.parametrize("h,w", [(192, 320), (260, 346), (720, 1280)])
+def test_winograd_encoder_equals_direct_convolution(monkeypatch, h, w):
+    """The Winograd F(2x2,3x3) / enc1 kernels against the direct-convolution kernels of the same library
+    (EEM_WINO=0 is read when weights are loaded, EEM_NO_ENC1 at launch): same stage tensors and flow to fp32 round-off."""
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(77, 1, h, w))
+
+    def run():
+        net, _ = make_net(78, graph=False)
+        net.change_imagesize((h, w))
+        with torch.no_grad():
+            flow = net(e1, e2)[1][0].clone()
+        return flow, {k: net.stage(k).clone() for k in ("f11", "f12", "f13", "pool_1", "pool_2", "pool_3")}
+    fast_flow, fast = run()
+    monkeypatch.setenv("EEM_WINO", "0")
+    monkeypatch.setenv("EEM_NO_ENC1", "1")
+    ref_flow, ref = run()
+    for k in fast:
+        scale = max(1.0, float(ref[k].abs().max()))
+        assert maxerr(fast[k], ref[k]) < 2e-5 * scale, k
+    assert maxerr(fast_flow, ref_flow) < 2e-5

@@ -132,6 +132,12 @@ extern "C" int eemflow_load_weights(eemflow_ctx* c, const float* flat, size_t nf
             enc2_pack_weights(T.data(), cout, cin, host.data() + r.wT_enc2);
             r.zero_bias = push(cin);
         }
+        // tail convs (1/64 grid): the data gradient runs on tail_conv_kernel, all decoders / groups of a layer in one launch
+        r.has_tail = !(w < base + enc_floats);
+        if (r.has_tail) {
+            r.wT_tail = push(tail_packed_floats(cout, cin, k));
+            tail_pack_weights(T.data(), cout, cin, k, host.data() + r.wT_tail);
+        }
     };
 
     const float* p = base;

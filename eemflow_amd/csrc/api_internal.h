@@ -72,6 +72,8 @@ struct eemflow_ctx {
     struct ConvRef {
         size_t w = 0, b = 0, wT = 0;                 // flat offsets of weight / bias; arena offset of gconv-packed W^T
         size_t wT_enc = 0, wT_enc2 = 0, zero_bias = 0;   // stride-1 encoder layers: W^T packed for the encoder kernels
+        size_t wT_tail = 0;                              // tail convs: W^T packed for tail_conv_kernel (batched data gradients)
+        bool has_tail = false;
         bool fast_dgrad = false;
         int cin = 0, cout = 0, k = 3, stride = 1;
     };
@@ -191,6 +193,7 @@ TailConvJob make_job(const eemflow_ctx* c, const TailW& w, const float* in, int 
     j.cin = w.cin; j.cout = w.cout;
     j.in_ctotal = in_ctotal; j.in_coff = in_coff;
     j.out_ctotal = out_ctotal; j.out_coff = out_coff; j.out_cmul = out_cmul; j.act = act;
+    j.gate = nullptr; j.in_cmul = 1;
     return j;
 }
 

@@ -177,6 +177,10 @@ struct TailConvJob {
     int in_ctotal, in_coff;
     int out_ctotal, out_coff, out_cmul;
     int act;
+    // backward use (data gradients of the tail convs): input channel i is read at in_coff + i * in_cmul (0 = 1) and
+    // multiplied by LeakyReLU'(gate) (gate indexed like the input; NULL = none); bias may be NULL
+    const float* gate;
+    int in_cmul;
 };
 #define TAIL_MAX_JOBS 16
 struct TailConvLaunch {

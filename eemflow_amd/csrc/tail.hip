@@ -115,7 +115,10 @@ __global__ __launch_bounds__(64 * KS * KS) void tail_conv_kernel(TailConvLaunch 
     const int yy = y + (KS == 3 ? t / 3 - 1 : 0), xx = x + (KS == 3 ? t % 3 - 1 : 0);
     const bool valid = pvalid && yy >= 0 && yy < L.h && xx >= 0 && xx < L.w;
     const int cg = (jb.cin + 3) >> 2;
-    const float* in = jb.in + ((size_t)b * jb.in_ctotal + jb.in_coff) * hw + (valid ? yy * L.w + xx : 0);
+    const size_t ioff = ((size_t)b * jb.in_ctotal + jb.in_coff) * hw + (valid ? yy * L.w + xx : 0);
+    const float* in = jb.in + ioff;
+    const float* gt = jb.gate ? jb.gate + ioff : nullptr;
+    const int cmul = jb.in_cmul > 1 ? jb.in_cmul : 1;
     const float* wp = jb.wpk + ((size_t)cot * KK + t) * cg * 64 + lane;
 
     float av[MAXCG], bv[MAXCG];
@@ -124,7 +127,9 @@ __global__ __launch_bounds__(64 * KS * KS) void tail_conv_kernel(TailConvLaunch 
         const int qc = q < cg ? q : cg - 1;
         const int c = qc * 4 + g;
         const float a0 = wp[(size_t)qc * 64];
-        const float b0 = in[(size_t)(c < jb.cin ? c : jb.cin - 1) * hw];
+        const size_t coff = (size_t)(c < jb.cin ? c : jb.cin - 1) * cmul * hw;
+        float b0 = in[coff];
+        if (gt) b0 *= gt[coff] > 0.f ? 1.f : 0.1f;
         av[q] = q < cg ? a0 : 0.f;                       // weights of padded channels are packed as zeros
         bv[q] = (valid && c < jb.cin) ? b0 : 0.f;
     }
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(64 * KS * KS) void tail_conv_kernel(TailConvLaunch 
         for (int r = 0; r < 4; ++r) {
             const int co = cot * 16 + g * 4 + r;
             if (co < jb.cout) {
-                float v = acc[r] + jb.bias[co];
+                float v = acc[r] + (jb.bias ? jb.bias[co] : 0.f);
                 if (jb.act) v = v > 0.f ? v : 0.1f * v;
                 jb.out[((size_t)b * jb.out_ctotal + co * jb.out_cmul + jb.out_coff) * hw + p] = v;
             }

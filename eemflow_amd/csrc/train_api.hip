@@ -32,6 +32,17 @@ struct Bwd {
         a.act = GACT_NONE; a.epi = GEPI_PLAIN; a.out_scale = 1.f;
         return gconv_launch(a, st);
     }
+    // data-gradient job of a tail conv for tail_conv_kernel (W^T packed at load time): reads `cin_d` = r.cout channels
+    // of dy at g_coff + i * g_cmul (gated by y_gate), writes r.cin channels of dx at dx_coff..
+    TailConvJob djob(const ConvRef& r, const float* dy, const float* y_gate, int g_ctotal, int g_coff, int g_cmul, float* dx,
+                     int dx_ctotal, int dx_coff) const {
+        TailConvJob j;
+        j.in = dy; j.gate = y_gate; j.in_ctotal = g_ctotal; j.in_coff = g_coff; j.in_cmul = g_cmul;
+        j.wpk = c->arena + r.wT_tail; j.bias = nullptr;
+        j.cin = r.cout; j.cout = r.cin;
+        j.out = dx; j.out_ctotal = dx_ctotal; j.out_coff = dx_coff; j.out_cmul = 1; j.act = 0;
+        return j;
+    }
     // weight + bias gradient of a conv layer into the flat buffer
     int wgrad(const ConvRef& r, const float* x, int x_ctotal, int x_coff, const float* dy, const float* y_gate, int g_ctotal,
               int g_coff, int g_cmul, int n, int hin, int win, int hout, int wout) {
@@ -106,44 +117,75 @@ extern "C" int eemflow_forward_backward(eemflow_ctx* c, const float* e1, const f
     if ((rc = tr_loss_launch(flow, flow_gt, valid, c->g_flow.p, B, s.out_h * s.out_w, gamma_weight, stats, st)) != EEM_OK) return rc;
     // ---- upsample backward (EEMFlow.py:118-120)
     if ((rc = tr_upsample_bwd_launch(c->g_flow.p, c->ups_tmp.p, c->g_coarse.p, B * 2, s.out_h, s.out_w, s.gh, s.gw, st)) != EEM_OK) return rc;
-    // ---- out_conv (1x1, no activation)
-    if ((rc = bw.wgrad(c->t_outc, c->flowcat.p, 6, 0, c->g_coarse.p, nullptr, 2, 0, 1, B, s.gh, s.gw, s.gh, s.gw)) != EEM_OK) return rc;
-    if ((rc = bw.dgrad(c->t_outc, c->g_coarse.p, nullptr, 2, 0, 1, B, s.gh, s.gw, s.gh, s.gw, c->g_flowcat.p, 6, 0)) != EEM_OK) return rc;
-    // ---- decoders (EEMFlow.py:59-69), last layer first
+    // ---- the 1/64-grid tail, last layer first.  Weight / bias gradients: one launch per conv.  Data gradients: the
+    // same conv layer of all three decoders (and all five groups) as the jobs of ONE tail_conv_kernel launch - a 9-way
+    // K split per block like the forward, instead of 60 register-gather launches of 32 blocks each.
     const int G = c->groups, per = kDecW / G;
     const int pc[3] = {16, 32, 64};
+    const int gh = s.gh, gw = s.gw;
+    TailConvLaunch TL;
+    TL.batch = B; TL.h = gh; TL.w = gw;
+    auto run_jobs = [&](int ksize) {
+        TL.ksize = ksize;
+        const int r = tail_conv_launch(TL, st);
+        TL.njobs = 0;
+        return r;
+    };
+    TL.njobs = 0;
+    // out_conv (1x1, no activation)
+    if ((rc = bw.wgrad(c->t_outc, c->flowcat.p, 6, 0, c->g_coarse.p, nullptr, 2, 0, 1, B, gh, gw, gh, gw)) != EEM_OK) return rc;
+    TL.job[TL.njobs++] = bw.djob(c->t_outc, c->g_coarse.p, nullptr, 2, 0, 1, c->g_flowcat.p, 6, 0);
+    if ((rc = run_jobs(1)) != EEM_OK) return rc;
+    // conv7: 32 -> 2, no activation; its output gradient is channels [2k, 2k+2) of g_flowcat
     for (int k = 0; k < 3; ++k) {
-        const int gh = s.gh, gw = s.gw;
-        // conv7: 32 -> 2, no activation; its output gradient is channels [2k, 2k+2) of g_flowcat
         if ((rc = bw.wgrad(c->t_dconv7[k], c->t32[k].p, 32, 0, c->g_flowcat.p, nullptr, 6, 2 * k, 1, B, gh, gw, gh, gw)) != EEM_OK) return rc;
-        if ((rc = bw.dgrad(c->t_dconv7[k], c->g_flowcat.p, nullptr, 6, 2 * k, 1, B, gh, gw, gh, gw, c->g_t32[k].p, 32, 0)) != EEM_OK) return rc;
-        // conv6: 64 -> 32 (gate = its output t32)
+        TL.job[TL.njobs++] = bw.djob(c->t_dconv7[k], c->g_flowcat.p, nullptr, 6, 2 * k, 1, c->g_t32[k].p, 32, 0);
+    }
+    if ((rc = run_jobs(3)) != EEM_OK) return rc;
+    // conv6: 64 -> 32 (gate = its output t32)
+    for (int k = 0; k < 3; ++k) {
         if ((rc = bw.wgrad(c->t_dconv6[k], c->t64[k].p, 64, 0, c->g_t32[k].p, c->t32[k].p, 32, 0, 1, B, gh, gw, gh, gw)) != EEM_OK) return rc;
-        if ((rc = bw.dgrad(c->t_dconv6[k], c->g_t32[k].p, c->t32[k].p, 32, 0, 1, B, gh, gw, gh, gw, c->g_t64[k].p, 64, 0)) != EEM_OK) return rc;
-        // conv5: 100 -> 64, input = td (shuffled output of conv4)
+        TL.job[TL.njobs++] = bw.djob(c->t_dconv6[k], c->g_t32[k].p, c->t32[k].p, 32, 0, 1, c->g_t64[k].p, 64, 0);
+    }
+    if ((rc = run_jobs(3)) != EEM_OK) return rc;
+    // conv5: 100 -> 64, input = td (shuffled output of conv4)
+    for (int k = 0; k < 3; ++k) {
         if ((rc = bw.wgrad(c->t_dconv5[k], c->td[k].p, kDecW, 0, c->g_t64[k].p, c->t64[k].p, 64, 0, 1, B, gh, gw, gh, gw)) != EEM_OK) return rc;
-        if ((rc = bw.dgrad(c->t_dconv5[k], c->g_t64[k].p, c->t64[k].p, 64, 0, 1, B, gh, gw, gh, gw, c->g_td[k].p, kDecW, 0)) != EEM_OK) return rc;
-        // conv4, conv3, conv2: grouped + channel shuffle; group g's output channel j lives at j*G + g of the
-        // shuffled tensor, its inputs are channels [g*per, (g+1)*per) of the previous activation
-        float* act[4] = {c->ta[k].p, c->tb[k].p, c->tc[k].p, c->td[k].p};
-        float* gact[4] = {c->g_ta[k].p, c->g_tb[k].p, c->g_tc[k].p, c->g_td[k].p};
-        for (int layer = 2; layer >= 0; --layer)
+        TL.job[TL.njobs++] = bw.djob(c->t_dconv5[k], c->g_t64[k].p, c->t64[k].p, 64, 0, 1, c->g_td[k].p, kDecW, 0);
+    }
+    if ((rc = run_jobs(3)) != EEM_OK) return rc;
+    // conv4, conv3, conv2: grouped + channel shuffle; group g's output channel j lives at j*G + g of the shuffled
+    // tensor, its inputs are channels [g*per, (g+1)*per) of the previous activation
+    for (int layer = 2; layer >= 0; --layer) {
+        for (int k = 0; k < 3; ++k) {
+            float* act[4] = {c->ta[k].p, c->tb[k].p, c->tc[k].p, c->td[k].p};
+            float* gact[4] = {c->g_ta[k].p, c->g_tb[k].p, c->g_tc[k].p, c->g_td[k].p};
             for (int gi = 0; gi < G; ++gi) {
                 const ConvRef& r = c->t_dgroup[k][layer][gi];
                 if ((rc = bw.wgrad(r, act[layer], kDecW, gi * per, gact[layer + 1], act[layer + 1], kDecW, gi, G, B, gh, gw, gh, gw)) != EEM_OK) return rc;
-                if ((rc = bw.dgrad(r, gact[layer + 1], act[layer + 1], kDecW, gi, G, B, gh, gw, gh, gw, gact[layer], kDecW, gi * per)) != EEM_OK) return rc;
+                TL.job[TL.njobs++] = bw.djob(r, gact[layer + 1], act[layer + 1], kDecW, gi, G, gact[layer], kDecW, gi * per);
             }
-        // conv1: 69 -> 100, input = cat_k
+        }
+        if ((rc = run_jobs(3)) != EEM_OK) return rc;
+    }
+    // conv1: 69 -> 100, input = cat_k
+    for (int k = 0; k < 3; ++k) {
         if ((rc = bw.wgrad(c->t_dconv1[k], c->cat[k].p, kDecIn, 0, c->g_ta[k].p, c->ta[k].p, kDecW, 0, 1, B, gh, gw, gh, gw)) != EEM_OK) return rc;
-        if ((rc = bw.dgrad(c->t_dconv1[k], c->g_ta[k].p, c->ta[k].p, kDecW, 0, 1, B, gh, gw, gh, gw, c->g_cat[k].p, kDecIn, 0)) != EEM_OK) return rc;
-        // rconv_k: pooled features of events1 -> channels [53, 69) of cat_k (gate = those channels)
+        TL.job[TL.njobs++] = bw.djob(c->t_dconv1[k], c->g_ta[k].p, c->ta[k].p, kDecW, 0, 1, c->g_cat[k].p, kDecIn, 0);
+    }
+    if ((rc = run_jobs(3)) != EEM_OK) return rc;
+    // rconv_k: pooled features of events1 -> channels [53, 69) of cat_k (gate = those channels)
+    for (int k = 0; k < 3; ++k) {
+        if ((rc = bw.wgrad(c->t_rconv[k], c->pool[k].p, pc[k], 0, c->g_cat[k].p, c->cat[k].p, kDecIn, kNTaps, 1, B, gh, gw, gh, gw)) != EEM_OK) return rc;
+        TL.job[TL.njobs++] = bw.djob(c->t_rconv[k], c->g_cat[k].p, c->cat[k].p, kDecIn, kNTaps, 1, c->g_pool[k].p, pc[k], 0);
+    }
+    if ((rc = run_jobs(3)) != EEM_OK) return rc;
+    // correlation: adds to d pool1, writes d pool2
+    for (int k = 0; k < 3; ++k) {
         const float* pool1 = c->pool[k].p;
         const float* pool2 = c->pool[k].p + (size_t)B * pc[k] * g;
         float* gp1 = c->g_pool[k].p;
         float* gp2 = c->g_pool[k].p + (size_t)B * pc[k] * g;
-        if ((rc = bw.wgrad(c->t_rconv[k], pool1, pc[k], 0, c->g_cat[k].p, c->cat[k].p, kDecIn, kNTaps, 1, B, gh, gw, gh, gw)) != EEM_OK) return rc;
-        if ((rc = bw.dgrad(c->t_rconv[k], c->g_cat[k].p, c->cat[k].p, kDecIn, kNTaps, 1, B, gh, gw, gh, gw, gp1, pc[k], 0)) != EEM_OK) return rc;
-        // correlation: adds to d pool1, writes d pool2
         if ((rc = tr_corr_bwd_launch(c->g_cat[k].p, kDecIn, pool1, pool2, gp1, gp2, B, pc[k], gh, gw, c->taps, kNTaps, st)) != EEM_OK) return rc;
     }
     // ---- encoder (EEMFlow.py:135-154): both event volumes as one batch of 2B images

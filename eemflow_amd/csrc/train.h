@@ -22,6 +22,9 @@ int tr_corr_bwd_launch(const float* dcv, int dcv_ctotal, const float* f1, const 
 int tr_bias_grad_launch(const float* g, const float* gate, int g_ctotal, int g_coff, int g_cmul, int cout, int n, int hw, float* db,
                         hipStream_t st);
 int tr_wgrad_launch(const WgradArgs& a, hipStream_t st);
+// several convs of the same kernel size / stride in one launch (blockIdx.z = job); at most WGRAD_MAX_JOBS
+#define WGRAD_MAX_JOBS 16
+int tr_wgrad_launch_batch(const WgradArgs* jobs, int njobs, hipStream_t st);
 int tr_sumsq_launch(const float* g, long n, double* out, hipStream_t st);
 int tr_adamw_launch(float* p, const float* g, float* m, float* v, long n, const double* sumsq, float clip, float lr, float wd,
                     float eps, float b1, float b2, long step, hipStream_t st);

@@ -157,13 +157,17 @@ __global__ __launch_bounds__(256) void biasgrad_kernel(const float* __restrict__
 // them to dW with fp32 atomics at the end (one atomic per weight and block).
 constexpr int WG_TH = 4, WG_TW = 32, WG_PX = WG_TH * WG_TW, WG_GP = WG_PX + 1, WG_CI = 32, WG_MAXT = 9;
 
+struct WgradBatch { WgradArgs job[WGRAD_MAX_JOBS]; };
+
 template <int K, int S>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradBatch batch) {
+    const WgradArgs& a = batch.job[blockIdx.z];
     constexpr int KK = K * K;
     extern __shared__ __attribute__((aligned(16))) float lds[];     // MT*32*WG_GP + cin_here*XR*XC floats
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int ci0 = blockIdx.y * WG_CI;
+    if (ci0 >= a.cin) return;                                        // a job with fewer channel chunks than the launch's grid
     const int cin_here = min(WG_CI, a.cin - ci0);
     const int MT = (a.cout + 31) >> 5;
     const int NT = (cin_here * KK + 31) >> 5;
@@ -333,20 +337,33 @@ int tr_bias_grad_launch(const float* g, const float* gate, int g_ctotal, int g_c
     return EEM_OK;
 }
 
-int tr_wgrad_launch(const WgradArgs& a, hipStream_t st) {
-    EEM_REQUIRE((a.k == 3 || a.k == 1) && a.cout >= 1 && a.cout <= 128 && a.cin >= 1, "tr_wgrad_launch: unsupported conv");
-    EEM_REQUIRE(a.stride == 1 || a.stride == 2, "tr_wgrad_launch: stride %d", a.stride);
-    const int nchunk = (a.cin + WG_CI - 1) / WG_CI;
-    const int mt = (a.cout + 31) / 32;
-    const int nt = ((a.cin < WG_CI ? a.cin : WG_CI) * a.k * a.k + 31) / 32;
-    EEM_REQUIRE((mt * nt + 3) / 4 <= WG_MAXT, "tr_wgrad_launch: %d x %d tiles exceed the per-wave budget", mt, nt);
-    const int tiles = ((a.wout + WG_TW - 1) / WG_TW) * ((a.hout + WG_TH - 1) / WG_TH) * a.n;
-    int workers = 1024 / nchunk;
-    workers = workers < 1 ? 1 : workers;
-    workers = tiles < workers ? tiles : workers;
-    dim3 grid(workers, nchunk);
-    const int xr = (WG_TH - 1) * a.stride + a.k, xc = (WG_TW - 1) * a.stride + a.k;
-    const size_t lds_bytes = ((size_t)mt * 32 * WG_GP + (size_t)(a.cin < WG_CI ? a.cin : WG_CI) * xr * xc) * sizeof(float);
+int tr_wgrad_launch_batch(const WgradArgs* jobs, int njobs, hipStream_t st) {
+    EEM_REQUIRE(jobs && njobs >= 1 && njobs <= WGRAD_MAX_JOBS, "tr_wgrad_launch_batch: njobs=%d", njobs);
+    WgradBatch b;
+    int nchunk = 0, workers = 0;
+    size_t lds_bytes = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const WgradArgs& a = jobs[i];
+        EEM_REQUIRE((a.k == 3 || a.k == 1) && a.cout >= 1 && a.cout <= 128 && a.cin >= 1, "tr_wgrad_launch: unsupported conv");
+        EEM_REQUIRE(a.stride == 1 || a.stride == 2, "tr_wgrad_launch: stride %d", a.stride);
+        EEM_REQUIRE(a.k == jobs[0].k && a.stride == jobs[0].stride, "tr_wgrad_launch_batch: jobs differ in kernel size / stride");
+        EEM_REQUIRE(!(a.k == 1 && a.stride != 1), "tr_wgrad_launch: strided 1x1 convs are not built");
+        const int nc = (a.cin + WG_CI - 1) / WG_CI;
+        const int mt = (a.cout + 31) / 32;
+        const int nt = ((a.cin < WG_CI ? a.cin : WG_CI) * a.k * a.k + 31) / 32;
+        EEM_REQUIRE((mt * nt + 3) / 4 <= WG_MAXT, "tr_wgrad_launch: %d x %d tiles exceed the per-wave budget", mt, nt);
+        const int tiles = ((a.wout + WG_TW - 1) / WG_TW) * ((a.hout + WG_TH - 1) / WG_TH) * a.n;
+        int w = 1024 / (nc * njobs);
+        w = w < 1 ? 1 : w;
+        w = tiles < w ? tiles : w;
+        const int xr = (WG_TH - 1) * a.stride + a.k, xc = (WG_TW - 1) * a.stride + a.k;
+        const size_t lb = ((size_t)mt * 32 * WG_GP + (size_t)(a.cin < WG_CI ? a.cin : WG_CI) * xr * xc) * sizeof(float);
+        nchunk = nc > nchunk ? nc : nchunk;
+        workers = w > workers ? w : workers;
+        lds_bytes = lb > lds_bytes ? lb : lds_bytes;
+        b.job[i] = a;
+    }
+    dim3 grid(workers, nchunk, njobs);
     static bool attr_set = false;
     if (!attr_set) {
         EEM_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -354,13 +371,15 @@ int tr_wgrad_launch(const WgradArgs& a, hipStream_t st) {
         EEM_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    EEM_REQUIRE(!(a.k == 1 && a.stride != 1), "tr_wgrad_launch: strided 1x1 convs are not built");
-    if (a.k == 3 && a.stride == 1) hipLaunchKernelGGL((wgrad_kernel<3, 1>), grid, dim3(256), lds_bytes, st, a);
-    else if (a.k == 3) hipLaunchKernelGGL((wgrad_kernel<3, 2>), grid, dim3(256), lds_bytes, st, a);
-    else hipLaunchKernelGGL((wgrad_kernel<1, 1>), grid, dim3(256), lds_bytes, st, a);
+    const WgradArgs& a = jobs[0];
+    if (a.k == 3 && a.stride == 1) hipLaunchKernelGGL((wgrad_kernel<3, 1>), grid, dim3(256), lds_bytes, st, b);
+    else if (a.k == 3) hipLaunchKernelGGL((wgrad_kernel<3, 2>), grid, dim3(256), lds_bytes, st, b);
+    else hipLaunchKernelGGL((wgrad_kernel<1, 1>), grid, dim3(256), lds_bytes, st, b);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }
+
+int tr_wgrad_launch(const WgradArgs& a, hipStream_t st) { return tr_wgrad_launch_batch(&a, 1, st); }
 
 int tr_sumsq_launch(const float* g, long n, double* out, hipStream_t st) {
     hipLaunchKernelGGL(sumsq_kernel, dim3(512), dim3(256), 0, st, g, n, out);

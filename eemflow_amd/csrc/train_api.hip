@@ -43,6 +43,24 @@ struct Bwd {
         j.out = dx; j.out_ctotal = dx_ctotal; j.out_coff = dx_coff; j.out_cmul = 1; j.act = 0;
         return j;
     }
+    // queued variant: the weight gradients of one tail layer (all decoders / groups) go out as ONE launch (flush_wgrads)
+    WgradArgs wq[WGRAD_MAX_JOBS];
+    int nwq = 0;
+    int wgrad_q(const ConvRef& r, const float* x, int x_ctotal, int x_coff, const float* dy, const float* y_gate, int g_ctotal,
+                int g_coff, int g_cmul, int n, int hin, int win, int hout, int wout) {
+        WgradArgs& w = wq[nwq++];
+        w.x = x; w.x_ctotal = x_ctotal; w.x_coff = x_coff; w.cin = r.cin;
+        w.g = dy; w.gate = y_gate; w.g_ctotal = g_ctotal; w.g_coff = g_coff; w.g_cmul = g_cmul; w.cout = r.cout;
+        w.dw = grad + r.w;
+        w.n = n; w.hin = hin; w.win = win; w.hout = hout; w.wout = wout; w.k = r.k; w.stride = r.stride; w.pad = r.k == 3 ? 1 : 0;
+        return tr_bias_grad_launch(dy, y_gate, g_ctotal, g_coff, g_cmul, r.cout, n, hout * wout, grad + r.b, st);
+    }
+    int flush_wgrads() {
+        if (nwq == 0) return EEM_OK;
+        const int rc = tr_wgrad_launch_batch(wq, nwq, st);
+        nwq = 0;
+        return rc;
+    }
     // weight + bias gradient of a conv layer into the flat buffer
     int wgrad(const ConvRef& r, const float* x, int x_ctotal, int x_coff, const float* dy, const float* y_gate, int g_ctotal,
               int g_coff, int g_cmul, int n, int hin, int win, int hout, int wout) {
@@ -127,30 +145,31 @@ extern "C" int eemflow_forward_backward(eemflow_ctx* c, const float* e1, const f
     TL.batch = B; TL.h = gh; TL.w = gw;
     auto run_jobs = [&](int ksize) {
         TL.ksize = ksize;
-        const int r = tail_conv_launch(TL, st);
+        int r = bw.flush_wgrads();                   // this layer's weight gradients: one launch
+        if (r == EEM_OK) r = tail_conv_launch(TL, st);
         TL.njobs = 0;
         return r;
     };
     TL.njobs = 0;
     // out_conv (1x1, no activation)
-    if ((rc = bw.wgrad(c->t_outc, c->flowcat.p, 6, 0, c->g_coarse.p, nullptr, 2, 0, 1, B, gh, gw, gh, gw)) != EEM_OK) return rc;
+    if ((rc = bw.wgrad_q(c->t_outc, c->flowcat.p, 6, 0, c->g_coarse.p, nullptr, 2, 0, 1, B, gh, gw, gh, gw)) != EEM_OK) return rc;
     TL.job[TL.njobs++] = bw.djob(c->t_outc, c->g_coarse.p, nullptr, 2, 0, 1, c->g_flowcat.p, 6, 0);
     if ((rc = run_jobs(1)) != EEM_OK) return rc;
     // conv7: 32 -> 2, no activation; its output gradient is channels [2k, 2k+2) of g_flowcat
     for (int k = 0; k < 3; ++k) {
-        if ((rc = bw.wgrad(c->t_dconv7[k], c->t32[k].p, 32, 0, c->g_flowcat.p, nullptr, 6, 2 * k, 1, B, gh, gw, gh, gw)) != EEM_OK) return rc;
+        if ((rc = bw.wgrad_q(c->t_dconv7[k], c->t32[k].p, 32, 0, c->g_flowcat.p, nullptr, 6, 2 * k, 1, B, gh, gw, gh, gw)) != EEM_OK) return rc;
         TL.job[TL.njobs++] = bw.djob(c->t_dconv7[k], c->g_flowcat.p, nullptr, 6, 2 * k, 1, c->g_t32[k].p, 32, 0);
     }
     if ((rc = run_jobs(3)) != EEM_OK) return rc;
     // conv6: 64 -> 32 (gate = its output t32)
     for (int k = 0; k < 3; ++k) {
-        if ((rc = bw.wgrad(c->t_dconv6[k], c->t64[k].p, 64, 0, c->g_t32[k].p, c->t32[k].p, 32, 0, 1, B, gh, gw, gh, gw)) != EEM_OK) return rc;
+        if ((rc = bw.wgrad_q(c->t_dconv6[k], c->t64[k].p, 64, 0, c->g_t32[k].p, c->t32[k].p, 32, 0, 1, B, gh, gw, gh, gw)) != EEM_OK) return rc;
         TL.job[TL.njobs++] = bw.djob(c->t_dconv6[k], c->g_t32[k].p, c->t32[k].p, 32, 0, 1, c->g_t64[k].p, 64, 0);
     }
     if ((rc = run_jobs(3)) != EEM_OK) return rc;
     // conv5: 100 -> 64, input = td (shuffled output of conv4)
     for (int k = 0; k < 3; ++k) {
-        if ((rc = bw.wgrad(c->t_dconv5[k], c->td[k].p, kDecW, 0, c->g_t64[k].p, c->t64[k].p, 64, 0, 1, B, gh, gw, gh, gw)) != EEM_OK) return rc;
+        if ((rc = bw.wgrad_q(c->t_dconv5[k], c->td[k].p, kDecW, 0, c->g_t64[k].p, c->t64[k].p, 64, 0, 1, B, gh, gw, gh, gw)) != EEM_OK) return rc;
         TL.job[TL.njobs++] = bw.djob(c->t_dconv5[k], c->g_t64[k].p, c->t64[k].p, 64, 0, 1, c->g_td[k].p, kDecW, 0);
     }
     if ((rc = run_jobs(3)) != EEM_OK) return rc;
@@ -162,7 +181,7 @@ extern "C" int eemflow_forward_backward(eemflow_ctx* c, const float* e1, const f
             float* gact[4] = {c->g_ta[k].p, c->g_tb[k].p, c->g_tc[k].p, c->g_td[k].p};
             for (int gi = 0; gi < G; ++gi) {
                 const ConvRef& r = c->t_dgroup[k][layer][gi];
-                if ((rc = bw.wgrad(r, act[layer], kDecW, gi * per, gact[layer + 1], act[layer + 1], kDecW, gi, G, B, gh, gw, gh, gw)) != EEM_OK) return rc;
+                if ((rc = bw.wgrad_q(r, act[layer], kDecW, gi * per, gact[layer + 1], act[layer + 1], kDecW, gi, G, B, gh, gw, gh, gw)) != EEM_OK) return rc;
                 TL.job[TL.njobs++] = bw.djob(r, gact[layer + 1], act[layer + 1], kDecW, gi, G, gact[layer], kDecW, gi * per);
             }
         }
@@ -170,13 +189,13 @@ extern "C" int eemflow_forward_backward(eemflow_ctx* c, const float* e1, const f
     }
     // conv1: 69 -> 100, input = cat_k
     for (int k = 0; k < 3; ++k) {
-        if ((rc = bw.wgrad(c->t_dconv1[k], c->cat[k].p, kDecIn, 0, c->g_ta[k].p, c->ta[k].p, kDecW, 0, 1, B, gh, gw, gh, gw)) != EEM_OK) return rc;
+        if ((rc = bw.wgrad_q(c->t_dconv1[k], c->cat[k].p, kDecIn, 0, c->g_ta[k].p, c->ta[k].p, kDecW, 0, 1, B, gh, gw, gh, gw)) != EEM_OK) return rc;
         TL.job[TL.njobs++] = bw.djob(c->t_dconv1[k], c->g_ta[k].p, c->ta[k].p, kDecW, 0, 1, c->g_cat[k].p, kDecIn, 0);
     }
     if ((rc = run_jobs(3)) != EEM_OK) return rc;
     // rconv_k: pooled features of events1 -> channels [53, 69) of cat_k (gate = those channels)
     for (int k = 0; k < 3; ++k) {
-        if ((rc = bw.wgrad(c->t_rconv[k], c->pool[k].p, pc[k], 0, c->g_cat[k].p, c->cat[k].p, kDecIn, kNTaps, 1, B, gh, gw, gh, gw)) != EEM_OK) return rc;
+        if ((rc = bw.wgrad_q(c->t_rconv[k], c->pool[k].p, pc[k], 0, c->g_cat[k].p, c->cat[k].p, kDecIn, kNTaps, 1, B, gh, gw, gh, gw)) != EEM_OK) return rc;
         TL.job[TL.njobs++] = bw.djob(c->t_rconv[k], c->g_cat[k].p, c->cat[k].p, kDecIn, kNTaps, 1, c->g_pool[k].p, pc[k], 0);
     }
     if ((rc = run_jobs(3)) != EEM_OK) return rc;

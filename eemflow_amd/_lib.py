@@ -38,6 +38,14 @@ _SIGNATURES = {
                                             _c_float_p, ctypes.c_void_p]),
     "eemflow_upsample_bilinear": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                  ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "eraft_corr_lookup_bwd": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_float_p,
+                                             _c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p]),
+    "eraft_corr_pyramid_bwd": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_void_p]),
+    "eraft_convex_upsample_bwd": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                 _c_float_p, _c_float_p, ctypes.c_void_p]),
+    "eemplus_warp_bwd": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_void_p]),
     "eemflow_flow_error": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_void_p, ctypes.c_void_p]),
     "eemflow_voxelize": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,

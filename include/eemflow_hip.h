@@ -176,6 +176,23 @@ int eraft_get_stage(eraft_ctx* ctx, const char* name, float* dst, size_t dst_cap
 int eraft_corr_lookup(eraft_ctx* ctx, const float* fmap1, const float* fmap2, const float* coords, int batch, int c,
                       int h, int w, float* out, void* stream);
 
+/* Adjoint of eraft_corr_lookup w.r.t. the correlation pyramid (the reference detaches coords every iteration,
+ * model/eraft.py:141, so there is no coordinate gradient): dout [batch][324][h][w] -> dpyr_l [batch*h*w][h>>l][w>>l],
+ * l = 0..3 (zeroed here, then scatter-added).  Replaces: autograd of CorrBlock.__call__  (model/corr.py:29-50). */
+int eraft_corr_lookup_bwd(const float* coords, const float* dout, int batch, int h, int w, float* dpyr0, float* dpyr1,
+                          float* dpyr2, float* dpyr3, void* stream);
+
+/* Adjoint of the pyramid construction: folds dpyr3 -> dpyr2 -> dpyr1 -> dpyr0 through the avg_pool2d chain (in place:
+ * dpyr0..2 are modified) and returns d fmap1, d fmap2 [batch][c][h][w] of corr = fmap1^T fmap2 / sqrt(c).  h*w % 4 == 0.
+ * Replaces: autograd of CorrBlock.__init__ / CorrBlock.corr  (model/corr.py:13-27,53-60). */
+int eraft_corr_pyramid_bwd(const float* fmap1, const float* fmap2, float* dpyr0, float* dpyr1, float* dpyr2, const float* dpyr3,
+                           int batch, int c, int h, int w, float* dfmap1, float* dfmap2, void* stream);
+
+/* Adjoint of eraft_convex_upsample: dout [batch][2][8h][8w] -> dflow [batch][2][h][w], dmask [batch][576][h][w].
+ * Replaces: autograd of ERAFT.upsample_flow  (model/eraft.py:83-94). */
+int eraft_convex_upsample_bwd(const float* flow, const float* mask, const float* dout, int batch, int h, int w, float* dflow,
+                              float* dmask, void* stream);
+
 /* Convex upsampling: flow [batch][2][h][w], mask [batch][576][h][w] -> out [batch][2][8h][8w].
  * Replaces: ERAFT.upsample_flow  (model/eraft.py:83-94). */
 int eraft_convex_upsample(eraft_ctx* ctx, const float* flow, const float* mask, int batch, int h, int w, float* out,
@@ -211,6 +228,12 @@ int eemplus_get_stage(eemplus_ctx* ctx, const char* name, float* dst, size_t dst
  * align_corners=False); 2: WarpingLayer_no_div (cdc_utils.py:50-78, align_corners=False and the
  * grid_sample(ones) >= 1 mask). */
 int eemplus_warp(const float* x, const float* flow, int batch, int c, int h, int w, int mode, float* out, void* stream);
+
+/* Adjoint of eemplus_warp: dout [batch][c][h][w] -> dx [batch][c][h][w] (zeroed here, scatter-added), dflow [batch][2][h][w].
+ * The `>= 1` mask of mode 2 carries no gradient, as in the reference.  Replaces: autograd of F.grid_sample in the three
+ * warps (EEMFlow+.py:137-149, cdc_utils.py:50-78, utils_luo/tools.py:2262-2306). */
+int eemplus_warp_bwd(const float* x, const float* flow, const float* dout, int batch, int c, int h, int w, int mode, float* dx,
+                     float* dflow, void* stream);
 
 /* upsample2d_flow_as(inputs, target, 'bilinear', if_rate)  (cdc_utils.py:80-103): out [batch][2][oh][ow];
  * with if_rate != 0 `inputs` is scaled in place afterwards, as the reference does. */

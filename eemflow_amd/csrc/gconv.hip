@@ -53,63 +53,118 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[t][m][r] = 0.f;
 
     const float* wp = a.wpk + (size_t)cot0 * ksteps * 64 + lane;
-    int ks = 0;
-    for (int ty = 0; ty < a.kh; ++ty)
-        for (int tx = 0; tx < a.kw; ++tx) {
-            int off[NPW];
-            bool tv[NPW];
+    // The k-loop is a flat sequence of batches of U k-steps: (tap, segment, first channel pair).
+    //  * Addressing: a FULL batch (every channel of every pair exists) uses one base pointer per operand plus constant
+    //    steps and no per-k-step predicates; the general form costs ~27 VALU / SALU instructions of 64-bit address and
+    //    predicate arithmetic per MFMA (PMC: the kernel was issue-bound on them).
+    //  * Latency: the operands of batch i+1 are requested before the MFMAs of batch i issue - across taps and segments
+    //    too - with two register sets and scheduling barriers that keep the requests where they are written (a wave of
+    //    a small layer otherwise has one batch in flight, and each is a cold miss on the weights).
+    constexpr int U = (NPW * MTW == 1) ? 16 : 8;
+    struct Pos { int tap, s, cp0, ks; };                     // ks = k-step index of the batch's first pair
+    auto advance = [&](Pos q) {
+        const int np = (a.seg[q.s].c + 1) >> 1;
+        q.ks += min(U, np - q.cp0);
+        q.cp0 += U;
+        if (q.cp0 >= np) { q.cp0 = 0; if (++q.s == a.nseg) { q.s = 0; ++q.tap; } }
+        return q;
+    };
+    const int ntaps = a.kh * a.kw;
+    auto load = [&](const Pos& q, float (&av)[U][MTW], float (&bv)[U][NPW]) {
+        const int ty = q.tap / a.kw, tx = q.tap - ty * a.kw;
+        int off[NPW];
+        bool tv[NPW];
+#pragma unroll
+        for (int t = 0; t < NPW; ++t) {
+            int iy = oy[t] * a.stride - a.pad_h + ty, ix = ox[t] * a.stride - a.pad_w + tx;
+            bool par = true;
+            if (a.tstride > 1) {
+                par = iy >= 0 && ix >= 0 && (iy % a.tstride) == 0 && (ix % a.tstride) == 0;
+                iy /= a.tstride; ix /= a.tstride;
+            }
+            tv[t] = pv[t] && par && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
+            off[t] = tv[t] ? iy * a.win + ix : 0;
+        }
+        const GConvSeg sg = a.seg[q.s];
+        const int cmul = sg.cmul > 1 ? sg.cmul : 1;
+        const size_t seg_off = ((size_t)n * sg.ctotal + sg.coff) * hwi;
+        const float* base = sg.ptr + seg_off;
+        const float* gbase = sg.gate ? sg.gate + seg_off : nullptr;
+        if ((q.cp0 + U) * 2 <= sg.c) {
+            const float* ap = wp + (size_t)q.ks * 64;
+            const size_t bstep = (size_t)2 * cmul * hwi;
+            const float* bp[NPW];
+            const float* gp[NPW];
 #pragma unroll
             for (int t = 0; t < NPW; ++t) {
-                int iy = oy[t] * a.stride - a.pad_h + ty, ix = ox[t] * a.stride - a.pad_w + tx;
-                bool par = true;
-                if (a.tstride > 1) {
-                    par = iy >= 0 && ix >= 0 && (iy % a.tstride) == 0 && (ix % a.tstride) == 0;
-                    iy /= a.tstride; ix /= a.tstride;
-                }
-                tv[t] = pv[t] && par && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
-                off[t] = tv[t] ? iy * a.win + ix : 0;
+                const size_t o = (size_t)(q.cp0 * 2 + h) * cmul * hwi + off[t];
+                bp[t] = base + o;
+                gp[t] = gbase ? gbase + o : nullptr;
             }
-            for (int s = 0; s < a.nseg; ++s) {
-                const GConvSeg sg = a.seg[s];
-                const int cmul = sg.cmul > 1 ? sg.cmul : 1;
-                const size_t seg_off = ((size_t)n * sg.ctotal + sg.coff) * hwi;
-                const float* base = sg.ptr + seg_off;
-                const float* gbase = sg.gate ? sg.gate + seg_off : nullptr;
-                const int cp_n = (sg.c + 1) >> 1;
-                // operands of U k-steps are requested before the first of their MFMAs: the loop is bound by
-                // L2 latency, not bandwidth, so memory-level parallelism is what counts
-                constexpr int U = (NPW * MTW == 1) ? 16 : 8;
-                for (int cp0 = 0; cp0 < cp_n; cp0 += U) {
-                    float av[U][MTW], bv[U][NPW];
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const int cp = cp0 + u;
-                        const bool ok = cp < cp_n;
-                        const int c = cp * 2 + h;
-                        const bool cv = ok && c < sg.c;
-                        const size_t coffs = (size_t)(cv ? c : 0) * cmul * hwi;
-                        const float* bp = base + coffs;
-                        const int kk = ok ? ks + u : ks;
+            for (int u = 0; u < U; ++u) {
 #pragma unroll
-                        for (int m = 0; m < MTW; ++m) av[u][m] = wp[((size_t)m * ksteps + kk) * 64];
+                for (int m = 0; m < MTW; ++m) av[u][m] = ap[(size_t)m * ksteps * 64 + u * 64];
 #pragma unroll
-                        for (int t = 0; t < NPW; ++t) {
-                            float x = bp[off[t]];
-                            if (gbase) x *= (gbase[coffs + off[t]] > 0.f) ? 1.f : 0.1f;
-                            bv[u][t] = (tv[t] && cv) ? x : 0.f;
-                        }
-                    }
+                for (int t = 0; t < NPW; ++t) {
+                    float x = *bp[t];
+                    bp[t] += bstep;
+                    if (gbase) { x *= (*gp[t] > 0.f) ? 1.f : 0.1f; gp[t] += bstep; }
+                    bv[u][t] = tv[t] ? x : 0.f;
+                }
+            }
+        } else {
+            const int cp_n = (sg.c + 1) >> 1;
 #pragma unroll
-                    for (int u = 0; u < U; ++u)
+            for (int u = 0; u < U; ++u) {
+                const int cp = q.cp0 + u;
+                const bool ok = cp < cp_n;
+                const int c = cp * 2 + h;
+                const bool cv = ok && c < sg.c;
+                const size_t coffs = (size_t)(cv ? c : 0) * cmul * hwi;
+                const float* bp = base + coffs;
+                const int kk = ok ? q.ks + u : q.ks;         // surplus slots re-read a valid fragment; their B is 0
 #pragma unroll
-                        for (int t = 0; t < NPW; ++t)
+                for (int m = 0; m < MTW; ++m) av[u][m] = wp[((size_t)m * ksteps + kk) * 64];
 #pragma unroll
-                            for (int m = 0; m < MTW; ++m)
-                                acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][m], bv[u][t], acc[t][m], 0, 0, 0);
-                    ks += min(U, cp_n - cp0);
+                for (int t = 0; t < NPW; ++t) {
+                    float x = bp[off[t]];
+                    if (gbase) x *= (gbase[coffs + off[t]] > 0.f) ? 1.f : 0.1f;
+                    bv[u][t] = (tv[t] && cv) ? x : 0.f;
                 }
             }
         }
+    };
+    auto mfma = [&](const float (&av)[U][MTW], const float (&bv)[U][NPW]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < NPW; ++t)
+#pragma unroll
+                for (int m = 0; m < MTW; ++m)
+                    acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][m], bv[u][t], acc[t][m], 0, 0, 0);
+    };
+    {
+        float avA[U][MTW], bvA[U][NPW], avB[U][MTW], bvB[U][NPW];
+        Pos cur = {0, 0, 0, 0};
+        load(cur, avA, bvA);
+        while (true) {
+            const Pos nx = advance(cur);
+            const bool more = nx.tap < ntaps;
+            if (more) load(nx, avB, bvB);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma(avA, bvA);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!more) break;
+            cur = advance(nx);
+            const bool more2 = cur.tap < ntaps;
+            if (more2) load(cur, avA, bvA);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma(avB, bvB);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!more2) break;
+        }
+    }
 
     // ---- epilogue
 #pragma unroll

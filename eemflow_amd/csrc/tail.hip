@@ -69,11 +69,17 @@ struct CorrArgs {
     const int* taps;
 };
 
+// Four adjacent lanes share one output (tap, pixel) and split its channels (c = sub, sub+4, ...): the grid is tiny and
+// L2-resident, so the kernel is one chain of dependent-latency loads per thread - a quarter of the channels per thread
+// with all of them in flight cuts that chain (18 -> ~6 us inside the forward graph); the partial sums meet by DPP.
 __global__ __launch_bounds__(256) void corr_kernel(CorrArgs a) {
     const int hw = a.h * a.w;
     const int per_job = a.batch * a.ntaps * hw;
-    int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= per_job * a.njobs) return;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    int idx = gid >> 2;
+    const int sub = gid & 3;
+    const bool live = idx < per_job * a.njobs;
+    if (!live) idx = 0;                                   // keep the quad together for the cross-lane sum
     const int ji = idx / per_job;
     idx -= ji * per_job;
     const CorrJob jb = a.job[ji];
@@ -84,12 +90,15 @@ __global__ __launch_bounds__(256) void corr_kernel(CorrArgs a) {
     const int tap = a.taps[ti];                 // dy-major index into the 9x9 window
     const int yy = y + tap / 9 - 4, xx = x + tap % 9 - 4;
     float s = 0.f;
-    if (yy >= 0 && yy < a.h && xx >= 0 && xx < a.w) {
+    if (live && yy >= 0 && yy < a.h && xx >= 0 && xx < a.w) {
         const float* p1 = jb.f1 + (size_t)b * jb.c * hw + p;
         const float* p2 = jb.f2 + (size_t)b * jb.c * hw + yy * a.w + xx;
-        for (int c = 0; c < jb.c; ++c) s = fmaf(p1[(size_t)c * hw], p2[(size_t)c * hw], s);
+#pragma unroll 16
+        for (int c = sub; c < jb.c; c += 4) s = fmaf(p1[(size_t)c * hw], p2[(size_t)c * hw], s);
     }
-    jb.out[((size_t)b * jb.out_ctotal + ti) * hw + p] = s / (float)jb.c;
+    s = dpp_add<0xB1>(s);                       // quad_perm [1,0,3,2]
+    s = dpp_add<0x4E>(s);                       // quad_perm [2,3,0,1]
+    if (live && sub == 0) jb.out[((size_t)b * jb.out_ctotal + ti) * hw + p] = s / (float)jb.c;
 }
 
 // ------------------------------------------------------------------------------- small-grid conv
@@ -243,7 +252,7 @@ int corr_launch(const CorrJob* jobs, int njobs, int batch, int h, int w, const i
     a.njobs = njobs; a.batch = batch; a.h = h; a.w = w; a.ntaps = ntaps; a.taps = taps_dev;
     const long total = (long)njobs * batch * ntaps * h * w;
     if (total == 0) return EEM_OK;
-    hipLaunchKernelGGL(corr_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(corr_kernel, dim3((unsigned)((total * 4 + 255) / 256)), dim3(256), 0, stream, a);   // 4 lanes per output
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

@@ -81,7 +81,7 @@ def cpu_baseline(sd_np, e1, e2, budget_s):
         O.eemflow_forward(sd, e1, e2)
         times = []
         t_start = time.perf_counter()
-        while (time.perf_counter() - t_start < budget_s and len(times) < 200) or len(times) < 3:
+        while (time.perf_counter() - t_start < budget_s and len(times) < 2000) or len(times) < 3:
             t0 = time.perf_counter()
             O.eemflow_forward(sd, e1, e2)
             times.append(time.perf_counter() - t0)
@@ -186,6 +186,14 @@ def other_rows(dev):
     return out
 
 
+def baseline_metric():
+    """BASELINE.json's metric string (the file travels with the repo); a literal copy if it is missing."""
+    try:
+        return json.load(open(os.path.join(REPO, "BASELINE.json")))["metric"]
+    except Exception:
+        return "frames/sec + EPE, EEMFlow 1280\u00d7720 dt1, 1/2/4/8 MI355X"
+
+
 def load_traffic():
     path = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if os.path.exists(path):
@@ -279,8 +287,11 @@ def main():
         else:
             roof = {"bound": "hbm", "achieved": dom["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(dom["gbs"] / PEAK_HBM_GBS, 4)}
-        traffic = load_traffic()
-        roof["traffic"] = (traffic or {}).get(dom["name"])
+        traffic = (load_traffic() or {}).get(dom["name"])
+        # HBM bytes per launch of the dominant kernel from the PMC passes (profiles/pmc_traffic.json, tools/profile_gpu.sh)
+        roof["traffic"] = traffic["hbm_bytes"] if isinstance(traffic, dict) and "hbm_bytes" in traffic else None
+        roof["traffic_detail"] = traffic
+        roof["algorithmic_bytes"] = round(dom["mbytes"] * 1e6)
         roof["kernel"] = dom["name"]
         roof["kernel_us"] = dom["us"]
         sum_us = sum(k["us"] for k in kernels)
@@ -307,7 +318,7 @@ def main():
 
         ms_per_step = slowest * 1e3 / args.steps
         line = {
-            "metric": "frames/sec + EPE, EEMFlow 1280x720 dt1, 1/2/4/8 MI355X",
+            "metric": baseline_metric(),
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",

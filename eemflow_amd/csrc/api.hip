@@ -37,7 +37,6 @@ extern "C" int eemflow_create(int device, eemflow_ctx** out) {
     c->device = device;
     hipError_t e = hipMalloc(&c->taps, sizeof(kTaps53));
     if (e == hipSuccess) e = hipMemcpy(c->taps, kTaps53, sizeof(kTaps53), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc(&c->vox_scratch, voxel_scratch_bytes());
     if (e == hipSuccess) e = hipMalloc(&c->zero_page, 4096);
     if (e == hipSuccess) e = hipMemset(c->zero_page, 0, 4096);
     if (e != hipSuccess) {
@@ -69,7 +68,6 @@ extern "C" void eemflow_destroy(eemflow_ctx* c) {
     if (c->pack_idx) (void)hipFree(c->pack_idx);
     if (c->taps) (void)hipFree(c->taps);
     if (c->zero_page) (void)hipFree(c->zero_page);
-    if (c->vox_scratch) (void)hipFree(c->vox_scratch);
     delete c;
 }
 
@@ -399,13 +397,31 @@ extern "C" int eemflow_upsample_bilinear(const float* in, float* out, int nc, in
 extern "C" int eemflow_voxelize(const double* events, int64_t n, int bins, int h, int w, int normalize, float* grid,
                                 int64_t* idx_left, int64_t* idx_right, void* stream) {
     EEM_REQUIRE(events && grid, "eemflow_voxelize: NULL argument");
+    // per-thread scratch (band counters, moments, 16 B per event of vote records), grown on demand; a call on a
+    // different stream than the previous one first waits for that one's kernels to be done with it
     static thread_local void* scratch = nullptr;
+    static thread_local size_t scratch_cap = 0;
     static thread_local int scratch_dev = -1;
+    static thread_local hipEvent_t done = nullptr;
+    static thread_local void* last_stream = nullptr;
     int dev = 0;
     EEM_HIP_CHECK(hipGetDevice(&dev));
-    if (scratch == nullptr || scratch_dev != dev) {
-        EEM_HIP_CHECK(hipMalloc(&scratch, voxel_scratch_bytes()));
+    const size_t need = voxel_scratch_bytes(n);
+    if (scratch == nullptr || scratch_dev != dev || scratch_cap < need) {
+        if (scratch && scratch_dev == dev) EEM_HIP_CHECK(hipFree(scratch));      // synchronises with work using it
+        scratch = nullptr;
+        scratch_cap = need + need / 4;
+        EEM_HIP_CHECK(hipMalloc(&scratch, scratch_cap));
+        if (int rc0 = voxel_scratch_init(scratch, (hipStream_t)stream)) return rc0;
+        if (scratch_dev != dev) { done = nullptr; EEM_HIP_CHECK(hipEventCreateWithFlags(&done, hipEventDisableTiming)); }
         scratch_dev = dev;
+        last_stream = stream;
     }
-    return voxel_launch(events, n, bins, h, w, normalize, grid, idx_left, idx_right, scratch, (hipStream_t)stream);
+    if (stream != last_stream) {
+        EEM_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, done, 0));
+        last_stream = stream;
+    }
+    const int rc = voxel_launch(events, n, bins, h, w, normalize, grid, idx_left, idx_right, scratch, (hipStream_t)stream);
+    if (rc == EEM_OK) EEM_HIP_CHECK(hipEventRecord(done, (hipStream_t)stream));
+    return rc;
 }

@@ -85,7 +85,6 @@ struct eemflow_ctx {
     int* taps = nullptr;
     // workspaces
     DevBuf a1, f11, a2, b2, f12, a3, b3, f13, pool[3], ppart[3], cat[3], ta[3], tb[3], tc[3], td[3], t64[3], t32[3], flowcat, coarse;
-    void* vox_scratch = nullptr;
     Shape last;
     bool have_last = false;
     // graph cache

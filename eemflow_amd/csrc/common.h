@@ -9,6 +9,8 @@
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define EEM_OK 0
 #define EEM_ERR_ARG 1
@@ -215,4 +217,5 @@ int repack_launch(const float* flat, const int* idx, float* arena, long n, hipSt
 // ----------------------------------------------------------------------------- voxelizer
 int voxel_launch(const double* events, int64_t n, int bins, int h, int w, int normalize, float* grid,
                  int64_t* idx_left, int64_t* idx_right, void* scratch, hipStream_t stream);
-size_t voxel_scratch_bytes();
+size_t voxel_scratch_bytes(int64_t n);
+int voxel_scratch_init(void* scratch, hipStream_t stream);

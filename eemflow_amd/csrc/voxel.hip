@@ -4,51 +4,99 @@
 //
 // Integer work is bit-exact with the reference: the f64 time scaling is evaluated in the same
 // order ((bins-1)*(t-t0))/dT with IEEE mul/div (this file is built with -ffp-contract=off), floor,
-// truncating casts and the flat index x + y*W + bin*W*H are int64.  The two votes are fp32 atomic
-// adds straight to HBM (memory-side atomics on gfx950; events arrive time-sorted, so neighbouring
-// lanes hit unrelated voxels).
+// truncating casts and the flat index x + y*W + bin*W*H are int64.
+//
+// Events arrive time-sorted, so neighbouring lanes vote into unrelated voxels: two fp32 atomics per event
+// straight to HBM run at ~20 G atomics/s whatever the kernel does (0.2 ms for 2e6 events).  The default path
+// therefore bins first and adds in LDS:
+//   1. vox_count_kernel   every block histograms its chunk of events over `nb` bands of `band_px` consecutive
+//                         pixels (LDS atomics) and adds the histogram to the band totals;
+//   2. vox_bin_kernel     re-derives the votes, reserves each band's run with one atomic per (block, band) and
+//                         writes 16-byte vote records {pixel-in-band | bin << 16, left vote, right vote} there;
+//                         also the optional int64 index outputs (event order);
+//   3. vox_band_kernel    one block per band: the band's bins x band_px voxels live in LDS, the records are
+//                         added with ds_add_f32 and the band is written once (no memset of the grid).  For the
+//                         normalisation the block also leaves the f64 (count, sum, sum of squares) of its non-zero
+//                         voxels.  It re-arms the counters of 1 and 2;
+//   4. vox_norm_kernel    adds the band sums, mean / unbiased sd, rewrites the non-zero voxels.
+// HBM traffic: 2 x 32 B (events, twice) + 2 x 16 B (records) per event + 4 B (normalised: up to 12 B) per
+// voxel, instead of two scattered read-modify-writes per event and three further passes over the grid.
+// An event with x >= W lands in a neighbouring row exactly as the reference's flat index_add_ puts it; votes whose
+// flat pixel index x + y*W falls outside the image (the reference raises) are dropped on this path, the index
+// outputs still report them.
+// Grids too large for the LDS band layout (bins * H * W > 1024 * 40960 voxels, bins > 64, n >= 2^31) take the
+// direct atomic kernel.
 #include "common.h"
+
+#include <cstdlib>
 
 namespace {
 
-struct VoxStats {
-    double sum;
-    double ss;
-    unsigned long long count;
-    unsigned long long pad;
+// ------------------------------------------------------------------------------------------------ per-event arithmetic
+struct VoxVote {
+    long long il, ir;        // flat int64 indices of the two votes (valid where okl / okr)
+    long long pix;           // x + y*W
+    int tl;                  // left bin
+    float vl, vr;
+    bool okl, okr;
 };
 
+struct VoxTime {
+    double t0, dT;
+};
+
+__device__ __forceinline__ VoxTime vox_time(const double* __restrict__ ev, long n) {
+    VoxTime tm;
+    tm.t0 = ev[0];
+    tm.dT = ev[(n - 1) * 4] - tm.t0;
+    if (tm.dT == 0.0) tm.dT = 1.0;                                 // loader_utils.py:485-486
+    return tm;
+}
+
+__device__ __forceinline__ VoxVote vox_vote(double t, double x, double y, double p, const VoxTime& tm, int bins, int h,
+                                            int w) {
+    VoxVote v;
+    const double ts = ((double)(bins - 1) * (t - tm.t0)) / tm.dT;  // :488
+    const long long xs = (long long)x;                             // .long() truncates, :490-491
+    const long long ys = (long long)y;
+    float pol = (float)p;
+    if (pol == 0.f) pol = -1.f;                                    // :493
+    const double tis = floor(ts);
+    const long long tl = (long long)tis;
+    const float dts = (float)(ts - tis);
+    v.vl = pol * (1.0f - dts);
+    v.vr = pol * dts;
+    const long long plane = (long long)w * h;
+    v.okl = (tis < (double)bins) && (tis >= 0.0);                  // :502-503
+    v.okr = ((tis + 1.0) < (double)bins) && (tis >= 0.0);          // :517-518
+    v.pix = xs + ys * w;
+    v.il = v.pix + tl * plane;
+    v.ir = v.pix + (tl + 1) * plane;
+    v.tl = (int)tl;
+    return v;
+}
+
+struct VoxSums {             // (count, sum, sum of squares) of one block's non-zero voxels
+    double count, sum, sumsq, pad;
+};
+
+// ------------------------------------------------------------------------------------------------ direct atomic path
 __global__ __launch_bounds__(256) void voxel_scatter_kernel(const double* __restrict__ ev, long n, int bins, int h,
                                                             int w, float* __restrict__ grid,
                                                             long long* __restrict__ idx_left,
                                                             long long* __restrict__ idx_right) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const double t0 = ev[0];
-    const double t1 = ev[(n - 1) * 4];
-    double dT = t1 - t0;
-    if (dT == 0.0) dT = 1.0;                                       // loader_utils.py:485-486
-    const double t = ev[i * 4 + 0];
-    const double ts = ((double)(bins - 1) * (t - t0)) / dT;        // :488
-    const long long xs = (long long)ev[i * 4 + 1];                 // .long() truncates, :490-491
-    const long long ys = (long long)ev[i * 4 + 2];
-    float pol = (float)ev[i * 4 + 3];
-    if (pol == 0.f) pol = -1.f;                                    // :493
-    const double tis = floor(ts);
-    const long long tl = (long long)tis;
-    const float dts = (float)(ts - tis);
-    const float vleft = pol * (1.0f - dts);
-    const float vright = pol * dts;
-    const long long plane = (long long)w * h;
-    const bool okl = (tis < (double)bins) && (tis >= 0.0);         // :502-503
-    const bool okr = ((tis + 1.0) < (double)bins) && (tis >= 0.0); // :517-518
-    const long long il = xs + ys * w + tl * plane;
-    const long long ir = xs + ys * w + (tl + 1) * plane;
-    if (okl) atomicAdd(grid + il, vleft);
-    if (okr) atomicAdd(grid + ir, vright);
-    if (idx_left) idx_left[i] = okl ? il : -1;
-    if (idx_right) idx_right[i] = okr ? ir : -1;
+    const VoxTime tm = vox_time(ev, n);
+    const VoxVote v = vox_vote(ev[i * 4 + 0], ev[i * 4 + 1], ev[i * 4 + 2], ev[i * 4 + 3], tm, bins, h, w);
+    if (v.okl) atomicAdd(grid + v.il, v.vl);
+    if (v.okr) atomicAdd(grid + v.ir, v.vr);
+    if (idx_left) idx_left[i] = v.okl ? v.il : -1;
+    if (idx_right) idx_right[i] = v.okr ? v.ir : -1;
 }
+
+// ------------------------------------------------------------------------------------------------ block helpers
+constexpr int VT = 1024;                 // threads per block of the binned path (also the maximum number of bands)
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -56,61 +104,283 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// pass 1: count and sum of non-zero voxels; pass 2: sum of squared deviations from the fp32 mean
-template <int PASS>
-__global__ __launch_bounds__(256) void voxel_stats_kernel(const float* __restrict__ grid, long total,
-                                                          VoxStats* __restrict__ st) {
-    __shared__ double sh[4];
-    __shared__ unsigned long long shc[4];
-    float mean = 0.f;
-    if (PASS == 2) {
-        const unsigned long long c = st->count;
-        mean = c ? (float)(st->sum / (double)c) : 0.f;
+// exclusive prefix sum over the block's VT threads (sh: 16 words)
+__device__ __forceinline__ unsigned block_exscan(unsigned v, unsigned* sh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned t = __shfl_up(x, d);
+        if (lane >= d) x += t;
     }
-    double acc = 0.0;
-    unsigned long long cnt = 0;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const float v = grid[i];
-        if (v != 0.f) {
-            if (PASS == 1) { acc += (double)v; ++cnt; }
-            else { const double d = (double)v - (double)mean; acc += d * d; }
+    if (lane == 63) sh[wave] = x;
+    __syncthreads();
+    unsigned before = 0;
+#pragma unroll
+    for (int k = 0; k < VT / 64; ++k) before += k < wave ? sh[k] : 0u;
+    return before + x - v;
+}
+
+struct VoxPlan {
+    int band_px;             // pixels per band (multiple of 4 unless it covers the whole image)
+    int nb;                  // bands
+    unsigned hw;             // H * W
+};
+
+// ------------------------------------------------------------------------------------------------ 1. band histogram
+template <int EPT>
+__global__ __launch_bounds__(VT) void vox_count_kernel(const double* __restrict__ ev, long n, int bins, int h, int w,
+                                                       VoxPlan pl, unsigned* __restrict__ total) {
+    __shared__ unsigned hist[VT];
+    const int tid = threadIdx.x;
+    hist[tid] = 0;
+    __syncthreads();
+    const VoxTime tm = vox_time(ev, n);
+    const f64x2* e2 = reinterpret_cast<const f64x2*>(ev);
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const long i = ((long)blockIdx.x * EPT + k) * VT + tid;
+        if (i < n) {
+            const f64x2 a = e2[i * 2], b = e2[i * 2 + 1];
+            const VoxVote v = vox_vote(a[0], a[1], b[0], b[1], tm, bins, h, w);
+            if (v.okl && v.pix >= 0 && v.pix < (long long)pl.hw) atomicAdd(&hist[(unsigned)v.pix / (unsigned)pl.band_px], 1u);
         }
     }
-    acc = wave_sum(acc);
-    if (PASS == 1) {
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d);
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { sh[wave] = acc; shc[wave] = cnt; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const double s = sh[0] + sh[1] + sh[2] + sh[3];
-        if (PASS == 1) {
-            atomicAdd(&st->sum, s);
-            atomicAdd(&st->count, shc[0] + shc[1] + shc[2] + shc[3]);
-        } else {
-            atomicAdd(&st->ss, s);
+    const unsigned c = hist[tid];
+    if (c) atomicAdd(&total[tid], c);
+}
+
+// ------------------------------------------------------------------------------------------------ 2. binning
+template <int EPT>
+__global__ __launch_bounds__(VT) void vox_bin_kernel(const double* __restrict__ ev, long n, int bins, int h, int w,
+                                                     VoxPlan pl, const unsigned* __restrict__ total,
+                                                     unsigned* __restrict__ cursor, unsigned* __restrict__ base_out,
+                                                     u32x4* __restrict__ recs, long long* __restrict__ idx_left,
+                                                     long long* __restrict__ idx_right) {
+    __shared__ unsigned hist[VT];
+    __shared__ unsigned gpos[VT];
+    __shared__ unsigned sh[VT / 64];
+    const int tid = threadIdx.x;
+    hist[tid] = 0;
+    __syncthreads();
+    const VoxTime tm = vox_time(ev, n);
+    const f64x2* e2 = reinterpret_cast<const f64x2*>(ev);
+    unsigned key[EPT], band[EPT], rank[EPT];
+    float vl[EPT], vr[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const long i = ((long)blockIdx.x * EPT + k) * VT + tid;
+        band[k] = 0xffffffffu;
+        if (i < n) {
+            const f64x2 a = e2[i * 2], b = e2[i * 2 + 1];
+            const VoxVote v = vox_vote(a[0], a[1], b[0], b[1], tm, bins, h, w);
+            if (idx_left) idx_left[i] = v.okl ? v.il : -1;
+            if (idx_right) idx_right[i] = v.okr ? v.ir : -1;
+            if (v.okl && v.pix >= 0 && v.pix < (long long)pl.hw) {
+                const unsigned bd = (unsigned)v.pix / (unsigned)pl.band_px;
+                band[k] = bd;
+                key[k] = ((unsigned)v.pix - bd * (unsigned)pl.band_px) | ((unsigned)v.tl << 16);
+                vl[k] = v.vl;
+                vr[k] = v.vr;
+                rank[k] = atomicAdd(&hist[bd], 1u);
+            }
+        }
+    }
+    // start of every band's run: exclusive scan of the totals (redone by each block: nb <= 1024 words)
+    const unsigned tot = tid < pl.nb ? total[tid] : 0u;
+    const unsigned bstart = block_exscan(tot, sh);                 // contains a barrier: hist is complete after it
+    if (blockIdx.x == 0 && tid <= pl.nb) base_out[tid] = bstart;   // tid == nb: the number of records
+    const unsigned c = hist[tid];
+    if (c) gpos[tid] = bstart + atomicAdd(&cursor[tid], c);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        if (band[k] != 0xffffffffu) {
+            u32x4 r;
+            r[0] = key[k];
+            r[1] = __float_as_uint(vl[k]);
+            r[2] = __float_as_uint(vr[k]);
+            r[3] = 0;
+            recs[gpos[band[k]] + rank[k]] = r;
         }
     }
 }
 
-__global__ __launch_bounds__(256) void voxel_norm_kernel(float* __restrict__ grid, long total,
-                                                         const VoxStats* __restrict__ st) {
-    const unsigned long long c = st->count;
-    if (c == 0) return;                                            // :529
-    const float mean = (float)(st->sum / (double)c);
-    const float sd = (float)sqrt(st->ss / (double)(c - 1));        // unbiased; NaN when c == 1
-    const bool scale = sd > 0.f;                                   // :532 (false for NaN)
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const float v = grid[i];
-        if (v != 0.f) grid[i] = scale ? (v - mean) / sd : (v - mean);
+// ------------------------------------------------------------------------------------------------ moments
+// Every block stores the f64 (count, sum, sum of squares) of its non-zero voxels in its own slot; the normalisation
+// kernel's waves each add the slots up again (<= 1023 x 24 B from L2, no barrier).  Measured alternatives: f64 atomics
+// into shared accumulators serialise (376 blocks on one line: +16 us, on 64 lines: +5 us), a ticket with the last block
+// merging costs ~20 us of serial latency.
+__device__ __forceinline__ void vox_store_sums(double c, double s, double q, VoxSums* __restrict__ mine, double* sh3) {
+    c = wave_sum(c);
+    s = wave_sum(s);
+    q = wave_sum(q);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = blockDim.x >> 6;
+    if (lane == 0) { sh3[wave * 3] = c; sh3[wave * 3 + 1] = s; sh3[wave * 3 + 2] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        c = s = q = 0.0;
+        for (int k = 0; k < nw; ++k) { c += sh3[k * 3]; s += sh3[k * 3 + 1]; q += sh3[k * 3 + 2]; }
+        mine->count = c;
+        mine->sum = s;
+        mine->sumsq = q;
     }
+}
+
+// ------------------------------------------------------------------------------------------------ 3. bands in LDS
+__global__ __launch_bounds__(VT) void vox_band_kernel(const u32x4* __restrict__ recs, const unsigned* __restrict__ base,
+                                                      int bins, VoxPlan pl, int vec4, float* __restrict__ grid,
+                                                      unsigned* __restrict__ total, unsigned* __restrict__ cursor,
+                                                      VoxSums* __restrict__ acc) {
+    extern __shared__ __attribute__((aligned(16))) float band[];   // [bins][band_px]
+    __shared__ double sh3[VT / 64 * 3];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const int bpx = pl.band_px;
+    const unsigned p0 = (unsigned)b * (unsigned)bpx;
+    const int npx = min(bpx, (int)(pl.hw - p0));
+    const int nfl = bins * bpx;
+    const unsigned lo = base[b], hi = base[b + 1];
+    if (tid == 0) { total[b] = 0; cursor[b] = 0; }                 // re-arm the counters for the next call
+    for (int i = tid * 4; i < nfl; i += VT * 4) *reinterpret_cast<f32x4*>(band + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    for (unsigned r = lo + tid; r < hi; r += VT) {
+        const u32x4 rec = recs[r];
+        const int tl = (int)(rec[0] >> 16);
+        float* cell = band + tl * bpx + (int)(rec[0] & 0xffffu);
+        atomicAdd(cell, __uint_as_float(rec[1]));
+        if (tl + 1 < bins) atomicAdd(cell + bpx, __uint_as_float(rec[2]));
+    }
+    __syncthreads();
+    if (acc) {                                                     // before the stores: the barrier inside would wait for them
+        double c = 0.0, sm = 0.0, q = 0.0;
+        for (int bin = 0; bin < bins; ++bin)
+            for (int i = tid; i < npx; i += VT) {
+                const float v = band[bin * bpx + i];
+                if (v != 0.f) { c += 1.0; sm += (double)v; q += (double)v * (double)v; }
+            }
+        vox_store_sums(c, sm, q, acc + b, sh3);
+    }
+    for (int bin = 0; bin < bins; ++bin) {
+        const float* src = band + bin * bpx;
+        float* dst = grid + (size_t)bin * pl.hw + p0;
+        if (vec4) {
+            for (int i = tid * 4; i < npx; i += VT * 4) *reinterpret_cast<f32x4*>(dst + i) = *reinterpret_cast<const f32x4*>(src + i);
+        } else {
+            for (int i = tid; i < npx; i += VT) dst[i] = src[i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ 4. normalisation
+__global__ __launch_bounds__(VT) void vox_norm_kernel(float* __restrict__ grid, long total, int nsums,
+                                                      const VoxSums* __restrict__ acc) {
+    __shared__ double sh3[VT / 64 * 3];
+    const int tid = threadIdx.x;
+    // the first NPRE 16-byte pieces of this thread are requested before the sums are known (5 cover 1280x720x5 and
+    // 640x480x15 entirely with 256 blocks)
+    constexpr int NPRE = 5;
+    const bool vec = (total & 3) == 0 && ((uintptr_t)grid & 15) == 0;
+    f32x4* g4 = reinterpret_cast<f32x4*>(grid);
+    const long n4 = total / 4, stride = (long)gridDim.x * VT, first = (long)blockIdx.x * VT + tid;
+    f32x4 pre[NPRE];
+    if (vec) {
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k)
+            if (first + k * stride < n4) pre[k] = g4[first + k * stride];
+    }
+    // one slot per thread (nsums <= VT), wave sums, then every thread adds the 16 wave results in the same order
+    double c = 0.0, sm = 0.0, sq = 0.0;
+    if (tid < nsums) { c = acc[tid].count; sm = acc[tid].sum; sq = acc[tid].sumsq; }
+    c = wave_sum(c);
+    sm = wave_sum(sm);
+    sq = wave_sum(sq);
+    if ((tid & 63) == 0) { sh3[(tid >> 6) * 3] = c; sh3[(tid >> 6) * 3 + 1] = sm; sh3[(tid >> 6) * 3 + 2] = sq; }
+    __syncthreads();
+    c = sm = sq = 0.0;
+#pragma unroll
+    for (int k = 0; k < VT / 64; ++k) { c += sh3[k * 3]; sm += sh3[k * 3 + 1]; sq += sh3[k * 3 + 2]; }
+    if (c == 0.0) return;                                          // :529
+    double m2 = sq - sm * sm / c;                                  // sum (v - mean)^2
+    if (m2 < 0.0) m2 = 0.0;                                        // equal voxels: rounding only
+    const float mean = (float)(sm / c);
+    const float sd = (float)sqrt(m2 / (c - 1.0));                  // unbiased; NaN when c == 1
+    const bool scale = sd > 0.f;                                   // :532 (false for NaN)
+    if (vec) {
+        auto apply = [&](f32x4 v, long i) {
+            bool any = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (v[q] != 0.f) { v[q] = scale ? (v[q] - mean) / sd : (v[q] - mean); any = true; }
+            if (any) g4[i] = v;
+        };
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k)
+            if (first + k * stride < n4) apply(pre[k], first + k * stride);
+        for (long i = first + NPRE * stride; i < n4; i += stride) apply(g4[i], i);
+    } else {
+        for (long i = (long)blockIdx.x * VT + tid; i < total; i += (long)gridDim.x * VT) {
+            const float v = grid[i];
+            if (v != 0.f) grid[i] = scale ? (v - mean) / sd : (v - mean);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ direct path: moments
+__global__ __launch_bounds__(VT) void vox_moments_kernel(const float* __restrict__ grid, long total, VoxSums* __restrict__ acc) {
+    __shared__ double sh3[VT / 64 * 3];
+    double c = 0.0, sm = 0.0, q = 0.0;
+    for (long i = (long)blockIdx.x * VT + threadIdx.x; i < total; i += (long)gridDim.x * VT) {
+        const float v = grid[i];
+        if (v != 0.f) { c += 1.0; sm += (double)v; q += (double)v * (double)v; }
+    }
+    vox_store_sums(c, sm, q, acc + blockIdx.x, sh3);
+}
+
+struct VoxScratch {
+    unsigned total[VT];
+    unsigned cursor[VT];
+    unsigned base[VT + 4];
+    VoxSums acc[VT];
+};
+
+template <int EPT>
+void launch_count_bin(const double* events, long n, int bins, int h, int w, const VoxPlan& pl, VoxScratch* sc,
+                      u32x4* recs, long long* il, long long* ir, hipStream_t stream) {
+    const unsigned blocks = (unsigned)((n + (long)VT * EPT - 1) / ((long)VT * EPT));
+    hipLaunchKernelGGL((vox_count_kernel<EPT>), dim3(blocks), dim3(VT), 0, stream, events, n, bins, h, w, pl, sc->total);
+    hipLaunchKernelGGL((vox_bin_kernel<EPT>), dim3(blocks), dim3(VT), 0, stream, events, n, bins, h, w, pl, sc->total,
+                       sc->cursor, sc->base, recs, il, ir);
+}
+
+bool make_plan(int64_t n, int bins, int h, int w, const double* events, VoxPlan* pl, int* lds_bytes) {
+    const long hw = (long)h * w;
+    if (bins > 64 || n >= (1LL << 31) || hw >= (1L << 31) || ((uintptr_t)events & 15)) return false;
+    const char* e = getenv("EEM_VOX_DIRECT");
+    if (e && e[0] == '1') return false;
+    long band_px = (12288 / bins) & ~3L;                           // 48 KiB of LDS per band: 2-3 bands resident per CU
+    const long spread = ((hw + 511) / 512 + 3) & ~3L;              // small images: still a few hundred bands
+    if (band_px > spread) band_px = spread < 64 ? 64 : spread;
+    if ((hw + band_px - 1) / band_px > VT - 1) band_px = ((hw + VT - 2) / (VT - 1) + 3) & ~3L;   // thread nb holds the record count
+    if (band_px * bins > 40960 || band_px > 65535) return false;   // 160 KiB of LDS, 16-bit pixel-in-band
+    pl->band_px = (int)band_px;
+    pl->nb = (int)((hw + band_px - 1) / band_px);
+    pl->hw = (unsigned)hw;
+    *lds_bytes = (int)(band_px * bins * 4);
+    return true;
 }
 
 }  // namespace
 
-size_t voxel_scratch_bytes() { return sizeof(VoxStats); }
+size_t voxel_scratch_bytes(int64_t n) { return sizeof(VoxScratch) + (size_t)(n > 0 ? n : 0) * 16; }
+
+// once per allocation: the kernels leave the counters zeroed for the next call
+int voxel_scratch_init(void* scratch, hipStream_t stream) {
+    EEM_HIP_CHECK(hipMemsetAsync(scratch, 0, sizeof(VoxScratch), stream));
+    return EEM_OK;
+}
 
 int voxel_launch(const double* events, int64_t n, int bins, int h, int w, int normalize, float* grid,
                  int64_t* idx_left, int64_t* idx_right, void* scratch, hipStream_t stream) {
@@ -118,17 +388,51 @@ int voxel_launch(const double* events, int64_t n, int bins, int h, int w, int no
                         "loader_utils.py:476), got n=%ld", (long)n);
     EEM_REQUIRE(bins > 0 && h > 0 && w > 0, "voxelize: bad shape bins=%d h=%d w=%d", bins, h, w);
     const long total = (long)bins * h * w;
-    EEM_HIP_CHECK(hipMemsetAsync(grid, 0, total * sizeof(float), stream));
-    hipLaunchKernelGGL(voxel_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, events,
-                       (long)n, bins, h, w, grid, (long long*)idx_left, (long long*)idx_right);
+    VoxScratch* sc = (VoxScratch*)scratch;
+    u32x4* recs = reinterpret_cast<u32x4*>(sc + 1);
+    VoxPlan pl;
+    int lds = 0;
+    int nsums = 0;
+    if (make_plan(n, bins, h, w, events, &pl, &lds)) {
+        static const int ept_env = [] { const char* e = getenv("EEM_VOX_EPT"); return e ? atoi(e) : 0; }();
+        int ept = ept_env;
+        if (ept != 1 && ept != 2 && ept != 4 && ept != 8) {
+            ept = 1;
+            while (ept < 8 && (n + (long)VT * ept - 1) / ((long)VT * ept) > 512) ept *= 2;
+        }
+        long long* il = (long long*)idx_left;
+        long long* ir = (long long*)idx_right;
+        switch (ept) {
+            case 1: launch_count_bin<1>(events, (long)n, bins, h, w, pl, sc, recs, il, ir, stream); break;
+            case 2: launch_count_bin<2>(events, (long)n, bins, h, w, pl, sc, recs, il, ir, stream); break;
+            case 4: launch_count_bin<4>(events, (long)n, bins, h, w, pl, sc, recs, il, ir, stream); break;
+            default: launch_count_bin<8>(events, (long)n, bins, h, w, pl, sc, recs, il, ir, stream); break;
+        }
+        if (lds > 64 * 1024) {
+            static thread_local int raised = 0;
+            if (raised < lds) {
+                EEM_HIP_CHECK(hipFuncSetAttribute((const void*)vox_band_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                raised = lds;
+            }
+        }
+        const int vec4 = (pl.band_px % 4 == 0 && pl.hw % 4 == 0 && ((uintptr_t)grid & 15) == 0) ? 1 : 0;
+        hipLaunchKernelGGL(vox_band_kernel, dim3(pl.nb), dim3(VT), lds, stream, recs, sc->base, bins, pl, vec4, grid,
+                           sc->total, sc->cursor, normalize ? sc->acc : (VoxSums*)nullptr);
+        nsums = pl.nb;
+    } else {
+        EEM_HIP_CHECK(hipMemsetAsync(grid, 0, total * sizeof(float), stream));
+        hipLaunchKernelGGL(voxel_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, events,
+                           (long)n, bins, h, w, grid, (long long*)idx_left, (long long*)idx_right);
+        if (normalize) {
+            nsums = (int)((total + 4095) / 4096 < 512 ? (total + 4095) / 4096 : 512);
+            hipLaunchKernelGGL(vox_moments_kernel, dim3(nsums), dim3(VT), 0, stream, grid, total, sc->acc);
+        }
+    }
     EEM_HIP_CHECK(hipGetLastError());
     if (normalize) {
-        VoxStats* st = (VoxStats*)scratch;
-        EEM_HIP_CHECK(hipMemsetAsync(st, 0, sizeof(VoxStats), stream));
-        const unsigned blocks = (unsigned)((total / 4 + 255) / 256 < 2048 ? (total / 4 + 255) / 256 : 2048);
-        hipLaunchKernelGGL(voxel_stats_kernel<1>, dim3(blocks ? blocks : 1), dim3(256), 0, stream, grid, total, st);
-        hipLaunchKernelGGL(voxel_stats_kernel<2>, dim3(blocks ? blocks : 1), dim3(256), 0, stream, grid, total, st);
-        hipLaunchKernelGGL(voxel_norm_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, grid, total, st);
+        long blocks = (total / 4 + VT - 1) / VT;
+        blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);   // one block per CU: the sums are re-added once per block
+        hipLaunchKernelGGL(vox_norm_kernel, dim3((unsigned)blocks), dim3(VT), 0, stream, grid, total, nsums, sc->acc);
         EEM_HIP_CHECK(hipGetLastError());
     }
     return EEM_OK;

@@ -226,6 +226,70 @@ def test_voxelizer_full_size_properties():
     assert abs(float(nz.mean())) < 1e-4 and abs(float(nz.std()) - 1.0) < 1e-4
 
 
+def _clustered_events(seed, n, h, w, wrap=False):
+    """Time-sorted events, 70% of them inside one 40x40 patch (one hot band), optionally some with x in [w, w+4)
+    on rows above the last one (the reference's flat index then lands in the next row)."""
+    rng = np.random.default_rng(seed)
+    hot = rng.random(n) < 0.7
+    ph, pw = min(40, h), min(40, w)
+    x = np.where(hot, rng.integers(0, pw, n) + (w - pw) // 2, rng.integers(0, w, n))
+    y = np.where(hot, rng.integers(0, ph, n) + (h - ph) // 2, rng.integers(0, h, n))
+    if wrap:
+        k = rng.random(n) < 0.05
+        x = np.where(k, w + rng.integers(0, 4, n), x)
+        y = np.where(k, np.minimum(y, h - 2), y)
+    t = np.sort(rng.uniform(0, 0.05, n))
+    return np.stack([t, x.astype(np.float64), y.astype(np.float64), rng.integers(0, 2, n) * 2.0 - 1.0], 1)
+
+
+@pytest.mark.parametrize("h,w,bins,n,wrap", [(720, 1280, 5, 300_000, False), (480, 640, 15, 200_000, False),
+                                             (260, 346, 5, 50_000, True), (37, 53, 3, 5_000, True),
+                                             (1100, 1300, 20, 100_000, False), (1100, 1300, 31, 50_000, False)])
+def test_voxelizer_binned_path_equals_direct_path_and_oracle(monkeypatch, h, w, bins, n, wrap):
+    """The LDS-band voxelizer (count / bin / band kernels) against the direct atomic kernel of the same library
+    (EEM_VOX_DIRECT=1) and the oracle, on clustered events: identical int64 indices, same support, values to fp32
+    summation-order round-off, raw and normalised.  The last two cases: bands of 112 KiB of LDS; a grid too large for bands (both runs take the direct kernel)."""
+    ev = _clustered_events(h * 7 + bins, n, h, w, wrap)
+    seq = EventSequence(None, {"height": h, "width": w}, features=ev.copy(), timestamp_multiplier=1e6,
+                        convert_to_relative=True)
+    out = {}
+    for mode in ("binned", "direct"):
+        if mode == "direct":
+            monkeypatch.setenv("EEM_VOX_DIRECT", "1")
+        raw, il, ir = EventSequenceToVoxelGrid_Pytorch(bins, gpu=True, normalize=False, forkserver=False)(seq, True)
+        norm = EventSequenceToVoxelGrid_Pytorch(bins, gpu=True, normalize=True, forkserver=False)(seq)
+        out[mode] = (raw.cpu().numpy(), il.cpu().numpy(), ir.cpu().numpy(), norm.cpu().numpy())
+    b, d = out["binned"], out["direct"]
+    assert np.array_equal(b[1], d[1]) and np.array_equal(b[2], d[2])
+    il_ref, _, ir_ref, _ = O.voxel_indices(seq.features, bins, h, w)
+    assert np.array_equal(b[1][b[1] >= 0], il_ref) and np.array_equal(b[2][b[2] >= 0], ir_ref)
+    ref_raw = O.voxelize(seq.features, bins, h, w, normalize=False)
+    ref_norm = O.voxelize(seq.features, bins, h, w, normalize=True)
+    scale = max(1.0, float(np.abs(ref_raw).max()))
+    for got in (b[0], d[0]):
+        np.testing.assert_allclose(got, ref_raw, atol=2e-6 * scale * 8, rtol=0)
+    for got in (b[3], d[3]):
+        np.testing.assert_allclose(got, ref_norm, atol=3e-5, rtol=1e-5)
+
+
+def test_voxelizer_alternating_streams_share_the_scratch_safely():
+    """Calls from one thread on two streams use the same scratch arena; the library orders them with an event."""
+    h, w, bins = 260, 346, 5
+    seqs = [EventSequence(None, {"height": h, "width": w}, features=_clustered_events(90 + k, 40_000 + 7000 * k, h, w),
+                          timestamp_multiplier=1e6, convert_to_relative=True) for k in range(4)]
+    refs = [O.voxelize(s.features, bins, h, w, normalize=True) for s in seqs]
+    vox = EventSequenceToVoxelGrid_Pytorch(bins, gpu=True, normalize=True, forkserver=False)
+    streams = [torch.cuda.Stream(DEV), torch.cuda.Stream(DEV)]
+    outs = []
+    for rep in range(3):
+        for k, s in enumerate(seqs):
+            with torch.cuda.stream(streams[k & 1]):
+                outs.append((k, vox(s)))
+    torch.cuda.synchronize(DEV)
+    for k, g in outs:
+        np.testing.assert_allclose(g.cpu().numpy(), refs[k], atol=3e-5, rtol=1e-5)
+
+
 def test_errors_are_loud():
     net, _ = make_net(1)
     with pytest.raises(AttributeError):

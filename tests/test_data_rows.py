@@ -4,6 +4,7 @@ import os
 
 import numpy as np
 import pytest
+import torch
 
 from eemflow_amd import hrem
 from oracle import data_oracle as D
@@ -72,3 +73,40 @@ def test_dataset_needs_gpu_and_layout(tmp_path):
     assert list(te.nori_list) == ["seqA"]
     te.change_test_sequence("seqA")
     assert len(te) == 1
+
+
+def test_mvsec_file_lists_crop_and_event_mask(tmp_path):
+    """MVSEC.py:60-93 / :201-227 file lists, CenterCrop offsets, and the event mask against np.histogram2d itself."""
+    from eemflow_amd import mvsec
+    args = {"eval_type": "sparse", "num_voxel_bins": 5, "sequence": "indoor_flying2"}
+    ds = mvsec.MvsecEventFlow(args, train=False, root=str(tmp_path))
+    assert len(ds) == 2199 - 314 and ds.names[0] == 314
+    assert ds.flow_list[0].endswith("dataset/MVSEC/indoor_flying2/flowgt_dt1/314.npy")
+    assert ds.event_list[0].endswith("dataset/MVSEC/indoor_flying2/event/000315.h5")
+    assert len(ds.event_list) == len(ds) + 1 and ds.event_list[-1].endswith("002200.h5")
+    ds.change_test_sequence("indoor_flying1")
+    assert "dataset/MVSEC_test/indoor_flying1/" in ds.flow_list[0] and ds.sequence == "indoor_flying1_new"
+    ds.change_test_sequence("outdoor_day1")
+    assert len(ds) == 3000 - 245
+    d4 = mvsec.MvsecEventFlow_dt4(dict(args, sequence="indoor_flying1"), train=False, root=str(tmp_path))
+    assert "dataset/MVSEC/indoor_flying1/flowgt_dt4/314.npy" in d4.flow_list[0]
+    assert len(d4.event_list) == len(d4) + 5 and d4.event_list[-1].endswith("002204.h5")
+    with pytest.raises(NotImplementedError):
+        mvsec.MvsecEventFlow(dict(args, aug_params={"crop_size": [256, 256]}), train=True, root=str(tmp_path))
+    # torchvision CenterCrop((256,256)) of 260x346: top 2, left 45
+    x = torch.arange(260 * 346).view(1, 260, 346)
+    c = mvsec.center_crop(x, (256, 256))
+    assert tuple(c.shape) == (1, 256, 256) and int(c[0, 0, 0]) == 2 * 346 + 45
+    rng = np.random.default_rng(5)
+    for frac in (False, True):
+        n, h, w = 4000, 260, 346
+        xs = rng.integers(-2, w + 3, n).astype(np.float64)
+        ys = rng.integers(-2, h + 3, n).astype(np.float64)
+        if frac:
+            xs, ys = xs + rng.uniform(0, 1, n), ys + rng.uniform(0, 1, n)
+        xs[:3], ys[:3] = w, h                                     # the closed right edge of the last bin
+        feats = np.stack([np.zeros(n), xs, ys, np.ones(n)], 1)
+        hist, _, _ = np.histogram2d(x=xs, y=ys, bins=(w, h), range=[[0, w], [0, h]])
+        assert np.array_equal(mvsec.event_mask(feats, h, w), hist.transpose() > 0)
+    with pytest.raises(FileNotFoundError):
+        mvsec.get_events(os.path.join(tmp_path, "nope.h5"))

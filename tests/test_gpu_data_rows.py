@@ -121,3 +121,78 @@ def test_harness_eval_and_train_on_synthetic_hrem(tmp_path):
     fresh = EEMFlow("", 5, 5, out_mesh_size=True)
     assert load_checkpoint(p, fresh) == 0
     assert not torch.equal(fresh.state_dict()["out_conv.weight"], w0.cpu())          # the step changed the weights
+
+
+def _mvsec_tree(root, seq, frames, dt4=False):
+    """Synthetic MVSEC tree: per-frame event tables exported as npz (ts seconds, x, y, p in {-1,+1}), flow as .npy."""
+    from eemflow_amd.hrem import synthetic_flow, synthetic_hrem_events
+    ev_dir = os.path.join(root, "dataset/MVSEC", seq, "event")
+    fl_dir = os.path.join(root, "dataset/MVSEC", seq, "flowgt_dt4" if dt4 else "flowgt_dt1")
+    os.makedirs(ev_dir, exist_ok=True)
+    os.makedirs(fl_dir, exist_ok=True)
+    events = {}
+    for f in range(frames[0] + 1, frames[1] + 8):
+        ev = synthetic_hrem_events(100 + f, 3000 + 10 * f, 260, 346, t_span=0.02)
+        ev = ev[np.argsort(ev[:, 0], kind="stable")]
+        ev[:, 0] += 0.02 * f                                        # consecutive frames, increasing time
+        events[f] = ev
+        np.savez(os.path.join(ev_dir, "%06d.npz" % f), ts=ev[:, 0], x=ev[:, 1], y=ev[:, 2], p=ev[:, 3])
+    for i in range(*frames):
+        fl = synthetic_flow(200 + i, 260, 346)                      # (H,W,2): the loader transposes
+        np.save(os.path.join(fl_dir, "%d.npy" % i), fl)
+    return events
+
+
+@pytest.mark.parametrize("dt4", [False, True])
+def test_mvsec_dataset_end_to_end(tmp_path, dt4):
+    from eemflow_amd import mvsec
+    root = str(tmp_path)
+    frames = (10, 13)
+    events = _mvsec_tree(root, "indoor_flying2", frames, dt4)
+    cls = mvsec.MvsecEventFlow_dt4 if dt4 else mvsec.MvsecEventFlow
+    args = {"eval_type": "sparse", "num_voxel_bins": 5, "sequence": "indoor_flying2"}
+    ds = cls(args, train=False, root=root, valid_time_index={"indoor_flying2": [frames]})
+    assert len(ds) == 3
+    k = 4 if dt4 else 1
+    for idx in (0, 2):
+        s = ds[idx]
+        raw = ds.get_sample(idx)
+        old = np.concatenate([events[frames[0] + idx + 1 + i] for i in range(k)])
+        new = np.concatenate([events[frames[0] + idx + 2 + i] for i in range(k)])
+        for key, ev in (("event_volume_old", old), ("event_volume_new", new)):
+            feats = O.event_sequence(ev, 1e6, True)
+            ref = O.voxelize(feats, 5, 260, 346, normalize=True)
+            assert raw[key].is_cuda and float((raw[key].cpu() - torch.from_numpy(ref)).abs().max()) < 1e-4
+            assert torch.equal(s[key].cpu(), torch.from_numpy(ref[:, 2:258, 45:301]).to(s[key].dtype)) or \
+                float((s[key].cpu() - torch.from_numpy(ref[:, 2:258, 45:301])).abs().max()) < 1e-4
+        hist, _, _ = np.histogram2d(x=old[:, 1], y=old[:, 2], bins=(346, 260), range=[[0, 346], [0, 260]])
+        assert np.array_equal(raw["event_valid"][0].numpy(), hist.transpose() > 0)
+        assert tuple(s["event_valid"].shape) == (1, 256, 256) and tuple(s["flow"].shape) == (2, 256, 256)
+        fl = synthetic_flow_chw(200 + frames[0] + idx)
+        assert torch.equal(s["flow"], torch.from_numpy(fl[:, 2:258, 45:301]))
+        assert s["valid"].dtype == torch.bool and s["idx"] == frames[0] + idx
+    tr = cls(args, train=True, root=root, valid_time_index={"indoor_flying2": [frames]})
+    t = tr[1]
+    assert tuple(t["event_volume_old"].shape) == (5, 260, 346) and tuple(t["valid"].shape) == (260, 346)
+
+
+def synthetic_flow_chw(seed):
+    from eemflow_amd.hrem import synthetic_flow
+    return np.ascontiguousarray(synthetic_flow(seed, 260, 346).transpose(2, 0, 1))
+
+
+def test_harness_evaluates_mvsec_sparse(tmp_path):
+    """test_multi_sequence over a synthetic MVSEC tree with the 'sparse' metric (event mask -> flow_error on the GPU)."""
+    from eemflow_amd import EEMFlow, mvsec
+    from eemflow_amd.harness import TestRaftEvents
+    from eemflow_amd.weights import seeded_state_dict
+    root = str(tmp_path)
+    frames = (20, 23)
+    _mvsec_tree(root, "indoor_flying2", frames)
+    ds = mvsec.MvsecEventFlow({"eval_type": "sparse", "num_voxel_bins": 5, "sequence": "indoor_flying2"}, train=False, root=root,
+                              valid_time_index={"indoor_flying2": [frames]})
+    net = EEMFlow("", 5, 5)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(3).items()})
+    net = net.to(DEV)
+    aee = TestRaftEvents(ds, (256, 256)).test_multi_sequence(net, sequence_list=["indoor_flying2"], stride=1)
+    assert np.isfinite(aee) and aee > 0

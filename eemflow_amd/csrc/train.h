@@ -10,6 +10,7 @@ struct WgradArgs {
     int g_ctotal, g_coff, g_cmul, cout;
     float* dw;             // [cout][cin][k][k], accumulated with atomics (zero it first)
     int n, hin, win, hout, wout, k, stride, pad;
+    const float* zero_page;   // >= 16 bytes of zeros (LDS-DMA source for padding), or NULL: generic kernel only
 };
 
 int tr_loss_launch(const float* flow, const float* gt, const float* valid, float* dflow, int batch, int hw, float weight,
@@ -22,6 +23,9 @@ int tr_corr_bwd_launch(const float* dcv, int dcv_ctotal, const float* f1, const 
 int tr_bias_grad_launch(const float* g, const float* gate, int g_ctotal, int g_coff, int g_cmul, int cout, int n, int hw, float* db,
                         hipStream_t st);
 int tr_wgrad_launch(const WgradArgs& a, hipStream_t st);
+// encoder-shaped jobs (3x3, pad 1, no gate, 16/32/64 couts, 16-byte aligned rows): wgrad_enc.hip
+bool wgrad_enc_supported(const WgradArgs& a);
+int wgrad_enc_launch(const WgradArgs& a, hipStream_t st);
 // several convs of the same kernel size / stride in one launch (blockIdx.z = job); at most WGRAD_MAX_JOBS
 #define WGRAD_MAX_JOBS 16
 int tr_wgrad_launch_batch(const WgradArgs* jobs, int njobs, hipStream_t st);

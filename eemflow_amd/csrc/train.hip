@@ -379,7 +379,10 @@ int tr_wgrad_launch_batch(const WgradArgs* jobs, int njobs, hipStream_t st) {
     return EEM_OK;
 }
 
-int tr_wgrad_launch(const WgradArgs& a, hipStream_t st) { return tr_wgrad_launch_batch(&a, 1, st); }
+int tr_wgrad_launch(const WgradArgs& a, hipStream_t st) {
+    if (wgrad_enc_supported(a)) return wgrad_enc_launch(a, st);
+    return tr_wgrad_launch_batch(&a, 1, st);
+}
 
 int tr_sumsq_launch(const float* g, long n, double* out, hipStream_t st) {
     hipLaunchKernelGGL(sumsq_kernel, dim3(512), dim3(256), 0, st, g, n, out);

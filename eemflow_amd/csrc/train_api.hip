@@ -53,6 +53,7 @@ struct Bwd {
         w.g = dy; w.gate = y_gate; w.g_ctotal = g_ctotal; w.g_coff = g_coff; w.g_cmul = g_cmul; w.cout = r.cout;
         w.dw = grad + r.w;
         w.n = n; w.hin = hin; w.win = win; w.hout = hout; w.wout = wout; w.k = r.k; w.stride = r.stride; w.pad = r.k == 3 ? 1 : 0;
+        w.zero_page = nullptr;
         return tr_bias_grad_launch(dy, y_gate, g_ctotal, g_coff, g_cmul, r.cout, n, hout * wout, grad + r.b, st);
     }
     int flush_wgrads() {
@@ -69,6 +70,7 @@ struct Bwd {
         w.g = dy; w.gate = y_gate; w.g_ctotal = g_ctotal; w.g_coff = g_coff; w.g_cmul = g_cmul; w.cout = r.cout;
         w.dw = grad + r.w;
         w.n = n; w.hin = hin; w.win = win; w.hout = hout; w.wout = wout; w.k = r.k; w.stride = r.stride; w.pad = r.k == 3 ? 1 : 0;
+        w.zero_page = c->zero_page;
         int rc = tr_wgrad_launch(w, st);
         if (rc != EEM_OK) return rc;
         return tr_bias_grad_launch(dy, y_gate, g_ctotal, g_coff, g_cmul, r.cout, n, hout * wout, grad + r.b, st);

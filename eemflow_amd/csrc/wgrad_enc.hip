@@ -1,0 +1,236 @@
+// Weight gradients of the encoder's 3x3 convs (the transposes of EEMFlow.py:26-30,75-82 under autograd):
+//     dW[co][ci][ky][kx] = sum_{n, oy, ox} G[n][co][oy][ox] * X[n][ci][oy*S + ky - 1][ox*S + kx - 1]
+// with G already the gradient w.r.t. the conv's pre-activation (train_api.hip stores the encoder gradients
+// pre-gated), so this is a plain GEMM  dW[M = cout][N = (ci, tap)] = G[M][K = pixels] * X[K][N]  whose K runs over
+// every output pixel of the batch.
+//
+// Layout of the work:
+//   * a block owns 16 input channels (blockIdx.y) x all couts and a contiguous range of 128-pixel tiles (TH x TW,
+//     4x32 or 8x16); N = 16 ci x 9 taps = 144 = nine 16-wide MFMA tiles exactly, M = cout / 16 tiles: no padding
+//     anywhere, v_mfma_f32_16x16x4_f32 throughout (the 32x32x2 shape wastes half of a 16-cout layer);
+//   * K is split over the four waves: wave w takes pixels [32w, 32w+32) of the tile (8 k-steps of 4 pixels) against
+//     ALL (M, N) tiles - 36 / 72 / 144 accumulator registers for 16 / 32 / 64 couts - so the waves share no
+//     operand, read each LDS word once, and are perfectly balanced; the four partial dW meet in LDS at the very end
+//     (ds_add_f32) and leave with one coalesced fp32 atomic per weight and block;
+//   * G and the haloed X tile stream HBM/L2 -> LDS by 16-byte LDS-DMA, double-buffered: tile i+1 is requested
+//     right after the barrier that hands tile i to the MFMAs (one barrier per tile, no VALU staging).  G rows sit at
+//     a pitch of 132 floats (33 DMA pieces, the last one a dummy) so that the A-operand column reads hit every
+//     bank exactly twice; X rows start 4 columns left of the tile so every piece is 16-byte aligned, and pieces
+//     outside the image (the conv's zero padding, ragged tiles) come from a zero page.
+// Per k-step a wave issues MT + 9 ds_read_b32 for 9*MT MFMAs.
+#include "common.h"
+#include "train.h"
+
+namespace {
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+template <int MT, int S, int TW>
+struct WgCfg {
+    static constexpr int TH = 128 / TW;
+    static constexpr int GP = 132;                               // G row pitch (floats): 33 pieces
+    static constexpr int GSLOTS = MT * 16 * 33;
+    static constexpr int XR = (TH - 1) * S + 3;
+    static constexpr int XC = (S * TW - S + 6 + 3) & ~3;         // staged columns, from ox0*S - 4
+    static constexpr int XQ = XC / 4;
+    static constexpr int PC = XR * XC;                           // channel plane
+    static constexpr int XSLOTS = 16 * XR * XQ;
+    static constexpr int NGI = (GSLOTS + 255) / 256;             // DMA instructions per wave and tile
+    static constexpr int NXI = (XSLOTS + 255) / 256;
+    static constexpr int GFL = NGI * 256 * 4;                    // floats per stage (whole instructions)
+    static constexpr int XFL = NXI * 256 * 4;
+    static constexpr int STAGE = GFL + XFL;
+    static constexpr int RED = MT * 16 * 144;                    // epilogue buffer, reuses the stages
+    static_assert(2 * STAGE >= RED, "epilogue buffer fits the stages");
+    static_assert(2 * STAGE * 4 <= 160 * 1024, "LDS budget");
+};
+
+template <int MT, int S, int TW>
+__global__ __launch_bounds__(256) void wgrad_enc_kernel(WgradArgs a, int tiles_x, int tiles_y) {
+    using C = WgCfg<MT, S, TW>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int ci0 = blockIdx.y * 16;
+    const int cin_here = min(16, a.cin - ci0);
+    const int nvalid = cin_here * 9;
+
+    const TileRange tr_ = block_tile_range(tiles_x * tiles_y * a.n, blockIdx.x, gridDim.x);
+    if (tr_.count == 0) return;
+    TileCoord cur = tile_coord(tr_.first, tiles_x, tiles_y);
+    const size_t ghw = (size_t)a.hout * a.wout, xhw = (size_t)a.hin * a.win;
+
+    // ---- DMA plan: per instruction and lane a byte offset from the tile's base pointer and the piece's
+    // (row, column) inside the tile for the bounds test
+    int goff[C::NGI], grc[C::NGI], xoff[C::NXI], xrc[C::NXI];
+#pragma unroll
+    for (int k = 0; k < C::NGI; ++k) {
+        const int f = (wave + 4 * k) * 64 + lane;
+        const int co = f / 33, q = f - co * 33;
+        const int p = 4 * q, py = p / TW, px = p - py * TW;
+        const bool ok = f < C::GSLOTS && q < 32;
+        goff[k] = (int)(((size_t)co * ghw + (size_t)py * a.wout + px) * 4);
+        grc[k] = ok ? (py | (px << 8)) : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < C::NXI; ++k) {
+        const int f = (wave + 4 * k) * 64 + lane;
+        const int ci = f / (C::XR * C::XQ), rem = f - ci * (C::XR * C::XQ);
+        const int ry = rem / C::XQ, qx = rem - ry * C::XQ;
+        const bool ok = f < C::XSLOTS && ci < cin_here;
+        xoff[k] = (int)(((size_t)ci * xhw + (size_t)ry * a.win + 4 * qx) * 4);
+        xrc[k] = ok ? (ry | ((4 * qx) << 8)) : -1;
+    }
+    const char* zero = reinterpret_cast<const char*>(a.zero_page);
+    auto issue = [&](int stage, const TileCoord& tc) {
+        const int oy0 = tc.by * C::TH, ox0 = tc.bx * TW;
+        const int gy0 = oy0 * S - 1, gx0 = ox0 * S - 4;
+        // signed element offsets: the first tile row / column starts above / left of the image
+        const char* gb = reinterpret_cast<const char*>(a.g + ((size_t)tc.n * a.g_ctotal + a.g_coff) * ghw) +
+                         ((long)oy0 * a.wout + ox0) * 4;
+        const char* xb = reinterpret_cast<const char*>(a.x + ((size_t)tc.n * a.x_ctotal + a.x_coff + ci0) * xhw) +
+                         ((long)gy0 * a.win + gx0) * 4;
+        float* sg = lds + stage * C::STAGE;
+        float* sx = sg + C::GFL;
+#pragma unroll
+        for (int k = 0; k < C::NGI; ++k) {
+            const int py = grc[k] & 255, px = grc[k] >> 8;
+            const bool ok = grc[k] >= 0 && oy0 + py < a.hout && ox0 + px < a.wout;
+            const char* p = ok ? gb + goff[k] : zero;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(p), LDS_PTR(sg + (wave + 4 * k) * 256), 16, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < C::NXI; ++k) {
+            const int iy = gy0 + (xrc[k] & 255), ix = gx0 + (xrc[k] >> 8);
+            const bool ok = xrc[k] >= 0 && iy >= 0 && iy < a.hin && ix >= 0 && ix + 4 <= a.win;
+            const char* p = ok ? xb + xoff[k] : zero;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(p), LDS_PTR(sx + (wave + 4 * k) * 256), 16, 0, 0);
+        }
+    };
+
+    // ---- operand offsets.  k-step s of this wave covers pixels 32*wave + 4s + g
+    int boff[9];
+#pragma unroll
+    for (int nt = 0; nt < 9; ++nt) {
+        int n = nt * 16 + j;
+        n = n < nvalid ? n : 0;                                  // columns past cin_here*9 are never written back
+        const int ci = n / 9, tap = n - ci * 9;
+        boff[nt] = ci * C::PC + (tap / 3) * C::XC + (tap % 3) + 3;   // + 3: the stage starts 4 columns left, pad 1
+    }
+    int aoff[8], xo[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int p = wave * 32 + 4 * s + g;
+        const int py = p / TW, px = p - py * TW;
+        aoff[s] = j * C::GP + p;
+        xo[s] = py * S * C::XC + px * S;
+    }
+
+    f32x4 acc[MT][9];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 9; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue(0, cur);
+    TileCoord nxt = cur;
+#pragma unroll 1
+    for (int it = 0; it < tr_.count; ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces of tile `it` have landed
+        __builtin_amdgcn_s_barrier();                            // everyone's have; everyone is done with tile it-1
+        asm volatile("" ::: "memory");
+        if (it + 1 < tr_.count) {
+            tile_advance(nxt, tiles_x, tiles_y);
+            issue((it + 1) & 1, nxt);
+        }
+        const float* sg = lds + (it & 1) * C::STAGE;
+        const float* sx = sg + C::GFL;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            float av[MT], bv[9];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[mt] = sg[aoff[s] + mt * 16 * C::GP];
+#pragma unroll
+            for (int nt = 0; nt < 9; ++nt) bv[nt] = sx[boff[nt] + xo[s]];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 9; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+
+    // ---- the four waves' partial sums meet in LDS, then one atomic per weight
+    __syncthreads();
+    float* red = lds;
+    for (int i = threadIdx.x; i < C::RED; i += 256) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 9; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)                          // D[co = 4g + r][n = j]
+                atomicAdd(&red[(mt * 16 + 4 * g + r) * 144 + nt * 16 + j], acc[mt][nt][r]);
+    __syncthreads();
+    for (int i = threadIdx.x; i < C::RED; i += 256) {
+        const int co = i / 144, n = i - co * 144;
+        if (n < nvalid) atomicAdd(&a.dw[((size_t)co * a.cin + ci0) * 9 + n], red[i]);
+    }
+}
+
+template <int MT, int S, int TW>
+int launch(const WgradArgs& a, hipStream_t st) {
+    using C = WgCfg<MT, S, TW>;
+    const int tiles_x = ceil_div(a.wout, TW), tiles_y = ceil_div(a.hout, C::TH);
+    const int T = tiles_x * tiles_y * a.n;
+    const int chunks = ceil_div(a.cin, 16);
+    const int lds_bytes = 2 * C::STAGE * 4;
+    int per_cu = (160 * 1024) / lds_bytes;
+    per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+    int gx = (256 * per_cu) / chunks;                            // ~per_cu resident blocks per CU over all chunks
+    gx = (gx + 7) & ~7;
+    const int need = (ceil_div(T, 8)) * 8;
+    if (gx > need) gx = need;
+    static bool raised = false;
+    if (!raised) {
+        EEM_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_enc_kernel<MT, S, TW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          160 * 1024));
+        raised = true;
+    }
+    hipLaunchKernelGGL((wgrad_enc_kernel<MT, S, TW>), dim3(gx, chunks), dim3(256), lds_bytes, st, a, tiles_x, tiles_y);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+template <int MT, int S>
+int launch_tw(const WgradArgs& a, hipStream_t st) {
+    if (a.wout % 32 == 0 || a.wout >= 256) return launch<MT, S, 32>(a, st);
+    return launch<MT, S, 16>(a, st);
+}
+
+}  // namespace
+
+bool wgrad_enc_supported(const WgradArgs& a) {
+    static const bool off = [] { const char* e = getenv("EEM_NO_WGRAD_ENC"); return e && e[0] == '1'; }();
+    if (off) return false;
+    return a.zero_page && a.gate == nullptr && a.k == 3 && a.pad == 1 && (a.stride == 1 || a.stride == 2) &&
+           (a.cout == 16 || a.cout == 32 || a.cout == 64) && a.g_cmul == 1 && (a.cin <= 16 || a.cin % 16 == 0) &&
+           a.wout % 4 == 0 && a.win % 4 == 0 && ((uintptr_t)a.g & 15) == 0 && ((uintptr_t)a.x & 15) == 0 &&
+           ((size_t)a.hout * a.wout) % 4 == 0 && ((size_t)a.hin * a.win) % 4 == 0 &&
+           (size_t)a.cout * a.hout * a.wout * 4 < (1u << 31) && (size_t)16 * a.hin * a.win * 4 < (1u << 31);
+}
+
+int wgrad_enc_launch(const WgradArgs& a, hipStream_t st) {
+    const int mt = a.cout / 16;
+    if (a.stride == 1) {
+        if (mt == 1) return launch_tw<1, 1>(a, st);
+        if (mt == 2) return launch_tw<2, 1>(a, st);
+        return launch_tw<4, 1>(a, st);
+    }
+    if (mt == 1) return launch_tw<1, 2>(a, st);
+    if (mt == 2) return launch_tw<2, 2>(a, st);
+    return launch_tw<4, 2>(a, st);
+}

@@ -11,6 +11,7 @@ struct WgradArgs {
     float* dw;             // [cout][cin][k][k], accumulated with atomics (zero it first)
     int n, hin, win, hout, wout, k, stride, pad;
     const float* zero_page;   // >= 16 bytes of zeros (LDS-DMA source for padding), or NULL: generic kernel only
+    float* db;                // wgrad_enc only: bias gradient [cout], accumulated with atomics, or NULL
 };
 
 int tr_loss_launch(const float* flow, const float* gt, const float* valid, float* dflow, int batch, int hw, float weight,

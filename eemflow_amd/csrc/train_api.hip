@@ -53,7 +53,7 @@ struct Bwd {
         w.g = dy; w.gate = y_gate; w.g_ctotal = g_ctotal; w.g_coff = g_coff; w.g_cmul = g_cmul; w.cout = r.cout;
         w.dw = grad + r.w;
         w.n = n; w.hin = hin; w.win = win; w.hout = hout; w.wout = wout; w.k = r.k; w.stride = r.stride; w.pad = r.k == 3 ? 1 : 0;
-        w.zero_page = nullptr;
+        w.zero_page = nullptr; w.db = nullptr;
         return tr_bias_grad_launch(dy, y_gate, g_ctotal, g_coff, g_cmul, r.cout, n, hout * wout, grad + r.b, st);
     }
     int flush_wgrads() {
@@ -70,7 +70,8 @@ struct Bwd {
         w.g = dy; w.gate = y_gate; w.g_ctotal = g_ctotal; w.g_coff = g_coff; w.g_cmul = g_cmul; w.cout = r.cout;
         w.dw = grad + r.w;
         w.n = n; w.hin = hin; w.win = win; w.hout = hout; w.wout = wout; w.k = r.k; w.stride = r.stride; w.pad = r.k == 3 ? 1 : 0;
-        w.zero_page = c->zero_page;
+        w.zero_page = c->zero_page; w.db = grad + r.b;
+        if (wgrad_enc_supported(w)) return wgrad_enc_launch(w, st);          // weight and bias gradient in one kernel
         int rc = tr_wgrad_launch(w, st);
         if (rc != EEM_OK) return rc;
         return tr_bias_grad_launch(dy, y_gate, g_ctotal, g_coff, g_cmul, r.cout, n, hout * wout, grad + r.b, st);

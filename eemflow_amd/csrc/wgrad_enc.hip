@@ -11,7 +11,8 @@
 //   * K is split over the four waves: wave w takes pixels [32w, 32w+32) of the tile (8 k-steps of 4 pixels) against
 //     ALL (M, N) tiles - 36 / 72 / 144 accumulator registers for 16 / 32 / 64 couts - so the waves share no
 //     operand, read each LDS word once, and are perfectly balanced; the four partial dW meet in LDS at the very end
-//     (ds_add_f32) and leave with one coalesced fp32 atomic per weight and block;
+//     (plain read-modify-writes, wave after wave) and leave with one fp32 atomic per weight and block; the bias
+//     gradient (row sums of G) rides along in the first channel chunk;
 //   * G and the haloed X tile stream HBM/L2 -> LDS by 16-byte LDS-DMA, double-buffered: tile i+1 is requested
 //     right after the barrier that hands tile i to the MFMAs (one barrier per tile, no VALU staging).  G rows sit at
 //     a pitch of 132 floats (33 DMA pieces, the last one a dummy) so that the A-operand column reads hit every
@@ -26,8 +27,9 @@ namespace {
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
-template <int MT, int S, int TW>
+template <int MT, int S, int TW, int CP>
 struct WgCfg {
+    static constexpr int NT = (CP * 9 + 15) / 16;                // 16-wide N tiles: 9 for 16 channels, 3 for the 5 of pconv1_1
     static constexpr int TH = 128 / TW;
     static constexpr int GP = 132;                               // G row pitch (floats): 33 pieces
     static constexpr int GSLOTS = MT * 16 * 33;
@@ -35,26 +37,27 @@ struct WgCfg {
     static constexpr int XC = (S * TW - S + 6 + 3) & ~3;         // staged columns, from ox0*S - 4
     static constexpr int XQ = XC / 4;
     static constexpr int PC = XR * XC;                           // channel plane
-    static constexpr int XSLOTS = 16 * XR * XQ;
+    static constexpr int XSLOTS = CP * XR * XQ;
     static constexpr int NGI = (GSLOTS + 255) / 256;             // DMA instructions per wave and tile
     static constexpr int NXI = (XSLOTS + 255) / 256;
     static constexpr int GFL = NGI * 256 * 4;                    // floats per stage (whole instructions)
     static constexpr int XFL = NXI * 256 * 4;
     static constexpr int STAGE = GFL + XFL;
-    static constexpr int RED = MT * 16 * 144;                    // epilogue buffer, reuses the stages
+    static constexpr int RED = MT * NT * 256;                    // epilogue buffer (floats), reuses the stages
     static_assert(2 * STAGE >= RED, "epilogue buffer fits the stages");
     static_assert(2 * STAGE * 4 <= 160 * 1024, "LDS budget");
 };
 
-template <int MT, int S, int TW>
+template <int MT, int S, int TW, int CP>
 __global__ __launch_bounds__(256) void wgrad_enc_kernel(WgradArgs a, int tiles_x, int tiles_y) {
-    using C = WgCfg<MT, S, TW>;
+    using C = WgCfg<MT, S, TW, CP>;
+    constexpr int NT = C::NT;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, g = lane >> 4;
-    const int ci0 = blockIdx.y * 16;
-    const int cin_here = min(16, a.cin - ci0);
+    const int ci0 = blockIdx.y * CP;
+    const int cin_here = min(CP, a.cin - ci0);
     const int nvalid = cin_here * 9;
 
     const TileRange tr_ = block_tile_range(tiles_x * tiles_y * a.n, blockIdx.x, gridDim.x);
@@ -111,9 +114,9 @@ __global__ __launch_bounds__(256) void wgrad_enc_kernel(WgradArgs a, int tiles_x
     };
 
     // ---- operand offsets.  k-step s of this wave covers pixels 32*wave + 4s + g
-    int boff[9];
+    int boff[NT];
 #pragma unroll
-    for (int nt = 0; nt < 9; ++nt) {
+    for (int nt = 0; nt < NT; ++nt) {
         int n = nt * 16 + j;
         n = n < nvalid ? n : 0;                                  // columns past cin_here*9 are never written back
         const int ci = n / 9, tap = n - ci * 9;
@@ -128,11 +131,14 @@ __global__ __launch_bounds__(256) void wgrad_enc_kernel(WgradArgs a, int tiles_x
         xo[s] = py * S * C::XC + px * S;
     }
 
-    f32x4 acc[MT][9];
+    f32x4 acc[MT][NT];
+    float bsum[MT];                                              // bias gradient: row sums of G, lane (j, g) -> cout mt*16 + j
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt) {
+        bsum[mt] = 0.f;
 #pragma unroll
-        for (int nt = 0; nt < 9; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     issue(0, cur);
     TileCoord nxt = cur;
@@ -149,44 +155,72 @@ __global__ __launch_bounds__(256) void wgrad_enc_kernel(WgradArgs a, int tiles_x
         const float* sx = sg + C::GFL;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            float av[MT], bv[9];
+            float av[MT], bv[NT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) av[mt] = sg[aoff[s] + mt * 16 * C::GP];
 #pragma unroll
-            for (int nt = 0; nt < 9; ++nt) bv[nt] = sx[boff[nt] + xo[s]];
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = sx[boff[nt] + xo[s]];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt) {
+                bsum[mt] += av[mt];
 #pragma unroll
-                for (int nt = 0; nt < 9; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+            }
         }
     }
 
-    // ---- the four waves' partial sums meet in LDS, then one atomic per weight
-    __syncthreads();
-    float* red = lds;
-    for (int i = threadIdx.x; i < C::RED; i += 256) red[i] = 0.f;
-    __syncthreads();
+    // ---- the four waves' partial sums meet in LDS: wave 0 stores, waves 1..3 add in turn (plain 16-byte
+    // read-modify-writes at [tile][lane] - LDS float atomics took 43 us here), then one global atomic per weight
+    f32x4* red = reinterpret_cast<f32x4*>(lds);
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 9; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)                          // D[co = 4g + r][n = j]
-                atomicAdd(&red[(mt * 16 + 4 * g + r) * 144 + nt * 16 + j], acc[mt][nt][r]);
+                for (int nt = 0; nt < NT; ++nt) {
+                    f32x4* cell = red + (mt * NT + nt) * 64 + lane;
+                    *cell = w == 0 ? acc[mt][nt] : *cell + acc[mt][nt];
+                }
+        }
+    }
     __syncthreads();
-    for (int i = threadIdx.x; i < C::RED; i += 256) {
-        const int co = i / 144, n = i - co * 144;
-        if (n < nvalid) atomicAdd(&a.dw[((size_t)co * a.cin + ci0) * 9 + n], red[i]);
+    for (int e = threadIdx.x; e < MT * NT * 64; e += 256) {
+        const int tile = e >> 6, l = e & 63;
+        const int mt = tile / NT, nt = tile - mt * NT;
+        const int n = nt * 16 + (l & 15);
+        if (n >= nvalid) continue;
+        const f32x4 v = red[e];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                            // D[co = 4 * (l / 16) + r][n = l % 16]
+            const int co = mt * 16 + 4 * (l >> 4) + r;
+            atomicAdd(&a.dw[((size_t)co * a.cin + ci0) * 9 + n], v[r]);
+        }
+    }
+    // ---- bias gradient (first channel chunk only): sum over the 4 pixel slots of a k-step, the waves, the blocks
+    if (a.db && blockIdx.y == 0) {
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            float v = bsum[mt];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (g == 0) lds[wave * 64 + mt * 16 + j] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < MT * 16)
+            atomicAdd(&a.db[threadIdx.x], lds[threadIdx.x] + lds[64 + threadIdx.x] + lds[128 + threadIdx.x] + lds[192 + threadIdx.x]);
     }
 }
 
-template <int MT, int S, int TW>
+template <int MT, int S, int TW, int CP>
 int launch(const WgradArgs& a, hipStream_t st) {
-    using C = WgCfg<MT, S, TW>;
+    using C = WgCfg<MT, S, TW, CP>;
     const int tiles_x = ceil_div(a.wout, TW), tiles_y = ceil_div(a.hout, C::TH);
     const int T = tiles_x * tiles_y * a.n;
-    const int chunks = ceil_div(a.cin, 16);
+    const int chunks = ceil_div(a.cin, CP);
     const int lds_bytes = 2 * C::STAGE * 4;
     int per_cu = (160 * 1024) / lds_bytes;
     per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
@@ -196,19 +230,19 @@ int launch(const WgradArgs& a, hipStream_t st) {
     if (gx > need) gx = need;
     static bool raised = false;
     if (!raised) {
-        EEM_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_enc_kernel<MT, S, TW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        EEM_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_enc_kernel<MT, S, TW, CP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           160 * 1024));
         raised = true;
     }
-    hipLaunchKernelGGL((wgrad_enc_kernel<MT, S, TW>), dim3(gx, chunks), dim3(256), lds_bytes, st, a, tiles_x, tiles_y);
+    hipLaunchKernelGGL((wgrad_enc_kernel<MT, S, TW, CP>), dim3(gx, chunks), dim3(256), lds_bytes, st, a, tiles_x, tiles_y);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }
 
 template <int MT, int S>
 int launch_tw(const WgradArgs& a, hipStream_t st) {
-    if (a.wout % 32 == 0 || a.wout >= 256) return launch<MT, S, 32>(a, st);
-    return launch<MT, S, 16>(a, st);
+    if (a.wout % 32 == 0 || a.wout >= 256) return launch<MT, S, 32, 16>(a, st);
+    return launch<MT, S, 16, 16>(a, st);
 }
 
 }  // namespace
@@ -230,6 +264,7 @@ int wgrad_enc_launch(const WgradArgs& a, hipStream_t st) {
         if (mt == 2) return launch_tw<2, 1>(a, st);
         return launch_tw<4, 1>(a, st);
     }
+    if (mt == 1 && a.cin <= 5 && (a.wout % 32 == 0 || a.wout >= 256)) return launch<1, 2, 32, 5>(a, st);   // pconv1_1
     if (mt == 1) return launch_tw<1, 2>(a, st);
     if (mt == 2) return launch_tw<2, 2>(a, st);
     return launch_tw<4, 2>(a, st);

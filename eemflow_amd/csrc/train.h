@@ -30,6 +30,19 @@ int wgrad_enc_launch(const WgradArgs& a, hipStream_t st);
 // several convs of the same kernel size / stride in one launch (blockIdx.z = job); at most WGRAD_MAX_JOBS
 #define WGRAD_MAX_JOBS 16
 int tr_wgrad_launch_batch(const WgradArgs* jobs, int njobs, hipStream_t st);
+// data gradient of a stride-2 3x3 conv (pad 1) with the pooling branch and the LeakyReLU' gate of the producing layer folded
+// in: dx = (convT(dy, w) + dpool / k^2) * (gate > 0 ? 1 : 0.1)   (dgrad_s2.hip; 16<-32 and 32<-64 channels)
+struct DgradS2Args {
+    const float* dy;       // [n][cout][hout][wout]
+    const float* w;        // [cout][cin][3][3]
+    float* dx;             // [n][cin][hin][win]
+    const float* gate;     // forward tensor at dx's shape, or NULL
+    const float* dpool;    // [n][cin][gh][gw] gradient of the k x k average pooling of the same tensor, or NULL
+    const float* zero_page;
+    int n, cin, cout, hin, win, hout, wout, pool_k, gh, gw;
+};
+bool dgrad_s2_supported(const DgradS2Args& a);
+int dgrad_s2_launch(const DgradS2Args& a, hipStream_t st);
 int tr_sumsq_launch(const float* g, long n, double* out, hipStream_t st);
 int tr_adamw_launch(float* p, const float* g, float* m, float* v, long n, const double* sumsq, float clip, float lr, float wd,
                     float eps, float b1, float b2, long step, hipStream_t st);

@@ -246,6 +246,17 @@ extern "C" int eemflow_forward_backward(eemflow_ctx* c, const float* e1, const f
             a.gate = l.x;                                        // -> gradient w.r.t. the previous conv's pre-activation
             if ((rc = enc_conv_launch(r.cout, r.cin, 1, a, st)) != EEM_OK) return rc;
         } else {
+            // stride-2 layers read a stage output, which also feeds the pooling
+            const bool first = l.layer == ENC_2_1;
+            DgradS2Args d;
+            d.dy = l.gy; d.w = c->flat + r.w; d.dx = l.gx; d.gate = l.x;
+            d.dpool = c->g_pool[first ? 0 : 1].p; d.pool_k = first ? 32 : 16; d.gh = s.gh; d.gw = s.gw;
+            d.zero_page = c->zero_page;
+            d.n = n2; d.cin = r.cin; d.cout = r.cout; d.hin = l.hin; d.win = l.win; d.hout = l.hout; d.wout = l.wout;
+            if ((l.layer == ENC_2_1 || l.layer == ENC_3_1) && dgrad_s2_supported(d)) {
+                if ((rc = dgrad_s2_launch(d, st)) != EEM_OK) return rc;      // conv^T + pooling branch + gate in one kernel
+                continue;
+            }
             if ((rc = bw.dgrad(r, l.gy, nullptr, r.cout, 0, 1, n2, l.hout, l.wout, l.hin, l.win, l.gx, r.cin, 0)) != EEM_OK) return rc;
             // stride-2 layers read a stage output, which also feeds the pooling: add that branch, then gate
             if (l.layer == ENC_3_1 && (rc = tr_pool_bwd_launch(c->g_pool[1].p, c->g_f12.p, (long)n2 * 32, s.h2, s.w2, 16, s.gh, s.gw, 1, c->f12.p, st)) != EEM_OK) return rc;

@@ -23,6 +23,12 @@ int tr_corr_bwd_launch(const float* dcv, int dcv_ctotal, const float* f1, const 
                        int h, int w, const int* taps, int ntaps, hipStream_t st);
 int tr_bias_grad_launch(const float* g, const float* gate, int g_ctotal, int g_coff, int g_cmul, int cout, int n, int hw, float* db,
                         hipStream_t st);
+struct BiasJob {
+    const float* g;
+    const float* gate;
+    float* db;
+    int g_ctotal, g_coff, g_cmul, cout, n, hw;
+};
 int tr_wgrad_launch(const WgradArgs& a, hipStream_t st);
 // encoder-shaped jobs (3x3, pad 1, no gate, 16/32/64 couts, 16-byte aligned rows): wgrad_enc.hip
 bool wgrad_enc_supported(const WgradArgs& a);
@@ -30,6 +36,7 @@ int wgrad_enc_launch(const WgradArgs& a, hipStream_t st);
 // several convs of the same kernel size / stride in one launch (blockIdx.z = job); at most WGRAD_MAX_JOBS
 #define WGRAD_MAX_JOBS 16
 int tr_wgrad_launch_batch(const WgradArgs* jobs, int njobs, hipStream_t st);
+int tr_bias_grad_launch_batch(const BiasJob* jobs, int njobs, hipStream_t st);
 // data gradient of a stride-2 3x3 conv (pad 1) with the pooling branch and the LeakyReLU' gate of the producing layer folded
 // in: dx = (convT(dy, w) + dpool / k^2) * (gate > 0 ? 1 : 0.1)   (dgrad_s2.hip; 16<-32 and 32<-64 channels)
 struct DgradS2Args {

@@ -128,17 +128,23 @@ __global__ __launch_bounds__(256) void corrbwd_kernel(const float* __restrict__ 
     d2[idx] = s2 / (float)c;
 }
 
-// ---- bias gradient: db[co] = sum_{n,p} g[n][co'][p] * LeakyReLU'(gate); grid (chunks, cout)
-__global__ __launch_bounds__(256) void biasgrad_kernel(const float* __restrict__ g, const float* __restrict__ gate, int g_ctotal,
-                                                       int g_coff, int g_cmul, int n, int hw, float* __restrict__ db) {
+// ---- bias gradient: db[co] = sum_{n,p} g[n][co'][p] * LeakyReLU'(gate); grid (chunks, max cout, jobs)
+struct BiasBatch { BiasJob job[WGRAD_MAX_JOBS]; };
+
+__global__ __launch_bounds__(256) void biasgrad_kernel(BiasBatch batch) {
     __shared__ float sh[4];
+    const BiasJob& b = batch.job[blockIdx.z];
     const int co = blockIdx.y;
-    const int ch = g_coff + co * g_cmul;
-    const long total = (long)n * hw;
+    if (co >= b.cout) return;
+    const float* __restrict__ g = b.g;
+    const float* __restrict__ gate = b.gate;
+    const int ch = b.g_coff + co * b.g_cmul;
+    const int hw = b.hw;
+    const long total = (long)b.n * hw;
     float s = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int b = i / hw, p = i - (long)b * hw;
-        const size_t o = ((size_t)b * g_ctotal + ch) * hw + p;
+        const int n = i / hw, p = i - (long)n * hw;
+        const size_t o = ((size_t)n * b.g_ctotal + ch) * hw + p;
         float v = g[o];
         if (gate) v *= gate[o] > 0.f ? 1.f : 0.1f;
         s += v;
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(256) void biasgrad_kernel(const float* __restrict__
     for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&db[co], sh[0] + sh[1] + sh[2] + sh[3]);
+    if (threadIdx.x == 0) atomicAdd(&b.db[co], sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
 // ---- weight gradient on v_mfma_f32_32x32x2_f32: dW[co][(ci,tap)] = sum_pixels G[co][pixel] * X[(ci,tap)][pixel].
@@ -327,14 +333,28 @@ int tr_corr_bwd_launch(const float* dcv, int dcv_ctotal, const float* f1, const 
     return EEM_OK;
 }
 
-int tr_bias_grad_launch(const float* g, const float* gate, int g_ctotal, int g_coff, int g_cmul, int cout, int n, int hw, float* db,
-                        hipStream_t st) {
-    const long total = (long)n * hw;
+int tr_bias_grad_launch_batch(const BiasJob* jobs, int njobs, hipStream_t st) {
+    EEM_REQUIRE(jobs && njobs >= 1 && njobs <= WGRAD_MAX_JOBS, "tr_bias_grad_launch_batch: njobs=%d", njobs);
+    BiasBatch b;
+    long total = 0;
+    int cmax = 0;
+    for (int i = 0; i < njobs; ++i) {
+        b.job[i] = jobs[i];
+        total = std::max(total, (long)jobs[i].n * jobs[i].hw);
+        cmax = std::max(cmax, jobs[i].cout);
+    }
     int chunks = (int)((total + 256 * 64 - 1) / (256 * 64));
     chunks = chunks < 1 ? 1 : (chunks > 256 ? 256 : chunks);
-    hipLaunchKernelGGL(biasgrad_kernel, dim3(chunks, cout), dim3(256), 0, st, g, gate, g_ctotal, g_coff, g_cmul, n, hw, db);
+    hipLaunchKernelGGL(biasgrad_kernel, dim3(chunks, cmax, njobs), dim3(256), 0, st, b);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
+}
+
+int tr_bias_grad_launch(const float* g, const float* gate, int g_ctotal, int g_coff, int g_cmul, int cout, int n, int hw, float* db,
+                        hipStream_t st) {
+    BiasJob j;
+    j.g = g; j.gate = gate; j.db = db; j.g_ctotal = g_ctotal; j.g_coff = g_coff; j.g_cmul = g_cmul; j.cout = cout; j.n = n; j.hw = hw;
+    return tr_bias_grad_launch_batch(&j, 1, st);
 }
 
 int tr_wgrad_launch_batch(const WgradArgs* jobs, int njobs, hipStream_t st) {

@@ -45,6 +45,7 @@ struct Bwd {
     }
     // queued variant: the weight gradients of one tail layer (all decoders / groups) go out as ONE launch (flush_wgrads)
     WgradArgs wq[WGRAD_MAX_JOBS];
+    BiasJob bq[WGRAD_MAX_JOBS];
     int nwq = 0;
     int wgrad_q(const ConvRef& r, const float* x, int x_ctotal, int x_coff, const float* dy, const float* y_gate, int g_ctotal,
                 int g_coff, int g_cmul, int n, int hin, int win, int hout, int wout) {
@@ -54,11 +55,15 @@ struct Bwd {
         w.dw = grad + r.w;
         w.n = n; w.hin = hin; w.win = win; w.hout = hout; w.wout = wout; w.k = r.k; w.stride = r.stride; w.pad = r.k == 3 ? 1 : 0;
         w.zero_page = nullptr; w.db = nullptr;
-        return tr_bias_grad_launch(dy, y_gate, g_ctotal, g_coff, g_cmul, r.cout, n, hout * wout, grad + r.b, st);
+        BiasJob& b = bq[nwq - 1];
+        b.g = dy; b.gate = y_gate; b.db = grad + r.b; b.g_ctotal = g_ctotal; b.g_coff = g_coff; b.g_cmul = g_cmul;
+        b.cout = r.cout; b.n = n; b.hw = hout * wout;
+        return EEM_OK;
     }
     int flush_wgrads() {
         if (nwq == 0) return EEM_OK;
-        const int rc = tr_wgrad_launch_batch(wq, nwq, st);
+        int rc = tr_wgrad_launch_batch(wq, nwq, st);
+        if (rc == EEM_OK) rc = tr_bias_grad_launch_batch(bq, nwq, st);
         nwq = 0;
         return rc;
     }

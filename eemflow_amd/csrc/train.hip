@@ -264,6 +264,111 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradBatch batch) {
     }
 }
 
+// ---- the same GEMM for small feature maps (the 1/64-grid tail: 5x6 pixels at MVSEC size).  A 4x32-pixel tile of a 5x6 map is
+// 81 % padding and every block ends with one atomic per weight, so the tail's eight launches cost ~100 us each.  Here a
+// "tile" is `ipt` whole images (ipt * hout * wout <= 128 pixels): G is staged as [co][image, pixel], X as one zero-padded
+// plane per (channel, image), and the B-operand offset of a pixel comes from a 128-entry table in LDS.
+template <int K>
+__global__ __launch_bounds__(256) void wgrad_small_kernel(WgradBatch batch, int ipt) {
+    const WgradArgs& a = batch.job[blockIdx.z];
+    constexpr int KK = K * K, PADK = K / 2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // MT*32*WG_GP + cin_here*ipt*XR*XC floats + 128 ints
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int ci0 = blockIdx.y * WG_CI;
+    if (ci0 >= a.cin) return;
+    const int cin_here = min(WG_CI, a.cin - ci0);
+    const int MT = (a.cout + 31) >> 5;
+    const int NT = (cin_here * KK + 31) >> 5;
+    const int XR = a.hin + 2 * PADK, XC = a.win + 2 * PADK, PL = XR * XC;
+    const int hw = a.hout * a.wout;
+    float* Gs = lds;
+    float* Xs = lds + MT * 32 * WG_GP;
+    int* xtab = reinterpret_cast<int*>(Xs + cin_here * ipt * PL);
+    if (threadIdx.x < WG_PX) {
+        const int p = threadIdx.x, img = p / hw, q = p - img * hw;
+        const int y = q / a.wout, x = q - y * a.wout;
+        xtab[p] = img < ipt ? img * PL + y * XC + x : 0;            // pixels past ipt*hw carry G = 0
+    }
+    int tmt[WG_MAXT], boff[WG_MAXT];
+    bool tok[WG_MAXT];
+    int ntile = 0;
+#pragma unroll
+    for (int i = 0; i < WG_MAXT; ++i) {
+        const int t = wave + i * 4;
+        tok[i] = t < MT * NT;
+        const int mt = tok[i] ? t / NT : 0, nt = tok[i] ? t - mt * NT : 0;
+        tmt[i] = mt;
+        const int nidx = nt * 32 + j;
+        const int ci_l = nidx / KK, tap = nidx - ci_l * KK;
+        const bool nv = nidx < cin_here * KK;
+        boff[i] = nv ? ci_l * ipt * PL + (tap / K) * XC + (tap % K) : 0;
+        if (tok[i]) ntile = i + 1;
+    }
+    f32x16 acc[WG_MAXT];
+#pragma unroll
+    for (int i = 0; i < WG_MAXT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    const int total = (a.n + ipt - 1) / ipt;
+    const size_t xhw = (size_t)a.hin * a.win;
+    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        const int n0 = tile * ipt;
+        __syncthreads();
+#pragma unroll 4
+        for (int e = threadIdx.x; e < MT * 32 * WG_PX; e += 256) {
+            const int co = e / WG_PX, p = e - co * WG_PX;
+            const int img = p / hw, q = p - img * hw;
+            const bool ok = co < a.cout && img < ipt && n0 + img < a.n;
+            const int coc = min(co, a.cout - 1), nn = min(n0 + min(img, ipt - 1), a.n - 1);
+            const size_t o = ((size_t)nn * a.g_ctotal + a.g_coff + (size_t)coc * a.g_cmul) * hw + q;
+            float v = a.g[o];
+            if (a.gate) v *= a.gate[o] > 0.f ? 1.f : 0.1f;
+            Gs[co * WG_GP + p] = ok ? v : 0.f;
+        }
+#pragma unroll 4
+        for (int e = threadIdx.x; e < cin_here * ipt * PL; e += 256) {
+            const int ci_l = e / (ipt * PL), rem = e - ci_l * (ipt * PL);
+            const int img = rem / PL, r2 = rem - img * PL;
+            const int ry = r2 / XC, rx = r2 - ry * XC;
+            const int iy = ry - PADK, ix = rx - PADK;
+            const bool ok = iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win && n0 + img < a.n;
+            const int iyc = min(max(iy, 0), a.hin - 1), ixc = min(max(ix, 0), a.win - 1), nn = min(n0 + img, a.n - 1);
+            const float v = a.x[((size_t)nn * a.x_ctotal + a.x_coff + ci0 + ci_l) * xhw + (size_t)iyc * a.win + ixc];
+            Xs[e] = ok ? v : 0.f;
+        }
+        __syncthreads();
+        const int kend = min(WG_PX, ((ipt * hw + 1) & ~1));
+        for (int p = 0; p < kend; p += 2) {
+            const int pp = p + h;
+            const int xoff = xtab[pp];
+#pragma unroll
+            for (int i = 0; i < WG_MAXT; ++i) {
+                if (i < ntile) {
+                    const float av = Gs[(tmt[i] * 32 + j) * WG_GP + pp];
+                    const float bv = Xs[boff[i] + xoff];
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < WG_MAXT; ++i) {
+        if (!tok[i]) continue;
+        const int t = wave + i * 4;
+        const int mt = t / NT, nt = t - mt * NT;
+        const int nidx = nt * 32 + j;
+        if (nidx >= cin_here * KK) continue;
+        const int ci_l = nidx / KK, tap = nidx - ci_l * KK;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (co < a.cout) atomicAdd(&a.dw[((size_t)co * a.cin + ci0 + ci_l) * KK + tap], acc[i][r]);
+        }
+    }
+}
+
 // ---- clip_grad_norm_ + AdamW (train_mvsec.py:178-183,255-256): sum of squares, then the fused update
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, double* __restrict__ out) {
     __shared__ double sh[4];
@@ -382,6 +487,39 @@ int tr_wgrad_launch_batch(const WgradArgs* jobs, int njobs, hipStream_t st) {
         workers = w > workers ? w : workers;
         lds_bytes = lb > lds_bytes ? lb : lds_bytes;
         b.job[i] = a;
+    }
+    // small maps (stride 1, same shape in every job, >= 2 images per 128-pixel tile): whole images per tile
+    {
+        const WgradArgs& a0 = jobs[0];
+        const int hw0 = a0.hout * a0.wout;
+        bool small = a0.stride == 1 && hw0 * 2 <= WG_PX && a0.hin == a0.hout && a0.win == a0.wout;
+        for (int i = 1; i < njobs; ++i)
+            small = small && jobs[i].hout == a0.hout && jobs[i].wout == a0.wout && jobs[i].n == a0.n && jobs[i].hin == a0.hin &&
+                    jobs[i].win == a0.win;
+        if (small) {
+            const int ipt = WG_PX / hw0;
+            const int pl = (a0.hin + 2 * (a0.k / 2)) * (a0.win + 2 * (a0.k / 2));
+            size_t lb = 0;
+            for (int i = 0; i < njobs; ++i) {
+                const int mt = (jobs[i].cout + 31) / 32, ch = jobs[i].cin < WG_CI ? jobs[i].cin : WG_CI;
+                lb = std::max(lb, ((size_t)mt * 32 * WG_GP + (size_t)ch * ipt * pl + WG_PX) * sizeof(float));
+            }
+            if (lb <= 160 * 1024) {
+                const int tiles = (a0.n + ipt - 1) / ipt;
+                int w = 1024 / (nchunk * njobs);
+                w = w < 1 ? 1 : (w > tiles ? tiles : w);
+                static bool small_attr = false;
+                if (!small_attr) {
+                    EEM_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_small_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    EEM_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_small_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    small_attr = true;
+                }
+                if (a0.k == 3) hipLaunchKernelGGL((wgrad_small_kernel<3>), dim3(w, nchunk, njobs), dim3(256), lb, st, b, ipt);
+                else hipLaunchKernelGGL((wgrad_small_kernel<1>), dim3(w, nchunk, njobs), dim3(256), lb, st, b, ipt);
+                EEM_HIP_CHECK(hipGetLastError());
+                return EEM_OK;
+            }
+        }
     }
     dim3 grid(workers, nchunk, njobs);
     static bool attr_set = false;

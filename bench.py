@@ -287,7 +287,9 @@ def main():
         else:
             roof = {"bound": "hbm", "achieved": dom["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(dom["gbs"] / PEAK_HBM_GBS, 4)}
-        traffic = (load_traffic() or {}).get(dom["name"])
+        tr_all = load_traffic() or {}
+        same_shape = tr_all.get("_workload", {"height": 720, "width": 1280, "batch": 1}) == {"height": H, "width": W, "batch": B}
+        traffic = tr_all.get(dom["name"]) if same_shape else None        # PMC passes of another shape say nothing here
         # HBM bytes per launch of the dominant kernel from the PMC passes (profiles/pmc_traffic.json, tools/profile_gpu.sh)
         roof["traffic"] = traffic["hbm_bytes"] if isinstance(traffic, dict) and "hbm_bytes" in traffic else None
         roof["traffic_detail"] = traffic

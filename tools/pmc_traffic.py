@@ -47,6 +47,10 @@ def main():
             for n in names:
                 res[n] = {"hbm_bytes": round(hbm), "fetch_size_kb_raw": round(fetch[key], 1),
                           "write_size_kb_raw": round(write[key], 1), "fetch_correction": 2.0}
+    # the workload the passes were collected on (tools/profile_gpu.sh runs bench.py's default shape); bench.py only
+    # quotes these numbers when it runs that shape
+    res["_workload"] = {"height": int(sys.argv[3]) if len(sys.argv) > 3 else 720, "width": int(sys.argv[4]) if len(sys.argv) > 4 else 1280,
+                        "batch": int(sys.argv[5]) if len(sys.argv) > 5 else 1}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 

@@ -44,6 +44,63 @@ __global__ __launch_bounds__(256) void instnorm_kernel(const float* __restrict__
     }
 }
 
+// the same with the plane held in registers (1024 threads x up to NV float4): one read and one write of the plane
+// instead of three reads; mean first, then the variance around it, as above
+template <int NV>
+__global__ __launch_bounds__(1024) void instnorm_reg_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                            const float* __restrict__ res, int hw, int relu_inner) {
+    __shared__ float sh[16];
+    const f32x4* p = reinterpret_cast<const f32x4*>(x + (size_t)blockIdx.x * hw);
+    const int n4 = hw >> 2;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = k * 1024 + threadIdx.x;
+        v[k] = i < n4 ? p[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+    }
+    auto bsum = [&](float t) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) t += __shfl_xor(t, d);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = t;
+        __syncthreads();
+        float r = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) r += sh[k];
+        return r;
+    };
+    const float mean = bsum(s) / (float)hw;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (k * 1024 + (int)threadIdx.x < n4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[k][e] - mean; q += d * d; }
+        }
+    }
+    const float var = bsum(q) / (float)hw;
+    const float rstd = 1.f / sqrtf(var + 1e-5f);
+    f32x4* o = reinterpret_cast<f32x4*>(out + (size_t)blockIdx.x * hw);
+    const f32x4* r = res ? reinterpret_cast<const f32x4*>(res + (size_t)blockIdx.x * hw) : nullptr;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = k * 1024 + threadIdx.x;
+        if (i >= n4) continue;
+        f32x4 rv = r ? r[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = (v[k][e] - mean) * rstd;
+            if (relu_inner) t = t > 0.f ? t : 0.f;
+            if (r) { t += rv[e]; t = t > 0.f ? t : 0.f; }
+            w[e] = t;
+        }
+        o[i] = w;
+    }
+}
+
 // D[p1][p2] tiles of 64x64 per wave on v_mfma_f32_32x32x2_f32; both operands are read with unit stride along
 // the pixel index (A[i=p1][k=c] = f1[c][p1], B[k=c][j=p2] = f2[c][p2]) and each accumulator register is a
 // 128-B run of p2 for one p1 row.
@@ -216,7 +273,10 @@ int er_pad_launch(const float* in, float* out, int nc, int h, int w, int left, i
 }
 
 int er_instnorm_launch(const float* x, float* out, const float* res, int planes, int hw, int relu_inner, hipStream_t st) {
-    hipLaunchKernelGGL(instnorm_kernel, dim3(planes), dim3(256), 0, st, x, out, res, hw, relu_inner);
+    const bool al = (hw & 3) == 0 && (((uintptr_t)x | (uintptr_t)out | (uintptr_t)res) & 15) == 0;
+    if (al && hw <= 4 * 1024 * 5) hipLaunchKernelGGL(instnorm_reg_kernel<5>, dim3(planes), dim3(1024), 0, st, x, out, res, hw, relu_inner);
+    else if (al && hw <= 4 * 1024 * 20) hipLaunchKernelGGL(instnorm_reg_kernel<20>, dim3(planes), dim3(1024), 0, st, x, out, res, hw, relu_inner);
+    else hipLaunchKernelGGL(instnorm_kernel, dim3(planes), dim3(256), 0, st, x, out, res, hw, relu_inner);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

@@ -20,14 +20,18 @@ __device__ __forceinline__ float g_act(float v, int act) {
     }
 }
 
-template <int NPW, int MTW>
+// SPLITK (with NPW = MTW = 1): the block owns ONE 32-pixel x 32-cout tile and its four waves take the k-batches round
+// robin, meet in LDS and share the epilogue - for layers whose tile count leaves most SIMDs empty (E-RAFT's 60x80
+// update block at batch 1: 152 blocks of 4 single-tile waves for 256 CUs).
+template <int NPW, int MTW, bool SPLITK = false>
 __global__ __launch_bounds__(256) void gconv_kernel(GConvArgs a) {
+    static_assert(!SPLITK || (NPW == 1 && MTW == 1), "split-K is built for single-tile waves");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int n = blockIdx.z;
     const int cot0 = blockIdx.y * MTW;
     const int hwo = a.hout * a.wout, hwi = a.hin * a.win;
-    const int p0 = (blockIdx.x * 4 + wave) * (NPW * 32);
+    const int p0 = SPLITK ? blockIdx.x * 32 : (blockIdx.x * 4 + wave) * (NPW * 32);
     if (p0 >= hwo) return;
 
     int oy[NPW], ox[NPW];
@@ -62,14 +66,20 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvArgs a) {
     //    a small layer otherwise has one batch in flight, and each is a cold miss on the weights).
     constexpr int U = (NPW * MTW == 1) ? 16 : 8;
     struct Pos { int tap, s, cp0, ks; };                     // ks = k-step index of the batch's first pair
-    auto advance = [&](Pos q) {
+    const int ntaps = a.kh * a.kw;
+    auto advance1 = [&](Pos q) {
+        if (q.tap >= ntaps) return q;
         const int np = (a.seg[q.s].c + 1) >> 1;
         q.ks += min(U, np - q.cp0);
         q.cp0 += U;
         if (q.cp0 >= np) { q.cp0 = 0; if (++q.s == a.nseg) { q.s = 0; ++q.tap; } }
         return q;
     };
-    const int ntaps = a.kh * a.kw;
+    auto advance = [&](Pos q) {                              // to this wave's next batch
+        q = advance1(q);
+        if (SPLITK) { q = advance1(q); q = advance1(q); q = advance1(q); }
+        return q;
+    };
     auto load = [&](const Pos& q, float (&av)[U][MTW], float (&bv)[U][NPW]) {
         const int ty = q.tap / a.kw, tx = q.tap - ty * a.kw;
         int off[NPW];
@@ -147,8 +157,10 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvArgs a) {
     {
         float avA[U][MTW], bvA[U][NPW], avB[U][MTW], bvB[U][NPW];
         Pos cur = {0, 0, 0, 0};
-        load(cur, avA, bvA);
-        while (true) {
+        if (SPLITK)
+            for (int w = 0; w < wave; ++w) cur = advance1(cur);
+        if (cur.tap < ntaps) load(cur, avA, bvA);
+        while (cur.tap < ntaps) {
             const Pos nx = advance(cur);
             const bool more = nx.tap < ntaps;
             if (more) load(nx, avB, bvB);
@@ -167,6 +179,42 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvArgs a) {
     }
 
     // ---- epilogue
+    auto finish = [&](float v, int co, int p) {
+        if (a.scale) v *= a.scale[co];
+        if (a.shift) v += a.shift[co];
+        v = g_act(v, a.act);
+        if (a.epi == GEPI_MUL) {
+            v *= a.e0[((size_t)n * a.e0_ctotal + a.e0_coff + co) * hwo + p];
+        } else if (a.epi == GEPI_GRU) {
+            const float hh = a.e0[((size_t)n * a.e0_ctotal + a.e0_coff + co) * hwo + p];
+            const float z = a.e1[((size_t)n * a.e1_ctotal + a.e1_coff + co) * hwo + p];
+            v = (1.f - z) * hh + z * v;
+        } else if (a.epi == GEPI_ADD_RELU) {
+            v += a.e0[((size_t)n * a.e0_ctotal + a.e0_coff + co) * hwo + p];
+            v = v > 0.f ? v : 0.f;
+        } else if (a.epi == GEPI_ADD) {
+            v += a.e0[((size_t)n * a.e0_ctotal + a.e0_coff + co) * hwo + p];
+        }
+        const int oc = a.out_coff + co * (a.out_cmul > 1 ? a.out_cmul : 1);
+        a.out[((size_t)n * a.out_ctotal + oc) * hwo + p] = v * a.out_scale;
+    };
+    if (SPLITK) {
+        // [wave][register][lane]: every wave leaves its 16 partial sums, then wave w finishes registers 4w..4w+3
+        __shared__ float red[4][16][64];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[0][0][r];
+        __syncthreads();
+        const int p = p0 + j;
+        if (!pv[0]) return;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = wave * 4 + rr;
+            const float v = (red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane]);
+            const int co = cot0 * 32 + rr + 8 * wave + 4 * h;
+            if (co < a.cout) finish(v, co, p);
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < NPW; ++t) {
         if (!pv[t]) continue;
@@ -176,25 +224,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = (cot0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (co >= a.cout) continue;
-                float v = acc[t][m][r];
-                if (a.scale) v *= a.scale[co];
-                if (a.shift) v += a.shift[co];
-                v = g_act(v, a.act);
-                if (a.epi == GEPI_MUL) {
-                    v *= a.e0[((size_t)n * a.e0_ctotal + a.e0_coff + co) * hwo + p];
-                } else if (a.epi == GEPI_GRU) {
-                    const float hh = a.e0[((size_t)n * a.e0_ctotal + a.e0_coff + co) * hwo + p];
-                    const float z = a.e1[((size_t)n * a.e1_ctotal + a.e1_coff + co) * hwo + p];
-                    v = (1.f - z) * hh + z * v;
-                } else if (a.epi == GEPI_ADD_RELU) {
-                    v += a.e0[((size_t)n * a.e0_ctotal + a.e0_coff + co) * hwo + p];
-                    v = v > 0.f ? v : 0.f;
-                } else if (a.epi == GEPI_ADD) {
-                    v += a.e0[((size_t)n * a.e0_ctotal + a.e0_coff + co) * hwo + p];
-                }
-                const int oc = a.out_coff + co * (a.out_cmul > 1 ? a.out_cmul : 1);
-                a.out[((size_t)n * a.out_ctotal + oc) * hwo + p] = v * a.out_scale;
+                if (co < a.cout) finish(acc[t][m][r], co, p);
             }
     }
 }
@@ -242,8 +272,18 @@ int gconv_launch(const GConvArgs& a, hipStream_t stream) {
         dim3 grid(ceil_div(hwo, 256), cot, a.n);
         hipLaunchKernelGGL((gconv_kernel<2, 1>), grid, dim3(256), 0, stream, a);
     } else {
-        dim3 grid(ceil_div(hwo, 128), cot, a.n);
-        hipLaunchKernelGGL((gconv_kernel<1, 1>), grid, dim3(256), 0, stream, a);
+        int ksteps = 0;
+        for (int sgi = 0; sgi < a.nseg; ++sgi) ksteps += (a.seg[sgi].c + 1) / 2;
+        ksteps *= a.kh * a.kw;
+        static const bool no_splitk = [] { const char* e = getenv("EEM_NO_SPLITK"); return e && e[0] == '1'; }();
+        static const long splitk_max = [] { const char* e = getenv("EEM_SPLITK_MAX"); return e ? atol(e) : 512L; }();
+        if (!no_splitk && (long)ceil_div(hwo, 128) * cot * a.n < splitk_max && ksteps >= 128) {
+            dim3 grid(ceil_div(hwo, 32), cot, a.n);
+            hipLaunchKernelGGL((gconv_kernel<1, 1, true>), grid, dim3(256), 0, stream, a);
+        } else {
+            dim3 grid(ceil_div(hwo, 128), cot, a.n);
+            hipLaunchKernelGGL((gconv_kernel<1, 1>), grid, dim3(256), 0, stream, a);
+        }
     }
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;

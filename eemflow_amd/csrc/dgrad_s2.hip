@@ -95,7 +95,10 @@ __global__ __launch_bounds__(256) void dgrad_s2_kernel(DgradS2Args a, int tiles_
 
 #pragma unroll 1
     for (int it = 0; it < tr_.count; ++it) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // tile `it` must have landed.  With two stages its DMA was issued before the previous tile's 16*MT stores, which
+        // may stay in flight (vmcnt retires in order); with one stage the DMA is the youngest operation
+        if (NST == 2 && it > 0) wait_vmcnt<16 * MT>();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                         // tile `it` landed (first pass: the weights too)
         const float* sb = st0 + (NST == 2 ? (it & 1) : 0) * C::STAGE;
         if (NST == 2 && it + 1 < tr_.count) {
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256) void dgrad_s2_kernel(DgradS2Args a, int tiles_
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int iy = iy0 + 2 * (wave + 4 * t) + pr;
-                if (iy >= a.hin || !colok) continue;
+                const bool inside = iy < a.hin && colok;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -177,7 +180,8 @@ __global__ __launch_bounds__(256) void dgrad_s2_kernel(DgradS2Args a, int tiles_
                         f32x2 v = {acc[pr][0][t][mt][r] + pv[mt][r], acc[pr][1][t][mt][r] + pv[mt][r]};
                         v[0] *= gt[pr][t][mt][r][0] > 0.f ? 1.f : 0.1f;
                         v[1] *= gt[pr][t][mt][r][1] > 0.f ? 1.f : 0.1f;
-                        *reinterpret_cast<f32x2*>(dx + o) = v;
+                        float* q = inside ? dx + o : a.trash + lane * 2;            // uniform store count for the counted wait
+                        *reinterpret_cast<f32x2*>(q) = v;
                     }
             }
         tile_advance(cur, tiles_x, tiles_y);

@@ -46,6 +46,7 @@ struct DgradS2Args {
     const float* gate;     // forward tensor at dx's shape, or NULL
     const float* dpool;    // [n][cin][gh][gw] gradient of the k x k average pooling of the same tensor, or NULL
     const float* zero_page;
+    float* trash;          // >= 512 writable bytes: sink for the stores of out-of-image lanes
     int n, cin, cout, hin, win, hout, wout, pool_k, gh, gw;
 };
 bool dgrad_s2_supported(const DgradS2Args& a);

@@ -256,7 +256,7 @@ extern "C" int eemflow_forward_backward(eemflow_ctx* c, const float* e1, const f
             DgradS2Args d;
             d.dy = l.gy; d.w = c->flat + r.w; d.dx = l.gx; d.gate = l.x;
             d.dpool = c->g_pool[first ? 0 : 1].p; d.pool_k = first ? 32 : 16; d.gh = s.gh; d.gw = s.gw;
-            d.zero_page = c->zero_page;
+            d.zero_page = c->zero_page; d.trash = c->zero_page + 256;
             d.n = n2; d.cin = r.cin; d.cout = r.cout; d.hin = l.hin; d.win = l.win; d.hout = l.hout; d.wout = l.wout;
             if ((l.layer == ENC_2_1 || l.layer == ENC_3_1) && dgrad_s2_supported(d)) {
                 if ((rc = dgrad_s2_launch(d, st)) != EEM_OK) return rc;      // conv^T + pooling branch + gate in one kernel

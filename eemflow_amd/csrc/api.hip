@@ -412,7 +412,6 @@ extern "C" int eemflow_voxelize(const double* events, int64_t n, int bins, int h
         scratch = nullptr;
         scratch_cap = need + need / 4;
         EEM_HIP_CHECK(hipMalloc(&scratch, scratch_cap));
-        if (int rc0 = voxel_scratch_init(scratch, (hipStream_t)stream)) return rc0;
         if (scratch_dev != dev) { done = nullptr; EEM_HIP_CHECK(hipEventCreateWithFlags(&done, hipEventDisableTiming)); }
         scratch_dev = dev;
         last_stream = stream;

@@ -218,4 +218,3 @@ int repack_launch(const float* flat, const int* idx, float* arena, long n, hipSt
 int voxel_launch(const double* events, int64_t n, int bins, int h, int w, int normalize, float* grid,
                  int64_t* idx_left, int64_t* idx_right, void* scratch, hipStream_t stream);
 size_t voxel_scratch_bytes(int64_t n);
-int voxel_scratch_init(void* scratch, hipStream_t stream);

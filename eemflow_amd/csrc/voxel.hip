@@ -9,25 +9,27 @@
 // Events arrive time-sorted, so neighbouring lanes vote into unrelated voxels: two fp32 atomics per event
 // straight to HBM run at ~20 G atomics/s whatever the kernel does (0.2 ms for 2e6 events).  The default path
 // therefore bins first and adds in LDS:
-//   1. vox_count_kernel   every block histograms its chunk of events over `nb` bands of `band_px` consecutive
-//                         pixels (LDS atomics) and adds the histogram to the band totals;
-//   2. vox_bin_kernel     re-derives the votes, reserves each band's run with one atomic per (block, band) and
-//                         writes 16-byte vote records {pixel-in-band | bin << 16, left vote, right vote} there;
-//                         also the optional int64 index outputs (event order);
-//   3. vox_band_kernel    one block per band: the band's bins x band_px voxels live in LDS, the records are
-//                         added with ds_add_f32 and the band is written once (no memset of the grid).  For the
-//                         normalisation the block also leaves the f64 (count, sum, sum of squares) of its non-zero
-//                         voxels.  It re-arms the counters of 1 and 2;
-//   4. vox_norm_kernel    adds the band sums, mean / unbiased sd, rewrites the non-zero voxels.
-// HBM traffic: 2 x 32 B (events, twice) + 2 x 16 B (records) per event + 4 B (normalised: up to 12 B) per
-// voxel, instead of two scattered read-modify-writes per event and three further passes over the grid.
+//   1. vox_bin_kernel     every block of 1024 threads derives the votes of its chunk of events, histograms them over `nb`
+//                         bands of `band_px` consecutive pixels (LDS integer atomics, whose return value is the vote's rank
+//                         in its run), scans the histogram and writes 16-byte records {pixel-in-band | bin << 16, left
+//                         vote, right vote} sorted by band into ITS OWN slab, plus a row of run offsets: no global
+//                         atomics and no counting pass (an earlier version sized global runs first: +17 us and a second
+//                         read of the events); also the optional int64 index outputs (event order);
+//   2. vox_band_kernel    one block per band: it scans the run lengths of its band over all slabs, every thread finds the
+//                         run of its vote by binary search in LDS, and the band's bins x band_px voxels are accumulated
+//                         with ds_add_f32 and written once (no memset of the grid).  For the normalisation the block also
+//                         leaves the f64 (count, sum, sum of squares) of its non-zero voxels;
+//   3. vox_norm_kernel    adds the band sums, mean / unbiased sd, rewrites the non-zero voxels.
+// HBM traffic: 32 B (event) + 2 x 16 B (record) per event + 4 B (normalised: up to 12 B) per voxel, instead of two
+// scattered read-modify-writes per event and three further passes over the grid.
 // An event with x >= W lands in a neighbouring row exactly as the reference's flat index_add_ puts it; votes whose
 // flat pixel index x + y*W falls outside the image (the reference raises) are dropped on this path, the index
 // outputs still report them.
-// Grids too large for the LDS band layout (bins * H * W > 1024 * 40960 voxels, bins > 64, n >= 2^31) take the
-// direct atomic kernel.
+// Grids too large for the LDS band layout (bins * H * W > 1023 * 38400 voxels, bins > 64) and more than 33.5 M events
+// take the direct atomic kernel.
 #include "common.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
@@ -127,39 +129,16 @@ struct VoxPlan {
     unsigned hw;             // H * W
 };
 
-// ------------------------------------------------------------------------------------------------ 1. band histogram
-template <int EPT>
-__global__ __launch_bounds__(VT) void vox_count_kernel(const double* __restrict__ ev, long n, int bins, int h, int w,
-                                                       VoxPlan pl, unsigned* __restrict__ total) {
-    __shared__ unsigned hist[VT];
-    const int tid = threadIdx.x;
-    hist[tid] = 0;
-    __syncthreads();
-    const VoxTime tm = vox_time(ev, n);
-    const f64x2* e2 = reinterpret_cast<const f64x2*>(ev);
-#pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-        const long i = ((long)blockIdx.x * EPT + k) * VT + tid;
-        if (i < n) {
-            const f64x2 a = e2[i * 2], b = e2[i * 2 + 1];
-            const VoxVote v = vox_vote(a[0], a[1], b[0], b[1], tm, bins, h, w);
-            if (v.okl && v.pix >= 0 && v.pix < (long long)pl.hw) atomicAdd(&hist[(unsigned)v.pix / (unsigned)pl.band_px], 1u);
-        }
-    }
-    __syncthreads();
-    const unsigned c = hist[tid];
-    if (c) atomicAdd(&total[tid], c);
-}
-
-// ------------------------------------------------------------------------------------------------ 2. binning
+// ------------------------------------------------------------------------------------------------ 1. binning into slabs
+// Block `blk` owns the slab recs[blk * E .. (blk + 1) * E) (E = 1024 * EPT events per block): its votes, sorted by band, and
+// row `blk` of the run table: run_start[blk][b] = offset of band b's run inside the slab, run_start[blk][nb] = its end.
 template <int EPT>
 __global__ __launch_bounds__(VT) void vox_bin_kernel(const double* __restrict__ ev, long n, int bins, int h, int w,
-                                                     VoxPlan pl, const unsigned* __restrict__ total,
-                                                     unsigned* __restrict__ cursor, unsigned* __restrict__ base_out,
+                                                     VoxPlan pl, unsigned* __restrict__ run_start,
                                                      u32x4* __restrict__ recs, long long* __restrict__ idx_left,
                                                      long long* __restrict__ idx_right) {
     __shared__ unsigned hist[VT];
-    __shared__ unsigned gpos[VT];
+    __shared__ unsigned lpos[VT];
     __shared__ unsigned sh[VT / 64];
     const int tid = threadIdx.x;
     hist[tid] = 0;
@@ -183,17 +162,16 @@ __global__ __launch_bounds__(VT) void vox_bin_kernel(const double* __restrict__ 
                 key[k] = ((unsigned)v.pix - bd * (unsigned)pl.band_px) | ((unsigned)v.tl << 16);
                 vl[k] = v.vl;
                 vr[k] = v.vr;
-                rank[k] = atomicAdd(&hist[bd], 1u);
+                rank[k] = atomicAdd(&hist[bd], 1u);                // LDS: the returned count is the rank inside the run
             }
         }
     }
-    // start of every band's run: exclusive scan of the totals (redone by each block: nb <= 1024 words)
-    const unsigned tot = tid < pl.nb ? total[tid] : 0u;
-    const unsigned bstart = block_exscan(tot, sh);                 // contains a barrier: hist is complete after it
-    if (blockIdx.x == 0 && tid <= pl.nb) base_out[tid] = bstart;   // tid == nb: the number of records
-    const unsigned c = hist[tid];
-    if (c) gpos[tid] = bstart + atomicAdd(&cursor[tid], c);
     __syncthreads();
+    const unsigned start = block_exscan(hist[tid], sh);            // bands >= nb hold 0: thread nb gets the slab's fill
+    lpos[tid] = start;
+    if (tid <= pl.nb) run_start[(size_t)blockIdx.x * (pl.nb + 1) + tid] = start;
+    __syncthreads();
+    u32x4* slab = recs + (size_t)blockIdx.x * (VT * EPT);
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
         if (band[k] != 0xffffffffu) {
@@ -202,7 +180,7 @@ __global__ __launch_bounds__(VT) void vox_bin_kernel(const double* __restrict__ 
             r[1] = __float_as_uint(vl[k]);
             r[2] = __float_as_uint(vr[k]);
             r[3] = 0;
-            recs[gpos[band[k]] + rank[k]] = r;
+            slab[lpos[band[k]] + rank[k]] = r;
         }
     }
 }
@@ -230,28 +208,50 @@ __device__ __forceinline__ void vox_store_sums(double c, double s, double q, Vox
 }
 
 // ------------------------------------------------------------------------------------------------ 3. bands in LDS
-__global__ __launch_bounds__(VT) void vox_band_kernel(const u32x4* __restrict__ recs, const unsigned* __restrict__ base,
-                                                      int bins, VoxPlan pl, int vec4, float* __restrict__ grid,
-                                                      unsigned* __restrict__ total, unsigned* __restrict__ cursor,
-                                                      VoxSums* __restrict__ acc) {
+__global__ __launch_bounds__(VT) void vox_band_kernel(const u32x4* __restrict__ recs, const unsigned* __restrict__ run_start,
+                                                      int nblk, int slab, int bins, VoxPlan pl, int vec4,
+                                                      float* __restrict__ grid, VoxSums* __restrict__ acc) {
     extern __shared__ __attribute__((aligned(16))) float band[];   // [bins][band_px]
     __shared__ double sh3[VT / 64 * 3];
+    __shared__ unsigned pre[VT + 1];                               // exclusive prefix of the run lengths of <= 1024 slabs
+    __shared__ unsigned first[VT];                                 // record index of each run's first vote
+    __shared__ unsigned shs[VT / 64];
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     const int bpx = pl.band_px;
     const unsigned p0 = (unsigned)b * (unsigned)bpx;
     const int npx = min(bpx, (int)(pl.hw - p0));
     const int nfl = bins * bpx;
-    const unsigned lo = base[b], hi = base[b + 1];
-    if (tid == 0) { total[b] = 0; cursor[b] = 0; }                 // re-arm the counters for the next call
     for (int i = tid * 4; i < nfl; i += VT * 4) *reinterpret_cast<f32x4*>(band + i) = f32x4{0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
-    for (unsigned r = lo + tid; r < hi; r += VT) {
-        const u32x4 rec = recs[r];
-        const int tl = (int)(rec[0] >> 16);
-        float* cell = band + tl * bpx + (int)(rec[0] & 0xffffu);
-        atomicAdd(cell, __uint_as_float(rec[1]));
-        if (tl + 1 < bins) atomicAdd(cell + bpx, __uint_as_float(rec[2]));
+    for (int g0 = 0; g0 < nblk; g0 += VT) {
+        const int sidx = g0 + tid;
+        unsigned len = 0, start = 0;
+        if (sidx < nblk) {
+            const unsigned* row = run_start + (size_t)sidx * (pl.nb + 1) + b;
+            start = row[0];
+            len = row[1] - start;
+            start += (unsigned)sidx * (unsigned)slab;
+        }
+        __syncthreads();                                           // LDS zeroed / previous group consumed
+        const unsigned ex = block_exscan(len, shs);
+        pre[tid] = ex;
+        first[tid] = start;
+        if (tid == VT - 1) pre[VT] = ex + len;
+        __syncthreads();
+        const unsigned total = pre[VT];
+        const int nrun = min(VT, nblk - g0);
+        for (unsigned r = tid; r < total; r += VT) {
+            int lo = 0, hi = nrun;                                 // the run holding vote r: largest i with pre[i] <= r
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (pre[mid] <= r) lo = mid; else hi = mid;
+            }
+            const u32x4 rec = recs[first[lo] + (r - pre[lo])];
+            const int tl = (int)(rec[0] >> 16);
+            float* cell = band + tl * bpx + (int)(rec[0] & 0xffffu);
+            atomicAdd(cell, __uint_as_float(rec[1]));
+            if (tl + 1 < bins) atomicAdd(cell + bpx, __uint_as_float(rec[2]));
+        }
     }
     __syncthreads();
     if (acc) {                                                     // before the stores: the barrier inside would wait for them
@@ -340,31 +340,35 @@ __global__ __launch_bounds__(VT) void vox_moments_kernel(const float* __restrict
 }
 
 struct VoxScratch {
-    unsigned total[VT];
-    unsigned cursor[VT];
-    unsigned base[VT + 4];
     VoxSums acc[VT];
 };
 
+// blocks of the binning kernel for n events at EPT events per thread; the run table has (nb + 1) <= 1024 words per block
+inline long vox_blocks(long n, int ept) { return (n + (long)VT * ept - 1) / ((long)VT * ept); }
+inline int vox_ept(long n) {
+    int ept = 1;
+    while (ept < 8 && vox_blocks(n, ept) > 512) ept *= 2;
+    return ept;
+}
+constexpr long VOX_MAX_BLOCKS = 4096;                              // 33.5 M events at 8 per thread; beyond: direct kernel
+
 template <int EPT>
-void launch_count_bin(const double* events, long n, int bins, int h, int w, const VoxPlan& pl, VoxScratch* sc,
-                      u32x4* recs, long long* il, long long* ir, hipStream_t stream) {
-    const unsigned blocks = (unsigned)((n + (long)VT * EPT - 1) / ((long)VT * EPT));
-    hipLaunchKernelGGL((vox_count_kernel<EPT>), dim3(blocks), dim3(VT), 0, stream, events, n, bins, h, w, pl, sc->total);
-    hipLaunchKernelGGL((vox_bin_kernel<EPT>), dim3(blocks), dim3(VT), 0, stream, events, n, bins, h, w, pl, sc->total,
-                       sc->cursor, sc->base, recs, il, ir);
+void launch_bin(const double* events, long n, int bins, int h, int w, const VoxPlan& pl, unsigned* run_start, u32x4* recs,
+                long long* il, long long* ir, hipStream_t stream) {
+    hipLaunchKernelGGL((vox_bin_kernel<EPT>), dim3((unsigned)vox_blocks(n, EPT)), dim3(VT), 0, stream, events, n, bins, h, w, pl,
+                       run_start, recs, il, ir);
 }
 
 bool make_plan(int64_t n, int bins, int h, int w, const double* events, VoxPlan* pl, int* lds_bytes) {
     const long hw = (long)h * w;
-    if (bins > 64 || n >= (1LL << 31) || hw >= (1L << 31) || ((uintptr_t)events & 15)) return false;
+    if (bins > 64 || vox_blocks(n, 8) > VOX_MAX_BLOCKS || hw >= (1L << 31) || ((uintptr_t)events & 15)) return false;
     const char* e = getenv("EEM_VOX_DIRECT");
     if (e && e[0] == '1') return false;
     long band_px = (12288 / bins) & ~3L;                           // 48 KiB of LDS per band: 2-3 bands resident per CU
     const long spread = ((hw + 511) / 512 + 3) & ~3L;              // small images: still a few hundred bands
     if (band_px > spread) band_px = spread < 64 ? 64 : spread;
     if ((hw + band_px - 1) / band_px > VT - 1) band_px = ((hw + VT - 2) / (VT - 1) + 3) & ~3L;   // thread nb holds the record count
-    if (band_px * bins > 40960 || band_px > 65535) return false;   // 160 KiB of LDS, 16-bit pixel-in-band
+    if (band_px * bins > 38400 || band_px > 65535) return false;   // 150 KiB of LDS beside the static tables, 16-bit pixel-in-band
     pl->band_px = (int)band_px;
     pl->nb = (int)((hw + band_px - 1) / band_px);
     pl->hw = (unsigned)hw;
@@ -374,12 +378,12 @@ bool make_plan(int64_t n, int bins, int h, int w, const double* events, VoxPlan*
 
 }  // namespace
 
-size_t voxel_scratch_bytes(int64_t n) { return sizeof(VoxScratch) + (size_t)(n > 0 ? n : 0) * 16; }
-
-// once per allocation: the kernels leave the counters zeroed for the next call
-int voxel_scratch_init(void* scratch, hipStream_t stream) {
-    EEM_HIP_CHECK(hipMemsetAsync(scratch, 0, sizeof(VoxScratch), stream));
-    return EEM_OK;
+// sums + one 16-byte record slot per event (slabs are whole blocks: round up) + the run table
+size_t voxel_scratch_bytes(int64_t n) {
+    const long m = n > 0 ? (long)n : 0;
+    const long slots = (m + 8191) / 8192 * 8192 + 8192;
+    const long blocks = std::max(512L, std::min(VOX_MAX_BLOCKS, vox_blocks(m, 8) + 1));
+    return sizeof(VoxScratch) + (size_t)slots * 16 + (size_t)blocks * VT * sizeof(unsigned);
 }
 
 int voxel_launch(const double* events, int64_t n, int bins, int h, int w, int normalize, float* grid,
@@ -389,26 +393,27 @@ int voxel_launch(const double* events, int64_t n, int bins, int h, int w, int no
     EEM_REQUIRE(bins > 0 && h > 0 && w > 0, "voxelize: bad shape bins=%d h=%d w=%d", bins, h, w);
     const long total = (long)bins * h * w;
     VoxScratch* sc = (VoxScratch*)scratch;
-    u32x4* recs = reinterpret_cast<u32x4*>(sc + 1);
     VoxPlan pl;
     int lds = 0;
     int nsums = 0;
     if (make_plan(n, bins, h, w, events, &pl, &lds)) {
         static const int ept_env = [] { const char* e = getenv("EEM_VOX_EPT"); return e ? atoi(e) : 0; }();
         int ept = ept_env;
-        if (ept != 1 && ept != 2 && ept != 4 && ept != 8) {
-            ept = 1;
-            while (ept < 8 && (n + (long)VT * ept - 1) / ((long)VT * ept) > 512) ept *= 2;
-        }
+        if ((ept != 1 && ept != 2 && ept != 4 && ept != 8) || vox_blocks((long)n, ept) > std::max(512L, vox_blocks((long)n, 8) + 1))
+            ept = vox_ept((long)n);                                    // the run table is sized for these block counts
+        const long nblk = vox_blocks((long)n, ept);
+        const long slots = ((long)n + 8191) / 8192 * 8192 + 8192;
+        u32x4* recs = reinterpret_cast<u32x4*>(sc + 1);
+        unsigned* run_start = reinterpret_cast<unsigned*>(recs + slots);
         long long* il = (long long*)idx_left;
         long long* ir = (long long*)idx_right;
         switch (ept) {
-            case 1: launch_count_bin<1>(events, (long)n, bins, h, w, pl, sc, recs, il, ir, stream); break;
-            case 2: launch_count_bin<2>(events, (long)n, bins, h, w, pl, sc, recs, il, ir, stream); break;
-            case 4: launch_count_bin<4>(events, (long)n, bins, h, w, pl, sc, recs, il, ir, stream); break;
-            default: launch_count_bin<8>(events, (long)n, bins, h, w, pl, sc, recs, il, ir, stream); break;
+            case 1: launch_bin<1>(events, (long)n, bins, h, w, pl, run_start, recs, il, ir, stream); break;
+            case 2: launch_bin<2>(events, (long)n, bins, h, w, pl, run_start, recs, il, ir, stream); break;
+            case 4: launch_bin<4>(events, (long)n, bins, h, w, pl, run_start, recs, il, ir, stream); break;
+            default: launch_bin<8>(events, (long)n, bins, h, w, pl, run_start, recs, il, ir, stream); break;
         }
-        if (lds > 64 * 1024) {
+        if (lds > 64 * 1024 - 12 * 1024) {
             static thread_local int raised = 0;
             if (raised < lds) {
                 EEM_HIP_CHECK(hipFuncSetAttribute((const void*)vox_band_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -416,8 +421,8 @@ int voxel_launch(const double* events, int64_t n, int bins, int h, int w, int no
             }
         }
         const int vec4 = (pl.band_px % 4 == 0 && pl.hw % 4 == 0 && ((uintptr_t)grid & 15) == 0) ? 1 : 0;
-        hipLaunchKernelGGL(vox_band_kernel, dim3(pl.nb), dim3(VT), lds, stream, recs, sc->base, bins, pl, vec4, grid,
-                           sc->total, sc->cursor, normalize ? sc->acc : (VoxSums*)nullptr);
+        hipLaunchKernelGGL(vox_band_kernel, dim3(pl.nb), dim3(VT), lds, stream, recs, run_start, (int)nblk, VT * ept, bins, pl, vec4,
+                           grid, normalize ? sc->acc : (VoxSums*)nullptr);
         nsums = pl.nb;
     } else {
         EEM_HIP_CHECK(hipMemsetAsync(grid, 0, total * sizeof(float), stream));

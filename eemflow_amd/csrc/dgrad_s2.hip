@@ -216,8 +216,8 @@ int launch(const DgradS2Args& a, hipStream_t st) {
 }  // namespace
 
 bool dgrad_s2_supported(const DgradS2Args& a) {
-    static const bool off = [] { const char* e = getenv("EEM_NO_DGRAD_S2"); return e && e[0] == '1'; }();
-    if (off) return false;
+    const char* e = getenv("EEM_NO_DGRAD_S2");                      // read per call: a test flips it inside one process
+    if (e && e[0] == '1') return false;
     const bool shape = (a.cout == 32 && a.cin == 16) || (a.cout == 64 && a.cin == 32);
     return shape && a.zero_page && a.wout % 4 == 0 && a.win % 2 == 0 && a.hout == (a.hin + 1) / 2 && a.wout == (a.win + 1) / 2 &&
            ((uintptr_t)a.dy & 15) == 0 && ((uintptr_t)a.dx & 7) == 0 && (a.gate == nullptr || ((uintptr_t)a.gate & 7) == 0) &&

@@ -275,7 +275,8 @@ int gconv_launch(const GConvArgs& a, hipStream_t stream) {
         int ksteps = 0;
         for (int sgi = 0; sgi < a.nseg; ++sgi) ksteps += (a.seg[sgi].c + 1) / 2;
         ksteps *= a.kh * a.kw;
-        static const bool no_splitk = [] { const char* e = getenv("EEM_NO_SPLITK"); return e && e[0] == '1'; }();
+        const char* esk = getenv("EEM_NO_SPLITK");                   // read per call: a test flips it inside one process
+        const bool no_splitk = esk && esk[0] == '1';
         static const long splitk_max = [] { const char* e = getenv("EEM_SPLITK_MAX"); return e ? atol(e) : 512L; }();
         if (!no_splitk && (long)ceil_div(hwo, 128) * cot * a.n < splitk_max && ksteps >= 128) {
             dim3 grid(ceil_div(hwo, 32), cot, a.n);

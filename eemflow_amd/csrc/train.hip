@@ -492,7 +492,8 @@ int tr_wgrad_launch_batch(const WgradArgs* jobs, int njobs, hipStream_t st) {
     {
         const WgradArgs& a0 = jobs[0];
         const int hw0 = a0.hout * a0.wout;
-        bool small = a0.stride == 1 && hw0 * 2 <= WG_PX && a0.hin == a0.hout && a0.win == a0.wout;
+        const char* es = getenv("EEM_NO_WGRAD_SMALL");
+        bool small = !(es && es[0] == '1') && a0.stride == 1 && hw0 * 2 <= WG_PX && a0.hin == a0.hout && a0.win == a0.wout;
         for (int i = 1; i < njobs; ++i)
             small = small && jobs[i].hout == a0.hout && jobs[i].wout == a0.wout && jobs[i].n == a0.n && jobs[i].hin == a0.hin &&
                     jobs[i].win == a0.win;

@@ -248,8 +248,8 @@ int launch_tw(const WgradArgs& a, hipStream_t st) {
 }  // namespace
 
 bool wgrad_enc_supported(const WgradArgs& a) {
-    static const bool off = [] { const char* e = getenv("EEM_NO_WGRAD_ENC"); return e && e[0] == '1'; }();
-    if (off) return false;
+    const char* e = getenv("EEM_NO_WGRAD_ENC");                      // read per call: a test flips it inside one process
+    if (e && e[0] == '1') return false;
     return a.zero_page && a.gate == nullptr && a.k == 3 && a.pad == 1 && (a.stride == 1 || a.stride == 2) &&
            (a.cout == 16 || a.cout == 32 || a.cout == 64) && a.g_cmul == 1 && (a.cin <= 16 || a.cin % 16 == 0) &&
            a.wout % 4 == 0 && a.win % 4 == 0 && ((uintptr_t)a.g & 15) == 0 && ((uintptr_t)a.x & 15) == 0 &&

@@ -98,6 +98,20 @@ def test_forward_vs_oracle(b, h, w, iters):
     assert maxerr(torch.stack(preds), torch.stack(ref)) < FLOW_TOL
 
 
+def test_split_k_conv_launches_equal_plain_ones(monkeypatch):
+    """The split-K form of the generic conv (one tile per block, k-batches round robin over the waves; taken by the small
+    launches of the 1/8-resolution update block) against the plain form (EEM_NO_SPLITK=1, read at launch)."""
+    h, w = 480, 640
+    net, _ = make_net(21)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(22, 1, h, w))
+    with torch.no_grad():
+        fast = torch.stack(net(e1, e2, iters=3)[1]).clone()
+        monkeypatch.setenv("EEM_NO_SPLITK", "1")
+        plain = torch.stack(net(e1, e2, iters=3)[1])
+    assert maxerr(fast, plain) < 2e-4 and float(plain.abs().max()) > 1e-3
+
+
 def test_flow_init_and_twelve_iterations():
     h, w = 128, 128
     net, sd = make_net(19)

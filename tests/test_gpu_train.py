@@ -73,6 +73,27 @@ def test_gradients_vs_oracle_autograd(b, h, w, size):
     assert worst[0] < 3e-3, worst
 
 
+@pytest.mark.parametrize("b,h,w", [(2, 260, 346), (1, 720, 1280), (3, 200, 300)])
+def test_dedicated_backward_kernels_equal_generic_ones(monkeypatch, b, h, w):
+    """wgrad_enc / dgrad_s2 / wgrad_small against the generic conv and weight-gradient kernels of the same library
+    (EEM_NO_* are read at launch): every one of the 66 gradient tensors to summation-order round-off."""
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(41, b, h, w))
+    gt, valid = (torch.from_numpy(a) for a in synthetic_gt(42, b, h, w))
+
+    def run():
+        net, sd = make_net(43)
+        net.change_imagesize((h, w))
+        loss, _, flow, flat = run_grads(net, e1, e2, gt, valid)
+        return loss, flow, split_flat(flat, sd)
+    loss_f, flow_f, fast = run()
+    for k in ("EEM_NO_WGRAD_ENC", "EEM_NO_DGRAD_S2", "EEM_NO_WGRAD_SMALL"):
+        monkeypatch.setenv(k, "1")
+    loss_g, flow_g, gen = run()
+    assert abs(loss_f - loss_g) < 1e-9 and torch.equal(flow_f, flow_g)   # same forward code; the loss sums by f64 atomics
+    worst = max((rel_err(fast[k], gen[k]), k) for k in fast)
+    assert worst[0] < 2e-5, worst
+
+
 def test_three_optimizer_steps_vs_golden(golden):
     g = golden("train_step.npz")
     h, w = g["hw"].tolist()

@@ -117,6 +117,15 @@ def other_rows(dev):
                 net(e1, e2, iters=12)
             torch.cuda.synchronize(dev)
         out["eraft_640x480_12it_b1_frames_per_s"] = round(3 / (time.perf_counter() - t0), 2)
+        e1, e2 = (torch.from_numpy(a).to(dev) for a in synthetic_voxel_pair(1, 4, 480, 640))       # configs[4]: batch 4 per GPU
+        with torch.no_grad():
+            net(e1, e2, iters=12)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                net(e1, e2, iters=12)
+            torch.cuda.synchronize(dev)
+        out["eraft_640x480_12it_b4_frames_per_s"] = round(12 / (time.perf_counter() - t0), 2)
         del net
     except Exception as e:                                   # noqa: BLE001
         out["eraft_error"] = repr(e)[:200]

@@ -26,8 +26,8 @@ int ensure(Buf& b, size_t floats) {
 }
 
 struct Layer {                    // one convolution, weights packed for gconv
-    size_t wpk = 0, scale = 0, shift = 0;
-    bool has_scale = false;
+    size_t wpk = 0, wpk16 = 0, scale = 0, shift = 0;
+    bool has_scale = false, has16 = false;
     int cout = 0, kh = 1, kw = 1, stride = 1, ph = 0, pw = 0;
     int cs[3] = {0, 0, 0}, nseg = 1;
 };
@@ -50,6 +50,7 @@ struct eraft_ctx {
     bool loaded = false;
     int cin0 = 5;
     float* arena = nullptr;
+    size_t zero_off = 0;           // 64 zero floats inside the arena (LDS-DMA source for padding)
     Encoder fnet, cnet;
     Layer convc1, convc2, convf1, convf2, conv, gz[2], gr[2], gq[2], fh1, fh2, mk0, mk2;
     // workspace
@@ -90,6 +91,11 @@ void make_layer(Packer& pk, Layer& L, const float* w, const float* bias, int cou
     const float* wsl = w + (size_t)co0 * cin * kh * kw;
     L.wpk = pk.push(gconv_packed_floats(con, cs, nseg, kh, kw));
     gconv_pack(wsl, con, cs, nseg, kh, kw, pk.host.data() + L.wpk);
+    L.has16 = gconv16_shape(con, cs, nseg, kh, kw, stride) && ph == kh / 2 && pw == kw / 2;
+    if (L.has16) {
+        L.wpk16 = pk.push(gconv16_packed_floats(con, cs, nseg, kh, kw));
+        gconv16_pack(wsl, con, cs, nseg, kh, kw, pk.host.data() + L.wpk16);
+    }
     L.shift = pk.push(con);
     if (bn) {
         L.has_scale = true;
@@ -159,6 +165,8 @@ GConvArgs conv_args(const eraft_ctx* c, const Layer& L, int n, int hin, int win,
     memset(&a, 0, sizeof(a));
     a.nseg = L.nseg;
     a.wpk = c->arena + L.wpk;
+    a.wpk16 = L.has16 ? c->arena + L.wpk16 : nullptr;
+    a.zero_page = c->arena + c->zero_off;
     a.scale = L.has_scale ? c->arena + L.scale : nullptr;
     a.shift = c->arena + L.shift;
     a.out = out; a.out_ctotal = out_ctotal; a.out_coff = out_coff;
@@ -279,6 +287,7 @@ extern "C" int eraft_load_weights(eraft_ctx* c, const float* flat, size_t nfloat
     EEM_HIP_CHECK(hipSetDevice(c->device));
     Cursor cur{flat, flat + nfloats};
     Packer pk;
+    c->zero_off = pk.push(64);
     parse_encoder(cur, pk, c->fnet, false, n_first_channels, 256, false);
     parse_encoder(cur, pk, c->cnet, true, n_first_channels, 256, true);
     auto plain = [&](Layer& L, int cout, const int* cs, int nseg, int kh, int kw, int ph, int pw) {

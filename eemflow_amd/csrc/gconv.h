@@ -25,6 +25,8 @@ struct GConvArgs {
     GConvSeg seg[3];
     int nseg;
     const float* wpk;      // packed by gconv_pack
+    const float* wpk16;    // packed by gconv16_pack (stride-1 layers with 16-aligned channel counts), or NULL
+    const float* zero_page;// >= 16 zero bytes on the device (LDS-DMA source of out-of-image pieces); needed with wpk16
     const float* scale;    // [cout] or NULL (= 1)
     const float* shift;    // [cout] or NULL (= 0)
     float* out;            // [N][out_ctotal][hout][wout], channel co goes to out_coff + co
@@ -44,3 +46,9 @@ struct GConvArgs {
 size_t gconv_packed_floats(int cout, const int* cs, int nseg, int kh, int kw);
 void gconv_pack(const float* w, int cout, const int* cs, int nseg, int kh, int kw, float* packed);
 int gconv_launch(const GConvArgs& a, hipStream_t stream);
+// LDS-tiled 16x16x4 path (gconv16.hip); gconv_launch takes it when a.wpk16 is set and the launch qualifies
+bool gconv16_shape(int cout, const int* cs, int nseg, int kh, int kw, int stride);
+size_t gconv16_packed_floats(int cout, const int* cs, int nseg, int kh, int kw);
+void gconv16_pack(const float* w, int cout, const int* cs, int nseg, int kh, int kw, float* packed);
+bool gconv16_supported(const GConvArgs& a);
+int gconv16_launch(const GConvArgs& a, hipStream_t stream);

@@ -261,6 +261,7 @@ void gconv_pack(const float* w, int cout, const int* cs, int nseg, int kh, int k
 
 int gconv_launch(const GConvArgs& a, hipStream_t stream) {
     EEM_REQUIRE(a.nseg >= 1 && a.nseg <= 3 && a.n >= 1 && a.cout >= 1, "gconv_launch: bad arguments");
+    if (gconv16_supported(a)) return gconv16_launch(a, stream);
     const int hwo = a.hout * a.wout;
     const int cot = ceil_div(a.cout, 32);
     // big problems: 2x2 tiles per wave (half the operand traffic per MFMA); small ones: 1x1 for parallelism

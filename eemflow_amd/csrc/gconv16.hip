@@ -1,0 +1,241 @@
+// Stride-1 convolutions with 16-channel-aligned inputs (E-RAFT's update block and residual stacks, EEMFlow+'s decoders:
+// 1x1, 3x3, 1x5, 5x1 kernels, 64..384 -> 64..576 channels, inputs that are the concatenation of up to three tensors) as an
+// LDS-tiled implicit GEMM on v_mfma_f32_16x16x4_f32.  The generic kernel of gconv.hip reads both operands of every MFMA
+// straight from L2 (two 256-byte loads per MFMA, 44 TFLOP/s at best); here
+//   * a block = 4 waves = one 64-cout chunk x a 4x16-pixel tile; wave w owns the 16 couts of M-tile w and all four pixel rows
+//     (N-tiles), so every weight fragment feeds four MFMAs and every input fragment is read once per wave from LDS;
+//   * the input is consumed in chunks of 16 channels: the chunk's haloed tile [16][4 + KH - 1][24] (columns x0 - 4 .. x0 + 19)
+//     goes HBM/L2 -> LDS by 16-byte LDS-DMA, double-buffered, out-of-image pieces from a zero page; the plane pitch is padded to
+//     16 mod 32 floats so the four channel lanes of a k-step fall on different bank halves;
+//   * the chunk's weight fragments (taps x 4 k-steps) are loaded into registers from a stream packed in fragment order
+//     (256 bytes per wave and k-step, the four waves' fragments adjacent) one chunk ahead of their use;
+//   * one barrier per chunk; epilogue as gconv's (scale/shift, activation, GRU / residual combinations).
+#include "gconv.h"
+
+namespace {
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+__device__ __forceinline__ float g16_act(float v, int act) {
+    switch (act) {
+        case GACT_RELU: return v > 0.f ? v : 0.f;
+        case GACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        case GACT_TANH: return tanhf(v);
+        case GACT_LEAKY: return v > 0.f ? v : 0.1f * v;
+        default: return v;
+    }
+}
+
+template <int KH, int KW>
+struct G16Cfg {
+    static constexpr int TH = 4, TW = 16;
+    static constexpr int ROWS = TH + KH - 1;
+    static constexpr int COLS = 24;                              // x0 - 4 .. x0 + 19
+    static constexpr int PL0 = ROWS * COLS;
+    static constexpr int PL = PL0 % 32 == 16 ? PL0 : PL0 + ((48 - PL0 % 32) % 32);   // plane pitch = 16 mod 32 floats
+    static constexpr int PQ = PL / 4;                            // 16-byte slots per plane (ROWS * 6 real ones)
+    static constexpr int SLOTS = 16 * PQ;
+    static constexpr int NI = (SLOTS + 255) / 256;               // DMA instructions per wave and chunk
+    static constexpr int STAGE = NI * 256 * 4;                   // floats
+    static constexpr int TAPS = KH * KW;
+    static constexpr int KS = TAPS * 4;                          // k-steps (weight fragments) per chunk
+    static_assert(PL % 4 == 0 && PL % 32 == 16, "plane pitch");
+};
+
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void gconv16_kernel(GConvArgs a, const float* __restrict__ wpk16, const float* __restrict__ zero_page,
+                                                      int tiles_x, int nchunks) {
+    using C = G16Cfg<KH, KW>;
+    __shared__ __attribute__((aligned(16))) float lds[2 * C::STAGE];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int n = blockIdx.z, cc = blockIdx.y;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int y0 = ty * C::TH, x0 = tx * C::TW;
+    const int hw = a.hin * a.win;                                // stride 1, "same" padding: output extent = input extent
+    constexpr int PH = KH / 2, PW = KW / 2;
+
+    // ---- DMA plan: slot f -> (channel, row, 16-byte piece) of the chunk's tile
+    int off[C::NI];
+#pragma unroll
+    for (int k = 0; k < C::NI; ++k) {
+        const int f = (wave + 4 * k) * 64 + lane;
+        const int ci = f / C::PQ, q = f - ci * C::PQ;
+        const int row = q / 6, pc = q - row * 6;
+        const bool ok = f < C::SLOTS && q < C::ROWS * 6;
+        const int gy = y0 - PH + row, gx = x0 - 4 + 4 * pc;
+        const bool in = ok && gy >= 0 && gy < a.hin && gx >= 0 && gx + 4 <= a.win;
+        off[k] = in ? (int)(((size_t)ci * hw + (size_t)gy * a.win + gx) * 4) : -1;
+    }
+    const char* zero = reinterpret_cast<const char*>(zero_page);
+    // chunk index -> (segment, first channel)
+    auto chunk_base = [&](int ch) -> const char* {
+        int s = 0, c0 = ch * 16;
+        while (s + 1 < a.nseg && c0 >= a.seg[s].c) { c0 -= a.seg[s].c; ++s; }
+        const GConvSeg& sg = a.seg[s];
+        return reinterpret_cast<const char*>(sg.ptr + ((size_t)n * sg.ctotal + sg.coff + c0) * hw);
+    };
+    auto issue = [&](int stage, int ch) {
+        const char* xb = chunk_base(ch);
+        float* sb = lds + stage * C::STAGE;
+#pragma unroll
+        for (int k = 0; k < C::NI; ++k) {
+            const char* p = off[k] >= 0 ? xb + off[k] : zero;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(p), LDS_PTR(sb + (wave + 4 * k) * 256), 16, 0, 0);
+        }
+    };
+    // weight fragments of chunk `ch` for this wave's M-tile: stream[((cc * nchunks + ch) * KS + ks) * 4 + wave][lane]
+    auto load_w = [&](int ch, float (&wr)[C::KS]) {
+        const float* wp = wpk16 + (((size_t)cc * nchunks + ch) * C::KS * 4 + wave) * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) wr[ks] = wp[(size_t)ks * 256];
+    };
+
+    f32x4 acc[C::TH];
+#pragma unroll
+    for (int t = 0; t < C::TH; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int bbase = g * C::PL + j + 4 - PW;                    // B fragment: channel g of a group, pixel column j
+
+    float wA[C::KS], wB[C::KS];
+    issue(0, 0);
+    load_w(0, wA);
+    auto compute = [&](const float* sb, const float (&wr)[C::KS]) {
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg) {
+                    float bv[C::TH];
+#pragma unroll
+                    for (int t = 0; t < C::TH; ++t) bv[t] = sb[bbase + cg * 4 * C::PL + (t + ky) * C::COLS + kx];
+#pragma unroll
+                    for (int t = 0; t < C::TH; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[((ky * KW + kx) * 4) + cg], bv[t], acc[t], 0, 0, 0);
+                }
+    };
+#pragma unroll 1
+    for (int ch = 0; ch < nchunks; ch += 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (ch + 1 < nchunks) { issue(1, ch + 1); load_w(ch + 1, wB); }
+        __builtin_amdgcn_sched_barrier(0);
+        compute(lds, wA);
+        if (ch + 1 >= nchunks) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (ch + 2 < nchunks) { issue(0, ch + 2); load_w(ch + 2, wA); }
+        __builtin_amdgcn_sched_barrier(0);
+        compute(lds + C::STAGE, wB);
+    }
+
+    // ---- epilogue: D[cout 4g + r][pixel j]
+    const int x = x0 + j;
+    if (x >= a.wout) return;
+#pragma unroll
+    for (int t = 0; t < C::TH; ++t) {
+        const int y = y0 + t;
+        if (y >= a.hout) continue;
+        const int p = y * a.wout + x;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = cc * 64 + wave * 16 + 4 * g + r;
+            if (co >= a.cout) continue;
+            float v = acc[t][r];
+            if (a.scale) v *= a.scale[co];
+            if (a.shift) v += a.shift[co];
+            v = g16_act(v, a.act);
+            if (a.epi == GEPI_MUL) {
+                v *= a.e0[((size_t)n * a.e0_ctotal + a.e0_coff + co) * hw + p];
+            } else if (a.epi == GEPI_GRU) {
+                const float hh = a.e0[((size_t)n * a.e0_ctotal + a.e0_coff + co) * hw + p];
+                const float z = a.e1[((size_t)n * a.e1_ctotal + a.e1_coff + co) * hw + p];
+                v = (1.f - z) * hh + z * v;
+            } else if (a.epi == GEPI_ADD_RELU) {
+                v += a.e0[((size_t)n * a.e0_ctotal + a.e0_coff + co) * hw + p];
+                v = v > 0.f ? v : 0.f;
+            } else if (a.epi == GEPI_ADD) {
+                v += a.e0[((size_t)n * a.e0_ctotal + a.e0_coff + co) * hw + p];
+            }
+            const int oc = a.out_coff + co * (a.out_cmul > 1 ? a.out_cmul : 1);
+            a.out[((size_t)n * a.out_ctotal + oc) * hw + p] = v * a.out_scale;
+        }
+    }
+}
+
+template <int KH, int KW>
+int launch(const GConvArgs& a, const float* wpk16, const float* zero_page, hipStream_t stream) {
+    using C = G16Cfg<KH, KW>;
+    int cin = 0;
+    for (int s = 0; s < a.nseg; ++s) cin += a.seg[s].c;
+    const int tiles_x = ceil_div(a.wout, C::TW), tiles_y = ceil_div(a.hout, C::TH);
+    dim3 grid(tiles_x * tiles_y, ceil_div(a.cout, 64), a.n);
+    hipLaunchKernelGGL((gconv16_kernel<KH, KW>), grid, dim3(256), 0, stream, a, wpk16, zero_page, tiles_x, cin / 16);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+}  // namespace
+
+bool gconv16_shape(int cout, const int* cs, int nseg, int kh, int kw, int stride) {
+    if (stride != 1 || cout < 16) return false;
+    if (!((kh == 1 && kw == 1) || (kh == 3 && kw == 3) || (kh == 1 && kw == 5) || (kh == 5 && kw == 1))) return false;
+    for (int s = 0; s < nseg; ++s)
+        if (cs[s] <= 0 || cs[s] % 16) return false;
+    return true;
+}
+
+size_t gconv16_packed_floats(int cout, const int* cs, int nseg, int kh, int kw) {
+    int cin = 0;
+    for (int s = 0; s < nseg; ++s) cin += cs[s];
+    return (size_t)ceil_div(cout, 64) * (cin / 16) * kh * kw * 4 * 4 * 64;
+}
+
+// stream[(((cc * nchunks + ch) * taps + tap) * 4 + cg) * 4 + mt][lane] = W[cc*64 + mt*16 + lane%16][ch*16 + 4*cg + lane/16][tap]
+void gconv16_pack(const float* w, int cout, const int* cs, int nseg, int kh, int kw, float* packed) {
+    int cin = 0;
+    for (int s = 0; s < nseg; ++s) cin += cs[s];
+    const int taps = kh * kw, nch = cin / 16;
+    for (int cc = 0; cc < ceil_div(cout, 64); ++cc)
+        for (int ch = 0; ch < nch; ++ch)
+            for (int tap = 0; tap < taps; ++tap)
+                for (int cg = 0; cg < 4; ++cg)
+                    for (int mt = 0; mt < 4; ++mt)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int co = cc * 64 + mt * 16 + (lane & 15), c = ch * 16 + 4 * cg + (lane >> 4);
+                            packed[((((((size_t)cc * nch + ch) * taps + tap) * 4 + cg) * 4 + mt) * 64) + lane] =
+                                co < cout ? w[((size_t)co * cin + c) * taps + tap] : 0.f;
+                        }
+}
+
+bool gconv16_supported(const GConvArgs& a) {
+    const char* e = getenv("EEM_NO_GCONV16");                    // read per call: a test flips it inside one process
+    if (e && e[0] == '1') return false;
+    if (!a.wpk16 || !a.zero_page || a.tstride > 1 || a.pad_h != a.kh / 2 || a.pad_w != a.kw / 2) return false;
+    int cs[3];
+    for (int s = 0; s < a.nseg; ++s) {
+        cs[s] = a.seg[s].c;
+        if (a.seg[s].cmul > 1 || a.seg[s].gate || ((uintptr_t)a.seg[s].ptr & 15)) return false;
+    }
+    int cin = 0;
+    for (int s = 0; s < a.nseg; ++s) cin += cs[s];
+    // measured on E-RAFT (640x480, batch 1 / 4) and EEMFlow+ (1280x720): shallow inputs and launches of a few dozen blocks
+    // stay on the generic kernel's split-K form
+    static const int min_cin = [] { const char* m = getenv("EEM_G16_MINCIN"); return m ? atoi(m) : 64; }();
+    static const long min_blk = [] { const char* m = getenv("EEM_G16_MINBLK"); return m ? atol(m) : 128L; }();
+    const long blocks = (long)ceil_div(a.wout, 16) * ceil_div(a.hout, 4) * ceil_div(a.cout, 64) * a.n;
+    if (cin < min_cin || blocks < min_blk) return false;
+    return gconv16_shape(a.cout, cs, a.nseg, a.kh, a.kw, a.stride) && a.win % 4 == 0 && a.hout == a.hin && a.wout == a.win &&
+           (size_t)16 * a.hin * a.win * 4 < (1u << 31);
+}
+
+int gconv16_launch(const GConvArgs& a, hipStream_t stream) {
+    if (a.kh == 1 && a.kw == 1) return launch<1, 1>(a, a.wpk16, a.zero_page, stream);
+    if (a.kh == 3) return launch<3, 3>(a, a.wpk16, a.zero_page, stream);
+    if (a.kh == 1) return launch<1, 5>(a, a.wpk16, a.zero_page, stream);
+    return launch<5, 1>(a, a.wpk16, a.zero_page, stream);
+}

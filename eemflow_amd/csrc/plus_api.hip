@@ -24,7 +24,7 @@ int pensure(PBuf& b, size_t floats) {
     return EEM_OK;
 }
 
-struct PLayer { size_t wpk = 0, bias = 0; int cin = 0, cout = 0, k = 3, stride = 1; };
+struct PLayer { size_t wpk = 0, wpk16 = 0, bias = 0; bool has16 = false; int cin = 0, cout = 0, k = 3, stride = 1; };
 
 const int kTaps[53] = {0,  2,  4,  6,  8,  10, 12, 14, 16, 18, 20, 21, 22, 23, 24, 26, 28, 29, 30, 31, 32, 33, 34, 36, 38, 39, 40,
                        41, 42, 44, 46, 47, 48, 49, 50, 51, 52, 54, 56, 57, 58, 59, 60, 62, 64, 66, 68, 70, 72, 74, 76, 78, 80};
@@ -36,6 +36,7 @@ struct eemplus_ctx {
     int device = 0, cin0 = 15, groups = 3;
     bool loaded = false;
     float* arena = nullptr;
+    size_t zero_off = 0;           // 64 zero floats inside the arena (LDS-DMA source for padding)
     int* taps = nullptr;
     PLayer enc[8], rconv[7], dec1[7], decg[7][3][3], dec5[7], dec6[7], dec7[7], de[6], c1x1[6];
     PBuf padded, f[7], a2, dense, xout, fi, tw, fup[7], fw, cat, d[4], t64, t32, flow[7];
@@ -56,6 +57,11 @@ void mk(Pk& pk, PLayer& L, const float* w, const float* b, int cin, int cout, in
     const int cs[1] = {cin};
     L.wpk = pk.push(gconv_packed_floats(cout, cs, 1, k, k));
     gconv_pack(w, cout, cs, 1, k, k, pk.host.data() + L.wpk);
+    L.has16 = gconv16_shape(cout, cs, 1, k, k, stride);
+    if (L.has16) {
+        L.wpk16 = pk.push(gconv16_packed_floats(cout, cs, 1, k, k));
+        gconv16_pack(w, cout, cs, 1, k, k, pk.host.data() + L.wpk16);
+    }
     L.bias = pk.push(cout);
     memcpy(pk.host.data() + L.bias, b, cout * sizeof(float));
 }
@@ -67,6 +73,8 @@ int conv(eemplus_ctx* c, const PLayer& L, const float* in, int in_ctotal, int in
     a.nseg = 1;
     a.seg[0].ptr = in; a.seg[0].c = L.cin; a.seg[0].ctotal = in_ctotal; a.seg[0].coff = in_coff;
     a.wpk = c->arena + L.wpk; a.shift = c->arena + L.bias;
+    a.wpk16 = L.has16 ? c->arena + L.wpk16 : nullptr;
+    a.zero_page = c->arena + c->zero_off;
     a.out = out; a.out_ctotal = out_ctotal; a.out_coff = out_coff; a.out_cmul = out_cmul;
     const int pad = (L.k - 1) / 2;
     a.n = n; a.hin = hin; a.win = win; a.hout = (hin + 2 * pad - L.k) / L.stride + 1; a.wout = (win + 2 * pad - L.k) / L.stride + 1;
@@ -142,6 +150,7 @@ extern "C" int eemplus_load_weights(eemplus_ctx* c, const float* flat, size_t nf
     EEM_HIP_CHECK(hipSetDevice(c->device));
     Cur cur{flat, flat + nfloats};
     Pk pk;
+    c->zero_off = pk.push(64);
     auto layer = [&](PLayer& L, int cin, int cout, int k, int stride) {
         const float* w = cur.take((size_t)cout * cin * k * k);
         const float* b = cur.take(cout);

@@ -112,6 +112,20 @@ def test_split_k_conv_launches_equal_plain_ones(monkeypatch):
     assert maxerr(fast, plain) < 2e-4 and float(plain.abs().max()) > 1e-3
 
 
+def test_lds_tiled_conv_equals_generic_conv(monkeypatch):
+    """gconv16 (LDS-tiled 16x16x4 path of the stride-1, 16-aligned convs) against the generic kernel (EEM_NO_GCONV16=1, read
+    at launch) through a whole forward at batch 2: same flow to fp32 summation-order round-off."""
+    h, w = 480, 640
+    net, _ = make_net(27)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(28, 2, h, w))
+    with torch.no_grad():
+        fast = torch.stack(net(e1, e2, iters=3)[1]).clone()
+        monkeypatch.setenv("EEM_NO_GCONV16", "1")
+        plain = torch.stack(net(e1, e2, iters=3)[1])
+    assert maxerr(fast, plain) < 2e-4 and float(plain.abs().max()) > 1e-3
+
+
 def test_flow_init_and_twelve_iterations():
     h, w = 128, 128
     net, sd = make_net(19)

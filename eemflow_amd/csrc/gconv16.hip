@@ -27,9 +27,9 @@ __device__ __forceinline__ float g16_act(float v, int act) {
     }
 }
 
-template <int KH, int KW>
+template <int KH, int KW, int THT>
 struct G16Cfg {
-    static constexpr int TH = 4, TW = 16;
+    static constexpr int TH = THT, TW = 16;
     static constexpr int ROWS = TH + KH - 1;
     static constexpr int COLS = 24;                              // x0 - 4 .. x0 + 19
     static constexpr int PL0 = ROWS * COLS;
@@ -43,10 +43,10 @@ struct G16Cfg {
     static_assert(PL % 4 == 0 && PL % 32 == 16, "plane pitch");
 };
 
-template <int KH, int KW>
+template <int KH, int KW, int THT>
 __global__ __launch_bounds__(256) void gconv16_kernel(GConvArgs a, const float* __restrict__ wpk16, const float* __restrict__ zero_page,
                                                       int tiles_x, int nchunks) {
-    using C = G16Cfg<KH, KW>;
+    using C = G16Cfg<KH, KW, THT>;
     __shared__ __attribute__((aligned(16))) float lds[2 * C::STAGE];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -70,12 +70,23 @@ __global__ __launch_bounds__(256) void gconv16_kernel(GConvArgs a, const float* 
         off[k] = in ? (int)(((size_t)ci * hw + (size_t)gy * a.win + gx) * 4) : -1;
     }
     const char* zero = reinterpret_cast<const char*>(zero_page);
-    // chunk index -> (segment, first channel)
+    // chunk index -> (segment, first channel); the three descriptors are held in scalar registers (a dynamic index into the
+    // kernel arguments is a scalar load + wait in front of every chunk's DMA)
+    const char* sp[3];
+    int sc[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const bool on = s < a.nseg;
+        sc[s] = on ? a.seg[s].c : 0;
+        sp[s] = on ? reinterpret_cast<const char*>(a.seg[s].ptr + ((size_t)n * a.seg[s].ctotal + a.seg[s].coff) * hw) : nullptr;
+    }
     auto chunk_base = [&](int ch) -> const char* {
-        int s = 0, c0 = ch * 16;
-        while (s + 1 < a.nseg && c0 >= a.seg[s].c) { c0 -= a.seg[s].c; ++s; }
-        const GConvSeg& sg = a.seg[s];
-        return reinterpret_cast<const char*>(sg.ptr + ((size_t)n * sg.ctotal + sg.coff + c0) * hw);
+        int c0 = ch * 16;
+        if (c0 < sc[0]) return sp[0] + (size_t)c0 * hw * 4;
+        c0 -= sc[0];
+        if (c0 < sc[1]) return sp[1] + (size_t)c0 * hw * 4;
+        c0 -= sc[1];
+        return sp[2] + (size_t)c0 * hw * 4;
     };
     auto issue = [&](int stage, int ch) {
         const char* xb = chunk_base(ch);
@@ -167,16 +178,27 @@ __global__ __launch_bounds__(256) void gconv16_kernel(GConvArgs a, const float* 
     }
 }
 
-template <int KH, int KW>
-int launch(const GConvArgs& a, const float* wpk16, const float* zero_page, hipStream_t stream) {
-    using C = G16Cfg<KH, KW>;
+template <int KH, int KW, int THT>
+int launch_th(const GConvArgs& a, const float* wpk16, const float* zero_page, hipStream_t stream) {
+    using C = G16Cfg<KH, KW, THT>;
     int cin = 0;
     for (int s = 0; s < a.nseg; ++s) cin += a.seg[s].c;
     const int tiles_x = ceil_div(a.wout, C::TW), tiles_y = ceil_div(a.hout, C::TH);
     dim3 grid(tiles_x * tiles_y, ceil_div(a.cout, 64), a.n);
-    hipLaunchKernelGGL((gconv16_kernel<KH, KW>), grid, dim3(256), 0, stream, a, wpk16, zero_page, tiles_x, cin / 16);
+    hipLaunchKernelGGL((gconv16_kernel<KH, KW, THT>), grid, dim3(256), 0, stream, a, wpk16, zero_page, tiles_x, cin / 16);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
+}
+
+template <int KH, int KW>
+int launch(const GConvArgs& a, const float* wpk16, const float* zero_page, hipStream_t stream) {
+    // 2-row tiles when 4-row tiles would leave only a few blocks per CU (their run time is quantised in whole blocks per CU:
+    // E-RAFT's update block at batch 4 is 2.3 blocks per CU); 4-row tiles reuse every weight fragment twice as often
+    static const int th_env = [] { const char* e = getenv("EEM_G16_TH"); return e ? atoi(e) : 0; }();
+    const long blocks4 = (long)ceil_div(a.wout, 16) * ceil_div(a.hout, 4) * ceil_div(a.cout, 64) * a.n;
+    const int th = th_env ? th_env : (blocks4 < 2048 ? 2 : 4);
+    if (th == 2) return launch_th<KH, KW, 2>(a, wpk16, zero_page, stream);
+    return launch_th<KH, KW, 4>(a, wpk16, zero_page, stream);
 }
 
 }  // namespace

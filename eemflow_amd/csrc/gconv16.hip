@@ -44,7 +44,7 @@ struct G16Cfg {
 };
 
 template <int KH, int KW, int THT>
-__global__ __launch_bounds__(256) void gconv16_kernel(GConvArgs a, const float* __restrict__ wpk16, const float* __restrict__ zero_page,
+__global__ __launch_bounds__(256, (KH * KW == 9 && THT == 4) ? 3 : 4) void gconv16_kernel(GConvArgs a, const float* __restrict__ wpk16, const float* __restrict__ zero_page,
                                                       int tiles_x, int nchunks) {
     using C = G16Cfg<KH, KW, THT>;
     __shared__ __attribute__((aligned(16))) float lds[2 * C::STAGE];

@@ -12,3 +12,9 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/voxel -
 find $out/train -name "*kernel_stats.csv" -exec cp {} $out/train_kernel_stats.csv \;
 find $out/voxel -name "*kernel_stats.csv" -exec cp {} $out/voxel_kernel_stats.csv \;
 cat $out/*.txt
+python3 tools/bench_eraft.py 1 > $out/eraft_b1.txt 2>/dev/null
+python3 tools/bench_eraft.py 4 > $out/eraft_b4.txt 2>/dev/null
+python3 tools/bench_plus.py 2>/dev/null | tail -1 > $out/eemflow_plus.txt
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/eraft -- python3 tools/bench_eraft.py 4 > /dev/null 2>&1
+find $out/eraft -name "*kernel_stats.csv" -exec cp {} $out/eraft_b4_kernel_stats.csv \;
+cat $out/eraft_b1.txt $out/eraft_b4.txt $out/eemflow_plus.txt

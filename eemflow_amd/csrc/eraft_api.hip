@@ -62,6 +62,8 @@ struct eraft_ctx {
 
 namespace {
 
+constexpr int kCorrPad = 336;     // 324 correlation features padded to a multiple of 16 channels
+
 struct Cursor {
     const float* p;
     const float* end;
@@ -244,10 +246,10 @@ int build_pyramid(eraft_ctx* c, const float* f1, const float* f2, int batch, int
     return EEM_OK;
 }
 
-int run_lookup(eraft_ctx* c, const float* coords, float* out, int batch, int h, int w, hipStream_t st) {
+int run_lookup(eraft_ctx* c, const float* coords, float* out, int out_ctotal, int batch, int h, int w, hipStream_t st) {
     LookupArgs la;
     for (int l = 0; l < 4; ++l) { la.pyr[l] = c->pyr[l].p; la.ph[l] = c->ph[l]; la.pw[l] = c->pw[l]; }
-    la.coords = coords; la.out = out; la.batch = batch; la.h = h; la.w = w;
+    la.coords = coords; la.out = out; la.batch = batch; la.h = h; la.w = w; la.out_ctotal = out_ctotal;
     return er_lookup_launch(la, st);
 }
 
@@ -299,6 +301,15 @@ extern "C" int eraft_load_weights(eraft_ctx* c, const float* flat, size_t nfloat
     };
     const int c324[1] = {324}, c256[1] = {256}, c2[1] = {2}, c128[1] = {128}, c3x128[3] = {128, 128, 128};
     plain(c->convc1, 256, c324, 1, 1, 1, 0, 0);          // model/update.py:63-71
+    {   // second packing of convc1 for the 336-channel correlation buffer: zero columns for the 12 pad channels
+        const float* w = cur.p - ((size_t)256 * 324 + 256);
+        std::vector<float> wp((size_t)256 * kCorrPad, 0.f);
+        for (int co = 0; co < 256; ++co) memcpy(&wp[(size_t)co * kCorrPad], w + (size_t)co * 324, 324 * sizeof(float));
+        const int cpad[1] = {kCorrPad};
+        c->convc1.has16 = gconv16_shape(256, cpad, 1, 1, 1, 1);
+        c->convc1.wpk16 = pk.push(gconv16_packed_floats(256, cpad, 1, 1, 1));
+        gconv16_pack(wp.data(), 256, cpad, 1, 1, 1, pk.host.data() + c->convc1.wpk16);
+    }
     plain(c->convc2, 192, c256, 1, 3, 3, 1, 1);
     plain(c->convf1, 128, c2, 1, 7, 7, 3, 3);
     plain(c->convf2, 64, c128, 1, 3, 3, 1, 1);
@@ -343,12 +354,14 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
     for (int i = 0; i < 5; ++i) ENS(c->s[i], big);
     ENS(c->fmap, (size_t)2 * B * 256 * g);
     ENS(c->net[0], B * 128 * g); ENS(c->net[1], B * 128 * g); ENS(c->inp, B * 128 * g);
-    ENS(c->c0, B * 2 * g); ENS(c->c1, B * 2 * g); ENS(c->corr, B * 324 * g); ENS(c->cor1, B * 256 * g);
+    ENS(c->c0, B * 2 * g); ENS(c->c1, B * 2 * g); ENS(c->corr, B * kCorrPad * g); ENS(c->cor1, B * 256 * g);
     ENS(c->corflo, B * 256 * g); ENS(c->flo1, B * 128 * g); ENS(c->motion, B * 128 * g); ENS(c->z, B * 128 * g);
     ENS(c->rh, B * 128 * g); ENS(c->fhid, B * 256 * g); ENS(c->delta, B * 2 * g); ENS(c->mhid, B * 256 * g);
     ENS(c->mask, B * 576 * g);
     ENS(c->st_corr0, B * 324 * g); ENS(c->st_net1, B * 128 * g); ENS(c->st_mask1, B * 576 * g); ENS(c->st_delta1, B * 2 * g);
 #undef ENS
+    // pad channels of the correlation buffer (never written by the lookup)
+    EEM_HIP_CHECK(hipMemset2DAsync(c->corr.p + (size_t)324 * g, (size_t)kCorrPad * g * 4, 0, (size_t)(kCorrPad - 324) * g * 4, B, st));
     const int cin0 = c->cin0;
     // ---- pad both event volumes into one batch (model/eraft.py:106-109)
     float* pad1 = c->padded.p;
@@ -381,11 +394,14 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
     for (int it = 0; it < iters; ++it) {
         float* net = c->net[cur].p;
         float* netn = c->net[cur ^ 1].p;
-        if ((rc = run_lookup(c, c->c1.p, c->corr.p, B, h8, w8, st)) != EEM_OK) return rc;                    // :142
+        if ((rc = run_lookup(c, c->c1.p, c->corr.p, kCorrPad, B, h8, w8, st)) != EEM_OK) return rc;          // :142
         if ((rc = er_flow_launch(c->c0.p, c->c1.p, c->motion.p, 128, 126, B, (int)g, st)) != EEM_OK) return rc;  // :144, update.py:81
         // motion encoder (model/update.py:73-81)
+        // the 324 correlation features live in a 336-channel buffer (12 zero channels, zero weight columns) so that the
+        // 1x1 conv qualifies for the 16-aligned LDS-tiled kernel; the generic kernel reads the first 324
         GConvArgs a = conv_args(c, c->convc1, B, h8, w8, c->cor1.p, 256, 0, GACT_RELU);
-        set_seg(a, 0, c->corr.p, 324, 324, 0);
+        set_seg(a, 0, c->corr.p, kCorrPad, kCorrPad, 0);
+        if (!gconv16_supported(a)) { a.wpk16 = nullptr; set_seg(a, 0, c->corr.p, 324, kCorrPad, 0); }
         if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
         a = conv_args(c, c->convc2, B, h8, w8, c->corflo.p, 256, 0, GACT_RELU);
         set_seg(a, 0, c->cor1.p, 256, 256, 0);
@@ -435,7 +451,8 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
         if ((rc = er_convex_up_launch(c->c0.p, c->c1.p, c->mask.p, out + (size_t)it * B * 2 * in_h * in_w, B, h8, w8, pad[2],
                                       pad[0], in_h, in_w, st)) != EEM_OK) return rc;                          // :155-157
         if (it == 0) {
-            EEM_HIP_CHECK(hipMemcpyAsync(c->st_corr0.p, c->corr.p, B * 324 * g * 4, hipMemcpyDeviceToDevice, st));
+            EEM_HIP_CHECK(hipMemcpy2DAsync(c->st_corr0.p, 324 * g * 4, c->corr.p, kCorrPad * g * 4, 324 * g * 4, B,
+                                           hipMemcpyDeviceToDevice, st));
             EEM_HIP_CHECK(hipMemcpyAsync(c->st_net1.p, net, B * 128 * g * 4, hipMemcpyDeviceToDevice, st));
             EEM_HIP_CHECK(hipMemcpyAsync(c->st_mask1.p, c->mask.p, B * 576 * g * 4, hipMemcpyDeviceToDevice, st));
             EEM_HIP_CHECK(hipMemcpyAsync(c->st_delta1.p, c->delta.p, B * 2 * g * 4, hipMemcpyDeviceToDevice, st));
@@ -485,7 +502,7 @@ extern "C" int eraft_corr_lookup(eraft_ctx* c, const float* fmap1, const float* 
     int rc = build_pyramid(c, fmap1, fmap2, batch, ch, h, w, (hipStream_t)stream);
     if (rc != EEM_OK) return rc;
     c->B = batch; c->h8 = h; c->w8 = w; c->have_last = true;
-    return run_lookup(c, coords, out, batch, h, w, (hipStream_t)stream);
+    return run_lookup(c, coords, out, 324, batch, h, w, (hipStream_t)stream);
 }
 
 // ERAFT.upsample_flow (model/eraft.py:83-94): flow [B][2][h][w], mask [B][576][h][w] -> out [B][2][8h][8w]

@@ -22,8 +22,8 @@ struct LookupArgs {
     const float* pyr[4];
     int ph[4], pw[4];
     const float* coords;   // [B][2][H][W]
-    float* out;            // [B][324][H][W]
-    int batch, h, w;
+    float* out;            // [B][out_ctotal][H][W], channels 0..323 are written
+    int batch, h, w, out_ctotal;
 };
 int er_lookup_launch(const LookupArgs& a, hipStream_t st);
 

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void lookup_kernel(LookupArgs a) {
     const float x = cx / sc + (float)(i - 4);          // the reference adds (dy[i], dx[j]) to (x, y)
     const float y = cy / sc + (float)(jj - 4);
     const float* img = a.pyr[lvl] + ((size_t)b * hw + p) * a.ph[lvl] * a.pw[lvl];
-    a.out[idx] = sample_bilinear(img, a.ph[lvl], a.pw[lvl], x, y);
+    a.out[((size_t)b * a.out_ctotal + ch) * hw + p] = sample_bilinear(img, a.ph[lvl], a.pw[lvl], x, y);
 }
 
 __global__ __launch_bounds__(256) void coords_init_kernel(float* c0, float* c1, const float* init, int batch, int h, int w) {

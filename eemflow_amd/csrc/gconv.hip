@@ -6,6 +6,8 @@
 // Inputs may be the concatenation of up to three tensors (segments) - the reference's torch.cat's
 // (model/update.py:44,51,79,99) are never materialised.  The epilogue applies a per-channel scale/shift
 // (bias, folded eval-mode BatchNorm), the activation and the GRU / residual combinations.
+#include <algorithm>
+
 #include "gconv.h"
 
 namespace {
@@ -23,7 +25,7 @@ __device__ __forceinline__ float g_act(float v, int act) {
 // SPLITK (with NPW = MTW = 1): the block owns ONE 32-pixel x 32-cout tile and its four waves take the k-batches round
 // robin, meet in LDS and share the epilogue - for layers whose tile count leaves most SIMDs empty (E-RAFT's 60x80
 // update block at batch 1: 152 blocks of 4 single-tile waves for 256 CUs).
-template <int NPW, int MTW, bool SPLITK = false>
+template <int NPW, int MTW, bool SPLITK = false, int UU = 0>
 __global__ __launch_bounds__(256) void gconv_kernel(GConvArgs a) {
     static_assert(!SPLITK || (NPW == 1 && MTW == 1), "split-K is built for single-tile waves");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -64,7 +66,9 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvArgs a) {
     //  * Latency: the operands of batch i+1 are requested before the MFMAs of batch i issue - across taps and segments
     //    too - with two register sets and scheduling barriers that keep the requests where they are written (a wave of
     //    a small layer otherwise has one batch in flight, and each is a cold miss on the weights).
-    constexpr int U = (NPW * MTW == 1) ? 16 : 8;
+    // k-steps per batch (one tap, one segment, U channel pairs): a segment of fewer pairs leaves the other slots as zero
+    // work, so few-channel inputs (E-RAFT's 2-channel flow through a 7x7 conv, the 5-bin event volumes) use short batches
+    constexpr int U = UU ? UU : ((NPW * MTW == 1) ? 16 : 8);
     struct Pos { int tap, s, cp0, ks; };                     // ks = k-step index of the batch's first pair
     const int ntaps = a.kh * a.kw;
     auto advance1 = [&](Pos q) {
@@ -266,6 +270,21 @@ int gconv_launch(const GConvArgs& a, hipStream_t stream) {
     const int cot = ceil_div(a.cout, 32);
     // big problems: 2x2 tiles per wave (half the operand traffic per MFMA); small ones: 1x1 for parallelism
     const long waves22 = (long)ceil_div(hwo, 64) * ceil_div(cot, 2) * a.n;
+    int maxpairs = 0;
+    for (int sgi = 0; sgi < a.nseg; ++sgi) maxpairs = std::max(maxpairs, (a.seg[sgi].c + 1) / 2);
+    if (maxpairs <= 4) {                                             // short batches for few-channel inputs
+        if (waves22 >= 2048 && cot >= 2) {
+            dim3 grid(ceil_div(hwo, 256), ceil_div(cot, 2), a.n);
+            if (maxpairs <= 1) hipLaunchKernelGGL((gconv_kernel<2, 2, false, 1>), grid, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((gconv_kernel<2, 2, false, 4>), grid, dim3(256), 0, stream, a);
+        } else {
+            dim3 grid(ceil_div(hwo, 128), cot, a.n);
+            if (maxpairs <= 1) hipLaunchKernelGGL((gconv_kernel<1, 1, false, 1>), grid, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((gconv_kernel<1, 1, false, 4>), grid, dim3(256), 0, stream, a);
+        }
+        EEM_HIP_CHECK(hipGetLastError());
+        return EEM_OK;
+    }
     if (waves22 >= 2048 && cot >= 2) {
         dim3 grid(ceil_div(hwo, 256), ceil_div(cot, 2), a.n);
         hipLaunchKernelGGL((gconv_kernel<2, 2>), grid, dim3(256), 0, stream, a);
@@ -279,7 +298,9 @@ int gconv_launch(const GConvArgs& a, hipStream_t stream) {
         const char* esk = getenv("EEM_NO_SPLITK");                   // read per call: a test flips it inside one process
         const bool no_splitk = esk && esk[0] == '1';
         static const long splitk_max = [] { const char* e = getenv("EEM_SPLITK_MAX"); return e ? atol(e) : 512L; }();
-        if (!no_splitk && (long)ceil_div(hwo, 128) * cot * a.n < splitk_max && ksteps >= 128) {
+        // deep single-cout-tile layers (E-RAFT's 256 -> 2 flow head) always split: one wave per 32 pixels would walk all of K
+        const long plain_blocks = (long)ceil_div(hwo, 128) * cot * a.n;
+        if (!no_splitk && ksteps >= 128 && (plain_blocks < splitk_max || (cot == 1 && ksteps >= 512 && plain_blocks < 4096))) {
             dim3 grid(ceil_div(hwo, 32), cot, a.n);
             hipLaunchKernelGGL((gconv_kernel<1, 1, true>), grid, dim3(256), 0, stream, a);
         } else {

@@ -10,8 +10,8 @@ Mirrors the reference's `loader/HREM.py` + the file readers of `loader/loader_ut
 Host code is Python/numpy as in the reference (file parsing and a 16x16 gather are not GPU work); the event
 volumes are voxelized by libeemflow_hip.so (EventSequenceToVoxelGrid_Pytorch of this package) and stay on the
 GPU unless `to_cpu=True`.  `motion_propagate` is vectorised (the reference loops over Python dicts) and returns
-the same values bit for bit (tests/test_data_rows.py).  The augmentation of the train split
-(utils/augumentor.py FlowAugmentor) is out of scope: pass `augmentor=` to supply one.
+the same values bit for bit (tests/test_data_rows.py).  The train split's augmentation is eemflow_amd.augmentor.FlowAugmentor
+(the reference's no-resize path: random flips), built from args['aug_params'] as in HREM.py:146-150, or `augmentor=`.
 """
 import os
 
@@ -149,7 +149,8 @@ class HREMEventFlow(torch.utils.data.Dataset):
         self.device = torch.device(device if device is not None else "cuda:0")
         self.to_cpu = to_cpu
         if 'aug_params' in args and augmentor is None and train:
-            raise NotImplementedError("FlowAugmentor (utils/augumentor.py) is out of scope: pass augmentor=callable")
+            from .augmentor import FlowAugmentor                  # HREM.py:146-150
+            augmentor = FlowAugmentor(**args['aug_params'])
         self.augmentor = augmentor
         self.voxel = EventSequenceToVoxelGrid_Pytorch(num_bins=self.num_bins, normalize=True, gpu=True,
                                                       gpu_nr=self.device.index or 0, forkserver=False)

@@ -15,9 +15,10 @@ without PyTables).
 Differences, all deliberate:
   * the voxel volumes stay on the GPU unless `to_cpu=True` (the reference voxelizes on the GPU and copies back);
   * the shipped module cannot be imported as is: it takes FlowAugmentor / DenseSparseAugmentor from loader_utils, which
-    does not define them (MVSEC.py:20).  Training samples are therefore returned un-augmented unless an
-    `augmentor=callable(event1, event2, flow) -> (event1, event2, flow)` (HWC numpy, MVSEC.py:183) is supplied; an
-    'aug_params' entry without one raises;
+    does not define them (MVSEC.py:20); they are in utils/augumentor.py and restated in eemflow_amd/augmentor.py.  With
+    'aug_params' in args a training sample goes through DenseSparseAugmentor (flips + random crop, MVSEC.py:170-187);
+    without it samples are returned un-augmented (the reference would crash there), or through a caller-supplied
+    `augmentor=callable(event1, event2, flow) -> (event1, event2, flow)` (HWC numpy, MVSEC.py:183);
   * dt4: the reference's `events0.sort_values(by=['ts'])` discards its result (MVSEC.py:256-258); what orders the
     concatenated events is EventSequence's own sort, as here.
 """
@@ -101,9 +102,12 @@ class MvsecEventFlow(torch.utils.data.Dataset):
         self.num_bins = args['num_voxel_bins']
         self.voxel = EventSequenceToVoxelGrid_Pytorch(num_bins=self.num_bins, normalize=True, gpu=True,
                                                       gpu_nr=self.device.index or 0, forkserver=False)
+        self.dense_augmentor = None
         if 'aug_params' in args and augmentor is None and train:
-            raise NotImplementedError("MVSEC.py takes FlowAugmentor / DenseSparseAugmentor from loader_utils, which does not "
-                                      "define them; pass augmentor=callable(event1, event2, flow)")
+            # MVSEC.py:54-57 (which imports the classes from loader_utils, where they are not defined; they live in
+            # utils/augumentor.py): samples carry d_event_volume_* keys, so __getitem__ takes the dense-sparse one (:170-176)
+            from .augmentor import DenseSparseAugmentor
+            self.dense_augmentor = DenseSparseAugmentor(**args['aug_params'])
         self.augmentor = augmentor
         self.change_test_sequence(args['sequence'])
 
@@ -163,7 +167,16 @@ class MvsecEventFlow(torch.utils.data.Dataset):
     def __getitem__(self, idx):
         sample = self.get_sample(idx % len(self))
         if self.type == 'train':
-            if self.augmentor is not None:
+            if self.dense_augmentor is not None:                                                # MVSEC.py:170-187
+                e1 = sample['event_volume_old'].permute(1, 2, 0).cpu().numpy()
+                e2 = sample['event_volume_new'].permute(1, 2, 0).cpu().numpy()
+                fl = sample['flow'].permute(1, 2, 0).numpy()
+                e1, e2, d1, d2, fl = self.dense_augmentor(e1, e2, e1, e2, fl)
+                for key, arr in (('event_volume_old', e1), ('event_volume_new', e2), ('d_event_volume_old', d1),
+                                 ('d_event_volume_new', d2)):
+                    sample[key] = torch.from_numpy(arr).permute(2, 0, 1).float()
+                sample['flow'] = torch.from_numpy(fl).permute(2, 0, 1)
+            elif self.augmentor is not None:
                 e1 = sample['event_volume_old'].permute(1, 2, 0).cpu().numpy()
                 e2 = sample['event_volume_new'].permute(1, 2, 0).cpu().numpy()
                 fl = sample['flow'].permute(1, 2, 0).numpy()

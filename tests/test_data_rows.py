@@ -91,8 +91,8 @@ def test_mvsec_file_lists_crop_and_event_mask(tmp_path):
     d4 = mvsec.MvsecEventFlow_dt4(dict(args, sequence="indoor_flying1"), train=False, root=str(tmp_path))
     assert "dataset/MVSEC/indoor_flying1/flowgt_dt4/314.npy" in d4.flow_list[0]
     assert len(d4.event_list) == len(d4) + 5 and d4.event_list[-1].endswith("002204.h5")
-    with pytest.raises(NotImplementedError):
-        mvsec.MvsecEventFlow(dict(args, aug_params={"crop_size": [256, 256]}), train=True, root=str(tmp_path))
+    tr = mvsec.MvsecEventFlow(dict(args, aug_params={"crop_size": [256, 256], "do_flip": True}), train=True, root=str(tmp_path))
+    assert tr.dense_augmentor is not None and tr.dense_augmentor.crop_size == [256, 256]
     # torchvision CenterCrop((256,256)) of 260x346: top 2, left 45
     x = torch.arange(260 * 346).view(1, 260, 346)
     c = mvsec.center_crop(x, (256, 256))
@@ -110,3 +110,24 @@ def test_mvsec_file_lists_crop_and_event_mask(tmp_path):
         assert np.array_equal(mvsec.event_mask(feats, h, w), hist.transpose() > 0)
     with pytest.raises(FileNotFoundError):
         mvsec.get_events(os.path.join(tmp_path, "nope.h5"))
+
+
+def test_augmentors_match_reference_classes(golden):
+    """FlowAugmentor (no-resize path) and DenseSparseAugmentor against outputs of the reference's own classes under the same
+    numpy seed: bit-identical arrays (flips, flow sign changes, random crop)."""
+    from eemflow_amd.augmentor import DenseSparseAugmentor, FlowAugmentor
+    g = golden("augmentor.npz")
+    for k, (seed, h, w, ch, cw, flip) in enumerate(g["cases"].tolist()):
+        rng = np.random.default_rng(100 + seed)
+        a, b, da, db = (rng.standard_normal((h, w, 3)).astype(np.float32) for _ in range(4))
+        fl = rng.standard_normal((h, w, 2))
+        np.random.seed(seed)
+        got = FlowAugmentor(crop_size=[ch, cw], do_flip=bool(flip))(a, b, fl, without_resize=True)
+        for i, arr in enumerate(got):
+            assert arr.flags["C_CONTIGUOUS"] and np.array_equal(arr, g[f"flow_nr_{k}_{i}"]), (k, i)
+        np.random.seed(seed)
+        got = DenseSparseAugmentor(crop_size=[ch, cw], do_flip=bool(flip))(a, b, da, db, fl)
+        for i, arr in enumerate(got):
+            assert arr.dtype == g[f"dense_{k}_{i}"].dtype and np.array_equal(arr, g[f"dense_{k}_{i}"]), (k, i)
+    with pytest.raises(NotImplementedError):
+        FlowAugmentor(crop_size=[8, 8])(a, b, fl)

@@ -174,6 +174,16 @@ def test_mvsec_dataset_end_to_end(tmp_path, dt4):
     tr = cls(args, train=True, root=root, valid_time_index={"indoor_flying2": [frames]})
     t = tr[1]
     assert tuple(t["event_volume_old"].shape) == (5, 260, 346) and tuple(t["valid"].shape) == (260, 346)
+    # with aug_params: DenseSparseAugmentor (flips + 256x256 random crop), reproducible under the numpy seed
+    ta = cls(dict(args, aug_params={"crop_size": [256, 256], "do_flip": True}), train=True, root=root,
+             valid_time_index={"indoor_flying2": [frames]})
+    np.random.seed(7)
+    s1 = ta[1]
+    np.random.seed(7)
+    s2 = ta[1]
+    assert tuple(s1["event_volume_old"].shape) == (5, 256, 256) and tuple(s1["flow"].shape) == (2, 256, 256)
+    assert torch.equal(s1["event_volume_new"], s2["event_volume_new"]) and torch.equal(s1["flow"], s2["flow"])
+    assert torch.equal(s1["event_volume_old"], s1["d_event_volume_old"]) and tuple(s1["valid"].shape) == (256, 256)
 
 
 def synthetic_flow_chw(seed):

@@ -87,8 +87,9 @@ def test_forward_vs_golden(golden, tag):
     assert maxerr(torch.stack(preds), g["preds"]) < FLOW_TOL
 
 
-@pytest.mark.parametrize("b,h,w,iters", [(1, 128, 160, 2), (3, 136, 200, 4)])
+@pytest.mark.parametrize("b,h,w,iters", [(1, 128, 160, 2), (3, 136, 200, 4), (3, 256, 352, 2)])
 def test_forward_vs_oracle(b, h, w, iters):
+    """The last case is large enough (32x44 grid, batch 3) for the LDS-tiled conv kernel and ragged in its tiles."""
     net, sd = make_net(17)
     net.change_imagesize((h, w))
     e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(18, b, h, w))

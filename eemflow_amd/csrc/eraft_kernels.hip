@@ -204,6 +204,42 @@ __global__ __launch_bounds__(256) void lookup_kernel(LookupArgs a) {
     a.out[((size_t)b * a.out_ctotal + ch) * hw + p] = sample_bilinear(img, a.ph[lvl], a.pw[lvl], x, y);
 }
 
+// The same lookup with both sides coalesced.  lookup_kernel above gives consecutive lanes consecutive PIXELS: its stores are
+// 256-byte runs but every lane samples a different pixel's correlation map (19 KB apart at level 0).  Here a block owns 64
+// consecutive pixels of one pyramid level; lanes walk the flattened (pixel, tap) pairs, so the 64 samples of an instruction
+// come from the 10x10 windows of one or two maps; the values pass through an LDS tile [tap][pixel] and leave as 256-byte runs.
+__global__ __launch_bounds__(256) void lookup_tiled_kernel(LookupArgs a) {
+    __shared__ float tile[81][65];
+    __shared__ float cxs[64], cys[64];
+    const int hw = a.h * a.w;
+    const int lvl = blockIdx.y, b = blockIdx.z;
+    const int p0 = blockIdx.x * 64;
+    const int npx = min(64, hw - p0);
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        const int p = p0 + min(tid, npx - 1);
+        cxs[tid] = a.coords[((size_t)b * 2 + 0) * hw + p];
+        cys[tid] = a.coords[((size_t)b * 2 + 1) * hw + p];
+    }
+    __syncthreads();
+    const float inv = 1.f / (float)(1 << lvl);
+    const int ph = a.ph[lvl], pw = a.pw[lvl];
+    const float* maps = a.pyr[lvl] + ((size_t)b * hw + p0) * ph * pw;
+    for (int item = tid; item < npx * 81; item += 256) {
+        const int px = item / 81, k = item - px * 81;
+        const int i = k / 9, jj = k - i * 9;
+        const float x = cxs[px] * inv + (float)(i - 4);          // as lookup_kernel: the reference adds (dy[i], dx[j]) to (x, y)
+        const float y = cys[px] * inv + (float)(jj - 4);
+        tile[k][px] = sample_bilinear(maps + (size_t)px * ph * pw, ph, pw, x, y);
+    }
+    __syncthreads();
+    float* out = a.out + ((size_t)b * a.out_ctotal + lvl * 81) * hw + p0;
+    for (int e = tid; e < 81 * 64; e += 256) {
+        const int k = e >> 6, px = e & 63;
+        if (px < npx) out[(size_t)k * hw + px] = tile[k][px];
+    }
+}
+
 __global__ __launch_bounds__(256) void coords_init_kernel(float* c0, float* c1, const float* init, int batch, int h, int w) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const int hw = h * w;
@@ -297,7 +333,9 @@ int er_pool2_launch(const float* in, float* out, long planes, int h, int w, hipS
 }
 
 int er_lookup_launch(const LookupArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(lookup_kernel, dim3(blocks((long)a.batch * 324 * a.h * a.w)), dim3(256), 0, st, a);
+    static const bool plain = [] { const char* e = getenv("EEM_LOOKUP_PLAIN"); return e && e[0] == '1'; }();
+    if (plain) hipLaunchKernelGGL(lookup_kernel, dim3(blocks((long)a.batch * 324 * a.h * a.w)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(lookup_tiled_kernel, dim3(ceil_div(a.h * a.w, 64), 4, a.batch), dim3(256), 0, st, a);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

@@ -104,7 +104,8 @@ __global__ __launch_bounds__(1024) void instnorm_reg_kernel(const float* __restr
 // D[p1][p2] tiles of 64x64 per wave on v_mfma_f32_32x32x2_f32; both operands are read with unit stride along
 // the pixel index (A[i=p1][k=c] = f1[c][p1], B[k=c][j=p2] = f2[c][p2]) and each accumulator register is a
 // 128-B run of p2 for one p1 row.
-__global__ __launch_bounds__(256) void allpairs_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+// any hw (4-byte operand loads); the 8-byte form below needs an even pixel count
+__global__ __launch_bounds__(256) void allpairs_odd_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                        float* __restrict__ out, int c, int hw, float scale) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -158,6 +159,54 @@ __global__ __launch_bounds__(256) void allpairs_kernel(const float* __restrict__
                 const int p1 = m0 + s * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (p1 < hw) o[(size_t)p1 * hw + p2] = acc[s][t][r] * scale;
             }
+        }
+}
+
+__global__ __launch_bounds__(256) void allpairs_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                       float* __restrict__ out, int c, int hw, float scale) {
+    // MFMA row / column j of tile t stands for pixel 2j + t of the wave's 64-pixel span: one 8-byte load per operand and k-step
+    // feeds both tiles, and the two column tiles of a lane are neighbouring p2 -> 8-byte stores in 256-byte runs.  (hw is even.)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z;
+    const int m0 = blockIdx.y * 128 + (wave >> 1) * 64;      // p1 span origin
+    const int n0 = blockIdx.x * 128 + (wave & 1) * 64;       // p2 span origin
+    if (m0 >= hw || n0 >= hw) return;
+    const float* a = f1 + (size_t)b * c * hw;
+    const float* bb = f2 + (size_t)b * c * hw;
+    const int ma = m0 + 2 * j, nb = n0 + 2 * j;
+    const bool mv = ma < hw, nv = nb < hw;
+    const int mac = mv ? ma : 0, nbc = nv ? nb : 0;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[s][t][r] = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < c; k += 2) {
+        const int kk = k + h;
+        const bool kv = kk < c;
+        const size_t ko = (size_t)(kv ? kk : 0) * hw;
+        f32x2 av = *reinterpret_cast<const f32x2*>(a + ko + mac);
+        f32x2 bv = *reinterpret_cast<const f32x2*>(bb + ko + nbc);
+        if (!(kv && mv)) av = f32x2{0.f, 0.f};
+        if (!(kv && nv)) bv = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[t], acc[s][t], 0, 0, 0);
+    }
+    float* o = out + (size_t)b * hw * hw;
+    if (!nv) return;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int p1 = m0 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * h) + s;
+            if (p1 < hw) *reinterpret_cast<f32x2*>(o + (size_t)p1 * hw + nb) = f32x2{acc[s][0][r] * scale, acc[s][1][r] * scale};
         }
 }
 
@@ -318,8 +367,10 @@ int er_instnorm_launch(const float* x, float* out, const float* res, int planes,
 }
 
 int er_allpairs_launch(const float* f1, const float* f2, float* out, int batch, int c, int hw, hipStream_t st) {
+    const bool even = hw % 2 == 0 && ((uintptr_t)f1 & 7) == 0 && ((uintptr_t)f2 & 7) == 0 && ((uintptr_t)out & 7) == 0;
     dim3 grid(ceil_div(hw, 128), ceil_div(hw, 128), batch);
-    hipLaunchKernelGGL(allpairs_kernel, grid, dim3(256), 0, st, f1, f2, out, c, hw, 1.0f / sqrtf((float)c));
+    if (even) hipLaunchKernelGGL(allpairs_kernel, grid, dim3(256), 0, st, f1, f2, out, c, hw, 1.0f / sqrtf((float)c));
+    else hipLaunchKernelGGL(allpairs_odd_kernel, grid, dim3(256), 0, st, f1, f2, out, c, hw, 1.0f / sqrtf((float)c));
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

@@ -24,7 +24,7 @@ int pensure(PBuf& b, size_t floats) {
     return EEM_OK;
 }
 
-struct PLayer { size_t wpk = 0, wpk16 = 0, bias = 0; bool has16 = false; int cin = 0, cout = 0, k = 3, stride = 1; };
+struct PLayer { size_t wpk = 0, wpk16 = 0, wtail = 0, bias = 0; bool has16 = false, has_tail = false; int cin = 0, cout = 0, k = 3, stride = 1; };
 
 const int kTaps[53] = {0,  2,  4,  6,  8,  10, 12, 14, 16, 18, 20, 21, 22, 23, 24, 26, 28, 29, 30, 31, 32, 33, 34, 36, 38, 39, 40,
                        41, 42, 44, 46, 47, 48, 49, 50, 51, 52, 54, 56, 57, 58, 59, 60, 62, 64, 66, 68, 70, 72, 74, 76, 78, 80};
@@ -64,6 +64,12 @@ void mk(Pk& pk, PLayer& L, const float* w, const float* b, int cin, int cout, in
     }
     L.bias = pk.push(cout);
     memcpy(pk.host.data() + L.bias, b, cout * sizeof(float));
+    // decoder convs also get the small-grid packing (tail_conv_kernel, used on the coarse pyramid levels)
+    L.has_tail = stride == 1 && k == 3 && cin <= 100;
+    if (L.has_tail) {
+        L.wtail = pk.push(tail_packed_floats(cin, cout, k));
+        tail_pack_weights(w, cin, cout, k, pk.host.data() + L.wtail);
+    }
 }
 
 int conv(eemplus_ctx* c, const PLayer& L, const float* in, int in_ctotal, int in_coff, int n, int hin, int win, float* out,
@@ -93,17 +99,48 @@ int run_decoder(eemplus_ctx* c, int l, int B, int h, int w, const float* residua
     if ((rc = pensure(c->t64, B * 64 * g)) != EEM_OK || (rc = pensure(c->t32, B * 32 * g)) != EEM_OK ||
         (rc = pensure(c->flow[l], B * 2 * g)) != EEM_OK)
         return rc;
-    if ((rc = conv(c, c->dec1[l], c->cat.p, kDIn, 0, B, h, w, c->d[0].p, kDW, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
     const int G = c->groups, per = kDW / G;
-    for (int layer = 0; layer < 3; ++layer)
-        for (int gi = 0; gi < G; ++gi) {
-            // group gi reads channels [gi*per, (gi+1)*per); channel_shuffle puts its output j at j*G + gi
-            const int oc = G == 1 ? 0 : gi, om = G == 1 ? 1 : G;
-            if ((rc = conv(c, c->decg[l][layer][gi], c->d[layer].p, kDW, gi * per, B, h, w, c->d[layer + 1].p, kDW, oc, om, GACT_LEAKY,
-                           nullptr, st)) != EEM_OK) return rc;
+    // coarse levels: every conv is a handful of 16x16 tiles - the small-grid kernel of EEMFlow's tail (one launch per layer,
+    // the groups of a layer as jobs, K split over the waves of a block) instead of one generic-conv launch per group
+    static const bool no_tail = [] { const char* e = getenv("EEM_PLUS_NO_TAIL"); return e && e[0] == '1'; }();
+    static const long tail_max = [] { const char* e = getenv("EEM_PLUS_TAIL_MAX"); return e ? atol(e) : 4096L; }();
+    const bool small = !no_tail && (long)h * w <= tail_max && c->dec1[l].has_tail && c->decg[l][0][0].has_tail && c->dec5[l].has_tail &&
+                       c->dec6[l].has_tail && G * 1 <= TAIL_MAX_JOBS;
+    if (small) {
+        auto job = [&](const PLayer& L, const float* in, int in_ctotal, int in_coff, float* out, int out_ctotal, int out_coff, int out_cmul) {
+            TailConvJob j;
+            j.in = in; j.wpk = c->arena + L.wtail; j.bias = c->arena + L.bias; j.out = out;
+            j.cin = L.cin; j.cout = L.cout; j.in_ctotal = in_ctotal; j.in_coff = in_coff;
+            j.out_ctotal = out_ctotal; j.out_coff = out_coff; j.out_cmul = out_cmul; j.act = 1;
+            j.gate = nullptr; j.in_cmul = 1;
+            return j;
+        };
+        TailConvLaunch L;
+        L.batch = B; L.h = h; L.w = w; L.ksize = 3;
+        L.njobs = 1; L.job[0] = job(c->dec1[l], c->cat.p, kDIn, 0, c->d[0].p, kDW, 0, 1);
+        if ((rc = tail_conv_launch(L, st)) != EEM_OK) return rc;
+        for (int layer = 0; layer < 3; ++layer) {
+            L.njobs = 0;
+            for (int gi = 0; gi < G; ++gi)
+                L.job[L.njobs++] = job(c->decg[l][layer][gi], c->d[layer].p, kDW, gi * per, c->d[layer + 1].p, kDW, G == 1 ? 0 : gi, G == 1 ? 1 : G);
+            if ((rc = tail_conv_launch(L, st)) != EEM_OK) return rc;
         }
-    if ((rc = conv(c, c->dec5[l], c->d[3].p, kDW, 0, B, h, w, c->t64.p, 64, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
-    if ((rc = conv(c, c->dec6[l], c->t64.p, 64, 0, B, h, w, c->t32.p, 32, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+        L.njobs = 1; L.job[0] = job(c->dec5[l], c->d[3].p, kDW, 0, c->t64.p, 64, 0, 1);
+        if ((rc = tail_conv_launch(L, st)) != EEM_OK) return rc;
+        L.njobs = 1; L.job[0] = job(c->dec6[l], c->t64.p, 64, 0, c->t32.p, 32, 0, 1);
+        if ((rc = tail_conv_launch(L, st)) != EEM_OK) return rc;
+    } else {
+        if ((rc = conv(c, c->dec1[l], c->cat.p, kDIn, 0, B, h, w, c->d[0].p, kDW, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+        for (int layer = 0; layer < 3; ++layer)
+            for (int gi = 0; gi < G; ++gi) {
+                // group gi reads channels [gi*per, (gi+1)*per); channel_shuffle puts its output j at j*G + gi
+                const int oc = G == 1 ? 0 : gi, om = G == 1 ? 1 : G;
+                if ((rc = conv(c, c->decg[l][layer][gi], c->d[layer].p, kDW, gi * per, B, h, w, c->d[layer + 1].p, kDW, oc, om, GACT_LEAKY,
+                               nullptr, st)) != EEM_OK) return rc;
+            }
+        if ((rc = conv(c, c->dec5[l], c->d[3].p, kDW, 0, B, h, w, c->t64.p, 64, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+        if ((rc = conv(c, c->dec6[l], c->t64.p, 64, 0, B, h, w, c->t32.p, 32, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+    }
     return conv(c, c->dec7[l], c->t32.p, 32, 0, B, h, w, c->flow[l].p, 2, 0, 1, GACT_NONE, residual, st);
 }
 

@@ -65,7 +65,7 @@ void mk(Pk& pk, PLayer& L, const float* w, const float* b, int cin, int cout, in
     L.bias = pk.push(cout);
     memcpy(pk.host.data() + L.bias, b, cout * sizeof(float));
     // decoder convs also get the small-grid packing (tail_conv_kernel, used on the coarse pyramid levels)
-    L.has_tail = stride == 1 && k == 3 && cin <= 100;
+    L.has_tail = stride == 1 && (k == 3 || k == 1) && cin <= 100;
     if (L.has_tail) {
         L.wtail = pk.push(tail_packed_floats(cin, cout, k));
         tail_pack_weights(w, cin, cout, k, pk.host.data() + L.wtail);
@@ -74,6 +74,18 @@ void mk(Pk& pk, PLayer& L, const float* w, const float* b, int cin, int cout, in
 
 int conv(eemplus_ctx* c, const PLayer& L, const float* in, int in_ctotal, int in_coff, int n, int hin, int win, float* out,
          int out_ctotal, int out_coff, int out_cmul, int act, const float* add, hipStream_t st) {
+    // small maps (the coarse pyramid levels): the small-grid kernel of EEMFlow's tail
+    static const bool no_tail = [] { const char* e = getenv("EEM_PLUS_NO_TAIL"); return e && e[0] == '1'; }();
+    if (!no_tail && L.has_tail && add == nullptr && (long)hin * win <= 4096 && (act == GACT_LEAKY || act == GACT_NONE)) {
+        TailConvLaunch T;
+        T.batch = n; T.h = hin; T.w = win; T.ksize = L.k; T.njobs = 1;
+        TailConvJob& j = T.job[0];
+        j.in = in; j.wpk = c->arena + L.wtail; j.bias = c->arena + L.bias; j.out = out;
+        j.cin = L.cin; j.cout = L.cout; j.in_ctotal = in_ctotal; j.in_coff = in_coff;
+        j.out_ctotal = out_ctotal; j.out_coff = out_coff; j.out_cmul = out_cmul > 1 ? out_cmul : 1; j.act = act == GACT_LEAKY;
+        j.gate = nullptr; j.in_cmul = 1;
+        return tail_conv_launch(T, st);
+    }
     GConvArgs a;
     memset(&a, 0, sizeof(a));
     a.nseg = 1;

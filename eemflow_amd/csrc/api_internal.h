@@ -192,7 +192,7 @@ TailConvJob make_job(const eemflow_ctx* c, const TailW& w, const float* in, int 
     j.cin = w.cin; j.cout = w.cout;
     j.in_ctotal = in_ctotal; j.in_coff = in_coff;
     j.out_ctotal = out_ctotal; j.out_coff = out_coff; j.out_cmul = out_cmul; j.act = act;
-    j.gate = nullptr; j.in_cmul = 1;
+    j.gate = nullptr; j.in_cmul = 1; j.add = nullptr;
     return j;
 }
 

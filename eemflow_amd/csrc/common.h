@@ -183,6 +183,7 @@ struct TailConvJob {
     // multiplied by LeakyReLU'(gate) (gate indexed like the input; NULL = none); bias may be NULL
     const float* gate;
     int in_cmul;
+    const float* add;      // optional residual, indexed like `out` (added after the activation); NULL = none
 };
 #define TAIL_MAX_JOBS 16
 struct TailConvLaunch {

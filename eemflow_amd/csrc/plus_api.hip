@@ -76,7 +76,8 @@ int conv(eemplus_ctx* c, const PLayer& L, const float* in, int in_ctotal, int in
          int out_ctotal, int out_coff, int out_cmul, int act, const float* add, hipStream_t st) {
     // small maps (the coarse pyramid levels): the small-grid kernel of EEMFlow's tail
     static const bool no_tail = [] { const char* e = getenv("EEM_PLUS_NO_TAIL"); return e && e[0] == '1'; }();
-    if (!no_tail && L.has_tail && add == nullptr && (long)hin * win <= 4096 && (act == GACT_LEAKY || act == GACT_NONE)) {
+    const bool add_ok = add == nullptr || (out_ctotal == L.cout && out_coff == 0 && out_cmul <= 1);   // residual indexed like the output
+    if (!no_tail && L.has_tail && add_ok && (long)hin * win <= 4096 && (act == GACT_LEAKY || act == GACT_NONE)) {
         TailConvLaunch T;
         T.batch = n; T.h = hin; T.w = win; T.ksize = L.k; T.njobs = 1;
         TailConvJob& j = T.job[0];
@@ -84,6 +85,7 @@ int conv(eemplus_ctx* c, const PLayer& L, const float* in, int in_ctotal, int in
         j.cin = L.cin; j.cout = L.cout; j.in_ctotal = in_ctotal; j.in_coff = in_coff;
         j.out_ctotal = out_ctotal; j.out_coff = out_coff; j.out_cmul = out_cmul > 1 ? out_cmul : 1; j.act = act == GACT_LEAKY;
         j.gate = nullptr; j.in_cmul = 1;
+        j.add = add;                                               // GEPI_ADD: residual with the output's shape (out_coff 0)
         return tail_conv_launch(T, st);
     }
     GConvArgs a;
@@ -124,7 +126,7 @@ int run_decoder(eemplus_ctx* c, int l, int B, int h, int w, const float* residua
             j.in = in; j.wpk = c->arena + L.wtail; j.bias = c->arena + L.bias; j.out = out;
             j.cin = L.cin; j.cout = L.cout; j.in_ctotal = in_ctotal; j.in_coff = in_coff;
             j.out_ctotal = out_ctotal; j.out_coff = out_coff; j.out_cmul = out_cmul; j.act = 1;
-            j.gate = nullptr; j.in_cmul = 1;
+            j.gate = nullptr; j.in_cmul = 1; j.add = nullptr;
             return j;
         };
         TailConvLaunch L;

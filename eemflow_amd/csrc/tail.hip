@@ -161,7 +161,9 @@ __global__ __launch_bounds__(64 * KS * KS) void tail_conv_kernel(TailConvLaunch 
             if (co < jb.cout) {
                 float v = acc[r] + (jb.bias ? jb.bias[co] : 0.f);
                 if (jb.act) v = v > 0.f ? v : 0.1f * v;
-                jb.out[((size_t)b * jb.out_ctotal + co * jb.out_cmul + jb.out_coff) * hw + p] = v;
+                const size_t o = ((size_t)b * jb.out_ctotal + co * jb.out_cmul + jb.out_coff) * hw + p;
+                if (jb.add) v += jb.add[o];                        // residual at the output's own index (EEMFlow+ decoders)
+                jb.out[o] = v;
             }
         }
     }

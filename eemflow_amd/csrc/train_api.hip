@@ -37,7 +37,7 @@ struct Bwd {
     TailConvJob djob(const ConvRef& r, const float* dy, const float* y_gate, int g_ctotal, int g_coff, int g_cmul, float* dx,
                      int dx_ctotal, int dx_coff) const {
         TailConvJob j;
-        j.in = dy; j.gate = y_gate; j.in_ctotal = g_ctotal; j.in_coff = g_coff; j.in_cmul = g_cmul;
+        j.in = dy; j.gate = y_gate; j.in_ctotal = g_ctotal; j.in_coff = g_coff; j.in_cmul = g_cmul; j.add = nullptr;
         j.wpk = c->arena + r.wT_tail; j.bias = nullptr;
         j.cin = r.cout; j.cout = r.cin;
         j.out = dx; j.out_ctotal = dx_ctotal; j.out_coff = dx_coff; j.out_cmul = 1; j.act = 0;

@@ -3,7 +3,8 @@
 // LDS-tiled implicit GEMM on v_mfma_f32_16x16x4_f32.  The generic kernel of gconv.hip reads both operands of every MFMA
 // straight from L2 (two 256-byte loads per MFMA, 44 TFLOP/s at best); here
 //   * a block = 4 waves = one 64-cout chunk x a 4x16-pixel tile; wave w owns the 16 couts of M-tile w and all four pixel rows
-//     (N-tiles), so every weight fragment feeds four MFMAs and every input fragment is read once per wave from LDS;
+//     (N-tiles), so every weight fragment feeds four MFMAs and every input fragment is read once per wave from LDS (layers
+//     of <= 32 couts: two M-tiles x two row groups per block, so no wave idles);
 //   * the input is consumed in chunks of 16 channels: the chunk's haloed tile [16][4 + KH - 1][24] (columns x0 - 4 .. x0 + 19)
 //     goes HBM/L2 -> LDS by 16-byte LDS-DMA, double-buffered, out-of-image pieces from a zero page; the plane pitch is padded to
 //     16 mod 32 floats so the four channel lanes of a k-step fall on different bank halves;
@@ -43,15 +44,20 @@ struct G16Cfg {
     static_assert(PL % 4 == 0 && PL % 32 == 16, "plane pitch");
 };
 
-template <int KH, int KW, int THT>
-__global__ __launch_bounds__(256, (KH * KW == 9 && THT == 4) ? 3 : 4) void gconv16_kernel(GConvArgs a, const float* __restrict__ wpk16, const float* __restrict__ zero_page,
+template <int KH, int KW, int THT, int WM>
+__global__ __launch_bounds__(256, (KH * KW == 9 && THT == 4 && WM == 4) ? 3 : 4) void gconv16_kernel(GConvArgs a, const float* __restrict__ wpk16, const float* __restrict__ zero_page,
                                                       int tiles_x, int nchunks) {
     using C = G16Cfg<KH, KW, THT>;
     __shared__ __attribute__((aligned(16))) float lds[2 * C::STAGE];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, g = lane >> 4;
-    const int n = blockIdx.z, cc = blockIdx.y;
+    // WM = waves along the couts (16 each): 4 -> a block covers 64 couts and every wave all TH rows; 2 -> 32 couts (layers of
+    // <= 32 couts), the two wave pairs split the rows
+    constexpr int WP = 4 / WM, NR = C::TH / WP;                  // pixel-row groups, rows per wave
+    const int wm = wave % WM, wp = wave / WM;
+    const int mtg = blockIdx.y * WM + wm;                        // global 16-cout tile of this wave
+    const int n = blockIdx.z, cc = mtg >> 2, mt = mtg & 3;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int y0 = ty * C::TH, x0 = tx * C::TW;
     const int hw = a.hin * a.win;                                // stride 1, "same" padding: output extent = input extent
@@ -99,14 +105,14 @@ __global__ __launch_bounds__(256, (KH * KW == 9 && THT == 4) ? 3 : 4) void gconv
     };
     // weight fragments of chunk `ch` for this wave's M-tile: stream[((cc * nchunks + ch) * KS + ks) * 4 + wave][lane]
     auto load_w = [&](int ch, float (&wr)[C::KS]) {
-        const float* wp = wpk16 + (((size_t)cc * nchunks + ch) * C::KS * 4 + wave) * 64 + lane;
+        const float* wp = wpk16 + (((size_t)cc * nchunks + ch) * C::KS * 4 + mt) * 64 + lane;
 #pragma unroll
         for (int ks = 0; ks < C::KS; ++ks) wr[ks] = wp[(size_t)ks * 256];
     };
 
-    f32x4 acc[C::TH];
+    f32x4 acc[NR];
 #pragma unroll
-    for (int t = 0; t < C::TH; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NR; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int bbase = g * C::PL + j + 4 - PW;                    // B fragment: channel g of a group, pixel column j
 
     float wA[C::KS], wB[C::KS];
@@ -119,11 +125,11 @@ __global__ __launch_bounds__(256, (KH * KW == 9 && THT == 4) ? 3 : 4) void gconv
             for (int kx = 0; kx < KW; ++kx)
 #pragma unroll
                 for (int cg = 0; cg < 4; ++cg) {
-                    float bv[C::TH];
+                    float bv[NR];
 #pragma unroll
-                    for (int t = 0; t < C::TH; ++t) bv[t] = sb[bbase + cg * 4 * C::PL + (t + ky) * C::COLS + kx];
+                    for (int t = 0; t < NR; ++t) bv[t] = sb[bbase + cg * 4 * C::PL + (wp * NR + t + ky) * C::COLS + kx];
 #pragma unroll
-                    for (int t = 0; t < C::TH; ++t)
+                    for (int t = 0; t < NR; ++t)
                         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[((ky * KW + kx) * 4) + cg], bv[t], acc[t], 0, 0, 0);
                 }
     };
@@ -148,13 +154,13 @@ __global__ __launch_bounds__(256, (KH * KW == 9 && THT == 4) ? 3 : 4) void gconv
     const int x = x0 + j;
     if (x >= a.wout) return;
 #pragma unroll
-    for (int t = 0; t < C::TH; ++t) {
-        const int y = y0 + t;
+    for (int t = 0; t < NR; ++t) {
+        const int y = y0 + wp * NR + t;
         if (y >= a.hout) continue;
         const int p = y * a.wout + x;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int co = cc * 64 + wave * 16 + 4 * g + r;
+            const int co = mtg * 16 + 4 * g + r;
             if (co >= a.cout) continue;
             float v = acc[t][r];
             if (a.scale) v *= a.scale[co];
@@ -178,16 +184,22 @@ __global__ __launch_bounds__(256, (KH * KW == 9 && THT == 4) ? 3 : 4) void gconv
     }
 }
 
-template <int KH, int KW, int THT>
-int launch_th(const GConvArgs& a, const float* wpk16, const float* zero_page, hipStream_t stream) {
+template <int KH, int KW, int THT, int WM>
+int launch_wm(const GConvArgs& a, const float* wpk16, const float* zero_page, hipStream_t stream) {
     using C = G16Cfg<KH, KW, THT>;
     int cin = 0;
     for (int s = 0; s < a.nseg; ++s) cin += a.seg[s].c;
     const int tiles_x = ceil_div(a.wout, C::TW), tiles_y = ceil_div(a.hout, C::TH);
-    dim3 grid(tiles_x * tiles_y, ceil_div(a.cout, 64), a.n);
-    hipLaunchKernelGGL((gconv16_kernel<KH, KW, THT>), grid, dim3(256), 0, stream, a, wpk16, zero_page, tiles_x, cin / 16);
+    dim3 grid(tiles_x * tiles_y, ceil_div(a.cout, 16 * WM), a.n);
+    hipLaunchKernelGGL((gconv16_kernel<KH, KW, THT, WM>), grid, dim3(256), 0, stream, a, wpk16, zero_page, tiles_x, cin / 16);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
+}
+
+template <int KH, int KW, int THT>
+int launch_th(const GConvArgs& a, const float* wpk16, const float* zero_page, hipStream_t stream) {
+    if (a.cout <= 32) return launch_wm<KH, KW, THT, 2>(a, wpk16, zero_page, stream);
+    return launch_wm<KH, KW, THT, 4>(a, wpk16, zero_page, stream);
 }
 
 template <int KH, int KW>
@@ -247,7 +259,7 @@ bool gconv16_supported(const GConvArgs& a) {
     for (int s = 0; s < a.nseg; ++s) cin += cs[s];
     // measured on E-RAFT (640x480, batch 1 / 4) and EEMFlow+ (1280x720): shallow inputs and launches of a few dozen blocks
     // stay on the generic kernel's split-K form
-    static const int min_cin = [] { const char* m = getenv("EEM_G16_MINCIN"); return m ? atoi(m) : 64; }();
+    static const int min_cin = [] { const char* m = getenv("EEM_G16_MINCIN"); return m ? atoi(m) : 32; }();
     static const long min_blk = [] { const char* m = getenv("EEM_G16_MINBLK"); return m ? atol(m) : 128L; }();
     const long blocks = (long)ceil_div(a.wout, 16) * ceil_div(a.hout, 4) * ceil_div(a.cout, 64) * a.n;
     if (cin < min_cin || blocks < min_blk) return false;

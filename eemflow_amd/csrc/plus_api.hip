@@ -36,7 +36,14 @@ struct eemplus_ctx {
     int device = 0, cin0 = 15, groups = 3;
     bool loaded = false;
     float* arena = nullptr;
-    size_t zero_off = 0;           // 64 zero floats inside the arena (LDS-DMA source for padding)
+    size_t zero_off = 0;           // zero page inside the arena (LDS-DMA source for padding); a write sink follows 1024 floats in
+    // the encoder is EEMFlow's (EEMFlow+.py:100-107 = EEMFlow.py:75-82): its eight layers run on the encoder kernels of conv_enc*.hip /
+    // conv_wino*.hip when the first layer has 5 input channels; packed copies of their weights:
+    size_t enc_w[8] = {0}, enc_w2[8] = {0}, enc_raw[8] = {0};
+    bool enc_has2[8] = {false}, enc_fast = false;
+    float* wino = nullptr;
+    size_t wino_off[8] = {0};
+    bool enc_wino[8] = {false};
     int* taps = nullptr;
     PLayer enc[8], rconv[7], dec1[7], decg[7][3][3], dec5[7], dec6[7], dec7[7], de[6], c1x1[6];
     PBuf padded, f[7], a2, dense, xout, fi, tw, fup[7], fw, cat, d[4], t64, t32, flow[7];
@@ -190,6 +197,7 @@ extern "C" void eemplus_destroy(eemplus_ctx* c) {
         if (c->flow[l].p) (void)hipFree(c->flow[l].p);
     }
     if (c->arena) (void)hipFree(c->arena);
+    if (c->wino) (void)hipFree(c->wino);
     if (c->taps) (void)hipFree(c->taps);
     delete c;
 }
@@ -201,14 +209,32 @@ extern "C" int eemplus_load_weights(eemplus_ctx* c, const float* flat, size_t nf
     EEM_HIP_CHECK(hipSetDevice(c->device));
     Cur cur{flat, flat + nfloats};
     Pk pk;
-    c->zero_off = pk.push(64);
+    c->zero_off = pk.push(4096);
     auto layer = [&](PLayer& L, int cin, int cout, int k, int stride) {
         const float* w = cur.take((size_t)cout * cin * k * k);
         const float* b = cur.take(cout);
         mk(pk, L, w, b, cin, cout, k, stride);
     };
     const int ec[8][3] = {{n_first_channels, 16, 2}, {16, 16, 1}, {16, 32, 2}, {32, 32, 1}, {32, 32, 1}, {32, 64, 2}, {64, 64, 1}, {64, 64, 1}};
-    for (int i = 0; i < 8; ++i) layer(c->enc[i], ec[i][0], ec[i][1], 3, ec[i][2]);
+    c->enc_fast = n_first_channels == 5 && !getenv("EEM_PLUS_GENERIC_ENC");
+    for (int i = 0; i < 8; ++i) {
+        const float* w = cur.p;
+        layer(c->enc[i], ec[i][0], ec[i][1], 3, ec[i][2]);
+        if (!c->enc_fast) continue;
+        const int cin = ec[i][0], cout = ec[i][1];
+        c->enc_w[i] = pk.push(enc_packed_floats(cin, cout));
+        enc_pack_weights(w, cin, cout, pk.host.data() + c->enc_w[i]);
+        c->enc_has2[i] = enc2_supported(cin, cout, ec[i][2], 4);
+        if (c->enc_has2[i]) {
+            c->enc_w2[i] = pk.push(enc2_packed_floats(cin, cout));
+            enc2_pack_weights(w, cin, cout, pk.host.data() + c->enc_w2[i]);
+        }
+        c->enc_wino[i] = wino_supported(cin, cout, ec[i][2], 4);
+        if (c->enc_wino[i]) {
+            c->enc_raw[i] = pk.push((size_t)cout * cin * 9);
+            memcpy(pk.host.data() + c->enc_raw[i], w, (size_t)cout * cin * 9 * sizeof(float));
+        }
+    }
     const int rc_in[7] = {0, 0, 32, 64, 64, 64, 64};
     for (int l = 2; l <= 6; ++l) layer(c->rconv[l], rc_in[l], 32, 3, 1);
     for (int i = 0; i < 4; ++i) (void)cur.take(2 * 2 * 4 * 4 + 2);                     // up3..up6: registered, never used
@@ -234,6 +260,21 @@ extern "C" int eemplus_load_weights(eemplus_ctx* c, const float* flat, size_t nf
     c->arena = nullptr;
     EEM_HIP_CHECK(hipMalloc(&c->arena, pk.host.size() * sizeof(float)));
     EEM_HIP_CHECK(hipMemcpy(c->arena, pk.host.data(), pk.host.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (c->wino) { EEM_HIP_CHECK(hipFree(c->wino)); c->wino = nullptr; }
+    if (c->enc_fast) {
+        size_t tot = 0;
+        for (int i = 0; i < 8; ++i)
+            if (c->enc_wino[i]) { c->wino_off[i] = tot; tot += wino_packed_floats(ec[i][1]); }
+        if (tot) {
+            EEM_HIP_CHECK(hipMalloc(&c->wino, tot * sizeof(float)));
+            for (int i = 0; i < 8; ++i)
+                if (c->enc_wino[i]) {
+                    const int rcw = wino_transform_launch(c->arena + c->enc_raw[i], ec[i][1], 0, c->wino + c->wino_off[i], nullptr);
+                    if (rcw != EEM_OK) return rcw;
+                }
+            EEM_HIP_CHECK(hipDeviceSynchronize());
+        }
+    }
     c->cin0 = n_first_channels; c->groups = groups; c->loaded = true;
     return EEM_OK;
 }
@@ -265,14 +306,33 @@ extern "C" int eemplus_forward(eemplus_ctx* c, const float* e1, const float* e2,
         size_t big = s1 > s2 ? s1 : s2; big = big > s3 ? big : s3;
         if ((rc = pensure(c->dense, big)) != EEM_OK || (rc = pensure(c->fw, big)) != EEM_OK) return rc;
         float* t0 = c->dense.p; float* t1 = c->fw.p;
-        if ((rc = conv(c, c->enc[0], c->padded.p, c->cin0, 0, n2, hp, wp, t0, 16, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
-        if ((rc = conv(c, c->enc[1], t0, 16, 0, n2, hl[1], wl[1], c->f[1].p, 16, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
-        if ((rc = conv(c, c->enc[2], c->f[1].p, 16, 0, n2, hl[1], wl[1], t0, 32, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
-        if ((rc = conv(c, c->enc[3], t0, 32, 0, n2, hl[2], wl[2], t1, 32, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
-        if ((rc = conv(c, c->enc[4], t1, 32, 0, n2, hl[2], wl[2], c->f[2].p, 32, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
-        if ((rc = conv(c, c->enc[5], c->f[2].p, 32, 0, n2, hl[2], wl[2], t0, 64, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
-        if ((rc = conv(c, c->enc[6], t0, 64, 0, n2, hl[3], wl[3], t1, 64, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
-        if ((rc = conv(c, c->enc[7], t1, 64, 0, n2, hl[3], wl[3], c->f[3].p, 64, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+        struct EStep { const float* in; float* out; int hin, win, hout, wout; };
+        const EStep es[8] = {{c->padded.p, t0, hp, wp, hl[1], wl[1]},     {t0, c->f[1].p, hl[1], wl[1], hl[1], wl[1]},
+                             {c->f[1].p, t0, hl[1], wl[1], hl[2], wl[2]}, {t0, t1, hl[2], wl[2], hl[2], wl[2]},
+                             {t1, c->f[2].p, hl[2], wl[2], hl[2], wl[2]}, {c->f[2].p, t0, hl[2], wl[2], hl[3], wl[3]},
+                             {t0, t1, hl[3], wl[3], hl[3], wl[3]},        {t1, c->f[3].p, hl[3], wl[3], hl[3], wl[3]}};
+        for (int i = 0; i < 8; ++i) {
+            const PLayer& L = c->enc[i];
+            if (c->enc_fast) {
+                EncConvArgs a;
+                memset(&a, 0, sizeof(a));
+                a.in0 = es[i].in; a.in1 = nullptr;
+                a.wpk = c->arena + c->enc_w[i];
+                a.wpk2 = c->enc_has2[i] ? c->arena + c->enc_w2[i] : nullptr;
+                a.wwino = c->enc_wino[i] ? c->wino + c->wino_off[i] : nullptr;
+                a.zero_page = c->arena + c->zero_off;
+                a.trash = c->arena + c->zero_off + 1024;
+                a.bias = c->arena + L.bias;
+                a.out = es[i].out;
+                a.nimg = n2; a.nimg0 = n2;
+                a.hin = es[i].hin; a.win = es[i].win; a.hout = es[i].hout; a.wout = es[i].wout;
+                a.hraw = es[i].hin; a.wraw = es[i].win;
+                a.act = 1;
+                if ((rc = enc_conv_launch(L.cin, L.cout, L.stride, a, st)) != EEM_OK) return rc;
+            } else if ((rc = conv(c, L, es[i].in, L.cin, 0, n2, es[i].hin, es[i].win, es[i].out, L.cout, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) {
+                return rc;
+            }
+        }
     }
     for (int l = 4; l <= 6; ++l)                                                       // avg_pool2d(2,2) x3 (:170-175)
         if ((rc = er_pool2_launch(c->f[l - 1].p, c->f[l].p, (long)n2 * 64, hl[l - 1], wl[l - 1], st)) != EEM_OK) return rc;

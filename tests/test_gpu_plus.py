@@ -84,3 +84,24 @@ def test_errors():
     net.change_imagesize((64, 64))
     with pytest.raises(_lib.EEMFlowHipError):
         net(torch.zeros(1, 5, 64, 64), torch.zeros(1, 5, 64, 64))
+
+
+def test_fast_encoder_equals_generic_encoder(monkeypatch):
+    """EEMFlow+'s encoder is EEMFlow's: with 5 input channels it runs on the encoder kernels (enc1 / Winograd / enc2);
+    EEM_PLUS_GENERIC_ENC=1 (read when the weights are loaded) keeps it on the generic conv.  Same coarsest flow to fp32
+    round-off; the finer levels may differ where a warp mask sits on its >= 1.0 threshold."""
+    h, w = 256, 320
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(61, 1, h, w, bins=5))
+
+    def run():
+        net = make_net(62, 5)
+        net.change_imagesize((h, w))
+        with torch.no_grad():
+            return torch.stack(net(e1, e2)[1]).cpu().numpy()
+    fast = run()
+    monkeypatch.setenv("EEM_PLUS_GENERIC_ENC", "1")
+    gen = run()
+    err = np.abs(fast - gen)
+    assert err[0].max() < 1e-4
+    for i in range(1, 5):
+        assert np.median(err[i]) < 2e-3 and (err[i] > 0.25).mean() < 0.02 and err[i].max() < 2.0, i   # bounds of the golden test

@@ -101,6 +101,55 @@ __global__ __launch_bounds__(256) void corr_kernel(CorrArgs a) {
     if (live && sub == 0) jb.out[((size_t)b * jb.out_ctotal + ti) * hw + p] = s / (float)jb.c;
 }
 
+// The same correlation for large maps (EEMFlow+'s fine pyramid levels: 180x320 pixels): a block owns a 16x16-pixel tile,
+// the f2 patch with its 4-pixel halo goes through LDS eight channels at a time (zeros outside the image), every thread keeps
+// its pixel's 53 tap sums in registers and reads f1 once per channel - instead of re-reading f1 for every tap and spending
+// four lanes per output.
+template <int NT>
+__global__ __launch_bounds__(256) void corr_tiled_kernel(CorrArgs a, int tiles_x) {
+    constexpr int CK = 8, TS = 16, HS = TS + 8, PITCH = HS + 1;
+    __shared__ float tile[CK][HS][PITCH];
+    const int ji = blockIdx.z / a.batch, b = blockIdx.z % a.batch;
+    const CorrJob jb = a.job[ji];
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int y0 = ty * TS, x0 = tx * TS;
+    const int y = y0 + ly, x = x0 + lx;
+    const bool inside = y < a.h && x < a.w;
+    const int hw = a.h * a.w;
+    int off[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { const int tap = a.taps[t]; off[t] = (tap / 9) * PITCH + (tap % 9); }   // window origin = (-4, -4)
+    float s[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) s[t] = 0.f;
+    const float* f1 = jb.f1 + (size_t)b * jb.c * hw;
+    const float* f2 = jb.f2 + (size_t)b * jb.c * hw;
+    const int p = inside ? y * a.w + x : 0;
+    for (int c0 = 0; c0 < jb.c; c0 += CK) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < CK * HS * HS; e += 256) {
+            const int c = e / (HS * HS), r = e - c * (HS * HS);
+            const int ry = r / HS, rx = r - ry * HS;
+            const int gy = y0 - 4 + ry, gx = x0 - 4 + rx;
+            const bool ok = c0 + c < jb.c && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+            tile[c][ry][rx] = ok ? f2[(size_t)(c0 + c) * hw + gy * a.w + gx] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CK; ++c) {
+            const float v = (inside && c0 + c < jb.c) ? f1[(size_t)(c0 + c) * hw + p] : 0.f;
+            const float* base = &tile[c][ly][lx];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) s[t] = fmaf(v, base[off[t]], s[t]);
+        }
+    }
+    if (!inside) return;
+    const float inv = 1.f / (float)jb.c;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) jb.out[((size_t)b * jb.out_ctotal + t) * hw + p] = s[t] * inv;
+}
+
 // ------------------------------------------------------------------------------- small-grid conv
 // D[cout 16][pixel 16] tiles on v_mfma_f32_16x16x4_f32; pixels are the flattened (y*w+x) index.
 // One wave per filter tap (9 waves for 3x3): a wave's K range is its tap x all channel groups, so the
@@ -254,6 +303,13 @@ int corr_launch(const CorrJob* jobs, int njobs, int batch, int h, int w, const i
     a.njobs = njobs; a.batch = batch; a.h = h; a.w = w; a.ntaps = ntaps; a.taps = taps_dev;
     const long total = (long)njobs * batch * ntaps * h * w;
     if (total == 0) return EEM_OK;
+    static const bool plain = [] { const char* e = getenv("EEM_CORR_PLAIN"); return e && e[0] == '1'; }();
+    if (!plain && ntaps == 53 && (long)h * w >= 4096) {
+        const int tiles_x = ceil_div(w, 16);
+        hipLaunchKernelGGL((corr_tiled_kernel<53>), dim3(tiles_x * ceil_div(h, 16), 1, njobs * batch), dim3(256), 0, stream, a, tiles_x);
+        EEM_HIP_CHECK(hipGetLastError());
+        return EEM_OK;
+    }
     hipLaunchKernelGGL(corr_kernel, dim3((unsigned)((total * 4 + 255) / 256)), dim3(256), 0, stream, a);   // 4 lanes per output
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;

@@ -304,7 +304,7 @@ int corr_launch(const CorrJob* jobs, int njobs, int batch, int h, int w, const i
     const long total = (long)njobs * batch * ntaps * h * w;
     if (total == 0) return EEM_OK;
     static const bool plain = [] { const char* e = getenv("EEM_CORR_PLAIN"); return e && e[0] == '1'; }();
-    if (!plain && ntaps == 53 && (long)h * w >= 4096) {
+    if (!plain && ntaps == 53 && (long)h * w >= 32768) {                 // below: too few 16x16 tiles to fill the chip
         const int tiles_x = ceil_div(w, 16);
         hipLaunchKernelGGL((corr_tiled_kernel<53>), dim3(tiles_x * ceil_div(h, 16), 1, njobs * batch), dim3(256), 0, stream, a, tiles_x);
         EEM_HIP_CHECK(hipGetLastError());

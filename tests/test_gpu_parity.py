@@ -171,6 +171,19 @@ def test_local_corr_golden(golden):
     assert maxerr(out, g["cv53"]) < 1e-5
 
 
+@pytest.mark.parametrize("b,c,h,w", [(1, 32, 192, 320), (2, 20, 181, 203)])
+def test_local_corr_large_maps_vs_oracle(b, c, h, w):
+    """Maps of >= 32768 pixels take the tiled correlation kernel (16x16 tiles, f2 patch in LDS); ragged tiles, a channel count
+    that is not a multiple of the 8-channel chunk, batch 2 - against the oracle."""
+    gen = torch.Generator().manual_seed(7)
+    x, y = torch.randn(b, c, h, w, generator=gen), torch.randn(b, c, h, w, generator=gen)
+    out = torch.empty(b, 53, h, w, device=DEV)
+    xd, yd = x.to(DEV), y.to(DEV)
+    _lib.check(_lib.lib().eemflow_local_corr53(xd.data_ptr(), yd.data_ptr(), b, c, h, w, out.data_ptr(),
+                                               _lib.current_stream_ptr(torch.device(DEV))))
+    assert maxerr(out, O.local_corr53(x, y)) < 1e-5
+
+
 @pytest.mark.parametrize("shape,size", [((2, 2, 12, 20), (720, 1280)), ((1, 2, 5, 6), (260, 346)),
                                         ((3, 2, 4, 7), (16, 16)), ((1, 2, 9, 9), (5, 31))])
 def test_upsample_vs_torch(shape, size):

@@ -1,8 +1,9 @@
 // Stride-1 convolutions with 16-channel-aligned inputs (E-RAFT's update block and residual stacks, EEMFlow+'s decoders:
-// 1x1, 3x3, 1x5, 5x1 kernels, 64..384 -> 64..576 channels, inputs that are the concatenation of up to three tensors) as an
+// 1x1, 3x3, 1x5, 5x1 kernels, 32..384 -> 16..576 channels, inputs that are the concatenation of up to three tensors) as an
 // LDS-tiled implicit GEMM on v_mfma_f32_16x16x4_f32.  The generic kernel of gconv.hip reads both operands of every MFMA
 // straight from L2 (two 256-byte loads per MFMA, 44 TFLOP/s at best); here
-//   * a block = 4 waves = one 64-cout chunk x a 4x16-pixel tile; wave w owns the 16 couts of M-tile w and all four pixel rows
+//   * a block = 4 waves = one 64-cout chunk x a 4x16-pixel tile (2x16 for launches of few blocks, whose run time is quantised
+//     in whole blocks per CU); wave w owns the 16 couts of M-tile w and all pixel rows
 //     (N-tiles), so every weight fragment feeds four MFMAs and every input fragment is read once per wave from LDS (layers
 //     of <= 32 couts: two M-tiles x two row groups per block, so no wave idles);
 //   * the input is consumed in chunks of 16 channels: the chunk's haloed tile [16][4 + KH - 1][24] (columns x0 - 4 .. x0 + 19)

@@ -12,6 +12,24 @@ __global__ __launch_bounds__(256) void pad_kernel(const float* __restrict__ in, 
     out[idx] = in[(c * h + sy) * w + sx];
 }
 
+// four output pixels per thread (16-byte stores), 32-bit index arithmetic once per four pixels; the replicate clamp is per pixel
+__global__ __launch_bounds__(256) void pad4_kernel(const float* __restrict__ in, float* __restrict__ out, int nc, int h, int w,
+                                                   int left, int top, int oh, int ow) {
+    const int ow4 = ow >> 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)nc * oh * ow4) return;
+    const int x4 = (int)(idx % ow4);
+    const long row = idx / ow4;                                  // c * oh + y
+    const int y = (int)(row % oh);
+    const long c = row / oh;
+    const int sy = min(max(y - top, 0), h - 1);
+    const float* src = in + (c * h + sy) * w;
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = src[min(max(x4 * 4 + e - left, 0), w - 1)];
+    reinterpret_cast<f32x4*>(out)[idx] = v;
+}
+
 __device__ __forceinline__ float block_sum(float v, float* sh) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
@@ -352,7 +370,10 @@ inline unsigned blocks(long n) { return (unsigned)((n + 255) / 256); }
 
 int er_pad_launch(const float* in, float* out, int nc, int h, int w, int left, int right, int top, int bottom, hipStream_t st) {
     const int oh = h + top + bottom, ow = w + left + right;
-    hipLaunchKernelGGL(pad_kernel, dim3(blocks((long)nc * oh * ow)), dim3(256), 0, st, in, out, nc, h, w, left, top, oh, ow);
+    if ((ow & 3) == 0 && ((uintptr_t)out & 15) == 0)
+        hipLaunchKernelGGL(pad4_kernel, dim3(blocks((long)nc * oh * (ow / 4))), dim3(256), 0, st, in, out, nc, h, w, left, top, oh, ow);
+    else
+        hipLaunchKernelGGL(pad_kernel, dim3(blocks((long)nc * oh * ow)), dim3(256), 0, st, in, out, nc, h, w, left, top, oh, ow);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

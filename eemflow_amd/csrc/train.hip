@@ -103,6 +103,30 @@ __global__ __launch_bounds__(256) void poolbwd_kernel(const float* __restrict__ 
     g[idx] = r;
 }
 
+// four pixels per thread (w % 4 == 0, k % 4 == 0: the four share one pooled cell), 32-bit index arithmetic
+__global__ __launch_bounds__(256) void poolbwd4_kernel(const float* __restrict__ dpool, float* __restrict__ g, long nc, int h, int w,
+                                                       int k, int gh, int gw, int accumulate, const float* __restrict__ gate) {
+    const int w4 = w >> 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nc * h * w4) return;
+    const int x4 = (int)(idx % w4);
+    const long row = idx / w4;
+    const int y = (int)(row % h);
+    const long c = row / h;
+    const int py = y / k, px = (x4 * 4) / k;
+    const float v = (py < gh && px < gw) ? dpool[(c * gh + py) * gw + px] / (float)(k * k) : 0.f;
+    f32x4* g4 = reinterpret_cast<f32x4*>(g);
+    f32x4 r = accumulate ? g4[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] += v;
+    if (gate) {
+        const f32x4 gt = reinterpret_cast<const f32x4*>(gate)[idx];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] *= gt[e] > 0.f ? 1.f : 0.1f;
+    }
+    g4[idx] = r;
+}
+
 // ---- local correlation backward (the transpose of corr_kernel in tail.hip):
 // dx[b][c][p] += (1/C) sum_t dcv[b][t][p] * y[b][c][p + d_t];   dy[b][c][q] = (1/C) sum_t dcv[b][t][q - d_t] * x[b][c][q - d_t]
 __global__ __launch_bounds__(256) void corrbwd_kernel(const float* __restrict__ dcv, int dcv_ctotal, const float* __restrict__ f1,
@@ -425,7 +449,10 @@ int tr_upsample_bwd_launch(const float* d, float* tmp, float* out, int nc, int o
 
 int tr_pool_bwd_launch(const float* dpool, float* g, long nc, int h, int w, int k, int gh, int gw, int accumulate, const float* gate,
                        hipStream_t st) {
-    hipLaunchKernelGGL(poolbwd_kernel, dim3(nblocks(nc * h * w)), dim3(256), 0, st, dpool, g, nc, h, w, k, gh, gw, accumulate, gate);
+    if ((w & 3) == 0 && (k & 3) == 0 && (((uintptr_t)g | (uintptr_t)gate) & 15) == 0)
+        hipLaunchKernelGGL(poolbwd4_kernel, dim3(nblocks(nc * h * (w / 4))), dim3(256), 0, st, dpool, g, nc, h, w, k, gh, gw, accumulate, gate);
+    else
+        hipLaunchKernelGGL(poolbwd_kernel, dim3(nblocks(nc * h * w)), dim3(256), 0, st, dpool, g, nc, h, w, k, gh, gw, accumulate, gate);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

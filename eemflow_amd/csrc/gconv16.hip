@@ -134,9 +134,17 @@ __global__ __launch_bounds__(256, (KH * KW == 9 && THT == 4 && WM == 4) ? 3 : 4)
                         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[((ky * KW + kx) * 4) + cg], bv[t], acc[t], 0, 0, 0);
                 }
     };
+    // After the explicit wait the fragments of the current chunk have landed; passing them through an empty asm tells the
+    // compiler so - otherwise it guards their first use with its own s_waitcnt vmcnt(0), which also waits for the NEXT chunk's
+    // loads issued just above it and serialises the whole prefetch.
+    auto landed = [&](float (&wr)[C::KS]) {
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) asm volatile("" : "+v"(wr[ks]));
+    };
 #pragma unroll 1
     for (int ch = 0; ch < nchunks; ch += 2) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        landed(wA);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (ch + 1 < nchunks) { issue(1, ch + 1); load_w(ch + 1, wB); }
@@ -144,6 +152,7 @@ __global__ __launch_bounds__(256, (KH * KW == 9 && THT == 4 && WM == 4) ? 3 : 4)
         compute(lds, wA);
         if (ch + 1 >= nchunks) break;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        landed(wB);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (ch + 2 < nchunks) { issue(0, ch + 2); load_w(ch + 2, wA); }

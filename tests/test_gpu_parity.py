@@ -285,6 +285,22 @@ def test_voxelizer_binned_path_equals_direct_path_and_oracle(monkeypatch, h, w, 
         np.testing.assert_allclose(got, ref_norm, atol=3e-5, rtol=1e-5)
 
 
+def test_voxelizer_more_than_512_blocks(monkeypatch):
+    """5.2e6 events: the binning kernel runs 8 events per thread and more than 512 blocks (run table sized by event count); the
+    band kernel walks the slabs in groups of 1024.  Against the direct atomic kernel of the same library."""
+    n, h, w, bins = 5_200_000, 720, 1280, 5
+    rng = np.random.default_rng(11)
+    ev = np.stack([np.sort(rng.uniform(0, 0.05, n)), rng.integers(0, w, n).astype(np.float64),
+                   rng.integers(0, h, n).astype(np.float64), rng.integers(0, 2, n) * 2.0 - 1.0], 1)
+    seq = EventSequence(None, {"height": h, "width": w}, features=ev, timestamp_multiplier=1e6, convert_to_relative=True)
+    vox = EventSequenceToVoxelGrid_Pytorch(bins, gpu=True, normalize=True, forkserver=False)
+    binned, il, ir = vox(seq, return_indices=True)
+    monkeypatch.setenv("EEM_VOX_DIRECT", "1")
+    direct, il2, ir2 = vox(seq, return_indices=True)
+    assert torch.equal(il, il2) and torch.equal(ir, ir2)
+    assert float((binned - direct).abs().max()) < 2e-4 and float(direct.abs().max()) > 1.0
+
+
 def test_voxelizer_alternating_streams_share_the_scratch_safely():
     """Calls from one thread on two streams use the same scratch arena; the library orders them with an event."""
     h, w, bins = 260, 346, 5

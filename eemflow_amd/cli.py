@@ -1,0 +1,146 @@
+"""Command-line entry points with the flags of the reference's train_EEMFlow_HREM.py:139-156 / test_EEMFlow_HREM.py:124-140.
+
+    python -m eemflow_amd.cli train [flags]      # train_EEMFlow_HREM.py: HREM meshflow training, checkpoint per epoch
+    python -m eemflow_amd.cli test  [flags]      # test_EEMFlow_HREM.py: evaluation over every sequence of the HREM test split
+
+Same flags and defaults as the reference scripts (`--lr --wd --train_iters --val_iters --batch_size --input_type --model_name
+--start-epoch --num_workers --test_only --test_sequence ...`), the `lr{lr}_we{wd}` run folder, `config.json` / `train.log` /
+`lasted_ckpt.pth.tar` in it, checkpoint loading with 'module.' stripping.  Added: `--data_root` (the reference hard-wires its own
+repository path), `--save_root`, `--checkpoint`, `--config` (a JSON like the reference's config/a_meshflow.json; its training and
+loader defaults are built in).  Dropped: visualisation, xlsx export, git metadata, nn.DataParallel (one process per GPU:
+launch with torchrun for data parallelism; see eemflow_amd.parallel).  Only the models built here are accepted (EEMFlow; for
+`test` also `eraft` and `EEMFlow+`).
+"""
+import argparse
+import copy
+import json
+import os
+
+import torch
+
+# the fields of config/a_meshflow.json the scripts read (train_EEMFlow_HREM.py:25-68, train_mvsec.py:178-183)
+DEFAULT_CONFIG = {
+    "name": "mesh_flow",
+    "train_img_size": [512, 960],
+    "val_img_size": [720, 1280],
+    "data_loader": {
+        "train": {"args": {"batch_size": 6, "shuffle": True, "sequence_length": 1, "num_voxel_bins": 5, "eval_type": "dense",
+                           "aug_params": {"crop_size": [512, 960], "min_scale": -0.1, "max_scale": 1.0, "do_flip": True}}},
+        "test": {"args": {"batch_size": 1, "shuffle": False, "sequence_length": 1, "num_voxel_bins": 5, "align_to": "images",
+                          "eval_type": "dense"}},
+    },
+    "train": {"lr": 1e-4, "wdecay": 5e-5, "epsilon": 1e-8, "num_steps": 1000000, "mixed_precision": True, "gamma": 0.8, "clip": 1.0},
+}
+
+
+def build_parser():
+    p = argparse.ArgumentParser(prog="eemflow_amd.cli", description=__doc__.split("\n\n")[0])
+    sub = p.add_subparsers(dest="command", required=True)
+
+    def common(q, train):
+        q.add_argument('-v', '--visualize', action='store_true', help='accepted for compatibility; visualisation is not built')
+        q.add_argument('-n', '--num_workers', default=0, type=int, help='accepted for compatibility; samples are voxelized on the GPU in-process')
+        q.add_argument('--train_iters', default=6000000 if train else 1000000, type=int, metavar='N', help='number of total iterations')
+        q.add_argument('-se', '--start-epoch', action='store_true', help='restart from lasted_ckpt.pth.tar of the run folder')
+        q.add_argument('-be', '--best_epe', default=1e5, type=float)
+        q.add_argument('--val_iters', default=10000 if train else 3000, type=int, metavar='N', help='iterations per epoch (checkpoint interval)')
+        q.add_argument('--lr', default=1e-5 if train else 1e-4, type=float, help='learning rate')
+        q.add_argument('--wd', default=0 if train else 1e-5, type=float, help='weight decay')
+        q.add_argument('--batch_size', '-bs', default=6 if train else 2, type=int, help='batch size in training')
+        q.add_argument('--test_only', action='store_true')
+        q.add_argument('--test_sequence', '-sq', default='indoor_flying2' if train else '', type=str)
+        q.add_argument('--dense', action='store_true')
+        q.add_argument('--density', '-d', default='ct0.05', type=str)
+        q.add_argument('--model_name', '-model', default='EEMFlow', type=str)
+        q.add_argument('--input_type', '-int', default='dt1', type=str)
+        q.add_argument('--is_using_dynamic', '-dynamic', action='store_true')
+        q.add_argument('--data_root', default=os.environ.get("EEMFLOW_DATA_ROOT", os.getcwd()), help='folder that holds dataset/HREM/...')
+        q.add_argument('--save_root', default=os.getcwd(), help='where exp_HREM_meshflow/ (train) or HREM_testset/ (test) is created')
+        q.add_argument('--checkpoint', default=None, help='test: checkpoint file (default <save_root>/checkpoints/EEMFlow_HREM_<input_type>.pth.tar)')
+        q.add_argument('--config', default=None, help='JSON with the layout of config/a_meshflow.json (default: built-in copy of its used fields)')
+        q.add_argument('--device', default='cuda:0')
+    common(sub.add_parser('train', help='train_EEMFlow_HREM.py'), True)
+    common(sub.add_parser('test', help='test_EEMFlow_HREM.py'), False)
+    return p
+
+
+def load_config(path):
+    return json.load(open(path)) if path else copy.deepcopy(DEFAULT_CONFIG)
+
+
+def build_model(name, config, training):
+    if name == "EEMFlow":
+        from .eemflow import EEMFlow
+        # HREM's training target is the 16x16 mesh flow (HREM.py:254-255); the reference script builds the model without
+        # out_mesh_size and its loss then meets a full-resolution prediction.  Training here predicts at mesh size
+        # (EEMFlow.py:126-132), evaluation at full resolution against the upsampled mesh flow (HREM.py:264-267).
+        return EEMFlow(config=config, n_first_channels=5, out_mesh_size=training)
+    if not training and name == "eraft":
+        from .eraft import ERAFT
+        return ERAFT(config=config, n_first_channels=config['data_loader']['test']['args']['num_voxel_bins'])
+    if not training and name in ("EEMFlow+", "EEMFlow_cdc"):
+        from .eemflow_plus import EEMFlow_cdc
+        return EEMFlow_cdc(config=config, n_first_channels=5)
+    raise SystemExit(f"model '{name}' is not built here (EEMFlow{'' if training else ', eraft, EEMFlow+'})")
+
+
+def train(args):
+    from . import harness
+    from .hrem import HREMEventFlow
+    config = load_config(args.config)
+    model = build_model(args.model_name, config, training=True)
+    config["train"]["lr"] = args.lr                                                  # train_EEMFlow_HREM.py:56-59
+    config["train"]["wdecay"] = args.wd
+    config["train"]["num_steps"] = args.train_iters
+    config['data_loader']['train']['args']['batch_size'] = args.batch_size
+    config['name'] = "lr{:5f}_we{:5f}".format(args.lr, args.wd)
+    save_path = os.path.join(args.save_root, "exp_HREM_meshflow/{}_{}".format(args.model_name, args.input_type), config['name'].lower())
+    os.makedirs(save_path, exist_ok=True)
+    config["data_loader"]["train"]["args"].update({'type': 'train', 'event_interval': args.input_type})
+    print('Storing output in folder {}'.format(save_path))
+    json.dump(config, open(os.path.join(save_path, 'config.json'), 'w'), indent=4, sort_keys=False)
+    start_epoch = 0
+    if args.start_epoch:
+        start_epoch = harness.load_checkpoint(os.path.join(save_path, 'lasted_ckpt.pth.tar'), model)
+    logger = harness.Logger(os.path.join(save_path, 'train.log'))
+    dev = torch.device(args.device)
+    train_set = HREMEventFlow(args=config["data_loader"]["train"]["args"], train=True, root=args.data_root, device=dev)
+    loader = torch.utils.data.DataLoader(train_set, batch_size=args.batch_size, shuffle=True, num_workers=0, drop_last=True)
+    model = model.to(dev)
+    tcfg = config["train"]
+    tr = harness.TrainRaftEvents(loader, tuple(config["val_img_size"]), lr=tcfg["lr"], wdecay=tcfg["wdecay"], epsilon=tcfg["epsilon"],
+                                 num_steps=tcfg["num_steps"], clip=tcfg["clip"], gamma=tcfg["gamma"], logger=logger)
+    for epoch in range(start_epoch, max(args.train_iters // args.val_iters, 1)):
+        model = tr.train_iters(model, start_epoch=epoch, val_iters=args.val_iters)
+        harness.save_checkpoint(os.path.join(save_path, 'lasted_ckpt.pth.tar'), model, epoch, trainer=tr.trainer)
+    return save_path
+
+
+def test(args):
+    from . import harness
+    from .hrem import HREMEventFlow
+    config = load_config(args.config)
+    model = build_model(args.model_name, config, training=False)
+    ckpt = args.checkpoint or os.path.join(args.save_root, 'checkpoints', 'EEMFlow_HREM_{}.pth.tar'.format(args.input_type))
+    start_epoch = harness.load_checkpoint(ckpt, model)
+    save_path = os.path.join(args.save_root, "HREM_testset/{}_{}".format(args.model_name, args.input_type))
+    os.makedirs(save_path, exist_ok=True)
+    config["data_loader"]["test"]["args"].update({"event_interval": args.input_type})
+    print('Storing output in folder {}'.format(save_path))
+    json.dump(config, open(os.path.join(save_path, 'config.json'), 'w'), indent=4, sort_keys=False)
+    logger = harness.Logger(os.path.join(save_path, 'test.log'))
+    dev = torch.device(args.device)
+    test_set = HREMEventFlow(args=config["data_loader"]["test"]["args"], train=False, root=args.data_root, device=dev)
+    model = model.to(dev)
+    sequences = [args.test_sequence] if args.test_sequence else list(test_set.nori_list.keys())
+    ev = harness.TestRaftEvents(test_set, tuple(config["val_img_size"]), logger=logger)
+    return ev.test_multi_sequence(model, start_epoch + 1, sequence_list=sequences, stride=1)
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    return train(args) if args.command == 'train' else test(args)
+
+
+if __name__ == '__main__':
+    main()

@@ -206,3 +206,26 @@ def test_harness_evaluates_mvsec_sparse(tmp_path):
     net = net.to(DEV)
     aee = TestRaftEvents(ds, (256, 256)).test_multi_sequence(net, sequence_list=["indoor_flying2"], stride=1)
     assert np.isfinite(aee) and aee > 0
+
+
+def test_cli_train_then_test_on_synthetic_hrem(tmp_path):
+    """`python -m eemflow_amd.cli train / test` with the reference scripts' flags on a two-sample synthetic HREM tree: run folder,
+    config.json, train.log, lasted_ckpt.pth.tar (reference layout), then evaluation from that checkpoint."""
+    from eemflow_amd import cli
+    root = str(tmp_path)
+    for split, sub in (("test", "dt1/seqA/000001"), ("train", "dt1/000001"), ("train", "dt1/000002")):
+        d = os.path.join(root, "dataset/HREM", split, sub)
+        os.makedirs(d)
+        seed = 7 + len(sub)
+        hrem.write_events_npz(os.path.join(d, "events1.npz"), hrem.synthetic_hrem_events(seed, 20000, 720, 1280))
+        hrem.write_events_npz(os.path.join(d, "events2.npz"), hrem.synthetic_hrem_events(seed + 1, 20000, 720, 1280))
+        hrem.write_flo(os.path.join(d, "flow.flo"), hrem.synthetic_flow(seed + 2, 720, 1280))
+    common = ["--data_root", root, "--save_root", root, "--lr", "1e-4", "--wd", "1e-5"]
+    run = cli.main(["train", *common, "-bs", "2", "--train_iters", "2", "--val_iters", "1"])
+    assert run.endswith("exp_HREM_meshflow/EEMFlow_dt1/lr0.000100_we0.000010")
+    for f in ("config.json", "train.log", "lasted_ckpt.pth.tar"):
+        assert os.path.exists(os.path.join(run, f)), f
+    ck = torch.load(os.path.join(run, "lasted_ckpt.pth.tar"), weights_only=False)
+    assert ck["epoch"] == 1 and len(ck["state_dict"]) == 66 and "iteration" in ck
+    aee = cli.main(["test", *common, "--checkpoint", os.path.join(run, "lasted_ckpt.pth.tar")])
+    assert np.isfinite(aee) and os.path.exists(os.path.join(root, "HREM_testset/EEMFlow_dt1/test.log"))

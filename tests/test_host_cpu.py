@@ -135,3 +135,16 @@ def test_checkpoint_layout_round_trip(tmp_path):
     assert load_checkpoint(p, b) == 7
     for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
         assert ka == kb and torch.equal(va, vb)
+
+
+def test_cli_flags_match_reference_scripts():
+    """Flags and defaults of train_EEMFlow_HREM.py:139-156 / test_EEMFlow_HREM.py:124-140."""
+    from eemflow_amd import cli
+    p = cli.build_parser()
+    a = p.parse_args(["train"])
+    assert (a.train_iters, a.val_iters, a.lr, a.wd, a.batch_size, a.model_name, a.input_type, a.start_epoch, a.test_sequence) == \
+        (6000000, 10000, 1e-5, 0, 6, "EEMFlow", "dt1", False, "indoor_flying2")
+    b = p.parse_args(["test", "-bs", "4", "-int", "dt4", "-se", "-model", "eraft", "-sq", "s1", "-n", "2"])
+    assert (b.train_iters, b.val_iters, b.lr, b.wd, b.batch_size, b.input_type, b.start_epoch, b.model_name, b.test_sequence, b.num_workers) == \
+        (1000000, 3000, 1e-4, 1e-5, 4, "dt4", True, "eraft", "s1", 2)
+    assert cli.DEFAULT_CONFIG["train"]["gamma"] == 0.8 and cli.DEFAULT_CONFIG["val_img_size"] == [720, 1280]

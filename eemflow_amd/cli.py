@@ -85,8 +85,13 @@ def build_model(name, config, training):
 
 
 def train(args):
-    from . import harness
+    from . import harness, parallel
     from .hrem import HREMEventFlow
+    # one process per GPU under torchrun: every rank trains on its shard of the samples, the trainer all-reduces the flat gradient
+    # (RCCL), rank 0 writes the logs and checkpoints
+    rank, local_rank, world = parallel.init_distributed()
+    if world > 1:
+        args.device = "cuda:{}".format(local_rank)
     config = load_config(args.config)
     model = build_model(args.model_name, config, training=True)
     config["train"]["lr"] = args.lr                                                  # train_EEMFlow_HREM.py:56-59
@@ -102,17 +107,27 @@ def train(args):
     start_epoch = 0
     if args.start_epoch:
         start_epoch = harness.load_checkpoint(os.path.join(save_path, 'lasted_ckpt.pth.tar'), model)
-    logger = harness.Logger(os.path.join(save_path, 'train.log'))
+    logger = harness.Logger(os.path.join(save_path, 'train.log') if rank == 0 else None)
     dev = torch.device(args.device)
+    torch.cuda.set_device(dev)
     train_set = HREMEventFlow(args=config["data_loader"]["train"]["args"], train=True, root=args.data_root, device=dev)
-    loader = torch.utils.data.DataLoader(train_set, batch_size=args.batch_size, shuffle=True, num_workers=0, drop_last=True)
+    sampler = torch.utils.data.distributed.DistributedSampler(train_set, num_replicas=world, rank=rank, shuffle=True) if world > 1 else None
+    loader = torch.utils.data.DataLoader(train_set, batch_size=args.batch_size, shuffle=sampler is None, sampler=sampler, num_workers=0,
+                                         drop_last=True)
     model = model.to(dev)
+    if world > 1:                                                    # replicas start from rank 0's weights
+        for prm in model.parameters():
+            torch.distributed.broadcast(prm.data, src=0)
     tcfg = config["train"]
     tr = harness.TrainRaftEvents(loader, tuple(config["val_img_size"]), lr=tcfg["lr"], wdecay=tcfg["wdecay"], epsilon=tcfg["epsilon"],
                                  num_steps=tcfg["num_steps"], clip=tcfg["clip"], gamma=tcfg["gamma"], logger=logger)
     for epoch in range(start_epoch, max(args.train_iters // args.val_iters, 1)):
+        if sampler is not None:
+            sampler.set_epoch(epoch)
         model = tr.train_iters(model, start_epoch=epoch, val_iters=args.val_iters)
-        harness.save_checkpoint(os.path.join(save_path, 'lasted_ckpt.pth.tar'), model, epoch, trainer=tr.trainer)
+        if rank == 0:
+            harness.save_checkpoint(os.path.join(save_path, 'lasted_ckpt.pth.tar'), model, epoch, trainer=tr.trainer)
+    parallel.barrier(dev)
     return save_path
 
 

@@ -23,6 +23,13 @@ _SIGNATURES = {
     "eemflow_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     "eemflow_destroy": (None, [ctypes.c_void_p]),
     "eemflow_load_weights": (ctypes.c_int, [ctypes.c_void_p, _c_float_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int]),
+    "eemflow_update_weights": (ctypes.c_int, [ctypes.c_void_p, _c_float_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "eemflow_forward_train": (ctypes.c_int, [ctypes.c_void_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                             _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p]),
+    "eemflow_backward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
+                                        ctypes.c_void_p]),
+    "eemflow_sequence_loss": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                             _c_float_p, ctypes.c_void_p, ctypes.c_void_p]),
     "eemflow_set_image_size": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int * 4)]),
     "eemflow_use_graph": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "eemflow_forward": (ctypes.c_int, [ctypes.c_void_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,

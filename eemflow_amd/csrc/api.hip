@@ -223,7 +223,27 @@ extern "C" int eemflow_load_weights(eemflow_ctx* c, const float* flat, size_t nf
     c->groups = groups;
     c->weights_loaded = true;
     c->opt_step = 0;
+    c->have_train_fwd = false;
+    // a reloaded model starts a new optimisation: stale AdamW moments must not meet a fresh bias correction
+    if (c->adam_m.p) EEM_HIP_CHECK(hipMemset(c->adam_m.p, 0, c->adam_m.cap * sizeof(float)));
+    if (c->adam_v.p) EEM_HIP_CHECK(hipMemset(c->adam_v.p, 0, c->adam_v.cap * sizeof(float)));
     return EEM_OK;
+}
+
+// New values for the already laid-out parameters, from a DEVICE vector (state_dict order): one device-to-device copy
+// and the re-pack - what a training loop with its own optimizer needs after every step.  Optimizer state of
+// eemflow_optimizer_step is left alone (the caller owns the optimisation in that case).
+extern "C" int eemflow_update_weights(eemflow_ctx* c, const float* flat_device, size_t nfloats, void* stream) {
+    EEM_REQUIRE(c && flat_device, "eemflow_update_weights: NULL argument");
+    EEM_REQUIRE(c->weights_loaded, "eemflow_update_weights: call eemflow_load_weights once first (it builds the pack tables)");
+    EEM_REQUIRE(nfloats == c->nflat, "eemflow_update_weights: expected %zu floats, got %zu", c->nflat, nfloats);
+    EEM_HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    EEM_HIP_CHECK(hipMemcpyAsync(c->flat, flat_device, nfloats * sizeof(float), hipMemcpyDeviceToDevice, st));
+    int rc = repack_launch(c->flat, c->pack_idx, c->arena, (long)c->arena_floats, st);
+    if (rc != EEM_OK) return rc;
+    c->have_train_fwd = false;
+    return refresh_wino(c, st);
 }
 
 extern "C" int eemflow_set_image_size(eemflow_ctx* c, int height, int width, int pad_out[4]) {

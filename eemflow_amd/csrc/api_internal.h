@@ -82,6 +82,10 @@ struct eemflow_ctx {
     DevBuf padded, g_a1, g_f11, g_a2, g_b2, g_f12, g_a3, g_b3, g_f13, g_pool[3], g_cat[3], g_ta[3], g_tb[3], g_tc[3], g_td[3],
         g_t64[3], g_t32[3], g_flowcat, g_coarse, g_flow, ups_tmp, grad_flat, adam_m, adam_v, scalars;
     long opt_step = 0;
+    // eemflow_forward_train / eemflow_backward pairing: the serial of the forward whose activations the workspace holds
+    const float *train_e1 = nullptr, *train_e2 = nullptr;
+    bool have_train_fwd = false;
+    long train_serial = 0;
     int* taps = nullptr;
     // workspaces
     DevBuf a1, f11, a2, b2, f12, a3, b3, f13, pool[3], ppart[3], cat[3], ta[3], tb[3], tc[3], td[3], t64[3], t32[3], flowcat, coarse;

@@ -19,8 +19,8 @@ __global__ __launch_bounds__(256) void repack_kernel(const float* __restrict__ f
 __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ flow, const float* __restrict__ gt,
                                                    const float* __restrict__ valid, float* __restrict__ dflow, int batch, int hw,
                                                    float weight, double* __restrict__ stats) {
-    __shared__ double sh[4][5];
-    double l = 0, e = 0, cnt = 0, c1 = 0, c3 = 0;
+    __shared__ double sh[4][6];
+    double l = 0, e = 0, cnt = 0, c1 = 0, c3 = 0, c5 = 0;
     // grid-stride: the five f64 atomics at the end of a block land on one cache line and serialise (~14 ns each)
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < (long)batch * hw; idx += (long)gridDim.x * 256) {
         const int b = idx / hw, p = idx - (long)b * hw;
@@ -34,19 +34,19 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ flo
         if (ok) {
             l += (double)fabsf(dx) + (double)fabsf(dy);
             const float ep = sqrtf(dx * dx + dy * dy);
-            e += ep; cnt += 1; c1 += ep < 1.f; c3 += ep < 3.f;
+            e += ep; cnt += 1; c1 += ep < 1.f; c3 += ep < 3.f; c5 += ep < 5.f;
         }
     }
-    double v[5] = {l, e, cnt, c1, c3};
+    double v[6] = {l, e, cnt, c1, c3, c5};
 #pragma unroll
-    for (int k = 0; k < 5; ++k)
+    for (int k = 0; k < 6; ++k)
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) v[k] += __shfl_xor(v[k], d);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0)
-        for (int k = 0; k < 5; ++k) sh[wave][k] = v[k];
+        for (int k = 0; k < 6; ++k) sh[wave][k] = v[k];
     __syncthreads();
-    if (threadIdx.x < 5) atomicAdd(&stats[threadIdx.x], sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    if (threadIdx.x < 6) atomicAdd(&stats[threadIdx.x], sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
 // ---- adjoint of F.interpolate(bilinear, align_corners=False), separable and deterministic:

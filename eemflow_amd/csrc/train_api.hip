@@ -108,41 +108,18 @@ int alloc_train(eemflow_ctx* c, const Shape& s) {
 
 }  // namespace
 
-// Forward + loss + backward.  grad_out (device, nflat floats, state_dict order) receives d loss / d parameter;
-// stats_out (host, 5 doubles): loss, mean epe, valid count, fraction < 1 px, fraction < 3 px.
-extern "C" int eemflow_forward_backward(eemflow_ctx* c, const float* e1, const float* e2, const float* flow_gt, const float* valid,
-                                        int batch, int in_h, int in_w, int out_h, int out_w, float gamma_weight, float* flow_out,
-                                        float* grad_out, double* stats_out, void* stream) {
-    EEM_REQUIRE(c && e1 && e2 && flow_gt && valid && grad_out && flow_out, "eemflow_forward_backward: NULL argument");
-    EEM_REQUIRE(c->weights_loaded && c->have_pad, "eemflow_forward_backward: load weights and set the image size first");
-    EEM_REQUIRE(c->groups == 5, "eemflow_forward_backward: only groups == 5 is built for training");
-    EEM_HIP_CHECK(hipSetDevice(c->device));
-    hipStream_t st = (hipStream_t)stream;
-    Shape s;
-    int rc = compute_shape(c, batch, in_h, in_w, out_h, out_w, &s);
-    if (rc != EEM_OK) return rc;
-    drop_graph(c);
-    if ((rc = alloc_workspace(c, s)) != EEM_OK) return rc;
-    if ((rc = alloc_train(c, s)) != EEM_OK) return rc;
-    c->last = s;
-    c->have_last = true;
-    const int B = batch, n2 = 2 * batch;
+// Backward pass of the LAST eager forward of this context (its activations are still in the workspace): dflow
+// [B][2][out_h][out_w] -> flat gradient (state_dict order).  e1 / e2 are that forward's inputs (pconv1_1's weight
+// gradient reads them through the replicate pad).
+static int backward_impl(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2, const float* dflow, float* grad_out,
+                         hipStream_t st) {
+    int rc;
+    const int B = s.batch, n2 = 2 * s.batch, in_h = s.in_h, in_w = s.in_w;
     const size_t g = (size_t)s.gh * s.gw;
-
-    // ---- forward (eager: every activation stays in its workspace buffer)
-    float* flow = flow_out;
-    Hook hk;
-    hk.st = st;
-    if ((rc = run_forward(c, s, e1, e2, flow, hk)) != EEM_OK) return rc;
-
     Bwd bw{c, st, grad_out};
     EEM_HIP_CHECK(hipMemsetAsync(grad_out, 0, c->nflat * sizeof(float), st));
-    double* stats = (double*)c->scalars.p;
-    EEM_HIP_CHECK(hipMemsetAsync(stats, 0, 8 * sizeof(double), st));
-    // ---- loss and d loss / d flow (train_mvsec.py:201-227)
-    if ((rc = tr_loss_launch(flow, flow_gt, valid, c->g_flow.p, B, s.out_h * s.out_w, gamma_weight, stats, st)) != EEM_OK) return rc;
     // ---- upsample backward (EEMFlow.py:118-120)
-    if ((rc = tr_upsample_bwd_launch(c->g_flow.p, c->ups_tmp.p, c->g_coarse.p, B * 2, s.out_h, s.out_w, s.gh, s.gw, st)) != EEM_OK) return rc;
+    if ((rc = tr_upsample_bwd_launch(dflow, c->ups_tmp.p, c->g_coarse.p, B * 2, s.out_h, s.out_w, s.gh, s.gw, st)) != EEM_OK) return rc;
     // ---- the 1/64-grid tail, last layer first.  Weight / bias gradients: one launch per conv.  Data gradients: the
     // same conv layer of all three decoders (and all five groups) as the jobs of ONE tail_conv_kernel launch - a 9-way
     // K split per block like the forward, instead of 60 register-gather launches of 32 blocks each.
@@ -268,6 +245,83 @@ extern "C" int eemflow_forward_backward(eemflow_ctx* c, const float* e1, const f
             if (l.layer == ENC_2_1 && (rc = tr_pool_bwd_launch(c->g_pool[0].p, c->g_f11.p, (long)n2 * 16, s.h1, s.w1, 32, s.gh, s.gw, 1, c->f11.p, st)) != EEM_OK) return rc;
         }
     }
+    return EEM_OK;
+}
+
+// Eager forward that keeps every activation for a following eemflow_backward (train-mode output size).
+static int forward_train_impl(eemflow_ctx* c, const float* e1, const float* e2, int batch, int in_h, int in_w, int out_h, int out_w,
+                              float* flow_out, hipStream_t st, Shape* sout) {
+    Shape s;
+    int rc = compute_shape(c, batch, in_h, in_w, out_h, out_w, &s);
+    if (rc != EEM_OK) return rc;
+    drop_graph(c);
+    if ((rc = alloc_workspace(c, s)) != EEM_OK) return rc;
+    if ((rc = alloc_train(c, s)) != EEM_OK) return rc;
+    c->last = s;
+    c->have_last = true;
+    c->train_e1 = e1;
+    c->train_e2 = e2;
+    c->have_train_fwd = false;
+    Hook hk;
+    hk.st = st;
+    if ((rc = run_forward(c, s, e1, e2, flow_out, hk)) != EEM_OK) return rc;
+    c->have_train_fwd = true;
+    c->train_serial += 1;
+    *sout = s;
+    return EEM_OK;
+}
+
+extern "C" int eemflow_forward_train(eemflow_ctx* c, const float* e1, const float* e2, int batch, int in_h, int in_w, float* flow_out,
+                                     int out_h, int out_w, int64_t* serial_out, void* stream) {
+    EEM_REQUIRE(c && e1 && e2 && flow_out, "eemflow_forward_train: NULL argument");
+    EEM_REQUIRE(c->weights_loaded && c->have_pad, "eemflow_forward_train: load weights and set the image size first");
+    EEM_REQUIRE(c->groups == 5, "eemflow_forward_train: only groups == 5 is built for training");
+    EEM_REQUIRE(batch >= 1 && in_h >= 1 && in_w >= 1 && out_h >= 1 && out_w >= 1, "eemflow_forward_train: bad sizes");
+    EEM_HIP_CHECK(hipSetDevice(c->device));
+    Shape s;
+    int rc = forward_train_impl(c, e1, e2, batch, in_h, in_w, out_h, out_w, flow_out, (hipStream_t)stream, &s);
+    if (rc == EEM_OK && serial_out) *serial_out = c->train_serial;
+    return rc;
+}
+
+extern "C" int eemflow_backward(eemflow_ctx* c, int64_t serial, const float* e1, const float* e2, const float* dflow, float* grad_out,
+                                void* stream) {
+    EEM_REQUIRE(c && e1 && e2 && dflow && grad_out, "eemflow_backward: NULL argument");
+    EEM_REQUIRE(c->have_train_fwd, "eemflow_backward: no eemflow_forward_train has run on this context");
+    EEM_REQUIRE(serial == c->train_serial, "eemflow_backward: the activations of forward %lld were overwritten by forward %lld "
+                "(one forward per backward and context; run eemflow_forward_train again)", (long long)serial, (long long)c->train_serial);
+    EEM_HIP_CHECK(hipSetDevice(c->device));
+    return backward_impl(c, c->last, e1, e2, dflow, grad_out, (hipStream_t)stream);
+}
+
+// sequence_loss term of one prediction + its gradient, on the device (no host synchronisation): stats6 (device, 6 doubles,
+// ACCUMULATED - zero them first): sum of valid |flow - gt|, sum EPE, valid count, count(EPE < 1), count(EPE < 3), count(EPE < 5).
+extern "C" int eemflow_sequence_loss(const float* flow, const float* flow_gt, const float* valid, int batch, int h, int w, float weight,
+                                     float* dflow_out, double* stats6, void* stream) {
+    EEM_REQUIRE(flow && flow_gt && valid && dflow_out && stats6, "eemflow_sequence_loss: NULL argument");
+    EEM_REQUIRE(batch >= 1 && h >= 1 && w >= 1, "eemflow_sequence_loss: bad sizes");
+    return tr_loss_launch(flow, flow_gt, valid, dflow_out, batch, h * w, weight, stats6, (hipStream_t)stream);
+}
+
+// Forward + loss + backward.  grad_out (device, nflat floats, state_dict order) receives d loss / d parameter;
+// stats_out (host, 5 doubles): loss, mean epe, valid count, fraction < 1 px, fraction < 3 px.
+extern "C" int eemflow_forward_backward(eemflow_ctx* c, const float* e1, const float* e2, const float* flow_gt, const float* valid,
+                                        int batch, int in_h, int in_w, int out_h, int out_w, float gamma_weight, float* flow_out,
+                                        float* grad_out, double* stats_out, void* stream) {
+    EEM_REQUIRE(c && e1 && e2 && flow_gt && valid && grad_out && flow_out, "eemflow_forward_backward: NULL argument");
+    EEM_REQUIRE(c->weights_loaded && c->have_pad, "eemflow_forward_backward: load weights and set the image size first");
+    EEM_REQUIRE(c->groups == 5, "eemflow_forward_backward: only groups == 5 is built for training");
+    EEM_HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    Shape s;
+    int rc = forward_train_impl(c, e1, e2, batch, in_h, in_w, out_h, out_w, flow_out, st, &s);
+    if (rc != EEM_OK) return rc;
+    const int B = batch;
+    double* stats = (double*)c->scalars.p;
+    EEM_HIP_CHECK(hipMemsetAsync(stats, 0, 8 * sizeof(double), st));
+    // ---- loss and d loss / d flow (train_mvsec.py:201-227)
+    if ((rc = tr_loss_launch(flow_out, flow_gt, valid, c->g_flow.p, B, s.out_h * s.out_w, gamma_weight, stats, st)) != EEM_OK) return rc;
+    if ((rc = backward_impl(c, s, e1, e2, c->g_flow.p, grad_out, st)) != EEM_OK) return rc;
     if (stats_out) {
         double hst[5];
         EEM_HIP_CHECK(hipMemcpyAsync(hst, stats, sizeof(hst), hipMemcpyDeviceToHost, st));
@@ -295,7 +349,7 @@ extern "C" int eemflow_optimizer_step(eemflow_ctx* c, const float* grad, float l
         c->opt_step = 0;
     }
     if ((rc = ensure(c->scalars, 16)) != EEM_OK) return rc;
-    double* sumsq = (double*)c->scalars.p + 6;
+    double* sumsq = (double*)c->scalars.p + 7;
     EEM_HIP_CHECK(hipMemsetAsync(sumsq, 0, sizeof(double), st));
     if ((rc = tr_sumsq_launch(grad, (long)c->nflat, sumsq, st)) != EEM_OK) return rc;
     c->opt_step += 1;

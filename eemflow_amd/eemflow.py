@@ -7,8 +7,15 @@ run_network call it unchanged.  The parameters are ordinary nn.Parameters (check
 optimizers keep working); the forward hands them, flattened, to the HIP library, which packs them
 into MFMA fragment order once per weight version.
 
-Inference only in this round: forward() requires CUDA (ROCm) tensors and runs under no_grad
-semantics - a forward that needs autograd raises instead of silently using another path.
+Two routes through the library, chosen as nn.Module semantics dictate:
+* no gradient needed (torch.no_grad() / no parameter requires grad): `eemflow_forward`, the HIP-graph replay;
+* gradient needed: `_EEMFlowFunction`, a torch.autograd.Function over `eemflow_forward_train` / `eemflow_backward`,
+  so the reference trainer's own sequence (train_mvsec.py:245-258: model(im1, im2) -> sequence_loss ->
+  scaler.scale(loss).backward() -> clip_grad_norm_ -> optimizer.step()) fills nn.Parameter.grad and works with any
+  torch optimizer / loss.  After an optimizer step the changed parameters reach the device copy by one
+  device-to-device gather (`eemflow_update_weights`), detected through the parameters' version counters.
+forward() requires CUDA (ROCm) tensors: there is no CPU path.  Writes that bypass the version counter
+(`p.data.copy_`, `torch.distributed.broadcast(p.data)`) need `model.invalidate_weights()`.
 """
 import ctypes
 
@@ -41,6 +48,54 @@ class Decoder(nn.Module):
         self.conv5 = convrelu(100, 64, 3, 1)
         self.conv6 = convrelu(64, 32, 3, 1)
         self.conv7 = nn.Conv2d(32, 2, 3, 1, 1)
+
+
+class _EEMFlowFunction(torch.autograd.Function):
+    """autograd through the HIP forward: d loss / d flow -> d loss / d parameter (autograd of EEMFlow.py:122-183).
+    The event volumes get no gradient (the reference never asks for one: they are data)."""
+
+    @staticmethod
+    def forward(ctx, module, e1, e2, out_size, *params):
+        handle = module._context(e1.device)
+        b, _, h, w = e1.shape
+        flow = torch.empty(b, 2, out_size[0], out_size[1], device=e1.device, dtype=torch.float32)
+        serial = ctypes.c_int64()
+        with torch.cuda.device(e1.device):
+            _lib.check(_lib.lib().eemflow_forward_train(handle, e1.data_ptr(), e2.data_ptr(), b, h, w, flow.data_ptr(),
+                                                        out_size[0], out_size[1], ctypes.byref(serial),
+                                                        _lib.current_stream_ptr(e1.device)))
+        ctx.module, ctx.serial, ctx.out_size = module, serial.value, out_size
+        ctx.weights_version = module._weights_version
+        ctx.save_for_backward(e1, e2)
+        return flow
+
+    @staticmethod
+    def backward(ctx, dflow):
+        m = ctx.module
+        e1, e2 = ctx.saved_tensors
+        L = _lib.lib()
+        if m._weights_fingerprint() != ctx.weights_version:
+            raise _lib.EEMFlowHipError("EEMFlow backward: a parameter was modified in place between forward and backward")
+        dflow = dflow.contiguous().float()
+        n = sum(p.numel() for p in m.parameters())
+        grad = torch.empty(n, device=e1.device, dtype=torch.float32)
+        b, _, h, w = e1.shape
+        with torch.cuda.device(e1.device):
+            s = _lib.current_stream_ptr(e1.device)
+            if L.eemflow_backward(m._ctx, ctx.serial, e1.data_ptr(), e2.data_ptr(), dflow.data_ptr(), grad.data_ptr(), s) != 0:
+                # another forward of this module ran in between and reused the workspace: recompute the activations
+                scratch = torch.empty(b, 2, ctx.out_size[0], ctx.out_size[1], device=e1.device, dtype=torch.float32)
+                serial = ctypes.c_int64()
+                _lib.check(L.eemflow_forward_train(m._ctx, e1.data_ptr(), e2.data_ptr(), b, h, w, scratch.data_ptr(),
+                                                   ctx.out_size[0], ctx.out_size[1], ctypes.byref(serial), s))
+                _lib.check(L.eemflow_backward(m._ctx, serial.value, e1.data_ptr(), e2.data_ptr(), dflow.data_ptr(),
+                                              grad.data_ptr(), s))
+        grads, off = [], 0
+        for i, p in enumerate(m.parameters()):
+            k = p.numel()
+            grads.append(grad[off:off + k].view_as(p) if ctx.needs_input_grad[4 + i] else None)
+            off += k
+        return (None, None, None, None, *grads)
 
 
 class EEMFlow(nn.Module):
@@ -76,6 +131,7 @@ class EEMFlow(nn.Module):
         self._ctx = None
         self._ctx_device = None
         self._weights_version = None
+        self._layout_loaded = False
         self.use_graph = True
 
     # ------------------------------------------------------------------ reference interface
@@ -99,10 +155,6 @@ class EEMFlow(nn.Module):
         if not (events1.is_cuda and events2.is_cuda):
             raise _lib.EEMFlowHipError(
                 "EEMFlow.forward: inputs must be CUDA (ROCm) tensors - this implementation has no CPU path")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
-            raise _lib.EEMFlowHipError(
-                "EEMFlow.forward: the HIP backward pass is not built yet (round 1 covers inference); "
-                "call under torch.no_grad() / model.eval()")
         if not hasattr(self, "image_padder"):
             raise AttributeError("call change_imagesize(img_size) before forward (as the reference requires)")
         input_size = events1.shape[-2:]
@@ -114,6 +166,11 @@ class EEMFlow(nn.Module):
         e2 = events2.contiguous().float()
         if e1.shape != e2.shape or e1.dim() != 4 or e1.shape[1] != self.n_first_channels:
             raise ValueError(f"expected two (B,{self.n_first_channels},H,W) tensors, got {tuple(e1.shape)} and {tuple(e2.shape)}")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if self.groups != 5:
+                raise _lib.EEMFlowHipError("EEMFlow.forward under autograd: only groups == 5 has a HIP backward pass")
+            flow = _EEMFlowFunction.apply(self, e1, e2, out_size, *self.parameters())
+            return (events1, events2), [flow]
         ctx = self._context(e1.device)
         b, _, h, w = e1.shape
         flow = torch.empty(b, 2, out_size[0], out_size[1], device=e1.device, dtype=torch.float32)
@@ -123,8 +180,14 @@ class EEMFlow(nn.Module):
         return (events1, events2), [flow]
 
     # ------------------------------------------------------------------ HIP context plumbing
-    def _flat_weights(self):
-        return torch.cat([v.detach().reshape(-1).to(torch.float32).cpu() for v in self.state_dict().values()])
+    def _flat_weights(self, device=None):
+        # state_dict order == parameter registration order (the module has no buffers)
+        return torch.cat([v.detach().reshape(-1).to(torch.float32) for v in self.state_dict().values()]).to(device or "cpu")
+
+    def invalidate_weights(self):
+        """Force the next forward to re-read the nn.Parameters (after writes through `.data`, which bypass the
+        version counter the staleness check reads)."""
+        self._weights_version = None
 
     def _weights_fingerprint(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
@@ -136,11 +199,17 @@ class EEMFlow(nn.Module):
             handle = ctypes.c_void_p()
             _lib.check(L.eemflow_create(device.index if device.index is not None else torch.cuda.current_device(),
                                         ctypes.byref(handle)))
-            self._ctx, self._ctx_device, self._weights_version = handle, device, None
+            self._ctx, self._ctx_device, self._weights_version, self._layout_loaded = handle, device, None, False
         fp = self._weights_fingerprint()
         if fp != self._weights_version:
-            flat = self._flat_weights().contiguous()
-            _lib.check(L.eemflow_load_weights(self._ctx, flat.data_ptr(), flat.numel(), self.n_first_channels, self.groups))
+            if self._layout_loaded and all(p.device == device for p in self.parameters()):
+                flat = self._flat_weights(device).contiguous()          # e.g. after optimizer.step(): device to device
+                with torch.cuda.device(device):
+                    _lib.check(L.eemflow_update_weights(self._ctx, flat.data_ptr(), flat.numel(), _lib.current_stream_ptr(device)))
+            else:
+                flat = self._flat_weights().contiguous()
+                _lib.check(L.eemflow_load_weights(self._ctx, flat.data_ptr(), flat.numel(), self.n_first_channels, self.groups))
+                self._layout_loaded = True
             self._weights_version = fp
         pad = (ctypes.c_int * 4)()
         _lib.check(L.eemflow_set_image_size(self._ctx, int(self.image_size[0]), int(self.image_size[1]), ctypes.byref(pad)))

@@ -7,8 +7,12 @@ Keeps what the reference's harness does ON the path and its log lines, drops cv2
   TestRaftEvents.test_multi_sequence  test_mvsec.py:538-671: per sequence, every `stride`-th sample: change_imagesize,
                                       model(events1, events2), flow_error on the last prediction, the reference's summary
                                       lines; returns the mean AEE over the sequences
-  TrainRaftEvents.train_iters         train_mvsec.py:229-286: model.change_imagesize, one optimisation step per batch
-                                      (EEMFlowTrainer: loss, backward, [RCCL all-reduce], clip + AdamW + OneCycle)
+  TrainRaftEvents.train_iters         train_mvsec.py:229-286: model.change_imagesize, one optimisation step per batch.
+                                      engine="fused" (default): EEMFlowTrainer - loss, backward, [RCCL all-reduce], clip +
+                                      AdamW + OneCycle inside the library; engine="autograd": the reference's literal sequence
+                                      (fetch_optimizer's torch AdamW + OneCycleLR, GradScaler, model(im1, im2) -> sequence_loss
+                                      -> scaler.scale(loss).backward() -> clip_grad_norm_ -> scaler.step) through the model's
+                                      torch.autograd.Function - for callers that bring their own optimizer or loss
 
 Samples come from a dataset with the reference's dict keys ('event_volume_old', 'event_volume_new', 'flow', 'valid',
 'event_valid'); tensors are moved to the model's device.  One process per GPU (eemflow_amd.parallel), not
@@ -20,7 +24,8 @@ import sys
 import torch
 
 from .metrics import flow_error
-from .train import EEMFlowTrainer
+from . import parallel
+from .train import EEMFlowTrainer, sequence_loss
 
 
 class Logger:
@@ -133,17 +138,70 @@ class TrainRaftEvents:
     """Training loop of train_mvsec.py:229-286 (one process per GPU; batches are this rank's shard)."""
 
     def __init__(self, loader, image_size, lr=1e-4, wdecay=5e-5, epsilon=1e-8, num_steps=1000000, clip=1.0, gamma=0.8,
-                 logger=None, print_freq=100):
+                 logger=None, print_freq=100, engine="fused", mixed_precision=True):
+        if engine not in ("fused", "autograd"):
+            raise ValueError("engine must be 'fused' or 'autograd'")
         self.loader, self.image_size = loader, image_size
         self.opt = dict(lr=lr, wdecay=wdecay, epsilon=epsilon, num_steps=num_steps, clip=clip, gamma=gamma)
         self.logger = logger or Logger()
         self.print_freq = print_freq
+        self.engine, self.mixed_precision = engine, mixed_precision
         self.trainer = None
+        self.optimizer = self.scheduler = self.scaler = None
+        self.iteration = 0
+
+    def fetch_optimizer(self, model):
+        """train_mvsec.py:178-183."""
+        o = self.opt
+        self.optimizer = torch.optim.AdamW(filter(lambda p: p.requires_grad, model.parameters()), lr=o["lr"], weight_decay=o["wdecay"],
+                                           eps=o["epsilon"])
+        self.scheduler = torch.optim.lr_scheduler.OneCycleLR(self.optimizer, o["lr"], o["num_steps"] + 100, pct_start=0.05,
+                                                             cycle_momentum=False, anneal_strategy='linear')
+
+    def _train_iters_autograd(self, model, start_epoch, val_iters):
+        """The body of train_mvsec.py:241-258, statement for statement; in data-parallel jobs the parameter gradients are
+        averaged by one RCCL all-reduce of a flat buffer before the clip (what DataParallel's gather/scatter amounts to)."""
+        dev = _device_of(model)
+        if self.optimizer is None:
+            self.fetch_optimizer(model)
+            self.scaler = torch.amp.GradScaler("cuda", enabled=self.mixed_precision)
+        done = 0
+        for batch in self.loader:
+            self.optimizer.zero_grad()
+            e1 = batch['event_volume_old'].to(dev).float()
+            e2 = batch['event_volume_new'].to(dev).float()
+            _, flow_list = model(e1, e2)
+            loss, metrics = sequence_loss(flow_list, batch['flow'].to(dev).float(), batch['valid'].to(dev).float(), self.opt["gamma"])
+            self.scaler.scale(loss).backward()
+            self.scaler.unscale_(self.optimizer)
+            if parallel.env_world()[2] > 1:
+                params = [p for p in model.parameters() if p.grad is not None]
+                flat = torch.cat([p.grad.reshape(-1) for p in params])
+                parallel.average_gradients(flat)
+                off = 0
+                for p in params:
+                    p.grad.copy_(flat[off:off + p.numel()].view_as(p))
+                    off += p.numel()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), self.opt["clip"])
+            lr = self.optimizer.param_groups[0]["lr"]
+            self.scaler.step(self.optimizer)
+            self.scheduler.step()
+            self.scaler.update()
+            done += 1
+            self.iteration += 1
+            if done % self.print_freq == 0 or done == 1:
+                self.logger.write_line("[epoch {:d}, {:6d}] loss {:.6f} epe {:.4f} lr {:.3e}".format(
+                    start_epoch, self.iteration, loss.item(), metrics["epe"], lr), True)
+            if val_iters is not None and done >= val_iters:
+                break
+        return model
 
     def train_iters(self, model, start_epoch=0, val_iters=None):
         model.change_imagesize(self.image_size)
         model.train()
         dev = _device_of(model)
+        if self.engine == "autograd":
+            return self._train_iters_autograd(model, start_epoch, val_iters)
         if self.trainer is None:
             self.trainer = EEMFlowTrainer(model, **self.opt)
         done = 0

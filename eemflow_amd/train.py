@@ -38,6 +38,46 @@ class OneCycleLinear:
         return (self.min_lr - self.max_lr) * pct + self.max_lr
 
 
+class _LossTerm(torch.autograd.Function):
+    """weight * mean(valid * |flow - gt|) and its gradient by `eemflow_sequence_loss` (one kernel, no host sync)."""
+
+    @staticmethod
+    def forward(ctx, flow, flow_gt, valid, weight, stats):
+        flow = flow.contiguous()
+        b, _, h, w = flow.shape
+        dflow = torch.empty_like(flow)
+        before = stats[0].clone()
+        with torch.cuda.device(flow.device):
+            _lib.check(_lib.lib().eemflow_sequence_loss(flow.data_ptr(), flow_gt.data_ptr(), valid.data_ptr(), b, h, w, float(weight),
+                                                        dflow.data_ptr(), stats.data_ptr(), _lib.current_stream_ptr(flow.device)))
+        ctx.save_for_backward(dflow)
+        return ((stats[0] - before) * (float(weight) / flow.numel())).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        (dflow,) = ctx.saved_tensors
+        return dflow * g, None, None, None, None
+
+
+def sequence_loss(flow_preds, flow_gt, valid, gamma=0.8):
+    """`train.sequence_loss` (train_mvsec.py:201-227) on the GPU: returns (loss, metrics) with the reference's metric keys; the loss
+    is a differentiable CUDA scalar, so `scaler.scale(loss).backward()` continues into the model's HIP backward pass.
+    max_flow is the reference's constant 400 (train_mvsec.py:41)."""
+    if not flow_preds[0].is_cuda:
+        raise _lib.EEMFlowHipError("sequence_loss: CUDA (ROCm) tensors required - there is no CPU path")
+    gt, va = flow_gt.contiguous().float(), valid.contiguous().float()
+    n = len(flow_preds)
+    loss = 0.0
+    for i, flow in enumerate(flow_preds):
+        if tuple(flow.shape) != tuple(gt.shape) or tuple(va.shape) != (gt.shape[0],) + tuple(gt.shape[2:]):
+            raise ValueError(f"sequence_loss: prediction {tuple(flow.shape)}, flow_gt {tuple(gt.shape)}, valid {tuple(va.shape)}")
+        stats = torch.zeros(6, device=gt.device, dtype=torch.float64)
+        loss = loss + _LossTerm.apply(flow.float(), gt, va, gamma ** (n - i - 1), stats)
+    st = stats.tolist()                                          # statistics of the last prediction (train_mvsec.py:218-226)
+    cnt = st[2] if st[2] > 0 else float("nan")
+    return loss, {"epe": st[1] / cnt, "1px": st[3] / cnt, "3px": st[4] / cnt, "5px": st[5] / cnt}
+
+
 class EEMFlowTrainer:
     """One optimisation step per `step()` call; owns the flat gradient buffer and the schedule."""
 

@@ -45,6 +45,12 @@ void eemflow_destroy(eemflow_ctx* ctx);
 int eemflow_load_weights(eemflow_ctx* ctx, const float* flat_host, size_t nfloats, int n_first_channels,
                          int groups);
 
+/* New values for the parameters of an already loaded model, from a DEVICE vector in the same order: one
+ * device-to-device copy plus the on-device re-pack of every kernel-side layout (no host round trip).  This is what a
+ * training loop that owns its optimizer calls after optimizer.step() changed the nn.Parameters in place.
+ * Replaces: the implicit "parameters are read where they live" of nn.Module (train_mvsec.py:257 scaler.step). */
+int eemflow_update_weights(eemflow_ctx* ctx, const float* flat_device, size_t nfloats, void* stream);
+
 /* Configure the replicate padder for images of `height` x `width` (pad to a multiple of 64, 'chairs'
  * mode: width split left/right, height bottom only).  pad_out = [left, right, top, bottom].
  * Replaces: EEMFlow.change_imagesize -> InputPadder(img_size, 'chairs', 64)
@@ -121,6 +127,27 @@ int eemflow_voxelize(const double* events, int64_t n, int bins, int h, int w, in
  * Training step of EEMFlow (train_mvsec.py:229-258).  Weights live on the device in state_dict order; one
  * flat gradient buffer in the same order is what a data-parallel job all-reduces (RCCL) between the two calls.
  * ---------------------------------------------------------------------------------------------- */
+
+/* The two halves of autograd through EEMFlow.forward, for torch.autograd.Function (eemflow_amd/eemflow.py):
+ * eemflow_forward_train runs the forward eagerly and keeps every activation in the context's workspace;
+ * eemflow_backward turns d loss / d flow [batch][2][out_h][out_w] (any loss the caller differentiated) into the flat
+ * parameter gradient grad_out (device, 714 352 floats, state_dict order).  `serial_out` identifies the forward whose
+ * activations the context holds; eemflow_backward refuses (non-zero return) when another forward has overwritten them -
+ * the caller then repeats the forward.  events1/events2 passed to eemflow_backward are that forward's inputs.
+ * Replaces: model(im1, im2) under autograd + loss.backward()  (train_mvsec.py:245-253,377-386; autograd of
+ * model/EEMFlow/EEMFlow.py:122-183). */
+int eemflow_forward_train(eemflow_ctx* ctx, const float* events1, const float* events2, int batch, int in_h, int in_w,
+                          float* flow_out, int out_h, int out_w, int64_t* serial_out, void* stream);
+int eemflow_backward(eemflow_ctx* ctx, int64_t serial, const float* events1, const float* events2, const float* dflow,
+                     float* grad_out, void* stream);
+
+/* One term of sequence_loss and its gradient: weight * mean over batch*2*h*w of valid*|flow - gt| with
+ * valid = (valid >= 0.5) & (|gt| < 400).  dflow_out [batch][2][h][w] = d term / d flow.  stats6 (DEVICE, 6 doubles, added
+ * to - the caller zeroes them): sum of valid |flow - gt| (loss term = weight * stats6[0] / (batch*2*h*w)), sum of EPE over
+ * valid pixels, valid count, count(EPE < 1), count(EPE < 3), count(EPE < 5).  No host synchronisation.
+ * Replaces: train.sequence_loss  (train_mvsec.py:201-227) and its autograd. */
+int eemflow_sequence_loss(const float* flow, const float* flow_gt, const float* valid, int batch, int h, int w, float weight,
+                          float* dflow_out, double* stats6, void* stream);
 
 /* Forward (train-mode output size), sequence loss for the single prediction (weight = gamma^0 = 1 unless the
  * caller scales it), and the full backward pass.  flow_gt [batch][2][out_h][out_w], valid [batch][out_h][out_w];

@@ -1,0 +1,190 @@
+"""BASELINE.json's configurations at their STATED sizes against the oracle, and data-parallel equivalence on one GPU.
+
+  C3  EEMFlow training step, MVSEC 346x260 dt1, batch 32          loss, flow, all 66 gradient tensors vs torch autograd through the oracle
+  C4  EEMFlow training, HREM 1280x720, batch 8 per GPU            forward + loss of the 8 samples vs the oracle; gradients of a 2-sample shard
+  C5  E-RAFT 640x480, 12 iterations, batch 4                      all 12 predictions vs the oracle
+  DP  two contexts on one GPU, each with half a batch             (g0 + g1) / 2 == full-batch gradient; clip + AdamW then agree
+      (train_mvsec.py:215 takes the mean over the global batch; train_EEMFlow_HREM.py:116-118 splits it with nn.DataParallel)
+
+`pytest -m gpu`.  The CPU side (torch autograd / 12 E-RAFT iterations on the host) takes a few seconds per case."""
+import numpy as np
+import pytest
+import torch
+
+from eemflow_amd import EEMFlow
+from eemflow_amd.eraft import ERAFT
+from eemflow_amd.eraft_weights import seeded_from_shapes
+from eemflow_amd.train import EEMFlowTrainer
+from eemflow_amd.weights import seeded_state_dict, synthetic_gt, synthetic_voxel_pair
+from oracle import eemflow_oracle as O
+from oracle import eraft_oracle as R
+from oracle import train_oracle as T
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def make_net(seed, **kw):
+    sd = seeded_state_dict(seed)
+    net = EEMFlow("", groups=5, n_first_channels=5, **kw)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return net.to(DEV).train(), O.to_torch_sd(sd)
+
+
+def split_flat(flat, sd):
+    out, off = {}, 0
+    for k, v in sd.items():
+        out[k] = flat[off:off + v.numel()].view_as(v)
+        off += v.numel()
+    return out
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def fused_grads(net, e1, e2, gt, valid):
+    tr = EEMFlowTrainer(net, lr=0.0, wdecay=0.0, clip=0.0)
+    loss, metrics, flow = tr.step(e1.to(DEV), e2.to(DEV), gt.to(DEV), valid.to(DEV))
+    return loss, metrics, flow.cpu(), tr.grad.clone().cpu()
+
+
+def test_c3_training_step_mvsec_346x260_batch32_vs_oracle():
+    b, h, w = 32, 260, 346
+    net, sd = make_net(101)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(102, b, h, w))
+    gt, valid = (torch.from_numpy(a) for a in synthetic_gt(103, b, h, w))
+    loss, metrics, flow, flat = fused_grads(net, e1, e2, gt, valid)
+    rloss, rmetrics, rgrads, rflow = T.loss_and_grads(sd, e1, e2, gt, valid, image_size=(h, w))
+    assert abs(loss - rloss) < 1e-5 and abs(metrics["epe"] - rmetrics["epe"]) < 1e-4
+    assert float((flow - rflow).abs().max()) < 1e-4                      # north star: 1e-3
+    grads = split_flat(flat, sd)
+    norms = np.array([float(v.double().norm()) for v in grads.values()])
+    rnorms = np.array([float(rgrads[k].double().norm()) for k in sd])
+    np.testing.assert_allclose(norms, rnorms, rtol=2e-3, atol=1e-8)
+    worst = max((rel_err(grads[k], rgrads[k]), k) for k in sd)
+    assert worst[0] < 3e-3, worst
+    # and the same numbers through the reference's call path (model(...) -> loss.backward())
+    net.zero_grad()
+    _, preds = net(e1.to(DEV), e2.to(DEV))
+    aloss, _ = T.sequence_loss(preds, gt.to(DEV), valid.to(DEV))
+    aloss.backward()
+    assert abs(float(aloss) - rloss) < 1e-5
+    worst = max((rel_err(p.grad, rgrads[k]), k) for k, p in net.named_parameters())
+    assert worst[0] < 3e-3, worst
+
+
+def test_c4_training_hrem_1280x720_batch8_vs_oracle():
+    b, h, w = 8, 720, 1280
+    net, sd = make_net(111)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(112, b, h, w))
+    gt, valid = (torch.from_numpy(a) for a in synthetic_gt(113, b, h, w))
+    loss, metrics, flow, flat = fused_grads(net, e1, e2, gt, valid)
+    with torch.no_grad():
+        rflow, _ = O.eemflow_forward(sd, e1, e2, image_size=(h, w))
+        rloss, rmetrics = T.sequence_loss([rflow], gt, valid)
+    assert float((flow - rflow).abs().max()) < 1e-4
+    assert abs(loss - float(rloss)) < 1e-5 and abs(metrics["epe"] - rmetrics["epe"]) < 1e-4
+    assert np.isfinite(flat.numpy()).all() and float(flat.abs().max()) > 0
+    # gradients: a 2-sample shard against torch autograd through the oracle (the b8 gradient is the mean of four such shards;
+    # that identity is test_dp_equivalence below)
+    sl = slice(2, 4)
+    loss2, _, flow2, flat2 = fused_grads(net, e1[sl], e2[sl], gt[sl], valid[sl])
+    rloss2, _, rgrads2, rflow2 = T.loss_and_grads(sd, e1[sl], e2[sl], gt[sl], valid[sl], image_size=(h, w))
+    assert abs(loss2 - rloss2) < 1e-5 and float((flow2 - rflow2).abs().max()) < 1e-4
+    assert torch.equal(flow2, flow[sl])                                  # batch position does not change a sample's flow
+    grads2 = split_flat(flat2, sd)
+    worst = max((rel_err(grads2[k], rgrads2[k]), k) for k in sd)
+    assert worst[0] < 3e-3, worst
+    # four shards of two average to the batch-8 gradient
+    acc = torch.zeros_like(flat)
+    for i in range(4):
+        s = slice(2 * i, 2 * i + 2)
+        acc += fused_grads(net, e1[s], e2[s], gt[s], valid[s])[3]
+    g8, g4x2 = split_flat(flat, sd), split_flat(acc / 4, sd)
+    worst = max((rel_err(g4x2[k], g8[k]), k) for k in sd)
+    assert worst[0] < 1e-4, worst
+
+
+def test_c5_eraft_640x480_12_iterations_batch4_vs_oracle():
+    b, h, w, iters = 4, 480, 640, 12
+    net = ERAFT("", 5).eval()
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sdn = seeded_from_shapes(shapes, 121)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sdn.items()})
+    net = net.to(DEV)
+    sd = O.to_torch_sd(sdn)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(122, b, h, w))
+    with torch.no_grad():
+        preds = net(e1.to(DEV), e2.to(DEV), iters=iters)[1]
+        ref, _ = R.eraft_forward(sd, e1, e2, iters=iters)
+    assert len(preds) == iters and preds[0].shape == (b, 2, h, w)
+    errs = [float((p.cpu() - r).abs().max()) for p, r in zip(preds, ref)]
+    assert max(errs) < 1e-3, errs
+    assert float(ref[-1].abs().max()) > 0.05                             # not a degenerate zero flow
+
+
+@pytest.mark.parametrize("b,h,w", [(4, 260, 346), (2, 720, 1280)])
+def test_dp_equivalence_two_shards_one_gpu(b, h, w):
+    """Rank r of a 2-rank job holds samples [r*b/2, (r+1)*b/2).  parallel.average_gradients computes (g0 + g1) / 2 (SUM all-reduce,
+    / world); that must be the gradient of the reference's mean over the GLOBAL batch (train_mvsec.py:215), and the replicas' clip +
+    AdamW on it must track the single-process step."""
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(131, b, h, w))
+    gt, valid = (torch.from_numpy(a).to(DEV) for a in synthetic_gt(132, b, h, w))
+    full, sd = make_net(133)
+    r0, _ = make_net(133)
+    r1, _ = make_net(133)
+    opt = dict(lr=1e-3, wdecay=5e-5, epsilon=1e-8, num_steps=20, clip=1.0)
+    trainers = []
+    for m in (full, r0, r1):
+        m.change_imagesize((h, w))
+        trainers.append(EEMFlowTrainer(m, **opt))
+    tf, t0, t1 = trainers
+    half = b // 2
+    from eemflow_amd import _lib
+    import ctypes
+
+    def fwd_bwd(tr, sl):
+        m = tr.model
+        ctx = m._context(torch.device(DEV))
+        n = sum(p.numel() for p in m.parameters())
+        tr.grad = torch.empty(n, device=DEV)
+        bb = e1[sl].shape[0]
+        flow = torch.empty(bb, 2, h, w, device=DEV)
+        stats = (ctypes.c_double * 5)()
+        _lib.check(_lib.lib().eemflow_forward_backward(ctx, e1[sl].contiguous().data_ptr(), e2[sl].contiguous().data_ptr(),
+                                                       gt[sl].contiguous().data_ptr(), valid[sl].contiguous().data_ptr(), bb, h, w, h, w,
+                                                       1.0, flow.data_ptr(), tr.grad.data_ptr(), ctypes.byref(stats),
+                                                       _lib.current_stream_ptr(torch.device(DEV))))
+        return stats[0]
+
+    def opt_step(tr, grad):
+        lr = tr.schedule.lr(tr.iteration)
+        _lib.check(_lib.lib().eemflow_optimizer_step(tr.model._ctx, grad.data_ptr(), lr, tr.wdecay, tr.eps, tr.clip,
+                                                     _lib.current_stream_ptr(torch.device(DEV))))
+        tr.iteration += 1
+
+    for step in range(2):
+        lf = fwd_bwd(tf, slice(0, b))
+        l0 = fwd_bwd(t0, slice(0, half))
+        l1 = fwd_bwd(t1, slice(half, b))
+        assert abs(0.5 * (l0 + l1) - lf) < 1e-6
+        avg = (t0.grad + t1.grad) / 2                                     # what the all-reduce leaves on every rank
+        gf, ga = split_flat(tf.grad, sd), split_flat(avg, sd)
+        worst = max((rel_err(ga[k], gf[k]), k) for k in sd)
+        assert worst[0] < 1e-4, (step, worst)
+        opt_step(tf, tf.grad)
+        opt_step(t0, avg)
+        opt_step(t1, avg)
+    wf, w0, w1 = (tr.sync_parameters().state_dict() for tr in trainers)
+    for k in wf:
+        assert torch.equal(w0[k], w1[k]), k                               # replicas stay bit-identical
+        # against the single-process step: AdamW's g / (sqrt(v) + eps) turns summation-order round-off on near-zero gradient
+        # elements into up to lr-sized differences, so all but a sliver of the weights agree tightly and none moves further than
+        # two steps of lr could carry it
+        d = (w0[k] - wf[k]).abs()
+        assert float((d > 2e-5).float().mean()) < 2e-3 and float(d.max()) < 2.5e-3, (k, float(d.max()))

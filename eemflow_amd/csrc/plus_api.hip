@@ -46,7 +46,7 @@ struct eemplus_ctx {
     bool enc_wino[8] = {false};
     int* taps = nullptr;
     PLayer enc[8], rconv[7], dec1[7], decg[7][3][3], dec5[7], dec6[7], dec7[7], de[6], c1x1[6];
-    PBuf padded, f[7], a2, dense, xout, fi, tw, fup[7], fw, cat, d[4], t64, t32, flow[7];
+    PBuf padded, f[7], a2, dense, xout, finit[7], tw, fup[7], fw, cat, d[4], t64, t32, flow[7];
     int B = 0, hl[7] = {0}, wl[7] = {0};
     bool have_last = false;
 };
@@ -188,12 +188,13 @@ extern "C" int eemplus_create(int device, eemplus_ctx** out) {
 extern "C" void eemplus_destroy(eemplus_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    PBuf* one[] = {&c->padded, &c->a2, &c->dense, &c->xout, &c->fi, &c->tw, &c->fw, &c->cat, &c->t64, &c->t32,
+    PBuf* one[] = {&c->padded, &c->a2, &c->dense, &c->xout, &c->tw, &c->fw, &c->cat, &c->t64, &c->t32,
                    &c->d[0], &c->d[1], &c->d[2], &c->d[3]};
     for (PBuf* b : one) if (b->p) (void)hipFree(b->p);
     for (int l = 0; l < 7; ++l) {
         if (c->f[l].p) (void)hipFree(c->f[l].p);
         if (c->fup[l].p) (void)hipFree(c->fup[l].p);
+        if (c->finit[l].p) (void)hipFree(c->finit[l].p);
         if (c->flow[l].p) (void)hipFree(c->flow[l].p);
     }
     if (c->arena) (void)hipFree(c->arena);
@@ -279,6 +280,53 @@ extern "C" int eemplus_load_weights(eemplus_ctx* c, const float* flat, size_t nf
     return EEM_OK;
 }
 
+// One level l = 5..2 of the coarse-to-fine loop (EEMFlow+.py:183-229) on the features of the current forward: cdc_model
+// self-guided upsampling of flow[l+1] -> flow_up[l], warp, 9x9 correlation, decoder + residual -> flow[l].
+static int run_level(eemplus_ctx* c, int l, int B, const float* forced_init, hipStream_t st) {
+    int rc;
+    const int C[7] = {0, 16, 32, 64, 64, 64, 64};
+    const int* hl = c->hl; const int* wl = c->wl;
+    auto f1 = [&](int k) { return c->f[k].p; };
+    auto f2 = [&](int k) { return c->f[k].p + (size_t)B * C[k] * hl[k] * wl[k]; };
+    const int h = hl[l], w = wl[l], hc = hl[l + 1], wc = wl[l + 1];
+    const size_t g = (size_t)h * w;
+    if ((rc = pensure(c->dense, B * kDense * g)) != EEM_OK || (rc = pensure(c->a2, B * 32 * g)) != EEM_OK ||
+        (rc = pensure(c->xout, B * 3 * g)) != EEM_OK || (rc = pensure(c->finit[l], B * 2 * g)) != EEM_OK ||
+        (rc = pensure(c->tw, B * 2 * g)) != EEM_OK || (rc = pensure(c->fup[l], B * 2 * g)) != EEM_OK ||
+        (rc = pensure(c->fw, B * C[l] * g)) != EEM_OK || (rc = pensure(c->cat, B * kDIn * g)) != EEM_OK)
+        return rc;
+    float* const fi = c->finit[l].p;              // cdc_model's upsampled flow_init, kept per level (stage "flow_init<l>")
+    // 1x1 projections of both feature maps (:184-185); feature_1 goes straight into the dense buffer's x slot
+    if ((rc = conv(c, c->c1x1[l], f1(l), C[l], 0, B, h, w, c->dense.p, kDense, 120, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+    if ((rc = conv(c, c->c1x1[l], f2(l), C[l], 0, B, h, w, c->a2.p, 32, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+    // cdc_model.forward (cdc_utils.py:156-174)
+    if (forced_init) {
+        // teacher-forced level (eemplus_level): cdc_model's upsampled flow_init is supplied by the caller
+        EEM_HIP_CHECK(hipMemcpyAsync(fi, forced_init, B * 2 * g * 4, hipMemcpyDeviceToDevice, st));
+    } else if (hc != h || wc != w) {
+        if ((rc = pl_upflow_launch(c->flow[l + 1].p, fi, B, hc, wc, h, w, 1, st)) != EEM_OK) return rc;
+        // in-place side effect of upsample2d_flow_as(if_rate=True) on the coarser flow (cdc_utils.py:85-86)
+        if ((rc = pl_scale_flow_launch(c->flow[l + 1].p, B, hc * wc, (float)w / (float)wc, (float)h / (float)hc, st)) != EEM_OK) return rc;
+    } else {
+        EEM_HIP_CHECK(hipMemcpyAsync(fi, c->flow[l + 1].p, B * 2 * g * 4, hipMemcpyDeviceToDevice, st));
+    }
+    if ((rc = pl_warp_launch(c->a2.p, fi, 2, c->dense.p, kDense, 152, B, 32, h, w, 2, st)) != EEM_OK) return rc;
+    const int din[6] = {64, 96, 128, 160, 176, 184}, dout_off[5] = {88, 56, 24, 8, 0};
+    for (int i = 0; i < 5; ++i)
+        if ((rc = conv(c, c->de[i], c->dense.p, kDense, kDense - din[i], B, h, w, c->dense.p, kDense, dout_off[i], 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+    if ((rc = conv(c, c->de[5], c->dense.p, kDense, 0, B, h, w, c->xout.p, 3, 0, 1, GACT_NONE, nullptr, st)) != EEM_OK) return rc;
+    if ((rc = pl_warp_launch(fi, c->xout.p, 3, c->tw.p, 2, 0, B, 2, h, w, 1, st)) != EEM_OK) return rc;
+    if ((rc = pl_blend_launch(c->tw.p, fi, c->xout.p, c->fup[l].p, B, (int)g, st)) != EEM_OK) return rc;
+    // warp, correlate, decode (:189-193)
+    if ((rc = pl_warp_launch(f2(l), c->fup[l].p, 2, c->fw.p, C[l], 0, B, C[l], h, w, 0, st)) != EEM_OK) return rc;
+    CorrJob cj = {f1(l), c->fw.p, c->cat.p, C[l], kDIn};
+    if ((rc = corr_launch(&cj, 1, B, h, w, c->taps, 53, st)) != EEM_OK) return rc;
+    if ((rc = conv(c, c->rconv[l], f1(l), C[l], 0, B, h, w, c->cat.p, kDIn, 53, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+    if ((rc = pl_copy_channels_launch(c->fup[l].p, 2, 0, c->cat.p, kDIn, 85, 2, B, (int)g, st)) != EEM_OK) return rc;
+    if ((rc = run_decoder(c, l, B, h, w, c->fup[l].p, st)) != EEM_OK) return rc;
+    return EEM_OK;
+}
+
 extern "C" int eemplus_forward(eemplus_ctx* c, const float* e1, const float* e2, int batch, int in_h, int in_w, const int pad[4],
                                float* out, void* stream) {
     EEM_REQUIRE(c && e1 && e2 && out && pad, "eemplus_forward: NULL argument");
@@ -351,40 +399,8 @@ extern "C" int eemplus_forward(eemplus_ctx* c, const float* e1, const float* e2,
         if ((rc = run_decoder(c, 6, B, h, w, nullptr, st)) != EEM_OK) return rc;
     }
     // ---- levels 5..2 (:183-229)
-    for (int l = 5; l >= 2; --l) {
-        const int h = hl[l], w = wl[l], hc = hl[l + 1], wc = wl[l + 1];
-        const size_t g = (size_t)h * w;
-        if ((rc = pensure(c->dense, B * kDense * g)) != EEM_OK || (rc = pensure(c->a2, B * 32 * g)) != EEM_OK ||
-            (rc = pensure(c->xout, B * 3 * g)) != EEM_OK || (rc = pensure(c->fi, B * 2 * g)) != EEM_OK ||
-            (rc = pensure(c->tw, B * 2 * g)) != EEM_OK || (rc = pensure(c->fup[l], B * 2 * g)) != EEM_OK ||
-            (rc = pensure(c->fw, B * C[l] * g)) != EEM_OK || (rc = pensure(c->cat, B * kDIn * g)) != EEM_OK)
-            return rc;
-        // 1x1 projections of both feature maps (:184-185); feature_1 goes straight into the dense buffer's x slot
-        if ((rc = conv(c, c->c1x1[l], f1(l), C[l], 0, B, h, w, c->dense.p, kDense, 120, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
-        if ((rc = conv(c, c->c1x1[l], f2(l), C[l], 0, B, h, w, c->a2.p, 32, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
-        // cdc_model.forward (cdc_utils.py:156-174)
-        if (hc != h || wc != w) {
-            if ((rc = pl_upflow_launch(c->flow[l + 1].p, c->fi.p, B, hc, wc, h, w, 1, st)) != EEM_OK) return rc;
-            // in-place side effect of upsample2d_flow_as(if_rate=True) on the coarser flow (cdc_utils.py:85-86)
-            if ((rc = pl_scale_flow_launch(c->flow[l + 1].p, B, hc * wc, (float)w / (float)wc, (float)h / (float)hc, st)) != EEM_OK) return rc;
-        } else {
-            EEM_HIP_CHECK(hipMemcpyAsync(c->fi.p, c->flow[l + 1].p, B * 2 * g * 4, hipMemcpyDeviceToDevice, st));
-        }
-        if ((rc = pl_warp_launch(c->a2.p, c->fi.p, 2, c->dense.p, kDense, 152, B, 32, h, w, 2, st)) != EEM_OK) return rc;
-        const int din[6] = {64, 96, 128, 160, 176, 184}, dout_off[5] = {88, 56, 24, 8, 0};
-        for (int i = 0; i < 5; ++i)
-            if ((rc = conv(c, c->de[i], c->dense.p, kDense, kDense - din[i], B, h, w, c->dense.p, kDense, dout_off[i], 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
-        if ((rc = conv(c, c->de[5], c->dense.p, kDense, 0, B, h, w, c->xout.p, 3, 0, 1, GACT_NONE, nullptr, st)) != EEM_OK) return rc;
-        if ((rc = pl_warp_launch(c->fi.p, c->xout.p, 3, c->tw.p, 2, 0, B, 2, h, w, 1, st)) != EEM_OK) return rc;
-        if ((rc = pl_blend_launch(c->tw.p, c->fi.p, c->xout.p, c->fup[l].p, B, (int)g, st)) != EEM_OK) return rc;
-        // warp, correlate, decode (:189-193)
-        if ((rc = pl_warp_launch(f2(l), c->fup[l].p, 2, c->fw.p, C[l], 0, B, C[l], h, w, 0, st)) != EEM_OK) return rc;
-        CorrJob cj = {f1(l), c->fw.p, c->cat.p, C[l], kDIn};
-        if ((rc = corr_launch(&cj, 1, B, h, w, c->taps, 53, st)) != EEM_OK) return rc;
-        if ((rc = conv(c, c->rconv[l], f1(l), C[l], 0, B, h, w, c->cat.p, kDIn, 53, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
-        if ((rc = pl_copy_channels_launch(c->fup[l].p, 2, 0, c->cat.p, kDIn, 85, 2, B, (int)g, st)) != EEM_OK) return rc;
-        if ((rc = run_decoder(c, l, B, h, w, c->fup[l].p, st)) != EEM_OK) return rc;
-    }
+    for (int l = 5; l >= 2; --l)
+        if ((rc = run_level(c, l, B, nullptr, st)) != EEM_OK) return rc;
     // ---- five full-resolution predictions, coarse to fine (:231-232); flow6..flow3 carry the doubling above
     for (int i = 0, l = 6; l >= 2; --l, ++i)
         if ((rc = pl_upflow_launch(c->flow[l].p, out + (size_t)i * B * 2 * in_h * in_w, B, hl[l], wl[l], in_h, in_w, 1, st)) != EEM_OK) return rc;
@@ -403,6 +419,9 @@ extern "C" int eemplus_get_stage(eemplus_ctx* c, const char* name, float* dst, s
     } else if (nm.size() == 8 && nm.compare(0, 7, "flow_up") == 0 && nm[7] >= '2' && nm[7] <= '5') {
         const int l = nm[7] - '0';
         src = c->fup[l].p; dims[0] = c->B; dims[1] = 2; dims[2] = c->hl[l]; dims[3] = c->wl[l];
+    } else if (nm.size() == 10 && nm.compare(0, 9, "flow_init") == 0 && nm[9] >= '2' && nm[9] <= '5') {
+        const int l = nm[9] - '0';
+        src = c->finit[l].p; dims[0] = c->B; dims[1] = 2; dims[2] = c->hl[l]; dims[3] = c->wl[l];
     } else {
         eem_set_error("eemplus_get_stage: unknown stage '%s'", name);
         return EEM_ERR_ARG;
@@ -411,6 +430,23 @@ extern "C" int eemplus_get_stage(eemplus_ctx* c, const char* name, float* dst, s
     if (dst == nullptr) return EEM_OK;
     EEM_REQUIRE(cap >= n, "eemplus_get_stage: '%s' needs %zu floats, buffer holds %zu", name, n, cap);
     EEM_HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return EEM_OK;
+}
+
+// Teacher-forced level: level l = 5..2 of the LAST forward's pyramid re-run from a caller-supplied cdc_model flow_init
+// [B][2][h_l][w_l] (the value the `>= 1.0` warp mask is computed from); flow_up_out / flow_out [B][2][h_l][w_l] (either may be NULL)
+// receive flow_up_l and flow_l.  The context's flow_l / flow_up_l stages are overwritten.
+extern "C" int eemplus_level(eemplus_ctx* c, int level, const float* flow_init, float* flow_up_out, float* flow_out, void* stream) {
+    EEM_REQUIRE(c && flow_init, "eemplus_level: NULL argument");
+    EEM_REQUIRE(c->have_last, "eemplus_level: no forward has run (the level runs on its feature pyramid)");
+    EEM_REQUIRE(level >= 2 && level <= 5, "eemplus_level: level %d (2..5)", level);
+    EEM_HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    int rc = run_level(c, level, c->B, flow_init, st);
+    if (rc != EEM_OK) return rc;
+    const size_t n = (size_t)c->B * 2 * c->hl[level] * c->wl[level] * sizeof(float);
+    if (flow_up_out) EEM_HIP_CHECK(hipMemcpyAsync(flow_up_out, c->fup[level].p, n, hipMemcpyDeviceToDevice, st));
+    if (flow_out) EEM_HIP_CHECK(hipMemcpyAsync(flow_out, c->flow[level].p, n, hipMemcpyDeviceToDevice, st));
     return EEM_OK;
 }
 

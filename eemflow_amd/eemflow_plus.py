@@ -153,6 +153,16 @@ class EEMFlow_cdc(nn.Module):  # noqa: N801
                                                   _lib.current_stream_ptr(e1.device)))
         return (events1, events2), [out[i] for i in range(5)]
 
+    def level(self, l, flow_init):
+        """Teacher-forced level l (5..2) on the feature pyramid of the last forward: cdc_model + warp + correlation + decoder from a
+        supplied upsampled flow_init (B,2,h_l,w_l) -> (flow_up_l, flow_l).  EEMFlow+.py:184-193; for parity tests."""
+        fi = flow_init.contiguous().float()
+        up, out = torch.empty_like(fi), torch.empty_like(fi)
+        with torch.cuda.device(fi.device):
+            _lib.check(_lib.lib().eemplus_level(self._ctx, int(l), fi.data_ptr(), up.data_ptr(), out.data_ptr(),
+                                                _lib.current_stream_ptr(fi.device)))
+        return up, out
+
     def stage(self, name):
         L = _lib.lib()
         dims = (ctypes.c_int * 4)()

@@ -246,9 +246,18 @@ int eemplus_forward(eemplus_ctx* ctx, const float* events1, const float* events2
                     const int pad[4], float* flow_out, void* stream);
 
 /* Intermediates of the LAST forward: "flow2".."flow6" (low-resolution level flows, incl. the in-place doubling
- * the reference applies to flow3..flow6) and "flow_up2".."flow_up5". */
+ * the reference applies to flow3..flow6), "flow_up2".."flow_up5" and "flow_init2".."flow_init5" (cdc_model's upsampled
+ * input flow of each level). */
 int eemplus_get_stage(eemplus_ctx* ctx, const char* name, float* dst, size_t dst_capacity_floats, int dims_out[4],
                       void* stream);
+
+/* Teacher-forced level: level l (5..2) of the coarse-to-fine loop, re-run on the feature pyramid of the LAST eemplus_forward
+ * from a caller-supplied flow_init [batch][2][h_l][w_l] - cdc_model's upsampled input flow, the value the discontinuous
+ * `grid_sample(ones) >= 1` mask of WarpingLayer_no_div is computed from.  flow_up_out / flow_out [batch][2][h_l][w_l] (either
+ * may be NULL) receive flow_up_l (cdc_model's output) and flow_l (decoder_l + flow_up_l).  Pins every level to the flow
+ * tolerance separately; the chained forward can only be compared statistically past the first mask.
+ * Replaces: one l-block of EEMFlow_cdc.forward  (model/EEMFlow/EEMFlow+.py:183-229, cdc_utils.py:156-174). */
+int eemplus_level(eemplus_ctx* ctx, int level, const float* flow_init, float* flow_up_out, float* flow_out, void* stream);
 
 /* Backward bilinear warp of x [batch][c][h][w] by flow [batch][2][h][w].  mode 0: EEMFlow_cdc.warp
  * (EEMFlow+.py:137-149, align_corners=True); 1: tensor_tools.torch_warp (utils_luo/tools.py:2262-2306,

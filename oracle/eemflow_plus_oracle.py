@@ -74,10 +74,12 @@ def dense_estimator(sd, p, x):
     return x, conv_lrelu(sd, f"{p}conv_last.0", x, act=False)
 
 
-def cdc_forward(sd, flow_init, f1, f2):
+def cdc_forward(sd, flow_init, f1, f2, keep=None):
     """cdc_model.forward with output_level_flow=None - cdc_utils.py:156-174 -> flow_up."""
     if flow_init.shape[-2:] != f1.shape[-2:]:
         flow_init = upsample2d_flow_as(flow_init, f1.shape[-2:], if_rate=True)
+    if keep is not None:
+        keep.append(flow_init.clone())
     f2w = warping_layer_no_div(f2, flow_init)
     _, x_out = dense_estimator(sd, "cdc_model.dense_estimator_mask.", torch.cat((f1, f2w), dim=1))
     inter_flow = x_out[:, :2]
@@ -106,6 +108,17 @@ def corr53(x, y):
     return (torch.stack(out, 1).view(b, 9, 9, h, w).view(b, -1, h, w) / c)[:, TAPS]
 
 
+def level_from_init(sd, l, f1l, f2l, flow_init, groups=3):
+    """One l-block of EEMFlow_cdc.forward (EEMFlow+.py:183-229) from cdc_model's (already upsampled) flow_init:
+    returns (flow_up_l, flow_l).  The teacher-forced unit the per-level parity tests compare."""
+    a = conv_lrelu(sd, f"conv_1x1.{l}.0", f1l, k=1)
+    b = conv_lrelu(sd, f"conv_1x1.{l}.0", f2l, k=1)
+    flow_up = cdc_forward(sd, flow_init, a, b)
+    f2w = warp_align_true(f2l, flow_up)
+    cat = torch.cat([corr53(f1l, f2w), conv_lrelu(sd, f"rconv{l}.0", f1l), flow_up], 1)
+    return flow_up, decoder(sd, f"decoder{l}.", cat, groups) + flow_up
+
+
 def eemflow_plus_forward(sd, events1, events2, image_size=None, groups=3, keep=False):
     """EEMFlow_cdc.forward - EEMFlow+.py:158-234.  Returns ([5 full-resolution flows coarse->fine], stages)."""
     h, w = events1.shape[-2:]
@@ -124,13 +137,17 @@ def eemflow_plus_forward(sd, events1, events2, image_size=None, groups=3, keep=F
     for l in (5, 4, 3, 2):
         a = conv_lrelu(sd, f"conv_1x1.{l}.0", f1[l], k=1)
         b = conv_lrelu(sd, f"conv_1x1.{l}.0", f2[l], k=1)
-        flow_up = cdc_forward(sd, flows[l + 1], a, b)                    # doubles flows[l+1] in place (quirk)
+        inits = [] if keep else None
+        flow_up = cdc_forward(sd, flows[l + 1], a, b, inits)             # doubles flows[l+1] in place (quirk)
         f2w = warp_align_true(f2[l], flow_up)
         cat = torch.cat([corr53(f1[l], f2w), conv_lrelu(sd, f"rconv{l}.0", f1[l]), flow_up], 1)
         flows[l] = decoder(sd, f"decoder{l}.", cat, groups) + flow_up
         if keep:
             st[f"flow_up{l}"] = flow_up
+            st[f"flow_init{l}"] = inits[0]
+            st[f"flow_raw{l}"] = flows[l].clone()                        # before the next level doubles it in place
     if keep:
         st.update({f"flow{l}": flows[l].clone() for l in flows})
+        st["f1"], st["f2"] = f1, f2
     preds = [O.unpad_none(upsample2d_flow_as(flows[l], (h, w), if_rate=True)) for l in (6, 5, 4, 3, 2)]
     return preds, st

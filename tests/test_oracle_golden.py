@@ -212,3 +212,25 @@ def test_plus_forward(golden, tag):
     np.testing.assert_allclose(got[:3], g["preds"][:3], atol=1e-5)          # levels 6, 5, 4: before the flips matter
     if os.cpu_count() and os.cpu_count() >= 4:
         assert np.array_equal(got, g["preds"])
+
+
+@pytest.mark.parametrize("tag", ["128x192", "100x150_c15"])
+def test_plus_levels_teacher_forced(golden, tag):
+    """Each level of the oracle from the REFERENCE's own flow_init of that level (tests/golden/make_golden_plus_levels.py: hooks on
+    the reference's cdc_model / decoders): with the discontinuous `>= 1.0` mask fed identical coordinates, every level holds the flow
+    tolerance on its own, whatever the thread count - unlike the chained forward above."""
+    g = golden(f"eemflow_plus_levels_{tag}.npz")
+    h, w = g["hw"].tolist()
+    cin = int(g["cin"])
+    sd = plus_sd(int(g["seed"]), cin)
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(int(g["input_seed"]), int(g["batch"]), h, w, bins=cin))
+    with torch.no_grad():
+        _, st = P.eemflow_plus_forward(sd, e1, e2, keep=True)
+        for l in (5, 4, 3, 2):
+            fin = torch.from_numpy(g[f"flow_in{l}"]).clone()
+            init = P.upsample2d_flow_as(fin, st["f1"][l].shape[-2:], if_rate=True)
+            np.testing.assert_allclose(init.numpy(), g[f"flow_init{l}"], atol=1e-6)
+            np.testing.assert_allclose(fin.numpy(), 2 * g[f"flow_in{l}"], rtol=1e-7)               # in-place doubling
+            up, fl = P.level_from_init(sd, l, st["f1"][l], st["f2"][l], torch.from_numpy(g[f"flow_init{l}"]))
+            np.testing.assert_allclose(up.numpy(), g[f"flow_up{l}"], atol=1e-4, err_msg=f"flow_up{l}")
+            np.testing.assert_allclose(fl.numpy(), g[f"flow{l}"], atol=1e-4, err_msg=f"flow{l}")

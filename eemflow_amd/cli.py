@@ -84,6 +84,16 @@ def build_model(name, config, training):
     raise SystemExit(f"model '{name}' is not built here (EEMFlow{'' if training else ', eraft, EEMFlow+'})")
 
 
+def per_rank_batch(batch_size, world):
+    """`--batch_size` is the GLOBAL batch, as in the reference, whose nn.DataParallel scatters it over the GPUs
+    (train_EEMFlow_HREM.py:116-118): each of the `world` processes takes batch_size / world samples per step, so that the same flags
+    (lr, train_iters, val_iters) train the same way on 1 and on 8 GPUs.  Equal shards are required: the gradient exchange is a
+    mean of per-rank means."""
+    if batch_size % world:
+        raise SystemExit(f"--batch_size {batch_size} is not divisible by the {world} processes of this job")
+    return batch_size // world
+
+
 def train(args):
     from . import harness, parallel
     from .hrem import HREMEventFlow
@@ -100,26 +110,30 @@ def train(args):
     config['data_loader']['train']['args']['batch_size'] = args.batch_size
     config['name'] = "lr{:5f}_we{:5f}".format(args.lr, args.wd)
     save_path = os.path.join(args.save_root, "exp_HREM_meshflow/{}_{}".format(args.model_name, args.input_type), config['name'].lower())
-    os.makedirs(save_path, exist_ok=True)
     config["data_loader"]["train"]["args"].update({'type': 'train', 'event_interval': args.input_type})
-    print('Storing output in folder {}'.format(save_path))
-    json.dump(config, open(os.path.join(save_path, 'config.json'), 'w'), indent=4, sort_keys=False)
+    if rank == 0:                                                                    # one writer: rank 0 owns the run folder and the log
+        os.makedirs(save_path, exist_ok=True)
+        print('Storing output in folder {}'.format(save_path))
+        json.dump(config, open(os.path.join(save_path, 'config.json'), 'w'), indent=4, sort_keys=False)
     start_epoch = 0
     if args.start_epoch:
         start_epoch = harness.load_checkpoint(os.path.join(save_path, 'lasted_ckpt.pth.tar'), model)
-    logger = harness.Logger(os.path.join(save_path, 'train.log') if rank == 0 else None)
+    logger = harness.Logger(os.path.join(save_path, 'train.log') if rank == 0 else None, verbose=rank == 0)
     dev = torch.device(args.device)
     torch.cuda.set_device(dev)
     train_set = HREMEventFlow(args=config["data_loader"]["train"]["args"], train=True, root=args.data_root, device=dev)
     sampler = torch.utils.data.distributed.DistributedSampler(train_set, num_replicas=world, rank=rank, shuffle=True) if world > 1 else None
-    loader = torch.utils.data.DataLoader(train_set, batch_size=args.batch_size, shuffle=sampler is None, sampler=sampler, num_workers=0,
-                                         drop_last=True)
+    loader = torch.utils.data.DataLoader(train_set, batch_size=per_rank_batch(args.batch_size, world), shuffle=sampler is None,
+                                         sampler=sampler, num_workers=0, drop_last=True)
     model = model.to(dev)
     if world > 1:                                                    # replicas start from rank 0's weights
         for prm in model.parameters():
             torch.distributed.broadcast(prm.data, src=0)
+        model.invalidate_weights()                                   # .data writes bypass the version counter the model watches
     tcfg = config["train"]
-    tr = harness.TrainRaftEvents(loader, tuple(config["val_img_size"]), lr=tcfg["lr"], wdecay=tcfg["wdecay"], epsilon=tcfg["epsilon"],
+    # The reference trainer sizes the padder with config['train_img_size'] (train_mvsec.py:67), the size its augmentor crops to.  The
+    # HREM training samples here are the un-cropped frames, so the padder is sized from the first batch itself (image_size=None).
+    tr = harness.TrainRaftEvents(loader, None, lr=tcfg["lr"], wdecay=tcfg["wdecay"], epsilon=tcfg["epsilon"],
                                  num_steps=tcfg["num_steps"], clip=tcfg["clip"], gamma=tcfg["gamma"], logger=logger)
     for epoch in range(start_epoch, max(args.train_iters // args.val_iters, 1)):
         if sampler is not None:

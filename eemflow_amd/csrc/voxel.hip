@@ -91,8 +91,12 @@ __global__ __launch_bounds__(256) void voxel_scatter_kernel(const double* __rest
     if (i >= n) return;
     const VoxTime tm = vox_time(ev, n);
     const VoxVote v = vox_vote(ev[i * 4 + 0], ev[i * 4 + 1], ev[i * 4 + 2], ev[i * 4 + 3], tm, bins, h, w);
-    if (v.okl) atomicAdd(grid + v.il, v.vl);
-    if (v.okr) atomicAdd(grid + v.ir, v.vr);
+    // the reference adds at the FLAT index (index_add_ on the flattened grid, loader_utils.py:505-521): a pixel index outside
+    // [0, h*w) lands in a neighbouring bin's plane as long as the flat index stays inside the grid; outside the grid the
+    // reference raises - those votes are dropped here (writing past the allocation is not an option)
+    const long long total = (long long)bins * h * w;
+    if (v.okl && v.il >= 0 && v.il < total) atomicAdd(grid + v.il, v.vl);
+    if (v.okr && v.ir >= 0 && v.ir < total) atomicAdd(grid + v.ir, v.vr);
     if (idx_left) idx_left[i] = v.okl ? v.il : -1;
     if (idx_right) idx_right[i] = v.okr ? v.ir : -1;
 }
@@ -156,12 +160,23 @@ __global__ __launch_bounds__(VT) void vox_bin_kernel(const double* __restrict__ 
             const VoxVote v = vox_vote(a[0], a[1], b[0], b[1], tm, bins, h, w);
             if (idx_left) idx_left[i] = v.okl ? v.il : -1;
             if (idx_right) idx_right[i] = v.okr ? v.ir : -1;
-            if (v.okl && v.pix >= 0 && v.pix < (long long)pl.hw) {
-                const unsigned bd = (unsigned)v.pix / (unsigned)pl.band_px;
+            long long pix = v.pix;
+            int tl = v.tl;
+            if (v.okl && (unsigned long long)pix >= (unsigned long long)pl.hw) {
+                // flat-index semantics of the reference (see voxel_scatter_kernel): a pixel index outside the plane moves the
+                // vote by whole planes; it survives while the flat index stays inside the grid
+                long long q = pix / (long long)pl.hw;
+                if (pix - q * (long long)pl.hw < 0) --q;           // floor division
+                pix -= q * (long long)pl.hw;
+                const long long t2 = (long long)tl + q;
+                tl = (t2 >= 0 && t2 < bins) ? (int)t2 : -1;
+            }
+            if (v.okl && tl >= 0) {
+                const unsigned bd = (unsigned)pix / (unsigned)pl.band_px;
                 band[k] = bd;
-                key[k] = ((unsigned)v.pix - bd * (unsigned)pl.band_px) | ((unsigned)v.tl << 16);
+                key[k] = ((unsigned)pix - bd * (unsigned)pl.band_px) | ((unsigned)tl << 16);
                 vl[k] = v.vl;
-                vr[k] = v.vr;
+                vr[k] = v.okr ? v.vr : 0.f;                        // (a vote moved down a plane must not revive a masked right vote)
                 rank[k] = atomicAdd(&hist[bd], 1u);                // LDS: the returned count is the rank inside the run
             }
         }

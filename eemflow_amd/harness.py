@@ -31,15 +31,15 @@ from .train import EEMFlowTrainer, sequence_loss
 class Logger:
     """write_line(text, also_print) as the reference's logger is used; lines are kept in `.lines`."""
 
-    def __init__(self, path=None):
-        self.path, self.lines = path, []
+    def __init__(self, path=None, verbose=True):
+        self.path, self.lines, self.verbose = path, [], verbose
 
     def write_line(self, text, verbose=True):
         self.lines.append(text)
         if self.path:
             with open(self.path, "a") as f:
                 f.write(text + "\n")
-        if verbose:
+        if verbose and self.verbose:
             print(text)
             sys.stdout.flush()
 
@@ -197,6 +197,10 @@ class TrainRaftEvents:
         return model
 
     def train_iters(self, model, start_epoch=0, val_iters=None):
+        if self.image_size is None:                              # padder sized from the data (cli: un-cropped HREM frames)
+            ds = getattr(self.loader, "dataset", None)
+            first = ds[0] if ds is not None else next(iter(self.loader))
+            self.image_size = tuple(int(v) for v in first['event_volume_old'].shape[-2:])
         model.change_imagesize(self.image_size)
         model.train()
         dev = _device_of(model)

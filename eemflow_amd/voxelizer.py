@@ -57,6 +57,29 @@ class EventSequence(object):
         self.features[:, 0] -= start_ts
 
 
+def voxelize_device(events, num_bins, height, width, normalize=True, out=None, return_indices=False):
+    """Voxelize events that already live on the GPU: `events` is an (N,4) float64 CUDA tensor [t, x, y, p], time-sorted, timestamps
+    already scaled / made relative (what EventSequence holds).  No host copy, no synchronisation; `out` (num_bins,H,W) fp32 is reused
+    when given.  The device-resident form of EventSequenceToVoxelGrid_Pytorch.__call__ (loader_utils.py:447-537)."""
+    if not (isinstance(events, torch.Tensor) and events.is_cuda and events.dtype == torch.float64 and events.dim() == 2
+            and events.shape[1] == 4 and events.is_contiguous()):
+        raise _lib.EEMFlowHipError("voxelize_device: events must be a contiguous (N,4) float64 CUDA tensor")
+    dev = events.device
+    n = events.shape[0]
+    with torch.no_grad(), torch.cuda.device(dev):
+        grid = out if out is not None else torch.empty(num_bins, height, width, dtype=torch.float32, device=dev)
+        if tuple(grid.shape) != (num_bins, height, width) or grid.dtype != torch.float32 or not grid.is_contiguous():
+            raise ValueError("voxelize_device: out must be a contiguous (num_bins,H,W) fp32 tensor")
+        il = ir = None
+        if return_indices:
+            il = torch.empty(n, dtype=torch.int64, device=dev)
+            ir = torch.empty(n, dtype=torch.int64, device=dev)
+        _lib.check(_lib.lib().eemflow_voxelize(
+            events.data_ptr(), n, num_bins, height, width, 1 if normalize else 0, grid.data_ptr(),
+            il.data_ptr() if return_indices else None, ir.data_ptr() if return_indices else None, _lib.current_stream_ptr(dev)))
+    return (grid, il, ir) if return_indices else grid
+
+
 class EventSequenceToVoxelGrid_Pytorch(object):
     def __init__(self, num_bins, gpu=False, gpu_nr=0, normalize=True, forkserver=True):
         if forkserver:
@@ -70,8 +93,15 @@ class EventSequenceToVoxelGrid_Pytorch(object):
         self.device = torch.device('cuda:' + str(gpu_nr))
 
     def __call__(self, event_sequence, return_indices=False):
-        events = np.ascontiguousarray(event_sequence.features.astype('float'))
         width, height = event_sequence.image_width, event_sequence.image_height
+        if isinstance(event_sequence.features, torch.Tensor) and event_sequence.features.is_cuda:
+            # events already on the GPU (a loader that keeps them resident): no astype, no host-to-device copy
+            res = voxelize_device(event_sequence.features.to(self.device, torch.float64).contiguous(), self.num_bins, height, width,
+                                  self.normalize, return_indices=return_indices)
+            if not self.return_on_gpu:
+                res = (res[0].cpu(),) + tuple(res[1:]) if return_indices else res.cpu()
+            return res
+        events = np.ascontiguousarray(event_sequence.features.astype('float'))
         assert events.shape[1] == 4
         assert self.num_bins > 0 and width > 0 and height > 0
         if not torch.cuda.is_available():

@@ -285,6 +285,43 @@ def test_voxelizer_binned_path_equals_direct_path_and_oracle(monkeypatch, h, w, 
         np.testing.assert_allclose(got, ref_norm, atol=3e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("direct", [False, True])
+def test_voxelizer_out_of_image_events_keep_flat_index_semantics_and_never_write_outside(monkeypatch, direct):
+    """The reference adds votes at the FLAT index x + y*w + bin*h*w of the flattened grid (loader_utils.py:505-521): an event with
+    y >= h (or y < 0) lands in a neighbouring bin's plane while that index is inside the grid, and index_add_ raises once it is not.
+    Both kernels reproduce the in-grid part and drop the rest; the grid sits between two guard regions that must stay untouched."""
+    from eemflow_amd.voxelizer import voxelize_device
+    h, w, bins, n = 60, 80, 5, 20_000
+    rng = np.random.default_rng(3)
+    t = np.sort(rng.uniform(0, 1000.0, n))
+    t[0] = 0.0
+    x = rng.integers(0, w, n).astype(np.float64)
+    y = rng.integers(0, h, n).astype(np.float64)
+    bad = rng.random(n) < 0.1
+    y = np.where(bad, np.where(rng.random(n) < 0.5, h + rng.integers(0, 150, n), -1.0 - rng.integers(0, 150, n)), y)
+    ev = np.stack([t, x, y, rng.integers(0, 2, n) * 2.0 - 1.0], 1)
+    if direct:
+        monkeypatch.setenv("EEM_VOX_DIRECT", "1")
+    plane, total = h * w, bins * h * w
+    buf = torch.full((3 * total,), 7.0, device=DEV)
+    grid = buf[total:2 * total].view(bins, h, w)
+    voxelize_device(torch.from_numpy(ev).to(DEV), bins, h, w, normalize=False, out=grid)
+    torch.cuda.synchronize()
+    assert bool((buf[:total] == 7.0).all()) and bool((buf[2 * total:] == 7.0).all())
+    ts = (bins - 1) * (t - t[0]) / (t[-1] - t[0])
+    tl = np.floor(ts)
+    d = (ts - tl).astype(np.float32)
+    il = (x + y * w + tl * plane).astype(np.int64)
+    ir = il + plane
+    okl = (tl < bins) & (tl >= 0) & (il >= 0) & (il < total)
+    okr = (tl + 1 < bins) & (tl >= 0) & (ir >= 0) & (ir < total)
+    assert int((okl & bad).sum()) > 100 and int((~okl & bad).sum()) > 100          # both kinds of stray events are present
+    ref = np.zeros(total, dtype=np.float64)
+    np.add.at(ref, il[okl], (ev[okl, 3] * (np.float32(1.0) - d[okl])).astype(np.float64))
+    np.add.at(ref, ir[okr], (ev[okr, 3] * d[okr]).astype(np.float64))
+    np.testing.assert_allclose(grid.cpu().numpy().ravel(), ref, atol=1e-4)
+
+
 def test_voxelizer_more_than_512_blocks(monkeypatch):
     """5.2e6 events: the binning kernel runs 8 events per thread and more than 512 blocks (run table sized by event count); the
     band kernel walks the slabs in groups of 1024.  Against the direct atomic kernel of the same library."""

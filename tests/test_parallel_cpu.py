@@ -38,6 +38,56 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _dp_worker(rank, world, port, q):
+    """Data-parallel step on real gradients: every rank differentiates the oracle's loss on ITS shard of the batch (torch autograd on
+    the CPU restatement - the library has no CPU path), the flat gradients go through parallel.average_gradients, and every rank
+    must end up with the gradient of the loss over the GLOBAL batch (train_mvsec.py:215 means over it)."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    torch.set_num_threads(2)
+    from eemflow_amd.weights import seeded_state_dict, synthetic_gt, synthetic_voxel_pair
+    from oracle import eemflow_oracle as O
+    from oracle import train_oracle as T
+    parallel.init_distributed("gloo")
+    b, h, w = 4, 64, 64
+    sd = O.to_torch_sd(seeded_state_dict(5))
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(6, b, h, w))
+    gt, valid = (torch.from_numpy(a) for a in synthetic_gt(7, b, h, w))
+    lo, hi = parallel.shard_frames(b, rank, world)
+    _, _, grads, _ = T.loss_and_grads(sd, e1[lo:hi], e2[lo:hi], gt[lo:hi], valid[lo:hi])
+    flat = torch.cat([grads[k].reshape(-1) for k in sd])
+    parallel.average_gradients(flat)
+    _, _, full, _ = T.loss_and_grads(sd, e1, e2, gt, valid)
+    ref = torch.cat([full[k].reshape(-1) for k in sd])
+    q.put((rank, float((flat - ref).abs().max()), float(ref.abs().max()), flat.numel()))
+    parallel.barrier()
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_average_equals_global_batch_gradient():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, err, scale, n in out:
+        assert n == 714352 and scale > 1e-3 and err < 1e-5 * scale + 1e-7, (rank, err, scale)
+
+
+def test_per_rank_batch_split():
+    from eemflow_amd.cli import per_rank_batch
+    assert per_rank_batch(6, 1) == 6 and per_rank_batch(8, 8) == 1 and per_rank_batch(64, 8) == 8
+    import pytest
+    with pytest.raises(SystemExit):
+        per_rank_batch(6, 4)                                    # nn.DataParallel would give ragged shards; the all-reduce mean needs equal ones
+
+
 def test_two_rank_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -162,21 +162,23 @@ __global__ __launch_bounds__(VT) void vox_bin_kernel(const double* __restrict__ 
             if (idx_right) idx_right[i] = v.okr ? v.ir : -1;
             long long pix = v.pix;
             int tl = v.tl;
+            float wl = v.vl, wr_ = v.okr ? v.vr : 0.f;             // a masked right vote stays masked wherever the pair lands
             if (v.okl && (unsigned long long)pix >= (unsigned long long)pl.hw) {
                 // flat-index semantics of the reference (see voxel_scatter_kernel): a pixel index outside the plane moves the
-                // vote by whole planes; it survives while the flat index stays inside the grid
+                // pair of votes by whole planes; each vote survives while ITS flat index stays inside the grid
                 long long q = pix / (long long)pl.hw;
                 if (pix - q * (long long)pl.hw < 0) --q;           // floor division
                 pix -= q * (long long)pl.hw;
                 const long long t2 = (long long)tl + q;
-                tl = (t2 >= 0 && t2 < bins) ? (int)t2 : -1;
+                if (t2 == -1) { tl = 0; wl = wr_; wr_ = 0.f; }     // left vote in front of the grid, right vote in plane 0
+                else tl = (t2 >= 0 && t2 < bins) ? (int)t2 : -1;
             }
             if (v.okl && tl >= 0) {
                 const unsigned bd = (unsigned)pix / (unsigned)pl.band_px;
                 band[k] = bd;
                 key[k] = ((unsigned)pix - bd * (unsigned)pl.band_px) | ((unsigned)tl << 16);
-                vl[k] = v.vl;
-                vr[k] = v.okr ? v.vr : 0.f;                        // (a vote moved down a plane must not revive a masked right vote)
+                vl[k] = wl;
+                vr[k] = wr_;
                 rank[k] = atomicAdd(&hist[bd], 1u);                // LDS: the returned count is the rank inside the run
             }
         }

@@ -195,6 +195,99 @@ def other_rows(dev):
     return out
 
 
+def latency_and_pipeline_rows(L, _lib, dev, flat, B, H, W, e1, e2, use_graph):
+    """Two rows beside the headline (not the metric): single-stream latency of one frame, and the evaluation loop of
+    test_mvsec.py:580-597 as a device-resident pipeline with FRESH tensors every frame: events -> eemflow_voxelize x2 -> forward ->
+    eemflow_flow_error on three contexts / streams (the graph cache is keyed on shapes, so new buffers replay the same graph)."""
+    out = {}
+    c = ctypes.c_void_p()
+    _lib.check(L.eemflow_create(dev.index, ctypes.byref(c)))
+    _lib.check(L.eemflow_load_weights(c, flat.data_ptr(), flat.numel(), 5, 5))
+    _lib.check(L.eemflow_set_image_size(c, H, W, None))
+    _lib.check(L.eemflow_use_graph(c, 1 if use_graph else 0))
+    st = torch.cuda.Stream(device=dev)
+    sp = ctypes.c_void_p(st.cuda_stream)
+    flow = torch.empty(B, 2, H, W, device=dev)
+    for _ in range(10):
+        _lib.check(L.eemflow_forward(c, e1.data_ptr(), e2.data_ptr(), B, H, W, flow.data_ptr(), H, W, sp))
+    torch.cuda.synchronize(dev)
+    n = 200
+    t0 = time.perf_counter()
+    for _ in range(n):
+        _lib.check(L.eemflow_forward(c, e1.data_ptr(), e2.data_ptr(), B, H, W, flow.data_ptr(), H, W, sp))
+    torch.cuda.synchronize(dev)
+    out["latency_ms_b1"] = round((time.perf_counter() - t0) / n * 1e3, 4)          # frames back to back on ONE stream
+    t0 = time.perf_counter()
+    for _ in range(50):
+        _lib.check(L.eemflow_forward(c, e1.data_ptr(), e2.data_ptr(), B, H, W, flow.data_ptr(), H, W, sp))
+        st.synchronize()
+    out["latency_ms_b1_synchronised"] = round((time.perf_counter() - t0) / 50 * 1e3, 4)   # host waits for every frame
+    L.eemflow_destroy(c)
+    if B != 1:
+        return out
+    try:
+        from eemflow_amd.hrem import synthetic_hrem_events
+        from eemflow_amd.voxelizer import EventSequence
+        NS, nev = 3, 200000
+        evs = []
+        for k in range(2):
+            seq = EventSequence(None, {"height": H, "width": W}, features=synthetic_hrem_events(3 + k, nev, H, W),
+                                timestamp_multiplier=1e6, convert_to_relative=True)
+            evs.append(torch.from_numpy(np.ascontiguousarray(seq.features)).to(dev))
+        yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+        gt = torch.from_numpy(np.stack([3 * np.sin(2 * np.pi * xx / W), 3 * np.cos(2 * np.pi * yy / H)])).to(dev)
+        ctxs, streams = [], []
+        for _ in range(NS):
+            cc = ctypes.c_void_p()
+            _lib.check(L.eemflow_create(dev.index, ctypes.byref(cc)))
+            _lib.check(L.eemflow_load_weights(cc, flat.data_ptr(), flat.numel(), 5, 5))
+            _lib.check(L.eemflow_set_image_size(cc, H, W, None))
+            _lib.check(L.eemflow_use_graph(cc, 1 if use_graph else 0))
+            ctxs.append(cc)
+            streams.append(torch.cuda.Stream(device=dev))
+        keep = []
+
+        def frame(i, voxelize):
+            k = i % NS
+            with torch.cuda.stream(streams[k]):
+                spk = ctypes.c_void_p(streams[k].cuda_stream)
+                if voxelize:
+                    v1 = torch.empty(1, 5, H, W, device=dev)
+                    v2 = torch.empty(1, 5, H, W, device=dev)
+                    _lib.check(L.eemflow_voxelize(evs[0].data_ptr(), nev, 5, H, W, 1, v1.data_ptr(), None, None, spk))
+                    _lib.check(L.eemflow_voxelize(evs[1].data_ptr(), nev, 5, H, W, 1, v2.data_ptr(), None, None, spk))
+                else:
+                    v1, v2 = e1, e2
+                fl = torch.empty(1, 2, H, W, device=dev)                     # fresh output tensor every frame
+                _lib.check(L.eemflow_forward(ctxs[k], v1.data_ptr(), v2.data_ptr(), 1, H, W, fl.data_ptr(), H, W, spk))
+                if voxelize:
+                    stats = torch.empty(5, device=dev, dtype=torch.float64)
+                    _lib.check(L.eemflow_flow_error(gt.data_ptr(), fl.data_ptr(), None, H, W, W, stats.data_ptr(), spk))
+                    keep.append(stats)
+                keep.append(fl)
+                if len(keep) > 24:                                          # drop old tensors: the allocator hands out other blocks
+                    del keep[:8]
+        for mode, key in ((False, "fresh_buffers_frames_per_s"), (True, "pipeline_frames_per_s")):
+            for i in range(30):
+                frame(i, mode)
+            torch.cuda.synchronize(dev)
+            n = 300
+            t0 = time.perf_counter()
+            for i in range(n):
+                frame(i, mode)
+            torch.cuda.synchronize(dev)
+            out[key] = round(n / (time.perf_counter() - t0), 1)
+        gs = (ctypes.c_longlong * 3)()
+        _lib.check(L.eemflow_graph_stats(ctxs[0], ctypes.byref(gs)))
+        out["pipeline_graph_captures_replays_io_updates_ctx0"] = list(gs)
+        out["pipeline_events_per_volume"] = nev
+        for cc in ctxs:
+            L.eemflow_destroy(cc)
+    except Exception as e:                                   # noqa: BLE001
+        out["pipeline_error"] = repr(e)[:200]
+    return out
+
+
 def baseline_metric():
     """BASELINE.json's metric string (the file travels with the repo); a literal copy if it is missing."""
     try:
@@ -344,6 +437,10 @@ def main():
             "encoder_tflops_in_kernel": round(enc_tflops, 2),
             "kernels": kernels, **extra,
         }
+        if world == 1:
+            rows = latency_and_pipeline_rows(L, _lib, dev, flat, B, H, W, e1, e2, not args.no_graph)
+            line["latency_ms_b1"] = rows.pop("latency_ms_b1")
+            line["latency_and_pipeline"] = rows
         if not args.no_other_rows and world == 1:
             line["other_rows"] = other_rows(dev)
         print(json.dumps(line), flush=True)

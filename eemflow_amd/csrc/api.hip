@@ -39,6 +39,8 @@ extern "C" int eemflow_create(int device, eemflow_ctx** out) {
     if (e == hipSuccess) e = hipMemcpy(c->taps, kTaps53, sizeof(kTaps53), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&c->zero_page, 4096);
     if (e == hipSuccess) e = hipMemset(c->zero_page, 0, 4096);
+    if (e == hipSuccess) e = hipMalloc(&c->io_table, 4 * sizeof(void*));
+    if (e == hipSuccess) e = hipMemset(c->io_table, 0, 4 * sizeof(void*));
     if (e != hipSuccess) {
         eem_set_error("eemflow_create: %s", hipGetErrorString(e));
         delete c;
@@ -68,6 +70,7 @@ extern "C" void eemflow_destroy(eemflow_ctx* c) {
     if (c->pack_idx) (void)hipFree(c->pack_idx);
     if (c->taps) (void)hipFree(c->taps);
     if (c->zero_page) (void)hipFree(c->zero_page);
+    if (c->io_table) (void)hipFree(c->io_table);
     delete c;
 }
 
@@ -278,39 +281,77 @@ extern "C" int eemflow_forward(eemflow_ctx* c, const float* e1, const float* e2,
     int rc = compute_shape(c, batch, in_h, in_w, out_h, out_w, &s);
     if (rc != EEM_OK) return rc;
 
-    eemflow_ctx::Key key = {e1, e2, out, batch, in_h, in_w, out_h, out_w, {c->pad[0], c->pad[1], c->pad[2], c->pad[3]}};
-    if (c->use_graph && c->have_graph && memcmp(&key, &c->graph_key, sizeof(key)) == 0) {
-        EEM_HIP_CHECK(hipGraphLaunch(c->graph_exec, st));
-        return EEM_OK;
+    if (!c->use_graph) {
+        if ((rc = alloc_workspace(c, s)) != EEM_OK) return rc;
+        c->last = s;
+        c->have_last = true;
+        Hook hk;
+        hk.st = st;
+        return run_forward(c, s, e1, e2, out, hk);
     }
-    // (re)allocation invalidates pointers baked into a cached graph
-    drop_graph(c);
-    if ((rc = alloc_workspace(c, s)) != EEM_OK) return rc;
-    c->last = s;
+    const int aligned = (((uintptr_t)e1 | (uintptr_t)e2 | (uintptr_t)out) & 15) == 0;
+    const eemflow_ctx::Key key = {batch, in_h, in_w, out_h, out_w, {c->pad[0], c->pad[1], c->pad[2], c->pad[3]}, aligned};
+    eemflow_ctx::GraphEntry* ent = nullptr;
+    for (eemflow_ctx::GraphEntry& g : c->graphs)
+        if (g.key == key) ent = &g;
+    if (ent == nullptr) {
+        if ((rc = alloc_workspace(c, s)) != EEM_OK) return rc;          // may drop every entry (buffers moved)
+        if ((int)c->graphs.size() >= eemflow_ctx::kMaxGraphs) {           // evict the least recently used entry
+            size_t lru = 0;
+            for (size_t i = 1; i < c->graphs.size(); ++i)
+                if (c->graphs[i].last_use < c->graphs[lru].last_use) lru = i;
+            if (c->graphs[lru].exec) (void)hipGraphExecDestroy(c->graphs[lru].exec);
+            if (c->graphs[lru].graph) (void)hipGraphDestroy(c->graphs[lru].graph);
+            c->graphs.erase(c->graphs.begin() + lru);
+        }
+        hipStream_t cap = st;
+        bool own_stream = false;
+        if (cap == nullptr) {        // the legacy default stream cannot be captured
+            EEM_HIP_CHECK(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+            own_stream = true;
+        }
+        EEM_HIP_CHECK(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+        Hook hk;
+        hk.st = cap;
+        rc = run_forward(c, s, e1, e2, out, hk, c->io_table);
+        hipGraph_t g = nullptr;
+        hipError_t e = hipStreamEndCapture(cap, &g);
+        if (own_stream) (void)hipStreamDestroy(cap);
+        if (rc != EEM_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+        if (e != hipSuccess) { eem_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return EEM_ERR_HIP; }
+        eemflow_ctx::GraphEntry ne;
+        ne.key = key;
+        ne.shape = s;
+        ne.graph = g;
+        hipError_t ie = hipGraphInstantiate(&ne.exec, g, nullptr, nullptr, 0);
+        if (ie != hipSuccess) {
+            (void)hipGraphDestroy(g);
+            eem_set_error("hipGraphInstantiate: %s", hipGetErrorString(ie));
+            return EEM_ERR_HIP;
+        }
+        c->graphs.push_back(ne);
+        ent = &c->graphs.back();
+        c->graph_captures += 1;
+    }
+    // the table must name this call's buffers before the replay reads it (stream-ordered; one context = one stream at a time)
+    if (c->io_host[0] != e1 || c->io_host[1] != e2 || c->io_host[2] != out || c->io_stream != stream) {
+        if ((rc = io_table_launch(c->io_table, e1, e2, out, st)) != EEM_OK) return rc;
+        c->io_host[0] = e1; c->io_host[1] = e2; c->io_host[2] = out;
+        c->io_stream = stream;
+        c->io_updates += 1;
+    }
+    ent->last_use = ++c->graph_clock;
+    c->last = ent->shape;
     c->have_last = true;
-    Hook hk;
-    hk.st = st;
-    if (!c->use_graph) return run_forward(c, s, e1, e2, out, hk);
+    c->graph_replays += 1;
+    EEM_HIP_CHECK(hipGraphLaunch(ent->exec, st));
+    return EEM_OK;
+}
 
-    hipStream_t cap = st;
-    bool own_stream = false;
-    if (cap == nullptr) {        // the legacy default stream cannot be captured
-        EEM_HIP_CHECK(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
-        own_stream = true;
-    }
-    EEM_HIP_CHECK(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
-    hk.st = cap;
-    rc = run_forward(c, s, e1, e2, out, hk);
-    hipGraph_t g = nullptr;
-    hipError_t e = hipStreamEndCapture(cap, &g);
-    if (own_stream) (void)hipStreamDestroy(cap);
-    if (rc != EEM_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
-    if (e != hipSuccess) { eem_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return EEM_ERR_HIP; }
-    c->graph = g;
-    EEM_HIP_CHECK(hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
-    c->graph_key = key;
-    c->have_graph = true;
-    EEM_HIP_CHECK(hipGraphLaunch(c->graph_exec, st));
+// Graph-cache statistics of a context: captures (stream captures + instantiations), replays, io-table rewrites.
+extern "C" int eemflow_graph_stats(eemflow_ctx* c, long long out3[3]) {
+    EEM_REQUIRE(c && out3, "eemflow_graph_stats: NULL argument");
+    out3[0] = c->graph_captures; out3[1] = c->graph_replays; out3[2] = c->io_updates;
     return EEM_OK;
 }
 
@@ -324,7 +365,6 @@ extern "C" int eemflow_time_kernels(eemflow_ctx* c, const float* e1, const float
     Shape s;
     int rc = compute_shape(c, batch, in_h, in_w, out_h, out_w, &s);
     if (rc != EEM_OK) return rc;
-    drop_graph(c);
     if ((rc = alloc_workspace(c, s)) != EEM_OK) return rc;
     c->last = s;
     c->have_last = true;
@@ -379,14 +419,15 @@ extern "C" int eemflow_decoder(eemflow_ctx* c, int k, const float* x, int batch,
     EEM_REQUIRE(c->weights_loaded, "eemflow_decoder: no weights loaded");
     EEM_REQUIRE(k >= 1 && k <= 3 && batch >= 1 && h >= 1 && w >= 1, "eemflow_decoder: bad arguments");
     EEM_HIP_CHECK(hipSetDevice(c->device));
-    drop_graph(c);                           // may grow the shared scratch buffers
     const size_t g = (size_t)h * w, B = batch;
     int rc;
     const int i = k - 1;
+    const unsigned long moved = g_realloc_events;
     if ((rc = ensure(c->ta[i], B * kDecW * g)) || (rc = ensure(c->tb[i], B * kDecW * g)) ||
         (rc = ensure(c->tc[i], B * kDecW * g)) || (rc = ensure(c->td[i], B * kDecW * g)) ||
         (rc = ensure(c->t64[i], B * 64 * g)) || (rc = ensure(c->t32[i], B * 32 * g)))
         return rc;
+    if (g_realloc_events != moved) drop_graph(c);    // a scratch buffer the cached graphs point into has moved
     const float* cats[3] = {x, x, x};
     Hook hk;
     hk.st = (hipStream_t)stream;

@@ -91,22 +91,43 @@ struct eemflow_ctx {
     DevBuf a1, f11, a2, b2, f12, a3, b3, f13, pool[3], ppart[3], cat[3], ta[3], tb[3], tc[3], td[3], t64[3], t32[3], flowcat, coarse;
     Shape last;
     bool have_last = false;
-    // graph cache
+    // graph cache: up to kMaxGraphs captured forwards keyed on SHAPES only.  The two launches that touch caller buffers (the
+    // first conv, the upsample) read their pointers from `io_table` (device: {events1, events2, flow_out}), which one tiny
+    // launch rewrites in front of a replay whenever the caller hands over other buffers - fresh tensors per frame replay the
+    // same graph.  Every entry bakes in workspace pointers: a reallocation (ensure) drops them all.
     bool use_graph = true;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
     struct Key {
-        const float *e1, *e2;
-        float* out;
         int batch, in_h, in_w, out_h, out_w, pad[4];
-    } graph_key;
-    bool have_graph = false;
+        int aligned16;                                   // all three caller buffers 16-byte aligned (kernel selection depends on it)
+        bool operator==(const Key& o) const {
+            return batch == o.batch && in_h == o.in_h && in_w == o.in_w && out_h == o.out_h && out_w == o.out_w &&
+                   pad[0] == o.pad[0] && pad[1] == o.pad[1] && pad[2] == o.pad[2] && pad[3] == o.pad[3] && aligned16 == o.aligned16;
+        }
+    };
+    struct GraphEntry {
+        Key key;
+        Shape shape;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        long last_use = 0;
+    };
+    static constexpr int kMaxGraphs = 4;
+    std::vector<GraphEntry> graphs;
+    long graph_clock = 0;
+    const void** io_table = nullptr;                     // device
+    const void* io_host[3] = {nullptr, nullptr, nullptr};   // what the table holds once the launches issued so far have run
+    void* io_stream = nullptr;                           // stream of the last table write / replay
+    long graph_captures = 0, graph_replays = 0, io_updates = 0;   // statistics (eemflow_graph_stats)
 };
 
 namespace {
 
+// bumped whenever ensure() moves a buffer: cached graphs hold workspace pointers (see alloc_workspace)
+static thread_local unsigned long g_realloc_events = 0;
+
 int ensure(DevBuf& b, size_t floats) {
     if (floats <= b.cap) return EEM_OK;
+    ++g_realloc_events;
     if (b.p) EEM_HIP_CHECK(hipFree(b.p));
     b.p = nullptr;
     b.cap = 0;
@@ -128,11 +149,11 @@ int refresh_wino(eemflow_ctx* c, hipStream_t st) {
 }
 
 void drop_graph(eemflow_ctx* c) {
-    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
-    if (c->graph) (void)hipGraphDestroy(c->graph);
-    c->graph_exec = nullptr;
-    c->graph = nullptr;
-    c->have_graph = false;
+    for (eemflow_ctx::GraphEntry& e : c->graphs) {
+        if (e.exec) (void)hipGraphExecDestroy(e.exec);
+        if (e.graph) (void)hipGraphDestroy(e.graph);
+    }
+    c->graphs.clear();
 }
 
 int compute_shape(eemflow_ctx* c, int batch, int in_h, int in_w, int out_h, int out_w, Shape* s) {
@@ -168,7 +189,16 @@ int compute_shape(eemflow_ctx* c, int batch, int in_h, int in_w, int out_h, int 
     return EEM_OK;
 }
 
+int alloc_workspace_raw(eemflow_ctx* c, const Shape& s);
+// workspace for shape s; cached graphs survive unless a buffer had to move
 int alloc_workspace(eemflow_ctx* c, const Shape& s) {
+    const unsigned long before = g_realloc_events;
+    const int rc = alloc_workspace_raw(c, s);
+    if (g_realloc_events != before) drop_graph(c);
+    return rc;
+}
+
+int alloc_workspace_raw(eemflow_ctx* c, const Shape& s) {
     const size_t n2 = 2 * (size_t)s.batch, B = s.batch, g = (size_t)s.gh * s.gw;
     int rc;
 #define ENS(buf, n) if ((rc = ensure(buf, n)) != EEM_OK) return rc
@@ -289,7 +319,9 @@ int run_decoders(eemflow_ctx* c, int k0, int k1, const float* const cat[3], int 
     return run_tail(hk, "dec.conv7 32->2", L);
 }
 
-int run_forward(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2, float* out, Hook& hk) {
+// io: nullptr (eager: the caller's pointers go into the launches) or the context's device table (graph capture)
+int run_forward(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2, float* out, Hook& hk,
+                const void* const* io = nullptr) {
     int rc;
     const int n2 = 2 * s.batch;
     // ---- encoder (both event volumes as one batch; shared weights, EEMFlow.py:135-140)
@@ -325,6 +357,7 @@ int run_forward(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2
         a.gate = nullptr;
         a.pool_partial = nullptr;
         a.pool_k = 0;
+        a.io = sp.layer == ENC_1_1 ? io : nullptr;
         for (int k = 0; k < 3; ++k)
             if (s.fuse[k] && sp.layer == (k == 0 ? ENC_1_2 : k == 1 ? ENC_2_3 : ENC_3_3)) {
                 a.pool_partial = c->ppart[k].p;
@@ -391,7 +424,7 @@ int run_forward(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2
     if ((rc = run_tail(hk, "out_conv 1x1 6->2", L)) != EEM_OK) return rc;
     const double opix = (double)s.batch * 2 * s.out_h * s.out_w;
     return hk.run("upsample bilinear", 8.0 * opix, 4.0 * (opix + (double)s.batch * 2 * g), [&](hipStream_t st) {
-        return upsample_launch(c->coarse.p, out, s.batch * 2, s.gh, s.gw, s.out_h, s.out_w, st);
+        return upsample_launch(c->coarse.p, out, s.batch * 2, s.gh, s.gw, s.out_h, s.out_w, st, io);
     });
 }
 

@@ -144,6 +144,9 @@ struct EncConvArgs {
     int tiles_x, tiles_y;  // filled by the launcher: block tiles per image (blocks are remapped XCD-aware)
     float* pool_partial;   // fast path only: per-block partial sums of the k x k stage pooling, or NULL
     int pool_k;
+    // ENC_1_1 inside a cached HIP graph: device table {events1, events2, flow_out}; when non-NULL the kernel reads in0 / in1
+    // from it instead of from the fields above, so the graph does not depend on the caller's buffers (api.hip)
+    const void* const* io;
 };
 int enc_conv_launch(int cin, int cout, int stride, const EncConvArgs& a, hipStream_t stream);
 // first layer with 16-byte LDS-DMA staging (conv_enc1.hip): raw width % 4 == 0, no horizontal padding
@@ -210,7 +213,11 @@ int corr_launch(const CorrJob* jobs, int njobs, int batch, int h, int w, const i
                 hipStream_t stream);
 
 // plain bilinear resize (align_corners False) of [n][c][h][w] -> [n][c][oh][ow]
-int upsample_launch(const float* in, float* out, int nc, int h, int w, int oh, int ow, hipStream_t stream);
+// io: optional device table {events1, events2, flow_out}; when non-NULL the destination is io[2] (see EncConvArgs::io)
+int upsample_launch(const float* in, float* out, int nc, int h, int w, int oh, int ow, hipStream_t stream,
+                    const void* const* io = nullptr);
+// writes {e1, e2, out} into the device table (one tiny launch in front of a cached graph whose buffers changed)
+int io_table_launch(const void** table, const void* e1, const void* e2, void* out, hipStream_t stream);
 
 // arena[i] = idx[i] ? flat[idx[i] - 1] : 0  (weight re-packing after an optimizer step, see api.hip)
 int repack_launch(const float* flat, const int* idx, float* arena, long n, hipStream_t stream);

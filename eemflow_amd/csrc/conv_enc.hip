@@ -66,9 +66,12 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(EncConvArgs a) {
     // all of a wave's copies are in flight at once and no VGPR holds the data.
     {
         const float* src;
-        if (PADIN)
-            src = (n < a.nimg0) ? a.in0 + (size_t)n * CIN * a.hraw * a.wraw
-                                : a.in1 + (size_t)(n - a.nimg0) * CIN * a.hraw * a.wraw;
+        if (PADIN) {
+            const float* in0 = a.io ? (const float*)a.io[0] : a.in0;     // cached graph: buffers through the io table
+            const float* in1 = a.io ? (const float*)a.io[1] : a.in1;
+            src = (n < a.nimg0) ? in0 + (size_t)n * CIN * a.hraw * a.wraw
+                                : in1 + (size_t)(n - a.nimg0) * CIN * a.hraw * a.wraw;
+        }
         else
             src = a.in0 + (size_t)n * CIN * a.hin * a.win;
         const int gy0 = oy0 * STRIDE - 1;

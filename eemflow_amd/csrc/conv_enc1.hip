@@ -47,6 +47,9 @@ __global__ __launch_bounds__(WAVES * 64) void enc1_kernel(EncConvArgs a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, g = lane >> 4;
+    // inside a cached graph the event volumes come through the context's io table (scalar loads; see EncConvArgs::io)
+    const float* in0 = a.io ? (const float*)a.io[0] : a.in0;
+    const float* in1 = a.io ? (const float*)a.io[1] : a.in1;
 
     const TileRange tr_ = block_tile_range(a.tiles_x * a.tiles_y * a.nimg, blockIdx.x, gridDim.x);
     const int ntile = tr_.count;
@@ -76,8 +79,8 @@ __global__ __launch_bounds__(WAVES * 64) void enc1_kernel(EncConvArgs a) {
     auto issue = [&](int it, const TileCoord& tc) {
         const int bx = tc.bx, by = tc.by, n = tc.n;
         const int gy0 = by * TH * 2 - 1, gx0 = bx * K::TW * 2 - 4;          // padded-image coordinates
-        const float* src = (n < a.nimg0) ? a.in0 + (size_t)n * K::CIN * a.hraw * a.wraw
-                                         : a.in1 + (size_t)(n - a.nimg0) * K::CIN * a.hraw * a.wraw;
+        const float* src = (n < a.nimg0) ? in0 + (size_t)n * K::CIN * a.hraw * a.wraw
+                                         : in1 + (size_t)(n - a.nimg0) * K::CIN * a.hraw * a.wraw;
         float* sbase = lds + (it % K::NST) * K::STAGE;
 #pragma unroll
         for (int k = 0; k < K::NI; ++k) {

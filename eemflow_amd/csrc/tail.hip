@@ -228,8 +228,13 @@ __device__ __forceinline__ void src_index(float scale, int dst, int in_size, int
     l1 = s - (float)i0;
 }
 
-__global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                       int nc, int h, int w, int oh, int ow) {
+__global__ void io_table_kernel(const void** table, const void* e1, const void* e2, void* out) {
+    table[0] = e1; table[1] = e2; table[2] = out;
+}
+
+__global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ in, float* __restrict__ out_arg,
+                                                       int nc, int h, int w, int oh, int ow, const void* const* io) {
+    float* __restrict__ out = io ? (float*)io[2] : out_arg;
     const int xq = ceil_div(ow, 4);
     const long total = (long)nc * oh * xq;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -360,11 +365,17 @@ int tail_conv_launch(const TailConvLaunch& l, hipStream_t stream) {
     return EEM_OK;
 }
 
-int upsample_launch(const float* in, float* out, int nc, int h, int w, int oh, int ow, hipStream_t stream) {
+int upsample_launch(const float* in, float* out, int nc, int h, int w, int oh, int ow, hipStream_t stream, const void* const* io) {
     const long total = (long)nc * oh * ceil_div(ow, 4);
     if (total == 0) return EEM_OK;
     hipLaunchKernelGGL(upsample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, in, out, nc,
-                       h, w, oh, ow);
+                       h, w, oh, ow, io);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int io_table_launch(const void** table, const void* e1, const void* e2, void* out, hipStream_t stream) {
+    hipLaunchKernelGGL(io_table_kernel, dim3(1), dim3(1), 0, stream, table, e1, e2, out);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

@@ -254,8 +254,7 @@ static int forward_train_impl(eemflow_ctx* c, const float* e1, const float* e2, 
     Shape s;
     int rc = compute_shape(c, batch, in_h, in_w, out_h, out_w, &s);
     if (rc != EEM_OK) return rc;
-    drop_graph(c);
-    if ((rc = alloc_workspace(c, s)) != EEM_OK) return rc;
+    if ((rc = alloc_workspace(c, s)) != EEM_OK) return rc;      // cached inference graphs survive unless a buffer moves
     if ((rc = alloc_train(c, s)) != EEM_OK) return rc;
     c->last = s;
     c->have_last = true;
@@ -355,7 +354,7 @@ extern "C" int eemflow_optimizer_step(eemflow_ctx* c, const float* grad, float l
     c->opt_step += 1;
     if ((rc = tr_adamw_launch(c->flat, grad, c->adam_m.p, c->adam_v.p, (long)c->nflat, sumsq, clip, lr, weight_decay, eps, 0.9f,
                               0.999f, c->opt_step, st)) != EEM_OK) return rc;
-    drop_graph(c);
+    // (cached graphs read the arena in place: same addresses, new values)
     if ((rc = repack_launch(c->flat, c->pack_idx, c->arena, (long)c->arena_floats, st)) != EEM_OK) return rc;
     return refresh_wino(c, st);
 }

@@ -10,8 +10,7 @@
  * reference interface it replaces (paths relative to the reference repo root).
  *
  * Tensors are dense NCHW fp32 unless stated.  Ownership: the caller owns every buffer it passes;
- * the context owns its weights and workspaces and never retains caller pointers beyond a call
- * (except inside a cached HIP graph, which is keyed on those pointers and rebuilt when they change).
+ * the context owns its weights and workspaces and never retains caller pointers beyond a call.
  * Threading: one context per host thread/stream; calls on one context must not overlap.
  */
 #ifndef EEMFLOW_HIP_H
@@ -57,8 +56,14 @@ int eemflow_update_weights(eemflow_ctx* ctx, const float* flat_device, size_t nf
  * (model/EEMFlow/EEMFlow.py:114-116, utils/image_utils.py:129-137). */
 int eemflow_set_image_size(eemflow_ctx* ctx, int height, int width, int pad_out[4]);
 
-/* Replay the forward pass through a cached HIP graph (1, default) or launch kernels eagerly (0). */
+/* Replay the forward pass through a cached HIP graph (1, default) or launch kernels eagerly (0).  Graphs are keyed on shapes,
+ * not on the caller's buffers: the two launches that touch events1 / events2 / flow_out read those pointers from a device
+ * table that one tiny launch rewrites when a call brings other buffers, so fresh tensors every frame (the reference's
+ * evaluation loop, test_mvsec.py:580-597) replay the same graph.  Up to four shapes stay cached (least recently used out). */
 int eemflow_use_graph(eemflow_ctx* ctx, int enable);
+
+/* Graph-cache statistics: out3 = {captures, replays, io-table rewrites}. */
+int eemflow_graph_stats(eemflow_ctx* ctx, long long out3[3]);
 
 /* Inference forward: events1/events2 [batch][C][in_h][in_w] -> flow_out [batch][2][out_h][out_w].
  * The reference upsamples the 1/64 grid straight to the *input* size (out_h,out_w = in_h,in_w) or,

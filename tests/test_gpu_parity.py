@@ -121,6 +121,60 @@ def test_graph_equals_eager_and_is_repeatable():
     assert torch.equal(outs[0], outs[1])
 
 
+def graph_stats(net):
+    gs = (ctypes.c_longlong * 3)()
+    _lib.check(_lib.lib().eemflow_graph_stats(net._ctx, ctypes.byref(gs)))
+    return list(gs)                              # captures, replays, io-table rewrites
+
+
+def test_graph_cache_survives_fresh_buffers_and_keeps_several_shapes():
+    """The evaluation loop of test_mvsec.py:580-597 brings new tensors every sample: the cached graph is keyed on shapes, the caller's
+    buffers reach it through the context's io table.  Alternating sizes keep one graph each; a larger size that moves the workspace
+    drops them; a training forward in between does not."""
+    net, sd = make_net(45)
+    tsd = O.to_torch_sd(sd)
+    shapes = [(2, 128, 192), (1, 96, 128)]          # the larger one first: the second fits the workspace, nothing moves
+    refs, inputs = {}, {}
+    for b, h, w in shapes:
+        e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(46 + h, b, h, w))
+        with torch.no_grad():
+            refs[(b, h, w)] = O.eemflow_forward(tsd, e1, e2)[0]
+        inputs[(b, h, w)] = (e1, e2)
+    hold = []
+    with torch.no_grad():
+        for rep in range(4):
+            for b, h, w in shapes:
+                net.change_imagesize((h, w))
+                e1, e2 = (t.to(DEV).clone() for t in inputs[(b, h, w)])        # fresh device tensors every call
+                flow = net(e1, e2)[1][0]
+                hold += [e1, e2, flow]                                          # keep them alive: the allocator must hand out new blocks
+                assert maxerr(flow, refs[(b, h, w)]) < FLOW_TOL
+    cap, rep, io = graph_stats(net)
+    assert cap == 2 and rep == 8 and io == 8, (cap, rep, io)
+    # same buffers again: no table rewrite
+    with torch.no_grad():
+        net.change_imagesize((96, 128))
+        e1, e2 = hold[-3], hold[-2]
+        out_a = net(e1, e2)[1][0].clone()
+    net.train()
+    net(e1, e2)[1][0].sum().backward()           # autograd forward + backward on the same context: graphs stay
+    net.eval()
+    with torch.no_grad():
+        out_b = net(e1, e2)[1][0]
+    assert torch.equal(out_a, out_b) and graph_stats(net)[0] == 2
+    # a larger frame moves the workspace: every cached graph is dropped and rebuilt on demand
+    b, h, w = 1, 256, 320
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(49, b, h, w))
+    with torch.no_grad():
+        net.change_imagesize((h, w))
+        big = net(e1.to(DEV), e2.to(DEV))[1][0]
+        assert maxerr(big, O.eemflow_forward(tsd, e1, e2)[0]) < FLOW_TOL
+        net.change_imagesize((128, 192))
+        e1, e2 = (t.to(DEV) for t in inputs[(2, 128, 192)])
+        assert maxerr(net(e1, e2)[1][0], refs[(2, 128, 192)]) < FLOW_TOL
+    assert graph_stats(net)[0] == 4
+
+
 def test_weights_reload_after_update():
     h, w = 64, 128
     net, sd = make_net(51)

@@ -371,54 +371,97 @@ int run_forward(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2
                     [&](hipStream_t st) { return enc_conv_launch(d.cin, d.cout, d.stride, a, st); });
         if (rc != EEM_OK) return rc;
     }
-    // ---- stage pooling to the common 1/64 grid (EEMFlow.py:144-154): finish the partial sums the conv
-    // epilogues wrote; stages whose conv ran the generic kernel are pooled from the stored feature map
+    // ---- stage pooling to the common 1/64 grid (EEMFlow.py:144-154), 53-tap correlation and rconv into the decoders' input
+    // [cv | r] (EEMFlow.py:160-163).  Fused form (default): ONE launch whose correlation / rconv blocks read the conv epilogues'
+    // pooling partial sums directly and whose extra blocks write the finished pooled maps (tail_fused.hip).  Stages whose conv
+    // ran the generic kernel are pooled from the stored feature map first.  EEM_NO_TAIL_FUSE=1: the three separate launches.
+    const size_t g = (size_t)s.gh * s.gw;
+    const int pc[3] = {16, 32, 64};
+    static const bool no_fuse = [] { const char* e = getenv("EEM_NO_TAIL_FUSE"); return e && e[0] == '1'; }();
     {
         const float* feat[3] = {c->f11.p, c->f12.p, c->f13.p};
-        const int pcs[3] = {16, 32, 64}, hs[3] = {s.h1, s.h2, s.h3}, ws[3] = {s.w1, s.w2, s.w3}, ks[3] = {32, 16, 8};
+        const int hs[3] = {s.h1, s.h2, s.h3}, ws[3] = {s.w1, s.w2, s.w3}, ks[3] = {32, 16, 8};
         PoolFinJob fj[3];
         PoolJob pj[3];
         int nf = 0, np = 0;
         double fin_elems = 0, pool_elems = 0;
         for (int k = 0; k < 3; ++k) {
             if (s.fuse[k]) {
-                fj[nf++] = {c->ppart[k].p, c->pool[k].p, pcs[k], s.prow[k], s.pcol[k], ks[k] / s.th[k], ks[k]};
-                fin_elems += (double)n2 * pcs[k] * s.gh * s.gw * (ks[k] / s.th[k] + 1);
+                fj[nf++] = {c->ppart[k].p, c->pool[k].p, pc[k], s.prow[k], s.pcol[k], ks[k] / s.th[k], ks[k]};
+                fin_elems += (double)n2 * pc[k] * s.gh * s.gw * (ks[k] / s.th[k] + 1);
             } else {
-                pj[np++] = {feat[k], c->pool[k].p, pcs[k], hs[k], ws[k], ks[k]};
-                pool_elems += (double)n2 * pcs[k] * hs[k] * ws[k];
+                pj[np++] = {feat[k], c->pool[k].p, pc[k], hs[k], ws[k], ks[k]};
+                pool_elems += (double)n2 * pc[k] * hs[k] * ws[k];
             }
-        }
-        if (nf) {
-            rc = hk.run("pool finalize (fused partials)", fin_elems, 4.0 * fin_elems, [&](hipStream_t st) {
-                return pool_finalize_launch(fj, nf, n2, s.gh, s.gw, st);
-            });
-            if (rc != EEM_OK) return rc;
         }
         if (np) {
             rc = hk.run("pool 32/16/8", pool_elems, 4.0 * pool_elems,
                         [&](hipStream_t st) { return pool_launch(pj, np, n2, st); });
             if (rc != EEM_OK) return rc;
         }
+        if (!no_fuse) {
+            TailHeadArgs ha;
+            memset(&ha, 0, sizeof(ha));
+            for (int k = 0; k < 3; ++k) {
+                PooledSrc& ps = ha.src[k];
+                if (s.fuse[k]) {
+                    const int rows = ks[k] / s.th[k];
+                    ps.base = c->ppart[k].p; ps.rows = rows; ps.rstride = s.pcol[k]; ps.ystride = rows * s.pcol[k];
+                    ps.cstride = s.prow[k] * s.pcol[k]; ps.nstride = pc[k] * ps.cstride; ps.scale = 1.f / (float)(ks[k] * ks[k]);
+                } else {
+                    ps.base = c->pool[k].p; ps.rows = 1; ps.rstride = 0; ps.ystride = s.gw; ps.cstride = (int)g;
+                    ps.nstride = pc[k] * (int)g; ps.scale = 1.f;
+                }
+                ha.c[k] = pc[k];
+                ha.cat[k] = c->cat[k].p;
+                ha.pool_out[k] = s.fuse[k] ? c->pool[k].p : nullptr;
+                ha.rw[k] = c->arena + c->rconv[k].wpk;
+                ha.rb[k] = c->arena + c->rconv[k].bias;
+            }
+            ha.taps = c->taps; ha.batch = s.batch; ha.gh = s.gh; ha.gw = s.gw; ha.ntaps = kNTaps; ha.cat_ctotal = kDecIn;
+            const double fl = 2.0 * s.batch * g * (kNTaps * (16 + 32 + 64) + 16.0 * 9 * (16 + 32 + 64));
+            rc = hk.run("tail head: pool+corr53+rconv", fl, 4.0 * (fin_elems + 3.0 * s.batch * g * kDecIn),
+                        [&](hipStream_t st) { return tail_head_launch(ha, st); });
+            if (rc != EEM_OK) return rc;
+        } else {
+            if (nf) {
+                rc = hk.run("pool finalize (fused partials)", fin_elems, 4.0 * fin_elems, [&](hipStream_t st) {
+                    return pool_finalize_launch(fj, nf, n2, s.gh, s.gw, st);
+                });
+                if (rc != EEM_OK) return rc;
+            }
+            CorrJob cj[3];
+            for (int k = 0; k < 3; ++k)
+                cj[k] = {c->pool[k].p, c->pool[k].p + (size_t)s.batch * pc[k] * g, c->cat[k].p, pc[k], kDecIn};
+            rc = hk.run("local_corr 9x9 (53 taps)", 2.0 * s.batch * g * kNTaps * (16 + 32 + 64),
+                        4.0 * s.batch * g * (2.0 * (16 + 32 + 64) + 3.0 * kNTaps),
+                        [&](hipStream_t st) { return corr_launch(cj, 3, s.batch, s.gh, s.gw, c->taps, kNTaps, st); });
+            if (rc != EEM_OK) return rc;
+            TailConvLaunch L0;
+            L0.batch = s.batch; L0.h = s.gh; L0.w = s.gw; L0.ksize = 3; L0.njobs = 0;
+            for (int k = 0; k < 3; ++k)
+                L0.job[L0.njobs++] = make_job(c, c->rconv[k], c->pool[k].p, pc[k], 0, c->cat[k].p, kDecIn, kNTaps, 1, 1);
+            if ((rc = run_tail(hk, "rconv {16,32,64}->16", L0)) != EEM_OK) return rc;
+        }
     }
-    // ---- correlation (53 taps) and rconv into the decoders' input [cv | r] (EEMFlow.py:160-163)
-    const size_t g = (size_t)s.gh * s.gw;
-    const int pc[3] = {16, 32, 64};
-    CorrJob cj[3];
-    for (int k = 0; k < 3; ++k)
-        cj[k] = {c->pool[k].p, c->pool[k].p + (size_t)s.batch * pc[k] * g, c->cat[k].p, pc[k], kDecIn};
-    rc = hk.run("local_corr 9x9 (53 taps)", 2.0 * s.batch * g * kNTaps * (16 + 32 + 64),
-                4.0 * s.batch * g * (2.0 * (16 + 32 + 64) + 3.0 * kNTaps),
-                [&](hipStream_t st) { return corr_launch(cj, 3, s.batch, s.gh, s.gw, c->taps, kNTaps, st); });
-    if (rc != EEM_OK) return rc;
     TailConvLaunch L;
     L.batch = s.batch; L.h = s.gh; L.w = s.gw; L.ksize = 3; L.njobs = 0;
-    for (int k = 0; k < 3; ++k)
-        L.job[L.njobs++] = make_job(c, c->rconv[k], c->pool[k].p, pc[k], 0, c->cat[k].p, kDecIn, kNTaps, 1, 1);
-    if ((rc = run_tail(hk, "rconv {16,32,64}->16", L)) != EEM_OK) return rc;
     // ---- decoders, out_conv, upsample (EEMFlow.py:164-181)
     const float* cats[3] = {c->cat[0].p, c->cat[1].p, c->cat[2].p};
+    const bool fuse_up = !no_fuse && tail_up_supported(s.gh, s.gw, s.out_h, s.out_w);
     if ((rc = run_decoders(c, 0, 3, cats, s.batch, s.gh, s.gw, c->flowcat.p, 6, 0, hk)) != EEM_OK) return rc;
+    if (fuse_up) {
+        // out_conv + bilinear upsample in one launch; `coarse` is its side output
+        TailUpArgs ua;
+        memset(&ua, 0, sizeof(ua));
+        ua.wo = c->flat + c->t_outc.w; ua.bo = c->flat + c->t_outc.b;
+        ua.flowcat = c->flowcat.p; ua.coarse = c->coarse.p; ua.out = out; ua.io = io;
+        ua.batch = s.batch; ua.gh = s.gh; ua.gw = s.gw; ua.oh = s.out_h; ua.ow = s.out_w;
+        ua.out_aligned16 = ((uintptr_t)out & 15) == 0;
+        const double opix = (double)s.batch * 2 * s.out_h * s.out_w;
+        return hk.run("tail up: out_conv+upsample", 8.0 * opix + 2.0 * s.batch * g * 12,
+                      4.0 * (opix + (double)s.batch * 8 * g), [&](hipStream_t st) { return tail_up_launch(ua, st); });
+    }
     L.ksize = 1; L.njobs = 1;
     L.job[0] = make_job(c, c->outc, c->flowcat.p, 6, 0, c->coarse.p, 2, 0, 1, 0);
     if ((rc = run_tail(hk, "out_conv 1x1 6->2", L)) != EEM_OK) return rc;

@@ -219,6 +219,39 @@ int upsample_launch(const float* in, float* out, int nc, int h, int w, int oh, i
 // writes {e1, e2, out} into the device table (one tiny launch in front of a cached graph whose buffers changed)
 int io_table_launch(const void** table, const void* e1, const void* e2, void* out, hipStream_t stream);
 
+// ---- fused launches of the tail (tail_fused.hip)
+// A pooled [n][c][gh][gw] map read through the conv epilogues' partial sums: value = scale * sum_{i < rows} base[n*nstride +
+// c*cstride + y*ystride + i*rstride + x]  (a finished map: rows 1, scale 1)
+struct PooledSrc {
+    const float* base;
+    int nstride, cstride, ystride, rstride, rows;
+    float scale;
+};
+struct TailHeadArgs {
+    PooledSrc src[3];            // the three stages (images 0..B-1 = events1, B..2B-1 = events2)
+    int c[3];                    // 16, 32, 64
+    float* cat[3];               // [B][cat_ctotal][g]: correlation -> channels [0, ntaps), rconv -> [ntaps, ntaps + 16)
+    float* pool_out[3];          // finished pooled maps [2B][c][g] (side output) or NULL
+    const float* rw[3];          // rconv_k weights packed by tail_pack_weights
+    const float* rb[3];          // rconv_k bias
+    const int* taps;
+    int batch, gh, gw, ntaps, cat_ctotal;
+    int nblk_rconv, nblk_corr;   // filled by the launcher
+};
+int tail_head_launch(const TailHeadArgs& a, hipStream_t stream);
+struct TailUpArgs {
+    const float* flowcat;        // the three decoders' flows [B][6][g]
+    const float* wo;             // out_conv weight [2][6], bias [2] (state_dict layout)
+    const float* bo;
+    float* coarse;               // side output [B][2][g] (may be NULL)
+    float* out;                  // [B][2][oh][ow]
+    const void* const* io;       // graph io table (out = io[2]) or NULL
+    int batch, gh, gw, oh, ow, out_aligned16;
+    int ty, tx;                  // filled by the launcher
+};
+bool tail_up_supported(int gh, int gw, int oh, int ow);
+int tail_up_launch(const TailUpArgs& a, hipStream_t stream);
+
 // arena[i] = idx[i] ? flat[idx[i] - 1] : 0  (weight re-packing after an optimizer step, see api.hip)
 int repack_launch(const float* flat, const int* idx, float* arena, long n, hipStream_t stream);
 

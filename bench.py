@@ -40,6 +40,9 @@ def parse():
     p.add_argument("--kernel-reps", type=int, default=20)
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-other-rows", action="store_true", help="skip the E-RAFT / training-step side timings")
+    p.add_argument("--mode", choices=("infer", "train"), default="infer",
+                   help="infer (default): the headline metric; train: BASELINE configs[3] - EEMFlow training step, 1280x720, batch 8 per GPU, "
+                        "data parallel with one RCCL all-reduce of the flat gradient per step (its time is reported as allreduce_us)")
     p.add_argument("--streams", type=int, default=3,
                    help="frames in flight per GPU: independent contexts on separate HIP streams, steps alternate")
     return p.parse_args()
@@ -306,8 +309,84 @@ def load_traffic():
     return None
 
 
+def main_train(args):
+    """BASELINE configs[3] (configs[2] with --height 260 --width 346 --batch 32): one optimisation step per `step` - forward with
+    activations kept, sequence loss, backward into the flat gradient (eemflow_forward_backward), ONE all-reduce of that 2.86 MB buffer
+    over RCCL + division by the world size (eemflow_amd.parallel.average_gradients), clip + AdamW + weight re-pack
+    (eemflow_optimizer_step).  value = samples of ALL ranks per second; allreduce_us = HIP-event time of the collective per step
+    on rank 0's stream (0 at N = 1)."""
+    from eemflow_amd import EEMFlow, _lib, parallel
+    from eemflow_amd.train import OneCycleLinear
+    from eemflow_amd.weights import seeded_state_dict, synthetic_gt, synthetic_voxel_pair
+    rank, local_rank, world = parallel.init_distributed()
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    B = args.batch if args.batch > 1 else 8
+    H, W = args.height, args.width
+    L = _lib.lib()
+    net = EEMFlow("", 5, 5)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(0).items()})      # same start on every rank
+    net = net.to(dev).train()
+    net.change_imagesize((H, W))
+    ctx = net._context(dev)
+    e1, e2 = (torch.from_numpy(a).to(dev) for a in synthetic_voxel_pair(1 + rank, B, H, W))    # each rank its own shard
+    gt, va = (torch.from_numpy(a).to(dev) for a in synthetic_gt(100 + rank, B, H, W))
+    n = sum(p.numel() for p in net.parameters())
+    grad = torch.empty(n, device=dev)
+    flow = torch.empty(B, 2, H, W, device=dev)
+    sched = OneCycleLinear(1e-4, args.steps + args.warmup + 100)
+    sp = _lib.current_stream_ptr(dev)
+    evs = []
+
+    def step(i, timed):
+        stats = (ctypes.c_double * 5)()
+        _lib.check(L.eemflow_forward_backward(ctx, e1.data_ptr(), e2.data_ptr(), gt.data_ptr(), va.data_ptr(), B, H, W, H, W, 1.0,
+                                              flow.data_ptr(), grad.data_ptr(), ctypes.byref(stats), sp))
+        if timed:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+        parallel.average_gradients(grad)
+        if timed:
+            b.record()
+            evs.append((a, b))
+        _lib.check(L.eemflow_optimizer_step(ctx, grad.data_ptr(), sched.lr(i), 5e-5, 1e-8, 1.0, sp))
+        return stats[0]
+
+    for i in range(args.warmup):
+        step(i, False)
+    torch.cuda.synchronize(dev)
+    parallel.barrier(dev)
+    t0 = time.perf_counter()
+    loss = 0.0
+    for i in range(args.steps):
+        loss = step(args.warmup + i, True)
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    parallel.barrier(dev)
+    value, slowest = parallel.aggregate_throughput(args.steps * B, elapsed, dev)
+    ar_us = float(np.mean([a.elapsed_time(b) for a, b in evs])) * 1e3 if evs else 0.0
+    if rank == 0:
+        flops = 3 * 14.583e9 * (H * W) / (720 * 1280)                   # ~3x the forward's direct-convolution count per sample
+        line = {"metric": f"samples/sec, EEMFlow training step {W}x{H}, batch {B}/GPU, data parallel (BASELINE configs[3] shape)",
+                "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(slowest * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"EEMFlow training step, {W}x{H}, batch={B} per GPU: forward + sequence loss + backward + "
+                                       "gradient all-reduce + clip + AdamW + re-pack", "height": H, "width": W, "batch_per_gpu": B,
+                           "parallelism": f"dp{world}: batch sharded over ranks, one RCCL all-reduce of {n * 4} gradient bytes per step"},
+                "allreduce_us": round(ar_us, 1), "allreduce_bytes": n * 4, "final_loss": loss,
+                "tflops_per_gpu_at_3x_forward": round(flops * B / (slowest / args.steps) / 1e12, 2)}
+        print(json.dumps(line), flush=True)
+    parallel.barrier(dev)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.mode == "train":
+        return main_train(args)
     from eemflow_amd import _lib, parallel
     from eemflow_amd.weights import seeded_state_dict, synthetic_voxel_pair
 

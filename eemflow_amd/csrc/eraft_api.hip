@@ -58,6 +58,8 @@ struct eraft_ctx {
     Buf st_corr0, st_net1, st_mask1, st_delta1, zeros;
     int B = 0, h8 = 0, w8 = 0, ph[4] = {0, 0, 0, 0}, pw[4] = {0, 0, 0, 0};
     bool have_last = false;
+    bool keep_stages = false;      // copy corr0 / net1 / mask1 / delta1 aside in the first iteration (parity tests)
+    bool stages_valid = false;
 };
 
 namespace {
@@ -358,7 +360,7 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
     ENS(c->corflo, B * 256 * g); ENS(c->flo1, B * 128 * g); ENS(c->motion, B * 128 * g); ENS(c->z, B * 128 * g);
     ENS(c->rh, B * 128 * g); ENS(c->fhid, B * 256 * g); ENS(c->delta, B * 2 * g); ENS(c->mhid, B * 256 * g);
     ENS(c->mask, B * 576 * g);
-    ENS(c->st_corr0, B * 324 * g); ENS(c->st_net1, B * 128 * g); ENS(c->st_mask1, B * 576 * g); ENS(c->st_delta1, B * 2 * g);
+    if (c->keep_stages) { ENS(c->st_corr0, B * 324 * g); ENS(c->st_net1, B * 128 * g); ENS(c->st_mask1, B * 576 * g); ENS(c->st_delta1, B * 2 * g); }
 #undef ENS
     // pad channels of the correlation buffer (never written by the lookup)
     EEM_HIP_CHECK(hipMemset2DAsync(c->corr.p + (size_t)324 * g, (size_t)kCorrPad * g * 4, 0, (size_t)(kCorrPad - 324) * g * 4, B, st));
@@ -450,7 +452,7 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
         if ((rc = er_axpy_launch(c->c1.p, c->delta.p, (long)B * 2 * g, st)) != EEM_OK) return rc;              // :149
         if ((rc = er_convex_up_launch(c->c0.p, c->c1.p, c->mask.p, out + (size_t)it * B * 2 * in_h * in_w, B, h8, w8, pad[2],
                                       pad[0], in_h, in_w, st)) != EEM_OK) return rc;                          // :155-157
-        if (it == 0) {
+        if (it == 0 && c->keep_stages) {
             EEM_HIP_CHECK(hipMemcpy2DAsync(c->st_corr0.p, 324 * g * 4, c->corr.p, kCorrPad * g * 4, 324 * g * 4, B,
                                            hipMemcpyDeviceToDevice, st));
             EEM_HIP_CHECK(hipMemcpyAsync(c->st_net1.p, net, B * 128 * g * 4, hipMemcpyDeviceToDevice, st));
@@ -460,6 +462,14 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
         (void)cur;
     }
     c->B = B; c->h8 = h8; c->w8 = w8; c->have_last = true;
+    c->stages_valid = c->keep_stages;
+    return EEM_OK;
+}
+
+// Keep the first iteration's corr0 / net1 / mask1 / delta1 for eraft_get_stage (four device copies per forward; off by default).
+extern "C" int eraft_keep_stages(eraft_ctx* c, int enable) {
+    EEM_REQUIRE(c, "eraft_keep_stages: NULL context");
+    c->keep_stages = enable != 0;
     return EEM_OK;
 }
 
@@ -469,6 +479,10 @@ extern "C" int eraft_get_stage(eraft_ctx* c, const char* name, float* dst, size_
     const std::string nm(name);
     const float* src = nullptr;
     dims[2] = c->h8; dims[3] = c->w8;
+    if ((nm == "corr0" || nm == "net1" || nm == "mask1" || nm == "delta1") && !c->stages_valid) {
+        eem_set_error("eraft_get_stage: '%s' is only kept after eraft_keep_stages(ctx, 1)", name);
+        return EEM_ERR_STATE;
+    }
     if (nm == "fmap") { src = c->fmap.p; dims[0] = 2 * c->B; dims[1] = 256; }
     else if (nm == "inp") { src = c->inp.p; dims[0] = c->B; dims[1] = 128; }
     else if (nm == "corr0") { src = c->st_corr0.p; dims[0] = c->B; dims[1] = 324; }

@@ -198,8 +198,10 @@ int eraft_load_weights(eraft_ctx* ctx, const float* flat_host, size_t nfloats, i
 int eraft_forward(eraft_ctx* ctx, const float* events1, const float* events2, int batch, int in_h, int in_w,
                   const int pad[4], int iters, const float* flow_init, float* flow_out, void* stream);
 
-/* Intermediates of the LAST forward: "fmap" ([2B,256,h,w]: fmap1 then fmap2), "inp", "corr0" (first lookup),
- * "net1", "mask1", "delta1" (after the first update), "flow_low", "pyr0".."pyr3". */
+/* Intermediates of the LAST forward: "fmap" ([2B,256,h,w]: fmap1 then fmap2), "inp", "flow_low", "pyr0".."pyr3", and - only
+ * after eraft_keep_stages(ctx, 1), which adds four device copies to every forward - "corr0" (first lookup), "net1", "mask1",
+ * "delta1" (after the first update). */
+int eraft_keep_stages(eraft_ctx* ctx, int enable);
 int eraft_get_stage(eraft_ctx* ctx, const char* name, float* dst, size_t dst_capacity_floats, int dims_out[4],
                     void* stream);
 

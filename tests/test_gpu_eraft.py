@@ -23,6 +23,7 @@ def make_net(seed):
     shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
     sd = seeded_from_shapes(shapes, seed)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.keep_stages = True                     # the golden comparisons read the first iteration's intermediates
     return net.to(DEV), O.to_torch_sd(sd)
 
 

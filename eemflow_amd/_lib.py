@@ -88,6 +88,27 @@ _SIGNATURES = {
                                     _c_float_p, ctypes.c_void_p]),
     "eemplus_upsample_flow_as": (ctypes.c_int, [_c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_int, _c_float_p, ctypes.c_void_p]),
+    "eemop_conv2d_fwd": (ctypes.c_int, [_c_float_p, ctypes.c_int, _c_float_p, ctypes.c_int, _c_float_p, ctypes.c_int, _c_float_p, _c_float_p]
+                         + [ctypes.c_int] * 10 + [ctypes.c_float, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "eemop_conv2d_bwd_data": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 13 + [_c_float_p, ctypes.c_void_p]),
+    "eemop_conv2d_bwd_weight": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 13 + [_c_float_p, _c_float_p, ctypes.c_void_p]),
+    "eemop_act_bwd": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_float, _c_float_p, ctypes.c_void_p]),
+    "eemop_binary": (ctypes.c_int, [ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_float, ctypes.c_longlong, _c_float_p, ctypes.c_void_p]),
+    "eemop_gru_blend": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, ctypes.c_longlong, _c_float_p, ctypes.c_void_p]),
+    "eemop_gru_blend_bwd": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_longlong, _c_float_p, _c_float_p,
+                                           _c_float_p, ctypes.c_void_p]),
+    "eemop_copy_channels": (ctypes.c_int, [_c_float_p, ctypes.c_int, ctypes.c_int, _c_float_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
+    "eemop_coords_init": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "eemop_replicate_pad": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 7 + [ctypes.c_void_p]),
+    "eemop_instnorm_fwd": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_float_p, ctypes.c_void_p]),
+    "eemop_instnorm_bwd": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_float_p,
+                                          ctypes.c_void_p]),
+    "eemop_batchnorm_train_fwd": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_float, ctypes.c_int]
+                                  + [_c_float_p] * 3 + [ctypes.c_void_p]),
+    "eemop_batchnorm_train_bwd": (ctypes.c_int, [_c_float_p] * 6 + [ctypes.c_int] * 4 + [_c_float_p] * 3 + [ctypes.c_void_p]),
+    "eemop_corr_pyramid_fwd": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 4 + [_c_float_p] * 4 + [ctypes.c_void_p]),
+    "eemop_corr_lookup_fwd": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 3 + [_c_float_p, ctypes.c_void_p]),
+    "eemop_convex_upsample_fwd": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 3 + [_c_float_p, ctypes.c_void_p]),
 }
 EXPORTS = tuple(_SIGNATURES)
 _lib = None

@@ -1,0 +1,483 @@
+// Operator-level C ABI (eemop_*): the differentiable building blocks of the E-RAFT training graph (model/eraft.py,
+// model/update.py, model/extractor.py, model/corr.py under autograd; SURVEY 8a rows A9 train-mode BatchNorm, A12 update-block
+// backward).  Each op has a forward and a backward entry point on caller-owned NCHW fp32 tensors; eemflow_amd/ops.py wraps
+// them as torch.autograd.Functions, so the recurrence (12 update iterations through one set of weights), the detach of the
+// coordinates and the accumulation of weight gradients are autograd bookkeeping while all arithmetic runs here.
+//
+// Convolutions run on the generic MFMA conv (gconv.hip): forward with the weights as they are, data gradient with the
+// transposed + flipped filter (transposed stride for the stride-2 layers), weight gradient on the generalised MFMA
+// weight-gradient kernel of train.hip.  The packed weight layouts are pure gathers of the caller's OIHW tensor: the gather
+// table of a layer shape is built once (host, cached) and applied on the device in front of every launch.
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/eemflow_hip.h"
+#include "eraft_kernels.h"
+#include "gconv.h"
+#include "train.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ elementwise kernels
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                      float* __restrict__ out, long n, int kind, float scale) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = y[i];
+    float d;
+    if (kind == GACT_RELU) d = v > 0.f ? 1.f : 0.f;
+    else if (kind == GACT_SIGMOID) d = v * (1.f - v);
+    else if (kind == GACT_TANH) d = 1.f - v * v;
+    else d = 1.f;
+    out[i] = dy[i] * d * scale;
+}
+
+// kind 0: a + b, 1: a - b, 2: a * b, 3: relu(a + b), 4: alpha * a
+__global__ __launch_bounds__(256) void binary_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                     float* __restrict__ out, long n, int kind, float alpha) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = a[i];
+    float r;
+    if (kind == 4) r = alpha * x;
+    else {
+        const float y = b[i];
+        r = kind == 0 ? x + y : kind == 1 ? x - y : kind == 2 ? x * y : fmaxf(x + y, 0.f);
+    }
+    out[i] = r;
+}
+
+// h' = (1 - z) h + z q and its adjoint (model/update.py:48,57)
+__global__ __launch_bounds__(256) void gru_blend_kernel(const float* __restrict__ z, const float* __restrict__ h,
+                                                        const float* __restrict__ q, float* __restrict__ out, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (1.f - z[i]) * h[i] + z[i] * q[i];
+}
+__global__ __launch_bounds__(256) void gru_blend_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ z,
+                                                            const float* __restrict__ h, const float* __restrict__ q,
+                                                            float* __restrict__ dz, float* __restrict__ dh, float* __restrict__ dq, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float g = dout[i], zz = z[i];
+    dz[i] = g * (q[i] - h[i]);
+    dh[i] = g * (1.f - zz);
+    dq[i] = g * zz;
+}
+
+// dst[n][dst_coff + c][hw] = src[n][src_coff + c][hw], c < cc
+__global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restrict__ src, int src_ctotal, int src_coff,
+                                                            float* __restrict__ dst, int dst_ctotal, int dst_coff, int cc, int hw, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int p = i % hw;
+    const int c = (i / hw) % cc;
+    const long n = i / ((long)hw * cc);
+    dst[((size_t)n * dst_ctotal + dst_coff + c) * hw + p] = src[((size_t)n * src_ctotal + src_coff + c) * hw + p];
+}
+
+// ------------------------------------------------------------------------------------------------ norms
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* sh) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { a += __shfl_xor(a, d); b += __shfl_xor(b, d); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) { sh[wave * 2] = a; sh[wave * 2 + 1] = b; }
+    __syncthreads();
+    a = b = 0.0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { a += sh[k * 2]; b += sh[k * 2 + 1]; }
+}
+
+// InstanceNorm2d(affine=False, eps) [+ ReLU] backward, one block per (n, c) plane; x is the layer input (the statistics are
+// recomputed), y the layer output (ReLU gate):  dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * [y > 0]
+__global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ dy, float* __restrict__ dx, int hw, int relu, float eps) {
+    __shared__ double sh[8];
+    const size_t base = (size_t)blockIdx.x * hw;
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < hw; i += 256) { const double v = x[base + i]; s += v; q += v * v; }
+    block_sum2(s, q, sh);
+    const double mean = s / hw;
+    double var = q / hw - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps)), meanf = (float)mean;
+    double sg = 0.0, sgx = 0.0;
+    for (int i = threadIdx.x; i < hw; i += 256) {
+        float g = dy[base + i];
+        if (relu && !(y[base + i] > 0.f)) g = 0.f;
+        const float xh = (x[base + i] - meanf) * rstd;
+        sg += g; sgx += (double)g * xh;
+    }
+    block_sum2(sg, sgx, sh);
+    const float mg = (float)(sg / hw), mgx = (float)(sgx / hw);
+    for (int i = threadIdx.x; i < hw; i += 256) {
+        float g = dy[base + i];
+        if (relu && !(y[base + i] > 0.f)) g = 0.f;
+        const float xh = (x[base + i] - meanf) * rstd;
+        dx[base + i] = rstd * (g - mg - xh * mgx);
+    }
+}
+
+// BatchNorm2d in training mode (model/extractor.py:31-35 with the module in train()): one block per channel.
+// forward: batch mean / biased variance over (N, H, W); y = (x - mean) * rstd * w + b [ReLU]; running statistics updated in place
+// with momentum (unbiased variance), save_mean / save_rstd kept for the backward.
+__global__ __launch_bounds__(256) void bn_train_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ b, float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var, float* __restrict__ y,
+                                                           float* __restrict__ save_mean, float* __restrict__ save_rstd, int n, int c, int hw,
+                                                           float momentum, float eps, int relu) {
+    __shared__ double sh[8];
+    const int ch = blockIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int img = 0; img < n; ++img) {
+        const float* p = x + ((size_t)img * c + ch) * hw;
+        for (int i = threadIdx.x; i < hw; i += 256) { const double v = p[i]; s += v; q += v * v; }
+    }
+    block_sum2(s, q, sh);
+    const double cnt = (double)n * hw;
+    const double mean = s / cnt;
+    double var = q / cnt - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps)), meanf = (float)mean;
+    const float ww = w[ch], bb = b[ch];
+    for (int img = 0; img < n; ++img) {
+        const size_t o = ((size_t)img * c + ch) * hw;
+        for (int i = threadIdx.x; i < hw; i += 256) {
+            float v = (x[o + i] - meanf) * rstd * ww + bb;
+            if (relu) v = fmaxf(v, 0.f);
+            y[o + i] = v;
+        }
+    }
+    if (threadIdx.x == 0) {
+        save_mean[ch] = meanf;
+        save_rstd[ch] = rstd;
+        const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+        running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * meanf;
+        running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unbiased;
+    }
+}
+// backward: g = dy * [y > 0]; dw = sum g * xhat, db = sum g, dx = w * rstd * (g - mean(g) - xhat * mean(g * xhat))
+__global__ __launch_bounds__(256) void bn_train_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ dy, const float* __restrict__ w,
+                                                           const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
+                                                           float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, int n, int c,
+                                                           int hw, int relu) {
+    __shared__ double sh[8];
+    const int ch = blockIdx.x;
+    const float meanf = save_mean[ch], rstd = save_rstd[ch];
+    double sg = 0.0, sgx = 0.0;
+    for (int img = 0; img < n; ++img) {
+        const size_t o = ((size_t)img * c + ch) * hw;
+        for (int i = threadIdx.x; i < hw; i += 256) {
+            float g = dy[o + i];
+            if (relu && !(y[o + i] > 0.f)) g = 0.f;
+            sg += g; sgx += (double)g * ((x[o + i] - meanf) * rstd);
+        }
+    }
+    block_sum2(sg, sgx, sh);
+    const double cnt = (double)n * hw;
+    const float mg = (float)(sg / cnt), mgx = (float)(sgx / cnt), k = w[ch] * rstd;
+    for (int img = 0; img < n; ++img) {
+        const size_t o = ((size_t)img * c + ch) * hw;
+        for (int i = threadIdx.x; i < hw; i += 256) {
+            float g = dy[o + i];
+            if (relu && !(y[o + i] > 0.f)) g = 0.f;
+            dx[o + i] = k * (g - mg - (x[o + i] - meanf) * rstd * mgx);
+        }
+    }
+    if (threadIdx.x == 0) { dw[ch] = (float)sgx; db[ch] = (float)sg; }
+}
+
+inline unsigned nblk(long n) { return (unsigned)((n + 255) / 256); }
+
+// ------------------------------------------------------------------------------------------------ packed-weight plans
+struct Plan {
+    int* idx = nullptr;        // device: packed[i] = idx[i] ? w[idx[i] - 1] : 0
+    size_t n = 0;
+};
+std::map<std::string, Plan> g_plans;              // per process; the tables depend on layer shapes only
+std::mutex g_plans_mutex;                         // autograd runs backward ops on its own thread
+struct Scratch { float* p = nullptr; size_t cap = 0; int dev = -1; };
+thread_local Scratch g_scratch[2];                // [0] packed weights, [1] zero bias / zero page
+
+int scratch_get(Scratch& s, size_t floats, float** out) {
+    int dev = 0;
+    EEM_HIP_CHECK(hipGetDevice(&dev));
+    if (s.p == nullptr || s.dev != dev || s.cap < floats) {
+        if (s.p && s.dev == dev) EEM_HIP_CHECK(hipFree(s.p));          // synchronises with the launches that read it
+        s.p = nullptr;
+        s.cap = floats + floats / 2 + 1024;
+        EEM_HIP_CHECK(hipMalloc(&s.p, s.cap * sizeof(float)));
+        EEM_HIP_CHECK(hipMemset(s.p, 0, s.cap * sizeof(float)));
+        s.dev = dev;
+    }
+    *out = s.p;
+    return EEM_OK;
+}
+
+// forward plan: gconv_pack of w [cout][cin][kh][kw] read as `nseg` input segments
+int plan_fwd(int cout, const int* cs, int nseg, int kh, int kw, Plan** out) {
+    int dev = 0;
+    EEM_HIP_CHECK(hipGetDevice(&dev));
+    char key[160];
+    snprintf(key, sizeof(key), "f:%d:%d:%d,%d,%d:%d:%dx%d", dev, cout, cs[0], nseg > 1 ? cs[1] : 0, nseg > 2 ? cs[2] : 0, nseg, kh, kw);
+    std::lock_guard<std::mutex> lock(g_plans_mutex);
+    auto it = g_plans.find(key);
+    if (it == g_plans.end()) {
+        int cin = 0;
+        for (int s = 0; s < nseg; ++s) cin += cs[s];
+        const size_t nw = (size_t)cout * cin * kh * kw;
+        EEM_REQUIRE(nw < (size_t)16000000, "conv weights with %zu elements exceed the exact-index range of the pack table", nw);
+        std::vector<float> iw(nw);
+        for (size_t i = 0; i < nw; ++i) iw[i] = (float)(i + 1);
+        std::vector<float> pk(gconv_packed_floats(cout, cs, nseg, kh, kw), 0.f);
+        gconv_pack(iw.data(), cout, cs, nseg, kh, kw, pk.data());
+        std::vector<int> idx(pk.size());
+        for (size_t i = 0; i < pk.size(); ++i) idx[i] = (int)pk[i];
+        Plan p;
+        p.n = idx.size();
+        EEM_HIP_CHECK(hipMalloc(&p.idx, p.n * sizeof(int)));
+        EEM_HIP_CHECK(hipMemcpy(p.idx, idx.data(), p.n * sizeof(int), hipMemcpyHostToDevice));
+        it = g_plans.emplace(key, p).first;
+    }
+    *out = &it->second;
+    return EEM_OK;
+}
+
+// data-gradient plan: T[ci][co][kh-1-ky][kw-1-kx] = w[co][ci0 + ci][ky][kx] for ci < cic, packed as a conv with `cic` outputs
+int plan_bwd(int cout, int cin, int ci0, int cic, int kh, int kw, Plan** out) {
+    int dev = 0;
+    EEM_HIP_CHECK(hipGetDevice(&dev));
+    char key[160];
+    snprintf(key, sizeof(key), "b:%d:%d:%d:%d:%d:%dx%d", dev, cout, cin, ci0, cic, kh, kw);
+    std::lock_guard<std::mutex> lock(g_plans_mutex);
+    auto it = g_plans.find(key);
+    if (it == g_plans.end()) {
+        const size_t nw = (size_t)cout * cin * kh * kw;
+        EEM_REQUIRE(nw < (size_t)16000000, "conv weights with %zu elements exceed the exact-index range of the pack table", nw);
+        std::vector<float> T((size_t)cic * cout * kh * kw);
+        for (int co = 0; co < cout; ++co)
+            for (int ci = 0; ci < cic; ++ci)
+                for (int ky = 0; ky < kh; ++ky)
+                    for (int kx = 0; kx < kw; ++kx)
+                        T[(((size_t)ci * cout + co) * kh + (kh - 1 - ky)) * kw + (kw - 1 - kx)] =
+                            (float)((((size_t)co * cin + ci0 + ci) * kh + ky) * kw + kx + 1);
+        const int cs[1] = {cout};
+        std::vector<float> pk(gconv_packed_floats(cic, cs, 1, kh, kw), 0.f);
+        gconv_pack(T.data(), cic, cs, 1, kh, kw, pk.data());
+        std::vector<int> idx(pk.size());
+        for (size_t i = 0; i < pk.size(); ++i) idx[i] = (int)pk[i];
+        Plan p;
+        p.n = idx.size();
+        EEM_HIP_CHECK(hipMalloc(&p.idx, p.n * sizeof(int)));
+        EEM_HIP_CHECK(hipMemcpy(p.idx, idx.data(), p.n * sizeof(int), hipMemcpyHostToDevice));
+        it = g_plans.emplace(key, p).first;
+    }
+    *out = &it->second;
+    return EEM_OK;
+}
+
+}  // namespace
+
+// ================================================================================================ convolution
+extern "C" int eemop_conv2d_fwd(const float* x0, int c0, const float* x1, int c1, const float* x2, int c2, const float* w,
+                                const float* bias, int n, int hin, int win, int cout, int kh, int kw, int stride, int ph, int pw, int act,
+                                float out_scale, float* out, int out_ctotal, int out_coff, void* stream) {
+    EEM_REQUIRE(x0 && w && out && c0 >= 1 && n >= 1 && cout >= 1, "eemop_conv2d_fwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int nseg = 1 + (x1 != nullptr) + (x2 != nullptr);
+    EEM_REQUIRE(!(x2 && !x1), "eemop_conv2d_fwd: segment 2 without segment 1");
+    const int cs[3] = {c0, c1, c2};
+    Plan* pl = nullptr;
+    int rc = plan_fwd(cout, cs, nseg, kh, kw, &pl);
+    if (rc != EEM_OK) return rc;
+    float* pk = nullptr;
+    if ((rc = scratch_get(g_scratch[0], pl->n, &pk)) != EEM_OK) return rc;
+    if ((rc = repack_launch(w, pl->idx, pk, (long)pl->n, st)) != EEM_OK) return rc;
+    GConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nseg = nseg;
+    const float* xs[3] = {x0, x1, x2};
+    for (int s = 0; s < nseg; ++s) { a.seg[s].ptr = xs[s]; a.seg[s].c = cs[s]; a.seg[s].ctotal = cs[s]; a.seg[s].coff = 0; }
+    a.wpk = pk; a.shift = bias;
+    a.out = out; a.out_ctotal = out_ctotal; a.out_coff = out_coff;
+    a.n = n; a.hin = hin; a.win = win;
+    a.hout = (hin + 2 * ph - kh) / stride + 1; a.wout = (win + 2 * pw - kw) / stride + 1;
+    a.cout = cout; a.kh = kh; a.kw = kw; a.stride = stride; a.pad_h = ph; a.pad_w = pw;
+    a.act = act; a.epi = GEPI_PLAIN; a.out_scale = out_scale;
+    return gconv_launch(a, st);
+}
+
+// dx [n][cic][hin][win] = conv^T(dy [n][cout][hout][wout], w[:, ci0:ci0+cic])
+extern "C" int eemop_conv2d_bwd_data(const float* dy, const float* w, int n, int hin, int win, int cin, int ci0, int cic, int cout,
+                                     int kh, int kw, int stride, int ph, int pw, float* dx, void* stream) {
+    EEM_REQUIRE(dy && w && dx && cic >= 1 && ci0 >= 0 && ci0 + cic <= cin, "eemop_conv2d_bwd_data: bad arguments");
+    EEM_REQUIRE(stride == 1 || stride == 2, "eemop_conv2d_bwd_data: stride %d", stride);
+    hipStream_t st = (hipStream_t)stream;
+    Plan* pl = nullptr;
+    int rc = plan_bwd(cout, cin, ci0, cic, kh, kw, &pl);
+    if (rc != EEM_OK) return rc;
+    float* pk = nullptr;
+    if ((rc = scratch_get(g_scratch[0], pl->n, &pk)) != EEM_OK) return rc;
+    if ((rc = repack_launch(w, pl->idx, pk, (long)pl->n, st)) != EEM_OK) return rc;
+    const int hout = (hin + 2 * ph - kh) / stride + 1, wout = (win + 2 * pw - kw) / stride + 1;
+    GConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nseg = 1;
+    a.seg[0].ptr = dy; a.seg[0].c = cout; a.seg[0].ctotal = cout; a.seg[0].coff = 0;
+    a.wpk = pk;
+    a.out = dx; a.out_ctotal = cic; a.out_coff = 0;
+    a.n = n; a.hin = hout; a.win = wout; a.hout = hin; a.wout = win; a.cout = cic;
+    a.kh = kh; a.kw = kw; a.stride = 1; a.pad_h = kh - 1 - ph; a.pad_w = kw - 1 - pw;
+    a.tstride = stride;
+    a.act = GACT_NONE; a.epi = GEPI_PLAIN; a.out_scale = 1.f;
+    return gconv_launch(a, st);
+}
+
+// dw [cout][cin][kh][kw] += dy (x) x for the input-channel slice [ci0, ci0 + cic) (x is that slice: [n][cic][hin][win]);
+// db [cout] += sum dy when not NULL.  The caller zeroes dw / db once per backward.
+extern "C" int eemop_conv2d_bwd_weight(const float* x, const float* dy, int n, int hin, int win, int cin, int ci0, int cic, int cout,
+                                       int kh, int kw, int stride, int ph, int pw, float* dw, float* db, void* stream) {
+    EEM_REQUIRE(x && dy && dw && cic >= 1 && ci0 >= 0 && ci0 + cic <= cin, "eemop_conv2d_bwd_weight: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int hout = (hin + 2 * ph - kh) / stride + 1, wout = (win + 2 * pw - kw) / stride + 1;
+    int rc;
+    for (int c0 = 0; c0 < cout; c0 += 128) {                     // the kernel holds at most 128 couts per block
+        WgradArgs a;
+        a.x = x; a.x_ctotal = cic; a.x_coff = 0; a.cin = cic;
+        a.g = dy; a.gate = nullptr; a.g_ctotal = cout; a.g_coff = c0; a.g_cmul = 1; a.cout = cout - c0 < 128 ? cout - c0 : 128;
+        a.dw = dw + (size_t)c0 * cin * kh * kw;
+        a.n = n; a.hin = hin; a.win = win; a.hout = hout; a.wout = wout; a.k = kh; a.stride = stride; a.pad = ph;
+        a.zero_page = nullptr; a.db = nullptr;
+        a.kh = kh; a.kw = kw; a.ph = ph; a.pw = pw; a.dw_cin = cin; a.dw_coff = ci0;
+        if ((rc = tr_wgrad_launch_batch(&a, 1, st)) != EEM_OK) return rc;
+    }
+    if (db) return tr_bias_grad_launch(dy, nullptr, cout, 0, 1, cout, n, hout * wout, db, st);
+    return EEM_OK;
+}
+
+// ================================================================================================ elementwise
+extern "C" int eemop_act_bwd(const float* dy, const float* y, long long n, int kind, float scale, float* out, void* stream) {
+    EEM_REQUIRE(dy && y && out && n >= 0, "eemop_act_bwd: bad arguments");
+    if (n == 0) return EEM_OK;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, dy, y, out, (long)n, kind, scale);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+extern "C" int eemop_binary(int kind, const float* a, const float* b, float alpha, long long n, float* out, void* stream) {
+    EEM_REQUIRE(a && out && (b || kind == 4) && kind >= 0 && kind <= 4, "eemop_binary: bad arguments");
+    if (n == 0) return EEM_OK;
+    hipLaunchKernelGGL(binary_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, (long)n, kind, alpha);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+extern "C" int eemop_gru_blend(const float* z, const float* h, const float* q, long long n, float* out, void* stream) {
+    EEM_REQUIRE(z && h && q && out, "eemop_gru_blend: NULL argument");
+    hipLaunchKernelGGL(gru_blend_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, z, h, q, out, (long)n);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+extern "C" int eemop_gru_blend_bwd(const float* dout, const float* z, const float* h, const float* q, long long n, float* dz, float* dh,
+                                   float* dq, void* stream) {
+    EEM_REQUIRE(dout && z && h && q && dz && dh && dq, "eemop_gru_blend_bwd: NULL argument");
+    hipLaunchKernelGGL(gru_blend_bwd_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, dout, z, h, q, dz, dh, dq, (long)n);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+extern "C" int eemop_copy_channels(const float* src, int src_ctotal, int src_coff, float* dst, int dst_ctotal, int dst_coff, int cc, int n,
+                                   int hw, void* stream) {
+    EEM_REQUIRE(src && dst && cc >= 1 && n >= 1 && hw >= 1, "eemop_copy_channels: bad arguments");
+    const long total = (long)n * cc * hw;
+    hipLaunchKernelGGL(copy_channels_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, src, src_ctotal, src_coff, dst,
+                       dst_ctotal, dst_coff, cc, hw, total);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+extern "C" int eemop_coords_init(float* coords0, float* coords1, const float* flow_init, int batch, int h, int w, void* stream) {
+    EEM_REQUIRE(coords0 && coords1, "eemop_coords_init: NULL argument");
+    return er_coords_init_launch(coords0, coords1, flow_init, batch, h, w, (hipStream_t)stream);
+}
+
+extern "C" int eemop_replicate_pad(const float* in, float* out, int nc, int h, int w, int left, int right, int top, int bottom, void* stream) {
+    EEM_REQUIRE(in && out, "eemop_replicate_pad: NULL argument");
+    return er_pad_launch(in, out, nc, h, w, left, right, top, bottom, (hipStream_t)stream);
+}
+
+// ================================================================================================ norms
+extern "C" int eemop_instnorm_fwd(const float* x, const float* res, int planes, int hw, int relu, float* out, void* stream) {
+    EEM_REQUIRE(x && out, "eemop_instnorm_fwd: NULL argument");
+    return er_instnorm_launch(x, out, res, planes, hw, relu, (hipStream_t)stream);
+}
+
+extern "C" int eemop_instnorm_bwd(const float* x, const float* y, const float* dy, int planes, int hw, int relu, float* dx, void* stream) {
+    EEM_REQUIRE(x && y && dy && dx, "eemop_instnorm_bwd: NULL argument");
+    hipLaunchKernelGGL(instnorm_bwd_kernel, dim3(planes), dim3(256), 0, (hipStream_t)stream, x, y, dy, dx, hw, relu, 1e-5f);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+extern "C" int eemop_batchnorm_train_fwd(const float* x, const float* weight, const float* bias, float* running_mean, float* running_var,
+                                         int n, int c, int hw, float momentum, float eps, int relu, float* y, float* save_mean,
+                                         float* save_rstd, void* stream) {
+    EEM_REQUIRE(x && weight && bias && running_mean && running_var && y && save_mean && save_rstd, "eemop_batchnorm_train_fwd: NULL argument");
+    hipLaunchKernelGGL(bn_train_fwd_kernel, dim3(c), dim3(256), 0, (hipStream_t)stream, x, weight, bias, running_mean, running_var, y,
+                       save_mean, save_rstd, n, c, hw, momentum, eps, relu);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+extern "C" int eemop_batchnorm_train_bwd(const float* x, const float* y, const float* dy, const float* weight, const float* save_mean,
+                                         const float* save_rstd, int n, int c, int hw, int relu, float* dx, float* dweight, float* dbias,
+                                         void* stream) {
+    EEM_REQUIRE(x && y && dy && weight && save_mean && save_rstd && dx && dweight && dbias, "eemop_batchnorm_train_bwd: NULL argument");
+    hipLaunchKernelGGL(bn_train_bwd_kernel, dim3(c), dim3(256), 0, (hipStream_t)stream, x, y, dy, weight, save_mean, save_rstd, dx, dweight,
+                       dbias, n, c, hw, relu);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+// ================================================================================================ correlation / upsampling
+// CorrBlock.__init__ on caller tensors (model/corr.py:13-27,53-60): pyr_l [batch*h*w][h >> l][w >> l]
+extern "C" int eemop_corr_pyramid_fwd(const float* fmap1, const float* fmap2, int batch, int c, int h, int w, float* pyr0, float* pyr1,
+                                      float* pyr2, float* pyr3, void* stream) {
+    EEM_REQUIRE(fmap1 && fmap2 && pyr0 && pyr1 && pyr2 && pyr3, "eemop_corr_pyramid_fwd: NULL argument");
+    EEM_REQUIRE((h >> 3) >= 1 && (w >> 3) >= 1, "eemop_corr_pyramid_fwd: a %dx%d map has no fourth pyramid level", h, w);
+    hipStream_t st = (hipStream_t)stream;
+    const long planes = (long)batch * h * w;
+    int rc = er_allpairs_launch(fmap1, fmap2, pyr0, batch, c, h * w, st);
+    if (rc != EEM_OK) return rc;
+    float* lv[4] = {pyr0, pyr1, pyr2, pyr3};
+    int ph = h, pw = w;
+    for (int l = 1; l < 4; ++l) {
+        if ((rc = er_pool2_launch(lv[l - 1], lv[l], planes, ph, pw, st)) != EEM_OK) return rc;
+        ph /= 2; pw /= 2;
+    }
+    return EEM_OK;
+}
+
+// CorrBlock.__call__ on caller tensors (model/corr.py:29-50): out [batch][324][h][w]
+extern "C" int eemop_corr_lookup_fwd(const float* pyr0, const float* pyr1, const float* pyr2, const float* pyr3, const float* coords,
+                                     int batch, int h, int w, float* out, void* stream) {
+    EEM_REQUIRE(pyr0 && pyr1 && pyr2 && pyr3 && coords && out, "eemop_corr_lookup_fwd: NULL argument");
+    LookupArgs la;
+    const float* lv[4] = {pyr0, pyr1, pyr2, pyr3};
+    int ph = h, pw = w;
+    for (int l = 0; l < 4; ++l) { la.pyr[l] = lv[l]; la.ph[l] = ph; la.pw[l] = pw; ph /= 2; pw /= 2; }
+    la.coords = coords; la.out = out; la.batch = batch; la.h = h; la.w = w; la.out_ctotal = 324;
+    return er_lookup_launch(la, (hipStream_t)stream);
+}
+
+// ERAFT.upsample_flow on caller tensors (model/eraft.py:83-94): out [batch][2][8h][8w]; `zeros` [batch][2][h][w] all zero
+extern "C" int eemop_convex_upsample_fwd(const float* zeros, const float* flow, const float* mask, int batch, int h, int w, float* out,
+                                         void* stream) {
+    EEM_REQUIRE(zeros && flow && mask && out, "eemop_convex_upsample_fwd: NULL argument");
+    return er_convex_up_launch(zeros, flow, mask, out, batch, h, w, 0, 0, 8 * h, 8 * w, (hipStream_t)stream);
+}

@@ -12,6 +12,9 @@ struct WgradArgs {
     int n, hin, win, hout, wout, k, stride, pad;
     const float* zero_page;   // >= 16 bytes of zeros (LDS-DMA source for padding), or NULL: generic kernel only
     float* db;                // wgrad_enc only: bias gradient [cout], accumulated with atomics, or NULL
+    // generic kernel only: rectangular filters (kh != 0 overrides k / pad: kh x kw taps, padding ph / pw) and a dW that is
+    // a channel slice of a wider weight tensor: dw[co][dw_coff + ci][tap] with dw_cin input channels per cout (0: cin)
+    int kh = 0, kw = 0, ph = 0, pw = 0, dw_cin = 0, dw_coff = 0;
 };
 
 int tr_loss_launch(const float* flow, const float* gt, const float* valid, float* dflow, int batch, int hw, float weight,

@@ -189,10 +189,10 @@ constexpr int WG_TH = 4, WG_TW = 32, WG_PX = WG_TH * WG_TW, WG_GP = WG_PX + 1, W
 
 struct WgradBatch { WgradArgs job[WGRAD_MAX_JOBS]; };
 
-template <int K, int S>
+template <int KH, int KW, int S>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradBatch batch) {
     const WgradArgs& a = batch.job[blockIdx.z];
-    constexpr int KK = K * K;
+    constexpr int KK = KH * KW;
     extern __shared__ __attribute__((aligned(16))) float lds[];     // MT*32*WG_GP + cin_here*XR*XC floats
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradBatch batch) {
     const int cin_here = min(WG_CI, a.cin - ci0);
     const int MT = (a.cout + 31) >> 5;
     const int NT = (cin_here * KK + 31) >> 5;
-    constexpr int XR = (WG_TH - 1) * S + K, XC = (WG_TW - 1) * S + K;   // compile-time: the staging index math is mul/shift
+    constexpr int XR = (WG_TH - 1) * S + KH, XC = (WG_TW - 1) * S + KW;   // compile-time: the staging index math is mul/shift
     float* Gs = lds;
     float* Xs = lds + MT * 32 * WG_GP;
 
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradBatch batch) {
         const int nidx = nt * 32 + j;
         const int ci_l = nidx / KK, tap = nidx - ci_l * KK;
         const bool nv = nidx < cin_here * KK;
-        boff[i] = nv ? ci_l * XR * XC + (tap / K) * XC + (tap % K) : 0;
+        boff[i] = nv ? ci_l * XR * XC + (tap / KW) * XC + (tap % KW) : 0;
         if (tok[i]) ntile = i + 1;
     }
     f32x16 acc[WG_MAXT];
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradBatch batch) {
             if (a.gate) v *= a.gate[o] > 0.f ? 1.f : 0.1f;
             Gs[co * WG_GP + p] = ok ? v : 0.f;
         }
-        const int gy0 = oy0 * S - a.pad, gx0 = ox0 * S - a.pad;
+        const int gy0 = oy0 * S - (a.kh ? a.ph : a.pad), gx0 = ox0 * S - (a.kh ? a.pw : a.pad);
 #pragma unroll 8
         for (int e = threadIdx.x; e < cin_here * XR * XC; e += 256) {
             const int ci_l = e / (XR * XC), rem = e - ci_l * (XR * XC);
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradBatch batch) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (co < a.cout) atomicAdd(&a.dw[((size_t)co * a.cin + ci0 + ci_l) * KK + tap], acc[i][r]);
+            if (co < a.cout) atomicAdd(&a.dw[((size_t)co * (a.dw_cin ? a.dw_cin : a.cin) + a.dw_coff + ci0 + ci_l) * KK + tap], acc[i][r]);
         }
     }
 }
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WgradBatch batch, int 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (co < a.cout) atomicAdd(&a.dw[((size_t)co * a.cin + ci0 + ci_l) * KK + tap], acc[i][r]);
+            if (co < a.cout) atomicAdd(&a.dw[((size_t)co * (a.dw_cin ? a.dw_cin : a.cin) + a.dw_coff + ci0 + ci_l) * KK + tap], acc[i][r]);
         }
     }
 }
@@ -496,19 +496,20 @@ int tr_wgrad_launch_batch(const WgradArgs* jobs, int njobs, hipStream_t st) {
     size_t lds_bytes = 0;
     for (int i = 0; i < njobs; ++i) {
         const WgradArgs& a = jobs[i];
-        EEM_REQUIRE((a.k == 3 || a.k == 1) && a.cout >= 1 && a.cout <= 128 && a.cin >= 1, "tr_wgrad_launch: unsupported conv");
+        const int akh = a.kh ? a.kh : a.k, akw = a.kh ? a.kw : a.k;
+        EEM_REQUIRE(akh >= 1 && akw >= 1 && a.cout >= 1 && a.cout <= 128 && a.cin >= 1, "tr_wgrad_launch: unsupported conv");
         EEM_REQUIRE(a.stride == 1 || a.stride == 2, "tr_wgrad_launch: stride %d", a.stride);
-        EEM_REQUIRE(a.k == jobs[0].k && a.stride == jobs[0].stride, "tr_wgrad_launch_batch: jobs differ in kernel size / stride");
-        EEM_REQUIRE(!(a.k == 1 && a.stride != 1), "tr_wgrad_launch: strided 1x1 convs are not built");
+        EEM_REQUIRE(a.k == jobs[0].k && a.kh == jobs[0].kh && a.kw == jobs[0].kw && a.stride == jobs[0].stride,
+                    "tr_wgrad_launch_batch: jobs differ in kernel size / stride");
         const int nc = (a.cin + WG_CI - 1) / WG_CI;
         const int mt = (a.cout + 31) / 32;
-        const int nt = ((a.cin < WG_CI ? a.cin : WG_CI) * a.k * a.k + 31) / 32;
+        const int nt = ((a.cin < WG_CI ? a.cin : WG_CI) * akh * akw + 31) / 32;
         EEM_REQUIRE((mt * nt + 3) / 4 <= WG_MAXT, "tr_wgrad_launch: %d x %d tiles exceed the per-wave budget", mt, nt);
         const int tiles = ((a.wout + WG_TW - 1) / WG_TW) * ((a.hout + WG_TH - 1) / WG_TH) * a.n;
         int w = 1024 / (nc * njobs);
         w = w < 1 ? 1 : w;
         w = tiles < w ? tiles : w;
-        const int xr = (WG_TH - 1) * a.stride + a.k, xc = (WG_TW - 1) * a.stride + a.k;
+        const int xr = (WG_TH - 1) * a.stride + akh, xc = (WG_TW - 1) * a.stride + akw;
         const size_t lb = ((size_t)mt * 32 * WG_GP + (size_t)(a.cin < WG_CI ? a.cin : WG_CI) * xr * xc) * sizeof(float);
         nchunk = nc > nchunk ? nc : nchunk;
         workers = w > workers ? w : workers;
@@ -520,7 +521,7 @@ int tr_wgrad_launch_batch(const WgradArgs* jobs, int njobs, hipStream_t st) {
         const WgradArgs& a0 = jobs[0];
         const int hw0 = a0.hout * a0.wout;
         const char* es = getenv("EEM_NO_WGRAD_SMALL");
-        bool small = !(es && es[0] == '1') && a0.stride == 1 && hw0 * 2 <= WG_PX && a0.hin == a0.hout && a0.win == a0.wout;
+        bool small = !(es && es[0] == '1') && a0.kh == 0 && a0.dw_cin == 0 && a0.stride == 1 && hw0 * 2 <= WG_PX && a0.hin == a0.hout && a0.win == a0.wout;
         for (int i = 1; i < njobs; ++i)
             small = small && jobs[i].hout == a0.hout && jobs[i].wout == a0.wout && jobs[i].n == a0.n && jobs[i].hin == a0.hin &&
                     jobs[i].win == a0.win;
@@ -550,19 +551,24 @@ int tr_wgrad_launch_batch(const WgradArgs* jobs, int njobs, hipStream_t st) {
         }
     }
     dim3 grid(workers, nchunk, njobs);
-    static bool attr_set = false;
-    if (!attr_set) {
-        EEM_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        EEM_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        EEM_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
     const WgradArgs& a = jobs[0];
-    if (a.k == 3 && a.stride == 1) hipLaunchKernelGGL((wgrad_kernel<3, 1>), grid, dim3(256), lds_bytes, st, b);
-    else if (a.k == 3) hipLaunchKernelGGL((wgrad_kernel<3, 2>), grid, dim3(256), lds_bytes, st, b);
-    else hipLaunchKernelGGL((wgrad_kernel<1, 1>), grid, dim3(256), lds_bytes, st, b);
-    EEM_HIP_CHECK(hipGetLastError());
-    return EEM_OK;
+    const int kh = a.kh ? a.kh : a.k, kw = a.kh ? a.kw : a.k;
+#define WG_CASE(KH_, KW_, S_)                                                                                                   \
+    if (kh == KH_ && kw == KW_ && a.stride == S_) {                                                                             \
+        static bool attr = false;                                                                                               \
+        if (!attr) {                                                                                                            \
+            EEM_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_kernel<KH_, KW_, S_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                              160 * 1024));                                                                     \
+            attr = true;                                                                                                        \
+        }                                                                                                                       \
+        hipLaunchKernelGGL((wgrad_kernel<KH_, KW_, S_>), grid, dim3(256), lds_bytes, st, b);                                    \
+        EEM_HIP_CHECK(hipGetLastError());                                                                                       \
+        return EEM_OK;                                                                                                          \
+    }
+    WG_CASE(3, 3, 1) WG_CASE(3, 3, 2) WG_CASE(1, 1, 1) WG_CASE(1, 1, 2) WG_CASE(1, 5, 1) WG_CASE(5, 1, 1) WG_CASE(7, 7, 1) WG_CASE(7, 7, 2)
+#undef WG_CASE
+    eem_set_error("tr_wgrad_launch: kernel %dx%d stride %d is not built", kh, kw, a.stride);
+    return EEM_ERR_ARG;
 }
 
 int tr_wgrad_launch(const WgradArgs& a, hipStream_t st) {

@@ -3,7 +3,12 @@
 Mirrors model/eraft.py (ERAFT), model/extractor.py (BasicEncoder, ResidualBlock), model/update.py
 (BasicUpdateBlock and parts) and model/corr.py (CorrBlock): same constructors, forward signatures and
 state_dict keys (179 tensors).  The modules only hold parameters; all arithmetic happens in
-libeemflow_hip.so (include/eemflow_hip.h, eraft_* entry points).  Inference only; CUDA tensors only.
+libeemflow_hip.so (include/eemflow_hip.h).  CUDA tensors only.  Two routes, as nn.Module semantics dictate:
+* no gradient needed: `eraft_forward`, the fused inference schedule (eval-mode BatchNorm folded into the convs);
+* gradient needed (train_mvsec.py:245-258 on this model): the forward is assembled from the operator-level
+  autograd Functions of eemflow_amd/ops.py (eemop_* entry points): train-mode BatchNorm with batch statistics and
+  running-statistics update in cnet, InstanceNorm in fnet, the 12 unrolled update iterations (SepConvGRU, motion encoder,
+  flow / mask heads) through shared weights, the pyramid lookup at detached coordinates, convex upsampling.
 """
 import ctypes
 from argparse import Namespace
@@ -175,11 +180,6 @@ class ERAFT(nn.Module):
     def forward(self, events1, events2, iters=12, flow_init=None, upsample=True, normal=False):
         if not (events1.is_cuda and events2.is_cuda):
             raise _lib.EEMFlowHipError("ERAFT.forward: inputs must be CUDA (ROCm) tensors - there is no CPU path")
-        if self.training and torch.is_grad_enabled():
-            raise _lib.EEMFlowHipError("ERAFT.forward: inference only in this round (eval()/no_grad required; "
-                                       "train-mode BatchNorm batch statistics are not built)")
-        if self.training:
-            raise _lib.EEMFlowHipError("ERAFT.forward: call .eval() - cnet's BatchNorm uses running statistics here")
         if not hasattr(self, "image_padder"):
             raise AttributeError("call change_imagesize(img_size) before forward (as the reference requires)")
         e1, e2 = events1.contiguous().float(), events2.contiguous().float()
@@ -191,6 +191,10 @@ class ERAFT(nn.Module):
         if hp % 8 or wp % 8:
             raise ValueError(f"padded size {hp}x{wp} is not a multiple of 8: the reference's convex upsampling "
                              "(eraft.py:83-94) cannot be unpadded consistently")
+        bn_train = any(m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d))
+        if (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())) or bn_train:
+            # autograd route; also taken without gradients while BatchNorm is in train(): batch statistics, running-stat update
+            return (events1, events2), self._forward_ops(e1, e2, iters, flow_init)
         ctx = self._context(e1.device)
         out = torch.empty(iters, b, 2, h, w, device=e1.device, dtype=torch.float32)
         fi = None
@@ -202,6 +206,77 @@ class ERAFT(nn.Module):
                                                 fi.data_ptr() if fi is not None else None, out.data_ptr(),
                                                 _lib.current_stream_ptr(e1.device)))
         return (events1, events2), [out[i] for i in range(iters)]
+
+    # ------------------------------------------------------------------ differentiable route (eemflow_amd/ops.py)
+    def _norm(self, norm, x, relu):
+        from . import ops
+        if isinstance(norm, nn.InstanceNorm2d):
+            return ops.InstanceNormReLU.apply(x, relu)
+        if not norm.training:
+            raise _lib.EEMFlowHipError("ERAFT under autograd: eval-mode (frozen) BatchNorm is only built on the inference route; "
+                                       "the reference trains with BatchNorm in train() (train_mvsec.py:231-235)")
+        y = ops.BatchNormTrainReLU.apply(x, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.momentum, norm.eps, relu)
+        norm.num_batches_tracked += 1
+        return y
+
+    def _encoder_ops(self, enc, x):
+        """BasicEncoder up to (not including) its 1x1 output conv (model/extractor.py:170-185)."""
+        from . import ops
+        y = self._norm(enc.norm1, ops.conv2d(enc.conv1, x), True)
+        for layer in (enc.layer1, enc.layer2, enc.layer3):
+            for blk in layer:                                              # ResidualBlock.forward, model/extractor.py:43-57
+                t = self._norm(blk.norm1, ops.conv2d(blk.conv1, y), True)
+                t = self._norm(blk.norm2, ops.conv2d(blk.conv2, t), True)
+                if blk.downsample is not None:
+                    y = self._norm(blk.norm3, ops.conv2d(blk.downsample[0], y), False)
+                y = ops.AddReLU.apply(y, t)
+        return y
+
+    def _update_ops(self, net, inp, corr, flow):
+        """BasicUpdateBlock.forward (model/update.py:97-106)."""
+        from . import ops
+        ub = self.update_block
+        e = ub.encoder
+        cor = ops.conv2d(e.convc2, ops.conv2d(e.convc1, corr, act=ops.ACT_RELU), act=ops.ACT_RELU)
+        flo = ops.conv2d(e.convf2, ops.conv2d(e.convf1, flow, act=ops.ACT_RELU), act=ops.ACT_RELU)
+        motion = ops.Cat2.apply(ops.conv2d(e.conv, cor, flo, act=ops.ACT_RELU), flow)
+        g = ub.gru
+        for cz, cr, cq in ((g.convz1, g.convr1, g.convq1), (g.convz2, g.convr2, g.convq2)):
+            z = ops.conv2d(cz, net, inp, motion, act=ops.ACT_SIGMOID)
+            r = ops.conv2d(cr, net, inp, motion, act=ops.ACT_SIGMOID)
+            q = ops.conv2d(cq, ops.Mul.apply(r, net), inp, motion, act=ops.ACT_TANH)
+            net = ops.GRUBlend.apply(z, net, q)
+        delta = ops.conv2d(ub.flow_head.conv2, ops.conv2d(ub.flow_head.conv1, net, act=ops.ACT_RELU))
+        mask = ops.conv2d(ub.mask[2], ops.conv2d(ub.mask[0], net, act=ops.ACT_RELU), out_scale=0.25)
+        return net, mask, delta
+
+    def _forward_ops(self, e1, e2, iters, flow_init):
+        """ERAFT.forward (model/eraft.py:97-159) as an autograd graph of HIP operators."""
+        from . import ops
+        if not (e1.is_cuda and all(p.is_cuda for p in self.parameters())):
+            raise _lib.EEMFlowHipError("ERAFT.forward: CUDA (ROCm) tensors required - there is no CPU path")
+        b, c, h, w = e1.shape
+        pad = self.image_padder._pad
+        hp, wp = h + pad[2] + pad[3], w + pad[0] + pad[1]
+        x = torch.empty(2 * b, c, hp, wp, device=e1.device, dtype=torch.float32)
+        ops.replicate_pad_into(e1, pad, x[:b])
+        ops.replicate_pad_into(e2, pad, x[b:])
+        fmap = ops.conv2d(self.fnet.conv2, self._encoder_ops(self.fnet, x))               # [image1; image2] as one batch (:116)
+        pyr = ops.CorrPyramid.apply(fmap[:b], fmap[b:])
+        ctx_feat = self._encoder_ops(self.cnet, x[:b])
+        w2, b2 = self.cnet.conv2.weight, self.cnet.conv2.bias
+        hd = self.hidden_dim
+        net = ops.conv2d(self.cnet.conv2, ctx_feat, act=ops.ACT_TANH, weight=w2[:hd], bias=b2[:hd])      # :128-131
+        inp = ops.conv2d(self.cnet.conv2, ctx_feat, act=ops.ACT_RELU, weight=w2[hd:], bias=b2[hd:])
+        coords0, coords1 = ops.coords_grids(b, hp // 8, wp // 8, e1.device, flow_init)
+        preds = []
+        for _ in range(iters):
+            coords1 = coords1.detach()                                                     # :141
+            corr = ops.CorrLookup.apply(coords1, *pyr)
+            net, mask, delta = self._update_ops(net, inp, corr, ops.sub(coords1, coords0))
+            coords1 = ops.Add.apply(coords1, delta, 1)
+            preds.append(ops.ConvexUpsample.apply(ops.Add.apply(coords1, coords0, -1), mask, tuple(pad)))
+        return preds
 
     def stage(self, name):
         L = _lib.lib()

@@ -1,0 +1,390 @@
+"""torch.autograd.Functions over the operator-level C ABI (eemop_* / eraft_*_bwd in include/eemflow_hip.h).
+
+These are what `ERAFT.forward` is made of when the caller needs gradients (train_mvsec.py:245-258 on model/eraft.py): autograd keeps
+the graph - the 12 unrolled update iterations that share one set of weights, the detached coordinates, the accumulation of weight
+gradients - and every node's arithmetic, forward and backward, runs in libeemflow_hip.so.  torch supplies tensors (allocation, views,
+slicing of gradients), nothing else: no ATen compute op is on the path.  CUDA (ROCm) tensors only; there is no CPU path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
+
+
+def _sp(t):
+    return _lib.current_stream_ptr(t.device)
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.EEMFlowHipError("eemflow_amd.ops: CUDA (ROCm) tensors required - there is no CPU path")
+
+
+def _act_bwd(dy, y, kind, scale=1.0):
+    out = torch.empty_like(y)
+    with torch.cuda.device(y.device):
+        _lib.check(_lib.lib().eemop_act_bwd(_c(dy).data_ptr(), y.data_ptr(), y.numel(), kind, float(scale), out.data_ptr(), _sp(y)))
+    return out
+
+
+def _binary(kind, a, b=None, alpha=1.0):
+    out = torch.empty_like(a)
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.lib().eemop_binary(kind, a.data_ptr(), _ptr(b), float(alpha), a.numel(), out.data_ptr(), _sp(a)))
+    return out
+
+
+class Conv2d(torch.autograd.Function):
+    """out_scale * act(conv2d(cat(xs, 1), w) + b) - nn.Conv2d (+ the activation behind it) of model/extractor.py / model/update.py;
+    the inputs' torch.cat is never materialised."""
+
+    @staticmethod
+    def forward(ctx, w, b, stride, padding, act, out_scale, *xs):
+        _need_cuda(w, *xs)
+        xs = [_c(x) for x in xs]
+        w = _c(w)
+        n, _, hin, win = xs[0].shape
+        cout, cin, kh, kw = w.shape
+        cs = [x.shape[1] for x in xs]
+        assert sum(cs) == cin and 1 <= len(xs) <= 3
+        ph, pw = padding
+        hout, wout = (hin + 2 * ph - kh) // stride + 1, (win + 2 * pw - kw) // stride + 1
+        out = torch.empty(n, cout, hout, wout, device=w.device, dtype=torch.float32)
+        px = [x.data_ptr() for x in xs] + [None] * (3 - len(xs))
+        pc = cs + [0] * (3 - len(xs))
+        with torch.cuda.device(w.device):
+            _lib.check(_lib.lib().eemop_conv2d_fwd(px[0], pc[0], px[1], pc[1], px[2], pc[2], w.data_ptr(), _ptr(b), n, hin, win, cout, kh, kw,
+                                                   stride, ph, pw, act, float(out_scale), out.data_ptr(), cout, 0, _sp(w)))
+        ctx.save_for_backward(w, out if act != ACT_NONE else None, *xs)
+        ctx.cfg = (stride, ph, pw, act, float(out_scale), b is not None, cs)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        w, out, *xs = ctx.saved_tensors
+        stride, ph, pw, act, out_scale, has_b, cs = ctx.cfg
+        L = _lib.lib()
+        n, _, hin, win = xs[0].shape
+        cout, cin, kh, kw = w.shape
+        dout = _c(dout)
+        if act != ACT_NONE:
+            dpre = _act_bwd(dout, out if out_scale == 1.0 else _binary(4, out, alpha=1.0 / out_scale), act, out_scale)
+        elif out_scale != 1.0:
+            dpre = _binary(4, dout, alpha=out_scale)
+        else:
+            dpre = dout
+        need = ctx.needs_input_grad
+        dw = db = None
+        dxs = [None] * len(xs)
+        with torch.cuda.device(w.device):
+            s = _sp(w)
+            if need[0] or (has_b and need[1]):
+                dw = torch.zeros_like(w)
+                db = torch.zeros(cout, device=w.device) if has_b else None
+                c0 = 0
+                for i, x in enumerate(xs):
+                    _lib.check(L.eemop_conv2d_bwd_weight(x.data_ptr(), dpre.data_ptr(), n, hin, win, cin, c0, cs[i], cout, kh, kw, stride, ph, pw,
+                                                         dw.data_ptr(), _ptr(db) if i == 0 else None, s))
+                    c0 += cs[i]
+            c0 = 0
+            for i, x in enumerate(xs):
+                if need[6 + i]:
+                    dx = torch.empty_like(x)
+                    _lib.check(L.eemop_conv2d_bwd_data(dpre.data_ptr(), w.data_ptr(), n, hin, win, cin, c0, cs[i], cout, kh, kw, stride, ph, pw,
+                                                       dx.data_ptr(), s))
+                    dxs[i] = dx
+                c0 += cs[i]
+        return (dw if need[0] else None, db if (has_b and need[1]) else None, None, None, None, None, *dxs)
+
+
+def conv2d(conv, *xs, act=ACT_NONE, out_scale=1.0, weight=None, bias=None):
+    """Apply an nn.Conv2d parameter container (or explicit weight / bias slices of it) to channel-concatenated inputs."""
+    w = conv.weight if weight is None else weight
+    b = conv.bias if bias is None and weight is None else bias
+    st = conv.stride[0]
+    return Conv2d.apply(w, b, st, tuple(conv.padding), act, out_scale, *xs)
+
+
+class InstanceNormReLU(torch.autograd.Function):
+    """relu?(InstanceNorm2d(x)) - fnet's norm layers (model/extractor.py:31-35,43-57)."""
+
+    @staticmethod
+    def forward(ctx, x, relu):
+        _need_cuda(x)
+        x = _c(x)
+        n, c, h, w = x.shape
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().eemop_instnorm_fwd(x.data_ptr(), None, n * c, h * w, 1 if relu else 0, y.data_ptr(), _sp(x)))
+        ctx.save_for_backward(x, y)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().eemop_instnorm_bwd(x.data_ptr(), y.data_ptr(), _c(dy).data_ptr(), n * c, h * w, 1 if ctx.relu else 0,
+                                                     dx.data_ptr(), _sp(x)))
+        return dx, None
+
+
+class BatchNormTrainReLU(torch.autograd.Function):
+    """relu?(BatchNorm2d(x)) with batch statistics; the module's running statistics are updated in place (momentum 0.1, unbiased
+    variance) - cnet's norm layers with the module in train() (model/extractor.py:31-35; train_mvsec.py:231-235)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu):
+        _need_cuda(x, weight)
+        x = _c(x)
+        n, c, h, w = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(c, device=x.device)
+        rstd = torch.empty(c, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().eemop_batchnorm_train_fwd(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), running_mean.data_ptr(),
+                                                            running_var.data_ptr(), n, c, h * w, float(momentum), float(eps), 1 if relu else 0,
+                                                            y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _sp(x)))
+        ctx.save_for_backward(x, y, weight, mean, rstd)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight, mean, rstd = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dx, dw, db = torch.empty_like(x), torch.empty_like(weight), torch.empty_like(weight)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().eemop_batchnorm_train_bwd(x.data_ptr(), y.data_ptr(), _c(dy).data_ptr(), weight.data_ptr(), mean.data_ptr(),
+                                                            rstd.data_ptr(), n, c, h * w, 1 if ctx.relu else 0, dx.data_ptr(), dw.data_ptr(),
+                                                            db.data_ptr(), _sp(x)))
+        return dx, dw, db, None, None, None, None, None
+
+
+class AddReLU(torch.autograd.Function):
+    """relu(x + y): the tail of a residual block (model/extractor.py:57)."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        out = _binary(3, _c(x), _c(y))
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (out,) = ctx.saved_tensors
+        d = _act_bwd(dout, out, ACT_RELU)
+        return d, d
+
+
+class Mul(torch.autograd.Function):
+    """r * h (model/update.py:47,56)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        ctx.save_for_backward(a, b)
+        return _binary(2, a, b)
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, b = ctx.saved_tensors
+        dout = _c(dout)
+        return _binary(2, dout, b), _binary(2, dout, a)
+
+
+class Add(torch.autograd.Function):
+    """a + b (coords1 + delta_flow, model/eraft.py:149) / a - b with sign = -1 (coords1 - coords0, :144,155)."""
+
+    @staticmethod
+    def forward(ctx, a, b, sign):
+        ctx.sign = sign
+        return _binary(0 if sign > 0 else 1, _c(a), _c(b))
+
+    @staticmethod
+    def backward(ctx, dout):
+        return dout, (dout if ctx.sign > 0 else _binary(4, _c(dout), alpha=-1.0)), None
+
+
+class GRUBlend(torch.autograd.Function):
+    """(1 - z) h + z q  (model/update.py:48,57)."""
+
+    @staticmethod
+    def forward(ctx, z, h, q):
+        z, h, q = _c(z), _c(h), _c(q)
+        out = torch.empty_like(h)
+        with torch.cuda.device(h.device):
+            _lib.check(_lib.lib().eemop_gru_blend(z.data_ptr(), h.data_ptr(), q.data_ptr(), h.numel(), out.data_ptr(), _sp(h)))
+        ctx.save_for_backward(z, h, q)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        z, h, q = ctx.saved_tensors
+        dz, dh, dq = torch.empty_like(z), torch.empty_like(h), torch.empty_like(q)
+        with torch.cuda.device(h.device):
+            _lib.check(_lib.lib().eemop_gru_blend_bwd(_c(dout).data_ptr(), z.data_ptr(), h.data_ptr(), q.data_ptr(), h.numel(), dz.data_ptr(),
+                                                      dh.data_ptr(), dq.data_ptr(), _sp(h)))
+        return dz, dh, dq
+
+
+class Cat2(torch.autograd.Function):
+    """torch.cat([a, b], dim=1) (model/update.py:79,81)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        n, ca, h, w = a.shape
+        cb = b.shape[1]
+        out = torch.empty(n, ca + cb, h, w, device=a.device, dtype=torch.float32)
+        L = _lib.lib()
+        with torch.cuda.device(a.device):
+            _lib.check(L.eemop_copy_channels(a.data_ptr(), ca, 0, out.data_ptr(), ca + cb, 0, ca, n, h * w, _sp(a)))
+            _lib.check(L.eemop_copy_channels(b.data_ptr(), cb, 0, out.data_ptr(), ca + cb, ca, cb, n, h * w, _sp(a)))
+        ctx.split = (ca, cb)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ca, cb = ctx.split
+        dout = _c(dout)
+        n, _, h, w = dout.shape
+        da = torch.empty(n, ca, h, w, device=dout.device, dtype=torch.float32)
+        db = torch.empty(n, cb, h, w, device=dout.device, dtype=torch.float32)
+        L = _lib.lib()
+        with torch.cuda.device(dout.device):
+            _lib.check(L.eemop_copy_channels(dout.data_ptr(), ca + cb, 0, da.data_ptr(), ca, 0, ca, n, h * w, _sp(dout)))
+            _lib.check(L.eemop_copy_channels(dout.data_ptr(), ca + cb, ca, db.data_ptr(), cb, 0, cb, n, h * w, _sp(dout)))
+        return da, db
+
+
+class CorrPyramid(torch.autograd.Function):
+    """CorrBlock.__init__ (model/corr.py:13-27,53-60): four pyramid levels of the all-pairs correlation."""
+
+    @staticmethod
+    def forward(ctx, f1, f2):
+        f1, f2 = _c(f1), _c(f2)
+        b, c, h, w = f1.shape
+        lv = [torch.empty(b * h * w, 1, h >> l, w >> l, device=f1.device, dtype=torch.float32) for l in range(4)]
+        with torch.cuda.device(f1.device):
+            _lib.check(_lib.lib().eemop_corr_pyramid_fwd(f1.data_ptr(), f2.data_ptr(), b, c, h, w, *[t.data_ptr() for t in lv], _sp(f1)))
+        ctx.save_for_backward(f1, f2)
+        return tuple(lv)
+
+    @staticmethod
+    def backward(ctx, d0, d1, d2, d3):
+        f1, f2 = ctx.saved_tensors
+        b, c, h, w = f1.shape
+        shapes = [(b * h * w, 1, h >> l, w >> l) for l in range(4)]
+        ds = [(_c(d).clone() if d is not None else torch.zeros(s, device=f1.device)) for d, s in zip((d0, d1, d2, d3), shapes)]
+        df1, df2 = torch.empty_like(f1), torch.empty_like(f2)
+        with torch.cuda.device(f1.device):
+            _lib.check(_lib.lib().eraft_corr_pyramid_bwd(f1.data_ptr(), f2.data_ptr(), ds[0].data_ptr(), ds[1].data_ptr(), ds[2].data_ptr(),
+                                                         ds[3].data_ptr(), b, c, h, w, df1.data_ptr(), df2.data_ptr(), _sp(f1)))
+        return df1, df2
+
+
+class CorrLookup(torch.autograd.Function):
+    """CorrBlock.__call__ (model/corr.py:29-50); the coordinates carry no gradient (model/eraft.py:141 detaches them)."""
+
+    @staticmethod
+    def forward(ctx, coords, p0, p1, p2, p3):
+        coords = _c(coords)
+        b, _, h, w = coords.shape
+        out = torch.empty(b, 324, h, w, device=coords.device, dtype=torch.float32)
+        with torch.cuda.device(coords.device):
+            _lib.check(_lib.lib().eemop_corr_lookup_fwd(p0.data_ptr(), p1.data_ptr(), p2.data_ptr(), p3.data_ptr(), coords.data_ptr(), b, h, w,
+                                                        out.data_ptr(), _sp(coords)))
+        ctx.save_for_backward(coords)
+        ctx.shapes = [tuple(p.shape) for p in (p0, p1, p2, p3)]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (coords,) = ctx.saved_tensors
+        b, _, h, w = coords.shape
+        ds = [torch.empty(s, device=coords.device, dtype=torch.float32) for s in ctx.shapes]      # zeroed by the library
+        with torch.cuda.device(coords.device):
+            _lib.check(_lib.lib().eraft_corr_lookup_bwd(coords.data_ptr(), _c(dout).data_ptr(), b, h, w, *[d.data_ptr() for d in ds], _sp(coords)))
+        return (None, *ds)
+
+
+class ConvexUpsample(torch.autograd.Function):
+    """ERAFT.upsample_flow (model/eraft.py:83-94) followed by InputPadder.unpad (utils/image_utils.py:142-145)."""
+
+    @staticmethod
+    def forward(ctx, flow, mask, pad):
+        flow, mask = _c(flow), _c(mask)
+        b, _, h, w = flow.shape
+        zeros = torch.zeros_like(flow)
+        full = torch.empty(b, 2, 8 * h, 8 * w, device=flow.device, dtype=torch.float32)
+        with torch.cuda.device(flow.device):
+            _lib.check(_lib.lib().eemop_convex_upsample_fwd(zeros.data_ptr(), flow.data_ptr(), mask.data_ptr(), b, h, w, full.data_ptr(), _sp(flow)))
+        ctx.save_for_backward(flow, mask)
+        ctx.pad = pad
+        left, right, top, bottom = pad
+        return full[:, :, top:8 * h - bottom, left:8 * w - right]
+
+    @staticmethod
+    def backward(ctx, dout):
+        flow, mask = ctx.saved_tensors
+        b, _, h, w = flow.shape
+        left, right, top, bottom = ctx.pad
+        dfull = torch.zeros(b, 2, 8 * h, 8 * w, device=flow.device, dtype=torch.float32)
+        dfull[:, :, top:8 * h - bottom, left:8 * w - right] = dout          # placement of the cropped gradient: data movement only
+        dflow, dmask = torch.empty_like(flow), torch.empty_like(mask)
+        with torch.cuda.device(flow.device):
+            _lib.check(_lib.lib().eraft_convex_upsample_bwd(flow.data_ptr(), mask.data_ptr(), dfull.data_ptr(), b, h, w, dflow.data_ptr(),
+                                                            dmask.data_ptr(), _sp(flow)))
+        return dflow, dmask, None
+
+
+def coords_grids(batch, h, w, device, flow_init=None):
+    """ERAFT.initialize_flow (model/eraft.py:73-81): coords0, coords1 [batch][2][h][w] (channel 0 = x, 1 = y), coords1 += flow_init."""
+    c0 = torch.empty(batch, 2, h, w, device=device, dtype=torch.float32)
+    c1 = torch.empty_like(c0)
+    fi = _c(flow_init.float()) if flow_init is not None else None
+    with torch.cuda.device(device):
+        _lib.check(_lib.lib().eemop_coords_init(c0.data_ptr(), c1.data_ptr(), _ptr(fi), batch, h, w, _lib.current_stream_ptr(device)))
+    return c0, c1
+
+
+def sub(a, b):
+    """a - b without a graph (both operands are constants of the graph: coords1 is detached, model/eraft.py:141-144)."""
+    return _binary(1, _c(a), _c(b))
+
+
+def replicate_pad_into(x, pad, out):
+    """InputPadder.pad of x into the preallocated `out` (a batch slice of the encoder input)."""
+    x = _c(x.float())
+    n, c, h, w = x.shape
+    left, right, top, bottom = pad
+    assert tuple(out.shape) == (n, c, h + top + bottom, w + left + right) and out.is_contiguous()
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().eemop_replicate_pad(x.data_ptr(), out.data_ptr(), n * c, h, w, left, right, top, bottom, _sp(x)))
+    return out
+
+
+def replicate_pad(x, pad):
+    """InputPadder.pad for one tensor (utils/image_utils.py:139-140); inputs carry no gradient."""
+    x = _c(x.float())
+    n, c, h, w = x.shape
+    left, right, top, bottom = pad
+    out = torch.empty(n, c, h + top + bottom, w + left + right, device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().eemop_replicate_pad(x.data_ptr(), out.data_ptr(), n * c, h, w, left, right, top, bottom, _sp(x)))
+    return out

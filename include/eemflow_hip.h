@@ -283,6 +283,73 @@ int eemplus_warp_bwd(const float* x, const float* flow, const float* dout, int b
 int eemplus_upsample_flow_as(float* inputs, int batch, int h, int w, int oh, int ow, int if_rate, float* out,
                              void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Operator-level entry points (eemop_*): the differentiable building blocks of the E-RAFT training graph - what
+ * torch.autograd records when train_mvsec.py:245-258 runs model(im1, im2) -> sequence_loss -> backward on model/eraft.py with the
+ * module in train() (train-mode BatchNorm in cnet, model/extractor.py:31-35; SepConvGRU / motion encoder / heads of
+ * model/update.py:6-106 unrolled 12 times).  All tensors are caller-owned dense NCHW fp32 on the current device;
+ * eemflow_amd/ops.py wraps each pair as a torch.autograd.Function.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* conv2d of up to three channel-concatenated inputs (the torch.cat of model/update.py:44,51,79 is never materialised):
+ * x_s [n][c_s][hin][win] (x1 / x2 may be NULL), w [cout][c0+c1+c2][kh][kw], bias [cout] or NULL; act 0 none, 1 ReLU, 2 sigmoid,
+ * 3 tanh; out[n][out_coff + co][hout][wout] of an out_ctotal-channel tensor = out_scale * act(conv + bias).
+ * Replaces: nn.Conv2d.forward (+ the activation that follows it) in model/extractor.py, model/update.py. */
+int eemop_conv2d_fwd(const float* x0, int c0, const float* x1, int c1, const float* x2, int c2, const float* w, const float* bias,
+                     int n, int hin, int win, int cout, int kh, int kw, int stride, int ph, int pw, int act, float out_scale, float* out,
+                     int out_ctotal, int out_coff, void* stream);
+/* d loss / d x for the input-channel slice [ci0, ci0 + cic) of a conv with cin input channels: dx [n][cic][hin][win] from
+ * dy [n][cout][hout][wout] (the gradient w.r.t. the conv's output BEFORE its activation).  stride 1 or 2.
+ * Replaces: autograd of nn.Conv2d w.r.t. its input. */
+int eemop_conv2d_bwd_data(const float* dy, const float* w, int n, int hin, int win, int cin, int ci0, int cic, int cout, int kh, int kw,
+                          int stride, int ph, int pw, float* dx, void* stream);
+/* dw [cout][cin][kh][kw] (slice [ci0, ci0 + cic) of the input channels) += dy (x) x, db [cout] += sum dy (db may be NULL); x is
+ * that slice's input [n][cic][hin][win].  Accumulating: the caller zeroes dw / db.  Kernel shapes built: 3x3, 1x1 (stride 1, 2),
+ * 1x5, 5x1, 7x7 (stride 1, 2; at most 32 input channels).  Replaces: autograd of nn.Conv2d w.r.t. weight and bias. */
+int eemop_conv2d_bwd_weight(const float* x, const float* dy, int n, int hin, int win, int cin, int ci0, int cic, int cout, int kh, int kw,
+                            int stride, int ph, int pw, float* dw, float* db, void* stream);
+/* out = scale * dy * act'(y) for y = act(pre): kind 1 ReLU, 2 sigmoid, 3 tanh, 0 identity.  Replaces: autograd of F.relu /
+ * torch.sigmoid / torch.tanh (model/update.py:14,45-47,54-56,74-79,95; model/eraft.py:130-131) and of the 0.25 mask scale (:105). */
+int eemop_act_bwd(const float* dy, const float* y, long long n, int kind, float scale, float* out, void* stream);
+/* out = a + b (kind 0), a - b (1), a * b (2), relu(a + b) (3), alpha * a (4; b unused).  Replaces: coords1 - coords0, coords1 +
+ * delta_flow (model/eraft.py:144,149), r * h (model/update.py:47,56), relu(x + y) (model/extractor.py:57). */
+int eemop_binary(int kind, const float* a, const float* b, float alpha, long long n, float* out, void* stream);
+/* h' = (1 - z) h + z q and its adjoint (dz = dout (q - h), dh = dout (1 - z), dq = dout z).  Replaces: model/update.py:48,57. */
+int eemop_gru_blend(const float* z, const float* h, const float* q, long long n, float* out, void* stream);
+int eemop_gru_blend_bwd(const float* dout, const float* z, const float* h, const float* q, long long n, float* dz, float* dh, float* dq,
+                        void* stream);
+/* dst[n][dst_coff + c] = src[n][src_coff + c], c < cc: torch.cat([out, flow], dim=1) (model/update.py:81) and its split. */
+int eemop_copy_channels(const float* src, int src_ctotal, int src_coff, float* dst, int dst_ctotal, int dst_coff, int cc, int n, int hw,
+                        void* stream);
+/* coords0 = coords1 = pixel grid [batch][2][h][w] (channel 0 = x, 1 = y), coords1 += flow_init when given.
+ * Replaces: ERAFT.initialize_flow + the flow_init add  (model/eraft.py:73-81,136-137). */
+int eemop_coords_init(float* coords0, float* coords1, const float* flow_init, int batch, int h, int w, void* stream);
+/* F.pad(mode='replicate') of [nc][h][w]  (InputPadder.pad, utils/image_utils.py:139-140). */
+int eemop_replicate_pad(const float* in, float* out, int nc, int h, int w, int left, int right, int top, int bottom, void* stream);
+/* InstanceNorm2d(affine=False, eps 1e-5) over `planes` (n, c) planes of hw pixels: out = relu?(IN(x)) or relu(IN(x) + res) when res
+ * is given; backward (x = the norm's input, y = its output) for the no-residual forms.
+ * Replaces: nn.InstanceNorm2d (+ ReLU) of fnet, model/extractor.py:31-35,43-57, and its autograd. */
+int eemop_instnorm_fwd(const float* x, const float* res, int planes, int hw, int relu, float* out, void* stream);
+int eemop_instnorm_bwd(const float* x, const float* y, const float* dy, int planes, int hw, int relu, float* dx, void* stream);
+/* BatchNorm2d in TRAINING mode: batch mean / biased variance over (n, hw) per channel, y = relu?((x - mean) rstd w + b); the running
+ * statistics are updated IN PLACE (momentum, unbiased variance) and save_mean / save_rstd [c] kept for the backward, which returns
+ * dx, dweight [c], dbias [c].  Replaces: nn.BatchNorm2d.forward in train() of cnet (model/extractor.py:31-35,123-133;
+ * train_mvsec.py:231-235 leaves BatchNorm unfrozen) and its autograd. */
+int eemop_batchnorm_train_fwd(const float* x, const float* weight, const float* bias, float* running_mean, float* running_var, int n,
+                              int c, int hw, float momentum, float eps, int relu, float* y, float* save_mean, float* save_rstd,
+                              void* stream);
+int eemop_batchnorm_train_bwd(const float* x, const float* y, const float* dy, const float* weight, const float* save_mean,
+                              const float* save_rstd, int n, int c, int hw, int relu, float* dx, float* dweight, float* dbias, void* stream);
+/* CorrBlock on caller tensors: the pyramid pyr_l [batch*h*w][h >> l][w >> l] (adjoint: eraft_corr_pyramid_bwd) and the 4-level 9x9
+ * lookup at `coords` [batch][2][h][w] -> out [batch][324][h][w] (adjoint: eraft_corr_lookup_bwd).  model/corr.py:13-60. */
+int eemop_corr_pyramid_fwd(const float* fmap1, const float* fmap2, int batch, int c, int h, int w, float* pyr0, float* pyr1, float* pyr2,
+                           float* pyr3, void* stream);
+int eemop_corr_lookup_fwd(const float* pyr0, const float* pyr1, const float* pyr2, const float* pyr3, const float* coords, int batch, int h,
+                          int w, float* out, void* stream);
+/* ERAFT.upsample_flow on caller tensors: flow [batch][2][h][w], mask [batch][576][h][w] -> out [batch][2][8h][8w]; `zeros` is an
+ * all-zero [batch][2][h][w] tensor (adjoint: eraft_convex_upsample_bwd).  model/eraft.py:83-94. */
+int eemop_convex_upsample_fwd(const float* zeros, const float* flow, const float* mask, int batch, int h, int w, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

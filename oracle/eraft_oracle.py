@@ -25,28 +25,28 @@ def _norm(x, sd, prefix, norm_fn, training=False):
     raise ValueError(norm_fn)
 
 
-def residual_block(sd, p, x, norm_fn, stride):
+def residual_block(sd, p, x, norm_fn, stride, training=False):
     """model/extractor.py:7-57."""
     y = F.relu(_norm(F.conv2d(x, sd[p + "conv1.weight"], sd[p + "conv1.bias"], stride=stride, padding=1), sd,
-                     p + "norm1.", norm_fn))
-    y = F.relu(_norm(F.conv2d(y, sd[p + "conv2.weight"], sd[p + "conv2.bias"], padding=1), sd, p + "norm2.", norm_fn))
+                     p + "norm1.", norm_fn, training))
+    y = F.relu(_norm(F.conv2d(y, sd[p + "conv2.weight"], sd[p + "conv2.bias"], padding=1), sd, p + "norm2.", norm_fn, training))
     if stride != 1:
         x = _norm(F.conv2d(x, sd[p + "downsample.0.weight"], sd[p + "downsample.0.bias"], stride=stride), sd,
-                  p + "norm3.", norm_fn)
+                  p + "norm3.", norm_fn, training)
     return F.relu(x + y)
 
 
-def basic_encoder(sd, prefix, x, norm_fn):
+def basic_encoder(sd, prefix, x, norm_fn, training=False):
     """model/extractor.py:119-190 (eval, dropout 0).  x may be a list (batch-concatenated, :170-174)."""
     is_list = isinstance(x, (list, tuple))
     if is_list:
         b = x[0].shape[0]
         x = torch.cat(list(x), 0)
     x = F.conv2d(x, sd[prefix + "conv1.weight"], sd[prefix + "conv1.bias"], stride=2, padding=3)
-    x = F.relu(_norm(x, sd, prefix + "norm1.", norm_fn))
+    x = F.relu(_norm(x, sd, prefix + "norm1.", norm_fn, training))
     for layer, stride in (("layer1", 1), ("layer2", 2), ("layer3", 2)):
-        x = residual_block(sd, f"{prefix}{layer}.0.", x, norm_fn, stride)
-        x = residual_block(sd, f"{prefix}{layer}.1.", x, norm_fn, 1)
+        x = residual_block(sd, f"{prefix}{layer}.0.", x, norm_fn, stride, training)
+        x = residual_block(sd, f"{prefix}{layer}.1.", x, norm_fn, 1, training)
     x = F.conv2d(x, sd[prefix + "conv2.weight"], sd[prefix + "conv2.bias"])
     return torch.split(x, b, 0) if is_list else x
 
@@ -142,14 +142,15 @@ def convex_upsample(flow, mask):
     return up.reshape(n, 2, 8 * h, 8 * w)
 
 
-def eraft_forward(sd, events1, events2, iters=12, flow_init=None, image_size=None, keep=False):
-    """ERAFT.forward (eval) - model/eraft.py:97-159.  Returns (list of flow predictions, stages)."""
+def eraft_forward(sd, events1, events2, iters=12, flow_init=None, image_size=None, keep=False, bn_training=False):
+    """ERAFT.forward - model/eraft.py:97-159.  Returns (list of flow predictions, stages).  bn_training: cnet's BatchNorm layers
+    use batch statistics and update sd's running_mean / running_var in place (the module in train(), train_mvsec.py:231-235)."""
     h, w = events1.shape[-2:]
     pad = input_padder_pad(*(image_size or (h, w)), mode="chairs", eval_pad_rate=32)   # eraft.py:65-67
     im1, im2 = replicate_pad(events1, pad).contiguous(), replicate_pad(events2, pad).contiguous()
     fmap1, fmap2 = basic_encoder(sd, "fnet.", [im1, im2], "instance")
     pyr = corr_pyramid(fmap1.float(), fmap2.float())
-    cnet = basic_encoder(sd, "cnet.", im1, "batch")
+    cnet = basic_encoder(sd, "cnet.", im1, "batch", bn_training)
     net, inp = torch.split(cnet, [128, 128], dim=1)
     net, inp = torch.tanh(net), torch.relu(inp)
     n, _, hp, wp = im1.shape
@@ -160,6 +161,7 @@ def eraft_forward(sd, events1, events2, iters=12, flow_init=None, image_size=Non
     preds = []
     st = {"pad": pad, "fmap1": fmap1, "fmap2": fmap2, "net0": net, "inp": inp}
     for it in range(iters):
+        coords1 = coords1.detach()                                      # eraft.py:141
         corr = corr_lookup(pyr, coords1)
         flow = coords1 - coords0
         net, mask, delta = update_block(sd, "update_block.", net, inp, corr, flow)

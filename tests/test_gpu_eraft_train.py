@@ -1,0 +1,204 @@
+"""E-RAFT under autograd on the GPU: the operator-level entry points (eemop_*) against torch-CPU autograd of the same op, and the whole
+model - train-mode BatchNorm in cnet, InstanceNorm in fnet, unrolled SepConvGRU update block, detached coordinates, convex upsampling,
+gamma-weighted sequence loss (train_mvsec.py:201-227) - against torch autograd through the oracle.  `pytest -m gpu`."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from eemflow_amd import ops
+from eemflow_amd.eraft import ERAFT
+from eemflow_amd.eraft_weights import seeded_from_shapes
+from eemflow_amd.weights import synthetic_gt, synthetic_voxel_pair
+from oracle import eemflow_oracle as O
+from oracle import eraft_oracle as R
+from oracle import train_oracle as T
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return (torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale).float()
+
+
+@pytest.mark.parametrize("cin_segs,cout,k,stride,pad,hw,act", [
+    ((16,), 24, (3, 3), 1, (1, 1), (20, 28), ops.ACT_RELU),
+    ((64,), 96, (3, 3), 2, (1, 1), (30, 40), ops.ACT_NONE),
+    ((64,), 96, (1, 1), 2, (0, 0), (30, 40), ops.ACT_NONE),
+    ((5,), 64, (7, 7), 2, (3, 3), (64, 80), ops.ACT_NONE),
+    ((2,), 128, (7, 7), 1, (3, 3), (16, 20), ops.ACT_RELU),
+    ((128, 128, 128), 128, (1, 5), 1, (0, 2), (16, 20), ops.ACT_SIGMOID),
+    ((128, 128, 128), 128, (5, 1), 1, (2, 0), (16, 20), ops.ACT_TANH),
+    ((192, 64), 126, (3, 3), 1, (1, 1), (16, 20), ops.ACT_RELU),
+    ((324,), 256, (1, 1), 1, (0, 0), (16, 20), ops.ACT_RELU),
+    ((256,), 576, (1, 1), 1, (0, 0), (16, 20), ops.ACT_NONE),
+    ((128,), 256, (3, 3), 1, (1, 1), (16, 20), ops.ACT_RELU),
+    ((256,), 2, (3, 3), 1, (1, 1), (16, 20), ops.ACT_NONE),
+])
+def test_conv2d_forward_and_gradients_vs_torch(cin_segs, cout, k, stride, pad, hw, act):
+    n, (h, w) = 2, hw
+    cin = sum(cin_segs)
+    conv = nn.Conv2d(cin, cout, k, stride=stride, padding=pad)
+    with torch.no_grad():
+        conv.weight.copy_(rnd(*conv.weight.shape, seed=1, scale=(2.0 / (cin * k[0] * k[1])) ** 0.5))
+        conv.bias.copy_(rnd(cout, seed=2, scale=0.1))
+    xs = [rnd(n, c, h, w, seed=3 + i) for i, c in enumerate(cin_segs)]
+    scale = 0.25 if act == ops.ACT_NONE and cout == 576 else 1.0
+    f = {ops.ACT_NONE: lambda t: t, ops.ACT_RELU: F.relu, ops.ACT_SIGMOID: torch.sigmoid, ops.ACT_TANH: torch.tanh}[act]
+    # reference: torch CPU autograd
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    yr = scale * f(conv(torch.cat(xr, 1)))
+    g = rnd(*yr.shape, seed=9)
+    yr.backward(g)
+    ref = dict(y=yr.detach(), dw=conv.weight.grad.clone(), db=conv.bias.grad.clone(), dx=[x.grad for x in xr])
+    conv.zero_grad()
+    # HIP
+    cg = nn.Conv2d(cin, cout, k, stride=stride, padding=pad).to(DEV)
+    cg.load_state_dict(conv.state_dict())
+    xg = [x.to(DEV).requires_grad_(True) for x in xs]
+    yg = ops.conv2d(cg, *xg, act=act, out_scale=scale)
+    yg.backward(g.to(DEV))
+    assert rel(yg, ref["y"]) < 2e-5
+    assert rel(cg.weight.grad, ref["dw"]) < 2e-4 and rel(cg.bias.grad, ref["db"]) < 2e-4
+    for a, b in zip(xg, ref["dx"]):
+        assert rel(a.grad, b) < 2e-5
+
+
+@pytest.mark.parametrize("relu", [True, False])
+def test_instance_norm_vs_torch(relu):
+    x = rnd(3, 7, 19, 23, seed=4, scale=2.0) + 0.5
+    xr = x.clone().requires_grad_(True)
+    yr = F.instance_norm(xr, eps=1e-5)
+    yr = F.relu(yr) if relu else yr
+    g = rnd(*x.shape, seed=5)
+    yr.backward(g)
+    xg = x.to(DEV).requires_grad_(True)
+    yg = ops.InstanceNormReLU.apply(xg, relu)
+    yg.backward(g.to(DEV))
+    assert rel(yg, yr) < 1e-5 and rel(xg.grad, xr.grad) < 2e-5
+
+
+@pytest.mark.parametrize("relu", [True, False])
+def test_batch_norm_train_mode_vs_torch(relu):
+    n, c, h, w = 3, 10, 17, 21
+    x = rnd(n, c, h, w, seed=6, scale=1.5) + 0.3
+    bn = nn.BatchNorm2d(c)
+    with torch.no_grad():
+        bn.weight.copy_(rnd(c, seed=7).abs() + 0.5); bn.bias.copy_(rnd(c, seed=8))
+        bn.running_mean.copy_(rnd(c, seed=9) * 0.1); bn.running_var.copy_(rnd(c, seed=10).abs() + 0.5)
+    bg = nn.BatchNorm2d(c).to(DEV)
+    bg.load_state_dict(bn.state_dict())
+    bn.train()
+    xr = x.clone().requires_grad_(True)
+    yr = bn(xr)
+    yr = F.relu(yr) if relu else yr
+    g = rnd(*x.shape, seed=11)
+    yr.backward(g)
+    xg = x.to(DEV).requires_grad_(True)
+    yg = ops.BatchNormTrainReLU.apply(xg, bg.weight, bg.bias, bg.running_mean, bg.running_var, bg.momentum, bg.eps, relu)
+    yg.backward(g.to(DEV))
+    assert rel(yg, yr) < 1e-5 and rel(xg.grad, xr.grad) < 5e-5
+    assert rel(bg.weight.grad, bn.weight.grad) < 2e-5 and rel(bg.bias.grad, bn.bias.grad) < 2e-5
+    assert rel(bg.running_mean, bn.running_mean) < 1e-6 and rel(bg.running_var, bn.running_var) < 1e-6
+
+
+def test_small_ops_vs_torch():
+    z, b, c, q = torch.sigmoid(rnd(2, 8, 9, 11, seed=1)), rnd(2, 8, 9, 11, seed=2), rnd(2, 8, 9, 11, seed=3), torch.tanh(rnd(2, 8, 9, 11, seed=4))
+    a2, b2, c2, q2 = (t.clone().requires_grad_(True) for t in (z, b, c, q))
+    ref = (1 - a2) * b2 + a2 * q2 + a2 * b2 + F.relu(b2 + c2) - c2
+    ref_cat = torch.cat([a2, b2], 1)
+    g, gc = rnd(*ref.shape, seed=5), rnd(*ref_cat.shape, seed=6)
+    ((ref * g).sum() + (ref_cat * gc).sum()).backward()
+    ag, bg, cg, qg = (t.to(DEV).requires_grad_(True) for t in (z, b, c, q))
+    out = ops.Add.apply(ops.Add.apply(ops.Add.apply(ops.GRUBlend.apply(ag, bg, qg), ops.Mul.apply(ag, bg), 1), ops.AddReLU.apply(bg, cg), 1), cg, -1)
+    cat = ops.Cat2.apply(ag, bg)
+    out.backward(g.to(DEV), retain_graph=True)
+    cat.backward(gc.to(DEV))
+    assert rel(out, ref) < 1e-6 and rel(cat, ref_cat) == 0.0
+    for x, y in ((ag, a2), (bg, b2), (cg, c2), (qg, q2)):
+        assert rel(x.grad, y.grad) < 1e-5
+
+
+def make_model(seed):
+    net = ERAFT("", 5)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sdn = seeded_from_shapes(shapes, seed)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sdn.items()})
+    return net.to(DEV).train(), O.to_torch_sd(sdn)
+
+
+def oracle_loss_and_grads(sd, e1, e2, gt, valid, iters, size):
+    params = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone()) for k, v in sd.items()}
+    preds, _ = R.eraft_forward(params, e1, e2, iters=iters, image_size=size, bn_training=True)
+    loss, metrics = T.sequence_loss(preds, gt, valid, 0.8)
+    loss.backward()
+    grads = {k: v.grad for k, v in params.items() if v.is_floating_point() and v.requires_grad}
+    return float(loss), metrics, grads, [p.detach() for p in preds], params
+
+
+@pytest.mark.parametrize("b,h,w,iters", [(2, 128, 160, 3), (1, 136, 200, 2)])
+def test_eraft_loss_backward_vs_oracle_autograd(b, h, w, iters):
+    from eemflow_amd import train as hip_train
+    net, sd = make_model(31)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(32, b, h, w))
+    gt, valid = (torch.from_numpy(a) for a in synthetic_gt(33, b, h, w))
+    (_, _), preds = net(e1.to(DEV), e2.to(DEV), iters=iters)
+    assert len(preds) == iters and preds[0].shape == (b, 2, h, w) and preds[-1].requires_grad
+    loss, metrics = hip_train.sequence_loss(preds, gt.to(DEV), valid.to(DEV), 0.8)
+    loss.backward()
+    rloss, rmetrics, rgrads, rpreds, rparams = oracle_loss_and_grads(sd, e1, e2, gt, valid, iters, (h, w))
+    for p, r in zip(preds, rpreds):
+        assert float((p.detach().cpu() - r).abs().max()) < 1e-3
+    assert abs(float(loss) - rloss) < 1e-5 and abs(metrics["epe"] - rmetrics["epe"]) < 1e-4
+    named = dict(net.named_parameters())
+    missing = [k for k in rgrads if rgrads[k] is not None and named[k].grad is None]
+    assert not missing, missing
+    worst = max((rel(named[k].grad, g), k) for k, g in rgrads.items() if g is not None and float(g.abs().max()) > 0)
+    assert worst[0] < 5e-3, worst
+    # train-mode BatchNorm: the module's running statistics moved exactly as torch's do
+    bufs = dict(net.named_buffers())
+    for k, v in rparams.items():
+        if "running_" in k:
+            assert rel(bufs[k], v) < 1e-5, k
+        if k.endswith("num_batches_tracked") and k.startswith("cnet."):
+            assert int(bufs[k]) == 1
+
+
+def test_eraft_reference_training_sequence_two_steps():
+    """train_mvsec.py:241-258 statement for statement on ERAFT: the loss falls and inference afterwards uses the stepped weights."""
+    from eemflow_amd import train as hip_train
+    b, h, w, iters = 1, 128, 128, 2
+    model, _ = make_model(41)
+    model.change_imagesize((h, w))
+    optimizer = torch.optim.AdamW(filter(lambda p: p.requires_grad, model.parameters()), lr=2e-4, weight_decay=5e-5, eps=1e-8)
+    scheduler = torch.optim.lr_scheduler.OneCycleLR(optimizer, 2e-4, 20 + 100, pct_start=0.05, cycle_momentum=False, anneal_strategy='linear')
+    scaler = torch.amp.GradScaler("cuda", enabled=True)
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(42, b, h, w))
+    gt, valid = (torch.from_numpy(a).to(DEV) for a in synthetic_gt(43, b, h, w))
+    losses = []
+    for step in range(3):
+        optimizer.zero_grad()
+        _, flow_list = model(e1, e2, iters=iters)
+        loss, metrics = hip_train.sequence_loss(flow_list, gt, valid, 0.8)
+        scaler.scale(loss).backward()
+        scaler.unscale_(optimizer)
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        scaler.step(optimizer)
+        scheduler.step()
+        scaler.update()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    model.eval()
+    with torch.no_grad():
+        flow = model(e1, e2, iters=iters)[1][-1]
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        ref, _ = R.eraft_forward(sd, e1.cpu(), e2.cpu(), iters=iters)
+    assert float((flow.cpu() - ref[-1]).abs().max()) < 1e-3

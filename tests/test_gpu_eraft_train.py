@@ -52,19 +52,22 @@ def test_conv2d_forward_and_gradients_vs_torch(cin_segs, cout, k, stride, pad, h
     xs = [rnd(n, c, h, w, seed=3 + i) for i, c in enumerate(cin_segs)]
     scale = 0.25 if act == ops.ACT_NONE and cout == 576 else 1.0
     f = {ops.ACT_NONE: lambda t: t, ops.ACT_RELU: F.relu, ops.ACT_SIGMOID: torch.sigmoid, ops.ACT_TANH: torch.tanh}[act]
-    # reference: torch CPU autograd
-    xr = [x.clone().requires_grad_(True) for x in xs]
-    yr = scale * f(conv(torch.cat(xr, 1)))
-    g = rnd(*yr.shape, seed=9)
-    yr.backward(g)
-    ref = dict(y=yr.detach(), dw=conv.weight.grad.clone(), db=conv.bias.grad.clone(), dx=[x.grad for x in xr])
-    conv.zero_grad()
     # HIP
     cg = nn.Conv2d(cin, cout, k, stride=stride, padding=pad).to(DEV)
     cg.load_state_dict(conv.state_dict())
     xg = [x.to(DEV).requires_grad_(True) for x in xs]
     yg = ops.conv2d(cg, *xg, act=act, out_scale=scale)
+    g = rnd(*yg.shape, seed=9)
     yg.backward(g.to(DEV))
+    # reference: torch CPU autograd.  ReLU's kink: a pre-activation within rounding of 0 may fall on either side, and one flipped
+    # pixel moves a weight gradient by |g x|; the reference therefore gates with the GPU's own mask (values agree to 1e-6 there)
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    pre = conv(torch.cat(xr, 1))
+    yr = scale * (pre * (yg.detach().cpu() > 0) if act == ops.ACT_RELU else f(pre))
+    if act == ops.ACT_RELU:
+        assert float((F.relu(pre) - yr).abs().max()) < 1e-5
+    yr.backward(g)
+    ref = dict(y=yr.detach(), dw=conv.weight.grad.clone(), db=conv.bias.grad.clone(), dx=[x.grad for x in xr])
     assert rel(yg, ref["y"]) < 2e-5
     assert rel(cg.weight.grad, ref["dw"]) < 2e-4 and rel(cg.bias.grad, ref["db"]) < 2e-4
     for a, b in zip(xg, ref["dx"]):
@@ -161,11 +164,20 @@ def test_eraft_loss_backward_vs_oracle_autograd(b, h, w, iters):
     named = dict(net.named_parameters())
     missing = [k for k in rgrads if rgrads[k] is not None and named[k].grad is None]
     assert not missing, missing
-    worst = max((rel(named[k].grad, g), k) for k, g in rgrads.items() if g is not None and float(g.abs().max()) > 0)
+    # a conv bias in front of a norm layer has an exactly zero gradient (the norm removes the mean): both sides hold round-off there
+    gmax = max(float(g.abs().max()) for g in rgrads.values() if g is not None)
+    live = {k: g for k, g in rgrads.items() if g is not None and float(g.abs().max()) > 1e-6 * gmax}
+    for k, g in rgrads.items():
+        if g is not None and k not in live:
+            assert float(named[k].grad.abs().max()) < 1e-4 * gmax, k
+    assert len(live) > 80
+    worst = max((rel(named[k].grad, g), k) for k, g in live.items())
     assert worst[0] < 5e-3, worst
     # train-mode BatchNorm: the module's running statistics moved exactly as torch's do
-    bufs = dict(net.named_buffers())
+    bufs = net.state_dict()
     for k, v in rparams.items():
+        if ".downsample.1." in k:
+            continue                           # alias of norm3 in the module; the functional oracle updates the norm3 entries
         if "running_" in k:
             assert rel(bufs[k], v) < 1e-5, k
         if k.endswith("num_batches_tracked") and k.startswith("cnet."):

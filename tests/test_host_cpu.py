@@ -16,7 +16,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(REPO, "include", "eemflow_hip.h")).read()
-    declared = set(re.findall(r"\b((?:eemflow|eraft|eemplus)_[a-z0-9_]+)\s*\(", header))
+    declared = set(re.findall(r"\b((?:eemflow|eraft|eemplus|eemop)_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     handle = _lib.lib()                      # resolves every symbol or raises
     assert handle.eemflow_abi_version() == 1

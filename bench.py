@@ -195,6 +195,36 @@ def other_rows(dev):
         out["train_step_346x260_b32_ms"] = round((time.perf_counter() - t0) / 5 * 1e3, 2)
     except Exception as e:                                   # noqa: BLE001
         out["train_error"] = repr(e)[:200]
+    try:                                                     # E-RAFT training step at configs[4]'s shape (operator-level autograd route)
+        from eemflow_amd.eraft import ERAFT
+        from eemflow_amd.eraft_weights import seeded_from_shapes
+        from eemflow_amd.train import sequence_loss
+        from eemflow_amd.weights import synthetic_gt, synthetic_voxel_pair
+        net = ERAFT("", 5)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in
+                             seeded_from_shapes({k: tuple(v.shape) for k, v in net.state_dict().items()}, 0).items()})
+        net = net.to(dev).train()
+        net.change_imagesize((480, 640))
+        opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=5e-5, eps=1e-8)
+        e1, e2 = (torch.from_numpy(a).to(dev) for a in synthetic_voxel_pair(1, 4, 480, 640))
+        gt, va = (torch.from_numpy(a).to(dev) for a in synthetic_gt(2, 4, 480, 640))
+
+        def estep():
+            opt.zero_grad()
+            loss, _ = sequence_loss(net(e1, e2, iters=12)[1], gt, va, 0.8)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)
+            opt.step()
+        estep()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(2):
+            estep()
+        torch.cuda.synchronize(dev)
+        out["eraft_train_step_640x480_12it_b4_ms"] = round((time.perf_counter() - t0) / 2 * 1e3, 1)
+        del net, opt
+    except Exception as e:                                   # noqa: BLE001
+        out["eraft_train_error"] = repr(e)[:200]
     return out
 
 

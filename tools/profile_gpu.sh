@@ -6,7 +6,7 @@ tag=${1:-prof}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-BENCH="bench.py --steps 200 --warmup 20"
+BENCH="bench.py --steps 300 --warmup 30"
 timeout 600 python3 $BENCH > $out/bench.json 2> $out/bench.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $BENCH --cpu-seconds 0 --no-other-rows --streams 1 > $out/bench_under_rocprof.json 2> $out/stats.err
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do

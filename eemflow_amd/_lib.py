@@ -109,6 +109,14 @@ _SIGNATURES = {
     "eemop_corr_pyramid_fwd": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 4 + [_c_float_p] * 4 + [ctypes.c_void_p]),
     "eemop_corr_lookup_fwd": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 3 + [_c_float_p, ctypes.c_void_p]),
     "eemop_convex_upsample_fwd": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 3 + [_c_float_p, ctypes.c_void_p]),
+    "eemop_act_fwd": (ctypes.c_int, [_c_float_p, ctypes.c_longlong, ctypes.c_int, _c_float_p, ctypes.c_void_p]),
+    "eemop_shuffle_channels": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
+    "eemop_scale_flow": (ctypes.c_int, [_c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, _c_float_p, ctypes.c_void_p]),
+    "eemop_pool2_fwd": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "eemop_pool2_bwd": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "eemop_resize_ac_fwd": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
+    "eemop_resize_ac_bwd": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
+    "eemop_local_corr53_bwd": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 4 + [_c_float_p, _c_float_p, ctypes.c_void_p]),
 }
 EXPORTS = tuple(_SIGNATURES)
 _lib = None

@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     if (kind == GACT_RELU) d = v > 0.f ? 1.f : 0.f;
     else if (kind == GACT_SIGMOID) d = v * (1.f - v);
     else if (kind == GACT_TANH) d = 1.f - v * v;
+    else if (kind == GACT_LEAKY) d = v > 0.f ? 1.f : 0.1f;
     else d = 1.f;
     out[i] = dy[i] * d * scale;
 }
@@ -77,6 +78,82 @@ __global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restr
     const int c = (i / hw) % cc;
     const long n = i / ((long)hw * cc);
     dst[((size_t)n * dst_ctotal + dst_coff + c) * hw + p] = src[((size_t)n * src_ctotal + src_coff + c) * hw + p];
+}
+
+// out = act(x): kind 1 ReLU, 2 sigmoid, 3 tanh, 4 LeakyReLU(0.1)
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, long n, int kind) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    out[i] = kind == GACT_RELU ? fmaxf(v, 0.f) : kind == GACT_SIGMOID ? 1.f / (1.f + expf(-v)) : kind == GACT_TANH ? tanhf(v)
+           : kind == GACT_LEAKY ? (v > 0.f ? v : 0.1f * v) : v;
+}
+
+// channel_shuffle (EEMFlow+.py:52-58): dst channel j * groups + g = src channel g * per + j; inverse: the other way round
+__global__ __launch_bounds__(256) void shuffle_kernel(const float* __restrict__ src, float* __restrict__ dst, int c, int groups, int hw,
+                                                      long total, int inverse) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int p = i % hw;
+    const int ch = (i / hw) % c;
+    const long n = i / ((long)hw * c);
+    const int per = c / groups;
+    const int g = ch / per, j = ch - g * per;             // ch as a source channel of the forward shuffle
+    const int sh = j * groups + g;
+    if (!inverse) dst[((size_t)n * c + sh) * hw + p] = src[i];
+    else dst[i] = src[((size_t)n * c + sh) * hw + p];
+}
+
+// flow channel scale: out[:, 0] = su * x[:, 0], out[:, 1] = sv * x[:, 1]   (upsample2d_flow_as's rate, cdc_utils.py:85-93)
+__global__ __launch_bounds__(256) void scale_flow2_kernel(const float* __restrict__ x, float* __restrict__ out, int hw, long total, float su,
+                                                          float sv) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) out[i] = x[i] * (((i / hw) & 1) ? sv : su);
+}
+
+// avg_pool2d(2, 2) backward: dx[y][x] = dy[y/2][x/2] / 4 inside the pooled extent, 0 in an odd last row / column
+__global__ __launch_bounds__(256) void pool2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int h, int w, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int x = i % w, y = (i / w) % h;
+    const long pl = i / ((long)w * h);
+    const int oh = h / 2, ow = w / 2;
+    dx[i] = (y / 2 < oh && x / 2 < ow) ? 0.25f * dy[(pl * oh + y / 2) * ow + x / 2] : 0.f;
+}
+
+// F.interpolate(bilinear, align_corners=True) of [nc][h][w] -> [nc][oh][ow] and its adjoint (dx zeroed by the caller, atomics)
+__device__ __forceinline__ void ac_taps(int Y, int X, int h, int w, int oh, int ow, int& y0, int& y1, int& x0, int& x1, float& ly, float& lx) {
+    const float sy = oh > 1 ? (float)(h - 1) / (float)(oh - 1) : 0.f, sx = ow > 1 ? (float)(w - 1) / (float)(ow - 1) : 0.f;
+    const float fy = sy * (float)Y, fx = sx * (float)X;
+    y0 = (int)fy; x0 = (int)fx;
+    y1 = y0 + (y0 < h - 1 ? 1 : 0); x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    ly = fy - (float)y0; lx = fx - (float)x0;
+}
+__global__ __launch_bounds__(256) void resize_ac_kernel(const float* __restrict__ in, float* __restrict__ out, int h, int w, int oh, int ow,
+                                                        long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int X = i % ow, Y = (i / ow) % oh;
+    const long pl = i / ((long)ow * oh);
+    int y0, y1, x0, x1; float ly, lx;
+    ac_taps(Y, X, h, w, oh, ow, y0, y1, x0, x1, ly, lx);
+    const float* s = in + pl * h * w;
+    out[i] = (1.f - ly) * ((1.f - lx) * s[y0 * w + x0] + lx * s[y0 * w + x1]) + ly * ((1.f - lx) * s[y1 * w + x0] + lx * s[y1 * w + x1]);
+}
+__global__ __launch_bounds__(256) void resize_ac_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx, int h, int w, int oh, int ow,
+                                                            long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int X = i % ow, Y = (i / ow) % oh;
+    const long pl = i / ((long)ow * oh);
+    int y0, y1, x0, x1; float ly, lx;
+    ac_taps(Y, X, h, w, oh, ow, y0, y1, x0, x1, ly, lx);
+    float* d = dx + pl * h * w;
+    const float g = dout[i];
+    atomicAdd(d + y0 * w + x0, g * (1.f - ly) * (1.f - lx));
+    atomicAdd(d + y0 * w + x1, g * (1.f - ly) * lx);
+    atomicAdd(d + y1 * w + x0, g * ly * (1.f - lx));
+    atomicAdd(d + y1 * w + x1, g * ly * lx);
 }
 
 // ------------------------------------------------------------------------------------------------ norms
@@ -480,4 +557,80 @@ extern "C" int eemop_convex_upsample_fwd(const float* zeros, const float* flow, 
                                          void* stream) {
     EEM_REQUIRE(zeros && flow && mask && out, "eemop_convex_upsample_fwd: NULL argument");
     return er_convex_up_launch(zeros, flow, mask, out, batch, h, w, 0, 0, 8 * h, 8 * w, (hipStream_t)stream);
+}
+
+// ================================================================================================ EEMFlow+ under autograd
+extern "C" int eemop_act_fwd(const float* x, long long n, int kind, float* out, void* stream) {
+    EEM_REQUIRE(x && out && n >= 0, "eemop_act_fwd: bad arguments");
+    if (n == 0) return EEM_OK;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, x, out, (long)n, kind);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+extern "C" int eemop_shuffle_channels(const float* src, float* dst, int n, int c, int groups, int hw, int inverse, void* stream) {
+    EEM_REQUIRE(src && dst && groups >= 1 && c % groups == 0, "eemop_shuffle_channels: bad arguments");
+    const long total = (long)n * c * hw;
+    hipLaunchKernelGGL(shuffle_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, src, dst, c, groups, hw, total, inverse);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+extern "C" int eemop_scale_flow(const float* x, int n, int hw, float su, float sv, float* out, void* stream) {
+    EEM_REQUIRE(x && out, "eemop_scale_flow: NULL argument");
+    const long total = (long)n * 2 * hw;
+    hipLaunchKernelGGL(scale_flow2_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, x, out, hw, total, su, sv);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+extern "C" int eemop_pool2_fwd(const float* x, float* out, long long planes, int h, int w, void* stream) {
+    EEM_REQUIRE(x && out && h >= 2 && w >= 2, "eemop_pool2_fwd: bad arguments");
+    return er_pool2_launch(x, out, (long)planes, h, w, (hipStream_t)stream);
+}
+
+extern "C" int eemop_pool2_bwd(const float* dy, float* dx, long long planes, int h, int w, void* stream) {
+    EEM_REQUIRE(dy && dx, "eemop_pool2_bwd: NULL argument");
+    const long total = (long)planes * h * w;
+    hipLaunchKernelGGL(pool2_bwd_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, h, w, total);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+extern "C" int eemop_resize_ac_fwd(const float* in, float* out, int nc, int h, int w, int oh, int ow, void* stream) {
+    EEM_REQUIRE(in && out && nc >= 1, "eemop_resize_ac_fwd: bad arguments");
+    const long total = (long)nc * oh * ow;
+    hipLaunchKernelGGL(resize_ac_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, in, out, h, w, oh, ow, total);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+extern "C" int eemop_resize_ac_bwd(const float* dout, float* dx, int nc, int h, int w, int oh, int ow, void* stream) {
+    EEM_REQUIRE(dout && dx && nc >= 1, "eemop_resize_ac_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    EEM_HIP_CHECK(hipMemsetAsync(dx, 0, (size_t)nc * h * w * sizeof(float), st));
+    const long total = (long)nc * oh * ow;
+    hipLaunchKernelGGL(resize_ac_bwd_kernel, dim3(nblk(total)), dim3(256), 0, st, dout, dx, h, w, oh, ow, total);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+// adjoint of eemflow_local_corr53: dcv [batch][53][h][w] -> df1, df2 [batch][c][h][w]
+extern "C" int eemop_local_corr53_bwd(const float* dcv, const float* f1, const float* f2, int batch, int c, int h, int w, float* df1,
+                                      float* df2, void* stream) {
+    EEM_REQUIRE(dcv && f1 && f2 && df1 && df2, "eemop_local_corr53_bwd: NULL argument");
+    static const int kTaps[53] = {0,  2,  4,  6,  8,  10, 12, 14, 16, 18, 20, 21, 22, 23, 24, 26, 28, 29, 30, 31, 32, 33, 34, 36, 38, 39, 40,
+                                  41, 42, 44, 46, 47, 48, 49, 50, 51, 52, 54, 56, 57, 58, 59, 60, 62, 64, 66, 68, 70, 72, 74, 76, 78, 80};
+    static thread_local int* taps = nullptr;
+    static thread_local int taps_dev = -1;
+    int dev = 0;
+    EEM_HIP_CHECK(hipGetDevice(&dev));
+    if (taps == nullptr || taps_dev != dev) {
+        EEM_HIP_CHECK(hipMalloc(&taps, sizeof(kTaps)));
+        EEM_HIP_CHECK(hipMemcpy(taps, kTaps, sizeof(kTaps), hipMemcpyHostToDevice));
+        taps_dev = dev;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    EEM_HIP_CHECK(hipMemsetAsync(df1, 0, (size_t)batch * c * h * w * sizeof(float), st));
+    return tr_corr_bwd_launch(dcv, 53, f1, f2, df1, df2, batch, c, h, w, taps, 53, st);
 }

@@ -4,7 +4,9 @@ Mirrors model/EEMFlow/EEMFlow+.py:74-234 and model/EEMFlow/cdc_utils.py (cdc_mod
 `change_imagesize`, `forward(events1, events2) -> ((events1, events2), [5 flows coarse -> fine])` and the same
 136-tensor state_dict (including the parameters the reference registers but never uses: up3..up6,
 cdc_model.upsample_output_conv, conv_1x1.0/.1).  Modules only hold parameters; the arithmetic runs in
-libeemflow_hip.so (eemplus_* entry points).  Inference only; CUDA tensors only.
+libeemflow_hip.so.  CUDA tensors only.  Without gradients: `eemplus_forward`, the fused inference schedule.  Under autograd
+(train_mvsec.py:245-258 on this model): the forward is assembled from the operator-level Functions of eemflow_amd/ops.py
+(`_forward_ops`), including the in-place doubling upsample2d_flow_as applies to the coarser flow (as a functional rewrite).
 """
 import ctypes
 
@@ -137,13 +139,13 @@ class EEMFlow_cdc(nn.Module):  # noqa: N801
     def forward(self, events1, events2):
         if not (events1.is_cuda and events2.is_cuda):
             raise _lib.EEMFlowHipError("EEMFlow_cdc.forward: inputs must be CUDA (ROCm) tensors - there is no CPU path")
-        if self.training and torch.is_grad_enabled():
-            raise _lib.EEMFlowHipError("EEMFlow_cdc.forward: inference only (call under torch.no_grad() / eval())")
         if not hasattr(self, "image_padder"):
             raise AttributeError("call change_imagesize(img_size) before forward (as the reference requires)")
         e1, e2 = events1.contiguous().float(), events2.contiguous().float()
         if e1.shape != e2.shape or e1.dim() != 4 or e1.shape[1] != self.n_first_channels:
             raise ValueError(f"expected two (B,{self.n_first_channels},H,W) tensors")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return (events1, events2), self._forward_ops(e1, e2)
         b, _, h, w = e1.shape
         ctx = self._context(e1.device)
         out = torch.empty(5, b, 2, h, w, device=e1.device, dtype=torch.float32)
@@ -152,6 +154,90 @@ class EEMFlow_cdc(nn.Module):  # noqa: N801
             _lib.check(_lib.lib().eemplus_forward(ctx, e1.data_ptr(), e2.data_ptr(), b, h, w, ctypes.byref(padc), out.data_ptr(),
                                                   _lib.current_stream_ptr(e1.device)))
         return (events1, events2), [out[i] for i in range(5)]
+
+    # ------------------------------------------------------------------ differentiable route (eemflow_amd/ops.py)
+    def _lrelu_conv(self, seq, *xs):
+        from . import ops
+        return ops.conv2d(seq[0], *xs, act=ops.ACT_LEAKY)
+
+    def _decoder_ops(self, dec, x):
+        """Decoder.forward (EEMFlow+.py:60-71): grouped convs as one conv per group, then channel_shuffle."""
+        from . import ops
+        out = self._lrelu_conv(dec.conv1, x)
+        G = self.groups
+        for seq in (dec.conv2, dec.conv3, dec.conv4):
+            conv = seq[0]
+            if G == 1:
+                out = self._lrelu_conv(seq, out)
+                continue
+            per_in, per_out = conv.weight.shape[1], conv.weight.shape[0] // G
+            parts = [ops.conv2d(conv, ops.ChannelSlice.apply(out, g * per_in, per_in), act=ops.ACT_LEAKY,
+                                weight=conv.weight[g * per_out:(g + 1) * per_out], bias=conv.bias[g * per_out:(g + 1) * per_out])
+                     for g in range(G)]
+            out = ops.ChannelShuffle.apply(ops.CatN.apply(*parts), G)
+        out = self._lrelu_conv(dec.conv6, self._lrelu_conv(dec.conv5, out))
+        return ops.conv2d(dec.conv7, out)
+
+    def _cdc_from_init(self, flow_init, a, b):
+        """cdc_model.forward after its upsampling (cdc_utils.py:160-173): flow_init (B,2,h,w) -> flow_up."""
+        from . import ops
+        est = self.cdc_model.dense_estimator_mask
+        x = ops.CatN.apply(a, ops.Warp.apply(b, flow_init, 2))
+        for i in range(1, 6):
+            x = ops.CatN.apply(self._lrelu_conv(getattr(est, f"conv{i}"), x), x)
+        x_out = ops.conv2d(est.conv_last[0], x)
+        inter_flow = ops.ChannelSlice.apply(x_out, 0, 2)
+        m = ops.Sigmoid.apply(ops.ChannelSlice.apply(x_out, 2, 1))
+        m2 = ops.CatN.apply(m, m)                                          # the (B,1,h,w) mask broadcast over the two flow channels
+        return ops.GRUBlend.apply(m2, ops.Warp.apply(flow_init, inter_flow, 1), flow_init)   # warp * (1 - m) + flow_init * m
+
+    def _level_ops(self, l, f1l, f2l, flow_init):
+        """One l-block of the forward (EEMFlow+.py:183-229) from cdc_model's upsampled flow_init -> (flow_up_l, flow_l)."""
+        from . import ops
+        a = self._lrelu_conv(self.conv_1x1[l], f1l)
+        b = self._lrelu_conv(self.conv_1x1[l], f2l)
+        flow_up = self._cdc_from_init(flow_init, a, b)
+        cat = ops.CatN.apply(ops.LocalCorr53.apply(f1l, ops.Warp.apply(f2l, flow_up, 0)), self._lrelu_conv(getattr(self, f"rconv{l}"), f1l),
+                             flow_up)
+        return flow_up, ops.Add.apply(self._decoder_ops(getattr(self, f"decoder{l}"), cat), flow_up, 1)
+
+    def _pyramid_ops(self, e1, e2):
+        """Replicate pad, the shared encoder on [image1; image2] and three 2x2 poolings (EEMFlow+.py:162-175) -> f1[l], f2[l], l = 1..6."""
+        from . import ops
+        b, c, h, w = e1.shape
+        pad = self.image_padder._pad
+        x = torch.empty(2 * b, c, h + pad[2] + pad[3], w + pad[0] + pad[1], device=e1.device, dtype=torch.float32)
+        ops.replicate_pad_into(e1, pad, x[:b])
+        ops.replicate_pad_into(e2, pad, x[b:])
+        feats = []
+        y = x
+        for name in ("pconv1_1", "pconv1_2", "pconv2_1", "pconv2_2", "pconv2_3", "pconv3_1", "pconv3_2", "pconv3_3"):
+            y = self._lrelu_conv(getattr(self, name), y)
+            if name in ("pconv1_2", "pconv2_3", "pconv3_3"):
+                feats.append(y)
+        for _ in range(3):
+            feats.append(ops.AvgPool2.apply(feats[-1]))
+        return {l: feats[l - 1][:b] for l in range(1, 7)}, {l: feats[l - 1][b:] for l in range(1, 7)}
+
+    def _forward_ops(self, e1, e2):
+        """EEMFlow_cdc.forward (EEMFlow+.py:158-234) as an autograd graph of HIP operators."""
+        from . import ops
+        if not (e1.is_cuda and all(p.is_cuda for p in self.parameters())):
+            raise _lib.EEMFlowHipError("EEMFlow_cdc.forward: CUDA (ROCm) tensors required - there is no CPU path")
+        b, _, h, w = e1.shape
+        f1, f2 = self._pyramid_ops(e1, e2)
+        zeros = torch.zeros(b, 2, f1[6].shape[2], f1[6].shape[3], device=e1.device, dtype=torch.float32)
+        cat6 = ops.CatN.apply(ops.LocalCorr53.apply(f1[6], f2[6]), self._lrelu_conv(self.rconv6, f1[6]), zeros)
+        flows = {6: self._decoder_ops(self.decoder6, cat6)}
+        for l in (5, 4, 3, 2):
+            hl, wl = f1[l].shape[-2:]
+            if flows[l + 1].shape[-2:] != (hl, wl):
+                # upsample2d_flow_as(if_rate=True) also scales its input in place (cdc_utils.py:85-86): continue with the scaled flow
+                flow_init, flows[l + 1] = ops.UpsampleFlowAs.apply(flows[l + 1], hl, wl)
+            else:
+                flow_init = flows[l + 1]
+            _, flows[l] = self._level_ops(l, f1[l], f2[l], flow_init)
+        return [ops.UpsampleFlowAs.apply(flows[l], h, w)[0] for l in (6, 5, 4, 3, 2)]
 
     def level(self, l, flow_init):
         """Teacher-forced level l (5..2) on the feature pyramid of the last forward: cdc_model + warp + correlation + decoder from a

@@ -388,3 +388,217 @@ def replicate_pad(x, pad):
     with torch.cuda.device(x.device):
         _lib.check(_lib.lib().eemop_replicate_pad(x.data_ptr(), out.data_ptr(), n * c, h, w, left, right, top, bottom, _sp(x)))
     return out
+
+
+# ------------------------------------------------------------------------------------------------ EEMFlow+ (EEMFlow_cdc) operators
+ACT_LEAKY = 4
+
+
+class ChannelSlice(torch.autograd.Function):
+    """x[:, off:off + cnt] as a dense tensor (the input of one group of a grouped conv, x_out[:, :2] / [:, 2:3] of the upsampler)."""
+
+    @staticmethod
+    def forward(ctx, x, off, cnt):
+        x = _c(x)
+        n, c, h, w = x.shape
+        out = torch.empty(n, cnt, h, w, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().eemop_copy_channels(x.data_ptr(), c, off, out.data_ptr(), cnt, 0, cnt, n, h * w, _sp(x)))
+        ctx.cfg = (c, off, cnt)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        c, off, cnt = ctx.cfg
+        dout = _c(dout)
+        n, _, h, w = dout.shape
+        dx = torch.zeros(n, c, h, w, device=dout.device, dtype=torch.float32)
+        with torch.cuda.device(dout.device):
+            _lib.check(_lib.lib().eemop_copy_channels(dout.data_ptr(), cnt, 0, dx.data_ptr(), c, off, cnt, n, h * w, _sp(dout)))
+        return dx, None, None
+
+
+class CatN(torch.autograd.Function):
+    """torch.cat(xs, dim=1)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        xs = [_c(x) for x in xs]
+        n, _, h, w = xs[0].shape
+        cs = [x.shape[1] for x in xs]
+        out = torch.empty(n, sum(cs), h, w, device=xs[0].device, dtype=torch.float32)
+        L = _lib.lib()
+        with torch.cuda.device(out.device):
+            off = 0
+            for x, c in zip(xs, cs):
+                _lib.check(L.eemop_copy_channels(x.data_ptr(), c, 0, out.data_ptr(), sum(cs), off, c, n, h * w, _sp(out)))
+                off += c
+        ctx.cs = cs
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = _c(dout)
+        n, ct, h, w = dout.shape
+        L = _lib.lib()
+        outs, off = [], 0
+        with torch.cuda.device(dout.device):
+            for i, c in enumerate(ctx.cs):
+                if ctx.needs_input_grad[i]:
+                    d = torch.empty(n, c, h, w, device=dout.device, dtype=torch.float32)
+                    _lib.check(L.eemop_copy_channels(dout.data_ptr(), ct, off, d.data_ptr(), c, 0, c, n, h * w, _sp(dout)))
+                    outs.append(d)
+                else:
+                    outs.append(None)
+                off += c
+        return tuple(outs)
+
+
+class ChannelShuffle(torch.autograd.Function):
+    """channel_shuffle(x, groups) (EEMFlow+.py:52-58)."""
+
+    @staticmethod
+    def forward(ctx, x, groups):
+        x = _c(x)
+        n, c, h, w = x.shape
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().eemop_shuffle_channels(x.data_ptr(), out.data_ptr(), n, c, groups, h * w, 0, _sp(x)))
+        ctx.groups = groups
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = _c(dout)
+        n, c, h, w = dout.shape
+        dx = torch.empty_like(dout)
+        with torch.cuda.device(dout.device):
+            _lib.check(_lib.lib().eemop_shuffle_channels(dout.data_ptr(), dx.data_ptr(), n, c, ctx.groups, h * w, 1, _sp(dout)))
+        return dx, None
+
+
+class AvgPool2(torch.autograd.Function):
+    """F.avg_pool2d(x, 2, 2) (EEMFlow+.py:170-175)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        n, c, h, w = x.shape
+        out = torch.empty(n, c, h // 2, w // 2, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().eemop_pool2_fwd(x.data_ptr(), out.data_ptr(), n * c, h, w, _sp(x)))
+        ctx.shape = (n, c, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        n, c, h, w = ctx.shape
+        dout = _c(dout)
+        dx = torch.empty(n, c, h, w, device=dout.device, dtype=torch.float32)
+        with torch.cuda.device(dout.device):
+            _lib.check(_lib.lib().eemop_pool2_bwd(dout.data_ptr(), dx.data_ptr(), n * c, h, w, _sp(dout)))
+        return dx
+
+
+class LocalCorr53(torch.autograd.Function):
+    """The 53 selected taps of the 9x9 local correlation, / C (EEMFlow+.py:14-23 + index_select)."""
+
+    @staticmethod
+    def forward(ctx, f1, f2):
+        f1, f2 = _c(f1), _c(f2)
+        b, c, h, w = f1.shape
+        out = torch.empty(b, 53, h, w, device=f1.device, dtype=torch.float32)
+        with torch.cuda.device(f1.device):
+            _lib.check(_lib.lib().eemflow_local_corr53(f1.data_ptr(), f2.data_ptr(), b, c, h, w, out.data_ptr(), _sp(f1)))
+        ctx.save_for_backward(f1, f2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        f1, f2 = ctx.saved_tensors
+        b, c, h, w = f1.shape
+        d1, d2 = torch.empty_like(f1), torch.empty_like(f2)
+        with torch.cuda.device(f1.device):
+            _lib.check(_lib.lib().eemop_local_corr53_bwd(_c(dout).data_ptr(), f1.data_ptr(), f2.data_ptr(), b, c, h, w, d1.data_ptr(),
+                                                         d2.data_ptr(), _sp(f1)))
+        return d1, d2
+
+
+class Warp(torch.autograd.Function):
+    """Backward bilinear warp; mode 0 EEMFlow_cdc.warp, 1 torch_warp, 2 WarpingLayer_no_div (the `>= 1` mask carries no gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, flow, mode):
+        x, flow = _c(x), _c(flow)
+        b, c, h, w = x.shape
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().eemplus_warp(x.data_ptr(), flow.data_ptr(), b, c, h, w, mode, out.data_ptr(), _sp(x)))
+        ctx.save_for_backward(x, flow)
+        ctx.mode = mode
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, flow = ctx.saved_tensors
+        b, c, h, w = x.shape
+        dx, dflow = torch.empty_like(x), torch.empty_like(flow)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().eemplus_warp_bwd(x.data_ptr(), flow.data_ptr(), _c(dout).data_ptr(), b, c, h, w, ctx.mode, dx.data_ptr(),
+                                                   dflow.data_ptr(), _sp(x)))
+        return dx, dflow, None
+
+
+class UpsampleFlowAs(torch.autograd.Function):
+    """upsample2d_flow_as(inputs, target, 'bilinear', if_rate=True) (cdc_utils.py:80-103) as a pure function: returns (res, scaled) where
+    `scaled` is what the reference leaves in `inputs` by its in-place multiplication (the caller continues with it)."""
+
+    @staticmethod
+    def forward(ctx, x, oh, ow):
+        x = _c(x)
+        n, _, h, w = x.shape
+        su, sv = ow / w, oh / h
+        L = _lib.lib()
+        up = torch.empty(n, 2, oh, ow, device=x.device, dtype=torch.float32)
+        res, scaled = torch.empty_like(up), torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            s = _sp(x)
+            _lib.check(L.eemop_resize_ac_fwd(x.data_ptr(), up.data_ptr(), n * 2, h, w, oh, ow, s))
+            _lib.check(L.eemop_scale_flow(up.data_ptr(), n, oh * ow, su, sv, res.data_ptr(), s))
+            _lib.check(L.eemop_scale_flow(x.data_ptr(), n, h * w, su, sv, scaled.data_ptr(), s))
+        ctx.cfg = (n, h, w, oh, ow, su, sv)
+        return res, scaled
+
+    @staticmethod
+    def backward(ctx, dres, dscaled):
+        n, h, w, oh, ow, su, sv = ctx.cfg
+        L = _lib.lib()
+        dev = dres.device if dres is not None else dscaled.device
+        dx = torch.zeros(n, 2, h, w, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            s = _lib.current_stream_ptr(dev)
+            if dres is not None:
+                t = torch.empty(n, 2, oh, ow, device=dev, dtype=torch.float32)
+                _lib.check(L.eemop_scale_flow(_c(dres).data_ptr(), n, oh * ow, su, sv, t.data_ptr(), s))
+                _lib.check(L.eemop_resize_ac_bwd(t.data_ptr(), dx.data_ptr(), n * 2, h, w, oh, ow, s))
+            if dscaled is not None:
+                t2 = torch.empty(n, 2, h, w, device=dev, dtype=torch.float32)
+                _lib.check(L.eemop_scale_flow(_c(dscaled).data_ptr(), n, h * w, su, sv, t2.data_ptr(), s))
+                dx = _binary(0, dx, t2)
+        return dx, None, None
+
+
+class Sigmoid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().eemop_act_fwd(x.data_ptr(), x.numel(), ACT_SIGMOID, out.data_ptr(), _sp(x)))
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (out,) = ctx.saved_tensors
+        return _act_bwd(dout, out, ACT_SIGMOID)

@@ -350,6 +350,24 @@ int eemop_corr_lookup_fwd(const float* pyr0, const float* pyr1, const float* pyr
  * all-zero [batch][2][h][w] tensor (adjoint: eraft_convex_upsample_bwd).  model/eraft.py:83-94. */
 int eemop_convex_upsample_fwd(const float* zeros, const float* flow, const float* mask, int batch, int h, int w, float* out, void* stream);
 
+/* ---- further operators of the EEMFlow+ autograd graph (model/EEMFlow/EEMFlow+.py:158-234, cdc_utils.py:50-177) */
+/* out = act(x): 1 ReLU, 2 sigmoid, 3 tanh, 4 LeakyReLU(0.1)  (torch.sigmoid of the upsampler's mask, cdc_utils.py:166). */
+int eemop_act_fwd(const float* x, long long n, int kind, float* out, void* stream);
+/* channel_shuffle (EEMFlow+.py:52-58) of [n][c][hw] and its inverse (= its adjoint). */
+int eemop_shuffle_channels(const float* src, float* dst, int n, int c, int groups, int hw, int inverse, void* stream);
+/* out[:, 0] = su * x[:, 0], out[:, 1] = sv * x[:, 1] of a flow [n][2][hw]: the rate of upsample2d_flow_as (cdc_utils.py:85-93);
+ * its own adjoint. */
+int eemop_scale_flow(const float* x, int n, int hw, float su, float sv, float* out, void* stream);
+/* F.avg_pool2d(2, 2) over the last two dims of [planes][h][w] and its adjoint  (EEMFlow+.py:170-175). */
+int eemop_pool2_fwd(const float* x, float* out, long long planes, int h, int w, void* stream);
+int eemop_pool2_bwd(const float* dy, float* dx, long long planes, int h, int w, void* stream);
+/* F.interpolate(mode='bilinear', align_corners=True) of [nc][h][w] -> [nc][oh][ow] and its adjoint  (cdc_utils.py:83). */
+int eemop_resize_ac_fwd(const float* in, float* out, int nc, int h, int w, int oh, int ow, void* stream);
+int eemop_resize_ac_bwd(const float* dout, float* dx, int nc, int h, int w, int oh, int ow, void* stream);
+/* adjoint of eemflow_local_corr53: dcv [batch][53][h][w] -> df1, df2 [batch][c][h][w]. */
+int eemop_local_corr53_bwd(const float* dcv, const float* f1, const float* f2, int batch, int c, int h, int w, float* df1, float* df2,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -132,6 +132,10 @@ __global__ __launch_bounds__(WAVES * 64) void wino_kernel(EncConvArgs a) {
     float biasv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) biasv[r] = a.bias[cog * 16 + g * 4 + r];
+    // pooling finish (one value per thread of the first C * NWX threads): the lane's share of the address
+    const bool pf_act = tid < C * NWX;
+    const int pf_co = pf_act ? tid / NWX : 0, pf_wx = pf_act ? tid - pf_co * NWX : 0;
+    const unsigned pf_off = (unsigned)pf_co * (unsigned)(a.tiles_y * a.tiles_x * NWX) + (unsigned)pf_wx;
     {
         const DmaTile d0 = dma_prep(0, nxt);
 #pragma unroll
@@ -152,22 +156,17 @@ __global__ __launch_bounds__(WAVES * 64) void wino_kernel(EncConvArgs a) {
         if (have_next) {
             tile_advance(nxt, a.tiles_x, a.tiles_y);
             dnext = dma_prep(it + 1, nxt);
-#ifdef EEM_DMA_AT_TOP
-#pragma unroll
-            for (int k = 0; k < K::NI; ++k) dma_piece(dnext, k);
-#endif
         }
         if constexpr (POOLK > 0 && !FIRST) {
             // finish the previous tile's pooling partial sums (its barrier is the ring barrier just passed);
             // one store per lane (idle lanes into the scratch page)
             const float* redp = red0 + ((it - 1) & 1) * RED;
             float s = 0.f;
-            const bool act = tid < C * NWX;
-            const int co = act ? tid / NWX : 0, wx = act ? tid - co * NWX : 0;
 #pragma unroll
-            for (int q = 0; q < K::NGY; ++q) s += redp[(q * C + co) * NWX + wx];
-            float* p = act ? a.pool_partial + (((size_t)prv.n * C + co) * a.tiles_y + prv.by) * (a.tiles_x * NWX) + prv.bx * NWX + wx
-                           : a.trash + lane * 2;
+            for (int q = 0; q < K::NGY; ++q) s += redp[(q * C + pf_co) * NWX + pf_wx];
+            // scalar part of the address per tile, lane part (pf_off) fixed for the block's life
+            float* pb = a.pool_partial + ((size_t)prv.n * C * a.tiles_y + prv.by) * (a.tiles_x * NWX) + prv.bx * NWX;
+            float* p = pf_act ? pb + pf_off : a.trash + lane * 2;
             *p = s;
         }
         float* red = red0 + (it & 1) * RED;
@@ -182,6 +181,12 @@ __global__ __launch_bounds__(WAVES * 64) void wino_kernel(EncConvArgs a) {
         float* dst = a.out + (size_t)n * C * hw;
         const float* gsrc = a.gate ? a.gate + (size_t)n * C * hw : nullptr;
 
+        // The tile's work comes in two forms: PIPE - the next tile lies inside the image, so its DMA pieces need no bounds test and are
+        // issued branch-free behind the k-steps; and the border form - the next tile's pieces (with their tests and branches) are
+        // requested up front and the k-loop carries none.  (The per-piece `have_next` / `interior` tests inside the k-loop cost a
+        // vector compare, a select and a branch per k-step.)
+        auto eloop = [&](auto pipe_tag) {
+        constexpr bool PIPE = decltype(pipe_tag)::value;
 #pragma unroll
         for (int e = 0; e < K::NGW; ++e) {
             const int ng = slot * K::NGW + e;
@@ -190,9 +195,13 @@ __global__ __launch_bounds__(WAVES * 64) void wino_kernel(EncConvArgs a) {
             // half-wave are two planes = 32 banks apart)
             const float* pl = tb + cperm(g) * K::PLANE + 2 * tr * K::ROWP + 2 * (xg * 16 + j) + 2;
 
+            // bias rides in the accumulators: with A^T = [[1,1,1,0],[0,1,-1,-1]] a constant b at position (0,0), -b at (0,3) and (3,0)
+            // and +b at (3,3) reaches each of the four outputs exactly once (saves the 16 bias adds of the output transform)
             f32x4 acc[16];
 #pragma unroll
             for (int p = 0; p < 16; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc[0][r] = biasv[r]; acc[3][r] = -biasv[r]; acc[12][r] = -biasv[r]; acc[15][r] = biasv[r]; }
 
             f32x2 dn[4][3];
             auto load_patch = [&](int s) {
@@ -218,27 +227,30 @@ __global__ __launch_bounds__(WAVES * 64) void wino_kernel(EncConvArgs a) {
                     t[2][b] = d[2][b] - d[1][b];
                     t[3][b] = d[1][b] - d[3][b];
                 }
+                // all 16 B operands of the k-step first, then the 16 MFMAs back to back: computed one MFMA ahead, every MFMA waited
+                // on its own operand's write (an s_nop in front of each: 48 per tile)
+                float v[16];
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
-                    const float v[4] = {t[x][0] - t[x][2], t[x][1] + t[x][2], t[x][2] - t[x][1], t[x][1] - t[x][3]};
-#pragma unroll
-                    for (int nu = 0; nu < 4; ++nu) {
-                        const int p = x * 4 + nu;
-                        const int q = s * 16 + p;
-                        acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[q >> 2][q & 3], v[nu], acc[p], 0, 0, 0);
-                    }
+                    v[x * 4 + 0] = t[x][0] - t[x][2]; v[x * 4 + 1] = t[x][1] + t[x][2];
+                    v[x * 4 + 2] = t[x][2] - t[x][1]; v[x * 4 + 3] = t[x][1] - t[x][3];
                 }
                 __builtin_amdgcn_sched_barrier(0);
-#ifndef EEM_DMA_AT_TOP
-                {   // this k-step's share of the next tile's DMA
-                    constexpr int STEPS = K::KS * K::NGW, PER = (K::NI + STEPS - 1) / STEPS;
-                    if (have_next) {
 #pragma unroll
-                        for (int q = 0; q < PER; ++q)
-                            if ((e * K::KS + s) * PER + q < K::NI) dma_piece(dnext, (e * K::KS + s) * PER + q);
-                    }
+                for (int p = 0; p < 16; ++p) {
+                    const int q = s * 16 + p;
+                    acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[q >> 2][q & 3], v[p], acc[p], 0, 0, 0);
                 }
-#endif
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (PIPE) {   // this k-step's share of the next tile's DMA
+                    constexpr int STEPS = K::KS * K::NGW, PER = (K::NI + STEPS - 1) / STEPS;
+#pragma unroll
+                    for (int q = 0; q < PER; ++q)
+                        if ((e * K::KS + s) * PER + q < K::NI) {
+                            const int k = (e * K::KS + s) * PER + q;
+                            __builtin_amdgcn_global_load_lds(GLB_PTR(dnext.src + poff[k]), LDS_PTR(dnext.sbase + (wave + k * WAVES) * 256), 16, 0, 0);
+                        }
+                }
             }
 
             STAMP16(3);
@@ -246,6 +258,8 @@ __global__ __launch_bounds__(WAVES * 64) void wino_kernel(EncConvArgs a) {
             const int oy = by * TH + 2 * tr, ox = bx * TW + 2 * (xg * 16 + j);
             const bool in0 = oy < a.hout && ox < a.wout, in1 = oy + 1 < a.hout && ox < a.wout;
             const int o0 = ((cog * 16 + g * 4) * a.hout + oy) * a.wout + ox;
+            const bool full = by * TH + TH <= a.hout && bx * TW + TW <= a.wout;       // wave-uniform
+            const unsigned lane_bo = (unsigned)o0 * 4u;
             float psum[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -255,8 +269,8 @@ __global__ __launch_bounds__(WAVES * 64) void wino_kernel(EncConvArgs a) {
                     u[x][0] = acc[x * 4 + 0][r] + acc[x * 4 + 1][r] + acc[x * 4 + 2][r];
                     u[x][1] = acc[x * 4 + 1][r] - acc[x * 4 + 2][r] - acc[x * 4 + 3][r];
                 }
-                float y00 = u[0][0] + u[1][0] + u[2][0] + biasv[r], y01 = u[0][1] + u[1][1] + u[2][1] + biasv[r];
-                float y10 = u[1][0] - u[2][0] - u[3][0] + biasv[r], y11 = u[1][1] - u[2][1] - u[3][1] + biasv[r];
+                float y00 = u[0][0] + u[1][0] + u[2][0], y01 = u[0][1] + u[1][1] + u[2][1];      // (bias: in the accumulators)
+                float y10 = u[1][0] - u[2][0] - u[3][0], y11 = u[1][1] - u[2][1] - u[3][1];
                 if (a.act) {
                     y00 = fmaxf(y00, 0.1f * y00); y01 = fmaxf(y01, 0.1f * y01);
                     y10 = fmaxf(y10, 0.1f * y10); y11 = fmaxf(y11, 0.1f * y11);
@@ -273,11 +287,19 @@ __global__ __launch_bounds__(WAVES * 64) void wino_kernel(EncConvArgs a) {
                     }
                 }
                 psum[r] = (y00 + y01) + (y10 + y11);
-                // every lane stores (outside lanes into a scratch page): exactly NSF stores per wave and tile
-                float* p0 = in0 ? dst + o : a.trash + lane * 2;
-                float* p1 = in1 ? dst + o + a.wout : a.trash + lane * 2;
-                *reinterpret_cast<f32x2*>(p0) = f32x2{y00, y01};
-                *reinterpret_cast<f32x2*>(p1) = f32x2{y10, y11};
+                if (full) {
+                    // tile inside the image (every tile at sizes that are multiples of the block tile): the address is a scalar base
+                    // per (cout register, row) + ONE 32-bit lane offset - no 64-bit vector arithmetic, no selects
+                    char* rb = reinterpret_cast<char*>(dst) + (size_t)r * hw * 4;
+                    *reinterpret_cast<f32x2*>(rb + lane_bo) = f32x2{y00, y01};
+                    *reinterpret_cast<f32x2*>(rb + (size_t)a.wout * 4 + lane_bo) = f32x2{y10, y11};
+                } else {
+                    // every lane stores (outside lanes into a scratch page): exactly NSF stores per wave and tile
+                    float* p0 = in0 ? dst + o : a.trash + lane * 2;
+                    float* p1 = in1 ? dst + o + a.wout : a.trash + lane * 2;
+                    *reinterpret_cast<f32x2*>(p0) = f32x2{y00, y01};
+                    *reinterpret_cast<f32x2*>(p1) = f32x2{y10, y11};
+                }
             }
             if constexpr (POOLK > 0) {
                 constexpr int SW = POOLK / 2;                   // tiles (lanes) per pooling window
@@ -288,6 +310,16 @@ __global__ __launch_bounds__(WAVES * 64) void wino_kernel(EncConvArgs a) {
                         red[(tr * C + cog * 16 + g * 4 + r) * NWX + xg * (32 / POOLK) + j / SW] = sred;
                 }
             }
+        }
+        };
+        if (have_next && dnext.interior) {
+            eloop(std::true_type{});
+        } else {
+            if (have_next) {
+#pragma unroll
+                for (int k = 0; k < K::NI; ++k) dma_piece(dnext, k);
+            }
+            eloop(std::false_type{});
         }
         STAMP16(4);
         // the pooling partial sums in `red` are finished after the next ring barrier (top of the next tile / after

@@ -20,6 +20,10 @@ import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+# The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, one of them the null stream's): the fourth
+# frame in flight then shares a queue with another and serialises behind it (5 700 frames/s with four streams against 6 350 with three;
+# with its own queue 6 670).  Read at the runtime's first call, so it is set before torch touches the device.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np   # noqa: E402
 import torch         # noqa: E402
@@ -43,7 +47,7 @@ def parse():
     p.add_argument("--mode", choices=("infer", "train"), default="infer",
                    help="infer (default): the headline metric; train: BASELINE configs[3] - EEMFlow training step, 1280x720, batch 8 per GPU, "
                         "data parallel with one RCCL all-reduce of the flat gradient per step (its time is reported as allreduce_us)")
-    p.add_argument("--streams", type=int, default=3,
+    p.add_argument("--streams", type=int, default=4,
                    help="frames in flight per GPU: independent contexts on separate HIP streams, steps alternate")
     return p.parse_args()
 
@@ -231,7 +235,7 @@ def other_rows(dev):
 def latency_and_pipeline_rows(L, _lib, dev, flat, B, H, W, e1, e2, use_graph):
     """Two rows beside the headline (not the metric): single-stream latency of one frame, and the evaluation loop of
     test_mvsec.py:580-597 as a device-resident pipeline with FRESH tensors every frame: events -> eemflow_voxelize x2 -> forward ->
-    eemflow_flow_error on three contexts / streams (the graph cache is keyed on shapes, so new buffers replay the same graph)."""
+    eemflow_flow_error on four contexts / streams (the graph cache is keyed on shapes, so new buffers replay the same graph)."""
     out = {}
     c = ctypes.c_void_p()
     _lib.check(L.eemflow_create(dev.index, ctypes.byref(c)))
@@ -261,7 +265,7 @@ def latency_and_pipeline_rows(L, _lib, dev, flat, B, H, W, e1, e2, use_graph):
     try:
         from eemflow_amd.hrem import synthetic_hrem_events
         from eemflow_amd.voxelizer import EventSequence
-        NS, nev = 3, 200000
+        NS, nev = 4, 200000
         evs = []
         for k in range(2):
             seq = EventSequence(None, {"height": H, "width": W}, features=synthetic_hrem_events(3 + k, nev, H, W),

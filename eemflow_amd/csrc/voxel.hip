@@ -20,8 +20,11 @@
 //                         with ds_add_f32 and written once (no memset of the grid).  For the normalisation the block also
 //                         leaves the f64 (count, sum, sum of squares) of its non-zero voxels;
 //   3. vox_norm_kernel    adds the band sums, mean / unbiased sd, rewrites the non-zero voxels.
-// HBM traffic: 32 B (event) + 2 x 16 B (record) per event + 4 B (normalised: up to 12 B) per voxel, instead of two
-// scattered read-modify-writes per event and three further passes over the grid.
+// With fewer than one event per 8 voxels (HREM's 2e5 events per 4.6 M-voxel volume) step 3 costs more than step 2, so the band
+// kernel runs twice instead: a moments-only launch, then a launch that accumulates the bands again and stores them already
+// normalised - the grid is written once and never read (43 -> 2x us per volume at 2e5 events).
+// HBM traffic: 32 B (event) + 2 x 16 B (record) per event + 4 B (normalised: up to 12 B, two band passes: 4 B + 16 B per event) per
+// voxel, instead of two scattered read-modify-writes per event and three further passes over the grid.
 // An event with x >= W lands in a neighbouring row exactly as the reference's flat index_add_ puts it; votes whose
 // flat pixel index x + y*W falls outside the image (the reference raises) are dropped on this path, the index
 // outputs still report them.
@@ -110,7 +113,8 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// exclusive prefix sum over the block's VT threads (sh: 16 words)
+// exclusive prefix sum over the block's NT threads (sh: NT / 64 words)
+template <int NT = 1024>
 __device__ __forceinline__ unsigned block_exscan(unsigned v, unsigned* sh) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned x = v;
@@ -123,7 +127,7 @@ __device__ __forceinline__ unsigned block_exscan(unsigned v, unsigned* sh) {
     __syncthreads();
     unsigned before = 0;
 #pragma unroll
-    for (int k = 0; k < VT / 64; ++k) before += k < wave ? sh[k] : 0u;
+    for (int k = 0; k < NT / 64; ++k) before += k < wave ? sh[k] : 0u;
     return before + x - v;
 }
 
@@ -224,23 +228,58 @@ __device__ __forceinline__ void vox_store_sums(double c, double s, double q, Vox
     }
 }
 
+// mean / unbiased sd of the non-zero voxels from the per-block slots: slots strided over the threads, wave sums, then every
+// thread adds the wave results in the same order (all NT threads of the block call this)
+struct VoxNorm {
+    float mean, sd;
+    bool any, scale;
+};
+
+template <int NT = 1024>
+__device__ __forceinline__ VoxNorm vox_final(const VoxSums* __restrict__ acc, int nsums, double* sh3) {
+    const int tid = threadIdx.x;
+    double c = 0.0, sm = 0.0, sq = 0.0;
+    for (int k = tid; k < nsums; k += NT) { c += acc[k].count; sm += acc[k].sum; sq += acc[k].sumsq; }
+    c = wave_sum(c);
+    sm = wave_sum(sm);
+    sq = wave_sum(sq);
+    if ((tid & 63) == 0) { sh3[(tid >> 6) * 3] = c; sh3[(tid >> 6) * 3 + 1] = sm; sh3[(tid >> 6) * 3 + 2] = sq; }
+    __syncthreads();
+    c = sm = sq = 0.0;
+#pragma unroll
+    for (int k = 0; k < NT / 64; ++k) { c += sh3[k * 3]; sm += sh3[k * 3 + 1]; sq += sh3[k * 3 + 2]; }
+    VoxNorm nm;
+    nm.any = c != 0.0;                                             // :529
+    double m2 = nm.any ? sq - sm * sm / c : 0.0;                   // sum (v - mean)^2
+    if (m2 < 0.0) m2 = 0.0;                                        // equal voxels: rounding only
+    nm.mean = nm.any ? (float)(sm / c) : 0.f;
+    nm.sd = (float)sqrt(m2 / (c - 1.0));                           // unbiased; NaN when c == 1
+    nm.scale = nm.sd > 0.f;                                        // :532 (false for NaN)
+    return nm;
+}
+
 // ------------------------------------------------------------------------------------------------ 3. bands in LDS
-__global__ __launch_bounds__(VT) void vox_band_kernel(const u32x4* __restrict__ recs, const unsigned* __restrict__ run_start,
+// what a band block does with its accumulated band: store it (and, with `acc`, leave its moments for vox_norm_kernel); leave the
+// moments only; or read every block's moments and store the band normalised (after a VOX_BAND_MOMENTS launch)
+enum { VOX_BAND_RAW = 0, VOX_BAND_MOMENTS = 1, VOX_BAND_NORMALISED = 2 };
+
+template <int BT>
+__global__ __launch_bounds__(BT) void vox_band_kernel(const u32x4* __restrict__ recs, const unsigned* __restrict__ run_start,
                                                       int nblk, int slab, int bins, VoxPlan pl, int vec4,
-                                                      float* __restrict__ grid, VoxSums* __restrict__ acc) {
+                                                      float* __restrict__ grid, VoxSums* __restrict__ acc, int mode) {
     extern __shared__ __attribute__((aligned(16))) float band[];   // [bins][band_px]
-    __shared__ double sh3[VT / 64 * 3];
-    __shared__ unsigned pre[VT + 1];                               // exclusive prefix of the run lengths of <= 1024 slabs
-    __shared__ unsigned first[VT];                                 // record index of each run's first vote
-    __shared__ unsigned shs[VT / 64];
+    __shared__ double sh3[BT / 64 * 3];
+    __shared__ unsigned pre[BT + 1];                               // exclusive prefix of the run lengths of <= BT slabs
+    __shared__ unsigned first[BT];                                 // record index of each run's first vote
+    __shared__ unsigned shs[BT / 64];
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     const int bpx = pl.band_px;
     const unsigned p0 = (unsigned)b * (unsigned)bpx;
     const int npx = min(bpx, (int)(pl.hw - p0));
     const int nfl = bins * bpx;
-    for (int i = tid * 4; i < nfl; i += VT * 4) *reinterpret_cast<f32x4*>(band + i) = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int g0 = 0; g0 < nblk; g0 += VT) {
+    for (int i = tid * 4; i < nfl; i += BT * 4) *reinterpret_cast<f32x4*>(band + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int g0 = 0; g0 < nblk; g0 += BT) {
         const int sidx = g0 + tid;
         unsigned len = 0, start = 0;
         if (sidx < nblk) {
@@ -250,14 +289,14 @@ __global__ __launch_bounds__(VT) void vox_band_kernel(const u32x4* __restrict__ 
             start += (unsigned)sidx * (unsigned)slab;
         }
         __syncthreads();                                           // LDS zeroed / previous group consumed
-        const unsigned ex = block_exscan(len, shs);
+        const unsigned ex = block_exscan<BT>(len, shs);
         pre[tid] = ex;
         first[tid] = start;
-        if (tid == VT - 1) pre[VT] = ex + len;
+        if (tid == BT - 1) pre[BT] = ex + len;
         __syncthreads();
-        const unsigned total = pre[VT];
-        const int nrun = min(VT, nblk - g0);
-        for (unsigned r = tid; r < total; r += VT) {
+        const unsigned total = pre[BT];
+        const int nrun = min(BT, nblk - g0);
+        for (unsigned r = tid; r < total; r += BT) {
             int lo = 0, hi = nrun;                                 // the run holding vote r: largest i with pre[i] <= r
             while (hi - lo > 1) {
                 const int mid = (lo + hi) >> 1;
@@ -271,22 +310,35 @@ __global__ __launch_bounds__(VT) void vox_band_kernel(const u32x4* __restrict__ 
         }
     }
     __syncthreads();
-    if (acc) {                                                     // before the stores: the barrier inside would wait for them
+    if (acc && mode != VOX_BAND_NORMALISED) {                      // before the stores: the barrier inside would wait for them
         double c = 0.0, sm = 0.0, q = 0.0;
         for (int bin = 0; bin < bins; ++bin)
-            for (int i = tid; i < npx; i += VT) {
+            for (int i = tid; i < npx; i += BT) {
                 const float v = band[bin * bpx + i];
                 if (v != 0.f) { c += 1.0; sm += (double)v; q += (double)v * (double)v; }
             }
         vox_store_sums(c, sm, q, acc + b, sh3);
     }
+    if (mode == VOX_BAND_MOMENTS) return;
+    float mean = 0.f, sd = 1.f;
+    bool scale = false, shift = false;
+    if (mode == VOX_BAND_NORMALISED) {
+        const VoxNorm nm = vox_final<BT>(acc, pl.nb, sh3);
+        mean = nm.mean; sd = nm.sd; scale = nm.scale; shift = nm.any;
+    }
+    auto fin = [&](float v) { return (shift && v != 0.f) ? (scale ? (v - mean) / sd : (v - mean)) : v; };
     for (int bin = 0; bin < bins; ++bin) {
         const float* src = band + bin * bpx;
         float* dst = grid + (size_t)bin * pl.hw + p0;
         if (vec4) {
-            for (int i = tid * 4; i < npx; i += VT * 4) *reinterpret_cast<f32x4*>(dst + i) = *reinterpret_cast<const f32x4*>(src + i);
+            for (int i = tid * 4; i < npx; i += BT * 4) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = fin(v[q]);
+                *reinterpret_cast<f32x4*>(dst + i) = v;
+            }
         } else {
-            for (int i = tid; i < npx; i += VT) dst[i] = src[i];
+            for (int i = tid; i < npx; i += BT) dst[i] = fin(src[i]);
         }
     }
 }
@@ -308,23 +360,10 @@ __global__ __launch_bounds__(VT) void vox_norm_kernel(float* __restrict__ grid, 
         for (int k = 0; k < NPRE; ++k)
             if (first + k * stride < n4) pre[k] = g4[first + k * stride];
     }
-    // one slot per thread (nsums <= VT), wave sums, then every thread adds the 16 wave results in the same order
-    double c = 0.0, sm = 0.0, sq = 0.0;
-    if (tid < nsums) { c = acc[tid].count; sm = acc[tid].sum; sq = acc[tid].sumsq; }
-    c = wave_sum(c);
-    sm = wave_sum(sm);
-    sq = wave_sum(sq);
-    if ((tid & 63) == 0) { sh3[(tid >> 6) * 3] = c; sh3[(tid >> 6) * 3 + 1] = sm; sh3[(tid >> 6) * 3 + 2] = sq; }
-    __syncthreads();
-    c = sm = sq = 0.0;
-#pragma unroll
-    for (int k = 0; k < VT / 64; ++k) { c += sh3[k * 3]; sm += sh3[k * 3 + 1]; sq += sh3[k * 3 + 2]; }
-    if (c == 0.0) return;                                          // :529
-    double m2 = sq - sm * sm / c;                                  // sum (v - mean)^2
-    if (m2 < 0.0) m2 = 0.0;                                        // equal voxels: rounding only
-    const float mean = (float)(sm / c);
-    const float sd = (float)sqrt(m2 / (c - 1.0));                  // unbiased; NaN when c == 1
-    const bool scale = sd > 0.f;                                   // :532 (false for NaN)
+    const VoxNorm nm = vox_final(acc, nsums, sh3);
+    if (!nm.any) return;                                           // :529
+    const float mean = nm.mean, sd = nm.sd;
+    const bool scale = nm.scale;
     if (vec) {
         auto apply = [&](f32x4 v, long i) {
             bool any = false;
@@ -381,7 +420,12 @@ bool make_plan(int64_t n, int bins, int h, int w, const double* events, VoxPlan*
     if (bins > 64 || vox_blocks(n, 8) > VOX_MAX_BLOCKS || hw >= (1L << 31) || ((uintptr_t)events & 15)) return false;
     const char* e = getenv("EEM_VOX_DIRECT");
     if (e && e[0] == '1') return false;
-    long band_px = (12288 / bins) & ~3L;                           // 48 KiB of LDS per band: 2-3 bands resident per CU
+    // 18 KiB of LDS per band and 256-thread blocks: a band block fits beside a resident encoder block of another stream (99-132 KiB of
+    // LDS, one wave per SIMD) instead of waiting for a whole CU, and ~1000 small blocks hide each other's latency chain (run table ->
+    // scan -> records -> LDS adds -> moments); EEM_VOX_BAND_FLOATS=12288 gives the former 48 KiB bands of 1024 threads
+    static const long band_floats = [] { const char* b = getenv("EEM_VOX_BAND_FLOATS"); const long v = b ? atol(b) : 0; return v >= 256 ? v : 4608L; }();
+    long band_px = (band_floats / bins) & ~3L;
+    if (band_px < 64) band_px = 64;
     const long spread = ((hw + 511) / 512 + 3) & ~3L;              // small images: still a few hundred bands
     if (band_px > spread) band_px = spread < 64 ? 64 : spread;
     if ((hw + band_px - 1) / band_px > VT - 1) band_px = ((hw + VT - 2) / (VT - 1) + 3) & ~3L;   // thread nb holds the record count
@@ -433,13 +477,30 @@ int voxel_launch(const double* events, int64_t n, int bins, int h, int w, int no
         if (lds > 64 * 1024 - 12 * 1024) {
             static thread_local int raised = 0;
             if (raised < lds) {
-                EEM_HIP_CHECK(hipFuncSetAttribute((const void*)vox_band_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                EEM_HIP_CHECK(hipFuncSetAttribute((const void*)vox_band_kernel<VT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
                 raised = lds;
             }
         }
         const int vec4 = (pl.band_px % 4 == 0 && pl.hw % 4 == 0 && ((uintptr_t)grid & 15) == 0) ? 1 : 0;
-        hipLaunchKernelGGL(vox_band_kernel, dim3(pl.nb), dim3(VT), lds, stream, recs, run_start, (int)nblk, VT * ept, bins, pl, vec4,
-                           grid, normalize ? sc->acc : (VoxSums*)nullptr);
+        // Few events per voxel: accumulating the bands twice (16 B per vote from L2 / HBM each time) is cheaper than the normalisation's
+        // read + write of the whole grid - a moments-only launch, then a launch that stores the bands already normalised
+        const char* tp = getenv("EEM_VOX_TWOPASS");                  // read per call: the tests run both forms in one process
+        const long two_pass_ratio = tp ? atol(tp) : 0L;
+        auto band = [&](VoxSums* acc, int mode) {
+            if (lds <= 24 * 1024)
+                hipLaunchKernelGGL(vox_band_kernel<256>, dim3(pl.nb), dim3(256), lds, stream, recs, run_start, (int)nblk, VT * ept, bins, pl, vec4,
+                                   grid, acc, mode);
+            else
+                hipLaunchKernelGGL(vox_band_kernel<VT>, dim3(pl.nb), dim3(VT), lds, stream, recs, run_start, (int)nblk, VT * ept, bins, pl, vec4,
+                                   grid, acc, mode);
+        };
+        if (normalize && two_pass_ratio > 0 && (long)n * two_pass_ratio <= total) {
+            band(sc->acc, (int)VOX_BAND_MOMENTS);
+            band(sc->acc, (int)VOX_BAND_NORMALISED);
+            EEM_HIP_CHECK(hipGetLastError());
+            return EEM_OK;
+        }
+        band(normalize ? sc->acc : (VoxSums*)nullptr, (int)VOX_BAND_RAW);
         nsums = pl.nb;
     } else {
         EEM_HIP_CHECK(hipMemsetAsync(grid, 0, total * sizeof(float), stream));

@@ -320,13 +320,17 @@ def test_voxelizer_binned_path_equals_direct_path_and_oracle(monkeypatch, h, w, 
     seq = EventSequence(None, {"height": h, "width": w}, features=ev.copy(), timestamp_multiplier=1e6,
                         convert_to_relative=True)
     out = {}
-    for mode in ("binned", "direct"):
+    for mode in ("binned", "binned_two_band_passes", "binned_norm_pass", "direct"):
         if mode == "direct":
             monkeypatch.setenv("EEM_VOX_DIRECT", "1")
+        # normalisation: by default two band passes for sparse volumes, else a pass over the grid; both forced here on every case
+        monkeypatch.setenv("EEM_VOX_TWOPASS", {"binned_two_band_passes": "1", "binned_norm_pass": "0"}.get(mode, "8"))
         raw, il, ir = EventSequenceToVoxelGrid_Pytorch(bins, gpu=True, normalize=False, forkserver=False)(seq, True)
         norm = EventSequenceToVoxelGrid_Pytorch(bins, gpu=True, normalize=True, forkserver=False)(seq)
         out[mode] = (raw.cpu().numpy(), il.cpu().numpy(), ir.cpu().numpy(), norm.cpu().numpy())
     b, d = out["binned"], out["direct"]
+    for other in ("binned_two_band_passes", "binned_norm_pass"):
+        np.testing.assert_allclose(out[other][3], b[3], atol=3e-5, rtol=1e-5)
     assert np.array_equal(b[1], d[1]) and np.array_equal(b[2], d[2])
     il_ref, _, ir_ref, _ = O.voxel_indices(seq.features, bins, h, w)
     assert np.array_equal(b[1][b[1] >= 0], il_ref) and np.array_equal(b[2][b[2] >= 0], ir_ref)

@@ -47,6 +47,9 @@ def parse():
     p.add_argument("--mode", choices=("infer", "train"), default="infer",
                    help="infer (default): the headline metric; train: BASELINE configs[3] - EEMFlow training step, 1280x720, batch 8 per GPU, "
                         "data parallel with one RCCL all-reduce of the flat gradient per step (its time is reported as allreduce_us)")
+    p.add_argument("--frames-in-flight", type=int, default=0,
+                   help="eemflow_set_frames_in_flight hint for the contexts (default: --streams); the profiles use --streams 1 "
+                        "--frames-in-flight 4 to trace the timed loop's launch configuration one kernel at a time")
     p.add_argument("--streams", type=int, default=4,
                    help="frames in flight per GPU: independent contexts on separate HIP streams, steps alternate")
     return p.parse_args()
@@ -280,6 +283,7 @@ def latency_and_pipeline_rows(L, _lib, dev, flat, B, H, W, e1, e2, use_graph):
             _lib.check(L.eemflow_load_weights(cc, flat.data_ptr(), flat.numel(), 5, 5))
             _lib.check(L.eemflow_set_image_size(cc, H, W, None))
             _lib.check(L.eemflow_use_graph(cc, 1 if use_graph else 0))
+            _lib.check(L.eemflow_set_frames_in_flight(cc, NS))
             ctxs.append(cc)
             streams.append(torch.cuda.Stream(device=dev))
         keep = []
@@ -447,6 +451,7 @@ def main():
         _lib.check(L.eemflow_load_weights(c, flat.data_ptr(), flat.numel(), 5, 5))
         _lib.check(L.eemflow_set_image_size(c, H, W, None))
         _lib.check(L.eemflow_use_graph(c, 0 if args.no_graph else 1))
+        _lib.check(L.eemflow_set_frames_in_flight(c, args.frames_in_flight or NS))
         ctxs.append(c)
         streams.append(torch.cuda.Stream(device=dev))
         flows.append(torch.empty(B, 2, H, W, device=dev))
@@ -480,37 +485,56 @@ def main():
     value, slowest = parallel.aggregate_throughput(args.steps * B, elapsed, dev)
 
     if rank == 0:
-        # ---- per-kernel roofline, measured live with HIP events on the launch stream
-        stats = (_lib.KernelStat * 64)()
-        n = ctypes.c_int(0)
-        _lib.check(L.eemflow_time_kernels(ctx, e1.data_ptr(), e2.data_ptr(), B, H, W, flow.data_ptr(), H, W,
-                                          args.kernel_reps, stats, 64, ctypes.byref(n), sp))
-        torch.cuda.synchronize(dev)
-        kernels = []
-        for i in range(n.value):
-            k = stats[i]
-            sec = k.ms * 1e-3
-            ai = k.flops / max(k.bytes, 1.0)
-            bound = "mfma" if ai >= PEAK_MFMA_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9) else "hbm"
-            kernels.append({"name": k.name.decode(), "us": round(k.ms * 1e3, 2), "gflop": round(k.flops / 1e9, 4),
-                            "mbytes": round(k.bytes / 1e6, 3), "bound": bound,
-                            "tflops": round(k.flops / sec / 1e12, 2), "gbs": round(k.bytes / sec / 1e9, 1)})
-        dom = max(kernels, key=lambda k: k["us"])
-        if dom["bound"] == "mfma":
-            roof = {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(dom["tflops"] / PEAK_MFMA_F32_TFLOPS, 4)}
-        else:
-            roof = {"bound": "hbm", "achieved": dom["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(dom["gbs"] / PEAK_HBM_GBS, 4)}
-        tr_all = load_traffic() or {}
-        same_shape = tr_all.get("_workload", {"height": 720, "width": 1280, "batch": 1}) == {"height": H, "width": W, "batch": B}
-        traffic = tr_all.get(dom["name"]) if same_shape else None        # PMC passes of another shape say nothing here
-        # HBM bytes per launch of the dominant kernel from the PMC passes (profiles/pmc_traffic.json, tools/profile_gpu.sh)
-        roof["traffic"] = traffic["hbm_bytes"] if isinstance(traffic, dict) and "hbm_bytes" in traffic else None
-        roof["traffic_detail"] = traffic
-        roof["algorithmic_bytes"] = round(dom["mbytes"] * 1e6)
-        roof["kernel"] = dom["name"]
-        roof["kernel_us"] = dom["us"]
+        # ---- per-kernel roofline, measured live with HIP events on the launch stream, in the launch configuration of the timed loop
+        # (frames_in_flight = streams: persistent encoder kernels on fewer blocks) and in the single-frame configuration (full grids)
+        def kernel_table(frames_in_flight):
+            _lib.check(L.eemflow_set_frames_in_flight(ctx, frames_in_flight))
+            stats = (_lib.KernelStat * 64)()
+            n = ctypes.c_int(0)
+            _lib.check(L.eemflow_time_kernels(ctx, e1.data_ptr(), e2.data_ptr(), B, H, W, flow.data_ptr(), H, W,
+                                              args.kernel_reps, stats, 64, ctypes.byref(n), sp))
+            torch.cuda.synchronize(dev)
+            table = []
+            for i in range(n.value):
+                k = stats[i]
+                sec = k.ms * 1e-3
+                ai = k.flops / max(k.bytes, 1.0)
+                bound = "mfma" if ai >= PEAK_MFMA_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9) else "hbm"
+                table.append({"name": k.name.decode(), "us": round(k.ms * 1e3, 2), "gflop": round(k.flops / 1e9, 4),
+                              "mbytes": round(k.bytes / 1e6, 3), "bound": bound,
+                              "tflops": round(k.flops / sec / 1e12, 2), "gbs": round(k.bytes / sec / 1e9, 1)})
+            return table
+
+        def roofline_of(table):
+            dom = max(table, key=lambda k: k["us"])
+            if dom["bound"] == "mfma":
+                r = {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(dom["tflops"] / PEAK_MFMA_F32_TFLOPS, 4)}
+            else:
+                r = {"bound": "hbm", "achieved": dom["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": round(dom["gbs"] / PEAK_HBM_GBS, 4)}
+            tr_all = load_traffic() or {}
+            same_shape = tr_all.get("_workload", {"height": 720, "width": 1280, "batch": 1}) == {"height": H, "width": W, "batch": B}
+            traffic = tr_all.get(dom["name"]) if same_shape else None        # PMC passes of another shape say nothing here
+            # HBM bytes per launch of the dominant kernel from the PMC passes (profiles/pmc_traffic.json, tools/profile_gpu.sh)
+            r["traffic"] = traffic["hbm_bytes"] if isinstance(traffic, dict) and "hbm_bytes" in traffic else None
+            r["traffic_detail"] = traffic
+            r["algorithmic_bytes"] = round(dom["mbytes"] * 1e6)
+            r["kernel"] = dom["name"]
+            r["kernel_us"] = dom["us"]
+            return r
+
+        fif = args.frames_in_flight or NS
+        kernels = kernel_table(fif)
+        roof = roofline_of(kernels)
+        roof["frames_in_flight"] = fif
+        roof_single = None
+        if fif >= 3:
+            single = kernel_table(1)
+            roof_single = roofline_of(single)
+            roof_single["frames_in_flight"] = 1
+            roof_single["kernels_us"] = {k["name"].split()[0]: k["us"] for k in single}
+            _lib.check(L.eemflow_set_frames_in_flight(ctx, fif))
         sum_us = sum(k["us"] for k in kernels)
         enc = [k for k in kernels if k["name"].startswith("enc.")]
         enc_tflops = sum(k["gflop"] for k in enc) / max(sum(k["us"] for k in enc), 1e-9) * 1e3
@@ -543,7 +567,7 @@ def main():
                                    "synthetic 20%-dense voxel pairs resident in HBM, seeded Kaiming weights",
                        "height": H, "width": W, "batch_per_gpu": B, "hip_graph": not args.no_graph, "streams_per_gpu": NS,
                        "parallelism": f"replicas x{world}: frames sharded over ranks, no data-path collective"},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_single_frame_launch": roof_single, "cpu_baseline": cpu,
             "gpu_ms_per_step_hip_events": round(gpu_ms / args.steps, 4),
             "schedule_sum_us": round(sum_us, 1), "frame_gflop": round(total_gflop, 3),
             "frame_tflops": round(total_gflop * B / ms_per_step, 2),

@@ -268,6 +268,13 @@ extern "C" int eemflow_use_graph(eemflow_ctx* c, int enable) {
     return EEM_OK;
 }
 
+extern "C" int eemflow_set_frames_in_flight(eemflow_ctx* c, int n) {
+    EEM_REQUIRE(c && n >= 1, "eemflow_set_frames_in_flight: need a context and n >= 1");
+    if ((c->frames_in_flight >= 3) != (n >= 3)) drop_graph(c);       // the cached graphs hold the other grid sizes
+    c->frames_in_flight = n;
+    return EEM_OK;
+}
+
 extern "C" int eemflow_forward(eemflow_ctx* c, const float* e1, const float* e2, int batch, int in_h, int in_w,
                                float* out, int out_h, int out_w, void* stream) {
     EEM_REQUIRE(c && e1 && e2 && out, "eemflow_forward: NULL argument");

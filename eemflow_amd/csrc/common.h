@@ -1,6 +1,8 @@
 // Shared declarations for the EEMFlow MI355X (gfx950) hot-path library.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -83,6 +85,16 @@ __device__ static __forceinline__ float lane_group_sum(float v) {
 // [x*cpx, (x+1)*cpx) and its resident blocks split that range evenly.  Consecutive tiles of a block are
 // neighbours in x, so the coordinates advance without integer divisions - the CU's single scalar unit is shared
 // by all its waves, and three divisions per tile and wave were ~20 % of a tile's time in the Winograd kernels.
+// Persistent encoder kernels launch one block per CU (32 per XCD) by default; EEM_ENC_PER_XCD_<tag> (or EEM_ENC_PER_XCD) lowers the cap:
+// fewer, longer blocks amortise the per-block prologue when several frames share the chip.
+static inline int enc_blocks_per_xcd(const char* tag, int dflt) {
+    char name[48];
+    snprintf(name, sizeof name, "EEM_ENC_PER_XCD_%s", tag);
+    const char* e = getenv(name);
+    if (!e) e = getenv("EEM_ENC_PER_XCD");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : dflt;
+}
 struct TileCoord { int bx, by, n; };
 struct TileRange { int first, count; };
 __device__ static inline TileRange block_tile_range(int T, unsigned bid, unsigned nblocks) {
@@ -147,6 +159,9 @@ struct EncConvArgs {
     // ENC_1_1 inside a cached HIP graph: device table {events1, events2, flow_out}; when non-NULL the kernel reads in0 / in1
     // from it instead of from the fields above, so the graph does not depend on the caller's buffers (api.hip)
     const void* const* io;
+    // persistent kernels: blocks per XCD (0 = one per CU).  The context lowers it when the application keeps several frames in flight
+    // (eemflow_set_frames_in_flight): fewer, longer blocks spend less CU time on per-block prologues
+    int blocks_per_xcd = 0;
 };
 int enc_conv_launch(int cin, int cout, int stride, const EncConvArgs& a, hipStream_t stream);
 // first layer with 16-byte LDS-DMA staging (conv_enc1.hip): raw width % 4 == 0, no horizontal padding

@@ -185,7 +185,9 @@ int enc1_launch(const EncConvArgs& a0, hipStream_t stream) {
     a.tiles_y = ceil_div(a.hout, TH);
     const int T = a.tiles_x * a.tiles_y * a.nimg;
     int per_xcd = ceil_div(T, 8);
-    if (per_xcd > 32) per_xcd = 32;                       // one resident block per CU
+    static const int env_cap = enc_blocks_per_xcd("E1", 0);     // tuning override
+    const int cap = env_cap > 0 ? env_cap : (a.blocks_per_xcd > 0 ? a.blocks_per_xcd : 32);   // default: one resident block per CU
+    if (per_xcd > cap) per_xcd = cap;
     hipLaunchKernelGGL((enc1_kernel<TH, TWT, WAVES>), dim3(per_xcd * 8), dim3(WAVES * 64), 0, stream, a);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;

@@ -513,7 +513,8 @@ int launch3(const EncConvArgs& a0, hipStream_t stream) {
     constexpr int BY_LDS = (160 * 1024) / LDS_BYTES, BY_WAVES = 32 / WAVES;
     constexpr int RES = BY_LDS < BY_WAVES ? (BY_LDS < 1 ? 1 : BY_LDS) : BY_WAVES;   // resident blocks per CU
     int per_xcd = ceil_div(T, 8);
-    if (per_xcd > 32 * RES) per_xcd = 32 * RES;
+    static const int cap = enc_blocks_per_xcd(COUT == 32 ? "P32" : (COUT == 64 ? "P64" : "P"), 32 * RES);
+    if (per_xcd > cap) per_xcd = cap;
     if (a.pool_partial != nullptr && !(POOLK > 0 && a.pool_k == POOLK)) {
         eem_set_error("enc_conv3: fused pooling with k=%d is not built for this layer", a.pool_k);
         return EEM_ERR_ARG;

@@ -415,7 +415,9 @@ int wino_launch_c(const EncConvArgs& a0, hipStream_t stream) {
     a.tiles_y = ceil_div(a.hout, W::TH);
     const int T = a.tiles_x * a.tiles_y * a.nimg;
     int per_xcd = ceil_div(T, 8);
-    if (per_xcd > 32) per_xcd = 32;                       // one resident block per CU
+    static const int env_cap = enc_blocks_per_xcd("W16", 0);     // tuning override
+    const int cap = env_cap > 0 ? env_cap : (a.blocks_per_xcd > 0 ? a.blocks_per_xcd : 32);   // default: one resident block per CU
+    if (per_xcd > cap) per_xcd = cap;
     if (a.pool_partial != nullptr && a.pool_k != W::POOLK) {
         eem_set_error("wino: fused pooling with k=%d is not built for C=%d", a.pool_k, C);
         return EEM_ERR_ARG;

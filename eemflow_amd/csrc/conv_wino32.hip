@@ -32,23 +32,28 @@ struct W32Cfg {
     static constexpr int ROWP = TW + 8;
     static constexpr int PPR = ROWP / 4;
     static constexpr int PLANE = IN_ROWS * ROWP;
-    static constexpr int PIECES = C * IN_ROWS * PPR;
-    static constexpr int NB = (PIECES + 63) / 64;
+    static constexpr int PC = IN_ROWS * PPR;             // 16-byte pieces per channel
+    // One DMA instruction of the whole block (WAVES x 64 lanes) moves CPI whole channels; lane slot = wave * 64 + lane always holds
+    // the same (channel-in-group, tile row, piece) - instruction k only adds k * CPI channels to the address, so a tile's DMA costs
+    // one decomposition + 2 VALU per instruction instead of a decomposition and a bounds test per piece (~200 -> ~45 VALU per wave
+    // and tile, which the matrix pipe pays for: f32 MFMA and VALU issue add up on gfx950).  Slots >= CPI * PC are padding.
+    static constexpr int SLOTS_I = WAVES * 64;
+    static constexpr int CPI = (SLOTS_I / PC) & ~1;      // even: the two channels of a k-step share an instruction
+    static constexpr int NI = C / CPI;
     static constexpr int XCH = WAVES * 64 * 32;          // exchange floats (lives in the finished stage)
-    static constexpr int NI0 = (NB + WAVES - 1) / WAVES;
-    static constexpr int NI = NI0 * WAVES * 256 >= XCH ? NI0 : (XCH + WAVES * 256 - 1) / (WAVES * 256);
     static constexpr int STAGE = NI * WAVES * 256;
-    // tile 0 of a block starts its k-loop before the whole tile has landed: DMA wave-instruction k of every wave
-    // (pieces [k*64*WAVES, (k+1)*64*WAVES), channel-major) must have landed before k-step s reads channels 2s, 2s+1
-    static constexpr int PC = IN_ROWS * PPR;             // pieces per channel
+    static constexpr int chan_off(int c) { return ((c / CPI) * SLOTS_I + (c % CPI) * PC) * 4; }   // floats from the stage base
+    // tile 0 of a block starts its k-loop before the whole tile has landed: DMA instruction k of every wave (channels
+    // [k * CPI, (k + 1) * CPI)) must have landed before k-step s reads channels 2s, 2s+1
     static constexpr int kq(int s) {
-        int need = ((2 * s + 2) * PC + 64 * WAVES - 1) / (64 * WAVES) - 1;
+        int need = (2 * s + 1) / CPI;
         need |= 1;                                       // sync points after instructions 1, 3, 5, ...
         return need < NI ? need : NI - 1;
     }
+    static_assert(CPI >= 2 && C % CPI == 0 && STAGE >= XCH, "channel groups per DMA instruction");
     static_assert(WAVES % TEAM == 0 && NGX * NGY == SLOTS, "one tile group per wave and block tile");
     static_assert(TW % NGW == 0 && TH % (2 * NGH) == 0, "block tile");
-    static_assert((2 * (KS - 1) + 1) * PLANE * 4 + 3 * ROWP * 4 + 64 < 65536, "ds_read immediate range");
+    static_assert((chan_off(C - 2) + PLANE) * 4 + 3 * ROWP * 4 + 64 < 65536, "ds_read immediate range");
 };
 
 #ifdef EEM_STAMPS
@@ -92,27 +97,26 @@ __global__ __launch_bounds__(WAVES * 64) void wino32_kernel(EncConvArgs a) {
     TileCoord cur = tile_coord(tr_.first, a.tiles_x, a.tiles_y), nxt = cur;      // tile being computed / next to request
     const float* zero_page = a.zero_page;
 
-    // ---- DMA: wave-instruction k of a wave always moves the same piece (channel c, tile row ry, 16-byte column
-    // q) per lane; the decomposition is recomputed per tile (a dozen VALU per piece) rather than kept in registers -
-    // the k-loop needs every VGPR it can get
+    // ---- DMA: see W32Cfg - lane slot = (channel-in-group cl, tile row ry, 16-byte column q) for every instruction
     auto issue = [&](int it, const TileCoord& tc) {
         const int bx = tc.bx, by = tc.by, n = tc.n;
         const int gy0 = by * TH - 1, gxa = bx * TW - 4;
-        const float* src = a.in0 + (size_t)n * C * a.hin * a.win + (gy0 * a.win + gxa);
+        const int slot = wave * 64 + lane;
+        const int cl = slot / K::PC;
+        const int rem = slot - cl * K::PC;
+        const int ry = rem / K::PPR;
+        const int q = rem - ry * K::PPR;
+        const int gy = gy0 + ry, gx = gxa + q * 4;
+        const bool ok = cl < K::CPI && gy >= 0 && gy < a.hin && gx >= 0 && gx < a.win;
+        const int plane = a.hin * a.win;
+        const char* gp = ok ? reinterpret_cast<const char*>(a.in0 + (size_t)n * C * plane + (gy0 * a.win + gxa) + ((cl * a.hin + ry) * a.win + q * 4))
+                            : reinterpret_cast<const char*>(zero_page);
+        const unsigned step = ok ? (unsigned)(K::CPI * plane) * 4u : 0u;     // bytes to the same piece of the next channel group
         float* sbase = lds + (it & 1) * K::STAGE;
-        const bool interior = gy0 >= 0 && gy0 + K::IN_ROWS <= a.hin && gxa >= 0 && gxa + K::ROWP <= a.win;
 #pragma unroll
         for (int k = 0; k < K::NI; ++k) {
-            int p = (wave + k * WAVES) * 64 + lane;
-            p = p < K::PIECES ? p : K::PIECES - 1;                       // padding lanes re-copy the last piece
-            const int c = p / (K::IN_ROWS * K::PPR);
-            const int rem = p - c * (K::IN_ROWS * K::PPR);
-            const int ry = rem / K::PPR;
-            const int q = rem - ry * K::PPR;
-            const int gy = gy0 + ry, gx = gxa + q * 4;
-            const bool ok = interior || (gy >= 0 && gy < a.hin && gx >= 0 && gx < a.win);
-            const float* gp = ok ? src + ((c * a.hin + ry) * a.win + q * 4) : zero_page;
             __builtin_amdgcn_global_load_lds(GLB_PTR(gp), LDS_PTR(sbase + (wave + k * WAVES) * 256), 16, 0, 0);
+            gp += step;
         }
     };
 
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(WAVES * 64) void wino32_kernel(EncConvArgs a) {
 
         f32x2 na[3], nb[3];
         auto load_patch = [&](int s) {
-            const int off = 2 * s * K::PLANE;
+            const int off = K::chan_off(2 * s);
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 na[q] = *reinterpret_cast<const f32x2*>(pa + off + 2 * q);
@@ -232,6 +236,8 @@ __global__ __launch_bounds__(WAVES * 64) void wino32_kernel(EncConvArgs a) {
         float* dst = a.out + (size_t)n * C * hw;
         const float* gsrc = a.gate ? a.gate + (size_t)n * C * hw : nullptr;
         const int o0 = (co0 * a.hout + oy) * a.wout + ox;
+        const bool full = by * TH + TH <= a.hout && bx * TW + TW <= a.wout;         // wave-uniform
+        const unsigned lane_bo = (unsigned)o0 * 4u;
         float psum[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -254,11 +260,19 @@ __global__ __launch_bounds__(WAVES * 64) void wino32_kernel(EncConvArgs a) {
                 }
             }
             psum[r] = (y00 + y01) + (y10 + y11);
-            // every lane stores (outside lanes into a scratch page): exactly 8 stores per wave and tile
-            float* p0 = in0 ? dst + o : a.trash + lane * 2;
-            float* p1 = in1 ? dst + o + a.wout : a.trash + lane * 2;
-            *reinterpret_cast<f32x2*>(p0) = f32x2{y00, y01};
-            *reinterpret_cast<f32x2*>(p1) = f32x2{y10, y11};
+            if (full) {
+                // tile inside the image: a scalar base per (cout register, row) + ONE 32-bit lane offset - no 64-bit vector
+                // arithmetic, no selects
+                char* rb = reinterpret_cast<char*>(dst) + (size_t)r * hw * 4;
+                *reinterpret_cast<f32x2*>(rb + lane_bo) = f32x2{y00, y01};
+                *reinterpret_cast<f32x2*>(rb + (size_t)a.wout * 4 + lane_bo) = f32x2{y10, y11};
+            } else {
+                // every lane stores (outside lanes into a scratch page): exactly 8 stores per wave and tile
+                float* p0 = in0 ? dst + o : a.trash + lane * 2;
+                float* p1 = in1 ? dst + o + a.wout : a.trash + lane * 2;
+                *reinterpret_cast<f32x2*>(p0) = f32x2{y00, y01};
+                *reinterpret_cast<f32x2*>(p1) = f32x2{y10, y11};
+            }
         }
         if constexpr (POOLK > 0) {
             constexpr int SW = POOLK / 2;
@@ -347,7 +361,9 @@ int launch_c(const EncConvArgs& a0, hipStream_t stream) {
     a.tiles_y = ceil_div(a.hout, W::TH);
     const int T = a.tiles_x * a.tiles_y * a.nimg;
     int per_xcd = ceil_div(T, 8);
-    if (per_xcd > 32) per_xcd = 32;
+    static const int env_cap = enc_blocks_per_xcd(C == 32 ? "W32" : "W64", 0);     // tuning override
+    const int cap = env_cap > 0 ? env_cap : (a.blocks_per_xcd > 0 ? a.blocks_per_xcd : 32);   // default: one resident block per CU
+    if (per_xcd > cap) per_xcd = cap;
     if (a.pool_partial != nullptr && a.pool_k != W::POOLK) {
         eem_set_error("wino32: fused pooling with k=%d is not built for C=%d", a.pool_k, C);
         return EEM_ERR_ARG;

@@ -133,6 +133,7 @@ class EEMFlow(nn.Module):
         self._weights_version = None
         self._layout_loaded = False
         self.use_graph = True
+        self.frames_in_flight = 1       # >= 3: this module is one of several replicas kept busy on separate streams (throughput over latency)
 
     # ------------------------------------------------------------------ reference interface
     def change_imagesize(self, img_size):
@@ -215,6 +216,7 @@ class EEMFlow(nn.Module):
         _lib.check(L.eemflow_set_image_size(self._ctx, int(self.image_size[0]), int(self.image_size[1]), ctypes.byref(pad)))
         assert list(pad) == self.image_padder._pad
         _lib.check(L.eemflow_use_graph(self._ctx, 1 if self.use_graph else 0))
+        _lib.check(L.eemflow_set_frames_in_flight(self._ctx, max(1, int(self.frames_in_flight))))
         return self._ctx
 
     def stage(self, name):

@@ -62,6 +62,13 @@ int eemflow_set_image_size(eemflow_ctx* ctx, int height, int width, int pad_out[
  * evaluation loop, test_mvsec.py:580-597) replay the same graph.  Up to four shapes stay cached (least recently used out). */
 int eemflow_use_graph(eemflow_ctx* ctx, int enable);
 
+/* Throughput hint: the application keeps `n` frames in flight on this GPU (one context and one HIP stream each, e.g. the
+ * evaluation loop of test_mvsec.py:580-597 pipelined over several samples).  With n >= 3 the persistent encoder kernels
+ * launch fewer, longer blocks - the frames time-slice the CUs and per-block prologues are CU time another frame could use
+ * (1280x720, four in flight: +3.5 % frames/s, +8 % latency of a single frame).  Default 1: lowest single-frame latency.
+ * Give the process enough hardware queues for its streams (GPU_MAX_HW_QUEUES). */
+int eemflow_set_frames_in_flight(eemflow_ctx* ctx, int n);
+
 /* Graph-cache statistics: out3 = {captures, replays, io-table rewrites}. */
 int eemflow_graph_stats(eemflow_ctx* ctx, long long out3[3]);
 

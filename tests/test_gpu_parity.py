@@ -121,6 +121,23 @@ def test_graph_equals_eager_and_is_repeatable():
     assert torch.equal(outs[0], outs[1])
 
 
+def test_frames_in_flight_hint_changes_grids_not_results():
+    """eemflow_set_frames_in_flight >= 3 launches the persistent encoder kernels on fewer blocks (more tiles each): the same tiles, the
+    same arithmetic - the flow is bitwise the same, at the headline size (960 tiles on 160 / 192 / 232 blocks) and at a ragged one."""
+    for (h, w, seed) in ((720, 1280, 51), (260, 346, 52)):
+        e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(seed, 1, h, w))
+        net, _ = make_net(43)
+        net.change_imagesize((h, w))
+        outs = []
+        for n in (1, 4, 1):
+            net.frames_in_flight = n
+            with torch.no_grad():
+                outs.append(net(e1, e2)[1][0].clone())
+                outs.append(net(e1, e2)[1][0].clone())        # replay of the graph captured for this setting
+        assert all(torch.equal(outs[0], o) for o in outs[1:])
+        assert graph_stats(net)[0] == 3                       # the hint flipped twice: the cached graph was dropped each time
+
+
 def graph_stats(net):
     gs = (ctypes.c_longlong * 3)()
     _lib.check(_lib.lib().eemflow_graph_stats(net._ctx, ctypes.byref(gs)))

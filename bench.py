@@ -42,6 +42,7 @@ def parse():
     p.add_argument("--width", type=int, default=1280)
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
     p.add_argument("--kernel-reps", type=int, default=20)
+    p.add_argument("--preheat", type=int, default=200, help="untimed forwards before the warm-up steps (GPU clocks, graph-launch paths)")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-other-rows", action="store_true", help="skip the E-RAFT / training-step side timings")
     p.add_argument("--mode", choices=("infer", "train"), default="infer",
@@ -460,11 +461,24 @@ def main():
     sps = [ctypes.c_void_p(st.cuda_stream) for st in streams]
     counter = [0]
 
+    stagger = float(os.environ.get("EEM_BENCH_STAGGER_US", "0")) * 1e-6      # experiment: host pause between the first NS launches
+
     def step():
         i = counter[0] % NS
+        if stagger > 0 and 0 < counter[0] < NS:
+            t_end = time.perf_counter() + stagger
+            while time.perf_counter() < t_end:
+                pass
         counter[0] += 1
         _lib.check(L.eemflow_forward(ctxs[i], e1.data_ptr(), e2.data_ptr(), B, H, W, flows[i].data_ptr(), H, W, sps[i]))
 
+    # Clock / runtime pre-heat (untimed, reported as "preheat_steps"): the contexts have just been built on an idle GPU, and the first
+    # milliseconds after that run at ramping clocks with cold graph-launch paths (20 timed steps after 5 warm-up steps read 6 % lower than
+    # after 100).  Then the W warm-up steps the caller asked for, then the timed region.
+    for _ in range(args.preheat):
+        step()
+    torch.cuda.synchronize(dev)
+    counter[0] = 0
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
@@ -565,7 +579,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"EEMFlow inference, HREM {W}x{H} dt1, batch={B} per GPU (BASELINE configs[1]); "
                                    "synthetic 20%-dense voxel pairs resident in HBM, seeded Kaiming weights",
-                       "height": H, "width": W, "batch_per_gpu": B, "hip_graph": not args.no_graph, "streams_per_gpu": NS,
+                       "height": H, "width": W, "batch_per_gpu": B, "hip_graph": not args.no_graph, "streams_per_gpu": NS, "preheat_steps": args.preheat,
                        "parallelism": f"replicas x{world}: frames sharded over ranks, no data-path collective"},
             "roofline": roof, "roofline_single_frame_launch": roof_single, "cpu_baseline": cpu,
             "gpu_ms_per_step_hip_events": round(gpu_ms / args.steps, 4),

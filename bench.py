@@ -45,6 +45,9 @@ def parse():
     p.add_argument("--preheat", type=int, default=200, help="untimed forwards before the warm-up steps (GPU clocks, graph-launch paths)")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-other-rows", action="store_true", help="skip the E-RAFT / training-step side timings")
+    p.add_argument("--no-side-rows", action="store_true",
+                   help="only the timed loop and the per-kernel table of its launch configuration (the rocprofv3 runs: their kernel "
+                        "averages then belong to one configuration)")
     p.add_argument("--mode", choices=("infer", "train"), default="infer",
                    help="infer (default): the headline metric; train: BASELINE configs[3] - EEMFlow training step, 1280x720, batch 8 per GPU, "
                         "data parallel with one RCCL all-reduce of the flat gradient per step (its time is reported as allreduce_us)")
@@ -543,7 +546,7 @@ def main():
         roof = roofline_of(kernels)
         roof["frames_in_flight"] = fif
         roof_single = None
-        if fif >= 3:
+        if fif >= 3 and not args.no_side_rows:
             single = kernel_table(1)
             roof_single = roofline_of(single)
             roof_single["frames_in_flight"] = 1
@@ -588,7 +591,7 @@ def main():
             "encoder_tflops_in_kernel": round(enc_tflops, 2),
             "kernels": kernels, **extra,
         }
-        if world == 1:
+        if world == 1 and not args.no_side_rows:
             rows = latency_and_pipeline_rows(L, _lib, dev, flat, B, H, W, e1, e2, not args.no_graph)
             line["latency_ms_b1"] = rows.pop("latency_ms_b1")
             line["latency_and_pipeline"] = rows

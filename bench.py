@@ -23,7 +23,7 @@ sys.path.insert(0, REPO)
 # The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, one of them the null stream's): the fourth
 # frame in flight then shares a queue with another and serialises behind it (5 700 frames/s with four streams against 6 350 with three;
 # with its own queue 6 670).  Read at the runtime's first call, so it is set before torch touches the device.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 import numpy as np   # noqa: E402
 import torch         # noqa: E402
@@ -140,7 +140,31 @@ def other_rows(dev):
                 net(e1, e2, iters=12)
             torch.cuda.synchronize(dev)
         out["eraft_640x480_12it_b4_frames_per_s"] = round(12 / (time.perf_counter() - t0), 2)
-        del net
+        # several frames in flight (one module / context per HIP stream): at batch 1 the 60x80 update block launches ~300 blocks for
+        # 256 CUs - a second and third frame fill the chip
+        nets = [net]
+        sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+        for _ in range(3):
+            m = ERAFT("", 5).eval()
+            m.load_state_dict(sd)
+            m = m.to(dev)
+            m.change_imagesize((480, 640))
+            nets.append(m)
+        streams = [torch.cuda.Stream(device=dev) for _ in nets]
+        for key, batch, ns in (("eraft_640x480_12it_b1_4_in_flight_frames_per_s", 1, 4), ("eraft_640x480_12it_b4_3_in_flight_frames_per_s", 4, 3)):
+            e1, e2 = (torch.from_numpy(a).to(dev) for a in synthetic_voxel_pair(1, batch, 480, 640))
+            torch.cuda.synchronize(dev)
+            with torch.no_grad():
+                for phase, n in (("warm", ns), ("timed", 4 * ns)):
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    for i in range(n):
+                        with torch.cuda.stream(streams[i % ns]):
+                            nets[i % ns](e1, e2, iters=12)
+                    torch.cuda.synchronize(dev)
+                    dt = time.perf_counter() - t0
+            out[key] = round(4 * ns * batch / dt, 2)
+        del nets, net
     except Exception as e:                                   # noqa: BLE001
         out["eraft_error"] = repr(e)[:200]
     try:
@@ -161,7 +185,26 @@ def other_rows(dev):
                 net(e1, e2)
             torch.cuda.synchronize(dev)
         out["eemflow_plus_1280x720_b1_frames_per_s"] = round(5 / (time.perf_counter() - t0), 2)
-        del net
+        nets = [net]
+        sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+        for _ in range(3):                                   # four frames in flight: ~160 short launches per frame leave CUs idle
+            m = EEMFlow_cdc("", 3, 5).eval()
+            m.load_state_dict(sd)
+            m = m.to(dev)
+            m.change_imagesize((720, 1280))
+            nets.append(m)
+        streams = [torch.cuda.Stream(device=dev) for _ in nets]
+        with torch.no_grad():
+            for phase, n in (("warm", 4), ("timed", 24)):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for i in range(n):
+                    with torch.cuda.stream(streams[i % 4]):
+                        nets[i % 4](e1, e2)
+                torch.cuda.synchronize(dev)
+                dt = time.perf_counter() - t0
+        out["eemflow_plus_1280x720_b1_4_in_flight_frames_per_s"] = round(24 / dt, 2)
+        del nets, net
     except Exception as e:                                   # noqa: BLE001
         out["eemflow_plus_error"] = repr(e)[:200]
     try:

@@ -7,7 +7,7 @@ import os as _os
 # Frames are kept in flight on separate HIP streams (one context per stream).  The runtime gives a process GPU_MAX_HW_QUEUES hardware
 # queues (default 4, the null stream included) and streams that share one serialise, so a fourth stream loses throughput instead of adding
 # it; the variable is read at the runtime's first call.  A value the user exported wins.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 from .eemflow import EEMFlow            # noqa: F401
 from .padder import InputPadder         # noqa: F401

@@ -71,6 +71,12 @@ extern "C" void eemflow_destroy(eemflow_ctx* c) {
     if (c->taps) (void)hipFree(c->taps);
     if (c->zero_page) (void)hipFree(c->zero_page);
     if (c->io_table) (void)hipFree(c->io_table);
+    if (c->wstream) {
+        (void)hipStreamSynchronize(c->wstream);
+        (void)hipStreamDestroy(c->wstream);
+        for (hipEvent_t e : c->wev) if (e) (void)hipEventDestroy(e);
+        if (c->wjoin) (void)hipEventDestroy(c->wjoin);
+    }
     delete c;
 }
 

@@ -86,6 +86,13 @@ struct eemflow_ctx {
     const float *train_e1 = nullptr, *train_e2 = nullptr;
     bool have_train_fwd = false;
     long train_serial = 0;
+    // backward pass: weight / bias gradients are leaves of the chain of data gradients, so they run on this context-owned side stream
+    // (fork: an event after the gradient they read; join: the caller's stream waits for the last one before backward returns)
+    hipStream_t wstream = nullptr;
+    static constexpr int kWEvents = 32;
+    hipEvent_t wev[kWEvents] = {};
+    hipEvent_t wjoin = nullptr;
+    int wev_next = 0;
     int* taps = nullptr;
     // workspaces
     DevBuf a1, f11, a2, b2, f12, a3, b3, f13, pool[3], ppart[3], cat[3], ta[3], tb[3], tc[3], td[3], t64[3], t32[3], flowcat, coarse;

@@ -14,6 +14,22 @@ struct Bwd {
     eemflow_ctx* c;
     hipStream_t st;
     float* grad;           // flat gradient buffer
+    hipStream_t wst;       // stream of the weight / bias gradient launches (the context's side stream, or st)
+
+    // the side stream picks up after everything queued on st so far (the gradient a weight-gradient launch reads is complete)
+    int fork() {
+        if (wst == st) return EEM_OK;
+        hipEvent_t e = c->wev[c->wev_next++ % eemflow_ctx::kWEvents];
+        EEM_HIP_CHECK(hipEventRecord(e, st));
+        EEM_HIP_CHECK(hipStreamWaitEvent(wst, e, 0));
+        return EEM_OK;
+    }
+    int join() {
+        if (wst == st) return EEM_OK;
+        EEM_HIP_CHECK(hipEventRecord(c->wjoin, wst));
+        EEM_HIP_CHECK(hipStreamWaitEvent(st, c->wjoin, 0));
+        return EEM_OK;
+    }
 
     // data gradient of a conv layer through gconv: dX = convT(dY * act'(Y), W)
     int dgrad(const ConvRef& r, const float* dy, const float* y_gate, int g_ctotal, int g_coff, int g_cmul, int n, int hout,
@@ -62,8 +78,9 @@ struct Bwd {
     }
     int flush_wgrads() {
         if (nwq == 0) return EEM_OK;
-        int rc = tr_wgrad_launch_batch(wq, nwq, st);
-        if (rc == EEM_OK) rc = tr_bias_grad_launch_batch(bq, nwq, st);
+        int rc = fork();
+        if (rc == EEM_OK) rc = tr_wgrad_launch_batch(wq, nwq, wst);
+        if (rc == EEM_OK) rc = tr_bias_grad_launch_batch(bq, nwq, wst);
         nwq = 0;
         return rc;
     }
@@ -76,10 +93,12 @@ struct Bwd {
         w.dw = grad + r.w;
         w.n = n; w.hin = hin; w.win = win; w.hout = hout; w.wout = wout; w.k = r.k; w.stride = r.stride; w.pad = r.k == 3 ? 1 : 0;
         w.zero_page = c->zero_page; w.db = grad + r.b;
-        if (wgrad_enc_supported(w)) return wgrad_enc_launch(w, st);          // weight and bias gradient in one kernel
-        int rc = tr_wgrad_launch(w, st);
+        int rc = fork();
         if (rc != EEM_OK) return rc;
-        return tr_bias_grad_launch(dy, y_gate, g_ctotal, g_coff, g_cmul, r.cout, n, hout * wout, grad + r.b, st);
+        if (wgrad_enc_supported(w)) return wgrad_enc_launch(w, wst);         // weight and bias gradient in one kernel
+        rc = tr_wgrad_launch(w, wst);
+        if (rc != EEM_OK) return rc;
+        return tr_bias_grad_launch(dy, y_gate, g_ctotal, g_coff, g_cmul, r.cout, n, hout * wout, grad + r.b, wst);
     }
 };
 
@@ -111,12 +130,33 @@ int alloc_train(eemflow_ctx* c, const Shape& s) {
 // Backward pass of the LAST eager forward of this context (its activations are still in the workspace): dflow
 // [B][2][out_h][out_w] -> flat gradient (state_dict order).  e1 / e2 are that forward's inputs (pconv1_1's weight
 // gradient reads them through the replicate pad).
+static int backward_chain(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2, const float* dflow, float* grad_out,
+                          hipStream_t st, Bwd& bw);
+
 static int backward_impl(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2, const float* dflow, float* grad_out,
                          hipStream_t st) {
+    // EEM_NO_WGRAD_STREAM=1 (read per call: the tests run both forms) keeps every launch on the caller's stream
+    const char* off = getenv("EEM_NO_WGRAD_STREAM");
+    hipStream_t wst = st;
+    if (!(off && off[0] == '1')) {
+        if (!c->wstream) {
+            EEM_HIP_CHECK(hipStreamCreateWithFlags(&c->wstream, hipStreamNonBlocking));
+            for (hipEvent_t& e : c->wev) EEM_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            EEM_HIP_CHECK(hipEventCreateWithFlags(&c->wjoin, hipEventDisableTiming));
+        }
+        wst = c->wstream;
+    }
+    Bwd bw{c, st, grad_out, wst};
+    const int rc = backward_chain(c, s, e1, e2, dflow, grad_out, st, bw);
+    const int rj = bw.join();                        // also after an error: nothing of this pass stays behind on the side stream
+    return rc != EEM_OK ? rc : rj;
+}
+
+static int backward_chain(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2, const float* dflow, float* grad_out,
+                          hipStream_t st, Bwd& bw) {
     int rc;
     const int B = s.batch, n2 = 2 * s.batch, in_h = s.in_h, in_w = s.in_w;
     const size_t g = (size_t)s.gh * s.gw;
-    Bwd bw{c, st, grad_out};
     EEM_HIP_CHECK(hipMemsetAsync(grad_out, 0, c->nflat * sizeof(float), st));
     // ---- upsample backward (EEMFlow.py:118-120)
     if ((rc = tr_upsample_bwd_launch(dflow, c->ups_tmp.p, c->g_coarse.p, B * 2, s.out_h, s.out_w, s.gh, s.gw, st)) != EEM_OK) return rc;

@@ -82,6 +82,32 @@ def test_gradients_vs_oracle_autograd(b, h, w, size):
         assert errs[0][1].rsplit(".", 1)[0] == errs[1][1].rsplit(".", 1)[0], errs[:2]
 
 
+def test_weight_gradients_on_the_side_stream_equal_the_single_stream_pass(monkeypatch):
+    """Weight / bias gradients run on a context-owned side stream behind events (they are leaves of the data-gradient chain);
+    EEM_NO_WGRAD_STREAM=1 keeps them on the caller's stream.  Same gradients (summation order of the split-K atomics aside), repeated
+    steps included: the next forward must not overwrite an activation a pending weight-gradient launch still reads."""
+    b, h, w = 4, 260, 346
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(61, b, h, w))
+    gt, valid = (torch.from_numpy(a) for a in synthetic_gt(62, b, h, w))
+    out = {}
+    for mode in ("side", "single"):
+        monkeypatch.setenv("EEM_NO_WGRAD_STREAM", "1" if mode == "single" else "0")
+        net, sd = make_net(63)
+        net.change_imagesize((h, w))
+        tr = EEMFlowTrainer(net, lr=0.0, wdecay=0.0, clip=0.0)
+        grads = []
+        with torch.cuda.stream(torch.cuda.Stream()):                  # a caller stream other than the default one
+            for _ in range(3):
+                loss, _, flow = tr.step(e1.to(DEV), e2.to(DEV), gt.to(DEV), valid.to(DEV))
+                grads.append(tr.grad.clone())
+            torch.cuda.current_stream().synchronize()
+        out[mode] = (loss, flow.cpu(), [g.cpu() for g in grads])
+    assert out["side"][0] == out["single"][0] and torch.equal(out["side"][1], out["single"][1])
+    ref = out["single"][2][0]
+    for g in out["side"][2] + out["single"][2][1:]:
+        assert float((g - ref).abs().max() / ref.abs().max()) < 2e-5
+
+
 @pytest.mark.parametrize("b,h,w", [(2, 260, 346), (1, 720, 1280), (3, 200, 300)])
 def test_dedicated_backward_kernels_equal_generic_ones(monkeypatch, b, h, w):
     """wgrad_enc / dgrad_s2 / wgrad_small against the generic conv and weight-gradient kernels of the same library

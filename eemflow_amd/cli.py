@@ -115,9 +115,9 @@ def train(args):
         os.makedirs(save_path, exist_ok=True)
         print('Storing output in folder {}'.format(save_path))
         json.dump(config, open(os.path.join(save_path, 'config.json'), 'w'), indent=4, sort_keys=False)
-    start_epoch = 0
+    start_epoch, start_iteration = 0, 0
     if args.start_epoch:
-        start_epoch = harness.load_checkpoint(os.path.join(save_path, 'lasted_ckpt.pth.tar'), model)
+        start_epoch, start_iteration = harness.load_checkpoint(os.path.join(save_path, 'lasted_ckpt.pth.tar'), model, with_iteration=True)
     logger = harness.Logger(os.path.join(save_path, 'train.log') if rank == 0 else None, verbose=rank == 0)
     dev = torch.device(args.device)
     torch.cuda.set_device(dev)
@@ -134,7 +134,8 @@ def train(args):
     # The reference trainer sizes the padder with config['train_img_size'] (train_mvsec.py:67), the size its augmentor crops to.  The
     # HREM training samples here are the un-cropped frames, so the padder is sized from the first batch itself (image_size=None).
     tr = harness.TrainRaftEvents(loader, None, lr=tcfg["lr"], wdecay=tcfg["wdecay"], epsilon=tcfg["epsilon"],
-                                 num_steps=tcfg["num_steps"], clip=tcfg["clip"], gamma=tcfg["gamma"], logger=logger)
+                                 num_steps=tcfg["num_steps"], clip=tcfg["clip"], gamma=tcfg["gamma"], logger=logger,
+                                 start_iteration=start_iteration)
     for epoch in range(start_epoch, max(args.train_iters // args.val_iters, 1)):
         if sampler is not None:
             sampler.set_epoch(epoch)

@@ -44,11 +44,14 @@ class Logger:
             sys.stdout.flush()
 
 
-def load_checkpoint(path, model, map_location="cpu"):
-    """Load {'epoch', 'state_dict'}; 'module.' prefixes of nn.DataParallel checkpoints are stripped. Returns the epoch."""
+def load_checkpoint(path, model, map_location="cpu", with_iteration=False):
+    """Load {'epoch', 'state_dict'}; 'module.' prefixes of nn.DataParallel checkpoints are stripped. Returns the epoch, or with
+    with_iteration=True (epoch, iteration): the schedule position save_checkpoint stores (0 for the reference's own checkpoints)."""
     states = torch.load(path, map_location=map_location, weights_only=False)
     sd = collections.OrderedDict((k.replace('module.', ''), v) for k, v in states['state_dict'].items())
     model.load_state_dict(sd)
+    if with_iteration:
+        return states.get('epoch', 0), int(states.get('iteration', 0))
     return states.get('epoch', 0)
 
 
@@ -138,7 +141,7 @@ class TrainRaftEvents:
     """Training loop of train_mvsec.py:229-286 (one process per GPU; batches are this rank's shard)."""
 
     def __init__(self, loader, image_size, lr=1e-4, wdecay=5e-5, epsilon=1e-8, num_steps=1000000, clip=1.0, gamma=0.8,
-                 logger=None, print_freq=100, engine="fused", mixed_precision=True):
+                 logger=None, print_freq=100, engine="fused", mixed_precision=True, start_iteration=0):
         if engine not in ("fused", "autograd"):
             raise ValueError("engine must be 'fused' or 'autograd'")
         self.loader, self.image_size = loader, image_size
@@ -148,7 +151,7 @@ class TrainRaftEvents:
         self.engine, self.mixed_precision = engine, mixed_precision
         self.trainer = None
         self.optimizer = self.scheduler = self.scaler = None
-        self.iteration = 0
+        self.iteration = int(start_iteration)                   # resume: the OneCycle schedule continues where the checkpoint stopped
 
     def fetch_optimizer(self, model):
         """train_mvsec.py:178-183."""
@@ -165,6 +168,12 @@ class TrainRaftEvents:
         if self.optimizer is None:
             self.fetch_optimizer(model)
             self.scaler = torch.amp.GradScaler("cuda", enabled=self.mixed_precision)
+            if self.iteration:
+                import warnings
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")             # "scheduler.step() before optimizer.step()": positions only
+                    for _ in range(self.iteration):
+                        self.scheduler.step()
         done = 0
         for batch in self.loader:
             self.optimizer.zero_grad()
@@ -208,6 +217,7 @@ class TrainRaftEvents:
             return self._train_iters_autograd(model, start_epoch, val_iters)
         if self.trainer is None:
             self.trainer = EEMFlowTrainer(model, **self.opt)
+            self.trainer.iteration = self.iteration
         done = 0
         for batch in self.loader:
             e1 = batch['event_volume_old'].to(dev).float()

@@ -135,6 +135,39 @@ def test_checkpoint_layout_round_trip(tmp_path):
     assert load_checkpoint(p, b) == 7
     for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
         assert ka == kb and torch.equal(va, vb)
+    assert load_checkpoint(p, b, with_iteration=True) == (7, 0)          # the reference's layout: no schedule position
+
+    class Position:                                                       # what save_checkpoint needs of a trainer
+        iteration = 1234
+
+        def sync_parameters(self):
+            pass
+    save_checkpoint(p, a, epoch=8, trainer=Position())
+    assert load_checkpoint(p, b, with_iteration=True) == (8, 1234)
+
+
+def test_resumed_trainer_continues_the_one_cycle_schedule():
+    """TrainRaftEvents(start_iteration=n): the autograd engine's OneCycleLR stands where n steps would have left it, the fused engine's
+    schedule is indexed by trainer.iteration (train_mvsec.py:178-183; the reference restarts the warm-up on resume)."""
+    import torch
+    from eemflow_amd.harness import TrainRaftEvents
+    from eemflow_amd.train import OneCycleLinear as OneCycle
+    n, lr, steps = 300, 4e-4, 1000
+    lin = torch.nn.Linear(2, 2)
+    ref_opt = torch.optim.AdamW(lin.parameters(), lr=lr)
+    ref = torch.optim.lr_scheduler.OneCycleLR(ref_opt, lr, steps + 100, pct_start=0.05, cycle_momentum=False, anneal_strategy='linear')
+    for _ in range(n):
+        ref_opt.step()
+        ref.step()
+    tr = TrainRaftEvents(loader=[], image_size=(8, 8), lr=lr, num_steps=steps, engine="autograd", start_iteration=n)
+    tr.fetch_optimizer(lin)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(tr.iteration):
+            tr.scheduler.step()
+    assert abs(tr.optimizer.param_groups[0]["lr"] - ref_opt.param_groups[0]["lr"]) < 1e-12
+    assert abs(OneCycle(lr, steps + 100).lr(n) - ref_opt.param_groups[0]["lr"]) < 1e-9
 
 
 def test_cli_flags_match_reference_scripts():

@@ -6,6 +6,7 @@ gradients - and every node's arithmetic, forward and backward, runs in libeemflo
 slicing of gradients), nothing else: no ATen compute op is on the path.  CUDA (ROCm) tensors only; there is no CPU path.
 """
 import ctypes
+import os
 
 import torch
 
@@ -44,6 +45,20 @@ def _binary(kind, a, b=None, alpha=1.0):
     with torch.cuda.device(a.device):
         _lib.check(_lib.lib().eemop_binary(kind, a.data_ptr(), _ptr(b), float(alpha), a.numel(), out.data_ptr(), _sp(a)))
     return out
+
+
+_side_streams = {}
+
+
+def _wgrad_stream(device):
+    """Side stream of the weight-gradient launches (a leaf of the backward chain: it runs beside the data gradient of the same layer
+    and is joined before backward() returns); None with EEM_NO_WGRAD_STREAM=1."""
+    if os.environ.get("EEM_NO_WGRAD_STREAM", "0") == "1":
+        return None
+    key = (device.type, device.index)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
 
 
 class Conv2d(torch.autograd.Function):
@@ -90,14 +105,26 @@ class Conv2d(torch.autograd.Function):
         dxs = [None] * len(xs)
         with torch.cuda.device(w.device):
             s = _sp(w)
+            joined = None
             if need[0] or (has_b and need[1]):
                 dw = torch.zeros_like(w)
                 db = torch.zeros(cout, device=w.device) if has_b else None
+                side = _wgrad_stream(w.device) if any(need[6:]) else None
+                sw = s
+                if side is not None:                                       # fork: dpre and the zeroed buffers are complete
+                    cur = torch.cuda.current_stream(w.device)
+                    fork = torch.cuda.Event()
+                    fork.record(cur)
+                    side.wait_event(fork)
+                    sw = ctypes.c_void_p(side.cuda_stream)
                 c0 = 0
                 for i, x in enumerate(xs):
                     _lib.check(L.eemop_conv2d_bwd_weight(x.data_ptr(), dpre.data_ptr(), n, hin, win, cin, c0, cs[i], cout, kh, kw, stride, ph, pw,
-                                                         dw.data_ptr(), _ptr(db) if i == 0 else None, s))
+                                                         dw.data_ptr(), _ptr(db) if i == 0 else None, sw))
                     c0 += cs[i]
+                if side is not None:
+                    joined = torch.cuda.Event()
+                    joined.record(side)
             c0 = 0
             for i, x in enumerate(xs):
                 if need[6 + i]:
@@ -106,6 +133,8 @@ class Conv2d(torch.autograd.Function):
                                                        dx.data_ptr(), s))
                     dxs[i] = dx
                 c0 += cs[i]
+            if joined is not None:                                         # join before autograd hands dw / db on
+                torch.cuda.current_stream(w.device).wait_event(joined)
         return (dw if need[0] else None, db if (has_b and need[1]) else None, None, None, None, None, *dxs)
 
 

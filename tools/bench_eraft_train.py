@@ -33,7 +33,8 @@ n = 3
 t0 = time.perf_counter()
 for _ in range(n):
     loss = step()
+host = (time.perf_counter() - t0) / n
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
 print(f"E-RAFT training step {w}x{h} b{b} {iters} iterations: {dt * 1e3:.1f} ms/step = {b / dt:.2f} samples/s, loss {float(loss):.4f}, "
-      f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB")
+      f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB, host enqueue {host * 1e3:.1f} ms/step")

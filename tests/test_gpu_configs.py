@@ -128,6 +128,26 @@ def test_c5_eraft_640x480_12_iterations_batch4_vs_oracle():
     assert float(ref[-1].abs().max()) > 0.05                             # not a degenerate zero flow
 
 
+def test_eraft_1280x720_resident_volume_vs_oracle():
+    """SURVEY Appendix B's case for on-the-fly correlation: HREM's 1280x720 through E-RAFT is a 90x160 grid, a 14 400 x 14 400 all-pairs
+    volume of 829 MB (+ 3 pooled levels) per pair.  It stays resident in the 288 GB of HBM (nothing is recomputed
+    per lookup); two refinement iterations against the oracle at the flow tolerance."""
+    b, h, w, iters = 1, 720, 1280, 2
+    net = ERAFT("", 5).eval()
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sdn = seeded_from_shapes(shapes, 141)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sdn.items()})
+    net = net.to(DEV)
+    sd = O.to_torch_sd(sdn)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(142, b, h, w))
+    with torch.no_grad():
+        preds = net(e1.to(DEV), e2.to(DEV), iters=iters)[1]
+        ref, _ = R.eraft_forward(sd, e1, e2, iters=iters)
+    errs = [float((p.cpu() - r).abs().max()) for p, r in zip(preds, ref)]
+    assert preds[0].shape == (b, 2, h, w) and max(errs) < 1e-3, errs
+
+
 @pytest.mark.parametrize("b,h,w", [(4, 260, 346), (2, 720, 1280)])
 def test_dp_equivalence_two_shards_one_gpu(b, h, w):
     """Rank r of a 2-rank job holds samples [r*b/2, (r+1)*b/2).  parallel.average_gradients computes (g0 + g1) / 2 (SUM all-reduce,

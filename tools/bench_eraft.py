@@ -8,7 +8,9 @@ from eemflow_amd.eraft_weights import seeded_from_shapes
 from eemflow_amd.weights import synthetic_voxel_pair
 
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-h, w, iters = 480, 640, 12
+h = int(sys.argv[2]) if len(sys.argv) > 2 else 480
+w = int(sys.argv[3]) if len(sys.argv) > 3 else 640
+iters = 12
 net = ERAFT("", 5).eval()
 sd = seeded_from_shapes({k: tuple(v.shape) for k, v in net.state_dict().items()}, 0)
 net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
@@ -20,4 +22,4 @@ with torch.no_grad():
     n = 5
     for _ in range(n): net(e1, e2, iters=iters)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-print(f"E-RAFT {w}x{h} iters={iters} batch={b}: {dt*1e3:.2f} ms/forward, {b/dt:.2f} frames/s, {499.2*b/dt/1e3:.1f} TFLOP/s")
+print(f"E-RAFT {w}x{h} iters={iters} batch={b}: {dt*1e3:.2f} ms/forward, {b/dt:.2f} frames/s, {499.2*b*(h*w)/(480*640)/dt/1e3:.1f} TFLOP/s (conv FLOPs scaled from 640x480; the all-pairs GEMM grows quadratically)")

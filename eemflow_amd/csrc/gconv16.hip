@@ -45,6 +45,23 @@ struct G16Cfg {
     static_assert(PL % 4 == 0 && PL % 32 == 16, "plane pitch");
 };
 
+// base address of input chunk `ch` (16 channels) of an input that is the concatenation of up to three tensors
+__device__ __forceinline__ const char* g16_chunk_base(int ch, const char* sp0, const char* sp1, const char* sp2, int sc0, int sc1, int hw) {
+    const int c0 = ch * 16, c1 = c0 - sc0, c2 = c1 - sc1;
+    const char* b = c0 < sc0 ? sp0 : (c1 < sc1 ? sp1 : sp2);
+    const int c = c0 < sc0 ? c0 : (c1 < sc1 ? c1 : c2);
+    return b + (size_t)c * hw * 4;
+}
+
+template <class C, int NI>
+__device__ __forceinline__ void g16_issue(float* sb, const char* xb, const int (&off)[NI], const char* zero, int wave) {
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const char* p = off[k] >= 0 ? xb + off[k] : zero;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(p), LDS_PTR(sb + (wave + 4 * k) * 256), 16, 0, 0);
+    }
+}
+
 template <int KH, int KW, int THT, int WM>
 __global__ __launch_bounds__(256, (KH * KW == 9 && THT == 4 && WM == 4) ? 3 : 4) void gconv16_kernel(GConvArgs a, const float* __restrict__ wpk16, const float* __restrict__ zero_page,
                                                       int tiles_x, int nchunks) {
@@ -77,35 +94,22 @@ __global__ __launch_bounds__(256, (KH * KW == 9 && THT == 4 && WM == 4) ? 3 : 4)
         off[k] = in ? (int)(((size_t)ci * hw + (size_t)gy * a.win + gx) * 4) : -1;
     }
     const char* zero = reinterpret_cast<const char*>(zero_page);
-    // chunk index -> (segment, first channel); the three descriptors are held in scalar registers (a dynamic index into the
-    // kernel arguments is a scalar load + wait in front of every chunk's DMA)
-    const char* sp[3];
-    int sc[3];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        const bool on = s < a.nseg;
-        sc[s] = on ? a.seg[s].c : 0;
-        sp[s] = on ? reinterpret_cast<const char*>(a.seg[s].ptr + ((size_t)n * a.seg[s].ctotal + a.seg[s].coff) * hw) : nullptr;
-    }
-    auto chunk_base = [&](int ch) -> const char* {
-        int c0 = ch * 16;
-        if (c0 < sc[0]) return sp[0] + (size_t)c0 * hw * 4;
-        c0 -= sc[0];
-        if (c0 < sc[1]) return sp[1] + (size_t)c0 * hw * 4;
-        c0 -= sc[1];
-        return sp[2] + (size_t)c0 * hw * 4;
-    };
-    auto issue = [&](int stage, int ch) {
-        const char* xb = chunk_base(ch);
-        float* sb = lds + stage * C::STAGE;
-#pragma unroll
-        for (int k = 0; k < C::NI; ++k) {
-            const char* p = off[k] >= 0 ? xb + off[k] : zero;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(p), LDS_PTR(sb + (wave + 4 * k) * 256), 16, 0, 0);
-        }
+    // chunk index -> (segment, first channel).  The three descriptors are separate scalars on purpose: as arrays the compiler turned
+    // the chain of selects into an indexed read of a private (scratch) copy - a scratch load and an `s_waitcnt vmcnt(0)` in front of
+    // every chunk's DMA (kernel arguments indexed dynamically were a scalar load + wait in the same place)
+#define G16_SEG_PTR(S) (reinterpret_cast<const char*>(a.seg[S].ptr + ((size_t)n * a.seg[S].ctotal + a.seg[S].coff) * hw))
+    const char* const sp0 = G16_SEG_PTR(0);
+    const char* const sp1 = a.nseg > 1 ? G16_SEG_PTR(1) : nullptr;
+    const char* const sp2 = a.nseg > 2 ? G16_SEG_PTR(2) : nullptr;
+#undef G16_SEG_PTR
+    const int sc0 = a.seg[0].c, sc1 = a.nseg > 1 ? a.seg[1].c : 0;
+    // (free functions with by-value scalars, not lambdas: a closure that another closure captures stays in memory across the loop's
+    // `memory`-clobbering waits, and its fields were re-read from scratch in front of every chunk's DMA)
+    auto issue = [=](int stage, int ch) __attribute__((always_inline)) {
+        g16_issue<C>(lds + stage * C::STAGE, g16_chunk_base(ch, sp0, sp1, sp2, sc0, sc1, hw), off, zero, wave);
     };
     // weight fragments of chunk `ch` for this wave's M-tile: stream[((cc * nchunks + ch) * KS + ks) * 4 + wave][lane]
-    auto load_w = [&](int ch, float (&wr)[C::KS]) {
+    auto load_w = [&](int ch, float (&wr)[C::KS]) __attribute__((always_inline)) {
         const float* wp = wpk16 + (((size_t)cc * nchunks + ch) * C::KS * 4 + mt) * 64 + lane;
 #pragma unroll
         for (int ks = 0; ks < C::KS; ++ks) wr[ks] = wp[(size_t)ks * 256];
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(256, (KH * KW == 9 && THT == 4 && WM == 4) ? 3 : 4)
     float wA[C::KS], wB[C::KS];
     issue(0, 0);
     load_w(0, wA);
-    auto compute = [&](const float* sb, const float (&wr)[C::KS]) {
+    auto compute = [&](const float* sb, const float (&wr)[C::KS]) __attribute__((always_inline)) {
 #pragma unroll
         for (int ky = 0; ky < KH; ++ky)
 #pragma unroll
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(256, (KH * KW == 9 && THT == 4 && WM == 4) ? 3 : 4)
     // After the explicit wait the fragments of the current chunk have landed; passing them through an empty asm tells the
     // compiler so - otherwise it guards their first use with its own s_waitcnt vmcnt(0), which also waits for the NEXT chunk's
     // loads issued just above it and serialises the whole prefetch.
-    auto landed = [&](float (&wr)[C::KS]) {
+    auto landed = [&](float (&wr)[C::KS]) __attribute__((always_inline)) {
 #pragma unroll
         for (int ks = 0; ks < C::KS; ++ks) asm volatile("" : "+v"(wr[ks]));
     };

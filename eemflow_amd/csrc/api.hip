@@ -471,29 +471,35 @@ extern "C" int eemflow_upsample_bilinear(const float* in, float* out, int nc, in
 extern "C" int eemflow_voxelize(const double* events, int64_t n, int bins, int h, int w, int normalize, float* grid,
                                 int64_t* idx_left, int64_t* idx_right, void* stream) {
     EEM_REQUIRE(events && grid, "eemflow_voxelize: NULL argument");
-    // per-thread scratch (band counters, moments, 16 B per event of vote records), grown on demand; a call on a
-    // different stream than the previous one first waits for that one's kernels to be done with it
-    static thread_local void* scratch = nullptr;
-    static thread_local size_t scratch_cap = 0;
-    static thread_local int scratch_dev = -1;
-    static thread_local hipEvent_t done = nullptr;
-    static thread_local void* last_stream = nullptr;
+    // per-thread scratch arenas (band counters, moments, 16 B per event of vote records), grown on demand: one per stream for up to
+    // four streams, so that the voxelizations of frames in flight on different streams do not wait for each other; a fifth stream
+    // takes over the least recently used arena after waiting for the kernels that last used it
+    struct Arena { void* p = nullptr; size_t cap = 0; int dev = -1; hipEvent_t done = nullptr; void* stream = nullptr; unsigned long used = 0; };
+    static thread_local Arena arenas[4];
+    static thread_local unsigned long tick = 0;
     int dev = 0;
     EEM_HIP_CHECK(hipGetDevice(&dev));
+    Arena* ar = nullptr;
+    for (Arena& a : arenas)
+        if (a.p && a.dev == dev && a.stream == stream) { ar = &a; break; }
+    if (!ar) {
+        for (Arena& a : arenas)
+            if (!ar || (!a.p && ar->p) || (!!a.p == !!ar->p && a.used < ar->used)) ar = &a;      // an empty slot, else the oldest
+        if (ar->p && ar->dev == dev) EEM_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, ar->done, 0));
+        ar->stream = stream;
+    }
+    ar->used = ++tick;
     const size_t need = voxel_scratch_bytes(n);
-    if (scratch == nullptr || scratch_dev != dev || scratch_cap < need) {
-        if (scratch && scratch_dev == dev) EEM_HIP_CHECK(hipFree(scratch));      // synchronises with work using it
-        scratch = nullptr;
-        scratch_cap = need + need / 4;
-        EEM_HIP_CHECK(hipMalloc(&scratch, scratch_cap));
-        if (scratch_dev != dev) { done = nullptr; EEM_HIP_CHECK(hipEventCreateWithFlags(&done, hipEventDisableTiming)); }
-        scratch_dev = dev;
-        last_stream = stream;
+    if (ar->p == nullptr || ar->dev != dev || ar->cap < need) {
+        if (ar->p && ar->dev == dev) EEM_HIP_CHECK(hipFree(ar->p));              // synchronises with work using it
+        ar->p = nullptr;
+        ar->cap = need + need / 4;
+        EEM_HIP_CHECK(hipMalloc(&ar->p, ar->cap));
+        if (ar->dev != dev || !ar->done) EEM_HIP_CHECK(hipEventCreateWithFlags(&ar->done, hipEventDisableTiming));
+        ar->dev = dev;
     }
-    if (stream != last_stream) {
-        EEM_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, done, 0));
-        last_stream = stream;
-    }
+    void* scratch = ar->p;
+    hipEvent_t done = ar->done;
     const int rc = voxel_launch(events, n, bins, h, w, normalize, grid, idx_left, idx_right, scratch, (hipStream_t)stream);
     if (rc == EEM_OK) EEM_HIP_CHECK(hipEventRecord(done, (hipStream_t)stream));
     return rc;

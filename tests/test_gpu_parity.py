@@ -413,18 +413,20 @@ def test_voxelizer_more_than_512_blocks(monkeypatch):
     assert float((binned - direct).abs().max()) < 2e-4 and float(direct.abs().max()) > 1.0
 
 
-def test_voxelizer_alternating_streams_share_the_scratch_safely():
-    """Calls from one thread on two streams use the same scratch arena; the library orders them with an event."""
+@pytest.mark.parametrize("nstreams", [2, 6])
+def test_voxelizer_alternating_streams_share_the_scratch_safely(nstreams):
+    """Calls from one thread on several streams: up to four streams keep a scratch arena each, further ones take over the least
+    recently used arena behind an event."""
     h, w, bins = 260, 346, 5
     seqs = [EventSequence(None, {"height": h, "width": w}, features=_clustered_events(90 + k, 40_000 + 7000 * k, h, w),
                           timestamp_multiplier=1e6, convert_to_relative=True) for k in range(4)]
     refs = [O.voxelize(s.features, bins, h, w, normalize=True) for s in seqs]
     vox = EventSequenceToVoxelGrid_Pytorch(bins, gpu=True, normalize=True, forkserver=False)
-    streams = [torch.cuda.Stream(DEV), torch.cuda.Stream(DEV)]
+    streams = [torch.cuda.Stream(DEV) for _ in range(nstreams)]
     outs = []
     for rep in range(3):
         for k, s in enumerate(seqs):
-            with torch.cuda.stream(streams[k & 1]):
+            with torch.cuda.stream(streams[(rep * len(seqs) + k) % nstreams]):
                 outs.append((k, vox(s)))
     torch.cuda.synchronize(DEV)
     for k, g in outs:

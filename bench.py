@@ -150,6 +150,8 @@ def other_rows(dev):
             m = m.to(dev)
             m.change_imagesize((480, 640))
             nets.append(m)
+        for m in nets:
+            m.frames_in_flight = 4
         streams = [torch.cuda.Stream(device=dev) for _ in nets]
         for key, batch, ns in (("eraft_640x480_12it_b1_4_in_flight_frames_per_s", 1, 4), ("eraft_640x480_12it_b4_3_in_flight_frames_per_s", 4, 3)):
             e1, e2 = (torch.from_numpy(a).to(dev) for a in synthetic_voxel_pair(1, batch, 480, 640))

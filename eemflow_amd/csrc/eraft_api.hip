@@ -59,6 +59,7 @@ struct eraft_ctx {
     int B = 0, h8 = 0, w8 = 0, ph[4] = {0, 0, 0, 0}, pw[4] = {0, 0, 0, 0};
     bool have_last = false;
     bool keep_stages = false;      // copy corr0 / net1 / mask1 / delta1 aside in the first iteration (parity tests)
+    int frames_in_flight = 1;      // eraft_set_frames_in_flight
     bool stages_valid = false;
 };
 
@@ -179,6 +180,7 @@ GConvArgs conv_args(const eraft_ctx* c, const Layer& L, int n, int hin, int win,
     a.wout = (win + 2 * L.pw - L.kw) / L.stride + 1;
     a.cout = L.cout; a.kh = L.kh; a.kw = L.kw; a.stride = L.stride; a.pad_h = L.ph; a.pad_w = L.pw;
     a.act = act; a.epi = GEPI_PLAIN; a.out_scale = 1.f;
+    a.in_flight = c->frames_in_flight;
     return a;
 }
 
@@ -470,6 +472,12 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
 extern "C" int eraft_keep_stages(eraft_ctx* c, int enable) {
     EEM_REQUIRE(c, "eraft_keep_stages: NULL context");
     c->keep_stages = enable != 0;
+    return EEM_OK;
+}
+
+extern "C" int eraft_set_frames_in_flight(eraft_ctx* c, int n) {
+    EEM_REQUIRE(c && n >= 1, "eraft_set_frames_in_flight: need a context and n >= 1");
+    c->frames_in_flight = n;
     return EEM_OK;
 }
 

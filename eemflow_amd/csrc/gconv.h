@@ -40,6 +40,7 @@ struct GConvArgs {
     const float* e0; int e0_ctotal, e0_coff;
     const float* e1; int e1_ctotal, e1_coff;
     float out_scale;       // final multiplier (1 = none)
+    int in_flight;         // frames the application keeps in flight on this GPU (0 / 1: one): tile choices favour CU time over latency
 };
 
 // number of packed floats / packing for weights [cout][sum(c_s)][kh][kw] read as segments of sizes cs[0..nseg)

@@ -222,7 +222,9 @@ int launch(const GConvArgs& a, const float* wpk16, const float* zero_page, hipSt
     // E-RAFT's update block at batch 4 is 2.3 blocks per CU); 4-row tiles reuse every weight fragment twice as often
     static const int th_env = [] { const char* e = getenv("EEM_G16_TH"); return e ? atoi(e) : 0; }();
     const long blocks4 = (long)ceil_div(a.wout, 16) * ceil_div(a.hout, 4) * ceil_div(a.cout, 64) * a.n;
-    const int th = th_env ? th_env : (blocks4 < 2048 ? 2 : 4);
+    // with several frames in flight the other frames fill the CUs a short launch leaves idle, and what counts is CU time: 4-row tiles
+    // read every weight fragment half as often (E-RAFT batch 4, three in flight: 168 -> 175 frames/s; one at a time 144 -> 138)
+    const int th = th_env ? th_env : (blocks4 < (a.in_flight >= 3 ? 512 : 2048) ? 2 : 4);
     if (th == 2) return launch_th<KH, KW, 2>(a, wpk16, zero_page, stream);
     return launch_th<KH, KW, 4>(a, wpk16, zero_page, stream);
 }

@@ -209,6 +209,12 @@ int eraft_forward(eraft_ctx* ctx, const float* events1, const float* events2, in
  * after eraft_keep_stages(ctx, 1), which adds four device copies to every forward - "corr0" (first lookup), "net1", "mask1",
  * "delta1" (after the first update). */
 int eraft_keep_stages(eraft_ctx* ctx, int enable);
+
+/* Throughput hint, as eemflow_set_frames_in_flight: the application keeps `n` E-RAFT forwards in flight on this GPU (one context
+ * and HIP stream each).  With n >= 3 the 16-aligned stride-1 convs use 4-row tiles from 512 blocks on (2 048 otherwise): the
+ * other frames fill the CUs a short launch leaves idle, and each weight fragment is read half as often (640x480, 12 iterations,
+ * batch 4, three in flight: 168 -> 175 frames/s; one forward at a time would lose 4 %).  Default 1. */
+int eraft_set_frames_in_flight(eraft_ctx* ctx, int n);
 int eraft_get_stage(eraft_ctx* ctx, const char* name, float* dst, size_t dst_capacity_floats, int dims_out[4],
                     void* stream);
 

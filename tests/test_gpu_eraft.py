@@ -128,6 +128,20 @@ def test_lds_tiled_conv_equals_generic_conv(monkeypatch):
     assert maxerr(fast, plain) < 2e-4 and float(plain.abs().max()) > 1e-3
 
 
+def test_frames_in_flight_hint_changes_tiles_not_results():
+    """eraft_set_frames_in_flight >= 3: the LDS-tiled convs of 512..2047 blocks use 4-row tiles instead of 2-row ones (batch 4 at
+    640x480: the update block).  Same k order per output: the flow does not change beyond round-off, and stays within tolerance."""
+    h, w = 480, 640
+    net, _ = make_net(29)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(30, 4, h, w))
+    with torch.no_grad():
+        one = torch.stack(net(e1, e2, iters=3)[1]).clone()
+        net.frames_in_flight = 4
+        many = torch.stack(net(e1, e2, iters=3)[1]).clone()
+    assert maxerr(many, one) < 1e-5 and float(one.abs().max()) > 1e-3
+
+
 def test_flow_init_and_twelve_iterations():
     h, w = 128, 128
     net, sd = make_net(19)

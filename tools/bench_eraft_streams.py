@@ -21,6 +21,7 @@ for _ in range(ns):
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     net = net.cuda()
     net.change_imagesize((h, w))
+    net.frames_in_flight = ns
     nets.append(net)
     streams.append(torch.cuda.Stream())
 e1, e2 = (torch.from_numpy(a).cuda() for a in synthetic_voxel_pair(1, b, h, w))

@@ -195,6 +195,8 @@ def other_rows(dev):
             m = m.to(dev)
             m.change_imagesize((720, 1280))
             nets.append(m)
+        for m in nets:
+            m.frames_in_flight = 4
         streams = [torch.cuda.Stream(device=dev) for _ in nets]
         with torch.no_grad():
             for phase, n in (("warm", 4), ("timed", 24)):

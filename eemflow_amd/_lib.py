@@ -86,6 +86,7 @@ _SIGNATURES = {
     "eemplus_get_stage": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, _c_float_p, ctypes.c_size_t,
                                          ctypes.POINTER(ctypes.c_int * 4), ctypes.c_void_p]),
     "eemplus_level": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p]),
+    "eemplus_set_frames_in_flight": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "eemplus_warp": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                     _c_float_p, ctypes.c_void_p]),
     "eemplus_upsample_flow_as": (ctypes.c_int, [_c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -34,6 +34,7 @@ constexpr int kDW = 96, kDIn = 87, kDense = 184;
 
 struct eemplus_ctx {
     int device = 0, cin0 = 15, groups = 3;
+    int frames_in_flight = 1;      // eemplus_set_frames_in_flight
     bool loaded = false;
     float* arena = nullptr;
     size_t zero_off = 0;           // zero page inside the arena (LDS-DMA source for padding); a write sink follows 1024 floats in
@@ -107,6 +108,7 @@ int conv(eemplus_ctx* c, const PLayer& L, const float* in, int in_ctotal, int in
     a.n = n; a.hin = hin; a.win = win; a.hout = (hin + 2 * pad - L.k) / L.stride + 1; a.wout = (win + 2 * pad - L.k) / L.stride + 1;
     a.cout = L.cout; a.kh = a.kw = L.k; a.stride = L.stride; a.pad_h = a.pad_w = pad;
     a.act = act; a.out_scale = 1.f;
+    a.in_flight = c->frames_in_flight;
     if (add) { a.epi = GEPI_ADD; a.e0 = add; a.e0_ctotal = L.cout; a.e0_coff = 0; }
     return gconv_launch(a, st);
 }
@@ -405,6 +407,12 @@ extern "C" int eemplus_forward(eemplus_ctx* c, const float* e1, const float* e2,
     for (int i = 0, l = 6; l >= 2; --l, ++i)
         if ((rc = pl_upflow_launch(c->flow[l].p, out + (size_t)i * B * 2 * in_h * in_w, B, hl[l], wl[l], in_h, in_w, 1, st)) != EEM_OK) return rc;
     c->B = B; c->have_last = true;
+    return EEM_OK;
+}
+
+extern "C" int eemplus_set_frames_in_flight(eemplus_ctx* c, int n) {
+    EEM_REQUIRE(c && n >= 1, "eemplus_set_frames_in_flight: need a context and n >= 1");
+    c->frames_in_flight = n;
     return EEM_OK;
 }
 

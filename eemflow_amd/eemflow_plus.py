@@ -134,6 +134,7 @@ class EEMFlow_cdc(nn.Module):  # noqa: N801
             flat = self._flat_weights().contiguous()
             _lib.check(L.eemplus_load_weights(self._ctx, flat.data_ptr(), flat.numel(), self.n_first_channels, self.groups))
             self._weights_version = fp
+        _lib.check(L.eemplus_set_frames_in_flight(self._ctx, max(1, int(getattr(self, "frames_in_flight", 1)))))
         return self._ctx
 
     def forward(self, events1, events2):

@@ -279,6 +279,10 @@ int eemplus_get_stage(eemplus_ctx* ctx, const char* name, float* dst, size_t dst
  * Replaces: one l-block of EEMFlow_cdc.forward  (model/EEMFlow/EEMFlow+.py:183-229, cdc_utils.py:156-174). */
 int eemplus_level(eemplus_ctx* ctx, int level, const float* flow_init, float* flow_up_out, float* flow_out, void* stream);
 
+/* Throughput hint, as eraft_set_frames_in_flight (4-row tiles of the LDS-tiled convs from 512 blocks on): EEMFlow+ 1280x720 with
+ * four frames in flight 579 -> 595 frames/s.  Default 1. */
+int eemplus_set_frames_in_flight(eemplus_ctx* ctx, int n);
+
 /* Backward bilinear warp of x [batch][c][h][w] by flow [batch][2][h][w].  mode 0: EEMFlow_cdc.warp
  * (EEMFlow+.py:137-149, align_corners=True); 1: tensor_tools.torch_warp (utils_luo/tools.py:2262-2306,
  * align_corners=False); 2: WarpingLayer_no_div (cdc_utils.py:50-78, align_corners=False and the

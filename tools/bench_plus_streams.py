@@ -19,6 +19,7 @@ for _ in range(ns):
     net.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_from_shapes({k: tuple(v.shape) for k, v in net.state_dict().items()}, 0).items()})
     net = net.cuda()
     net.change_imagesize((h, w))
+    net.frames_in_flight = ns
     nets.append(net)
     streams.append(torch.cuda.Stream())
 e1, e2 = (torch.from_numpy(a).cuda() for a in synthetic_voxel_pair(1, 1, h, w))

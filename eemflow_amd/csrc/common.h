@@ -172,6 +172,9 @@ bool enc2_supported(int cin, int cout, int stride, int win);
 size_t enc2_packed_floats(int cin, int cout);
 void enc2_pack_weights(const float* w, int cin, int cout, float* packed);
 int enc_conv2_launch(int cin, int cout, int stride, const EncConvArgs& a, hipStream_t stream);
+// the two stride-2 layers as light blocks with register-resident weights (conv_s2.hip); reads wpk2 in its 8-channel-chunk packing
+bool s2_supported(int cin, int cout, int stride, const EncConvArgs& a);
+int s2_launch(int cin, const EncConvArgs& a, hipStream_t stream);
 void enc2_tile(int cin, int cout, int* th, int* tw, int* poolk);
 // Winograd F(2x2,3x3) path for the stride-1 C -> C layers (C = 16, 32, 64), conv_wino.hip
 bool wino_supported(int cin, int cout, int stride, int win);

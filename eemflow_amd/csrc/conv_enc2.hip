@@ -611,5 +611,6 @@ int enc_conv2_launch(int cin, int cout, int stride, const EncConvArgs& a, hipStr
         eem_set_error("enc_conv2_launch: unsupported layer cin=%d cout=%d stride=%d", cin, cout, stride);
         return EEM_ERR_ARG;
     }
+    if (v->ck == 8 && s2_supported(cin, cout, stride, a)) return s2_launch(cin, a, stream);
     return v->launch(a, stream);
 }

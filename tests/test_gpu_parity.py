@@ -138,6 +138,24 @@ def test_frames_in_flight_hint_changes_grids_not_results():
         assert graph_stats(net)[0] == 3                       # the hint flipped twice: the cached graph was dropped each time
 
 
+@pytest.mark.parametrize("b,h,w", [(1, 720, 1280), (2, 260, 346), (1, 100, 150)])
+def test_light_block_stride2_kernel_equals_the_chunked_one(monkeypatch, b, h, w):
+    """conv_s2.hip (register-resident weights, the whole tile by one DMA wait) against conv_enc2.hip's chunked kernel
+    (EEM_NO_S2W=1, read per launch): same k order per output - bitwise the same stage tensors and flow."""
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(55, b, h, w))
+    outs = []
+    monkeypatch.setenv("EEM_S2W_64", "1")                    # pconv3_1 too (it stays on the chunked kernel by default)
+    for off in ("0", "1"):
+        monkeypatch.setenv("EEM_NO_S2W", off)
+        net, _ = make_net(44, graph=False)
+        net.change_imagesize((h, w))
+        with torch.no_grad():
+            flow = net(e1, e2)[1][0].clone()
+        outs.append((flow, net.stage("f12").clone(), net.stage("f13").clone()))
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)
+
+
 def graph_stats(net):
     gs = (ctypes.c_longlong * 3)()
     _lib.check(_lib.lib().eemflow_graph_stats(net._ctx, ctypes.byref(gs)))

@@ -102,7 +102,8 @@ def test_weight_gradients_on_the_side_stream_equal_the_single_stream_pass(monkey
                 grads.append(tr.grad.clone())
             torch.cuda.current_stream().synchronize()
         out[mode] = (loss, flow.cpu(), [g.cpu() for g in grads])
-    assert out["side"][0] == out["single"][0] and torch.equal(out["side"][1], out["single"][1])
+    assert abs(out["side"][0] - out["single"][0]) < 1e-12 * abs(out["single"][0])      # f64 atomics of the loss kernel: order only
+    assert torch.equal(out["side"][1], out["single"][1])
     ref = out["single"][2][0]
     for g in out["side"][2] + out["single"][2][1:]:
         assert float((g - ref).abs().max() / ref.abs().max()) < 2e-5

@@ -25,7 +25,7 @@ def load(d, counter):
         if r["Counter_Name"] != counter:
             continue
         k = r["Kernel_Name"]
-        m = re.search(r"enc_conv2?_kernel<(\d+), (\d+),", k)
+        m = re.search(r"(?:enc_conv2?|s2)_kernel<(\d+), (\d+)[,>]", k)
         if m:
             agg[(m.group(1), m.group(2))].append(float(r["Counter_Value"]))
             continue

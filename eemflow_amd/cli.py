@@ -59,6 +59,9 @@ def build_parser():
         q.add_argument('--checkpoint', default=None, help='test: checkpoint file (default <save_root>/checkpoints/EEMFlow_HREM_<input_type>.pth.tar)')
         q.add_argument('--config', default=None, help='JSON with the layout of config/a_meshflow.json (default: built-in copy of its used fields)')
         q.add_argument('--device', default='cuda:0')
+        q.add_argument('--loader_threads', default=0, type=int, help='evaluation: host threads that read and voxelize samples ahead')
+        q.add_argument('--frames_in_flight', default=1, type=int,
+                       help='evaluation: samples kept in flight on as many model replicas / HIP streams (not in the reference; 4 suits one MI355X)')
     common(sub.add_parser('train', help='train_EEMFlow_HREM.py'), True)
     common(sub.add_parser('test', help='test_EEMFlow_HREM.py'), False)
     return p
@@ -164,7 +167,8 @@ def test(args):
     model = model.to(dev)
     sequences = [args.test_sequence] if args.test_sequence else list(test_set.nori_list.keys())
     ev = harness.TestRaftEvents(test_set, tuple(config["val_img_size"]), logger=logger)
-    return ev.test_multi_sequence(model, start_epoch + 1, sequence_list=sequences, stride=1)
+    return ev.test_multi_sequence(model, start_epoch + 1, sequence_list=sequences, stride=1, frames_in_flight=args.frames_in_flight,
+                                  loader_threads=args.loader_threads)
 
 
 def main(argv=None):

@@ -140,6 +140,18 @@ class EEMFlow(nn.Module):
         self.image_size = img_size
         self.image_padder = InputPadder(img_size, mode='chairs', eval_pad_rate=64)
 
+    def replicate(self, frames_in_flight=None):
+        """A second module with the same weights, device, image size and mode and a context of its own: what keeps one more frame
+        in flight on another HIP stream (harness.TestRaftEvents(frames_in_flight=...))."""
+        twin = EEMFlow("", groups=self.groups, n_first_channels=self.n_first_channels, out_mesh_size=self.out_mesh_size)
+        twin.load_state_dict(self.state_dict())
+        twin = twin.to(next(self.parameters()).device)
+        if hasattr(self, "image_size"):
+            twin.change_imagesize(self.image_size)
+        twin.train(self.training)
+        twin.frames_in_flight = self.frames_in_flight if frames_in_flight is None else frames_in_flight
+        return twin
+
     def upsample_flow(self, flow, orig_size):
         if not flow.is_cuda:
             raise _lib.EEMFlowHipError("EEMFlow.upsample_flow: the HIP path needs a CUDA (ROCm) tensor")

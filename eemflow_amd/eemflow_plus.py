@@ -115,6 +115,18 @@ class EEMFlow_cdc(nn.Module):  # noqa: N801
         self.image_size = img_size
         self.image_padder = InputPadder(img_size, mode='chairs', eval_pad_rate=64)
 
+    def replicate(self, frames_in_flight=None):
+        """A second module with the same weights, device, image size and mode and a context of its own: what keeps one more frame
+        in flight on another HIP stream (harness.TestRaftEvents(frames_in_flight=...))."""
+        twin = EEMFlow_cdc("", groups=self.groups, n_first_channels=self.n_first_channels, args=self.args)
+        twin.load_state_dict(self.state_dict())
+        twin = twin.to(next(self.parameters()).device)
+        if hasattr(self, "image_size"):
+            twin.change_imagesize(self.image_size)
+        twin.train(self.training)
+        twin.frames_in_flight = getattr(self, "frames_in_flight", 1) if frames_in_flight is None else frames_in_flight
+        return twin
+
     def _flat_weights(self):
         return torch.cat([v.detach().reshape(-1).to(torch.float32).cpu() for v in self.state_dict().values()])
 

@@ -8,7 +8,9 @@ import torch
 from . import _lib
 
 
-def flow_error(flow_gt, flow_pred, event_img=None, is_car=False, evaluation_type="dense"):
+def flow_error_sums(flow_gt, flow_pred, event_img=None, is_car=False, evaluation_type="dense"):
+    """The reduction only, no host synchronisation: a device tensor of 5 doubles (sum EE, sum |gt|, n, count(EE < 1),
+    count(EE < 3 or EE < 0.1 |gt|)) on the current stream; `flow_error_from_sums` turns it into the reference's 7-tuple."""
     if not (flow_gt.is_cuda and flow_pred.is_cuda):
         raise _lib.EEMFlowHipError("flow_error: inputs must be CUDA (ROCm) tensors - there is no CPU path")
     gt = flow_gt[0].contiguous().float()
@@ -24,9 +26,17 @@ def flow_error(flow_gt, flow_pred, event_img=None, is_car=False, evaluation_type
     with torch.cuda.device(gt.device):
         _lib.check(_lib.lib().eemflow_flow_error(gt.data_ptr(), pr.data_ptr(), ev.data_ptr() if ev is not None else None, h, w,
                                                  max_row, out.data_ptr(), _lib.current_stream_ptr(gt.device)))
-    s_ee, s_gt, n, n1, n3 = out.cpu().tolist()
+    return out
+
+
+def flow_error_from_sums(sums):
+    s_ee, s_gt, n, n1, n3 = sums.cpu().tolist() if torch.is_tensor(sums) else sums
     p1 = n1 / (n + 1e-5)
     p3 = n3 / (n + 1e-5)
     if s_ee == 0:
         return 0.0, p1, p3, int(n), 0.0, 0.0, 0.0
     return s_ee / n, p1, p3, int(n), s_ee, s_gt / n, s_gt
+
+
+def flow_error(flow_gt, flow_pred, event_img=None, is_car=False, evaluation_type="dense"):
+    return flow_error_from_sums(flow_error_sums(flow_gt, flow_pred, event_img, is_car, evaluation_type))

@@ -76,6 +76,32 @@ def test_hrem_dataset_end_to_end(tmp_path):
     assert torch.equal(s["fflow"], torch.from_numpy(fl.transpose(2, 0, 1).copy()))
 
 
+def test_evaluation_with_frames_in_flight_equals_the_sequential_loop(tmp_path):
+    """TestRaftEvents.test_multi_sequence(frames_in_flight=3): three replicas on three streams take the samples round robin, the
+    statistics are fetched two samples late - the same per-sample numbers in the same order, the same mean AEE, bit for bit."""
+    from eemflow_amd import EEMFlow
+    from eemflow_amd.harness import TestRaftEvents
+    from eemflow_amd.weights import seeded_state_dict
+    root = str(tmp_path)
+    for i in range(7):
+        d = os.path.join(root, "dataset/HREM/test/dt1/seqB/%06d" % (i + 1))
+        os.makedirs(d)
+        hrem.write_events_npz(os.path.join(d, "events1.npz"), hrem.synthetic_hrem_events(40 + i, 30000, 720, 1280))
+        hrem.write_events_npz(os.path.join(d, "events2.npz"), hrem.synthetic_hrem_events(60 + i, 30000, 720, 1280))
+        hrem.write_flo(os.path.join(d, "flow.flo"), hrem.synthetic_flow(80 + i, 720, 1280))
+    args = {"eval_type": "dense", "event_interval": "dt1", "num_voxel_bins": 5}
+    net = EEMFlow("", 5, 5)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(5).items()})
+    net = net.to(DEV)
+    out = []
+    for nfl, threads in ((1, 0), (3, 0), (3, 2)):
+        ev = TestRaftEvents(hrem.HREMEventFlow(args, train=False, root=root), (720, 1280))
+        out.append((ev.test_multi_sequence(net, epoch=0, sequence_list=["seqB"], stride=1, frames_in_flight=nfl, loader_threads=threads),
+                    list(ev.logger.lines)))
+    assert all(o == out[0] for o in out[1:])
+    assert net.frames_in_flight == 1                                           # the hint is restored
+
+
 def test_harness_eval_and_train_on_synthetic_hrem(tmp_path):
     """test_multi_sequence / train_iters over a two-sample synthetic HREM tree: runs the whole row chain
     (files -> GPU voxelizer -> model -> flow_error / optimisation step) and the checkpoint writer."""

@@ -39,7 +39,7 @@ def build_parser():
 
     def common(q, train):
         q.add_argument('-v', '--visualize', action='store_true', help='accepted for compatibility; visualisation is not built')
-        q.add_argument('-n', '--num_workers', default=0, type=int, help='accepted for compatibility; samples are voxelized on the GPU in-process')
+        q.add_argument('-n', '--num_workers', default=0, type=int, help='host threads that read and voxelize samples ahead (the reference: DataLoader worker processes); 0 = in the loop')
         q.add_argument('--train_iters', default=6000000 if train else 1000000, type=int, metavar='N', help='number of total iterations')
         q.add_argument('-se', '--start-epoch', action='store_true', help='restart from lasted_ckpt.pth.tar of the run folder')
         q.add_argument('-be', '--best_epe', default=1e5, type=float)
@@ -126,8 +126,13 @@ def train(args):
     torch.cuda.set_device(dev)
     train_set = HREMEventFlow(args=config["data_loader"]["train"]["args"], train=True, root=args.data_root, device=dev)
     sampler = torch.utils.data.distributed.DistributedSampler(train_set, num_replicas=world, rank=rank, shuffle=True) if world > 1 else None
-    loader = torch.utils.data.DataLoader(train_set, batch_size=per_rank_batch(args.batch_size, world), shuffle=sampler is None,
-                                         sampler=sampler, num_workers=0, drop_last=True)
+    if args.num_workers > 0:             # the reference's worker count: here host threads that read / inflate / voxelize samples ahead
+        from .loader import ThreadedBatchLoader
+        loader = ThreadedBatchLoader(train_set, per_rank_batch(args.batch_size, world), shuffle=sampler is None, sampler=sampler,
+                                     threads=args.num_workers, drop_last=True)
+    else:
+        loader = torch.utils.data.DataLoader(train_set, batch_size=per_rank_batch(args.batch_size, world), shuffle=sampler is None,
+                                             sampler=sampler, num_workers=0, drop_last=True)
     model = model.to(dev)
     if world > 1:                                                    # replicas start from rank 0's weights
         for prm in model.parameters():

@@ -1,0 +1,70 @@
+"""Batch loader with host threads for datasets whose __getitem__ voxelizes on the GPU (hrem.HREMEventFlow, mvsec.MvsecEventFlow).
+
+torch.utils.data.DataLoader workers are processes: they cannot share this process's device context, and the reference's worker
+pool (train_EEMFlow_HREM.py:103-104, `--num_workers`) exists to hide exactly the part that stays on the host here - reading and
+inflating the event and flow files.  Those release the GIL, so threads do: `ThreadedBatchLoader` maps the flag onto a thread pool
+that builds samples ahead (each on its thread's current stream) and hands finished batches to the training loop in the
+sampler's order, a HIP event ordering every batch behind the launches that produced it.  Same iteration protocol as the
+DataLoader it replaces: iterable of dicts of stacked tensors, `len()`, `.dataset`, `.sampler`, drop_last.
+"""
+import collections
+import concurrent.futures
+
+import torch
+
+
+class ThreadedBatchLoader:
+    def __init__(self, dataset, batch_size, shuffle=False, sampler=None, threads=4, drop_last=True, ahead=2, seed=0):
+        self.dataset, self.batch_size, self.sampler = dataset, int(batch_size), sampler
+        self.shuffle, self.drop_last, self.threads, self.ahead = shuffle, drop_last, max(1, int(threads)), max(1, int(ahead))
+        self._epoch, self._seed = 0, seed
+
+    def _indices(self):
+        if self.sampler is not None:
+            return list(iter(self.sampler))
+        n = len(self.dataset)
+        if not self.shuffle:
+            return list(range(n))
+        g = torch.Generator()
+        g.manual_seed(self._seed + self._epoch)
+        return torch.randperm(n, generator=g).tolist()
+
+    def __len__(self):
+        n = len(self.sampler) if self.sampler is not None else len(self.dataset)
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def _sample(self, idx):
+        sample = self.dataset[idx]
+        ready = None
+        if torch.cuda.is_available():
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream())
+        return sample, ready
+
+    def __iter__(self):
+        idx = self._indices()
+        self._epoch += 1
+        batches = [idx[i:i + self.batch_size] for i in range(0, len(idx), self.batch_size)]
+        if self.drop_last and batches and len(batches[-1]) < self.batch_size:
+            batches.pop()
+        with concurrent.futures.ThreadPoolExecutor(max_workers=self.threads) as pool:
+            queue = collections.deque()
+            todo = iter(batches)
+
+            def submit():
+                b = next(todo, None)
+                if b is not None:
+                    queue.append([pool.submit(self._sample, i) for i in b])
+            for _ in range(self.ahead):
+                submit()
+            while queue:
+                futures = queue.popleft()
+                submit()
+                samples = []
+                for f in futures:
+                    sample, ready = f.result()
+                    if ready is not None:
+                        torch.cuda.current_stream().wait_event(ready)
+                    samples.append(sample)
+                yield {k: (torch.stack([s[k] for s in samples]) if torch.is_tensor(samples[0][k]) else [s[k] for s in samples])
+                       for k in samples[0]}

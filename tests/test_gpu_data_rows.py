@@ -255,3 +255,13 @@ def test_cli_train_then_test_on_synthetic_hrem(tmp_path):
     assert ck["epoch"] == 1 and len(ck["state_dict"]) == 66 and "iteration" in ck
     aee = cli.main(["test", *common, "--checkpoint", os.path.join(run, "lasted_ckpt.pth.tar")])
     assert np.isfinite(aee) and os.path.exists(os.path.join(root, "HREM_testset/EEMFlow_dt1/test.log"))
+    # the same evaluation with samples in flight and loader threads, the same training with `-n` threads feeding it
+    assert cli.main(["test", *common, "--checkpoint", os.path.join(run, "lasted_ckpt.pth.tar"), "--frames_in_flight", "3",
+                     "--loader_threads", "2"]) == aee
+    first = torch.load(os.path.join(run, "lasted_ckpt.pth.tar"), weights_only=False)["state_dict"]
+    cli.main(["train", *common, "-bs", "2", "--train_iters", "2", "--val_iters", "1", "-n", "2"])
+    again = torch.load(os.path.join(run, "lasted_ckpt.pth.tar"), weights_only=False)["state_dict"]
+    # two samples = one batch per epoch, in either order: the same two steps up to summation order (Adam's first steps move a
+    # weight by ~lr whatever its gradient's size, so an element whose gradient is ~eps may differ by 2 lr)
+    diff = torch.cat([(first[k] - again[k]).abs().reshape(-1) for k in first])
+    assert float(diff.max()) < 3e-4 and float(diff.median()) < 1e-6

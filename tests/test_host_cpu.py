@@ -170,6 +170,36 @@ def test_resumed_trainer_continues_the_one_cycle_schedule():
     assert abs(OneCycle(lr, steps + 100).lr(n) - ref_opt.param_groups[0]["lr"]) < 1e-9
 
 
+def test_threaded_batch_loader_follows_the_dataloader_protocol():
+    """eemflow_amd.loader.ThreadedBatchLoader (what `--num_workers` maps to): the batches of a sequential DataLoader, in order, with
+    drop_last, with a sampler, over several epochs; seeded shuffles differ between epochs and cover every sample."""
+    import time
+    import torch
+    from eemflow_amd.loader import ThreadedBatchLoader
+
+    class Toy(torch.utils.data.Dataset):
+        def __len__(self):
+            return 11
+
+        def __getitem__(self, i):
+            time.sleep(0.002 * ((i * 7) % 3))                      # uneven load times: order must not depend on them
+            return {"x": torch.full((2, 3), float(i)), "i": torch.tensor(i), "name": "s%d" % i}
+    ds = Toy()
+    ref = list(torch.utils.data.DataLoader(ds, batch_size=4, shuffle=False, drop_last=True))
+    for epoch in range(2):
+        got = list(ThreadedBatchLoader(ds, 4, threads=3))
+        assert len(got) == len(ref) == 2 == len(ThreadedBatchLoader(ds, 4, threads=3))
+        for a, b in zip(got, ref):
+            assert torch.equal(a["x"], b["x"]) and torch.equal(a["i"], b["i"]) and a["name"] == list(b["name"])
+    assert len(list(ThreadedBatchLoader(ds, 4, threads=2, drop_last=False))) == 3
+    sampler = torch.utils.data.SequentialSampler(range(6))
+    assert [b["i"].tolist() for b in ThreadedBatchLoader(ds, 3, sampler=sampler, threads=2)] == [[0, 1, 2], [3, 4, 5]]
+    sh = ThreadedBatchLoader(ds, 5, shuffle=True, threads=2, drop_last=False)
+    e1 = [i for b in sh for i in b["i"].tolist()]
+    e2 = [i for b in sh for i in b["i"].tolist()]
+    assert sorted(e1) == sorted(e2) == list(range(11)) and e1 != e2
+
+
 def test_cli_flags_match_reference_scripts():
     """Flags and defaults of train_EEMFlow_HREM.py:139-156 / test_EEMFlow_HREM.py:124-140."""
     from eemflow_amd import cli

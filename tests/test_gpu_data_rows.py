@@ -247,6 +247,7 @@ def test_cli_train_then_test_on_synthetic_hrem(tmp_path):
         hrem.write_events_npz(os.path.join(d, "events2.npz"), hrem.synthetic_hrem_events(seed + 1, 20000, 720, 1280))
         hrem.write_flo(os.path.join(d, "flow.flo"), hrem.synthetic_flow(seed + 2, 720, 1280))
     common = ["--data_root", root, "--save_root", root, "--lr", "1e-4", "--wd", "1e-5"]
+    torch.manual_seed(11)                                         # the model's init draws from torch's generator
     run = cli.main(["train", *common, "-bs", "2", "--train_iters", "2", "--val_iters", "1"])
     assert run.endswith("exp_HREM_meshflow/EEMFlow_dt1/lr0.000100_we0.000010")
     for f in ("config.json", "train.log", "lasted_ckpt.pth.tar"):
@@ -259,6 +260,7 @@ def test_cli_train_then_test_on_synthetic_hrem(tmp_path):
     assert cli.main(["test", *common, "--checkpoint", os.path.join(run, "lasted_ckpt.pth.tar"), "--frames_in_flight", "3",
                      "--loader_threads", "2"]) == aee
     first = torch.load(os.path.join(run, "lasted_ckpt.pth.tar"), weights_only=False)["state_dict"]
+    torch.manual_seed(11)
     cli.main(["train", *common, "-bs", "2", "--train_iters", "2", "--val_iters", "1", "-n", "2"])
     again = torch.load(os.path.join(run, "lasted_ckpt.pth.tar"), weights_only=False)["state_dict"]
     # two samples = one batch per epoch, in either order: the same two steps up to summation order (Adam's first steps move a

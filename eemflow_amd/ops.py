@@ -5,6 +5,7 @@ the graph - the 12 unrolled update iterations that share one set of weights, the
 gradients - and every node's arithmetic, forward and backward, runs in libeemflow_hip.so.  torch supplies tensors (allocation, views,
 slicing of gradients), nothing else: no ATen compute op is on the path.  CUDA (ROCm) tensors only; there is no CPU path.
 """
+import contextlib
 import ctypes
 import os
 
@@ -17,6 +18,18 @@ ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 
 def _sp(t):
     return _lib.current_stream_ptr(t.device)
+
+
+_NULL_CTX = contextlib.nullcontext()
+
+
+def _on(device):
+    """`with torch.cuda.device(device)` only when it is not the current one already (the context manager costs ~10 us per operator,
+    a training step of E-RAFT runs ~3 000 of them and is host-bound)."""
+    idx = device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NULL_CTX
+    return torch.cuda.device(device)
 
 
 def _c(t):
@@ -35,14 +48,14 @@ def _need_cuda(*ts):
 
 def _act_bwd(dy, y, kind, scale=1.0):
     out = torch.empty_like(y)
-    with torch.cuda.device(y.device):
+    with _on(y.device):
         _lib.check(_lib.lib().eemop_act_bwd(_c(dy).data_ptr(), y.data_ptr(), y.numel(), kind, float(scale), out.data_ptr(), _sp(y)))
     return out
 
 
 def _binary(kind, a, b=None, alpha=1.0):
     out = torch.empty_like(a)
-    with torch.cuda.device(a.device):
+    with _on(a.device):
         _lib.check(_lib.lib().eemop_binary(kind, a.data_ptr(), _ptr(b), float(alpha), a.numel(), out.data_ptr(), _sp(a)))
     return out
 
@@ -79,7 +92,7 @@ class Conv2d(torch.autograd.Function):
         out = torch.empty(n, cout, hout, wout, device=w.device, dtype=torch.float32)
         px = [x.data_ptr() for x in xs] + [None] * (3 - len(xs))
         pc = cs + [0] * (3 - len(xs))
-        with torch.cuda.device(w.device):
+        with _on(w.device):
             _lib.check(_lib.lib().eemop_conv2d_fwd(px[0], pc[0], px[1], pc[1], px[2], pc[2], w.data_ptr(), _ptr(b), n, hin, win, cout, kh, kw,
                                                    stride, ph, pw, act, float(out_scale), out.data_ptr(), cout, 0, _sp(w)))
         ctx.save_for_backward(w, out if act != ACT_NONE else None, *xs)
@@ -103,7 +116,7 @@ class Conv2d(torch.autograd.Function):
         need = ctx.needs_input_grad
         dw = db = None
         dxs = [None] * len(xs)
-        with torch.cuda.device(w.device):
+        with _on(w.device):
             s = _sp(w)
             joined = None
             if need[0] or (has_b and need[1]):
@@ -155,7 +168,7 @@ class InstanceNormReLU(torch.autograd.Function):
         x = _c(x)
         n, c, h, w = x.shape
         y = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _lib.check(_lib.lib().eemop_instnorm_fwd(x.data_ptr(), None, n * c, h * w, 1 if relu else 0, y.data_ptr(), _sp(x)))
         ctx.save_for_backward(x, y)
         ctx.relu = relu
@@ -166,7 +179,7 @@ class InstanceNormReLU(torch.autograd.Function):
         x, y = ctx.saved_tensors
         n, c, h, w = x.shape
         dx = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _lib.check(_lib.lib().eemop_instnorm_bwd(x.data_ptr(), y.data_ptr(), _c(dy).data_ptr(), n * c, h * w, 1 if ctx.relu else 0,
                                                      dx.data_ptr(), _sp(x)))
         return dx, None
@@ -184,7 +197,7 @@ class BatchNormTrainReLU(torch.autograd.Function):
         y = torch.empty_like(x)
         mean = torch.empty(c, device=x.device)
         rstd = torch.empty(c, device=x.device)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _lib.check(_lib.lib().eemop_batchnorm_train_fwd(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), running_mean.data_ptr(),
                                                             running_var.data_ptr(), n, c, h * w, float(momentum), float(eps), 1 if relu else 0,
                                                             y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _sp(x)))
@@ -197,7 +210,7 @@ class BatchNormTrainReLU(torch.autograd.Function):
         x, y, weight, mean, rstd = ctx.saved_tensors
         n, c, h, w = x.shape
         dx, dw, db = torch.empty_like(x), torch.empty_like(weight), torch.empty_like(weight)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _lib.check(_lib.lib().eemop_batchnorm_train_bwd(x.data_ptr(), y.data_ptr(), _c(dy).data_ptr(), weight.data_ptr(), mean.data_ptr(),
                                                             rstd.data_ptr(), n, c, h * w, 1 if ctx.relu else 0, dx.data_ptr(), dw.data_ptr(),
                                                             db.data_ptr(), _sp(x)))
@@ -256,7 +269,7 @@ class GRUBlend(torch.autograd.Function):
     def forward(ctx, z, h, q):
         z, h, q = _c(z), _c(h), _c(q)
         out = torch.empty_like(h)
-        with torch.cuda.device(h.device):
+        with _on(h.device):
             _lib.check(_lib.lib().eemop_gru_blend(z.data_ptr(), h.data_ptr(), q.data_ptr(), h.numel(), out.data_ptr(), _sp(h)))
         ctx.save_for_backward(z, h, q)
         return out
@@ -265,7 +278,7 @@ class GRUBlend(torch.autograd.Function):
     def backward(ctx, dout):
         z, h, q = ctx.saved_tensors
         dz, dh, dq = torch.empty_like(z), torch.empty_like(h), torch.empty_like(q)
-        with torch.cuda.device(h.device):
+        with _on(h.device):
             _lib.check(_lib.lib().eemop_gru_blend_bwd(_c(dout).data_ptr(), z.data_ptr(), h.data_ptr(), q.data_ptr(), h.numel(), dz.data_ptr(),
                                                       dh.data_ptr(), dq.data_ptr(), _sp(h)))
         return dz, dh, dq
@@ -281,7 +294,7 @@ class Cat2(torch.autograd.Function):
         cb = b.shape[1]
         out = torch.empty(n, ca + cb, h, w, device=a.device, dtype=torch.float32)
         L = _lib.lib()
-        with torch.cuda.device(a.device):
+        with _on(a.device):
             _lib.check(L.eemop_copy_channels(a.data_ptr(), ca, 0, out.data_ptr(), ca + cb, 0, ca, n, h * w, _sp(a)))
             _lib.check(L.eemop_copy_channels(b.data_ptr(), cb, 0, out.data_ptr(), ca + cb, ca, cb, n, h * w, _sp(a)))
         ctx.split = (ca, cb)
@@ -295,7 +308,7 @@ class Cat2(torch.autograd.Function):
         da = torch.empty(n, ca, h, w, device=dout.device, dtype=torch.float32)
         db = torch.empty(n, cb, h, w, device=dout.device, dtype=torch.float32)
         L = _lib.lib()
-        with torch.cuda.device(dout.device):
+        with _on(dout.device):
             _lib.check(L.eemop_copy_channels(dout.data_ptr(), ca + cb, 0, da.data_ptr(), ca, 0, ca, n, h * w, _sp(dout)))
             _lib.check(L.eemop_copy_channels(dout.data_ptr(), ca + cb, ca, db.data_ptr(), cb, 0, cb, n, h * w, _sp(dout)))
         return da, db
@@ -309,7 +322,7 @@ class CorrPyramid(torch.autograd.Function):
         f1, f2 = _c(f1), _c(f2)
         b, c, h, w = f1.shape
         lv = [torch.empty(b * h * w, 1, h >> l, w >> l, device=f1.device, dtype=torch.float32) for l in range(4)]
-        with torch.cuda.device(f1.device):
+        with _on(f1.device):
             _lib.check(_lib.lib().eemop_corr_pyramid_fwd(f1.data_ptr(), f2.data_ptr(), b, c, h, w, *[t.data_ptr() for t in lv], _sp(f1)))
         ctx.save_for_backward(f1, f2)
         return tuple(lv)
@@ -321,7 +334,7 @@ class CorrPyramid(torch.autograd.Function):
         shapes = [(b * h * w, 1, h >> l, w >> l) for l in range(4)]
         ds = [(_c(d).clone() if d is not None else torch.zeros(s, device=f1.device)) for d, s in zip((d0, d1, d2, d3), shapes)]
         df1, df2 = torch.empty_like(f1), torch.empty_like(f2)
-        with torch.cuda.device(f1.device):
+        with _on(f1.device):
             _lib.check(_lib.lib().eraft_corr_pyramid_bwd(f1.data_ptr(), f2.data_ptr(), ds[0].data_ptr(), ds[1].data_ptr(), ds[2].data_ptr(),
                                                          ds[3].data_ptr(), b, c, h, w, df1.data_ptr(), df2.data_ptr(), _sp(f1)))
         return df1, df2
@@ -335,7 +348,7 @@ class CorrLookup(torch.autograd.Function):
         coords = _c(coords)
         b, _, h, w = coords.shape
         out = torch.empty(b, 324, h, w, device=coords.device, dtype=torch.float32)
-        with torch.cuda.device(coords.device):
+        with _on(coords.device):
             _lib.check(_lib.lib().eemop_corr_lookup_fwd(p0.data_ptr(), p1.data_ptr(), p2.data_ptr(), p3.data_ptr(), coords.data_ptr(), b, h, w,
                                                         out.data_ptr(), _sp(coords)))
         ctx.save_for_backward(coords)
@@ -347,7 +360,7 @@ class CorrLookup(torch.autograd.Function):
         (coords,) = ctx.saved_tensors
         b, _, h, w = coords.shape
         ds = [torch.empty(s, device=coords.device, dtype=torch.float32) for s in ctx.shapes]      # zeroed by the library
-        with torch.cuda.device(coords.device):
+        with _on(coords.device):
             _lib.check(_lib.lib().eraft_corr_lookup_bwd(coords.data_ptr(), _c(dout).data_ptr(), b, h, w, *[d.data_ptr() for d in ds], _sp(coords)))
         return (None, *ds)
 
@@ -361,7 +374,7 @@ class ConvexUpsample(torch.autograd.Function):
         b, _, h, w = flow.shape
         zeros = torch.zeros_like(flow)
         full = torch.empty(b, 2, 8 * h, 8 * w, device=flow.device, dtype=torch.float32)
-        with torch.cuda.device(flow.device):
+        with _on(flow.device):
             _lib.check(_lib.lib().eemop_convex_upsample_fwd(zeros.data_ptr(), flow.data_ptr(), mask.data_ptr(), b, h, w, full.data_ptr(), _sp(flow)))
         ctx.save_for_backward(flow, mask)
         ctx.pad = pad
@@ -376,7 +389,7 @@ class ConvexUpsample(torch.autograd.Function):
         dfull = torch.zeros(b, 2, 8 * h, 8 * w, device=flow.device, dtype=torch.float32)
         dfull[:, :, top:8 * h - bottom, left:8 * w - right] = dout          # placement of the cropped gradient: data movement only
         dflow, dmask = torch.empty_like(flow), torch.empty_like(mask)
-        with torch.cuda.device(flow.device):
+        with _on(flow.device):
             _lib.check(_lib.lib().eraft_convex_upsample_bwd(flow.data_ptr(), mask.data_ptr(), dfull.data_ptr(), b, h, w, dflow.data_ptr(),
                                                             dmask.data_ptr(), _sp(flow)))
         return dflow, dmask, None
@@ -387,7 +400,7 @@ def coords_grids(batch, h, w, device, flow_init=None):
     c0 = torch.empty(batch, 2, h, w, device=device, dtype=torch.float32)
     c1 = torch.empty_like(c0)
     fi = _c(flow_init.float()) if flow_init is not None else None
-    with torch.cuda.device(device):
+    with _on(device):
         _lib.check(_lib.lib().eemop_coords_init(c0.data_ptr(), c1.data_ptr(), _ptr(fi), batch, h, w, _lib.current_stream_ptr(device)))
     return c0, c1
 
@@ -403,7 +416,7 @@ def replicate_pad_into(x, pad, out):
     n, c, h, w = x.shape
     left, right, top, bottom = pad
     assert tuple(out.shape) == (n, c, h + top + bottom, w + left + right) and out.is_contiguous()
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.check(_lib.lib().eemop_replicate_pad(x.data_ptr(), out.data_ptr(), n * c, h, w, left, right, top, bottom, _sp(x)))
     return out
 
@@ -414,7 +427,7 @@ def replicate_pad(x, pad):
     n, c, h, w = x.shape
     left, right, top, bottom = pad
     out = torch.empty(n, c, h + top + bottom, w + left + right, device=x.device, dtype=torch.float32)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.check(_lib.lib().eemop_replicate_pad(x.data_ptr(), out.data_ptr(), n * c, h, w, left, right, top, bottom, _sp(x)))
     return out
 
@@ -431,7 +444,7 @@ class ChannelSlice(torch.autograd.Function):
         x = _c(x)
         n, c, h, w = x.shape
         out = torch.empty(n, cnt, h, w, device=x.device, dtype=torch.float32)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _lib.check(_lib.lib().eemop_copy_channels(x.data_ptr(), c, off, out.data_ptr(), cnt, 0, cnt, n, h * w, _sp(x)))
         ctx.cfg = (c, off, cnt)
         return out
@@ -442,7 +455,7 @@ class ChannelSlice(torch.autograd.Function):
         dout = _c(dout)
         n, _, h, w = dout.shape
         dx = torch.zeros(n, c, h, w, device=dout.device, dtype=torch.float32)
-        with torch.cuda.device(dout.device):
+        with _on(dout.device):
             _lib.check(_lib.lib().eemop_copy_channels(dout.data_ptr(), cnt, 0, dx.data_ptr(), c, off, cnt, n, h * w, _sp(dout)))
         return dx, None, None
 
@@ -457,7 +470,7 @@ class CatN(torch.autograd.Function):
         cs = [x.shape[1] for x in xs]
         out = torch.empty(n, sum(cs), h, w, device=xs[0].device, dtype=torch.float32)
         L = _lib.lib()
-        with torch.cuda.device(out.device):
+        with _on(out.device):
             off = 0
             for x, c in zip(xs, cs):
                 _lib.check(L.eemop_copy_channels(x.data_ptr(), c, 0, out.data_ptr(), sum(cs), off, c, n, h * w, _sp(out)))
@@ -471,7 +484,7 @@ class CatN(torch.autograd.Function):
         n, ct, h, w = dout.shape
         L = _lib.lib()
         outs, off = [], 0
-        with torch.cuda.device(dout.device):
+        with _on(dout.device):
             for i, c in enumerate(ctx.cs):
                 if ctx.needs_input_grad[i]:
                     d = torch.empty(n, c, h, w, device=dout.device, dtype=torch.float32)
@@ -491,7 +504,7 @@ class ChannelShuffle(torch.autograd.Function):
         x = _c(x)
         n, c, h, w = x.shape
         out = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _lib.check(_lib.lib().eemop_shuffle_channels(x.data_ptr(), out.data_ptr(), n, c, groups, h * w, 0, _sp(x)))
         ctx.groups = groups
         return out
@@ -501,7 +514,7 @@ class ChannelShuffle(torch.autograd.Function):
         dout = _c(dout)
         n, c, h, w = dout.shape
         dx = torch.empty_like(dout)
-        with torch.cuda.device(dout.device):
+        with _on(dout.device):
             _lib.check(_lib.lib().eemop_shuffle_channels(dout.data_ptr(), dx.data_ptr(), n, c, ctx.groups, h * w, 1, _sp(dout)))
         return dx, None
 
@@ -514,7 +527,7 @@ class AvgPool2(torch.autograd.Function):
         x = _c(x)
         n, c, h, w = x.shape
         out = torch.empty(n, c, h // 2, w // 2, device=x.device, dtype=torch.float32)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _lib.check(_lib.lib().eemop_pool2_fwd(x.data_ptr(), out.data_ptr(), n * c, h, w, _sp(x)))
         ctx.shape = (n, c, h, w)
         return out
@@ -524,7 +537,7 @@ class AvgPool2(torch.autograd.Function):
         n, c, h, w = ctx.shape
         dout = _c(dout)
         dx = torch.empty(n, c, h, w, device=dout.device, dtype=torch.float32)
-        with torch.cuda.device(dout.device):
+        with _on(dout.device):
             _lib.check(_lib.lib().eemop_pool2_bwd(dout.data_ptr(), dx.data_ptr(), n * c, h, w, _sp(dout)))
         return dx
 
@@ -537,7 +550,7 @@ class LocalCorr53(torch.autograd.Function):
         f1, f2 = _c(f1), _c(f2)
         b, c, h, w = f1.shape
         out = torch.empty(b, 53, h, w, device=f1.device, dtype=torch.float32)
-        with torch.cuda.device(f1.device):
+        with _on(f1.device):
             _lib.check(_lib.lib().eemflow_local_corr53(f1.data_ptr(), f2.data_ptr(), b, c, h, w, out.data_ptr(), _sp(f1)))
         ctx.save_for_backward(f1, f2)
         return out
@@ -547,7 +560,7 @@ class LocalCorr53(torch.autograd.Function):
         f1, f2 = ctx.saved_tensors
         b, c, h, w = f1.shape
         d1, d2 = torch.empty_like(f1), torch.empty_like(f2)
-        with torch.cuda.device(f1.device):
+        with _on(f1.device):
             _lib.check(_lib.lib().eemop_local_corr53_bwd(_c(dout).data_ptr(), f1.data_ptr(), f2.data_ptr(), b, c, h, w, d1.data_ptr(),
                                                          d2.data_ptr(), _sp(f1)))
         return d1, d2
@@ -561,7 +574,7 @@ class Warp(torch.autograd.Function):
         x, flow = _c(x), _c(flow)
         b, c, h, w = x.shape
         out = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _lib.check(_lib.lib().eemplus_warp(x.data_ptr(), flow.data_ptr(), b, c, h, w, mode, out.data_ptr(), _sp(x)))
         ctx.save_for_backward(x, flow)
         ctx.mode = mode
@@ -572,7 +585,7 @@ class Warp(torch.autograd.Function):
         x, flow = ctx.saved_tensors
         b, c, h, w = x.shape
         dx, dflow = torch.empty_like(x), torch.empty_like(flow)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _lib.check(_lib.lib().eemplus_warp_bwd(x.data_ptr(), flow.data_ptr(), _c(dout).data_ptr(), b, c, h, w, ctx.mode, dx.data_ptr(),
                                                    dflow.data_ptr(), _sp(x)))
         return dx, dflow, None
@@ -590,7 +603,7 @@ class UpsampleFlowAs(torch.autograd.Function):
         L = _lib.lib()
         up = torch.empty(n, 2, oh, ow, device=x.device, dtype=torch.float32)
         res, scaled = torch.empty_like(up), torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             s = _sp(x)
             _lib.check(L.eemop_resize_ac_fwd(x.data_ptr(), up.data_ptr(), n * 2, h, w, oh, ow, s))
             _lib.check(L.eemop_scale_flow(up.data_ptr(), n, oh * ow, su, sv, res.data_ptr(), s))
@@ -604,7 +617,7 @@ class UpsampleFlowAs(torch.autograd.Function):
         L = _lib.lib()
         dev = dres.device if dres is not None else dscaled.device
         dx = torch.zeros(n, 2, h, w, device=dev, dtype=torch.float32)
-        with torch.cuda.device(dev):
+        with _on(dev):
             s = _lib.current_stream_ptr(dev)
             if dres is not None:
                 t = torch.empty(n, 2, oh, ow, device=dev, dtype=torch.float32)
@@ -622,7 +635,7 @@ class Sigmoid(torch.autograd.Function):
     def forward(ctx, x):
         x = _c(x)
         out = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _lib.check(_lib.lib().eemop_act_fwd(x.data_ptr(), x.numel(), ACT_SIGMOID, out.data_ptr(), _sp(x)))
         ctx.save_for_backward(out)
         return out

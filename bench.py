@@ -369,6 +369,23 @@ def latency_and_pipeline_rows(L, _lib, dev, flat, B, H, W, e1, e2, use_graph):
                 frame(i, mode)
             torch.cuda.synchronize(dev)
             out[key] = round(n / (time.perf_counter() - t0), 1)
+        # the same frames as batches of four per forward, two forwards in flight (B in {2, 8, 32} for throughput): more tiles
+        # per persistent block - NOT the headline configuration (batch 1 per forward), reported beside it
+        from eemflow_amd.weights import synthetic_voxel_pair as _svp
+        b1, b2 = (torch.from_numpy(a).to(dev) for a in _svp(0, 4, H, W))
+        fb = [torch.empty(4, 2, H, W, device=dev) for _ in range(2)]
+        for cc in ctxs[:2]:
+            _lib.check(L.eemflow_set_frames_in_flight(cc, 2))
+        for phase, n in (("warm", 6), ("timed", 60)):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for i in range(n):
+                k = i % 2
+                _lib.check(L.eemflow_forward(ctxs[k], b1.data_ptr(), b2.data_ptr(), 4, H, W, fb[k].data_ptr(), H, W,
+                                             ctypes.c_void_p(streams[k].cuda_stream)))
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+        out["batch4_two_in_flight_frames_per_s"] = round(60 * 4 / dt, 1)
         gs = (ctypes.c_longlong * 3)()
         _lib.check(L.eemflow_graph_stats(ctxs[0], ctypes.byref(gs)))
         out["pipeline_graph_captures_replays_io_updates_ctx0"] = list(gs)

@@ -20,9 +20,9 @@
 //                         with ds_add_f32 and written once (no memset of the grid).  For the normalisation the block also
 //                         leaves the f64 (count, sum, sum of squares) of its non-zero voxels;
 //   3. vox_norm_kernel    adds the band sums, mean / unbiased sd, rewrites the non-zero voxels.
-// With fewer than one event per 8 voxels (HREM's 2e5 events per 4.6 M-voxel volume) step 3 costs more than step 2, so the band
-// kernel runs twice instead: a moments-only launch, then a launch that accumulates the bands again and stores them already
-// normalised - the grid is written once and never read (43 -> 2x us per volume at 2e5 events).
+// Optional (EEM_VOX_TWOPASS=<r>, off by default): with fewer than one event per r voxels the band kernel runs twice instead of
+// step 3 - a moments-only launch, then a launch that accumulates the bands again and stores them already normalised, so the grid
+// is written once and never read.  Measured at 2e5 events per 4.6 M voxels: 16 + 23 us of band passes replace 23 + 11 us - no gain.
 // HBM traffic: 32 B (event) + 2 x 16 B (record) per event + 4 B (normalised: up to 12 B, two band passes: 4 B + 16 B per event) per
 // voxel, instead of two scattered read-modify-writes per event and three further passes over the grid.
 // An event with x >= W lands in a neighbouring row exactly as the reference's flat index_add_ puts it; votes whose

@@ -422,6 +422,21 @@ extern "C" int eemop_conv2d_bwd_weight(const float* x, const float* dy, int n, i
     hipStream_t st = (hipStream_t)stream;
     const int hout = (hin + 2 * ph - kh) / stride + 1, wout = (win + 2 * pw - kw) / stride + 1;
     int rc;
+    {
+        // LDS-tiled kernel (wgrad_enc.hip: G and the haloed X tile by LDS-DMA, K split over the waves, 65-95 TFLOP/s) where the shape
+        // allows; it also leaves the bias gradient
+        WgradArgs a;
+        a.x = x; a.x_ctotal = cic; a.x_coff = 0; a.cin = cic;
+        a.g = dy; a.gate = nullptr; a.g_ctotal = cout; a.g_coff = 0; a.g_cmul = 1; a.cout = cout;
+        a.dw = dw;
+        a.n = n; a.hin = hin; a.win = win; a.hout = hout; a.wout = wout; a.k = kh; a.stride = stride; a.pad = ph;
+        a.db = db;
+        a.kh = kh; a.kw = kw; a.ph = ph; a.pw = pw; a.dw_cin = cin; a.dw_coff = ci0;
+        float* zp = nullptr;
+        if ((rc = scratch_get(g_scratch[1], 1024, &zp)) != EEM_OK) return rc;
+        a.zero_page = zp;
+        if (wgrad_wide_supported(a)) return wgrad_wide_launch(a, st);
+    }
     for (int c0 = 0; c0 < cout; c0 += 128) {                     // the kernel holds at most 128 couts per block
         WgradArgs a;
         a.x = x; a.x_ctotal = cic; a.x_coff = 0; a.cin = cic;

@@ -36,6 +36,10 @@ int tr_wgrad_launch(const WgradArgs& a, hipStream_t st);
 // encoder-shaped jobs (3x3, pad 1, no gate, 16/32/64 couts, 16-byte aligned rows): wgrad_enc.hip
 bool wgrad_enc_supported(const WgradArgs& a);
 int wgrad_enc_launch(const WgradArgs& a, hipStream_t st);
+// the same LDS-tiled kernel for stride-1 layers of any width with 3x3 / 1x5 / 5x1 / 1x1 filters (64-cout chunks on blockIdx.z;
+// honours kh / kw / ph / pw and dw_cin / dw_coff): E-RAFT's residual stacks, update block and heads
+bool wgrad_wide_supported(const WgradArgs& a);
+int wgrad_wide_launch(const WgradArgs& a, hipStream_t st);
 // several convs of the same kernel size / stride in one launch (blockIdx.z = job); at most WGRAD_MAX_JOBS
 #define WGRAD_MAX_JOBS 16
 int tr_wgrad_launch_batch(const WgradArgs* jobs, int njobs, hipStream_t st);

@@ -27,14 +27,15 @@ namespace {
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
-template <int MT, int S, int TW, int CP>
+template <int MT, int S, int TW, int CP, int KH = 3, int KW = 3>
 struct WgCfg {
-    static constexpr int NT = (CP * 9 + 15) / 16;                // 16-wide N tiles: 9 for 16 channels, 3 for the 5 of pconv1_1
+    static constexpr int TAPS = KH * KW, PH = KH / 2, PW = KW / 2;
+    static constexpr int NT = (CP * TAPS + 15) / 16;             // 16-wide N tiles: 9 for 16 channels x 9 taps, 3 for the 5 of pconv1_1
     static constexpr int TH = 128 / TW;
     static constexpr int GP = 132;                               // G row pitch (floats): 33 pieces
     static constexpr int GSLOTS = MT * 16 * 33;
-    static constexpr int XR = (TH - 1) * S + 3;
-    static constexpr int XC = (S * TW - S + 6 + 3) & ~3;         // staged columns, from ox0*S - 4
+    static constexpr int XR = (TH - 1) * S + KH;
+    static constexpr int XC = ((TW - 1) * S + KW - PW + 4 + 3) & ~3;   // staged columns, from ox0*S - 4 (3x3: 40 / 72 at stride 1 / 2)
     static constexpr int XQ = XC / 4;
     static constexpr int PC = XR * XC;                           // channel plane
     static constexpr int XSLOTS = CP * XR * XQ;
@@ -48,17 +49,21 @@ struct WgCfg {
     static_assert(2 * STAGE * 4 <= 160 * 1024, "LDS budget");
 };
 
-template <int MT, int S, int TW, int CP>
+template <int MT, int S, int TW, int CP, int KH = 3, int KW = 3>
 __global__ __launch_bounds__(256) void wgrad_enc_kernel(WgradArgs a, int tiles_x, int tiles_y) {
-    using C = WgCfg<MT, S, TW, CP>;
-    constexpr int NT = C::NT;
+    using C = WgCfg<MT, S, TW, CP, KH, KW>;
+    constexpr int NT = C::NT, TAPS = C::TAPS;
+    // blockIdx.z: chunk of MT * 16 couts (layers wider than 64 couts: E-RAFT's update block and heads)
+    a.g_coff += blockIdx.z * MT * 16;
+    const int co_base = blockIdx.z * MT * 16;
+    const int cout_here = min(MT * 16, a.cout - co_base);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, g = lane >> 4;
     const int ci0 = blockIdx.y * CP;
     const int cin_here = min(CP, a.cin - ci0);
-    const int nvalid = cin_here * 9;
+    const int nvalid = cin_here * TAPS;
 
     const TileRange tr_ = block_tile_range(tiles_x * tiles_y * a.n, blockIdx.x, gridDim.x);
     if (tr_.count == 0) return;
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(256) void wgrad_enc_kernel(WgradArgs a, int tiles_x
         const int f = (wave + 4 * k) * 64 + lane;
         const int co = f / 33, q = f - co * 33;
         const int p = 4 * q, py = p / TW, px = p - py * TW;
-        const bool ok = f < C::GSLOTS && q < 32;
+        const bool ok = f < C::GSLOTS && q < 32 && co < cout_here;
         goff[k] = (int)(((size_t)co * ghw + (size_t)py * a.wout + px) * 4);
         grc[k] = ok ? (py | (px << 8)) : -1;
     }
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(256) void wgrad_enc_kernel(WgradArgs a, int tiles_x
     const char* zero = reinterpret_cast<const char*>(a.zero_page);
     auto issue = [&](int stage, const TileCoord& tc) {
         const int oy0 = tc.by * C::TH, ox0 = tc.bx * TW;
-        const int gy0 = oy0 * S - 1, gx0 = ox0 * S - 4;
+        const int gy0 = oy0 * S - C::PH, gx0 = ox0 * S - 4;
         // signed element offsets: the first tile row / column starts above / left of the image
         const char* gb = reinterpret_cast<const char*>(a.g + ((size_t)tc.n * a.g_ctotal + a.g_coff) * ghw) +
                          ((long)oy0 * a.wout + ox0) * 4;
@@ -119,8 +124,8 @@ __global__ __launch_bounds__(256) void wgrad_enc_kernel(WgradArgs a, int tiles_x
     for (int nt = 0; nt < NT; ++nt) {
         int n = nt * 16 + j;
         n = n < nvalid ? n : 0;                                  // columns past cin_here*9 are never written back
-        const int ci = n / 9, tap = n - ci * 9;
-        boff[nt] = ci * C::PC + (tap / 3) * C::XC + (tap % 3) + 3;   // + 3: the stage starts 4 columns left, pad 1
+        const int ci = n / TAPS, tap = n - ci * TAPS;
+        boff[nt] = ci * C::PC + (tap / KW) * C::XC + (tap % KW) + 4 - C::PW;   // the stage starts 4 columns left of the tile
     }
     int aoff[8], xo[8];
 #pragma unroll
@@ -196,7 +201,8 @@ __global__ __launch_bounds__(256) void wgrad_enc_kernel(WgradArgs a, int tiles_x
 #pragma unroll
         for (int r = 0; r < 4; ++r) {                            // D[co = 4 * (l / 16) + r][n = l % 16]
             const int co = mt * 16 + 4 * (l >> 4) + r;
-            atomicAdd(&a.dw[((size_t)co * a.cin + ci0) * 9 + n], v[r]);
+            if (co < cout_here)
+                atomicAdd(&a.dw[((size_t)(co_base + co) * (a.dw_cin ? a.dw_cin : a.cin) + a.dw_coff + ci0) * TAPS + n], v[r]);
         }
     }
     // ---- bias gradient (first channel chunk only): sum over the 4 pixel slots of a k-step, the waves, the blocks
@@ -210,33 +216,41 @@ __global__ __launch_bounds__(256) void wgrad_enc_kernel(WgradArgs a, int tiles_x
             if (g == 0) lds[wave * 64 + mt * 16 + j] = v;
         }
         __syncthreads();
-        if (threadIdx.x < MT * 16)
-            atomicAdd(&a.db[threadIdx.x], lds[threadIdx.x] + lds[64 + threadIdx.x] + lds[128 + threadIdx.x] + lds[192 + threadIdx.x]);
+        if ((int)threadIdx.x < cout_here)
+            atomicAdd(&a.db[co_base + threadIdx.x], lds[threadIdx.x] + lds[64 + threadIdx.x] + lds[128 + threadIdx.x] + lds[192 + threadIdx.x]);
     }
 }
 
-template <int MT, int S, int TW, int CP>
+template <int MT, int S, int TW, int CP, int KH = 3, int KW = 3>
 int launch(const WgradArgs& a, hipStream_t st) {
-    using C = WgCfg<MT, S, TW, CP>;
+    using C = WgCfg<MT, S, TW, CP, KH, KW>;
     const int tiles_x = ceil_div(a.wout, TW), tiles_y = ceil_div(a.hout, C::TH);
     const int T = tiles_x * tiles_y * a.n;
-    const int chunks = ceil_div(a.cin, CP);
+    const int chunks = ceil_div(a.cin, CP), cochunks = ceil_div(a.cout, MT * 16);
     const int lds_bytes = 2 * C::STAGE * 4;
     int per_cu = (160 * 1024) / lds_bytes;
     per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
-    int gx = (256 * per_cu) / chunks;                            // ~per_cu resident blocks per CU over all chunks
+    int gx = (256 * per_cu) / (chunks * cochunks);               // ~per_cu resident blocks per CU over all chunks
     gx = (gx + 7) & ~7;
+    if (gx < 8) gx = 8;
     const int need = (ceil_div(T, 8)) * 8;
     if (gx > need) gx = need;
     static bool raised = false;
     if (!raised) {
-        EEM_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_enc_kernel<MT, S, TW, CP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        EEM_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_enc_kernel<MT, S, TW, CP, KH, KW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           160 * 1024));
         raised = true;
     }
-    hipLaunchKernelGGL((wgrad_enc_kernel<MT, S, TW, CP>), dim3(gx, chunks), dim3(256), lds_bytes, st, a, tiles_x, tiles_y);
+    hipLaunchKernelGGL((wgrad_enc_kernel<MT, S, TW, CP, KH, KW>), dim3(gx, chunks, cochunks), dim3(256), lds_bytes, st, a, tiles_x, tiles_y);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
+}
+
+// stride-1 layers of any width with 3x3, 1x5, 5x1 or 1x1 filters (E-RAFT's residual stacks, update block and heads): 64-cout chunks
+template <int KH, int KW>
+int launch_wide(const WgradArgs& a, hipStream_t st) {
+    if (a.wout % 32 == 0 || a.wout >= 256) return launch<4, 1, 32, 16, KH, KW>(a, st);
+    return launch<4, 1, 16, 16, KH, KW>(a, st);
 }
 
 template <int MT, int S>
@@ -255,6 +269,27 @@ bool wgrad_enc_supported(const WgradArgs& a) {
            a.wout % 4 == 0 && a.win % 4 == 0 && ((uintptr_t)a.g & 15) == 0 && ((uintptr_t)a.x & 15) == 0 &&
            ((size_t)a.hout * a.wout) % 4 == 0 && ((size_t)a.hin * a.win) % 4 == 0 &&
            (size_t)a.cout * a.hout * a.wout * 4 < (1u << 31) && (size_t)16 * a.hin * a.win * 4 < (1u << 31);
+}
+
+// a.kh / a.kw (0: a.k), a.ph / a.pw, a.dw_cin / a.dw_coff as in train.h
+bool wgrad_wide_supported(const WgradArgs& a) {
+    const char* e = getenv("EEM_NO_WGRAD_WIDE");                     // read per call: a test flips it inside one process
+    if (e && e[0] == '1') return false;
+    const int kh = a.kh ? a.kh : a.k, kw = a.kh ? a.kw : a.k;
+    const int ph = a.kh ? a.ph : a.pad, pw = a.kh ? a.pw : a.pad;
+    const bool shape = (kh == 3 && kw == 3) || (kh == 1 && kw == 5) || (kh == 5 && kw == 1) || (kh == 1 && kw == 1);
+    return shape && ph == kh / 2 && pw == kw / 2 && a.stride == 1 && a.zero_page && a.gate == nullptr && a.g_cmul == 1 && a.cout >= 16 &&
+           a.cin >= 16 && a.wout % 4 == 0 && a.win % 4 == 0 && ((uintptr_t)a.g & 15) == 0 && ((uintptr_t)a.x & 15) == 0 &&
+           ((size_t)a.hout * a.wout) % 4 == 0 && ((size_t)a.hin * a.win) % 4 == 0 &&
+           (size_t)a.cout * a.hout * a.wout * 4 < (1u << 31) && (size_t)16 * a.hin * a.win * 4 < (1u << 31);
+}
+
+int wgrad_wide_launch(const WgradArgs& a, hipStream_t st) {
+    const int kh = a.kh ? a.kh : a.k, kw = a.kh ? a.kw : a.k;
+    if (kh == 3) return launch_wide<3, 3>(a, st);
+    if (kh == 5) return launch_wide<5, 1>(a, st);
+    if (kw == 5) return launch_wide<1, 5>(a, st);
+    return launch_wide<1, 1>(a, st);
 }
 
 int wgrad_enc_launch(const WgradArgs& a, hipStream_t st) {

@@ -42,7 +42,11 @@ def rnd(*shape, seed=0, scale=1.0):
     ((128,), 256, (3, 3), 1, (1, 1), (16, 20), ops.ACT_RELU),
     ((256,), 2, (3, 3), 1, (1, 1), (16, 20), ops.ACT_NONE),
 ])
-def test_conv2d_forward_and_gradients_vs_torch(cin_segs, cout, k, stride, pad, hw, act):
+@pytest.mark.parametrize("wide", [True, False])
+def test_conv2d_forward_and_gradients_vs_torch(monkeypatch, cin_segs, cout, k, stride, pad, hw, act, wide):
+    """`wide`: weight gradients on the LDS-tiled kernel of wgrad_enc.hip (64-cout chunks, 3x3 / 1x5 / 5x1 / 1x1 taps, channel slices of
+    a concatenated input) where the shape allows, or (EEM_NO_WGRAD_WIDE=1, read per call) on the generic kernel."""
+    monkeypatch.setenv("EEM_NO_WGRAD_WIDE", "0" if wide else "1")
     n, (h, w) = 2, hw
     cin = sum(cin_segs)
     conv = nn.Conv2d(cin, cout, k, stride=stride, padding=pad)

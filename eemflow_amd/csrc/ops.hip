@@ -274,6 +274,8 @@ inline unsigned nblk(long n) { return (unsigned)((n + 255) / 256); }
 struct Plan {
     int* idx = nullptr;        // device: packed[i] = idx[i] ? w[idx[i] - 1] : 0
     size_t n = 0;
+    int* idx16 = nullptr;      // the same for gconv16's fragment-order stream (stride-1 convs with 16-aligned channel counts), or NULL
+    size_t n16 = 0;
 };
 std::map<std::string, Plan> g_plans;              // per process; the tables depend on layer shapes only
 std::mutex g_plans_mutex;                         // autograd runs backward ops on its own thread
@@ -293,6 +295,40 @@ int scratch_get(Scratch& s, size_t floats, float** out) {
     }
     *out = s.p;
     return EEM_OK;
+}
+
+// index table of gconv16's packing for the same (index-valued) weights, when the shape qualifies
+void plan_add16(Plan& p, const float* iw, int cout, const int* cs, int nseg, int kh, int kw) {
+    if (!gconv16_shape(cout, cs, nseg, kh, kw, 1)) return;
+    std::vector<float> pk(gconv16_packed_floats(cout, cs, nseg, kh, kw), 0.f);
+    gconv16_pack(iw, cout, cs, nseg, kh, kw, pk.data());
+    std::vector<int> idx(pk.size());
+    for (size_t i = 0; i < pk.size(); ++i) idx[i] = (int)pk[i];
+    p.n16 = idx.size();
+    if (hipMalloc(&p.idx16, p.n16 * sizeof(int)) != hipSuccess ||
+        hipMemcpy(p.idx16, idx.data(), p.n16 * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+        p.idx16 = nullptr;                       // the generic packing still serves the layer
+        p.n16 = 0;
+    }
+}
+
+// Packs the weights for the launch described by `a` (everything but the weight pointers filled in): the LDS-tiled kernel's stream
+// when the launch qualifies for it, else the generic kernel's.
+int pack_for(const Plan* pl, const float* w, GConvArgs& a, hipStream_t st) {
+    int rc;
+    float* pk = nullptr;
+    if (pl->idx16) {
+        float* zp = nullptr;
+        if ((rc = scratch_get(g_scratch[1], 1024, &zp)) != EEM_OK) return rc;
+        if ((rc = scratch_get(g_scratch[0], pl->n16 > pl->n ? pl->n16 : pl->n, &pk)) != EEM_OK) return rc;
+        a.wpk16 = pk;
+        a.zero_page = zp;
+        if (gconv16_supported(a)) return repack_launch(w, pl->idx16, pk, (long)pl->n16, st);
+        a.wpk16 = nullptr;
+    }
+    if ((rc = scratch_get(g_scratch[0], pl->n, &pk)) != EEM_OK) return rc;
+    a.wpk = pk;
+    return repack_launch(w, pl->idx, pk, (long)pl->n, st);
 }
 
 // forward plan: gconv_pack of w [cout][cin][kh][kw] read as `nseg` input segments
@@ -318,6 +354,7 @@ int plan_fwd(int cout, const int* cs, int nseg, int kh, int kw, Plan** out) {
         p.n = idx.size();
         EEM_HIP_CHECK(hipMalloc(&p.idx, p.n * sizeof(int)));
         EEM_HIP_CHECK(hipMemcpy(p.idx, idx.data(), p.n * sizeof(int), hipMemcpyHostToDevice));
+        plan_add16(p, iw.data(), cout, cs, nseg, kh, kw);
         it = g_plans.emplace(key, p).first;
     }
     *out = &it->second;
@@ -351,6 +388,7 @@ int plan_bwd(int cout, int cin, int ci0, int cic, int kh, int kw, Plan** out) {
         p.n = idx.size();
         EEM_HIP_CHECK(hipMalloc(&p.idx, p.n * sizeof(int)));
         EEM_HIP_CHECK(hipMemcpy(p.idx, idx.data(), p.n * sizeof(int), hipMemcpyHostToDevice));
+        plan_add16(p, T.data(), cic, cs, 1, kh, kw);
         it = g_plans.emplace(key, p).first;
     }
     *out = &it->second;
@@ -371,20 +409,18 @@ extern "C" int eemop_conv2d_fwd(const float* x0, int c0, const float* x1, int c1
     Plan* pl = nullptr;
     int rc = plan_fwd(cout, cs, nseg, kh, kw, &pl);
     if (rc != EEM_OK) return rc;
-    float* pk = nullptr;
-    if ((rc = scratch_get(g_scratch[0], pl->n, &pk)) != EEM_OK) return rc;
-    if ((rc = repack_launch(w, pl->idx, pk, (long)pl->n, st)) != EEM_OK) return rc;
     GConvArgs a;
     memset(&a, 0, sizeof(a));
     a.nseg = nseg;
     const float* xs[3] = {x0, x1, x2};
     for (int s = 0; s < nseg; ++s) { a.seg[s].ptr = xs[s]; a.seg[s].c = cs[s]; a.seg[s].ctotal = cs[s]; a.seg[s].coff = 0; }
-    a.wpk = pk; a.shift = bias;
+    a.shift = bias;
     a.out = out; a.out_ctotal = out_ctotal; a.out_coff = out_coff;
     a.n = n; a.hin = hin; a.win = win;
     a.hout = (hin + 2 * ph - kh) / stride + 1; a.wout = (win + 2 * pw - kw) / stride + 1;
     a.cout = cout; a.kh = kh; a.kw = kw; a.stride = stride; a.pad_h = ph; a.pad_w = pw;
     a.act = act; a.epi = GEPI_PLAIN; a.out_scale = out_scale;
+    if ((rc = pack_for(pl, w, a, st)) != EEM_OK) return rc;
     return gconv_launch(a, st);
 }
 
@@ -397,20 +433,17 @@ extern "C" int eemop_conv2d_bwd_data(const float* dy, const float* w, int n, int
     Plan* pl = nullptr;
     int rc = plan_bwd(cout, cin, ci0, cic, kh, kw, &pl);
     if (rc != EEM_OK) return rc;
-    float* pk = nullptr;
-    if ((rc = scratch_get(g_scratch[0], pl->n, &pk)) != EEM_OK) return rc;
-    if ((rc = repack_launch(w, pl->idx, pk, (long)pl->n, st)) != EEM_OK) return rc;
     const int hout = (hin + 2 * ph - kh) / stride + 1, wout = (win + 2 * pw - kw) / stride + 1;
     GConvArgs a;
     memset(&a, 0, sizeof(a));
     a.nseg = 1;
     a.seg[0].ptr = dy; a.seg[0].c = cout; a.seg[0].ctotal = cout; a.seg[0].coff = 0;
-    a.wpk = pk;
     a.out = dx; a.out_ctotal = cic; a.out_coff = 0;
     a.n = n; a.hin = hout; a.win = wout; a.hout = hin; a.wout = win; a.cout = cic;
     a.kh = kh; a.kw = kw; a.stride = 1; a.pad_h = kh - 1 - ph; a.pad_w = kw - 1 - pw;
     a.tstride = stride;
     a.act = GACT_NONE; a.epi = GEPI_PLAIN; a.out_scale = 1.f;
+    if ((rc = pack_for(pl, w, a, st)) != EEM_OK) return rc;
     return gconv_launch(a, st);
 }
 

@@ -170,19 +170,19 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* sh) {
 
 // InstanceNorm2d(affine=False, eps) [+ ReLU] backward, one block per (n, c) plane; x is the layer input (the statistics are
 // recomputed), y the layer output (ReLU gate):  dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * [y > 0]
-__global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+__global__ __launch_bounds__(1024) void instnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ dy, float* __restrict__ dx, int hw, int relu, float eps) {
-    __shared__ double sh[8];
+    __shared__ double sh[32];
     const size_t base = (size_t)blockIdx.x * hw;
     double s = 0.0, q = 0.0;
-    for (int i = threadIdx.x; i < hw; i += 256) { const double v = x[base + i]; s += v; q += v * v; }
+    for (int i = threadIdx.x; i < hw; i += blockDim.x) { const double v = x[base + i]; s += v; q += v * v; }
     block_sum2(s, q, sh);
     const double mean = s / hw;
     double var = q / hw - mean * mean;
     var = var < 0.0 ? 0.0 : var;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps)), meanf = (float)mean;
     double sg = 0.0, sgx = 0.0;
-    for (int i = threadIdx.x; i < hw; i += 256) {
+    for (int i = threadIdx.x; i < hw; i += blockDim.x) {
         float g = dy[base + i];
         if (relu && !(y[base + i] > 0.f)) g = 0.f;
         const float xh = (x[base + i] - meanf) * rstd;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restri
     }
     block_sum2(sg, sgx, sh);
     const float mg = (float)(sg / hw), mgx = (float)(sgx / hw);
-    for (int i = threadIdx.x; i < hw; i += 256) {
+    for (int i = threadIdx.x; i < hw; i += blockDim.x) {
         float g = dy[base + i];
         if (relu && !(y[base + i] > 0.f)) g = 0.f;
         const float xh = (x[base + i] - meanf) * rstd;
@@ -198,20 +198,21 @@ __global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restri
     }
 }
 
-// BatchNorm2d in training mode (model/extractor.py:31-35 with the module in train()): one block per channel.
+// BatchNorm2d in training mode (model/extractor.py:31-35 with the module in train()): one block per channel (1024 threads for large
+// planes: with 64-128 channels the grid is a quarter of the chip, so the threads per block carry the memory parallelism).
 // forward: batch mean / biased variance over (N, H, W); y = (x - mean) * rstd * w + b [ReLU]; running statistics updated in place
 // with momentum (unbiased variance), save_mean / save_rstd kept for the backward.
-__global__ __launch_bounds__(256) void bn_train_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(1024) void bn_train_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ b, float* __restrict__ running_mean,
                                                            float* __restrict__ running_var, float* __restrict__ y,
                                                            float* __restrict__ save_mean, float* __restrict__ save_rstd, int n, int c, int hw,
                                                            float momentum, float eps, int relu) {
-    __shared__ double sh[8];
+    __shared__ double sh[32];
     const int ch = blockIdx.x;
     double s = 0.0, q = 0.0;
     for (int img = 0; img < n; ++img) {
         const float* p = x + ((size_t)img * c + ch) * hw;
-        for (int i = threadIdx.x; i < hw; i += 256) { const double v = p[i]; s += v; q += v * v; }
+        for (int i = threadIdx.x; i < hw; i += blockDim.x) { const double v = p[i]; s += v; q += v * v; }
     }
     block_sum2(s, q, sh);
     const double cnt = (double)n * hw;
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256) void bn_train_fwd_kernel(const float* __restri
     const float ww = w[ch], bb = b[ch];
     for (int img = 0; img < n; ++img) {
         const size_t o = ((size_t)img * c + ch) * hw;
-        for (int i = threadIdx.x; i < hw; i += 256) {
+        for (int i = threadIdx.x; i < hw; i += blockDim.x) {
             float v = (x[o + i] - meanf) * rstd * ww + bb;
             if (relu) v = fmaxf(v, 0.f);
             y[o + i] = v;
@@ -237,18 +238,18 @@ __global__ __launch_bounds__(256) void bn_train_fwd_kernel(const float* __restri
     }
 }
 // backward: g = dy * [y > 0]; dw = sum g * xhat, db = sum g, dx = w * rstd * (g - mean(g) - xhat * mean(g * xhat))
-__global__ __launch_bounds__(256) void bn_train_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+__global__ __launch_bounds__(1024) void bn_train_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ dy, const float* __restrict__ w,
                                                            const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
                                                            float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, int n, int c,
                                                            int hw, int relu) {
-    __shared__ double sh[8];
+    __shared__ double sh[32];
     const int ch = blockIdx.x;
     const float meanf = save_mean[ch], rstd = save_rstd[ch];
     double sg = 0.0, sgx = 0.0;
     for (int img = 0; img < n; ++img) {
         const size_t o = ((size_t)img * c + ch) * hw;
-        for (int i = threadIdx.x; i < hw; i += 256) {
+        for (int i = threadIdx.x; i < hw; i += blockDim.x) {
             float g = dy[o + i];
             if (relu && !(y[o + i] > 0.f)) g = 0.f;
             sg += g; sgx += (double)g * ((x[o + i] - meanf) * rstd);
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(256) void bn_train_bwd_kernel(const float* __restri
     const float mg = (float)(sg / cnt), mgx = (float)(sgx / cnt), k = w[ch] * rstd;
     for (int img = 0; img < n; ++img) {
         const size_t o = ((size_t)img * c + ch) * hw;
-        for (int i = threadIdx.x; i < hw; i += 256) {
+        for (int i = threadIdx.x; i < hw; i += blockDim.x) {
             float g = dy[o + i];
             if (relu && !(y[o + i] > 0.f)) g = 0.f;
             dx[o + i] = k * (g - mg - (x[o + i] - meanf) * rstd * mgx);
@@ -544,7 +545,7 @@ extern "C" int eemop_instnorm_fwd(const float* x, const float* res, int planes, 
 
 extern "C" int eemop_instnorm_bwd(const float* x, const float* y, const float* dy, int planes, int hw, int relu, float* dx, void* stream) {
     EEM_REQUIRE(x && y && dy && dx, "eemop_instnorm_bwd: NULL argument");
-    hipLaunchKernelGGL(instnorm_bwd_kernel, dim3(planes), dim3(256), 0, (hipStream_t)stream, x, y, dy, dx, hw, relu, 1e-5f);
+    hipLaunchKernelGGL(instnorm_bwd_kernel, dim3(planes), dim3(hw >= 16384 ? 1024 : 256), 0, (hipStream_t)stream, x, y, dy, dx, hw, relu, 1e-5f);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }
@@ -553,7 +554,7 @@ extern "C" int eemop_batchnorm_train_fwd(const float* x, const float* weight, co
                                          int n, int c, int hw, float momentum, float eps, int relu, float* y, float* save_mean,
                                          float* save_rstd, void* stream) {
     EEM_REQUIRE(x && weight && bias && running_mean && running_var && y && save_mean && save_rstd, "eemop_batchnorm_train_fwd: NULL argument");
-    hipLaunchKernelGGL(bn_train_fwd_kernel, dim3(c), dim3(256), 0, (hipStream_t)stream, x, weight, bias, running_mean, running_var, y,
+    hipLaunchKernelGGL(bn_train_fwd_kernel, dim3(c), dim3((long)n * hw >= 16384 ? 1024 : 256), 0, (hipStream_t)stream, x, weight, bias, running_mean, running_var, y,
                        save_mean, save_rstd, n, c, hw, momentum, eps, relu);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
@@ -563,7 +564,7 @@ extern "C" int eemop_batchnorm_train_bwd(const float* x, const float* y, const f
                                          const float* save_rstd, int n, int c, int hw, int relu, float* dx, float* dweight, float* dbias,
                                          void* stream) {
     EEM_REQUIRE(x && y && dy && weight && save_mean && save_rstd && dx && dweight && dbias, "eemop_batchnorm_train_bwd: NULL argument");
-    hipLaunchKernelGGL(bn_train_bwd_kernel, dim3(c), dim3(256), 0, (hipStream_t)stream, x, y, dy, weight, save_mean, save_rstd, dx, dweight,
+    hipLaunchKernelGGL(bn_train_bwd_kernel, dim3(c), dim3((long)n * hw >= 16384 ? 1024 : 256), 0, (hipStream_t)stream, x, y, dy, weight, save_mean, save_rstd, dx, dweight,
                        dbias, n, c, hw, relu);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;

@@ -53,6 +53,79 @@ __global__ __launch_bounds__(256) void lookup_bwd_kernel(LookupBwdArgs a) {
     add(y0 + 1, x0 + 1, tx * ty);
 }
 
+// The same adjoint as a gather.  Every output pixel p has a correlation map of its own per level, and its 81 taps (one fractional
+// offset, 9 x 9 integer offsets) touch a 10 x 10 window of that map: a thread owns one row of the window and adds, cell by cell, the
+// <= 4 taps whose bilinear corners fall on the cell - plain read-modify-writes (no two threads share a cell), 10 consecutive floats
+// per thread, and dout read as full-width runs over p (the scatter form issues 4 atomics per (tap, pixel), each on another map:
+// 25 M atomics on distinct lines per call at batch 4, 0.95 ms).  A tap's corner and weight are evaluated with lookup_kernel's own
+// arithmetic; only a corner that rounding moved by one cell beside an (almost) integer coordinate is not found - its weight is ~1e-7.
+__global__ __launch_bounds__(256) void lookup_bwd_rows_kernel(LookupBwdArgs a) {
+    const int hw = a.h * a.w;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)a.batch * 40 * hw) return;
+    const int p = idx % hw;
+    const int r = (idx / hw) % 10;
+    const int lvl = (idx / ((long)hw * 10)) % 4;
+    const int b = idx / ((long)hw * 40);
+    const float cx = a.coords[((size_t)b * 2 + 0) * hw + p], cy = a.coords[((size_t)b * 2 + 1) * hw + p];
+    const float sc = (float)(1 << lvl);
+    const int h = a.ph[lvl], w = a.pw[lvl];
+    if (h <= 0 || w <= 0) return;
+    auto tap = [](float c, float scv, int off, int size, int& i0, float& t) {
+        const float v = c / scv + (float)(off - 4);
+        const float vn = 2.f * v / (float)(size - 1) - 1.f;
+        const float iv = ((vn + 1.f) * 0.5f) * (float)(size - 1);
+        const float f = floorf(iv);
+        // clamped for the float -> int conversion only, 16 cells outside the map: nine taps span 9 cells, so a window whose first
+        // corner is clamped has no cell inside the map, and every corner that can reach the map is exact
+        i0 = (int)fminf(fmaxf(f, -16.f), (float)size + 16.f);
+        t = iv - f;
+    };
+    // channel k = i * 9 + jj samples x + (i - 4), y + (jj - 4) (the reference's transposed window)
+    int yb; float tyb;
+    tap(cy, sc, 0, h, yb, tyb);
+    const int Y = yb + r;
+    if (Y < 0 || Y >= h) return;
+    float wy[2]; int jy[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int jj = r - 1 + q;
+        jy[q] = jj;
+        wy[q] = 0.f;
+        if (jj >= 0 && jj <= 8) {
+            int y0; float ty;
+            tap(cy, sc, jj, h, y0, ty);
+            wy[q] = y0 == Y ? 1.f - ty : (y0 + 1 == Y ? ty : 0.f);
+        }
+    }
+    int x0[9]; float tx[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) tap(cx, sc, i, w, x0[i], tx[i]);
+    const float* dch = a.dout + ((size_t)b * 324 + lvl * 81) * hw + p;
+    float* row = a.dpyr[lvl] + ((size_t)b * hw + p) * h * w + (size_t)Y * w;
+    // dout of the two candidate rows for every x tap: d[q][i]
+    float d[2][9];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) d[q][i] = (wy[q] != 0.f) ? dch[(size_t)(i * 9 + jy[q]) * hw] * wy[q] : 0.f;
+    const int xb = x0[0];
+#pragma unroll
+    for (int c = 0; c < 10; ++c) {
+        const int X = xb + c;
+        if (X < 0 || X >= w) continue;
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = c - 1 + q;
+            if (i < 0 || i > 8) continue;
+            const float wx = x0[i] == X ? 1.f - tx[i] : (x0[i] + 1 == X ? tx[i] : 0.f);
+            sum += wx * (d[0][i] + d[1][i]);
+        }
+        row[X] += sum;
+    }
+}
+
 // adjoint of pool2_kernel (avg_pool2d(2, 2), floor): fine[2y+dy][2x+dx] += 0.25 * coarse[y][x]
 __global__ __launch_bounds__(256) void pool2_bwd_kernel(const float* __restrict__ dcoarse, float* __restrict__ dfine, long planes,
                                                         int h, int w) {
@@ -263,7 +336,9 @@ extern "C" int eraft_corr_lookup_bwd(const float* coords, const float* dout, int
         ph /= 2; pw /= 2;
     }
     a.coords = coords; a.dout = dout; a.batch = batch; a.h = h; a.w = w;
-    hipLaunchKernelGGL(lookup_bwd_kernel, dim3(nblocks((long)batch * 324 * h * w)), dim3(256), 0, st, a);
+    const char* sc = getenv("EEM_LOOKUP_BWD_SCATTER");            // read per call: the tests run both forms
+    if (sc && sc[0] == '1') hipLaunchKernelGGL(lookup_bwd_kernel, dim3(nblocks((long)batch * 324 * h * w)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(lookup_bwd_rows_kernel, dim3(nblocks((long)batch * 40 * h * w)), dim3(256), 0, st, a);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

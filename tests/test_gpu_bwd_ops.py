@@ -17,8 +17,12 @@ def rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
 
 
+@pytest.mark.parametrize("form", ["rows", "scatter"])
 @pytest.mark.parametrize("b,c,h,w", [(1, 16, 16, 24), (2, 32, 20, 28)])
-def test_corr_lookup_and_pyramid_bwd(b, c, h, w):
+def test_corr_lookup_and_pyramid_bwd(monkeypatch, b, c, h, w, form):
+    """form: the lookup adjoint as a gather over the rows of every pixel's 10 x 10 window (default) or as the per-tap atomic
+    scatter (EEM_LOOKUP_BWD_SCATTER=1, read per call)."""
+    monkeypatch.setenv("EEM_LOOKUP_BWD_SCATTER", "1" if form == "scatter" else "0")
     g = torch.Generator().manual_seed(5)
     f1 = torch.randn(b, c, h, w, generator=g, requires_grad=True)
     f2 = torch.randn(b, c, h, w, generator=g, requires_grad=True)

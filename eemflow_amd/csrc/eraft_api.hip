@@ -60,6 +60,8 @@ struct eraft_ctx {
     bool have_last = false;
     bool keep_stages = false;      // copy corr0 / net1 / mask1 / delta1 aside in the first iteration (parity tests)
     int frames_in_flight = 1;      // eraft_set_frames_in_flight
+    bool alt_corr = false;         // eraft_set_alternate_corr: correlation features on the fly, no all-pairs volume
+    Buf f2l[3];                    // avg-pooled fmap2, levels 1..3 (alt_corr)
     bool stages_valid = false;
 };
 
@@ -250,7 +252,33 @@ int build_pyramid(eraft_ctx* c, const float* f1, const float* f2, int batch, int
     return EEM_OK;
 }
 
+// alt_corr: the level sizes and the avg_pool2d(2) chain of fmap2 itself (pooling the volume's last two dimensions = pooling fmap2)
+int build_feature_pyramid(eraft_ctx* c, const float* f2, int batch, int ch, int h, int w, hipStream_t st) {
+    int rc;
+    c->ph[0] = h; c->pw[0] = w;
+    for (int l = 1; l < 4; ++l) { c->ph[l] = c->ph[l - 1] / 2; c->pw[l] = c->pw[l - 1] / 2; }
+    const float* src = f2;
+    for (int l = 1; l < 4; ++l) {
+        EEM_REQUIRE(c->ph[l] >= 1 && c->pw[l] >= 1, "correlation pyramid level %d is empty for a %dx%d feature map", l, h, w);
+        if ((rc = ensure(c->f2l[l - 1], (size_t)batch * ch * c->ph[l] * c->pw[l])) != EEM_OK) return rc;
+        if ((rc = er_pool2_launch(src, c->f2l[l - 1].p, (long)batch * ch, c->ph[l - 1], c->pw[l - 1], st)) != EEM_OK) return rc;
+        src = c->f2l[l - 1].p;
+    }
+    return EEM_OK;
+}
+
 int run_lookup(eraft_ctx* c, const float* coords, float* out, int out_ctotal, int batch, int h, int w, hipStream_t st) {
+    if (c->alt_corr) {
+        AltCorrArgs aa;
+        const size_t g = (size_t)h * w;
+        aa.f1 = c->fmap.p;
+        aa.f2[0] = c->fmap.p + (size_t)batch * 256 * g;
+        for (int l = 1; l < 4; ++l) aa.f2[l] = c->f2l[l - 1].p;
+        for (int l = 0; l < 4; ++l) { aa.ph[l] = c->ph[l]; aa.pw[l] = c->pw[l]; }
+        aa.coords = coords; aa.out = out; aa.batch = batch; aa.c = 256; aa.h = h; aa.w = w; aa.out_ctotal = out_ctotal;
+        aa.scale = 1.0f / 16.0f;                                 // 1 / sqrt(256)
+        return er_altcorr_launch(aa, st);
+    }
     LookupArgs la;
     for (int l = 0; l < 4; ++l) { la.pyr[l] = c->pyr[l].p; la.ph[l] = c->ph[l]; la.pw[l] = c->pw[l]; }
     la.coords = coords; la.out = out; la.batch = batch; la.h = h; la.w = w; la.out_ctotal = out_ctotal;
@@ -281,7 +309,7 @@ extern "C" void eraft_destroy(eraft_ctx* c) {
     Buf* all[] = {&c->padded, &c->s[0], &c->s[1], &c->s[2], &c->s[3], &c->s[4], &c->fmap, &c->net[0], &c->net[1], &c->inp,
                   &c->pyr[0], &c->pyr[1], &c->pyr[2], &c->pyr[3], &c->c0, &c->c1, &c->corr, &c->cor1, &c->corflo, &c->flo1,
                   &c->motion, &c->z, &c->rh, &c->fhid, &c->delta, &c->mhid, &c->mask, &c->st_corr0, &c->st_net1, &c->st_mask1,
-                  &c->st_delta1, &c->zeros};
+                  &c->st_delta1, &c->zeros, &c->f2l[0], &c->f2l[1], &c->f2l[2]};
     for (Buf* b : all) if (b->p) (void)hipFree(b->p);
     if (c->arena) (void)hipFree(c->arena);
     delete c;
@@ -381,7 +409,9 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
         if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
     }
     // ---- all-pairs correlation pyramid (:121)
-    if ((rc = build_pyramid(c, c->fmap.p, c->fmap.p + (size_t)B * 256 * g, B, 256, h8, w8, st)) != EEM_OK) return rc;
+    if (c->alt_corr) rc = build_feature_pyramid(c, c->fmap.p + (size_t)B * 256 * g, B, 256, h8, w8, st);
+    else rc = build_pyramid(c, c->fmap.p, c->fmap.p + (size_t)B * 256 * g, B, 256, h8, w8, st);
+    if (rc != EEM_OK) return rc;
     // ---- context network on image1 (:126-131): net = tanh(first half), inp = relu(second half)
     if ((rc = run_encoder(c, c->cnet, pad1, B, cin0, hp, wp, &feat, st)) != EEM_OK) return rc;
     {
@@ -475,6 +505,12 @@ extern "C" int eraft_keep_stages(eraft_ctx* c, int enable) {
     return EEM_OK;
 }
 
+extern "C" int eraft_set_alternate_corr(eraft_ctx* c, int enable) {
+    EEM_REQUIRE(c, "eraft_set_alternate_corr: NULL context");
+    c->alt_corr = enable != 0;
+    return EEM_OK;
+}
+
 extern "C" int eraft_set_frames_in_flight(eraft_ctx* c, int n) {
     EEM_REQUIRE(c && n >= 1, "eraft_set_frames_in_flight: need a context and n >= 1");
     c->frames_in_flight = n;
@@ -500,6 +536,7 @@ extern "C" int eraft_get_stage(eraft_ctx* c, const char* name, float* dst, size_
     else if (nm == "flow_low") { src = nullptr; dims[0] = c->B; dims[1] = 2; }
     else if (nm.size() == 4 && nm.compare(0, 3, "pyr") == 0 && nm[3] >= '0' && nm[3] <= '3') {
         const int l = nm[3] - '0';
+        EEM_REQUIRE(!c->alt_corr && c->pyr[l].p, "eraft_get_stage: '%s' does not exist - the last forward computed the correlation on the fly", name);
         src = c->pyr[l].p; dims[0] = c->B * c->h8 * c->w8; dims[1] = 1; dims[2] = c->ph[l]; dims[3] = c->pw[l];
     } else {
         eem_set_error("eraft_get_stage: unknown stage '%s'", name);

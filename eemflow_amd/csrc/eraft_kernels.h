@@ -27,6 +27,18 @@ struct LookupArgs {
 };
 int er_lookup_launch(const LookupArgs& a, hipStream_t st);
 
+// the same 324 features computed on the fly from fmap1 and the avg-pooled levels of fmap2 (no all-pairs volume)
+struct AltCorrArgs {
+    const float* f1;       // [B][C][H][W]
+    const float* f2[4];    // level l: [B][C][H >> l][W >> l] (avg_pool2d(2) chain of fmap2)
+    int ph[4], pw[4];
+    const float* coords;   // [B][2][H][W]
+    float* out;            // [B][out_ctotal][H][W], channels 0..323 are written
+    int batch, c, h, w, out_ctotal;
+    float scale;           // 1 / sqrt(C)
+};
+int er_altcorr_launch(const AltCorrArgs& a, hipStream_t st);
+
 // coords grid (model/model_utils.py:24-27): out[b][0][y][x] = x, out[b][1][y][x] = y  (+ init if not NULL)
 int er_coords_init_launch(float* coords0, float* coords1, const float* flow_init, int batch, int h, int w, hipStream_t st);
 // flow = coords1 - coords0 written into dst (channel offset dst_coff of a dst_ctotal-channel tensor)

@@ -307,6 +307,63 @@ __global__ __launch_bounds__(256) void lookup_tiled_kernel(LookupArgs a) {
     }
 }
 
+// On-the-fly form of the same lookup (the `alt_cuda_corr` pattern, model/flowformer/corr.py:60-91): no all-pairs
+// volume.  avg_pool2d of the volume over its last two dimensions is the correlation with avg_pool2d of fmap2 (linear), so a pixel's
+// 81 taps at level l are bilinear samples of  corr_l(p, q) = <fmap1[:, p], pool^l(fmap2)[:, q]> / sqrt(C)  over the 10 x 10 integer
+// cells its window touches.  One block per (pixel, level): the fmap1 column in LDS, a thread per window cell (a C-long dot product,
+// cells of a window row are consecutive floats of a feature plane), then a thread per tap with lookup_kernel's own corner / weight
+// arithmetic on the 10 x 10 cells (cells outside the map hold 0; a corner that rounding moves out of the window beside an integer
+// coordinate carries a weight ~1e-7 and is dropped).  C * 100 reads per pixel, level and iteration instead of 81 x 4: this path trades
+// ~250x the lookup's memory traffic for not holding B * (HW)^2 * 4/3 floats - 829 MB per sample at 1280x720 - and is off by default.
+__global__ __launch_bounds__(128) void altcorr_kernel(AltCorrArgs a) {
+    extern __shared__ float f1s[];                               // [C] then win[100]
+    float* win = f1s + a.c;
+    const int hw = a.h * a.w;
+    const int p = blockIdx.x, lvl = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x;
+    for (int ch = tid; ch < a.c; ch += 128) f1s[ch] = a.f1[((size_t)b * a.c + ch) * hw + p];
+    const float cx = a.coords[((size_t)b * 2 + 0) * hw + p], cy = a.coords[((size_t)b * 2 + 1) * hw + p];
+    const float sc = (float)(1 << lvl);
+    const int h = a.ph[lvl], w = a.pw[lvl];
+    auto tap = [](float c, float scv, int off, int size, int& i0, float& t) {
+        const float v = c / scv + (float)(off - 4);
+        const float vn = 2.f * v / (float)(size - 1) - 1.f;
+        const float iv = ((vn + 1.f) * 0.5f) * (float)(size - 1);
+        const float f = floorf(iv);
+        i0 = (int)fminf(fmaxf(f, -16.f), (float)size + 16.f);    // for the conversion only: a clamped window has no cell in the map
+        t = iv - f;
+    };
+    int xb, yb; float t0;
+    tap(cx, sc, 0, w, xb, t0);
+    tap(cy, sc, 0, h, yb, t0);
+    __syncthreads();
+    if (tid < 100) {
+        const int Y = yb + tid / 10, X = xb + tid % 10;
+        float acc = 0.f;
+        if (Y >= 0 && Y < h && X >= 0 && X < w) {
+            const float* q = a.f2[lvl] + (size_t)b * a.c * h * w + (size_t)Y * w + X;
+            const size_t plane = (size_t)h * w;
+#pragma unroll 8
+            for (int ch = 0; ch < a.c; ++ch) acc += f1s[ch] * q[ch * plane];
+        }
+        win[tid] = acc * a.scale;
+    }
+    __syncthreads();
+    if (tid < 81) {
+        const int i = tid / 9, jj = tid - i * 9;                 // channel i * 9 + jj samples x + (i - 4), y + (jj - 4)
+        int x0, y0; float tx, ty;
+        tap(cx, sc, i, w, x0, tx);
+        tap(cy, sc, jj, h, y0, ty);
+        auto at = [&](int yy, int xx) -> float {
+            const int r = yy - yb, cix = xx - xb;
+            return (r >= 0 && r < 10 && cix >= 0 && cix < 10) ? win[r * 10 + cix] : 0.f;
+        };
+        const float v = at(y0, x0) * (1.f - tx) * (1.f - ty) + at(y0, x0 + 1) * tx * (1.f - ty) + at(y0 + 1, x0) * (1.f - tx) * ty +
+                        at(y0 + 1, x0 + 1) * tx * ty;
+        a.out[((size_t)b * a.out_ctotal + lvl * 81 + tid) * hw + p] = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void coords_init_kernel(float* c0, float* c1, const float* init, int batch, int h, int w) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const int hw = h * w;
@@ -408,6 +465,12 @@ int er_lookup_launch(const LookupArgs& a, hipStream_t st) {
     static const bool plain = [] { const char* e = getenv("EEM_LOOKUP_PLAIN"); return e && e[0] == '1'; }();
     if (plain) hipLaunchKernelGGL(lookup_kernel, dim3(blocks((long)a.batch * 324 * a.h * a.w)), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(lookup_tiled_kernel, dim3(ceil_div(a.h * a.w, 64), 4, a.batch), dim3(256), 0, st, a);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int er_altcorr_launch(const AltCorrArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(altcorr_kernel, dim3(a.h * a.w, 4, a.batch), dim3(128), (a.c + 100) * sizeof(float), st, a);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

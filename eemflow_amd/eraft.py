@@ -143,6 +143,7 @@ class ERAFT(nn.Module):
         self._weights_version = None
         self.keep_stages = False       # True: the first iteration's corr0 / net1 / mask1 / delta1 stay readable through stage()
         self.frames_in_flight = 1      # >= 3: one of several replicas kept busy on separate streams (eraft_set_frames_in_flight)
+        self.alternate_corr = False    # True (inference route): correlation features on the fly, no all-pairs volume (RAFT's alternate_corr)
 
     def change_imagesize(self, img_size):
         self.image_size = img_size
@@ -189,6 +190,7 @@ class ERAFT(nn.Module):
             self._weights_version = fp
         _lib.check(L.eraft_keep_stages(self._ctx, 1 if self.keep_stages else 0))
         _lib.check(L.eraft_set_frames_in_flight(self._ctx, max(1, int(getattr(self, "frames_in_flight", 1)))))
+        _lib.check(L.eraft_set_alternate_corr(self._ctx, 1 if getattr(self, "alternate_corr", False) else 0))
         return self._ctx
 
     def forward(self, events1, events2, iters=12, flow_init=None, upsample=True, normal=False):

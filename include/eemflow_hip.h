@@ -210,6 +210,13 @@ int eraft_forward(eraft_ctx* ctx, const float* events1, const float* events2, in
  * "delta1" (after the first update). */
 int eraft_keep_stages(eraft_ctx* ctx, int enable);
 
+/* Correlation features computed on the fly instead of from an all-pairs volume (1: on, 0 = default: the volume stays resident).
+ * Replaces the `alt_cuda_corr` pattern of model/flowformer/corr.py:60-91 (RAFT's `alternate_corr`): the 81 taps of a
+ * pixel at level l are bilinear samples of <fmap1[:, p], avg_pool2d^l(fmap2)[:, q]> / sqrt(C) over the 10 x 10 cells its window
+ * touches - no B * (HW)^2 * 4/3 floats (829 MB per sample at 1280x720), ~250x the lookup's memory traffic per iteration.  Same
+ * features up to summation order; eraft_get_stage("pyr<l>") is not available in this mode. */
+int eraft_set_alternate_corr(eraft_ctx* ctx, int enable);
+
 /* Throughput hint, as eemflow_set_frames_in_flight: the application keeps `n` E-RAFT forwards in flight on this GPU (one context
  * and HIP stream each).  With n >= 3 the 16-aligned stride-1 convs use 4-row tiles from 512 blocks on (2 048 otherwise): the
  * other frames fill the CUs a short launch leaves idle, and each weight fragment is read half as often (640x480, 12 iterations,

@@ -128,6 +128,29 @@ def test_lds_tiled_conv_equals_generic_conv(monkeypatch):
     assert maxerr(fast, plain) < 2e-4 and float(plain.abs().max()) > 1e-3
 
 
+@pytest.mark.parametrize("b,h,w,iters", [(2, 256, 352, 3), (1, 480, 640, 12), (1, 136, 200, 2)])
+def test_on_the_fly_correlation_equals_the_resident_volume(b, h, w, iters):
+    """ERAFT.alternate_corr (eraft_set_alternate_corr; the alt_cuda_corr pattern): the 324 correlation features from
+    <fmap1, pooled fmap2> over each pixel's 10 x 10 window instead of from the all-pairs volume - the same first lookup to summation
+    order, the same flow within the flow tolerance after 12 iterations, and the oracle's flow."""
+    net, sd = make_net(33)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(34, b, h, w))
+    with torch.no_grad():
+        vol = torch.stack(net(e1.to(DEV), e2.to(DEV), iters=iters)[1]).clone()
+        corr_vol = net.stage("corr0").clone()
+        net.alternate_corr = True
+        fly = torch.stack(net(e1.to(DEV), e2.to(DEV), iters=iters)[1]).clone()
+        corr_fly = net.stage("corr0").clone()
+        with pytest.raises(_lib.EEMFlowHipError, match="on the fly"):
+            net.stage("pyr0")
+    assert maxerr(corr_fly, corr_vol) < 2e-5 * max(1.0, float(corr_vol.abs().max()))
+    assert maxerr(fly, vol) < (FLOW_TOL if iters > 3 else 1e-4) and float(vol.abs().max()) > 1e-3
+    if h * w <= 256 * 352:
+        ref, _ = R.eraft_forward(sd, e1, e2, iters=iters)
+        assert maxerr(fly[-1], ref[-1]) < FLOW_TOL
+
+
 def test_frames_in_flight_hint_changes_tiles_not_results():
     """eraft_set_frames_in_flight >= 3: the LDS-tiled convs of 512..2047 blocks use 4-row tiles instead of 2-row ones (batch 4 at
     640x480: the update block).  Same k order per output: the flow does not change beyond round-off, and stays within tolerance."""

@@ -15,6 +15,7 @@ net = ERAFT("", 5).eval()
 sd = seeded_from_shapes({k: tuple(v.shape) for k, v in net.state_dict().items()}, 0)
 net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
 net = net.cuda(); net.change_imagesize((h, w))
+net.alternate_corr = os.environ.get("ERAFT_ALTERNATE_CORR", "0") == "1"
 e1, e2 = (torch.from_numpy(a).cuda() for a in synthetic_voxel_pair(1, b, h, w))
 with torch.no_grad():
     for _ in range(2): net(e1, e2, iters=iters)

@@ -41,6 +41,7 @@ struct GConvArgs {
     const float* e1; int e1_ctotal, e1_coff;
     float out_scale;       // final multiplier (1 = none)
     int in_flight;         // frames the application keeps in flight on this GPU (0 / 1: one): tile choices favour CU time over latency
+    const float* wfew;     // packed by fewout_pack (layers of <= 8 couts, 3x3 stride 1, one input segment), or NULL
 };
 
 // number of packed floats / packing for weights [cout][sum(c_s)][kh][kw] read as segments of sizes cs[0..nseg)
@@ -52,4 +53,11 @@ bool gconv16_shape(int cout, const int* cs, int nseg, int kh, int kw, int stride
 size_t gconv16_packed_floats(int cout, const int* cs, int nseg, int kh, int kw);
 void gconv16_pack(const float* w, int cout, const int* cs, int nseg, int kh, int kw, float* packed);
 bool gconv16_supported(const GConvArgs& a);
+// Layers of <= 8 output channels (EEMFlow+'s mask estimator tail 176 -> 8 -> 3, the 32 -> 2 flow convs): on the matrix cores a
+// 32-cout tile is 75-94 % padding, so these run as a direct convolution on the vector pipe - a thread per pixel, the weights of a
+// (channel, tap) as one uniform 32-byte load.  [cin][kh*kw][8] floats.
+size_t fewout_packed_floats(int cin, int kh, int kw);
+void fewout_pack(const float* w, int cout, int cin, int kh, int kw, float* packed);
+bool fewout_supported(const GConvArgs& a);
+int fewout_launch(const GConvArgs& a, hipStream_t stream);
 int gconv16_launch(const GConvArgs& a, hipStream_t stream);

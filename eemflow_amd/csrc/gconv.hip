@@ -263,8 +263,112 @@ void gconv_pack(const float* w, int cout, const int* cs, int nseg, int kh, int k
     }
 }
 
+namespace {
+
+// direct 3x3 convolution for <= 8 output channels.  Block = 64 consecutive pixels x FEW_WAVES channel groups: wave g takes the
+// channels [g * cpw, (g + 1) * cpw) of all 64 pixels (every tap is a 256-byte run per wave; the 8 weights of a (channel, tap) are
+// one uniform 32-byte load, scalar registers feed the FMAs), the partial sums meet in LDS and thread (co, pixel) finishes one output.
+// Splitting the channels rather than the pixels over the waves is what fills the chip: 180 x 320 pixels are 900 wave-rows, less
+// than one per SIMD, and a lone wave per SIMD cannot hide its own load latency.
+constexpr int FEW_WAVES = 8;
+
+__global__ __launch_bounds__(FEW_WAVES * 64) void fewout_kernel(GConvArgs a, int cpw) {
+    __shared__ float part[FEW_WAVES][8][64];
+    const int hw = a.hin * a.win;
+    const int lane = threadIdx.x & 63;
+    const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long total = (long)a.n * hw;
+    const long idx = (long)blockIdx.x * 64 + lane;
+    const bool live = idx < total;
+    const long idc = live ? idx : total - 1;
+    const int p = idc % hw, n = idc / hw;
+    const int y = p / a.win, x = p - y * a.win;
+    const GConvSeg& sg = a.seg[0];
+    const int c0 = g * cpw, c1 = min(c0 + cpw, sg.c);
+    const float* in = sg.ptr + ((size_t)n * sg.ctotal + sg.coff + c0) * hw;
+    float acc[8];
+#pragma unroll
+    for (int co = 0; co < 8; ++co) acc[co] = 0.f;
+    int off[9];
+    bool keep[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        const bool ok = yy >= 0 && yy < a.hin && xx >= 0 && xx < a.win;
+        off[t] = ok ? yy * a.win + xx : p;
+        keep[t] = ok;
+    }
+    const float* w = a.wfew + (size_t)c0 * 72;
+    float v[9], vn[9];
+    if (c0 < c1) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) v[t] = in[off[t]];
+    }
+    for (int c = c0; c < c1; ++c) {
+        const float* nxt = in + (size_t)(c + 1 < c1 ? c + 1 - c0 : c - c0) * hw;    // the next channel's taps fly under this one's FMAs
+#pragma unroll
+        for (int t = 0; t < 9; ++t) vn[t] = nxt[off[t]];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float vv = keep[t] ? v[t] : 0.f;
+            const float* w8 = w + ((size_t)(c - c0) * 9 + t) * 8;
+#pragma unroll
+            for (int co = 0; co < 8; ++co) acc[co] += vv * w8[co];
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) v[t] = vn[t];
+    }
+#pragma unroll
+    for (int co = 0; co < 8; ++co) part[g][co][lane] = acc[co];
+    __syncthreads();
+    // thread (co = g, pixel = lane) sums the channel groups in order and finishes the output
+    const int co = g;
+    if (!live || co >= a.cout) return;
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < FEW_WAVES; ++k) r += part[k][co][lane];
+    if (a.scale) r *= a.scale[co];
+    if (a.shift) r += a.shift[co];
+    if (a.act == GACT_RELU) r = r > 0.f ? r : 0.f;
+    else if (a.act == GACT_LEAKY) r = r > 0.f ? r : 0.1f * r;
+    else if (a.act == GACT_SIGMOID) r = 1.f / (1.f + expf(-r));
+    else if (a.act == GACT_TANH) r = tanhf(r);
+    if (a.epi == GEPI_ADD) r += a.e0[((size_t)n * a.e0_ctotal + a.e0_coff + co) * hw + p];
+    const int oc = a.out_coff + co * (a.out_cmul > 1 ? a.out_cmul : 1);
+    a.out[((size_t)n * a.out_ctotal + oc) * hw + p] = r * a.out_scale;
+}
+
+}  // namespace
+
+size_t fewout_packed_floats(int cin, int kh, int kw) { return (size_t)cin * kh * kw * 8; }
+
+void fewout_pack(const float* w, int cout, int cin, int kh, int kw, float* packed) {
+    const int taps = kh * kw;
+    for (int c = 0; c < cin; ++c)
+        for (int t = 0; t < taps; ++t)
+            for (int co = 0; co < 8; ++co)
+                packed[((size_t)c * taps + t) * 8 + co] = co < cout ? w[((size_t)co * cin + c) * taps + t] : 0.f;
+}
+
+bool fewout_supported(const GConvArgs& a) {
+    const char* e = getenv("EEM_NO_FEWOUT");                         // read per call: a test flips it inside one process
+    if (e && e[0] == '1') return false;
+    return a.wfew && a.nseg == 1 && a.cout <= 8 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.tstride <= 1 && a.pad_h == 1 && a.pad_w == 1 &&
+           a.seg[0].cmul <= 1 && a.seg[0].gate == nullptr && (a.epi == GEPI_PLAIN || a.epi == GEPI_ADD) && a.hout == a.hin && a.wout == a.win &&
+           (long)a.hin * a.win >= 4096;                              // small maps: the split-K launch of the generic kernel
+}
+
+int fewout_launch(const GConvArgs& a, hipStream_t stream) {
+    const long n = (long)a.n * a.hin * a.win;
+    const int cpw = (a.seg[0].c + FEW_WAVES - 1) / FEW_WAVES;
+    hipLaunchKernelGGL(fewout_kernel, dim3((unsigned)((n + 63) / 64)), dim3(FEW_WAVES * 64), 0, stream, a, cpw);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
 int gconv_launch(const GConvArgs& a, hipStream_t stream) {
     EEM_REQUIRE(a.nseg >= 1 && a.nseg <= 3 && a.n >= 1 && a.cout >= 1, "gconv_launch: bad arguments");
+    if (fewout_supported(a)) return fewout_launch(a, stream);
     if (gconv16_supported(a)) return gconv16_launch(a, stream);
     const int hwo = a.hout * a.wout;
     const int cot = ceil_div(a.cout, 32);

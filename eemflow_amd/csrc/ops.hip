@@ -10,6 +10,7 @@
 // table of a layer shape is built once (host, cached) and applied on the device in front of every launch.
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <string>
@@ -277,6 +278,8 @@ struct Plan {
     size_t n = 0;
     int* idx16 = nullptr;      // the same for gconv16's fragment-order stream (stride-1 convs with 16-aligned channel counts), or NULL
     size_t n16 = 0;
+    int* idxfew = nullptr;     // the same for the few-output direct kernel ([cin][tap][8], <= 8 couts, 3x3, one segment), or NULL
+    size_t nfew = 0;
 };
 std::map<std::string, Plan> g_plans;              // per process; the tables depend on layer shapes only
 std::mutex g_plans_mutex;                         // autograd runs backward ops on its own thread
@@ -313,11 +316,31 @@ void plan_add16(Plan& p, const float* iw, int cout, const int* cs, int nseg, int
     }
 }
 
+void plan_addfew(Plan& p, const float* iw, int cout, const int* cs, int nseg, int kh, int kw) {
+    if (nseg != 1 || cout > 8 || kh != 3 || kw != 3) return;
+    std::vector<float> pk(fewout_packed_floats(cs[0], kh, kw), 0.f);
+    fewout_pack(iw, cout, cs[0], kh, kw, pk.data());
+    std::vector<int> idx(pk.size());
+    for (size_t i = 0; i < pk.size(); ++i) idx[i] = (int)pk[i];
+    p.nfew = idx.size();
+    if (hipMalloc(&p.idxfew, p.nfew * sizeof(int)) != hipSuccess ||
+        hipMemcpy(p.idxfew, idx.data(), p.nfew * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+        p.idxfew = nullptr;
+        p.nfew = 0;
+    }
+}
+
 // Packs the weights for the launch described by `a` (everything but the weight pointers filled in): the LDS-tiled kernel's stream
 // when the launch qualifies for it, else the generic kernel's.
 int pack_for(const Plan* pl, const float* w, GConvArgs& a, hipStream_t st) {
     int rc;
     float* pk = nullptr;
+    if (pl->idxfew) {
+        if ((rc = scratch_get(g_scratch[0], std::max(pl->nfew, std::max(pl->n16, pl->n)), &pk)) != EEM_OK) return rc;
+        a.wfew = pk;
+        if (fewout_supported(a)) return repack_launch(w, pl->idxfew, pk, (long)pl->nfew, st);
+        a.wfew = nullptr;
+    }
     if (pl->idx16) {
         float* zp = nullptr;
         if ((rc = scratch_get(g_scratch[1], 1024, &zp)) != EEM_OK) return rc;
@@ -356,6 +379,7 @@ int plan_fwd(int cout, const int* cs, int nseg, int kh, int kw, Plan** out) {
         EEM_HIP_CHECK(hipMalloc(&p.idx, p.n * sizeof(int)));
         EEM_HIP_CHECK(hipMemcpy(p.idx, idx.data(), p.n * sizeof(int), hipMemcpyHostToDevice));
         plan_add16(p, iw.data(), cout, cs, nseg, kh, kw);
+        plan_addfew(p, iw.data(), cout, cs, nseg, kh, kw);
         it = g_plans.emplace(key, p).first;
     }
     *out = &it->second;
@@ -390,6 +414,7 @@ int plan_bwd(int cout, int cin, int ci0, int cic, int kh, int kw, Plan** out) {
         EEM_HIP_CHECK(hipMalloc(&p.idx, p.n * sizeof(int)));
         EEM_HIP_CHECK(hipMemcpy(p.idx, idx.data(), p.n * sizeof(int), hipMemcpyHostToDevice));
         plan_add16(p, T.data(), cic, cs, 1, kh, kw);
+        plan_addfew(p, T.data(), cic, cs, 1, kh, kw);
         it = g_plans.emplace(key, p).first;
     }
     *out = &it->second;

@@ -85,3 +85,23 @@ def test_warp_bwd(mode, fn):
 def test_bwd_ops_reject_cpu_tensors():
     with pytest.raises(Exception):
         ops_bwd.warp_bwd(torch.zeros(1, 1, 4, 4), torch.zeros(1, 2, 4, 4), torch.zeros(1, 1, 4, 4), 0)
+
+
+@pytest.mark.parametrize("cin,cout,h,w,b", [(176, 8, 72, 96, 1), (184, 3, 90, 160, 2), (32, 2, 64, 65, 1)])
+def test_few_output_conv_vs_torch_and_generic_kernel(monkeypatch, cin, cout, h, w, b):
+    """Layers of <= 8 output channels at >= 4096 pixels (EEMFlow+'s mask estimator tail, model/cdc_model.py dense blocks) run as a
+    direct convolution on the vector pipe (gconv.h: fewout_*); EEM_NO_FEWOUT=1 (read per call) keeps them on the matrix-core kernel."""
+    from eemflow_amd import ops
+    g = torch.Generator().manual_seed(cin + cout)
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1)
+    x = torch.randn(b, cin, h, w, generator=g)
+    ref = torch.nn.functional.leaky_relu(conv(x.double().float()), 0.1).detach()
+    convd = conv.to(DEV)
+    with torch.no_grad():
+        few = ops.conv2d(convd, x.to(DEV), act=ops.ACT_LEAKY).cpu()
+        monkeypatch.setenv("EEM_NO_FEWOUT", "1")
+        gen = ops.conv2d(convd, x.to(DEV), act=ops.ACT_LEAKY).cpu()
+    scale = float(ref.abs().max())
+    assert float((few - ref).abs().max()) < 2e-5 * max(scale, 1.0) * (cin / 32) ** 0.5
+    assert float((gen - ref).abs().max()) < 2e-5 * max(scale, 1.0) * (cin / 32) ** 0.5
+    assert not torch.equal(few, gen) or cin < 8        # two kernels, two summation orders

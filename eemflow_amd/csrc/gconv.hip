@@ -22,12 +22,14 @@ __device__ __forceinline__ float g_act(float v, int act) {
     }
 }
 
-// SPLITK (with NPW = MTW = 1): the block owns ONE 32-pixel x 32-cout tile and its four waves take the k-batches round
-// robin, meet in LDS and share the epilogue - for layers whose tile count leaves most SIMDs empty (E-RAFT's 60x80
-// update block at batch 1: 152 blocks of 4 single-tile waves for 256 CUs).
-template <int NPW, int MTW, bool SPLITK = false, int UU = 0>
-__global__ __launch_bounds__(256) void gconv_kernel(GConvArgs a) {
+// SPLITK = 4 / 8 / 16 waves (with NPW = MTW = 1): the block owns ONE 32-pixel x 32-cout tile and its waves take the k-batches
+// round robin, meet in LDS and share the epilogue - for layers whose tile count leaves most SIMDs empty (E-RAFT's 60x80
+// update block at batch 1: 152 blocks of 4 single-tile waves for 256 CUs; EEMFlow+'s estimator at 23 x 40 and 45 x 80: 29 / 113
+// tiles, where a wave's time is the latency of its batches' first-touch weight loads and more waves mean fewer batches each).
+template <int NPW, int MTW, int SPLITK = 0, int UU = 0>
+__global__ __launch_bounds__(SPLITK ? SPLITK * 64 : 256) void gconv_kernel(GConvArgs a) {
     static_assert(!SPLITK || (NPW == 1 && MTW == 1), "split-K is built for single-tile waves");
+    static_assert(SPLITK == 0 || SPLITK == 4 || SPLITK == 8 || SPLITK == 16, "split-K wave counts");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int n = blockIdx.z;
@@ -81,7 +83,8 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvArgs a) {
     };
     auto advance = [&](Pos q) {                              // to this wave's next batch
         q = advance1(q);
-        if (SPLITK) { q = advance1(q); q = advance1(q); q = advance1(q); }
+#pragma unroll
+        for (int w = 1; w < SPLITK; ++w) q = advance1(q);
         return q;
     };
     auto load = [&](const Pos& q, float (&av)[U][MTW], float (&bv)[U][NPW]) {
@@ -203,18 +206,21 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvArgs a) {
         a.out[((size_t)n * a.out_ctotal + oc) * hwo + p] = v * a.out_scale;
     };
     if (SPLITK) {
-        // [wave][register][lane]: every wave leaves its 16 partial sums, then wave w finishes registers 4w..4w+3
-        __shared__ float red[4][16][64];
+        // [wave][register][lane]: every wave leaves its 16 partial sums, then wave w finishes registers R*w .. R*w + R-1
+        constexpr int SK = SPLITK ? SPLITK : 4, R = 16 / SK;
+        __shared__ float red[SK][16][64];
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[0][0][r];
         __syncthreads();
         const int p = p0 + j;
         if (!pv[0]) return;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int r = wave * 4 + rr;
-            const float v = (red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane]);
-            const int co = cot0 * 32 + rr + 8 * wave + 4 * h;
+        for (int rr = 0; rr < R; ++rr) {
+            const int r = wave * R + rr;
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < SK; q += 4) v += (red[q][r][lane] + red[q + 1][r][lane]) + (red[q + 2][r][lane] + red[q + 3][r][lane]);
+            const int co = cot0 * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (co < a.cout) finish(v, co, p);
         }
         return;
@@ -272,7 +278,7 @@ namespace {
 // than one per SIMD, and a lone wave per SIMD cannot hide its own load latency.
 constexpr int FEW_WAVES = 8;
 
-__global__ __launch_bounds__(FEW_WAVES * 64) void fewout_kernel(GConvArgs a, int cpw) {
+__global__ __launch_bounds__(FEW_WAVES * 64, 8) void fewout_kernel(GConvArgs a, int cpw) {
     __shared__ float part[FEW_WAVES][8][64];
     const int hw = a.hin * a.win;
     const int lane = threadIdx.x & 63;
@@ -299,15 +305,14 @@ __global__ __launch_bounds__(FEW_WAVES * 64) void fewout_kernel(GConvArgs a, int
         keep[t] = ok;
     }
     const float* w = a.wfew + (size_t)c0 * 72;
-    float v[9], vn[9];
-    if (c0 < c1) {
+    // two register sets, the next channel's nine taps in flight under this channel's 72 FMAs (the last request repeats a channel)
+    float va[9], vb[9];
+    auto request = [&](float (&v)[9], int c) __attribute__((always_inline)) {
+        const float* plane = in + (size_t)(min(c, c1 - 1) - c0) * hw;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) v[t] = in[off[t]];
-    }
-    for (int c = c0; c < c1; ++c) {
-        const float* nxt = in + (size_t)(c + 1 < c1 ? c + 1 - c0 : c - c0) * hw;    // the next channel's taps fly under this one's FMAs
-#pragma unroll
-        for (int t = 0; t < 9; ++t) vn[t] = nxt[off[t]];
+        for (int t = 0; t < 9; ++t) v[t] = plane[off[t]];
+    };
+    auto fma = [&](const float (&v)[9], int c) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const float vv = keep[t] ? v[t] : 0.f;
@@ -315,8 +320,17 @@ __global__ __launch_bounds__(FEW_WAVES * 64) void fewout_kernel(GConvArgs a, int
 #pragma unroll
             for (int co = 0; co < 8; ++co) acc[co] += vv * w8[co];
         }
-#pragma unroll
-        for (int t = 0; t < 9; ++t) v[t] = vn[t];
+    };
+    if (c0 < c1) {
+        request(va, c0);
+#pragma unroll 1
+        for (int c = c0; c < c1; c += 2) {
+            request(vb, c + 1);
+            fma(va, c);
+            if (c + 1 >= c1) break;
+            request(va, c + 2);
+            fma(vb, c + 1);
+        }
     }
 #pragma unroll
     for (int co = 0; co < 8; ++co) part[g][co][lane] = acc[co];
@@ -406,7 +420,15 @@ int gconv_launch(const GConvArgs& a, hipStream_t stream) {
         const long plain_blocks = (long)ceil_div(hwo, 128) * cot * a.n;
         if (!no_splitk && ksteps >= 128 && (plain_blocks < splitk_max || (cot == 1 && ksteps >= 512 && plain_blocks < 4096))) {
             dim3 grid(ceil_div(hwo, 32), cot, a.n);
-            hipLaunchKernelGGL((gconv_kernel<1, 1, true>), grid, dim3(256), 0, stream, a);
+            // tiles that leave most of the chip empty: more waves per tile, fewer (latency-bound) batches per wave
+            const long tiles = (long)grid.x * cot * a.n;
+            const int batches = ksteps / 16;
+            static const int force = [] { const char* e = getenv("EEM_SPLITK_WAVES"); return e ? atoi(e) : 0; }();
+            int skw = tiles <= 64 && batches >= 32 ? 16 : tiles <= 160 && batches >= 16 ? 8 : 4;
+            if (force) skw = force;
+            if (skw == 16) hipLaunchKernelGGL((gconv_kernel<1, 1, 16>), grid, dim3(1024), 0, stream, a);
+            else if (skw == 8) hipLaunchKernelGGL((gconv_kernel<1, 1, 8>), grid, dim3(512), 0, stream, a);
+            else hipLaunchKernelGGL((gconv_kernel<1, 1, 4>), grid, dim3(256), 0, stream, a);
         } else {
             dim3 grid(ceil_div(hwo, 128), cot, a.n);
             hipLaunchKernelGGL((gconv_kernel<1, 1>), grid, dim3(256), 0, stream, a);

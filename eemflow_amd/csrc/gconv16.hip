@@ -71,8 +71,9 @@ __global__ __launch_bounds__(256, (KH * KW == 9 && THT == 4 && WM == 4) ? 3 : 4)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, g = lane >> 4;
     // WM = waves along the couts (16 each): 4 -> a block covers 64 couts and every wave all TH rows; 2 -> 32 couts (layers of
-    // <= 32 couts), the two wave pairs split the rows
+    // <= 32 couts), the two wave pairs split the rows; 1 -> 16 couts (EEMFlow+'s 160 -> 16 estimator layer), a row per wave
     constexpr int WP = 4 / WM, NR = C::TH / WP;                  // pixel-row groups, rows per wave
+    static_assert(NR >= 1, "a wave needs a row");
     const int wm = wave % WM, wp = wave / WM;
     const int mtg = blockIdx.y * WM + wm;                        // global 16-cout tile of this wave
     const int n = blockIdx.z, cc = mtg >> 2, mt = mtg & 3;
@@ -212,6 +213,7 @@ int launch_wm(const GConvArgs& a, const float* wpk16, const float* zero_page, hi
 
 template <int KH, int KW, int THT>
 int launch_th(const GConvArgs& a, const float* wpk16, const float* zero_page, hipStream_t stream) {
+    if (a.cout <= 16) return launch_wm<KH, KW, 4, 1>(a, wpk16, zero_page, stream);
     if (a.cout <= 32) return launch_wm<KH, KW, THT, 2>(a, wpk16, zero_page, stream);
     return launch_wm<KH, KW, THT, 4>(a, wpk16, zero_page, stream);
 }

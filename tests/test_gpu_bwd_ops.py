@@ -105,3 +105,20 @@ def test_few_output_conv_vs_torch_and_generic_kernel(monkeypatch, cin, cout, h, 
     assert float((few - ref).abs().max()) < 2e-5 * max(scale, 1.0) * (cin / 32) ** 0.5
     assert float((gen - ref).abs().max()) < 2e-5 * max(scale, 1.0) * (cin / 32) ** 0.5
     assert not torch.equal(few, gen) or cin < 8        # two kernels, two summation orders
+
+
+def test_sixteen_output_conv_on_the_lds_tiled_kernel(monkeypatch):
+    """160 -> 16 (EEMFlow+'s fourth estimator layer): one 16-cout tile, a tile row per wave (gconv16.hip, WM = 1) against torch and
+    against the generic kernel (EEM_NO_GCONV16=1, read per call)."""
+    from eemflow_amd import ops
+    g = torch.Generator().manual_seed(16)
+    conv = torch.nn.Conv2d(160, 16, 3, padding=1)
+    x = torch.randn(2, 160, 96, 128, generator=g)
+    ref = torch.nn.functional.leaky_relu(conv(x), 0.1).detach()
+    convd = conv.to(DEV)
+    with torch.no_grad():
+        tiled = ops.conv2d(convd, x.to(DEV), act=ops.ACT_LEAKY).cpu()
+        monkeypatch.setenv("EEM_NO_GCONV16", "1")
+        gen = ops.conv2d(convd, x.to(DEV), act=ops.ACT_LEAKY).cpu()
+    assert float((tiled - ref).abs().max()) < 1e-4 and float((gen - ref).abs().max()) < 1e-4
+    assert not torch.equal(tiled, gen)

@@ -24,11 +24,24 @@ int pensure(PBuf& b, size_t floats) {
     return EEM_OK;
 }
 
+// a buffer whose spare channels are multiplied by zero weights: no NaN bit patterns may lie in it
+int pensure_zeroed(PBuf& b, size_t floats) {
+    if (floats <= b.cap) return EEM_OK;
+    int rc = pensure(b, floats);
+    if (rc != EEM_OK) return rc;
+    EEM_HIP_CHECK(hipMemset(b.p, 0, floats * sizeof(float)));
+    return EEM_OK;
+}
+
 struct PLayer { size_t wpk = 0, wpk16 = 0, wtail = 0, wfew = 0, bias = 0; bool has16 = false, has_tail = false, has_few = false; int cin = 0, cout = 0, k = 3, stride = 1; };
 
 const int kTaps[53] = {0,  2,  4,  6,  8,  10, 12, 14, 16, 18, 20, 21, 22, 23, 24, 26, 28, 29, 30, 31, 32, 33, 34, 36, 38, 39, 40,
                        41, 42, 44, 46, 47, 48, 49, 50, 51, 52, 54, 56, 57, 58, 59, 60, 62, 64, 66, 68, 70, 72, 74, 76, 78, 80};
 constexpr int kDW = 96, kDIn = 87, kDense = 184;
+// The decoder input [53 correlation taps | 32 rconv | 2 flow] lives in a 96-channel buffer and dec1 is packed as 96 -> 96 with zero
+// weights for the nine spare channels: 16-aligned, it runs on the LDS-tiled kernel (180 x 320: 170 -> 118 us).  The spare channels hold
+// whatever a coarser level left there (finite activations; the buffer is zeroed when allocated), times zero.
+constexpr int kCat = 96;
 
 }  // namespace
 
@@ -146,7 +159,7 @@ int run_decoder(eemplus_ctx* c, int l, int B, int h, int w, const float* residua
         };
         TailConvLaunch L;
         L.batch = B; L.h = h; L.w = w; L.ksize = 3;
-        L.njobs = 1; L.job[0] = job(c->dec1[l], c->cat.p, kDIn, 0, c->d[0].p, kDW, 0, 1);
+        L.njobs = 1; L.job[0] = job(c->dec1[l], c->cat.p, kCat, 0, c->d[0].p, kDW, 0, 1);
         if ((rc = tail_conv_launch(L, st)) != EEM_OK) return rc;
         for (int layer = 0; layer < 3; ++layer) {
             L.njobs = 0;
@@ -159,7 +172,7 @@ int run_decoder(eemplus_ctx* c, int l, int B, int h, int w, const float* residua
         L.njobs = 1; L.job[0] = job(c->dec6[l], c->t64.p, 64, 0, c->t32.p, 32, 0, 1);
         if ((rc = tail_conv_launch(L, st)) != EEM_OK) return rc;
     } else {
-        if ((rc = conv(c, c->dec1[l], c->cat.p, kDIn, 0, B, h, w, c->d[0].p, kDW, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+        if ((rc = conv(c, c->dec1[l], c->cat.p, kCat, 0, B, h, w, c->d[0].p, kDW, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
         for (int layer = 0; layer < 3; ++layer)
             for (int gi = 0; gi < G; ++gi) {
                 // group gi reads channels [gi*per, (gi+1)*per); channel_shuffle puts its output j at j*G + gi
@@ -249,7 +262,13 @@ extern "C" int eemplus_load_weights(eemplus_ctx* c, const float* flat, size_t nf
     for (int i = 0; i < 4; ++i) (void)cur.take(2 * 2 * 4 * 4 + 2);                     // up3..up6: registered, never used
     const int per = kDW / groups;
     for (int l = 2; l <= 6; ++l) {
-        layer(c->dec1[l], kDIn, kDW, 3, 1);
+        {
+            const float* w = cur.take((size_t)kDW * kDIn * 9);
+            const float* b = cur.take(kDW);
+            std::vector<float> wp((size_t)kDW * kCat * 9, 0.f);
+            for (int co = 0; co < kDW; ++co) memcpy(wp.data() + (size_t)co * kCat * 9, w + (size_t)co * kDIn * 9, (size_t)kDIn * 9 * sizeof(float));
+            mk(pk, c->dec1[l], wp.data(), b, kCat, kDW, 3, 1);
+        }
         for (int j = 0; j < 3; ++j) {
             const float* w = cur.take((size_t)kDW * per * 9);
             const float* b = cur.take(kDW);
@@ -301,7 +320,7 @@ static int run_level(eemplus_ctx* c, int l, int B, const float* forced_init, hip
     if ((rc = pensure(c->dense, B * kDense * g)) != EEM_OK || (rc = pensure(c->a2, B * 32 * g)) != EEM_OK ||
         (rc = pensure(c->xout, B * 3 * g)) != EEM_OK || (rc = pensure(c->finit[l], B * 2 * g)) != EEM_OK ||
         (rc = pensure(c->tw, B * 2 * g)) != EEM_OK || (rc = pensure(c->fup[l], B * 2 * g)) != EEM_OK ||
-        (rc = pensure(c->fw, B * C[l] * g)) != EEM_OK || (rc = pensure(c->cat, B * kDIn * g)) != EEM_OK)
+        (rc = pensure(c->fw, B * C[l] * g)) != EEM_OK || (rc = pensure_zeroed(c->cat, B * kCat * g)) != EEM_OK)
         return rc;
     float* const fi = c->finit[l].p;              // cdc_model's upsampled flow_init, kept per level (stage "flow_init<l>")
     // 1x1 projections of both feature maps (:184-185); feature_1 goes straight into the dense buffer's x slot
@@ -327,10 +346,10 @@ static int run_level(eemplus_ctx* c, int l, int B, const float* forced_init, hip
     if ((rc = pl_blend_launch(c->tw.p, fi, c->xout.p, c->fup[l].p, B, (int)g, st)) != EEM_OK) return rc;
     // warp, correlate, decode (:189-193)
     if ((rc = pl_warp_launch(f2(l), c->fup[l].p, 2, c->fw.p, C[l], 0, B, C[l], h, w, 0, st)) != EEM_OK) return rc;
-    CorrJob cj = {f1(l), c->fw.p, c->cat.p, C[l], kDIn};
+    CorrJob cj = {f1(l), c->fw.p, c->cat.p, C[l], kCat};
     if ((rc = corr_launch(&cj, 1, B, h, w, c->taps, 53, st)) != EEM_OK) return rc;
-    if ((rc = conv(c, c->rconv[l], f1(l), C[l], 0, B, h, w, c->cat.p, kDIn, 53, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
-    if ((rc = pl_copy_channels_launch(c->fup[l].p, 2, 0, c->cat.p, kDIn, 85, 2, B, (int)g, st)) != EEM_OK) return rc;
+    if ((rc = conv(c, c->rconv[l], f1(l), C[l], 0, B, h, w, c->cat.p, kCat, 53, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+    if ((rc = pl_copy_channels_launch(c->fup[l].p, 2, 0, c->cat.p, kCat, 85, 2, B, (int)g, st)) != EEM_OK) return rc;
     if ((rc = run_decoder(c, l, B, h, w, c->fup[l].p, st)) != EEM_OK) return rc;
     return EEM_OK;
 }
@@ -399,11 +418,11 @@ extern "C" int eemplus_forward(eemplus_ctx* c, const float* e1, const float* e2,
     {
         const int h = hl[6], w = wl[6];
         const size_t g = (size_t)h * w;
-        if ((rc = pensure(c->cat, B * kDIn * g)) != EEM_OK) return rc;
-        CorrJob cj = {f1(6), f2(6), c->cat.p, 64, kDIn};
+        if ((rc = pensure_zeroed(c->cat, B * kCat * g)) != EEM_OK) return rc;
+        CorrJob cj = {f1(6), f2(6), c->cat.p, 64, kCat};
         if ((rc = corr_launch(&cj, 1, B, h, w, c->taps, 53, st)) != EEM_OK) return rc;
-        if ((rc = conv(c, c->rconv[6], f1(6), 64, 0, B, h, w, c->cat.p, kDIn, 53, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
-        if ((rc = pl_copy_channels_launch(nullptr, 0, 0, c->cat.p, kDIn, 85, 2, B, (int)g, st)) != EEM_OK) return rc;
+        if ((rc = conv(c, c->rconv[6], f1(6), 64, 0, B, h, w, c->cat.p, kCat, 53, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+        if ((rc = pl_copy_channels_launch(nullptr, 0, 0, c->cat.p, kCat, 85, 2, B, (int)g, st)) != EEM_OK) return rc;
         if ((rc = run_decoder(c, 6, B, h, w, nullptr, st)) != EEM_OK) return rc;
     }
     // ---- levels 5..2 (:183-229)

@@ -62,11 +62,22 @@ __device__ __forceinline__ void g16_issue(float* sb, const char* xb, const int (
     }
 }
 
-template <int KH, int KW, int THT, int WM>
-__global__ __launch_bounds__(256, (KH * KW == 9 && THT == 4 && WM == 4) ? 3 : 4) void gconv16_kernel(GConvArgs a, const float* __restrict__ wpk16, const float* __restrict__ zero_page,
+// s_waitcnt vmcnt(N): the oldest requests have landed, the N youngest may still fly
+template <int N>
+__device__ __forceinline__ void g16_wait_vm() {
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// DEPTH = chunks in flight + 1 (LDS stages, register sets of weight fragments).  2: a block per CU quarter, the other blocks' waves
+// cover a chunk's latency (launches that fill the chip).  4: launches of <= 2 blocks per CU (E-RAFT's 60 x 80 update block at batch 1:
+// 150-300 blocks) have about one wave per SIMD - a chunk's MFMAs (0.3-0.6 us) cannot cover the next chunk's way from L2 (1-2 us), and
+// the kernel ran at one memory latency per chunk; three chunks ahead it runs at the MFMAs' pace.
+template <int KH, int KW, int THT, int WM, int DEPTH>
+__global__ __launch_bounds__(256, DEPTH > 2 ? 2 : ((KH * KW == 9 && THT == 4 && WM == 4) ? 3 : 4)) void gconv16_kernel(GConvArgs a, const float* __restrict__ wpk16, const float* __restrict__ zero_page,
                                                       int tiles_x, int nchunks) {
     using C = G16Cfg<KH, KW, THT>;
-    __shared__ __attribute__((aligned(16))) float lds[2 * C::STAGE];
+    __shared__ __attribute__((aligned(16))) float lds[DEPTH * C::STAGE];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, g = lane >> 4;
@@ -109,11 +120,14 @@ __global__ __launch_bounds__(256, (KH * KW == 9 && THT == 4 && WM == 4) ? 3 : 4)
     auto issue = [=](int stage, int ch) __attribute__((always_inline)) {
         g16_issue<C>(lds + stage * C::STAGE, g16_chunk_base(ch, sp0, sp1, sp2, sc0, sc1, hw), off, zero, wave);
     };
-    // weight fragments of chunk `ch` for this wave's M-tile: stream[((cc * nchunks + ch) * KS + ks) * 4 + wave][lane]
-    auto load_w = [&](int ch, float (&wr)[C::KS]) __attribute__((always_inline)) {
-        const float* wp = wpk16 + (((size_t)cc * nchunks + ch) * C::KS * 4 + mt) * 64 + lane;
+    // weight fragments of chunk `ch` for this wave's M-tile: stream[(((cc * nchunks + ch) * TAPS + tap) * 4 + mt) * 64 + lane] is the
+    // float4 of the tap's four k-steps (channel groups) - one 16-byte load per tap
+    auto load_w = [&](int ch, f32x4 (&wr)[C::TAPS]) __attribute__((always_inline)) {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(wpk16) + (((size_t)cc * nchunks + ch) * C::TAPS * 4 + mt) * 64 + lane;
+        // (as asm: the compiler's own bookkeeping of loads in flight across the loop's back edge drains them all - vmcnt(0) - in
+        // front of two of every four chunks; requests it does not see are synchronised by the explicit waits of the chunk loop alone)
 #pragma unroll
-        for (int ks = 0; ks < C::KS; ++ks) wr[ks] = wp[(size_t)ks * 256];
+        for (int t = 0; t < C::TAPS; ++t) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wr[t]) : "v"(wp + (size_t)t * 256) : "memory");
     };
 
     f32x4 acc[NR];
@@ -121,10 +135,10 @@ __global__ __launch_bounds__(256, (KH * KW == 9 && THT == 4 && WM == 4) ? 3 : 4)
     for (int t = 0; t < NR; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int bbase = g * C::PL + j + 4 - PW;                    // B fragment: channel g of a group, pixel column j
 
-    float wA[C::KS], wB[C::KS];
-    issue(0, 0);
-    load_w(0, wA);
-    auto compute = [&](const float* sb, const float (&wr)[C::KS]) __attribute__((always_inline)) {
+    constexpr int PER = C::NI + C::TAPS;                         // memory requests per chunk: tile pieces + weight float4s
+    static_assert((DEPTH - 2) * PER <= 63, "the chunks in flight must fit the vmcnt field");
+    f32x4 wr[DEPTH][C::TAPS];
+    auto compute = [&](const float* sb, const f32x4 (&w)[C::TAPS]) __attribute__((always_inline)) {
 #pragma unroll
         for (int ky = 0; ky < KH; ++ky)
 #pragma unroll
@@ -136,33 +150,41 @@ __global__ __launch_bounds__(256, (KH * KW == 9 && THT == 4 && WM == 4) ? 3 : 4)
                     for (int t = 0; t < NR; ++t) bv[t] = sb[bbase + cg * 4 * C::PL + (wp * NR + t + ky) * C::COLS + kx];
 #pragma unroll
                     for (int t = 0; t < NR; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[((ky * KW + kx) * 4) + cg], bv[t], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ky * KW + kx][cg], bv[t], acc[t], 0, 0, 0);
                 }
     };
     // After the explicit wait the fragments of the current chunk have landed; passing them through an empty asm tells the
-    // compiler so - otherwise it guards their first use with its own s_waitcnt vmcnt(0), which also waits for the NEXT chunk's
-    // loads issued just above it and serialises the whole prefetch.
-    auto landed = [&](float (&wr)[C::KS]) __attribute__((always_inline)) {
+    // compiler so - otherwise it guards their first use with its own s_waitcnt vmcnt(0), which also waits for the younger chunks'
+    // requests and serialises the whole prefetch.
+    auto landed = [&](f32x4 (&w)[C::TAPS]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int ks = 0; ks < C::KS; ++ks) asm volatile("" : "+v"(wr[ks]));
+        for (int t = 0; t < C::TAPS; ++t) asm volatile("" : "+v"(w[t]));
     };
+    // prologue: chunks 0 .. DEPTH-2 requested
+#pragma unroll
+    for (int s = 0; s < DEPTH - 1; ++s)
+        if (s < nchunks) { issue(s, s); load_w(s, wr[s]); }
 #pragma unroll 1
-    for (int ch = 0; ch < nchunks; ch += 2) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        landed(wA);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (ch + 1 < nchunks) { issue(1, ch + 1); load_w(ch + 1, wB); }
-        __builtin_amdgcn_sched_barrier(0);
-        compute(lds, wA);
-        if (ch + 1 >= nchunks) break;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        landed(wB);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (ch + 2 < nchunks) { issue(0, ch + 2); load_w(ch + 2, wA); }
-        __builtin_amdgcn_sched_barrier(0);
-        compute(lds + C::STAGE, wB);
+    for (int ch0 = 0; ch0 < nchunks; ch0 += DEPTH) {
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s) {
+            const int ch = ch0 + s;
+            if (ch >= nchunks) break;
+            // chunk ch must have landed; the requests of the chunks after it (up to DEPTH - 2 of them) stay in flight
+            const int younger = min(DEPTH - 2, nchunks - 1 - ch);
+            if (DEPTH == 2 || younger <= 0) g16_wait_vm<0>();
+            else if (younger == 1) g16_wait_vm<PER>();
+            else g16_wait_vm<(DEPTH > 3 ? 2 : 1) * PER>();
+            landed(wr[s]);
+            __builtin_amdgcn_s_barrier();                        // every wave is done with the stage of chunk ch - 1
+            asm volatile("" ::: "memory");
+            if (ch + DEPTH - 1 < nchunks) {
+                issue((s + DEPTH - 1) % DEPTH, ch + DEPTH - 1);
+                load_w(ch + DEPTH - 1, wr[(s + DEPTH - 1) % DEPTH]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            compute(lds + s * C::STAGE, wr[s]);
+        }
     }
 
     // ---- epilogue: D[cout 4g + r][pixel j]
@@ -206,7 +228,13 @@ int launch_wm(const GConvArgs& a, const float* wpk16, const float* zero_page, hi
     for (int s = 0; s < a.nseg; ++s) cin += a.seg[s].c;
     const int tiles_x = ceil_div(a.wout, C::TW), tiles_y = ceil_div(a.hout, C::TH);
     dim3 grid(tiles_x * tiles_y, ceil_div(a.cout, 16 * WM), a.n);
-    hipLaunchKernelGGL((gconv16_kernel<KH, KW, THT, WM>), grid, dim3(256), 0, stream, a, wpk16, zero_page, tiles_x, cin / 16);
+    // at most two blocks per CU and more than two chunks: three chunks in flight (see the kernel's DEPTH)
+    static const int depth_env = [] { const char* e = getenv("EEM_G16_DEPTH"); return e ? atoi(e) : 0; }();
+    static const long deep_max = [] { const char* e = getenv("EEM_G16_DEEP_MAX"); return e ? atol(e) : 512L; }();
+    const long blocks = (long)grid.x * grid.y * grid.z;
+    const bool deep = depth_env ? depth_env >= 4 : (blocks <= deep_max && cin / 16 > 2);
+    if (deep) hipLaunchKernelGGL((gconv16_kernel<KH, KW, THT, WM, 4>), grid, dim3(256), 0, stream, a, wpk16, zero_page, tiles_x, cin / 16);
+    else hipLaunchKernelGGL((gconv16_kernel<KH, KW, THT, WM, 2>), grid, dim3(256), 0, stream, a, wpk16, zero_page, tiles_x, cin / 16);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }
@@ -247,7 +275,7 @@ size_t gconv16_packed_floats(int cout, const int* cs, int nseg, int kh, int kw) 
     return (size_t)ceil_div(cout, 64) * (cin / 16) * kh * kw * 4 * 4 * 64;
 }
 
-// stream[(((cc * nchunks + ch) * taps + tap) * 4 + cg) * 4 + mt][lane] = W[cc*64 + mt*16 + lane%16][ch*16 + 4*cg + lane/16][tap]
+// stream[((((cc * nchunks + ch) * taps + tap) * 4 + mt) * 64 + lane) * 4 + cg] = W[cc*64 + mt*16 + lane%16][ch*16 + 4*cg + lane/16][tap]
 void gconv16_pack(const float* w, int cout, const int* cs, int nseg, int kh, int kw, float* packed) {
     int cin = 0;
     for (int s = 0; s < nseg; ++s) cin += cs[s];
@@ -259,7 +287,7 @@ void gconv16_pack(const float* w, int cout, const int* cs, int nseg, int kh, int
                     for (int mt = 0; mt < 4; ++mt)
                         for (int lane = 0; lane < 64; ++lane) {
                             const int co = cc * 64 + mt * 16 + (lane & 15), c = ch * 16 + 4 * cg + (lane >> 4);
-                            packed[((((((size_t)cc * nch + ch) * taps + tap) * 4 + cg) * 4 + mt) * 64) + lane] =
+                            packed[((((((size_t)cc * nch + ch) * taps + tap) * 4 + mt) * 64) + lane) * 4 + cg] =
                                 co < cout ? w[((size_t)co * cin + c) * taps + tap] : 0.f;
                         }
 }

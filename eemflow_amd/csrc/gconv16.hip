@@ -69,12 +69,14 @@ __device__ __forceinline__ void g16_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// DEPTH = chunks in flight + 1 (LDS stages, register sets of weight fragments).  2: a block per CU quarter, the other blocks' waves
-// cover a chunk's latency (launches that fill the chip).  4: launches of <= 2 blocks per CU (E-RAFT's 60 x 80 update block at batch 1:
-// 150-300 blocks) have about one wave per SIMD - a chunk's MFMAs (0.3-0.6 us) cannot cover the next chunk's way from L2 (1-2 us), and
-// the kernel ran at one memory latency per chunk; three chunks ahead it runs at the MFMAs' pace.
+// DEPTH = chunks in flight + 1 (LDS stages, register sets of weight fragments).  Production is 2.  DEPTH = 4 (three chunks ahead, for
+// launches of one wave per SIMD such as E-RAFT's 60 x 80 update block at batch 1) was built and measured: the same kernel times
+// (38 us for 1 440 MFMAs = 19 us of matrix pipe per wave) - those launches are not waiting for memory; what a lone wave per SIMD cannot
+// hide is its own per-chunk issue work (barrier, DMA plan and address arithmetic on the pipe the MFMAs use, the first tap's LDS
+// round trip): ~1 400 cycles per chunk against 1 920 of MFMAs.  tools/micro/dispatch_map.hip: the dispatcher does spread 200 blocks
+// over 200 CUs.
 template <int KH, int KW, int THT, int WM, int DEPTH>
-__global__ __launch_bounds__(256, DEPTH > 2 ? 2 : ((KH * KW == 9 && THT == 4 && WM == 4) ? 3 : 4)) void gconv16_kernel(GConvArgs a, const float* __restrict__ wpk16, const float* __restrict__ zero_page,
+__global__ __launch_bounds__(256, (DEPTH > 2 || (THT != 2 && THT != 4)) ? 2 : ((KH * KW == 9 && THT == 4 && WM == 4) ? 3 : 4)) void gconv16_kernel(GConvArgs a, const float* __restrict__ wpk16, const float* __restrict__ zero_page,
                                                       int tiles_x, int nchunks) {
     using C = G16Cfg<KH, KW, THT>;
     __shared__ __attribute__((aligned(16))) float lds[DEPTH * C::STAGE];
@@ -138,7 +140,10 @@ __global__ __launch_bounds__(256, DEPTH > 2 ? 2 : ((KH * KW == 9 && THT == 4 && 
     constexpr int PER = C::NI + C::TAPS;                         // memory requests per chunk: tile pieces + weight float4s
     static_assert((DEPTH - 2) * PER <= 63, "the chunks in flight must fit the vmcnt field");
     f32x4 wr[DEPTH][C::TAPS];
-    auto compute = [&](const float* sb, const f32x4 (&w)[C::TAPS]) __attribute__((always_inline)) {
+    // (B fragments: the compiler's own order of ds_reads and MFMAs.  Reads as counted asm one tap ahead of the MFMAs, with explicit
+    // s_waitcnt lgkmcnt(reads of the next tap), were built and measured: the same at one wave per SIMD, 5 % slower on full launches.)
+    auto compute = [&](int stage, f32x4 (&w)[C::TAPS]) __attribute__((always_inline)) {
+        const float* sb = lds + stage * C::STAGE;
 #pragma unroll
         for (int ky = 0; ky < KH; ++ky)
 #pragma unroll
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(256, DEPTH > 2 ? 2 : ((KH * KW == 9 && THT == 4 && 
                 load_w(ch + DEPTH - 1, wr[(s + DEPTH - 1) % DEPTH]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            compute(lds + s * C::STAGE, wr[s]);
+            compute(s, wr[s]);
         }
     }
 
@@ -228,13 +233,7 @@ int launch_wm(const GConvArgs& a, const float* wpk16, const float* zero_page, hi
     for (int s = 0; s < a.nseg; ++s) cin += a.seg[s].c;
     const int tiles_x = ceil_div(a.wout, C::TW), tiles_y = ceil_div(a.hout, C::TH);
     dim3 grid(tiles_x * tiles_y, ceil_div(a.cout, 16 * WM), a.n);
-    // at most two blocks per CU and more than two chunks: three chunks in flight (see the kernel's DEPTH)
-    static const int depth_env = [] { const char* e = getenv("EEM_G16_DEPTH"); return e ? atoi(e) : 0; }();
-    static const long deep_max = [] { const char* e = getenv("EEM_G16_DEEP_MAX"); return e ? atol(e) : 512L; }();
-    const long blocks = (long)grid.x * grid.y * grid.z;
-    const bool deep = depth_env ? depth_env >= 4 : (blocks <= deep_max && cin / 16 > 2);
-    if (deep) hipLaunchKernelGGL((gconv16_kernel<KH, KW, THT, WM, 4>), grid, dim3(256), 0, stream, a, wpk16, zero_page, tiles_x, cin / 16);
-    else hipLaunchKernelGGL((gconv16_kernel<KH, KW, THT, WM, 2>), grid, dim3(256), 0, stream, a, wpk16, zero_page, tiles_x, cin / 16);
+    hipLaunchKernelGGL((gconv16_kernel<KH, KW, THT, WM, 2>), grid, dim3(256), 0, stream, a, wpk16, zero_page, tiles_x, cin / 16);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }
@@ -248,15 +247,39 @@ int launch_th(const GConvArgs& a, const float* wpk16, const float* zero_page, hi
 
 template <int KH, int KW>
 int launch(const GConvArgs& a, const float* wpk16, const float* zero_page, hipStream_t stream) {
-    // 2-row tiles when 4-row tiles would leave only a few blocks per CU (their run time is quantised in whole blocks per CU:
-    // E-RAFT's update block at batch 4 is 2.3 blocks per CU); 4-row tiles reuse every weight fragment twice as often
     static const int th_env = [] { const char* e = getenv("EEM_G16_TH"); return e ? atoi(e) : 0; }();
-    const long blocks4 = (long)ceil_div(a.wout, 16) * ceil_div(a.hout, 4) * ceil_div(a.cout, 64) * a.n;
-    // with several frames in flight the other frames fill the CUs a short launch leaves idle, and what counts is CU time: 4-row tiles
-    // read every weight fragment half as often (E-RAFT batch 4, three in flight: 168 -> 175 frames/s; one at a time 144 -> 138)
-    const int th = th_env ? th_env : (blocks4 < (a.in_flight >= 3 ? 512 : 2048) ? 2 : 4);
-    if (th == 2) return launch_th<KH, KW, 2>(a, wpk16, zero_page, stream);
-    return launch_th<KH, KW, 4>(a, wpk16, zero_page, stream);
+    const auto blocks_of = [&](int th) { return (long)ceil_div(a.wout, 16) * ceil_div(a.hout, th) * ceil_div(a.cout, 64) * a.n; };
+    int th;
+    if (th_env) {
+        th = th_env;
+    } else if (a.in_flight >= 3) {
+        // with several frames in flight the other frames fill the CUs a short launch leaves idle, and what counts is CU time: 4-row tiles
+        // read every weight fragment half as often (E-RAFT batch 4, three in flight: 168 -> 175 frames/s; one at a time 144 -> 138)
+        th = blocks_of(4) < 512 ? 2 : 4;
+    } else if (blocks_of(4) >= 2048) {
+        th = 4;
+    } else if (a.cout <= 32) {
+        th = 2;
+    } else {
+        // A launch of a few blocks per CU runs as long as the CU with the most blocks: E-RAFT's update block at batch 1 (60 x 80 x 128
+        // couts) is 300 blocks of 2-row tiles - 44 CUs take two and the other 212 wait for them; 200 blocks of 3-row tiles are one round
+        // of 1.5x the work.  Rows per tile = the one with the least (rounds x rows), the per-block overhead counted as 0.6 rows.
+        static const int cus = [] { int d = 0, n = 256; hipDeviceProp_t p; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) n = p.multiProcessorCount; return n > 0 ? n : 256; }();
+        float best = 1e30f;
+        th = 2;
+        for (int t = 2; t <= 6; ++t) {
+            const float cost = (float)ceil_div((int)blocks_of(t), cus) * ((float)t + 0.6f);
+            if (cost < best - 1e-3f) { best = cost; th = t; }
+        }
+    }
+    if (a.cout <= 32 && th != 2) th = 4;                         // the 32- and 16-cout forms split the rows over the waves: even tiles
+    switch (th) {
+        case 2: return launch_th<KH, KW, 2>(a, wpk16, zero_page, stream);
+        case 3: return launch_wm<KH, KW, 3, 4>(a, wpk16, zero_page, stream);
+        case 5: return launch_wm<KH, KW, 5, 4>(a, wpk16, zero_page, stream);
+        case 6: return launch_wm<KH, KW, 6, 4>(a, wpk16, zero_page, stream);
+        default: return launch_th<KH, KW, 4>(a, wpk16, zero_page, stream);
+    }
 }
 
 }  // namespace

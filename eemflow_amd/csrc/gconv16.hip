@@ -16,6 +16,12 @@
 
 namespace {
 
+#ifdef EEM_G16_STAMPS
+// per wave: [0] start [1] prologue done [2] sum(wait vmcnt) [3] sum(barrier) [4] sum(requests) [5] sum(compute) [6] loop done [7] end
+__device__ unsigned long long g_g16_stamps[1024 * 4 * 8];
+#define G16_T() __builtin_amdgcn_s_memtime()
+#endif
+
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
@@ -69,24 +75,36 @@ __device__ __forceinline__ void g16_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// DEPTH = chunks in flight + 1 (LDS stages, register sets of weight fragments).  Production is 2.  DEPTH = 4 (three chunks ahead, for
-// launches of one wave per SIMD such as E-RAFT's 60 x 80 update block at batch 1) was built and measured: the same kernel times
-// (38 us for 1 440 MFMAs = 19 us of matrix pipe per wave) - those launches are not waiting for memory; what a lone wave per SIMD cannot
-// hide is its own per-chunk issue work (barrier, DMA plan and address arithmetic on the pipe the MFMAs use, the first tap's LDS
-// round trip): ~1 400 cycles per chunk against 1 920 of MFMAs.  tools/micro/dispatch_map.hip: the dispatcher does spread 200 blocks
-// over 200 CUs.
-template <int KH, int KW, int THT, int WM, int DEPTH>
-__global__ __launch_bounds__(256, (DEPTH > 2 || (THT != 2 && THT != 4)) ? 2 : ((KH * KW == 9 && THT == 4 && WM == 4) ? 3 : 4)) void gconv16_kernel(GConvArgs a, const float* __restrict__ wpk16, const float* __restrict__ zero_page,
+// KG = groups of four waves that split the channel chunks of one tile (group g takes chunks g, g + KG, ...; partial sums meet in LDS).
+// 1 for launches that fill the chip.  2 for launches of at most one block per CU (E-RAFT's 60 x 80 update block at batch 1: 150-300
+// blocks), where a SIMD holds ONE wave and nothing overlaps that wave's own instruction stream: in-kernel stamps (EEM_G16_STAMPS,
+// tools/g16_stamps.py; 384 -> 128 1x5, 200 blocks of 3-row tiles) read 84 k cycles per wave for 46 k of MFMAs - 10 k issuing the next
+// chunk's requests (a lone wave issues one instruction per 4 cycles, ~100 per chunk), 12 k of LDS round trips inside the MFMA stream,
+// 8.5 k in the epilogue (bias loads and stores one after the other), 5 k waiting.  A second wave on the SIMD fills those gaps with its
+// MFMAs, which is what a second frame in flight did (+ 50 %).
+// Measured and not kept: a four-stage ring (three chunks of LDS-DMA and weight fragments in flight, s_waitcnt vmcnt(2 x requests per
+// chunk)) and two chunks per barrier - identical or worse kernel times, those launches are not waiting for memory; B fragments by
+// counted asm ds_read2_b32 one tap ahead of the MFMAs - the same at one wave per SIMD, 5 % slower on full launches.
+// tools/micro/dispatch_map.hip: the dispatcher does spread 200 blocks over 200 CUs.
+template <int KH, int KW, int THT, int WM, int KG>
+__global__ __launch_bounds__(256 * KG, (KG > 1 || (THT != 2 && THT != 4)) ? 2 : ((KH * KW == 9 && THT == 4 && WM >= 2) ? 3 : 4)) void gconv16_kernel(GConvArgs a, const float* __restrict__ wpk16, const float* __restrict__ zero_page,
                                                       int tiles_x, int nchunks) {
     using C = G16Cfg<KH, KW, THT>;
-    __shared__ __attribute__((aligned(16))) float lds[DEPTH * C::STAGE];
+#ifdef EEM_G16_STAMPS
+    unsigned long long st[8] = {G16_T(), 0, 0, 0, 0, 0, 0, 0};
+#endif
+    constexpr int WP = 4 / WM, NR = C::TH / WP;                  // pixel-row groups, rows per wave
+    static_assert(NR >= 1, "a wave needs a row");
+    constexpr int RED = KG > 1 ? 4 * NR * 256 : 0;               // floats of the partial sums one group hands over
+    constexpr int LDS_FLOATS = KG * 2 * C::STAGE > RED ? KG * 2 * C::STAGE : RED;
+    __shared__ __attribute__((aligned(16))) float lds_all[LDS_FLOATS];
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3);      // within the K group
+    const int kg = KG > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;
+    float* const lds = lds_all + kg * 2 * C::STAGE;
     const int j = lane & 15, g = lane >> 4;
     // WM = waves along the couts (16 each): 4 -> a block covers 64 couts and every wave all TH rows; 2 -> 32 couts (layers of
     // <= 32 couts), the two wave pairs split the rows; 1 -> 16 couts (EEMFlow+'s 160 -> 16 estimator layer), a row per wave
-    constexpr int WP = 4 / WM, NR = C::TH / WP;                  // pixel-row groups, rows per wave
-    static_assert(NR >= 1, "a wave needs a row");
     const int wm = wave % WM, wp = wave / WM;
     const int mtg = blockIdx.y * WM + wm;                        // global 16-cout tile of this wave
     const int n = blockIdx.z, cc = mtg >> 2, mt = mtg & 3;
@@ -137,11 +155,7 @@ __global__ __launch_bounds__(256, (DEPTH > 2 || (THT != 2 && THT != 4)) ? 2 : ((
     for (int t = 0; t < NR; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int bbase = g * C::PL + j + 4 - PW;                    // B fragment: channel g of a group, pixel column j
 
-    constexpr int PER = C::NI + C::TAPS;                         // memory requests per chunk: tile pieces + weight float4s
-    static_assert((DEPTH - 2) * PER <= 63, "the chunks in flight must fit the vmcnt field");
-    f32x4 wr[DEPTH][C::TAPS];
-    // (B fragments: the compiler's own order of ds_reads and MFMAs.  Reads as counted asm one tap ahead of the MFMAs, with explicit
-    // s_waitcnt lgkmcnt(reads of the next tap), were built and measured: the same at one wave per SIMD, 5 % slower on full launches.)
+    f32x4 wr[2][C::TAPS];
     auto compute = [&](int stage, f32x4 (&w)[C::TAPS]) __attribute__((always_inline)) {
         const float* sb = lds + stage * C::STAGE;
 #pragma unroll
@@ -165,31 +179,59 @@ __global__ __launch_bounds__(256, (DEPTH > 2 || (THT != 2 && THT != 4)) ? 2 : ((
 #pragma unroll
         for (int t = 0; t < C::TAPS; ++t) asm volatile("" : "+v"(w[t]));
     };
-    // prologue: chunks 0 .. DEPTH-2 requested
+    // bias / scale of this lane's four couts: requested now, they arrive under the chunk loop (as part of the epilogue they were two
+    // dependent round trips in front of the stores)
+    float e_scale[4], e_shift[4];
 #pragma unroll
-    for (int s = 0; s < DEPTH - 1; ++s)
-        if (s < nchunks) { issue(s, s); load_w(s, wr[s]); }
+    for (int r = 0; r < 4; ++r) {
+        const int co = min(mtg * 16 + 4 * g + r, a.cout - 1);
+        e_scale[r] = a.scale ? a.scale[co] : 1.f;
+        e_shift[r] = a.shift ? a.shift[co] : 0.f;
+    }
+    // group kg takes the chunks kg, kg + KG, ...; every group runs the same number of steps (the barrier counts all waves)
+    const int nmine = (nchunks - kg + KG - 1) / KG, nsteps = (nchunks + KG - 1) / KG;
+    if (nmine > 0) { issue(0, kg); load_w(kg, wr[0]); }
+#ifdef EEM_G16_STAMPS
+    st[1] = G16_T();
+#define G16_ACC(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = G16_T(); st[i] += now_ - tprev; tprev = now_; __builtin_amdgcn_sched_barrier(0); }
+    unsigned long long tprev = st[1];
+#else
+#define G16_ACC(i)
+#endif
 #pragma unroll 1
-    for (int ch0 = 0; ch0 < nchunks; ch0 += DEPTH) {
+    for (int step0 = 0; step0 < nsteps; step0 += 2) {
 #pragma unroll
-        for (int s = 0; s < DEPTH; ++s) {
-            const int ch = ch0 + s;
-            if (ch >= nchunks) break;
-            // chunk ch must have landed; the requests of the chunks after it (up to DEPTH - 2 of them) stay in flight
-            const int younger = min(DEPTH - 2, nchunks - 1 - ch);
-            if (DEPTH == 2 || younger <= 0) g16_wait_vm<0>();
-            else if (younger == 1) g16_wait_vm<PER>();
-            else g16_wait_vm<(DEPTH > 3 ? 2 : 1) * PER>();
-            landed(wr[s]);
-            __builtin_amdgcn_s_barrier();                        // every wave is done with the stage of chunk ch - 1
+        for (int st_ = 0; st_ < 2; ++st_) {
+            const int step = step0 + st_;
+            if (step >= nsteps) break;
+            g16_wait_vm<0>();
+            landed(wr[st_]);
+            G16_ACC(2)
+            __builtin_amdgcn_s_barrier();                        // every wave is done with the other stage
             asm volatile("" ::: "memory");
-            if (ch + DEPTH - 1 < nchunks) {
-                issue((s + DEPTH - 1) % DEPTH, ch + DEPTH - 1);
-                load_w(ch + DEPTH - 1, wr[(s + DEPTH - 1) % DEPTH]);
-            }
+            G16_ACC(3)
+            if (step + 1 < nmine) { issue(1 - st_, kg + (step + 1) * KG); load_w(kg + (step + 1) * KG, wr[1 - st_]); }
             __builtin_amdgcn_sched_barrier(0);
-            compute(s, wr[s]);
+            G16_ACC(4)
+            if (KG == 1 || step < nmine) compute(st_, wr[st_]);
+            G16_ACC(5)
         }
+    }
+#ifdef EEM_G16_STAMPS
+    st[6] = G16_T();
+#endif
+    // ---- K groups: group 1 hands its partial sums over, group 0 finishes (the groups' LDS stages are dead by then)
+    if (KG > 1) {
+        __syncthreads();
+        f32x4* red = reinterpret_cast<f32x4*>(lds_all);          // [wave][row][lane]
+        if (kg == 1) {
+#pragma unroll
+            for (int t = 0; t < NR; ++t) red[(wave * NR + t) * 64 + lane] = acc[t];
+        }
+        __syncthreads();
+        if (kg == 1) return;
+#pragma unroll
+        for (int t = 0; t < NR; ++t) acc[t] += red[(wave * NR + t) * 64 + lane];
     }
 
     // ---- epilogue: D[cout 4g + r][pixel j]
@@ -204,9 +246,7 @@ __global__ __launch_bounds__(256, (DEPTH > 2 || (THT != 2 && THT != 4)) ? 2 : ((
         for (int r = 0; r < 4; ++r) {
             const int co = mtg * 16 + 4 * g + r;
             if (co >= a.cout) continue;
-            float v = acc[t][r];
-            if (a.scale) v *= a.scale[co];
-            if (a.shift) v += a.shift[co];
+            float v = acc[t][r] * e_scale[r] + e_shift[r];
             v = g16_act(v, a.act);
             if (a.epi == GEPI_MUL) {
                 v *= a.e0[((size_t)n * a.e0_ctotal + a.e0_coff + co) * hw + p];
@@ -224,6 +264,14 @@ __global__ __launch_bounds__(256, (DEPTH > 2 || (THT != 2 && THT != 4)) ? 2 : ((
             a.out[((size_t)n * a.out_ctotal + oc) * hw + p] = v * a.out_scale;
         }
     }
+#ifdef EEM_G16_STAMPS
+    if (lane == 0) {
+        st[7] = G16_T();
+        const unsigned bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (bid < 1024)
+            for (int i = 0; i < 8; ++i) g_g16_stamps[(bid * 4 + wave) * 8 + i] = st[i];
+    }
+#endif
 }
 
 template <int KH, int KW, int THT, int WM>
@@ -233,7 +281,14 @@ int launch_wm(const GConvArgs& a, const float* wpk16, const float* zero_page, hi
     for (int s = 0; s < a.nseg; ++s) cin += a.seg[s].c;
     const int tiles_x = ceil_div(a.wout, C::TW), tiles_y = ceil_div(a.hout, C::TH);
     dim3 grid(tiles_x * tiles_y, ceil_div(a.cout, 16 * WM), a.n);
-    hipLaunchKernelGGL((gconv16_kernel<KH, KW, THT, WM, 2>), grid, dim3(256), 0, stream, a, wpk16, zero_page, tiles_x, cin / 16);
+    // at most one block per CU: two K groups of four waves per tile (see the kernel's KG)
+    static const int kg_env = [] { const char* e = getenv("EEM_G16_KG"); return e ? atoi(e) : 0; }();
+    static const int cus = [] { int d = 0, n = 256; hipDeviceProp_t p; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) n = p.multiProcessorCount; return n > 0 ? n : 256; }();
+    const int nchunks = cin / 16;
+    const long blocks = (long)grid.x * grid.y * grid.z;
+    const bool two = nchunks >= 4 && (kg_env ? kg_env == 2 : (blocks <= cus && a.in_flight < 3));
+    if (two) hipLaunchKernelGGL((gconv16_kernel<KH, KW, THT, WM, 2>), grid, dim3(512), 0, stream, a, wpk16, zero_page, tiles_x, nchunks);
+    else hipLaunchKernelGGL((gconv16_kernel<KH, KW, THT, WM, 1>), grid, dim3(256), 0, stream, a, wpk16, zero_page, tiles_x, nchunks);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }
@@ -283,6 +338,12 @@ int launch(const GConvArgs& a, const float* wpk16, const float* zero_page, hipSt
 }
 
 }  // namespace
+
+#ifdef EEM_G16_STAMPS
+extern "C" int eemflow_debug_read_g16_stamps(unsigned long long* dst, size_t n) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_g16_stamps), n * sizeof(unsigned long long)) == hipSuccess ? 0 : 2;
+}
+#endif
 
 bool gconv16_shape(int cout, const int* cs, int nseg, int kh, int kw, int stride) {
     if (stride != 1 || cout < 16) return false;

@@ -153,7 +153,8 @@ def test_on_the_fly_correlation_equals_the_resident_volume(b, h, w, iters):
 
 def test_frames_in_flight_hint_changes_tiles_not_results():
     """eraft_set_frames_in_flight >= 3: the LDS-tiled convs of 512..2047 blocks use 4-row tiles instead of 2-row ones (batch 4 at
-    640x480: the update block).  Same k order per output: the flow does not change beyond round-off, and stays within tolerance."""
+    640x480: the update block), and launches of at most one block per CU keep one group of waves per tile instead of two that split
+    the channel chunks (a different summation order): the flow changes by round-off only."""
     h, w = 480, 640
     net, _ = make_net(29)
     net.change_imagesize((h, w))
@@ -162,7 +163,7 @@ def test_frames_in_flight_hint_changes_tiles_not_results():
         one = torch.stack(net(e1, e2, iters=3)[1]).clone()
         net.frames_in_flight = 4
         many = torch.stack(net(e1, e2, iters=3)[1]).clone()
-    assert maxerr(many, one) < 1e-5 and float(one.abs().max()) > 1e-3
+    assert maxerr(many, one) < 2e-4 and float(one.abs().max()) > 1e-3
 
 
 def test_flow_init_and_twelve_iterations():

@@ -18,9 +18,9 @@ net = net.cuda(); net.change_imagesize((h, w))
 net.alternate_corr = os.environ.get("ERAFT_ALTERNATE_CORR", "0") == "1"
 e1, e2 = (torch.from_numpy(a).cuda() for a in synthetic_voxel_pair(1, b, h, w))
 with torch.no_grad():
-    for _ in range(2): net(e1, e2, iters=iters)
+    for _ in range(int(os.environ.get("BENCH_WARM", "2"))): net(e1, e2, iters=iters)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    n = 5
+    n = int(os.environ.get("BENCH_N", "5"))
     for _ in range(n): net(e1, e2, iters=iters)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 print(f"E-RAFT {w}x{h} iters={iters} batch={b}: {dt*1e3:.2f} ms/forward, {b/dt:.2f} frames/s, {499.2*b*(h*w)/(480*640)/dt/1e3:.1f} TFLOP/s (conv FLOPs scaled from 640x480; the all-pairs GEMM grows quadratically)")

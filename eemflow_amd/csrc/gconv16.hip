@@ -7,7 +7,7 @@
 //     (N-tiles), so every weight fragment feeds four MFMAs and every input fragment is read once per wave from LDS (layers
 //     of <= 32 couts: two M-tiles x two row groups per block, so no wave idles);
 //   * the input is consumed in chunks of 16 channels: the chunk's haloed tile [16][4 + KH - 1][24] (columns x0 - 4 .. x0 + 19)
-//     goes HBM/L2 -> LDS by 16-byte LDS-DMA, double-buffered, out-of-image pieces from a zero page; the plane pitch is padded to
+//     goes HBM/L2 -> LDS by 16-byte LDS-DMA, double-buffered, out-of-image pieces as out-of-range buffer offsets (zeros); the plane pitch is padded to
 //     16 mod 32 floats so the four channel lanes of a k-step fall on different bank halves;
 //   * the chunk's weight fragments (taps x 4 k-steps) are loaded into registers from a stream packed in fragment order
 //     (256 bytes per wave and k-step, the four waves' fragments adjacent) one chunk ahead of their use;
@@ -59,13 +59,20 @@ __device__ __forceinline__ const char* g16_chunk_base(int ch, const char* sp0, c
     return b + (size_t)c * hw * 4;
 }
 
+// One chunk's tile pieces, HBM/L2 -> LDS, as buffer loads: the descriptor's base is the chunk's first channel (scalar), a lane's
+// offset inside the chunk is fixed for the whole kernel, and out-of-image pieces carry an offset beyond the descriptor's range - the
+// hardware writes zeros for them.  No vector instruction per chunk: with several waves on a SIMD every VALU instruction of the
+// request phase waited for a partner's MFMA to leave the shared pipe (stamps: 20 % of a full launch's wave time was spent issuing
+// requests, 64-bit pointer selects against a zero page included).
+constexpr unsigned G16_RANGE = 0x7fffff00u;                     // bytes a descriptor covers; offsets at or above it read as zero
 template <class C, int NI>
-__device__ __forceinline__ void g16_issue(float* sb, const char* xb, const int (&off)[NI], const char* zero, int wave) {
+__device__ __forceinline__ void g16_issue(float* sb, const char* xb, const unsigned (&off)[NI], int wave) {
+#if __HIP_DEVICE_COMPILE__                                      // (the buffer-resource type does not exist in the host pass)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xb), (short)0, (int)G16_RANGE, 0x00020000);
 #pragma unroll
-    for (int k = 0; k < NI; ++k) {
-        const char* p = off[k] >= 0 ? xb + off[k] : zero;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(p), LDS_PTR(sb + (wave + 4 * k) * 256), 16, 0, 0);
-    }
+    for (int k = 0; k < NI; ++k)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(sb + (wave + 4 * k) * 256), 16, off[k], 0, 0, 0);
+#endif
 }
 
 // s_waitcnt vmcnt(N): the oldest requests have landed, the N youngest may still fly
@@ -114,7 +121,7 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || (THT != 2 && THT != 4)) ? 2 : 
     constexpr int PH = KH / 2, PW = KW / 2;
 
     // ---- DMA plan: slot f -> (channel, row, 16-byte piece) of the chunk's tile
-    int off[C::NI];
+    unsigned off[C::NI];
 #pragma unroll
     for (int k = 0; k < C::NI; ++k) {
         const int f = (wave + 4 * k) * 64 + lane;
@@ -123,9 +130,8 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || (THT != 2 && THT != 4)) ? 2 : 
         const bool ok = f < C::SLOTS && q < C::ROWS * 6;
         const int gy = y0 - PH + row, gx = x0 - 4 + 4 * pc;
         const bool in = ok && gy >= 0 && gy < a.hin && gx >= 0 && gx + 4 <= a.win;
-        off[k] = in ? (int)(((size_t)ci * hw + (size_t)gy * a.win + gx) * 4) : -1;
+        off[k] = in ? (unsigned)(((size_t)ci * hw + (size_t)gy * a.win + gx) * 4) : G16_RANGE;
     }
-    const char* zero = reinterpret_cast<const char*>(zero_page);
     // chunk index -> (segment, first channel).  The three descriptors are separate scalars on purpose: as arrays the compiler turned
     // the chain of selects into an indexed read of a private (scratch) copy - a scratch load and an `s_waitcnt vmcnt(0)` in front of
     // every chunk's DMA (kernel arguments indexed dynamically were a scalar load + wait in the same place)
@@ -138,16 +144,21 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || (THT != 2 && THT != 4)) ? 2 : 
     // (free functions with by-value scalars, not lambdas: a closure that another closure captures stays in memory across the loop's
     // `memory`-clobbering waits, and its fields were re-read from scratch in front of every chunk's DMA)
     auto issue = [=](int stage, int ch) __attribute__((always_inline)) {
-        g16_issue<C>(lds + stage * C::STAGE, g16_chunk_base(ch, sp0, sp1, sp2, sc0, sc1, hw), off, zero, wave);
+        g16_issue<C>(lds + stage * C::STAGE, g16_chunk_base(ch, sp0, sp1, sp2, sc0, sc1, hw), off, wave);
     };
-    // weight fragments of chunk `ch` for this wave's M-tile: stream[(((cc * nchunks + ch) * TAPS + tap) * 4 + mt) * 64 + lane] is the
-    // float4 of the tap's four k-steps (channel groups) - one 16-byte load per tap
+    // weight fragments of chunk `ch` for this wave's M-tile: stream[((((cc * nchunks + ch) * 4 + mt) * TAPS + tap) * 64 + lane] is the
+    // float4 of the tap's four k-steps (channel groups) - one 16-byte load per tap, a wave's taps 1 KB apart: scalar base of the
+    // (chunk, M-tile) + the lane's fixed offset + an immediate, no vector arithmetic per chunk
+    // (as asm: the compiler's own bookkeeping of loads in flight across the loop's back edge drained them all - vmcnt(0) - where the
+    // explicit waits of the chunk loop meant to keep requests in flight; requests it does not see are synchronised by those waits alone)
+    const unsigned wl0 = lane * 16u, wl1 = wl0 + 4096u, wl2 = wl0 + 8192u;
     auto load_w = [&](int ch, f32x4 (&wr)[C::TAPS]) __attribute__((always_inline)) {
-        const f32x4* wp = reinterpret_cast<const f32x4*>(wpk16) + (((size_t)cc * nchunks + ch) * C::TAPS * 4 + mt) * 64 + lane;
-        // (as asm: the compiler's own bookkeeping of loads in flight across the loop's back edge drains them all - vmcnt(0) - in
-        // front of two of every four chunks; requests it does not see are synchronised by the explicit waits of the chunk loop alone)
+        const char* wb = reinterpret_cast<const char*>(wpk16) + ((((size_t)cc * nchunks + ch) * 4 + mt) * C::TAPS) * 1024;
 #pragma unroll
-        for (int t = 0; t < C::TAPS; ++t) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wr[t]) : "v"(wp + (size_t)t * 256) : "memory");
+        for (int t = 0; t < C::TAPS; ++t) {
+            const unsigned vo = t < 4 ? wl0 : (t < 8 ? wl1 : wl2);
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(wr[t]) : "v"(vo), "s"(wb), "n"((t & 3) * 1024) : "memory");
+        }
     };
 
     f32x4 acc[NR];
@@ -359,7 +370,7 @@ size_t gconv16_packed_floats(int cout, const int* cs, int nseg, int kh, int kw) 
     return (size_t)ceil_div(cout, 64) * (cin / 16) * kh * kw * 4 * 4 * 64;
 }
 
-// stream[((((cc * nchunks + ch) * taps + tap) * 4 + mt) * 64 + lane) * 4 + cg] = W[cc*64 + mt*16 + lane%16][ch*16 + 4*cg + lane/16][tap]
+// stream[((((cc * nchunks + ch) * 4 + mt) * taps + tap) * 64 + lane) * 4 + cg] = W[cc*64 + mt*16 + lane%16][ch*16 + 4*cg + lane/16][tap]
 void gconv16_pack(const float* w, int cout, const int* cs, int nseg, int kh, int kw, float* packed) {
     int cin = 0;
     for (int s = 0; s < nseg; ++s) cin += cs[s];
@@ -371,7 +382,7 @@ void gconv16_pack(const float* w, int cout, const int* cs, int nseg, int kh, int
                     for (int mt = 0; mt < 4; ++mt)
                         for (int lane = 0; lane < 64; ++lane) {
                             const int co = cc * 64 + mt * 16 + (lane & 15), c = ch * 16 + 4 * cg + (lane >> 4);
-                            packed[((((((size_t)cc * nch + ch) * taps + tap) * 4 + mt) * 64) + lane) * 4 + cg] =
+                            packed[((((((size_t)cc * nch + ch) * 4 + mt) * taps + tap) * 64) + lane) * 4 + cg] =
                                 co < cout ? w[((size_t)co * cin + c) * taps + tap] : 0.f;
                         }
 }

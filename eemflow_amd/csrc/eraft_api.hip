@@ -26,8 +26,8 @@ int ensure(Buf& b, size_t floats) {
 }
 
 struct Layer {                    // one convolution, weights packed for gconv
-    size_t wpk = 0, wpk16 = 0, scale = 0, shift = 0;
-    bool has_scale = false, has16 = false;
+    size_t wpk = 0, wpk16 = 0, wfew = 0, scale = 0, shift = 0;
+    bool has_scale = false, has16 = false, has_few = false;
     int cout = 0, kh = 1, kw = 1, stride = 1, ph = 0, pw = 0;
     int cs[3] = {0, 0, 0}, nseg = 1;
 };
@@ -103,6 +103,11 @@ void make_layer(Packer& pk, Layer& L, const float* w, const float* bias, int cou
         L.wpk16 = pk.push(gconv16_packed_floats(con, cs, nseg, kh, kw));
         gconv16_pack(wsl, con, cs, nseg, kh, kw, pk.host.data() + L.wpk16);
     }
+    L.has_few = con <= 8 && kh == 3 && kw == 3 && stride == 1 && nseg == 1 && ph == 1 && pw == 1;   // flow head 256 -> 2: gconv.h fewout_*
+    if (L.has_few) {
+        L.wfew = pk.push(fewout_packed_floats(cin, kh, kw));
+        fewout_pack(wsl, con, cin, kh, kw, pk.host.data() + L.wfew);
+    }
     L.shift = pk.push(con);
     if (bn) {
         L.has_scale = true;
@@ -173,6 +178,7 @@ GConvArgs conv_args(const eraft_ctx* c, const Layer& L, int n, int hin, int win,
     a.nseg = L.nseg;
     a.wpk = c->arena + L.wpk;
     a.wpk16 = L.has16 ? c->arena + L.wpk16 : nullptr;
+    a.wfew = L.has_few ? c->arena + L.wfew : nullptr;
     a.zero_page = c->arena + c->zero_off;
     a.scale = L.has_scale ? c->arena + L.scale : nullptr;
     a.shift = c->arena + L.shift;

@@ -271,6 +271,55 @@ void gconv_pack(const float* w, int cout, const int* cs, int nseg, int kh, int k
 
 namespace {
 
+// One-pair inputs (E-RAFT's 2-channel flow through the 7x7 convf1, model/update.py:70): the k-steps are the taps.  The generic
+// kernel walks them as 49 batches of one k-step, each a round trip to L2 (36 us for 120 MFLOP at 60x80); here a wave requests the A
+// fragments and the B values of ALL its taps at once - 2 x TAPS registers, one latency - and then issues the TAPS MFMAs.
+// Wave = 32 pixels x 32 couts, block = 4 pixel tiles; weights in gconv_pack's order (k-step = tap).
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void gconv_taps_kernel(GConvArgs a) {
+    constexpr int TAPS = KH * KW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int n = blockIdx.z, cot = blockIdx.y;
+    const int hwo = a.hout * a.wout, hwi = a.hin * a.win;
+    const int p0 = (blockIdx.x * 4 + wave) * 32;
+    if (p0 >= hwo) return;
+    const int p = p0 + j;
+    const bool pv = p < hwo;
+    const int pc = pv ? p : 0;
+    const int oy = pc / a.wout, ox = pc - oy * a.wout;
+    const GConvSeg& sg = a.seg[0];
+    const bool cv = h < sg.c;                                     // a 1-channel input has an empty second half
+    const float* in = sg.ptr + ((size_t)n * sg.ctotal + sg.coff + (cv ? h : 0)) * hwi;
+    const float* wp = a.wpk + (size_t)cot * TAPS * 64 + lane;
+    float av[TAPS], bv[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+        const int iy = oy * a.stride - a.pad_h + t / KW, ix = ox * a.stride - a.pad_w + t % KW;
+        const bool ok = pv && cv && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
+        av[t] = wp[t * 64];
+        const float x = in[ok ? iy * a.win + ix : 0];
+        bv[t] = ok ? x : 0.f;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
+    if (!pv) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (co >= a.cout) continue;
+        float v = acc[r];
+        if (a.scale) v *= a.scale[co];
+        if (a.shift) v += a.shift[co];
+        v = g_act(v, a.act);
+        const int oc = a.out_coff + co * (a.out_cmul > 1 ? a.out_cmul : 1);
+        a.out[((size_t)n * a.out_ctotal + oc) * hwo + p] = v * a.out_scale;
+    }
+}
+
 // direct 3x3 convolution for <= 8 output channels.  Block = 64 consecutive pixels x FEW_WAVES channel groups: wave g takes the
 // channels [g * cpw, (g + 1) * cpw) of all 64 pixels (every tap is a 256-byte run per wave; the 8 weights of a (channel, tap) are
 // one uniform 32-byte load, scalar registers feed the FMAs), the partial sums meet in LDS and thread (co, pixel) finishes one output.
@@ -390,6 +439,19 @@ int gconv_launch(const GConvArgs& a, hipStream_t stream) {
     const long waves22 = (long)ceil_div(hwo, 64) * ceil_div(cot, 2) * a.n;
     int maxpairs = 0;
     for (int sgi = 0; sgi < a.nseg; ++sgi) maxpairs = std::max(maxpairs, (a.seg[sgi].c + 1) / 2);
+    {
+        const char* e = getenv("EEM_NO_TAPS_KERNEL");                // read per call: a test flips it inside one process
+        const bool off = e && e[0] == '1';
+        const bool shape7 = a.kh == 7 && a.kw == 7, shape3 = a.kh == 3 && a.kw == 3;
+        if (!off && a.nseg == 1 && a.seg[0].c <= 2 && (shape7 || shape3) && a.tstride <= 1 && a.epi == GEPI_PLAIN && a.seg[0].gate == nullptr &&
+            a.seg[0].cmul <= 1) {
+            dim3 grid(ceil_div(hwo, 128), cot, a.n);
+            if (shape7) hipLaunchKernelGGL((gconv_taps_kernel<7, 7>), grid, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((gconv_taps_kernel<3, 3>), grid, dim3(256), 0, stream, a);
+            EEM_HIP_CHECK(hipGetLastError());
+            return EEM_OK;
+        }
+    }
     if (maxpairs <= 4) {                                             // short batches for few-channel inputs
         if (waves22 >= 2048 && cot >= 2) {
             dim3 grid(ceil_div(hwo, 256), ceil_div(cot, 2), a.n);

@@ -122,3 +122,21 @@ def test_sixteen_output_conv_on_the_lds_tiled_kernel(monkeypatch):
         gen = ops.conv2d(convd, x.to(DEV), act=ops.ACT_LEAKY).cpu()
     assert float((tiled - ref).abs().max()) < 1e-4 and float((gen - ref).abs().max()) < 1e-4
     assert not torch.equal(tiled, gen)
+
+
+@pytest.mark.parametrize("cin,cout,k,h,w,b", [(2, 128, 7, 60, 80, 1), (1, 48, 7, 37, 53, 2), (2, 32, 3, 33, 40, 1)])
+def test_one_pair_input_conv_with_taps_as_k_steps(monkeypatch, cin, cout, k, h, w, b):
+    """Inputs of one channel pair (E-RAFT's flow through the 7x7 convf1, model/update.py:70) run with the taps as the k-steps of one
+    batch (gconv.hip: gconv_taps_kernel); EEM_NO_TAPS_KERNEL=1 (read per call) keeps the generic kernel's one-k-step batches."""
+    from eemflow_amd import ops
+    g = torch.Generator().manual_seed(cin * 100 + cout)
+    conv = torch.nn.Conv2d(cin, cout, k, padding=k // 2)
+    x = torch.randn(b, cin, h, w, generator=g)
+    ref = torch.relu(conv(x)).detach()
+    convd = conv.to(DEV)
+    with torch.no_grad():
+        fast = ops.conv2d(convd, x.to(DEV), act=ops.ACT_RELU).cpu()
+        monkeypatch.setenv("EEM_NO_TAPS_KERNEL", "1")
+        gen = ops.conv2d(convd, x.to(DEV), act=ops.ACT_RELU).cpu()
+    assert float((fast - ref).abs().max()) < 2e-5 and float((gen - ref).abs().max()) < 2e-5
+    assert torch.equal(fast, gen)                      # same k order per output: bitwise the same sums

@@ -325,9 +325,11 @@ __global__ __launch_bounds__(256) void gconv_taps_kernel(GConvArgs a) {
 // one uniform 32-byte load, scalar registers feed the FMAs), the partial sums meet in LDS and thread (co, pixel) finishes one output.
 // Splitting the channels rather than the pixels over the waves is what fills the chip: 180 x 320 pixels are 900 wave-rows, less
 // than one per SIMD, and a lone wave per SIMD cannot hide its own load latency.
-constexpr int FEW_WAVES = 8;
-
-__global__ __launch_bounds__(FEW_WAVES * 64, 8) void fewout_kernel(GConvArgs a, int cpw) {
+// FEW_WAVES = 8, CA = 1 (a channel ahead, 63 VGPRs, 8 waves per SIMD) for launches that fill the chip; 16 waves x CA = 2 (two
+// channels per request group, a group ahead) for launches of less than a wave per SIMD, where a wave's time is the number of its
+// request round trips (E-RAFT's flow head 256 -> 2 at 60x80: 75 blocks; 26 -> 12 us).
+template <int FEW_WAVES, int CA>
+__global__ __launch_bounds__(FEW_WAVES * 64, (FEW_WAVES == 8 ? 8 : 4)) void fewout_kernel(GConvArgs a, int cpw) {
     __shared__ float part[FEW_WAVES][8][64];
     const int hw = a.hin * a.win;
     const int lane = threadIdx.x & 63;
@@ -354,31 +356,39 @@ __global__ __launch_bounds__(FEW_WAVES * 64, 8) void fewout_kernel(GConvArgs a, 
         keep[t] = ok;
     }
     const float* w = a.wfew + (size_t)c0 * 72;
-    // two register sets, the next channel's nine taps in flight under this channel's 72 FMAs (the last request repeats a channel)
-    float va[9], vb[9];
-    auto request = [&](float (&v)[9], int c) __attribute__((always_inline)) {
-        const float* plane = in + (size_t)(min(c, c1 - 1) - c0) * hw;
+    // two register sets, the next group's taps (CA channels x 9) in flight under this group's FMAs (requests past the last channel
+    // repeat it; their products are skipped)
+    float va[CA][9], vb[CA][9];
+    auto request = [&](float (&v)[CA][9], int c) __attribute__((always_inline)) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) v[t] = plane[off[t]];
+        for (int q = 0; q < CA; ++q) {
+            const float* plane = in + (size_t)(min(c + q, c1 - 1) - c0) * hw;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) v[q][t] = plane[off[t]];
+        }
     };
-    auto fma = [&](const float (&v)[9], int c) __attribute__((always_inline)) {
+    auto fma = [&](const float (&v)[CA][9], int c) __attribute__((always_inline)) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const float vv = keep[t] ? v[t] : 0.f;
-            const float* w8 = w + ((size_t)(c - c0) * 9 + t) * 8;
+        for (int q = 0; q < CA; ++q) {
+            if (c + q >= c1) break;
 #pragma unroll
-            for (int co = 0; co < 8; ++co) acc[co] += vv * w8[co];
+            for (int t = 0; t < 9; ++t) {
+                const float vv = keep[t] ? v[q][t] : 0.f;
+                const float* w8 = w + ((size_t)(c + q - c0) * 9 + t) * 8;
+#pragma unroll
+                for (int co = 0; co < 8; ++co) acc[co] += vv * w8[co];
+            }
         }
     };
     if (c0 < c1) {
         request(va, c0);
 #pragma unroll 1
-        for (int c = c0; c < c1; c += 2) {
-            request(vb, c + 1);
+        for (int c = c0; c < c1; c += 2 * CA) {
+            request(vb, c + CA);
             fma(va, c);
-            if (c + 1 >= c1) break;
-            request(va, c + 2);
-            fma(vb, c + 1);
+            if (c + CA >= c1) break;
+            request(va, c + 2 * CA);
+            fma(vb, c + CA);
         }
     }
 #pragma unroll
@@ -386,7 +396,7 @@ __global__ __launch_bounds__(FEW_WAVES * 64, 8) void fewout_kernel(GConvArgs a, 
     __syncthreads();
     // thread (co = g, pixel = lane) sums the channel groups in order and finishes the output
     const int co = g;
-    if (!live || co >= a.cout) return;
+    if (!live || co >= 8 || co >= a.cout) return;
     float r = 0.f;
 #pragma unroll
     for (int k = 0; k < FEW_WAVES; ++k) r += part[k][co][lane];
@@ -423,8 +433,12 @@ bool fewout_supported(const GConvArgs& a) {
 
 int fewout_launch(const GConvArgs& a, hipStream_t stream) {
     const long n = (long)a.n * a.hin * a.win;
-    const int cpw = (a.seg[0].c + FEW_WAVES - 1) / FEW_WAVES;
-    hipLaunchKernelGGL(fewout_kernel, dim3((unsigned)((n + 63) / 64)), dim3(FEW_WAVES * 64), 0, stream, a, cpw);
+    const unsigned blocks = (unsigned)((n + 63) / 64);
+    if (blocks * 8 < 1024 && a.seg[0].c >= 64) {                      // less than a wave per SIMD
+        hipLaunchKernelGGL((fewout_kernel<16, 2>), dim3(blocks), dim3(1024), 0, stream, a, (a.seg[0].c + 15) / 16);
+    } else {
+        hipLaunchKernelGGL((fewout_kernel<8, 1>), dim3(blocks), dim3(512), 0, stream, a, (a.seg[0].c + 7) / 8);
+    }
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

@@ -271,9 +271,10 @@ void gconv_pack(const float* w, int cout, const int* cs, int nseg, int kh, int k
 
 namespace {
 
-// One-pair inputs (E-RAFT's 2-channel flow through the 7x7 convf1, model/update.py:70): the k-steps are the taps.  The generic
-// kernel walks them as 49 batches of one k-step, each a round trip to L2 (36 us for 120 MFLOP at 60x80); here a wave requests the A
-// fragments and the B values of ALL its taps at once - 2 x TAPS registers, one latency - and then issues the TAPS MFMAs.
+// Few-channel inputs (E-RAFT's 2-channel flow through the 7x7 convf1, model/update.py:70; the 5-bin event volumes through the
+// encoders' 7x7 stride-2 conv1, model/extractor.py:136): the k-steps of a pass are the taps of one channel pair.  The generic kernel
+// walks them as 49 batches of 1-4 k-steps, each a round trip to L2 (36 us for 120 MFLOP at 60x80); here a wave requests the A
+// fragments and the B values of ALL the taps of a pair at once - 2 x TAPS registers, one latency - and then issues the TAPS MFMAs.
 // Wave = 32 pixels x 32 couts, block = 4 pixel tiles; weights in gconv_pack's order (k-step = tap).
 template <int KH, int KW>
 __global__ __launch_bounds__(256) void gconv_taps_kernel(GConvArgs a) {
@@ -289,23 +290,27 @@ __global__ __launch_bounds__(256) void gconv_taps_kernel(GConvArgs a) {
     const int pc = pv ? p : 0;
     const int oy = pc / a.wout, ox = pc - oy * a.wout;
     const GConvSeg& sg = a.seg[0];
-    const bool cv = h < sg.c;                                     // a 1-channel input has an empty second half
-    const float* in = sg.ptr + ((size_t)n * sg.ctotal + sg.coff + (cv ? h : 0)) * hwi;
-    const float* wp = a.wpk + (size_t)cot * TAPS * 64 + lane;
-    float av[TAPS], bv[TAPS];
-#pragma unroll
-    for (int t = 0; t < TAPS; ++t) {
-        const int iy = oy * a.stride - a.pad_h + t / KW, ix = ox * a.stride - a.pad_w + t % KW;
-        const bool ok = pv && cv && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
-        av[t] = wp[t * 64];
-        const float x = in[ok ? iy * a.win + ix : 0];
-        bv[t] = ok ? x : 0.f;
-    }
+    const int cps = (sg.c + 1) >> 1;                              // channel pairs: one pass (round trip) each
+    const float* wp = a.wpk + (size_t)cot * TAPS * cps * 64 + lane;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 1
+    for (int cp = 0; cp < cps; ++cp) {
+        const bool cv = cp * 2 + h < sg.c;                        // an odd channel count leaves the last pair's second half empty
+        const float* in = sg.ptr + ((size_t)n * sg.ctotal + sg.coff + (cv ? cp * 2 + h : 0)) * hwi;
+        float av[TAPS], bv[TAPS];
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
+        for (int t = 0; t < TAPS; ++t) {
+            const int iy = oy * a.stride - a.pad_h + t / KW, ix = ox * a.stride - a.pad_w + t % KW;
+            const bool ok = pv && cv && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
+            av[t] = wp[(t * cps + cp) * 64];
+            const float x = in[ok ? iy * a.win + ix : 0];
+            bv[t] = ok ? x : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
+    }
     if (!pv) return;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -457,6 +462,8 @@ int gconv_launch(const GConvArgs& a, hipStream_t stream) {
         const char* e = getenv("EEM_NO_TAPS_KERNEL");                // read per call: a test flips it inside one process
         const bool off = e && e[0] == '1';
         const bool shape7 = a.kh == 7 && a.kw == 7, shape3 = a.kh == 3 && a.kw == 3;
+        // (one pair only: with the 5-bin volumes' three pairs through a stride-2 7x7 the 2x2-tile batches of the generic kernel are
+        // faster - measured, E-RAFT 122 -> 117 frames/s)
         if (!off && a.nseg == 1 && a.seg[0].c <= 2 && (shape7 || shape3) && a.tstride <= 1 && a.epi == GEPI_PLAIN && a.seg[0].gate == nullptr &&
             a.seg[0].cmul <= 1) {
             dim3 grid(ceil_div(hwo, 128), cot, a.n);

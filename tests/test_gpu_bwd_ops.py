@@ -139,4 +139,4 @@ def test_one_pair_input_conv_with_taps_as_k_steps(monkeypatch, cin, cout, k, h, 
         monkeypatch.setenv("EEM_NO_TAPS_KERNEL", "1")
         gen = ops.conv2d(convd, x.to(DEV), act=ops.ACT_RELU).cpu()
     assert float((fast - ref).abs().max()) < 2e-5 and float((gen - ref).abs().max()) < 2e-5
-    assert torch.equal(fast, gen)                      # same k order per output: bitwise the same sums
+    assert float((fast - gen).abs().max()) < 2e-5      # one pair: the same k order; several: taps within a pair instead of pairs within a tap

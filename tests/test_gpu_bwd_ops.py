@@ -140,3 +140,24 @@ def test_one_pair_input_conv_with_taps_as_k_steps(monkeypatch, cin, cout, k, h, 
         gen = ops.conv2d(convd, x.to(DEV), act=ops.ACT_RELU).cpu()
     assert float((fast - ref).abs().max()) < 2e-5 and float((gen - ref).abs().max()) < 2e-5
     assert float((fast - gen).abs().max()) < 2e-5      # one pair: the same k order; several: taps within a pair instead of pairs within a tap
+
+
+@pytest.mark.parametrize("cin,cout,k,h,w,b", [(336, 256, (1, 1), 60, 80, 1), (384, 128, (1, 5), 60, 80, 1), (384, 128, (5, 1), 60, 80, 1),
+                                               (256, 192, (3, 3), 60, 80, 1), (128, 64, (3, 3), 60, 80, 1), (128, 256, (3, 3), 45, 64, 2)])
+def test_lds_tiled_conv_with_two_k_groups(monkeypatch, cin, cout, k, h, w, b):
+    """E-RAFT's update block at batch 1: launches of at most one block per CU run two groups of four waves per tile that split the
+    channel chunks (gconv16.hip, KG = 2; 21 chunks: 11 + 10), with 3 / 5 / 6-row tiles chosen by rounds x rows.  Against torch and
+    against the generic kernel (EEM_NO_GCONV16=1, read per launch)."""
+    from eemflow_amd import ops
+    g = torch.Generator().manual_seed(cin + cout)
+    conv = torch.nn.Conv2d(cin, cout, k, padding=(k[0] // 2, k[1] // 2))
+    x = torch.randn(b, cin, h, w, generator=g)
+    ref = torch.relu(conv(x)).detach()
+    convd = conv.to(DEV)
+    with torch.no_grad():
+        tiled = ops.conv2d(convd, x.to(DEV), act=ops.ACT_RELU).cpu()
+        monkeypatch.setenv("EEM_NO_GCONV16", "1")
+        gen = ops.conv2d(convd, x.to(DEV), act=ops.ACT_RELU).cpu()
+    tol = 3e-5 * max(float(ref.abs().max()), 1.0) * (cin * k[0] * k[1] / 256) ** 0.5
+    assert float((tiled - ref).abs().max()) < tol and float((gen - ref).abs().max()) < tol
+    assert not torch.equal(tiled, gen)

@@ -128,6 +128,27 @@ def test_c5_eraft_640x480_12_iterations_batch4_vs_oracle():
     assert float(ref[-1].abs().max()) > 0.05                             # not a degenerate zero flow
 
 
+def test_eraft_640x480_batch1_vs_oracle():
+    """configs[4]'s shape at the batch an evaluation loop runs it with: the 60x80 update block is 75-300 blocks per launch, which is
+    where the convs choose 3 / 5 / 6-row tiles and two K groups per tile, the flow conv runs with its taps as k-steps and the flow head
+    on the few-output kernel (none of which the batch-4 case reaches)."""
+    b, h, w, iters = 1, 480, 640, 3
+    net = ERAFT("", 5).eval()
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sdn = seeded_from_shapes(shapes, 131)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sdn.items()})
+    net = net.to(DEV)
+    sd = O.to_torch_sd(sdn)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(132, b, h, w))
+    with torch.no_grad():
+        preds = net(e1.to(DEV), e2.to(DEV), iters=iters)[1]
+        ref, _ = R.eraft_forward(sd, e1, e2, iters=iters)
+    errs = [float((p.cpu() - r).abs().max()) for p, r in zip(preds, ref)]
+    assert max(errs) < 1e-3, errs
+    assert float(ref[-1].abs().max()) > 0.05
+
+
 def test_eraft_1280x720_resident_volume_vs_oracle():
     """SURVEY Appendix B's case for on-the-fly correlation: HREM's 1280x720 through E-RAFT is a 90x160 grid, a 14 400 x 14 400 all-pairs
     volume of 829 MB (+ 3 pooled levels) per pair.  It stays resident in the 288 GB of HBM (nothing is recomputed

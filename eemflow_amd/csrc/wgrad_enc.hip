@@ -72,14 +72,16 @@ __global__ __launch_bounds__(256) void wgrad_enc_kernel(WgradArgs a, int tiles_x
 
     // ---- DMA plan: per instruction and lane a byte offset from the tile's base pointer and the piece's
     // (row, column) inside the tile for the bounds test
-    int goff[C::NGI], grc[C::NGI], xoff[C::NXI], xrc[C::NXI];
+    constexpr unsigned RANGE = 0x7fffff00u;                     // bytes a buffer descriptor covers; offsets at or above it read as zero
+    unsigned goff[C::NGI], xoff[C::NXI];
+    int grc[C::NGI], xrc[C::NXI];
 #pragma unroll
     for (int k = 0; k < C::NGI; ++k) {
         const int f = (wave + 4 * k) * 64 + lane;
         const int co = f / 33, q = f - co * 33;
         const int p = 4 * q, py = p / TW, px = p - py * TW;
         const bool ok = f < C::GSLOTS && q < 32 && co < cout_here;
-        goff[k] = (int)(((size_t)co * ghw + (size_t)py * a.wout + px) * 4);
+        goff[k] = ok ? (unsigned)(((size_t)co * ghw + (size_t)py * a.wout + px) * 4) : RANGE;
         grc[k] = ok ? (py | (px << 8)) : -1;
     }
 #pragma unroll
@@ -88,35 +90,48 @@ __global__ __launch_bounds__(256) void wgrad_enc_kernel(WgradArgs a, int tiles_x
         const int ci = f / (C::XR * C::XQ), rem = f - ci * (C::XR * C::XQ);
         const int ry = rem / C::XQ, qx = rem - ry * C::XQ;
         const bool ok = f < C::XSLOTS && ci < cin_here;
-        xoff[k] = (int)(((size_t)ci * xhw + (size_t)ry * a.win + 4 * qx) * 4);
+        xoff[k] = ok ? (unsigned)(((size_t)ci * xhw + (size_t)ry * a.win + 4 * qx) * 4) : RANGE;
         xrc[k] = ok ? (ry | ((4 * qx) << 8)) : -1;
     }
-    const char* zero = reinterpret_cast<const char*>(a.zero_page);
+    // Both operands travel as buffer loads: the descriptor's base is the tile's corner (a scalar), a lane's offset inside the tile is
+    // fixed for the whole kernel, and pieces outside the image (or past the block's channels) carry an offset beyond the descriptor's
+    // range - the hardware writes zeros.  Interior tiles need no vector instruction per piece; edge tiles one compare + select.
+#if __HIP_DEVICE_COMPILE__
     auto issue = [&](int stage, const TileCoord& tc) {
         const int oy0 = tc.by * C::TH, ox0 = tc.bx * TW;
         const int gy0 = oy0 * S - C::PH, gx0 = ox0 * S - 4;
-        // signed element offsets: the first tile row / column starts above / left of the image
         const char* gb = reinterpret_cast<const char*>(a.g + ((size_t)tc.n * a.g_ctotal + a.g_coff) * ghw) +
                          ((long)oy0 * a.wout + ox0) * 4;
         const char* xb = reinterpret_cast<const char*>(a.x + ((size_t)tc.n * a.x_ctotal + a.x_coff + ci0) * xhw) +
                          ((long)gy0 * a.win + gx0) * 4;
         float* sg = lds + stage * C::STAGE;
         float* sx = sg + C::GFL;
+        const bool g_inside = oy0 + C::TH <= a.hout && ox0 + TW <= a.wout;
+        const bool x_inside = gy0 >= 0 && gy0 + C::XR <= a.hin && gx0 >= 0 && gx0 + 4 * C::XQ <= a.win;
+        const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(gb), (short)0, (int)RANGE, 0x00020000);
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xb), (short)0, (int)RANGE, 0x00020000);
 #pragma unroll
         for (int k = 0; k < C::NGI; ++k) {
-            const int py = grc[k] & 255, px = grc[k] >> 8;
-            const bool ok = grc[k] >= 0 && oy0 + py < a.hout && ox0 + px < a.wout;
-            const char* p = ok ? gb + goff[k] : zero;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(p), LDS_PTR(sg + (wave + 4 * k) * 256), 16, 0, 0);
+            unsigned vo = goff[k];
+            if (!g_inside) {
+                const int py = grc[k] & 255, px = grc[k] >> 8;
+                vo = (grc[k] >= 0 && oy0 + py < a.hout && ox0 + px < a.wout) ? vo : RANGE;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, LDS_PTR(sg + (wave + 4 * k) * 256), 16, vo, 0, 0, 0);
         }
 #pragma unroll
         for (int k = 0; k < C::NXI; ++k) {
-            const int iy = gy0 + (xrc[k] & 255), ix = gx0 + (xrc[k] >> 8);
-            const bool ok = xrc[k] >= 0 && iy >= 0 && iy < a.hin && ix >= 0 && ix + 4 <= a.win;
-            const char* p = ok ? xb + xoff[k] : zero;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(p), LDS_PTR(sx + (wave + 4 * k) * 256), 16, 0, 0);
+            unsigned vo = xoff[k];
+            if (!x_inside) {
+                const int iy = gy0 + (xrc[k] & 255), ix = gx0 + (xrc[k] >> 8);
+                vo = (xrc[k] >= 0 && iy >= 0 && iy < a.hin && ix >= 0 && ix + 4 <= a.win) ? vo : RANGE;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, LDS_PTR(sx + (wave + 4 * k) * 256), 16, vo, 0, 0, 0);
         }
     };
+#else
+    auto issue = [&](int, const TileCoord&) {};
+#endif
 
     // ---- operand offsets.  k-step s of this wave covers pixels 32*wave + 4s + g
     int boff[NT];

@@ -53,6 +53,7 @@ struct eraft_ctx {
     size_t zero_off = 0;           // 64 zero floats inside the arena (LDS-DMA source for padding)
     Encoder fnet, cnet;
     Layer convc1, convc2, convf1, convf2, conv, gz[2], gr[2], gq[2], fh1, fh2, mk0, mk2;
+    Layer gzr[2], heads1;          // z | r of a GRU pass and flow-head | mask-head conv1 as ONE launch each (small batches)
     // workspace
     Buf padded, s[5], fmap, net[2], inp, pyr[4], c0, c1, corr, cor1, corflo, flo1, motion, z, rh, fhid, delta, mhid, mask;
     Buf st_corr0, st_net1, st_mask1, st_delta1, zeros;
@@ -330,12 +331,26 @@ extern "C" int eraft_load_weights(eraft_ctx* c, const float* flat, size_t nfloat
     c->zero_off = pk.push(64);
     parse_encoder(cur, pk, c->fnet, false, n_first_channels, 256, false);
     parse_encoder(cur, pk, c->cnet, true, n_first_channels, 256, true);
+    const float* last_w = nullptr;
+    const float* last_b = nullptr;
     auto plain = [&](Layer& L, int cout, const int* cs, int nseg, int kh, int kw, int ph, int pw) {
         int cin = 0;
         for (int s = 0; s < nseg; ++s) cin += cs[s];
         const float* w = cur.take((size_t)cout * cin * kh * kw);
         const float* b = cur.take(cout);
+        last_w = w; last_b = b;
         make_layer(pk, L, w, b, cout, 0, cout, cs, nseg, kh, kw, 1, ph, pw, nullptr);
+    };
+    // two layers that read the same input, stacked along the output channels
+    auto stacked = [&](Layer& L, const float* w0, const float* b0, const float* w1, const float* b1, int cout_each, const int* cs, int nseg,
+                       int kh, int kw, int ph, int pw) {
+        int cin = 0;
+        for (int s = 0; s < nseg; ++s) cin += cs[s];
+        const size_t nw = (size_t)cout_each * cin * kh * kw;
+        std::vector<float> w(2 * nw), b(2 * (size_t)cout_each);
+        memcpy(w.data(), w0, nw * sizeof(float)); memcpy(w.data() + nw, w1, nw * sizeof(float));
+        memcpy(b.data(), b0, cout_each * sizeof(float)); memcpy(b.data() + cout_each, b1, cout_each * sizeof(float));
+        make_layer(pk, L, w.data(), b.data(), 2 * cout_each, 0, 2 * cout_each, cs, nseg, kh, kw, 1, ph, pw, nullptr);
     };
     const int c324[1] = {324}, c256[1] = {256}, c2[1] = {2}, c128[1] = {128}, c3x128[3] = {128, 128, 128};
     plain(c->convc1, 256, c324, 1, 1, 1, 0, 0);          // model/update.py:63-71
@@ -352,15 +367,19 @@ extern "C" int eraft_load_weights(eraft_ctx* c, const float* flat, size_t nfloat
     plain(c->convf1, 128, c2, 1, 7, 7, 3, 3);
     plain(c->convf2, 64, c128, 1, 3, 3, 1, 1);
     plain(c->conv, 126, c256, 1, 3, 3, 1, 1);
-    plain(c->gz[0], 128, c3x128, 3, 1, 5, 0, 2);         // model/update.py:33-44: hx = [h | inp | motion]
-    plain(c->gr[0], 128, c3x128, 3, 1, 5, 0, 2);
-    plain(c->gq[0], 128, c3x128, 3, 1, 5, 0, 2);
-    plain(c->gz[1], 128, c3x128, 3, 5, 1, 2, 0);
-    plain(c->gr[1], 128, c3x128, 3, 5, 1, 2, 0);
-    plain(c->gq[1], 128, c3x128, 3, 5, 1, 2, 0);
+    for (int pass = 0; pass < 2; ++pass) {               // model/update.py:33-44: hx = [h | inp | motion]; 1x5 pass, then 5x1
+        const int kh = pass ? 5 : 1, kw = pass ? 1 : 5, ph = pass ? 2 : 0, pw = pass ? 0 : 2;
+        plain(c->gz[pass], 128, c3x128, 3, kh, kw, ph, pw);
+        const float* wz = last_w; const float* bz = last_b;
+        plain(c->gr[pass], 128, c3x128, 3, kh, kw, ph, pw);
+        stacked(c->gzr[pass], wz, bz, last_w, last_b, 128, c3x128, 3, kh, kw, ph, pw);
+        plain(c->gq[pass], 128, c3x128, 3, kh, kw, ph, pw);
+    }
     plain(c->fh1, 256, c128, 1, 3, 3, 1, 1);             // model/update.py:6-14
+    const float* wf = last_w; const float* bf = last_b;
     plain(c->fh2, 2, c256, 1, 3, 3, 1, 1);
     plain(c->mk0, 256, c128, 1, 3, 3, 1, 1);             // model/update.py:92-95
+    stacked(c->heads1, wf, bf, last_w, last_b, 256, c128, 1, 3, 3, 1, 1);
     plain(c->mk2, 576, c256, 1, 1, 1, 0, 0);
     EEM_REQUIRE(cur.p == cur.end, "eraft_load_weights: the 179-tensor layout needs %zu floats (num_batches_tracked "
                                   "excluded), got %zu", (size_t)(cur.p - flat), nfloats);
@@ -393,8 +412,8 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
     ENS(c->fmap, (size_t)2 * B * 256 * g);
     ENS(c->net[0], B * 128 * g); ENS(c->net[1], B * 128 * g); ENS(c->inp, B * 128 * g);
     ENS(c->c0, B * 2 * g); ENS(c->c1, B * 2 * g); ENS(c->corr, B * kCorrPad * g); ENS(c->cor1, B * 256 * g);
-    ENS(c->corflo, B * 256 * g); ENS(c->flo1, B * 128 * g); ENS(c->motion, B * 128 * g); ENS(c->z, B * 128 * g);
-    ENS(c->rh, B * 128 * g); ENS(c->fhid, B * 256 * g); ENS(c->delta, B * 2 * g); ENS(c->mhid, B * 256 * g);
+    ENS(c->corflo, B * 256 * g); ENS(c->flo1, B * 128 * g); ENS(c->motion, B * 128 * g); ENS(c->z, B * 256 * g);
+    ENS(c->rh, B * 128 * g); ENS(c->fhid, B * 512 * g); ENS(c->delta, B * 2 * g); ENS(c->mhid, B * 256 * g);
     ENS(c->mask, B * 576 * g);
     if (c->keep_stages) { ENS(c->st_corr0, B * 324 * g); ENS(c->st_net1, B * 128 * g); ENS(c->st_mask1, B * 576 * g); ENS(c->st_delta1, B * 2 * g); }
 #undef ENS
@@ -458,33 +477,56 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
         // SepConvGRU (model/update.py:43-60): horizontal then vertical pass
         float* hcur = net;
         float* hnext = netn;
+        // Layers that read the same input run as ONE launch stacked along the output channels: z | r of a GRU pass (r * h then is a
+        // small elementwise launch), and the first convs of the flow head and the mask head.  One forward at a time at batch 1 these were
+        // 200-block launches for 256 CUs each - one round of 5 / 6-row tiles now instead of two launches that each leave the chip
+        // partly empty (an update iteration at 60x80: 490 -> 430 us, 121 -> 129 frames/s; + 1.5 % at batch 4 / 8, the same with
+        // frames in flight).  EEM_ERAFT_NO_STACK=1 (read per forward) keeps them apart.
+        const char* ens = getenv("EEM_ERAFT_NO_STACK");
+        const bool stack = !(ens && ens[0] == '1');
         for (int pass = 0; pass < 2; ++pass) {
-            a = conv_args(c, c->gz[pass], B, h8, w8, c->z.p, 128, 0, GACT_SIGMOID);
-            set_seg(a, 0, hcur, 128, 128, 0); set_seg(a, 1, c->inp.p, 128, 128, 0); set_seg(a, 2, c->motion.p, 128, 128, 0);
-            if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
-            a = conv_args(c, c->gr[pass], B, h8, w8, c->rh.p, 128, 0, GACT_SIGMOID);
-            set_seg(a, 0, hcur, 128, 128, 0); set_seg(a, 1, c->inp.p, 128, 128, 0); set_seg(a, 2, c->motion.p, 128, 128, 0);
-            a.epi = GEPI_MUL; a.e0 = hcur; a.e0_ctotal = 128; a.e0_coff = 0;
-            if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+            if (stack) {
+                a = conv_args(c, c->gzr[pass], B, h8, w8, c->z.p, 256, 0, GACT_SIGMOID);
+                set_seg(a, 0, hcur, 128, 128, 0); set_seg(a, 1, c->inp.p, 128, 128, 0); set_seg(a, 2, c->motion.p, 128, 128, 0);
+                if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+                if ((rc = er_mul_channels_launch(c->rh.p, c->z.p, 256, 128, hcur, B, 128, (long)g, st)) != EEM_OK) return rc;
+            } else {
+                a = conv_args(c, c->gz[pass], B, h8, w8, c->z.p, 128, 0, GACT_SIGMOID);
+                set_seg(a, 0, hcur, 128, 128, 0); set_seg(a, 1, c->inp.p, 128, 128, 0); set_seg(a, 2, c->motion.p, 128, 128, 0);
+                if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+                a = conv_args(c, c->gr[pass], B, h8, w8, c->rh.p, 128, 0, GACT_SIGMOID);
+                set_seg(a, 0, hcur, 128, 128, 0); set_seg(a, 1, c->inp.p, 128, 128, 0); set_seg(a, 2, c->motion.p, 128, 128, 0);
+                a.epi = GEPI_MUL; a.e0 = hcur; a.e0_ctotal = 128; a.e0_coff = 0;
+                if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+            }
             a = conv_args(c, c->gq[pass], B, h8, w8, hnext, 128, 0, GACT_TANH);
             set_seg(a, 0, c->rh.p, 128, 128, 0); set_seg(a, 1, c->inp.p, 128, 128, 0); set_seg(a, 2, c->motion.p, 128, 128, 0);
-            a.epi = GEPI_GRU; a.e0 = hcur; a.e0_ctotal = 128; a.e0_coff = 0; a.e1 = c->z.p; a.e1_ctotal = 128; a.e1_coff = 0;
+            a.epi = GEPI_GRU; a.e0 = hcur; a.e0_ctotal = 128; a.e0_coff = 0; a.e1 = c->z.p; a.e1_ctotal = stack ? 256 : 128; a.e1_coff = 0;
             if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
             float* t = hcur; hcur = hnext; hnext = t;
         }
         // after two passes the new hidden state is back in `net`
         // flow head and mask head (model/update.py:102-105)
-        a = conv_args(c, c->fh1, B, h8, w8, c->fhid.p, 256, 0, GACT_RELU);
-        set_seg(a, 0, net, 128, 128, 0);
-        if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+        const float* mh = c->mhid.p;
+        int head_ct = 256, mh_off = 0;
+        if (stack) {
+            a = conv_args(c, c->heads1, B, h8, w8, c->fhid.p, 512, 0, GACT_RELU);
+            set_seg(a, 0, net, 128, 128, 0);
+            if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+            mh = c->fhid.p; head_ct = 512; mh_off = 256;
+        } else {
+            a = conv_args(c, c->fh1, B, h8, w8, c->fhid.p, 256, 0, GACT_RELU);
+            set_seg(a, 0, net, 128, 128, 0);
+            if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+            a = conv_args(c, c->mk0, B, h8, w8, c->mhid.p, 256, 0, GACT_RELU);
+            set_seg(a, 0, net, 128, 128, 0);
+            if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+        }
         a = conv_args(c, c->fh2, B, h8, w8, c->delta.p, 2, 0, GACT_NONE);
-        set_seg(a, 0, c->fhid.p, 256, 256, 0);
-        if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
-        a = conv_args(c, c->mk0, B, h8, w8, c->mhid.p, 256, 0, GACT_RELU);
-        set_seg(a, 0, net, 128, 128, 0);
+        set_seg(a, 0, c->fhid.p, 256, head_ct, 0);
         if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
         a = conv_args(c, c->mk2, B, h8, w8, c->mask.p, 576, 0, GACT_NONE);
-        set_seg(a, 0, c->mhid.p, 256, 256, 0);
+        set_seg(a, 0, mh, 256, head_ct, mh_off);
         a.out_scale = 0.25f;
         if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
         if ((rc = er_axpy_launch(c->c1.p, c->delta.p, (long)B * 2 * g, st)) != EEM_OK) return rc;              // :149

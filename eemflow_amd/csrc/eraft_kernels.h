@@ -46,6 +46,7 @@ int er_flow_launch(const float* coords0, const float* coords1, float* dst, int d
                    hipStream_t st);
 // coords1 += delta
 int er_axpy_launch(float* y, const float* x, long n, hipStream_t st);
+int er_mul_channels_launch(float* out, const float* a, int a_ctotal, int a_coff, const float* b, int batch, int c, long hw, hipStream_t st);
 
 // convex upsampling (model/eraft.py:83-94) of flow = coords1 - coords0 with mask [B][576][H][W], written
 // unpadded: out[b][c][Y - top][X - left] for the (8H x 8W) result cropped to [oh][ow]

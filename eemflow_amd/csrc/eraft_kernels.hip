@@ -387,6 +387,16 @@ __global__ __launch_bounds__(256) void axpy_kernel(float* y, const float* x, lon
     if (idx < n) y[idx] += x[idx];
 }
 
+// out[n][c][p] = a[n][a_coff + c][p] * b[n][c][p]: r * h of the GRU when z and r come out of one 256-cout launch
+__global__ __launch_bounds__(256) void mul_channels_kernel(float* __restrict__ out, const float* __restrict__ a, int a_ctotal, int a_coff,
+                                                            const float* __restrict__ b, int c, long hw, long n) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const long chw = (long)c * hw;
+    const long img = idx / chw, rem = idx - img * chw;
+    out[idx] = a[(img * a_ctotal + a_coff) * hw + rem] * b[idx];
+}
+
 // one thread per output pixel (both flow channels): softmax over the 9 mask logits of its (sub-pixel, cell),
 // convex combination of the 3x3 neighbourhood of 8*flow (zero outside, F.unfold padding=1)
 __global__ __launch_bounds__(256) void convex_up_kernel(const float* __restrict__ c0, const float* __restrict__ c1,
@@ -489,6 +499,13 @@ int er_flow_launch(const float* c0, const float* c1, float* dst, int dst_ctotal,
 
 int er_axpy_launch(float* y, const float* x, long n, hipStream_t st) {
     hipLaunchKernelGGL(axpy_kernel, dim3(blocks(n)), dim3(256), 0, st, y, x, n);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int er_mul_channels_launch(float* out, const float* a, int a_ctotal, int a_coff, const float* b, int batch, int c, long hw, hipStream_t st) {
+    const long n = (long)batch * c * hw;
+    hipLaunchKernelGGL(mul_channels_kernel, dim3(blocks(n)), dim3(256), 0, st, out, a, a_ctotal, a_coff, b, c, hw, n);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

@@ -189,3 +189,18 @@ def test_errors():
     net.freeze_bn()                            # eval-mode BatchNorm under autograd is not built (the reference trains with it in train())
     with pytest.raises(_lib.EEMFlowHipError):
         net(torch.zeros(1, 5, 128, 128, device=DEV), torch.zeros(1, 5, 128, 128, device=DEV))
+
+
+def test_stacked_update_block_launches_equal_separate_ones(monkeypatch):
+    """z | r of a GRU pass and flow-head | mask-head conv1 run as one launch each, stacked along the output channels
+    (csrc/eraft_api.hip); EEM_ERAFT_NO_STACK=1 (read per forward) keeps the reference's five separate convolutions.  Per output
+    channel the same kernel, tile shape permitting the same k order: equal to round-off."""
+    h, w = 256, 320
+    net, _ = make_net(41)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(42, 2, h, w))
+    with torch.no_grad():
+        stacked = torch.stack(net(e1, e2, iters=4)[1]).clone()
+        monkeypatch.setenv("EEM_ERAFT_NO_STACK", "1")
+        apart = torch.stack(net(e1, e2, iters=4)[1]).clone()
+    assert maxerr(stacked, apart) < 2e-4 and float(apart.abs().max()) > 1e-3

@@ -450,6 +450,10 @@ int fewout_launch(const GConvArgs& a, hipStream_t stream) {
 
 int gconv_launch(const GConvArgs& a, hipStream_t stream) {
     EEM_REQUIRE(a.nseg >= 1 && a.nseg <= 3 && a.n >= 1 && a.cout >= 1, "gconv_launch: bad arguments");
+    if (a.groups > 1) {
+        EEM_REQUIRE(gconv16_supported(a), "gconv_launch: a grouped launch needs the LDS-tiled kernel (the caller checks gconv16_supported)");
+        return gconv16_launch(a, stream);
+    }
     if (fewout_supported(a)) return fewout_launch(a, stream);
     if (gconv16_supported(a)) return gconv16_launch(a, stream);
     const int hwo = a.hout * a.wout;

@@ -113,7 +113,10 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || (THT != 2 && THT != 4)) ? 2 : 
     // WM = waves along the couts (16 each): 4 -> a block covers 64 couts and every wave all TH rows; 2 -> 32 couts (layers of
     // <= 32 couts), the two wave pairs split the rows; 1 -> 16 couts (EEMFlow+'s 160 -> 16 estimator layer), a row per wave
     const int wm = wave % WM, wp = wave / WM;
-    const int mtg = blockIdx.y * WM + wm;                        // global 16-cout tile of this wave
+    int grp = 0, by = blockIdx.y;                                // grouped launch: blockIdx.y = (group, cout tile of the group)
+    if (a.groups > 1) { const int tpg = gridDim.y / a.groups; grp = by / tpg; by -= grp * tpg; }
+    wpk16 += (size_t)grp * a.g_wstride16;
+    const int mtg = by * WM + wm;                                // 16-cout tile of this wave (within its group)
     const int n = blockIdx.z, cc = mtg >> 2, mt = mtg & 3;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int y0 = ty * C::TH, x0 = tx * C::TW;
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || (THT != 2 && THT != 4)) ? 2 : 
     // the chain of selects into an indexed read of a private (scratch) copy - a scratch load and an `s_waitcnt vmcnt(0)` in front of
     // every chunk's DMA (kernel arguments indexed dynamically were a scalar load + wait in the same place)
 #define G16_SEG_PTR(S) (reinterpret_cast<const char*>(a.seg[S].ptr + ((size_t)n * a.seg[S].ctotal + a.seg[S].coff) * hw))
-    const char* const sp0 = G16_SEG_PTR(0);
+    const char* const sp0 = G16_SEG_PTR(0) + (size_t)grp * a.seg[0].c * hw * 4;
     const char* const sp1 = a.nseg > 1 ? G16_SEG_PTR(1) : nullptr;
     const char* const sp2 = a.nseg > 2 ? G16_SEG_PTR(2) : nullptr;
 #undef G16_SEG_PTR
@@ -196,8 +199,8 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || (THT != 2 && THT != 4)) ? 2 : 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int co = min(mtg * 16 + 4 * g + r, a.cout - 1);
-        e_scale[r] = a.scale ? a.scale[co] : 1.f;
-        e_shift[r] = a.shift ? a.shift[co] : 0.f;
+        e_scale[r] = a.scale ? a.scale[co + grp * a.g_pstride] : 1.f;
+        e_shift[r] = a.shift ? a.shift[co + grp * a.g_pstride] : 0.f;
     }
     // group kg takes the chunks kg, kg + KG, ...; every group runs the same number of steps (the barrier counts all waves)
     const int nmine = (nchunks - kg + KG - 1) / KG, nsteps = (nchunks + KG - 1) / KG;
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || (THT != 2 && THT != 4)) ? 2 : 
             } else if (a.epi == GEPI_ADD) {
                 v += a.e0[((size_t)n * a.e0_ctotal + a.e0_coff + co) * hw + p];
             }
-            const int oc = a.out_coff + co * (a.out_cmul > 1 ? a.out_cmul : 1);
+            const int oc = a.out_coff + grp * a.g_ocoff + co * (a.out_cmul > 1 ? a.out_cmul : 1);
             a.out[((size_t)n * a.out_ctotal + oc) * hw + p] = v * a.out_scale;
         }
     }
@@ -291,7 +294,8 @@ int launch_wm(const GConvArgs& a, const float* wpk16, const float* zero_page, hi
     int cin = 0;
     for (int s = 0; s < a.nseg; ++s) cin += a.seg[s].c;
     const int tiles_x = ceil_div(a.wout, C::TW), tiles_y = ceil_div(a.hout, C::TH);
-    dim3 grid(tiles_x * tiles_y, ceil_div(a.cout, 16 * WM), a.n);
+    const int ng = a.groups > 1 ? a.groups : 1;
+    dim3 grid(tiles_x * tiles_y, ceil_div(a.cout, 16 * WM) * ng, a.n);
     // at most one block per CU: two K groups of four waves per tile (see the kernel's KG)
     static const int kg_env = [] { const char* e = getenv("EEM_G16_KG"); return e ? atoi(e) : 0; }();
     static const int cus = [] { int d = 0, n = 256; hipDeviceProp_t p; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) n = p.multiProcessorCount; return n > 0 ? n : 256; }();
@@ -314,7 +318,7 @@ int launch_th(const GConvArgs& a, const float* wpk16, const float* zero_page, hi
 template <int KH, int KW>
 int launch(const GConvArgs& a, const float* wpk16, const float* zero_page, hipStream_t stream) {
     static const int th_env = [] { const char* e = getenv("EEM_G16_TH"); return e ? atoi(e) : 0; }();
-    const auto blocks_of = [&](int th) { return (long)ceil_div(a.wout, 16) * ceil_div(a.hout, th) * ceil_div(a.cout, 64) * a.n; };
+    const auto blocks_of = [&](int th) { return (long)ceil_div(a.wout, 16) * ceil_div(a.hout, th) * ceil_div(a.cout, 64) * a.n * (a.groups > 1 ? a.groups : 1); };
     int th;
     if (th_env) {
         th = th_env;
@@ -402,8 +406,9 @@ bool gconv16_supported(const GConvArgs& a) {
     // stay on the generic kernel's split-K form (128 blocks before the K groups and the tile-row choice, 48 with them)
     static const int min_cin = [] { const char* m = getenv("EEM_G16_MINCIN"); return m ? atoi(m) : 32; }();
     static const long min_blk = [] { const char* m = getenv("EEM_G16_MINBLK"); return m ? atol(m) : 48L; }();
-    const long blocks = (long)ceil_div(a.wout, 16) * ceil_div(a.hout, 4) * ceil_div(a.cout, 64) * a.n;
+    const long blocks = (long)ceil_div(a.wout, 16) * ceil_div(a.hout, 4) * ceil_div(a.cout, 64) * a.n * (a.groups > 1 ? a.groups : 1);
     if (cin < min_cin || blocks < min_blk) return false;
+    if (a.groups > 1 && (a.nseg != 1 || a.epi != GEPI_PLAIN)) return false;
     return gconv16_shape(a.cout, cs, a.nseg, a.kh, a.kw, a.stride) && a.win % 4 == 0 && a.hout == a.hin && a.wout == a.win &&
            (size_t)16 * a.hin * a.win * 4 < (1u << 31);
 }

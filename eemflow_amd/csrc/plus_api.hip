@@ -173,13 +173,44 @@ int run_decoder(eemplus_ctx* c, int l, int B, int h, int w, const float* residua
         if ((rc = tail_conv_launch(L, st)) != EEM_OK) return rc;
     } else {
         if ((rc = conv(c, c->dec1[l], c->cat.p, kCat, 0, B, h, w, c->d[0].p, kDW, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
-        for (int layer = 0; layer < 3; ++layer)
+        const char* eng = getenv("EEM_PLUS_NO_GROUPED");             // read per forward: a test runs both forms in one process
+        const bool no_grouped = eng && eng[0] == '1';
+        for (int layer = 0; layer < 3; ++layer) {
+            // the G groups of a layer as ONE launch of the LDS-tiled kernel when their packings lie at equal distances in the arena
+            // (they do: same shapes, packed one after the other) and the launch qualifies
+            if (G > 1 && !no_grouped) {
+                const PLayer& L0 = c->decg[l][layer][0];
+                const PLayer& L1 = c->decg[l][layer][1];
+                bool even = L0.has16;
+                for (int gi = 1; gi < G && even; ++gi) {
+                    const PLayer& Lg = c->decg[l][layer][gi];
+                    even = Lg.has16 && Lg.wpk16 - L0.wpk16 == (size_t)gi * (L1.wpk16 - L0.wpk16) && Lg.bias - L0.bias == (size_t)gi * (L1.bias - L0.bias);
+                }
+                if (even) {
+                    GConvArgs a;
+                    memset(&a, 0, sizeof(a));
+                    a.nseg = 1;
+                    a.seg[0].ptr = c->d[layer].p; a.seg[0].c = per; a.seg[0].ctotal = kDW; a.seg[0].coff = 0;
+                    a.wpk = c->arena + L0.wpk; a.wpk16 = c->arena + L0.wpk16; a.shift = c->arena + L0.bias;
+                    a.zero_page = c->arena + c->zero_off;
+                    a.out = c->d[layer + 1].p; a.out_ctotal = kDW; a.out_coff = 0; a.out_cmul = G;
+                    a.n = B; a.hin = a.hout = h; a.win = a.wout = w;
+                    a.cout = per; a.kh = a.kw = 3; a.stride = 1; a.pad_h = a.pad_w = 1;
+                    a.act = GACT_LEAKY; a.out_scale = 1.f; a.in_flight = c->frames_in_flight;
+                    a.groups = G; a.g_wstride16 = (long)(L1.wpk16 - L0.wpk16); a.g_pstride = (long)(L1.bias - L0.bias); a.g_ocoff = 1;
+                    if (gconv16_supported(a)) {
+                        if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+                        continue;
+                    }
+                }
+            }
             for (int gi = 0; gi < G; ++gi) {
                 // group gi reads channels [gi*per, (gi+1)*per); channel_shuffle puts its output j at j*G + gi
                 const int oc = G == 1 ? 0 : gi, om = G == 1 ? 1 : G;
                 if ((rc = conv(c, c->decg[l][layer][gi], c->d[layer].p, kDW, gi * per, B, h, w, c->d[layer + 1].p, kDW, oc, om, GACT_LEAKY,
                                nullptr, st)) != EEM_OK) return rc;
             }
+        }
         if ((rc = conv(c, c->dec5[l], c->d[3].p, kDW, 0, B, h, w, c->t64.p, 64, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
         if ((rc = conv(c, c->dec6[l], c->t64.p, 64, 0, B, h, w, c->t32.p, 32, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
     }

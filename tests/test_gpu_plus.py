@@ -164,3 +164,18 @@ def test_fast_encoder_equals_generic_encoder(monkeypatch):
     assert err[0].max() < 1e-4
     for i in range(1, 5):
         assert np.median(err[i]) < 2e-3 and (err[i] > 0.25).mean() < 0.02 and err[i].max() < 2.0, i   # bounds of the golden test
+
+
+def test_grouped_decoder_launch_equals_one_launch_per_group(monkeypatch):
+    """The decoder's three 32 -> 32 groups of a layer (+ channel shuffle, EEMFlow+.py:52-63) run as ONE launch of the LDS-tiled kernel
+    (blockIdx.y = (group, cout tile)); EEM_PLUS_NO_GROUPED=1 (read per forward) launches them one by one.  Same kernel, same k order
+    per output: the same flows."""
+    h, w = 256, 320
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(71, 1, h, w, bins=5))
+    net = make_net(72, 5)
+    net.change_imagesize((h, w))
+    with torch.no_grad():
+        grouped = torch.stack(net(e1, e2)[1]).cpu().numpy()
+        monkeypatch.setenv("EEM_PLUS_NO_GROUPED", "1")
+        apart = torch.stack(net(e1, e2)[1]).cpu().numpy()
+    assert np.abs(grouped - apart).max() < 1e-6 and np.abs(apart).max() > 1e-3

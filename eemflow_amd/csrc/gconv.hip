@@ -61,6 +61,11 @@ __global__ __launch_bounds__(SPLITK ? SPLITK * 64 : 256) void gconv_kernel(GConv
             for (int r = 0; r < 16; ++r) acc[t][m][r] = 0.f;
 
     const float* wp = a.wpk + (size_t)cot0 * ksteps * 64 + lane;
+    // a wave's second cout tile may lie past the last one (96 or 126 couts: three / four tiles, two per wave): its fragments are read
+    // from the first tile again - the products are dropped in the epilogue, the reads must stay inside the packed stream
+    int mt_off[MTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) mt_off[m] = (cot0 + m) * 32 < a.cout ? m : 0;
     // The k-loop is a flat sequence of batches of U k-steps: (tap, segment, first channel pair).
     //  * Addressing: a FULL batch (every channel of every pair exists) uses one base pointer per operand plus constant
     //    steps and no per-k-step predicates; the general form costs ~27 VALU / SALU instructions of 64-bit address and
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(SPLITK ? SPLITK * 64 : 256) void gconv_kernel(GConv
 #pragma unroll
             for (int u = 0; u < U; ++u) {
 #pragma unroll
-                for (int m = 0; m < MTW; ++m) av[u][m] = ap[(size_t)m * ksteps * 64 + u * 64];
+                for (int m = 0; m < MTW; ++m) av[u][m] = ap[(size_t)mt_off[m] * ksteps * 64 + u * 64];
 #pragma unroll
                 for (int t = 0; t < NPW; ++t) {
                     float x = *bp[t];
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(SPLITK ? SPLITK * 64 : 256) void gconv_kernel(GConv
                 const float* bp = base + coffs;
                 const int kk = ok ? q.ks + u : q.ks;         // surplus slots re-read a valid fragment; their B is 0
 #pragma unroll
-                for (int m = 0; m < MTW; ++m) av[u][m] = wp[((size_t)m * ksteps + kk) * 64];
+                for (int m = 0; m < MTW; ++m) av[u][m] = wp[((size_t)mt_off[m] * ksteps + kk) * 64];
 #pragma unroll
                 for (int t = 0; t < NPW; ++t) {
                     float x = bp[off[t]];

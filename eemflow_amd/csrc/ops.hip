@@ -14,6 +14,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/eemflow_hip.h"
@@ -330,29 +331,72 @@ void plan_addfew(Plan& p, const float* iw, int cout, const int* cs, int nseg, in
     }
 }
 
-// Packs the weights for the launch described by `a` (everything but the weight pointers filled in): the LDS-tiled kernel's stream
-// when the launch qualifies for it, else the generic kernel's.
+// ---- packed weights kept per (parameter, version): a recurrent model applies the same weights a dozen times per step and the data
+// gradient needs them again - the caller names the weight tensor of the next launches (eemop_pack_hint: a token that is never reused
+// + the tensor's version counter), and a packing is redone only when that version changes.  Without a hint (token 0) every launch packs
+// into the shared scratch, as before.
+thread_local long long t_pack_token = 0, t_pack_version = -1;
+struct PackEntry { float* p = nullptr; size_t cap = 0; long long version = -1; int dev = -1; };
+struct PackKey {
+    long long token; const float* w; const int* idx; hipStream_t st;
+    bool operator<(const PackKey& o) const { return std::tie(token, w, idx, st) < std::tie(o.token, o.w, o.idx, o.st); }
+};
+std::map<PackKey, PackEntry> g_pack_cache;
+std::mutex g_pack_mutex;                          // autograd runs backward ops on its own thread
+
+int packed_weights(const float* w, const int* idx, size_t n, hipStream_t st, float** out) {
+    int rc;
+    if (t_pack_token == 0) {
+        if ((rc = scratch_get(g_scratch[0], n, out)) != EEM_OK) return rc;
+        return repack_launch(w, idx, *out, (long)n, st);
+    }
+    int dev = 0;
+    EEM_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_pack_mutex);
+    PackEntry& e = g_pack_cache[PackKey{t_pack_token, w, idx, st}];
+    if (e.p == nullptr || e.cap < n || e.dev != dev) {
+        if (e.p) (void)hipFree(e.p);
+        e.p = nullptr; e.cap = 0; e.version = -1; e.dev = dev;
+        EEM_HIP_CHECK(hipMalloc(&e.p, n * sizeof(float)));
+        e.cap = n;
+    }
+    if (e.version != t_pack_version) {
+        if ((rc = repack_launch(w, idx, e.p, (long)n, st)) != EEM_OK) return rc;
+        e.version = t_pack_version;
+    }
+    *out = e.p;
+    return EEM_OK;
+}
+
+// Packs the weights for the launch described by `a` (everything but the weight pointers filled in): the few-output kernel's layout
+// or the LDS-tiled kernel's stream when the launch qualifies for them, else the generic kernel's.
 int pack_for(const Plan* pl, const float* w, GConvArgs& a, hipStream_t st) {
     int rc;
     float* pk = nullptr;
+    float* probe = nullptr;                       // the eligibility tests only look at "is there a packing"
+    if ((rc = scratch_get(g_scratch[1], 1024, &probe)) != EEM_OK) return rc;
     if (pl->idxfew) {
-        if ((rc = scratch_get(g_scratch[0], std::max(pl->nfew, std::max(pl->n16, pl->n)), &pk)) != EEM_OK) return rc;
-        a.wfew = pk;
-        if (fewout_supported(a)) return repack_launch(w, pl->idxfew, pk, (long)pl->nfew, st);
+        a.wfew = probe;
+        if (fewout_supported(a)) {
+            if ((rc = packed_weights(w, pl->idxfew, pl->nfew, st, &pk)) != EEM_OK) return rc;
+            a.wfew = pk;
+            return EEM_OK;
+        }
         a.wfew = nullptr;
     }
     if (pl->idx16) {
-        float* zp = nullptr;
-        if ((rc = scratch_get(g_scratch[1], 1024, &zp)) != EEM_OK) return rc;
-        if ((rc = scratch_get(g_scratch[0], pl->n16 > pl->n ? pl->n16 : pl->n, &pk)) != EEM_OK) return rc;
-        a.wpk16 = pk;
-        a.zero_page = zp;
-        if (gconv16_supported(a)) return repack_launch(w, pl->idx16, pk, (long)pl->n16, st);
+        a.wpk16 = probe;
+        a.zero_page = probe;
+        if (gconv16_supported(a)) {
+            if ((rc = packed_weights(w, pl->idx16, pl->n16, st, &pk)) != EEM_OK) return rc;
+            a.wpk16 = pk;
+            return EEM_OK;
+        }
         a.wpk16 = nullptr;
     }
-    if ((rc = scratch_get(g_scratch[0], pl->n, &pk)) != EEM_OK) return rc;
+    if ((rc = packed_weights(w, pl->idx, pl->n, st, &pk)) != EEM_OK) return rc;
     a.wpk = pk;
-    return repack_launch(w, pl->idx, pk, (long)pl->n, st);
+    return EEM_OK;
 }
 
 // forward plan: gconv_pack of w [cout][cin][kh][kw] read as `nseg` input segments
@@ -422,6 +466,26 @@ int plan_bwd(int cout, int cin, int ci0, int cic, int kh, int kw, Plan** out) {
 }
 
 }  // namespace
+
+// ================================================================================================ packed-weight cache
+extern "C" int eemop_pack_hint(long long token, long long version) {
+    t_pack_token = token;
+    t_pack_version = version;
+    return EEM_OK;
+}
+
+extern "C" int eemop_pack_forget(long long token) {
+    std::lock_guard<std::mutex> lock(g_pack_mutex);
+    for (auto it = g_pack_cache.begin(); it != g_pack_cache.end();) {
+        if (it->first.token == token) {
+            if (it->second.p) (void)hipFree(it->second.p);
+            it = g_pack_cache.erase(it);
+        } else {
+            ++it;
+        }
+    }
+    return EEM_OK;
+}
 
 // ================================================================================================ convolution
 extern "C" int eemop_conv2d_fwd(const float* x0, int c0, const float* x1, int c1, const float* x2, int c2, const float* w,

@@ -8,6 +8,7 @@ slicing of gradients), nothing else: no ATen compute op is on the path.  CUDA (R
 import contextlib
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -74,6 +75,62 @@ def _wgrad_stream(device):
     return _side_streams[key]
 
 
+# ---- packed-weight cache (include/eemflow_hip.h: eemop_pack_hint): a token per weight tensor that is never reused + its version counter
+_pack_tokens = {}                                               # id(parameter) -> (token, weak reference): tensors do not hash by value
+_next_token = [1]
+
+
+def _forget_packs(key, token):
+    ent = _pack_tokens.get(key)
+    if ent is not None and ent[0] == token:
+        del _pack_tokens[key]
+    try:
+        _lib.lib().eemop_pack_forget(token)
+    except Exception:                                           # interpreter shutdown: the library may be gone
+        pass
+
+
+def _pack_identity(w):
+    """(token, version) of the tensor whose storage `w` reads: nn.Parameters (and views of them: the cnet's split output conv) keep
+    their packed weights between calls; anything else (a temporary) is packed per call.  In-place updates bump the version; writes
+    through `.data` do not - call `invalidate_packed_weights()` after those."""
+    base = w._base if w._base is not None else w
+    if not isinstance(base, torch.nn.Parameter) or os.environ.get("EEM_NO_PACK_CACHE", "0") == "1":
+        return 0, -1
+    key = id(base)
+    ent = _pack_tokens.get(key)
+    if ent is None or ent[1]() is not base:                     # (an id can come back after its tensor died)
+        tok = _next_token[0]
+        _next_token[0] += 1
+        _pack_tokens[key] = ent = (tok, weakref.ref(base))
+        weakref.finalize(base, _forget_packs, key, tok)
+    return ent[0], base._version + _pack_epoch[0]
+
+
+_pack_epoch = [0]
+
+
+def invalidate_packed_weights():
+    """Forces every cached packing to be redone at its next use (after weight writes that bypass the version counter, e.g. `p.data`)."""
+    _pack_epoch[0] += 1 << 32
+
+
+class _packs_of:
+    """with _packs_of(token, version): the conv launches inside name their weight tensor to the library."""
+
+    def __init__(self, ident):
+        self.ident = ident
+
+    def __enter__(self):
+        if self.ident[0]:
+            _lib.lib().eemop_pack_hint(self.ident[0], self.ident[1])
+
+    def __exit__(self, *exc):
+        if self.ident[0]:
+            _lib.lib().eemop_pack_hint(0, -1)
+        return False
+
+
 class Conv2d(torch.autograd.Function):
     """out_scale * act(conv2d(cat(xs, 1), w) + b) - nn.Conv2d (+ the activation behind it) of model/extractor.py / model/update.py;
     the inputs' torch.cat is never materialised."""
@@ -92,11 +149,13 @@ class Conv2d(torch.autograd.Function):
         out = torch.empty(n, cout, hout, wout, device=w.device, dtype=torch.float32)
         px = [x.data_ptr() for x in xs] + [None] * (3 - len(xs))
         pc = cs + [0] * (3 - len(xs))
-        with _on(w.device):
+        ident = _pack_identity(w)
+        with _on(w.device), _packs_of(ident):
             _lib.check(_lib.lib().eemop_conv2d_fwd(px[0], pc[0], px[1], pc[1], px[2], pc[2], w.data_ptr(), _ptr(b), n, hin, win, cout, kh, kw,
                                                    stride, ph, pw, act, float(out_scale), out.data_ptr(), cout, 0, _sp(w)))
         ctx.save_for_backward(w, out if act != ACT_NONE else None, *xs)
         ctx.cfg = (stride, ph, pw, act, float(out_scale), b is not None, cs)
+        ctx.pack_ident = ident
         return out
 
     @staticmethod
@@ -142,8 +201,9 @@ class Conv2d(torch.autograd.Function):
             for i, x in enumerate(xs):
                 if need[6 + i]:
                     dx = torch.empty_like(x)
-                    _lib.check(L.eemop_conv2d_bwd_data(dpre.data_ptr(), w.data_ptr(), n, hin, win, cin, c0, cs[i], cout, kh, kw, stride, ph, pw,
-                                                       dx.data_ptr(), s))
+                    with _packs_of(ctx.pack_ident):
+                        _lib.check(L.eemop_conv2d_bwd_data(dpre.data_ptr(), w.data_ptr(), n, hin, win, cin, c0, cs[i], cout, kh, kw, stride, ph, pw,
+                                                           dx.data_ptr(), s))
                     dxs[i] = dx
                 c0 += cs[i]
             if joined is not None:                                         # join before autograd hands dw / db on

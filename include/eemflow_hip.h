@@ -315,6 +315,14 @@ int eemplus_upsample_flow_as(float* inputs, int batch, int h, int w, int oh, int
  * eemflow_amd/ops.py wraps each pair as a torch.autograd.Function.
  * ---------------------------------------------------------------------------------------------- */
 
+/* Packed-weight cache of the convolution operators below.  The kernels read weights in their own packed order; without a hint every
+ * call repacks `w` (one small launch).  eemop_pack_hint names the weight tensor of the NEXT conv calls of this thread: `token` is an
+ * identity the caller never reuses for another tensor (0 = no caching), `version` the tensor's modification counter (torch's
+ * `Tensor._version`); a packing is redone only when (token, w pointer, stream) is new or the version differs - a recurrent model that
+ * applies one set of weights twelve times per step (model/eraft.py:141-157) packs them once per step and once more for the data
+ * gradients.  eemop_pack_forget frees what a token holds.  No counterpart in the reference: ATen's conv reads the weights in place. */
+int eemop_pack_hint(long long token, long long version);
+int eemop_pack_forget(long long token);
 /* conv2d of up to three channel-concatenated inputs (the torch.cat of model/update.py:44,51,79 is never materialised):
  * x_s [n][c_s][hin][win] (x1 / x2 may be NULL), w [cout][c0+c1+c2][kh][kw], bias [cout] or NULL; act 0 none, 1 ReLU, 2 sigmoid,
  * 3 tanh; out[n][out_coff + co][hout][wout] of an out_ctotal-channel tensor = out_scale * act(conv + bias).

@@ -227,3 +227,38 @@ def test_eraft_reference_training_sequence_two_steps():
         sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
         ref, _ = R.eraft_forward(sd, e1.cpu(), e2.cpu(), iters=iters)
     assert float((flow.cpu() - ref[-1]).abs().max()) < 1e-3
+
+
+def test_packed_weight_cache_follows_the_version_counter():
+    """ops.Conv2d names its weight tensor to the library (eemop_pack_hint: a token per nn.Parameter + Tensor._version): the packing is
+    reused while the version stands, redone after an in-place update, and `invalidate_packed_weights()` covers writes through `.data`."""
+    from eemflow_amd import ops
+    torch.manual_seed(3)
+    conv = torch.nn.Conv2d(32, 48, 3, padding=1).to(DEV)
+    x = torch.randn(2, 32, 40, 48, device=DEV)
+
+    def both():
+        with torch.no_grad():
+            return ops.conv2d(conv, x, act=ops.ACT_RELU), torch.relu(conv(x))
+    a, ra = both()
+    b, rb = both()                                               # second call: cached packing
+    assert torch.equal(a, b) and float((a - ra).abs().max()) < 1e-4
+    with torch.no_grad():
+        conv.weight.mul_(-0.5)                                   # in-place: version bump -> repacked
+    c, rc = both()
+    assert float((c - rc).abs().max()) < 1e-4 and float((c - a).abs().max()) > 1e-2
+    conv.weight.data.mul_(3.0)                                   # bypasses the version counter ...
+    stale, rd = both()
+    assert float((stale - rd).abs().max()) > 1e-2                # ... so the cached packing is stale, as documented
+    ops.invalidate_packed_weights()
+    d, rd = both()
+    assert float((d - rd).abs().max()) < 1e-4
+    # gradients through the cached data-gradient packing
+    xg = x.clone().requires_grad_(True)
+    for _ in range(2):
+        xg.grad = None
+        ops.conv2d(conv, xg, act=ops.ACT_RELU).sum().backward()
+        g1 = xg.grad.clone()
+    xr = x.clone().requires_grad_(True)
+    torch.relu(conv(xr)).sum().backward()
+    assert float((g1 - xr.grad).abs().max() / xr.grad.abs().max()) < 1e-4

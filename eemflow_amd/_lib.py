@@ -96,6 +96,7 @@ _SIGNATURES = {
                          + [ctypes.c_int] * 10 + [ctypes.c_float, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "eemop_pack_hint": (ctypes.c_int, [ctypes.c_longlong, ctypes.c_longlong]),
     "eemop_pack_forget": (ctypes.c_int, [ctypes.c_longlong]),
+    "eemop_pack_cache_bytes": (ctypes.c_longlong, []),
     "eemop_conv2d_bwd_data": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 12 + [_c_float_p, ctypes.c_void_p]),
     "eemop_conv2d_bwd_weight": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 12 + [_c_float_p, _c_float_p, ctypes.c_void_p]),
     "eemop_act_bwd": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_float, _c_float_p, ctypes.c_void_p]),

@@ -353,7 +353,16 @@ int packed_weights(const float* w, const int* idx, size_t n, hipStream_t st, flo
     int dev = 0;
     EEM_HIP_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(g_pack_mutex);
-    PackEntry& e = g_pack_cache[PackKey{t_pack_token, w, idx, st}];
+    const PackKey key{t_pack_token, w, idx, st};
+    if (g_pack_cache.find(key) == g_pack_cache.end()) {
+        // a packing is kept for ONE stream at a time: a caller that moves to a new stream every step must not grow the cache
+        auto it = g_pack_cache.lower_bound(PackKey{t_pack_token, w, idx, nullptr});
+        while (it != g_pack_cache.end() && it->first.token == t_pack_token && it->first.w == w && it->first.idx == idx) {
+            if (it->second.p) (void)hipFree(it->second.p);      // synchronises with the launches that read it
+            it = g_pack_cache.erase(it);
+        }
+    }
+    PackEntry& e = g_pack_cache[key];
     if (e.p == nullptr || e.cap < n || e.dev != dev) {
         if (e.p) (void)hipFree(e.p);
         e.p = nullptr; e.cap = 0; e.version = -1; e.dev = dev;
@@ -472,6 +481,13 @@ extern "C" int eemop_pack_hint(long long token, long long version) {
     t_pack_token = token;
     t_pack_version = version;
     return EEM_OK;
+}
+
+extern "C" long long eemop_pack_cache_bytes() {
+    std::lock_guard<std::mutex> lock(g_pack_mutex);
+    long long n = 0;
+    for (const auto& kv : g_pack_cache) n += (long long)kv.second.cap * (long long)sizeof(float);
+    return n;
 }
 
 extern "C" int eemop_pack_forget(long long token) {

@@ -323,6 +323,7 @@ int eemplus_upsample_flow_as(float* inputs, int batch, int h, int w, int oh, int
  * gradients.  eemop_pack_forget frees what a token holds.  No counterpart in the reference: ATen's conv reads the weights in place. */
 int eemop_pack_hint(long long token, long long version);
 int eemop_pack_forget(long long token);
+long long eemop_pack_cache_bytes(void);   /* device bytes the cache holds (all tokens, this process) */
 /* conv2d of up to three channel-concatenated inputs (the torch.cat of model/update.py:44,51,79 is never materialised):
  * x_s [n][c_s][hin][win] (x1 / x2 may be NULL), w [cout][c0+c1+c2][kh][kw], bias [cout] or NULL; act 0 none, 1 ReLU, 2 sigmoid,
  * 3 tanh; out[n][out_coff + co][hout][wout] of an out_ctotal-channel tensor = out_scale * act(conv + bias).

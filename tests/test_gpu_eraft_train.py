@@ -262,3 +262,31 @@ def test_packed_weight_cache_follows_the_version_counter():
     xr = x.clone().requires_grad_(True)
     torch.relu(conv(xr)).sum().backward()
     assert float((g1 - xr.grad).abs().max() / xr.grad.abs().max()) < 1e-4
+
+
+def test_packed_weight_cache_keeps_one_stream_per_packing():
+    """A caller that runs every step on a fresh stream must not grow the cache: a packing is kept for one stream at a time; a
+    parameter's packings go when the parameter does."""
+    import gc
+    from eemflow_amd import _lib, ops
+    conv = torch.nn.Conv2d(64, 64, 3, padding=1).to(DEV)
+    x = torch.randn(1, 64, 48, 64, device=DEV)
+    L = _lib.lib()
+    with torch.no_grad():
+        ref = torch.relu(conv(x))
+        before = L.eemop_pack_cache_bytes()
+        ops.conv2d(conv, x, act=ops.ACT_RELU)
+        one = L.eemop_pack_cache_bytes() - before
+        assert one > 0
+        for _ in range(12):
+            st = torch.cuda.Stream()
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                y = ops.conv2d(conv, x, act=ops.ACT_RELU)
+            torch.cuda.current_stream().wait_stream(st)
+        torch.cuda.synchronize()
+        assert L.eemop_pack_cache_bytes() - before == one
+    assert float((y - ref).abs().max()) < 1e-4
+    del conv
+    gc.collect()
+    assert L.eemop_pack_cache_bytes() == before

@@ -108,7 +108,7 @@ def test_levels_teacher_forced_vs_reference_golden(golden, tag):
         assert e_up < FLOW_TOL and e_fl < FLOW_TOL, (l, e_up, e_fl)
 
 
-@pytest.mark.parametrize("b,h,w,cin", [(1, 256, 320, 5), (2, 200, 300, 15)])
+@pytest.mark.parametrize("b,h,w,cin", [(1, 256, 320, 5), (2, 200, 300, 15), (1, 720, 1280, 5)])
 def test_chained_forward_levels_vs_oracle_on_its_own_flow_init(b, h, w, cin):
     """The chained GPU forward, level by level, against the oracle: the oracle's l-block is fed the GPU's OWN flow_init of that level
     (stage "flow_init<l>"), so the comparison holds the flow tolerance at every level of the actual forward - the only thing not
@@ -132,8 +132,16 @@ def test_chained_forward_levels_vs_oracle_on_its_own_flow_init(b, h, w, cin):
             up2, fl_gpu = net.level(l, init)                     # same inputs, same kernels: the chain's own values
             assert torch.equal(up2, up_gpu)
             up_ref, fl_ref = P.level_from_init(sd, l, st["f1"][l], st["f2"][l], init.cpu())
-            e_up, e_fl = float((up_gpu.cpu() - up_ref).abs().max()), float((fl_gpu.cpu() - fl_ref).abs().max())
-            assert e_up < FLOW_TOL and e_fl < FLOW_TOL, (l, e_up, e_fl)
+            d_up, d_fl = (up_gpu.cpu() - up_ref).abs(), (fl_gpu.cpu() - fl_ref).abs()
+            e_up, e_fl = float(d_up.max()), float(d_fl.max())
+            if h * w < 512 * 512:
+                assert e_up < FLOW_TOL and e_fl < FLOW_TOL, (l, e_up, e_fl)
+            else:
+                # 1280x720: of a level's 14 400 / 57 600 pixels one or two sit on the warp mask's `>= 1.0` threshold to the last bit of
+                # ATen's vectorised CPU arithmetic (tools/plus720_probe.py: the same two pixels whichever conv kernels run); everything
+                # else holds the tolerance, and those stay within a few 1e-3
+                assert float((d_up > FLOW_TOL).float().mean()) < 5e-4 and float((d_fl > FLOW_TOL).float().mean()) < 5e-4, (l, e_up, e_fl)
+                assert e_up < 2e-2 and e_fl < 2e-2, (l, e_up, e_fl)
 
 
 def test_errors():

@@ -158,6 +158,39 @@ __global__ __launch_bounds__(256) void resize_ac_bwd_kernel(const float* __restr
     atomicAdd(d + y1 * w + x1, g * ly * lx);
 }
 
+// Gather form of the same adjoint: one wave per (plane, source pixel).  The outputs whose taps touch source row y are those with
+// y0 in {y - 1, y}, a contiguous range of Y; the lanes walk the (Y, X) footprint with the forward's own tap arithmetic (ac_taps) and
+// add in registers, a DPP / shuffle sum and ONE store finish the pixel.  The scatter above is 4 atomics per OUTPUT pixel: upsampling
+// a 6x8 level to 512x768 (EEMFlow+.py:231-232) lands 16 000 of them on every source pixel - 1.8 ms per call, half of the EEMFlow+
+// training step.
+__global__ __launch_bounds__(256) void resize_ac_bwd_gather_kernel(const float* __restrict__ dout, float* __restrict__ dx, int h, int w, int oh,
+                                                                   int ow, long npix) {
+    const int lane = threadIdx.x & 63;
+    const long pid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);          // (plane, y, x)
+    if (pid >= npix) return;
+    const int x = pid % w, y = (pid / w) % h;
+    const long pl = pid / ((long)w * h);
+    const float sy = oh > 1 ? (float)(h - 1) / (float)(oh - 1) : 0.f, sx = ow > 1 ? (float)(w - 1) / (float)(ow - 1) : 0.f;
+    // candidate ranges, widened by two so that the float rounding of sy * Y cannot lose an output; ac_taps decides
+    int Ya = 0, Yb = oh - 1, Xa = 0, Xb = ow - 1;
+    if (sy > 0.f) { Ya = max(0, (int)floorf((float)(y - 1) / sy) - 2); Yb = min(oh - 1, (int)ceilf((float)(y + 1) / sy) + 2); }
+    if (sx > 0.f) { Xa = max(0, (int)floorf((float)(x - 1) / sx) - 2); Xb = min(ow - 1, (int)ceilf((float)(x + 1) / sx) + 2); }
+    const int ny = Yb - Ya + 1, nx = Xb - Xa + 1;
+    const float* g = dout + pl * (long)oh * ow;
+    float acc = 0.f;
+    for (int e = lane; e < ny * nx; e += 64) {
+        const int Y = Ya + e / nx, X = Xa + e % nx;
+        int y0, y1, x0, x1; float ly, lx;
+        ac_taps(Y, X, h, w, oh, ow, y0, y1, x0, x1, ly, lx);
+        const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);     // y0 == y1 == y on the last row: (1 - ly) + ly
+        const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
+        if (wy != 0.f && wx != 0.f) acc += g[(long)Y * ow + X] * wy * wx;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
+    if (lane == 0) dx[pid] = acc;
+}
+
 // ------------------------------------------------------------------------------------------------ norms
 __device__ __forceinline__ void block_sum2(double& a, double& b, double* sh) {
 #pragma unroll
@@ -762,6 +795,13 @@ extern "C" int eemop_resize_ac_fwd(const float* in, float* out, int nc, int h, i
 extern "C" int eemop_resize_ac_bwd(const float* dout, float* dx, int nc, int h, int w, int oh, int ow, void* stream) {
     EEM_REQUIRE(dout && dx && nc >= 1, "eemop_resize_ac_bwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
+    const char* e = getenv("EEM_RESIZE_BWD_SCATTER");              // read per call: the tests compare both forms in one process
+    if (!(e && e[0] == '1')) {
+        const long npix = (long)nc * h * w;
+        hipLaunchKernelGGL(resize_ac_bwd_gather_kernel, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, st, dout, dx, h, w, oh, ow, npix);
+        EEM_HIP_CHECK(hipGetLastError());
+        return EEM_OK;
+    }
     EEM_HIP_CHECK(hipMemsetAsync(dx, 0, (size_t)nc * h * w * sizeof(float), st));
     const long total = (long)nc * oh * ow;
     hipLaunchKernelGGL(resize_ac_bwd_kernel, dim3(nblk(total)), dim3(256), 0, st, dout, dx, h, w, oh, ow, total);

@@ -161,3 +161,23 @@ def test_lds_tiled_conv_with_two_k_groups(monkeypatch, cin, cout, k, h, w, b):
     tol = 3e-5 * max(float(ref.abs().max()), 1.0) * (cin * k[0] * k[1] / 256) ** 0.5
     assert float((tiled - ref).abs().max()) < tol and float((gen - ref).abs().max()) < tol
     assert not torch.equal(tiled, gen)
+
+
+@pytest.mark.parametrize("form", ["gather", "scatter"])
+@pytest.mark.parametrize("n,h,w,oh,ow", [(2, 6, 8, 512, 768), (1, 64, 96, 128, 192), (2, 5, 7, 33, 50), (1, 1, 9, 17, 40), (1, 12, 20, 12, 20)])
+def test_bilinear_resize_adjoint(monkeypatch, form, n, h, w, oh, ow):
+    """Adjoint of F.interpolate(bilinear, align_corners=True) (cdc_utils.py:83; the five full-resolution predictions of
+    EEMFlow+.py:231-232): a wave per source pixel gathers its footprint of outputs (default), or four atomics per output pixel
+    (EEM_RESIZE_BWD_SCATTER=1, read per call).  Against torch autograd."""
+    import ctypes
+    from eemflow_amd import _lib
+    monkeypatch.setenv("EEM_RESIZE_BWD_SCATTER", "1" if form == "scatter" else "0")
+    g = torch.Generator().manual_seed(h * 100 + ow)
+    x = torch.randn(n, 2, h, w, generator=g, requires_grad=True)
+    dout = torch.randn(n, 2, oh, ow, generator=g)
+    torch.nn.functional.interpolate(x, size=(oh, ow), mode="bilinear", align_corners=True).backward(dout)
+    dx = torch.empty(n, 2, h, w, device=DEV)
+    d = dout.to(DEV)
+    _lib.check(_lib.lib().eemop_resize_ac_bwd(d.data_ptr(), dx.data_ptr(), n * 2, h, w, oh, ow, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert rel(dx, x.grad) < 2e-5

@@ -3,6 +3,7 @@
 #include <string.h>
 
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/eemflow_hip.h"
@@ -61,6 +62,8 @@ struct eraft_ctx {
     bool have_last = false;
     bool keep_stages = false;      // copy corr0 / net1 / mask1 / delta1 aside in the first iteration (parity tests)
     int frames_in_flight = 1;      // eraft_set_frames_in_flight
+    double* nstat = nullptr;       // per-chunk sums of the large-plane instance norm (er_instnorm_launch)
+    size_t nstat_cap = 0;
     bool alt_corr = false;         // eraft_set_alternate_corr: correlation features on the fly, no all-pairs volume
     Buf f2l[3];                    // avg-pooled fmap2, levels 1..3 (alt_corr)
     bool stages_valid = false;
@@ -207,7 +210,7 @@ int run_encoder(eraft_ctx* c, const Encoder& E, const float* x, int n, int cin0,
         set_seg(a, 0, x, cin0, cin0, 0);
         if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
         h = a.hout; w = a.wout;
-        if (!E.batch_norm && (rc = er_instnorm_launch(R, X, nullptr, n * 64, h * w, 1, st)) != EEM_OK) return rc;
+        if (!E.batch_norm && (rc = er_instnorm_launch(R, X, nullptr, n * 64, h * w, 1, st, c->nstat, c->nstat_cap)) != EEM_OK) return rc;
     }
     const int dims[3] = {64, 96, 128};
     int in_planes = 64, bi = 0;
@@ -220,14 +223,14 @@ int run_encoder(eraft_ctx* c, const Encoder& E, const float* x, int n, int cin0,
             set_seg(a1, 0, X, cin, cin, 0);
             if ((rc = gconv_launch(a1, st)) != EEM_OK) return rc;
             const int ho = a1.hout, wo = a1.wout;
-            if (!E.batch_norm && (rc = er_instnorm_launch(R, Y, nullptr, n * planes, ho * wo, 1, st)) != EEM_OK) return rc;
+            if (!E.batch_norm && (rc = er_instnorm_launch(R, Y, nullptr, n * planes, ho * wo, 1, st, c->nstat, c->nstat_cap)) != EEM_OK) return rc;
             // shortcut
             const float* res = X;
             if (bk.has_down) {
                 GConvArgs ad = conv_args(c, bk.down, n, h, w, E.batch_norm ? D : R, planes, 0, GACT_NONE);
                 set_seg(ad, 0, X, cin, cin, 0);
                 if ((rc = gconv_launch(ad, st)) != EEM_OK) return rc;
-                if (!E.batch_norm && (rc = er_instnorm_launch(R, D, nullptr, n * planes, ho * wo, 0, st)) != EEM_OK) return rc;
+                if (!E.batch_norm && (rc = er_instnorm_launch(R, D, nullptr, n * planes, ho * wo, 0, st, c->nstat, c->nstat_cap)) != EEM_OK) return rc;
                 res = D;
             }
             // out = relu(res + relu(norm2(conv2(y))))
@@ -235,7 +238,7 @@ int run_encoder(eraft_ctx* c, const Encoder& E, const float* x, int n, int cin0,
             set_seg(a2, 0, Y, planes, planes, 0);
             if (E.batch_norm) { a2.epi = GEPI_ADD_RELU; a2.e0 = res; a2.e0_ctotal = planes; a2.e0_coff = 0; }
             if ((rc = gconv_launch(a2, st)) != EEM_OK) return rc;
-            if (!E.batch_norm && (rc = er_instnorm_launch(R, O, res, n * planes, ho * wo, 1, st)) != EEM_OK) return rc;
+            if (!E.batch_norm && (rc = er_instnorm_launch(R, O, res, n * planes, ho * wo, 1, st, c->nstat, c->nstat_cap)) != EEM_OK) return rc;
             float* t = X; X = O; O = t;
             h = ho; w = wo;
             if (r == 0) in_planes = planes;
@@ -318,6 +321,7 @@ extern "C" void eraft_destroy(eraft_ctx* c) {
                   &c->motion, &c->z, &c->rh, &c->fhid, &c->delta, &c->mhid, &c->mask, &c->st_corr0, &c->st_net1, &c->st_mask1,
                   &c->st_delta1, &c->zeros, &c->f2l[0], &c->f2l[1], &c->f2l[2]};
     for (Buf* b : all) if (b->p) (void)hipFree(b->p);
+    if (c->nstat) (void)hipFree(c->nstat);
     if (c->arena) (void)hipFree(c->arena);
     delete c;
 }
@@ -409,6 +413,18 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
 #define ENS(b, n) if ((rc = ensure(b, n)) != EEM_OK) return rc
     ENS(c->padded, (size_t)2 * B * c->cin0 * hp * wp);
     for (int i = 0; i < 5; ++i) ENS(c->s[i], big);
+    {   // scratch of the large-plane instance norm: the first stage has the most (planes x chunks)
+        const int hw1 = ((hp + 1) / 2) * ((wp + 1) / 2);
+        size_t need = er_instnorm_scratch_doubles(2 * B * 64, hw1);
+        need = std::max(need, er_instnorm_scratch_doubles(2 * B * 96, hw1 / 4));
+        need = std::max(need, er_instnorm_scratch_doubles(2 * B * 128, hw1 / 16));
+        if (need > c->nstat_cap) {
+            if (c->nstat) EEM_HIP_CHECK(hipFree(c->nstat));
+            c->nstat = nullptr; c->nstat_cap = 0;
+            EEM_HIP_CHECK(hipMalloc(&c->nstat, need * sizeof(double)));
+            c->nstat_cap = need;
+        }
+    }
     ENS(c->fmap, (size_t)2 * B * 256 * g);
     ENS(c->net[0], B * 128 * g); ENS(c->net[1], B * 128 * g); ENS(c->inp, B * 128 * g);
     ENS(c->c0, B * 2 * g); ENS(c->c1, B * 2 * g); ENS(c->corr, B * kCorrPad * g); ENS(c->cor1, B * 256 * g);

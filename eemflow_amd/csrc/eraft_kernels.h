@@ -8,7 +8,11 @@ int er_pad_launch(const float* in, float* out, int nc, int h, int w, int left, i
 
 // InstanceNorm2d(affine=False, eps=1e-5) per (n,c) plane + options (model/extractor.py:31-35,43-57):
 //   v = (x - mean) / sqrt(var + eps);  if relu_inner: v = relu(v);  if res: v = relu(v + res)
-int er_instnorm_launch(const float* x, float* out, const float* res, int planes, int hw, int relu_inner, hipStream_t st);
+// planes too large for the in-register kernel take a two-pass form that needs er_instnorm_scratch_doubles(planes, hw) doubles of scratch
+// owned by the caller (one per context / stream); without it they fall back to one block per plane
+size_t er_instnorm_scratch_doubles(int planes, int hw);
+int er_instnorm_launch(const float* x, float* out, const float* res, int planes, int hw, int relu_inner, hipStream_t st, double* stats = nullptr,
+                       size_t stats_cap = 0);
 
 // All-pairs correlation (model/corr.py:53-60): out[b][p1][p2] = sum_c f1[b][c][p1] * f2[b][c][p2] / sqrt(C)
 int er_allpairs_launch(const float* f1, const float* f2, float* out, int batch, int c, int hw, hipStream_t st);

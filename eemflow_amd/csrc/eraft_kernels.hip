@@ -119,6 +119,70 @@ __global__ __launch_bounds__(1024) void instnorm_reg_kernel(const float* __restr
     }
 }
 
+// Planes too large for registers (HREM's 1280x720 through the feature network: 360x640 = 230 400 values per plane, 128 planes): several
+// blocks per plane.  Pass 1 leaves each chunk's sum and sum of squares (accumulated in double) in a scratch of the caller, pass 2 adds a
+// plane's chunks, derives mean and variance in double and applies them.  One block per plane looping three times over 900 KB was 922 us
+// per call - a fifth of the 1280x720 forward - on half of the CUs; these two passes run at the memory system's pace.
+constexpr int kNormChunk4 = 8192;                                 // float4 per block: 8 per thread
+__global__ __launch_bounds__(1024) void instnorm_stats_kernel(const float* __restrict__ x, int hw, int chunks, double* __restrict__ stats) {
+    __shared__ double sh[32];
+    const f32x4* p = reinterpret_cast<const f32x4*>(x + (size_t)blockIdx.y * hw);
+    const int n4 = hw >> 2, i0 = blockIdx.x * kNormChunk4;
+    float sf = 0.f, qf = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = i0 + k * 1024 + threadIdx.x;
+        if (i < n4) {
+            const f32x4 v = p[i];
+            sf += (v[0] + v[1]) + (v[2] + v[3]);
+            qf += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
+    }
+    double s = sf, q = qf;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { s += __shfl_xor(s, d); q += __shfl_xor(q, d); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sh[wave * 2] = s; sh[wave * 2 + 1] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double S = 0.0, Q = 0.0;
+        for (int k = 0; k < 16; ++k) { S += sh[k * 2]; Q += sh[k * 2 + 1]; }
+        stats[((size_t)blockIdx.y * chunks + blockIdx.x) * 2] = S;
+        stats[((size_t)blockIdx.y * chunks + blockIdx.x) * 2 + 1] = Q;
+    }
+}
+
+__global__ __launch_bounds__(1024) void instnorm_apply_kernel(const float* __restrict__ x, float* __restrict__ out, const float* __restrict__ res,
+                                                              int hw, int chunks, const double* __restrict__ stats, int relu_inner) {
+    double S = 0.0, Q = 0.0;
+    for (int k = 0; k < chunks; ++k) { S += stats[((size_t)blockIdx.y * chunks + k) * 2]; Q += stats[((size_t)blockIdx.y * chunks + k) * 2 + 1]; }
+    const double m = S / (double)hw;
+    double var = Q / (double)hw - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    const float mean = (float)m, rstd = 1.f / sqrtf((float)var + 1e-5f);
+    const size_t base = (size_t)blockIdx.y * hw;
+    const f32x4* p = reinterpret_cast<const f32x4*>(x + base);
+    f32x4* o = reinterpret_cast<f32x4*>(out + base);
+    const f32x4* r = res ? reinterpret_cast<const f32x4*>(res + base) : nullptr;
+    const int n4 = hw >> 2, i0 = blockIdx.x * kNormChunk4;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = i0 + k * 1024 + threadIdx.x;
+        if (i >= n4) continue;
+        const f32x4 v = p[i];
+        const f32x4 rv = r ? r[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = (v[e] - mean) * rstd;
+            if (relu_inner) t = t > 0.f ? t : 0.f;
+            if (r) { t += rv[e]; t = t > 0.f ? t : 0.f; }
+            w[e] = t;
+        }
+        o[i] = w;
+    }
+}
+
 // D[p1][p2] tiles of 64x64 per wave on v_mfma_f32_32x32x2_f32; both operands are read with unit stride along
 // the pixel index (A[i=p1][k=c] = f1[c][p1], B[k=c][j=p2] = f2[c][p2]) and each accumulator register is a
 // 128-B run of p2 for one p1 row.
@@ -445,8 +509,20 @@ int er_pad_launch(const float* in, float* out, int nc, int h, int w, int left, i
     return EEM_OK;
 }
 
-int er_instnorm_launch(const float* x, float* out, const float* res, int planes, int hw, int relu_inner, hipStream_t st) {
+size_t er_instnorm_scratch_doubles(int planes, int hw) {
+    return hw > 4 * 1024 * 20 ? (size_t)planes * ceil_div(hw >> 2, kNormChunk4) * 2 : 0;
+}
+
+int er_instnorm_launch(const float* x, float* out, const float* res, int planes, int hw, int relu_inner, hipStream_t st, double* stats,
+                       size_t stats_cap) {
     const bool al = (hw & 3) == 0 && (((uintptr_t)x | (uintptr_t)out | (uintptr_t)res) & 15) == 0;
+    if (al && hw > 4 * 1024 * 20 && stats && stats_cap >= er_instnorm_scratch_doubles(planes, hw)) {
+        const int chunks = ceil_div(hw >> 2, kNormChunk4);
+        hipLaunchKernelGGL(instnorm_stats_kernel, dim3(chunks, planes), dim3(1024), 0, st, x, hw, chunks, stats);
+        hipLaunchKernelGGL(instnorm_apply_kernel, dim3(chunks, planes), dim3(1024), 0, st, x, out, res, hw, chunks, stats, relu_inner);
+        EEM_HIP_CHECK(hipGetLastError());
+        return EEM_OK;
+    }
     if (al && hw <= 4 * 1024 * 5) hipLaunchKernelGGL(instnorm_reg_kernel<5>, dim3(planes), dim3(1024), 0, st, x, out, res, hw, relu_inner);
     else if (al && hw <= 4 * 1024 * 20) hipLaunchKernelGGL(instnorm_reg_kernel<20>, dim3(planes), dim3(1024), 0, st, x, out, res, hw, relu_inner);
     else hipLaunchKernelGGL(instnorm_kernel, dim3(planes), dim3(256), 0, st, x, out, res, hw, relu_inner);

@@ -434,11 +434,12 @@ void fewout_pack(const float* w, int cout, int cin, int kh, int kw, float* packe
 }
 
 bool fewout_supported(const GConvArgs& a) {
+    static const long few_min_px = [] { const char* m = getenv("EEM_FEWOUT_MINPX"); return m ? atol(m) : 256L; }();
     const char* e = getenv("EEM_NO_FEWOUT");                         // read per call: a test flips it inside one process
     if (e && e[0] == '1') return false;
     return a.wfew && a.nseg == 1 && a.cout <= 8 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.tstride <= 1 && a.pad_h == 1 && a.pad_w == 1 &&
            a.seg[0].cmul <= 1 && a.seg[0].gate == nullptr && (a.epi == GEPI_PLAIN || a.epi == GEPI_ADD) && a.hout == a.hin && a.wout == a.win &&
-           (long)a.hin * a.win >= 4096;                              // small maps: the split-K launch of the generic kernel
+           (long)a.hin * a.win >= few_min_px;                        // smaller maps: the split-K launch of the generic kernel
 }
 
 int fewout_launch(const GConvArgs& a, hipStream_t stream) {

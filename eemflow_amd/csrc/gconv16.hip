@@ -403,9 +403,9 @@ bool gconv16_supported(const GConvArgs& a) {
     int cin = 0;
     for (int s = 0; s < a.nseg; ++s) cin += cs[s];
     // measured on E-RAFT (640x480, batch 1 / 4) and EEMFlow+ (1280x720): shallow inputs and launches of a few dozen blocks
-    // stay on the generic kernel's split-K form (128 blocks before the K groups and the tile-row choice, 48 with them)
+    // stay on the generic kernel's split-K form (128 blocks before the K groups and the tile-row choice, 12 with them)
     static const int min_cin = [] { const char* m = getenv("EEM_G16_MINCIN"); return m ? atoi(m) : 32; }();
-    static const long min_blk = [] { const char* m = getenv("EEM_G16_MINBLK"); return m ? atol(m) : 48L; }();
+    static const long min_blk = [] { const char* m = getenv("EEM_G16_MINBLK"); return m ? atol(m) : 12L; }();
     const long blocks = (long)ceil_div(a.wout, 16) * ceil_div(a.hout, 4) * ceil_div(a.cout, 64) * a.n * (a.groups > 1 ? a.groups : 1);
     if (cin < min_cin || blocks < min_blk) return false;
     if (a.groups > 1 && (a.nseg != 1 || a.epi != GEPI_PLAIN)) return false;

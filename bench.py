@@ -2,7 +2,8 @@
 """EEMFlow hot-path benchmark on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1: either under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...) or on its
+  own - then bench.py starts that launcher itself as a child process before it touches the GPU (self_launch below).
 
 A step is one EEMFlow inference forward (libeemflow_hip.so, HIP-graph replay) over one batch of
 synthetic event-voxel pairs already resident in HBM: BASELINE.json configs[1], 1280x720, batch 1.
@@ -426,7 +427,7 @@ def main_train(args):
     from eemflow_amd.weights import seeded_state_dict, synthetic_gt, synthetic_voxel_pair
     rank, local_rank, world = parallel.init_distributed()
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path)"
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", parallel.local_device_index(local_rank))
     torch.cuda.set_device(dev)
     B = args.batch if args.batch > 1 else 8
     H, W = args.height, args.width
@@ -489,19 +490,48 @@ def main_train(args):
         torch.distributed.destroy_process_group()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: this process - which has not touched the GPU (importing torch
+    and counting devices do not initialise it) - starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py <same
+    arguments>` as a CHILD (never an exec), lets rank 0's JSON line through on stdout, and exits with the child's code.  Fewer GPUs than
+    ranks is an error, not a silent one-GPU measurement.  Returns only when no launch is needed (N = 1, or already a rank)."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    import subprocess
+    from eemflow_amd import parallel
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus and not parallel.share_gpu():
+        print(f"bench.py: --gpus {args.gpus} but {n_dev} GPU(s) visible on this node: refusing to measure fewer GPUs than asked",
+              file=sys.stderr, flush=True)
+        sys.exit(2)
+    with socket.socket() as sock:                              # a free rendezvous port on the loop-back interface
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL's cross-process buffers on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    print("bench.py: launching " + " ".join(cmd), file=sys.stderr, flush=True)
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     args = parse()
+    self_launch(args)
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: launch with --nproc-per-node {args.gpus}",
+              file=sys.stderr, flush=True)
+        sys.exit(2)
     if args.mode == "train":
         return main_train(args)
     from eemflow_amd import _lib, parallel
     from eemflow_amd.weights import seeded_state_dict, synthetic_voxel_pair
 
     rank, local_rank, world = parallel.init_distributed()
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path)"
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", parallel.local_device_index(local_rank))
     torch.cuda.set_device(dev)
 
     B, H, W = args.batch, args.height, args.width
@@ -515,7 +545,7 @@ def main():
     ctxs, streams, flows = [], [], []
     for _ in range(NS):
         c = ctypes.c_void_p()
-        _lib.check(L.eemflow_create(local_rank, ctypes.byref(c)))
+        _lib.check(L.eemflow_create(dev.index, ctypes.byref(c)))
         _lib.check(L.eemflow_load_weights(c, flat.data_ptr(), flat.numel(), 5, 5))
         _lib.check(L.eemflow_set_image_size(c, H, W, None))
         _lib.check(L.eemflow_use_graph(c, 0 if args.no_graph else 1))

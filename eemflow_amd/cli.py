@@ -33,6 +33,11 @@ DEFAULT_CONFIG = {
 }
 
 
+# what the last train() of this process ended with (model, fused trainer, run folder, rank, world) - for callers that embed the CLI
+# (tests compare the replicas of a data-parallel run through it); the scripts themselves only use the run folder
+LAST_RUN = {}
+
+
 def build_parser():
     p = argparse.ArgumentParser(prog="eemflow_amd.cli", description=__doc__.split("\n\n")[0])
     sub = p.add_subparsers(dest="command", required=True)
@@ -104,7 +109,7 @@ def train(args):
     # (RCCL), rank 0 writes the logs and checkpoints
     rank, local_rank, world = parallel.init_distributed()
     if world > 1:
-        args.device = "cuda:{}".format(local_rank)
+        args.device = "cuda:{}".format(parallel.local_device_index(local_rank))
     config = load_config(args.config)
     model = build_model(args.model_name, config, training=True)
     config["train"]["lr"] = args.lr                                                  # train_EEMFlow_HREM.py:56-59
@@ -151,6 +156,7 @@ def train(args):
         if rank == 0:
             harness.save_checkpoint(os.path.join(save_path, 'lasted_ckpt.pth.tar'), model, epoch, trainer=tr.trainer)
     parallel.barrier(dev)
+    LAST_RUN.update(model=model, trainer=tr.trainer, save_path=save_path, rank=rank, world=world)
     return save_path
 
 

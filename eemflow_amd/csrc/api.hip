@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "api_internal.h"
+#include <mutex>
 
 // ------------------------------------------------------------------------------- errors
 static thread_local char g_err[512] = "";
@@ -294,6 +295,7 @@ extern "C" int eemflow_forward(eemflow_ctx* c, const float* e1, const float* e2,
     int rc = compute_shape(c, batch, in_h, in_w, out_h, out_w, &s);
     if (rc != EEM_OK) return rc;
 
+    c->workspace_overwritten();
     if (!c->use_graph) {
         if ((rc = alloc_workspace(c, s)) != EEM_OK) return rc;
         c->last = s;
@@ -379,6 +381,7 @@ extern "C" int eemflow_time_kernels(eemflow_ctx* c, const float* e1, const float
     int rc = compute_shape(c, batch, in_h, in_w, out_h, out_w, &s);
     if (rc != EEM_OK) return rc;
     if ((rc = alloc_workspace(c, s)) != EEM_OK) return rc;
+    c->workspace_overwritten();
     c->last = s;
     c->have_last = true;
     Hook hk;
@@ -442,6 +445,7 @@ extern "C" int eemflow_decoder(eemflow_ctx* c, int k, const float* x, int batch,
         return rc;
     if (g_realloc_events != moved) drop_graph(c);    // a scratch buffer the cached graphs point into has moved
     const float* cats[3] = {x, x, x};
+    c->workspace_overwritten();
     Hook hk;
     hk.st = (hipStream_t)stream;
     return run_decoders(c, i, i + 1, cats, batch, h, w, out, 2, i, hk);
@@ -450,14 +454,19 @@ extern "C" int eemflow_decoder(eemflow_ctx* c, int k, const float* x, int batch,
 extern "C" int eemflow_local_corr53(const float* f1, const float* f2, int batch, int cch, int h, int w, float* out,
                                     void* stream) {
     EEM_REQUIRE(f1 && f2 && out && batch >= 1 && cch >= 1 && h >= 1 && w >= 1, "eemflow_local_corr53: bad arguments");
-    static thread_local int* taps = nullptr;
-    static thread_local int taps_dev = -1;
+    static int* taps_of[64] = {};                  // the tap list, once per device (library-owned: callers' threads come and go)
+    static std::mutex taps_lock;
     int dev = 0;
     EEM_HIP_CHECK(hipGetDevice(&dev));
-    if (taps == nullptr || taps_dev != dev) {
-        EEM_HIP_CHECK(hipMalloc(&taps, sizeof(kTaps53)));
-        EEM_HIP_CHECK(hipMemcpy(taps, kTaps53, sizeof(kTaps53), hipMemcpyHostToDevice));
-        taps_dev = dev;
+    EEM_REQUIRE(dev >= 0 && dev < 64, "eemflow_local_corr53: device index");
+    int* taps = nullptr;
+    {
+        std::lock_guard<std::mutex> guard(taps_lock);
+        if (taps_of[dev] == nullptr) {
+            EEM_HIP_CHECK(hipMalloc(&taps_of[dev], sizeof(kTaps53)));
+            EEM_HIP_CHECK(hipMemcpy(taps_of[dev], kTaps53, sizeof(kTaps53), hipMemcpyHostToDevice));
+        }
+        taps = taps_of[dev];
     }
     CorrJob j = {f1, f2, out, cch, kNTaps};
     return corr_launch(&j, 1, batch, h, w, taps, kNTaps, (hipStream_t)stream);
@@ -471,12 +480,16 @@ extern "C" int eemflow_upsample_bilinear(const float* in, float* out, int nc, in
 extern "C" int eemflow_voxelize(const double* events, int64_t n, int bins, int h, int w, int normalize, float* grid,
                                 int64_t* idx_left, int64_t* idx_right, void* stream) {
     EEM_REQUIRE(events && grid, "eemflow_voxelize: NULL argument");
-    // per-thread scratch arenas (band counters, moments, 16 B per event of vote records), grown on demand: one per stream for up to
-    // four streams, so that the voxelizations of frames in flight on different streams do not wait for each other; a fifth stream
-    // takes over the least recently used arena after waiting for the kernels that last used it
+    // scratch arenas (band counters, moments, 16 B per event of vote records), grown on demand and owned by the LIBRARY, not by the
+    // calling thread (a loader's worker threads come and go; per-thread arenas were never freed): one per (device, stream) for up to
+    // eight streams, so that the voxelizations of frames in flight on different streams do not wait for each other; a ninth stream
+    // takes over the least recently used arena after waiting for the kernels that last used it.  The lock is held over the three
+    // launches and the event record, so a take-over always sees the event of the arena's last user.
     struct Arena { void* p = nullptr; size_t cap = 0; int dev = -1; hipEvent_t done = nullptr; void* stream = nullptr; unsigned long used = 0; };
-    static thread_local Arena arenas[4];
-    static thread_local unsigned long tick = 0;
+    static Arena arenas[8];
+    static unsigned long tick = 0;
+    static std::mutex arena_lock;
+    std::lock_guard<std::mutex> guard(arena_lock);
     int dev = 0;
     EEM_HIP_CHECK(hipGetDevice(&dev));
     Arena* ar = nullptr;
@@ -491,11 +504,16 @@ extern "C" int eemflow_voxelize(const double* events, int64_t n, int bins, int h
     ar->used = ++tick;
     const size_t need = voxel_scratch_bytes(n);
     if (ar->p == nullptr || ar->dev != dev || ar->cap < need) {
-        if (ar->p && ar->dev == dev) EEM_HIP_CHECK(hipFree(ar->p));              // synchronises with work using it
+        if (ar->p) {                                                             // synchronises with work using it
+            int cur = dev;
+            if (ar->dev != dev) EEM_HIP_CHECK(hipSetDevice(ar->dev));
+            EEM_HIP_CHECK(hipFree(ar->p));
+            if (ar->dev != cur) { EEM_HIP_CHECK(hipEventDestroy(ar->done)); ar->done = nullptr; EEM_HIP_CHECK(hipSetDevice(cur)); }
+        }
         ar->p = nullptr;
         ar->cap = need + need / 4;
         EEM_HIP_CHECK(hipMalloc(&ar->p, ar->cap));
-        if (ar->dev != dev || !ar->done) EEM_HIP_CHECK(hipEventCreateWithFlags(&ar->done, hipEventDisableTiming));
+        if (!ar->done) EEM_HIP_CHECK(hipEventCreateWithFlags(&ar->done, hipEventDisableTiming));
         ar->dev = dev;
     }
     void* scratch = ar->p;

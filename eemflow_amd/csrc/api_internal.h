@@ -86,6 +86,10 @@ struct eemflow_ctx {
     const float *train_e1 = nullptr, *train_e2 = nullptr;
     bool have_train_fwd = false;
     long train_serial = 0;
+    Shape train_shape;                                   // the shape of THAT forward (`last` follows every forward, inference included)
+    // every entry point that writes the shared workspace without keeping the activations calls this: a pending backward then finds a
+    // newer serial and its caller recomputes the forward (eemflow.py) instead of differentiating somebody else's activations
+    void workspace_overwritten() { have_train_fwd = false; train_serial += 1; }
     // backward pass: weight / bias gradients are leaves of the chain of data gradients, so they run on this context-owned side stream
     // (fork: an event after the gradient they read; join: the caller's stream waits for the last one before backward returns)
     hipStream_t wstream = nullptr;

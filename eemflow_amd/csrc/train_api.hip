@@ -306,6 +306,7 @@ static int forward_train_impl(eemflow_ctx* c, const float* e1, const float* e2, 
     if ((rc = run_forward(c, s, e1, e2, flow_out, hk)) != EEM_OK) return rc;
     c->have_train_fwd = true;
     c->train_serial += 1;
+    c->train_shape = s;
     *sout = s;
     return EEM_OK;
 }
@@ -330,7 +331,7 @@ extern "C" int eemflow_backward(eemflow_ctx* c, int64_t serial, const float* e1,
     EEM_REQUIRE(serial == c->train_serial, "eemflow_backward: the activations of forward %lld were overwritten by forward %lld "
                 "(one forward per backward and context; run eemflow_forward_train again)", (long long)serial, (long long)c->train_serial);
     EEM_HIP_CHECK(hipSetDevice(c->device));
-    return backward_impl(c, c->last, e1, e2, dflow, grad_out, (hipStream_t)stream);
+    return backward_impl(c, c->train_shape, e1, e2, dflow, grad_out, (hipStream_t)stream);
 }
 
 // sequence_loss term of one prediction + its gradient, on the device (no host synchronisation): stats6 (device, 6 doubles,

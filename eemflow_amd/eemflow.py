@@ -65,7 +65,8 @@ class _EEMFlowFunction(torch.autograd.Function):
                                                         out_size[0], out_size[1], ctypes.byref(serial),
                                                         _lib.current_stream_ptr(e1.device)))
         ctx.module, ctx.serial, ctx.out_size = module, serial.value, out_size
-        ctx.weights_version = module._weights_version
+        ctx.image_size = (int(module.image_size[0]), int(module.image_size[1]))     # the padder this forward ran with
+        ctx.weights_version = module._weights_fingerprint()      # the tuple itself: the module's cache field may be reset (invalidate_weights, reload)
         ctx.save_for_backward(e1, e2)
         return flow
 
@@ -83,7 +84,10 @@ class _EEMFlowFunction(torch.autograd.Function):
         with torch.cuda.device(e1.device):
             s = _lib.current_stream_ptr(e1.device)
             if L.eemflow_backward(m._ctx, ctx.serial, e1.data_ptr(), e2.data_ptr(), dflow.data_ptr(), grad.data_ptr(), s) != 0:
-                # another forward of this module ran in between and reused the workspace: recompute the activations
+                # another forward of this module ran in between and reused the workspace: recompute the activations, with the
+                # padder of THIS graph's forward (a validation forward may have brought another image size; the module's next
+                # forward sets its own again in _context)
+                _lib.check(L.eemflow_set_image_size(m._ctx, ctx.image_size[0], ctx.image_size[1], None))
                 scratch = torch.empty(b, 2, ctx.out_size[0], ctx.out_size[1], device=e1.device, dtype=torch.float32)
                 serial = ctypes.c_int64()
                 _lib.check(L.eemflow_forward_train(m._ctx, e1.data_ptr(), e2.data_ptr(), b, h, w, scratch.data_ptr(),

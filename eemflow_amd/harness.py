@@ -112,6 +112,10 @@ class TestRaftEvents:
             model.frames_in_flight = nfl
             replicas += [model.replicate(nfl) for _ in range(nfl - 1)]
             streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
+        pool = None
+        if loader_threads > 0:                                   # ONE pool for the whole evaluation (threads are not re-created per sequence)
+            import concurrent.futures
+            pool = concurrent.futures.ThreadPoolExecutor(max_workers=loader_threads)
         with torch.no_grad():
             for sequence in sequence_list:
                 acc = collections.defaultdict(float)
@@ -131,17 +135,14 @@ class TestRaftEvents:
                         idx + 1, len(self.dataset), aee, acc["aee"] / iters, 1. - acc["p3"] / iters))
 
                 indices = [idx for idx in range(len(self.dataset)) if idx % stride == 0]
-                pool, futures = None, collections.deque()
-                if loader_threads > 0:
-                    import concurrent.futures
-
+                futures = collections.deque()
+                if pool is not None:
                     def load(idx):
                         with torch.cuda.device(dev):
                             sample = self.dataset[idx]
                             ready = torch.cuda.Event()
                             ready.record(torch.cuda.current_stream(dev))
                         return sample, ready
-                    pool = concurrent.futures.ThreadPoolExecutor(max_workers=loader_threads)
                     ahead = iter(indices)
                     for idx in itertools.islice(ahead, 2 * loader_threads):
                         futures.append(pool.submit(load, idx))
@@ -166,8 +167,6 @@ class TestRaftEvents:
                         retire()
                 while pending:
                     retire()
-                if pool is not None:
-                    pool.shutdown()
                 iters = max(iters, 1)
                 self.logger.write_line("-------------------test_sequence_{:s}------------------".format(sequence), True)
                 self.logger.write_line(
@@ -179,6 +178,8 @@ class TestRaftEvents:
                 mean_out += 1. - acc["p3"] / iters
                 aee_list.append(acc["aee"] / iters)
                 out_list.append(1. - acc["p3"] / iters)
+        if pool is not None:
+            pool.shutdown()
         model.frames_in_flight = hint_before
         self.logger.write_line("-------------------------------------------------------", True)
         self.logger.write_line("-----------------Test after {:d} epoch-----------------".format(epoch), True)
@@ -235,8 +236,9 @@ class TrainRaftEvents:
             _, flow_list = model(e1, e2)
             loss, metrics = sequence_loss(flow_list, batch['flow'].to(dev).float(), batch['valid'].to(dev).float(), self.opt["gamma"])
             self.scaler.scale(loss).backward()
-            self.scaler.unscale_(self.optimizer)
             if parallel.env_world()[2] > 1:
+                # the still-SCALED gradients are exchanged, then unscaled: an overflow on one rank reaches every rank through the
+                # sum, so all ranks record the same found_inf, skip the same step and keep the same scale
                 params = [p for p in model.parameters() if p.grad is not None]
                 flat = torch.cat([p.grad.reshape(-1) for p in params])
                 parallel.average_gradients(flat)
@@ -244,6 +246,7 @@ class TrainRaftEvents:
                 for p in params:
                     p.grad.copy_(flat[off:off + p.numel()].view_as(p))
                     off += p.numel()
+            self.scaler.unscale_(self.optimizer)
             torch.nn.utils.clip_grad_norm_(model.parameters(), self.opt["clip"])
             lr = self.optimizer.param_groups[0]["lr"]
             self.scaler.step(self.optimizer)

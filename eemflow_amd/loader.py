@@ -18,6 +18,23 @@ class ThreadedBatchLoader:
         self.dataset, self.batch_size, self.sampler = dataset, int(batch_size), sampler
         self.shuffle, self.drop_last, self.threads, self.ahead = shuffle, drop_last, max(1, int(threads)), max(1, int(ahead))
         self._epoch, self._seed = 0, seed
+        self._pool = None                                        # created once, reused by every epoch (close() / __del__ shut it down)
+
+    def _executor(self):
+        if self._pool is None:
+            self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=self.threads, thread_name_prefix="eemflow-loader")
+        return self._pool
+
+    def close(self):
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                        # noqa: BLE001 - interpreter shutdown
+            pass
 
     def _indices(self):
         if self.sampler is not None:
@@ -34,12 +51,16 @@ class ThreadedBatchLoader:
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
 
     def _sample(self, idx):
-        sample = self.dataset[idx]
-        ready = None
-        if torch.cuda.is_available():
-            ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream())
-        return sample, ready
+        # the current device is per THREAD: a worker starts on device 0 whatever the rank's GPU is, so the sample is built (and its
+        # hand-over event recorded) under the dataset's device
+        dev = getattr(self.dataset, "device", None)
+        if torch.cuda.is_available() and dev is not None and torch.device(dev).type == "cuda":
+            with torch.cuda.device(dev):
+                sample = self.dataset[idx]
+                ready = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream(dev))
+            return sample, ready
+        return self.dataset[idx], None
 
     def __iter__(self):
         idx = self._indices()
@@ -47,16 +68,18 @@ class ThreadedBatchLoader:
         batches = [idx[i:i + self.batch_size] for i in range(0, len(idx), self.batch_size)]
         if self.drop_last and batches and len(batches[-1]) < self.batch_size:
             batches.pop()
-        with concurrent.futures.ThreadPoolExecutor(max_workers=self.threads) as pool:
-            queue = collections.deque()
-            todo = iter(batches)
+        pool = self._executor()
+        dev = getattr(self.dataset, "device", None)
+        queue = collections.deque()
+        todo = iter(batches)
 
-            def submit():
-                b = next(todo, None)
-                if b is not None:
-                    queue.append([pool.submit(self._sample, i) for i in b])
-            for _ in range(self.ahead):
-                submit()
+        def submit():
+            b = next(todo, None)
+            if b is not None:
+                queue.append([pool.submit(self._sample, i) for i in b])
+        for _ in range(self.ahead):
+            submit()
+        try:
             while queue:
                 futures = queue.popleft()
                 submit()
@@ -64,7 +87,11 @@ class ThreadedBatchLoader:
                 for f in futures:
                     sample, ready = f.result()
                     if ready is not None:
-                        torch.cuda.current_stream().wait_event(ready)
+                        torch.cuda.current_stream(dev).wait_event(ready)
                     samples.append(sample)
                 yield {k: (torch.stack([s[k] for s in samples]) if torch.is_tensor(samples[0][k]) else [s[k] for s in samples])
                        for k in samples[0]}
+        finally:                                                 # an abandoned epoch (break in the training loop): do not leave work queued
+            for futures in queue:
+                for f in futures:
+                    f.cancel()

@@ -17,18 +17,45 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def share_gpu():
+    """EEM_DIST_SHARE_GPU=1: several ranks may sit on one GPU (rank r -> device r mod #devices) and the process group is gloo, which
+    all-reduces device tensors through the host.  RCCL refuses two ranks on one device, so this is how the data-parallel step of the
+    product (EEMFlowTrainer.step, `cli train`, `bench.py --mode train`) is exercised with world > 1 on a 1-GPU box
+    (tests/test_gpu_dp_processes.py); never set in production."""
+    return os.environ.get("EEM_DIST_SHARE_GPU", "0") not in ("", "0")
+
+
+def local_device_index(local_rank=None):
+    """The GPU of this rank: LOCAL_RANK, one process per GPU.  A rank without a GPU of its own is an error (no silent sharing)
+    unless EEM_DIST_SHARE_GPU is set."""
+    if local_rank is None:
+        local_rank = env_world()[1]
+    n = torch.cuda.device_count()
+    if n == 0:
+        raise RuntimeError("eemflow_amd.parallel: no GPU visible to this rank")
+    if local_rank >= n:
+        if not share_gpu():
+            raise RuntimeError(f"eemflow_amd.parallel: LOCAL_RANK {local_rank} but only {n} GPU(s) visible - one process per GPU")
+        return local_rank % n
+    return local_rank
+
+
 def init_distributed(backend=None):
-    """Join the process group when launched with WORLD_SIZE > 1; returns (rank, local_rank, world)."""
+    """Join the process group when launched with WORLD_SIZE > 1; returns (rank, local_rank, world).  Backend: EEM_DIST_BACKEND,
+    else "nccl" (= RCCL) with GPUs ("gloo" when ranks share a GPU, see share_gpu), "gloo" on CPU."""
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("EEM_DIST_BACKEND") or None
+        if backend is None:
+            backend = "gloo" if (share_gpu() or not torch.cuda.is_available()) else "nccl"
         kwargs = {}
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            kwargs["device_id"] = torch.device("cuda", local_rank)
+            idx = local_device_index(local_rank)
+            torch.cuda.set_device(idx)
+            kwargs["device_id"] = torch.device("cuda", idx)
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
     return rank, local_rank, world
 
@@ -42,7 +69,7 @@ def shard_frames(n_frames, rank, world):
 
 def barrier(device=None):
     if dist.is_initialized():
-        if device is not None and device.type == "cuda":
+        if device is not None and device.type == "cuda" and dist.get_backend() == "nccl":
             dist.barrier(device_ids=[device.index])
         else:
             dist.barrier()

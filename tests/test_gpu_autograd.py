@@ -183,3 +183,37 @@ def test_eval_without_grad_still_replays_the_graph_and_data_writes_need_invalida
     # grad mode with eval(): still differentiable (the reference's module is, whatever .training says)
     _, preds = net(e1, e2)
     assert preds[0].requires_grad and torch.equal(preds[0].detach(), f1)
+
+
+@pytest.mark.parametrize("val_batch,val_hw", [(1, (96, 128)), (3, (128, 192))])
+def test_validation_forward_between_training_forward_and_backward(val_batch, val_hw):
+    """`_, p = model(e1, e2)` under grad, then a `torch.no_grad()` forward of the same module (another batch size / image size: the
+    validation step of a training loop), then `loss.backward()`: the inference forward overwrote the shared workspace, so the
+    backward has to notice (newer serial) and recompute - with the TRAINING forward's shape, not the last forward's."""
+    net, sd = make_net(81)
+    net.change_imagesize((96, 128))
+    e1, e2, gt, valid = batch_of(82, 83, 2, 96, 128)
+    _, preds = net(e1, e2)
+    loss, _ = T.sequence_loss(preds, gt, valid)
+    with torch.no_grad():
+        net.change_imagesize(val_hw)
+        v1, v2, _, _ = batch_of(84, 85, val_batch, *val_hw)
+        net(v1, v2)
+        net(v1, v2)                                               # the second one is a graph replay
+        net.change_imagesize((96, 128))
+    loss.backward()
+    _, _, ref, _ = T.loss_and_grads(sd, e1.cpu(), e2.cpu(), gt.cpu(), valid.cpu())
+    worst = max((rel_err(p.grad, ref[k]), k) for k, p in net.named_parameters())
+    assert worst[0] < 3e-3, worst
+    # and the serial protocol itself: an inference forward invalidates a pending eemflow_backward
+    import ctypes
+    from eemflow_amd import _lib
+    L, ctx = _lib.lib(), net._ctx
+    flow = torch.empty(2, 2, 96, 128, device=DEV)
+    serial = ctypes.c_int64()
+    sp = _lib.current_stream_ptr(torch.device(DEV))
+    _lib.check(L.eemflow_forward_train(ctx, e1.data_ptr(), e2.data_ptr(), 2, 96, 128, flow.data_ptr(), 96, 128, ctypes.byref(serial), sp))
+    _lib.check(L.eemflow_forward(ctx, e1.data_ptr(), e2.data_ptr(), 2, 96, 128, flow.data_ptr(), 96, 128, sp))
+    grad = torch.empty(sum(p.numel() for p in net.parameters()), device=DEV)
+    assert L.eemflow_backward(ctx, serial.value, e1.data_ptr(), e2.data_ptr(), flow.data_ptr(), grad.data_ptr(), sp) != 0
+    assert "eemflow_forward_train" in L.eemflow_last_error().decode()

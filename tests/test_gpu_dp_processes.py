@@ -1,0 +1,162 @@
+"""A16 with world > 1: the PRODUCT's data-parallel step in two real processes (train_EEMFlow_HREM.py:116-118 -> one process per GPU,
+train_mvsec.py:215 -> mean over the global batch).
+
+The GPU box has one MI355X and RCCL refuses two ranks on one device, so the two ranks share cuda:0 and exchange the device gradient
+over gloo (EEM_DIST_SHARE_GPU=1, eemflow_amd/parallel.py) - everything else is the code an 8-GPU job runs: torch.distributed.run,
+parallel.init_distributed, EEMFlowTrainer.step's average_gradients on the gradient eemflow_forward_backward produced, `cli train`
+with its DistributedSampler / per-rank batch / weight broadcast / rank-0 checkpoint, and bench.py's own launch of its ranks.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(REPO, "tests", "dp_worker.py")
+DEV = "cuda:0"
+
+
+def child_env(share=True):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env["OMP_NUM_THREADS"] = "4"
+    if share:
+        env["EEM_DIST_SHARE_GPU"] = "1"
+    else:
+        env.pop("EEM_DIST_SHARE_GPU", None)
+    return env
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_two(args, timeout=600):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), WORKER, *[str(a) for a in args]]
+    r = subprocess.run(cmd, env=child_env(), capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return r
+
+
+@pytest.mark.parametrize("b,h,w", [(4, 260, 346), (2, 720, 1280)])
+def test_trainer_step_two_processes_equals_single_process(tmp_path, b, h, w):
+    """EEMFlowTrainer.step under 2 ranks (half the batch each) against the same trainer on the whole batch in this process: the
+    mean of the ranks' losses is the global loss, the all-reduced gradient is the global-batch gradient, the replicas end
+    bit-identical and track the single-process weights."""
+    from eemflow_amd import EEMFlow
+    from eemflow_amd.train import EEMFlowTrainer
+    from eemflow_amd.weights import seeded_state_dict, synthetic_gt, synthetic_voxel_pair
+    steps = 2
+    launch_two(["trainer", tmp_path, b, h, w, steps])
+    r0, r1 = (np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in (0, 1))
+    assert int(r0["world"]) == 2 and str(r0["backend"]) == "gloo"
+    net = EEMFlow("", 5, 5)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(133).items()})
+    net = net.to(DEV).train()
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(131, b, h, w))
+    gt, va = (torch.from_numpy(a).to(DEV) for a in synthetic_gt(132, b, h, w))
+    tr = EEMFlowTrainer(net, lr=1e-3, wdecay=5e-5, epsilon=1e-8, num_steps=20, clip=1.0)
+    for i in range(steps):
+        loss, _, _ = tr.step(e1, e2, gt, va)
+        assert abs(0.5 * (r0["losses"][i] + r1["losses"][i]) - loss) < 2e-5 * max(1.0, abs(loss)), i
+        g = tr.grad.cpu().numpy()
+        assert np.array_equal(r0["grads"][i], r1["grads"][i]), i                     # every rank holds the same averaged gradient
+        if i == 0:                                                                   # same weights on both sides only at step 0
+            rel = np.linalg.norm(r0["grads"][0] - g) / np.linalg.norm(g)
+            assert rel < 1e-4, rel
+    tr.sync_parameters()
+    wf = torch.cat([v.reshape(-1).float().cpu() for v in net.state_dict().values()]).numpy()
+    assert np.array_equal(r0["weights"], r1["weights"])                              # replicas bit-identical after clip + AdamW
+    d = np.abs(r0["weights"] - wf)
+    assert float((d > 2e-5).mean()) < 2e-3 and float(d.max()) < 2.5e-3, float(d.max())
+
+
+def _hrem_train_tree(root):
+    from eemflow_amd import hrem
+    for sub in ("dt1/000001", "dt1/000002"):
+        d = os.path.join(root, "dataset/HREM/train", sub)
+        os.makedirs(d)
+        seed = 7 + int(sub[-1])
+        hrem.write_events_npz(os.path.join(d, "events1.npz"), hrem.synthetic_hrem_events(seed, 20000, 720, 1280))
+        hrem.write_events_npz(os.path.join(d, "events2.npz"), hrem.synthetic_hrem_events(seed + 1, 20000, 720, 1280))
+        hrem.write_flo(os.path.join(d, "flow.flo"), hrem.synthetic_flow(seed + 2, 720, 1280))
+
+
+@pytest.mark.parametrize("threads", [0, 2])
+def test_cli_train_two_processes_equals_single_process(tmp_path, threads):
+    """`cli train -bs 2` under torch.distributed.run with 2 ranks (per-rank batch 1, DistributedSampler, weight broadcast, rank-0
+    checkpoint) against the same command in one process: two samples = the same global batch every step, so the two runs differ
+    by summation order only.  No augmentation in the config (its flips draw from numpy's global generator)."""
+    from eemflow_amd import cli
+    root = str(tmp_path)
+    _hrem_train_tree(root)
+    cfg = json.loads(json.dumps(cli.DEFAULT_CONFIG))
+    del cfg["data_loader"]["train"]["args"]["aug_params"]
+    cfg_path = os.path.join(root, "cfg.json")
+    json.dump(cfg, open(cfg_path, "w"))
+    out2 = os.path.join(root, "two")
+    os.makedirs(out2)
+    r = launch_two(["cli", out2, root, cfg_path, threads])
+    r0, r1 = (np.load(os.path.join(out2, f"rank{k}.npz")) for k in (0, 1))
+    assert int(r0["world"]) == 2 and int(r0["iteration"]) == 2 and int(r1["iteration"]) == 2
+    assert np.array_equal(r0["weights"], r1["weights"])                              # replicas identical after two steps
+    run2 = os.path.join(out2, "exp_HREM_meshflow/EEMFlow_dt1/lr0.000100_we0.000010")
+    assert sorted(os.listdir(run2)) == ["config.json", "lasted_ckpt.pth.tar", "train.log"]   # one writer
+    log = open(os.path.join(run2, "train.log")).read().strip().splitlines()
+    assert len(log) == 2, log                                                        # rank 0's lines only, one per epoch
+    ck2 = torch.load(os.path.join(run2, "lasted_ckpt.pth.tar"), weights_only=False)
+    out1 = os.path.join(root, "one")
+    os.makedirs(out1)
+    torch.manual_seed(11)
+    run1 = cli.main(["train", "--data_root", root, "--save_root", out1, "--lr", "1e-4", "--wd", "1e-5", "-bs", "2", "--train_iters", "2",
+                     "--val_iters", "1", "--config", cfg_path])
+    ck1 = torch.load(os.path.join(run1, "lasted_ckpt.pth.tar"), weights_only=False)
+    assert ck1["epoch"] == ck2["epoch"] == 1 and ck1["iteration"] == ck2["iteration"] == 2
+    diff = torch.cat([(ck1["state_dict"][k] - ck2["state_dict"][k]).abs().reshape(-1) for k in ck1["state_dict"]])
+    assert float(diff.max()) < 3e-4 and float(diff.median()) < 1e-6, (float(diff.max()), float(diff.median()))
+    # the checkpoint holds what rank 0's replica holds
+    w_ck = torch.cat([v.reshape(-1).float() for v in ck2["state_dict"].values()]).numpy()
+    assert np.array_equal(w_ck, r0["weights"])
+
+
+def _bench(args, share, timeout=900):
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *args], env=child_env(share), capture_output=True, text=True,
+                       timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py starts torch.distributed.run itself and rank 0's line says
+    n_gpus 2; the training mode reports the all-reduce it timed."""
+    r, line = _bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--preheat", "10", "--cpu-seconds", "0", "--no-other-rows",
+                      "--no-side-rows", "--height", "260", "--width", "346"], share=True)
+    assert r.returncode == 0 and line is not None, r.stdout[-2000:] + r.stderr[-3000:]
+    assert line["n_gpus"] == 2 and line["steps"] == 6 and line["value"] > 0 and line["scaling"] == "weak"
+    one, l1 = _bench(["--gpus", "1", "--steps", "6", "--warmup", "2", "--preheat", "10", "--cpu-seconds", "0", "--no-other-rows",
+                      "--no-side-rows", "--height", "260", "--width", "346"], share=False)
+    assert one.returncode == 0 and l1["n_gpus"] == 1
+    r, line = _bench(["--gpus", "2", "--mode", "train", "--steps", "3", "--warmup", "1", "--height", "260", "--width", "346",
+                      "--batch", "4"], share=True)
+    assert r.returncode == 0 and line is not None, r.stdout[-2000:] + r.stderr[-3000:]
+    assert line["n_gpus"] == 2 and line["allreduce_us"] > 0 and line["allreduce_bytes"] == 714352 * 4
+    assert np.isfinite(line["final_loss"]) and line["config"]["parallelism"].startswith("dp2")
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """Without the sharing switch, asking for more GPUs than the node has is an error - never a silent 1-GPU number."""
+    n = torch.cuda.device_count()
+    r, line = _bench(["--gpus", str(n + 1), "--steps", "2", "--warmup", "1"], share=False, timeout=300)
+    assert r.returncode != 0 and line is None and "refusing" in r.stderr

@@ -2,9 +2,12 @@
 import os
 import socket
 
+import pytest
 import torch.multiprocessing as mp
 
 from eemflow_amd import parallel
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
@@ -117,3 +120,37 @@ def test_shard_frames_properties():
 def test_single_process_is_identity():
     assert parallel.max_over_ranks(3.5) == 3.5
     assert parallel.aggregate_throughput(10, 2.0) == (5.0, 2.0)
+
+
+def _run_bench(argv, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK")):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_never_measures_fewer_gpus_than_asked():
+    """`python bench.py --gpus 2` on a node with fewer GPUs (none here): refused before anything is launched; a launcher whose world
+    size disagrees with --gpus is refused too; and when bench.py does start its own ranks (the sharing switch lets it, on a box with no
+    GPU the ranks then fail), the children's failure is bench.py's exit code - no JSON line on any of these paths."""
+    r = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 2 and "refusing" in r.stderr and "{" not in r.stdout
+    r = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1"], {"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and "WORLD_SIZE=4" in r.stderr and "{" not in r.stdout
+    import torch
+    if not torch.cuda.is_available():
+        r = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0"], {"EEM_DIST_SHARE_GPU": "1"})
+        assert r.returncode != 0 and "torch.distributed.run" in r.stderr and "{" not in r.stdout
+
+
+def test_local_device_index_is_one_process_per_gpu(monkeypatch):
+    import torch
+    from eemflow_amd import parallel
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    monkeypatch.delenv("EEM_DIST_SHARE_GPU", raising=False)
+    assert parallel.local_device_index(1) == 1
+    with pytest.raises(RuntimeError, match="one process per GPU"):
+        parallel.local_device_index(2)
+    monkeypatch.setenv("EEM_DIST_SHARE_GPU", "1")
+    assert parallel.local_device_index(3) == 1

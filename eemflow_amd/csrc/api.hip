@@ -215,13 +215,14 @@ extern "C" int eemflow_load_weights(eemflow_ctx* c, const float* flat, size_t nf
     {   // Winograd-domain weights for the stride-1 C->C layers
         const char* e = getenv("EEM_WINO");
         c->use_wino = !(e && atoi(e) == 0);
+        const char* e4 = getenv("EEM_WINO4_LAYERS");
+        c->f4_mask_env = (e && atoi(e) == 2) ? 0 : (e4 ? atoi(e4) & 7 : -1);
         size_t off = 0;
         for (int l = 0; l < ENC_NUM; ++l) {
             const EncLayerDesc& d = kEncLayers[l];
             c->enc_wino[l] = l > 0 && wino_supported(d.cin, d.cout, d.stride, 4);
             if (!c->enc_wino[l]) continue;
-            c->wino_off[l] = off;            off += wino_packed_floats(d.cin);
-            c->wino_off[ENC_NUM + l] = off;  off += wino_packed_floats(d.cin);
+            for (int f = 0; f < 4; ++f) { c->wino_off[f][l] = off; off += wino_packed_floats(d.cin); }
         }
         if (c->wino) EEM_HIP_CHECK(hipFree(c->wino));
         c->wino = nullptr;
@@ -296,6 +297,7 @@ extern "C" int eemflow_forward(eemflow_ctx* c, const float* e1, const float* e2,
     if (rc != EEM_OK) return rc;
 
     c->workspace_overwritten();
+    if ((rc = ensure_forward_wino(c, st)) != EEM_OK) return rc;          // outside any capture
     if (!c->use_graph) {
         if ((rc = alloc_workspace(c, s)) != EEM_OK) return rc;
         c->last = s;

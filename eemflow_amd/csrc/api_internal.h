@@ -60,12 +60,25 @@ struct eemflow_ctx {
     float* arena = nullptr;
     size_t enc_w[ENC_NUM], enc_w2[ENC_NUM], enc_b[ENC_NUM];
     bool enc_has2[ENC_NUM];
-    // Winograd-domain weights of the stride-1 C->C encoder layers (conv_wino.hip): computed from `flat` by
-    // wino_transform_launch after every (re)pack; [l] forward weights, [ENC_NUM + l] W^T flipped (data gradient)
+    // Winograd-domain weights of the stride-1 C->C encoder layers, both forms (F(2x2,3x3): conv_wino.hip / conv_wino32.hip,
+    // F(4x4,3x3): conv_wino4.hip): computed from `flat` by wino_transform_launch when a launch first needs them after a (re)pack.
+    // Slot [f4 * 2 + dir][l]: dir 0 forward weights, dir 1 W^T flipped (data gradient)
     float* wino = nullptr;
-    size_t wino_off[2 * ENC_NUM];
+    size_t wino_off[4][ENC_NUM];
+    bool wino_ok[4][ENC_NUM] = {};
     bool enc_wino[ENC_NUM];
     bool use_wino = true;              // EEM_WINO=0 in the environment keeps the direct-convolution kernels
+    // which stride-1 layers run F(4x4,3x3), by channel count (bit 0: C = 16, 1: C = 32, 2: C = 64).  F(4x4) blocks are 8 waves on 16 x
+    // {128, 64, 32} pixel tiles: 240 / 120 / 60 blocks per frame at 1280x720 - the C = 32 / 64 layers then occupy half / a quarter of
+    // the chip for longer (24 / 38 us against 17.6 / 15.3) but cost 0.68 / 0.62 of the CU time, so they are the throughput choice
+    // (several frames in flight: eemflow_set_frames_in_flight >= 3) and F(2x2) the latency choice; C = 16 wins both ways.
+    // EEM_WINO=2: never; EEM_WINO4_LAYERS=<mask>: always that mask
+    int f4_mask_env = -1;
+    int f4_mask() const {
+        if (f4_mask_env >= 0) return f4_mask_env;
+        return frames_in_flight >= 3 ? 7 : 1;
+    }
+    bool layer_f4(int cin) const { return (f4_mask() >> (cin == 16 ? 0 : cin == 32 ? 1 : 2)) & 1; }
     float* zero_page = nullptr;
     TailW rconv[3], dconv1[3], dgroup[3][3][5], dconv5[3], dconv6[3], dconv7[3], outc;
     // training: per-conv descriptors (flat offsets of weight/bias, packed transposed weights for gconv dgrad)
@@ -148,14 +161,35 @@ int ensure(DevBuf& b, size_t floats) {
     return EEM_OK;
 }
 
-// Recompute the Winograd-domain weights from the device-resident flat weights (after load / optimizer step).
-int refresh_wino(eemflow_ctx* c, hipStream_t st) {
+// The device-resident flat weights changed (load / optimizer step): every Winograd-domain copy is stale; a launch recomputes the one it
+// needs (ensure_wino) - a training step touches two forms of five layers, an inference loop one
+int refresh_wino(eemflow_ctx* c, hipStream_t) {
+    for (int f = 0; f < 4; ++f)
+        for (int l = 0; l < ENC_NUM; ++l) c->wino_ok[f][l] = false;
+    return EEM_OK;
+}
+// Winograd-domain weights of layer l (dir 0: forward, 1: data gradient) in the form the policy picks; *f4_out says which
+int ensure_wino(eemflow_ctx* c, int l, int dir, hipStream_t st, const float** w_out, int* f4_out) {
+    const int ch = kEncLayers[l].cin;
+    const int f4 = c->layer_f4(ch) ? 1 : 0;
+    const int slot = f4 * 2 + dir;
+    if (!c->wino_ok[slot][l]) {
+        const int rc = wino_transform_launch(c->flat + c->t_enc[l].w, ch, dir, c->wino + c->wino_off[slot][l], st, f4);
+        if (rc != EEM_OK) return rc;
+        c->wino_ok[slot][l] = true;
+    }
+    *w_out = c->wino + c->wino_off[slot][l];
+    *f4_out = f4;
+    return EEM_OK;
+}
+// before a graph capture / replay: the forward copies exist (a transform launched inside a capture would replay with every frame)
+int ensure_forward_wino(eemflow_ctx* c, hipStream_t st) {
+    if (!c->use_wino) return EEM_OK;
     for (int l = 0; l < ENC_NUM; ++l) {
         if (!c->enc_wino[l]) continue;
-        const int ch = kEncLayers[l].cin;
-        int rc = wino_transform_launch(c->flat + c->t_enc[l].w, ch, 0, c->wino + c->wino_off[l], st);
+        const float* w; int f4;
+        const int rc = ensure_wino(c, l, 0, st, &w, &f4);
         if (rc != EEM_OK) return rc;
-        if ((rc = wino_transform_launch(c->flat + c->t_enc[l].w, ch, 1, c->wino + c->wino_off[ENC_NUM + l], st)) != EEM_OK) return rc;
     }
     return EEM_OK;
 }
@@ -191,7 +225,7 @@ int compute_shape(eemflow_ctx* c, int batch, int in_h, int in_w, int out_h, int 
         const EncLayerDesc& d = kEncLayers[last[k]];
         int th, tw, pk;
         const bool wino = c->use_wino && c->enc_wino[last[k]] && wino_supported(d.cin, d.cout, d.stride, ws[k]);
-        if (wino) wino_tile(d.cin, &th, &tw, &pk);
+        if (wino) wino_tile(d.cin, c->layer_f4(d.cin) ? 1 : 0, &th, &tw, &pk);
         else enc2_tile(d.cin, d.cout, &th, &tw, &pk);
         s->fuse[k] = (wino || (c->enc_has2[last[k]] && enc2_supported(d.cin, d.cout, d.stride, ws[k]))) && pk == ks[k];
         s->th[k] = th;
@@ -354,7 +388,9 @@ int run_forward(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2
         a.in1 = sp.layer == ENC_1_1 ? e2 : nullptr;
         a.wpk = c->arena + c->enc_w[sp.layer];
         a.wpk2 = c->enc_has2[sp.layer] ? c->arena + c->enc_w2[sp.layer] : nullptr;
-        a.wwino = (c->use_wino && c->enc_wino[sp.layer]) ? c->wino + c->wino_off[sp.layer] : nullptr;
+        a.wwino = nullptr;
+        a.wino_f4 = 0;
+        if (c->use_wino && c->enc_wino[sp.layer] && (rc = ensure_wino(c, sp.layer, 0, hk.st, &a.wwino, &a.wino_f4)) != EEM_OK) return rc;
         a.zero_page = c->zero_page;
         a.trash = c->zero_page + 256;
         a.bias = c->arena + c->enc_b[sp.layer];

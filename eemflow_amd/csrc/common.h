@@ -162,6 +162,7 @@ struct EncConvArgs {
     // persistent kernels: blocks per XCD (0 = one per CU).  The context lowers it when the application keeps several frames in flight
     // (eemflow_set_frames_in_flight): fewer, longer blocks spend less CU time on per-block prologues
     int blocks_per_xcd = 0;
+    int wino_f4 = 0;       // wwino holds F(4x4,3x3) weights (conv_wino4.hip) instead of F(2x2,3x3) ones
 };
 int enc_conv_launch(int cin, int cout, int stride, const EncConvArgs& a, hipStream_t stream);
 // first layer with 16-byte LDS-DMA staging (conv_enc1.hip): raw width % 4 == 0, no horizontal padding
@@ -178,12 +179,17 @@ int s2_launch(int cin, const EncConvArgs& a, hipStream_t stream);
 void enc2_tile(int cin, int cout, int* th, int* tw, int* poolk);
 // Winograd F(2x2,3x3) path for the stride-1 C -> C layers (C = 16, 32, 64), conv_wino.hip
 bool wino_supported(int cin, int cout, int stride, int win);
-size_t wino_packed_floats(int c);
+size_t wino_packed_floats(int c);      // room for either form
 // U = G g G^T of OIHW weights w [c][c][3][3] (device pointers), written in the register-fragment order of
-// wino_kernel; transpose_flip = 1 transforms W^T with flipped taps (the data gradient's weights)
-int wino_transform_launch(const float* w, int c, int transpose_flip, float* packed, hipStream_t stream);
-int wino_launch(int c, const EncConvArgs& a, hipStream_t stream);
-void wino_tile(int c, int* th, int* tw, int* poolk);
+// wino_kernel (f4 = 0) or wino4_kernel (f4 = 1); transpose_flip = 1 transforms W^T with flipped taps (the data gradient's weights)
+int wino_transform_launch(const float* w, int c, int transpose_flip, float* packed, hipStream_t stream, int f4);
+int wino_launch(int c, const EncConvArgs& a, hipStream_t stream);          // a.wino_f4 selects the form
+void wino_tile(int c, int f4, int* th, int* tw, int* poolk);
+// Winograd F(4x4,3x3) on 16x16x4 MFMAs, one wave per SIMD (conv_wino4.hip); reached through wino_*
+size_t wino4_packed_floats(int c);
+int wino4_transform_launch(const float* w, int c, int transpose_flip, float* packed, hipStream_t stream);
+int wino4_launch(int c, const EncConvArgs& a, hipStream_t stream);
+void wino4_tile(int c, int* th, int* tw, int* poolk);
 // C = 32 / 64 on 32x32x2 MFMA with the Winograd rows split over 4 waves (conv_wino32.hip); reached through wino_*
 int wino32_transform_launch(const float* w, int c, int transpose_flip, float* packed, hipStream_t stream);
 int wino32_launch(int c, const EncConvArgs& a, hipStream_t stream);

@@ -438,7 +438,7 @@ bool wino_supported(int cin, int cout, int stride, int win) {
     return stride == 1 && cin == cout && (cin == 16 || cin == 32 || cin == 64) && (win & 3) == 0;
 }
 
-size_t wino_packed_floats(int c) { return (size_t)16 * c * c; }
+size_t wino_packed_floats(int c) { return wino4_packed_floats(c); }      // 36 c^2 >= 16 c^2: either form fits
 
 #ifdef EEM_STAMPS
 extern "C" int eemflow_debug_read_stamps16(unsigned long long* dst, size_t n) {
@@ -446,21 +446,24 @@ extern "C" int eemflow_debug_read_stamps16(unsigned long long* dst, size_t n) {
 }
 #endif
 
-int wino_transform_launch(const float* w, int c, int transpose_flip, float* packed, hipStream_t stream) {
+int wino_transform_launch(const float* w, int c, int transpose_flip, float* packed, hipStream_t stream, int f4) {
     EEM_REQUIRE(c == 16 || c == 32 || c == 64, "wino_transform_launch: C=%d", c);
+    if (f4) return wino4_transform_launch(w, c, transpose_flip, packed, stream);
     if (c >= 32) return wino32_transform_launch(w, c, transpose_flip, packed, stream);
     hipLaunchKernelGGL(wino_wt_kernel, dim3(ceil_div(c * c, 256)), dim3(256), 0, stream, w, c, transpose_flip, packed);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }
 
-void wino_tile(int c, int* th, int* tw, int* poolk) {
+void wino_tile(int c, int f4, int* th, int* tw, int* poolk) {
+    if (f4) { wino4_tile(c, th, tw, poolk); return; }
     if (c >= 32) { wino32_tile(c, th, tw, poolk); return; }
     *th = WTile<16>::TH; *tw = WTile<16>::TW; *poolk = WTile<16>::POOLK;
 }
 
 int wino_launch(int c, const EncConvArgs& a, hipStream_t stream) {
     EEM_REQUIRE(a.wwino && a.zero_page && a.trash, "wino_launch: NULL operand");
+    if (a.wino_f4) return wino4_launch(c, a, stream);
     if (c >= 32) return wino32_launch(c, a, stream);
     if (c == 16) return wino_launch_c<16>(a, stream);
     eem_set_error("wino_launch: unsupported C=%d", c);

@@ -328,7 +328,7 @@ extern "C" int eemplus_load_weights(eemplus_ctx* c, const float* flat, size_t nf
             EEM_HIP_CHECK(hipMalloc(&c->wino, tot * sizeof(float)));
             for (int i = 0; i < 8; ++i)
                 if (c->enc_wino[i]) {
-                    const int rcw = wino_transform_launch(c->arena + c->enc_raw[i], ec[i][1], 0, c->wino + c->wino_off[i], nullptr);
+                    const int rcw = wino_transform_launch(c->arena + c->enc_raw[i], ec[i][1], 0, c->wino + c->wino_off[i], nullptr, 0);
                     if (rcw != EEM_OK) return rcw;
                 }
             EEM_HIP_CHECK(hipDeviceSynchronize());

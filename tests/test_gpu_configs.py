@@ -217,7 +217,10 @@ def test_dp_equivalence_two_shards_one_gpu(b, h, w):
         avg = (t0.grad + t1.grad) / 2                                     # what the all-reduce leaves on every rank
         gf, ga = split_flat(tf.grad, sd), split_flat(avg, sd)
         worst = max((rel_err(ga[k], gf[k]), k) for k in sd)
-        assert worst[0] < 1e-4, (step, worst)
+        # step 0: the same weights on both sides, so only the summation order differs.  Step 1: the replicas' weights and the
+        # single-process weights have been through one AdamW step on gradients that differ in round-off - g / (sqrt(v) + eps) moves
+        # a near-zero gradient element by up to lr either way (the weight bound below) - so the gradients agree to that, not to 1e-4
+        assert worst[0] < (1e-4 if step == 0 else 5e-3), (step, worst)
         opt_step(tf, tf.grad)
         opt_step(t0, avg)
         opt_step(t1, avg)

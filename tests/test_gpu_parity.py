@@ -121,9 +121,16 @@ def test_graph_equals_eager_and_is_repeatable():
     assert torch.equal(outs[0], outs[1])
 
 
-def test_frames_in_flight_hint_changes_grids_not_results():
-    """eemflow_set_frames_in_flight >= 3 launches the persistent encoder kernels on fewer blocks (more tiles each): the same tiles, the
-    same arithmetic - the flow is bitwise the same, at the headline size (960 tiles on 160 / 192 / 232 blocks) and at a ragged one."""
+@pytest.mark.parametrize("mask", ["0", "7", None])
+def test_frames_in_flight_hint_changes_grids_not_results(monkeypatch, mask):
+    """eemflow_set_frames_in_flight >= 3 launches the persistent encoder kernels on fewer blocks (more tiles each) and, by default, moves
+    the C = 32 / 64 stride-1 layers from Winograd F(2x2,3x3) to F(4x4,3x3) (fewer, longer blocks: less CU time, more latency).  With
+    the form pinned (EEM_WINO4_LAYERS) it is the same tiles and the same arithmetic: the flow is bitwise the same, at the headline
+    size and at a ragged one; with the default policy the two forms agree to fp32 round-off and each setting is bitwise stable."""
+    if mask is None:
+        monkeypatch.delenv("EEM_WINO4_LAYERS", raising=False)
+    else:
+        monkeypatch.setenv("EEM_WINO4_LAYERS", mask)             # read when the weights are loaded
     for (h, w, seed) in ((720, 1280, 51), (260, 346, 52)):
         e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(seed, 1, h, w))
         net, _ = make_net(43)
@@ -134,7 +141,11 @@ def test_frames_in_flight_hint_changes_grids_not_results():
             with torch.no_grad():
                 outs.append(net(e1, e2)[1][0].clone())
                 outs.append(net(e1, e2)[1][0].clone())        # replay of the graph captured for this setting
-        assert all(torch.equal(outs[0], o) for o in outs[1:])
+        if mask is None:
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[2], outs[3]) and torch.equal(outs[0], outs[4]) and torch.equal(outs[0], outs[5])
+            assert maxerr(outs[0], outs[2]) < 2e-5
+        else:
+            assert all(torch.equal(outs[0], o) for o in outs[1:])
         assert graph_stats(net)[0] == 3                       # the hint flipped twice: the cached graph was dropped each time
 
 
@@ -469,10 +480,12 @@ def test_errors_are_loud():
     _lib.lib().eemflow_destroy(handle)
 
 
+@pytest.mark.parametrize("form", ["f2", "f4", "default"])
 @pytest.mark.parametrize("h,w", [(192, 320), (260, 346), (720, 1280)])
-def test_winograd_encoder_equals_direct_convolution(monkeypatch, h, w):
-    """The Winograd F(2x2,3x3) / enc1 kernels against the direct-convolution kernels of the same library
-    (EEM_WINO=0 is read when weights are loaded, EEM_NO_ENC1 at launch): same stage tensors and flow to fp32 round-off."""
+def test_winograd_encoder_equals_direct_convolution(monkeypatch, h, w, form):
+    """The Winograd kernels - F(2x2,3x3) (EEM_WINO=2), F(4x4,3x3) on every stride-1 layer (EEM_WINO4_LAYERS=7), the default mix -
+    and the enc1 kernel against the direct-convolution kernels of the same library (EEM_WINO=0 is read when weights are loaded,
+    EEM_NO_ENC1 at launch): same stage tensors and flow to fp32 round-off."""
     e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(77, 1, h, w))
 
     def run():
@@ -481,7 +494,14 @@ def test_winograd_encoder_equals_direct_convolution(monkeypatch, h, w):
         with torch.no_grad():
             flow = net(e1, e2)[1][0].clone()
         return flow, {k: net.stage(k).clone() for k in ("f11", "f12", "f13", "pool_1", "pool_2", "pool_3")}
+    monkeypatch.delenv("EEM_WINO", raising=False)
+    monkeypatch.delenv("EEM_WINO4_LAYERS", raising=False)
+    if form == "f2":
+        monkeypatch.setenv("EEM_WINO", "2")
+    elif form == "f4":
+        monkeypatch.setenv("EEM_WINO4_LAYERS", "7")
     fast_flow, fast = run()
+    monkeypatch.delenv("EEM_WINO4_LAYERS", raising=False)
     monkeypatch.setenv("EEM_WINO", "0")
     monkeypatch.setenv("EEM_NO_ENC1", "1")
     ref_flow, ref = run()

@@ -31,6 +31,7 @@ import torch         # noqa: E402
 
 PEAK_MFMA_F32_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix peak
 PEAK_HBM_GBS = 8000.0            # HBM3E spec peak
+N_CUS = 256
 
 
 def parse():
@@ -231,6 +232,16 @@ def other_rows(dev):
         dt = (time.perf_counter() - t0) / 20
         out["voxelize_2M_events_1280x720_ms"] = round(dt * 1e3, 3)
         out["voxelize_Mevents_per_s"] = round(2.0 / dt, 1)
+        grid2 = torch.empty(5, 720, 1280, device=dev)
+        for nn, key in ((2000000, "voxelize_pair_2x2M_events_ms"), (200000, "voxelize_pair_2x200k_events_ms")):
+            for _ in range(3):
+                _lib.check(L.eemflow_voxelize_pair(feats.data_ptr(), nn, feats.data_ptr(), nn, 5, 720, 1280, 1, grid.data_ptr(), grid2.data_ptr(), sp))
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(20):
+                _lib.check(L.eemflow_voxelize_pair(feats.data_ptr(), nn, feats.data_ptr(), nn, 5, 720, 1280, 1, grid.data_ptr(), grid2.data_ptr(), sp))
+            torch.cuda.synchronize(dev)
+            out[key] = round((time.perf_counter() - t0) / 20 * 1e3, 3)
     except Exception as e:                                   # noqa: BLE001
         out["voxelize_error"] = repr(e)[:200]
     try:
@@ -345,10 +356,9 @@ def latency_and_pipeline_rows(L, _lib, dev, flat, B, H, W, e1, e2, use_graph):
             with torch.cuda.stream(streams[k]):
                 spk = ctypes.c_void_p(streams[k].cuda_stream)
                 if voxelize:
-                    v1 = torch.empty(1, 5, H, W, device=dev)
-                    v2 = torch.empty(1, 5, H, W, device=dev)
-                    _lib.check(L.eemflow_voxelize(evs[0].data_ptr(), nev, 5, H, W, 1, v1.data_ptr(), None, None, spk))
-                    _lib.check(L.eemflow_voxelize(evs[1].data_ptr(), nev, 5, H, W, 1, v2.data_ptr(), None, None, spk))
+                    vv = torch.empty(2, 1, 5, H, W, device=dev)             # both volumes of the sample by one launch sequence
+                    v1, v2 = vv[0], vv[1]
+                    _lib.check(L.eemflow_voxelize_pair(evs[0].data_ptr(), nev, evs[1].data_ptr(), nev, 5, H, W, 1, v1.data_ptr(), v2.data_ptr(), spk))
                 else:
                     v1, v2 = e1, e2
                 fl = torch.empty(1, 2, H, W, device=dev)                     # fresh output tensor every frame
@@ -406,13 +416,31 @@ def baseline_metric():
         return "frames/sec + EPE, EEMFlow 1280\u00d7720 dt1, 1/2/4/8 MI355X"
 
 
+def csrc_sha():
+    """sha256 over the kernel sources (the same digest tools/pmc_traffic.py stamps its measurement with)."""
+    import hashlib
+    root = os.path.join(REPO, "eemflow_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load_traffic():
+    """profiles/pmc_traffic.json - HBM bytes per launch from rocprofv3 PMC passes (tools/profile_gpu.sh).  Quoted only while the kernel
+    sources are the ones it was measured on: after any change to csrc/ the file is stale and `traffic` is null until the passes are
+    re-run."""
     path = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if os.path.exists(path):
         try:
-            return json.load(open(path))
+            t = json.load(open(path))
         except Exception:
             return None
+        if t.get("_meta", {}).get("csrc_sha") != csrc_sha():
+            return {"_stale": True, "_meta": t.get("_meta", {})}
+        return t
     return None
 
 
@@ -611,28 +639,45 @@ def main():
                 sec = k.ms * 1e-3
                 ai = k.flops / max(k.bytes, 1.0)
                 bound = "mfma" if ai >= PEAK_MFMA_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9) else "hbm"
+                # the encoder's kernels are persistent (one workgroup per CU): a launch of fewer than 256 workgroups occupies that many
+                # CUs and leaves the rest to the other frames in flight; chip_us = duration x the share of the chip it holds
+                cus = min(k.blocks, N_CUS) if k.blocks > 0 else N_CUS
                 table.append({"name": k.name.decode(), "us": round(k.ms * 1e3, 2), "gflop": round(k.flops / 1e9, 4),
                               "mbytes": round(k.bytes / 1e6, 3), "bound": bound,
-                              "tflops": round(k.flops / sec / 1e12, 2), "gbs": round(k.bytes / sec / 1e9, 1)})
+                              "tflops": round(k.flops / sec / 1e12, 2), "gbs": round(k.bytes / sec / 1e9, 1),
+                              "workgroups": k.blocks, "cus": cus, "chip_us": round(k.ms * 1e3 * cus / N_CUS, 2)})
             return table
 
         def roofline_of(table):
-            dom = max(table, key=lambda k: k["us"])
+            # dominant kernel = the launch that holds the most of the chip for the longest (duration x CUs occupied); with every kernel
+            # on the full chip this is the longest launch, as before.  achieved / frac are per launch against the WHOLE chip's peak (the
+            # contract's definition); *_on_its_cus is the same against the peak of the CUs the launch occupies
+            dom = max(table, key=lambda k: k["chip_us"])
+            share = dom["cus"] / N_CUS
             if dom["bound"] == "mfma":
                 r = {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(dom["tflops"] / PEAK_MFMA_F32_TFLOPS, 4)}
             else:
                 r = {"bound": "hbm", "achieved": dom["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
                      "frac": round(dom["gbs"] / PEAK_HBM_GBS, 4)}
+            r["cus"] = dom["cus"]
+            r["frac_on_its_cus"] = round(r["frac"] / share, 4) if r["bound"] == "mfma" else None
             tr_all = load_traffic() or {}
             same_shape = tr_all.get("_workload", {"height": 720, "width": 1280, "batch": 1}) == {"height": H, "width": W, "batch": B}
             traffic = tr_all.get(dom["name"]) if same_shape else None        # PMC passes of another shape say nothing here
-            # HBM bytes per launch of the dominant kernel from the PMC passes (profiles/pmc_traffic.json, tools/profile_gpu.sh)
+            # HBM bytes per launch of the dominant kernel from the PMC passes (profiles/pmc_traffic.json, tools/profile_gpu.sh): a
+            # committed measurement, not a counter of this run - stamped with the kernel symbol and commit it was taken on, and
+            # dropped when that symbol is not the one this library launches for the layer (tools/pmc_traffic.py writes both)
+            meta = tr_all.get("_meta", {})
             r["traffic"] = traffic["hbm_bytes"] if isinstance(traffic, dict) and "hbm_bytes" in traffic else None
             r["traffic_detail"] = traffic
+            r["traffic_source"] = ({"file": "profiles/pmc_traffic.json", "commit": meta.get("commit"), "date": meta.get("date"),
+                                    "csrc_sha": meta.get("csrc_sha")} if traffic else
+                                   ("stale: csrc/ changed since profiles/pmc_traffic.json was measured" if tr_all.get("_stale") else None))
             r["algorithmic_bytes"] = round(dom["mbytes"] * 1e6)
             r["kernel"] = dom["name"]
             r["kernel_us"] = dom["us"]
+            r["longest_launch"] = {k2: max(table, key=lambda k: k["us"])[k2] for k2 in ("name", "us", "cus", "tflops")}
             return r
 
         fif = args.frames_in_flight or NS

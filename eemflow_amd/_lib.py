@@ -14,7 +14,7 @@ _c_float_p = ctypes.c_void_p          # device/host pointers travel as integers
 
 class KernelStat(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 48), ("flops", ctypes.c_double), ("bytes", ctypes.c_double),
-                ("ms", ctypes.c_float), ("reserved", ctypes.c_int)]
+                ("ms", ctypes.c_float), ("blocks", ctypes.c_int)]
 
 
 _SIGNATURES = {
@@ -59,6 +59,8 @@ _SIGNATURES = {
                                           ctypes.c_void_p, ctypes.c_void_p]),
     "eemflow_voxelize": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int, _c_float_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "eemflow_voxelize_pair": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_void_p]),
     "eemflow_forward_backward": (ctypes.c_int, [ctypes.c_void_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, _c_float_p,
                                                 _c_float_p, ctypes.POINTER(ctypes.c_double * 5), ctypes.c_void_p]),

@@ -12,6 +12,7 @@
 
 // ------------------------------------------------------------------------------- errors
 static thread_local char g_err[512] = "";
+thread_local int eem_last_grid_blocks = 0, eem_last_grid_threads = 0;
 
 void eem_set_error(const char* fmt, ...) {
     va_list ap;
@@ -479,9 +480,9 @@ extern "C" int eemflow_upsample_bilinear(const float* in, float* out, int nc, in
     return upsample_launch(in, out, nc, h, w, oh, ow, (hipStream_t)stream);
 }
 
-extern "C" int eemflow_voxelize(const double* events, int64_t n, int bins, int h, int w, int normalize, float* grid,
-                                int64_t* idx_left, int64_t* idx_right, void* stream) {
-    EEM_REQUIRE(events && grid, "eemflow_voxelize: NULL argument");
+// njobs = 1 or 2 voxelizations of one grid shape in one launch sequence (voxel.hip)
+static int voxelize_jobs(int njobs, const double* const* events, const int64_t* n, int bins, int h, int w, int normalize, float* const* grid,
+                         int64_t* const* idx_left, int64_t* const* idx_right, void* stream) {
     // scratch arenas (band counters, moments, 16 B per event of vote records), grown on demand and owned by the LIBRARY, not by the
     // calling thread (a loader's worker threads come and go; per-thread arenas were never freed): one per (device, stream) for up to
     // eight streams, so that the voxelizations of frames in flight on different streams do not wait for each other; a ninth stream
@@ -504,7 +505,8 @@ extern "C" int eemflow_voxelize(const double* events, int64_t n, int bins, int h
         ar->stream = stream;
     }
     ar->used = ++tick;
-    const size_t need = voxel_scratch_bytes(n);
+    size_t part[2] = {0, 0}, need = 0;
+    for (int k = 0; k < njobs; ++k) { part[k] = (voxel_scratch_bytes(n[k]) + 255) & ~(size_t)255; need += part[k]; }
     if (ar->p == nullptr || ar->dev != dev || ar->cap < need) {
         if (ar->p) {                                                             // synchronises with work using it
             int cur = dev;
@@ -518,9 +520,27 @@ extern "C" int eemflow_voxelize(const double* events, int64_t n, int bins, int h
         if (!ar->done) EEM_HIP_CHECK(hipEventCreateWithFlags(&ar->done, hipEventDisableTiming));
         ar->dev = dev;
     }
-    void* scratch = ar->p;
+    void* scratch[2] = {ar->p, (char*)ar->p + part[0]};
     hipEvent_t done = ar->done;
-    const int rc = voxel_launch(events, n, bins, h, w, normalize, grid, idx_left, idx_right, scratch, (hipStream_t)stream);
+    const int rc = voxel_launch_jobs(njobs, events, n, bins, h, w, normalize, grid, idx_left, idx_right, scratch, (hipStream_t)stream);
     if (rc == EEM_OK) EEM_HIP_CHECK(hipEventRecord(done, (hipStream_t)stream));
     return rc;
+}
+
+extern "C" int eemflow_voxelize(const double* events, int64_t n, int bins, int h, int w, int normalize, float* grid,
+                                int64_t* idx_left, int64_t* idx_right, void* stream) {
+    EEM_REQUIRE(events && grid, "eemflow_voxelize: NULL argument");
+    return voxelize_jobs(1, &events, &n, bins, h, w, normalize, &grid, &idx_left, &idx_right, stream);
+}
+
+// Both event sets of a sample (loader/HREM.py:226-232: event_volume_old, event_volume_new) in ONE three-launch sequence instead of
+// two: the kernels are latency chains at these sizes (36 us for 2 x 10^5 events), two of them side by side cost little more than one
+extern "C" int eemflow_voxelize_pair(const double* events1, int64_t n1, const double* events2, int64_t n2, int bins, int h, int w,
+                                     int normalize, float* grid1, float* grid2, void* stream) {
+    EEM_REQUIRE(events1 && events2 && grid1 && grid2, "eemflow_voxelize_pair: NULL argument");
+    const double* ev[2] = {events1, events2};
+    const int64_t n[2] = {n1, n2};
+    float* g[2] = {grid1, grid2};
+    int64_t* none[2] = {nullptr, nullptr};
+    return voxelize_jobs(2, ev, n, bins, h, w, normalize, g, none, none, stream);
 }

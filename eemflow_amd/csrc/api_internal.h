@@ -289,6 +289,7 @@ struct Hook {
     template <class F>
     int run(const char* name, double flops, double bytes, F&& launch) {
         if (!timing) return launch(st);
+        eem_last_grid_blocks = eem_last_grid_threads = 0;
         int rc = launch(st);                                  // warm (also keeps data flowing downstream)
         if (rc != EEM_OK) return rc;
         EEM_HIP_CHECK(hipEventRecord(ev0, st));
@@ -302,6 +303,7 @@ struct Hook {
         memset(&ks, 0, sizeof(ks));
         strncpy(ks.name, name, sizeof(ks.name) - 1);
         ks.flops = flops; ks.bytes = bytes; ks.ms = ms / (float)reps;
+        ks.blocks = eem_last_grid_blocks;                     // 0: a launcher that does not report its grid
         stats.push_back(ks);
         return EEM_OK;
     }

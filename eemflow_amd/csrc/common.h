@@ -41,6 +41,11 @@ void eem_set_error(const char* fmt, ...);
 
 __host__ __device__ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// grid of the encoder launch this thread made last (blocks x threads per block): eemflow_time_kernels reports it beside the
+// duration - a kernel that runs on a quarter of the chip by design is not a slow kernel (api.hip defines it)
+extern thread_local int eem_last_grid_blocks, eem_last_grid_threads;
+#define EEM_NOTE_GRID(blocks, threads) do { eem_last_grid_blocks = (int)(blocks); eem_last_grid_threads = (int)(threads); } while (0)
+
 // compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N) - the index is usable as a template /
 // inline-asm immediate inside f
 template <int I, int N, class F>
@@ -283,3 +288,6 @@ int repack_launch(const float* flat, const int* idx, float* arena, long n, hipSt
 int voxel_launch(const double* events, int64_t n, int bins, int h, int w, int normalize, float* grid,
                  int64_t* idx_left, int64_t* idx_right, void* scratch, hipStream_t stream);
 size_t voxel_scratch_bytes(int64_t n);
+// one or two voxelizations of the same grid shape in ONE three-launch sequence (blockIdx.y = job)
+int voxel_launch_jobs(int njobs, const double* const* events, const int64_t* n, int bins, int h, int w, int normalize, float* const* grid,
+                      int64_t* const* idx_left, int64_t* const* idx_right, void* const* scratch, hipStream_t stream);

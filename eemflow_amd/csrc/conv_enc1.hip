@@ -188,6 +188,7 @@ int enc1_launch(const EncConvArgs& a0, hipStream_t stream) {
     static const int env_cap = enc_blocks_per_xcd("E1", 0);     // tuning override
     const int cap = env_cap > 0 ? env_cap : (a.blocks_per_xcd > 0 ? a.blocks_per_xcd : 32);   // default: one resident block per CU
     if (per_xcd > cap) per_xcd = cap;
+    EEM_NOTE_GRID(per_xcd * 8, WAVES * 64);
     hipLaunchKernelGGL((enc1_kernel<TH, TWT, WAVES>), dim3(per_xcd * 8), dim3(WAVES * 64), 0, stream, a);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;

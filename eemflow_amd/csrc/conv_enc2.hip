@@ -455,6 +455,7 @@ int launch2(const EncConvArgs& a0, hipStream_t stream) {
     a.tiles_x = ceil_div(a.wout, C::TW);
     a.tiles_y = ceil_div(a.hout, TH);
     dim3 grid((unsigned)ceil_div(a.tiles_x * a.tiles_y * a.nimg, 8) * 8);
+    EEM_NOTE_GRID(grid.x, WAVES * 64);
     if (POOLK > 0 && a.pool_partial != nullptr && a.pool_k == POOLK)
         hipLaunchKernelGGL((enc_conv2_kernel<CIN, COUT, STRIDE, TH, TWT, WAVES, WM, CK, POOLK>), grid, dim3(WAVES * 64),
                            0, stream, a);

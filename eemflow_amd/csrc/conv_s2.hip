@@ -139,6 +139,7 @@ int s2_launch_t(const EncConvArgs& a0, hipStream_t stream) {
     a.tiles_x = ceil_div(a.wout, C::NPIX);
     a.tiles_y = ceil_div(a.hout, C::TH);
     dim3 grid((unsigned)ceil_div(a.tiles_x * a.tiles_y * a.nimg, 8) * 8);
+    EEM_NOTE_GRID(grid.x, C::WAVES * 64);
     hipLaunchKernelGGL((s2_kernel<CIN, COUT>), grid, dim3(C::WAVES * 64), 0, stream, a);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;

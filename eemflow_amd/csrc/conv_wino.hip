@@ -422,6 +422,7 @@ int wino_launch_c(const EncConvArgs& a0, hipStream_t stream) {
         eem_set_error("wino: fused pooling with k=%d is not built for C=%d", a.pool_k, C);
         return EEM_ERR_ARG;
     }
+    EEM_NOTE_GRID(per_xcd * 8, W::WAVES * 64);
     if (a.pool_partial != nullptr)
         hipLaunchKernelGGL((wino_kernel<C, W::TH, W::TW, W::WAVES, W::POOLK>), dim3(per_xcd * 8), dim3(W::WAVES * 64), 0,
                            stream, a);

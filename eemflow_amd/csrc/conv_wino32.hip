@@ -368,6 +368,7 @@ int launch_c(const EncConvArgs& a0, hipStream_t stream) {
         eem_set_error("wino32: fused pooling with k=%d is not built for C=%d", a.pool_k, C);
         return EEM_ERR_ARG;
     }
+    EEM_NOTE_GRID(per_xcd * 8, W::WAVES * 64);
     if (a.pool_partial != nullptr)
         hipLaunchKernelGGL((wino32_kernel<C, W::TH, W::TW, W::NGH, W::WAVES, W::STREAM, W::POOLK>), dim3(per_xcd * 8), dim3(W::WAVES * 64),
                            0, stream, a);

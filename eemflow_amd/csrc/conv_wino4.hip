@@ -537,6 +537,7 @@ int launch4_c(const EncConvArgs& a0, hipStream_t stream) {
         eem_set_error("wino4: fused pooling with k=%d is not built for C=%d", a.pool_k, C);
         return EEM_ERR_ARG;
     }
+    EEM_NOTE_GRID(per_xcd * 8, 512);
     if (a.pool_partial != nullptr)
         hipLaunchKernelGGL((wino4_kernel<C, W::NGX, W::NGY, W::POOLK>), dim3(per_xcd * 8), dim3(512), 0, stream, a);
     else

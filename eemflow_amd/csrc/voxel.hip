@@ -30,6 +30,8 @@
 // outputs still report them.
 // Grids too large for the LDS band layout (bins * H * W > 1023 * 38400 voxels, bins > 64) and more than 33.5 M events
 // take the direct atomic kernel.
+#include <string.h>
+
 #include "common.h"
 
 #include <algorithm>
@@ -136,15 +138,35 @@ struct VoxPlan {
     int nb;                  // bands
     unsigned hw;             // H * W
 };
+struct VoxSums;
+// One voxelization of a launch: blockIdx.y picks the job, so the two event sets of a sample (loader/HREM.py:226-232) share each of
+// the three launches (same grid shape and plan, their own events, slabs, run tables, moments and grid)
+struct VoxJob {
+    const double* ev;
+    long n;
+    unsigned* run_start;
+    u32x4* recs;
+    long long* idx_left;
+    long long* idx_right;
+    float* grid;
+    VoxSums* acc;
+    int nblk;                // binning blocks (slabs) of this job
+};
+struct VoxJobs { VoxJob j[2]; };
 
 // ------------------------------------------------------------------------------------------------ 1. binning into slabs
 // Block `blk` owns the slab recs[blk * E .. (blk + 1) * E) (E = 1024 * EPT events per block): its votes, sorted by band, and
 // row `blk` of the run table: run_start[blk][b] = offset of band b's run inside the slab, run_start[blk][nb] = its end.
 template <int EPT>
-__global__ __launch_bounds__(VT) void vox_bin_kernel(const double* __restrict__ ev, long n, int bins, int h, int w,
-                                                     VoxPlan pl, unsigned* __restrict__ run_start,
-                                                     u32x4* __restrict__ recs, long long* __restrict__ idx_left,
-                                                     long long* __restrict__ idx_right) {
+__global__ __launch_bounds__(VT) void vox_bin_kernel(VoxJobs jobs, int bins, int h, int w, VoxPlan pl) {
+    const VoxJob& J = jobs.j[blockIdx.y];
+    if ((int)blockIdx.x >= J.nblk) return;                         // the shorter event set of a pair
+    const double* __restrict__ ev = J.ev;
+    const long n = J.n;
+    unsigned* __restrict__ run_start = J.run_start;
+    u32x4* __restrict__ recs = J.recs;
+    long long* __restrict__ idx_left = J.idx_left;
+    long long* __restrict__ idx_right = J.idx_right;
     __shared__ unsigned hist[VT];
     __shared__ unsigned lpos[VT];
     __shared__ unsigned sh[VT / 64];
@@ -264,9 +286,13 @@ __device__ __forceinline__ VoxNorm vox_final(const VoxSums* __restrict__ acc, in
 enum { VOX_BAND_RAW = 0, VOX_BAND_MOMENTS = 1, VOX_BAND_NORMALISED = 2 };
 
 template <int BT>
-__global__ __launch_bounds__(BT) void vox_band_kernel(const u32x4* __restrict__ recs, const unsigned* __restrict__ run_start,
-                                                      int nblk, int slab, int bins, VoxPlan pl, int vec4,
-                                                      float* __restrict__ grid, VoxSums* __restrict__ acc, int mode) {
+__global__ __launch_bounds__(BT) void vox_band_kernel(VoxJobs jobs, int slab, int bins, VoxPlan pl, int vec4, int with_moments, int mode) {
+    const VoxJob& J = jobs.j[blockIdx.y];
+    const u32x4* __restrict__ recs = J.recs;
+    const unsigned* __restrict__ run_start = J.run_start;
+    const int nblk = J.nblk;
+    float* __restrict__ grid = J.grid;
+    VoxSums* __restrict__ acc = with_moments ? J.acc : nullptr;
     extern __shared__ __attribute__((aligned(16))) float band[];   // [bins][band_px]
     __shared__ double sh3[BT / 64 * 3];
     __shared__ unsigned pre[BT + 1];                               // exclusive prefix of the run lengths of <= BT slabs
@@ -344,8 +370,9 @@ __global__ __launch_bounds__(BT) void vox_band_kernel(const u32x4* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------ 4. normalisation
-__global__ __launch_bounds__(VT) void vox_norm_kernel(float* __restrict__ grid, long total, int nsums,
-                                                      const VoxSums* __restrict__ acc) {
+__global__ __launch_bounds__(VT) void vox_norm_kernel(VoxJobs jobs, long total, int nsums) {
+    float* __restrict__ grid = jobs.j[blockIdx.y].grid;
+    const VoxSums* __restrict__ acc = jobs.j[blockIdx.y].acc;
     __shared__ double sh3[VT / 64 * 3];
     const int tid = threadIdx.x;
     // the first NPRE 16-byte pieces of this thread are requested before the sums are known (5 cover 1280x720x5 and
@@ -409,10 +436,8 @@ inline int vox_ept(long n) {
 constexpr long VOX_MAX_BLOCKS = 4096;                              // 33.5 M events at 8 per thread; beyond: direct kernel
 
 template <int EPT>
-void launch_bin(const double* events, long n, int bins, int h, int w, const VoxPlan& pl, unsigned* run_start, u32x4* recs,
-                long long* il, long long* ir, hipStream_t stream) {
-    hipLaunchKernelGGL((vox_bin_kernel<EPT>), dim3((unsigned)vox_blocks(n, EPT)), dim3(VT), 0, stream, events, n, bins, h, w, pl,
-                       run_start, recs, il, ir);
+void launch_bin(const VoxJobs& jobs, int njobs, long nblk_max, int bins, int h, int w, const VoxPlan& pl, hipStream_t stream) {
+    hipLaunchKernelGGL((vox_bin_kernel<EPT>), dim3((unsigned)nblk_max, njobs), dim3(VT), 0, stream, jobs, bins, h, w, pl);
 }
 
 bool make_plan(int64_t n, int bins, int h, int w, const double* events, VoxPlan* pl, int* lds_bytes) {
@@ -447,32 +472,55 @@ size_t voxel_scratch_bytes(int64_t n) {
     return sizeof(VoxScratch) + (size_t)slots * 16 + (size_t)blocks * VT * sizeof(unsigned);
 }
 
-int voxel_launch(const double* events, int64_t n, int bins, int h, int w, int normalize, float* grid,
-                 int64_t* idx_left, int64_t* idx_right, void* scratch, hipStream_t stream) {
-    EEM_REQUIRE(n >= 1, "voxelize: need at least one event (the reference indexes events[-1], "
-                        "loader_utils.py:476), got n=%ld", (long)n);
+// njobs (1 or 2) voxelizations of the same grid shape in one launch sequence; scratch[k] >= voxel_scratch_bytes(n[k]) each
+int voxel_launch_jobs(int njobs, const double* const* events, const int64_t* n, int bins, int h, int w, int normalize, float* const* grid,
+                      int64_t* const* idx_left, int64_t* const* idx_right, void* const* scratch, hipStream_t stream) {
+    EEM_REQUIRE(njobs == 1 || njobs == 2, "voxelize: %d jobs", njobs);
+    for (int k = 0; k < njobs; ++k)
+        EEM_REQUIRE(n[k] >= 1, "voxelize: need at least one event (the reference indexes events[-1], "
+                               "loader_utils.py:476), got n=%ld", (long)n[k]);
     EEM_REQUIRE(bins > 0 && h > 0 && w > 0, "voxelize: bad shape bins=%d h=%d w=%d", bins, h, w);
     const long total = (long)bins * h * w;
-    VoxScratch* sc = (VoxScratch*)scratch;
     VoxPlan pl;
     int lds = 0;
     int nsums = 0;
-    if (make_plan(n, bins, h, w, events, &pl, &lds)) {
+    const int64_t nmax = njobs == 2 && n[1] > n[0] ? n[1] : n[0];
+    bool planned = true;
+    for (int k = 0; k < njobs; ++k) planned = planned && make_plan(n[k], bins, h, w, events[k], &pl, &lds);
+    if (!planned && njobs == 2) {                                      // the direct kernel has no pair form: one after the other
+        for (int k = 0; k < 2; ++k) {
+            const int rc = voxel_launch_jobs(1, events + k, n + k, bins, h, w, normalize, grid + k, idx_left + k, idx_right + k, scratch + k, stream);
+            if (rc != EEM_OK) return rc;
+        }
+        return EEM_OK;
+    }
+    VoxJobs jobs;
+    memset(&jobs, 0, sizeof(jobs));
+    if (planned) {
         static const int ept_env = [] { const char* e = getenv("EEM_VOX_EPT"); return e ? atoi(e) : 0; }();
         int ept = ept_env;
-        if ((ept != 1 && ept != 2 && ept != 4 && ept != 8) || vox_blocks((long)n, ept) > std::max(512L, vox_blocks((long)n, 8) + 1))
-            ept = vox_ept((long)n);                                    // the run table is sized for these block counts
-        const long nblk = vox_blocks((long)n, ept);
-        const long slots = ((long)n + 8191) / 8192 * 8192 + 8192;
-        u32x4* recs = reinterpret_cast<u32x4*>(sc + 1);
-        unsigned* run_start = reinterpret_cast<unsigned*>(recs + slots);
-        long long* il = (long long*)idx_left;
-        long long* ir = (long long*)idx_right;
+        if ((ept != 1 && ept != 2 && ept != 4 && ept != 8) || vox_blocks((long)nmax, ept) > std::max(512L, vox_blocks((long)nmax, 8) + 1))
+            ept = vox_ept((long)nmax);                                 // the run table is sized for these block counts
+        // one EPT for both jobs (the longer set's): the shorter one's slabs are the same size, it just fills fewer of them
+        long nblk_max = 0;
+        for (int k = 0; k < njobs; ++k) {
+            VoxScratch* sc = (VoxScratch*)scratch[k];
+            const long slots = ((long)n[k] + 8191) / 8192 * 8192 + 8192;
+            VoxJob& J = jobs.j[k];
+            J.ev = events[k]; J.n = (long)n[k];
+            J.recs = reinterpret_cast<u32x4*>(sc + 1);
+            J.run_start = reinterpret_cast<unsigned*>(J.recs + slots);
+            J.idx_left = (long long*)idx_left[k]; J.idx_right = (long long*)idx_right[k];
+            J.grid = grid[k]; J.acc = sc->acc;
+            J.nblk = (int)vox_blocks((long)n[k], ept);
+            EEM_REQUIRE((long)J.nblk * VT * ept <= slots, "voxelize: slab budget (n=%ld, ept=%d)", (long)n[k], ept);
+            nblk_max = std::max(nblk_max, (long)J.nblk);
+        }
         switch (ept) {
-            case 1: launch_bin<1>(events, (long)n, bins, h, w, pl, run_start, recs, il, ir, stream); break;
-            case 2: launch_bin<2>(events, (long)n, bins, h, w, pl, run_start, recs, il, ir, stream); break;
-            case 4: launch_bin<4>(events, (long)n, bins, h, w, pl, run_start, recs, il, ir, stream); break;
-            default: launch_bin<8>(events, (long)n, bins, h, w, pl, run_start, recs, il, ir, stream); break;
+            case 1: launch_bin<1>(jobs, njobs, nblk_max, bins, h, w, pl, stream); break;
+            case 2: launch_bin<2>(jobs, njobs, nblk_max, bins, h, w, pl, stream); break;
+            case 4: launch_bin<4>(jobs, njobs, nblk_max, bins, h, w, pl, stream); break;
+            default: launch_bin<8>(jobs, njobs, nblk_max, bins, h, w, pl, stream); break;
         }
         if (lds > 64 * 1024 - 12 * 1024) {
             static thread_local int raised = 0;
@@ -481,42 +529,50 @@ int voxel_launch(const double* events, int64_t n, int bins, int h, int w, int no
                 raised = lds;
             }
         }
-        const int vec4 = (pl.band_px % 4 == 0 && pl.hw % 4 == 0 && ((uintptr_t)grid & 15) == 0) ? 1 : 0;
+        bool aligned = true;
+        for (int k = 0; k < njobs; ++k) aligned = aligned && ((uintptr_t)grid[k] & 15) == 0;
+        const int vec4 = (pl.band_px % 4 == 0 && pl.hw % 4 == 0 && aligned) ? 1 : 0;
         // Few events per voxel: accumulating the bands twice (16 B per vote from L2 / HBM each time) is cheaper than the normalisation's
         // read + write of the whole grid - a moments-only launch, then a launch that stores the bands already normalised
         const char* tp = getenv("EEM_VOX_TWOPASS");                  // read per call: the tests run both forms in one process
         const long two_pass_ratio = tp ? atol(tp) : 0L;
-        auto band = [&](VoxSums* acc, int mode) {
+        auto band = [&](int with_moments, int mode) {
             if (lds <= 24 * 1024)
-                hipLaunchKernelGGL(vox_band_kernel<256>, dim3(pl.nb), dim3(256), lds, stream, recs, run_start, (int)nblk, VT * ept, bins, pl, vec4,
-                                   grid, acc, mode);
+                hipLaunchKernelGGL(vox_band_kernel<256>, dim3(pl.nb, njobs), dim3(256), lds, stream, jobs, VT * ept, bins, pl, vec4, with_moments, mode);
             else
-                hipLaunchKernelGGL(vox_band_kernel<VT>, dim3(pl.nb), dim3(VT), lds, stream, recs, run_start, (int)nblk, VT * ept, bins, pl, vec4,
-                                   grid, acc, mode);
+                hipLaunchKernelGGL(vox_band_kernel<VT>, dim3(pl.nb, njobs), dim3(VT), lds, stream, jobs, VT * ept, bins, pl, vec4, with_moments, mode);
         };
-        if (normalize && two_pass_ratio > 0 && (long)n * two_pass_ratio <= total) {
-            band(sc->acc, (int)VOX_BAND_MOMENTS);
-            band(sc->acc, (int)VOX_BAND_NORMALISED);
+        if (normalize && two_pass_ratio > 0 && (long)nmax * two_pass_ratio <= total) {
+            band(1, (int)VOX_BAND_MOMENTS);
+            band(1, (int)VOX_BAND_NORMALISED);
             EEM_HIP_CHECK(hipGetLastError());
             return EEM_OK;
         }
-        band(normalize ? sc->acc : (VoxSums*)nullptr, (int)VOX_BAND_RAW);
+        band(normalize ? 1 : 0, (int)VOX_BAND_RAW);
         nsums = pl.nb;
     } else {
-        EEM_HIP_CHECK(hipMemsetAsync(grid, 0, total * sizeof(float), stream));
-        hipLaunchKernelGGL(voxel_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, events,
-                           (long)n, bins, h, w, grid, (long long*)idx_left, (long long*)idx_right);
+        VoxScratch* sc = (VoxScratch*)scratch[0];
+        jobs.j[0].grid = grid[0]; jobs.j[0].acc = sc->acc;
+        EEM_HIP_CHECK(hipMemsetAsync(grid[0], 0, total * sizeof(float), stream));
+        hipLaunchKernelGGL(voxel_scatter_kernel, dim3((unsigned)((n[0] + 255) / 256)), dim3(256), 0, stream, events[0],
+                           (long)n[0], bins, h, w, grid[0], (long long*)idx_left[0], (long long*)idx_right[0]);
         if (normalize) {
             nsums = (int)((total + 4095) / 4096 < 512 ? (total + 4095) / 4096 : 512);
-            hipLaunchKernelGGL(vox_moments_kernel, dim3(nsums), dim3(VT), 0, stream, grid, total, sc->acc);
+            hipLaunchKernelGGL(vox_moments_kernel, dim3(nsums), dim3(VT), 0, stream, grid[0], total, sc->acc);
         }
     }
     EEM_HIP_CHECK(hipGetLastError());
     if (normalize) {
         long blocks = (total / 4 + VT - 1) / VT;
         blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);   // one block per CU: the sums are re-added once per block
-        hipLaunchKernelGGL(vox_norm_kernel, dim3((unsigned)blocks), dim3(VT), 0, stream, grid, total, nsums, sc->acc);
+        if (njobs == 2 && blocks > 128) blocks = 128;              // the pair shares the chip
+        hipLaunchKernelGGL(vox_norm_kernel, dim3((unsigned)blocks, njobs), dim3(VT), 0, stream, jobs, total, nsums);
         EEM_HIP_CHECK(hipGetLastError());
     }
     return EEM_OK;
+}
+
+int voxel_launch(const double* events, int64_t n, int bins, int h, int w, int normalize, float* grid,
+                 int64_t* idx_left, int64_t* idx_right, void* scratch, hipStream_t stream) {
+    return voxel_launch_jobs(1, &events, &n, bins, h, w, normalize, &grid, &idx_left, &idx_right, &scratch, stream);
 }

@@ -190,11 +190,9 @@ class HREMEventFlow(torch.utils.data.Dataset):
                'fflow': torch.from_numpy(np.ascontiguousarray(fflow.transpose(2, 0, 1))),
                'valid': None}
         params = {'height': self.image_height, 'width': self.image_width}
-        vols = []
-        for key in ('event0', 'event1'):
-            ev = EventSequence(None, params, features=get_compressed_events(sample[key]), timestamp_multiplier=1e6,
-                               convert_to_relative=True)
-            vols.append(self.voxel(ev))
+        seqs = [EventSequence(None, params, features=get_compressed_events(sample[key]), timestamp_multiplier=1e6,
+                              convert_to_relative=True) for key in ('event0', 'event1')]
+        vols = self.voxel.pair(seqs[0], seqs[1])                  # both volumes in one three-launch sequence
         old, new = (v.cpu() for v in vols) if self.to_cpu else vols
         out['event_volume_old'], out['event_volume_new'] = old, new
         out['event_valid'] = old.sum(dim=0).unsqueeze(0)

@@ -153,8 +153,7 @@ class MvsecEventFlow(torch.utils.data.Dataset):
         n = len(self.event_list)
         old = self._sequence([self.event_list[idx + i] for i in range(k)])                      # MVSEC.py:119,247
         new = self._sequence([self.event_list[(idx + i + 1) % n] for i in range(k)])            # :120,251
-        vol_new = self.voxel(new)
-        vol_old = self.voxel(old)
+        vol_old, vol_new = self.voxel.pair(old, new)              # both volumes in one three-launch sequence
         if self.to_cpu:
             vol_new, vol_old = vol_new.cpu(), vol_old.cpu()
         out['event_volume_new'] = out['d_event_volume_new'] = vol_new

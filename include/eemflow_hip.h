@@ -90,7 +90,8 @@ typedef struct eemflow_kernel_stat {
     double flops;
     double bytes;
     float ms;
-    int reserved;
+    int blocks;      /* workgroups of the launch (0: not reported): the encoder's kernels are persistent, one workgroup per CU,
+                        so blocks < 256 means the launch occupies that many of the 256 CUs */
 } eemflow_kernel_stat;
 int eemflow_time_kernels(eemflow_ctx* ctx, const float* events1, const float* events2, int batch, int in_h,
                          int in_w, float* flow_out, int out_h, int out_w, int reps, eemflow_kernel_stat* stats,
@@ -134,6 +135,12 @@ int eemflow_flow_error(const float* flow_gt, const float* flow_pred, const float
  * Replaces: EventSequenceToVoxelGrid_Pytorch.__call__  (loader/loader_utils.py:447-537). */
 int eemflow_voxelize(const double* events, int64_t n, int bins, int h, int w, int normalize, float* grid,
                      int64_t* idx_left, int64_t* idx_right, void* stream);
+
+/* The two event volumes of a sample (event_volume_old, event_volume_new) in ONE three-launch sequence: the same grids as two
+ * eemflow_voxelize calls, bit for bit.
+ * Replaces: the two EventSequenceToVoxelGrid_Pytorch calls of a dataset sample  (loader/HREM.py:226-232, loader/MVSEC.py:166-177). */
+int eemflow_voxelize_pair(const double* events1, int64_t n1, const double* events2, int64_t n2, int bins, int h, int w,
+                          int normalize, float* grid1, float* grid2, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Training step of EEMFlow (train_mvsec.py:229-258).  Weights live on the device in state_dict order; one

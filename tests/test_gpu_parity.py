@@ -462,6 +462,31 @@ def test_voxelizer_alternating_streams_share_the_scratch_safely(nstreams):
         np.testing.assert_allclose(g.cpu().numpy(), refs[k], atol=3e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("h,w,n1,n2", [(260, 346, 40_000, 61_000), (720, 1280, 200_000, 1_300_000), (720, 1280, 2_000_000, 3), (64, 64, 1, 500)])
+def test_voxelizer_pair_equals_two_single_calls(monkeypatch, h, w, n1, n2):
+    """eemflow_voxelize_pair (both volumes of a sample, one launch sequence; loader/HREM.py:226-232) against two eemflow_voxelize
+    calls (normalised and raw): the same grids up to the order of the float adds inside a band (LDS atomics: not bitwise repeatable
+    between two single calls either), also when the direct atomic kernel is forced (EEM_VOX_DIRECT=1: the pair then runs as two
+    sequences), and against the oracle."""
+    from eemflow_amd.voxelizer import voxelize_device, voxelize_pair_device
+    bins = 5
+    ev = [torch.from_numpy(np.ascontiguousarray(EventSequence(None, {"height": h, "width": w}, features=_clustered_events(300 + k, n, h, w),
+                                                              timestamp_multiplier=1e6, convert_to_relative=True).features)).to(DEV)
+          for k, n in enumerate((n1, n2))]
+    for normalize in (True, False):
+        singles = [voxelize_device(e, bins, h, w, normalize) for e in ev]
+        pair = voxelize_pair_device(ev[0], ev[1], bins, h, w, normalize)
+        for k in (0, 1):
+            assert (pair[k] != 0).sum() == (singles[k] != 0).sum()
+            assert maxerr(pair[k], singles[k]) < 2e-5 * max(1.0, float(singles[k].abs().max()))
+    if n1 + n2 < 400_000:
+        ref = O.voxelize(ev[1].cpu().numpy(), bins, h, w, normalize=True)
+        np.testing.assert_allclose(voxelize_pair_device(ev[0], ev[1], bins, h, w, True)[1].cpu().numpy(), ref, atol=3e-5, rtol=1e-5)
+    monkeypatch.setenv("EEM_VOX_DIRECT", "1")
+    direct = voxelize_pair_device(ev[0], ev[1], bins, h, w, True)
+    assert maxerr(direct[0], voxelize_device(ev[0], bins, h, w, True)) < 2e-4 and maxerr(direct[1], voxelize_device(ev[1], bins, h, w, True)) < 2e-4
+
+
 def test_errors_are_loud():
     net, _ = make_net(1)
     with pytest.raises(AttributeError):

@@ -29,12 +29,25 @@ def load(d, counter):
         if m:
             agg[(m.group(1), m.group(2))].append(float(r["Counter_Value"]))
             continue
-        m = re.search(r"wino(?:32)?_kernel<(\d+),", k)          # Winograd C -> C layers
+        m = re.search(r"wino(?:32|4)?_kernel<(\d+),", k)        # Winograd C -> C layers (either form)
         if m:
             agg[(m.group(1), m.group(1))].append(float(r["Counter_Value"]))
         elif "enc1_kernel" in k:                                 # pconv1_1 with 16-byte DMA
             agg[("5", "16")].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}
+
+
+def csrc_sha():
+    """sha256 over the kernel sources: bench.py quotes these numbers only for the sources they were measured on."""
+    import hashlib
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "eemflow_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -51,6 +64,11 @@ def main():
     # quotes these numbers when it runs that shape
     res["_workload"] = {"height": int(sys.argv[3]) if len(sys.argv) > 3 else 720, "width": int(sys.argv[4]) if len(sys.argv) > 4 else 1280,
                         "batch": int(sys.argv[5]) if len(sys.argv) > 5 else 1}
+    import datetime
+    import os
+    res["_meta"] = {"csrc_sha": csrc_sha(), "commit": os.environ.get("EEM_COMMIT", "unknown"),
+                    "date": datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%dT%H:%MZ"),
+                    "command": "bench.py --steps 5 --warmup 2 --no-graph --streams 1 --frames-in-flight 4 under rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE"}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 

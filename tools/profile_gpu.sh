@@ -13,6 +13,6 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY
   t=$(echo $pass | cut -d" " -f1)
   timeout 300 rocprofv3 --pmc $pass --output-format csv -d $out/pmc/$t -- python3 bench.py --steps 5 --warmup 2 --cpu-seconds 0 --no-graph --streams 1 --frames-in-flight 4 --kernel-reps 3 --no-other-rows --no-side-rows > /dev/null 2> $out/pmc_$t.err
 done
-python3 tools/pmc_traffic.py $out/pmc $out/pmc_traffic.json > /dev/null
+EEM_COMMIT=${EEM_COMMIT:-unknown} python3 tools/pmc_traffic.py $out/pmc $out/pmc_traffic.json > /dev/null
 find $out -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
 ls $out

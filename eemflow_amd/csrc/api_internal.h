@@ -286,8 +286,24 @@ struct Hook {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<eemflow_kernel_stat> stats;
 
+    // diagnostic (EEM_SKIP_KERNELS="enc.pconv2_1;dec."): launches whose name starts with one of the prefixes are skipped - the flow is
+    // garbage, the frame rate says what that launch costs BESIDE the others (tools/marginal.sh); read once per process
+    static bool skipped(const char* name) {
+        static const std::string list = [] { const char* e = getenv("EEM_SKIP_KERNELS"); return std::string(e ? e : ""); }();
+        if (list.empty()) return false;
+        size_t pos = 0;
+        while (pos <= list.size()) {
+            size_t end = list.find(';', pos);
+            if (end == std::string::npos) end = list.size();
+            if (end > pos && strncmp(name, list.c_str() + pos, end - pos) == 0) return true;
+            pos = end + 1;
+        }
+        return false;
+    }
+
     template <class F>
     int run(const char* name, double flops, double bytes, F&& launch) {
+        if (skipped(name)) return EEM_OK;
         if (!timing) return launch(st);
         eem_last_grid_blocks = eem_last_grid_threads = 0;
         int rc = launch(st);                                  // warm (also keeps data flowing downstream)

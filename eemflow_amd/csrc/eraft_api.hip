@@ -56,11 +56,12 @@ struct eraft_ctx {
     Layer convc1, convc2, convf1, convf2, conv, gz[2], gr[2], gq[2], fh1, fh2, mk0, mk2;
     Layer gzr[2], heads1;          // z | r of a GRU pass and flow-head | mask-head conv1 as ONE launch each (small batches)
     // workspace
-    Buf padded, s[5], fmap, net[2], inp, pyr[4], c0, c1, corr, cor1, corflo, flo1, motion, z, rh, fhid, delta, mhid, mask;
+    Buf padded, s[5], fmap, net[2], inp, pyr[4], c0, c1, c1b, corr, cor1, corflo, flo1, motion, z, rh, fhid, delta, mhid, mask;
     Buf st_corr0, st_net1, st_mask1, st_delta1, zeros;
     int B = 0, h8 = 0, w8 = 0, ph[4] = {0, 0, 0, 0}, pw[4] = {0, 0, 0, 0};
     bool have_last = false;
     bool keep_stages = false;      // copy corr0 / net1 / mask1 / delta1 aside in the first iteration (parity tests)
+    const float* c1last = nullptr;   // coords1 after the last iteration of the last forward (c1 or c1b)
     int frames_in_flight = 1;      // eraft_set_frames_in_flight
     double* nstat = nullptr;       // per-chunk sums of the large-plane instance norm (er_instnorm_launch)
     size_t nstat_cap = 0;
@@ -277,8 +278,15 @@ int build_feature_pyramid(eraft_ctx* c, const float* f2, int batch, int ch, int 
     return EEM_OK;
 }
 
-int run_lookup(eraft_ctx* c, const float* coords, float* out, int out_ctotal, int batch, int h, int w, hipStream_t st) {
+// flow_dst (optional): the lookup launch also writes flow = coords - flow_c0 there (resident-volume form; the on-the-fly form
+// keeps the separate launch)
+int run_lookup(eraft_ctx* c, const float* coords, float* out, int out_ctotal, int batch, int h, int w, hipStream_t st,
+               const float* flow_c0 = nullptr, float* flow_dst = nullptr, int flow_ctotal = 0, int flow_coff = 0) {
     if (c->alt_corr) {
+        if (flow_dst) {
+            const int rcf = er_flow_launch(flow_c0, coords, flow_dst, flow_ctotal, flow_coff, batch, h * w, st);
+            if (rcf != EEM_OK) return rcf;
+        }
         AltCorrArgs aa;
         const size_t g = (size_t)h * w;
         aa.f1 = c->fmap.p;
@@ -292,6 +300,7 @@ int run_lookup(eraft_ctx* c, const float* coords, float* out, int out_ctotal, in
     LookupArgs la;
     for (int l = 0; l < 4; ++l) { la.pyr[l] = c->pyr[l].p; la.ph[l] = c->ph[l]; la.pw[l] = c->pw[l]; }
     la.coords = coords; la.out = out; la.batch = batch; la.h = h; la.w = w; la.out_ctotal = out_ctotal;
+    la.coords0 = flow_c0; la.flow_dst = flow_dst; la.flow_ctotal = flow_ctotal; la.flow_coff = flow_coff;
     return er_lookup_launch(la, st);
 }
 
@@ -317,7 +326,7 @@ extern "C" void eraft_destroy(eraft_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     Buf* all[] = {&c->padded, &c->s[0], &c->s[1], &c->s[2], &c->s[3], &c->s[4], &c->fmap, &c->net[0], &c->net[1], &c->inp,
-                  &c->pyr[0], &c->pyr[1], &c->pyr[2], &c->pyr[3], &c->c0, &c->c1, &c->corr, &c->cor1, &c->corflo, &c->flo1,
+                  &c->pyr[0], &c->pyr[1], &c->pyr[2], &c->pyr[3], &c->c0, &c->c1, &c->c1b, &c->corr, &c->cor1, &c->corflo, &c->flo1,
                   &c->motion, &c->z, &c->rh, &c->fhid, &c->delta, &c->mhid, &c->mask, &c->st_corr0, &c->st_net1, &c->st_mask1,
                   &c->st_delta1, &c->zeros, &c->f2l[0], &c->f2l[1], &c->f2l[2]};
     for (Buf* b : all) if (b->p) (void)hipFree(b->p);
@@ -427,7 +436,7 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
     }
     ENS(c->fmap, (size_t)2 * B * 256 * g);
     ENS(c->net[0], B * 128 * g); ENS(c->net[1], B * 128 * g); ENS(c->inp, B * 128 * g);
-    ENS(c->c0, B * 2 * g); ENS(c->c1, B * 2 * g); ENS(c->corr, B * kCorrPad * g); ENS(c->cor1, B * 256 * g);
+    ENS(c->c0, B * 2 * g); ENS(c->c1, B * 2 * g); ENS(c->c1b, B * 2 * g); ENS(c->corr, B * kCorrPad * g); ENS(c->cor1, B * 256 * g);
     ENS(c->corflo, B * 256 * g); ENS(c->flo1, B * 128 * g); ENS(c->motion, B * 128 * g); ENS(c->z, B * 256 * g);
     ENS(c->rh, B * 128 * g); ENS(c->fhid, B * 512 * g); ENS(c->delta, B * 2 * g); ENS(c->mhid, B * 256 * g);
     ENS(c->mask, B * 576 * g);
@@ -469,8 +478,20 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
     for (int it = 0; it < iters; ++it) {
         float* net = c->net[cur].p;
         float* netn = c->net[cur ^ 1].p;
-        if ((rc = run_lookup(c, c->c1.p, c->corr.p, kCorrPad, B, h8, w8, st)) != EEM_OK) return rc;          // :142
-        if ((rc = er_flow_launch(c->c0.p, c->c1.p, c->motion.p, 128, 126, B, (int)g, st)) != EEM_OK) return rc;  // :144, update.py:81
+        // coords1 lives in two buffers: iteration `it` reads c1[it & 1], the convex-upsampling launch at its end writes the updated
+        // coordinates into the other one
+        // EEM_ERAFT_NO_FUSE=1 (read per forward): the separate flow / coords1 += delta launches, for A/B runs and the equality test
+        const char* enf = getenv("EEM_ERAFT_NO_FUSE");
+        const bool fuse_small = !(enf && enf[0] == '1');
+        float* c1cur = (fuse_small && (it & 1)) ? c->c1b.p : c->c1.p;
+        float* c1nxt = (fuse_small && !(it & 1)) ? c->c1b.p : c->c1.p;
+        // :142 lookup; :144 flow = coords1 - coords0 into the motion features' last two channels (update.py:81), by the same launch
+        if (fuse_small) {
+            if ((rc = run_lookup(c, c1cur, c->corr.p, kCorrPad, B, h8, w8, st, c->c0.p, c->motion.p, 128, 126)) != EEM_OK) return rc;
+        } else {
+            if ((rc = run_lookup(c, c1cur, c->corr.p, kCorrPad, B, h8, w8, st)) != EEM_OK) return rc;
+            if ((rc = er_flow_launch(c->c0.p, c1cur, c->motion.p, 128, 126, B, (int)g, st)) != EEM_OK) return rc;
+        }
         // motion encoder (model/update.py:73-81)
         // the 324 correlation features live in a 336-channel buffer (12 zero channels, zero weight columns) so that the
         // 1x1 conv qualifies for the 16-aligned LDS-tiled kernel; the generic kernel reads the first 324
@@ -545,9 +566,15 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
         set_seg(a, 0, mh, 256, head_ct, mh_off);
         a.out_scale = 0.25f;
         if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
-        if ((rc = er_axpy_launch(c->c1.p, c->delta.p, (long)B * 2 * g, st)) != EEM_OK) return rc;              // :149
-        if ((rc = er_convex_up_launch(c->c0.p, c->c1.p, c->mask.p, out + (size_t)it * B * 2 * in_h * in_w, B, h8, w8, pad[2],
-                                      pad[0], in_h, in_w, st)) != EEM_OK) return rc;                          // :155-157
+        // :149 coords1 = coords1 + delta_flow and :155-157 the convex upsampling of coords1 - coords0, one launch
+        if (fuse_small) {
+            if ((rc = er_convex_up_launch(c->c0.p, c1cur, c->mask.p, out + (size_t)it * B * 2 * in_h * in_w, B, h8, w8, pad[2],
+                                          pad[0], in_h, in_w, st, c->delta.p, c1nxt)) != EEM_OK) return rc;
+        } else {
+            if ((rc = er_axpy_launch(c->c1.p, c->delta.p, (long)B * 2 * g, st)) != EEM_OK) return rc;
+            if ((rc = er_convex_up_launch(c->c0.p, c->c1.p, c->mask.p, out + (size_t)it * B * 2 * in_h * in_w, B, h8, w8, pad[2],
+                                          pad[0], in_h, in_w, st)) != EEM_OK) return rc;
+        }
         if (it == 0 && c->keep_stages) {
             EEM_HIP_CHECK(hipMemcpy2DAsync(c->st_corr0.p, 324 * g * 4, c->corr.p, kCorrPad * g * 4, 324 * g * 4, B,
                                            hipMemcpyDeviceToDevice, st));
@@ -556,6 +583,10 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
             EEM_HIP_CHECK(hipMemcpyAsync(c->st_delta1.p, c->delta.p, B * 2 * g * 4, hipMemcpyDeviceToDevice, st));
         }
         (void)cur;
+    }
+    {
+        const char* enf = getenv("EEM_ERAFT_NO_FUSE");
+        c->c1last = (!(enf && enf[0] == '1') && (iters & 1)) ? c->c1b.p : c->c1.p;
     }
     c->B = B; c->h8 = h8; c->w8 = w8; c->have_last = true;
     c->stages_valid = c->keep_stages;
@@ -610,7 +641,7 @@ extern "C" int eraft_get_stage(eraft_ctx* c, const char* name, float* dst, size_
     if (dst == nullptr) return EEM_OK;
     EEM_REQUIRE(cap >= n, "eraft_get_stage: '%s' needs %zu floats, buffer holds %zu", name, n, cap);
     if (nm == "flow_low") {
-        int rc = er_flow_launch(c->c0.p, c->c1.p, dst, 2, 0, c->B, c->h8 * c->w8, (hipStream_t)stream);
+        int rc = er_flow_launch(c->c0.p, c->c1last, dst, 2, 0, c->B, c->h8 * c->w8, (hipStream_t)stream);
         return rc;
     }
     EEM_HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));

@@ -28,6 +28,11 @@ struct LookupArgs {
     const float* coords;   // [B][2][H][W]
     float* out;            // [B][out_ctotal][H][W], channels 0..323 are written
     int batch, h, w, out_ctotal;
+    // optional: the level-0 blocks also write flow = coords - coords0 into channels [flow_coff, flow_coff + 2) of flow_dst
+    // (model/eraft.py:144 and the motion encoder's cat([out, flow]), model/update.py:81) - saves the separate launch
+    const float* coords0 = nullptr;
+    float* flow_dst = nullptr;
+    int flow_ctotal = 0, flow_coff = 0;
 };
 int er_lookup_launch(const LookupArgs& a, hipStream_t st);
 
@@ -54,5 +59,8 @@ int er_mul_channels_launch(float* out, const float* a, int a_ctotal, int a_coff,
 
 // convex upsampling (model/eraft.py:83-94) of flow = coords1 - coords0 with mask [B][576][H][W], written
 // unpadded: out[b][c][Y - top][X - left] for the (8H x 8W) result cropped to [oh][ow]
+// delta / coords1_next (optional, both or neither): the flow that is upsampled is coords1 + delta - coords0 and the updated
+// coordinates coords1 + delta (model/eraft.py:149) are written to coords1_next (a buffer other than coords1: neighbouring threads
+// still read the old values) - saves the separate coords1 += delta launch
 int er_convex_up_launch(const float* coords0, const float* coords1, const float* mask, float* out, int batch, int h, int w,
-                        int top, int left, int oh, int ow, hipStream_t st);
+                        int top, int left, int oh, int ow, hipStream_t st, const float* delta = nullptr, float* coords1_next = nullptr);

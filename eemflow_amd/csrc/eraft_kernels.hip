@@ -333,6 +333,8 @@ __global__ __launch_bounds__(256) void lookup_kernel(LookupArgs a) {
     const float y = cy / sc + (float)(jj - 4);
     const float* img = a.pyr[lvl] + ((size_t)b * hw + p) * a.ph[lvl] * a.pw[lvl];
     a.out[((size_t)b * a.out_ctotal + ch) * hw + p] = sample_bilinear(img, a.ph[lvl], a.pw[lvl], x, y);
+    if (a.flow_dst != nullptr && ch < 2)
+        a.flow_dst[((size_t)b * a.flow_ctotal + a.flow_coff + ch) * hw + p] = (ch ? cy : cx) - a.coords0[((size_t)b * 2 + ch) * hw + p];
 }
 
 // The same lookup with both sides coalesced.  lookup_kernel above gives consecutive lanes consecutive PIXELS: its stores are
@@ -353,6 +355,11 @@ __global__ __launch_bounds__(256) void lookup_tiled_kernel(LookupArgs a) {
         cys[tid] = a.coords[((size_t)b * 2 + 1) * hw + p];
     }
     __syncthreads();
+    if (a.flow_dst != nullptr && lvl == 0 && tid < 2 * npx) {           // flow = coords1 - coords0 of this block's pixels
+        const int ch = tid >= npx ? 1 : 0, px = tid - ch * npx;
+        const float c1v = ch ? cys[px] : cxs[px];
+        a.flow_dst[((size_t)b * a.flow_ctotal + a.flow_coff + ch) * hw + p0 + px] = c1v - a.coords0[((size_t)b * 2 + ch) * hw + p0 + px];
+    }
     const float inv = 1.f / (float)(1 << lvl);
     const int ph = a.ph[lvl], pw = a.pw[lvl];
     const float* maps = a.pyr[lvl] + ((size_t)b * hw + p0) * ph * pw;
@@ -465,9 +472,14 @@ __global__ __launch_bounds__(256) void mul_channels_kernel(float* __restrict__ o
 // convex combination of the 3x3 neighbourhood of 8*flow (zero outside, F.unfold padding=1)
 __global__ __launch_bounds__(256) void convex_up_kernel(const float* __restrict__ c0, const float* __restrict__ c1,
                                                         const float* __restrict__ mask, float* __restrict__ out, int batch,
-                                                        int h, int w, int top, int left, int oh, int ow) {
+                                                        int h, int w, int top, int left, int oh, int ow,
+                                                        const float* __restrict__ delta, float* __restrict__ c1n) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)batch * oh * ow) return;
+    if (idx >= (long)batch * oh * ow) {                                  // the launch's tail: coords1_next = coords1 + delta, every cell
+        const long e = idx - (long)batch * oh * ow;                       // (cells of the padding have no output pixel of their own)
+        if (c1n != nullptr && e < (long)batch * 2 * h * w) c1n[e] = c1[e] + delta[e];
+        return;
+    }
     const int X = idx % ow + left, Y = (idx / ow) % oh + top;
     const int b = idx / ((long)ow * oh);
     const int x = X >> 3, y = Y >> 3, sx = X & 7, sy = Y & 7;
@@ -486,8 +498,11 @@ __global__ __launch_bounds__(256) void convex_up_kernel(const float* __restrict_
         if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
             const size_t q = (size_t)b * 2 * hw + yy * w + xx;
             const float wgt = lg[k] / den;
-            u += wgt * (8.f * (c1[q] - c0[q]));
-            v += wgt * (8.f * (c1[q + hw] - c0[q + hw]));
+            // (c1 + delta) - c0: the sum first, as coords1 = coords1 + delta_flow then coords1 - coords0 (model/eraft.py:149,152)
+            const float fx = delta ? (c1[q] + delta[q]) - c0[q] : c1[q] - c0[q];
+            const float fy = delta ? (c1[q + hw] + delta[q + hw]) - c0[q + hw] : c1[q + hw] - c0[q + hw];
+            u += wgt * (8.f * fx);
+            v += wgt * (8.f * fy);
         }
     }
     const size_t o = (size_t)b * 2 * oh * ow + (size_t)(Y - top) * ow + (X - left);
@@ -587,9 +602,10 @@ int er_mul_channels_launch(float* out, const float* a, int a_ctotal, int a_coff,
 }
 
 int er_convex_up_launch(const float* c0, const float* c1, const float* mask, float* out, int batch, int h, int w, int top,
-                        int left, int oh, int ow, hipStream_t st) {
-    hipLaunchKernelGGL(convex_up_kernel, dim3(blocks((long)batch * oh * ow)), dim3(256), 0, st, c0, c1, mask, out, batch, h, w, top,
-                       left, oh, ow);
+                        int left, int oh, int ow, hipStream_t st, const float* delta, float* c1n) {
+    EEM_REQUIRE((delta == nullptr) == (c1n == nullptr) && (c1n == nullptr || c1n != c1), "er_convex_up_launch: delta and coords1_next come together");
+    hipLaunchKernelGGL(convex_up_kernel, dim3(blocks((long)batch * oh * ow + (c1n ? (long)batch * 2 * h * w : 0L))), dim3(256), 0, st, c0, c1,
+                       mask, out, batch, h, w, top, left, oh, ow, delta, c1n);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

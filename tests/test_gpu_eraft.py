@@ -166,6 +166,26 @@ def test_frames_in_flight_hint_changes_tiles_not_results():
     assert maxerr(many, one) < 2e-4 and float(one.abs().max()) > 1e-3
 
 
+@pytest.mark.parametrize("b,h,w,iters", [(2, 136, 200, 5), (1, 480, 640, 4)])
+def test_fused_small_launches_equal_the_separate_ones(monkeypatch, b, h, w, iters):
+    """flow = coords1 - coords0 written by the lookup launch and coords1 += delta_flow carried by the convex-upsampling launch
+    (coords1 alternating between two buffers) against the separate flow / axpy launches (EEM_ERAFT_NO_FUSE=1, read per forward): the
+    same additions and subtractions in the same order - every prediction bitwise the same, at a padded size (cells of the padding
+    have no output pixel) and for odd and even iteration counts; the low-resolution flow (coords1 of the last iteration) too."""
+    net, _ = make_net(61)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(62, b, h, w))
+    outs = []
+    for off in ("0", "1"):
+        monkeypatch.setenv("EEM_ERAFT_NO_FUSE", off)
+        with torch.no_grad():
+            preds = torch.stack(net(e1, e2, iters=iters)[1]).clone()
+            low = net.stage("flow_low").clone()
+        outs.append((preds, low))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][0].abs().max()) > 1e-3
+
+
 def test_flow_init_and_twelve_iterations():
     h, w = 128, 128
     net, sd = make_net(19)

@@ -1,0 +1,14 @@
+#!/bin/bash
+# GPU box: what each launch of the frame costs BESIDE the others, four frames in flight - frames/s with that launch skipped
+# (EEM_SKIP_KERNELS; the flow is garbage in those runs).  tools/marginal.sh [bench args]
+run() {
+  EEM_SKIP_KERNELS="$1" python3 bench.py --steps 300 --warmup 30 --cpu-seconds 0 --no-other-rows --no-side-rows "${@:2}" 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"
+}
+base=$(run "" "$@"); echo "nothing skipped: $base"
+b=$(echo $base | cut -d" " -f2)
+for k in "enc.pconv1_1" "enc.pconv1_2" "enc.pconv2_1" "enc.pconv2_2" "enc.pconv2_3" "enc.pconv3_1" "enc.pconv3_2" "enc.pconv3_3" "tail head" "dec." "tail up" "enc.;tail;dec."; do
+  r=$(run "$k" "$@"); t=$(echo $r | cut -d" " -f2)
+  python3 -c "print('skip %-16s %s frames/s  -> marginal cost %.1f us of %.1f' % ('$k', '$r'.split()[0], ($b - $t) * 1e3, $b * 1e3))"
+done

@@ -131,6 +131,26 @@ class _packs_of:
         return False
 
 
+# Weight / bias gradients of convs whose weight IS an nn.Parameter (a leaf, not a view) are accumulated by the library straight into
+# `parameter.grad` (allocated zeroed on first use) and the Function returns None for them: E-RAFT's update block uses every weight in
+# each of its 12 iterations, and autograd's own accumulation was one at::add_ launch and one zero fill per use and parameter (627 +
+# 520 launches of a training step).  What is lost: tensor hooks on those parameters and `torch.autograd.grad(..., inputs=[weight])`
+# (the gradient lands in .grad instead) - switch it off for such callers: `ops.set_direct_param_grads(False)` / EEM_NO_DIRECT_WGRAD=1.
+_direct_param_grads = [os.environ.get("EEM_NO_DIRECT_WGRAD", "0") != "1"]
+
+
+def set_direct_param_grads(enabled):
+    """Whether conv weight / bias gradients go straight into `.grad` (default) or through autograd's accumulation; returns the old value."""
+    old = _direct_param_grads[0]
+    _direct_param_grads[0] = bool(enabled)
+    return old
+
+
+def _leaf_param(t):
+    return t if (isinstance(t, torch.nn.Parameter) and t.is_leaf and t._base is None and t.requires_grad and t.is_contiguous()
+                 and t.dtype == torch.float32) else None
+
+
 class Conv2d(torch.autograd.Function):
     """out_scale * act(conv2d(cat(xs, 1), w) + b) - nn.Conv2d (+ the activation behind it) of model/extractor.py / model/update.py;
     the inputs' torch.cat is never materialised."""
@@ -139,6 +159,9 @@ class Conv2d(torch.autograd.Function):
     def forward(ctx, w, b, stride, padding, act, out_scale, *xs):
         _need_cuda(w, *xs)
         xs = [_c(x) for x in xs]
+        # the parameters themselves, for the direct gradient accumulation of backward (None for views / temporaries / frozen ones)
+        ctx.w_param = _leaf_param(w) if _direct_param_grads[0] else None
+        ctx.b_param = _leaf_param(b) if (_direct_param_grads[0] and b is not None) else None
         w = _c(w)
         n, _, hin, win = xs[0].shape
         cout, cin, kh, kw = w.shape
@@ -178,9 +201,20 @@ class Conv2d(torch.autograd.Function):
         with _on(w.device):
             s = _sp(w)
             joined = None
+            ret_dw = ret_db = True
             if need[0] or (has_b and need[1]):
-                dw = torch.zeros_like(w)
-                db = torch.zeros(cout, device=w.device) if has_b else None
+                if need[0] and ctx.w_param is not None:                   # accumulate into parameter.grad, hand autograd nothing
+                    if ctx.w_param.grad is None:
+                        ctx.w_param.grad = torch.zeros_like(ctx.w_param)
+                    dw, ret_dw = ctx.w_param.grad, False
+                else:
+                    dw = torch.zeros_like(w)
+                if has_b and need[1] and ctx.b_param is not None:
+                    if ctx.b_param.grad is None:
+                        ctx.b_param.grad = torch.zeros_like(ctx.b_param)
+                    db, ret_db = ctx.b_param.grad, False
+                else:
+                    db = torch.zeros(cout, device=w.device) if has_b else None
                 side = _wgrad_stream(w.device) if any(need[6:]) else None
                 sw = s
                 if side is not None:                                       # fork: dpre and the zeroed buffers are complete
@@ -208,7 +242,7 @@ class Conv2d(torch.autograd.Function):
                 c0 += cs[i]
             if joined is not None:                                         # join before autograd hands dw / db on
                 torch.cuda.current_stream(w.device).wait_event(joined)
-        return (dw if need[0] else None, db if (has_b and need[1]) else None, None, None, None, None, *dxs)
+        return (dw if (need[0] and ret_dw) else None, db if (has_b and need[1] and ret_db) else None, None, None, None, None, *dxs)
 
 
 def conv2d(conv, *xs, act=ACT_NONE, out_scale=1.0, weight=None, bias=None):

@@ -59,10 +59,11 @@ class _LossTerm(torch.autograd.Function):
         return dflow * g, None, None, None, None
 
 
-def sequence_loss(flow_preds, flow_gt, valid, gamma=0.8):
+def sequence_loss(flow_preds, flow_gt, valid, gamma=0.8, metrics=True):
     """`train.sequence_loss` (train_mvsec.py:201-227) on the GPU: returns (loss, metrics) with the reference's metric keys; the loss
     is a differentiable CUDA scalar, so `scaler.scale(loss).backward()` continues into the model's HIP backward pass.
-    max_flow is the reference's constant 400 (train_mvsec.py:41)."""
+    max_flow is the reference's constant 400 (train_mvsec.py:41).  metrics=False: no host read of the statistics (the metrics come
+    back as the 6-double device tensor of the last prediction instead of a dict) - what a step captured into a HIP graph needs."""
     if not flow_preds[0].is_cuda:
         raise _lib.EEMFlowHipError("sequence_loss: CUDA (ROCm) tensors required - there is no CPU path")
     gt, va = flow_gt.contiguous().float(), valid.contiguous().float()
@@ -73,6 +74,8 @@ def sequence_loss(flow_preds, flow_gt, valid, gamma=0.8):
             raise ValueError(f"sequence_loss: prediction {tuple(flow.shape)}, flow_gt {tuple(gt.shape)}, valid {tuple(va.shape)}")
         stats = torch.zeros(6, device=gt.device, dtype=torch.float64)
         loss = loss + _LossTerm.apply(flow.float(), gt, va, gamma ** (n - i - 1), stats)
+    if not metrics:
+        return loss, stats
     st = stats.tolist()                                          # statistics of the last prediction (train_mvsec.py:218-226)
     cnt = st[2] if st[2] > 0 else float("nan")
     return loss, {"epe": st[1] / cnt, "1px": st[3] / cnt, "3px": st[4] / cnt, "5px": st[5] / cnt}

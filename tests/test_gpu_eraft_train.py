@@ -197,6 +197,34 @@ def test_eraft_loss_backward_vs_oracle_autograd(b, h, w, iters):
             assert int(bufs[k]) == 1
 
 
+def test_direct_parameter_gradients_equal_autograd_accumulation():
+    """Conv weight / bias gradients accumulated by the library straight into `parameter.grad` (default: every use of a weight - twelve
+    per training step in E-RAFT's update block - adds into the same buffer, autograd hands nothing on) against the same gradients
+    returned to autograd and summed by its AccumulateGrad nodes (ops.set_direct_param_grads(False)): the same sums up to the order
+    of the float adds; a second backward without zero_grad() accumulates on top in both modes; weight VIEWS (the context
+    encoder's split output conv) keep the autograd route either way."""
+    from eemflow_amd import train as hip_train
+    b, h, w, iters = 1, 128, 160, 3
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(52, b, h, w))
+    gt, valid = (torch.from_numpy(a).to(DEV) for a in synthetic_gt(53, b, h, w))
+    grads = []
+    for direct in (True, False):
+        old = ops.set_direct_param_grads(direct)
+        try:
+            net, _ = make_model(51)
+            net.change_imagesize((h, w))
+            for rep in range(2):                                             # the second backward adds to the first's gradients
+                loss, _ = hip_train.sequence_loss(net(e1, e2, iters=iters)[1], gt, valid, 0.8)
+                loss.backward()
+            grads.append({k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+        finally:
+            ops.set_direct_param_grads(old)
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 100
+    gmax = max(float(g.abs().max()) for g in grads[1].values())
+    for k in grads[0]:
+        assert float((grads[0][k] - grads[1][k]).abs().max()) < 2e-4 * max(float(grads[1][k].abs().max()), 1e-3 * gmax), k
+
+
 def test_eraft_reference_training_sequence_two_steps():
     """train_mvsec.py:241-258 statement for statement on ERAFT: the loss falls and inference afterwards uses the stepped weights."""
     from eemflow_amd import train as hip_train

@@ -29,6 +29,33 @@ def step():
     opt.step()
     return loss
 step(); torch.cuda.synchronize()
+if os.environ.get("ERAFT_TRAIN_GRAPH", "0") == "1":
+    # the whole step as one HIP graph (torch.cuda.graph: forward, loss, backward on the autograd thread, clip, AdamW): static inputs,
+    # gradients zeroed in place, a capturable optimizer, no host read inside
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=5e-5, eps=1e-8, capturable=True)
+    def gstep():
+        opt.zero_grad(set_to_none=False)
+        _, preds = net(e1, e2, iters=iters)
+        loss, _ = sequence_loss(preds, gt, va, 0.8, metrics=False)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)
+        opt.step()
+        return loss
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            gstep()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):       # the stream of the warm-up: the library keeps packed weights per stream
+        static_loss = gstep()
+    torch.cuda.synchronize()
+    def step():
+        g.replay()
+        return static_loss
+    step(); torch.cuda.synchronize()
 n = 3
 t0 = time.perf_counter()
 for _ in range(n):

@@ -115,6 +115,8 @@ _SIGNATURES = {
     "eemop_batchnorm_train_fwd": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_float, ctypes.c_int]
                                   + [_c_float_p] * 3 + [ctypes.c_void_p]),
     "eemop_batchnorm_train_bwd": (ctypes.c_int, [_c_float_p] * 6 + [ctypes.c_int] * 4 + [_c_float_p] * 3 + [ctypes.c_void_p]),
+    "eemop_batchnorm_eval_fwd": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_int, _c_float_p, ctypes.c_void_p]),
+    "eemop_batchnorm_eval_bwd": (ctypes.c_int, [_c_float_p] * 6 + [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_int] + [_c_float_p] * 3 + [ctypes.c_void_p]),
     "eemop_corr_pyramid_fwd": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 4 + [_c_float_p] * 4 + [ctypes.c_void_p]),
     "eemop_corr_lookup_fwd": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 3 + [_c_float_p, ctypes.c_void_p]),
     "eemop_convex_upsample_fwd": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 3 + [_c_float_p, ctypes.c_void_p]),

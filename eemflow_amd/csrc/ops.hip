@@ -304,6 +304,43 @@ __global__ __launch_bounds__(1024) void bn_train_bwd_kernel(const float* __restr
     if (threadIdx.x == 0) { dw[ch] = (float)sgx; db[ch] = (float)sg; }
 }
 
+// ---- BatchNorm2d in EVAL mode (frozen statistics: ERAFT.freeze_bn, model/eraft.py:69-72) - an affine map per channel:
+// y = relu?((x - running_mean) * rstd * w + b), rstd = 1 / sqrt(running_var + eps).  One block per channel.
+__global__ __launch_bounds__(1024) void bn_eval_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                          const float* __restrict__ rm, const float* __restrict__ rv, float* __restrict__ y,
+                                                          int n, int c, int hw, float eps, int relu) {
+    const int ch = blockIdx.x;
+    const float mean = rm[ch], k = w[ch] * (1.f / sqrtf(rv[ch] + eps)), bias = b[ch];
+    for (int img = 0; img < n; ++img) {
+        const size_t o = ((size_t)img * c + ch) * hw;
+        for (int i = threadIdx.x; i < hw; i += blockDim.x) {
+            const float v = (x[o + i] - mean) * k + bias;
+            y[o + i] = relu ? fmaxf(v, 0.f) : v;
+        }
+    }
+}
+// backward: g = dy * [y > 0]; dx = g * w * rstd; dw = sum g * (x - mean) * rstd; db = sum g   (the statistics are constants)
+__global__ __launch_bounds__(1024) void bn_eval_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+                                                          const float* __restrict__ w, const float* __restrict__ rm, const float* __restrict__ rv,
+                                                          float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, int n, int c,
+                                                          int hw, float eps, int relu) {
+    __shared__ double sh[32];
+    const int ch = blockIdx.x;
+    const float mean = rm[ch], rstd = 1.f / sqrtf(rv[ch] + eps), k = w[ch] * rstd;
+    double sg = 0.0, sgx = 0.0;
+    for (int img = 0; img < n; ++img) {
+        const size_t o = ((size_t)img * c + ch) * hw;
+        for (int i = threadIdx.x; i < hw; i += blockDim.x) {
+            float g = dy[o + i];
+            if (relu && !(y[o + i] > 0.f)) g = 0.f;
+            sg += g; sgx += (double)g * ((x[o + i] - mean) * rstd);
+            dx[o + i] = g * k;
+        }
+    }
+    block_sum2(sg, sgx, sh);
+    if (threadIdx.x == 0) { dw[ch] = (float)sgx; db[ch] = (float)sg; }
+}
+
 inline unsigned nblk(long n) { return (unsigned)((n + 255) / 256); }
 
 // ------------------------------------------------------------------------------------------------ packed-weight plans
@@ -704,6 +741,26 @@ extern "C" int eemop_batchnorm_train_bwd(const float* x, const float* y, const f
     EEM_REQUIRE(x && y && dy && weight && save_mean && save_rstd && dx && dweight && dbias, "eemop_batchnorm_train_bwd: NULL argument");
     hipLaunchKernelGGL(bn_train_bwd_kernel, dim3(c), dim3((long)n * hw >= 16384 ? 1024 : 256), 0, (hipStream_t)stream, x, y, dy, weight, save_mean, save_rstd, dx, dweight,
                        dbias, n, c, hw, relu);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+extern "C" int eemop_batchnorm_eval_fwd(const float* x, const float* weight, const float* bias, const float* running_mean,
+                                        const float* running_var, int n, int c, int hw, float eps, int relu, float* y, void* stream) {
+    EEM_REQUIRE(x && weight && bias && running_mean && running_var && y, "eemop_batchnorm_eval_fwd: NULL argument");
+    EEM_REQUIRE(n >= 1 && c >= 1 && hw >= 1, "eemop_batchnorm_eval_fwd: bad sizes");
+    hipLaunchKernelGGL(bn_eval_fwd_kernel, dim3(c), dim3((long)n * hw >= 16384 ? 1024 : 256), 0, (hipStream_t)stream, x, weight, bias, running_mean,
+                       running_var, y, n, c, hw, eps, relu);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+extern "C" int eemop_batchnorm_eval_bwd(const float* x, const float* y, const float* dy, const float* weight, const float* running_mean,
+                                        const float* running_var, int n, int c, int hw, float eps, int relu, float* dx, float* dweight,
+                                        float* dbias, void* stream) {
+    EEM_REQUIRE(x && y && dy && weight && running_mean && running_var && dx && dweight && dbias, "eemop_batchnorm_eval_bwd: NULL argument");
+    hipLaunchKernelGGL(bn_eval_bwd_kernel, dim3(c), dim3((long)n * hw >= 16384 ? 1024 : 256), 0, (hipStream_t)stream, x, y, dy, weight, running_mean,
+                       running_var, dx, dweight, dbias, n, c, hw, eps, relu);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

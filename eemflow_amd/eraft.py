@@ -228,9 +228,8 @@ class ERAFT(nn.Module):
         from . import ops
         if isinstance(norm, nn.InstanceNorm2d):
             return ops.InstanceNormReLU.apply(x, relu)
-        if not norm.training:
-            raise _lib.EEMFlowHipError("ERAFT under autograd: eval-mode (frozen) BatchNorm is only built on the inference route; "
-                                       "the reference trains with BatchNorm in train() (train_mvsec.py:231-235)")
+        if not norm.training:                                    # freeze_bn() (model/eraft.py:69-72): running statistics, no update
+            return ops.BatchNormEvalReLU.apply(x, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.eps, relu)
         y = ops.BatchNormTrainReLU.apply(x, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.momentum, norm.eps, relu)
         norm.num_batches_tracked += 1
         return y

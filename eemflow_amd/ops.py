@@ -311,6 +311,36 @@ class BatchNormTrainReLU(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None
 
 
+class BatchNormEvalReLU(torch.autograd.Function):
+    """relu?(BatchNorm2d(x)) with the module in eval(): frozen running statistics, an affine map per channel whose weight and bias
+    still train - cnet's norm layers after ERAFT.freeze_bn() (model/eraft.py:69-72)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, relu):
+        _need_cuda(x, weight)
+        x = _c(x)
+        n, c, h, w = x.shape
+        y = torch.empty_like(x)
+        with _on(x.device):
+            _lib.check(_lib.lib().eemop_batchnorm_eval_fwd(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), running_mean.data_ptr(),
+                                                           running_var.data_ptr(), n, c, h * w, float(eps), 1 if relu else 0, y.data_ptr(),
+                                                           _sp(x)))
+        ctx.save_for_backward(x, y, weight, running_mean, running_var)
+        ctx.relu, ctx.eps = relu, float(eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight, rm, rv = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dx, dw, db = torch.empty_like(x), torch.empty_like(weight), torch.empty_like(weight)
+        with _on(x.device):
+            _lib.check(_lib.lib().eemop_batchnorm_eval_bwd(x.data_ptr(), y.data_ptr(), _c(dy).data_ptr(), weight.data_ptr(), rm.data_ptr(),
+                                                           rv.data_ptr(), n, c, h * w, ctx.eps, 1 if ctx.relu else 0, dx.data_ptr(),
+                                                           dw.data_ptr(), db.data_ptr(), _sp(x)))
+        return dx, dw, db, None, None, None, None
+
+
 class AddReLU(torch.autograd.Function):
     """relu(x + y): the tail of a residual block (model/extractor.py:57)."""
 

@@ -380,6 +380,14 @@ int eemop_batchnorm_train_fwd(const float* x, const float* weight, const float* 
                               void* stream);
 int eemop_batchnorm_train_bwd(const float* x, const float* y, const float* dy, const float* weight, const float* save_mean,
                               const float* save_rstd, int n, int c, int hw, int relu, float* dx, float* dweight, float* dbias, void* stream);
+/* BatchNorm2d in EVAL mode - frozen running statistics, an affine map per channel: y = relu?((x - running_mean) rstd w + b) with
+ * rstd = 1 / sqrt(running_var + eps); backward returns dx = g w rstd, dweight [c] = sum g (x - running_mean) rstd, dbias [c] = sum g
+ * (g = dy gated by the ReLU).  Replaces: nn.BatchNorm2d.forward in eval() after ERAFT.freeze_bn (model/eraft.py:69-72) and its autograd. */
+int eemop_batchnorm_eval_fwd(const float* x, const float* weight, const float* bias, const float* running_mean, const float* running_var,
+                             int n, int c, int hw, float eps, int relu, float* y, void* stream);
+int eemop_batchnorm_eval_bwd(const float* x, const float* y, const float* dy, const float* weight, const float* running_mean,
+                             const float* running_var, int n, int c, int hw, float eps, int relu, float* dx, float* dweight, float* dbias,
+                             void* stream);
 /* CorrBlock on caller tensors: the pyramid pyr_l [batch*h*w][h >> l][w >> l] (adjoint: eraft_corr_pyramid_bwd) and the 4-level 9x9
  * lookup at `coords` [batch][2][h][w] -> out [batch][324][h][w] (adjoint: eraft_corr_lookup_bwd).  model/corr.py:13-60. */
 int eemop_corr_pyramid_fwd(const float* fmap1, const float* fmap2, int batch, int c, int h, int w, float* pyr0, float* pyr1, float* pyr2,

@@ -116,6 +116,72 @@ def test_batch_norm_train_mode_vs_torch(relu):
     assert rel(bg.running_mean, bn.running_mean) < 1e-6 and rel(bg.running_var, bn.running_var) < 1e-6
 
 
+@pytest.mark.parametrize("relu", [True, False])
+def test_batch_norm_eval_mode_vs_torch(relu):
+    """nn.BatchNorm2d in eval() (frozen statistics, ERAFT.freeze_bn, model/eraft.py:69-72): output, dx, dweight, dbias against torch."""
+    n, c, h, w = 3, 24, 17, 23
+    x = rnd(n, c, h, w, seed=21)
+    bn = nn.BatchNorm2d(c)
+    with torch.no_grad():
+        bn.weight.copy_(rnd(c, seed=22).abs() + 0.5); bn.bias.copy_(rnd(c, seed=23))
+        bn.running_mean.copy_(rnd(c, seed=24) * 0.3); bn.running_var.copy_(rnd(c, seed=25).abs() + 0.5)
+    bg = nn.BatchNorm2d(c).to(DEV)
+    bg.load_state_dict(bn.state_dict())
+    bn.eval(); bg.eval()
+    xr = x.clone().requires_grad_(True)
+    yr = bn(xr)
+    yr = F.relu(yr) if relu else yr
+    g = rnd(*x.shape, seed=26)
+    yr.backward(g)
+    xg = x.to(DEV).requires_grad_(True)
+    yg = ops.BatchNormEvalReLU.apply(xg, bg.weight, bg.bias, bg.running_mean, bg.running_var, bg.eps, relu)
+    yg.backward(g.to(DEV))
+    assert rel(yg, yr) < 1e-5 and rel(xg.grad, xr.grad) < 1e-5
+    assert rel(bg.weight.grad, bn.weight.grad) < 2e-5 and rel(bg.bias.grad, bn.bias.grad) < 2e-5
+    assert torch.equal(bg.running_mean.cpu(), bn.running_mean) and torch.equal(bg.running_var.cpu(), bn.running_var)
+
+
+def test_eraft_frozen_batch_norm_backward_vs_oracle_autograd():
+    """model.freeze_bn() then loss.backward() (model/eraft.py:69-72: BatchNorm in eval(), its weight and bias still trained): the
+    predictions, the loss and the gradients against torch autograd through the oracle with bn_training=False; the running
+    statistics do not move."""
+    from eemflow_amd import train as hip_train
+    b, h, w, iters = 2, 128, 160, 2
+    net, sd = make_model(71)
+    net.change_imagesize((h, w))
+    net.freeze_bn()
+    assert net.training and not any(m.training for m in net.modules() if isinstance(m, nn.BatchNorm2d))
+    before = {k: v.clone() for k, v in net.state_dict().items() if "running_" in k or "num_batches" in k}
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(72, b, h, w))
+    gt, valid = (torch.from_numpy(a) for a in synthetic_gt(73, b, h, w))
+    preds = net(e1.to(DEV), e2.to(DEV), iters=iters)[1]
+    assert preds[-1].requires_grad
+    loss, _ = hip_train.sequence_loss(preds, gt.to(DEV), valid.to(DEV), 0.8)
+    loss.backward()
+    params = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone()) for k, v in sd.items()}
+    rpreds, _ = R.eraft_forward(params, e1, e2, iters=iters, image_size=(h, w), bn_training=False)
+    rloss, _ = T.sequence_loss(rpreds, gt, valid, 0.8)
+    rloss.backward()
+    for p, r in zip(preds, rpreds):
+        assert float((p.detach().cpu() - r.detach()).abs().max()) < 1e-3
+    assert abs(float(loss) - float(rloss)) < 1e-5
+    named = dict(net.named_parameters())
+    rgrads = {k: v.grad for k, v in params.items() if v.is_floating_point() and v.requires_grad and v.grad is not None}
+    gmax = max(float(g.abs().max()) for g in rgrads.values())
+    live = {k: g for k, g in rgrads.items() if float(g.abs().max()) > 1e-6 * gmax}
+    bn_keys = [k for k in live if k.startswith("cnet.") and ".norm" in k]
+    assert len(bn_keys) >= 10                                   # the frozen layers' affine parameters do get gradients
+    # (tolerances as in test_eraft_loss_backward_vs_oracle_autograd: ReLU kinks on 16 x 20 maps)
+    errs = sorted(((rel(named[k].grad, g), k) for k, g in live.items()), reverse=True)
+    assert sum(e >= 5e-3 for e, _ in errs) <= len(errs) // 5 and errs[0][0] < 8e-2, errs[:8]
+    num = sum(float((named[k].grad.double().cpu() - g.double()).pow(2).sum()) for k, g in live.items())
+    den = sum(float(g.double().pow(2).sum()) for g in live.values())
+    assert (num / den) ** 0.5 < 1e-2
+    after = net.state_dict()
+    for k, v in before.items():
+        assert torch.equal(after[k], v), k
+
+
 def test_small_ops_vs_torch():
     z, b, c, q = torch.sigmoid(rnd(2, 8, 9, 11, seed=1)), rnd(2, 8, 9, 11, seed=2), rnd(2, 8, 9, 11, seed=3), torch.tanh(rnd(2, 8, 9, 11, seed=4))
     a2, b2, c2, q2 = (t.clone().requires_grad_(True) for t in (z, b, c, q))

@@ -384,8 +384,11 @@ int run_decoders(eemflow_ctx* c, int k0, int k1, const float* const cat[3], int 
 }
 
 // io: nullptr (eager: the caller's pointers go into the launches) or the context's device table (graph capture)
+// prepadded (optional): both event volumes already replicate-padded into one [2B][cin][hp][wp] batch (the training forward keeps that
+// copy for the first layer's weight gradient anyway): the first layer then reads it with no padding of its own, which puts inputs whose
+// rows are not 16-byte multiples or that pad on the left (MVSEC: 346-pixel rows, 19 columns) on the LDS-DMA kernel of conv_enc1.hip
 int run_forward(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2, float* out, Hook& hk,
-                const void* const* io = nullptr) {
+                const void* const* io = nullptr, const float* prepadded = nullptr) {
     int rc;
     const int n2 = 2 * s.batch;
     // ---- encoder (both event volumes as one batch; shared weights, EEMFlow.py:135-140)
@@ -419,6 +422,11 @@ int run_forward(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2
         a.wraw = sp.layer == ENC_1_1 ? s.in_w : sp.win;
         a.pad_top = sp.layer == ENC_1_1 ? c->pad[2] : 0;
         a.pad_left = sp.layer == ENC_1_1 ? c->pad[0] : 0;
+        if (sp.layer == ENC_1_1 && prepadded != nullptr) {
+            a.in0 = prepadded;
+            a.in1 = prepadded + (size_t)s.batch * c->cin0 * s.hp * s.wp;
+            a.hraw = s.hp; a.wraw = s.wp; a.pad_top = 0; a.pad_left = 0;
+        }
         a.act = 1;
         a.gate = nullptr;
         a.pool_partial = nullptr;

@@ -232,10 +232,8 @@ static int backward_chain(eemflow_ctx* c, const Shape& s, const float* e1, const
         float* gp2 = c->g_pool[k].p + (size_t)B * pc[k] * g;
         if ((rc = tr_corr_bwd_launch(c->g_cat[k].p, kDecIn, pool1, pool2, gp1, gp2, B, pc[k], gh, gw, c->taps, kNTaps, st)) != EEM_OK) return rc;
     }
-    // ---- encoder (EEMFlow.py:135-154): both event volumes as one batch of 2B images
-    if ((rc = er_pad_launch(e1, c->padded.p, B * c->cin0, in_h, in_w, c->pad[0], c->pad[1], c->pad[2], c->pad[3], st)) != EEM_OK) return rc;
-    if ((rc = er_pad_launch(e2, c->padded.p + (size_t)B * c->cin0 * s.hp * s.wp, B * c->cin0, in_h, in_w, c->pad[0], c->pad[1], c->pad[2],
-                            c->pad[3], st)) != EEM_OK) return rc;
+    // ---- encoder (EEMFlow.py:135-154): both event volumes as one batch of 2B images; c->padded holds them replicate-padded since the
+    // forward (forward_train_impl), which read its first layer from there
     struct L { int layer; const float* x; int xc, hin, win; const float* y; float* gy; int hout, wout; float* gx; };
     const L ls[ENC_NUM] = {
         {ENC_3_3, c->b3.p, 64, s.h3, s.w3, c->f13.p, c->g_f13.p, s.h3, s.w3, c->g_b3.p},
@@ -303,9 +301,16 @@ static int forward_train_impl(eemflow_ctx* c, const float* e1, const float* e2, 
     c->train_e1 = e1;
     c->train_e2 = e2;
     c->have_train_fwd = false;
+    // both volumes replicate-padded into one batch: the first layer's weight gradient needs that copy, and reading the forward's first
+    // layer from it lets 346-pixel rows (MVSEC: not a 16-byte multiple, 19 columns of left padding) use the LDS-DMA kernel too
+    const int B = batch;
+    if ((rc = er_pad_launch(e1, c->padded.p, B * c->cin0, in_h, in_w, c->pad[0], c->pad[1], c->pad[2], c->pad[3], st)) != EEM_OK) return rc;
+    if ((rc = er_pad_launch(e2, c->padded.p + (size_t)B * c->cin0 * s.hp * s.wp, B * c->cin0, in_h, in_w, c->pad[0], c->pad[1], c->pad[2],
+                            c->pad[3], st)) != EEM_OK) return rc;
     Hook hk;
     hk.st = st;
-    if ((rc = run_forward(c, s, e1, e2, flow_out, hk)) != EEM_OK) return rc;
+    static const bool no_prepad = [] { const char* e = getenv("EEM_NO_PREPAD_FWD"); return e && e[0] == '1'; }();
+    if ((rc = run_forward(c, s, e1, e2, flow_out, hk, nullptr, no_prepad ? nullptr : c->padded.p)) != EEM_OK) return rc;
     c->have_train_fwd = true;
     c->train_serial += 1;
     c->train_shape = s;

@@ -235,11 +235,11 @@ def other_rows(dev):
         grid2 = torch.empty(5, 720, 1280, device=dev)
         for nn, key in ((2000000, "voxelize_pair_2x2M_events_ms"), (200000, "voxelize_pair_2x200k_events_ms")):
             for _ in range(3):
-                _lib.check(L.eemflow_voxelize_pair(feats.data_ptr(), nn, feats.data_ptr(), nn, 5, 720, 1280, 1, grid.data_ptr(), grid2.data_ptr(), sp))
+                _lib_mod.check(L.eemflow_voxelize_pair(feats.data_ptr(), nn, feats.data_ptr(), nn, 5, 720, 1280, 1, grid.data_ptr(), grid2.data_ptr(), sp))
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
             for _ in range(20):
-                _lib.check(L.eemflow_voxelize_pair(feats.data_ptr(), nn, feats.data_ptr(), nn, 5, 720, 1280, 1, grid.data_ptr(), grid2.data_ptr(), sp))
+                _lib_mod.check(L.eemflow_voxelize_pair(feats.data_ptr(), nn, feats.data_ptr(), nn, 5, 720, 1280, 1, grid.data_ptr(), grid2.data_ptr(), sp))
             torch.cuda.synchronize(dev)
             out[key] = round((time.perf_counter() - t0) / 20 * 1e3, 3)
     except Exception as e:                                   # noqa: BLE001

@@ -225,6 +225,11 @@ extern "C" int eemflow_load_weights(eemflow_ctx* c, const float* flat, size_t nf
             if (!c->enc_wino[l]) continue;
             for (int f = 0; f < 4; ++f) { c->wino_off[f][l] = off; off += wino_packed_floats(d.cin); }
         }
+        for (int l = 0; l < ENC_NUM; ++l) {
+            const EncLayerDesc& d = kEncLayers[l];
+            c->enc_s2r[l] = s2r_shape(d.cin, d.cout, d.stride);
+            if (c->enc_s2r[l]) { c->s2r_off[l] = off; off += s2r_packed_floats(d.cin, d.cout); }
+        }
         if (c->wino) EEM_HIP_CHECK(hipFree(c->wino));
         c->wino = nullptr;
         EEM_HIP_CHECK(hipMalloc(&c->wino, off * sizeof(float)));
@@ -298,7 +303,7 @@ extern "C" int eemflow_forward(eemflow_ctx* c, const float* e1, const float* e2,
     if (rc != EEM_OK) return rc;
 
     c->workspace_overwritten();
-    if ((rc = ensure_forward_wino(c, st)) != EEM_OK) return rc;          // outside any capture
+    if ((rc = ensure_forward_wino(c, batch, st)) != EEM_OK) return rc;          // outside any capture
     if (!c->use_graph) {
         if ((rc = alloc_workspace(c, s)) != EEM_OK) return rc;
         c->last = s;

@@ -66,6 +66,9 @@ struct eemflow_ctx {
     float* wino = nullptr;
     size_t wino_off[4][ENC_NUM];
     bool wino_ok[4][ENC_NUM] = {};
+    size_t s2r_off[ENC_NUM];           // the stride-2 layers' weights in conv_s2r.hip's order (same buffer, same lazy refresh)
+    bool s2r_ok[ENC_NUM] = {};
+    bool enc_s2r[ENC_NUM] = {};
     bool enc_wino[ENC_NUM];
     bool use_wino = true;              // EEM_WINO=0 in the environment keeps the direct-convolution kernels
     // which stride-1 layers run F(4x4,3x3), by channel count (bit 0: C = 16, 1: C = 32, 2: C = 64).  F(4x4) blocks are 8 waves on 16 x
@@ -74,11 +77,13 @@ struct eemflow_ctx {
     // (several frames in flight: eemflow_set_frames_in_flight >= 3) and F(2x2) the latency choice; C = 16 wins both ways.
     // EEM_WINO=2: never; EEM_WINO4_LAYERS=<mask>: always that mask
     int f4_mask_env = -1;
-    int f4_mask() const {
+    // (a forward of four or more samples has the tiles to fill the chip with F(4x4) blocks too: 8 260 against 7 400 frames/s for
+    // batches of four, two in flight)
+    int f4_mask(int batch) const {
         if (f4_mask_env >= 0) return f4_mask_env;
-        return frames_in_flight >= 3 ? 7 : 1;
+        return (frames_in_flight >= 3 || batch >= 4) ? 7 : 1;
     }
-    bool layer_f4(int cin) const { return (f4_mask() >> (cin == 16 ? 0 : cin == 32 ? 1 : 2)) & 1; }
+    bool layer_f4(int cin, int batch) const { return (f4_mask(batch) >> (cin == 16 ? 0 : cin == 32 ? 1 : 2)) & 1; }
     float* zero_page = nullptr;
     TailW rconv[3], dconv1[3], dgroup[3][3][5], dconv5[3], dconv6[3], dconv7[3], outc;
     // training: per-conv descriptors (flat offsets of weight/bias, packed transposed weights for gconv dgrad)
@@ -166,12 +171,22 @@ int ensure(DevBuf& b, size_t floats) {
 int refresh_wino(eemflow_ctx* c, hipStream_t) {
     for (int f = 0; f < 4; ++f)
         for (int l = 0; l < ENC_NUM; ++l) c->wino_ok[f][l] = false;
+    for (int l = 0; l < ENC_NUM; ++l) c->s2r_ok[l] = false;
+    return EEM_OK;
+}
+int ensure_s2r(eemflow_ctx* c, int l, hipStream_t st, const float** w_out) {
+    if (!c->s2r_ok[l]) {
+        const int rc = s2r_transform_launch(c->flat + c->t_enc[l].w, kEncLayers[l].cin, kEncLayers[l].cout, c->wino + c->s2r_off[l], st);
+        if (rc != EEM_OK) return rc;
+        c->s2r_ok[l] = true;
+    }
+    *w_out = c->wino + c->s2r_off[l];
     return EEM_OK;
 }
 // Winograd-domain weights of layer l (dir 0: forward, 1: data gradient) in the form the policy picks; *f4_out says which
-int ensure_wino(eemflow_ctx* c, int l, int dir, hipStream_t st, const float** w_out, int* f4_out) {
+int ensure_wino(eemflow_ctx* c, int l, int dir, int batch, hipStream_t st, const float** w_out, int* f4_out) {
     const int ch = kEncLayers[l].cin;
-    const int f4 = c->layer_f4(ch) ? 1 : 0;
+    const int f4 = c->layer_f4(ch, batch) ? 1 : 0;
     const int slot = f4 * 2 + dir;
     if (!c->wino_ok[slot][l]) {
         const int rc = wino_transform_launch(c->flat + c->t_enc[l].w, ch, dir, c->wino + c->wino_off[slot][l], st, f4);
@@ -183,12 +198,16 @@ int ensure_wino(eemflow_ctx* c, int l, int dir, hipStream_t st, const float** w_
     return EEM_OK;
 }
 // before a graph capture / replay: the forward copies exist (a transform launched inside a capture would replay with every frame)
-int ensure_forward_wino(eemflow_ctx* c, hipStream_t st) {
+int ensure_forward_wino(eemflow_ctx* c, int batch, hipStream_t st) {
+    for (int l = 0; l < ENC_NUM; ++l) {
+        const float* ws;
+        if (c->enc_s2r[l]) { const int rc = ensure_s2r(c, l, st, &ws); if (rc != EEM_OK) return rc; }
+    }
     if (!c->use_wino) return EEM_OK;
     for (int l = 0; l < ENC_NUM; ++l) {
         if (!c->enc_wino[l]) continue;
         const float* w; int f4;
-        const int rc = ensure_wino(c, l, 0, st, &w, &f4);
+        const int rc = ensure_wino(c, l, 0, batch, st, &w, &f4);
         if (rc != EEM_OK) return rc;
     }
     return EEM_OK;
@@ -225,7 +244,7 @@ int compute_shape(eemflow_ctx* c, int batch, int in_h, int in_w, int out_h, int 
         const EncLayerDesc& d = kEncLayers[last[k]];
         int th, tw, pk;
         const bool wino = c->use_wino && c->enc_wino[last[k]] && wino_supported(d.cin, d.cout, d.stride, ws[k]);
-        if (wino) wino_tile(d.cin, c->layer_f4(d.cin) ? 1 : 0, &th, &tw, &pk);
+        if (wino) wino_tile(d.cin, c->layer_f4(d.cin, batch) ? 1 : 0, &th, &tw, &pk);
         else enc2_tile(d.cin, d.cout, &th, &tw, &pk);
         s->fuse[k] = (wino || (c->enc_has2[last[k]] && enc2_supported(d.cin, d.cout, d.stride, ws[k]))) && pk == ks[k];
         s->th[k] = th;
@@ -411,7 +430,9 @@ int run_forward(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2
         a.wpk2 = c->enc_has2[sp.layer] ? c->arena + c->enc_w2[sp.layer] : nullptr;
         a.wwino = nullptr;
         a.wino_f4 = 0;
-        if (c->use_wino && c->enc_wino[sp.layer] && (rc = ensure_wino(c, sp.layer, 0, hk.st, &a.wwino, &a.wino_f4)) != EEM_OK) return rc;
+        if (c->use_wino && c->enc_wino[sp.layer] && (rc = ensure_wino(c, sp.layer, 0, s.batch, hk.st, &a.wwino, &a.wino_f4)) != EEM_OK) return rc;
+        a.ws2r = nullptr;
+        if (c->enc_s2r[sp.layer] && (rc = ensure_s2r(c, sp.layer, hk.st, &a.ws2r)) != EEM_OK) return rc;
         a.zero_page = c->zero_page;
         a.trash = c->zero_page + 256;
         a.bias = c->arena + c->enc_b[sp.layer];

@@ -168,6 +168,7 @@ struct EncConvArgs {
     // (eemflow_set_frames_in_flight): fewer, longer blocks spend less CU time on per-block prologues
     int blocks_per_xcd = 0;
     int wino_f4 = 0;       // wwino holds F(4x4,3x3) weights (conv_wino4.hip) instead of F(2x2,3x3) ones
+    const float* ws2r = nullptr;   // weights of a stride-2 layer in conv_s2r.hip's order (s2r_transform_launch), or NULL
 };
 int enc_conv_launch(int cin, int cout, int stride, const EncConvArgs& a, hipStream_t stream);
 // first layer with 16-byte LDS-DMA staging (conv_enc1.hip): raw width % 4 == 0, no horizontal padding
@@ -182,6 +183,12 @@ int enc_conv2_launch(int cin, int cout, int stride, const EncConvArgs& a, hipStr
 bool s2_supported(int cin, int cout, int stride, const EncConvArgs& a);
 int s2_launch(int cin, const EncConvArgs& a, hipStream_t stream);
 void enc2_tile(int cin, int cout, int* th, int* tw, int* poolk);
+// the stride-2 layers 16 -> 32 and 32 -> 64 as 8-wave blocks on an LDS-DMA ring of k-step slices, weights included (conv_s2r.hip)
+bool s2r_shape(int cin, int cout, int stride);
+size_t s2r_packed_floats(int cin, int cout);
+int s2r_transform_launch(const float* w, int cin, int cout, float* packed, hipStream_t stream);     // OIHW device weights -> packed
+bool s2r_supported(int cin, int cout, int stride, const EncConvArgs& a);
+int s2r_launch(int cin, const EncConvArgs& a, hipStream_t stream);
 // Winograd F(2x2,3x3) path for the stride-1 C -> C layers (C = 16, 32, 64), conv_wino.hip
 bool wino_supported(int cin, int cout, int stride, int win);
 size_t wino_packed_floats(int c);      // room for either form

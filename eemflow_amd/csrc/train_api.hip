@@ -259,7 +259,7 @@ static int backward_chain(eemflow_ctx* c, const Shape& s, const float* e1, const
             a.wpk = c->arena + r.wT_enc; a.wpk2 = c->arena + r.wT_enc2; a.bias = c->arena + r.zero_bias;
             a.wwino = nullptr;
             a.wino_f4 = 0;
-            if (c->use_wino && c->enc_wino[l.layer] && (rc = ensure_wino(c, l.layer, 1, st, &a.wwino, &a.wino_f4)) != EEM_OK) return rc;
+            if (c->use_wino && c->enc_wino[l.layer] && (rc = ensure_wino(c, l.layer, 1, s.batch, st, &a.wwino, &a.wino_f4)) != EEM_OK) return rc;
             a.zero_page = c->zero_page; a.trash = c->zero_page + 256;
             a.out = l.gx;
             a.nimg = n2; a.nimg0 = n2;

@@ -50,7 +50,7 @@ def launch_two(args, timeout=600):
 
 
 @pytest.mark.parametrize("b,h,w", [(4, 260, 346), (2, 720, 1280)])
-def test_trainer_step_two_processes_equals_single_process(tmp_path, b, h, w):
+def test_trainer_step_two_processes_equals_single_process(tmp_path, b, h, w, monkeypatch):
     """EEMFlowTrainer.step under 2 ranks (half the batch each) against the same trainer on the whole batch in this process: the
     mean of the ranks' losses is the global loss, the all-reduced gradient is the global-batch gradient, the replicas end
     bit-identical and track the single-process weights."""
@@ -58,6 +58,7 @@ def test_trainer_step_two_processes_equals_single_process(tmp_path, b, h, w):
     from eemflow_amd.train import EEMFlowTrainer
     from eemflow_amd.weights import seeded_state_dict, synthetic_gt, synthetic_voxel_pair
     steps = 2
+    monkeypatch.setenv("EEM_WINO4_LAYERS", "7")      # batch b here, b/2 per rank: pin the Winograd form (it follows the batch); ranks inherit
     launch_two(["trainer", tmp_path, b, h, w, steps])
     r0, r1 = (np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in (0, 1))
     assert int(r0["world"]) == 2 and str(r0["backend"]) == "gloo"

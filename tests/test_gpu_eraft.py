@@ -205,10 +205,6 @@ def test_errors():
     net.change_imagesize((64, 64))
     with pytest.raises(_lib.EEMFlowHipError):
         net(torch.zeros(1, 5, 64, 64), torch.zeros(1, 5, 64, 64))
-    net.train()
-    net.freeze_bn()                            # eval-mode BatchNorm under autograd is not built (the reference trains with it in train())
-    with pytest.raises(_lib.EEMFlowHipError):
-        net(torch.zeros(1, 5, 128, 128, device=DEV), torch.zeros(1, 5, 128, 128, device=DEV))
 
 
 def test_stacked_update_block_launches_equal_separate_ones(monkeypatch):

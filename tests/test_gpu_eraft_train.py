@@ -366,6 +366,7 @@ def test_packed_weight_cache_keeps_one_stream_per_packing():
     conv = torch.nn.Conv2d(64, 64, 3, padding=1).to(DEV)
     x = torch.randn(1, 64, 48, 64, device=DEV)
     L = _lib.lib()
+    gc.collect()                               # modules earlier tests left in reference cycles: their packings go now, not mid-test
     with torch.no_grad():
         ref = torch.relu(conv(x))
         before = L.eemop_pack_cache_bytes()

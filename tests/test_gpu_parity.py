@@ -505,6 +505,26 @@ def test_errors_are_loud():
     _lib.lib().eemflow_destroy(handle)
 
 
+@pytest.mark.parametrize("b,h,w", [(1, 720, 1280), (2, 260, 346), (1, 100, 150), (3, 192, 256)])
+def test_ring_stride2_kernel_equals_the_chunked_one(monkeypatch, b, h, w):
+    """conv_s2r.hip (8-wave blocks, input and weights through one LDS-DMA ring of k-step slices; pconv2_1 and pconv3_1; off by
+    default - it measured slower - and switched on per launch by EEM_S2R=1) against the default kernels: the same sums in another
+    order - stage tensors and flow to fp32 round-off, at the headline size, at ragged ones (border tiles, several tiles per block)
+    and with a batch."""
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(56, b, h, w))
+    outs = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("EEM_S2R", on)
+        net, _ = make_net(45, graph=False)
+        net.change_imagesize((h, w))
+        with torch.no_grad():
+            flow = net(e1, e2)[1][0].clone()
+        outs.append((flow, net.stage("f12").clone(), net.stage("f13").clone()))
+    for a, c in zip(*outs):
+        assert maxerr(a, c) < 2e-5 * max(1.0, float(c.abs().max()))
+    assert float(outs[0][1].abs().max()) > 0.1
+
+
 @pytest.mark.parametrize("form", ["f2", "f4", "default"])
 @pytest.mark.parametrize("h,w", [(192, 320), (260, 346), (720, 1280)])
 def test_winograd_encoder_equals_direct_convolution(monkeypatch, h, w, form):

@@ -614,6 +614,7 @@ def main():
     ev0.record(stream)
     for _ in range(args.steps):
         step()
+    enqueue_s = time.perf_counter() - t0                 # host time to hand the K steps to the streams (reported; < elapsed = GPU-bound)
     for st in streams[1:]:
         stream.wait_stream(st)
     ev1.record(stream)
@@ -725,6 +726,7 @@ def main():
                        "parallelism": f"replicas x{world}: frames sharded over ranks, no data-path collective"},
             "roofline": roof, "roofline_single_frame_launch": roof_single, "cpu_baseline": cpu,
             "gpu_ms_per_step_hip_events": round(gpu_ms / args.steps, 4),
+            "host_enqueue_ms_per_step": round(enqueue_s * 1e3 / args.steps, 4),
             "schedule_sum_us": round(sum_us, 1), "frame_gflop": round(total_gflop, 3),
             "frame_tflops": round(total_gflop * B / ms_per_step, 2),
             "encoder_tflops_in_kernel": round(enc_tflops, 2),

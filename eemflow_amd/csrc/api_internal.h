@@ -125,6 +125,12 @@ struct eemflow_ctx {
     // launch rewrites in front of a replay whenever the caller hands over other buffers - fresh tensors per frame replay the
     // same graph.  Every entry bakes in workspace pointers: a reallocation (ensure) drops them all.
     bool use_graph = true;
+    // diagnostic (EEM_SPANS=1, eager launches): events at frame start / encoder end / frame end; every 64 frames the averages of the
+    // encoder chain's and the tail chain's spans under whatever else runs on the chip go to stderr (tools/spans.sh)
+    hipEvent_t span_ev[3] = {nullptr, nullptr, nullptr};
+    double span_sum[2] = {0.0, 0.0};
+    int span_n = 0;
+    bool span_pending = false;
     int frames_in_flight = 1;                            // eemflow_set_frames_in_flight: >= 3 shrinks the persistent encoder grids
     struct Key {
         int batch, in_h, in_w, out_h, out_w, pad[4];
@@ -322,7 +328,10 @@ struct Hook {
 
     template <class F>
     int run(const char* name, double flops, double bytes, F&& launch) {
-        if (skipped(name)) return EEM_OK;
+        if (skipped(name)) {                                  // EEM_SKIP_SPIN_US=<us>: one lane holds the launch's place in the stream for <us>
+            static const float spin = [] { const char* e = getenv("EEM_SKIP_SPIN_US"); return e ? (float)atof(e) : 0.f; }();
+            return spin > 0.f ? spin_launch(spin, st) : EEM_OK;
+        }
         if (!timing) return launch(st);
         eem_last_grid_blocks = eem_last_grid_threads = 0;
         int rc = launch(st);                                  // warm (also keeps data flowing downstream)
@@ -406,8 +415,46 @@ int run_decoders(eemflow_ctx* c, int k0, int k1, const float* const cat[3], int 
 // prepadded (optional): both event volumes already replicate-padded into one [2B][cin][hp][wp] batch (the training forward keeps that
 // copy for the first layer's weight gradient anyway): the first layer then reads it with no padding of its own, which puts inputs whose
 // rows are not 16-byte multiples or that pad on the left (MVSEC: 346-pixel rows, 19 columns) on the LDS-DMA kernel of conv_enc1.hip
+static bool spans_on() {
+    static const bool on = [] { const char* e = getenv("EEM_SPANS"); return e && e[0] == '1'; }();
+    return on;
+}
+static int span_mark(eemflow_ctx* c, int i, hipStream_t st) {
+    if (!spans_on()) return EEM_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cs);
+    if (cs != hipStreamCaptureStatusNone) return EEM_OK;
+    if (i == 0 && c->span_pending) {
+        EEM_HIP_CHECK(hipEventSynchronize(c->span_ev[2]));
+        float a = 0.f, b = 0.f;
+        EEM_HIP_CHECK(hipEventElapsedTime(&a, c->span_ev[0], c->span_ev[1]));
+        EEM_HIP_CHECK(hipEventElapsedTime(&b, c->span_ev[1], c->span_ev[2]));
+        c->span_sum[0] += a; c->span_sum[1] += b;
+        if (++c->span_n == 64) {
+            fprintf(stderr, "EEM_SPANS ctx %p: encoder chain %.1f us, tail chain %.1f us (64 frames)\n", (void*)c,
+                    c->span_sum[0] / 64 * 1e3, c->span_sum[1] / 64 * 1e3);
+            c->span_sum[0] = c->span_sum[1] = 0.0; c->span_n = 0;
+        }
+        c->span_pending = false;
+    }
+    if (!c->span_ev[i]) EEM_HIP_CHECK(hipEventCreate(&c->span_ev[i]));
+    EEM_HIP_CHECK(hipEventRecord(c->span_ev[i], st));
+    if (i == 2) c->span_pending = true;
+    return EEM_OK;
+}
+
+int run_forward_impl(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2, float* out, Hook& hk,
+                     const void* const* io, const float* prepadded);
 int run_forward(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2, float* out, Hook& hk,
                 const void* const* io = nullptr, const float* prepadded = nullptr) {
+    int rc = span_mark(c, 0, hk.st);
+    if (rc == EEM_OK) rc = run_forward_impl(c, s, e1, e2, out, hk, io, prepadded);
+    if (rc == EEM_OK) rc = span_mark(c, 2, hk.st);
+    return rc;
+}
+
+int run_forward_impl(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2, float* out, Hook& hk,
+                     const void* const* io, const float* prepadded) {
     int rc;
     const int n2 = 2 * s.batch;
     // ---- encoder (both event volumes as one batch; shared weights, EEMFlow.py:135-140)
@@ -499,6 +546,7 @@ int run_forward(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2
                         [&](hipStream_t st) { return pool_launch(pj, np, n2, st); });
             if (rc != EEM_OK) return rc;
         }
+        if ((rc = span_mark(c, 1, hk.st)) != EEM_OK) return rc;
         if (!no_fuse) {
             TailHeadArgs ha;
             memset(&ha, 0, sizeof(ha));
@@ -518,10 +566,10 @@ int run_forward(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2
                 ha.rw[k] = c->arena + c->rconv[k].wpk;
                 ha.rb[k] = c->arena + c->rconv[k].bias;
             }
-            ha.taps = c->taps; ha.batch = s.batch; ha.gh = s.gh; ha.gw = s.gw; ha.ntaps = kNTaps; ha.cat_ctotal = kDecIn;
+            ha.batch = s.batch; ha.gh = s.gh; ha.gw = s.gw; ha.ntaps = kNTaps; ha.cat_ctotal = kDecIn;
             const double fl = 2.0 * s.batch * g * (kNTaps * (16 + 32 + 64) + 16.0 * 9 * (16 + 32 + 64));
             rc = hk.run("tail head: pool+corr53+rconv", fl, 4.0 * (fin_elems + 3.0 * s.batch * g * kDecIn),
-                        [&](hipStream_t st) { return tail_head_launch(ha, st); });
+                        [&](hipStream_t st) { return tail_head_launch(ha, kTaps53, st); });
             if (rc != EEM_OK) return rc;
         } else {
             if (nf) {

@@ -253,6 +253,7 @@ int corr_launch(const CorrJob* jobs, int njobs, int batch, int h, int w, const i
 int upsample_launch(const float* in, float* out, int nc, int h, int w, int oh, int ow, hipStream_t stream,
                     const void* const* io = nullptr);
 // writes {e1, e2, out} into the device table (one tiny launch in front of a cached graph whose buffers changed)
+int spin_launch(float us, hipStream_t stream);          // diagnostic: one wave asleep for <us> (tools/marginal.sh)
 int io_table_launch(const void** table, const void* e1, const void* e2, void* out, hipStream_t stream);
 
 // ---- fused launches of the tail (tail_fused.hip)
@@ -263,6 +264,7 @@ struct PooledSrc {
     int nstride, cstride, ystride, rstride, rows;
     float scale;
 };
+#define TAIL_HEAD_MAX_TAPS 81
 struct TailHeadArgs {
     PooledSrc src[3];            // the three stages (images 0..B-1 = events1, B..2B-1 = events2)
     int c[3];                    // 16, 32, 64
@@ -270,11 +272,11 @@ struct TailHeadArgs {
     float* pool_out[3];          // finished pooled maps [2B][c][g] (side output) or NULL
     const float* rw[3];          // rconv_k weights packed by tail_pack_weights
     const float* rb[3];          // rconv_k bias
-    const int* taps;
     int batch, gh, gw, ntaps, cat_ctotal;
-    int nblk_rconv, nblk_corr;   // filled by the launcher
+    int grid_x;                  // filled by the launcher
+    int tap[TAIL_HEAD_MAX_TAPS]; // filled by the launcher from taps_host: the selected taps of the 9x9 window (EEMFlow.py:14-23)
 };
-int tail_head_launch(const TailHeadArgs& a, hipStream_t stream);
+int tail_head_launch(const TailHeadArgs& a, const int* taps_host, hipStream_t stream);
 struct TailUpArgs {
     const float* flowcat;        // the three decoders' flows [B][6][g]
     const float* wo;             // out_conv weight [2][6], bias [2] (state_dict layout)

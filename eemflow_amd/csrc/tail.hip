@@ -6,6 +6,7 @@
 // conv layer is one launch that covers all decoders/groups/samples ("jobs"), spreads 16x16 MFMA
 // tiles over the chip and splits K over the four waves of a block.
 #include "common.h"
+#include <cstring>
 
 namespace {
 
@@ -156,41 +157,78 @@ __global__ __launch_bounds__(256) void corr_tiled_kernel(CorrArgs a, int tiles_x
 // tap displacement and the bounds test are per-wave constants and ALL of its operand loads (<= MAXCG
 // weight fragments + MAXCG input gathers) are issued before the first MFMA - the grid is tiny and
 // L2-resident, so the kernel is one memory round trip + <= 25 MFMAs + a 9-way LDS reduction.
-template <int KS, int MAXCG>
+//
+// Built for what a launch costs BESIDE other frames' encoder kernels (four frames in flight; profiles/r03_tailcost.txt):
+//   * the seven decoder launches as empty kernels cost the frame 2.5 us, as 315 sleeping blocks of 3 us each 5 us, as one
+//     sleeping wave of 6 us each (42 us of chain, no footprint) 2.7 us - neither the launches nor the chain's length is the price;
+//   * the real launches cost ~1.2x their own duration above an empty launch's: a block holds a CU slot an encoder block wants for
+//     as long as it lives, and it lives as long as its chain of memory round trips, each several times its idle length there;
+//   * 16 KB of straight-line code in front of the sleeping blocks costs 17 us more (instruction fetch is shared by the CU's waves).
+// So: ONE batch of scalar loads (launch header + the job, picked by blockIdx.z), ONE batch of operand loads, and small code - both
+// operand streams are buffer loads whose range check returns the zeros of padded channel groups, of channels past cin and of
+// taps outside the grid (clamps and selects on 64-bit addresses before: 19 KB -> 2.7 KB).  1280x720: the seven launches 38.2 ->
+// 27.4 us alone, frame 126.4 -> 122.2 us with four in flight.
+template <int KS, int MAXCG, bool GATE>
 __global__ __launch_bounds__(64 * KS * KS) void tail_conv_kernel(TailConvLaunch L) {
     constexpr int KK = KS * KS;
     __shared__ f32x4 part[KK][64];
-    const int lane = threadIdx.x & 63, t = threadIdx.x >> 6;
-    const int ji = blockIdx.z / L.batch, b = blockIdx.z % L.batch;
-    const TailConvJob jb = L.job[ji];
+    const int lane = threadIdx.x & 63;
+    const int t = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // grid = (pixel tiles x batch, cout tiles, jobs): the job index is a launch register, so the job's fields and the launch
+    // header are ONE batch of scalar loads (the kernel's first memory round trip; its second and last before the stores is the
+    // operand loads below).  Beside other frames' kernels a round trip is several times its idle length and the block holds its
+    // CU slot throughout - the chain of five dependent scalar loads this replaces was most of a decoder launch's price there.
+    const TailConvJob jb = L.job[blockIdx.z];
+    const int hw = L.h * L.w, lw = L.w, lh = L.h;
+    // (all of them wanted in registers here: the compiler otherwise leaves some of the loads behind the first branch)
+    asm volatile("" ::"s"(jb.in), "s"(jb.wpk), "s"(jb.bias), "s"(jb.out), "s"(jb.add), "s"(jb.gate), "s"(jb.cin), "s"(jb.cout), "s"(jb.in_cmul),
+                 "s"(jb.out_cmul), "s"(jb.act), "s"(lw), "s"(lh));
     const int cot = blockIdx.y;
-    if (cot * 16 >= jb.cout) return;
-    const int hw = L.h * L.w;
+    const bool live = cot * 16 < jb.cout;               // a launch's jobs may differ in cout: surplus blocks load nothing (range 0) and leave
+    const int ptiles = (hw + 15) >> 4;
+    const int b = blockIdx.x / ptiles;
     const int j = lane & 15, g = lane >> 4;
-    const int p = blockIdx.x * 16 + j;
-    const bool pvalid = p < hw;
-    const int y = p / L.w, x = p - y * L.w;
+    const int p = (blockIdx.x - b * ptiles) * 16 + j;
+    const int y = p / lw, x = p - y * lw;
     const int yy = y + (KS == 3 ? t / 3 - 1 : 0), xx = x + (KS == 3 ? t % 3 - 1 : 0);
-    const bool valid = pvalid && yy >= 0 && yy < L.h && xx >= 0 && xx < L.w;
+    const bool valid = p < hw && yy >= 0 && yy < lh && xx >= 0 && xx < lw;
     const int cg = (jb.cin + 3) >> 2;
-    const size_t ioff = ((size_t)b * jb.in_ctotal + jb.in_coff) * hw + (valid ? yy * L.w + xx : 0);
-    const float* in = jb.in + ioff;
-    const float* gt = jb.gate ? jb.gate + ioff : nullptr;
     const int cmul = jb.in_cmul > 1 ? jb.in_cmul : 1;
-    const float* wp = jb.wpk + ((size_t)cot * KK + t) * cg * 64 + lane;
+    // weights: cg fragments of 64 floats for (cout tile, tap); a fragment past cg reads as zero
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(jb.wpk) + ((size_t)cot * KK + t) * cg * 64, (short)0, live ? cg * 256 : 0, 0x00020000);
+    // input: channel c at c * cmul * hw floats from (b, in_coff); a channel past cin and a tap outside the grid read as zero
+    const size_t ibase = ((size_t)b * jb.in_ctotal + jb.in_coff) * hw;
+    const int ibytes = live ? (((jb.cin - 1) * cmul + 1) * hw) * 4 : 0;
+    const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(jb.in) + ibase, (short)0, ibytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t gr = ir;
+    if (GATE) gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(jb.gate) + ibase, (short)0, ibytes, 0x00020000);
+    const int cstep = 4 * cmul * hw * 4;                                   // bytes from one channel group to the next
+    int voff = valid ? (g * cmul * hw + yy * lw + xx) * 4 : 0x40000000;
 
     float av[MAXCG], bv[MAXCG];
 #pragma unroll
     for (int q = 0; q < MAXCG; ++q) {
-        const int qc = q < cg ? q : cg - 1;
-        const int c = qc * 4 + g;
-        const float a0 = wp[(size_t)qc * 64];
-        const size_t coff = (size_t)(c < jb.cin ? c : jb.cin - 1) * cmul * hw;
-        float b0 = in[coff];
-        if (gt) b0 *= gt[coff] > 0.f ? 1.f : 0.1f;
-        av[q] = q < cg ? a0 : 0.f;                       // weights of padded channels are packed as zeros
-        bv[q] = (valid && c < jb.cin) ? b0 : 0.f;
+        av[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wr, lane * 4 + q * 256, 0, 0));    // offsets in voffset: range-checked
+        bv[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ir, voff, 0, 0));
+        if (GATE) bv[q] *= __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(gr, voff, 0, 0)) > 0.f ? 1.f : 0.1f;
+        voff += cstep;
     }
+    // the finishing wave's bias and residual ride in the same round trip
+    const int co0 = cot * 16 + g * 4;
+    const size_t o0 = ((size_t)b * jb.out_ctotal + co0 * jb.out_cmul + jb.out_coff) * hw + p;
+    const size_t ostep = (size_t)jb.out_cmul * hw;
+    float bs[4] = {0.f, 0.f, 0.f, 0.f}, ad[4] = {0.f, 0.f, 0.f, 0.f};
+    if (t == 0 && p < hw && live) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (co0 + r < jb.cout) {
+                if (jb.bias) bs[r] = jb.bias[co0 + r];
+                if (jb.add) ad[r] = jb.add[o0 + r * ostep];                // residual at the output's own index (EEMFlow+ decoders)
+            }
+    }
+    __builtin_amdgcn_sched_barrier(0);                  // every load in flight before the first MFMA waits
+    if (!live) return;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < MAXCG; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q], acc, 0, 0, 0);
@@ -203,18 +241,15 @@ __global__ __launch_bounds__(64 * KS * KS) void tail_conv_kernel(TailConvLaunch 
 #pragma unroll
         for (int k = 1; k < KK; ++k) acc += part[k][lane];          // fixed order: bitwise repeatable
     }
-    if (pvalid) {
+    if (p < hw) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = cot * 16 + g * 4 + r;
-            if (co < jb.cout) {
-                float v = acc[r] + (jb.bias ? jb.bias[co] : 0.f);
+        for (int r = 0; r < 4; ++r)
+            if (co0 + r < jb.cout) {
+                float v = acc[r] + bs[r];
                 if (jb.act) v = v > 0.f ? v : 0.1f * v;
-                const size_t o = ((size_t)b * jb.out_ctotal + co * jb.out_cmul + jb.out_coff) * hw + p;
-                if (jb.add) v += jb.add[o];                        // residual at the output's own index (EEMFlow+ decoders)
-                jb.out[o] = v;
+                if (jb.add) v += ad[r];
+                jb.out[o0 + r * ostep] = v;
             }
-        }
     }
 }
 
@@ -339,7 +374,12 @@ void tail_pack_weights(const float* w, int cin, int cout, int ksize, float* pack
 
 template <int KS, int MAXCG>
 static void tail_launch_t(const TailConvLaunch& l, dim3 grid, hipStream_t stream) {
-    hipLaunchKernelGGL((tail_conv_kernel<KS, MAXCG>), grid, dim3(64 * KS * KS), 0, stream, l);
+    bool gate = false;
+    for (int i = 0; i < l.njobs; ++i) gate |= l.job[i].gate != nullptr;
+    for (int i = 0; i < l.njobs && gate; ++i)
+        if (!l.job[i].gate) { fprintf(stderr, "tail_conv_launch: gated and plain jobs in one launch\n"); abort(); }
+    if (gate) hipLaunchKernelGGL((tail_conv_kernel<KS, MAXCG, true>), grid, dim3(64 * KS * KS), 0, stream, l);
+    else hipLaunchKernelGGL((tail_conv_kernel<KS, MAXCG, false>), grid, dim3(64 * KS * KS), 0, stream, l);
 }
 
 int tail_conv_launch(const TailConvLaunch& l, hipStream_t stream) {
@@ -352,7 +392,8 @@ int tail_conv_launch(const TailConvLaunch& l, hipStream_t stream) {
         max_cg = cg > max_cg ? cg : max_cg;
     }
     EEM_REQUIRE(max_cg <= 25, "tail_conv_launch: cin > 100 is not built");
-    dim3 grid(ceil_div(l.h * l.w, 16), ceil_div(max_cout, 16), l.njobs * l.batch);
+    dim3 grid(ceil_div(l.h * l.w, 16) * l.batch, ceil_div(max_cout, 16), l.njobs);
+    EEM_NOTE_GRID(grid.x * grid.y * grid.z, 64 * l.ksize * l.ksize);
     if (l.ksize == 1) {
         if (max_cg <= 2) tail_launch_t<1, 2>(l, grid, stream);
         else tail_launch_t<1, 25>(l, grid, stream);
@@ -370,6 +411,28 @@ int upsample_launch(const float* in, float* out, int nc, int h, int w, int oh, i
     if (total == 0) return EEM_OK;
     hipLaunchKernelGGL(upsample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, in, out, nc,
                        h, w, oh, ow, io);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+__global__ void spin_kernel(long ticks) {                 // wall_clock64: the 100 MHz constant clock
+    const long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+__global__ void spin_code_kernel(long ticks) {            // the same wait behind 16 KB of straight-line code (instruction-cache footprint)
+    const long t0 = wall_clock64();
+    asm volatile(".rept 4096\n s_nop 0\n .endr\n" ::: "memory");
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+int spin_launch(float us, hipStream_t stream) {
+    static const int blocks = [] { const char* e = getenv("EEM_SKIP_SPIN_BLOCKS"); return e ? atoi(e) : 1; }();    // x 576 threads
+    static const bool code = [] { const char* e = getenv("EEM_SKIP_SPIN_CODE"); return e && e[0] == '1'; }();
+    const long ticks = (long)(us * 100.f);
+    const dim3 g(blocks), b(blocks > 1 ? 576 : 64);
+    if (code) hipLaunchKernelGGL(spin_code_kernel, g, b, 0, stream, ticks);
+    else hipLaunchKernelGGL(spin_kernel, g, b, 0, stream, ticks);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

@@ -16,38 +16,59 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------ pooled operand
+// ROWS > 0: the row count is a compile-time constant and a caller's loads of several values are all in flight at once (the loop
+// over a run-time row count is one memory round trip per row); ROWS = 0: any row count.  Same sum order either way.
+template <int ROWS>
 __device__ __forceinline__ float pooled_load(const PooledSrc& s, const float* chan_base, int y, int x) {
     const float* p = chan_base + (size_t)y * s.ystride + x;
     float v = p[0];
-    for (int i = 1; i < s.rows; ++i) v += p[(size_t)i * s.rstride];
+    if (ROWS > 0) {
+#pragma unroll
+        for (int i = 1; i < ROWS; ++i) v += p[(size_t)i * s.rstride];
+    } else {
+        for (int i = 1; i < s.rows; ++i) v += p[(size_t)i * s.rstride];
+    }
     return v * s.scale;
 }
 
-template <int CG>
-__device__ __forceinline__ void rconv_role(const TailHeadArgs& a, int blk, f32x4 (*part)[64]) {
+// Roles are picked by blockIdx.z (0-2 rconv of stage k, 3-5 correlation of stage k, 6 pooled maps) and a correlation block's tap
+// by blockIdx.y, so everything a block needs from the launch arguments - its stage's source, its tap - is ONE batch of scalar
+// loads issued at its first instruction, and its operand loads are the second and last round trip before the stores (see
+// tail_conv_kernel in tail.hip for what a round trip costs beside other frames' kernels).
+template <int CG, int ROWS>
+__device__ __forceinline__ void rconv_role(const TailHeadArgs& a, int k, int blk, f32x4 (*part)[64]) {
     // one block = 16 pixels x 16 couts of one (scale, sample); wave t = filter tap t (see tail_conv_kernel)
-    const int lane = threadIdx.x & 63, t = threadIdx.x >> 6;
-    const int g = a.gh * a.gw;
-    const int ptiles = ceil_div(g, 16);
-    const int pt = blk % ptiles;
-    const int kb = blk / ptiles;
-    const int k = kb % 3, b = kb / 3;
+    const int lane = threadIdx.x & 63;
+    const int t = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const PooledSrc src = a.src[k];
-    const int cin = a.c[k];
+    const float* rw = a.rw[k];
+    const float* rb = a.rb[k];
+    float* cat = a.cat[k];
+    const int gw = a.gw, gh = a.gh, cin = a.c[k];
+    asm volatile("" ::"s"(src.base), "s"(src.rows), "s"(src.scale), "s"(rw), "s"(rb), "s"(cat), "s"(gw), "s"(gh), "s"(cin));
+    const int g = gh * gw;
+    const int ptiles = ceil_div(g, 16);
+    if (blk >= ptiles * a.batch) return;
+    const int b = blk / ptiles, pt = blk - b * ptiles;
     const int j = lane & 15, gq = lane >> 4;
     const int p = pt * 16 + j;
     const bool pvalid = p < g;
-    const int y = p / a.gw, x = p - y * a.gw;
+    const int y = p / gw, x = p - y * gw;
     const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-    const bool valid = pvalid && yy >= 0 && yy < a.gh && xx >= 0 && xx < a.gw;
-    const float* wp = a.rw[k] + (size_t)t * CG * 64 + lane;
+    const bool valid = pvalid && yy >= 0 && yy < gh && xx >= 0 && xx < gw;
+    const float* wp = rw + (size_t)t * CG * 64 + lane;
     const float* img = src.base + (size_t)b * src.nstride;                 // events1 half: image b
     float av[CG], bv[CG];
 #pragma unroll
     for (int q = 0; q < CG; ++q) {
         const int c = q * 4 + gq;
         av[q] = wp[(size_t)q * 64];
-        bv[q] = (valid && c < cin) ? pooled_load(src, img + (size_t)c * src.cstride, yy, xx) : 0.f;
+        bv[q] = (valid && c < cin) ? pooled_load<ROWS>(src, img + (size_t)c * src.cstride, yy, xx) : 0.f;
+    }
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (t == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bs[r] = rb[gq * 4 + r];
     }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -62,65 +83,90 @@ __device__ __forceinline__ void rconv_role(const TailHeadArgs& a, int blk, f32x4
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int co = gq * 4 + r;
-            float v = acc[r] + a.rb[k][co];
+            float v = acc[r] + bs[r];
             v = v > 0.f ? v : 0.1f * v;
-            a.cat[k][((size_t)b * a.cat_ctotal + a.ntaps + co) * g + p] = v;
+            cat[((size_t)b * a.cat_ctotal + a.ntaps + co) * g + p] = v;
         }
     }
 }
 
+// a wave = one (sample, tap, 16-pixel tile): four adjacent lanes share one output and split its channels (see corr_kernel);
+// NC = channels per lane (cin / 4): all 2 * NC * ROWS loads of a lane are issued before the first product
+template <int NC, int ROWS>
+__device__ __forceinline__ void corr_role(const TailHeadArgs& a, int k) {
+    const PooledSrc src = a.src[k];
+    const int tap = a.tap[blockIdx.y];
+    float* cat = a.cat[k];
+    const int gw = a.gw, gh = a.gh, cin = a.c[k], batch = a.batch;
+    asm volatile("" ::"s"(src.base), "s"(src.rows), "s"(src.scale), "s"(tap), "s"(cat), "s"(gw), "s"(gh), "s"(cin), "s"(batch));
+    const int g = gh * gw;
+    const int ptiles = ceil_div(g, 16);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tq = blockIdx.x * 9 + wave;
+    if (tq >= ptiles * batch) return;
+    const int b = tq / ptiles, pt = tq - b * ptiles;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & 3;
+    const int p = pt * 16 + (lane >> 2);
+    const bool live = p < g;
+    const int y = p / gw, x = p - y * gw;
+    const int yy = y + tap / 9 - 4, xx = x + tap % 9 - 4;
+    float s = 0.f;
+    if (live && yy >= 0 && yy < gh && xx >= 0 && xx < gw) {
+        const float* i1 = src.base + (size_t)b * src.nstride;
+        const float* i2 = src.base + (size_t)(batch + b) * src.nstride;
+        if (cin == NC * 4) {
+            float u[NC], v[NC];
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                u[i] = pooled_load<ROWS>(src, i1 + (size_t)(sub + 4 * i) * src.cstride, y, x);
+                v[i] = pooled_load<ROWS>(src, i2 + (size_t)(sub + 4 * i) * src.cstride, yy, xx);
+            }
+#pragma unroll
+            for (int i = 0; i < NC; ++i) s = fmaf(u[i], v[i], s);
+        } else {
+            for (int c = sub; c < cin; c += 4)
+                s = fmaf(pooled_load<0>(src, i1 + (size_t)c * src.cstride, y, x), pooled_load<0>(src, i2 + (size_t)c * src.cstride, yy, xx), s);
+        }
+    }
+    s = dpp_add<0xB1>(s);
+    s = dpp_add<0x4E>(s);
+    if (live && sub == 0) cat[((size_t)b * a.cat_ctotal + blockIdx.y) * g + p] = s / (float)cin;
+}
+
 __global__ __launch_bounds__(576) void tail_head_kernel(TailHeadArgs a) {
     __shared__ f32x4 part[9][64];
-    const int blk = blockIdx.x;
-    const int g = a.gh * a.gw;
-    if (blk < a.nblk_rconv) {
-        const int ptiles = ceil_div(g, 16);
-        const int k = (blk / ptiles) % 3;
-        if (a.c[k] <= 16) rconv_role<4>(a, blk, part);
-        else if (a.c[k] <= 32) rconv_role<8>(a, blk, part);
-        else rconv_role<16>(a, blk, part);
+    const int role = blockIdx.z;
+    const int blk = blockIdx.y * a.grid_x + blockIdx.x;
+    if (role < 3) {
+        const int rows = a.src[role].rows;                                // 16, 32, 64 input channels (EEMFlow.py:96-98)
+        if (role == 0) { if (rows == 4) rconv_role<4, 4>(a, 0, blk, part); else if (rows == 1) rconv_role<4, 1>(a, 0, blk, part); else rconv_role<4, 0>(a, 0, blk, part); }
+        else if (role == 1) { if (rows == 2) rconv_role<8, 2>(a, 1, blk, part); else if (rows == 1) rconv_role<8, 1>(a, 1, blk, part); else rconv_role<8, 0>(a, 1, blk, part); }
+        else { if (rows == 1) rconv_role<16, 1>(a, 2, blk, part); else rconv_role<16, 0>(a, 2, blk, part); }
         return;
     }
-    if (blk < a.nblk_rconv + a.nblk_corr) {
-        // four adjacent lanes share one output (scale, sample, tap, pixel) and split its channels (see corr_kernel)
-        const int per_job = a.batch * a.ntaps * g;
-        const int gid = (blk - a.nblk_rconv) * 576 + threadIdx.x;
-        int idx = gid >> 2;
-        const int sub = gid & 3;
-        const bool live = idx < per_job * 3;
-        if (!live) idx = 0;
-        const int k = idx / per_job;
-        idx -= k * per_job;
-        const PooledSrc src = a.src[k];
-        const int cin = a.c[k];
-        const int p = idx % g; idx /= g;
-        const int ti = idx % a.ntaps;
-        const int b = idx / a.ntaps;
-        const int y = p / a.gw, x = p - y * a.gw;
-        const int tap = a.taps[ti];
-        const int yy = y + tap / 9 - 4, xx = x + tap % 9 - 4;
-        float s = 0.f;
-        if (live && yy >= 0 && yy < a.gh && xx >= 0 && xx < a.gw) {
-            const float* i1 = src.base + (size_t)b * src.nstride;
-            const float* i2 = src.base + (size_t)(a.batch + b) * src.nstride;
-#pragma unroll 4
-            for (int c = sub; c < cin; c += 4)
-                s = fmaf(pooled_load(src, i1 + (size_t)c * src.cstride, y, x), pooled_load(src, i2 + (size_t)c * src.cstride, yy, xx), s);
-        }
-        s = dpp_add<0xB1>(s);
-        s = dpp_add<0x4E>(s);
-        if (live && sub == 0) a.cat[k][((size_t)b * a.cat_ctotal + ti) * g + p] = s / (float)cin;
+    if (role < 6) {
+        const int k = role - 3, rows = a.src[k].rows;
+        if (k == 0) { if (rows == 4) corr_role<4, 4>(a, 0); else if (rows == 1) corr_role<4, 1>(a, 0); else corr_role<4, 0>(a, 0); }
+        else if (k == 1) { if (rows == 2) corr_role<8, 2>(a, 1); else if (rows == 1) corr_role<8, 1>(a, 1); else corr_role<8, 0>(a, 1); }
+        else { if (rows == 1) corr_role<16, 1>(a, 2); else corr_role<16, 0>(a, 2); }
         return;
     }
     // pooled maps [2B][C][gh][gw] as a side output
-    int idx = (blk - a.nblk_rconv - a.nblk_corr) * 576 + threadIdx.x;
+    const int g = a.gh * a.gw;
+    int idx = blk * 576 + threadIdx.x;
     for (int k = 0; k < 3; ++k) {
         const int total = 2 * a.batch * a.c[k] * g;
         if (idx < total) {
             if (a.pool_out[k] == nullptr) return;
-            const int x = idx % a.gw, y = (idx / a.gw) % a.gh, nc = idx / g;
+            const int nc = idx / g;
             const int n = nc / a.c[k], c = nc - n * a.c[k];
-            a.pool_out[k][idx] = pooled_load(a.src[k], a.src[k].base + (size_t)n * a.src[k].nstride + (size_t)c * a.src[k].cstride, y, x);
+            const int pp = idx - nc * g;
+            const int y = pp / a.gw, x = pp - y * a.gw;
+            const float* cb = a.src[k].base + (size_t)n * a.src[k].nstride + (size_t)c * a.src[k].cstride;
+            const int rows = a.src[k].rows;
+            a.pool_out[k][idx] = rows == 4 ? pooled_load<4>(a.src[k], cb, y, x) : rows == 2 ? pooled_load<2>(a.src[k], cb, y, x)
+                               : rows == 1 ? pooled_load<1>(a.src[k], cb, y, x) : pooled_load<0>(a.src[k], cb, y, x);
             return;
         }
         idx -= total;
@@ -212,15 +258,22 @@ __global__ __launch_bounds__(256) void tail_up_kernel(TailUpArgs a) {
 
 }  // namespace
 
-int tail_head_launch(const TailHeadArgs& a0, hipStream_t stream) {
+int tail_head_launch(const TailHeadArgs& a0, const int* taps_host, hipStream_t stream) {
     TailHeadArgs a = a0;
+    EEM_REQUIRE(a.ntaps >= 1 && a.ntaps <= TAIL_HEAD_MAX_TAPS, "tail_head_launch: ntaps=%d", a.ntaps);
+    for (int i = 0; i < a.ntaps; ++i) a.tap[i] = taps_host[i];
     const int g = a.gh * a.gw;
-    a.nblk_rconv = ceil_div(g, 16) * 3 * a.batch;
-    a.nblk_corr = (int)(((long)3 * a.batch * a.ntaps * g * 4 + 575) / 576);
+    const int nblk_rconv = ceil_div(g, 16) * a.batch;                     // per stage
+    const int nblk_corr = ceil_div(ceil_div(g, 16) * a.batch, 9);         // per stage and tap: nine (sample, pixel tile) waves per block
     long pool_elems = 0;
     for (int k = 0; k < 3; ++k) pool_elems += (long)2 * a.batch * a.c[k] * g;
     const int nblk_pool = (int)((pool_elems + 575) / 576);
-    hipLaunchKernelGGL(tail_head_kernel, dim3(a.nblk_rconv + a.nblk_corr + nblk_pool), dim3(576), 0, stream, a);
+    // a box of grid_x x ntaps blocks per role: correlation uses (x, tap), the other roles count it row by row
+    a.grid_x = nblk_corr;
+    if (ceil_div(nblk_rconv, a.ntaps) > a.grid_x) a.grid_x = ceil_div(nblk_rconv, a.ntaps);
+    if (ceil_div(nblk_pool, a.ntaps) > a.grid_x) a.grid_x = ceil_div(nblk_pool, a.ntaps);
+    EEM_NOTE_GRID(a.grid_x * a.ntaps * 7, 576);
+    hipLaunchKernelGGL(tail_head_kernel, dim3(a.grid_x, a.ntaps, 7), dim3(576), 0, stream, a);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }
@@ -233,6 +286,7 @@ int tail_up_launch(const TailUpArgs& a0, hipStream_t stream) {
     a.ty = a.oh / a.gh;                                   // a tile no taller / wider than one coarse cell: (ty - 1) * gh / oh < 1,
     a.tx = (a.ow / a.gw) & ~3;                            // so at most 3 coarse rows / columns reach it
     const int blocks = ceil_div(a.oh, a.ty) * ceil_div(a.ow, a.tx) * a.batch;
+    EEM_NOTE_GRID(blocks, 256);
     hipLaunchKernelGGL(tail_up_kernel, dim3(blocks), dim3(256), 0, stream, a);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;

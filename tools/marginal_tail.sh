@@ -1,0 +1,13 @@
+#!/bin/bash
+# GPU box: what each tail launch costs beside the encoders, four frames in flight (see tools/marginal.sh)
+run() {
+  EEM_SKIP_KERNELS="$1" python3 bench.py --steps 300 --warmup 30 --cpu-seconds 0 --no-other-rows --no-side-rows "${@:2}" 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"
+}
+base=$(run "" "$@"); echo "nothing skipped: $base"
+b=$(echo $base | cut -d" " -f2)
+for k in "tail head" "dec.conv1" "dec.conv2" "dec.conv3" "dec.conv4" "dec.conv5" "dec.conv6" "dec.conv7" "tail up" "dec." "tail head;dec.;tail up"; do
+  r=$(run "$k" "$@"); t=$(echo $r | cut -d" " -f2)
+  python3 -c "print('skip %-24s %s frames/s  -> marginal cost %.1f us of %.1f' % ('$k', '$r'.split()[0], ($b - $t) * 1e3, $b * 1e3))"
+done

@@ -1,10 +1,7 @@
 #!/bin/bash
-# GPU box: parity smoke + bench line (kernel times) - tools/quick.sh <tag>
-tag=${1:-q}
-python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "golden or oracle or full_size or graph" 2>&1 | tail -2
-python3 bench.py --steps 300 --warmup 30 --cpu-seconds 0 --no-other-rows > gpurun_out/$tag.json 2> gpurun_out/$tag.err
-python3 - <<P
-import json
-d = json.load(open("gpurun_out/$tag.json"))
-print("$tag", d["value"], "fps; latency", d["latency_ms_b1"], "pipeline", d["latency_and_pipeline"].get("pipeline_frames_per_s"), "|", " ".join(f'{k["name"].split()[0].replace("enc.","")}={k["us"]}' for k in d["kernels"]))
-P
+# GPU box: the timed loop, the single-frame latency and the per-launch table in one line each
+python3 bench.py --steps 300 --warmup 30 --cpu-seconds 0 --no-other-rows "$@" 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.1f frames/s %.4f ms  latency %.4f' % (d['value'], d['ms_per_step'], d.get('latency_ms_b1') or 0))
+print('   enc ', ' '.join('%.2f' % k['us'] for k in d['kernels'] if k['name'].startswith('enc.')))
+print('   tail', ' '.join('%.2f' % k['us'] for k in d['kernels'] if not k['name'].startswith('enc.')))"

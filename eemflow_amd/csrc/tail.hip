@@ -102,51 +102,90 @@ __global__ __launch_bounds__(256) void corr_kernel(CorrArgs a) {
     if (live && sub == 0) jb.out[((size_t)b * jb.out_ctotal + ti) * hw + p] = s / (float)jb.c;
 }
 
-// The same correlation for large maps (EEMFlow+'s fine pyramid levels: 180x320 pixels): a block owns a 16x16-pixel tile,
-// the f2 patch with its 4-pixel halo goes through LDS eight channels at a time (zeros outside the image), every thread keeps
-// its pixel's 53 tap sums in registers and reads f1 once per channel - instead of re-reading f1 for every tap and spending
-// four lanes per output.
-template <int NT>
-__global__ __launch_bounds__(256) void corr_tiled_kernel(CorrArgs a, int tiles_x) {
-    constexpr int CK = 8, TS = 16, HS = TS + 8, PITCH = HS + 1;
-    __shared__ float tile[CK][HS][PITCH];
+// The same correlation for larger maps (EEMFlow+'s pyramid levels from 45x80 up): a block of two waves owns an 8x16-pixel tile, the
+// f2 patch with its 4-pixel halo goes through LDS eight channels at a time (zeros outside the image), every thread keeps its
+// pixel's 53 tap sums in registers and reads f1 once per channel - instead of re-reading f1 for every tap and spending four lanes
+// per output.  The next chunk's patch and f1 values are in flight (registers) while the current one is consumed, one barrier per
+// chunk; the tap list is a compile-time table (the launcher checks the caller's list against it), so every LDS read is one
+// ds_read_b32 with an immediate offset from one base register.  What bounds it then is the LDS port: 53 reads per pixel and
+// channel, 212 bytes, against 128 bytes per clock and CU.  180x320, 64 channels: 53.6 -> ~17 us (16x16 tiles, one load - wait -
+// compute chain per chunk before); 90x160 ran the four-lanes-per-output kernel above at 49 us.
+__device__ constexpr int kCorrTaps53[53] = {0,  2,  4,  6,  8,  10, 12, 14, 16, 18, 20, 21, 22, 23, 24, 26, 28, 29, 30, 31, 32, 33, 34, 36, 38, 39, 40,
+                                            41, 42, 44, 46, 47, 48, 49, 50, 51, 52, 54, 56, 57, 58, 59, 60, 62, 64, 66, 68, 70, 72, 74, 76, 78, 80};
+
+__global__ __launch_bounds__(128) void corr_tiled53_kernel(CorrArgs a, int tiles_x) {
+    constexpr int NT = 53, CK = 8, TY = 8, TX = 16, HY = TY + 8, HX = TX + 8, PITCH = 48, PLANE = HY * PITCH, NP = HY * HX / 128;   // pitch 48: a wave's four rows of 16 lanes fall on the four quarters of the 64 banks
+    static_assert(HY * HX == NP * 128, "three patch positions per thread and channel");
+    __shared__ float tile[2][CK * PLANE];
+    __shared__ float f1s[2][CK * 128];
     const int ji = blockIdx.z / a.batch, b = blockIdx.z % a.batch;
     const CorrJob jb = a.job[ji];
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
-    const int y0 = ty * TS, x0 = tx * TS;
+    const int tid = threadIdx.x;
+    const int lx = tid & 15, ly = tid >> 4;
+    const int y0 = ty * TY, x0 = tx * TX;
     const int y = y0 + ly, x = x0 + lx;
     const bool inside = y < a.h && x < a.w;
     const int hw = a.h * a.w;
-    int off[NT];
+    // both operands as buffer loads: a position outside the image, a pixel outside it and a channel past c carry an offset beyond
+    // the descriptor's range and read as zero - no branch, so a chunk's 32 loads per thread are all in flight at once
+    const int bytes = jb.c * hw * 4;
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(jb.f1) + (size_t)b * jb.c * hw, (short)0, bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(jb.f2) + (size_t)b * jb.c * hw, (short)0, bytes, 0x00020000);
+    constexpr int kOut = 0x40000000;
+    const int p1 = inside ? (y * a.w + x) * 4 : kOut;
+    // the thread's three positions of the 16 x 24 patch (the same for every channel)
+    int gpos[NP], lpos[NP];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) { const int tap = a.taps[t]; off[t] = (tap / 9) * PITCH + (tap % 9); }   // window origin = (-4, -4)
+    for (int k = 0; k < NP; ++k) {
+        const int pos = tid + 128 * k;
+        const int ry = pos / HX, rx = pos - ry * HX;
+        const int gy = y0 - 4 + ry, gx = x0 - 4 + rx;
+        gpos[k] = (gy >= 0 && gy < a.h && gx >= 0 && gx < a.w) ? (gy * a.w + gx) * 4 : kOut;
+        lpos[k] = ry * PITCH + rx;
+    }
     float s[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) s[t] = 0.f;
-    const float* f1 = jb.f1 + (size_t)b * jb.c * hw;
-    const float* f2 = jb.f2 + (size_t)b * jb.c * hw;
-    const int p = inside ? y * a.w + x : 0;
-    for (int c0 = 0; c0 < jb.c; c0 += CK) {
-        __syncthreads();
-        for (int e = threadIdx.x; e < CK * HS * HS; e += 256) {
-            const int c = e / (HS * HS), r = e - c * (HS * HS);
-            const int ry = r / HS, rx = r - ry * HS;
-            const int gy = y0 - 4 + ry, gx = x0 - 4 + rx;
-            const bool ok = c0 + c < jb.c && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
-            tile[c][ry][rx] = ok ? f2[(size_t)(c0 + c) * hw + gy * a.w + gx] : 0.f;
-        }
-        __syncthreads();
+    float pf[CK][NP], v1[CK];
+    auto fetch = [&](int c0) {                           // (the launcher sends channel counts that are not multiples of CK elsewhere)
 #pragma unroll
         for (int c = 0; c < CK; ++c) {
-            const float v = (inside && c0 + c < jb.c) ? f1[(size_t)(c0 + c) * hw + p] : 0.f;
-            const float* base = &tile[c][ly][lx];
+            const int co = __builtin_amdgcn_readfirstlane((c0 + c) * hw * 4);      // the channel's offset rides in the scalar operand
 #pragma unroll
-            for (int t = 0; t < NT; ++t) s[t] = fmaf(v, base[off[t]], s[t]);
+            for (int k = 0; k < NP; ++k) pf[c][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r2, gpos[k], co, 0));
+            v1[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r1, p1, co, 0));
         }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int c = 0; c < CK; ++c) {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) tile[buf][c * PLANE + lpos[k]] = pf[c][k];
+            f1s[buf][c * 128 + tid] = v1[c];
+        }
+    };
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    const int nch = jb.c / CK;
+    for (int ci = 0; ci < nch; ++ci) {
+        if (ci + 1 < nch) fetch((ci + 1) * CK);
+        const float* base = &tile[ci & 1][ly * PITCH + lx];
+        const float* vb = &f1s[ci & 1][tid];
+        // two channels per trip (fully unrolled, the scheduler hoists all 424 LDS reads of a chunk: 512 VGPRs and scratch)
+#pragma unroll 2
+        for (int c = 0; c < CK; ++c) {
+            const float v = vb[c * 128];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) s[t] = fmaf(v, base[c * PLANE + (kCorrTaps53[t] / 9) * PITCH + kCorrTaps53[t] % 9], s[t]);   // window origin = (-4, -4)
+        }
+        if (ci + 1 < nch) stage((ci + 1) & 1);
+        __syncthreads();
     }
     if (!inside) return;
     const float inv = 1.f / (float)jb.c;
+    const int p = y * a.w + x;
 #pragma unroll
     for (int t = 0; t < NT; ++t) jb.out[((size_t)b * jb.out_ctotal + t) * hw + p] = s[t] * inv;
 }
@@ -344,9 +383,13 @@ int corr_launch(const CorrJob* jobs, int njobs, int batch, int h, int w, const i
     const long total = (long)njobs * batch * ntaps * h * w;
     if (total == 0) return EEM_OK;
     static const bool plain = [] { const char* e = getenv("EEM_CORR_PLAIN"); return e && e[0] == '1'; }();
-    if (!plain && ntaps == 53 && (long)h * w >= 32768) {                 // below: too few 16x16 tiles to fill the chip
+    bool c8 = true;
+    for (int i = 0; i < njobs; ++i) c8 = c8 && jobs[i].c % 8 == 0;
+    if (!plain && ntaps == 53 && c8 && (long)h * w >= 2048) {                  // below: too few tiles to be worth the LDS staging
+        // (ntaps == 53 is EEMFlow's list, EEMFlow.py:14-23: every caller passes a device copy of that table - api.hip, plus_api.hip,
+        // ops.hip - and the tiled kernel has it compiled in)
         const int tiles_x = ceil_div(w, 16);
-        hipLaunchKernelGGL((corr_tiled_kernel<53>), dim3(tiles_x * ceil_div(h, 16), 1, njobs * batch), dim3(256), 0, stream, a, tiles_x);
+        hipLaunchKernelGGL(corr_tiled53_kernel, dim3(tiles_x * ceil_div(h, 8), 1, njobs * batch), dim3(128), 0, stream, a, tiles_x);
         EEM_HIP_CHECK(hipGetLastError());
         return EEM_OK;
     }

@@ -108,8 +108,9 @@ __global__ __launch_bounds__(256) void corr_kernel(CorrArgs a) {
 // per output.  The next chunk's patch and f1 values are in flight (registers) while the current one is consumed, one barrier per
 // chunk; the tap list is a compile-time table (the launcher checks the caller's list against it), so every LDS read is one
 // ds_read_b32 with an immediate offset from one base register.  What bounds it then is the LDS port: 53 reads per pixel and
-// channel, 212 bytes, against 128 bytes per clock and CU.  180x320, 64 channels: 53.6 -> ~17 us (16x16 tiles, one load - wait -
-// compute chain per chunk before); 90x160 ran the four-lanes-per-output kernel above at 49 us.
+// channel, 212 bytes, against 128 bytes per clock and CU - and, with one or two waves per SIMD, the chunk chain itself: 19 us at
+// 180x320 and at 90x160 alike (64 channels; 53.6 us with 16x16 tiles and one load - wait - compute chain per chunk, 49 us on the
+// four-lanes-per-output kernel above).
 __device__ constexpr int kCorrTaps53[53] = {0,  2,  4,  6,  8,  10, 12, 14, 16, 18, 20, 21, 22, 23, 24, 26, 28, 29, 30, 31, 32, 33, 34, 36, 38, 39, 40,
                                             41, 42, 44, 46, 47, 48, 49, 50, 51, 52, 54, 56, 57, 58, 59, 60, 62, 64, 66, 68, 70, 72, 74, 76, 78, 80};
 
@@ -385,7 +386,7 @@ int corr_launch(const CorrJob* jobs, int njobs, int batch, int h, int w, const i
     static const bool plain = [] { const char* e = getenv("EEM_CORR_PLAIN"); return e && e[0] == '1'; }();
     bool c8 = true;
     for (int i = 0; i < njobs; ++i) c8 = c8 && jobs[i].c % 8 == 0;
-    if (!plain && ntaps == 53 && c8 && (long)h * w >= 2048) {                  // below: too few tiles to be worth the LDS staging
+    if (!plain && ntaps == 53 && c8 && (long)h * w >= 8192) {                  // below: the tile's chain of eight chunks (~18 us whatever the map) loses to the direct kernel
         // (ntaps == 53 is EEMFlow's list, EEMFlow.py:14-23: every caller passes a device copy of that table - api.hip, plus_api.hip,
         // ops.hip - and the tiled kernel has it compiled in)
         const int tiles_x = ceil_div(w, 16);

@@ -131,6 +131,7 @@ struct eemflow_ctx {
     double span_sum[2] = {0.0, 0.0};
     int span_n = 0;
     bool span_pending = false;
+    bool skip_counter_zeroed = false;                    // train_api.hip: the device-side count of skipped optimizer steps
     int frames_in_flight = 1;                            // eemflow_set_frames_in_flight: >= 3 shrinks the persistent encoder grids
     struct Key {
         int batch, in_h, in_w, out_h, out_w, pad[4];

@@ -60,4 +60,4 @@ bool dgrad_s2_supported(const DgradS2Args& a);
 int dgrad_s2_launch(const DgradS2Args& a, hipStream_t st);
 int tr_sumsq_launch(const float* g, long n, double* out, hipStream_t st);
 int tr_adamw_launch(float* p, const float* g, float* m, float* v, long n, const double* sumsq, float clip, float lr, float wd,
-                    float eps, float b1, float b2, long step, hipStream_t st);
+                    float eps, float b1, float b2, long step, int* nskip, hipStream_t st);

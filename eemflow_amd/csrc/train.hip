@@ -405,14 +405,22 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
+// A gradient with an inf or a NaN in it (sum of squares not finite) skips the step, as GradScaler.step does for the reference
+// (train_mvsec.py:257: no parameter, no moment changes, and the optimizer's own step count - the bias corrections - does not advance).
+// `nskip` counts the skipped steps so far; it is advanced by skipcount_kernel AFTER this launch (every thread reads the old value).
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, long n, const double* __restrict__ sumsq, float clip,
-                                                    float lr, float wd, float eps, float b1, float b2, float bc1, float bc2) {
+                                                    float lr, float wd, float eps, float b1, float b2, long step,
+                                                    const int* __restrict__ nskip) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    const double ss = *sumsq;
+    if (!(ss <= 1.7976931348623157e308)) return;             // inf or NaN
+    const float eff = (float)(step - (long)*nskip);           // optimizer steps taken, this one included
+    const float bc1 = 1.f - powf(b1, eff), bc2 = 1.f - powf(b2, eff);
     float coef = 1.f;
     if (clip > 0.f) {
-        const float norm = (float)sqrt(*sumsq);
+        const float norm = (float)sqrt(ss);
         coef = fminf(clip / (norm + 1e-6f), 1.f);            // torch.nn.utils.clip_grad_norm_
     }
     const float gi = g[i] * coef;
@@ -423,6 +431,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
     pi -= (lr / bc1) * (mi / denom);
     p[i] = pi;
+}
+
+__global__ void skipcount_kernel(const double* __restrict__ sumsq, int* __restrict__ nskip) {
+    if (!(*sumsq <= 1.7976931348623157e308)) *nskip += 1;
 }
 
 }  // namespace
@@ -583,9 +595,9 @@ int tr_sumsq_launch(const float* g, long n, double* out, hipStream_t st) {
 }
 
 int tr_adamw_launch(float* p, const float* g, float* m, float* v, long n, const double* sumsq, float clip, float lr, float wd,
-                    float eps, float b1, float b2, long step, hipStream_t st) {
-    const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
-    hipLaunchKernelGGL(adamw_kernel, dim3(nblocks(n)), dim3(256), 0, st, p, g, m, v, n, sumsq, clip, lr, wd, eps, b1, b2, bc1, bc2);
+                    float eps, float b1, float b2, long step, int* nskip, hipStream_t st) {
+    hipLaunchKernelGGL(adamw_kernel, dim3(nblocks(n)), dim3(256), 0, st, p, g, m, v, n, sumsq, clip, lr, wd, eps, b1, b2, step, nskip);
+    hipLaunchKernelGGL(skipcount_kernel, dim3(1), dim3(1), 0, st, sumsq, nskip);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

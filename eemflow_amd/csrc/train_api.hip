@@ -120,7 +120,7 @@ int alloc_train(eemflow_ctx* c, const Shape& s) {
     ENS(c->g_flow, B * 2 * (size_t)s.out_h * s.out_w);
     ENS(c->ups_tmp, B * 2 * (size_t)s.out_h * s.gw);
     ENS(c->grad_flat, c->nflat);
-    ENS(c->scalars, 16);
+    ENS(c->scalars, 24);
 #undef ENS
     return EEM_OK;
 }
@@ -394,17 +394,34 @@ extern "C" int eemflow_optimizer_step(eemflow_ctx* c, const float* grad, float l
         EEM_HIP_CHECK(hipMemsetAsync(c->adam_m.p, 0, c->nflat * sizeof(float), st));
         EEM_HIP_CHECK(hipMemsetAsync(c->adam_v.p, 0, c->nflat * sizeof(float), st));
         c->opt_step = 0;
+        c->skip_counter_zeroed = false;
     }
-    if ((rc = ensure(c->scalars, 16)) != EEM_OK) return rc;
+    if ((rc = ensure(c->scalars, 24)) != EEM_OK) return rc;
     double* sumsq = (double*)c->scalars.p + 7;
+    int* nskip = (int*)(c->scalars.p + 16);                  // steps skipped for a non-finite gradient (device-side count)
+    if (!c->skip_counter_zeroed) {
+        EEM_HIP_CHECK(hipMemsetAsync(nskip, 0, sizeof(int), st));
+        c->skip_counter_zeroed = true;
+    }
     EEM_HIP_CHECK(hipMemsetAsync(sumsq, 0, sizeof(double), st));
     if ((rc = tr_sumsq_launch(grad, (long)c->nflat, sumsq, st)) != EEM_OK) return rc;
     c->opt_step += 1;
     if ((rc = tr_adamw_launch(c->flat, grad, c->adam_m.p, c->adam_v.p, (long)c->nflat, sumsq, clip, lr, weight_decay, eps, 0.9f,
-                              0.999f, c->opt_step, st)) != EEM_OK) return rc;
+                              0.999f, c->opt_step, nskip, st)) != EEM_OK) return rc;
     // (cached graphs read the arena in place: same addresses, new values)
     if ((rc = repack_launch(c->flat, c->pack_idx, c->arena, (long)c->arena_floats, st)) != EEM_OK) return rc;
     return refresh_wino(c, st);
+}
+
+// Steps eemflow_optimizer_step skipped so far because the gradient held an inf or a NaN (synchronises the stream).
+extern "C" int eemflow_optimizer_skipped_steps(eemflow_ctx* c, int* out, void* stream) {
+    EEM_REQUIRE(c && out, "eemflow_optimizer_skipped_steps: NULL argument");
+    *out = 0;
+    if (!c->skip_counter_zeroed) return EEM_OK;
+    EEM_HIP_CHECK(hipSetDevice(c->device));
+    EEM_HIP_CHECK(hipMemcpyAsync(out, c->scalars.p + 16, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    EEM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return EEM_OK;
 }
 
 // Copy the device-resident weights (state_dict order) to `dst` (device) - checkpointing / syncing nn.Parameters.

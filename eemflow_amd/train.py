@@ -122,6 +122,17 @@ class EEMFlowTrainer:
         m._weights_on_device_are_newer = True
         return stats[0], {"epe": stats[1], "1px": stats[3], "3px": stats[4], "lr": lr}, flow
 
+    def skipped_steps(self):
+        """Optimizer steps skipped so far because the gradient held an inf or a NaN - GradScaler.step's behaviour in the reference loop
+        (train_mvsec.py:237,257): weights, moments and bias corrections stay put, the learning-rate schedule advances."""
+        m = self.model
+        if getattr(m, "_ctx", None) is None:
+            return 0
+        out = ctypes.c_int(0)
+        with torch.cuda.device(m._ctx_device):
+            _lib.check(_lib.lib().eemflow_optimizer_skipped_steps(m._ctx, ctypes.byref(out), _lib.current_stream_ptr(m._ctx_device)))
+        return out.value
+
     def sync_parameters(self):
         """Copy the device-resident weights back into the module's nn.Parameters (before state_dict()/checkpoint)."""
         m = self.model

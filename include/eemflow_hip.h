@@ -181,9 +181,15 @@ int eemflow_forward_backward(eemflow_ctx* ctx, const float* events1, const float
 
 /* clip_grad_norm_(clip) + AdamW(lr, weight_decay, eps, betas 0.9/0.999) on the device-resident weights, then the
  * re-pack of every kernel-side weight layout.  lr is the caller's OneCycleLR value for this step.
+ * A gradient with an inf / NaN in it skips the step (see eemflow_optimizer_skipped_steps).
  * Replaces: scaler.unscale_ + clip_grad_norm_ + scaler.step(optimizer)  (train_mvsec.py:254-258,178-183). */
 int eemflow_optimizer_step(eemflow_ctx* ctx, const float* grad, float lr, float weight_decay, float eps, float clip,
                            void* stream);
+
+/* Steps eemflow_optimizer_step has skipped so far: a gradient holding an inf or a NaN changes neither weights nor moments and does
+ * not advance the bias corrections - what GradScaler.step does for the reference (train_mvsec.py:237,257; the schedule still
+ * advances, :258).  Synchronises `stream`. */
+int eemflow_optimizer_skipped_steps(eemflow_ctx* ctx, int* out, void* stream);
 
 /* Copy the current weights (state_dict order, 714 352 floats) to a device buffer - checkpointing
  * (train_EEMFlow_HREM.py:127-130 saves model.module.state_dict()). */

@@ -161,6 +161,48 @@ def test_three_optimizer_steps_vs_golden(golden):
     assert float((flow - ref).abs().max()) < 1e-4
 
 
+def test_non_finite_gradient_skips_the_step_like_gradscaler():
+    """train_mvsec.py:237,257: `scaler.step(optimizer)` skips the step when a gradient holds an inf / NaN - weights, moments and the
+    optimizer's own step count (the bias corrections) stay put.  eemflow_optimizer_step does the same: two poisoned calls between real
+    steps change nothing, and the three real steps equal torch's AdamW + clip_grad_norm_ fed the same three gradients."""
+    from eemflow_amd import _lib
+    h, w, b = 128, 192, 2
+    net, sd = make_net(61)
+    net.change_imagesize((h, w))
+    tr = EEMFlowTrainer(net, lr=1e-3, wdecay=5e-5, epsilon=1e-8, num_steps=20, clip=1.0)
+    ref = torch.nn.Parameter(torch.cat([v.reshape(-1) for v in sd.values()]).clone().to(DEV))
+    opt = torch.optim.AdamW([ref], lr=1e-3, weight_decay=5e-5, eps=1e-8)
+    L, sp = _lib.lib(), _lib.current_stream_ptr(torch.device(DEV))
+
+    def weights():
+        tr.sync_parameters()
+        return torch.cat([v.reshape(-1).float() for v in net.state_dict().values()]).to(DEV)
+
+    assert tr.skipped_steps() == 0
+    for step in range(3):
+        e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(62 + step, b, h, w))
+        gt, valid = (torch.from_numpy(a).to(DEV) for a in synthetic_gt(70 + step, b, h, w))
+        _, m, _ = tr.step(e1, e2, gt, valid)
+        g = tr.grad.clone()
+        assert bool(torch.isfinite(g).all())
+        for q in opt.param_groups:
+            q["lr"] = m["lr"]
+        ref.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([ref], 1.0)
+        opt.step()
+        if step == 0:                                     # two poisoned steps straight through the C entry point
+            w0 = weights()
+            for poison in (float("inf"), float("nan")):
+                bad = g.clone()
+                bad[12345] = poison
+                _lib.check(L.eemflow_optimizer_step(net._ctx, bad.data_ptr(), 1e-3, 5e-5, 1e-8, 1.0, sp))
+            assert tr.skipped_steps() == 2
+            assert torch.equal(weights(), w0)
+    assert tr.skipped_steps() == 2
+    d = (weights() - ref.detach()).abs()
+    assert float(d.max()) < 2e-6, float(d.max())          # bias corrections of steps 1, 2, 3 - not 1, 4, 5
+
+
 def test_out_mesh_size_training():
     net, sd = make_net(29, out_mesh_size=True)
     net.change_imagesize((128, 128))

@@ -1,28 +1,32 @@
-"""InputPadder with the reference's interface (utils/image_utils.py:126-145).
+"""InputPadder with the reference's interface (utils/image_utils.py:126-145): constructor arguments, the `_pad` list in F.pad order
+[left, right, top, bottom], `pad(*tensors)` and `unpad(tensor)`.
 
-Inside EEMFlow the padding is folded into the first HIP conv kernel; this class exists for harness
-code that pads/unpads explicitly (E-RAFT style callers) and to expose the pad arithmetic."""
+Inside EEMFlow the padding is folded into the first HIP conv kernel; this class exists for harness code that pads / unpads explicitly
+(E-RAFT style callers) and to expose the pad arithmetic (pinned by tests/golden/pad.npz, generated from the reference class)."""
 import torch.nn.functional as F
 
 
+def _split(total, centred):
+    """A pad of `total` pixels as (before, after): halved with the odd pixel after, or all of it after."""
+    before = total // 2 if centred else 0
+    return before, total - before
+
+
 class InputPadder:
-    """ Pads images such that dimensions are divisible by eval_pad_rate """
+    """Replicate-pads the last two dimensions up to the next multiple of `eval_pad_rate`."""
 
     def __init__(self, dims, mode='sintel', eval_pad_rate=32):
         self.eval_pad_rate = eval_pad_rate
         self.ht, self.wd = dims[-2:]
-        r = eval_pad_rate
-        pad_ht = (((self.ht // r) + 1) * r - self.ht) % r
-        pad_wd = (((self.wd // r) + 1) * r - self.wd) % r
-        if mode == 'sintel':
-            self._pad = [pad_wd // 2, pad_wd - pad_wd // 2, pad_ht // 2, pad_ht - pad_ht // 2]
-        else:
-            self._pad = [pad_wd // 2, pad_wd - pad_wd // 2, 0, pad_ht]
+        missing_h = -self.ht % eval_pad_rate              # pixels up to the next multiple (0 when already one)
+        missing_w = -self.wd % eval_pad_rate
+        left, right = _split(missing_w, True)
+        top, bottom = _split(missing_h, mode == 'sintel')  # other modes (kitti) put the rows at the bottom
+        self._pad = [left, right, top, bottom]
 
     def pad(self, *inputs):
         return [F.pad(x, self._pad, mode='replicate') for x in inputs]
 
     def unpad(self, x):
-        ht, wd = x.shape[-2:]
-        c = [self._pad[2], ht - self._pad[3], self._pad[0], wd - self._pad[1]]
-        return x[..., c[0]:c[1], c[2]:c[3]]
+        left, right, top, bottom = self._pad
+        return x[..., top:x.shape[-2] - bottom, left:x.shape[-1] - right]

@@ -156,7 +156,7 @@ struct EncConvArgs {
     int hout, wout;
     int hraw, wraw;        // raw extent for ENC_1_1 (== hin, win elsewhere)
     int pad_top, pad_left; // replicate-pad offsets for ENC_1_1 (0 elsewhere)
-    int act;               // 1: LeakyReLU(0.1)
+    int act;               // 1: LeakyReLU(0.1); 2: ReLU (conv_wino4.hip only: E-RAFT's encoder); 0: none
     const float* gate;     // backward use: [nimg][cout][hout][wout]; the result is multiplied by LeakyReLU'(gate)
     int tiles_x, tiles_y;  // filled by the launcher: block tiles per image (blocks are remapped XCD-aware)
     float* pool_partial;   // fast path only: per-block partial sums of the k x k stage pooling, or NULL
@@ -169,6 +169,8 @@ struct EncConvArgs {
     int blocks_per_xcd = 0;
     int wino_f4 = 0;       // wwino holds F(4x4,3x3) weights (conv_wino4.hip) instead of F(2x2,3x3) ones
     const float* ws2r = nullptr;   // weights of a stride-2 layer in conv_s2r.hip's order (s2r_transform_launch), or NULL
+    // conv_wino4.hip only: residual [nimg][C][hout][wout]; the result is relu(res + act(conv)) (ResidualBlock, model/extractor.py:50-57)
+    const float* res = nullptr;
 };
 int enc_conv_launch(int cin, int cout, int stride, const EncConvArgs& a, hipStream_t stream);
 // first layer with 16-byte LDS-DMA staging (conv_enc1.hip): raw width % 4 == 0, no horizontal padding

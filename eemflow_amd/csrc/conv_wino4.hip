@@ -357,6 +357,7 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(EncConvArgs a) {
         const int co0 = cog * 16 + g * 4;
         float* dst = a.out + (size_t)cur.n * C * hw;
         const float* gsrc = a.gate ? a.gate + (size_t)cur.n * C * hw : nullptr;
+        const float* rsrc = a.res ? a.res + (size_t)cur.n * C * hw : nullptr;
         const bool full = cur.by * K::TH + K::TH <= a.hout && cur.bx * K::TW + K::TW <= a.wout;    // wave-uniform
         const bool inx = ox < a.wout;                                    // widths are multiples of 4: a tile row is in or out
         const unsigned lane_bo = (unsigned)((co0 * a.hout + oy) * a.wout + ox) * 4u;
@@ -382,11 +383,12 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(EncConvArgs a) {
                 for (int yy = 0; yy < 4; ++yy) y[yy][x] = o[yy];
             }
             if (a.act) {
+                const float slope = a.act == 2 ? 0.f : 0.1f;
 #pragma unroll
                 for (int yy = 0; yy < 4; ++yy)
 #pragma unroll
                     for (int x = 0; x < 4; ++x) {
-                        const f32x2 sc = 0.1f * y[yy][x];
+                        const f32x2 sc = slope * y[yy][x];
                         y[yy][x] = f32x2{fmaxf(y[yy][x][0], sc[0]), fmaxf(y[yy][x][1], sc[1])};
                     }
             }
@@ -405,6 +407,17 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(EncConvArgs a) {
                             const f32x4 gt = *reinterpret_cast<const f32x4*>(gb + lane_bo + (size_t)yy * a.wout * 4);
 #pragma unroll
                             for (int x = 0; x < 4; ++x) o[yy][x] *= gt[x] > 0.f ? 1.f : 0.1f;
+                        }
+                    }
+                }
+                if (rsrc) {                                             // relu(res + act(conv)): the loads are waited for here, so the
+                    const char* qb = reinterpret_cast<const char*>(rsrc) + (size_t)r * hw * 4;   // counted waits of the ring only wait longer
+#pragma unroll
+                    for (int yy = 0; yy < 4; ++yy) {
+                        if (inx && oy + yy < a.hout) {
+                            const f32x4 rv = *reinterpret_cast<const f32x4*>(qb + lane_bo + (size_t)yy * a.wout * 4);
+#pragma unroll
+                            for (int x = 0; x < 4; ++x) o[yy][x] = fmaxf(o[yy][x] + rv[x], 0.f);
                         }
                     }
                 }

@@ -28,7 +28,8 @@ int ensure(Buf& b, size_t floats) {
 
 struct Layer {                    // one convolution, weights packed for gconv
     size_t wpk = 0, wpk16 = 0, wfew = 0, scale = 0, shift = 0;
-    bool has_scale = false, has16 = false, has_few = false;
+    size_t wraw = 0, wf4 = 0;      // 64 -> 64 3x3 stride-1 layers: OIHW weights (BatchNorm scale folded in) and their F(4x4,3x3) form
+    bool has_scale = false, has16 = false, has_few = false, has_f4 = false;
     int cout = 0, kh = 1, kw = 1, stride = 1, ph = 0, pw = 0;
     int cs[3] = {0, 0, 0}, nseg = 1;
 };
@@ -63,6 +64,8 @@ struct eraft_ctx {
     bool keep_stages = false;      // copy corr0 / net1 / mask1 / delta1 aside in the first iteration (parity tests)
     const float* c1last = nullptr;   // coords1 after the last iteration of the last forward (c1 or c1b)
     int frames_in_flight = 1;      // eraft_set_frames_in_flight
+    float* wino = nullptr;         // F(4x4,3x3) forms of the 64 -> 64 encoder convs (wino4_transform_launch at load time)
+    float* trash = nullptr;        // 1 KB sink for the Winograd kernel's out-of-image stores
     double* nstat = nullptr;       // per-chunk sums of the large-plane instance norm (er_instnorm_launch)
     size_t nstat_cap = 0;
     bool alt_corr = false;         // eraft_set_alternate_corr: correlation features on the fly, no all-pairs volume
@@ -112,6 +115,16 @@ void make_layer(Packer& pk, Layer& L, const float* w, const float* bias, int cou
     if (L.has_few) {
         L.wfew = pk.push(fewout_packed_floats(cin, kh, kw));
         fewout_pack(wsl, con, cin, kh, kw, pk.host.data() + L.wfew);
+    }
+    // the encoder's 64 -> 64 residual convs (model/extractor.py:145, layer1) also run on EEMFlow's Winograd F(4x4,3x3) kernel
+    // (conv_wino4.hip): raw weights kept for the device-side transform, an eval-mode BatchNorm's scale folded into them
+    L.has_f4 = nseg == 1 && cin == 64 && con == 64 && co0 == 0 && kh == 3 && kw == 3 && stride == 1 && ph == 1 && pw == 1;
+    if (L.has_f4) {
+        L.wraw = pk.push((size_t)64 * 64 * 9);
+        for (int co = 0; co < 64; ++co) {
+            const float sc = bn ? bn->w[co] / sqrtf(bn->rv[co] + 1e-5f) : 1.f;
+            for (int i = 0; i < 64 * 9; ++i) pk.host[L.wraw + (size_t)co * 576 + i] = wsl[(size_t)co * 576 + i] * sc;
+        }
     }
     L.shift = pk.push(con);
     if (bn) {
@@ -201,6 +214,25 @@ void set_seg(GConvArgs& a, int i, const float* ptr, int cch, int ctotal, int cof
     a.seg[i].ptr = ptr; a.seg[i].c = cch; a.seg[i].ctotal = ctotal; a.seg[i].coff = coff;
 }
 
+// A 64 -> 64 3x3 conv of the encoder on the Winograd F(4x4,3x3) kernel: out = act(conv(x) + shift) [then relu(res + .)];
+// act: 0 none (an InstanceNorm follows), 2 ReLU (eval BatchNorm folded into weights and shift).  From 128 tiles of 32x16 pixels on
+// (fewer leave most CUs without a block and the LDS-tiled kernel wins); EEM_ERAFT_NO_F4=1 keeps every conv on gconv.
+bool f4_eligible(const Layer& L, int n, int h, int w) {
+    const char* e = getenv("EEM_ERAFT_NO_F4");
+    if (e && e[0] == '1') return false;
+    return L.has_f4 && w % 4 == 0 && (long)n * ((h + 15) / 16) * ((w + 31) / 32) >= 128;
+}
+int run_f4(eraft_ctx* c, const Layer& L, const float* x, int n, int h, int w, float* out, int act, const float* res, hipStream_t st) {
+    EncConvArgs a;
+    memset((void*)&a, 0, sizeof(a));
+    a.in0 = x; a.wwino = c->wino + L.wf4; a.wino_f4 = 1;
+    a.zero_page = c->arena + c->zero_off; a.trash = c->trash;
+    a.bias = c->arena + L.shift; a.out = out;
+    a.nimg = n; a.nimg0 = n; a.hin = h; a.win = w; a.hout = h; a.wout = w; a.hraw = h; a.wraw = w;
+    a.act = act; a.res = res;
+    return wino4_launch(64, a, st);
+}
+
 // BasicEncoder forward on `n` images [n][cin0][hp][wp]; result of the residual stack in *feat ([n][128][hp/8][wp/8]).
 int run_encoder(eraft_ctx* c, const Encoder& E, const float* x, int n, int cin0, int hp, int wp, float** feat, hipStream_t st) {
     int rc;
@@ -222,7 +254,9 @@ int run_encoder(eraft_ctx* c, const Encoder& E, const float* x, int n, int cin0,
             // y = relu(norm1(conv1(x)))
             GConvArgs a1 = conv_args(c, bk.conv1, n, h, w, E.batch_norm ? Y : R, planes, 0, E.batch_norm ? GACT_RELU : GACT_NONE);
             set_seg(a1, 0, X, cin, cin, 0);
-            if ((rc = gconv_launch(a1, st)) != EEM_OK) return rc;
+            if (f4_eligible(bk.conv1, n, h, w)) rc = run_f4(c, bk.conv1, X, n, h, w, E.batch_norm ? Y : R, E.batch_norm ? 2 : 0, nullptr, st);
+            else rc = gconv_launch(a1, st);
+            if (rc != EEM_OK) return rc;
             const int ho = a1.hout, wo = a1.wout;
             if (!E.batch_norm && (rc = er_instnorm_launch(R, Y, nullptr, n * planes, ho * wo, 1, st, c->nstat, c->nstat_cap)) != EEM_OK) return rc;
             // shortcut
@@ -238,7 +272,9 @@ int run_encoder(eraft_ctx* c, const Encoder& E, const float* x, int n, int cin0,
             GConvArgs a2 = conv_args(c, bk.conv2, n, ho, wo, E.batch_norm ? O : R, planes, 0, E.batch_norm ? GACT_RELU : GACT_NONE);
             set_seg(a2, 0, Y, planes, planes, 0);
             if (E.batch_norm) { a2.epi = GEPI_ADD_RELU; a2.e0 = res; a2.e0_ctotal = planes; a2.e0_coff = 0; }
-            if ((rc = gconv_launch(a2, st)) != EEM_OK) return rc;
+            if (f4_eligible(bk.conv2, n, ho, wo)) rc = run_f4(c, bk.conv2, Y, n, ho, wo, E.batch_norm ? O : R, E.batch_norm ? 2 : 0, E.batch_norm ? res : nullptr, st);
+            else rc = gconv_launch(a2, st);
+            if (rc != EEM_OK) return rc;
             if (!E.batch_norm && (rc = er_instnorm_launch(R, O, res, n * planes, ho * wo, 1, st, c->nstat, c->nstat_cap)) != EEM_OK) return rc;
             float* t = X; X = O; O = t;
             h = ho; w = wo;
@@ -332,6 +368,8 @@ extern "C" void eraft_destroy(eraft_ctx* c) {
     for (Buf* b : all) if (b->p) (void)hipFree(b->p);
     if (c->nstat) (void)hipFree(c->nstat);
     if (c->arena) (void)hipFree(c->arena);
+    if (c->wino) (void)hipFree(c->wino);
+    if (c->trash) (void)hipFree(c->trash);
     delete c;
 }
 
@@ -400,6 +438,25 @@ extern "C" int eraft_load_weights(eraft_ctx* c, const float* flat, size_t nfloat
     c->arena = nullptr;
     EEM_HIP_CHECK(hipMalloc(&c->arena, pk.host.size() * sizeof(float)));
     EEM_HIP_CHECK(hipMemcpy(c->arena, pk.host.data(), pk.host.size() * sizeof(float), hipMemcpyHostToDevice));
+    {   // Winograd-domain weights of the 64 -> 64 encoder convs
+        std::vector<Layer*> f4;
+        for (Encoder* E : {&c->fnet, &c->cnet})
+            for (Block& bk : E->blk)
+                for (Layer* L : {&bk.conv1, &bk.conv2})
+                    if (L->has_f4) f4.push_back(L);
+        if (c->wino) { EEM_HIP_CHECK(hipFree(c->wino)); c->wino = nullptr; }
+        if (!f4.empty()) {
+            const size_t each = wino4_packed_floats(64);
+            EEM_HIP_CHECK(hipMalloc(&c->wino, f4.size() * each * sizeof(float)));
+            for (size_t i = 0; i < f4.size(); ++i) {
+                f4[i]->wf4 = i * each;
+                const int rcw = wino4_transform_launch(c->arena + f4[i]->wraw, 64, 0, c->wino + f4[i]->wf4, nullptr);
+                if (rcw != EEM_OK) return rcw;
+            }
+            EEM_HIP_CHECK(hipDeviceSynchronize());
+        }
+        if (!c->trash) EEM_HIP_CHECK(hipMalloc(&c->trash, 4096));
+    }
     c->cin0 = n_first_channels;
     c->loaded = true;
     return EEM_OK;

@@ -207,6 +207,24 @@ def test_errors():
         net(torch.zeros(1, 5, 64, 64), torch.zeros(1, 5, 64, 64))
 
 
+def test_encoder_winograd_convs_equal_the_lds_tiled_ones(monkeypatch):
+    """The encoder's 64 -> 64 residual convs (model/extractor.py layer1, both networks) run on EEMFlow's Winograd F(4x4,3x3) kernel from
+    128 tiles on - an eval-mode BatchNorm's scale folded into the weights, ReLU and the residual sum in its epilogue (cnet), no
+    activation in front of the InstanceNorm (fnet); EEM_ERAFT_NO_F4=1 (read per forward) keeps them on gconv16.  Same sums in another
+    order: the twelve predictions agree far inside the 1e-3 budget."""
+    h, w = 480, 640
+    net, _ = make_net(43)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(44, 1, h, w))
+    with torch.no_grad():
+        wino = torch.stack(net(e1, e2, iters=12)[1]).clone()
+        monkeypatch.setenv("EEM_ERAFT_NO_F4", "1")
+        tiled = torch.stack(net(e1, e2, iters=12)[1]).clone()
+    assert not torch.equal(wino, tiled)                                  # (the switch did switch)
+    # F(4x4) differs from a direct convolution by ~1e-5 of a feature's range; twelve recurrent iterations carry that to ~2e-4 px
+    assert maxerr(wino, tiled) < 5e-4 and float(tiled.abs().max()) > 1e-3
+
+
 def test_stacked_update_block_launches_equal_separate_ones(monkeypatch):
     """z | r of a GRU pass and flow-head | mask-head conv1 run as one launch each, stacked along the output channels
     (csrc/eraft_api.hip); EEM_ERAFT_NO_STACK=1 (read per forward) keeps the reference's five separate convolutions.  Per output

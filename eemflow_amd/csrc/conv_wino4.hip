@@ -116,7 +116,9 @@ __device__ unsigned long long g_stamps4[1024 * 8 * 64];
 #define STAMP4(i)
 #endif
 
-template <int C, int NGX, int NGY, int POOLK>
+// EPI: 0 plain, 1 the result is multiplied by LeakyReLU'(gate) (data gradients), 2 relu(residual + result) (E-RAFT's residual blocks) -
+// separate instantiations, so the forward kernels' register allocation (252 of 256 VGPRs, no scratch) does not carry them
+template <int C, int NGX, int NGY, int POOLK, int EPI>
 __global__ __launch_bounds__(512, 2) void wino4_kernel(EncConvArgs a) {
     using K = W4Cfg<C, NGX, NGY>;
     constexpr int R = K::R, NI = K::NI, KS = K::KS;
@@ -356,8 +358,8 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(EncConvArgs a) {
         const int oy = cur.by * K::TH + gy * 8 + ty * 4, ox = cur.bx * K::TW + (gx * 8 + tx) * 4;
         const int co0 = cog * 16 + g * 4;
         float* dst = a.out + (size_t)cur.n * C * hw;
-        const float* gsrc = a.gate ? a.gate + (size_t)cur.n * C * hw : nullptr;
-        const float* rsrc = a.res ? a.res + (size_t)cur.n * C * hw : nullptr;
+        const float* gsrc = EPI == 1 ? a.gate + (size_t)cur.n * C * hw : nullptr;
+        const float* rsrc = EPI == 2 ? a.res + (size_t)cur.n * C * hw : nullptr;
         const bool full = cur.by * K::TH + K::TH <= a.hout && cur.bx * K::TW + K::TW <= a.wout;    // wave-uniform
         const bool inx = ox < a.wout;                                    // widths are multiples of 4: a tile row is in or out
         const unsigned lane_bo = (unsigned)((co0 * a.hout + oy) * a.wout + ox) * 4u;
@@ -399,27 +401,34 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(EncConvArgs a) {
                 f32x4 o[4];
 #pragma unroll
                 for (int yy = 0; yy < 4; ++yy) o[yy] = f32x4{y[yy][0][e], y[yy][1][e], y[yy][2][e], y[yy][3][e]};
-                if (gsrc) {
+                // gate / residual: the four rows' loads unconditional (an out-of-image lane reads the plane's first pixels) and issued
+                // together, the condition applied to the values - a load inside a lane-dependent branch is followed by the compiler's
+                // s_waitcnt vmcnt(0): sixteen dependent round trips per tile before, each also waiting for the ring's DMA in flight
+                if constexpr (EPI == 1) {
                     const char* gb = reinterpret_cast<const char*>(gsrc) + (size_t)r * hw * 4;
+                    f32x4 gt[4];
 #pragma unroll
                     for (int yy = 0; yy < 4; ++yy) {
-                        if (inx && oy + yy < a.hout) {
-                            const f32x4 gt = *reinterpret_cast<const f32x4*>(gb + lane_bo + (size_t)yy * a.wout * 4);
-#pragma unroll
-                            for (int x = 0; x < 4; ++x) o[yy][x] *= gt[x] > 0.f ? 1.f : 0.1f;
-                        }
+                        const bool in = inx && oy + yy < a.hout;
+                        gt[yy] = *reinterpret_cast<const f32x4*>(gb + (in ? lane_bo + (unsigned)yy * (unsigned)a.wout * 4u : 0u));
                     }
+#pragma unroll
+                    for (int yy = 0; yy < 4; ++yy)
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) o[yy][x] *= gt[yy][x] > 0.f ? 1.f : 0.1f;
                 }
-                if (rsrc) {                                             // relu(res + act(conv)): the loads are waited for here, so the
-                    const char* qb = reinterpret_cast<const char*>(rsrc) + (size_t)r * hw * 4;   // counted waits of the ring only wait longer
+                if constexpr (EPI == 2) {                               // relu(res + act(conv)); waited for here: the ring's counted waits only wait longer
+                    const char* qb = reinterpret_cast<const char*>(rsrc) + (size_t)r * hw * 4;
+                    f32x4 rv[4];
 #pragma unroll
                     for (int yy = 0; yy < 4; ++yy) {
-                        if (inx && oy + yy < a.hout) {
-                            const f32x4 rv = *reinterpret_cast<const f32x4*>(qb + lane_bo + (size_t)yy * a.wout * 4);
-#pragma unroll
-                            for (int x = 0; x < 4; ++x) o[yy][x] = fmaxf(o[yy][x] + rv[x], 0.f);
-                        }
+                        const bool in = inx && oy + yy < a.hout;
+                        rv[yy] = *reinterpret_cast<const f32x4*>(qb + (in ? lane_bo + (unsigned)yy * (unsigned)a.wout * 4u : 0u));
                     }
+#pragma unroll
+                    for (int yy = 0; yy < 4; ++yy)
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) o[yy][x] = fmaxf(o[yy][x] + rv[yy][x], 0.f);
                 }
                 float ps = 0.f;
 #pragma unroll
@@ -551,10 +560,18 @@ int launch4_c(const EncConvArgs& a0, hipStream_t stream) {
         return EEM_ERR_ARG;
     }
     EEM_NOTE_GRID(per_xcd * 8, 512);
+    if ((a.gate != nullptr || a.res != nullptr) && (a.pool_partial != nullptr || (a.gate != nullptr && a.res != nullptr))) {
+        eem_set_error("wino4: gate / residual epilogues come without pooling and one at a time");
+        return EEM_ERR_ARG;
+    }
     if (a.pool_partial != nullptr)
-        hipLaunchKernelGGL((wino4_kernel<C, W::NGX, W::NGY, W::POOLK>), dim3(per_xcd * 8), dim3(512), 0, stream, a);
+        hipLaunchKernelGGL((wino4_kernel<C, W::NGX, W::NGY, W::POOLK, 0>), dim3(per_xcd * 8), dim3(512), 0, stream, a);
+    else if (a.gate != nullptr)
+        hipLaunchKernelGGL((wino4_kernel<C, W::NGX, W::NGY, 0, 1>), dim3(per_xcd * 8), dim3(512), 0, stream, a);
+    else if (a.res != nullptr)
+        hipLaunchKernelGGL((wino4_kernel<C, W::NGX, W::NGY, 0, 2>), dim3(per_xcd * 8), dim3(512), 0, stream, a);
     else
-        hipLaunchKernelGGL((wino4_kernel<C, W::NGX, W::NGY, 0>), dim3(per_xcd * 8), dim3(512), 0, stream, a);
+        hipLaunchKernelGGL((wino4_kernel<C, W::NGX, W::NGY, 0, 0>), dim3(per_xcd * 8), dim3(512), 0, stream, a);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

@@ -119,18 +119,25 @@ __global__ __launch_bounds__(256) void dgrad_s2_kernel(DgradS2Args a, int tiles_
             for (int r = 0; r < 4; ++r) {
                 const int ci = mt * 16 + 4 * g + r;
                 const size_t plane = ((size_t)cur.n * CI + ci);
-                pv[mt][r] = 0.f;
-                if (dpool) {
+                // every load unconditional, from a clamped (always valid) address, the condition applied to the value: a load inside a
+                // branch is followed by the compiler's s_waitcnt vmcnt(0) - twenty dependent round trips per tile, each also waiting for
+                // the next tile's DMA (346x260 batch 32: 291 -> 100 us for the 32 -> 16 layer)
+                {
                     const int py = iy0 / a.pool_k, px = ix / a.pool_k;
-                    if (py < a.gh && px < a.gw) pv[mt][r] = dpool[(plane * a.gh + py) * a.gw + px] * pool_scale;
+                    const bool pok = dpool && py < a.gh && px < a.gw;
+                    const float* pp = dpool ? dpool + (plane * a.gh + min(py, a.gh - 1)) * a.gw + min(px, a.gw - 1) : a.zero_page;
+                    const float pvv = *pp;
+                    pv[mt][r] = pok ? pvv * pool_scale : 0.f;
                 }
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         const int iy = iy0 + 2 * (wave + 4 * t) + pr;
-                        gt[pr][t][mt][r] = f32x2{1.f, 1.f};
-                        if (gate && colok && iy < a.hin) gt[pr][t][mt][r] = *reinterpret_cast<const f32x2*>(gate + plane * xhw + (size_t)iy * a.win + ix);
+                        const bool gok = gate && colok && iy < a.hin;
+                        const float* gp = gate ? gate + plane * xhw + (size_t)min(iy, a.hin - 1) * a.win + (colok ? ix : 0) : a.zero_page;
+                        const f32x2 gv = *reinterpret_cast<const f32x2*>(gp);
+                        gt[pr][t][mt][r] = gok ? gv : f32x2{1.f, 1.f};
                     }
             }
 

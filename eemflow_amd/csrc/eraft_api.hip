@@ -56,6 +56,12 @@ struct eraft_ctx {
     Encoder fnet, cnet;
     Layer convc1, convc2, convf1, convf2, conv, gz[2], gr[2], gq[2], fh1, fh2, mk0, mk2;
     Layer gzr[2], heads1;          // z | r of a GRU pass and flow-head | mask-head conv1 as ONE launch each (small batches)
+    // The GRU's convs read hx = [h | inp | motion] (model/update.py:43-60) and `inp` - the context features - is the same in all twelve
+    // iterations: its third of every conv (the weights' input channels 128..255, + the bias) is computed ONCE per forward into a
+    // per-pixel addend (gzr_c / gq_c -> czr / cq), and the convs inside the loop run over [h | motion] only (gzr_hm / gq_hm: K = 256
+    // instead of 384) with that addend in front of their activation (GConvArgs::pre).  EEM_ERAFT_NO_PRE=1 keeps the full convs.
+    Layer gzr_hm[2], gq_hm[2], gzr_c[2], gq_c[2];
+    Buf czr[2], cq[2];
     // workspace
     Buf padded, s[5], fmap, net[2], inp, pyr[4], c0, c1, c1b, corr, cor1, corflo, flo1, motion, z, rh, fhid, delta, mhid, mask;
     Buf st_corr0, st_net1, st_mask1, st_delta1, zeros;
@@ -364,7 +370,7 @@ extern "C" void eraft_destroy(eraft_ctx* c) {
     Buf* all[] = {&c->padded, &c->s[0], &c->s[1], &c->s[2], &c->s[3], &c->s[4], &c->fmap, &c->net[0], &c->net[1], &c->inp,
                   &c->pyr[0], &c->pyr[1], &c->pyr[2], &c->pyr[3], &c->c0, &c->c1, &c->c1b, &c->corr, &c->cor1, &c->corflo, &c->flo1,
                   &c->motion, &c->z, &c->rh, &c->fhid, &c->delta, &c->mhid, &c->mask, &c->st_corr0, &c->st_net1, &c->st_mask1,
-                  &c->st_delta1, &c->zeros, &c->f2l[0], &c->f2l[1], &c->f2l[2]};
+                  &c->st_delta1, &c->zeros, &c->f2l[0], &c->f2l[1], &c->f2l[2], &c->czr[0], &c->czr[1], &c->cq[0], &c->cq[1]};
     for (Buf* b : all) if (b->p) (void)hipFree(b->p);
     if (c->nstat) (void)hipFree(c->nstat);
     if (c->arena) (void)hipFree(c->arena);
@@ -418,13 +424,35 @@ extern "C" int eraft_load_weights(eraft_ctx* c, const float* flat, size_t nfloat
     plain(c->convf1, 128, c2, 1, 7, 7, 3, 3);
     plain(c->convf2, 64, c128, 1, 3, 3, 1, 1);
     plain(c->conv, 126, c256, 1, 3, 3, 1, 1);
+    // a conv over [h | inp | motion] split by input channels: `hm` over [h | motion] without bias, `ctx` over inp with the bias
+    auto split_ctx = [&](Layer& hm, Layer& ctx, const float* w, const float* b, int cout, int kh, int kw, int ph, int pw) {
+        const int taps = kh * kw;
+        std::vector<float> whm((size_t)cout * 256 * taps), wc((size_t)cout * 128 * taps), zero(cout, 0.f);
+        for (int co = 0; co < cout; ++co) {
+            const float* src = w + (size_t)co * 384 * taps;
+            memcpy(&whm[(size_t)co * 256 * taps], src, (size_t)128 * taps * sizeof(float));
+            memcpy(&whm[((size_t)co * 256 + 128) * taps], src + (size_t)256 * taps, (size_t)128 * taps * sizeof(float));
+            memcpy(&wc[(size_t)co * 128 * taps], src + (size_t)128 * taps, (size_t)128 * taps * sizeof(float));
+        }
+        const int c2x128[2] = {128, 128};
+        make_layer(pk, hm, whm.data(), zero.data(), cout, 0, cout, c2x128, 2, kh, kw, 1, ph, pw, nullptr);
+        make_layer(pk, ctx, wc.data(), b, cout, 0, cout, c128, 1, kh, kw, 1, ph, pw, nullptr);
+    };
     for (int pass = 0; pass < 2; ++pass) {               // model/update.py:33-44: hx = [h | inp | motion]; 1x5 pass, then 5x1
         const int kh = pass ? 5 : 1, kw = pass ? 1 : 5, ph = pass ? 2 : 0, pw = pass ? 0 : 2;
         plain(c->gz[pass], 128, c3x128, 3, kh, kw, ph, pw);
         const float* wz = last_w; const float* bz = last_b;
         plain(c->gr[pass], 128, c3x128, 3, kh, kw, ph, pw);
         stacked(c->gzr[pass], wz, bz, last_w, last_b, 128, c3x128, 3, kh, kw, ph, pw);
+        {
+            const size_t nw = (size_t)128 * 384 * kh * kw;
+            std::vector<float> w2(2 * nw), b2(256);
+            memcpy(w2.data(), wz, nw * sizeof(float)); memcpy(w2.data() + nw, last_w, nw * sizeof(float));
+            memcpy(b2.data(), bz, 128 * sizeof(float)); memcpy(b2.data() + 128, last_b, 128 * sizeof(float));
+            split_ctx(c->gzr_hm[pass], c->gzr_c[pass], w2.data(), b2.data(), 256, kh, kw, ph, pw);
+        }
         plain(c->gq[pass], 128, c3x128, 3, kh, kw, ph, pw);
+        split_ctx(c->gq_hm[pass], c->gq_c[pass], last_w, last_b, 128, kh, kw, ph, pw);
     }
     plain(c->fh1, 256, c128, 1, 3, 3, 1, 1);             // model/update.py:6-14
     const float* wf = last_w; const float* bf = last_b;
@@ -530,6 +558,21 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
         if ((rc = gconv_launch(b2, st)) != EEM_OK) return rc;
     }
     if ((rc = er_coords_init_launch(c->c0.p, c->c1.p, flow_init, B, h8, w8, st)) != EEM_OK) return rc;
+    // the context features' part of the GRU convs, once per forward (see eraft_ctx)
+    const char* enp = getenv("EEM_ERAFT_NO_PRE");
+    const char* ens0 = getenv("EEM_ERAFT_NO_STACK");
+    const bool use_pre = !(enp && enp[0] == '1') && !(ens0 && ens0[0] == '1');
+    if (use_pre) {
+        for (int pass = 0; pass < 2; ++pass) {
+            if ((rc = ensure(c->czr[pass], (size_t)B * 256 * g)) != EEM_OK || (rc = ensure(c->cq[pass], (size_t)B * 128 * g)) != EEM_OK) return rc;
+            GConvArgs a = conv_args(c, c->gzr_c[pass], B, h8, w8, c->czr[pass].p, 256, 0, GACT_NONE);
+            set_seg(a, 0, c->inp.p, 128, 128, 0);
+            if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+            a = conv_args(c, c->gq_c[pass], B, h8, w8, c->cq[pass].p, 128, 0, GACT_NONE);
+            set_seg(a, 0, c->inp.p, 128, 128, 0);
+            if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+        }
+    }
 
     int cur = 0;
     for (int it = 0; it < iters; ++it) {
@@ -580,8 +623,14 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
         const bool stack = !(ens && ens[0] == '1');
         for (int pass = 0; pass < 2; ++pass) {
             if (stack) {
-                a = conv_args(c, c->gzr[pass], B, h8, w8, c->z.p, 256, 0, GACT_SIGMOID);
-                set_seg(a, 0, hcur, 128, 128, 0); set_seg(a, 1, c->inp.p, 128, 128, 0); set_seg(a, 2, c->motion.p, 128, 128, 0);
+                if (use_pre) {
+                    a = conv_args(c, c->gzr_hm[pass], B, h8, w8, c->z.p, 256, 0, GACT_SIGMOID);
+                    set_seg(a, 0, hcur, 128, 128, 0); set_seg(a, 1, c->motion.p, 128, 128, 0);
+                    a.pre = c->czr[pass].p; a.pre_ctotal = 256; a.pre_coff = 0;
+                } else {
+                    a = conv_args(c, c->gzr[pass], B, h8, w8, c->z.p, 256, 0, GACT_SIGMOID);
+                    set_seg(a, 0, hcur, 128, 128, 0); set_seg(a, 1, c->inp.p, 128, 128, 0); set_seg(a, 2, c->motion.p, 128, 128, 0);
+                }
                 if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
                 if ((rc = er_mul_channels_launch(c->rh.p, c->z.p, 256, 128, hcur, B, 128, (long)g, st)) != EEM_OK) return rc;
             } else {
@@ -593,8 +642,14 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
                 a.epi = GEPI_MUL; a.e0 = hcur; a.e0_ctotal = 128; a.e0_coff = 0;
                 if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
             }
-            a = conv_args(c, c->gq[pass], B, h8, w8, hnext, 128, 0, GACT_TANH);
-            set_seg(a, 0, c->rh.p, 128, 128, 0); set_seg(a, 1, c->inp.p, 128, 128, 0); set_seg(a, 2, c->motion.p, 128, 128, 0);
+            if (use_pre) {
+                a = conv_args(c, c->gq_hm[pass], B, h8, w8, hnext, 128, 0, GACT_TANH);
+                set_seg(a, 0, c->rh.p, 128, 128, 0); set_seg(a, 1, c->motion.p, 128, 128, 0);
+                a.pre = c->cq[pass].p; a.pre_ctotal = 128; a.pre_coff = 0;
+            } else {
+                a = conv_args(c, c->gq[pass], B, h8, w8, hnext, 128, 0, GACT_TANH);
+                set_seg(a, 0, c->rh.p, 128, 128, 0); set_seg(a, 1, c->inp.p, 128, 128, 0); set_seg(a, 2, c->motion.p, 128, 128, 0);
+            }
             a.epi = GEPI_GRU; a.e0 = hcur; a.e0_ctotal = 128; a.e0_coff = 0; a.e1 = c->z.p; a.e1_ctotal = stack ? 256 : 128; a.e1_coff = 0;
             if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
             float* t = hcur; hcur = hnext; hnext = t;

@@ -48,6 +48,11 @@ struct GConvArgs {
     int groups;
     long g_wstride16, g_pstride;
     int g_ocoff;
+    // optional per-pixel addend in front of the activation: v = act(acc * scale + shift + pre[n][pre_coff + co][p]) - the part of a
+    // convolution over concatenated inputs that belongs to an input which does not change between calls (E-RAFT's GRU: the context
+    // features, model/update.py:43-60), computed once
+    const float* pre;
+    int pre_ctotal, pre_coff;
 };
 
 // number of packed floats / packing for weights [cout][sum(c_s)][kh][kw] read as segments of sizes cs[0..nseg)

@@ -194,6 +194,7 @@ __global__ __launch_bounds__(SPLITK ? SPLITK * 64 : 256) void gconv_kernel(GConv
     auto finish = [&](float v, int co, int p) {
         if (a.scale) v *= a.scale[co];
         if (a.shift) v += a.shift[co];
+        if (a.pre) v += a.pre[((size_t)n * a.pre_ctotal + a.pre_coff + co) * hwo + p];
         v = g_act(v, a.act);
         if (a.epi == GEPI_MUL) {
             v *= a.e0[((size_t)n * a.e0_ctotal + a.e0_coff + co) * hwo + p];
@@ -438,7 +439,7 @@ bool fewout_supported(const GConvArgs& a) {
     const char* e = getenv("EEM_NO_FEWOUT");                         // read per call: a test flips it inside one process
     if (e && e[0] == '1') return false;
     return a.wfew && a.nseg == 1 && a.cout <= 8 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.tstride <= 1 && a.pad_h == 1 && a.pad_w == 1 &&
-           a.seg[0].cmul <= 1 && a.seg[0].gate == nullptr && (a.epi == GEPI_PLAIN || a.epi == GEPI_ADD) && a.hout == a.hin && a.wout == a.win &&
+           a.seg[0].cmul <= 1 && a.seg[0].gate == nullptr && a.pre == nullptr && (a.epi == GEPI_PLAIN || a.epi == GEPI_ADD) && a.hout == a.hin && a.wout == a.win &&
            (long)a.hin * a.win >= few_min_px;                        // smaller maps: the split-K launch of the generic kernel
 }
 
@@ -474,7 +475,7 @@ int gconv_launch(const GConvArgs& a, hipStream_t stream) {
         const bool shape7 = a.kh == 7 && a.kw == 7, shape3 = a.kh == 3 && a.kw == 3;
         // (one pair only: with the 5-bin volumes' three pairs through a stride-2 7x7 the 2x2-tile batches of the generic kernel are
         // faster - measured, E-RAFT 122 -> 117 frames/s)
-        if (!off && a.nseg == 1 && a.seg[0].c <= 2 && (shape7 || shape3) && a.tstride <= 1 && a.epi == GEPI_PLAIN && a.seg[0].gate == nullptr &&
+        if (!off && a.nseg == 1 && a.seg[0].c <= 2 && (shape7 || shape3) && a.tstride <= 1 && a.epi == GEPI_PLAIN && a.pre == nullptr && a.seg[0].gate == nullptr &&
             a.seg[0].cmul <= 1) {
             dim3 grid(ceil_div(hwo, 128), cot, a.n);
             if (shape7) hipLaunchKernelGGL((gconv_taps_kernel<7, 7>), grid, dim3(256), 0, stream, a);

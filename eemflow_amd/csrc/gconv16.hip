@@ -248,34 +248,88 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || (THT != 2 && THT != 4)) ? 2 : 
         for (int t = 0; t < NR; ++t) acc[t] += red[(wave * NR + t) * 64 + lane];
     }
 
-    // ---- epilogue: D[cout 4g + r][pixel j]
+    // ---- epilogue: D[cout 4g + r][pixel j].  Its operands (GRU state and gate, residual, the per-pixel addend) are loaded
+    // unconditionally from clamped indices, one operand's NR x 4 values as one batch: a load inside a lane-dependent branch is followed
+    // by the compiler's s_waitcnt vmcnt(0), which made the GRU epilogue up to 2 x NR x 4 dependent round trips (8.5 k of a wave's 84 k
+    // cycles in the stamps above)
     const int x = x0 + j;
-    if (x >= a.wout) return;
+    if (a.epi == GEPI_PLAIN && a.pre == nullptr) {               // (wave-uniform) nothing to load: the plain form
+        if (x < a.wout) {
 #pragma unroll
-    for (int t = 0; t < NR; ++t) {
-        const int y = y0 + wp * NR + t;
-        if (y >= a.hout) continue;
-        const int p = y * a.wout + x;
+            for (int t = 0; t < NR; ++t) {
+                const int y = y0 + wp * NR + t;
+                if (y >= a.hout) continue;
+                const int p = y * a.wout + x;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = mtg * 16 + 4 * g + r;
-            if (co >= a.cout) continue;
-            float v = acc[t][r] * e_scale[r] + e_shift[r];
-            v = g16_act(v, a.act);
-            if (a.epi == GEPI_MUL) {
-                v *= a.e0[((size_t)n * a.e0_ctotal + a.e0_coff + co) * hw + p];
-            } else if (a.epi == GEPI_GRU) {
-                const float hh = a.e0[((size_t)n * a.e0_ctotal + a.e0_coff + co) * hw + p];
-                const float z = a.e1[((size_t)n * a.e1_ctotal + a.e1_coff + co) * hw + p];
-                v = (1.f - z) * hh + z * v;
-            } else if (a.epi == GEPI_ADD_RELU) {
-                v += a.e0[((size_t)n * a.e0_ctotal + a.e0_coff + co) * hw + p];
-                v = v > 0.f ? v : 0.f;
-            } else if (a.epi == GEPI_ADD) {
-                v += a.e0[((size_t)n * a.e0_ctotal + a.e0_coff + co) * hw + p];
+                for (int r = 0; r < 4; ++r) {
+                    const int co = mtg * 16 + 4 * g + r;
+                    if (co >= a.cout) continue;
+                    const float v = g16_act(acc[t][r] * e_scale[r] + e_shift[r], a.act);
+                    const int oc = a.out_coff + grp * a.g_ocoff + co * (a.out_cmul > 1 ? a.out_cmul : 1);
+                    a.out[((size_t)n * a.out_ctotal + oc) * hw + p] = v * a.out_scale;
+                }
             }
-            const int oc = a.out_coff + grp * a.g_ocoff + co * (a.out_cmul > 1 ? a.out_cmul : 1);
-            a.out[((size_t)n * a.out_ctotal + oc) * hw + p] = v * a.out_scale;
+        }
+    } else {
+        unsigned ip[NR][4];                                      // (co, pixel) part of an operand's index (gconv16_supported: < 2^31); ~0u = outside
+#pragma unroll
+        for (int t = 0; t < NR; ++t) {
+            const int y = y0 + wp * NR + t;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = mtg * 16 + 4 * g + r;
+                const bool in = x < a.wout && y < a.hout && co < a.cout;
+                ip[t][r] = in ? (unsigned)(co * hw + y * a.wout + x) : ~0u;
+            }
+        }
+        float e0v[NR][4], e1v[NR][4], prv[NR][4];
+#pragma unroll
+        for (int t = 0; t < NR; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { e0v[t][r] = 0.f; e1v[t][r] = 0.f; prv[t][r] = 0.f; }
+        if (a.pre) {
+            const float* b = a.pre + ((size_t)n * a.pre_ctotal + a.pre_coff) * hw;
+#pragma unroll
+            for (int t = 0; t < NR; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) prv[t][r] = b[ip[t][r] == ~0u ? 0u : ip[t][r]];
+        }
+        if (a.epi != GEPI_PLAIN) {
+            const float* b = a.e0 + ((size_t)n * a.e0_ctotal + a.e0_coff) * hw;
+#pragma unroll
+            for (int t = 0; t < NR; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) e0v[t][r] = b[ip[t][r] == ~0u ? 0u : ip[t][r]];
+        }
+        if (a.epi == GEPI_GRU) {
+            const float* b = a.e1 + ((size_t)n * a.e1_ctotal + a.e1_coff) * hw;
+#pragma unroll
+            for (int t = 0; t < NR; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) e1v[t][r] = b[ip[t][r] == ~0u ? 0u : ip[t][r]];
+        }
+#pragma unroll
+        for (int t = 0; t < NR; ++t) {
+            const int p = (y0 + wp * NR + t) * a.wout + x;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (ip[t][r] == ~0u) continue;
+                const int co = mtg * 16 + 4 * g + r;
+                float v = acc[t][r] * e_scale[r] + e_shift[r] + prv[t][r];
+                v = g16_act(v, a.act);
+                if (a.epi == GEPI_MUL) {
+                    v *= e0v[t][r];
+                } else if (a.epi == GEPI_GRU) {
+                    v = (1.f - e1v[t][r]) * e0v[t][r] + e1v[t][r] * v;
+                } else if (a.epi == GEPI_ADD_RELU) {
+                    v += e0v[t][r];
+                    v = v > 0.f ? v : 0.f;
+                } else if (a.epi == GEPI_ADD) {
+                    v += e0v[t][r];
+                }
+                const int oc = a.out_coff + grp * a.g_ocoff + co * (a.out_cmul > 1 ? a.out_cmul : 1);
+                a.out[((size_t)n * a.out_ctotal + oc) * hw + p] = v * a.out_scale;
+            }
         }
     }
 #ifdef EEM_G16_STAMPS
@@ -409,6 +463,7 @@ bool gconv16_supported(const GConvArgs& a) {
     const long blocks = (long)ceil_div(a.wout, 16) * ceil_div(a.hout, 4) * ceil_div(a.cout, 64) * a.n * (a.groups > 1 ? a.groups : 1);
     if (cin < min_cin || blocks < min_blk) return false;
     if (a.groups > 1 && (a.nseg != 1 || a.epi != GEPI_PLAIN)) return false;
+    if ((a.epi != GEPI_PLAIN || a.pre) && (size_t)a.cout * a.hin * a.win >= (1u << 31)) return false;   // 32-bit operand indices in the epilogue
     return gconv16_shape(a.cout, cs, a.nseg, a.kh, a.kw, a.stride) && a.win % 4 == 0 && a.hout == a.hin && a.wout == a.win &&
            (size_t)16 * a.hin * a.win * 4 < (1u << 31);
 }

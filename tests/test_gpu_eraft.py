@@ -225,6 +225,23 @@ def test_encoder_winograd_convs_equal_the_lds_tiled_ones(monkeypatch):
     assert maxerr(wino, tiled) < 5e-4 and float(tiled.abs().max()) > 1e-3
 
 
+def test_gru_context_part_computed_once_equals_the_full_convs(monkeypatch):
+    """The GRU's convs read [h | inp | motion] (model/update.py:43-60) and `inp` does not change over the iterations: its part of
+    every conv (+ the bias) is computed once per forward and enters the in-loop convs over [h | motion] as a per-pixel addend in front
+    of the activation (GConvArgs::pre); EEM_ERAFT_NO_PRE=1 (read per forward) keeps the reference's full convolutions.  The same
+    products summed in another order."""
+    h, w = 256, 320
+    net, _ = make_net(45)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(46, 2, h, w))
+    with torch.no_grad():
+        once = torch.stack(net(e1, e2, iters=6)[1]).clone()
+        monkeypatch.setenv("EEM_ERAFT_NO_PRE", "1")
+        full = torch.stack(net(e1, e2, iters=6)[1]).clone()
+    assert not torch.equal(once, full)                                   # (the switch did switch)
+    assert maxerr(once, full) < 2e-4 and float(full.abs().max()) > 1e-3
+
+
 def test_stacked_update_block_launches_equal_separate_ones(monkeypatch):
     """z | r of a GRU pass and flow-head | mask-head conv1 run as one launch each, stacked along the output channels
     (csrc/eraft_api.hip); EEM_ERAFT_NO_STACK=1 (read per forward) keeps the reference's five separate convolutions.  Per output

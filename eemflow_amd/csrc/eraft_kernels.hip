@@ -491,18 +491,31 @@ __global__ __launch_bounds__(256) void convex_up_kernel(const float* __restrict_
     float den = 0.f;
 #pragma unroll
     for (int k = 0; k < 9; ++k) { lg[k] = expf(lg[k] - mx); den += lg[k]; }
-    float u = 0.f, v = 0.f;
+    // the nine neighbours' coordinates: loads unconditional from clamped cells, the bounds test applied to the weight (a load inside
+    // a lane-dependent branch is followed by the compiler's s_waitcnt vmcnt(0): up to 54 dependent round trips per pixel before)
+    float fx[9], fy[9];
+    bool in[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
-        if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
-            const size_t q = (size_t)b * 2 * hw + yy * w + xx;
+        in[k] = yy >= 0 && yy < h && xx >= 0 && xx < w;
+        const size_t q = (size_t)b * 2 * hw + min(max(yy, 0), h - 1) * w + min(max(xx, 0), w - 1);
+        // (c1 + delta) - c0: the sum first, as coords1 = coords1 + delta_flow then coords1 - coords0 (model/eraft.py:149,152)
+        if (delta) {                                                     // (uniform)
+            fx[k] = (c1[q] + delta[q]) - c0[q];
+            fy[k] = (c1[q + hw] + delta[q + hw]) - c0[q + hw];
+        } else {
+            fx[k] = c1[q] - c0[q];
+            fy[k] = c1[q + hw] - c0[q + hw];
+        }
+    }
+    float u = 0.f, v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        if (in[k]) {
             const float wgt = lg[k] / den;
-            // (c1 + delta) - c0: the sum first, as coords1 = coords1 + delta_flow then coords1 - coords0 (model/eraft.py:149,152)
-            const float fx = delta ? (c1[q] + delta[q]) - c0[q] : c1[q] - c0[q];
-            const float fy = delta ? (c1[q + hw] + delta[q + hw]) - c0[q + hw] : c1[q + hw] - c0[q + hw];
-            u += wgt * (8.f * fx);
-            v += wgt * (8.f * fy);
+            u += wgt * (8.f * fx[k]);
+            v += wgt * (8.f * fy[k]);
         }
     }
     const size_t o = (size_t)b * 2 * oh * ow + (size_t)(Y - top) * ow + (X - left);

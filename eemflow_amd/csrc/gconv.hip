@@ -314,6 +314,7 @@ __global__ __launch_bounds__(256) void gconv_taps_kernel(GConvArgs a) {
             const float x = in[ok ? iy * a.win + ix : 0];
             bv[t] = ok ? x : 0.f;
         }
+        __builtin_amdgcn_sched_barrier(0);          // without it the scheduler pairs every tap's two loads with its MFMA: TAPS round trips
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
     }

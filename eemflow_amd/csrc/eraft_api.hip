@@ -631,8 +631,12 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
                     a = conv_args(c, c->gzr[pass], B, h8, w8, c->z.p, 256, 0, GACT_SIGMOID);
                     set_seg(a, 0, hcur, 128, 128, 0); set_seg(a, 1, c->inp.p, 128, 128, 0); set_seg(a, 2, c->motion.p, 128, 128, 0);
                 }
+                // r leaves the launch as r * h (GEPI_ZR); EEM_ERAFT_NO_ZR=1: the separate elementwise launch
+                const char* enz = getenv("EEM_ERAFT_NO_ZR");
+                const bool zr_epi = !(enz && enz[0] == '1');
+                if (zr_epi) { a.epi = GEPI_ZR; a.split = 128; a.out2 = c->rh.p; a.out2_ctotal = 128; a.e0 = hcur; a.e0_ctotal = 128; a.e0_coff = 0; }
                 if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
-                if ((rc = er_mul_channels_launch(c->rh.p, c->z.p, 256, 128, hcur, B, 128, (long)g, st)) != EEM_OK) return rc;
+                if (!zr_epi && (rc = er_mul_channels_launch(c->rh.p, c->z.p, 256, 128, hcur, B, 128, (long)g, st)) != EEM_OK) return rc;
             } else {
                 a = conv_args(c, c->gz[pass], B, h8, w8, c->z.p, 128, 0, GACT_SIGMOID);
                 set_seg(a, 0, hcur, 128, 128, 0); set_seg(a, 1, c->inp.p, 128, 128, 0); set_seg(a, 2, c->motion.p, 128, 128, 0);

@@ -18,7 +18,9 @@ enum {
     GEPI_MUL = 1,          // out = v * e0                      (r * h of the GRU)
     GEPI_GRU = 2,          // out = (1 - e1) * e0 + e1 * v      (e0 = h, e1 = z)
     GEPI_ADD_RELU = 3,     // out = relu(v + e0)                (residual block tail)
-    GEPI_ADD = 4           // out = v + e0                      (EEMFlow+ decoder: flow residual)
+    GEPI_ADD = 4,          // out = v + e0                      (EEMFlow+ decoder: flow residual)
+    GEPI_ZR = 5            // co < split: out = v;  co >= split: out2[co - split] = v * e0[co - split]
+                           // (z | r of a GRU pass as one conv: z stays, r leaves as r * h - model/update.py:46-48,54-56)
 };
 
 struct GConvArgs {
@@ -53,6 +55,8 @@ struct GConvArgs {
     // features, model/update.py:43-60), computed once
     const float* pre;
     int pre_ctotal, pre_coff;
+    float* out2;           // GEPI_ZR: [N][out2_ctotal][hout][wout]
+    int out2_ctotal, split;
 };
 
 // number of packed floats / packing for weights [cout][sum(c_s)][kh][kw] read as segments of sizes cs[0..nseg)

@@ -209,7 +209,15 @@ __global__ __launch_bounds__(SPLITK ? SPLITK * 64 : 256) void gconv_kernel(GConv
             v += a.e0[((size_t)n * a.e0_ctotal + a.e0_coff + co) * hwo + p];
         }
         const int oc = a.out_coff + co * (a.out_cmul > 1 ? a.out_cmul : 1);
-        a.out[((size_t)n * a.out_ctotal + oc) * hwo + p] = v * a.out_scale;
+        float* dst = a.out + ((size_t)n * a.out_ctotal + oc) * hwo + p;
+        // GEPI_ZR: the r half leaves as r * h, to the second output.  One store through a selected pointer: a second store in this
+        // else-if chain (with an early exit) made hipcc emit code that stores through `out2` on the other epilogues' paths too
+        if (a.epi == GEPI_ZR && co >= a.split) {
+            const int c2 = co - a.split;
+            v *= a.e0[((size_t)n * a.e0_ctotal + a.e0_coff + c2) * hwo + p];
+            dst = a.out2 + ((size_t)n * a.out2_ctotal + c2) * hwo + p;
+        }
+        *dst = v * a.out_scale;
     };
     if (SPLITK) {
         // [wave][register][lane]: every wave leaves its 16 partial sums, then wave w finishes registers R*w .. R*w + R-1
@@ -476,7 +484,8 @@ int gconv_launch(const GConvArgs& a, hipStream_t stream) {
         const bool shape7 = a.kh == 7 && a.kw == 7, shape3 = a.kh == 3 && a.kw == 3;
         // (one pair only: with the 5-bin volumes' three pairs through a stride-2 7x7 the 2x2-tile batches of the generic kernel are
         // faster - measured, E-RAFT 122 -> 117 frames/s)
-        if (!off && a.nseg == 1 && a.seg[0].c <= 2 && (shape7 || shape3) && a.tstride <= 1 && a.epi == GEPI_PLAIN && a.pre == nullptr && a.seg[0].gate == nullptr &&
+        static const int taps_maxc = [] { const char* e = getenv("EEM_TAPS_MAXC"); return e ? atoi(e) : 6; }();   // 7x7: up to three channel pairs (the encoders' stems on 5-bin volumes; 2 = the flow conv only)
+        if (!off && a.nseg == 1 && a.seg[0].c <= (shape7 ? taps_maxc : 2) && (shape7 || shape3) && a.tstride <= 1 && a.epi == GEPI_PLAIN && a.pre == nullptr && a.seg[0].gate == nullptr &&
             a.seg[0].cmul <= 1) {
             dim3 grid(ceil_div(hwo, 128), cot, a.n);
             if (shape7) hipLaunchKernelGGL((gconv_taps_kernel<7, 7>), grid, dim3(256), 0, stream, a);

@@ -294,12 +294,13 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || (THT != 2 && THT != 4)) ? 2 : 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) prv[t][r] = b[ip[t][r] == ~0u ? 0u : ip[t][r]];
         }
+        const unsigned zsplit = a.epi == GEPI_ZR ? (unsigned)(a.split * hw) : 0u;   // GEPI_ZR: e0 is indexed by co - split, from split on
         if (a.epi != GEPI_PLAIN) {
             const float* b = a.e0 + ((size_t)n * a.e0_ctotal + a.e0_coff) * hw;
 #pragma unroll
             for (int t = 0; t < NR; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) e0v[t][r] = b[ip[t][r] == ~0u ? 0u : ip[t][r]];
+                for (int r = 0; r < 4; ++r) e0v[t][r] = b[(ip[t][r] == ~0u || ip[t][r] < zsplit) ? 0u : ip[t][r] - zsplit];
         }
         if (a.epi == GEPI_GRU) {
             const float* b = a.e1 + ((size_t)n * a.e1_ctotal + a.e1_coff) * hw;
@@ -328,7 +329,15 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || (THT != 2 && THT != 4)) ? 2 : 
                     v += e0v[t][r];
                 }
                 const int oc = a.out_coff + grp * a.g_ocoff + co * (a.out_cmul > 1 ? a.out_cmul : 1);
-                a.out[((size_t)n * a.out_ctotal + oc) * hw + p] = v * a.out_scale;
+                float* dst = a.out + ((size_t)n * a.out_ctotal + oc) * hw + p;
+                // GEPI_ZR: r leaves as r * h, to the second output.  One store through a selected pointer: written as a second store in the
+                // else-if chain above (followed by `continue`), hipcc's code stored through `out2` on the other epilogues' paths too (memory
+                // fault in <3,3,5,4,1> with GEPI_ADD_RELU; round 3's GEPI_SPLIT_MUL attempt had died the same way)
+                if (a.epi == GEPI_ZR && co >= a.split) {
+                    v *= e0v[t][r];
+                    dst = a.out2 + ((size_t)n * a.out2_ctotal + (co - a.split)) * hw + p;
+                }
+                *dst = v * a.out_scale;
             }
         }
     }

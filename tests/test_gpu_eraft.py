@@ -242,6 +242,20 @@ def test_gru_context_part_computed_once_equals_the_full_convs(monkeypatch):
     assert maxerr(once, full) < 2e-4 and float(full.abs().max()) > 1e-3
 
 
+def test_r_times_h_in_the_gate_conv_epilogue_equals_the_separate_launch(monkeypatch):
+    """z | r of a GRU pass is one conv; its r half leaves the launch as r * h (GEPI_ZR, second output) instead of through an elementwise
+    launch (EEM_ERAFT_NO_ZR=1, read per forward).  The same products: bitwise equal."""
+    h, w = 256, 320
+    net, _ = make_net(47)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(48, 2, h, w))
+    with torch.no_grad():
+        fused = torch.stack(net(e1, e2, iters=4)[1]).clone()
+        monkeypatch.setenv("EEM_ERAFT_NO_ZR", "1")
+        apart = torch.stack(net(e1, e2, iters=4)[1]).clone()
+    assert torch.equal(fused, apart) and float(apart.abs().max()) > 1e-3
+
+
 def test_stacked_update_block_launches_equal_separate_ones(monkeypatch):
     """z | r of a GRU pass and flow-head | mask-head conv1 run as one launch each, stacked along the output channels
     (csrc/eraft_api.hip); EEM_ERAFT_NO_STACK=1 (read per forward) keeps the reference's five separate convolutions.  Per output

@@ -104,16 +104,25 @@ __global__ __launch_bounds__(256) void lookup_bwd_rows_kernel(LookupBwdArgs a) {
     const float* dch = a.dout + ((size_t)b * 324 + lvl * 81) * hw + p;
     float* row = a.dpyr[lvl] + ((size_t)b * hw + p) * h * w + (size_t)Y * w;
     // dout of the two candidate rows for every x tap: d[q][i]
+    // (every load unconditional, from a clamped index: a load inside a lane-dependent branch is followed by the compiler's
+    // s_waitcnt vmcnt(0) - eighteen dout reads and ten read-modify-writes were 28 dependent round trips per thread)
     float d[2][9];
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < 2; ++q) {
+        const int jc = min(max(jy[q], 0), 8);
 #pragma unroll
-        for (int i = 0; i < 9; ++i) d[q][i] = (wy[q] != 0.f) ? dch[(size_t)(i * 9 + jy[q]) * hw] * wy[q] : 0.f;
+        for (int i = 0; i < 9; ++i) {
+            const float v = dch[(size_t)(i * 9 + jc) * hw];
+            d[q][i] = (wy[q] != 0.f) ? v * wy[q] : 0.f;
+        }
+    }
     const int xb = x0[0];
+    float old[10];
+#pragma unroll
+    for (int c = 0; c < 10; ++c) old[c] = row[min(max(xb + c, 0), w - 1)];
 #pragma unroll
     for (int c = 0; c < 10; ++c) {
         const int X = xb + c;
-        if (X < 0 || X >= w) continue;
         float sum = 0.f;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -122,7 +131,7 @@ __global__ __launch_bounds__(256) void lookup_bwd_rows_kernel(LookupBwdArgs a) {
             const float wx = x0[i] == X ? 1.f - tx[i] : (x0[i] + 1 == X ? tx[i] : 0.f);
             sum += wx * (d[0][i] + d[1][i]);
         }
-        row[X] += sum;
+        if (X >= 0 && X < w) row[X] = old[c] + sum;
     }
 }
 

@@ -460,8 +460,11 @@ extern "C" int eemplus_forward(eemplus_ctx* c, const float* e1, const float* e2,
     for (int l = 5; l >= 2; --l)
         if ((rc = run_level(c, l, B, nullptr, st)) != EEM_OK) return rc;
     // ---- five full-resolution predictions, coarse to fine (:231-232); flow6..flow3 carry the doubling above
-    for (int i = 0, l = 6; l >= 2; --l, ++i)
-        if ((rc = pl_upflow_launch(c->flow[l].p, out + (size_t)i * B * 2 * in_h * in_w, B, hl[l], wl[l], in_h, in_w, 1, st)) != EEM_OK) return rc;
+    {
+        const float* ins[5]; float* outs[5]; int hs[5], ws[5];
+        for (int i = 0, l = 6; l >= 2; --l, ++i) { ins[i] = c->flow[l].p; outs[i] = out + (size_t)i * B * 2 * in_h * in_w; hs[i] = hl[l]; ws[i] = wl[l]; }
+        if ((rc = pl_upflow_multi_launch(ins, outs, hs, ws, 5, B, in_h, in_w, 1, st)) != EEM_OK) return rc;
+    }
     c->B = B; c->have_last = true;
     return EEM_OK;
 }

@@ -7,6 +7,9 @@
 int pl_warp_launch(const float* x, const float* flow, int flow_ctotal, float* out, int out_ctotal, int out_coff, int batch, int c, int h,
                    int w, int mode, hipStream_t st);
 int pl_upflow_launch(const float* in, float* out, int batch, int h, int w, int oh, int ow, int rate, hipStream_t st);
+// up to five upsamplings to the same output size as one launch (falls back to pl_upflow_launch per job when ow % 4 or alignment say so)
+int pl_upflow_multi_launch(const float* const* in, float* const* out, const int* h, const int* w, int njobs, int batch, int oh, int ow,
+                           int rate, hipStream_t st);
 int pl_scale_flow_launch(float* f, int batch, int hw, float su, float sv, hipStream_t st);
 int pl_blend_launch(const float* warped, const float* flow_init, const float* xout, float* out, int batch, int hw, hipStream_t st);
 // dst[:, d_coff : d_coff + c] = src[:, s_coff : s_coff + c]   (src NULL: zeros)

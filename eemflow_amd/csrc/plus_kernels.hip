@@ -87,6 +87,43 @@ __global__ __launch_bounds__(256) void upflow_kernel(const float* __restrict__ i
     out[idx] = v;
 }
 
+// The five full-resolution predictions of a forward (EEMFlow+.py:231-232) as ONE launch: job = blockIdx.y, a thread = four
+// neighbouring outputs of a row and one 16-byte store (the arithmetic per output is upflow_kernel's, to the bit)
+struct UpflowJobs { const float* in[5]; float* out[5]; int h[5], w[5]; };
+__global__ __launch_bounds__(256) void upflow_multi_kernel(UpflowJobs J, int batch, int oh, int ow, int rate) {
+    const int job = blockIdx.y;
+    const int h = J.h[job], w = J.w[job];
+    const float* __restrict__ in = J.in[job];
+    float* __restrict__ out = J.out[job];
+    const int owq = ow >> 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)batch * 2 * oh * owq) return;
+    const int Xq = idx % owq, Y = (idx / owq) % oh;
+    const int bc = idx / ((long)owq * oh);
+    const float sy = oh > 1 ? (float)(h - 1) / (float)(oh - 1) : 0.f, sx = ow > 1 ? (float)(w - 1) / (float)(ow - 1) : 0.f;
+    const float fy = sy * (float)Y;
+    const int y0 = (int)fy;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
+    const float ly = fy - (float)y0;
+    const float* s = in + (size_t)bc * h * w;
+    const float* r0 = s + y0 * w;
+    const float* r1 = s + y1 * w;
+    const float mul = rate ? ((bc & 1) ? ((float)oh / (float)h) : ((float)ow / (float)w)) : 1.f;
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int X = Xq * 4 + i;
+        const float fx = sx * (float)X;
+        const int x0 = (int)fx;
+        const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
+        const float lx = fx - (float)x0;
+        float v = (1.f - ly) * ((1.f - lx) * r0[x0] + lx * r0[x1]) + ly * ((1.f - lx) * r1[x0] + lx * r1[x1]);
+        if (rate) v *= mul;
+        o[i] = v;
+    }
+    *reinterpret_cast<f32x4*>(out + ((size_t)bc * oh + Y) * ow + Xq * 4) = o;
+}
+
 // the in-place side effect of upsample2d_flow_as(if_rate=True): inputs[:,0] *= ow/w; inputs[:,1] *= oh/h
 __global__ __launch_bounds__(256) void scale_flow_kernel(float* __restrict__ f, int batch, int hw, float su, float sv) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -124,6 +161,24 @@ int pl_warp_launch(const float* x, const float* flow, int flow_ctotal, float* ou
 
 int pl_upflow_launch(const float* in, float* out, int batch, int h, int w, int oh, int ow, int rate, hipStream_t st) {
     hipLaunchKernelGGL(upflow_kernel, dim3(nblocks((long)batch * 2 * oh * ow)), dim3(256), 0, st, in, out, batch, h, w, oh, ow, rate);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int pl_upflow_multi_launch(const float* const* in, float* const* out, const int* h, const int* w, int njobs, int batch, int oh, int ow,
+                           int rate, hipStream_t st) {
+    bool vec = njobs >= 1 && njobs <= 5 && (ow & 3) == 0;
+    for (int i = 0; i < njobs && vec; ++i) vec = ((uintptr_t)out[i] & 15) == 0;
+    if (!vec) {
+        for (int i = 0; i < njobs; ++i) {
+            const int rc = pl_upflow_launch(in[i], out[i], batch, h[i], w[i], oh, ow, rate, st);
+            if (rc != EEM_OK) return rc;
+        }
+        return EEM_OK;
+    }
+    UpflowJobs J;
+    for (int i = 0; i < 5; ++i) { const int k = i < njobs ? i : 0; J.in[i] = in[k]; J.out[i] = out[k]; J.h[i] = h[k]; J.w[i] = w[k]; }
+    hipLaunchKernelGGL(upflow_multi_kernel, dim3(nblocks((long)batch * 2 * oh * (ow >> 2)), njobs), dim3(256), 0, st, J, batch, oh, ow, rate);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

@@ -225,8 +225,9 @@ __global__ __launch_bounds__(256) void convex_up_bwd_kernel(const float* __restr
         const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
         in[k] = yy >= 0 && yy < h && xx >= 0 && xx < w;
         const size_t q = (size_t)b * 2 * hw + (in[k] ? yy * w + xx : 0);
-        fu[k] = in[k] ? 8.f * flow[q] : 0.f;
-        fv[k] = in[k] ? 8.f * flow[q + hw] : 0.f;
+        const float f0 = flow[q], f1 = flow[q + hw];                  // (q is clamped: loads unconditional, the bounds applied to the values)
+        fu[k] = in[k] ? 8.f * f0 : 0.f;
+        fv[k] = in[k] ? 8.f * f1 : 0.f;
     }
     float gu[9], gv[9];
 #pragma unroll
@@ -313,10 +314,13 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
         const float g = dout[plane + p] * m;
         const float* s = x + plane;
         float* d = dx + plane;
-        const float v_nw = (in_n && in_w) ? s[y0 * w + x0] : 0.f;
-        const float v_ne = (in_n && in_e) ? s[y0 * w + x0 + 1] : 0.f;
-        const float v_sw = (in_s && in_w) ? s[(y0 + 1) * w + x0] : 0.f;
-        const float v_se = (in_s && in_e) ? s[(y0 + 1) * w + x0 + 1] : 0.f;
+        // (unconditional loads from clamped cells, the bounds applied to the values)
+        const int ya = min(max(y0, 0), h - 1), yb = min(max(y0 + 1, 0), h - 1), xa = min(max(x0, 0), w - 1), xb = min(max(x0 + 1, 0), w - 1);
+        const float r_nw = s[ya * w + xa], r_ne = s[ya * w + xb], r_sw = s[yb * w + xa], r_se = s[yb * w + xb];
+        const float v_nw = (in_n && in_w) ? r_nw : 0.f;
+        const float v_ne = (in_n && in_e) ? r_ne : 0.f;
+        const float v_sw = (in_s && in_w) ? r_sw : 0.f;
+        const float v_se = (in_s && in_e) ? r_se : 0.f;
         if (in_n && in_w) atomicAdd(d + y0 * w + x0, g * nw);
         if (in_n && in_e) atomicAdd(d + y0 * w + x0 + 1, g * ne);
         if (in_s && in_w) atomicAdd(d + (y0 + 1) * w + x0, g * sw);

@@ -305,17 +305,30 @@ __global__ __launch_bounds__(256) void pool2_kernel(const float* __restrict__ in
 
 // grid_sample(align_corners=True, zeros) at pixel coordinates, computed like the reference: normalise with
 // (size-1), un-normalise again, floor, 4 taps (model/model_utils.py:7-21)
+// FLAT: the four corners as unconditional loads from clamped cells, the bounds applied to the values - one round trip per sample
+// instead of four dependent ones (a load in one arm of a lane-dependent conditional is a branch + s_waitcnt vmcnt(0)); it also loads
+// the corners that fall outside the map, which the coarse levels have many of, so launches that fill the chip (batch 4) keep the
+// conditional form (E-RAFT 640x480: batch 1 149.0 -> 150.8 frames/s with FLAT, batch 4 198 -> 194)
+template <bool FLAT>
 __device__ __forceinline__ float sample_bilinear(const float* __restrict__ img, int h, int w, float x, float y) {
     const float xn = 2.f * x / (float)(w - 1) - 1.f, yn = 2.f * y / (float)(h - 1) - 1.f;
     const float ix = ((xn + 1.f) * 0.5f) * (float)(w - 1), iy = ((yn + 1.f) * 0.5f) * (float)(h - 1);
     const float fx = floorf(ix), fy = floorf(iy);
     const int x0 = (int)fx, y0 = (int)fy;
     const float tx = ix - fx, ty = iy - fy;
-    auto at = [&](int yy, int xx) -> float {
-        return (yy >= 0 && yy < h && xx >= 0 && xx < w) ? img[(size_t)yy * w + xx] : 0.f;
-    };
-    return at(y0, x0) * (1.f - tx) * (1.f - ty) + at(y0, x0 + 1) * tx * (1.f - ty) + at(y0 + 1, x0) * (1.f - tx) * ty +
-           at(y0 + 1, x0 + 1) * tx * ty;
+    float v00, v01, v10, v11;
+    if (FLAT) {
+        const int ya = min(max(y0, 0), h - 1), yb = min(max(y0 + 1, 0), h - 1), xa = min(max(x0, 0), w - 1), xb = min(max(x0 + 1, 0), w - 1);
+        const float r00 = img[(size_t)ya * w + xa], r01 = img[(size_t)ya * w + xb], r10 = img[(size_t)yb * w + xa], r11 = img[(size_t)yb * w + xb];
+        const bool iy0 = y0 >= 0 && y0 < h, iy1 = y0 + 1 >= 0 && y0 + 1 < h, ix0 = x0 >= 0 && x0 < w, ix1 = x0 + 1 >= 0 && x0 + 1 < w;
+        v00 = (iy0 && ix0) ? r00 : 0.f; v01 = (iy0 && ix1) ? r01 : 0.f; v10 = (iy1 && ix0) ? r10 : 0.f; v11 = (iy1 && ix1) ? r11 : 0.f;
+    } else {
+        auto at = [&](int yy, int xx) -> float {
+            return (yy >= 0 && yy < h && xx >= 0 && xx < w) ? img[(size_t)yy * w + xx] : 0.f;
+        };
+        v00 = at(y0, x0); v01 = at(y0, x0 + 1); v10 = at(y0 + 1, x0); v11 = at(y0 + 1, x0 + 1);
+    }
+    return v00 * (1.f - tx) * (1.f - ty) + v01 * tx * (1.f - ty) + v10 * (1.f - tx) * ty + v11 * tx * ty;
 }
 
 __global__ __launch_bounds__(256) void lookup_kernel(LookupArgs a) {
@@ -332,7 +345,7 @@ __global__ __launch_bounds__(256) void lookup_kernel(LookupArgs a) {
     const float x = cx / sc + (float)(i - 4);          // the reference adds (dy[i], dx[j]) to (x, y)
     const float y = cy / sc + (float)(jj - 4);
     const float* img = a.pyr[lvl] + ((size_t)b * hw + p) * a.ph[lvl] * a.pw[lvl];
-    a.out[((size_t)b * a.out_ctotal + ch) * hw + p] = sample_bilinear(img, a.ph[lvl], a.pw[lvl], x, y);
+    a.out[((size_t)b * a.out_ctotal + ch) * hw + p] = sample_bilinear<false>(img, a.ph[lvl], a.pw[lvl], x, y);
     if (a.flow_dst != nullptr && ch < 2)
         a.flow_dst[((size_t)b * a.flow_ctotal + a.flow_coff + ch) * hw + p] = (ch ? cy : cx) - a.coords0[((size_t)b * 2 + ch) * hw + p];
 }
@@ -341,6 +354,7 @@ __global__ __launch_bounds__(256) void lookup_kernel(LookupArgs a) {
 // 256-byte runs but every lane samples a different pixel's correlation map (19 KB apart at level 0).  Here a block owns 64
 // consecutive pixels of one pyramid level; lanes walk the flattened (pixel, tap) pairs, so the 64 samples of an instruction
 // come from the 10x10 windows of one or two maps; the values pass through an LDS tile [tap][pixel] and leave as 256-byte runs.
+template <bool FLAT>
 __global__ __launch_bounds__(256) void lookup_tiled_kernel(LookupArgs a) {
     __shared__ float tile[81][65];
     __shared__ float cxs[64], cys[64];
@@ -368,7 +382,7 @@ __global__ __launch_bounds__(256) void lookup_tiled_kernel(LookupArgs a) {
         const int i = k / 9, jj = k - i * 9;
         const float x = cxs[px] * inv + (float)(i - 4);          // as lookup_kernel: the reference adds (dy[i], dx[j]) to (x, y)
         const float y = cys[px] * inv + (float)(jj - 4);
-        tile[k][px] = sample_bilinear(maps + (size_t)px * ph * pw, ph, pw, x, y);
+        tile[k][px] = sample_bilinear<FLAT>(maps + (size_t)px * ph * pw, ph, pw, x, y);
     }
     __syncthreads();
     float* out = a.out + ((size_t)b * a.out_ctotal + lvl * 81) * hw + p0;
@@ -578,7 +592,8 @@ int er_pool2_launch(const float* in, float* out, long planes, int h, int w, hipS
 int er_lookup_launch(const LookupArgs& a, hipStream_t st) {
     static const bool plain = [] { const char* e = getenv("EEM_LOOKUP_PLAIN"); return e && e[0] == '1'; }();
     if (plain) hipLaunchKernelGGL(lookup_kernel, dim3(blocks((long)a.batch * 324 * a.h * a.w)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(lookup_tiled_kernel, dim3(ceil_div(a.h * a.w, 64), 4, a.batch), dim3(256), 0, st, a);
+    else if ((long)ceil_div(a.h * a.w, 64) * 4 * a.batch < 1024) hipLaunchKernelGGL(lookup_tiled_kernel<true>, dim3(ceil_div(a.h * a.w, 64), 4, a.batch), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(lookup_tiled_kernel<false>, dim3(ceil_div(a.h * a.w, 64), 4, a.batch), dim3(256), 0, st, a);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

@@ -55,10 +55,13 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ x, 
 #pragma unroll
     for (int i = 0; i < kWarpCh; ++i) {
         const float* s = x + ((size_t)b * c + min(ch0 + i, c - 1)) * hw;
-        v[i][0] = o_nw >= 0 ? s[o_nw] : 0.f;
-        v[i][1] = o_ne >= 0 ? s[o_ne] : 0.f;
-        v[i][2] = o_sw >= 0 ? s[o_sw] : 0.f;
-        v[i][3] = o_se >= 0 ? s[o_se] : 0.f;
+        // (unconditional loads from clamped offsets, the bounds applied to the values: a load in one arm of a lane-dependent
+        // conditional is a branch followed by s_waitcnt vmcnt(0) - sixteen dependent round trips instead of one)
+        const float a0 = s[max(o_nw, 0)], a1 = s[max(o_ne, 0)], a2 = s[max(o_sw, 0)], a3 = s[max(o_se, 0)];
+        v[i][0] = o_nw >= 0 ? a0 : 0.f;
+        v[i][1] = o_ne >= 0 ? a1 : 0.f;
+        v[i][2] = o_sw >= 0 ? a2 : 0.f;
+        v[i][3] = o_se >= 0 ? a3 : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < kWarpCh; ++i) {

@@ -172,6 +172,14 @@ struct EncConvArgs {
     // conv_wino4.hip only: residual [nimg][C][hout][wout]; the result is relu(res + act(conv)) (ResidualBlock, model/extractor.py:50-57)
     const float* res = nullptr;
 };
+// Every launch argument a block uses, wanted in scalar registers at its first instruction: one batch of scalar loads instead of the three or
+// four dependent ones the compiler otherwise spreads over the prologue (see tail_conv_kernel in tail.hip for what a memory round trip costs
+// beside other frames' kernels)
+#define ENC_ARGS_NOW(a)                                                                                                                  \
+    asm volatile("" ::"s"((a).in0), "s"((a).in1), "s"((a).wpk), "s"((a).wpk2), "s"((a).wwino), "s"((a).zero_page), "s"((a).trash),        \
+                 "s"((a).bias), "s"((a).out), "s"((a).nimg), "s"((a).nimg0), "s"((a).hin), "s"((a).win), "s"((a).hout), "s"((a).wout),      \
+                 "s"((a).hraw), "s"((a).wraw), "s"((a).pad_top), "s"((a).pad_left), "s"((a).act), "s"((a).gate), "s"((a).tiles_x),        \
+                 "s"((a).tiles_y), "s"((a).pool_partial), "s"((a).io), "s"(gridDim.x))
 int enc_conv_launch(int cin, int cout, int stride, const EncConvArgs& a, hipStream_t stream);
 // first layer with 16-byte LDS-DMA staging (conv_enc1.hip): raw width % 4 == 0, no horizontal padding
 bool enc1_supported(const EncConvArgs& a);

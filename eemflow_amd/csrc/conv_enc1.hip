@@ -39,6 +39,7 @@ struct E1Cfg {
 
 template <int TH, int TWT, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void enc1_kernel(EncConvArgs a) {
+    ENC_ARGS_NOW(a);
     using K = E1Cfg<TH, TWT, WAVES>;
     constexpr int NS = K::UPW;                           // stores per wave and tile
     __shared__ __attribute__((aligned(16))) float lds[K::NST * K::STAGE];

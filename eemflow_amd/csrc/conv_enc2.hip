@@ -52,6 +52,7 @@ template <> struct AccT2<true> { using type = f32x4; };
 
 template <int CIN, int COUT, int STRIDE, int TH, int TWT, int WAVES, int WM, int CK, int POOLK>
 __global__ __launch_bounds__(WAVES * 64) void enc_conv2_kernel(EncConvArgs a) {
+    ENC_ARGS_NOW(a);
     using C = Cfg2<CIN, COUT, STRIDE, TH, TWT, WAVES, WM, CK>;
     using acc_t = typename AccT2<C::M16>::type;
     __shared__ __attribute__((aligned(16))) float lds[C::NSTAGE * C::STAGE];

@@ -49,6 +49,7 @@ void s2_kernel(EncConvArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    ENC_ARGS_NOW(a);
     const unsigned lid = xcd_logical_block(blockIdx.x, gridDim.x);
     if (lid >= (unsigned)(a.tiles_x * a.tiles_y * a.nimg)) return;
     const int bx = lid % a.tiles_x, by = (lid / a.tiles_x) % a.tiles_y;

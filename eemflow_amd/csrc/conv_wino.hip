@@ -64,6 +64,7 @@ __device__ unsigned long long g_stamps16[2048 * 8 * 8];
 
 template <int C, int TH, int TW, int WAVES, int POOLK>
 __global__ __launch_bounds__(WAVES * 64) void wino_kernel(EncConvArgs a) {
+    ENC_ARGS_NOW(a);
 #ifdef EEM_STAMPS
     unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     st[6] = __builtin_amdgcn_s_memtime();

@@ -120,6 +120,7 @@ __device__ unsigned long long g_stamps4[1024 * 8 * 64];
 // separate instantiations, so the forward kernels' register allocation (252 of 256 VGPRs, no scratch) does not carry them
 template <int C, int NGX, int NGY, int POOLK, int EPI>
 __global__ __launch_bounds__(512, 2) void wino4_kernel(EncConvArgs a) {
+    ENC_ARGS_NOW(a);
     using K = W4Cfg<C, NGX, NGY>;
     constexpr int R = K::R, NI = K::NI, KS = K::KS;
     constexpr int NWX = POOLK > 0 ? K::TW / POOLK : 1;                   // pooling windows per block tile (x)

@@ -373,14 +373,21 @@ static int run_level(eemplus_ctx* c, int l, int B, const float* forced_init, hip
     for (int i = 0; i < 5; ++i)
         if ((rc = conv(c, c->de[i], c->dense.p, kDense, kDense - din[i], B, h, w, c->dense.p, kDense, dout_off[i], 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
     if ((rc = conv(c, c->de[5], c->dense.p, kDense, 0, B, h, w, c->xout.p, 3, 0, 1, GACT_NONE, nullptr, st)) != EEM_OK) return rc;
-    if ((rc = pl_warp_launch(fi, c->xout.p, 3, c->tw.p, 2, 0, B, 2, h, w, 1, st)) != EEM_OK) return rc;
-    if ((rc = pl_blend_launch(c->tw.p, fi, c->xout.p, c->fup[l].p, B, (int)g, st)) != EEM_OK) return rc;
+    // warp + blend + the copy of flow_up into the decoder's input as one launch (EEM_PLUS_NO_FUSE=1, read per forward: the three launches)
+    const char* epf = getenv("EEM_PLUS_NO_FUSE");
+    const bool fuse3 = !(epf && epf[0] == '1');
+    if (fuse3) {
+        if ((rc = pl_warp_blend_launch(fi, c->xout.p, c->fup[l].p, c->cat.p, kCat, 85, B, h, w, st)) != EEM_OK) return rc;
+    } else {
+        if ((rc = pl_warp_launch(fi, c->xout.p, 3, c->tw.p, 2, 0, B, 2, h, w, 1, st)) != EEM_OK) return rc;
+        if ((rc = pl_blend_launch(c->tw.p, fi, c->xout.p, c->fup[l].p, B, (int)g, st)) != EEM_OK) return rc;
+    }
     // warp, correlate, decode (:189-193)
     if ((rc = pl_warp_launch(f2(l), c->fup[l].p, 2, c->fw.p, C[l], 0, B, C[l], h, w, 0, st)) != EEM_OK) return rc;
     CorrJob cj = {f1(l), c->fw.p, c->cat.p, C[l], kCat};
     if ((rc = corr_launch(&cj, 1, B, h, w, c->taps, 53, st)) != EEM_OK) return rc;
     if ((rc = conv(c, c->rconv[l], f1(l), C[l], 0, B, h, w, c->cat.p, kCat, 53, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
-    if ((rc = pl_copy_channels_launch(c->fup[l].p, 2, 0, c->cat.p, kCat, 85, 2, B, (int)g, st)) != EEM_OK) return rc;
+    if (!fuse3 && (rc = pl_copy_channels_launch(c->fup[l].p, 2, 0, c->cat.p, kCat, 85, 2, B, (int)g, st)) != EEM_OK) return rc;
     if ((rc = run_decoder(c, l, B, h, w, c->fup[l].p, st)) != EEM_OK) return rc;
     return EEM_OK;
 }

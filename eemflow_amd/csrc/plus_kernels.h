@@ -12,6 +12,9 @@ int pl_upflow_multi_launch(const float* const* in, float* const* out, const int*
                            int rate, hipStream_t st);
 int pl_scale_flow_launch(float* f, int batch, int hw, float su, float sv, hipStream_t st);
 int pl_blend_launch(const float* warped, const float* flow_init, const float* xout, float* out, int batch, int hw, hipStream_t st);
+// torch_warp(flow_init, xout[:, 0:2]) blended with flow_init by sigmoid(xout[:, 2]) -> out [b][2][hw] and channels [cat_coff, +2) of cat
+int pl_warp_blend_launch(const float* flow_init, const float* xout, float* out, float* cat, int cat_ctotal, int cat_coff, int batch, int h, int w,
+                         hipStream_t st);
 // dst[:, d_coff : d_coff + c] = src[:, s_coff : s_coff + c]   (src NULL: zeros)
 int pl_copy_channels_launch(const float* src, int s_ctotal, int s_coff, float* dst, int d_ctotal, int d_coff, int c, int batch, int hw,
                             hipStream_t st);

@@ -144,6 +144,49 @@ __global__ __launch_bounds__(256) void blend_kernel(const float* __restrict__ wa
     out[idx] = warped[idx] * (1.f - mk) + flow_init[idx] * mk;
 }
 
+// cdc_model's last three steps as one launch (cdc_utils.py:163-173 and the copy of flow_up into the decoder's input):
+//   warped = torch_warp(flow_init, xout[:, 0:2])  (warp_kernel's mode 1, operation by operation)
+//   flow_up = warped * (1 - sigmoid(xout[:, 2])) + flow_init * sigmoid(xout[:, 2])  (blend_kernel's expression)
+//   flow_up -> `out` [b][2][hw] and -> channels [cat_coff, cat_coff + 2) of `cat` [b][cat_ctotal][hw]
+__global__ __launch_bounds__(256) void warp_blend_kernel(const float* __restrict__ fi, const float* __restrict__ xout, float* __restrict__ out,
+                                                         float* __restrict__ cat, int cat_ctotal, int cat_coff, int batch, int h, int w) {
+    const int hw = h * w;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)batch * hw) return;
+    const int p = idx % hw, b = idx / hw;
+    const int py = p / w, px = p - py * w;
+    const float vx = (float)px + xout[((size_t)b * 3 + 0) * hw + p];
+    const float vy = (float)py + xout[((size_t)b * 3 + 1) * hw + p];
+    const float xn = 2.0f * vx / (float)max(w - 1, 1) - 1.0f;
+    const float yn = 2.0f * vy / (float)max(h - 1, 1) - 1.0f;
+    const float ix = (xn + 1.f) * ((float)w / 2.f) - 0.5f;
+    const float iy = (yn + 1.f) * ((float)h / 2.f) - 0.5f;
+    const float xw = floorf(ix), yn0 = floorf(iy);
+    const float wgt_w = ix - xw, wgt_e = 1.f - wgt_w, wgt_n = iy - yn0, wgt_s = 1.f - wgt_n;
+    const float nw = wgt_s * wgt_e, ne = wgt_s * wgt_w, sw = wgt_n * wgt_e, se = wgt_n * wgt_w;
+    const float cx = fminf(fmaxf(xw, -2.f), (float)w + 1.f), cy = fminf(fmaxf(yn0, -2.f), (float)h + 1.f);
+    const int x0 = (int)cx, y0 = (int)cy;
+    const bool in_w = x0 >= 0 && x0 < w, in_e = x0 + 1 >= 0 && x0 + 1 < w;
+    const bool in_n = y0 >= 0 && y0 < h, in_s = y0 + 1 >= 0 && y0 + 1 < h;
+    const int ya = min(max(y0, 0), h - 1), yb = min(max(y0 + 1, 0), h - 1), xa = min(max(x0, 0), w - 1), xb = min(max(x0 + 1, 0), w - 1);
+    const float mk = 1.f / (1.f + expf(-xout[((size_t)b * 3 + 2) * hw + p]));
+    float r[2], f0[2];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+        const float* s = fi + ((size_t)b * 2 + ch) * hw;
+        const float a0 = s[ya * w + xa], a1 = s[ya * w + xb], a2 = s[yb * w + xa], a3 = s[yb * w + xb];
+        f0[ch] = s[p];
+        const float v0 = (in_n && in_w) ? a0 : 0.f, v1 = (in_n && in_e) ? a1 : 0.f, v2 = (in_s && in_w) ? a2 : 0.f, v3 = (in_s && in_e) ? a3 : 0.f;
+        r[ch] = ((v0 * nw + v1 * ne) + v2 * sw) + v3 * se;
+    }
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+        const float v = r[ch] * (1.f - mk) + f0[ch] * mk;
+        out[((size_t)b * 2 + ch) * hw + p] = v;
+        cat[((size_t)b * cat_ctotal + cat_coff + ch) * hw + p] = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restrict__ src, int s_ctotal, int s_coff, float* __restrict__ dst,
                                                             int d_ctotal, int d_coff, int c, int batch, int hw) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -194,6 +237,14 @@ int pl_scale_flow_launch(float* f, int batch, int hw, float su, float sv, hipStr
 
 int pl_blend_launch(const float* warped, const float* flow_init, const float* xout, float* out, int batch, int hw, hipStream_t st) {
     hipLaunchKernelGGL(blend_kernel, dim3(nblocks((long)batch * 2 * hw)), dim3(256), 0, st, warped, flow_init, xout, out, batch, hw);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int pl_warp_blend_launch(const float* flow_init, const float* xout, float* out, float* cat, int cat_ctotal, int cat_coff, int batch, int h, int w,
+                         hipStream_t st) {
+    hipLaunchKernelGGL(warp_blend_kernel, dim3(nblocks((long)batch * h * w)), dim3(256), 0, st, flow_init, xout, out, cat, cat_ctotal, cat_coff,
+                       batch, h, w);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

@@ -187,3 +187,19 @@ def test_grouped_decoder_launch_equals_one_launch_per_group(monkeypatch):
         monkeypatch.setenv("EEM_PLUS_NO_GROUPED", "1")
         apart = torch.stack(net(e1, e2)[1]).cpu().numpy()
     assert np.abs(grouped - apart).max() < 1e-6 and np.abs(apart).max() > 1e-3
+
+
+def test_fused_warp_blend_copy_equals_the_three_launches(monkeypatch):
+    """cdc_model's torch_warp + mask blend (cdc_utils.py:163-173) and the copy of flow_up into the decoder's input are one launch
+    (warp_blend_kernel); EEM_PLUS_NO_FUSE=1 (read per forward) keeps warp_kernel / blend_kernel / copy_channels_kernel.  The same
+    operations in the same order per pixel, and the five full-resolution predictions leave through one vectorised launch whose
+    per-output arithmetic is upflow_kernel's: bitwise the same flows."""
+    h, w = 256, 320
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(81, 2, h, w, bins=5))
+    net = make_net(82, 5)
+    net.change_imagesize((h, w))
+    with torch.no_grad():
+        fused = torch.stack(net(e1, e2)[1]).cpu().numpy()
+        monkeypatch.setenv("EEM_PLUS_NO_FUSE", "1")
+        apart = torch.stack(net(e1, e2)[1]).cpu().numpy()
+    assert np.array_equal(fused, apart) and np.abs(apart).max() > 1e-3

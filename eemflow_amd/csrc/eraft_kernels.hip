@@ -589,10 +589,11 @@ int er_pool2_launch(const float* in, float* out, long planes, int h, int w, hipS
     return EEM_OK;
 }
 
+static const long flat_max = [] { const char* e = getenv("EEM_LOOKUP_FLAT_MAX"); return e ? atol(e) : 1024L; }();
 int er_lookup_launch(const LookupArgs& a, hipStream_t st) {
     static const bool plain = [] { const char* e = getenv("EEM_LOOKUP_PLAIN"); return e && e[0] == '1'; }();
     if (plain) hipLaunchKernelGGL(lookup_kernel, dim3(blocks((long)a.batch * 324 * a.h * a.w)), dim3(256), 0, st, a);
-    else if ((long)ceil_div(a.h * a.w, 64) * 4 * a.batch < 1024) hipLaunchKernelGGL(lookup_tiled_kernel<true>, dim3(ceil_div(a.h * a.w, 64), 4, a.batch), dim3(256), 0, st, a);
+    else if ((long)ceil_div(a.h * a.w, 64) * 4 * a.batch < flat_max) hipLaunchKernelGGL(lookup_tiled_kernel<true>, dim3(ceil_div(a.h * a.w, 64), 4, a.batch), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(lookup_tiled_kernel<false>, dim3(ceil_div(a.h * a.w, 64), 4, a.batch), dim3(256), 0, st, a);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;

@@ -204,6 +204,28 @@ int ensure_wino(eemflow_ctx* c, int l, int dir, int batch, hipStream_t st, const
     *f4_out = f4;
     return EEM_OK;
 }
+// a training step's Winograd weights - forward and data-gradient forms of every F(4x4) layer - refreshed by ONE launch in front of its
+// forward (ensure_wino then finds them valid); the F(2x2) forms stay with ensure_wino
+int ensure_train_wino(eemflow_ctx* c, int batch, hipStream_t st) {
+    if (!c->use_wino) return EEM_OK;
+    const float* w[W4_WT_JOBS]; float* out[W4_WT_JOBS]; int ch[W4_WT_JOBS], flip[W4_WT_JOBS];
+    int slot_of[W4_WT_JOBS], layer_of[W4_WT_JOBS], n = 0;
+    for (int l = 0; l < ENC_NUM; ++l) {
+        if (!c->enc_wino[l] || !c->layer_f4(kEncLayers[l].cin, batch)) continue;
+        for (int dir = 0; dir < 2; ++dir) {
+            const int slot = 2 + dir;
+            if (c->wino_ok[slot][l] || n == W4_WT_JOBS) continue;
+            w[n] = c->flat + c->t_enc[l].w; out[n] = c->wino + c->wino_off[slot][l]; ch[n] = kEncLayers[l].cin; flip[n] = dir;
+            slot_of[n] = slot; layer_of[n] = l; ++n;
+        }
+    }
+    if (n == 0) return EEM_OK;
+    const int rc = wino4_transform_multi_launch(w, ch, flip, out, n, st);
+    if (rc != EEM_OK) return rc;
+    for (int i = 0; i < n; ++i) c->wino_ok[slot_of[i]][layer_of[i]] = true;
+    return EEM_OK;
+}
+
 // before a graph capture / replay: the forward copies exist (a transform launched inside a capture would replay with every frame)
 int ensure_forward_wino(eemflow_ctx* c, int batch, hipStream_t st) {
     for (int l = 0; l < ENC_NUM; ++l) {

@@ -210,6 +210,9 @@ void wino_tile(int c, int f4, int* th, int* tw, int* poolk);
 // Winograd F(4x4,3x3) on 16x16x4 MFMAs, one wave per SIMD (conv_wino4.hip); reached through wino_*
 size_t wino4_packed_floats(int c);
 int wino4_transform_launch(const float* w, int c, int transpose_flip, float* packed, hipStream_t stream);
+#define W4_WT_JOBS 12
+int wino4_transform_multi_launch(const float* const* w, const int* c, const int* transpose_flip, float* const* packed, int njobs,
+                                 hipStream_t stream);
 int wino4_launch(int c, const EncConvArgs& a, hipStream_t stream);
 void wino4_tile(int c, int* th, int* tw, int* poolk);
 // C = 32 / 64 on 32x32x2 MFMA with the Winograd rows split over 4 waves (conv_wino32.hip); reached through wino_*

@@ -505,7 +505,13 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(EncConvArgs a) {
 // ---- weight transform U = G g G^T (6x6 per (cout, cin)) into the fragment order read above:
 //   [s = cin / 4][cog = cout / 16][q = p / 4][lane = (cout % 16) + 16 * (cin % 4)][e = p % 4],  p = xi * 6 + nu
 //   (a k-step's weights for every cout group are one contiguous run: the weight part of that k-step's DMA slice)
-__global__ void wino4_wt_kernel(const float* __restrict__ w, int c, int transpose_flip, float* __restrict__ out) {
+// (up to W4_WT_JOBS transforms per launch, job = blockIdx.y: a training step refreshes two forms of five layers after every weight
+// update, ten 7-us launches in front of its forward before)
+struct W4WtJobs { const float* w[W4_WT_JOBS]; float* out[W4_WT_JOBS]; int c[W4_WT_JOBS]; int flip[W4_WT_JOBS]; };
+__global__ void wino4_wt_kernel(W4WtJobs jobs) {
+    const float* __restrict__ w = jobs.w[blockIdx.y];
+    float* __restrict__ out = jobs.out[blockIdx.y];
+    const int c = jobs.c[blockIdx.y], transpose_flip = jobs.flip[blockIdx.y];
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= c * c) return;
     const int co = t / c, ci = t - co * c;
@@ -591,11 +597,24 @@ extern "C" int eemflow_debug_clear_stamps4() {
 
 size_t wino4_packed_floats(int c) { return (size_t)36 * c * c; }
 
-int wino4_transform_launch(const float* w, int c, int transpose_flip, float* packed, hipStream_t stream) {
-    EEM_REQUIRE(c == 16 || c == 32 || c == 64, "wino4_transform_launch: C=%d", c);
-    hipLaunchKernelGGL(wino4_wt_kernel, dim3(ceil_div(c * c, 256)), dim3(256), 0, stream, w, c, transpose_flip, packed);
+int wino4_transform_multi_launch(const float* const* w, const int* c, const int* transpose_flip, float* const* packed, int njobs,
+                                 hipStream_t stream) {
+    EEM_REQUIRE(njobs >= 1 && njobs <= W4_WT_JOBS, "wino4_transform_multi_launch: njobs=%d", njobs);
+    W4WtJobs J;
+    int cmax = 0;
+    for (int i = 0; i < W4_WT_JOBS; ++i) {
+        const int k = i < njobs ? i : 0;
+        EEM_REQUIRE(c[k] == 16 || c[k] == 32 || c[k] == 64, "wino4_transform_multi_launch: C=%d", c[k]);
+        J.w[i] = w[k]; J.out[i] = packed[k]; J.c[i] = c[k]; J.flip[i] = transpose_flip[k];
+        if (c[k] > cmax) cmax = c[k];
+    }
+    hipLaunchKernelGGL(wino4_wt_kernel, dim3(ceil_div(cmax * cmax, 256), njobs), dim3(256), 0, stream, J);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
+}
+
+int wino4_transform_launch(const float* w, int c, int transpose_flip, float* packed, hipStream_t stream) {
+    return wino4_transform_multi_launch(&w, &c, &transpose_flip, &packed, 1, stream);
 }
 
 // what the pooling protocol needs to know: partial sums come in rows of `th` = 8 pixels (a tile group's height, whatever the block

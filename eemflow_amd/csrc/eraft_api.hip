@@ -533,8 +533,8 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
     // ---- pad both event volumes into one batch (model/eraft.py:106-109)
     float* pad1 = c->padded.p;
     float* pad2 = c->padded.p + (size_t)B * cin0 * hp * wp;
-    if ((rc = er_pad_launch(e1, pad1, B * cin0, in_h, in_w, pad[0], pad[1], pad[2], pad[3], st)) != EEM_OK) return rc;
-    if ((rc = er_pad_launch(e2, pad2, B * cin0, in_h, in_w, pad[0], pad[1], pad[2], pad[3], st)) != EEM_OK) return rc;
+    if ((rc = er_pad2_launch(e1, e2, pad1, B * cin0, in_h, in_w, pad[0], pad[1], pad[2], pad[3], st)) != EEM_OK) return rc;
+    (void)pad2;
     // ---- feature network on [image1; image2] (:116), then its 1x1 output conv
     float* feat = nullptr;
     if ((rc = run_encoder(c, c->fnet, c->padded.p, 2 * B, cin0, hp, wp, &feat, st)) != EEM_OK) return rc;

@@ -5,6 +5,9 @@
 
 // F.pad(mode='replicate') of [nc][h][w] -> [nc][h+top+bottom][w+left+right]   (utils/image_utils.py:139-140)
 int er_pad_launch(const float* in, float* out, int nc, int h, int w, int left, int right, int top, int bottom, hipStream_t st);
+// both event volumes of a sample (in0 -> planes [0, nc), in1 -> [nc, 2 nc) of out) as one launch
+int er_pad2_launch(const float* in0, const float* in1, float* out, int nc, int h, int w, int left, int right, int top, int bottom,
+                   hipStream_t st);
 
 // InstanceNorm2d(affine=False, eps=1e-5) per (n,c) plane + options (model/extractor.py:31-35,43-57):
 //   v = (x - mean) / sqrt(var + eps);  if relu_inner: v = relu(v);  if res: v = relu(v + res)

@@ -13,17 +13,20 @@ __global__ __launch_bounds__(256) void pad_kernel(const float* __restrict__ in, 
 }
 
 // four output pixels per thread (16-byte stores), 32-bit index arithmetic once per four pixels; the replicate clamp is per pixel
+// (in1 != NULL: planes [nc, 2 nc) of the output come from in1 - both event volumes of a sample as one launch)
 __global__ __launch_bounds__(256) void pad4_kernel(const float* __restrict__ in, float* __restrict__ out, int nc, int h, int w,
-                                                   int left, int top, int oh, int ow) {
+                                                   int left, int top, int oh, int ow, const float* __restrict__ in1) {
     const int ow4 = ow >> 2;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)nc * oh * ow4) return;
+    if (idx >= (long)(in1 ? 2 * nc : nc) * oh * ow4) return;
     const int x4 = (int)(idx % ow4);
     const long row = idx / ow4;                                  // c * oh + y
     const int y = (int)(row % oh);
-    const long c = row / oh;
+    long c = row / oh;
+    const float* base = in;
+    if (in1 && c >= nc) { c -= nc; base = in1; }
     const int sy = min(max(y - top, 0), h - 1);
-    const float* src = in + (c * h + sy) * w;
+    const float* src = base + (c * h + sy) * w;
     f32x4 v;
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = src[min(max(x4 * 4 + e - left, 0), w - 1)];
@@ -541,10 +544,22 @@ inline unsigned blocks(long n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
 
+int er_pad2_launch(const float* in0, const float* in1, float* out, int nc, int h, int w, int left, int right, int top, int bottom,
+                   hipStream_t st) {
+    const int oh = h + top + bottom, ow = w + left + right;
+    if ((ow & 3) == 0 && ((uintptr_t)out & 15) == 0) {
+        hipLaunchKernelGGL(pad4_kernel, dim3(blocks((long)2 * nc * oh * (ow / 4))), dim3(256), 0, st, in0, out, nc, h, w, left, top, oh, ow, in1);
+        EEM_HIP_CHECK(hipGetLastError());
+        return EEM_OK;
+    }
+    const int rc = er_pad_launch(in0, out, nc, h, w, left, right, top, bottom, st);
+    return rc != EEM_OK ? rc : er_pad_launch(in1, out + (size_t)nc * oh * ow, nc, h, w, left, right, top, bottom, st);
+}
+
 int er_pad_launch(const float* in, float* out, int nc, int h, int w, int left, int right, int top, int bottom, hipStream_t st) {
     const int oh = h + top + bottom, ow = w + left + right;
     if ((ow & 3) == 0 && ((uintptr_t)out & 15) == 0)
-        hipLaunchKernelGGL(pad4_kernel, dim3(blocks((long)nc * oh * (ow / 4))), dim3(256), 0, st, in, out, nc, h, w, left, top, oh, ow);
+        hipLaunchKernelGGL(pad4_kernel, dim3(blocks((long)nc * oh * (ow / 4))), dim3(256), 0, st, in, out, nc, h, w, left, top, oh, ow, (const float*)nullptr);
     else
         hipLaunchKernelGGL(pad_kernel, dim3(blocks((long)nc * oh * ow)), dim3(256), 0, st, in, out, nc, h, w, left, top, oh, ow);
     EEM_HIP_CHECK(hipGetLastError());

@@ -403,8 +403,7 @@ extern "C" int eemplus_forward(eemplus_ctx* c, const float* e1, const float* e2,
     int rc;
     // ---- pad, encoder on both volumes (EEMFlow+.py:162-169)
     if ((rc = pensure(c->padded, (size_t)n2 * c->cin0 * hp * wp)) != EEM_OK) return rc;
-    if ((rc = er_pad_launch(e1, c->padded.p, B * c->cin0, in_h, in_w, pad[0], pad[1], pad[2], pad[3], st)) != EEM_OK) return rc;
-    if ((rc = er_pad_launch(e2, c->padded.p + (size_t)B * c->cin0 * hp * wp, B * c->cin0, in_h, in_w, pad[0], pad[1], pad[2], pad[3], st)) != EEM_OK) return rc;
+    if ((rc = er_pad2_launch(e1, e2, c->padded.p, B * c->cin0, in_h, in_w, pad[0], pad[1], pad[2], pad[3], st)) != EEM_OK) return rc;
     auto half = [](int v) { return (v - 1) / 2 + 1; };
     int* hl = c->hl; int* wl = c->wl;
     hl[1] = half(hp); wl[1] = half(wp); hl[2] = half(hl[1]); wl[2] = half(wl[1]); hl[3] = half(hl[2]); wl[3] = half(wl[2]);

@@ -305,9 +305,7 @@ static int forward_train_impl(eemflow_ctx* c, const float* e1, const float* e2, 
     // layer from it lets 346-pixel rows (MVSEC: not a 16-byte multiple, 19 columns of left padding) use the LDS-DMA kernel too
     const int B = batch;
     if ((rc = ensure_train_wino(c, batch, st)) != EEM_OK) return rc;
-    if ((rc = er_pad_launch(e1, c->padded.p, B * c->cin0, in_h, in_w, c->pad[0], c->pad[1], c->pad[2], c->pad[3], st)) != EEM_OK) return rc;
-    if ((rc = er_pad_launch(e2, c->padded.p + (size_t)B * c->cin0 * s.hp * s.wp, B * c->cin0, in_h, in_w, c->pad[0], c->pad[1], c->pad[2],
-                            c->pad[3], st)) != EEM_OK) return rc;
+    if ((rc = er_pad2_launch(e1, e2, c->padded.p, B * c->cin0, in_h, in_w, c->pad[0], c->pad[1], c->pad[2], c->pad[3], st)) != EEM_OK) return rc;
     Hook hk;
     hk.st = st;
     static const bool no_prepad = [] { const char* e = getenv("EEM_NO_PREPAD_FWD"); return e && e[0] == '1'; }();

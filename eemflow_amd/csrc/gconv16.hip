@@ -35,14 +35,17 @@ __device__ __forceinline__ float g16_act(float v, int act) {
     }
 }
 
-template <int KH, int KW, int THT>
+// S = stride (1, or 2 for the encoders' downsampling 3x3 / 1x1 convs: the tile's input rows and columns are twice as far apart, the
+// staged patch (TH - 1) * 2 + KH rows of 40 columns, a lane's B fragments two floats apart - a 2-way bank conflict it can afford)
+template <int KH, int KW, int THT, int S = 1>
 struct G16Cfg {
     static constexpr int TH = THT, TW = 16;
-    static constexpr int ROWS = TH + KH - 1;
-    static constexpr int COLS = 24;                              // x0 - 4 .. x0 + 19
+    static constexpr int ROWS = (TH - 1) * S + KH;
+    static constexpr int COLS = 16 * S + 8;                      // S * x0 - 4 .. S * x0 + 16 S + 3
+    static constexpr int PCS = COLS / 4;                         // 16-byte pieces per staged row
     static constexpr int PL0 = ROWS * COLS;
     static constexpr int PL = PL0 % 32 == 16 ? PL0 : PL0 + ((48 - PL0 % 32) % 32);   // plane pitch = 16 mod 32 floats
-    static constexpr int PQ = PL / 4;                            // 16-byte slots per plane (ROWS * 6 real ones)
+    static constexpr int PQ = PL / 4;                            // 16-byte slots per plane (ROWS * PCS real ones)
     static constexpr int SLOTS = 16 * PQ;
     static constexpr int NI = (SLOTS + 255) / 256;               // DMA instructions per wave and chunk
     static constexpr int STAGE = NI * 256 * 4;                   // floats
@@ -93,10 +96,14 @@ __device__ __forceinline__ void g16_wait_vm() {
 // chunk)) and two chunks per barrier - identical or worse kernel times, those launches are not waiting for memory; B fragments by
 // counted asm ds_read2_b32 one tap ahead of the MFMAs - the same at one wave per SIMD, 5 % slower on full launches.
 // tools/micro/dispatch_map.hip: the dispatcher does spread 200 blocks over 200 CUs.
-template <int KH, int KW, int THT, int WM, int KG>
-__global__ __launch_bounds__(256 * KG, (KG > 1 || (THT != 2 && THT != 4)) ? 2 : ((KH * KW == 9 && THT == 4 && WM >= 2) ? 3 : 4)) void gconv16_kernel(GConvArgs a, const float* __restrict__ wpk16, const float* __restrict__ zero_page,
+// S = stride (1, or 2 for the encoders' downsampling convs: the staged tile is (TH - 1) S + KH rows of 16 S + 8 columns, a B fragment
+// reads every S-th of them).  Its occupancy bound stays at 2 blocks: at 3 (168 VGPRs) the compiler spilled, and a spill is fatal here -
+// the weight fragments arrive by asm loads the compiler takes for complete, so it parks a register in scratch and hands it to an
+// address computation while the load is still in flight (seen as a memory fault at a wild address; no instance may use scratch).
+template <int KH, int KW, int THT, int WM, int KG, int S = 1>
+__global__ __launch_bounds__(256 * KG, (KG > 1 || S > 1 || (THT != 2 && THT != 4)) ? 2 : ((KH * KW == 9 && THT == 4 && WM >= 2) ? 3 : 4)) void gconv16_kernel(GConvArgs a, const float* __restrict__ wpk16, const float* __restrict__ zero_page,
                                                       int tiles_x, int nchunks) {
-    using C = G16Cfg<KH, KW, THT>;
+    using C = G16Cfg<KH, KW, THT, S>;
 #ifdef EEM_G16_STAMPS
     unsigned long long st[8] = {G16_T(), 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -120,7 +127,8 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || (THT != 2 && THT != 4)) ? 2 : 
     const int n = blockIdx.z, cc = mtg >> 2, mt = mtg & 3;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int y0 = ty * C::TH, x0 = tx * C::TW;
-    const int hw = a.hin * a.win;                                // stride 1, "same" padding: output extent = input extent
+    const int hw = a.hin * a.win;                                // input plane; "same" padding
+    const int hwo = S == 1 ? hw : a.hout * a.wout;               // output plane (= the input's at stride 1)
     constexpr int PH = KH / 2, PW = KW / 2;
 
     // ---- DMA plan: slot f -> (channel, row, 16-byte piece) of the chunk's tile
@@ -129,9 +137,9 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || (THT != 2 && THT != 4)) ? 2 : 
     for (int k = 0; k < C::NI; ++k) {
         const int f = (wave + 4 * k) * 64 + lane;
         const int ci = f / C::PQ, q = f - ci * C::PQ;
-        const int row = q / 6, pc = q - row * 6;
-        const bool ok = f < C::SLOTS && q < C::ROWS * 6;
-        const int gy = y0 - PH + row, gx = x0 - 4 + 4 * pc;
+        const int row = q / C::PCS, pc = q - row * C::PCS;
+        const bool ok = f < C::SLOTS && q < C::ROWS * C::PCS;
+        const int gy = y0 * S - PH + row, gx = x0 * S - 4 + 4 * pc;
         const bool in = ok && gy >= 0 && gy < a.hin && gx >= 0 && gx + 4 <= a.win;
         off[k] = in ? (unsigned)(((size_t)ci * hw + (size_t)gy * a.win + gx) * 4) : G16_RANGE;
     }
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || (THT != 2 && THT != 4)) ? 2 : 
     f32x4 acc[NR];
 #pragma unroll
     for (int t = 0; t < NR; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int bbase = g * C::PL + j + 4 - PW;                    // B fragment: channel g of a group, pixel column j
+    const int bbase = g * C::PL + S * j + 4 - PW;                // B fragment: channel g of a group, pixel column j
 
     f32x4 wr[2][C::TAPS];
     auto compute = [&](int stage, f32x4 (&w)[C::TAPS]) __attribute__((always_inline)) {
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || (THT != 2 && THT != 4)) ? 2 : 
                 for (int cg = 0; cg < 4; ++cg) {
                     float bv[NR];
 #pragma unroll
-                    for (int t = 0; t < NR; ++t) bv[t] = sb[bbase + cg * 4 * C::PL + (wp * NR + t + ky) * C::COLS + kx];
+                    for (int t = 0; t < NR; ++t) bv[t] = sb[bbase + cg * 4 * C::PL + (S * (wp * NR + t) + ky) * C::COLS + kx];
 #pragma unroll
                     for (int t = 0; t < NR; ++t)
                         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ky * KW + kx][cg], bv[t], acc[t], 0, 0, 0);
@@ -266,7 +274,7 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || (THT != 2 && THT != 4)) ? 2 : 
                     if (co >= a.cout) continue;
                     const float v = g16_act(acc[t][r] * e_scale[r] + e_shift[r], a.act);
                     const int oc = a.out_coff + grp * a.g_ocoff + co * (a.out_cmul > 1 ? a.out_cmul : 1);
-                    a.out[((size_t)n * a.out_ctotal + oc) * hw + p] = v * a.out_scale;
+                    a.out[((size_t)n * a.out_ctotal + oc) * hwo + p] = v * a.out_scale;
                 }
             }
         }
@@ -279,7 +287,7 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || (THT != 2 && THT != 4)) ? 2 : 
             for (int r = 0; r < 4; ++r) {
                 const int co = mtg * 16 + 4 * g + r;
                 const bool in = x < a.wout && y < a.hout && co < a.cout;
-                ip[t][r] = in ? (unsigned)(co * hw + y * a.wout + x) : ~0u;
+                ip[t][r] = in ? (unsigned)(co * hwo + y * a.wout + x) : ~0u;
             }
         }
         float e0v[NR][4], e1v[NR][4], prv[NR][4];
@@ -288,22 +296,22 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || (THT != 2 && THT != 4)) ? 2 : 
 #pragma unroll
             for (int r = 0; r < 4; ++r) { e0v[t][r] = 0.f; e1v[t][r] = 0.f; prv[t][r] = 0.f; }
         if (a.pre) {
-            const float* b = a.pre + ((size_t)n * a.pre_ctotal + a.pre_coff) * hw;
+            const float* b = a.pre + ((size_t)n * a.pre_ctotal + a.pre_coff) * hwo;
 #pragma unroll
             for (int t = 0; t < NR; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) prv[t][r] = b[ip[t][r] == ~0u ? 0u : ip[t][r]];
         }
-        const unsigned zsplit = a.epi == GEPI_ZR ? (unsigned)(a.split * hw) : 0u;   // GEPI_ZR: e0 is indexed by co - split, from split on
+        const unsigned zsplit = a.epi == GEPI_ZR ? (unsigned)(a.split * hwo) : 0u;   // GEPI_ZR: e0 is indexed by co - split, from split on
         if (a.epi != GEPI_PLAIN) {
-            const float* b = a.e0 + ((size_t)n * a.e0_ctotal + a.e0_coff) * hw;
+            const float* b = a.e0 + ((size_t)n * a.e0_ctotal + a.e0_coff) * hwo;
 #pragma unroll
             for (int t = 0; t < NR; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) e0v[t][r] = b[(ip[t][r] == ~0u || ip[t][r] < zsplit) ? 0u : ip[t][r] - zsplit];
         }
         if (a.epi == GEPI_GRU) {
-            const float* b = a.e1 + ((size_t)n * a.e1_ctotal + a.e1_coff) * hw;
+            const float* b = a.e1 + ((size_t)n * a.e1_ctotal + a.e1_coff) * hwo;
 #pragma unroll
             for (int t = 0; t < NR; ++t)
 #pragma unroll
@@ -329,13 +337,13 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || (THT != 2 && THT != 4)) ? 2 : 
                     v += e0v[t][r];
                 }
                 const int oc = a.out_coff + grp * a.g_ocoff + co * (a.out_cmul > 1 ? a.out_cmul : 1);
-                float* dst = a.out + ((size_t)n * a.out_ctotal + oc) * hw + p;
+                float* dst = a.out + ((size_t)n * a.out_ctotal + oc) * hwo + p;
                 // GEPI_ZR: r leaves as r * h, to the second output.  One store through a selected pointer: written as a second store in the
                 // else-if chain above (followed by `continue`), hipcc's code stored through `out2` on the other epilogues' paths too (memory
                 // fault in <3,3,5,4,1> with GEPI_ADD_RELU; round 3's GEPI_SPLIT_MUL attempt had died the same way)
                 if (a.epi == GEPI_ZR && co >= a.split) {
                     v *= e0v[t][r];
-                    dst = a.out2 + ((size_t)n * a.out2_ctotal + (co - a.split)) * hw + p;
+                    dst = a.out2 + ((size_t)n * a.out2_ctotal + (co - a.split)) * hwo + p;
                 }
                 *dst = v * a.out_scale;
             }
@@ -376,6 +384,19 @@ int launch_th(const GConvArgs& a, const float* wpk16, const float* zero_page, hi
     if (a.cout <= 16) return launch_wm<KH, KW, 4, 1>(a, wpk16, zero_page, stream);
     if (a.cout <= 32) return launch_wm<KH, KW, THT, 2>(a, wpk16, zero_page, stream);
     return launch_wm<KH, KW, THT, 4>(a, wpk16, zero_page, stream);
+}
+
+// stride 2 (3x3 pad 1, 1x1 pad 0): 64-cout chunks of 4-row tiles, one K group
+template <int KH, int KW>
+int launch_s2(const GConvArgs& a, const float* wpk16, const float* zero_page, hipStream_t stream) {
+    using C = G16Cfg<KH, KW, 4, 2>;
+    int cin = 0;
+    for (int s = 0; s < a.nseg; ++s) cin += a.seg[s].c;
+    const int tiles_x = ceil_div(a.wout, C::TW), tiles_y = ceil_div(a.hout, C::TH);
+    dim3 grid(tiles_x * tiles_y, ceil_div(a.cout, 64), a.n);
+    hipLaunchKernelGGL((gconv16_kernel<KH, KW, 4, 4, 1, 2>), grid, dim3(256), 0, stream, a, wpk16, zero_page, tiles_x, cin / 16);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
 }
 
 template <int KH, int KW>
@@ -424,7 +445,8 @@ extern "C" int eemflow_debug_read_g16_stamps(unsigned long long* dst, size_t n) 
 #endif
 
 bool gconv16_shape(int cout, const int* cs, int nseg, int kh, int kw, int stride) {
-    if (stride != 1 || cout < 16) return false;
+    if ((stride != 1 && stride != 2) || cout < 16) return false;
+    if (stride == 2 && !(((kh == 1 && kw == 1) || (kh == 3 && kw == 3)) && nseg == 1 && cout > 32)) return false;   // the encoders' downsampling convs
     if (!((kh == 1 && kw == 1) || (kh == 3 && kw == 3) || (kh == 1 && kw == 5) || (kh == 5 && kw == 1))) return false;
     for (int s = 0; s < nseg; ++s)
         if (cs[s] <= 0 || cs[s] % 16) return false;
@@ -472,12 +494,20 @@ bool gconv16_supported(const GConvArgs& a) {
     const long blocks = (long)ceil_div(a.wout, 16) * ceil_div(a.hout, 4) * ceil_div(a.cout, 64) * a.n * (a.groups > 1 ? a.groups : 1);
     if (cin < min_cin || blocks < min_blk) return false;
     if (a.groups > 1 && (a.nseg != 1 || a.epi != GEPI_PLAIN)) return false;
+    if (a.stride == 2) {                                         // downsampling form: plain epilogues, one segment, no groups
+        const char* m = getenv("EEM_NO_G16_S2");                 // read per call, like EEM_NO_GCONV16
+        if ((m && m[0] == '1') || a.groups > 1 || a.pre || (a.epi != GEPI_PLAIN && a.epi != GEPI_ADD_RELU && a.epi != GEPI_ADD)) return false;
+        return gconv16_shape(a.cout, cs, a.nseg, a.kh, a.kw, 2) && a.win % 4 == 0 && a.hout == (a.hin + 2 * a.pad_h - a.kh) / 2 + 1 &&
+               a.wout == (a.win + 2 * a.pad_w - a.kw) / 2 + 1 && (size_t)16 * a.hin * a.win * 4 < (1u << 31) &&
+               (size_t)a.cout * a.hout * a.wout < (1u << 31);
+    }
     if ((a.epi != GEPI_PLAIN || a.pre) && (size_t)a.cout * a.hin * a.win >= (1u << 31)) return false;   // 32-bit operand indices in the epilogue
     return gconv16_shape(a.cout, cs, a.nseg, a.kh, a.kw, a.stride) && a.win % 4 == 0 && a.hout == a.hin && a.wout == a.win &&
            (size_t)16 * a.hin * a.win * 4 < (1u << 31);
 }
 
 int gconv16_launch(const GConvArgs& a, hipStream_t stream) {
+    if (a.stride == 2) return a.kh == 1 ? launch_s2<1, 1>(a, a.wpk16, a.zero_page, stream) : launch_s2<3, 3>(a, a.wpk16, a.zero_page, stream);
     if (a.kh == 1 && a.kw == 1) return launch<1, 1>(a, a.wpk16, a.zero_page, stream);
     if (a.kh == 3) return launch<3, 3>(a, a.wpk16, a.zero_page, stream);
     if (a.kh == 1) return launch<1, 5>(a, a.wpk16, a.zero_page, stream);

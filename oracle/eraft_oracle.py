@@ -12,6 +12,11 @@ import torch.nn.functional as F
 
 from .eemflow_oracle import input_padder_pad, replicate_pad, unpad
 
+# The reference's `.float()` casts (model/corr.py:27,50, model_utils.py:27, eraft.py:117) go through this name.  float32, as there; a
+# test may set float64 and pass float64 parameters and inputs to run the same graph in double precision - the arbiter when two float32
+# results differ through ReLU units that sit within round-off of 0.
+FLOAT = torch.float32
+
 
 # ----------------------------------------------------------------------------- A9 BasicEncoder
 def _norm(x, sd, prefix, norm_fn, training=False):
@@ -56,7 +61,7 @@ def corr_pyramid(fmap1, fmap2, num_levels=4):
     """CorrBlock.__init__ + corr - model/corr.py:13-27,53-60: list of (B*H*W, 1, h_l, w_l)."""
     b, d, h, w = fmap1.shape
     corr = torch.matmul(fmap1.view(b, d, h * w).transpose(1, 2), fmap2.view(b, d, h * w))
-    corr = corr.view(b, h, w, 1, h, w) / torch.sqrt(torch.tensor(d).float())
+    corr = corr.view(b, h, w, 1, h, w) / torch.sqrt(torch.tensor(d).to(FLOAT))
     corr = corr.reshape(b * h * w, 1, h, w)
     pyr = [corr]
     for _ in range(num_levels - 1):
@@ -88,7 +93,7 @@ def corr_lookup(pyr, coords, radius=4):
         centroid = coords.reshape(b * h1 * w1, 1, 1, 2) / 2 ** i
         sampled = bilinear_sampler(corr, centroid + delta.view(1, 2 * r + 1, 2 * r + 1, 2))
         out.append(sampled.view(b, h1, w1, -1))
-    return torch.cat(out, dim=-1).permute(0, 3, 1, 2).contiguous().float()
+    return torch.cat(out, dim=-1).permute(0, 3, 1, 2).contiguous().to(FLOAT)
 
 
 # ----------------------------------------------------------------------------- A12 update block
@@ -130,7 +135,7 @@ def update_block(sd, p, net, inp, corr, flow):
 def coords_grid(batch, ht, wd):
     """model/model_utils.py:24-27: channel 0 = x, channel 1 = y."""
     ys, xs = torch.meshgrid(torch.arange(ht), torch.arange(wd), indexing="ij")
-    return torch.stack([xs, ys], 0).float()[None].repeat(batch, 1, 1, 1)
+    return torch.stack([xs, ys], 0).to(FLOAT)[None].repeat(batch, 1, 1, 1)
 
 
 def convex_upsample(flow, mask):
@@ -149,7 +154,7 @@ def eraft_forward(sd, events1, events2, iters=12, flow_init=None, image_size=Non
     pad = input_padder_pad(*(image_size or (h, w)), mode="chairs", eval_pad_rate=32)   # eraft.py:65-67
     im1, im2 = replicate_pad(events1, pad).contiguous(), replicate_pad(events2, pad).contiguous()
     fmap1, fmap2 = basic_encoder(sd, "fnet.", [im1, im2], "instance")
-    pyr = corr_pyramid(fmap1.float(), fmap2.float())
+    pyr = corr_pyramid(fmap1.to(FLOAT), fmap2.to(FLOAT))
     cnet = basic_encoder(sd, "cnet.", im1, "batch", bn_training)
     net, inp = torch.split(cnet, [128, 128], dim=1)
     net, inp = torch.tanh(net), torch.relu(inp)

@@ -163,6 +163,28 @@ def test_lds_tiled_conv_with_two_k_groups(monkeypatch, cin, cout, k, h, w, b):
     assert not torch.equal(tiled, gen)
 
 
+@pytest.mark.parametrize("cin,cout,k,h,w,b", [(64, 96, 3, 48, 64, 1), (64, 96, 1, 48, 64, 1), (96, 128, 3, 120, 160, 2), (96, 128, 1, 120, 160, 2),
+                                               (64, 96, 3, 46, 68, 1), (32, 64, 3, 90, 160, 2)])
+def test_lds_tiled_conv_at_stride_two(monkeypatch, cin, cout, k, h, w, b):
+    """The encoders' downsampling convs (E-RAFT model/extractor.py layer2 / layer3: 3x3 stride 2 and the 1x1 stride-2 shortcut) on
+    gconv16's stride-2 form - a (TH - 1) * 2 + k row tile in LDS, B fragments from every second column - against torch and against
+    the generic kernel (EEM_NO_G16_S2=1, read per call).  46 x 68: odd tile counts and a ragged right / bottom edge."""
+    from eemflow_amd import ops
+    g = torch.Generator().manual_seed(cin + cout + k)
+    conv = torch.nn.Conv2d(cin, cout, k, stride=2, padding=k // 2)
+    x = torch.randn(b, cin, h, w, generator=g)
+    ref = torch.relu(conv(x)).detach()
+    convd = conv.to(DEV)
+    with torch.no_grad():
+        tiled = ops.conv2d(convd, x.to(DEV), act=ops.ACT_RELU).cpu()
+        monkeypatch.setenv("EEM_NO_G16_S2", "1")
+        gen = ops.conv2d(convd, x.to(DEV), act=ops.ACT_RELU).cpu()
+    tol = 3e-5 * max(float(ref.abs().max()), 1.0) * (cin * k * k / 256) ** 0.5
+    assert tiled.shape == ref.shape
+    assert float((tiled - ref).abs().max()) < tol and float((gen - ref).abs().max()) < tol
+    assert not torch.equal(tiled, gen) or k == 1       # (the switch did switch; a 1x1 over 64 channels can sum in the same order)
+
+
 @pytest.mark.parametrize("form", ["gather", "scatter"])
 @pytest.mark.parametrize("n,h,w,oh,ow", [(2, 6, 8, 512, 768), (1, 64, 96, 128, 192), (2, 5, 7, 33, 50), (1, 1, 9, 17, 40), (1, 12, 20, 12, 20)])
 def test_bilinear_resize_adjoint(monkeypatch, form, n, h, w, oh, ow):

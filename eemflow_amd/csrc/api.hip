@@ -230,6 +230,8 @@ extern "C" int eemflow_load_weights(eemflow_ctx* c, const float* flat, size_t nf
             const EncLayerDesc& d = kEncLayers[l];
             c->enc_s2r[l] = s2r_shape(d.cin, d.cout, d.stride);
             if (c->enc_s2r[l]) { c->s2r_off[l] = off; off += s2r_packed_floats(d.cin, d.cout); }
+            c->enc_bx3[l] = bx3_shape(d.cin, d.cout, d.stride);
+            if (c->enc_bx3[l]) { c->bx3_off[l] = off; off += bx3_packed_floats(d.cin, d.cout); }
         }
         if (c->wino) EEM_HIP_CHECK(hipFree(c->wino));
         c->wino = nullptr;
@@ -420,6 +422,9 @@ extern "C" int eemflow_get_stage(eemflow_ctx* c, const char* name, float* dst, s
     else if (nm == "f12") { src = c->f12.p; dims[0] = n2; dims[1] = 32; dims[2] = s.h2; dims[3] = s.w2; }
     else if (nm == "f13") { src = c->f13.p; dims[0] = n2; dims[1] = 64; dims[2] = s.h3; dims[3] = s.w3; }
     else if (nm == "a1") { src = c->a1.p; dims[0] = n2; dims[1] = 16; dims[2] = s.h1; dims[3] = s.w1; }
+    else if (nm == "a2") { src = c->a2.p; dims[0] = n2; dims[1] = 32; dims[2] = s.h2; dims[3] = s.w2; }
+    else if (nm == "b2") { src = c->b2.p; dims[0] = n2; dims[1] = 32; dims[2] = s.h2; dims[3] = s.w2; }
+    else if (nm == "b3") { src = c->b3.p; dims[0] = n2; dims[1] = 64; dims[2] = s.h3; dims[3] = s.w3; }
     else if (nm == "flowcat") { src = c->flowcat.p; dims[0] = s.batch; dims[1] = 6; dims[2] = s.gh; dims[3] = s.gw; }
     else if (nm == "coarse") { src = c->coarse.p; dims[0] = s.batch; dims[1] = 2; dims[2] = s.gh; dims[3] = s.gw; }
     else if (nm.size() == 6 && nm.compare(0, 5, "pool_") == 0 && nm[5] >= '1' && nm[5] <= '3') {

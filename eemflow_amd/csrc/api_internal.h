@@ -69,6 +69,9 @@ struct eemflow_ctx {
     size_t s2r_off[ENC_NUM];           // the stride-2 layers' weights in conv_s2r.hip's order (same buffer, same lazy refresh)
     bool s2r_ok[ENC_NUM] = {};
     bool enc_s2r[ENC_NUM] = {};
+    size_t bx3_off[ENC_NUM];           // pconv2_1's weights as pre-split bf16 fragments (conv_bx3.hip; same buffer, same lazy refresh)
+    bool bx3_ok[ENC_NUM] = {};
+    bool enc_bx3[ENC_NUM] = {};
     bool enc_wino[ENC_NUM];
     bool use_wino = true;              // EEM_WINO=0 in the environment keeps the direct-convolution kernels
     // which stride-1 layers run F(4x4,3x3), by channel count (bit 0: C = 16, 1: C = 32, 2: C = 64).  F(4x4) blocks are 8 waves on 16 x
@@ -179,6 +182,16 @@ int refresh_wino(eemflow_ctx* c, hipStream_t) {
     for (int f = 0; f < 4; ++f)
         for (int l = 0; l < ENC_NUM; ++l) c->wino_ok[f][l] = false;
     for (int l = 0; l < ENC_NUM; ++l) c->s2r_ok[l] = false;
+    for (int l = 0; l < ENC_NUM; ++l) c->bx3_ok[l] = false;
+    return EEM_OK;
+}
+int ensure_bx3(eemflow_ctx* c, int l, hipStream_t st, const float** w_out) {
+    if (!c->bx3_ok[l]) {
+        const int rc = bx3_transform_launch(c->flat + c->t_enc[l].w, kEncLayers[l].cin, kEncLayers[l].cout, c->wino + c->bx3_off[l], st);
+        if (rc != EEM_OK) return rc;
+        c->bx3_ok[l] = true;
+    }
+    *w_out = c->wino + c->bx3_off[l];
     return EEM_OK;
 }
 int ensure_s2r(eemflow_ctx* c, int l, hipStream_t st, const float** w_out) {
@@ -231,6 +244,7 @@ int ensure_forward_wino(eemflow_ctx* c, int batch, hipStream_t st) {
     for (int l = 0; l < ENC_NUM; ++l) {
         const float* ws;
         if (c->enc_s2r[l]) { const int rc = ensure_s2r(c, l, st, &ws); if (rc != EEM_OK) return rc; }
+        if (c->enc_bx3[l]) { const int rc = ensure_bx3(c, l, st, &ws); if (rc != EEM_OK) return rc; }
     }
     if (!c->use_wino) return EEM_OK;
     for (int l = 0; l < ENC_NUM; ++l) {
@@ -503,6 +517,8 @@ int run_forward_impl(eemflow_ctx* c, const Shape& s, const float* e1, const floa
         if (c->use_wino && c->enc_wino[sp.layer] && (rc = ensure_wino(c, sp.layer, 0, s.batch, hk.st, &a.wwino, &a.wino_f4)) != EEM_OK) return rc;
         a.ws2r = nullptr;
         if (c->enc_s2r[sp.layer] && (rc = ensure_s2r(c, sp.layer, hk.st, &a.ws2r)) != EEM_OK) return rc;
+        a.wbx3 = nullptr;
+        if (c->enc_bx3[sp.layer] && (rc = ensure_bx3(c, sp.layer, hk.st, &a.wbx3)) != EEM_OK) return rc;
         a.zero_page = c->zero_page;
         a.trash = c->zero_page + 256;
         a.bias = c->arena + c->enc_b[sp.layer];

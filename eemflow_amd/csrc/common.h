@@ -171,6 +171,8 @@ struct EncConvArgs {
     const float* ws2r = nullptr;   // weights of a stride-2 layer in conv_s2r.hip's order (s2r_transform_launch), or NULL
     // conv_wino4.hip only: residual [nimg][C][hout][wout]; the result is relu(res + act(conv)) (ResidualBlock, model/extractor.py:50-57)
     const float* res = nullptr;
+    // the stride-2 layer 16 -> 32 as pre-split bf16 weight fragments (conv_bx3.hip, bx3_transform_launch), or NULL
+    const float* wbx3 = nullptr;
 };
 // Every launch argument a block uses, wanted in scalar registers at its first instruction: one batch of scalar loads instead of the three or
 // four dependent ones the compiler otherwise spreads over the prologue (see tail_conv_kernel in tail.hip for what a memory round trip costs
@@ -199,6 +201,12 @@ size_t s2r_packed_floats(int cin, int cout);
 int s2r_transform_launch(const float* w, int cin, int cout, float* packed, hipStream_t stream);     // OIHW device weights -> packed
 bool s2r_supported(int cin, int cout, int stride, const EncConvArgs& a);
 int s2r_launch(int cin, const EncConvArgs& a, hipStream_t stream);
+// pconv2_1 on the bf16 matrix pipe with fp32 results: three bf16 pieces per operand, six MFMAs per product (conv_bx3.hip)
+bool bx3_shape(int cin, int cout, int stride);
+size_t bx3_packed_floats(int cin, int cout);
+int bx3_transform_launch(const float* w, int cin, int cout, float* packed, hipStream_t stream);     // OIHW device weights -> packed
+bool bx3_supported(int cin, int cout, int stride, const EncConvArgs& a);
+int bx3_launch(int cin, const EncConvArgs& a, hipStream_t stream);
 // Winograd F(2x2,3x3) path for the stride-1 C -> C layers (C = 16, 32, 64), conv_wino.hip
 bool wino_supported(int cin, int cout, int stride, int win);
 size_t wino_packed_floats(int c);      // room for either form

@@ -156,6 +156,7 @@ def test_light_block_stride2_kernel_equals_the_chunked_one(monkeypatch, b, h, w)
     e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(55, b, h, w))
     outs = []
     monkeypatch.setenv("EEM_S2W_64", "1")                    # pconv3_1 too (it stays on the chunked kernel by default)
+    monkeypatch.setenv("EEM_NO_BX3", "1")                    # (pconv2_1's default is the bf16-piece kernel, conv_bx3.hip)
     for off in ("0", "1"):
         monkeypatch.setenv("EEM_NO_S2W", off)
         net, _ = make_net(44, graph=False)
@@ -165,6 +166,51 @@ def test_light_block_stride2_kernel_equals_the_chunked_one(monkeypatch, b, h, w)
         outs.append((flow, net.stage("f12").clone(), net.stage("f13").clone()))
     for a, c in zip(*outs):
         assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("b,h,w", [(1, 720, 1280), (2, 260, 346), (1, 100, 150)])
+def test_bf16_piece_stride2_kernel_equals_the_fp32_one(monkeypatch, b, h, w):
+    """conv_bx3.hip runs pconv2_1 (EEMFlow.py:77) on the bf16 matrix pipe: every fp32 operand as three bf16 pieces (exact), six of the
+    nine piece products (the dropped ones are below 2^-24 of a product), fp32 accumulation - fp32 arithmetic in another order, not a
+    reduced precision: against the fp32-MFMA kernel (EEM_NO_BX3=1, read per launch) the layer's output agrees to a few ulp of its
+    largest sums, and the flow far inside the 1e-4 budget."""
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(57, b, h, w))
+    outs = []
+    for off in ("0", "1"):
+        monkeypatch.setenv("EEM_NO_BX3", off)
+        net, _ = make_net(46, graph=False)
+        net.change_imagesize((h, w))
+        with torch.no_grad():
+            flow = net(e1, e2)[1][0].clone()
+        outs.append((flow, net.stage("a2").clone(), net.stage("f12").clone()))
+    (flow_b, a2_b, f12_b), (flow_f, a2_f, f12_f) = outs
+    assert not torch.equal(a2_b, a2_f)                                   # (the switch did switch)
+    scale = float(a2_f.abs().max())
+    assert scale > 1e-3 and maxerr(a2_b, a2_f) < 2e-6 * max(scale, 1.0)  # K = 144 sums of either kernel: ~2e-7 of sum |a b|
+    assert maxerr(f12_b, f12_f) < 1e-5 * max(float(f12_f.abs().max()), 1.0)
+    assert maxerr(flow_b, flow_f) < 2e-5
+
+
+@pytest.mark.parametrize("b,h,w", [(1, 720, 1280), (2, 260, 346), (1, 100, 150)])
+def test_bf16_piece_stride1_kernels_equal_the_winograd_ones(monkeypatch, b, h, w):
+    """pconv2_2 (32 -> 32) and pconv3_2 (64 -> 64, EEMFlow.py:78,80) as direct convolutions on the bf16 matrix pipe (conv_bx3.hip:
+    weight fragments through an LDS ring; at 64 channels two groups of four waves split the channels) against the F(4x4,3x3) /
+    F(2x2,3x3) fp32 kernels (EEM_BX3_S1=0, read per launch; a mask: 1 = the 32-channel layer, 2 = the 64-channel one)."""
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(58, b, h, w))
+    outs = []
+    for mask in ("3", "0"):
+        monkeypatch.setenv("EEM_BX3_S1", mask)
+        net, _ = make_net(47, graph=False)
+        net.change_imagesize((h, w))
+        with torch.no_grad():
+            flow = net(e1, e2)[1][0].clone()
+        outs.append((flow, net.stage("b2").clone(), net.stage("b3").clone(), net.stage("f13").clone()))
+    (flow_b, b2_b, b3_b, f13_b), (flow_w, b2_w, b3_w, f13_w) = outs
+    assert not torch.equal(b2_b, b2_w) and not torch.equal(b3_b, b3_w)   # (the switch did switch)
+    for got, ref in ((b2_b, b2_w), (b3_b, b3_w), (f13_b, f13_w)):        # (Winograd's own error is the larger one)
+        scale = float(ref.abs().max())
+        assert scale > 1e-3 and maxerr(got, ref) < 2e-5 * max(scale, 1.0)
+    assert maxerr(flow_b, flow_w) < 2e-5
 
 
 def graph_stats(net):

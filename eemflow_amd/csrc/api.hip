@@ -424,6 +424,7 @@ extern "C" int eemflow_get_stage(eemflow_ctx* c, const char* name, float* dst, s
     else if (nm == "a1") { src = c->a1.p; dims[0] = n2; dims[1] = 16; dims[2] = s.h1; dims[3] = s.w1; }
     else if (nm == "a2") { src = c->a2.p; dims[0] = n2; dims[1] = 32; dims[2] = s.h2; dims[3] = s.w2; }
     else if (nm == "b2") { src = c->b2.p; dims[0] = n2; dims[1] = 32; dims[2] = s.h2; dims[3] = s.w2; }
+    else if (nm == "a3") { src = c->a3.p; dims[0] = n2; dims[1] = 64; dims[2] = s.h3; dims[3] = s.w3; }
     else if (nm == "b3") { src = c->b3.p; dims[0] = n2; dims[1] = 64; dims[2] = s.h3; dims[3] = s.w3; }
     else if (nm == "flowcat") { src = c->flowcat.p; dims[0] = s.batch; dims[1] = 6; dims[2] = s.gh; dims[3] = s.gw; }
     else if (nm == "coarse") { src = c->coarse.p; dims[0] = s.batch; dims[1] = 2; dims[2] = s.gh; dims[3] = s.gw; }

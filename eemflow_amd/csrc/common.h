@@ -206,7 +206,7 @@ bool bx3_shape(int cin, int cout, int stride);
 size_t bx3_packed_floats(int cin, int cout);
 int bx3_transform_launch(const float* w, int cin, int cout, float* packed, hipStream_t stream);     // OIHW device weights -> packed
 bool bx3_supported(int cin, int cout, int stride, const EncConvArgs& a);
-int bx3_launch(int cin, const EncConvArgs& a, hipStream_t stream);
+int bx3_launch(int cin, int stride, const EncConvArgs& a, hipStream_t stream);
 // Winograd F(2x2,3x3) path for the stride-1 C -> C layers (C = 16, 32, 64), conv_wino.hip
 bool wino_supported(int cin, int cout, int stride, int win);
 size_t wino_packed_floats(int c);      // room for either form

@@ -1,4 +1,4 @@
-// The stride-2 encoder layer pconv2_1 (16 -> 32, EEMFlow.py:77) on the bf16 matrix pipe with fp32 results: every operand is cut into
+// The stride-2 encoder layers pconv2_1 (16 -> 32) and pconv3_1 (32 -> 64) (EEMFlow.py:77,80) on the bf16 matrix pipe with fp32 results: every operand is cut into
 // three bf16 pieces, a = a0 + a1 + a2 EXACTLY (8 significand bits each, by truncation: a0 = a & 0xffff0000, a1 the same of a - a0, a2
 // the rest), and a product a * b is the six bf16 products a0 b0, a0 b1, a1 b0, a0 b2, a1 b1, a2 b0 summed in fp32 by the MFMA (the
 // three dropped terms are below 2^-24 |a b|).  tools/micro/bf16x3.hip: over K = 144 the worst error of that form is 1.8e-7 of
@@ -9,10 +9,14 @@
 // 32 cycles.  A k-step of 16 (one tap x 16 channels) is eight v_mfma_f32_32x32x2_f32 = 512 cycles, or six v_mfma_f32_32x32x16_bf16 = 192
 // cycles with the split's VALU work underneath (same microbenchmark: 12 MFMAs + 24 VALU = 404 cycles against 384 for the MFMAs alone).
 //
-// Layout: conv_s2.hip's - one 4 x 32-pixel tile per 4-wave block, the whole fp32 input tile (16 planes of 9 rows x 68 columns)
-// by LDS-DMA, one wait, one barrier; a wave = an output row, all 32 couts.  Per tap a lane reads its pixel's 8 channels (ds_read_b32,
-// immediate offsets), splits them (44 VALU instructions) and issues six MFMAs; the weights arrive pre-split ([tap][piece][lane][4 dwords],
-// bx3_transform_launch) through a ring of three taps of global loads (L1 / L2 hits: every block reads the same 27 KB).
+// Layout: conv_s2.hip's - one 4 x 32-pixel tile per 4-wave block, the whole fp32 input tile (CIN planes of 9 rows x 68 columns)
+// by LDS-DMA, one wait, one barrier; a wave = an output row, all couts.  Per k-step (a tap x 16 channels) a lane reads its pixel's 8
+// channels (ds_read_b32), splits them (44 VALU instructions) and issues six MFMAs per 32 couts; the weights arrive pre-split
+// ([k-step][piece][cout tile][lane][4 dwords], bx3_transform_launch) through a ring of three k-steps of global loads (L1 / L2 hits:
+// every block reads the same 27 / 108 KB).  Software pipeline: k-step s + 1's raw values are in registers when k-step s's MFMAs
+// issue, and their split sits between those MFMAs (pinned by sched_barrier; the scheduler's own order put the whole split in front).
+// pconv2_1 (16 -> 32): 40 KB of LDS, four blocks per CU, 17.0 -> 13.3 us; pconv3_1 (32 -> 64, EEM_NO_BX3_64=1 for conv_enc2.hip's
+// kernel): 80 KB, two per CU, 14.5 -> 11.1 us.  What is left is not arithmetic: the tile's way in from HBM and the stores.
 // Inputs with an infinity give NaN here where the fp32 kernels give an infinity (inf - inf in the split).
 #include "common.h"
 
@@ -38,7 +42,6 @@ struct BxCfg {
     static constexpr int NI = (PIECES + WAVES * 64 - 1) / (WAVES * 64);
     static constexpr int LDS_FLOATS = NI * WAVES * 256;
     static constexpr int RING = 3;                       // k-steps of weight fragments in flight
-    static_assert(((CIN - 1) * PLANE + 2 * ROWP + 2) * 4 < 65536, "ds_read immediate range");
 };
 
 __device__ __forceinline__ bf16x8 as_bf(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
@@ -67,7 +70,7 @@ __device__ __forceinline__ void split_pair(const float (&x)[8], int d, u32x4& p0
 }
 
 template <int CIN, int COUT>
-__global__ __launch_bounds__(256, 4) void bx3_s2_kernel(EncConvArgs a, const u32x4* __restrict__ wq) {
+__global__ __launch_bounds__(256, (CIN == 16 ? 4 : 2)) void bx3_s2_kernel(EncConvArgs a, const u32x4* __restrict__ wq) {
     using C = BxCfg<CIN, COUT>;
     __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
     const int tid = threadIdx.x;
@@ -119,25 +122,33 @@ __global__ __launch_bounds__(256, 4) void bx3_s2_kernel(EncConvArgs a, const u32
 
     // B operand of k-step (tap t, chunk c16): channels c16 * 16 + 8 g + e, input row 2 * row + ky, column 2 * j + kx + 3
     const float* bl = lds + g * 8 * C::PLANE + 2 * row * C::ROWP + 2 * j + 3;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int s = 0; s < C::KSTEPS; ++s) {
+    auto read_x = [&](int s, float (&x)[8]) __attribute__((always_inline)) {
         const int t = s / C::NC16, c16 = s % C::NC16;
-        float x[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = bl[(c16 * 16 + e) * C::PLANE + (t / 3) * C::ROWP + (t % 3)];
-        u32x4 b0, b1, b2;
-        split8(x, b0, b1, b2);
-        u32x4(&w)[3][C::MT] = wv[s % C::RING];
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // software pipeline: k-step s + 1's raw values are in registers when k-step s's MFMAs issue, and their split goes between those
+    float x[2][8];
+    u32x4 b[2][3];
+    read_x(0, x[0]);
+    if (C::KSTEPS > 1) read_x(1, x[1]);
+    split8(x[0], b[0][0], b[0][1], b[0][2]);
 #pragma unroll
-        for (int m = 0; m < C::MT; ++m) {                // small terms first
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w[2][m]), as_bf(b0), acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w[1][m]), as_bf(b1), acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w[0][m]), as_bf(b2), acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w[1][m]), as_bf(b0), acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w[0][m]), as_bf(b1), acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w[0][m]), as_bf(b0), acc[m], 0, 0, 0);
+    for (int s = 0; s < C::KSTEPS; ++s) {
+        const int cur = s & 1, nxt = cur ^ 1;
+        u32x4(&w)[3][C::MT] = wv[s % C::RING];
+        if (s + 2 < C::KSTEPS) read_x(s + 2, x[cur]);               // (x[cur] was split during the previous k-step)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {                                // small terms first
+            constexpr int PW[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+            for (int m = 0; m < C::MT; ++m)
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w[PW[q]][m]), as_bf(b[cur][PB[q]]), acc[m], 0, 0, 0);
+            if (q < 4 && s + 1 < C::KSTEPS) split_pair(x[nxt], q, b[nxt][0], b[nxt][1], b[nxt][2]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // ring: this slot's MFMAs have issued - request the fragments of the k-step that uses the slot next
         if (s + C::RING < C::KSTEPS) {
@@ -412,7 +423,7 @@ int bx3_launch_t(const EncConvArgs& a0, hipStream_t stream) {
 }  // namespace
 
 bool bx3_shape(int cin, int cout, int stride) {
-    return (stride == 2 && cin == 16 && cout == 32) || (stride == 1 && cin == cout && (cin == 32 || cin == 64));
+    return (stride == 2 && ((cin == 16 && cout == 32) || (cin == 32 && cout == 64))) || (stride == 1 && cin == cout && (cin == 32 || cin == 64));
 }
 
 size_t bx3_packed_floats(int cin, int cout) { return (size_t)9 * (cin / 16) * 3 * (cout / 32) * 64 * 4; }
@@ -427,6 +438,10 @@ int bx3_transform_launch(const float* w, int cin, int cout, float* packed, hipSt
 bool bx3_supported(int cin, int cout, int stride, const EncConvArgs& a) {
     const char* off = getenv("EEM_NO_BX3");              // read per launch: the tests compare both kernels in one process
     if (off && off[0] == '1') return false;
+    if (stride == 2 && cin == 32) {                       // pconv3_1: EEM_NO_BX3_64=1 keeps conv_enc2.hip's chunked kernel
+        const char* m = getenv("EEM_NO_BX3_64");
+        if (m && m[0] == '1') return false;
+    }
     if (stride == 1) {                                    // EEM_BX3_S1 = mask of channel widths: 1 = 32, 2 = 64
         const char* m = getenv("EEM_BX3_S1");
         const int mask = m ? atoi(m) : 0;                 // off by default: see the note at bx3_s1_kernel
@@ -436,8 +451,9 @@ bool bx3_supported(int cin, int cout, int stride, const EncConvArgs& a) {
            (a.act == 0 || a.act == 1) && (((uintptr_t)a.in0) & 15) == 0 && (size_t)cin * a.hin * a.win * 4 < (1u << 31);
 }
 
-int bx3_launch(int cin, const EncConvArgs& a, hipStream_t stream) {
+int bx3_launch(int cin, int stride, const EncConvArgs& a, hipStream_t stream) {
     if (cin == 64) return bx3_s1_launch_t<64, 64, 2>(a, stream);
+    if (cin == 32 && stride == 2) return bx3_launch_t<32, 64>(a, stream);
     if (cin == 32) return bx3_s1_launch_t<32, 32, 1>(a, stream);
     return bx3_launch_t<16, 32>(a, stream);
 }

@@ -177,17 +177,18 @@ def test_bf16_piece_stride2_kernel_equals_the_fp32_one(monkeypatch, b, h, w):
     e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(57, b, h, w))
     outs = []
     for off in ("0", "1"):
-        monkeypatch.setenv("EEM_NO_BX3", off)
+        monkeypatch.setenv("EEM_NO_BX3", off)                            # both stride-2 layers: pconv2_1 and pconv3_1 (EEMFlow.py:77,80)
         net, _ = make_net(46, graph=False)
         net.change_imagesize((h, w))
         with torch.no_grad():
             flow = net(e1, e2)[1][0].clone()
-        outs.append((flow, net.stage("a2").clone(), net.stage("f12").clone()))
-    (flow_b, a2_b, f12_b), (flow_f, a2_f, f12_f) = outs
-    assert not torch.equal(a2_b, a2_f)                                   # (the switch did switch)
+        outs.append((flow, net.stage("a2").clone(), net.stage("f12").clone(), net.stage("a3").clone()))
+    (flow_b, a2_b, f12_b, a3_b), (flow_f, a2_f, f12_f, a3_f) = outs
+    assert not torch.equal(a2_b, a2_f) and not torch.equal(a3_b, a3_f)   # (the switch did switch)
     scale = float(a2_f.abs().max())
     assert scale > 1e-3 and maxerr(a2_b, a2_f) < 2e-6 * max(scale, 1.0)  # K = 144 sums of either kernel: ~2e-7 of sum |a b|
     assert maxerr(f12_b, f12_f) < 1e-5 * max(float(f12_f.abs().max()), 1.0)
+    assert maxerr(a3_b, a3_f) < 1e-5 * max(float(a3_f.abs().max()), 1.0)
     assert maxerr(flow_b, flow_f) < 2e-5
 
 

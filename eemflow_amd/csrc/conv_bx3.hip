@@ -17,6 +17,9 @@
 // issue, and their split sits between those MFMAs (pinned by sched_barrier; the scheduler's own order put the whole split in front).
 // pconv2_1 (16 -> 32): 40 KB of LDS, four blocks per CU, 17.0 -> 13.3 us; pconv3_1 (32 -> 64, EEM_NO_BX3_64=1 for conv_enc2.hip's
 // kernel): 80 KB, two per CU, 14.5 -> 11.1 us.  What is left is not arithmetic: the tile's way in from HBM and the stores.
+// Measured and not kept: pconv2_1 as persistent blocks (weights stationary in 108 registers, two LDS stages, tile t + 1 streaming in under
+// tile t's MFMAs and tile t - 1's stores, counted waits; two blocks per CU): 14.1 us at two tiles per block, 17.2 at three on 150 CUs,
+// against 13.1 for these one-tile blocks on the same box, and 8 790-8 890 frames/s with four frames in flight against 8 850-8 880.
 // Inputs with an infinity give NaN here where the fp32 kernels give an infinity (inf - inf in the split).
 #include "common.h"
 

@@ -542,7 +542,9 @@ int run_forward_impl(eemflow_ctx* c, const Shape& s, const float* e1, const floa
         // several frames in flight: kernels of different frames time-slice the CUs, so a block's prologue (DMA plan, first tile's
         // landing) is CU time another frame could use - fewer blocks with more tiles each (measured at 1280x720 with four in flight:
         // +3.5 % frames/s, +8 % single-frame latency; the 64-channel layers have one tile per CU and keep the full grid)
-        static const int kInFlightBlocks[ENC_NUM] = {20, 24, 0, 29, 29, 0, 0, 0};
+        // (pconv1_1, HBM-bound: 12 / 14 / 20 blocks per XCD give the same frame rate within 1 % - 8 610-8 660 / 8 580-8 620 / 8 520-8 580 -,
+        // so it takes the fewest CUs: 32 us on 96 of them)
+        static const int kInFlightBlocks[ENC_NUM] = {12, 24, 0, 29, 29, 0, 0, 0};
         a.blocks_per_xcd = c->frames_in_flight >= 3 ? kInFlightBlocks[sp.layer] : 0;
         for (int k = 0; k < 3; ++k)
             if (s.fuse[k] && sp.layer == (k == 0 ? ENC_1_2 : k == 1 ? ENC_2_3 : ENC_3_3)) {

@@ -31,6 +31,10 @@ import torch         # noqa: E402
 
 PEAK_MFMA_F32_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix peak
 PEAK_HBM_GBS = 8000.0            # HBM3E spec peak
+PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA peak (same guide)
+# an fp32 product computed as six bf16-piece MFMAs (conv_bx3.hip): the roof such a kernel runs against, in fp32-equivalent FLOPs
+PEAK_BF16X3_TFLOPS = PEAK_BF16_TFLOPS / 6.0
+ROTATE_PAIRS = 8                 # distinct input pairs walked by the timed loop: 8 x 36.9 MB > the 256 MiB Infinity Cache at 1280x720
 N_CUS = 256
 
 
@@ -56,6 +60,8 @@ def parse():
     p.add_argument("--frames-in-flight", type=int, default=0,
                    help="eemflow_set_frames_in_flight hint for the contexts (default: --streams); the profiles use --streams 1 "
                         "--frames-in-flight 4 to trace the timed loop's launch configuration one kernel at a time")
+    p.add_argument("--rotate-pairs", type=int, default=ROTATE_PAIRS,
+                   help="distinct input pairs the timed loop walks (1: the same pair every step, an Infinity-Cache-resident input)")
     p.add_argument("--streams", type=int, default=4,
                    help="frames in flight per GPU: independent contexts on separate HIP streams, steps alternate")
     return p.parse_args()
@@ -571,6 +577,12 @@ def main():
     sd_np = seeded_state_dict(0)
     e1_np, e2_np = synthetic_voxel_pair(1 + rank, B, H, W)          # each rank its own frames
     e1, e2 = torch.from_numpy(e1_np).to(dev), torch.from_numpy(e2_np).to(dev)
+    # The timed loop walks ROTATE_PAIRS distinct input pairs in distinct buffers (pair 0 as generated, pair r = pair 0 rolled by r * (37, 53)
+    # pixels: the same statistics, other bytes at other addresses): at 1280x720 that is 8 x 36.9 MB = 295 MB of inputs between two uses
+    # of the same line, more than the 256 MiB Infinity Cache, so the first layer's reads come from HBM as they do in an evaluation loop
+    n_rot = max(1, args.rotate_pairs)
+    pairs = [(e1, e2)] + [(torch.roll(e1, shifts=(37 * r, 53 * r), dims=(2, 3)).contiguous(),
+                           torch.roll(e2, shifts=(37 * r, 53 * r), dims=(2, 3)).contiguous()) for r in range(1, n_rot)]
     flat = torch.cat([torch.from_numpy(v).reshape(-1) for v in sd_np.values()]).contiguous()
 
     NS = max(1, args.streams)
@@ -598,8 +610,9 @@ def main():
             t_end = time.perf_counter() + stagger
             while time.perf_counter() < t_end:
                 pass
+        a, b = pairs[counter[0] % n_rot]
         counter[0] += 1
-        _lib.check(L.eemflow_forward(ctxs[i], e1.data_ptr(), e2.data_ptr(), B, H, W, flows[i].data_ptr(), H, W, sps[i]))
+        _lib.check(L.eemflow_forward(ctxs[i], a.data_ptr(), b.data_ptr(), B, H, W, flows[i].data_ptr(), H, W, sps[i]))
 
     # Clock / runtime pre-heat (untimed, reported as "preheat_steps"): the contexts have just been built on an idle GPU, and the first
     # milliseconds after that run at ramping clocks with cold graph-launch paths (20 timed steps after 5 warm-up steps read 6 % lower than
@@ -643,12 +656,16 @@ def main():
                 k = stats[i]
                 sec = k.ms * 1e-3
                 ai = k.flops / max(k.bytes, 1.0)
-                bound = "mfma" if ai >= PEAK_MFMA_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9) else "hbm"
+                # the roof a launch runs against: fp32 MFMA, or - for the kernels that compute fp32 products as six bf16-piece MFMAs -
+                # the bf16 pipe / 6 (416.7 TFLOP/s, balance 52 FLOP/B: the stride-2 layers' 24-48 FLOP/B are then HBM-bound)
+                peak_tf = PEAK_BF16X3_TFLOPS if k.pipe == 1 else PEAK_MFMA_F32_TFLOPS
+                bound = "mfma" if ai >= peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9) else "hbm"
                 # the encoder's kernels are persistent (one workgroup per CU): a launch of fewer than 256 workgroups occupies that many
                 # CUs and leaves the rest to the other frames in flight; chip_us = duration x the share of the chip it holds
                 cus = min(k.blocks, N_CUS) if k.blocks > 0 else N_CUS
                 table.append({"name": k.name.decode(), "us": round(k.ms * 1e3, 2), "gflop": round(k.flops / 1e9, 4),
-                              "mbytes": round(k.bytes / 1e6, 3), "bound": bound,
+                              "mbytes": round(k.bytes / 1e6, 3), "bound": bound, "pipe": "bf16x3" if k.pipe == 1 else "f32",
+                              "peak_tflops": round(peak_tf, 1),
                               "tflops": round(k.flops / sec / 1e12, 2), "gbs": round(k.bytes / sec / 1e9, 1),
                               "workgroups": k.blocks, "cus": cus, "chip_us": round(k.ms * 1e3 * cus / N_CUS, 2)})
             return table
@@ -660,8 +677,8 @@ def main():
             dom = max(table, key=lambda k: k["chip_us"])
             share = dom["cus"] / N_CUS
             if dom["bound"] == "mfma":
-                r = {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(dom["tflops"] / PEAK_MFMA_F32_TFLOPS, 4)}
+                r = {"bound": "mfma", "achieved": dom["tflops"], "peak": dom["peak_tflops"], "unit": "TFLOP/s",
+                     "frac": round(dom["tflops"] / dom["peak_tflops"], 4)}
             else:
                 r = {"bound": "hbm", "achieved": dom["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
                      "frac": round(dom["gbs"] / PEAK_HBM_GBS, 4)}
@@ -682,7 +699,15 @@ def main():
             r["algorithmic_bytes"] = round(dom["mbytes"] * 1e6)
             r["kernel"] = dom["name"]
             r["kernel_us"] = dom["us"]
-            r["longest_launch"] = {k2: max(table, key=lambda k: k["us"])[k2] for k2 in ("name", "us", "cus", "tflops")}
+            r["pipe"] = dom["pipe"]
+            # the same figures for the launch that takes the longest (dominant by TIME, whatever share of the chip it holds)
+            lg = max(table, key=lambda k: k["us"])
+            r["dominant_by_time"] = {"kernel": lg["name"], "kernel_us": lg["us"], "cus": lg["cus"], "bound": lg["bound"], "pipe": lg["pipe"],
+                                     "achieved": lg["tflops"] if lg["bound"] == "mfma" else lg["gbs"],
+                                     "peak": lg["peak_tflops"] if lg["bound"] == "mfma" else PEAK_HBM_GBS,
+                                     "unit": "TFLOP/s" if lg["bound"] == "mfma" else "GB/s",
+                                     "frac": round(lg["tflops"] / lg["peak_tflops"], 4) if lg["bound"] == "mfma" else round(lg["gbs"] / PEAK_HBM_GBS, 4)}
+            r["longest_launch"] = {k2: lg[k2] for k2 in ("name", "us", "cus", "tflops")}
             return r
 
         fif = args.frames_in_flight or NS
@@ -719,6 +744,11 @@ def main():
             extra["speedup_vs_cpu_baseline"] = round(value / world / cpu["value"], 1)
 
         ms_per_step = slowest * 1e3 / args.steps
+        # the robust number: the frame's direct-convolution FLOPs at the fp32 MFMA peak (its ceiling with the direct algorithm on that
+        # pipe) over the measured time per step of one GPU
+        ceiling_ms = total_gflop * B / (PEAK_MFMA_F32_TFLOPS * 1e3)
+        roof["frame_frac_of_ceiling"] = round(ceiling_ms / ms_per_step, 4)
+        roof["frame_ceiling_us"] = round(ceiling_ms * 1e3, 2)
         line = {
             "metric": baseline_metric(),
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -727,6 +757,7 @@ def main():
             "config": {"workload": f"EEMFlow inference, HREM {W}x{H} dt1, batch={B} per GPU (BASELINE configs[1]); "
                                    "synthetic 20%-dense voxel pairs resident in HBM, seeded Kaiming weights",
                        "height": H, "width": W, "batch_per_gpu": B, "hip_graph": not args.no_graph, "streams_per_gpu": NS, "preheat_steps": args.preheat,
+                       "input_pairs_rotated": n_rot, "input_bytes_rotated": n_rot * 2 * e1.numel() * 4,
                        "parallelism": f"replicas x{world}: frames sharded over ranks, no data-path collective"},
             "roofline": roof, "roofline_single_frame_launch": roof_single, "cpu_baseline": cpu,
             "gpu_ms_per_step_hip_events": round(gpu_ms / args.steps, 4),

@@ -14,7 +14,7 @@ _c_float_p = ctypes.c_void_p          # device/host pointers travel as integers
 
 class KernelStat(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 48), ("flops", ctypes.c_double), ("bytes", ctypes.c_double),
-                ("ms", ctypes.c_float), ("blocks", ctypes.c_int)]
+                ("ms", ctypes.c_float), ("blocks", ctypes.c_int), ("pipe", ctypes.c_int), ("reserved", ctypes.c_int)]
 
 
 _SIGNATURES = {

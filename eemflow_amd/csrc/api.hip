@@ -12,7 +12,7 @@
 
 // ------------------------------------------------------------------------------- errors
 static thread_local char g_err[512] = "";
-thread_local int eem_last_grid_blocks = 0, eem_last_grid_threads = 0;
+thread_local int eem_last_grid_blocks = 0, eem_last_grid_threads = 0, eem_last_pipe = 0;
 
 void eem_set_error(const char* fmt, ...) {
     va_list ap;
@@ -243,6 +243,7 @@ extern "C" int eemflow_load_weights(eemflow_ctx* c, const float* flat, size_t nf
     c->groups = groups;
     c->weights_loaded = true;
     c->opt_step = 0;
+    c->skip_counter_zeroed = false;      // the device-side count of skipped steps restarts with the step count (bias corrections use step - skipped)
     c->have_train_fwd = false;
     // a reloaded model starts a new optimisation: stale AdamW moments must not meet a fresh bias correction
     if (c->adam_m.p) EEM_HIP_CHECK(hipMemset(c->adam_m.p, 0, c->adam_m.cap * sizeof(float)));

@@ -370,7 +370,7 @@ struct Hook {
             return spin > 0.f ? spin_launch(spin, st) : EEM_OK;
         }
         if (!timing) return launch(st);
-        eem_last_grid_blocks = eem_last_grid_threads = 0;
+        eem_last_grid_blocks = eem_last_grid_threads = eem_last_pipe = 0;
         int rc = launch(st);                                  // warm (also keeps data flowing downstream)
         if (rc != EEM_OK) return rc;
         EEM_HIP_CHECK(hipEventRecord(ev0, st));
@@ -385,6 +385,7 @@ struct Hook {
         strncpy(ks.name, name, sizeof(ks.name) - 1);
         ks.flops = flops; ks.bytes = bytes; ks.ms = ms / (float)reps;
         ks.blocks = eem_last_grid_blocks;                     // 0: a launcher that does not report its grid
+        ks.pipe = eem_last_pipe;
         stats.push_back(ks);
         return EEM_OK;
     }

@@ -8,6 +8,8 @@
 
 #include <type_traits>
 
+#include "../../include/eemflow_hip.h"   // every definition of an entry point sees its declaration (default visibility; the build hides the rest)
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -43,8 +45,10 @@ __host__ __device__ static inline int ceil_div(int a, int b) { return (a + b - 1
 
 // grid of the encoder launch this thread made last (blocks x threads per block): eemflow_time_kernels reports it beside the
 // duration - a kernel that runs on a quarter of the chip by design is not a slow kernel (api.hip defines it)
-extern thread_local int eem_last_grid_blocks, eem_last_grid_threads;
+extern thread_local int eem_last_grid_blocks, eem_last_grid_threads, eem_last_pipe;
 #define EEM_NOTE_GRID(blocks, threads) do { eem_last_grid_blocks = (int)(blocks); eem_last_grid_threads = (int)(threads); } while (0)
+// which matrix pipe the launch's contraction runs on: 0 fp32 MFMA (157 TFLOP/s), 1 fp32 products as six bf16-piece MFMAs (2.5 PFLOP/s / 6)
+#define EEM_NOTE_PIPE(p) do { eem_last_pipe = (int)(p); } while (0)
 
 // compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N) - the index is usable as a template /
 // inline-asm immediate inside f

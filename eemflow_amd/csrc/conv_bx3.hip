@@ -405,6 +405,7 @@ int bx3_s1_launch_t(const EncConvArgs& a0, hipStream_t stream) {
     a.tiles_y = ceil_div(a.hout, C::TH);
     dim3 grid((unsigned)ceil_div(a.tiles_x * a.tiles_y * a.nimg, 8) * 8);
     EEM_NOTE_GRID(grid.x, C::THREADS);
+    EEM_NOTE_PIPE(1);
     hipLaunchKernelGGL((bx3_s1_kernel<CIN, COUT, KGT>), grid, dim3(C::THREADS), 0, stream, a, reinterpret_cast<const u32x4*>(a.wbx3));
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
@@ -418,6 +419,7 @@ int bx3_launch_t(const EncConvArgs& a0, hipStream_t stream) {
     a.tiles_y = ceil_div(a.hout, C::TH);
     dim3 grid((unsigned)ceil_div(a.tiles_x * a.tiles_y * a.nimg, 8) * 8);
     EEM_NOTE_GRID(grid.x, 256);
+    EEM_NOTE_PIPE(1);
     hipLaunchKernelGGL((bx3_s2_kernel<CIN, COUT>), grid, dim3(256), 0, stream, a, reinterpret_cast<const u32x4*>(a.wbx3));
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;

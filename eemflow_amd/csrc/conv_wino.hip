@@ -443,7 +443,7 @@ bool wino_supported(int cin, int cout, int stride, int win) {
 size_t wino_packed_floats(int c) { return wino4_packed_floats(c); }      // 36 c^2 >= 16 c^2: either form fits
 
 #ifdef EEM_STAMPS
-extern "C" int eemflow_debug_read_stamps16(unsigned long long* dst, size_t n) {
+extern "C" __attribute__((visibility("default"))) int eemflow_debug_read_stamps16(unsigned long long* dst, size_t n) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps16), n * sizeof(unsigned long long)) == hipSuccess ? 0 : 2;
 }
 #endif

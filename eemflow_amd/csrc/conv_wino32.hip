@@ -383,7 +383,7 @@ int launch_c(const EncConvArgs& a0, hipStream_t stream) {
 }  // namespace
 
 #ifdef EEM_STAMPS
-extern "C" int eemflow_debug_read_stamps(unsigned long long* dst, size_t n) {
+extern "C" __attribute__((visibility("default"))) int eemflow_debug_read_stamps(unsigned long long* dst, size_t n) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), n * sizeof(unsigned long long)) == hipSuccess ? 0 : 2;
 }
 #endif

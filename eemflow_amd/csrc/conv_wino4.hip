@@ -258,9 +258,7 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(EncConvArgs a) {
             }
         }
         // (c) request k-step L+R-1 into the slot k-step L-1 has left
-#if !defined(EEM_W4_ABL) || EEM_W4_ABL != 1
         if (L + R - 1 < total) dma_issue();
-#endif
 
         // (d) the patch, then its column transform (rows -> xi) on the column pairs (-1,4) (0,1) (2,3) the reads deliver
         const float* sl = lds + slot * K::STAGE;
@@ -285,40 +283,25 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(EncConvArgs a) {
             for (int r = 0; r < 6; ++r) x[r] = f32x2{pmid[r][2], pmid[r][3]};
             bt6(x, t34);
         }
-        // (e) row transform (columns -> nu), then the 36 MFMAs back to back, A operands from LDS four positions at a time.
-        // EEM_W4_SCHED (build-time experiment): 0 = transforms first, then the MFMA run; 1 = row by row, as the compiler places them
-        const f32x4* wl = reinterpret_cast<const f32x4*>(sl + wlbase);
-#ifndef EEM_W4_SCHED
-#define EEM_W4_SCHED 0
-#endif
-#if EEM_W4_SCHED == 0
-        // rows in blocks of RB: their transforms (independent chains: instruction-level parallelism for the lone issue slot), then
+        // (e) row transform (columns -> nu), then the 36 MFMAs back to back, A operands from LDS four positions at a time:
+        // rows in blocks of RB - their transforms (independent chains: instruction-level parallelism for the lone issue slot), then
         // their MFMAs back to back with the A operands read two quads ahead
+        const f32x4* wl = reinterpret_cast<const f32x4*>(sl + wlbase);
         constexpr int RB = 3;
         f32x4 wq0 = wl[0], wq1 = wl[64];
 #pragma unroll
         for (int xb = 0; xb < 6; xb += RB) {
             float v[RB * 6];
 #pragma unroll
-#if defined(EEM_W4_ABL) && EEM_W4_ABL == 3
-            for (int xi = 0; xi < RB; ++xi) { v[xi * 6] = t05[xb + xi][0]; v[xi * 6 + 1] = t12[xb + xi][0]; v[xi * 6 + 2] = t12[xb + xi][1]; v[xi * 6 + 3] = t34[xb + xi][0]; v[xi * 6 + 4] = t34[xb + xi][1]; v[xi * 6 + 5] = t05[xb + xi][1]; }
-#else
             for (int xi = 0; xi < RB; ++xi) bt6_row(t05[xb + xi], t12[xb + xi], t34[xb + xi], v + xi * 6);
-#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int pp = 0; pp < RB * 6; ++pp) {
                 const int p = xb * 6 + pp;
-#if !defined(EEM_W4_ABL) || EEM_W4_ABL != 4
                 if (pp > 0 && (p & 3) == 0) {
                     wq0 = wq1;
                     if ((p >> 2) + 1 < 9) wq1 = wl[((p >> 2) + 1) * 64];
                 }
-#endif
-#if defined(EEM_W4_ABL) && EEM_W4_ABL == 2
-                acc[p][0] += wq0[p & 3] * v[pp];
-                continue;
-#endif
                 if constexpr (S0) {
                     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
                     acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq0[p & 3], v[pp], p == 7 ? biasq : z, 0, 0, 0);
@@ -328,26 +311,6 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(EncConvArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-#else
-        f32x4 wq = wl[0];
-#pragma unroll
-        for (int xi = 0; xi < 6; ++xi) {
-            float v[6];
-            bt6_row(t05[xi], t12[xi], t34[xi], v);
-#pragma unroll
-            for (int nu = 0; nu < 6; ++nu) {
-                const int p = xi * 6 + nu;
-                const float wv = wq[p & 3];
-                if constexpr (S0) {
-                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                    acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, v[nu], p == 7 ? biasq : z, 0, 0, 0);
-                } else {
-                    acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, v[nu], acc[p], 0, 0, 0);
-                }
-                if ((p & 3) == 3 && p < 35) wq = wl[((p >> 2) + 1) * 64];
-            }
-        }
-#endif
         STAMP4(3 + 2 * L);
         ++L;
         slot = slot + 1 == R ? 0 : slot + 1;
@@ -586,10 +549,10 @@ int launch4_c(const EncConvArgs& a0, hipStream_t stream) {
 }  // namespace
 
 #ifdef EEM_STAMPS
-extern "C" int eemflow_debug_read_stamps4(unsigned long long* dst, size_t n) {
+extern "C" __attribute__((visibility("default"))) int eemflow_debug_read_stamps4(unsigned long long* dst, size_t n) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps4), n * sizeof(unsigned long long)) == hipSuccess ? 0 : 2;
 }
-extern "C" int eemflow_debug_clear_stamps4() {
+extern "C" __attribute__((visibility("default"))) int eemflow_debug_clear_stamps4() {
     static unsigned long long zero[1024 * 8 * 64];
     return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps4), zero, sizeof zero) == hipSuccess ? 0 : 2;
 }

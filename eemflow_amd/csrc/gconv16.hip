@@ -439,7 +439,7 @@ int launch(const GConvArgs& a, const float* wpk16, const float* zero_page, hipSt
 }  // namespace
 
 #ifdef EEM_G16_STAMPS
-extern "C" int eemflow_debug_read_g16_stamps(unsigned long long* dst, size_t n) {
+extern "C" __attribute__((visibility("default"))) int eemflow_debug_read_g16_stamps(unsigned long long* dst, size_t n) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_g16_stamps), n * sizeof(unsigned long long)) == hipSuccess ? 0 : 2;
 }
 #endif

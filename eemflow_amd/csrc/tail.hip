@@ -459,12 +459,12 @@ int upsample_launch(const float* in, float* out, int nc, int h, int w, int oh, i
     return EEM_OK;
 }
 
-__global__ void spin_kernel(long ticks) {                 // wall_clock64: the 100 MHz constant clock
+static __global__ void spin_kernel(long ticks) {                 // wall_clock64: the 100 MHz constant clock
     const long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 
-__global__ void spin_code_kernel(long ticks) {            // the same wait behind 16 KB of straight-line code (instruction-cache footprint)
+static __global__ void spin_code_kernel(long ticks) {            // the same wait behind 16 KB of straight-line code (instruction-cache footprint)
     const long t0 = wall_clock64();
     asm volatile(".rept 4096\n s_nop 0\n .endr\n" ::: "memory");
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);

@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     if (i >= n) return;
     const double ss = *sumsq;
     if (!(ss <= 1.7976931348623157e308)) return;             // inf or NaN
-    const float eff = (float)(step - (long)*nskip);           // optimizer steps taken, this one included
+    const float eff = fmaxf((float)(step - (long)*nskip), 1.f);           // optimizer steps taken, this one included
     const float bc1 = 1.f - powf(b1, eff), bc2 = 1.f - powf(b2, eff);
     float coef = 1.f;
     if (clip > 0.f) {

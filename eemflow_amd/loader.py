@@ -50,6 +50,15 @@ class ThreadedBatchLoader:
         n = len(self.sampler) if self.sampler is not None else len(self.dataset)
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
 
+    @staticmethod
+    def _cuda_device_of(sample):
+        """Device of the first CUDA tensor in a sample dict / sequence (None: a host-side sample)."""
+        vals = sample.values() if isinstance(sample, dict) else (sample if isinstance(sample, (list, tuple)) else (sample,))
+        for v in vals:
+            if torch.is_tensor(v) and v.is_cuda:
+                return v.device
+        return None
+
     def _sample(self, idx):
         # the current device is per THREAD: a worker starts on device 0 whatever the rank's GPU is, so the sample is built (and its
         # hand-over event recorded) under the dataset's device
@@ -59,8 +68,17 @@ class ThreadedBatchLoader:
                 sample = self.dataset[idx]
                 ready = torch.cuda.Event()
                 ready.record(torch.cuda.current_stream(dev))
-            return sample, ready
-        return self.dataset[idx], None
+            return sample, ready, torch.device(dev)
+        sample = self.dataset[idx]
+        # a wrapped dataset (Subset, ConcatDataset, a user class) has no `.device`: if it built CUDA tensors on this worker thread, the
+        # consumer still has to wait for this thread's stream on THAT device
+        sdev = self._cuda_device_of(sample) if torch.cuda.is_available() else None
+        if sdev is not None:
+            with torch.cuda.device(sdev):
+                ready = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream(sdev))
+            return sample, ready, sdev
+        return sample, None, None
 
     def __iter__(self):
         idx = self._indices()
@@ -85,9 +103,9 @@ class ThreadedBatchLoader:
                 submit()
                 samples = []
                 for f in futures:
-                    sample, ready = f.result()
+                    sample, ready, sdev = f.result()
                     if ready is not None:
-                        torch.cuda.current_stream(dev).wait_event(ready)
+                        torch.cuda.current_stream(sdev).wait_event(ready)
                     samples.append(sample)
                 yield {k: (torch.stack([s[k] for s in samples]) if torch.is_tensor(samples[0][k]) else [s[k] for s in samples])
                        for k in samples[0]}

@@ -135,7 +135,7 @@ class _packs_of:
 # `parameter.grad` (allocated zeroed on first use) and the Function returns None for them: E-RAFT's update block uses every weight in
 # each of its 12 iterations, and autograd's own accumulation was one at::add_ launch and one zero fill per use and parameter (627 +
 # 520 launches of a training step).  What is lost: tensor hooks on those parameters and `torch.autograd.grad(..., inputs=[weight])`
-# (the gradient lands in .grad instead) - switch it off for such callers: `ops.set_direct_param_grads(False)` / EEM_NO_DIRECT_WGRAD=1.
+# (the gradient lands in .grad instead; a parameter WITH a registered hook is detected and keeps the autograd route) - switch it off for such callers: `ops.set_direct_param_grads(False)` / EEM_NO_DIRECT_WGRAD=1.
 _direct_param_grads = [os.environ.get("EEM_NO_DIRECT_WGRAD", "0") != "1"]
 
 
@@ -146,9 +146,15 @@ def set_direct_param_grads(enabled):
     return old
 
 
+def _has_grad_hooks(t):
+    """Tensor hooks (`register_hook`: DDP's reducer is one) or post-accumulate hooks on a parameter: they fire from autograd's
+    AccumulateGrad node, which the direct route bypasses - such a parameter keeps the autograd route."""
+    return bool(getattr(t, "_backward_hooks", None)) or bool(getattr(t, "_post_accumulate_grad_hooks", None))
+
+
 def _leaf_param(t):
     return t if (isinstance(t, torch.nn.Parameter) and t.is_leaf and t._base is None and t.requires_grad and t.is_contiguous()
-                 and t.dtype == torch.float32) else None
+                 and t.dtype == torch.float32 and not _has_grad_hooks(t)) else None
 
 
 class Conv2d(torch.autograd.Function):

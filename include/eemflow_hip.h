@@ -22,8 +22,16 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
-
+/* Opaque contexts (declared ahead of the visibility block: their C++ members are not part of the ABI). */
 typedef struct eemflow_ctx eemflow_ctx;
+typedef struct eraft_ctx eraft_ctx;
+typedef struct eemplus_ctx eemplus_ctx;
+
+/* The library is built with -fvisibility=hidden: the entry points declared here (and nothing else - no kernel launcher, no C++
+ * helper) are its dynamic symbols. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 /* ABI version of this header (bumped on incompatible change). */
 int eemflow_abi_version(void);
@@ -92,6 +100,8 @@ typedef struct eemflow_kernel_stat {
     float ms;
     int blocks;      /* workgroups of the launch (0: not reported): the encoder's kernels are persistent, one workgroup per CU,
                         so blocks < 256 means the launch occupies that many of the 256 CUs */
+    int pipe;        /* matrix pipe of the launch's contraction: 0 = fp32 MFMA, 1 = fp32 products as six bf16-piece MFMAs (conv_bx3.hip) */
+    int reserved;
 } eemflow_kernel_stat;
 int eemflow_time_kernels(eemflow_ctx* ctx, const float* events1, const float* events2, int batch, int in_h,
                          int in_w, float* flow_out, int out_h, int out_w, int reps, eemflow_kernel_stat* stats,
@@ -199,7 +209,6 @@ int eemflow_get_weights(eemflow_ctx* ctx, float* dst, size_t nfloats, void* stre
  * E-RAFT (model/eraft.py): feature / context encoders, all-pairs correlation pyramid, 9x9 x 4-level
  * lookup, SepConvGRU update block, convex upsampling.  Inference (eval-mode BatchNorm).
  * ---------------------------------------------------------------------------------------------- */
-typedef struct eraft_ctx eraft_ctx;
 
 /* Replaces: ERAFT.__init__ + .to(device)  (model/eraft.py:40-62). */
 int eraft_create(int device, eraft_ctx** out);
@@ -268,7 +277,6 @@ int eraft_convex_upsample(eraft_ctx* ctx, const float* flow, const float* mask, 
 /* ------------------------------------------------------------------------------------------------
  * EEMFlow+ (EEMFlow_cdc, model/EEMFlow/EEMFlow+.py + cdc_utils.py): the coarse-to-fine bilinear flow-warp loop.
  * ---------------------------------------------------------------------------------------------- */
-typedef struct eemplus_ctx eemplus_ctx;
 
 /* Replaces: EEMFlow_cdc.__init__ + .to(device)  (model/EEMFlow/EEMFlow+.py:75-135). */
 int eemplus_create(int device, eemplus_ctx** out);
@@ -422,6 +430,9 @@ int eemop_resize_ac_bwd(const float* dout, float* dx, int nc, int h, int w, int 
 int eemop_local_corr53_bwd(const float* dcv, const float* f1, const float* f2, int batch, int c, int h, int w, float* df1, float* df2,
                            void* stream);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -222,9 +222,12 @@ def oracle_loss_and_grads(sd, e1, e2, gt, valid, iters, size, dtype=torch.float3
     return float(loss), metrics, grads, [p.detach() for p in preds], params
 
 
+@pytest.mark.parametrize("path", ["default", "generic_s2"])
 @pytest.mark.parametrize("b,h,w,iters", [(2, 128, 160, 3), (1, 136, 200, 2)])
-def test_eraft_loss_backward_vs_oracle_autograd(b, h, w, iters):
+def test_eraft_loss_backward_vs_oracle_autograd(monkeypatch, b, h, w, iters, path):
     from eemflow_amd import train as hip_train
+    if path == "generic_s2":                  # the encoders' stride-2 convs on the generic kernel: the operator set the tight bounds were set on
+        monkeypatch.setenv("EEM_NO_G16_S2", "1")
     net, sd = make_model(31)
     net.change_imagesize((h, w))
     e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(32, b, h, w))
@@ -265,8 +268,14 @@ def test_eraft_loss_backward_vs_oracle_autograd(b, h, w, iters):
 
     l2_lib, errs = against_exact({k: named[k].grad for k in live})
     l2_f32, _ = against_exact(rgrads)
-    assert l2_lib < max(3 * l2_f32, 5e-4), (l2_lib, l2_f32)
-    assert errs[0][0] < 0.15 and sum(e >= 5e-3 for e, _ in errs) <= (2 * len(errs)) // 5, errs[:8]
+    if path == "generic_s2":
+        # per-tensor bounds as they stood before the stride-2 convs moved to gconv16 (worst 1.4e-2 / 4.4e-2, 2 / 6 tensors beyond 5e-3):
+        # an operator bug (a wrong tap, a missing term) moves whole tensors by tens of percent and fails here
+        assert errs[0][0] < 8e-2 and sum(e >= 5e-3 for e, _ in errs) <= len(errs) // 5, errs[:8]
+        assert l2_lib < max(1.5 * l2_f32, 3e-4), (l2_lib, l2_f32)
+    else:
+        assert l2_lib < max(1.5 * l2_f32, 3e-4), (l2_lib, l2_f32)
+        assert errs[0][0] < 0.15 and sum(e >= 5e-3 for e, _ in errs) <= (2 * len(errs)) // 5, errs[:8]
     # train-mode BatchNorm: the module's running statistics moved exactly as torch's do
     bufs = net.state_dict()
     for k, v in rparams.items():
@@ -304,6 +313,36 @@ def test_direct_parameter_gradients_equal_autograd_accumulation():
     gmax = max(float(g.abs().max()) for g in grads[1].values())
     for k in grads[0]:
         assert float((grads[0][k] - grads[1][k]).abs().max()) < 2e-4 * max(float(grads[1][k].abs().max()), 1e-3 * gmax), k
+
+
+def test_parameter_hooks_keep_the_autograd_route():
+    """A parameter with a tensor hook (what DDP's reducer registers) or a post-accumulate hook must see its gradient through autograd's
+    AccumulateGrad node: the direct `.grad` accumulation steps aside for exactly those parameters (ops._leaf_param), the others keep it."""
+    from eemflow_amd import train as hip_train
+    b, h, w, iters = 1, 128, 160, 2
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(54, b, h, w))
+    gt, valid = (torch.from_numpy(a).to(DEV) for a in synthetic_gt(55, b, h, w))
+    net, _ = make_model(56)
+    net.change_imagesize((h, w))
+    named = dict(net.named_parameters())
+    hooked = [k for k in named if k.endswith("convz1.weight") or k.endswith("convc1.weight")]
+    assert len(hooked) == 2
+    seen, post = {}, {}
+    for k in hooked:
+        named[k].register_hook(lambda g, k=k: seen.__setitem__(k, g.clone()))
+    named[hooked[0]].register_post_accumulate_grad_hook(lambda p: post.__setitem__("n", post.get("n", 0) + 1))
+    loss, _ = hip_train.sequence_loss(net(e1, e2, iters=iters)[1], gt, valid, 0.8)
+    loss.backward()
+    assert set(seen) == set(hooked) and post.get("n") == 1
+    ref, _ = make_model(56)
+    ref.change_imagesize((h, w))
+    loss2, _ = hip_train.sequence_loss(ref(e1, e2, iters=iters)[1], gt, valid, 0.8)
+    loss2.backward()
+    rnamed = dict(ref.named_parameters())
+    for k in hooked:                                     # the hooked route and the direct route give the same gradient
+        g = rnamed[k].grad
+        assert float((named[k].grad - g).abs().max()) < 2e-4 * float(g.abs().max()), k
+        assert float((seen[k] - g).abs().max()) < 2e-4 * float(g.abs().max()), k
 
 
 def test_eraft_reference_training_sequence_two_steps():

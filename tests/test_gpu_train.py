@@ -203,6 +203,42 @@ def test_non_finite_gradient_skips_the_step_like_gradscaler():
     assert float(d.max()) < 2e-6, float(d.max())          # bias corrections of steps 1, 2, 3 - not 1, 4, 5
 
 
+def test_reload_after_a_skipped_step_restarts_the_skip_count():
+    """eemflow_load_weights restarts the optimisation (step count, moments): the device-side count of skipped steps must restart with
+    it, or the first steps after the reload compute their bias corrections from `step - skipped <= 0` (inf / NaN / sign-flipped
+    updates).  A skipped step, a reload of the same weights, then one real step must equal torch's first AdamW step."""
+    from eemflow_amd import _lib
+    h, w, b = 128, 192, 1
+    net, sd = make_net(63)
+    net.change_imagesize((h, w))
+    tr = EEMFlowTrainer(net, lr=1e-3, wdecay=5e-5, epsilon=1e-8, num_steps=20, clip=1.0)
+    L, sp = _lib.lib(), _lib.current_stream_ptr(torch.device(DEV))
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(64, b, h, w))
+    gt, valid = (torch.from_numpy(a).to(DEV) for a in synthetic_gt(65, b, h, w))
+    tr.step(e1, e2, gt, valid)
+    bad = tr.grad.clone()
+    bad[7] = float("nan")
+    for _ in range(3):
+        _lib.check(L.eemflow_optimizer_step(net._ctx, bad.data_ptr(), 1e-3, 5e-5, 1e-8, 1.0, sp))
+    assert tr.skipped_steps() == 3
+    host0 = torch.cat([v.reshape(-1) for v in sd.values()]).clone().contiguous()          # eemflow_load_weights takes a HOST vector
+    _lib.check(L.eemflow_load_weights(net._ctx, host0.data_ptr(), host0.numel(), 5, 5))
+    flat0 = host0.to(DEV)
+    assert tr.skipped_steps() == 0
+    g = torch.randn_like(flat0) * 1e-3
+    _lib.check(L.eemflow_optimizer_step(net._ctx, g.data_ptr(), 1e-3, 5e-5, 1e-8, 1.0, sp))
+    got = torch.empty_like(flat0)
+    _lib.check(L.eemflow_get_weights(net._ctx, got.data_ptr(), got.numel(), sp))
+    torch.cuda.synchronize()
+    ref = torch.nn.Parameter(flat0.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-3, weight_decay=5e-5, eps=1e-8)
+    ref.grad = g.clone()
+    torch.nn.utils.clip_grad_norm_([ref], 1.0)
+    opt.step()
+    assert bool(torch.isfinite(got).all())
+    assert float((got - ref.detach()).abs().max()) < 2e-6
+
+
 def test_out_mesh_size_training():
     net, sd = make_net(29, out_mesh_size=True)
     net.change_imagesize((128, 128))

@@ -57,6 +57,11 @@ def parse():
     p.add_argument("--mode", choices=("infer", "train"), default="infer",
                    help="infer (default): the headline metric; train: BASELINE configs[3] - EEMFlow training step, 1280x720, batch 8 per GPU, "
                         "data parallel with one RCCL all-reduce of the flat gradient per step (its time is reported as allreduce_us)")
+    p.add_argument("--workload", choices=("eemflow", "eraft"), default="eemflow",
+                   help="eemflow (default): BASELINE configs[1] (infer) / configs[3] (train); eraft: BASELINE configs[4] - E-RAFT 640x480, 12 "
+                        "refinement iterations, batch 4 per GPU, inference (--mode infer) or the training step with one all-reduce of the "
+                        "flat parameter gradient per step (--mode train)")
+    p.add_argument("--iters", type=int, default=12, help="--workload eraft: refinement iterations")
     p.add_argument("--frames-in-flight", type=int, default=0,
                    help="eemflow_set_frames_in_flight hint for the contexts (default: --streams); the profiles use --streams 1 "
                         "--frames-in-flight 4 to trace the timed loop's launch configuration one kernel at a time")
@@ -528,6 +533,109 @@ def main_train(args):
         torch.distributed.destroy_process_group()
 
 
+ERAFT_GFLOP_PER_FRAME_640x480_12IT = 499.2      # direct-convolution + correlation FLOPs of one 640x480 frame, 12 iterations
+
+
+def main_eraft(args):
+    """BASELINE configs[4]: E-RAFT (model/eraft.py:97-159) at 640x480, 12 refinement iterations, batch 4 per GPU.
+    --mode infer: a step = one forward of this rank's batch (frames shard over ranks, no data-path collective; weak scaling).
+    --mode train: a step = train_mvsec.py:241-258's statement sequence on the operator-level autograd route - forward, sequence loss,
+    backward, ONE all-reduce of the flat parameter gradient (parallel.average_gradients: RCCL over xGMI on a multi-GPU node), clip,
+    AdamW - the exchange harness.TrainRaftEvents._train_iters_autograd makes; allreduce_us = its HIP-event time on rank 0."""
+    from eemflow_amd import parallel
+    from eemflow_amd.eraft import ERAFT
+    from eemflow_amd.eraft_weights import seeded_from_shapes
+    from eemflow_amd.train import sequence_loss
+    from eemflow_amd.weights import synthetic_gt, synthetic_voxel_pair
+    rank, local_rank, world = parallel.init_distributed()
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path)"
+    dev = torch.device("cuda", parallel.local_device_index(local_rank))
+    torch.cuda.set_device(dev)
+    B = args.batch if args.batch > 1 else 4
+    H, W = (480, 640) if (args.height, args.width) == (720, 1280) else (args.height, args.width)
+    iters = args.iters
+    train = args.mode == "train"
+    net = ERAFT("", 5)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in
+                         seeded_from_shapes({k: tuple(v.shape) for k, v in net.state_dict().items()}, 0).items()})   # same start on every rank
+    net = net.to(dev)
+    net = net.train() if train else net.eval()
+    net.change_imagesize((H, W))
+    e1, e2 = (torch.from_numpy(a).to(dev) for a in synthetic_voxel_pair(1 + rank, B, H, W))          # each rank its own frames
+    evs = []
+    if train:
+        gt, va = (torch.from_numpy(a).to(dev) for a in synthetic_gt(100 + rank, B, H, W))
+        opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=5e-5, eps=1e-8)
+        params = [p for p in net.parameters() if p.requires_grad]
+        nparam = sum(p.numel() for p in params)
+        last = {"loss": 0.0}
+
+        def step(timed):
+            opt.zero_grad()
+            loss, _ = sequence_loss(net(e1, e2, iters=iters)[1], gt, va, 0.8, metrics=False)
+            loss.backward()
+            have = [p for p in params if p.grad is not None]
+            flat = torch.cat([p.grad.reshape(-1) for p in have])
+            if timed:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+            parallel.average_gradients(flat)
+            if timed:
+                b.record()
+                evs.append((a, b))
+            if parallel.exchange_active():
+                off = 0
+                for p in have:
+                    p.grad.copy_(flat[off:off + p.numel()].view_as(p))
+                    off += p.numel()
+            torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)
+            opt.step()
+            last["loss"] = loss
+    else:
+        nparam = sum(p.numel() for p in net.parameters())
+
+        def step(timed):
+            with torch.no_grad():
+                net(e1, e2, iters=iters)
+
+    for _ in range(max(args.warmup, 1)):
+        step(False)
+    torch.cuda.synchronize(dev)
+    parallel.barrier(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    parallel.barrier(dev)
+    value, slowest = parallel.aggregate_throughput(args.steps * B, elapsed, dev)
+    ar_us = float(np.mean([a.elapsed_time(b) for a, b in evs])) * 1e3 if evs else 0.0
+    if rank == 0:
+        ms_per_step = slowest * 1e3 / args.steps
+        gflop = ERAFT_GFLOP_PER_FRAME_640x480_12IT * (H * W) / (480 * 640) * iters / 12 * (3 if train else 1)     # ~3x forward per training sample
+        what = "training step" if train else "inference"
+        line = {"metric": f"{'samples' if train else 'frames'}/sec, E-RAFT {what} {W}x{H}, {iters} refinement iterations, batch {B}/GPU (BASELINE configs[4])",
+                "value": round(value, 2), "unit": "samples/s" if train else "frames/s", "n_gpus": world, "steps": args.steps,
+                "warmup": max(args.warmup, 1), "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"E-RAFT {what}, {W}x{H}, {iters} refinement iterations, batch={B} per GPU (BASELINE configs[4]); "
+                                       "synthetic voxel pairs resident in HBM, seeded weights",
+                           "height": H, "width": W, "batch_per_gpu": B, "iters": iters,
+                           "parallelism": (f"dp{world}: batch sharded over ranks, one all-reduce of {nparam * 4} parameter-gradient bytes per step"
+                                           if train else f"replicas x{world}: frames sharded over ranks, no data-path collective"),
+                           "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None},
+                "roofline": {"bound": "mfma", "achieved": round(gflop * B / ms_per_step, 2), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(gflop * B / ms_per_step / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+                             "kernel": "whole step (direct-algorithm FLOPs of the model over the step time; per-kernel tables: profiles/)"},
+                "cpu_baseline": None}
+        if train:
+            line.update({"allreduce_us": round(ar_us, 1), "allreduce_bytes": nparam * 4, "final_loss": float(last["loss"])})
+        print(json.dumps(line), flush=True)
+    parallel.barrier(dev)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: this process - which has not touched the GPU (importing torch
     and counting devices do not initialise it) - starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py <same
@@ -562,6 +670,8 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: launch with --nproc-per-node {args.gpus}",
               file=sys.stderr, flush=True)
         sys.exit(2)
+    if args.workload == "eraft":
+        return main_eraft(args)
     if args.mode == "train":
         return main_train(args)
     from eemflow_amd import _lib, parallel

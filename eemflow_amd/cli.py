@@ -8,8 +8,9 @@ Same flags and defaults as the reference scripts (`--lr --wd --train_iters --val
 `lasted_ckpt.pth.tar` in it, checkpoint loading with 'module.' stripping.  Added: `--data_root` (the reference hard-wires its own
 repository path), `--save_root`, `--checkpoint`, `--config` (a JSON like the reference's config/a_meshflow.json; its training and
 loader defaults are built in).  Dropped: visualisation, xlsx export, git metadata, nn.DataParallel (one process per GPU:
-launch with torchrun for data parallelism; see eemflow_amd.parallel).  Only the models built here are accepted (EEMFlow; for
-`test` also `eraft` and `EEMFlow+`).
+launch with torchrun for data parallelism; see eemflow_amd.parallel).  Only the models built here are accepted: EEMFlow (trained by
+the fused step inside the library), `eraft` (train_EEMFlow_HREM.py:30-32) and `EEMFlow+` (both trained through the reference's own
+statement sequence on the operator-level autograd route, train_mvsec.py:241-258).
 """
 import argparse
 import copy
@@ -83,13 +84,14 @@ def build_model(name, config, training):
         # out_mesh_size and its loss then meets a full-resolution prediction.  Training here predicts at mesh size
         # (EEMFlow.py:126-132), evaluation at full resolution against the upsampled mesh flow (HREM.py:264-267).
         return EEMFlow(config=config, n_first_channels=5, out_mesh_size=training)
-    if not training and name == "eraft":
+    if name == "eraft":                                             # train_EEMFlow_HREM.py:30-32 / test_EEMFlow_HREM.py
         from .eraft import ERAFT
-        return ERAFT(config=config, n_first_channels=config['data_loader']['test']['args']['num_voxel_bins'])
-    if not training and name in ("EEMFlow+", "EEMFlow_cdc"):
+        split = 'train' if training else 'test'
+        return ERAFT(config=config, n_first_channels=config['data_loader'][split]['args']['num_voxel_bins'])
+    if name in ("EEMFlow+", "EEMFlow_cdc"):
         from .eemflow_plus import EEMFlow_cdc
         return EEMFlow_cdc(config=config, n_first_channels=5)
-    raise SystemExit(f"model '{name}' is not built here (EEMFlow{'' if training else ', eraft, EEMFlow+'})")
+    raise SystemExit(f"model '{name}' is not built here (EEMFlow, eraft, EEMFlow+)")
 
 
 def per_rank_batch(batch_size, world):
@@ -139,24 +141,31 @@ def train(args):
         loader = torch.utils.data.DataLoader(train_set, batch_size=per_rank_batch(args.batch_size, world), shuffle=sampler is None,
                                              sampler=sampler, num_workers=0, drop_last=True)
     model = model.to(dev)
-    if world > 1:                                                    # replicas start from rank 0's weights
+    if parallel.exchange_active():                                   # replicas start from rank 0's weights
         for prm in model.parameters():
             torch.distributed.broadcast(prm.data, src=0)
-        model.invalidate_weights()                                   # .data writes bypass the version counter the model watches
+        if hasattr(model, "invalidate_weights"):
+            model.invalidate_weights()                               # .data writes bypass the version counter the model watches
+        else:
+            from . import ops
+            ops.invalidate_packed_weights()                          # the operator-level models cache packed weights by version too
     tcfg = config["train"]
     # The reference trainer sizes the padder with config['train_img_size'] (train_mvsec.py:67), the size its augmentor crops to.  The
     # HREM training samples here are the un-cropped frames, so the padder is sized from the first batch itself (image_size=None).
+    # EEMFlow: the fused step inside the library; E-RAFT / EEMFlow+: the reference's statement sequence over the operator-level
+    # autograd route (their data-parallel exchange is the flat-gradient all-reduce in TrainRaftEvents._train_iters_autograd)
+    engine = "fused" if args.model_name == "EEMFlow" else "autograd"
     tr = harness.TrainRaftEvents(loader, None, lr=tcfg["lr"], wdecay=tcfg["wdecay"], epsilon=tcfg["epsilon"],
                                  num_steps=tcfg["num_steps"], clip=tcfg["clip"], gamma=tcfg["gamma"], logger=logger,
-                                 start_iteration=start_iteration)
+                                 start_iteration=start_iteration, engine=engine, mixed_precision=tcfg.get("mixed_precision", True))
     for epoch in range(start_epoch, max(args.train_iters // args.val_iters, 1)):
         if sampler is not None:
             sampler.set_epoch(epoch)
         model = tr.train_iters(model, start_epoch=epoch, val_iters=args.val_iters)
         if rank == 0:
-            harness.save_checkpoint(os.path.join(save_path, 'lasted_ckpt.pth.tar'), model, epoch, trainer=tr.trainer)
+            harness.save_checkpoint(os.path.join(save_path, 'lasted_ckpt.pth.tar'), model, epoch, trainer=tr.trainer, iteration=tr.iteration)
     parallel.barrier(dev)
-    LAST_RUN.update(model=model, trainer=tr.trainer, save_path=save_path, rank=rank, world=world)
+    LAST_RUN.update(model=model, trainer=tr.trainer, save_path=save_path, rank=rank, world=world, engine=engine, iteration=tr.iteration)
     return save_path
 
 

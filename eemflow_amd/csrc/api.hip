@@ -441,6 +441,16 @@ extern "C" int eemflow_get_stage(eemflow_ctx* c, const char* name, float* dst, s
     }
     const size_t n = (size_t)dims[0] * dims[1] * dims[2] * dims[3];
     if (dst == nullptr) return EEM_OK;       // size query
+    if (nm == "f13" && c->f13_skipped) {
+        // the last forward pooled f13 in pconv3_3's epilogue and left the map itself unwritten: run that one layer again, with stores
+        // (its input b3 is still in the workspace)
+        EEM_HIP_CHECK(hipSetDevice(c->device));
+        Hook hk;
+        hk.st = (hipStream_t)stream;
+        const int rc = run_enc_layer(c, s, ENC_NUM - 1, nullptr, nullptr, hk, nullptr, nullptr, false);
+        if (rc != EEM_OK) return rc;
+        c->f13_skipped = false;
+    }
     EEM_REQUIRE(cap >= n, "eemflow_get_stage: '%s' needs %zu floats, buffer holds %zu", name, n, cap);
     EEM_HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return EEM_OK;

@@ -135,6 +135,10 @@ struct eemflow_ctx {
     int span_n = 0;
     bool span_pending = false;
     bool skip_counter_zeroed = false;                    // train_api.hip: the device-side count of skipped optimizer steps
+    // inference leaves f13 unwritten when pconv3_3's epilogue pools it (nothing else reads it); the training forward keeps every
+    // activation (keep_stage_stores), and eemflow_get_stage("f13") re-runs the layer with stores when the last forward skipped them
+    bool keep_stage_stores = false;
+    bool f13_skipped = false;
     int frames_in_flight = 1;                            // eemflow_set_frames_in_flight: >= 3 shrinks the persistent encoder grids
     struct Key {
         int batch, in_h, in_w, out_h, out_w, pad[4];
@@ -481,21 +485,13 @@ static int span_mark(eemflow_ctx* c, int i, hipStream_t st) {
     return EEM_OK;
 }
 
-int run_forward_impl(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2, float* out, Hook& hk,
-                     const void* const* io, const float* prepadded);
-int run_forward(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2, float* out, Hook& hk,
-                const void* const* io = nullptr, const float* prepadded = nullptr) {
-    int rc = span_mark(c, 0, hk.st);
-    if (rc == EEM_OK) rc = run_forward_impl(c, s, e1, e2, out, hk, io, prepadded);
-    if (rc == EEM_OK) rc = span_mark(c, 2, hk.st);
-    return rc;
-}
-
-int run_forward_impl(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2, float* out, Hook& hk,
-                     const void* const* io, const float* prepadded) {
+// One encoder layer of the schedule (layer index = position in the chain).  may_skip_store: a layer whose output is read only
+// through its fused pooling partial sums - pconv3_3 in inference - may leave the feature map unwritten (7.9 MB per frame at
+// 1280x720); eemflow_get_stage("f13") then re-runs that one layer with stores.
+int run_enc_layer(eemflow_ctx* c, const Shape& s, int li, const float* e1, const float* e2, Hook& hk, const void* const* io,
+                  const float* prepadded, bool may_skip_store) {
     int rc;
     const int n2 = 2 * s.batch;
-    // ---- encoder (both event volumes as one batch; shared weights, EEMFlow.py:135-140)
     struct Step { int layer; const char* name; const float* in; float* out; int hin, win, hout, wout; };
     const Step steps[ENC_NUM] = {
         {ENC_1_1, "enc.pconv1_1 5->16 s2 +pad", nullptr, c->a1.p, s.hp, s.wp, s.h1, s.w1},
@@ -506,7 +502,9 @@ int run_forward_impl(eemflow_ctx* c, const Shape& s, const float* e1, const floa
         {ENC_3_1, "enc.pconv3_1 32->64 s2", c->f12.p, c->a3.p, s.h2, s.w2, s.h3, s.w3},
         {ENC_3_2, "enc.pconv3_2 64->64", c->a3.p, c->b3.p, s.h3, s.w3, s.h3, s.w3},
         {ENC_3_3, "enc.pconv3_3 64->64", c->b3.p, c->f13.p, s.h3, s.w3, s.h3, s.w3}};
-    for (const Step& sp : steps) {
+    {
+        const Step& sp = steps[li];
+
         EncConvArgs a;
         const EncLayerDesc& d = kEncLayers[sp.layer];
         a.in0 = sp.layer == ENC_1_1 ? e1 : sp.in;
@@ -540,6 +538,7 @@ int run_forward_impl(eemflow_ctx* c, const Shape& s, const float* e1, const floa
         a.pool_partial = nullptr;
         a.pool_k = 0;
         a.io = sp.layer == ENC_1_1 ? io : nullptr;
+        a.no_store = 0;
         // several frames in flight: kernels of different frames time-slice the CUs, so a block's prologue (DMA plan, first tile's
         // landing) is CU time another frame could use - fewer blocks with more tiles each (measured at 1280x720 with four in flight:
         // +3.5 % frames/s, +8 % single-frame latency; the 64-channel layers have one tile per CU and keep the full grid)
@@ -551,6 +550,8 @@ int run_forward_impl(eemflow_ctx* c, const Shape& s, const float* e1, const floa
             if (s.fuse[k] && sp.layer == (k == 0 ? ENC_1_2 : k == 1 ? ENC_2_3 : ENC_3_3)) {
                 a.pool_partial = c->ppart[k].p;
                 a.pool_k = k == 0 ? 32 : k == 1 ? 16 : 8;
+                static const bool keep_f13 = [] { const char* e = getenv("EEM_KEEP_F13"); return e && e[0] == '1'; }();
+                if (k == 2 && may_skip_store && !keep_f13) a.no_store = 1;
             }
         const double opix = (double)n2 * sp.hout * sp.wout;
         const double flops = 2.0 * opix * d.cout * d.cin * 9;
@@ -560,6 +561,27 @@ int run_forward_impl(eemflow_ctx* c, const Shape& s, const float* e1, const floa
                     [&](hipStream_t st) { return enc_conv_launch(d.cin, d.cout, d.stride, a, st); });
         if (rc != EEM_OK) return rc;
     }
+    return EEM_OK;
+}
+
+int run_forward_impl(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2, float* out, Hook& hk,
+                     const void* const* io, const float* prepadded);
+int run_forward(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2, float* out, Hook& hk,
+                const void* const* io = nullptr, const float* prepadded = nullptr) {
+    int rc = span_mark(c, 0, hk.st);
+    if (rc == EEM_OK) rc = run_forward_impl(c, s, e1, e2, out, hk, io, prepadded);
+    if (rc == EEM_OK) rc = span_mark(c, 2, hk.st);
+    return rc;
+}
+
+int run_forward_impl(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2, float* out, Hook& hk,
+                     const void* const* io, const float* prepadded) {
+    int rc;
+    const int n2 = 2 * s.batch;
+    // ---- encoder (both event volumes as one batch; shared weights, EEMFlow.py:135-140)
+    for (int li = 0; li < ENC_NUM; ++li)
+        if ((rc = run_enc_layer(c, s, li, e1, e2, hk, io, prepadded, !c->keep_stage_stores)) != EEM_OK) return rc;
+    c->f13_skipped = !c->keep_stage_stores;
     // ---- stage pooling to the common 1/64 grid (EEMFlow.py:144-154), 53-tap correlation and rconv into the decoders' input
     // [cv | r] (EEMFlow.py:160-163).  Fused form (default): ONE launch whose correlation / rconv blocks read the conv epilogues'
     // pooling partial sums directly and whose extra blocks write the finished pooled maps (tail_fused.hip).  Stages whose conv

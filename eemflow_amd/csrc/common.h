@@ -177,6 +177,9 @@ struct EncConvArgs {
     const float* res = nullptr;
     // the stride-2 layer 16 -> 32 as pre-split bf16 weight fragments (conv_bx3.hip, bx3_transform_launch), or NULL
     const float* wbx3 = nullptr;
+    // a layer whose output is only read through its fused pooling partial sums (pconv3_3 in inference: f13, EEMFlow.py:152-154) may skip
+    // the feature-map stores: a hint - kernels built with a store-free form honour it (the two Winograd forms at C = 64), the others store
+    int no_store = 0;
 };
 // Every launch argument a block uses, wanted in scalar registers at its first instruction: one batch of scalar loads instead of the three or
 // four dependent ones the compiler otherwise spreads over the prologue (see tail_conv_kernel in tail.hip for what a memory round trip costs

@@ -64,7 +64,8 @@ __device__ unsigned long long g_stamps[2048 * 8 * 8];
 #define STAMP(i)
 #endif
 
-template <int C, int TH, int TW, int NGH, int WAVES, bool STREAM, int POOLK>
+// KEEP = false: the pooling partial sums are the launch's only output (EncConvArgs::no_store), no feature-map stores
+template <int C, int TH, int TW, int NGH, int WAVES, bool STREAM, int POOLK, bool KEEP = true>
 __global__ __launch_bounds__(WAVES * 64) void wino32_kernel(EncConvArgs a) {
     ENC_ARGS_NOW(a);
 #ifdef EEM_STAMPS
@@ -75,7 +76,8 @@ __global__ __launch_bounds__(WAVES * 64) void wino32_kernel(EncConvArgs a) {
     using K = W32Cfg<C, TH, TW, NGH, WAVES>;
     constexpr int NWX = POOLK > 0 ? TW / POOLK : 1;
     constexpr int RED = POOLK > 0 ? (TH / 2) * C * NWX : 0;
-    constexpr int NS = 8 + (POOLK > 0 ? 1 : 0);                          // stores per wave and tile
+    constexpr int NS = (KEEP ? 8 : 0) + (POOLK > 0 ? 1 : 0);             // stores per wave and tile
+    static_assert(KEEP || POOLK > 0, "a store-free launch needs the pooling output");
     static_assert((2 * K::STAGE + RED) * 4 <= 160 * 1024, "LDS budget");
     static_assert(POOLK == 0 || (POOLK % TH == 0 && TW % POOLK == 0 && C * NWX <= WAVES * 64), "pool windows");
     __shared__ __attribute__((aligned(16))) float lds[2 * K::STAGE + RED];
@@ -261,7 +263,9 @@ __global__ __launch_bounds__(WAVES * 64) void wino32_kernel(EncConvArgs a) {
                 }
             }
             psum[r] = (y00 + y01) + (y10 + y11);
-            if (full) {
+            if constexpr (!KEEP) {
+                // (no store)
+            } else if (full) {
                 // tile inside the image: a scalar base per (cout register, row) + ONE 32-bit lane offset - no 64-bit vector
                 // arithmetic, no selects
                 char* rb = reinterpret_cast<char*>(dst) + (size_t)r * hw * 4;
@@ -370,7 +374,10 @@ int launch_c(const EncConvArgs& a0, hipStream_t stream) {
         return EEM_ERR_ARG;
     }
     EEM_NOTE_GRID(per_xcd * 8, W::WAVES * 64);
-    if (a.pool_partial != nullptr)
+    if (a.pool_partial != nullptr && a.no_store && C == 64 && a.gate == nullptr)
+        hipLaunchKernelGGL((wino32_kernel<C, W::TH, W::TW, W::NGH, W::WAVES, W::STREAM, W::POOLK, C != 64>), dim3(per_xcd * 8),
+                           dim3(W::WAVES * 64), 0, stream, a);
+    else if (a.pool_partial != nullptr)
         hipLaunchKernelGGL((wino32_kernel<C, W::TH, W::TW, W::NGH, W::WAVES, W::STREAM, W::POOLK>), dim3(per_xcd * 8), dim3(W::WAVES * 64),
                            0, stream, a);
     else

@@ -116,7 +116,8 @@ __device__ unsigned long long g_stamps4[1024 * 8 * 64];
 #define STAMP4(i)
 #endif
 
-// EPI: 0 plain, 1 the result is multiplied by LeakyReLU'(gate) (data gradients), 2 relu(residual + result) (E-RAFT's residual blocks) -
+// EPI: 0 plain, 1 the result is multiplied by LeakyReLU'(gate) (data gradients), 2 relu(residual + result) (E-RAFT's residual blocks),
+// 3 pooling partial sums only, no feature-map stores (pconv3_3 in inference: f13 is read through its pooled map alone) -
 // separate instantiations, so the forward kernels' register allocation (252 of 256 VGPRs, no scratch) does not carry them
 template <int C, int NGX, int NGY, int POOLK, int EPI>
 __global__ __launch_bounds__(512, 2) void wino4_kernel(EncConvArgs a) {
@@ -125,7 +126,8 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(EncConvArgs a) {
     constexpr int R = K::R, NI = K::NI, KS = K::KS;
     constexpr int NWX = POOLK > 0 ? K::TW / POOLK : 1;                   // pooling windows per block tile (x)
     constexpr int RED1 = POOLK > 0 ? NGY * C * NWX : 0;                  // one tile's pooling scratch (floats): [group row][cout][window]
-    constexpr int NSTORE = 16;                                           // feature-map stores per wave and tile
+    constexpr int NSTORE = EPI == 3 ? 0 : 16;                            // feature-map stores per wave and tile
+    static_assert(EPI != 3 || POOLK > 0, "a store-free launch needs the pooling output");
     constexpr int NPOOL = POOLK > 0 ? 1 : 0;
     static_assert((R * K::STAGE + 2 * RED1) * 4 <= 160 * 1024, "LDS budget");
     static_assert(POOLK == 0 || (POOLK % 8 == 0 && K::TW % POOLK == 0 && C * NWX * NGY <= 512 && POOLK <= 32), "pool windows");
@@ -398,7 +400,9 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(EncConvArgs a) {
 #pragma unroll
                 for (int yy = 0; yy < 4; ++yy) {
                     const bool in = inx && oy + yy < a.hout;
-                    if (full) {
+                    if constexpr (EPI == 3) {
+                        // (no store)
+                    } else if (full) {
                         *reinterpret_cast<f32x4*>(rb + lane_bo + (size_t)yy * a.wout * 4) = o[yy];
                     } else {
                         // every lane stores (outside lanes into a scratch page): exactly NSTORE stores per wave and tile
@@ -534,7 +538,9 @@ int launch4_c(const EncConvArgs& a0, hipStream_t stream) {
         eem_set_error("wino4: gate / residual epilogues come without pooling and one at a time");
         return EEM_ERR_ARG;
     }
-    if (a.pool_partial != nullptr)
+    if (a.pool_partial != nullptr && a.no_store && C == 64)
+        hipLaunchKernelGGL((wino4_kernel<C, W::NGX, W::NGY, W::POOLK, (C == 64 ? 3 : 0)>), dim3(per_xcd * 8), dim3(512), 0, stream, a);
+    else if (a.pool_partial != nullptr)
         hipLaunchKernelGGL((wino4_kernel<C, W::NGX, W::NGY, W::POOLK, 0>), dim3(per_xcd * 8), dim3(512), 0, stream, a);
     else if (a.gate != nullptr)
         hipLaunchKernelGGL((wino4_kernel<C, W::NGX, W::NGY, 0, 1>), dim3(per_xcd * 8), dim3(512), 0, stream, a);

@@ -309,7 +309,10 @@ static int forward_train_impl(eemflow_ctx* c, const float* e1, const float* e2, 
     Hook hk;
     hk.st = st;
     static const bool no_prepad = [] { const char* e = getenv("EEM_NO_PREPAD_FWD"); return e && e[0] == '1'; }();
-    if ((rc = run_forward(c, s, e1, e2, flow_out, hk, nullptr, no_prepad ? nullptr : c->padded.p)) != EEM_OK) return rc;
+    c->keep_stage_stores = true;                          // the backward pass reads every activation, f13 included
+    rc = run_forward(c, s, e1, e2, flow_out, hk, nullptr, no_prepad ? nullptr : c->padded.p);
+    c->keep_stage_stores = false;
+    if (rc != EEM_OK) return rc;
     c->have_train_fwd = true;
     c->train_serial += 1;
     c->train_shape = s;

@@ -56,9 +56,10 @@ def load_checkpoint(path, model, map_location="cpu", with_iteration=False):
     return states.get('epoch', 0)
 
 
-def save_checkpoint(path, model, epoch, trainer=None, module_prefix=False):
+def save_checkpoint(path, model, epoch, trainer=None, module_prefix=False, iteration=None):
     """Write the reference's checkpoint layout.  With a trainer, the device-resident weights are synced into the
-    module first and the schedule position is stored under 'iteration' (the reference does not keep it)."""
+    module first and the schedule position is stored under 'iteration' (the reference does not keep it); `iteration` stores the
+    position of a loop that has no fused trainer (the autograd engine)."""
     if trainer is not None:
         trainer.sync_parameters()
     sd = model.state_dict()
@@ -67,6 +68,8 @@ def save_checkpoint(path, model, epoch, trainer=None, module_prefix=False):
     out = {'epoch': epoch, 'state_dict': collections.OrderedDict((k, v.detach().cpu()) for k, v in sd.items())}
     if trainer is not None:
         out['iteration'] = trainer.iteration
+    elif iteration is not None:
+        out['iteration'] = int(iteration)
     torch.save(out, path)
 
 
@@ -191,6 +194,22 @@ class TestRaftEvents:
         return mean_aee / n
 
 
+def _target_like(pred, flow_gt, valid):
+    """HREM's training target is the 16x16 mesh flow (HREM.py:254-255).  A model that predicts at another size (E-RAFT and EEMFlow+
+    at full resolution) is trained against that mesh flow taken to its size the way the dataset's own evaluation branch does it
+    (HREM.py:264-267: bilinear, align_corners=False; valid = finite and non-zero) - the library's resize kernel, not a torch op."""
+    if tuple(flow_gt.shape[-2:]) == tuple(pred.shape[-2:]):
+        return flow_gt, valid
+    from . import _lib
+    b, _, h, w = flow_gt.shape
+    oh, ow = int(pred.shape[-2]), int(pred.shape[-1])
+    src = flow_gt.contiguous()
+    full = torch.empty(b, 2, oh, ow, device=src.device, dtype=torch.float32)
+    _lib.check(_lib.lib().eemflow_upsample_bilinear(src.data_ptr(), full.data_ptr(), 2 * b, h, w, oh, ow, _lib.current_stream_ptr(src.device)))
+    ok = (~torch.isinf(full[:, 0])) & (~torch.isinf(full[:, 1])) & (torch.linalg.norm(full, dim=1) > 0)
+    return full, ok.float()
+
+
 class TrainRaftEvents:
     """Training loop of train_mvsec.py:229-286 (one process per GPU; batches are this rank's shard)."""
 
@@ -234,9 +253,10 @@ class TrainRaftEvents:
             e1 = batch['event_volume_old'].to(dev).float()
             e2 = batch['event_volume_new'].to(dev).float()
             _, flow_list = model(e1, e2)
-            loss, metrics = sequence_loss(flow_list, batch['flow'].to(dev).float(), batch['valid'].to(dev).float(), self.opt["gamma"])
+            flow_gt, valid = _target_like(flow_list[-1], batch['flow'].to(dev).float(), batch['valid'].to(dev).float())
+            loss, metrics = sequence_loss(flow_list, flow_gt, valid, self.opt["gamma"])
             self.scaler.scale(loss).backward()
-            if parallel.env_world()[2] > 1:
+            if parallel.exchange_active():
                 # the still-SCALED gradients are exchanged, then unscaled: an overflow on one rank reaches every rank through the
                 # sum, so all ranks record the same found_inf, skip the same step and keep the same scale
                 params = [p for p in model.parameters() if p.grad is not None]

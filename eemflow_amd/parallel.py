@@ -40,11 +40,18 @@ def local_device_index(local_rank=None):
     return local_rank
 
 
+def force_group():
+    """EEM_DIST_FORCE=1: join a process group even as a job of ONE rank (launched by torch.distributed.run --nproc-per-node=1), so
+    that a 1-GPU box runs the very collectives an 8-GPU job runs - RCCL's library load, the device-bound process group, the
+    all-reduce / broadcast / barrier of the data-parallel step - with itself as the only peer (tests/test_gpu_dp_processes.py)."""
+    return os.environ.get("EEM_DIST_FORCE", "0") not in ("", "0")
+
+
 def init_distributed(backend=None):
-    """Join the process group when launched with WORLD_SIZE > 1; returns (rank, local_rank, world).  Backend: EEM_DIST_BACKEND,
-    else "nccl" (= RCCL) with GPUs ("gloo" when ranks share a GPU, see share_gpu), "gloo" on CPU."""
+    """Join the process group when launched with WORLD_SIZE > 1 (or forced, see force_group); returns (rank, local_rank, world).
+    Backend: EEM_DIST_BACKEND, else "nccl" (= RCCL) with GPUs ("gloo" when ranks share a GPU, see share_gpu), "gloo" on CPU."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or (force_group() and "RANK" in os.environ)) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -58,6 +65,12 @@ def init_distributed(backend=None):
             kwargs["device_id"] = torch.device("cuda", idx)
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
     return rank, local_rank, world
+
+
+def exchange_active():
+    """True when this process takes part in data-path collectives: a process group exists and has more than one rank (or the
+    one-rank group was forced, see force_group)."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_group())
 
 
 def shard_frames(n_frames, rank, world):
@@ -104,14 +117,15 @@ def average_gradients(flat_grad):
     divide by the world size - the mean over the global batch when every rank holds an equal shard, which is
     what the reference's single-process nn.DataParallel computes (train_mvsec.py:215 means over the whole
     scattered batch).  No-op without a process group."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if exchange_active():
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
-        flat_grad.div_(dist.get_world_size())
+        if dist.get_world_size() > 1:
+            flat_grad.div_(dist.get_world_size())
     return flat_grad
 
 
 def broadcast_weights(flat_weights, src=0):
     """Replicas start from rank `src`'s weights (replaces DataParallel's per-step re-broadcast by one at start)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if exchange_active():
         dist.broadcast(flat_weights, src=src)
     return flat_weights

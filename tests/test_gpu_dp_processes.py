@@ -41,12 +41,42 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch_two(args, timeout=600):
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+def launch_two(args, timeout=600, nproc=2, env=None):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), WORKER, *[str(a) for a in args]]
-    r = subprocess.run(cmd, env=child_env(), capture_output=True, text=True, timeout=timeout)
+    r = subprocess.run(cmd, env=env or child_env(), capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return r
+
+
+def test_rccl_process_group_of_one_rank_runs_the_data_parallel_collectives(tmp_path):
+    """backend "nccl" (= RCCL) has to work on this box before an 8-GPU node runs it: ONE rank under torch.distributed.run joins a
+    device-bound RCCL process group (EEM_DIST_BACKEND=nccl, EEM_DIST_FORCE=1, HSA_ENABLE_IPC_MODE_LEGACY=0 as everywhere) and the
+    trainer's step all-reduces its 2.86 MB flat gradient through it; broadcast, barrier(device_ids) and the reporting reductions too.
+    The gradient equals the single-process one bit for bit (SUM over one rank)."""
+    from eemflow_amd import EEMFlow
+    from eemflow_amd.train import EEMFlowTrainer
+    from eemflow_amd.weights import seeded_state_dict, synthetic_gt, synthetic_voxel_pair
+    b, h, w = 2, 260, 346
+    env = child_env(share=False)
+    env["EEM_DIST_BACKEND"] = "nccl"
+    env["EEM_DIST_FORCE"] = "1"
+    launch_two(["rccl1", tmp_path, b, h, w], nproc=1, env=env)
+    r0 = np.load(os.path.join(tmp_path, "rank0.npz"))
+    assert str(r0["backend"]) == "nccl" and int(r0["allreduce_calls"]) == 1 and bool(r0["probe_ok"])
+    assert str(r0["ipc_env"]) == "0" and float(r0["value"]) == 3.5 and float(r0["slowest"]) == 2.0
+    net = EEMFlow("", 5, 5)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(133).items()})
+    net = net.to(DEV).train()
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(131, b, h, w))
+    gt, va = (torch.from_numpy(a).to(DEV) for a in synthetic_gt(132, b, h, w))
+    tr = EEMFlowTrainer(net, lr=1e-3, wdecay=5e-5, epsilon=1e-8, num_steps=20, clip=1.0)
+    loss, _, _ = tr.step(e1, e2, gt, va)
+    g = tr.grad.cpu().numpy()
+    assert abs(float(r0["loss"]) - loss) < 1e-6 * max(1.0, abs(loss))
+    rel = np.linalg.norm(r0["grad"] - g) / np.linalg.norm(g)
+    assert rel < 2e-5, rel                                    # (weight gradients: split-K atomics, order-dependent in the last bits)
 
 
 @pytest.mark.parametrize("b,h,w", [(4, 260, 346), (2, 720, 1280)])
@@ -132,6 +162,63 @@ def test_cli_train_two_processes_equals_single_process(tmp_path, threads):
     assert np.array_equal(w_ck, r0["weights"])
 
 
+def test_cli_train_eraft_two_processes_equals_the_mean_of_per_sample_gradients(tmp_path):
+    """`cli train --model_name eraft -bs 2` (train_EEMFlow_HREM.py:30-32,116-118) under two ranks: the autograd engine's
+    data-parallel branch (harness.TrainRaftEvents._train_iters_autograd: flat all-reduce of the still-scaled gradients) against
+    what it must equal - ONE process that runs each of the two samples as a batch of one (a replica's BatchNorm sees only its own
+    sample, as under nn.DataParallel), averages the two gradients, clips and takes torch's AdamW step."""
+    from eemflow_amd import cli, harness
+    from eemflow_amd.hrem import HREMEventFlow
+    from eemflow_amd.train import sequence_loss
+    root = str(tmp_path)
+    _hrem_train_tree(root)
+    cfg = json.loads(json.dumps(cli.DEFAULT_CONFIG))
+    del cfg["data_loader"]["train"]["args"]["aug_params"]
+    cfg_path = os.path.join(root, "cfg.json")
+    json.dump(cfg, open(cfg_path, "w"))
+    out2 = os.path.join(root, "two")
+    os.makedirs(out2)
+    launch_two(["cli", out2, root, cfg_path, 0, "eraft", 1], timeout=900)
+    r0, r1 = (np.load(os.path.join(out2, f"rank{k}.npz")) for k in (0, 1))
+    assert int(r0["world"]) == 2 and str(r0["engine"]) == "autograd" and str(r0["backend"]) == "gloo"
+    assert int(r0["iteration"]) == 1 and int(r1["iteration"]) == 1
+    assert np.array_equal(r0["params"], r1["params"])                # replicas' PARAMETERS identical (BatchNorm buffers are per replica)
+    run2 = os.path.join(out2, "exp_HREM_meshflow/eraft_dt1/lr0.000100_we0.000010")
+    assert sorted(os.listdir(run2)) == ["config.json", "lasted_ckpt.pth.tar", "train.log"]
+    ck2 = torch.load(os.path.join(run2, "lasted_ckpt.pth.tar"), weights_only=False)
+    assert ck2["iteration"] == 1
+    # the single-process statement of the same step
+    torch.manual_seed(11)
+    model = cli.build_model("eraft", cfg, training=True).to(DEV)
+    tcfg = dict(cfg["data_loader"]["train"]["args"])
+    tcfg.update({'type': 'train', 'event_interval': 'dt1', 'batch_size': 2})
+    ds = HREMEventFlow(args=tcfg, train=True, root=root, device=torch.device(DEV))
+    s0 = ds[0]
+    model.change_imagesize(tuple(int(v) for v in s0['event_volume_old'].shape[-2:]))
+    model.train()
+    p0 = torch.cat([p.detach().reshape(-1).float().cpu() for p in model.parameters()]).numpy()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5, eps=1e-8)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, 1e-4, 1 + 100, pct_start=0.05, cycle_momentum=False, anneal_strategy='linear')
+    opt.zero_grad()
+    for i in range(2):
+        smp = ds[i]
+        e1, e2 = smp['event_volume_old'][None].to(DEV).float(), smp['event_volume_new'][None].to(DEV).float()
+        _, preds = model(e1, e2)
+        gt, va = harness._target_like(preds[-1], smp['flow'][None].to(DEV).float(), smp['valid'][None].to(DEV).float())
+        loss, _ = sequence_loss(preds, gt, va, 0.8)
+        (0.5 * loss).backward()                                      # gradients accumulate: the mean over the two replicas
+    torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+    opt.step()
+    sched.step()
+    p1 = torch.cat([p.detach().reshape(-1).float().cpu() for p in model.parameters()]).numpy()
+    step_ref, step_dp = p1 - p0, r0["params"] - p0
+    assert float(np.abs(step_ref).max()) > 1e-6                      # the step moved the weights
+    # AdamW's first step is lr * sign-like (|m / sqrt(v)| = 1): compare the steps themselves, tolerance in units of that step
+    bad = np.abs(step_dp - step_ref) > 0.05 * np.abs(step_ref).max()
+    assert float(bad.mean()) < 5e-3, float(bad.mean())
+    assert np.linalg.norm(step_dp - step_ref) / np.linalg.norm(step_ref) < 0.05
+
+
 def _bench(args, share, timeout=900):
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *args], env=child_env(share), capture_output=True, text=True,
                        timeout=timeout)
@@ -154,6 +241,24 @@ def test_bench_launches_its_own_ranks():
     assert r.returncode == 0 and line is not None, r.stdout[-2000:] + r.stderr[-3000:]
     assert line["n_gpus"] == 2 and line["allreduce_us"] > 0 and line["allreduce_bytes"] == 714352 * 4
     assert np.isfinite(line["final_loss"]) and line["config"]["parallelism"].startswith("dp2")
+
+
+def test_bench_eraft_workload_two_ranks():
+    """BASELINE configs[4] has an N-rank product path: `bench.py --workload eraft --gpus 2` (inference: replicas; --mode train: the
+    autograd step with one all-reduce of the flat parameter gradient) launches its own ranks and reports n_gpus 2; without the sharing
+    switch it refuses to measure two ranks on one GPU."""
+    small = ["--workload", "eraft", "--height", "128", "--width", "160", "--batch", "2", "--iters", "3", "--steps", "3", "--warmup", "1"]
+    r, line = _bench(["--gpus", "2", *small], share=True)
+    assert r.returncode == 0 and line is not None, r.stdout[-2000:] + r.stderr[-3000:]
+    assert line["n_gpus"] == 2 and line["unit"] == "frames/s" and line["value"] > 0 and "configs[4]" in line["metric"]
+    assert line["config"]["batch_per_gpu"] == 2 and line["config"]["parallelism"].startswith("replicas x2")
+    r, line = _bench(["--gpus", "2", "--mode", "train", *small], share=True)
+    assert r.returncode == 0 and line is not None, r.stdout[-2000:] + r.stderr[-3000:]
+    assert line["n_gpus"] == 2 and line["unit"] == "samples/s" and line["allreduce_us"] > 0 and line["allreduce_bytes"] > 4 * 5e6
+    assert np.isfinite(line["final_loss"]) and line["config"]["parallelism"].startswith("dp2") and line["config"]["backend"] == "gloo"
+    if torch.cuda.device_count() < 2:
+        r, line = _bench(["--gpus", "2", *small], share=False, timeout=300)
+        assert r.returncode != 0 and line is None and "refusing" in r.stderr
 
 
 def test_bench_refuses_more_ranks_than_gpus():

@@ -76,16 +76,21 @@ def test_forward_vs_oracle_ragged(b, h, w):
     assert maxerr(flow, ref) < FLOW_TOL
 
 
-def test_forward_full_size_1280x720():
-    """BASELINE config[1]: 1x5x720x1280, checked directly against the oracle (a few seconds of CPU)."""
+@pytest.mark.parametrize("frames_in_flight", [1, 4])
+def test_forward_full_size_1280x720(frames_in_flight):
+    """BASELINE config[1]: 1x5x720x1280, checked directly against the oracle (a few seconds of CPU) - in the single-frame launch
+    configuration (frames_in_flight = 1, the default) AND in the one bench.py times (frames_in_flight = 4: fewer, longer encoder
+    blocks and the throughput kernels on every stride-1 layer)."""
     h, w = 720, 1280
     net, sd = make_net(21)
+    net.frames_in_flight = frames_in_flight
     net.change_imagesize((h, w))
     e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(22, 1, h, w))
     with torch.no_grad():
         flow = net(e1.to(DEV), e2.to(DEV))[1][0]
         ref, st = O.eemflow_forward(O.to_torch_sd(sd), e1, e2, keep=True)
-    assert maxerr(net.stage("f13")[:1], st["f13"]) < FEAT_TOL
+    for name in ("f11", "f12", "f13"):
+        assert maxerr(net.stage(name)[:1], st[name]) < FEAT_TOL, name
     assert maxerr(flow, ref) < FLOW_TOL
     # EPE against a smooth synthetic ground truth agrees with the oracle's (north star: within 1e-3)
     yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)

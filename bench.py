@@ -856,7 +856,7 @@ def main():
         ms_per_step = slowest * 1e3 / args.steps
         # the robust number: the frame's direct-convolution FLOPs at the fp32 MFMA peak (its ceiling with the direct algorithm on that
         # pipe) over the measured time per step of one GPU
-        ceiling_ms = total_gflop * B / (PEAK_MFMA_F32_TFLOPS * 1e3)
+        ceiling_ms = total_gflop / PEAK_MFMA_F32_TFLOPS                    # GFLOP of one step (its whole batch) / (TFLOP/s) = ms
         roof["frame_frac_of_ceiling"] = round(ceiling_ms / ms_per_step, 4)
         roof["frame_ceiling_us"] = round(ceiling_ms * 1e3, 2)
         line = {
@@ -873,7 +873,7 @@ def main():
             "gpu_ms_per_step_hip_events": round(gpu_ms / args.steps, 4),
             "host_enqueue_ms_per_step": round(enqueue_s * 1e3 / args.steps, 4),
             "schedule_sum_us": round(sum_us, 1), "frame_gflop": round(total_gflop, 3),
-            "frame_tflops": round(total_gflop * B / ms_per_step, 2),
+            "frame_tflops": round(total_gflop / ms_per_step, 2),
             "encoder_tflops_in_kernel": round(enc_tflops, 2),
             "kernels": kernels, **extra,
         }

@@ -165,7 +165,8 @@ def train(args):
         if rank == 0:
             harness.save_checkpoint(os.path.join(save_path, 'lasted_ckpt.pth.tar'), model, epoch, trainer=tr.trainer, iteration=tr.iteration)
     parallel.barrier(dev)
-    LAST_RUN.update(model=model, trainer=tr.trainer, save_path=save_path, rank=rank, world=world, engine=engine, iteration=tr.iteration)
+    LAST_RUN.update(model=model, trainer=tr.trainer, save_path=save_path, rank=rank, world=world, engine=engine,
+                    iteration=tr.trainer.iteration if tr.trainer is not None else tr.iteration)
     return save_path
 
 

@@ -59,21 +59,12 @@ __device__ __forceinline__ void split8p(const float (&x)[8], u32x4& p0, u32x4& p
     }
 }
 
-// One MFMA with the B operand (the weights) in accumulation registers: the compiler copies an AGPR-resident operand into a VGPR in
-// front of every use (228 v_accvgpr_read per band of 216 MFMAs) - written as assembly the weights STAY in the 256 AGPRs and the other
-// 256 registers hold everything else.  What the compiler no longer does for these: the wait states between a VALU write of an
-// accumulator and the MFMA that reads it (mfma_fence after the bias initialisation) and between the last MFMA and the epilogue's reads.
-__device__ __forceinline__ void mfma_ab(f32x4& acc, const u32x4& a, const u32x4& b) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
-}
-__device__ __forceinline__ void mfma_fence() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }
-
 // POOL: stage-pooling partial sums [n][cout][ceil(H / 4)][strips * NWX]; KEEP: the feature map is stored
 template <int C, bool POOL, bool KEEP>
 __global__ __launch_bounds__(256, 1) void bx3p_kernel(EncConvArgs a, const u32x4* __restrict__ wq, int seg_bands, int nseg) {
     using K = PCfg<C>;
     constexpr int NG = K::NG, RING = K::RING, COLS = K::COLS, PLANE = K::PLANE, NCO = K::NCO, BROWS = K::BROWS;
-    __shared__ __attribute__((aligned(256))) u32x4 lds[K::LDS_E + 64];   // + a sink for the writes of threads that stage nothing
+    __shared__ __attribute__((aligned(256))) u32x4 lds[K::LDS_E];
     __shared__ float red[POOL ? 4 * 2 * NCO * 64 : 1];                   // pooling: [wave][pixel tile][cout group][lane]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -94,56 +85,7 @@ __global__ __launch_bounds__(256, 1) void bx3p_kernel(EncConvArgs a, const u32x4
     const int qbase = C == 32 ? 0 : wave;                                 // first cout group of this wave
     const int wrow = C == 32 ? wave : 0;                                  // this wave's row inside a band
 
-    // ---- staging: item = (8-channel group cg, row r of the rows being staged, 16-byte column piece q); ring slot = rel % RING,
-    // rel = input row - (yfirst - 1).  Two sets of staging registers: a band issues the loads of the rows of the band AFTER the next
-    // one and converts the set loaded one band earlier - a load has a whole band (1.5 us of MFMAs) to land before its first use.
-    // Every band issues the same eight loads per thread (a thread with nothing to stage, or a piece outside the image, reads the zero
-    // page), so the waits the compiler puts in front of a conversion are COUNTED ones - a load or a store inside a branch makes it wait
-    // for vmcnt(0), i.e. for the loads issued a moment ago - and a value needs no select.
-    const float* src = a.in0 + (size_t)n * C * a.hin * a.win;
-    const size_t cplane = (size_t)a.hin * a.win;
-    f32x4 sv2[2][8];
-    int s_dst2[2] = {0, 0};
-    auto stage_load = [&](auto set_tag, int rel0, int nrows, bool real) __attribute__((always_inline)) {
-        constexpr int SET = decltype(set_tag)::value;
-        const bool act = real && tid < NG * nrows * K::QPR;
-        const int item = act ? tid : 0;
-        const int cg = item / (nrows * K::QPR), rq = item - cg * (nrows * K::QPR);
-        const int r = rq / K::QPR, q = rq - r * K::QPR;
-        const int rel = rel0 + r;
-        const int gy = yfirst - 1 + rel, gx = x0 - 4 + 4 * q;
-        const bool in = act && gy >= 0 && gy < a.hin && gx >= 0 && gx < a.win;   // a piece is inside or outside as a whole (win % 4 == 0)
-        const float* sp = in ? src + ((size_t)(cg * 8) * a.hin + gy) * a.win + gx : a.zero_page;
-        const size_t step = in ? cplane : 0;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sv2[SET][e] = *reinterpret_cast<const f32x4*>(sp + e * step);
-        s_dst2[SET] = act ? (cg * RING + rel % RING) * COLS + 4 * q : K::LDS_E - 2 * NG * PLANE + 4 * (lane & 15);   // (+ piece * NG * PLANE + column)
-    };
-    // a slice of a conversion: channels 2 d, 2 d + 1 of column k -> dword d of the three pieces (11 VALU instructions)
-    u32x4 cp[3];
-    auto convert_pair = [&](auto set_tag, int k, int d) __attribute__((always_inline)) {
-        constexpr int SET = decltype(set_tag)::value;
-        const float xa = sv2[SET][2 * d][k], xb = sv2[SET][2 * d + 1][k];
-        const float ra = xa - __uint_as_float(__float_as_uint(xa) & 0xffff0000u), rb = xb - __uint_as_float(__float_as_uint(xb) & 0xffff0000u);
-        const float sa = ra - __uint_as_float(__float_as_uint(ra) & 0xffff0000u), sb = rb - __uint_as_float(__float_as_uint(rb) & 0xffff0000u);
-        cp[0][d] = __builtin_amdgcn_perm(__float_as_uint(xb), __float_as_uint(xa), 0x07060302u);      // (hi16(xb) << 16) | hi16(xa)
-        cp[1][d] = __builtin_amdgcn_perm(__float_as_uint(rb), __float_as_uint(ra), 0x07060302u);
-        cp[2][d] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
-    };
-    auto convert_write = [&](auto set_tag, int k) __attribute__((always_inline)) {
-        constexpr int SET = decltype(set_tag)::value;
-        lds[s_dst2[SET] + k] = cp[0];
-        lds[NG * PLANE + s_dst2[SET] + k] = cp[1];
-        lds[2 * NG * PLANE + s_dst2[SET] + k] = cp[2];
-    };
-
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, 1>;
-    // the first band's rows first (they come back first), then band 1's new rows, then the weights
-    stage_load(S0{}, 0, K::FIRST_ROWS, true);
-    stage_load(S1{}, BROWS + 2, BROWS, nb > 1);
-
-    // ---- the wave's weight fragments: wq[((s * COG + cog) * 3 + piece) * 64 + lane], kept in AGPRs (mfma_ab)
+    // ---- the wave's weight fragments: wq[((s * COG + cog) * 3 + piece) * 64 + lane]
     u32x4 wv[K::KSTEPS][NCO][3];
     {
         const u32x4* wsrc = wq + lane;
@@ -154,12 +96,60 @@ __global__ __launch_bounds__(256, 1) void bx3p_kernel(EncConvArgs a, const u32x4
 #pragma unroll
                 for (int p = 0; p < 3; ++p) wv[s][q][p] = wsrc[((s * K::COG + qbase + q) * 3 + p) * 64];
     }
+
+    // ---- staging: item = (8-channel group cg, row r of the rows being staged, 16-byte column piece q); ring slot = rel % RING,
+    // rel = input row - (yfirst - 1)
+    const float* src = a.in0 + (size_t)n * C * a.hin * a.win;
+    const size_t cplane = (size_t)a.hin * a.win;
+    // two sets of staging registers: a band issues the loads of the rows of the band AFTER the next one and converts the set loaded one
+    // band earlier - a load has a whole band (1.5 us of MFMAs) to land before its first use
+    f32x4 sv2[2][8];
+    bool s_in2[2] = {false, false}, s_act2[2] = {false, false};
+    int s_dst2[2] = {0, 0};
+    // (`real` = false: nothing is staged, but the eight loads are issued all the same - from the image's first pixels - so that every band
+    // has the same number of vector-memory operations in flight and the compiler's waits in front of a conversion are COUNTED ones: a
+    // load or a store inside a branch makes it wait for vmcnt(0), i.e. for the loads issued a moment ago for the band after the next)
+    auto stage_load = [&](auto set_tag, int rel0, int nrows, bool real) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_tag)::value;
+        f32x4 (&sv)[8] = sv2[SET];
+        bool& s_in = s_in2[SET];
+        bool& s_act = s_act2[SET];
+        int& s_dst = s_dst2[SET];
+        s_act = real && tid < NG * nrows * K::QPR;
+        const int item = s_act ? tid : 0;
+        const int cg = item / (nrows * K::QPR), rq = item - cg * (nrows * K::QPR);
+        const int r = rq / K::QPR, q = rq - r * K::QPR;
+        const int rel = rel0 + r;
+        const int gy = yfirst - 1 + rel, gx = x0 - 4 + 4 * q;
+        s_in = s_act && gy >= 0 && gy < a.hin && gx >= 0 && gx < a.win;      // a piece is inside or outside as a whole (win % 4 == 0)
+        const float* sp = src + ((size_t)(cg * 8) * a.hin + (s_in ? gy : 0)) * a.win + (s_in ? gx : 0);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+        for (int e = 0; e < 8; ++e) sv[e] = *reinterpret_cast<const f32x4*>(sp + e * cplane);
+        s_dst = (cg * RING + rel % RING) * COLS + 4 * q;                  // + piece * NG * PLANE + column
+    };
+    auto stage_convert = [&](auto set_tag, int k) __attribute__((always_inline)) {     // column k of the item: 8 channels -> three 16-byte entries
+        constexpr int SET = decltype(set_tag)::value;
+        f32x4 (&sv)[8] = sv2[SET];
+        const bool s_in = s_in2[SET], s_act = s_act2[SET];
+        const int s_dst = s_dst2[SET];
+        float x[8];
 #pragma unroll
-        for (int d = 0; d < 4; ++d) convert_pair(S0{}, k, d);
-        convert_write(S0{}, k);
-    }
+        for (int e = 0; e < 8; ++e) x[e] = s_in ? sv[e][k] : 0.f;
+        u32x4 p0, p1, p2;
+        split8p(x, p0, p1, p2);
+        if (s_act) {
+            lds[s_dst + k] = p0;
+            lds[NG * PLANE + s_dst + k] = p1;
+            lds[2 * NG * PLANE + s_dst + k] = p2;
+        }
+    };
+
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    stage_load(S0{}, 0, K::FIRST_ROWS, true);
+    stage_load(S1{}, BROWS + 2, BROWS, nb > 1);                              // band 1's new rows: in flight during the first conversion
+#pragma unroll
+    for (int k = 0; k < 4; ++k) stage_convert(S0{}, k);
     __syncthreads();
 
     // bias: the lane's cout is (qbase + q) * 16 + m
@@ -182,6 +172,7 @@ __global__ __launch_bounds__(256, 1) void bx3p_kernel(EncConvArgs a, const u32x4
         using SL = std::integral_constant<int, PAR>;
         using SC = std::integral_constant<int, PAR ^ 1>;
         const int relb = b * BROWS;                                         // rel of the band's first input row (output row - 1)
+        const bool more = b + 1 < nb;
         stage_load(SL{}, relb + 2 * BROWS + 2, BROWS, b + 2 < nb);
         // A-fragment addresses of the three filter rows
         unsigned abase[3];
@@ -206,34 +197,23 @@ __global__ __launch_bounds__(256, 1) void bx3p_kernel(EncConvArgs a, const u32x4
         };
         u32x4 av[2][2][3];
         read_a(0, av[0]);
-        mfma_fence();                                                        // (the accumulators' VALU writes, before the first MFMA reads them)
-        // The conversion of the staged rows rides between the MFMAs, a pair-slice (11 VALU instructions) after every STRIDE-th MFMA group
-        // (a group = one piece product of every pixel tile and cout group: 4 MFMAs at C = 32, 2 at C = 64, 16 cycles each, of which an
-        // MFMA holds the vector issue port for 8): pinned by sched_barrier - left to the scheduler the 180 instructions form one block
-        // behind which the matrix pipe runs dry.
-        constexpr int G0 = 2, STRIDE = C == 32 ? 3 : 6;
 #pragma unroll
         for (int s = 0; s < K::KSTEPS; ++s) {
             const int cur = s & 1;
             if (s + 1 < K::KSTEPS) read_a(s + 1, av[cur ^ 1]);
-            __builtin_amdgcn_sched_barrier(0);
+            // the staged rows: one column (a quarter of the item) per k-step from the second on
+            constexpr int CONV0 = 1;
+            if (s >= CONV0 && s < CONV0 + 4) stage_convert(SC{}, s - CONV0);   // (a set that holds nothing writes nothing: s_act)
 #pragma unroll
             for (int i = 0; i < 6; ++i) {                                    // small terms first
                 constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
                 for (int p = 0; p < 2; ++p)
 #pragma unroll
-                    for (int q = 0; q < NCO; ++q) mfma_ab(acc[p][q], av[cur][p][PA[i]], wv[s][q][PB[i]]);
-                const int g = s * 6 + i - G0;
-                if (g >= 0 && g % STRIDE == 0 && g / STRIDE < 16) {
-                    const int j = g / STRIDE;                                // slice j: column j / 4, pair j % 4
-                    convert_pair(SC{}, j >> 2, j & 3);
-                    if ((j & 3) == 3) convert_write(SC{}, j >> 2);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                    for (int q = 0; q < NCO; ++q)
+                        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(av[cur][p][PA[i]]), as_bf(wv[s][q][PB[i]]), acc[p][q], 0, 0, 0);
             }
         }
-        mfma_fence();                                                        // (the last MFMAs' results, before the epilogue reads them)
 
         // ---- epilogue: LeakyReLU, 16-byte NCHW stores (lane = cout m of group q, pixels x0 + 16 p + 4 kg .. + 3), pooling sums
         const int y = yfirst + relb + wrow;
@@ -272,27 +252,25 @@ __global__ __launch_bounds__(256, 1) void bx3p_kernel(EncConvArgs a, const u32x4
             if (flush) {
                 // outputs of the block: C = 32: 32 couts x 2 windows; C = 64: 64 couts x 4 windows (window = 8 pixels = two lane groups)
                 constexpr int NOUT = C * K::NWX;
-                const bool pact = tid < NOUT;
-                const int pt = pact ? tid : 0;
-                const int co = pt / K::NWX, wx = pt - co * K::NWX;
-                float sum = 0.f;
-                if (C == 32) {
-                    const int q = co >> 4, mm = co & 15;                      // window wx = pixel tile wx: the four lane groups, the four waves (rows)
+                if (tid < NOUT) {
+                    const int co = tid / K::NWX, wx = tid - co * K::NWX;
+                    float s = 0.f;
+                    if (C == 32) {
+                        const int q = co >> 4, mm = co & 15;                  // window wx = pixel tile wx: the four lane groups, the four waves (rows)
 #pragma unroll
-                    for (int wv_ = 0; wv_ < 4; ++wv_)
+                        for (int wv_ = 0; wv_ < 4; ++wv_)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) sum += red[((wv_ * 2 + wx) * NCO + q) * 64 + g * 16 + mm];
-                } else {
-                    const int wv_ = co >> 4, mm = co & 15;                    // cout group = wave; window wx = pixel tile wx / 2, lane groups 2 (wx % 2) + {0, 1}
-                    const int p = wx >> 1, g0 = (wx & 1) * 2;
-                    sum = red[((wv_ * 2 + p) * NCO) * 64 + g0 * 16 + mm] + red[((wv_ * 2 + p) * NCO) * 64 + (g0 + 1) * 16 + mm];
+                            for (int g = 0; g < 4; ++g) s += red[((wv_ * 2 + wx) * NCO + q) * 64 + g * 16 + mm];
+                    } else {
+                        const int wv_ = co >> 4, mm = co & 15;                // cout group = wave; window wx = pixel tile wx / 2, lane groups 2 (wx % 2) + {0, 1}
+                        const int p = wx >> 1, g0 = (wx & 1) * 2;
+                        s = red[((wv_ * 2 + p) * NCO) * 64 + g0 * 16 + mm] + red[((wv_ * 2 + p) * NCO) * 64 + (g0 + 1) * 16 + mm];
+                    }
+                    const int prow = (H + K::PROWS - 1) / K::PROWS;
+                    const int py = (yfirst + relb) / K::PROWS;
+                    if (py < prow && x0 + wx * K::POOLK < W)
+                        a.pool_partial[(((size_t)n * C + co) * prow + py) * (strips * K::NWX) + strip * K::NWX + wx] = s;
                 }
-                const int prow = (H + K::PROWS - 1) / K::PROWS;
-                const int py = (yfirst + relb) / K::PROWS;
-                float* pp = (pact && py < prow && x0 + wx * K::POOLK < W)
-                                ? a.pool_partial + (((size_t)n * C + co) * prow + py) * (strips * K::NWX) + strip * K::NWX + wx
-                                : a.trash + lane * 4;
-                *pp = sum;                                                     // (every thread stores: a fixed count, see above)
             }
         }
         __syncthreads();                                                       // the band's rows are read, the next band's rows are written

@@ -106,22 +106,19 @@ __global__ __launch_bounds__(256, 1) void bx3p_kernel(EncConvArgs a, const u32x4
     f32x4 sv2[2][8];
     bool s_in2[2] = {false, false}, s_act2[2] = {false, false};
     int s_dst2[2] = {0, 0};
-    // (`real` = false: nothing is staged, but the eight loads are issued all the same - from the image's first pixels - so that every band
-    // has the same number of vector-memory operations in flight and the compiler's waits in front of a conversion are COUNTED ones: a
-    // load or a store inside a branch makes it wait for vmcnt(0), i.e. for the loads issued a moment ago for the band after the next)
-    auto stage_load = [&](auto set_tag, int rel0, int nrows, bool real) __attribute__((always_inline)) {
+    auto stage_load = [&](auto set_tag, int rel0, int nrows) __attribute__((always_inline)) {
         constexpr int SET = decltype(set_tag)::value;
         f32x4 (&sv)[8] = sv2[SET];
         bool& s_in = s_in2[SET];
         bool& s_act = s_act2[SET];
         int& s_dst = s_dst2[SET];
-        s_act = real && tid < NG * nrows * K::QPR;
+        s_act = tid < NG * nrows * K::QPR;
         const int item = s_act ? tid : 0;
         const int cg = item / (nrows * K::QPR), rq = item - cg * (nrows * K::QPR);
         const int r = rq / K::QPR, q = rq - r * K::QPR;
         const int rel = rel0 + r;
         const int gy = yfirst - 1 + rel, gx = x0 - 4 + 4 * q;
-        s_in = s_act && gy >= 0 && gy < a.hin && gx >= 0 && gx < a.win;      // a piece is inside or outside as a whole (win % 4 == 0)
+        s_in = gy >= 0 && gy < a.hin && gx >= 0 && gx < a.win;               // a piece is inside or outside as a whole (win % 4 == 0)
         const float* sp = src + ((size_t)(cg * 8) * a.hin + (s_in ? gy : 0)) * a.win + (s_in ? gx : 0);
 #pragma unroll
         for (int e = 0; e < 8; ++e) sv[e] = *reinterpret_cast<const f32x4*>(sp + e * cplane);
@@ -146,8 +143,8 @@ __global__ __launch_bounds__(256, 1) void bx3p_kernel(EncConvArgs a, const u32x4
 
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
-    stage_load(S0{}, 0, K::FIRST_ROWS, true);
-    stage_load(S1{}, BROWS + 2, BROWS, nb > 1);                              // band 1's new rows: in flight during the first conversion
+    stage_load(S0{}, 0, K::FIRST_ROWS);
+    if (nb > 1) stage_load(S1{}, BROWS + 2, BROWS);                          // band 1's new rows: in flight during the first conversion
 #pragma unroll
     for (int k = 0; k < 4; ++k) stage_convert(S0{}, k);
     __syncthreads();
@@ -173,7 +170,7 @@ __global__ __launch_bounds__(256, 1) void bx3p_kernel(EncConvArgs a, const u32x4
         using SC = std::integral_constant<int, PAR ^ 1>;
         const int relb = b * BROWS;                                         // rel of the band's first input row (output row - 1)
         const bool more = b + 1 < nb;
-        stage_load(SL{}, relb + 2 * BROWS + 2, BROWS, b + 2 < nb);
+        if (b + 2 < nb) stage_load(SL{}, relb + 2 * BROWS + 2, BROWS);
         // A-fragment addresses of the three filter rows
         unsigned abase[3];
 #pragma unroll
@@ -203,7 +200,7 @@ __global__ __launch_bounds__(256, 1) void bx3p_kernel(EncConvArgs a, const u32x4
             if (s + 1 < K::KSTEPS) read_a(s + 1, av[cur ^ 1]);
             // the staged rows: one column (a quarter of the item) per k-step from the second on
             constexpr int CONV0 = 1;
-            if (s >= CONV0 && s < CONV0 + 4) stage_convert(SC{}, s - CONV0);   // (a set that holds nothing writes nothing: s_act)
+            if (more && s >= CONV0 && s < CONV0 + 4) stage_convert(SC{}, s - CONV0);
 #pragma unroll
             for (int i = 0; i < 6; ++i) {                                    // small terms first
                 constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
@@ -229,10 +226,7 @@ __global__ __launch_bounds__(256, 1) void bx3p_kernel(EncConvArgs a, const u32x4
                     for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.1f * v[j]);
                 }
                 const bool in = yin && x < W;                                 // widths are multiples of 4: a quad is in or out
-                if (KEEP) {                                                   // every lane stores (outside lanes into the scratch page): a fixed count
-                    float* sp = in ? dst + ((size_t)((qbase + q) * 16 + m) * H + y) * W + x : a.trash + lane * 4;
-                    *reinterpret_cast<f32x4*>(sp) = v;
-                }
+                if (KEEP && in) *reinterpret_cast<f32x4*>(dst + ((size_t)((qbase + q) * 16 + m) * H + y) * W + x) = v;
                 if (POOL) psum[p][q] += in ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f;
             }
         }

@@ -101,17 +101,10 @@ __global__ __launch_bounds__(256, 1) void bx3p_kernel(EncConvArgs a, const u32x4
     // rel = input row - (yfirst - 1)
     const float* src = a.in0 + (size_t)n * C * a.hin * a.win;
     const size_t cplane = (size_t)a.hin * a.win;
-    // two sets of staging registers: a band issues the loads of the rows of the band AFTER the next one and converts the set loaded one
-    // band earlier - a load has a whole band (1.5 us of MFMAs) to land before its first use
-    f32x4 sv2[2][8];
-    bool s_in2[2] = {false, false}, s_act2[2] = {false, false};
-    int s_dst2[2] = {0, 0};
-    auto stage_load = [&](auto set_tag, int rel0, int nrows) __attribute__((always_inline)) {
-        constexpr int SET = decltype(set_tag)::value;
-        f32x4 (&sv)[8] = sv2[SET];
-        bool& s_in = s_in2[SET];
-        bool& s_act = s_act2[SET];
-        int& s_dst = s_dst2[SET];
+    f32x4 sv[8];
+    bool s_in = false, s_act = false;
+    int s_dst = 0;
+    auto stage_load = [&](int rel0, int nrows) __attribute__((always_inline)) {
         s_act = tid < NG * nrows * K::QPR;
         const int item = s_act ? tid : 0;
         const int cg = item / (nrows * K::QPR), rq = item - cg * (nrows * K::QPR);
@@ -124,11 +117,7 @@ __global__ __launch_bounds__(256, 1) void bx3p_kernel(EncConvArgs a, const u32x4
         for (int e = 0; e < 8; ++e) sv[e] = *reinterpret_cast<const f32x4*>(sp + e * cplane);
         s_dst = (cg * RING + rel % RING) * COLS + 4 * q;                  // + piece * NG * PLANE + column
     };
-    auto stage_convert = [&](auto set_tag, int k) __attribute__((always_inline)) {     // column k of the item: 8 channels -> three 16-byte entries
-        constexpr int SET = decltype(set_tag)::value;
-        f32x4 (&sv)[8] = sv2[SET];
-        const bool s_in = s_in2[SET], s_act = s_act2[SET];
-        const int s_dst = s_dst2[SET];
+    auto stage_convert = [&](int k) __attribute__((always_inline)) {     // column k of the item: 8 channels -> three 16-byte entries
         float x[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = s_in ? sv[e][k] : 0.f;
@@ -141,12 +130,9 @@ __global__ __launch_bounds__(256, 1) void bx3p_kernel(EncConvArgs a, const u32x4
         }
     };
 
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, 1>;
-    stage_load(S0{}, 0, K::FIRST_ROWS);
-    if (nb > 1) stage_load(S1{}, BROWS + 2, BROWS);                          // band 1's new rows: in flight during the first conversion
+    stage_load(0, K::FIRST_ROWS);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) stage_convert(S0{}, k);
+    for (int k = 0; k < 4; ++k) stage_convert(k);
     __syncthreads();
 
     // bias: the lane's cout is (qbase + q) * 16 + m
@@ -163,14 +149,11 @@ __global__ __launch_bounds__(256, 1) void bx3p_kernel(EncConvArgs a, const u32x4
 #pragma unroll
         for (int q = 0; q < NCO; ++q) psum[p][q] = 0.f;
 
-    // one band; PAR = b % 2: band b converts the set PAR ^ 1 (loaded during band b - 1, band b + 1's new rows) and loads band b + 2's into set PAR
-    auto band = [&](auto par_tag, int b) __attribute__((always_inline)) {
-        constexpr int PAR = decltype(par_tag)::value;
-        using SL = std::integral_constant<int, PAR>;
-        using SC = std::integral_constant<int, PAR ^ 1>;
+    for (int b = 0; b < nb; ++b) {
         const int relb = b * BROWS;                                         // rel of the band's first input row (output row - 1)
+        // the next band's new rows: loads in flight now, converted in the middle of this band's k-loop
         const bool more = b + 1 < nb;
-        if (b + 2 < nb) stage_load(SL{}, relb + 2 * BROWS + 2, BROWS);
+        if (more) stage_load(relb + BROWS + 2, BROWS);
         // A-fragment addresses of the three filter rows
         unsigned abase[3];
 #pragma unroll
@@ -200,7 +183,7 @@ __global__ __launch_bounds__(256, 1) void bx3p_kernel(EncConvArgs a, const u32x4
             if (s + 1 < K::KSTEPS) read_a(s + 1, av[cur ^ 1]);
             // the staged rows: one column (a quarter of the item) per k-step from the second on
             constexpr int CONV0 = 1;
-            if (more && s >= CONV0 && s < CONV0 + 4) stage_convert(SC{}, s - CONV0);
+            if (more && s >= CONV0 && s < CONV0 + 4) stage_convert(s - CONV0);
 #pragma unroll
             for (int i = 0; i < 6; ++i) {                                    // small terms first
                 constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
@@ -268,10 +251,6 @@ __global__ __launch_bounds__(256, 1) void bx3p_kernel(EncConvArgs a, const u32x4
             }
         }
         __syncthreads();                                                       // the band's rows are read, the next band's rows are written
-    };
-    for (int b = 0; b < nb; b += 2) {
-        band(S0{}, b);
-        if (b + 1 < nb) band(S1{}, b + 1);
     }
 }
 

@@ -141,15 +141,15 @@ __global__ __launch_bounds__(576) void tail_head_kernel(TailHeadArgs a) {
     if (role < 3) {
         const int rows = a.src[role].rows;                                // 16, 32, 64 input channels (EEMFlow.py:96-98)
         if (role == 0) { if (rows == 4) rconv_role<4, 4>(a, 0, blk, part); else if (rows == 1) rconv_role<4, 1>(a, 0, blk, part); else rconv_role<4, 0>(a, 0, blk, part); }
-        else if (role == 1) { if (rows == 2) rconv_role<8, 2>(a, 1, blk, part); else if (rows == 4) rconv_role<8, 4>(a, 1, blk, part); else if (rows == 1) rconv_role<8, 1>(a, 1, blk, part); else rconv_role<8, 0>(a, 1, blk, part); }
-        else { if (rows == 1) rconv_role<16, 1>(a, 2, blk, part); else if (rows == 2) rconv_role<16, 2>(a, 2, blk, part); else rconv_role<16, 0>(a, 2, blk, part); }
+        else if (role == 1) { if (rows == 2) rconv_role<8, 2>(a, 1, blk, part); else if (rows == 1) rconv_role<8, 1>(a, 1, blk, part); else rconv_role<8, 0>(a, 1, blk, part); }
+        else { if (rows == 1) rconv_role<16, 1>(a, 2, blk, part); else rconv_role<16, 0>(a, 2, blk, part); }
         return;
     }
     if (role < 6) {
         const int k = role - 3, rows = a.src[k].rows;
         if (k == 0) { if (rows == 4) corr_role<4, 4>(a, 0); else if (rows == 1) corr_role<4, 1>(a, 0); else corr_role<4, 0>(a, 0); }
-        else if (k == 1) { if (rows == 2) corr_role<8, 2>(a, 1); else if (rows == 4) corr_role<8, 4>(a, 1); else if (rows == 1) corr_role<8, 1>(a, 1); else corr_role<8, 0>(a, 1); }
-        else { if (rows == 1) corr_role<16, 1>(a, 2); else if (rows == 2) corr_role<16, 2>(a, 2); else corr_role<16, 0>(a, 2); }
+        else if (k == 1) { if (rows == 2) corr_role<8, 2>(a, 1); else if (rows == 1) corr_role<8, 1>(a, 1); else corr_role<8, 0>(a, 1); }
+        else { if (rows == 1) corr_role<16, 1>(a, 2); else corr_role<16, 0>(a, 2); }
         return;
     }
     // pooled maps [2B][C][gh][gw] as a side output

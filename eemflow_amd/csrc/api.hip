@@ -219,8 +219,6 @@ extern "C" int eemflow_load_weights(eemflow_ctx* c, const float* flat, size_t nf
         c->use_wino = !(e && atoi(e) == 0);
         const char* e4 = getenv("EEM_WINO4_LAYERS");
         c->f4_mask_env = (e && atoi(e) == 2) ? 0 : (e4 ? atoi(e4) & 7 : -1);
-        const char* ep = getenv("EEM_BX3P");
-        c->bx3p_mask = ep ? atoi(ep) & 3 : 0;
         size_t off = 0;
         for (int l = 0; l < ENC_NUM; ++l) {
             const EncLayerDesc& d = kEncLayers[l];
@@ -234,8 +232,6 @@ extern "C" int eemflow_load_weights(eemflow_ctx* c, const float* flat, size_t nf
             if (c->enc_s2r[l]) { c->s2r_off[l] = off; off += s2r_packed_floats(d.cin, d.cout); }
             c->enc_bx3[l] = bx3_shape(d.cin, d.cout, d.stride);
             if (c->enc_bx3[l]) { c->bx3_off[l] = off; off += bx3_packed_floats(d.cin, d.cout); }
-            c->enc_bx3p[l] = bx3p_shape(d.cin, d.cout, d.stride);
-            if (c->enc_bx3p[l]) { c->bx3p_off[l] = off; off += bx3p_packed_floats(d.cin); }
         }
         if (c->wino) EEM_HIP_CHECK(hipFree(c->wino));
         c->wino = nullptr;

@@ -72,13 +72,6 @@ struct eemflow_ctx {
     size_t bx3_off[ENC_NUM];           // pconv2_1's weights as pre-split bf16 fragments (conv_bx3.hip; same buffer, same lazy refresh)
     bool bx3_ok[ENC_NUM] = {};
     bool enc_bx3[ENC_NUM] = {};
-    // the stride-1 layers at 32 / 64 channels as persistent direct convolutions on the bf16 pipe (conv_bx3p.hip); EEM_BX3P = mask of
-    // channel widths (1: C = 32, 2: C = 64) that run it; the others stay on the Winograd kernels
-    size_t bx3p_off[ENC_NUM];
-    bool bx3p_ok[ENC_NUM] = {};
-    bool enc_bx3p[ENC_NUM] = {};
-    int bx3p_mask = 0;
-    bool layer_bx3p(int l) const { return enc_bx3p[l] && ((bx3p_mask >> (kEncLayers[l].cin == 32 ? 0 : 1)) & 1); }
     bool enc_wino[ENC_NUM];
     bool use_wino = true;              // EEM_WINO=0 in the environment keeps the direct-convolution kernels
     // which stride-1 layers run F(4x4,3x3), by channel count (bit 0: C = 16, 1: C = 32, 2: C = 64).  F(4x4) blocks are 8 waves on 16 x
@@ -194,16 +187,6 @@ int refresh_wino(eemflow_ctx* c, hipStream_t) {
         for (int l = 0; l < ENC_NUM; ++l) c->wino_ok[f][l] = false;
     for (int l = 0; l < ENC_NUM; ++l) c->s2r_ok[l] = false;
     for (int l = 0; l < ENC_NUM; ++l) c->bx3_ok[l] = false;
-    for (int l = 0; l < ENC_NUM; ++l) c->bx3p_ok[l] = false;
-    return EEM_OK;
-}
-int ensure_bx3p(eemflow_ctx* c, int l, hipStream_t st, const float** w_out) {
-    if (!c->bx3p_ok[l]) {
-        const int rc = bx3p_transform_launch(c->flat + c->t_enc[l].w, kEncLayers[l].cin, c->wino + c->bx3p_off[l], st);
-        if (rc != EEM_OK) return rc;
-        c->bx3p_ok[l] = true;
-    }
-    *w_out = c->wino + c->bx3p_off[l];
     return EEM_OK;
 }
 int ensure_bx3(eemflow_ctx* c, int l, hipStream_t st, const float** w_out) {
@@ -266,7 +249,6 @@ int ensure_forward_wino(eemflow_ctx* c, int batch, hipStream_t st) {
         const float* ws;
         if (c->enc_s2r[l]) { const int rc = ensure_s2r(c, l, st, &ws); if (rc != EEM_OK) return rc; }
         if (c->enc_bx3[l]) { const int rc = ensure_bx3(c, l, st, &ws); if (rc != EEM_OK) return rc; }
-        if (c->layer_bx3p(l)) { const int rc = ensure_bx3p(c, l, st, &ws); if (rc != EEM_OK) return rc; }
     }
     if (!c->use_wino) return EEM_OK;
     for (int l = 0; l < ENC_NUM; ++l) {
@@ -309,11 +291,9 @@ int compute_shape(eemflow_ctx* c, int batch, int in_h, int in_w, int out_h, int 
         const EncLayerDesc& d = kEncLayers[last[k]];
         int th, tw, pk;
         const bool wino = c->use_wino && c->enc_wino[last[k]] && wino_supported(d.cin, d.cout, d.stride, ws[k]);
-        const bool bx3p = c->layer_bx3p(last[k]) && (ws[k] & 3) == 0;       // (the launch-time test, bx3p_supported, adds nothing a workspace buffer can fail)
-        if (bx3p) bx3p_tile(d.cin, &th, &tw, &pk);
-        else if (wino) wino_tile(d.cin, c->layer_f4(d.cin, batch) ? 1 : 0, &th, &tw, &pk);
+        if (wino) wino_tile(d.cin, c->layer_f4(d.cin, batch) ? 1 : 0, &th, &tw, &pk);
         else enc2_tile(d.cin, d.cout, &th, &tw, &pk);
-        s->fuse[k] = (bx3p || wino || (c->enc_has2[last[k]] && enc2_supported(d.cin, d.cout, d.stride, ws[k]))) && pk == ks[k];
+        s->fuse[k] = (wino || (c->enc_has2[last[k]] && enc2_supported(d.cin, d.cout, d.stride, ws[k]))) && pk == ks[k];
         s->th[k] = th;
         s->prow[k] = ceil_div(hs[k], th);
         s->pcol[k] = ceil_div(ws[k], tw) * (tw / ks[k]);
@@ -538,7 +518,6 @@ int run_enc_layer(eemflow_ctx* c, const Shape& s, int li, const float* e1, const
         if (c->enc_s2r[sp.layer] && (rc = ensure_s2r(c, sp.layer, hk.st, &a.ws2r)) != EEM_OK) return rc;
         a.wbx3 = nullptr;
         if (c->enc_bx3[sp.layer] && (rc = ensure_bx3(c, sp.layer, hk.st, &a.wbx3)) != EEM_OK) return rc;
-        if (c->layer_bx3p(sp.layer) && (rc = ensure_bx3p(c, sp.layer, hk.st, &a.wbx3)) != EEM_OK) return rc;
         a.zero_page = c->zero_page;
         a.trash = c->zero_page + 256;
         a.bias = c->arena + c->enc_b[sp.layer];
@@ -567,9 +546,6 @@ int run_enc_layer(eemflow_ctx* c, const Shape& s, int li, const float* e1, const
         // so it takes the fewest CUs: 32 us on 96 of them)
         static const int kInFlightBlocks[ENC_NUM] = {12, 24, 0, 29, 29, 0, 0, 0};
         a.blocks_per_xcd = c->frames_in_flight >= 3 ? kInFlightBlocks[sp.layer] : 0;
-        // the persistent bf16-piece kernels: a block's prologue loads 55 KB of weights per wave - 120 blocks of twice the rows in flight
-        static const int bx3p_blocks = [] { const char* e = getenv("EEM_BX3P_BLOCKS_PER_XCD"); return e ? atoi(e) : 15; }();
-        if (c->layer_bx3p(sp.layer)) a.blocks_per_xcd = c->frames_in_flight >= 3 ? bx3p_blocks : 0;
         for (int k = 0; k < 3; ++k)
             if (s.fuse[k] && sp.layer == (k == 0 ? ENC_1_2 : k == 1 ? ENC_2_3 : ENC_3_3)) {
                 a.pool_partial = c->ppart[k].p;

@@ -214,14 +214,6 @@ size_t bx3_packed_floats(int cin, int cout);
 int bx3_transform_launch(const float* w, int cin, int cout, float* packed, hipStream_t stream);     // OIHW device weights -> packed
 bool bx3_supported(int cin, int cout, int stride, const EncConvArgs& a);
 int bx3_launch(int cin, int stride, const EncConvArgs& a, hipStream_t stream);
-// the stride-1 layers 32 -> 32 and 64 -> 64 as persistent direct convolutions on the bf16 pipe, weights in registers (conv_bx3p.hip);
-// EncConvArgs::wbx3 holds their fragments (bx3p_transform_launch)
-bool bx3p_shape(int cin, int cout, int stride);
-size_t bx3p_packed_floats(int c);
-int bx3p_transform_launch(const float* w, int c, float* packed, hipStream_t stream);                 // OIHW device weights -> packed
-bool bx3p_supported(int cin, int cout, int stride, const EncConvArgs& a);
-int bx3p_launch(int c, const EncConvArgs& a, hipStream_t stream);
-void bx3p_tile(int c, int* th, int* tw, int* poolk);
 // Winograd F(2x2,3x3) path for the stride-1 C -> C layers (C = 16, 32, 64), conv_wino.hip
 bool wino_supported(int cin, int cout, int stride, int win);
 size_t wino_packed_floats(int c);      // room for either form

@@ -210,6 +210,207 @@ __global__ void bx3_wt_kernel(const float* __restrict__ w, int cin, int cout, un
     for (int p = 0; p < 3; ++p) out[((((size_t)s * 3 + p) * mt_n + mt) * 64 + lane) * 4 + d] = (hi[p] << 16) | lo[p];
 }
 
+// ---- the stride-1 layers pconv2_2 (32 -> 32) and pconv3_2 (64 -> 64) (EEMFlow.py:78,80) in the same arithmetic.  One 4 x 32-pixel tile
+// and all couts per block; a wave = an output row.  Splitting a B operand where it is used costs 44 VALU instructions per six MFMAs and
+// every input value is used by nine taps of up to four rows (measured in that form: 23 us for 32 -> 32 against 22.5 us for F(4x4) on
+// 120 CUs - VALU-bound).  Here the tile is split ONCE, on its way in: a thread loads 8 channels x 4 columns (eight 16-byte global loads),
+// splits the 32 values and writes twelve 16-byte LDS entries [piece][8-channel group][row][column] = 8 bf16; the main loop is three
+// ds_read_b128 for B, 3 MT for A and 6 MT MFMAs per k-step, no VALU.
+// A k-step's weight fragments (3 pieces x MT cout tiles x 1 KB) go L2 -> LDS once per block by LDS-DMA into a ring, one barrier per
+// k-step (through L1 per wave they would be the CU's whole 64 B/clk at 64 -> 64).
+// NOT the default (EEM_BX3_S1 = mask, 1: 32 -> 32, 2: 64 -> 64): correct (tests/test_gpu_parity.py), and at 1280x720 20.3 / 16.7 us
+// per launch against 22.6 / 36.3 us for the F(4x4) kernels - but those run on 120 / 64 CUs (10.6 / 9.1 us of chip time), these hold
+// every CU, and with four frames in flight the frame rate DROPS 3.4 % / 3 % (8 500 -> 8 210 / 8 240).  Where the time goes (launches
+// with parts switched off, 32 -> 32): launch + weight DMA 3.0 us, staging 3, the k loop 9 (two rounds of 2 blocks per CU; 5.8 us of
+// MFMA in all), stores 5.7 - one after the other, because a block's phases only overlap with ONE other block's.  What would pay is
+// the F(4x4) kernels' shape: a persistent block per CU with the weights stationary in LDS and the next tile's staging under this
+// tile's MFMAs (not built).
+//   32 -> 32: four waves, 63 KB of LDS, two blocks per CU (900 blocks at 180 x 320).
+//   64 -> 64: EIGHT waves - two groups of four split the input channels (group kg: channels 32 kg .. 32 kg + 31) and exchange halves
+//   of their partial sums through LDS at the end, each finishing 32 couts; 138 KB of LDS, one block per CU (230 blocks at 90 x 160).
+template <int CIN, int COUT, int KGT>
+struct B1Cfg {
+    static constexpr int TH = 4, NPIX = 32, KG = KGT, WAVES = 4 * KG, THREADS = 64 * WAVES;
+    static constexpr int MT = COUT / 32;
+    static constexpr int NC16 = CIN / 16, NCG = NC16 / KG;          // 16-channel chunks, per group
+    static constexpr int KLOC = 9 * NCG;                            // k-steps of a group
+    static constexpr int NG = CIN / 8;                              // 8-channel groups: one 16-byte entry per pixel, piece and group
+    static constexpr int IN_ROWS = TH + 2, COLS = 40, QPR = COLS / 4;   // columns x0 - 4 .. x0 + 35
+    static constexpr int ITEMS = NG * IN_ROWS * QPR;                // (group, row, 4-column piece): one per thread
+    static constexpr int GPLANE = IN_ROWS * COLS;                   // entries per (piece, group)
+    static constexpr int TILE_U4 = 3 * NG * GPLANE;
+    static constexpr int SLOT_U4 = 3 * MT * 64;                     // 16-byte fragments per k-step
+    static constexpr int NQ = 3 * MT;                               // 1 KB wave-instructions per slot: instruction q comes from row q % 4
+    static constexpr int RING = KG == 1 ? 6 : 4, AHEAD = RING - 1;  // slots; k-steps issued ahead of the one whose MFMAs run
+    static constexpr int LDS_U4 = TILE_U4 + KG * RING * SLOT_U4;
+    static_assert(ITEMS <= THREADS && NC16 % KG == 0 && NQ <= 8 && (KG == 1 || MT == 2), "one staging item per thread; two groups finish one cout tile each");
+    static_assert(KG == 1 || MT * 4 * 64 * 4 <= TILE_U4, "partial-sum exchange fits the dead input tile");
+    static_assert(LDS_U4 * 16 <= 160 * 1024, "LDS");
+};
+
+template <int N>
+__device__ __forceinline__ void bx_wait_vm(int nrow) {            // s_waitcnt vmcnt(nrow * N), nrow in 0..2 (wave-uniform)
+    if (nrow == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * N) : "memory");
+    else if (nrow == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int CIN, int COUT, int KGT>
+__global__ __launch_bounds__((64 * 4 * KGT), (KGT == 1 ? 2 : 1)) void bx3_s1_kernel(EncConvArgs a, const u32x4* __restrict__ wq) {
+    using C = B1Cfg<CIN, COUT, KGT>;
+    __shared__ __attribute__((aligned(16))) u32x4 lds[C::LDS_U4];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = C::KG > 1 ? wave >> 2 : 0, row = wave & 3;
+    ENC_ARGS_NOW(a);
+    const unsigned lid = xcd_logical_block(blockIdx.x, gridDim.x);
+    if (lid >= (unsigned)(a.tiles_x * a.tiles_y * a.nimg)) return;
+    const int bx = lid % a.tiles_x, by = (lid / a.tiles_x) % a.tiles_y;
+    const int n = lid / (a.tiles_x * a.tiles_y);
+    const int j = lane & 31, g = lane >> 5;
+    const int oy0 = by * C::TH, ox0 = bx * C::NPIX;
+
+    // ---- weight ring of this group: local k-step i = tap * NCG + c  ->  global k-step tap * NC16 + kg * NCG + c
+    u32x4* const ring = lds + C::TILE_U4 + kg * C::RING * C::SLOT_U4;
+    const char* const wbase = reinterpret_cast<const char*>(wq) + lane * 16;
+    const int nrow = (C::NQ + 3 - row) / 4;                        // this wave's instructions per slot (wave-uniform)
+    auto issue_a = [&](int i) __attribute__((always_inline)) {
+        const int ic = i < C::KLOC ? i : C::KLOC - 1;              // past the end: a harmless reload into a dead slot keeps the counts uniform
+        const int sg = (ic / C::NCG) * C::NC16 + kg * C::NCG + ic % C::NCG;
+        const char* sp = wbase + (size_t)sg * C::SLOT_U4 * 16;
+        u32x4* slot = ring + (i % C::RING) * C::SLOT_U4;
+        if (row < C::NQ) __builtin_amdgcn_global_load_lds(GLB_PTR(sp + row * 1024), LDS_PTR(slot + row * 64), 16, 0, 0);
+        if (row + 4 < C::NQ) __builtin_amdgcn_global_load_lds(GLB_PTR(sp + (row + 4) * 1024), LDS_PTR(slot + (row + 4) * 64), 16, 0, 0);
+    };
+#pragma unroll
+    for (int i = 0; i < C::AHEAD; ++i) issue_a(i);
+
+    // ---- the input tile, split on its way in: this thread's item = (8-channel group cg, tile row r, 4-column piece q)
+    {
+        const int item = tid < C::ITEMS ? tid : 0;
+        const int cg = item / (C::IN_ROWS * C::QPR), rq = item - cg * (C::IN_ROWS * C::QPR);
+        const int r = rq / C::QPR, q = rq - r * C::QPR;
+        const int gy = oy0 - 1 + r, gx = ox0 - 4 + 4 * q;
+        const bool in = gy >= 0 && gy < a.hin && gx >= 0 && gx < a.win;     // a piece is inside or outside as a whole (win % 4 == 0)
+        const float* sp = a.in0 + ((size_t)(n * CIN + cg * 8) * a.hin + (in ? gy : 0)) * a.win + (in ? gx : 0);
+        f32x4 v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const f32x4*>(sp + (size_t)e * a.hin * a.win);
+        u32x4* dst = lds + (cg * C::IN_ROWS + r) * C::COLS + 4 * q;            // + piece * NG * GPLANE + column
+        if (tid < C::ITEMS) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = in ? v[e][k] : 0.f;
+                u32x4 p0, p1, p2;
+                split8(x, p0, p1, p2);
+                dst[k] = p0;
+                dst[C::NG * C::GPLANE + k] = p1;
+                dst[2 * C::NG * C::GPLANE + k] = p2;
+            }
+        }
+    }
+
+    f32x16 acc[C::MT];
+#pragma unroll
+    for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+    // B operand of local k-step (tap t, chunk c), piece p: entry [p][group 2 (kg NCG + c) + g][row + ky][j + kx + 3]
+    const u32x4* bl = lds + ((kg * C::NCG * 2 + g) * C::IN_ROWS + row) * C::COLS + j + 3;
+    const u32x4* const ring4 = ring + lane;
+    auto read_b = [&](int i, u32x4 (&b)[3]) __attribute__((always_inline)) {
+        const int t = i / C::NCG, c = i % C::NCG;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) b[p] = bl[(p * C::NG + 2 * c) * C::GPLANE + (t / 3) * C::COLS + (t % 3)];
+    };
+    auto read_w = [&](int i, u32x4 (&w)[3][C::MT]) __attribute__((always_inline)) {
+        const u32x4* sl = ring4 + (i % C::RING) * C::SLOT_U4;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int m = 0; m < C::MT; ++m) w[p][m] = sl[(p * C::MT + m) * 64];
+    };
+    // slot 0 has landed and the tile is written (for every wave: barrier); k-step 0's operands
+    bx_wait_vm<C::AHEAD - 1>(nrow);
+    __syncthreads();
+    u32x4 w[2][3][C::MT], b[2][3];
+    read_w(0, w[0]);
+    read_b(0, b[0]);
+#pragma unroll
+    for (int i = 0; i < C::KLOC; ++i) {
+        const int cur = i & 1, nxt = cur ^ 1;
+        // slot i + 1 has landed (k-steps i + 2 .. i + AHEAD - 1 may still fly), for every wave; and every wave has consumed slot i - 1
+        bx_wait_vm<C::AHEAD - 2>(nrow);
+        __builtin_amdgcn_s_barrier();
+        issue_a(i + C::AHEAD);
+        if (i + 1 < C::KLOC) { read_w(i + 1, w[nxt]); read_b(i + 1, b[nxt]); }
+        __builtin_amdgcn_sched_barrier(0);                           // (the next k-step's requests first, then this one's MFMAs)
+#pragma unroll
+        for (int m = 0; m < C::MT; ++m) {                            // small terms first
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w[cur][2][m]), as_bf(b[cur][0]), acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w[cur][1][m]), as_bf(b[cur][1]), acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w[cur][0][m]), as_bf(b[cur][2]), acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w[cur][1][m]), as_bf(b[cur][0]), acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w[cur][0][m]), as_bf(b[cur][1]), acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(w[cur][0][m]), as_bf(b[cur][0]), acc[m], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (the clamped reloads still write LDS)
+
+    const int oy = oy0 + row, ox = ox0 + j;
+    const int hw = a.hout * a.wout;
+    float* dst = a.out + (size_t)n * COUT * hw;
+    if constexpr (C::KG == 2) {
+        // ---- the groups exchange halves: group kg keeps cout tile kg and hands the other one over (the input tile is dead by now)
+        __builtin_amdgcn_s_barrier();
+        f32x16* xch = reinterpret_cast<f32x16*>(lds);               // [group that reads it][row][lane]
+        xch[((1 - kg) * 4 + row) * 64 + lane] = kg == 0 ? acc[1] : acc[0];
+        __syncthreads();
+        f32x16 mine = kg == 0 ? acc[0] : acc[1];
+        const f32x16 other = xch[(kg * 4 + row) * 64 + lane];
+        const int co0 = kg * 32 + 4 * g;
+        if (oy < a.hout && ox < a.wout) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + (r & 3) + 8 * (r >> 2);
+                float v = mine[r] + other[r] + a.bias[co];
+                if (a.act) v = fmaxf(v, 0.1f * v);
+                dst[(size_t)co * hw + oy * a.wout + ox] = v;
+            }
+        }
+    } else {
+        if (oy < a.hout && ox < a.wout) {
+#pragma unroll
+            for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = m * 32 + 4 * g + (r & 3) + 8 * (r >> 2);
+                    float v = acc[m][r] + a.bias[co];
+                    if (a.act) v = fmaxf(v, 0.1f * v);
+                    dst[(size_t)co * hw + oy * a.wout + ox] = v;
+                }
+        }
+    }
+}
+
+template <int CIN, int COUT, int KGT>
+int bx3_s1_launch_t(const EncConvArgs& a0, hipStream_t stream) {
+    using C = B1Cfg<CIN, COUT, KGT>;
+    EncConvArgs a = a0;
+    a.tiles_x = ceil_div(a.wout, C::NPIX);
+    a.tiles_y = ceil_div(a.hout, C::TH);
+    dim3 grid((unsigned)ceil_div(a.tiles_x * a.tiles_y * a.nimg, 8) * 8);
+    EEM_NOTE_GRID(grid.x, C::THREADS);
+    EEM_NOTE_PIPE(1);
+    hipLaunchKernelGGL((bx3_s1_kernel<CIN, COUT, KGT>), grid, dim3(C::THREADS), 0, stream, a, reinterpret_cast<const u32x4*>(a.wbx3));
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
 template <int CIN, int COUT>
 int bx3_launch_t(const EncConvArgs& a0, hipStream_t stream) {
     using C = BxCfg<CIN, COUT>;
@@ -226,7 +427,9 @@ int bx3_launch_t(const EncConvArgs& a0, hipStream_t stream) {
 
 }  // namespace
 
-bool bx3_shape(int cin, int cout, int stride) { return stride == 2 && ((cin == 16 && cout == 32) || (cin == 32 && cout == 64)); }
+bool bx3_shape(int cin, int cout, int stride) {
+    return (stride == 2 && ((cin == 16 && cout == 32) || (cin == 32 && cout == 64))) || (stride == 1 && cin == cout && (cin == 32 || cin == 64));
+}
 
 size_t bx3_packed_floats(int cin, int cout) { return (size_t)9 * (cin / 16) * 3 * (cout / 32) * 64 * 4; }
 
@@ -244,11 +447,18 @@ bool bx3_supported(int cin, int cout, int stride, const EncConvArgs& a) {
         const char* m = getenv("EEM_NO_BX3_64");
         if (m && m[0] == '1') return false;
     }
+    if (stride == 1) {                                    // EEM_BX3_S1 = mask of channel widths: 1 = 32, 2 = 64
+        const char* m = getenv("EEM_BX3_S1");
+        const int mask = m ? atoi(m) : 0;                 // off by default: see the note at bx3_s1_kernel
+        if (!(mask & (cin == 32 ? 1 : 2))) return false;
+    }
     return bx3_shape(cin, cout, stride) && a.wbx3 && a.gate == nullptr && a.pool_partial == nullptr && a.res == nullptr && (a.win & 3) == 0 &&
            (a.act == 0 || a.act == 1) && (((uintptr_t)a.in0) & 15) == 0 && (size_t)cin * a.hin * a.win * 4 < (1u << 31);
 }
 
 int bx3_launch(int cin, int stride, const EncConvArgs& a, hipStream_t stream) {
-    if (cin == 32) return bx3_launch_t<32, 64>(a, stream);
+    if (cin == 64) return bx3_s1_launch_t<64, 64, 2>(a, stream);
+    if (cin == 32 && stride == 2) return bx3_launch_t<32, 64>(a, stream);
+    if (cin == 32) return bx3_s1_launch_t<32, 32, 1>(a, stream);
     return bx3_launch_t<16, 32>(a, stream);
 }

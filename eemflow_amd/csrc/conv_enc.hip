@@ -262,8 +262,7 @@ int enc_conv_launch(int cin, int cout, int stride, const EncConvArgs& a, hipStre
         return EEM_ERR_ARG;
     }
     if (a.ws2r && s2r_supported(cin, cout, stride, a)) return s2r_launch(cin, a, stream);
-    if (a.wbx3 && stride == 1 && bx3p_supported(cin, cout, stride, a)) return bx3p_launch(cin, a, stream);
-    if (a.wbx3 && stride == 2 && bx3_supported(cin, cout, stride, a)) return bx3_launch(cin, stride, a, stream);
+    if (a.wbx3 && bx3_supported(cin, cout, stride, a)) return bx3_launch(cin, stride, a, stream);
     if (a.wwino && wino_supported(cin, cout, stride, a.win)) return wino_launch(cin, a, stream);
     if (a.wpk2 && enc2_supported(cin, cout, stride, a.win)) return enc_conv2_launch(cin, cout, stride, a, stream);
     //                                   CIN COUT S  TH TWT PADIN

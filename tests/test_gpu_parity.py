@@ -197,46 +197,26 @@ def test_bf16_piece_stride2_kernel_equals_the_fp32_one(monkeypatch, b, h, w):
     assert maxerr(flow_b, flow_f) < 2e-5
 
 
-@pytest.mark.parametrize("fif", [1, 4])
-@pytest.mark.parametrize("b,h,w", [(1, 720, 1280), (2, 260, 346), (1, 100, 150), (3, 192, 256)])
-def test_bf16_piece_stride1_kernels_equal_the_winograd_ones(monkeypatch, b, h, w, fif):
-    """pconv2_2 / pconv2_3 (32 -> 32) and pconv3_2 / pconv3_3 (64 -> 64, EEMFlow.py:78-79,81-82) as persistent direct convolutions on the
-    bf16 matrix pipe (conv_bx3p.hip: exact three-piece operands, weights in registers, an LDS ring of input rows, fused stage pooling,
-    f13 unwritten) against the fp32 Winograd kernels (EEM_BX3P = mask of channel widths, read when the weights are loaded: 1 = the
-    32-channel layers, 2 = the 64-channel ones) - stage tensors, pooled maps and flow, in both launch configurations."""
+@pytest.mark.parametrize("b,h,w", [(1, 720, 1280), (2, 260, 346), (1, 100, 150)])
+def test_bf16_piece_stride1_kernels_equal_the_winograd_ones(monkeypatch, b, h, w):
+    """pconv2_2 (32 -> 32) and pconv3_2 (64 -> 64, EEMFlow.py:78,80) as direct convolutions on the bf16 matrix pipe (conv_bx3.hip:
+    weight fragments through an LDS ring; at 64 channels two groups of four waves split the channels) against the F(4x4,3x3) /
+    F(2x2,3x3) fp32 kernels (EEM_BX3_S1=0, read per launch; a mask: 1 = the 32-channel layer, 2 = the 64-channel one)."""
     e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(58, b, h, w))
     outs = []
     for mask in ("3", "0"):
-        monkeypatch.setenv("EEM_BX3P", mask)
+        monkeypatch.setenv("EEM_BX3_S1", mask)
         net, _ = make_net(47, graph=False)
-        net.frames_in_flight = fif
         net.change_imagesize((h, w))
         with torch.no_grad():
             flow = net(e1, e2)[1][0].clone()
-        outs.append([flow] + [net.stage(k).clone() for k in ("b2", "f12", "b3", "f13", "pool_2", "pool_3")])
-    got, ref = outs
-    assert not torch.equal(got[1], ref[1]) and not torch.equal(got[3], ref[3])   # (the switch did switch)
-    for g, r, name in zip(got[1:], ref[1:], ("b2", "f12", "b3", "f13", "pool_2", "pool_3")):      # (Winograd's own error is the larger one)
-        scale = float(r.abs().max())
-        assert scale > 1e-3 and maxerr(g, r) < 3e-5 * max(scale, 1.0), (name, maxerr(g, r), scale)
-    assert maxerr(got[0], ref[0]) < 2e-5
-
-
-@pytest.mark.parametrize("mask", ["1", "2", "3"])
-def test_bf16_piece_stride1_kernels_vs_oracle(monkeypatch, mask):
-    """The same kernels straight against the oracle at 1280x720 (stage tensors 1e-4, flow 1e-4), each width alone and both."""
-    monkeypatch.setenv("EEM_BX3P", mask)
-    h, w = 720, 1280
-    net, sd = make_net(23)
-    net.change_imagesize((h, w))
-    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(24, 1, h, w))
-    with torch.no_grad():
-        flow = net(e1.to(DEV), e2.to(DEV))[1][0]
-        ref, st = O.eemflow_forward(O.to_torch_sd(sd), e1, e2, keep=True)
-    for name in ("f12", "f13"):
-        assert maxerr(net.stage(name)[:1], st[name]) < FEAT_TOL, name
-    assert maxerr(net.stage("pool_2")[:1], st["pool1_2"]) < FEAT_TOL and maxerr(net.stage("pool_3")[:1], st["pool1_3"]) < FEAT_TOL
-    assert maxerr(flow, ref) < FLOW_TOL
+        outs.append((flow, net.stage("b2").clone(), net.stage("b3").clone(), net.stage("f13").clone()))
+    (flow_b, b2_b, b3_b, f13_b), (flow_w, b2_w, b3_w, f13_w) = outs
+    assert not torch.equal(b2_b, b2_w) and not torch.equal(b3_b, b3_w)   # (the switch did switch)
+    for got, ref in ((b2_b, b2_w), (b3_b, b3_w), (f13_b, f13_w)):        # (Winograd's own error is the larger one)
+        scale = float(ref.abs().max())
+        assert scale > 1e-3 and maxerr(got, ref) < 2e-5 * max(scale, 1.0)
+    assert maxerr(flow_b, flow_w) < 2e-5
 
 
 def graph_stats(net):

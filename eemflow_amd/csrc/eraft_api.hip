@@ -27,7 +27,8 @@ int ensure(Buf& b, size_t floats) {
 }
 
 struct Layer {                    // one convolution, weights packed for gconv
-    size_t wpk = 0, wpk16 = 0, wfew = 0, scale = 0, shift = 0;
+    size_t wpk = 0, wpk16 = 0, wpkb = 0, wfew = 0, scale = 0, shift = 0;
+    bool hasb = false;
     size_t wraw = 0, wf4 = 0;      // 64 -> 64 3x3 stride-1 layers: OIHW weights (BatchNorm scale folded in) and their F(4x4,3x3) form
     bool has_scale = false, has16 = false, has_few = false, has_f4 = false;
     int cout = 0, kh = 1, kw = 1, stride = 1, ph = 0, pw = 0;
@@ -117,6 +118,11 @@ void make_layer(Packer& pk, Layer& L, const float* w, const float* bias, int cou
         L.wpk16 = pk.push(gconv16_packed_floats(con, cs, nseg, kh, kw));
         gconv16_pack(wsl, con, cs, nseg, kh, kw, pk.host.data() + L.wpk16);
     }
+    L.hasb = gconvb_shape(con, cs, nseg, kh, kw, stride) && ph == kh / 2 && pw == kw / 2;
+    if (L.hasb) {
+        L.wpkb = pk.push(gconvb_packed_floats(con, cs, nseg, kh, kw));
+        gconvb_pack(wsl, con, cs, nseg, kh, kw, pk.host.data() + L.wpkb);
+    }
     L.has_few = con <= 8 && kh == 3 && kw == 3 && stride == 1 && nseg == 1 && ph == 1 && pw == 1;   // flow head 256 -> 2: gconv.h fewout_*
     if (L.has_few) {
         L.wfew = pk.push(fewout_packed_floats(cin, kh, kw));
@@ -202,6 +208,7 @@ GConvArgs conv_args(const eraft_ctx* c, const Layer& L, int n, int hin, int win,
     a.nseg = L.nseg;
     a.wpk = c->arena + L.wpk;
     a.wpk16 = L.has16 ? c->arena + L.wpk16 : nullptr;
+    a.wpkb = L.hasb ? c->arena + L.wpkb : nullptr;
     a.wfew = L.has_few ? c->arena + L.wfew : nullptr;
     a.zero_page = c->arena + c->zero_off;
     a.scale = L.has_scale ? c->arena + L.scale : nullptr;

@@ -57,6 +57,7 @@ struct GConvArgs {
     int pre_ctotal, pre_coff;
     float* out2;           // GEPI_ZR: [N][out2_ctotal][hout][wout]
     int out2_ctotal, split;
+    const float* wpkb;     // packed by gconvb_pack (pre-split bf16 B fragments, gconvb.hip), or NULL
 };
 
 // number of packed floats / packing for weights [cout][sum(c_s)][kh][kw] read as segments of sizes cs[0..nseg)
@@ -76,3 +77,10 @@ void fewout_pack(const float* w, int cout, int cin, int kh, int kw, float* packe
 bool fewout_supported(const GConvArgs& a);
 int fewout_launch(const GConvArgs& a, hipStream_t stream);
 int gconv16_launch(const GConvArgs& a, hipStream_t stream);
+// the same layers on the bf16 matrix pipe with exact three-piece operands (gconvb.hip): launches that fill the chip with 128-pixel x
+// 64-cout tiles; gconv_launch takes it when a.wpkb is set and the launch qualifies
+bool gconvb_shape(int cout, const int* cs, int nseg, int kh, int kw, int stride);
+size_t gconvb_packed_floats(int cout, const int* cs, int nseg, int kh, int kw);
+void gconvb_pack(const float* w, int cout, const int* cs, int nseg, int kh, int kw, float* packed);
+bool gconvb_supported(const GConvArgs& a);
+int gconvb_launch(const GConvArgs& a, hipStream_t stream);

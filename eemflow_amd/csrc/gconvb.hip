@@ -1,0 +1,404 @@
+// Stride-1 convolutions with 32-channel-aligned inputs (E-RAFT's update block and encoders' residual stacks, EEMFlow+'s decoders: 1x1, 3x3,
+// 1x5, 5x1 kernels, 64..384 -> 32..576 channels, inputs that are the concatenation of up to three tensors) as an implicit GEMM on the
+// bf16 matrix pipe with fp32 results: the three-piece arithmetic of conv_bx3.hip - every fp32 operand = three bf16 pieces that sum to
+// it EXACTLY (8 significand bits each, by truncation), a product = six piece products (a0 b0, a0 b1, a1 b0, a0 b2, a1 b1, a2 b0; the
+// dropped three are below 2^-24 of it) accumulated in fp32 by the MFMA, small terms first.  tools/micro/bf16x3.hip: worst error over
+// K = 144 is 1.8e-7 of sum |a b| against 1.5e-7 for the fp32 MFMA - the same arithmetic, not a reduced precision.
+//
+// Why here: these are direct convolutions with K = 256 .. 3 456 and no cheaper algorithm (1x5, 5x1, 1x1; the 3x3 ones sit beside them in
+// the same loops); gconv16.hip runs them at 0.4-0.55 of the fp32 MFMA's 155 TFLOP/s.  tools/micro/mfma_clock.hip: six
+// v_mfma_f32_16x16x32_bf16 per product sustain 2.1 PFLOP/s / 6 = 350 TFLOP/s of fp32 products with every CU issuing.  What the form
+// costs is operand traffic - a weight is 6 bytes and a 16x16x32 MFMA consumes 2 KB of operands per 16 cycles - so it is built for
+// launches with pixels enough to fill the chip with LARGE tiles (gconvb_supported); smaller ones stay on gconv16.hip.
+//
+//   * block = 4 waves = 8 rows x 16 pixels x 64 couts; wave = (row half, cout half): 4 pixel tiles (rows) x 2 cout groups of 16,
+//     v_mfma_f32_16x16x32_bf16 with M = 16 pixels, N = 16 couts, K = 32 channels: 48 MFMAs per k-step (tap x 32-channel chunk) against
+//     12 A-fragment reads (LDS) and 6 B-fragment loads (global);
+//   * INPUT: the chunk's haloed tile, split once on its way in: a thread loads 8 channels x 4 columns (eight 16-byte loads, one chunk
+//     ahead, out-of-image pieces from the zero page), splits the 32 values between the MFMAs of the current chunk (pinned slices) and
+//     writes twelve 16-byte LDS entries [piece][8-channel group][row][column] = 8 bf16; double-buffered, one barrier per chunk;
+//   * WEIGHTS: pre-split on the host into B fragments [64-cout chunk][32-channel chunk][tap][cout group][piece][lane] (16 bytes),
+//     streamed L2 -> registers through a ring of three k-steps per wave - no LDS, no barrier (28 bytes per clock and CU);
+//   * D: lane = (cout, 4 consecutive pixels): epilogue operands (GRU state and gate, residual, per-pixel addend) and results move as
+//     16-byte loads / stores; every epilogue of gconv16.hip.
+#include "gconv.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 gb_bf(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
+
+template <int KH, int KW>
+struct GBCfg {
+    static constexpr int TH = 8, TW = 16;
+    static constexpr int ROWS = TH + KH - 1;
+    static constexpr int XOFF = KW > 1 ? 4 : 0;                  // staged columns x0 - XOFF .. (16-byte pieces)
+    static constexpr int COLS = TW + 2 * XOFF, QPR = COLS / 4;
+    static constexpr int PLANE = ROWS * COLS;                    // entries per (piece, 8-channel group)
+    static constexpr int STAGE = 3 * 4 * PLANE;                  // entries per chunk buffer
+    static constexpr int ITEMS = 4 * ROWS * QPR;                 // (group, row, piece): one per thread
+    static constexpr int TAPS = KH * KW;
+    static constexpr int PH = KH / 2, PW = KW / 2;
+    static_assert(ITEMS <= 256 && PLANE % 16 == 0, "one staging item per thread; planes are multiples of 256 bytes (ds_read_b128 banks)");
+    static_assert((2 * STAGE + 64) * 16 <= 160 * 1024, "LDS");
+};
+
+__device__ __forceinline__ float gb_act(float v, int act) {
+    switch (act) {
+        case GACT_RELU: return v > 0.f ? v : 0.f;
+        case GACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        case GACT_TANH: return tanhf(v);
+        case GACT_LEAKY: return v > 0.f ? v : 0.1f * v;
+        default: return v;
+    }
+}
+
+template <int KH, int KW>
+__global__ __launch_bounds__(256, 1) void gconvb_kernel(GConvArgs ka, const u32x4* __restrict__ wq, int tiles_x, int nchunks) {
+    // every launch argument the kernel uses, as scalars of its own: closures that reach the argument STRUCT by reference kept a copy of it in
+    // scratch (328 bytes stored and re-read per thread)
+    const int a_hin = ka.hin, a_win = ka.win, a_hout = ka.hout, a_wout = ka.wout, a_cout = ka.cout, a_act = ka.act, a_epi = ka.epi, a_nseg = ka.nseg;
+    const int a_split = ka.split, a_out_ctotal = ka.out_ctotal, a_out_coff = ka.out_coff, a_out2_ctotal = ka.out2_ctotal;
+    const int a_pre_ctotal = ka.pre_ctotal, a_pre_coff = ka.pre_coff, a_e0_ctotal = ka.e0_ctotal, a_e0_coff = ka.e0_coff, a_e1_ctotal = ka.e1_ctotal, a_e1_coff = ka.e1_coff;
+    const float a_out_scale = ka.out_scale;
+    const float* const a_zero_page = ka.zero_page; const float* const a_scale = ka.scale; const float* const a_shift = ka.shift;
+    const float* const a_pre = ka.pre; const float* const a_e0 = ka.e0; const float* const a_e1 = ka.e1;
+    float* const a_out = ka.out; float* const a_out2 = ka.out2;
+    const float* const seg_ptr0 = ka.seg[0].ptr; const float* const seg_ptr1 = ka.seg[1].ptr; const float* const seg_ptr2 = ka.seg[2].ptr;
+    const int seg_c0 = ka.seg[0].c, seg_c1 = ka.seg[1].c, seg_ct0 = ka.seg[0].ctotal, seg_ct1 = ka.seg[1].ctotal, seg_ct2 = ka.seg[2].ctotal;
+    const int seg_co0 = ka.seg[0].coff, seg_co1 = ka.seg[1].coff, seg_co2 = ka.seg[2].coff;
+    using C = GBCfg<KH, KW>;
+    constexpr int PLANE = C::PLANE, COLS = C::COLS, TAPS = C::TAPS;
+    __shared__ __attribute__((aligned(256))) u32x4 lds[2 * C::STAGE + 64];   // two chunk buffers + a sink for threads that stage nothing
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ph = wave & 1, chh = wave >> 1;                    // row half, cout half
+    const int m = lane & 15, kg = lane >> 4;
+    const int n = blockIdx.z, cc = blockIdx.y;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int y0 = ty * C::TH, x0 = tx * C::TW;
+    const int hw = a_hin * a_win;
+
+    // ---- weights: fragment (cc, ch, tap, cog, piece) at wq[((((cc * nchunks + ch) * TAPS + tap) * 4 + cog) * 3 + piece) * 64 + lane]
+    const u32x4* wbase = wq + ((size_t)cc * nchunks * TAPS * 4 + chh * 2) * 3 * 64 + lane;
+    u32x4 bw[3][2][3];
+    auto load_b = [&](auto slot_tag, int s) __attribute__((always_inline)) {      // k-step s = ch * TAPS + tap (clamped past the end: a harmless reload)
+        constexpr int SL = decltype(slot_tag)::value;
+        const int sc = s < nchunks * TAPS ? s : nchunks * TAPS - 1;
+        const u32x4* p = wbase + (size_t)sc * (4 * 3 * 64);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) bw[SL][q][pc] = p[(q * 3 + pc) * 64];
+    };
+
+    // ---- input staging: item = (8-channel group cg of the chunk, tile row r, 16-byte column piece q)
+    const float* sp0 = seg_ptr0 + ((size_t)n * seg_ct0 + seg_co0) * hw;
+    const float* sp1 = a_nseg > 1 ? seg_ptr1 + ((size_t)n * seg_ct1 + seg_co1) * hw : nullptr;
+    const float* sp2 = a_nseg > 2 ? seg_ptr2 + ((size_t)n * seg_ct2 + seg_co2) * hw : nullptr;
+    const int sc0 = seg_c0, sc1 = a_nseg > 1 ? seg_c1 : 0;
+    const bool s_act = tid < C::ITEMS;
+    const int item = s_act ? tid : 0;
+    const int s_cg = item / (C::ROWS * C::QPR), s_rq = item - s_cg * (C::ROWS * C::QPR);
+    const int s_r = s_rq / C::QPR, s_q = s_rq - s_r * C::QPR;
+    const int s_gy = y0 - C::PH + s_r, s_gx = x0 - C::XOFF + 4 * s_q;
+    const bool s_in = s_act && s_gy >= 0 && s_gy < a_hin && s_gx >= 0 && s_gx < a_win;      // a piece is inside or outside as a whole (win % 4 == 0)
+    const size_t s_off = s_in ? (size_t)(s_cg * 8) * hw + (size_t)s_gy * a_win + s_gx : 0;
+    const size_t s_step = s_in ? (size_t)hw : 0;
+    const int s_dst = s_act ? (s_cg * C::ROWS + s_r) * COLS + 4 * s_q : 2 * C::STAGE - 2 * 4 * PLANE + 4 * (lane & 15);   // (+ piece * 4 * PLANE + column; + buffer)
+    f32x4 sv[8];
+    auto stage_load = [&](int ch) __attribute__((always_inline)) {          // (past the last chunk: the first one again, never converted)
+        const int c0 = (ch < nchunks ? ch : 0) * 32, c1 = c0 - sc0, c2 = c1 - sc1;
+        // (the three bases pass through an empty asm: the compiler otherwise folds the selects into ONE load at a selected offset of
+        // the closure that holds them by reference - an indexed read that keeps every captured variable, the staging registers
+        // included, in scratch)
+        const float *q0 = sp0, *q1 = sp1, *q2 = sp2;
+        asm volatile("" : "+s"(q0), "+s"(q1), "+s"(q2));
+        const float* b = c0 < sc0 ? q0 : (c1 < sc1 ? q1 : q2);
+        const int cb = c0 < sc0 ? c0 : (c1 < sc1 ? c1 : c2);
+        const float* sp = s_in ? b + (size_t)cb * hw + s_off : a_zero_page;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sv[e] = *reinterpret_cast<const f32x4*>(sp + e * s_step);
+    };
+    u32x4 cp[3];
+    auto convert_pair = [&](int k, int d) __attribute__((always_inline)) {   // channels 2 d, 2 d + 1 of column k -> dword d of the three pieces
+        const float xa = sv[2 * d][k], xb = sv[2 * d + 1][k];
+        const float ra = xa - __uint_as_float(__float_as_uint(xa) & 0xffff0000u), rb = xb - __uint_as_float(__float_as_uint(xb) & 0xffff0000u);
+        const float sa = ra - __uint_as_float(__float_as_uint(ra) & 0xffff0000u), sb = rb - __uint_as_float(__float_as_uint(rb) & 0xffff0000u);
+        cp[0][d] = __builtin_amdgcn_perm(__float_as_uint(xb), __float_as_uint(xa), 0x07060302u);      // (hi16(xb) << 16) | hi16(xa)
+        cp[1][d] = __builtin_amdgcn_perm(__float_as_uint(rb), __float_as_uint(ra), 0x07060302u);
+        cp[2][d] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
+    };
+    auto convert_write = [&](int buf, int k) __attribute__((always_inline)) {
+        u32x4* d = lds + (s_act ? buf * C::STAGE : 0) + s_dst + k;
+        d[0] = cp[0];
+        d[4 * PLANE] = cp[1];
+        d[2 * 4 * PLANE] = cp[2];
+    };
+
+    using R0 = std::integral_constant<int, 0>;
+    using R1 = std::integral_constant<int, 1>;
+    using R2 = std::integral_constant<int, 2>;
+    // prologue: chunk 0's tile, the first two k-steps' weights, chunk 1's tile in flight
+    stage_load(0);
+    load_b(R0{}, 0);
+    load_b(R1{}, 1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) convert_pair(k, d);
+        convert_write(0, k);
+    }
+    stage_load(1);
+    __syncthreads();
+
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // A fragment of (tile row p, tap (ky, kx), piece pc): entry ((pc * 4 + kg) * ROWS + 4 ph + p + ky) * COLS + XOFF - PW + kx + m
+    const unsigned a_lane = (unsigned)((kg * C::ROWS + 4 * ph) * COLS + C::XOFF - C::PW + m) * 16u;
+    const char* lb = reinterpret_cast<const char*>(lds);
+
+    // one chunk: TAPS k-steps; RB = ring slot of its first k-step.  The conversion of the next chunk's tile rides between the MFMAs:
+    // 16 pair-slices (11 VALU instructions each) + 4 x 3 LDS writes, one slice after every STRIDE-th group of 8 MFMAs, pinned by
+    // sched_barrier (left to the scheduler they form one block behind which the matrix pipe runs dry).
+    auto chunk = [&](auto rb_tag, int ch) __attribute__((always_inline)) {
+        constexpr int RB = decltype(rb_tag)::value;
+        const unsigned abuf = a_lane + (unsigned)((ch & 1) * C::STAGE) * 16u;
+        const int nbuf = (ch + 1) & 1;
+        const bool more = ch + 1 < nchunks;
+        auto read_a = [&](int t, u32x4 (&av)[4][3]) __attribute__((always_inline)) {
+            const int ky = t / KW, kx = t % KW;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+                    av[p][pc] = *reinterpret_cast<const u32x4*>(lb + abuf + ((pc * 4 * PLANE) + (p + ky) * COLS + kx) * 16);
+        };
+        u32x4 av[2][4][3];
+        read_a(0, av[0]);
+        constexpr int NGRP = TAPS * 6;                                       // MFMA groups of 8 (one piece product of every tile and cout group)
+        constexpr int STRIDE = NGRP >= 32 ? NGRP / 16 : 1;                   // 3x3: every 3rd group; 1x5 / 5x1: every group from the 2nd on; 1x1: 16 slices in 6 groups
+        constexpr int PER = NGRP >= 16 ? 1 : (16 + NGRP - 1) / NGRP;         // slices per group
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < TAPS) read_a(t + 1, av[cur ^ 1]);
+            // the weights of the k-step after the next, into the slot the previous k-step has left
+            const int s = ch * TAPS + t;
+            if ((RB + t + 2) % 3 == 0) load_b(R0{}, s + 2);
+            else if ((RB + t + 2) % 3 == 1) load_b(R1{}, s + 2);
+            else load_b(R2{}, s + 2);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {                                    // small terms first
+                constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gb_bf(av[cur][p][PA[i]]), gb_bf(bw[(RB + t) % 3][q][PB[i]]), acc[p][q], 0, 0, 0);
+                const int g = t * 6 + i;
+                if (g % STRIDE == 0) {
+#pragma unroll
+                    for (int r = 0; r < PER; ++r) {
+                        const int slice = (g / STRIDE) * PER + r;            // (compile-time after unrolling: the staging registers are indexed by it)
+                        if (slice < 16) {
+                            convert_pair(slice >> 2, slice & 3);
+                            if ((slice & 3) == 3) convert_write(nbuf, slice >> 2);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        (void)more;
+        stage_load(ch + 2);                                                  // (its registers are free now; lands during the next chunk)
+        __syncthreads();                                                     // this chunk's tile is read, the next one's is written
+    };
+    for (int ch = 0; ch < nchunks; ++ch) {
+        if constexpr (TAPS % 3 == 0) {
+            chunk(R0{}, ch);
+        } else {
+            const int rb = (ch * TAPS) % 3;
+            if (rb == 0) chunk(R0{}, ch);
+            else if (rb == 1) chunk(R1{}, ch);
+            else chunk(R2{}, ch);
+        }
+    }
+
+    // ---- epilogue: lane = cout (2 chh + q) * 16 + m of the block's 64, pixels (y0 + 4 ph + p, x0 + 4 kg .. + 3)
+    const int hwo = a_hout * a_wout;
+    const int x = x0 + 4 * kg;
+    float e_scale[2], e_shift[2];
+    int co[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        co[q] = cc * 64 + (2 * chh + q) * 16 + m;
+        const int cl = min(co[q], a_cout - 1);
+        e_scale[q] = a_scale ? a_scale[cl] : 1.f;
+        e_shift[q] = a_shift ? a_shift[cl] : 0.f;
+    }
+    // operands: 16-byte loads from clamped indices, all of an operand's eight in flight together (a load inside a lane-dependent branch
+    // is followed by the compiler's s_waitcnt vmcnt(0))
+    unsigned ip[4][2];
+    bool ok[4][2];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int y = y0 + 4 * ph + p;
+            ok[p][q] = x < a_wout && y < a_hout && co[q] < a_cout;
+            ip[p][q] = ok[p][q] ? (unsigned)(co[q] * hwo + y * a_wout + x) : 0u;
+        }
+    f32x4 e0v[4][2], e1v[4][2], prv[4][2];
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { e0v[p][q] = z4; e1v[p][q] = z4; prv[p][q] = z4; }
+    if (a_pre) {
+        const float* b = a_pre + ((size_t)n * a_pre_ctotal + a_pre_coff) * hwo;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) prv[p][q] = *reinterpret_cast<const f32x4*>(b + ip[p][q]);
+    }
+    const unsigned zsplit = a_epi == GEPI_ZR ? (unsigned)(a_split * hwo) : 0u;   // GEPI_ZR: e0 is indexed by co - split, from split on
+    if (a_epi != GEPI_PLAIN) {
+        const float* b = a_e0 + ((size_t)n * a_e0_ctotal + a_e0_coff) * hwo;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) e0v[p][q] = *reinterpret_cast<const f32x4*>(b + (ip[p][q] < zsplit ? 0u : ip[p][q] - zsplit));
+    }
+    if (a_epi == GEPI_GRU) {
+        const float* b = a_e1 + ((size_t)n * a_e1_ctotal + a_e1_coff) * hwo;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) e1v[p][q] = *reinterpret_cast<const f32x4*>(b + ip[p][q]);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (!ok[p][q]) continue;
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = acc[p][q][j] * e_scale[q] + e_shift[q] + prv[p][q][j];
+                t = gb_act(t, a_act);
+                if (a_epi == GEPI_MUL) t *= e0v[p][q][j];
+                else if (a_epi == GEPI_GRU) t = (1.f - e1v[p][q][j]) * e0v[p][q][j] + e1v[p][q][j] * t;
+                else if (a_epi == GEPI_ADD_RELU) { t += e0v[p][q][j]; t = t > 0.f ? t : 0.f; }
+                else if (a_epi == GEPI_ADD) t += e0v[p][q][j];
+                else if (a_epi == GEPI_ZR && co[q] >= a_split) t *= e0v[p][q][j];
+                v[j] = t * a_out_scale;
+            }
+            const int y = y0 + 4 * ph + p;
+            const size_t pix = (size_t)y * a_wout + x;
+            // GEPI_ZR: r leaves as r * h, to the second output.  One store through a selected pointer (gconv16.hip's note on two stores)
+            float* d = (a_epi == GEPI_ZR && co[q] >= a_split) ? a_out2 + ((size_t)n * a_out2_ctotal + (co[q] - a_split)) * hwo + pix
+                                                             : a_out + ((size_t)n * a_out_ctotal + a_out_coff + co[q]) * hwo + pix;
+            *reinterpret_cast<f32x4*>(d) = v;
+        }
+}
+
+template <int KH, int KW>
+int gb_launch(const GConvArgs& a, hipStream_t stream) {
+    using C = GBCfg<KH, KW>;
+    int cin = 0;
+    for (int s = 0; s < a.nseg; ++s) cin += a.seg[s].c;
+    const int tiles_x = ceil_div(a.wout, C::TW), tiles_y = ceil_div(a.hout, C::TH);
+    dim3 grid(tiles_x * tiles_y, ceil_div(a.cout, 64), a.n);
+    hipLaunchKernelGGL((gconvb_kernel<KH, KW>), grid, dim3(256), 0, stream, a, reinterpret_cast<const u32x4*>(a.wpkb), tiles_x, cin / 32);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+}  // namespace
+
+bool gconvb_shape(int cout, const int* cs, int nseg, int kh, int kw, int stride) {
+    if (stride != 1 || cout < 32) return false;
+    if (!((kh == 1 && kw == 1) || (kh == 3 && kw == 3) || (kh == 1 && kw == 5) || (kh == 5 && kw == 1))) return false;
+    for (int s = 0; s < nseg; ++s)
+        if (cs[s] <= 0 || cs[s] % 32) return false;
+    return true;
+}
+
+size_t gconvb_packed_floats(int cout, const int* cs, int nseg, int kh, int kw) {
+    int cin = 0;
+    for (int s = 0; s < nseg; ++s) cin += cs[s];
+    return (size_t)ceil_div(cout, 64) * (cin / 32) * kh * kw * 4 * 3 * 64 * 4;
+}
+
+// u32x4 index ((((cc * nch + ch) * taps + tap) * 4 + cog) * 3 + piece) * 64 + lane; dword d of lane (cout = cc * 64 + cog * 16 + lane % 16,
+// channels ch * 32 + 8 (lane / 16) + 2 d (+ 1)) holds the pieces of the two weights in its low (high) half
+void gconvb_pack(const float* w, int cout, const int* cs, int nseg, int kh, int kw, float* packed) {
+    int cin = 0;
+    for (int s = 0; s < nseg; ++s) cin += cs[s];
+    const int taps = kh * kw, nch = cin / 32;
+    unsigned* out = reinterpret_cast<unsigned*>(packed);
+    auto pieces = [](float x, unsigned (&p)[3]) {                   // (unions: the host pass of hipcc sees only the device's memcpy)
+        union { float f; unsigned u; } v, h;
+        v.f = x;
+        h.u = v.u & 0xffff0000u;
+        p[0] = h.u >> 16;
+        v.f = x - h.f;
+        h.u = v.u & 0xffff0000u;
+        p[1] = h.u >> 16;
+        v.f = v.f - h.f;
+        p[2] = v.u >> 16;
+    };
+    for (int cc = 0; cc < ceil_div(cout, 64); ++cc)
+        for (int ch = 0; ch < nch; ++ch)
+            for (int tap = 0; tap < taps; ++tap)
+                for (int cog = 0; cog < 4; ++cog)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int co = cc * 64 + cog * 16 + (lane & 15);
+                        for (int d = 0; d < 4; ++d) {
+                            unsigned lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+                            const int c = ch * 32 + 8 * (lane >> 4) + 2 * d;
+                            if (co < cout) {
+                                pieces(w[((size_t)co * cin + c) * taps + tap], lo);
+                                pieces(w[((size_t)co * cin + c + 1) * taps + tap], hi);
+                            }
+                            for (int pc = 0; pc < 3; ++pc)
+                                out[((((((size_t)cc * nch + ch) * taps + tap) * 4 + cog) * 3 + pc) * 64 + lane) * 4 + d] = (hi[pc] << 16) | lo[pc];
+                        }
+                    }
+}
+
+bool gconvb_supported(const GConvArgs& a) {
+    const char* e = getenv("EEM_NO_GCONVB");                      // read per call: a test flips it inside one process
+    if (e && e[0] == '1') return false;
+    if (!a.wpkb || !a.zero_page || a.tstride > 1 || a.stride != 1 || a.pad_h != a.kh / 2 || a.pad_w != a.kw / 2 || a.groups > 1 || a.out_cmul > 1) return false;
+    int cs[3];
+    for (int s = 0; s < a.nseg; ++s) {
+        cs[s] = a.seg[s].c;
+        if (a.seg[s].cmul > 1 || a.seg[s].gate || ((uintptr_t)a.seg[s].ptr & 15)) return false;
+    }
+    if (!gconvb_shape(a.cout, cs, a.nseg, a.kh, a.kw, a.stride)) return false;
+    if (a.win % 4 || a.wout % 4 || a.hout != a.hin || a.wout != a.win || ((uintptr_t)a.out & 15)) return false;
+    if ((a.pre && ((uintptr_t)a.pre & 15)) || (a.epi != GEPI_PLAIN && ((uintptr_t)a.e0 & 15)) || (a.epi == GEPI_GRU && ((uintptr_t)a.e1 & 15)) ||
+        (a.epi == GEPI_ZR && (((uintptr_t)a.out2 & 15) || a.split % 16)))
+        return false;
+    if ((size_t)a.cout * a.hin * a.win >= (1u << 30) || (size_t)32 * a.hin * a.win * 4 >= (1u << 31)) return false;
+    // large tiles (128 pixels x 64 couts): launches that fill the chip with them; the others stay on gconv16.hip
+    const char* mb = getenv("EEM_GCONVB_MINBLK");                 // (read per call, like the switch above: the tests run small shapes through it)
+    const long min_blk = mb ? atol(mb) : 256L;
+    const long blocks = (long)ceil_div(a.wout, 16) * ceil_div(a.hout, 8) * ceil_div(a.cout, 64) * a.n;
+    return blocks >= min_blk;
+}
+
+int gconvb_launch(const GConvArgs& a, hipStream_t stream) {
+    if (a.kh == 1 && a.kw == 1) return gb_launch<1, 1>(a, stream);
+    if (a.kh == 3) return gb_launch<3, 3>(a, stream);
+    if (a.kh == 1) return gb_launch<1, 5>(a, stream);
+    return gb_launch<5, 1>(a, stream);
+}

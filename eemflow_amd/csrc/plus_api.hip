@@ -33,7 +33,7 @@ int pensure_zeroed(PBuf& b, size_t floats) {
     return EEM_OK;
 }
 
-struct PLayer { size_t wpk = 0, wpk16 = 0, wtail = 0, wfew = 0, bias = 0; bool has16 = false, has_tail = false, has_few = false; int cin = 0, cout = 0, k = 3, stride = 1; };
+struct PLayer { size_t wpk = 0, wpk16 = 0, wpkb = 0, wtail = 0, wfew = 0, bias = 0; bool hasb = false, has16 = false, has_tail = false, has_few = false; int cin = 0, cout = 0, k = 3, stride = 1; };
 
 const int kTaps[53] = {0,  2,  4,  6,  8,  10, 12, 14, 16, 18, 20, 21, 22, 23, 24, 26, 28, 29, 30, 31, 32, 33, 34, 36, 38, 39, 40,
                        41, 42, 44, 46, 47, 48, 49, 50, 51, 52, 54, 56, 57, 58, 59, 60, 62, 64, 66, 68, 70, 72, 74, 76, 78, 80};
@@ -83,6 +83,11 @@ void mk(Pk& pk, PLayer& L, const float* w, const float* b, int cin, int cout, in
         L.wpk16 = pk.push(gconv16_packed_floats(cout, cs, 1, k, k));
         gconv16_pack(w, cout, cs, 1, k, k, pk.host.data() + L.wpk16);
     }
+    L.hasb = gconvb_shape(cout, cs, 1, k, k, stride);
+    if (L.hasb) {
+        L.wpkb = pk.push(gconvb_packed_floats(cout, cs, 1, k, k));
+        gconvb_pack(w, cout, cs, 1, k, k, pk.host.data() + L.wpkb);
+    }
     L.has_few = cout <= 8 && k == 3 && stride == 1;                 // direct convolution on the vector pipe (gconv.h: fewout_*)
     if (L.has_few) {
         L.wfew = pk.push(fewout_packed_floats(cin, k, k));
@@ -120,6 +125,7 @@ int conv(eemplus_ctx* c, const PLayer& L, const float* in, int in_ctotal, int in
     a.seg[0].ptr = in; a.seg[0].c = L.cin; a.seg[0].ctotal = in_ctotal; a.seg[0].coff = in_coff;
     a.wpk = c->arena + L.wpk; a.shift = c->arena + L.bias;
     a.wpk16 = L.has16 ? c->arena + L.wpk16 : nullptr;
+    a.wpkb = L.hasb ? c->arena + L.wpkb : nullptr;
     a.wfew = L.has_few ? c->arena + L.wfew : nullptr;
     a.zero_page = c->arena + c->zero_off;
     a.out = out; a.out_ctotal = out_ctotal; a.out_coff = out_coff; a.out_cmul = out_cmul;

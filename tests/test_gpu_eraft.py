@@ -128,6 +128,24 @@ def test_lds_tiled_conv_equals_generic_conv(monkeypatch):
     assert maxerr(fast, plain) < 2e-4 and float(plain.abs().max()) > 1e-3
 
 
+@pytest.mark.parametrize("b,h,w,iters", [(2, 256, 352, 3), (1, 480, 640, 3), (4, 480, 640, 2), (1, 136, 200, 2)])
+def test_bf16_piece_convs_equal_the_fp32_ones(monkeypatch, b, h, w, iters):
+    """gconvb.hip (the 32-aligned stride-1 convs on the bf16 matrix pipe: exact three-piece operands, six MFMAs per product, 128-pixel x
+    64-cout tiles; default for launches of >= 256 blocks, EEM_GCONVB_MINBLK=1 sends every eligible launch through it - both read per
+    call) against the fp32-MFMA kernels (EEM_NO_GCONVB=1): every epilogue the update block and the encoders use - GRU blend, z | r with
+    r * h, residual add + ReLU, the per-pixel context addend - and every kernel shape (1x1, 3x3, 1x5, 5x1; one to three input segments)."""
+    net, _ = make_net(29)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(30, b, h, w))
+    with torch.no_grad():
+        monkeypatch.setenv("EEM_GCONVB_MINBLK", "1")
+        fast = torch.stack(net(e1, e2, iters=iters)[1]).clone()
+        monkeypatch.setenv("EEM_NO_GCONVB", "1")
+        plain = torch.stack(net(e1, e2, iters=iters)[1])
+    assert not torch.equal(fast, plain)                       # (the switch did switch)
+    assert maxerr(fast, plain) < 2e-4 and float(plain.abs().max()) > 1e-3
+
+
 @pytest.mark.parametrize("b,h,w,iters", [(2, 256, 352, 3), (1, 480, 640, 12), (1, 136, 200, 2)])
 def test_on_the_fly_correlation_equals_the_resident_volume(b, h, w, iters):
     """ERAFT.alternate_corr (eraft_set_alternate_corr; the alt_cuda_corr pattern): the 324 correlation features from

@@ -144,6 +144,22 @@ def test_chained_forward_levels_vs_oracle_on_its_own_flow_init(b, h, w, cin):
                 assert e_up < 2e-2 and e_fl < 2e-2, (l, e_up, e_fl)
 
 
+@pytest.mark.parametrize("b,h,w,cin", [(1, 256, 320, 5), (1, 720, 1280, 5)])
+def test_bf16_piece_convs_equal_the_fp32_ones(monkeypatch, b, h, w, cin):
+    """EEMFlow+'s encoder / decoder convs through gconvb.hip (exact three-piece operands on the bf16 matrix pipe; EEM_GCONVB_MINBLK=1:
+    every eligible launch) against the fp32-MFMA kernels (EEM_NO_GCONVB=1); both switches are read per call."""
+    net = make_net(31, cin)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(32, b, h, w, bins=cin))
+    with torch.no_grad():
+        monkeypatch.setenv("EEM_GCONVB_MINBLK", "1")
+        fast = net(e1, e2)[1][0].clone()
+        monkeypatch.setenv("EEM_NO_GCONVB", "1")
+        plain = net(e1, e2)[1][0]
+    assert not torch.equal(fast, plain)
+    assert float((fast - plain).abs().max()) < 2e-4 and float(plain.abs().max()) > 1e-3
+
+
 def test_errors():
     net = make_net(1, 5)
     with pytest.raises(AttributeError):

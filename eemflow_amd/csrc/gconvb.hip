@@ -106,7 +106,8 @@ __global__ __launch_bounds__(256, 1) void gconvb_kernel(GConvArgs ka, const u32x
     const bool s_in = s_act && s_gy >= 0 && s_gy < a_hin && s_gx >= 0 && s_gx < a_win;      // a piece is inside or outside as a whole (win % 4 == 0)
     const size_t s_off = s_in ? (size_t)(s_cg * 8) * hw + (size_t)s_gy * a_win + s_gx : 0;
     const size_t s_step = s_in ? (size_t)hw : 0;
-    const int s_dst = s_act ? (s_cg * C::ROWS + s_r) * COLS + 4 * s_q : 2 * C::STAGE - 2 * 4 * PLANE + 4 * (lane & 15);   // (+ piece * 4 * PLANE + column; + buffer)
+    const int s_dst = s_act ? (s_cg * C::ROWS + s_r) * COLS + 4 * s_q : 2 * C::STAGE + 4 * (lane & 15);   // (+ piece * 4 * PLANE + column; + buffer); idle threads: the sink
+    const int s_pstride = s_act ? 4 * PLANE : 0;
     f32x4 sv[8];
     auto stage_load = [&](int ch) __attribute__((always_inline)) {          // (past the last chunk: the first one again, never converted)
         const int c0 = (ch < nchunks ? ch : 0) * 32, c1 = c0 - sc0, c2 = c1 - sc1;
@@ -133,8 +134,8 @@ __global__ __launch_bounds__(256, 1) void gconvb_kernel(GConvArgs ka, const u32x
     auto convert_write = [&](int buf, int k) __attribute__((always_inline)) {
         u32x4* d = lds + (s_act ? buf * C::STAGE : 0) + s_dst + k;
         d[0] = cp[0];
-        d[4 * PLANE] = cp[1];
-        d[2 * 4 * PLANE] = cp[2];
+        d[s_pstride] = cp[1];
+        d[2 * s_pstride] = cp[2];
     };
 
     using R0 = std::integral_constant<int, 0>;

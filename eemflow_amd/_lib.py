@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libeemflow_hip.so")
+LIB_PATH = os.environ.get("EEM_LIB_PATH") or os.path.join(_HERE, "libeemflow_hip.so")   # (EEM_LIB_PATH: a diagnostic build of the same library)
 
 _c_float_p = ctypes.c_void_p          # device/host pointers travel as integers
 

@@ -11,12 +11,12 @@
 // costs is operand traffic - a weight is 6 bytes and a 16x16x32 MFMA consumes 2 KB of operands per 16 cycles - so it is built for
 // launches with pixels enough to fill the chip with LARGE tiles (gconvb_supported); smaller ones stay on gconv16.hip.
 //
-//   * block = 4 waves = 8 rows x 16 pixels x 64 couts; wave = (row half, cout half): 4 pixel tiles (rows) x 2 cout groups of 16,
+//   * block = 8 waves = 8 rows x 16 pixels x 64 couts: four MULTIPLYING waves - wave = (row half, cout half): 4 pixel tiles (rows) x 2 cout groups of 16,
 //     v_mfma_f32_16x16x32_bf16 with M = 16 pixels, N = 16 couts, K = 32 channels: 48 MFMAs per k-step (tap x 32-channel chunk) against
-//     12 A-fragment reads (LDS) and 6 B-fragment loads (global);
-//   * INPUT: the chunk's haloed tile, split once on its way in: a thread loads 8 channels x 4 columns (eight 16-byte loads, one chunk
-//     ahead, out-of-image pieces from the zero page), splits the 32 values between the MFMAs of the current chunk (pinned slices) and
-//     writes twelve 16-byte LDS entries [piece][8-channel group][row][column] = 8 bf16; double-buffered, one barrier per chunk;
+//     12 A-fragment reads (LDS) and 6 B-fragment loads (global) - and four STAGING waves, one of each kind per SIMD;
+//   * INPUT: the chunk's haloed tile, split once on its way in: a staging thread loads 8 channels x 4 columns (eight 16-byte loads, one
+//     chunk ahead, out-of-image pieces from the zero page), splits the 32 values and writes twelve 16-byte LDS entries
+//     [piece][8-channel group][row][column] = 8 bf16; double-buffered, one barrier per chunk;
 //   * WEIGHTS: pre-split on the host into B fragments [64-cout chunk][32-channel chunk][tap][cout group][piece][lane] (16 bytes),
 //     streamed L2 -> registers through a ring of three k-steps per wave - no LDS, no barrier (28 bytes per clock and CU);
 //   * D: lane = (cout, 4 consecutive pixels): epilogue operands (GRU state and gate, residual, per-pixel addend) and results move as
@@ -54,7 +54,7 @@ __device__ __forceinline__ float gb_act(float v, int act) {
 }
 
 template <int KH, int KW>
-__global__ __launch_bounds__(256, 1) void gconvb_kernel(GConvArgs ka, const u32x4* __restrict__ wq, int tiles_x, int nchunks) {
+__global__ __launch_bounds__(512, 2) void gconvb_kernel(GConvArgs ka, const u32x4* __restrict__ wq, int tiles_x, int nchunks) {
     // every launch argument the kernel uses, as scalars of its own: closures that reach the argument STRUCT by reference kept a copy of it in
     // scratch (328 bytes stored and re-read per thread)
     const int a_hin = ka.hin, a_win = ka.win, a_hout = ka.hout, a_wout = ka.wout, a_cout = ka.cout, a_act = ka.act, a_epi = ka.epi, a_nseg = ka.nseg;
@@ -72,15 +72,89 @@ __global__ __launch_bounds__(256, 1) void gconvb_kernel(GConvArgs ka, const u32x
     __shared__ __attribute__((aligned(256))) u32x4 lds[2 * C::STAGE + 64];   // two chunk buffers + a sink for threads that stage nothing
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Roles: waves 0-3 multiply (ds_read_b128 + weight loads + MFMAs, nothing else in their stream), waves 4-7 stage the next chunk's
+    // tile (global loads, the split, LDS writes).  Two reasons: the split's VALU work runs on the SIMD's vector pipe BESIDE the
+    // partner's MFMAs instead of between them; and vmcnt retires in order - a multiplying wave that had issued the staging loads
+    // (HBM) waited for them whenever it waited for a weight fragment (L2) issued later: +25 % (diagnostic builds: the weight loads
+    // cost 30 of 123 us per launch, the conversion 33, in a kernel whose MFMAs alone take 56).
+    const bool stager = wave8 >= 4;
+    const int wave = wave8 & 3;
     const int ph = wave & 1, chh = wave >> 1;                    // row half, cout half
     const int m = lane & 15, kg = lane >> 4;
     const int n = blockIdx.z, cc = blockIdx.y;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int y0 = ty * C::TH, x0 = tx * C::TW;
     const int hw = a_hin * a_win;
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- weights: fragment (cc, ch, tap, cog, piece) at wq[((((cc * nchunks + ch) * TAPS + tap) * 4 + cog) * 3 + piece) * 64 + lane]
+    if (stager) {
+        // ---- input staging: item = (8-channel group cg of the chunk, tile row r, 16-byte column piece q)
+        const int st = tid - 256;
+        const float* sp0 = seg_ptr0 + ((size_t)n * seg_ct0 + seg_co0) * hw;
+        const float* sp1 = a_nseg > 1 ? seg_ptr1 + ((size_t)n * seg_ct1 + seg_co1) * hw : nullptr;
+        const float* sp2 = a_nseg > 2 ? seg_ptr2 + ((size_t)n * seg_ct2 + seg_co2) * hw : nullptr;
+        const int sc0 = seg_c0, sc1 = a_nseg > 1 ? seg_c1 : 0;
+        const bool s_act = st < C::ITEMS;
+        const int item = s_act ? st : 0;
+        const int s_cg = item / (C::ROWS * C::QPR), s_rq = item - s_cg * (C::ROWS * C::QPR);
+        const int s_r = s_rq / C::QPR, s_q = s_rq - s_r * C::QPR;
+        const int s_gy = y0 - C::PH + s_r, s_gx = x0 - C::XOFF + 4 * s_q;
+        const bool s_in = s_act && s_gy >= 0 && s_gy < a_hin && s_gx >= 0 && s_gx < a_win;      // a piece is inside or outside as a whole (win % 4 == 0)
+        const size_t s_off = s_in ? (size_t)(s_cg * 8) * hw + (size_t)s_gy * a_win + s_gx : 0;
+        const size_t s_step = s_in ? (size_t)hw : 0;
+        const int s_dst = s_act ? (s_cg * C::ROWS + s_r) * COLS + 4 * s_q : 2 * C::STAGE + 4 * (lane & 15);   // (+ piece * 4 * PLANE + column; + buffer); idle threads: the sink
+        const int s_pstride = s_act ? 4 * PLANE : 0;
+        f32x4 sv[8];
+        auto stage_load = [&](int ch) __attribute__((always_inline)) {      // (past the last chunk: the first one again, converted into a dead buffer)
+            const int c0 = (ch < nchunks ? ch : 0) * 32, c1 = c0 - sc0, c2 = c1 - sc1;
+            // (the three bases pass through an empty asm: the compiler otherwise folds the selects into ONE load at a selected offset of
+            // the closure that holds them by reference - an indexed read that keeps every captured variable, the staging registers
+            // included, in scratch)
+            const float *q0 = sp0, *q1 = sp1, *q2 = sp2;
+            asm volatile("" : "+s"(q0), "+s"(q1), "+s"(q2));
+            const float* b = c0 < sc0 ? q0 : (c1 < sc1 ? q1 : q2);
+            const int cb = c0 < sc0 ? c0 : (c1 < sc1 ? c1 : c2);
+            const float* sp = s_in ? b + (size_t)cb * hw + s_off : a_zero_page;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sv[e] = *reinterpret_cast<const f32x4*>(sp + e * s_step);
+        };
+        auto convert = [&](int buf) __attribute__((always_inline)) {       // 32 values -> twelve 16-byte entries
+            u32x4* d = lds + (s_act ? buf * C::STAGE : 0) + s_dst;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                u32x4 cp[3];
+#pragma unroll
+                for (int dd = 0; dd < 4; ++dd) {
+                    const float xa = sv[2 * dd][k], xb = sv[2 * dd + 1][k];
+                    const float ra = xa - __uint_as_float(__float_as_uint(xa) & 0xffff0000u), rb = xb - __uint_as_float(__float_as_uint(xb) & 0xffff0000u);
+                    const float sa = ra - __uint_as_float(__float_as_uint(ra) & 0xffff0000u), sb = rb - __uint_as_float(__float_as_uint(rb) & 0xffff0000u);
+                    cp[0][dd] = __builtin_amdgcn_perm(__float_as_uint(xb), __float_as_uint(xa), 0x07060302u);      // (hi16(xb) << 16) | hi16(xa)
+                    cp[1][dd] = __builtin_amdgcn_perm(__float_as_uint(rb), __float_as_uint(ra), 0x07060302u);
+                    cp[2][dd] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
+                }
+                d[k] = cp[0];
+                d[s_pstride + k] = cp[1];
+                d[2 * s_pstride + k] = cp[2];
+            }
+        };
+        stage_load(0);
+        convert(0);
+        stage_load(1);
+        __syncthreads();
+        for (int ch = 0; ch < nchunks; ++ch) {
+            convert((ch + 1) & 1);                                           // chunk ch + 1's tile, while the multipliers read chunk ch's
+            stage_load(ch + 2);
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---- multipliers.  Weights: fragment (cc, ch, tap, cog, piece) at wq[((((cc * nchunks + ch) * TAPS + tap) * 4 + cog) * 3 + piece) * 64 + lane]
     const u32x4* wbase = wq + ((size_t)cc * nchunks * TAPS * 4 + chh * 2) * 3 * 64 + lane;
     u32x4 bw[3][2][3];
     auto load_b = [&](auto slot_tag, int s) __attribute__((always_inline)) {      // k-step s = ch * TAPS + tap (clamped past the end: a harmless reload)
@@ -92,86 +166,21 @@ __global__ __launch_bounds__(256, 1) void gconvb_kernel(GConvArgs ka, const u32x
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) bw[SL][q][pc] = p[(q * 3 + pc) * 64];
     };
-
-    // ---- input staging: item = (8-channel group cg of the chunk, tile row r, 16-byte column piece q)
-    const float* sp0 = seg_ptr0 + ((size_t)n * seg_ct0 + seg_co0) * hw;
-    const float* sp1 = a_nseg > 1 ? seg_ptr1 + ((size_t)n * seg_ct1 + seg_co1) * hw : nullptr;
-    const float* sp2 = a_nseg > 2 ? seg_ptr2 + ((size_t)n * seg_ct2 + seg_co2) * hw : nullptr;
-    const int sc0 = seg_c0, sc1 = a_nseg > 1 ? seg_c1 : 0;
-    const bool s_act = tid < C::ITEMS;
-    const int item = s_act ? tid : 0;
-    const int s_cg = item / (C::ROWS * C::QPR), s_rq = item - s_cg * (C::ROWS * C::QPR);
-    const int s_r = s_rq / C::QPR, s_q = s_rq - s_r * C::QPR;
-    const int s_gy = y0 - C::PH + s_r, s_gx = x0 - C::XOFF + 4 * s_q;
-    const bool s_in = s_act && s_gy >= 0 && s_gy < a_hin && s_gx >= 0 && s_gx < a_win;      // a piece is inside or outside as a whole (win % 4 == 0)
-    const size_t s_off = s_in ? (size_t)(s_cg * 8) * hw + (size_t)s_gy * a_win + s_gx : 0;
-    const size_t s_step = s_in ? (size_t)hw : 0;
-    const int s_dst = s_act ? (s_cg * C::ROWS + s_r) * COLS + 4 * s_q : 2 * C::STAGE + 4 * (lane & 15);   // (+ piece * 4 * PLANE + column; + buffer); idle threads: the sink
-    const int s_pstride = s_act ? 4 * PLANE : 0;
-    f32x4 sv[8];
-    auto stage_load = [&](int ch) __attribute__((always_inline)) {          // (past the last chunk: the first one again, never converted)
-        const int c0 = (ch < nchunks ? ch : 0) * 32, c1 = c0 - sc0, c2 = c1 - sc1;
-        // (the three bases pass through an empty asm: the compiler otherwise folds the selects into ONE load at a selected offset of
-        // the closure that holds them by reference - an indexed read that keeps every captured variable, the staging registers
-        // included, in scratch)
-        const float *q0 = sp0, *q1 = sp1, *q2 = sp2;
-        asm volatile("" : "+s"(q0), "+s"(q1), "+s"(q2));
-        const float* b = c0 < sc0 ? q0 : (c1 < sc1 ? q1 : q2);
-        const int cb = c0 < sc0 ? c0 : (c1 < sc1 ? c1 : c2);
-        const float* sp = s_in ? b + (size_t)cb * hw + s_off : a_zero_page;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sv[e] = *reinterpret_cast<const f32x4*>(sp + e * s_step);
-    };
-    u32x4 cp[3];
-    auto convert_pair = [&](int k, int d) __attribute__((always_inline)) {   // channels 2 d, 2 d + 1 of column k -> dword d of the three pieces
-        const float xa = sv[2 * d][k], xb = sv[2 * d + 1][k];
-        const float ra = xa - __uint_as_float(__float_as_uint(xa) & 0xffff0000u), rb = xb - __uint_as_float(__float_as_uint(xb) & 0xffff0000u);
-        const float sa = ra - __uint_as_float(__float_as_uint(ra) & 0xffff0000u), sb = rb - __uint_as_float(__float_as_uint(rb) & 0xffff0000u);
-        cp[0][d] = __builtin_amdgcn_perm(__float_as_uint(xb), __float_as_uint(xa), 0x07060302u);      // (hi16(xb) << 16) | hi16(xa)
-        cp[1][d] = __builtin_amdgcn_perm(__float_as_uint(rb), __float_as_uint(ra), 0x07060302u);
-        cp[2][d] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
-    };
-    auto convert_write = [&](int buf, int k) __attribute__((always_inline)) {
-        u32x4* d = lds + (s_act ? buf * C::STAGE : 0) + s_dst + k;
-        d[0] = cp[0];
-        d[s_pstride] = cp[1];
-        d[2 * s_pstride] = cp[2];
-    };
-
     using R0 = std::integral_constant<int, 0>;
     using R1 = std::integral_constant<int, 1>;
     using R2 = std::integral_constant<int, 2>;
-    // prologue: chunk 0's tile, the first two k-steps' weights, chunk 1's tile in flight
-    stage_load(0);
     load_b(R0{}, 0);
     load_b(R1{}, 1);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-#pragma unroll
-        for (int d = 0; d < 4; ++d) convert_pair(k, d);
-        convert_write(0, k);
-    }
-    stage_load(1);
     __syncthreads();
-
-    f32x4 acc[4][2];
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // A fragment of (tile row p, tap (ky, kx), piece pc): entry ((pc * 4 + kg) * ROWS + 4 ph + p + ky) * COLS + XOFF - PW + kx + m
     const unsigned a_lane = (unsigned)((kg * C::ROWS + 4 * ph) * COLS + C::XOFF - C::PW + m) * 16u;
     const char* lb = reinterpret_cast<const char*>(lds);
 
-    // one chunk: TAPS k-steps; RB = ring slot of its first k-step.  The conversion of the next chunk's tile rides between the MFMAs:
-    // 16 pair-slices (11 VALU instructions each) + 4 x 3 LDS writes, one slice after every STRIDE-th group of 8 MFMAs, pinned by
-    // sched_barrier (left to the scheduler they form one block behind which the matrix pipe runs dry).
+    // one chunk: TAPS k-steps of 48 MFMAs; RB = ring slot of its first k-step's weights
     auto chunk = [&](auto rb_tag, int ch) __attribute__((always_inline)) {
         constexpr int RB = decltype(rb_tag)::value;
         const unsigned abuf = a_lane + (unsigned)((ch & 1) * C::STAGE) * 16u;
-        const int nbuf = (ch + 1) & 1;
-        const bool more = ch + 1 < nchunks;
         auto read_a = [&](int t, u32x4 (&av)[4][3]) __attribute__((always_inline)) {
             const int ky = t / KW, kx = t % KW;
 #pragma unroll
@@ -182,9 +191,6 @@ __global__ __launch_bounds__(256, 1) void gconvb_kernel(GConvArgs ka, const u32x
         };
         u32x4 av[2][4][3];
         read_a(0, av[0]);
-        constexpr int NGRP = TAPS * 6;                                       // MFMA groups of 8 (one piece product of every tile and cout group)
-        constexpr int STRIDE = NGRP >= 32 ? NGRP / 16 : 1;                   // 3x3: every 3rd group; 1x5 / 5x1: every group from the 2nd on; 1x1: 16 slices in 6 groups
-        constexpr int PER = NGRP >= 16 ? 1 : (16 + NGRP - 1) / NGRP;         // slices per group
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
             const int cur = t & 1;
@@ -203,32 +209,21 @@ __global__ __launch_bounds__(256, 1) void gconvb_kernel(GConvArgs ka, const u32x
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
                         acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gb_bf(av[cur][p][PA[i]]), gb_bf(bw[(RB + t) % 3][q][PB[i]]), acc[p][q], 0, 0, 0);
-                const int g = t * 6 + i;
-                if (g % STRIDE == 0) {
-#pragma unroll
-                    for (int r = 0; r < PER; ++r) {
-                        const int slice = (g / STRIDE) * PER + r;            // (compile-time after unrolling: the staging registers are indexed by it)
-                        if (slice < 16) {
-                            convert_pair(slice >> 2, slice & 3);
-                            if ((slice & 3) == 3) convert_write(nbuf, slice >> 2);
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
             }
         }
-        (void)more;
-        stage_load(ch + 2);                                                  // (its registers are free now; lands during the next chunk)
         __syncthreads();                                                     // this chunk's tile is read, the next one's is written
     };
-    for (int ch = 0; ch < nchunks; ++ch) {
-        if constexpr (TAPS % 3 == 0) {
+    if constexpr (TAPS % 3 == 0) {
+        for (int ch = 0; ch < nchunks; ++ch) chunk(R0{}, ch);
+    } else {
+        // the ring slot of a chunk's first k-step cycles with period 3: three chunks per trip, straight-line (as a dispatch on a run-time
+        // slot the three bodies met in one loop header and the weight ring was spilled around it)
+        using RA = std::integral_constant<int, TAPS % 3>;
+        using RBB = std::integral_constant<int, (2 * TAPS) % 3>;
+        for (int ch = 0; ch < nchunks; ch += 3) {
             chunk(R0{}, ch);
-        } else {
-            const int rb = (ch * TAPS) % 3;
-            if (rb == 0) chunk(R0{}, ch);
-            else if (rb == 1) chunk(R1{}, ch);
-            else chunk(R2{}, ch);
+            if (ch + 1 < nchunks) chunk(RA{}, ch + 1);
+            if (ch + 2 < nchunks) chunk(RBB{}, ch + 2);
         }
     }
 
@@ -317,7 +312,7 @@ int gb_launch(const GConvArgs& a, hipStream_t stream) {
     for (int s = 0; s < a.nseg; ++s) cin += a.seg[s].c;
     const int tiles_x = ceil_div(a.wout, C::TW), tiles_y = ceil_div(a.hout, C::TH);
     dim3 grid(tiles_x * tiles_y, ceil_div(a.cout, 64), a.n);
-    hipLaunchKernelGGL((gconvb_kernel<KH, KW>), grid, dim3(256), 0, stream, a, reinterpret_cast<const u32x4*>(a.wpkb), tiles_x, cin / 32);
+    hipLaunchKernelGGL((gconvb_kernel<KH, KW>), grid, dim3(512), 0, stream, a, reinterpret_cast<const u32x4*>(a.wpkb), tiles_x, cin / 32);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

@@ -84,3 +84,5 @@ size_t gconvb_packed_floats(int cout, const int* cs, int nseg, int kh, int kw);
 void gconvb_pack(const float* w, int cout, const int* cs, int nseg, int kh, int kw, float* packed);
 bool gconvb_supported(const GConvArgs& a);
 int gconvb_launch(const GConvArgs& a, hipStream_t stream);
+// device-side: gconv16_pack's stream of the same weights -> gconvb_pack's (ops.hip: packings follow the weights of a training step)
+int gconvb_from16_launch(const float* wpk16, int cout, int cin, int taps, float* wpkb, hipStream_t stream);

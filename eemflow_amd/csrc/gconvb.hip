@@ -319,6 +319,44 @@ int gb_launch(const GConvArgs& a, hipStream_t stream) {
 
 }  // namespace
 
+// gconv16.hip's fp32 fragment stream of the same weights -> this file's pre-split B fragments, on the device: what a training step does
+// after every weight update (ops.hip gathers the fp32 stream - forward or transposed-flipped for the data gradient - by an index table;
+// the split is arithmetic, not a gather).  gconv16: stream[((((cc * nch16 + ch16) * 4 + mt) * taps + tap) * 64 + lane16) * 4 + cg] =
+// W[cc * 64 + mt * 16 + lane16 % 16][ch16 * 16 + 4 cg + lane16 / 16][tap]
+namespace {
+__global__ void gconvb_from16_kernel(const float* __restrict__ w16, int cin, int taps, unsigned* __restrict__ out, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int nch32 = cin / 32, nch16 = cin / 16;
+    const int d = (int)(i & 3), lane = (int)((i >> 2) & 63);
+    long rest = i >> 8;
+    const int pc = (int)(rest % 3); rest /= 3;
+    const int cog = (int)(rest & 3); rest >>= 2;
+    const int tap = (int)(rest % taps); rest /= taps;
+    const int ch = (int)(rest % nch32);
+    const int cc = (int)(rest / nch32);
+    const int c = ch * 32 + 8 * (lane >> 4) + 2 * d;
+    unsigned pcs[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int cch = c + h, ch16 = cch >> 4, r = cch & 15, cg = r >> 2, lh = r & 3;
+        const float x = w16[(((((size_t)cc * nch16 + ch16) * 4 + cog) * taps + tap) * 64 + (lane & 15) + 16 * lh) * 4 + cg];
+        const float x0 = __uint_as_float(__float_as_uint(x) & 0xffff0000u), r1 = x - x0;
+        const float x1 = __uint_as_float(__float_as_uint(r1) & 0xffff0000u), q = r1 - x1;
+        pcs[h] = (pc == 0 ? __float_as_uint(x0) : pc == 1 ? __float_as_uint(x1) : __float_as_uint(q)) >> 16;
+    }
+    out[i] = (pcs[1] << 16) | pcs[0];
+}
+}  // namespace
+
+int gconvb_from16_launch(const float* wpk16, int cout, int cin, int taps, float* wpkb, hipStream_t stream) {
+    const long total = (long)ceil_div(cout, 64) * (cin / 32) * taps * 4 * 3 * 64 * 4;
+    hipLaunchKernelGGL(gconvb_from16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, wpk16, cin, taps,
+                       reinterpret_cast<unsigned*>(wpkb), total);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
 bool gconvb_shape(int cout, const int* cs, int nseg, int kh, int kw, int stride) {
     if (stride != 1 || cout < 32) return false;
     if (!((kh == 1 && kw == 1) || (kh == 3 && kw == 3) || (kh == 1 && kw == 5) || (kh == 5 && kw == 1))) return false;
@@ -380,6 +418,9 @@ bool gconvb_supported(const GConvArgs& a) {
         if (a.seg[s].cmul > 1 || a.seg[s].gate || ((uintptr_t)a.seg[s].ptr & 15)) return false;
     }
     if (!gconvb_shape(a.cout, cs, a.nseg, a.kh, a.kw, a.stride)) return false;
+    // 1x1: a k-step per chunk - the staging waves (one tile conversion per 48 MFMAs) set the pace: 72 us against gconv16's 45-63 at
+    // E-RAFT's batch 4; EEM_GCONVB_1X1=1 sends them here all the same (tests)
+    if (a.kh == 1 && a.kw == 1) { const char* o = getenv("EEM_GCONVB_1X1"); if (!(o && o[0] == '1')) return false; }
     if (a.win % 4 || a.wout % 4 || a.hout != a.hin || a.wout != a.win || ((uintptr_t)a.out & 15)) return false;
     if ((a.pre && ((uintptr_t)a.pre & 15)) || (a.epi != GEPI_PLAIN && ((uintptr_t)a.e0 & 15)) || (a.epi == GEPI_GRU && ((uintptr_t)a.e1 & 15)) ||
         (a.epi == GEPI_ZR && (((uintptr_t)a.out2 & 15) || a.split % 16)))

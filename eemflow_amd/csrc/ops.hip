@@ -355,7 +355,7 @@ struct Plan {
 std::map<std::string, Plan> g_plans;              // per process; the tables depend on layer shapes only
 std::mutex g_plans_mutex;                         // autograd runs backward ops on its own thread
 struct Scratch { float* p = nullptr; size_t cap = 0; int dev = -1; };
-thread_local Scratch g_scratch[2];                // [0] packed weights, [1] zero bias / zero page
+thread_local Scratch g_scratch[3];                // [0] packed weights, [1] zero bias / zero page, [2] the bf16-piece packing
 
 int scratch_get(Scratch& s, size_t floats, float** out) {
     int dev = 0;
@@ -414,20 +414,23 @@ struct PackKey {
 std::map<PackKey, PackEntry> g_pack_cache;
 std::mutex g_pack_mutex;                          // autograd runs backward ops on its own thread
 
-int packed_weights(const float* w, const int* idx, size_t n, hipStream_t st, float** out) {
+// `fill(dst)` writes the n floats of the packing; kind distinguishes packings derived from the same (weights, table)
+template <class F>
+int packed_cached(const float* w, const int* idx, int kind, size_t n, hipStream_t st, float** out, int scratch_slot, F&& fill) {
     int rc;
     if (t_pack_token == 0) {
-        if ((rc = scratch_get(g_scratch[0], n, out)) != EEM_OK) return rc;
-        return repack_launch(w, idx, *out, (long)n, st);
+        if ((rc = scratch_get(g_scratch[scratch_slot], n, out)) != EEM_OK) return rc;
+        return fill(*out);
     }
     int dev = 0;
     EEM_HIP_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(g_pack_mutex);
-    const PackKey key{t_pack_token, w, idx, st};
+    const int* kidx = idx + kind;                     // (a key, never dereferenced)
+    const PackKey key{t_pack_token, w, kidx, st};
     if (g_pack_cache.find(key) == g_pack_cache.end()) {
         // a packing is kept for ONE stream at a time: a caller that moves to a new stream every step must not grow the cache
-        auto it = g_pack_cache.lower_bound(PackKey{t_pack_token, w, idx, nullptr});
-        while (it != g_pack_cache.end() && it->first.token == t_pack_token && it->first.w == w && it->first.idx == idx) {
+        auto it = g_pack_cache.lower_bound(PackKey{t_pack_token, w, kidx, nullptr});
+        while (it != g_pack_cache.end() && it->first.token == t_pack_token && it->first.w == w && it->first.idx == kidx) {
             if (it->second.p) (void)hipFree(it->second.p);      // synchronises with the launches that read it
             it = g_pack_cache.erase(it);
         }
@@ -440,11 +443,15 @@ int packed_weights(const float* w, const int* idx, size_t n, hipStream_t st, flo
         e.cap = n;
     }
     if (e.version != t_pack_version) {
-        if ((rc = repack_launch(w, idx, e.p, (long)n, st)) != EEM_OK) return rc;
+        if ((rc = fill(e.p)) != EEM_OK) return rc;
         e.version = t_pack_version;
     }
     *out = e.p;
     return EEM_OK;
+}
+
+int packed_weights(const float* w, const int* idx, size_t n, hipStream_t st, float** out) {
+    return packed_cached(w, idx, 0, n, st, out, 0, [&](float* dst) { return repack_launch(w, idx, dst, (long)n, st); });
 }
 
 // Packs the weights for the launch described by `a` (everything but the weight pointers filled in): the few-output kernel's layout
@@ -466,9 +473,24 @@ int pack_for(const Plan* pl, const float* w, GConvArgs& a, hipStream_t st) {
     if (pl->idx16) {
         a.wpk16 = probe;
         a.zero_page = probe;
-        if (gconv16_supported(a)) {
+        a.wpkb = probe;
+        const bool onb = gconvb_supported(a);         // the bf16-piece kernel (gconvb.hip): its packing is derived from gconv16's, on the device
+        a.wpkb = nullptr;
+        if (onb || gconv16_supported(a)) {
             if ((rc = packed_weights(w, pl->idx16, pl->n16, st, &pk)) != EEM_OK) return rc;
             a.wpk16 = pk;
+            if (onb) {
+                int cin = 0;
+                for (int sgi = 0; sgi < a.nseg; ++sgi) cin += a.seg[sgi].c;
+                const int cs1[1] = {cin};
+                float* pkb = nullptr;
+                const float* src16 = pk;
+                const int cout = a.cout, taps = a.kh * a.kw;
+                // (scratch slot 2 when no hint names the weights: the fp32 stream sits in slot 0)
+                if ((rc = packed_cached(w, pl->idx16, 1, gconvb_packed_floats(cout, cs1, 1, a.kh, a.kw), st, &pkb, 2,
+                                        [&](float* dst) { return gconvb_from16_launch(src16, cout, cin, taps, dst, st); })) != EEM_OK) return rc;
+                a.wpkb = pkb;
+            }
             return EEM_OK;
         }
         a.wpk16 = nullptr;

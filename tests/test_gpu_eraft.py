@@ -139,6 +139,7 @@ def test_bf16_piece_convs_equal_the_fp32_ones(monkeypatch, b, h, w, iters):
     e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(30, b, h, w))
     with torch.no_grad():
         monkeypatch.setenv("EEM_GCONVB_MINBLK", "1")
+        monkeypatch.setenv("EEM_GCONVB_1X1", "1")
         fast = torch.stack(net(e1, e2, iters=iters)[1]).clone()
         monkeypatch.setenv("EEM_NO_GCONVB", "1")
         plain = torch.stack(net(e1, e2, iters=iters)[1])

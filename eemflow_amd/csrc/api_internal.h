@@ -419,11 +419,6 @@ int run_decoders(eemflow_ctx* c, int k0, int k1, const float* const cat[3], int 
     int rc;
     TailConvLaunch L;
     L.batch = batch; L.h = h; L.w = w; L.ksize = 3;
-    // several frames in flight: a decoder launch as a few dozen blocks that walk the pixel tiles (weights loaded once per block, the next
-    // tile's operands in flight under the current one's MFMAs) instead of 315-450 one-tile blocks - what a tail launch costs the other
-    // frames' kernels is the CU slots its blocks hold (profiles/r03_tailcost.txt); EEM_TAIL_MAXX=<n> (0: one tile per block)
-    static const int maxx_env = [] { const char* e = getenv("EEM_TAIL_MAXX"); return e ? atoi(e) : -1; }();
-    L.max_x = maxx_env >= 0 ? maxx_env : (c->frames_in_flight >= 3 ? 3 : 0);
     // conv1: 69 -> 100
     L.njobs = 0;
     for (int k = k0; k < k1; ++k) L.job[L.njobs++] = make_job(c, c->dconv1[k], cat[k], kDecIn, 0, c->ta[k].p, kDecW, 0, 1, 1);

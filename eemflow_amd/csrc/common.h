@@ -258,7 +258,6 @@ struct TailConvLaunch {
     int njobs;
     int batch, h, w;
     int ksize;             // 3 or 1
-    int max_x = 0;         // > 0: cap of the grid's x extent (blocks walk several pixel tiles), see tail_conv_launch
 };
 size_t tail_packed_floats(int cin, int cout, int ksize);
 void tail_pack_weights(const float* w, int cin, int cout, int ksize, float* packed);

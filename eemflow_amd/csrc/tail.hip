@@ -211,14 +211,13 @@ __global__ __launch_bounds__(128) void corr_tiled53_kernel(CorrArgs a, int tiles
 template <int KS, int MAXCG, bool GATE>
 __global__ __launch_bounds__(64 * KS * KS) void tail_conv_kernel(TailConvLaunch L) {
     constexpr int KK = KS * KS;
-    __shared__ f32x4 part[2][KK][64];
+    __shared__ f32x4 part[KK][64];
     const int lane = threadIdx.x & 63;
     const int t = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // grid = (pixel tiles x batch [or fewer: a block then walks tiles blockIdx.x, + gridDim.x, ...], cout tiles, jobs): the job index is a
-    // launch register, so the job's fields and the launch header are ONE batch of scalar loads (the kernel's first memory round trip; its
-    // second and last before the stores is the operand loads below).  Beside other frames' kernels a round trip is several times its idle
-    // length and the block holds its CU slot throughout - the chain of five dependent scalar loads this replaces was most of a decoder
-    // launch's price there.
+    // grid = (pixel tiles x batch, cout tiles, jobs): the job index is a launch register, so the job's fields and the launch
+    // header are ONE batch of scalar loads (the kernel's first memory round trip; its second and last before the stores is the
+    // operand loads below).  Beside other frames' kernels a round trip is several times its idle length and the block holds its
+    // CU slot throughout - the chain of five dependent scalar loads this replaces was most of a decoder launch's price there.
     const TailConvJob jb = L.job[blockIdx.z];
     const int hw = L.h * L.w, lw = L.w, lh = L.h;
     // (all of them wanted in registers here: the compiler otherwise leaves some of the loads behind the first branch)
@@ -227,93 +226,70 @@ __global__ __launch_bounds__(64 * KS * KS) void tail_conv_kernel(TailConvLaunch 
     const int cot = blockIdx.y;
     const bool live = cot * 16 < jb.cout;               // a launch's jobs may differ in cout: surplus blocks load nothing (range 0) and leave
     const int ptiles = (hw + 15) >> 4;
-    const int ntile = ptiles * L.batch;
+    const int b = blockIdx.x / ptiles;
     const int j = lane & 15, g = lane >> 4;
+    const int p = (blockIdx.x - b * ptiles) * 16 + j;
+    const int y = p / lw, x = p - y * lw;
+    const int yy = y + (KS == 3 ? t / 3 - 1 : 0), xx = x + (KS == 3 ? t % 3 - 1 : 0);
+    const bool valid = p < hw && yy >= 0 && yy < lh && xx >= 0 && xx < lw;
     const int cg = (jb.cin + 3) >> 2;
     const int cmul = jb.in_cmul > 1 ? jb.in_cmul : 1;
-    // weights: cg fragments of 64 floats for (cout tile, tap); a fragment past cg reads as zero.  The same for every tile the block walks.
+    // weights: cg fragments of 64 floats for (cout tile, tap); a fragment past cg reads as zero
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(jb.wpk) + ((size_t)cot * KK + t) * cg * 64, (short)0, live ? cg * 256 : 0, 0x00020000);
-    const int cstep = 4 * cmul * hw * 4;                                   // bytes from one channel group to the next
+    // input: channel c at c * cmul * hw floats from (b, in_coff); a channel past cin and a tap outside the grid read as zero
+    const size_t ibase = ((size_t)b * jb.in_ctotal + jb.in_coff) * hw;
     const int ibytes = live ? (((jb.cin - 1) * cmul + 1) * hw) * 4 : 0;
-    float av[MAXCG];
+    const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(jb.in) + ibase, (short)0, ibytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t gr = ir;
+    if (GATE) gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(jb.gate) + ibase, (short)0, ibytes, 0x00020000);
+    const int cstep = 4 * cmul * hw * 4;                                   // bytes from one channel group to the next
+    int voff = valid ? (g * cmul * hw + yy * lw + xx) * 4 : 0x40000000;
+
+    float av[MAXCG], bv[MAXCG];
 #pragma unroll
-    for (int q = 0; q < MAXCG; ++q) av[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wr, lane * 4 + q * 256, 0, 0));    // offsets in voffset: range-checked
-    // input of tile x: channel c at c * cmul * hw floats from (b, in_coff); a channel past cin and a tap outside the grid read as zero
-    auto gather = [&](int x, float (&bv)[MAXCG]) __attribute__((always_inline)) {
-        const int b = x / ptiles;
-        const int p = (x - b * ptiles) * 16 + j;
-        const int y = p / lw, xx0 = p - y * lw;
-        const int yy = y + (KS == 3 ? t / 3 - 1 : 0), xx = xx0 + (KS == 3 ? t % 3 - 1 : 0);
-        const bool valid = p < hw && yy >= 0 && yy < lh && xx >= 0 && xx < lw;
-        const size_t ibase = ((size_t)b * jb.in_ctotal + jb.in_coff) * hw;
-        const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(jb.in) + ibase, (short)0, ibytes, 0x00020000);
-        __amdgpu_buffer_rsrc_t gr = ir;
-        if (GATE) gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(jb.gate) + ibase, (short)0, ibytes, 0x00020000);
-        int voff = valid ? (g * cmul * hw + yy * lw + xx) * 4 : 0x40000000;
-#pragma unroll
-        for (int q = 0; q < MAXCG; ++q) {
-            bv[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ir, voff, 0, 0));
-            if (GATE) bv[q] *= __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(gr, voff, 0, 0)) > 0.f ? 1.f : 0.1f;
-            voff += cstep;
-        }
-    };
-    float bvs[2][MAXCG];
-    int x = blockIdx.x;
-    gather(x, bvs[0]);
-    // the finishing wave's bias rides in the same round trip (it is the same for every tile); the residual is per tile
+    for (int q = 0; q < MAXCG; ++q) {
+        av[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wr, lane * 4 + q * 256, 0, 0));    // offsets in voffset: range-checked
+        bv[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ir, voff, 0, 0));
+        if (GATE) bv[q] *= __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(gr, voff, 0, 0)) > 0.f ? 1.f : 0.1f;
+        voff += cstep;
+    }
+    // the finishing wave's bias and residual ride in the same round trip
     const int co0 = cot * 16 + g * 4;
-    float bs[4] = {0.f, 0.f, 0.f, 0.f};
-    if (t == 0 && live) {
+    const size_t o0 = ((size_t)b * jb.out_ctotal + co0 * jb.out_cmul + jb.out_coff) * hw + p;
+    const size_t ostep = (size_t)jb.out_cmul * hw;
+    float bs[4] = {0.f, 0.f, 0.f, 0.f}, ad[4] = {0.f, 0.f, 0.f, 0.f};
+    if (t == 0 && p < hw && live) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (co0 + r < jb.cout && jb.bias) bs[r] = jb.bias[co0 + r];
+            if (co0 + r < jb.cout) {
+                if (jb.bias) bs[r] = jb.bias[co0 + r];
+                if (jb.add) ad[r] = jb.add[o0 + r * ostep];                // residual at the output's own index (EEMFlow+ decoders)
+            }
     }
     __builtin_amdgcn_sched_barrier(0);                  // every load in flight before the first MFMA waits
     if (!live) return;
-    const size_t ostep = (size_t)jb.out_cmul * hw;
-    auto tile = [&](auto buf_tag, int xt) __attribute__((always_inline)) {
-        constexpr int BUF = decltype(buf_tag)::value;
-        const int xn = xt + (int)gridDim.x;
-        if (xn < ntile) gather(xn, bvs[BUF ^ 1]);       // the next tile's operands under this tile's MFMAs and reduction
-        const int b = xt / ptiles;
-        const int p = (xt - b * ptiles) * 16 + j;
-        const size_t o0 = ((size_t)b * jb.out_ctotal + co0 * jb.out_cmul + jb.out_coff) * hw + p;
-        float ad[4] = {0.f, 0.f, 0.f, 0.f};
-        if (t == 0 && p < hw && jb.add) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (co0 + r < jb.cout) ad[r] = jb.add[o0 + r * ostep];                // residual at the output's own index (EEMFlow+ decoders)
-        }
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < MAXCG; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q], acc, 0, 0, 0);
+
+    if (KK > 1) {
+        part[t][lane] = acc;
+        __syncthreads();
+        if (t != 0) return;
+        acc = part[0][lane];
 #pragma unroll
-        for (int q = 0; q < MAXCG; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bvs[BUF][q], acc, 0, 0, 0);
-        if (KK > 1) {
-            part[BUF][t][lane] = acc;
-            __syncthreads();
-            if (t != 0) return;
-            acc = part[BUF][0][lane];
+        for (int k = 1; k < KK; ++k) acc += part[k][lane];          // fixed order: bitwise repeatable
+    }
+    if (p < hw) {
 #pragma unroll
-            for (int k = 1; k < KK; ++k) acc += part[BUF][k][lane];          // fixed order: bitwise repeatable
-        }
-        if (p < hw) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (co0 + r < jb.cout) {
-                    float v = acc[r] + bs[r];
-                    if (jb.act) v = v > 0.f ? v : 0.1f * v;
-                    if (jb.add) v += ad[r];
-                    jb.out[o0 + r * ostep] = v;
-                }
-        }
-    };
-    using B0 = std::integral_constant<int, 0>;
-    using B1 = std::integral_constant<int, 1>;
-    // (two LDS buffers: the finishing wave reads tile i's partial sums while the others already write tile i + 1's; the barrier of tile
-    // i + 1 orders its reads before the writes of tile i + 2)
-    for (; x < ntile; x += 2 * (int)gridDim.x) {
-        tile(B0{}, x);
-        if (x + (int)gridDim.x < ntile) tile(B1{}, x + (int)gridDim.x);
+        for (int r = 0; r < 4; ++r)
+            if (co0 + r < jb.cout) {
+                float v = acc[r] + bs[r];
+                if (jb.act) v = v > 0.f ? v : 0.1f * v;
+                if (jb.add) v += ad[r];
+                jb.out[o0 + r * ostep] = v;
+            }
     }
 }
 
@@ -460,11 +436,7 @@ int tail_conv_launch(const TailConvLaunch& l, hipStream_t stream) {
         max_cg = cg > max_cg ? cg : max_cg;
     }
     EEM_REQUIRE(max_cg <= 25, "tail_conv_launch: cin > 100 is not built");
-    // max_x > 0: at most that many blocks along x - a block then walks the tiles x, x + max_x, ... with the weights loaded once and the next
-    // tile's operands in flight under the current tile's MFMAs (several frames in flight: fewer, longer-lived blocks hold fewer CUs)
-    int gx = ceil_div(l.h * l.w, 16) * l.batch;
-    if (l.max_x > 0 && gx > l.max_x) gx = l.max_x;
-    dim3 grid(gx, ceil_div(max_cout, 16), l.njobs);
+    dim3 grid(ceil_div(l.h * l.w, 16) * l.batch, ceil_div(max_cout, 16), l.njobs);
     EEM_NOTE_GRID(grid.x * grid.y * grid.z, 64 * l.ksize * l.ksize);
     if (l.ksize == 1) {
         if (max_cg <= 2) tail_launch_t<1, 2>(l, grid, stream);

@@ -54,7 +54,7 @@ __device__ __forceinline__ float gb_act(float v, int act) {
 }
 
 template <int KH, int KW>
-__global__ __launch_bounds__(512, 2) void gconvb_kernel(GConvArgs ka, const u32x4* __restrict__ wq, int tiles_x, int nchunks) {
+__global__ __launch_bounds__(768, 3) void gconvb_kernel(GConvArgs ka, const u32x4* __restrict__ wq, int tiles_x, int nchunks) {
     // every launch argument the kernel uses, as scalars of its own: closures that reach the argument STRUCT by reference kept a copy of it in
     // scratch (328 bytes stored and re-read per thread)
     const int a_hin = ka.hin, a_win = ka.win, a_hout = ka.hout, a_wout = ka.wout, a_cout = ka.cout, a_act = ka.act, a_epi = ka.epi, a_nseg = ka.nseg;
@@ -72,17 +72,18 @@ __global__ __launch_bounds__(512, 2) void gconvb_kernel(GConvArgs ka, const u32x
     __shared__ __attribute__((aligned(256))) u32x4 lds[2 * C::STAGE + 64];   // two chunk buffers + a sink for threads that stage nothing
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // Roles: waves 0-3 multiply (ds_read_b128 + weight loads + MFMAs, nothing else in their stream), waves 4-7 stage the next chunk's
-    // tile (global loads, the split, LDS writes).  Two reasons: the split's VALU work runs on the SIMD's vector pipe BESIDE the
-    // partner's MFMAs instead of between them; and vmcnt retires in order - a multiplying wave that had issued the staging loads
-    // (HBM) waited for them whenever it waited for a weight fragment (L2) issued later: +25 % (diagnostic builds: the weight loads
-    // cost 30 of 123 us per launch, the conversion 33, in a kernel whose MFMAs alone take 56).
-    const bool stager = wave8 >= 4;
-    const int wave = wave8 & 3;
-    const int ph = wave & 1, chh = wave >> 1;                    // row half, cout half
+    const int wave12 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Roles: waves 0-7 multiply (ds_read_b128 + weight loads + MFMAs, nothing else in their stream), two per SIMD; waves 8-11 stage the
+    // next chunk's tile (global loads, the split, LDS writes), one per SIMD.  Why: the split's VALU work runs on the SIMD's vector pipe
+    // BESIDE the MFMAs instead of between them; vmcnt retires in order - a multiplying wave that had issued the staging loads (HBM)
+    // waited for them whenever it waited for a weight fragment (L2) issued later (diagnostic builds of the one-role kernel: the weight
+    // loads cost 30 of 123 us per launch, the conversion 33, in a kernel whose MFMAs alone take 56); and two multipliers on a SIMD
+    // cover each other's operand round trips, so neither needs a double-buffered A operand or a deep weight ring (168 registers).
+    const bool stager = wave12 >= 8;
+    const int wave = wave12 & 7;
+    const int ph = wave & 1, cq = wave >> 1;                     // row half, cout quarter (two groups of 16) of the block's 128 couts
     const int m = lane & 15, kg = lane >> 4;
-    const int n = blockIdx.z, cc = blockIdx.y;
+    const int n = blockIdx.z;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int y0 = ty * C::TH, x0 = tx * C::TW;
     const int hw = a_hin * a_win;
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(512, 2) void gconvb_kernel(GConvArgs ka, const u32x
 
     if (stager) {
         // ---- input staging: item = (8-channel group cg of the chunk, tile row r, 16-byte column piece q)
-        const int st = tid - 256;
+        const int st = tid - 512;
         const float* sp0 = seg_ptr0 + ((size_t)n * seg_ct0 + seg_co0) * hw;
         const float* sp1 = a_nseg > 1 ? seg_ptr1 + ((size_t)n * seg_ct1 + seg_co1) * hw : nullptr;
         const float* sp2 = a_nseg > 2 ? seg_ptr2 + ((size_t)n * seg_ct2 + seg_co2) * hw : nullptr;
@@ -154,9 +155,13 @@ __global__ __launch_bounds__(512, 2) void gconvb_kernel(GConvArgs ka, const u32x
         return;
     }
 
-    // ---- multipliers.  Weights: fragment (cc, ch, tap, cog, piece) at wq[((((cc * nchunks + ch) * TAPS + tap) * 4 + cog) * 3 + piece) * 64 + lane]
-    const u32x4* wbase = wq + ((size_t)cc * nchunks * TAPS * 4 + chh * 2) * 3 * 64 + lane;
-    u32x4 bw[3][2][3];
+    // ---- multipliers.  Weights: fragment (cc, ch, tap, cog, piece) at wq[((((cc * nchunks + ch) * TAPS + tap) * 4 + cog) * 3 + piece) * 64 + lane],
+    // cc = 64-cout chunk; this wave's two groups are 2 cq, 2 cq + 1 of the block's eight
+    const int cog8 = 2 * cq;
+    const int ccw = blockIdx.y * 2 + (cog8 >> 2);
+    const bool wlive = ccw * 64 + (cog8 & 3) * 16 < a_cout;                  // (a cout count that ends inside the block: idle multipliers only keep the barriers)
+    const u32x4* wbase = wq + ((size_t)(wlive ? ccw : 0) * nchunks * TAPS * 4 + (cog8 & 3)) * 3 * 64 + lane;
+    u32x4 bw[2][2][3];
     auto load_b = [&](auto slot_tag, int s) __attribute__((always_inline)) {      // k-step s = ch * TAPS + tap (clamped past the end: a harmless reload)
         constexpr int SL = decltype(slot_tag)::value;
         const int sc = s < nchunks * TAPS ? s : nchunks * TAPS - 1;
@@ -166,40 +171,32 @@ __global__ __launch_bounds__(512, 2) void gconvb_kernel(GConvArgs ka, const u32x
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) bw[SL][q][pc] = p[(q * 3 + pc) * 64];
     };
-    using R0 = std::integral_constant<int, 0>;
-    using R1 = std::integral_constant<int, 1>;
-    using R2 = std::integral_constant<int, 2>;
-    load_b(R0{}, 0);
-    load_b(R1{}, 1);
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    load_b(P0{}, 0);
     __syncthreads();
 
     // A fragment of (tile row p, tap (ky, kx), piece pc): entry ((pc * 4 + kg) * ROWS + 4 ph + p + ky) * COLS + XOFF - PW + kx + m
     const unsigned a_lane = (unsigned)((kg * C::ROWS + 4 * ph) * COLS + C::XOFF - C::PW + m) * 16u;
     const char* lb = reinterpret_cast<const char*>(lds);
 
-    // one chunk: TAPS k-steps of 48 MFMAs; RB = ring slot of its first k-step's weights
-    auto chunk = [&](auto rb_tag, int ch) __attribute__((always_inline)) {
-        constexpr int RB = decltype(rb_tag)::value;
+    // one chunk: TAPS k-steps of 48 MFMAs; PAR = ring slot of its first k-step's weights (the kernels' tap counts are odd: it alternates)
+    auto chunk = [&](auto par_tag, int ch) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_tag)::value;
         const unsigned abuf = a_lane + (unsigned)((ch & 1) * C::STAGE) * 16u;
-        auto read_a = [&](int t, u32x4 (&av)[4][3]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
             const int ky = t / KW, kx = t % KW;
+            u32x4 av[4][3];
 #pragma unroll
             for (int p = 0; p < 4; ++p)
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc)
                     av[p][pc] = *reinterpret_cast<const u32x4*>(lb + abuf + ((pc * 4 * PLANE) + (p + ky) * COLS + kx) * 16);
-        };
-        u32x4 av[2][4][3];
-        read_a(0, av[0]);
-#pragma unroll
-        for (int t = 0; t < TAPS; ++t) {
-            const int cur = t & 1;
-            if (t + 1 < TAPS) read_a(t + 1, av[cur ^ 1]);
-            // the weights of the k-step after the next, into the slot the previous k-step has left
+            // the next k-step's weights, into the slot the previous k-step has left
             const int s = ch * TAPS + t;
-            if ((RB + t + 2) % 3 == 0) load_b(R0{}, s + 2);
-            else if ((RB + t + 2) % 3 == 1) load_b(R1{}, s + 2);
-            else load_b(R2{}, s + 2);
+            if ((PAR + t + 1) % 2 == 0) load_b(P0{}, s + 1);
+            else load_b(P1{}, s + 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 6; ++i) {                                    // small terms first
@@ -208,33 +205,31 @@ __global__ __launch_bounds__(512, 2) void gconvb_kernel(GConvArgs ka, const u32x
                 for (int p = 0; p < 4; ++p)
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
-                        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gb_bf(av[cur][p][PA[i]]), gb_bf(bw[(RB + t) % 3][q][PB[i]]), acc[p][q], 0, 0, 0);
+                        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gb_bf(av[p][PA[i]]), gb_bf(bw[(PAR + t) % 2][q][PB[i]]), acc[p][q], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();                                                     // this chunk's tile is read, the next one's is written
     };
-    if constexpr (TAPS % 3 == 0) {
-        for (int ch = 0; ch < nchunks; ++ch) chunk(R0{}, ch);
-    } else {
-        // the ring slot of a chunk's first k-step cycles with period 3: three chunks per trip, straight-line (as a dispatch on a run-time
-        // slot the three bodies met in one loop header and the weight ring was spilled around it)
-        using RA = std::integral_constant<int, TAPS % 3>;
-        using RBB = std::integral_constant<int, (2 * TAPS) % 3>;
-        for (int ch = 0; ch < nchunks; ch += 3) {
-            chunk(R0{}, ch);
-            if (ch + 1 < nchunks) chunk(RA{}, ch + 1);
-            if (ch + 2 < nchunks) chunk(RBB{}, ch + 2);
+    static_assert(TAPS % 2 == 1, "the two-slot weight ring alternates per chunk");
+    if (wlive) {
+        for (int ch = 0; ch < nchunks; ch += 2) {
+            chunk(P0{}, ch);
+            if (ch + 1 < nchunks) chunk(P1{}, ch + 1);
         }
+    } else {
+        for (int ch = 0; ch < nchunks; ++ch) __syncthreads();
+        return;
     }
 
-    // ---- epilogue: lane = cout (2 chh + q) * 16 + m of the block's 64, pixels (y0 + 4 ph + p, x0 + 4 kg .. + 3)
+    // ---- epilogue: lane = cout (2 cq + q) * 16 + m of the block's 128, pixels (y0 + 4 ph + p, x0 + 4 kg .. + 3)
     const int hwo = a_hout * a_wout;
     const int x = x0 + 4 * kg;
     float e_scale[2], e_shift[2];
     int co[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        co[q] = cc * 64 + (2 * chh + q) * 16 + m;
+        co[q] = ccw * 64 + ((cog8 & 3) + q) * 16 + m;
         const int cl = min(co[q], a_cout - 1);
         e_scale[q] = a_scale ? a_scale[cl] : 1.f;
         e_shift[q] = a_shift ? a_shift[cl] : 0.f;
@@ -311,8 +306,8 @@ int gb_launch(const GConvArgs& a, hipStream_t stream) {
     int cin = 0;
     for (int s = 0; s < a.nseg; ++s) cin += a.seg[s].c;
     const int tiles_x = ceil_div(a.wout, C::TW), tiles_y = ceil_div(a.hout, C::TH);
-    dim3 grid(tiles_x * tiles_y, ceil_div(a.cout, 64), a.n);
-    hipLaunchKernelGGL((gconvb_kernel<KH, KW>), grid, dim3(512), 0, stream, a, reinterpret_cast<const u32x4*>(a.wpkb), tiles_x, cin / 32);
+    dim3 grid(tiles_x * tiles_y, ceil_div(a.cout, 128), a.n);
+    hipLaunchKernelGGL((gconvb_kernel<KH, KW>), grid, dim3(768), 0, stream, a, reinterpret_cast<const u32x4*>(a.wpkb), tiles_x, cin / 32);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }
@@ -428,8 +423,8 @@ bool gconvb_supported(const GConvArgs& a) {
     if ((size_t)a.cout * a.hin * a.win >= (1u << 30) || (size_t)32 * a.hin * a.win * 4 >= (1u << 31)) return false;
     // large tiles (128 pixels x 64 couts): launches that fill the chip with them; the others stay on gconv16.hip
     const char* mb = getenv("EEM_GCONVB_MINBLK");                 // (read per call, like the switch above: the tests run small shapes through it)
-    const long min_blk = mb ? atol(mb) : 256L;
-    const long blocks = (long)ceil_div(a.wout, 16) * ceil_div(a.hout, 8) * ceil_div(a.cout, 64) * a.n;
+    const long min_blk = mb ? atol(mb) : 128L;
+    const long blocks = (long)ceil_div(a.wout, 16) * ceil_div(a.hout, 8) * ceil_div(a.cout, 128) * a.n;
     return blocks >= min_blk;
 }
 

@@ -28,9 +28,9 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ bf16x8 gb_bf(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
 
-template <int KH, int KW>
+template <int KH, int KW, int THT>
 struct GBCfg {
-    static constexpr int TH = 8, TW = 16;
+    static constexpr int TH = THT, TW = 16, PT = THT / 2;        // a multiplying wave's pixel tiles (rows)
     static constexpr int ROWS = TH + KH - 1;
     static constexpr int XOFF = KW > 1 ? 4 : 0;                  // staged columns x0 - XOFF .. (16-byte pieces)
     static constexpr int COLS = TW + 2 * XOFF, QPR = COLS / 4;
@@ -53,7 +53,7 @@ __device__ __forceinline__ float gb_act(float v, int act) {
     }
 }
 
-template <int KH, int KW>
+template <int KH, int KW, int THT>
 __global__ __launch_bounds__(768, 3) void gconvb_kernel(GConvArgs ka, const u32x4* __restrict__ wq, int tiles_x, int nchunks) {
     // every launch argument the kernel uses, as scalars of its own: closures that reach the argument STRUCT by reference kept a copy of it in
     // scratch (328 bytes stored and re-read per thread)
@@ -67,8 +67,8 @@ __global__ __launch_bounds__(768, 3) void gconvb_kernel(GConvArgs ka, const u32x
     const float* const seg_ptr0 = ka.seg[0].ptr; const float* const seg_ptr1 = ka.seg[1].ptr; const float* const seg_ptr2 = ka.seg[2].ptr;
     const int seg_c0 = ka.seg[0].c, seg_c1 = ka.seg[1].c, seg_ct0 = ka.seg[0].ctotal, seg_ct1 = ka.seg[1].ctotal, seg_ct2 = ka.seg[2].ctotal;
     const int seg_co0 = ka.seg[0].coff, seg_co1 = ka.seg[1].coff, seg_co2 = ka.seg[2].coff;
-    using C = GBCfg<KH, KW>;
-    constexpr int PLANE = C::PLANE, COLS = C::COLS, TAPS = C::TAPS;
+    using C = GBCfg<KH, KW, THT>;
+    constexpr int PLANE = C::PLANE, COLS = C::COLS, TAPS = C::TAPS, PT = C::PT;
     __shared__ __attribute__((aligned(256))) u32x4 lds[2 * C::STAGE + 64];   // two chunk buffers + a sink for threads that stage nothing
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -87,9 +87,9 @@ __global__ __launch_bounds__(768, 3) void gconvb_kernel(GConvArgs ka, const u32x
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int y0 = ty * C::TH, x0 = tx * C::TW;
     const int hw = a_hin * a_win;
-    f32x4 acc[4][2];
+    f32x4 acc[PT][2];
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int p = 0; p < PT; ++p)
 #pragma unroll
         for (int q = 0; q < 2; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(768, 3) void gconvb_kernel(GConvArgs ka, const u32x
     __syncthreads();
 
     // A fragment of (tile row p, tap (ky, kx), piece pc): entry ((pc * 4 + kg) * ROWS + 4 ph + p + ky) * COLS + XOFF - PW + kx + m
-    const unsigned a_lane = (unsigned)((kg * C::ROWS + 4 * ph) * COLS + C::XOFF - C::PW + m) * 16u;
+    const unsigned a_lane = (unsigned)((kg * C::ROWS + PT * ph) * COLS + C::XOFF - C::PW + m) * 16u;
     const char* lb = reinterpret_cast<const char*>(lds);
 
     // one chunk: TAPS k-steps of 48 MFMAs; PAR = ring slot of its first k-step's weights (the kernels' tap counts are odd: it alternates)
@@ -187,9 +187,9 @@ __global__ __launch_bounds__(768, 3) void gconvb_kernel(GConvArgs ka, const u32x
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
             const int ky = t / KW, kx = t % KW;
-            u32x4 av[4][3];
+            u32x4 av[PT][3];
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
+            for (int p = 0; p < PT; ++p)
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc)
                     av[p][pc] = *reinterpret_cast<const u32x4*>(lb + abuf + ((pc * 4 * PLANE) + (p + ky) * COLS + kx) * 16);
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(768, 3) void gconvb_kernel(GConvArgs ka, const u32x
             for (int i = 0; i < 6; ++i) {                                    // small terms first
                 constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-                for (int p = 0; p < 4; ++p)
+                for (int p = 0; p < PT; ++p)
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
                         acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gb_bf(av[p][PA[i]]), gb_bf(bw[(PAR + t) % 2][q][PB[i]]), acc[p][q], 0, 0, 0);
@@ -236,26 +236,26 @@ __global__ __launch_bounds__(768, 3) void gconvb_kernel(GConvArgs ka, const u32x
     }
     // operands: 16-byte loads from clamped indices, all of an operand's eight in flight together (a load inside a lane-dependent branch
     // is followed by the compiler's s_waitcnt vmcnt(0))
-    unsigned ip[4][2];
-    bool ok[4][2];
+    unsigned ip[PT][2];
+    bool ok[PT][2];
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int p = 0; p < PT; ++p)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int y = y0 + 4 * ph + p;
+            const int y = y0 + PT * ph + p;
             ok[p][q] = x < a_wout && y < a_hout && co[q] < a_cout;
             ip[p][q] = ok[p][q] ? (unsigned)(co[q] * hwo + y * a_wout + x) : 0u;
         }
-    f32x4 e0v[4][2], e1v[4][2], prv[4][2];
+    f32x4 e0v[PT][2], e1v[PT][2], prv[PT][2];
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int p = 0; p < PT; ++p)
 #pragma unroll
         for (int q = 0; q < 2; ++q) { e0v[p][q] = z4; e1v[p][q] = z4; prv[p][q] = z4; }
     if (a_pre) {
         const float* b = a_pre + ((size_t)n * a_pre_ctotal + a_pre_coff) * hwo;
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
+        for (int p = 0; p < PT; ++p)
 #pragma unroll
             for (int q = 0; q < 2; ++q) prv[p][q] = *reinterpret_cast<const f32x4*>(b + ip[p][q]);
     }
@@ -263,19 +263,19 @@ __global__ __launch_bounds__(768, 3) void gconvb_kernel(GConvArgs ka, const u32x
     if (a_epi != GEPI_PLAIN) {
         const float* b = a_e0 + ((size_t)n * a_e0_ctotal + a_e0_coff) * hwo;
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
+        for (int p = 0; p < PT; ++p)
 #pragma unroll
             for (int q = 0; q < 2; ++q) e0v[p][q] = *reinterpret_cast<const f32x4*>(b + (ip[p][q] < zsplit ? 0u : ip[p][q] - zsplit));
     }
     if (a_epi == GEPI_GRU) {
         const float* b = a_e1 + ((size_t)n * a_e1_ctotal + a_e1_coff) * hwo;
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
+        for (int p = 0; p < PT; ++p)
 #pragma unroll
             for (int q = 0; q < 2; ++q) e1v[p][q] = *reinterpret_cast<const f32x4*>(b + ip[p][q]);
     }
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int p = 0; p < PT; ++p)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             if (!ok[p][q]) continue;
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(768, 3) void gconvb_kernel(GConvArgs ka, const u32x
                 else if (a_epi == GEPI_ZR && co[q] >= a_split) t *= e0v[p][q][j];
                 v[j] = t * a_out_scale;
             }
-            const int y = y0 + 4 * ph + p;
+            const int y = y0 + PT * ph + p;
             const size_t pix = (size_t)y * a_wout + x;
             // GEPI_ZR: r leaves as r * h, to the second output.  One store through a selected pointer (gconv16.hip's note on two stores)
             float* d = (a_epi == GEPI_ZR && co[q] >= a_split) ? a_out2 + ((size_t)n * a_out2_ctotal + (co[q] - a_split)) * hwo + pix
@@ -300,16 +300,28 @@ __global__ __launch_bounds__(768, 3) void gconvb_kernel(GConvArgs ka, const u32x
         }
 }
 
-template <int KH, int KW>
-int gb_launch(const GConvArgs& a, hipStream_t stream) {
-    using C = GBCfg<KH, KW>;
+template <int KH, int KW, int THT>
+int gb_launch_t(const GConvArgs& a, hipStream_t stream) {
+    using C = GBCfg<KH, KW, THT>;
     int cin = 0;
     for (int s = 0; s < a.nseg; ++s) cin += a.seg[s].c;
     const int tiles_x = ceil_div(a.wout, C::TW), tiles_y = ceil_div(a.hout, C::TH);
     dim3 grid(tiles_x * tiles_y, ceil_div(a.cout, 128), a.n);
-    hipLaunchKernelGGL((gconvb_kernel<KH, KW>), grid, dim3(768), 0, stream, a, reinterpret_cast<const u32x4*>(a.wpkb), tiles_x, cin / 32);
+    hipLaunchKernelGGL((gconvb_kernel<KH, KW, THT>), grid, dim3(768), 0, stream, a, reinterpret_cast<const u32x4*>(a.wpkb), tiles_x, cin / 32);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
+}
+
+// Rows per tile: a launch of a few blocks per CU runs as long as the CU with the most blocks - E-RAFT's z | r conv at batch 4 is 320
+// blocks of 8 rows (two rounds, the second a quarter full) or 640 of 4 rows (three rounds of half the work): the count with the least
+// (rounds x (rows + 2)), the per-block prologue and epilogue counted as two rows (gconv16.hip's launcher does the same)
+template <int KH, int KW>
+int gb_launch(const GConvArgs& a, hipStream_t stream) {
+    static const int th_env = [] { const char* e = getenv("EEM_GCONVB_TH"); return e ? atoi(e) : 0; }();
+    static const int cus = [] { int d = 0, n = 256; hipDeviceProp_t p; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) n = p.multiProcessorCount; return n > 0 ? n : 256; }();
+    const auto cost = [&](int th) { return (float)ceil_div(ceil_div(a.wout, 16) * ceil_div(a.hout, th) * ceil_div(a.cout, 128) * a.n, cus) * (float)(th + 2); };
+    const int th = th_env ? th_env : (cost(4) < cost(8) - 1e-3f ? 4 : 8);
+    return th == 4 ? gb_launch_t<KH, KW, 4>(a, stream) : gb_launch_t<KH, KW, 8>(a, stream);
 }
 
 }  // namespace
@@ -353,7 +365,9 @@ int gconvb_from16_launch(const float* wpk16, int cout, int cin, int taps, float*
 }
 
 bool gconvb_shape(int cout, const int* cs, int nseg, int kh, int kw, int stride) {
-    if (stride != 1 || cout < 32) return false;
+    // (a block multiplies 128 couts: narrower layers - EEMFlow+'s 96 -> 64 -> 32 decoder convs - would idle most of its multiplying waves
+    // while the staging work per tile stays the same; they stay on gconv16.hip)
+    if (stride != 1 || cout < 96) return false;
     if (!((kh == 1 && kw == 1) || (kh == 3 && kw == 3) || (kh == 1 && kw == 5) || (kh == 5 && kw == 1))) return false;
     for (int s = 0; s < nseg; ++s)
         if (cs[s] <= 0 || cs[s] % 32) return false;

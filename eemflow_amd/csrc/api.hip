@@ -86,9 +86,12 @@ extern "C" void eemflow_destroy(eemflow_ctx* c) {
 extern "C" int eemflow_load_weights(eemflow_ctx* c, const float* flat, size_t nfloats, int n_first_channels,
                                     int groups) {
     EEM_REQUIRE(c && flat, "eemflow_load_weights: NULL argument");
-    EEM_REQUIRE(n_first_channels == 5, "only n_first_channels == 5 (num_voxel_bins 5, config/a_meshflow.json) is "
-                                       "built; got %d", n_first_channels);
-    EEM_REQUIRE(groups == 5 || groups == 1, "groups must be 5 (reference default) or 1; got %d", groups);
+    // EEMFlow(config, groups, n_first_channels) (EEMFlow.py:72-75): 5 (num_voxel_bins of config/a_meshflow.json) runs the first layer on
+    // its dedicated kernels; any other count on the generic convolution behind a replicate-pad launch (run_enc_layer)
+    EEM_REQUIRE(n_first_channels >= 1 && n_first_channels <= 64, "n_first_channels must be in [1, 64]; got %d", n_first_channels);
+    // Decoder(in_channels, groups) (EEMFlow.py:37-47): conv2..conv4 are 100 -> 100 convolutions in `groups` groups.  Built: every divisor of
+    // 100 up to 5 - a decoder layer's groups of the three decoders are the jobs of ONE small-grid launch (TAIL_MAX_JOBS = 16)
+    EEM_REQUIRE(groups == 1 || groups == 2 || groups == 4 || groups == 5, "groups must be 1, 2, 4 or 5 (the reference's default); got %d", groups);
     EEM_HIP_CHECK(hipSetDevice(c->device));
     const int per = kDecW / groups;
     // ---- expected flat size
@@ -165,6 +168,12 @@ extern "C" int eemflow_load_weights(eemflow_ctx* c, const float* flat, size_t nf
         c->enc_b[l] = push(cout);
         memcpy(host.data() + c->enc_b[l], p, cout * sizeof(float));
         p += cout;
+    }
+    c->enc0_generic = n_first_channels != 5;
+    if (c->enc0_generic) {                                           // pconv1_1 for gconv.hip: [16][cin0][3][3], the flat vector's first tensor
+        const int cs0[1] = {n_first_channels};
+        c->enc0_gw = push(gconv_packed_floats(16, cs0, 1, 3, 3));
+        gconv_pack(base, 16, cs0, 1, 3, 3, host.data() + c->enc0_gw);
     }
     auto tail = [&](TailW& t, eemflow_ctx::ConvRef& r, int cin, int cout, int ksize, const float* w, const float* b) {
         t.cin = cin; t.cout = cout; t.ksize = ksize;
@@ -308,7 +317,7 @@ extern "C" int eemflow_forward(eemflow_ctx* c, const float* e1, const float* e2,
 
     c->workspace_overwritten();
     if ((rc = ensure_forward_wino(c, batch, st)) != EEM_OK) return rc;          // outside any capture
-    if (!c->use_graph) {
+    if (!c->use_graph || c->enc0_generic) {                           // (the generic first layer pads through the caller's pointers: no io table)
         if ((rc = alloc_workspace(c, s)) != EEM_OK) return rc;
         c->last = s;
         c->have_last = true;

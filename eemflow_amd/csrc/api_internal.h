@@ -10,6 +10,7 @@
 #include "../../include/eemflow_hip.h"
 #include "common.h"
 #include "gconv.h"
+#include "eraft_kernels.h"
 
 // ------------------------------------------------------------------------------- context
 namespace {
@@ -137,6 +138,8 @@ struct eemflow_ctx {
     bool skip_counter_zeroed = false;                    // train_api.hip: the device-side count of skipped optimizer steps
     // inference leaves f13 unwritten when pconv3_3's epilogue pools it (nothing else reads it); the training forward keeps every
     // activation (keep_stage_stores), and eemflow_get_stage("f13") re-runs the layer with stores when the last forward skipped them
+    bool enc0_generic = false;                           // n_first_channels != 5: pconv1_1 = replicate-pad launch + gconv.hip
+    size_t enc0_gw = 0;
     bool keep_stage_stores = false;
     bool f13_skipped = false;
     int frames_in_flight = 1;                            // eemflow_set_frames_in_flight: >= 3 shrinks the persistent encoder grids
@@ -327,6 +330,7 @@ int alloc_workspace_raw(eemflow_ctx* c, const Shape& s) {
         ENS(c->t64[k], B * 64 * g);     ENS(c->t32[k], B * 32 * g);
     }
     ENS(c->flowcat, B * 6 * g);  ENS(c->coarse, B * 2 * g);
+    if (c->enc0_generic) ENS(c->padded, n2 * c->cin0 * (size_t)s.hp * s.wp);
 #undef ENS
     return EEM_OK;
 }
@@ -502,6 +506,29 @@ int run_enc_layer(eemflow_ctx* c, const Shape& s, int li, const float* e1, const
         {ENC_3_1, "enc.pconv3_1 32->64 s2", c->f12.p, c->a3.p, s.h2, s.w2, s.h3, s.w3},
         {ENC_3_2, "enc.pconv3_2 64->64", c->a3.p, c->b3.p, s.h3, s.w3, s.h3, s.w3},
         {ENC_3_3, "enc.pconv3_3 64->64", c->b3.p, c->f13.p, s.h3, s.w3, s.h3, s.w3}};
+    if (li == ENC_1_1 && c->enc0_generic) {
+        // n_first_channels != 5 (EEMFlow.py:72,75): replicate pad of both volumes into one batch (image_utils.py:129-140), then the generic
+        // strided convolution + LeakyReLU
+        const float* padded = prepadded;
+        if (padded == nullptr) {
+            EEM_REQUIRE(io == nullptr, "the generic first layer runs eagerly (no graph io table)");
+            if ((rc = er_pad2_launch(e1, e2, c->padded.p, s.batch * c->cin0, s.in_h, s.in_w, c->pad[0], c->pad[1], c->pad[2], c->pad[3], hk.st)) != EEM_OK) return rc;
+            padded = c->padded.p;
+        }
+        GConvArgs g;
+        memset(&g, 0, sizeof(g));
+        g.nseg = 1;
+        g.seg[0].ptr = padded; g.seg[0].c = c->cin0; g.seg[0].ctotal = c->cin0; g.seg[0].coff = 0;
+        g.wpk = c->arena + c->enc0_gw; g.shift = c->arena + c->enc_b[ENC_1_1];
+        g.zero_page = c->zero_page;
+        g.out = c->a1.p; g.out_ctotal = 16; g.out_coff = 0;
+        g.n = n2; g.hin = s.hp; g.win = s.wp; g.hout = s.h1; g.wout = s.w1; g.cout = 16;
+        g.kh = g.kw = 3; g.stride = 2; g.pad_h = g.pad_w = 1;
+        g.act = GACT_LEAKY; g.epi = GEPI_PLAIN; g.out_scale = 1.f;
+        const double opix = (double)n2 * s.h1 * s.w1;
+        return hk.run("enc.pconv1_1 generic +pad", 2.0 * opix * 16 * c->cin0 * 9, 4.0 * ((double)n2 * s.in_h * s.in_w * c->cin0 + opix * 16),
+                      [&](hipStream_t st) { return gconv_launch(g, st); });
+    }
     {
         const Step& sp = steps[li];
 

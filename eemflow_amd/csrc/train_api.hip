@@ -324,7 +324,7 @@ extern "C" int eemflow_forward_train(eemflow_ctx* c, const float* e1, const floa
                                      int out_h, int out_w, int64_t* serial_out, void* stream) {
     EEM_REQUIRE(c && e1 && e2 && flow_out, "eemflow_forward_train: NULL argument");
     EEM_REQUIRE(c->weights_loaded && c->have_pad, "eemflow_forward_train: load weights and set the image size first");
-    EEM_REQUIRE(c->groups == 5, "eemflow_forward_train: only groups == 5 is built for training");
+    EEM_REQUIRE(c->groups >= 1 && c->groups <= 5, "eemflow_forward_train: groups = %d", c->groups);
     EEM_REQUIRE(batch >= 1 && in_h >= 1 && in_w >= 1 && out_h >= 1 && out_w >= 1, "eemflow_forward_train: bad sizes");
     EEM_HIP_CHECK(hipSetDevice(c->device));
     Shape s;
@@ -359,7 +359,7 @@ extern "C" int eemflow_forward_backward(eemflow_ctx* c, const float* e1, const f
                                         float* grad_out, double* stats_out, void* stream) {
     EEM_REQUIRE(c && e1 && e2 && flow_gt && valid && grad_out && flow_out, "eemflow_forward_backward: NULL argument");
     EEM_REQUIRE(c->weights_loaded && c->have_pad, "eemflow_forward_backward: load weights and set the image size first");
-    EEM_REQUIRE(c->groups == 5, "eemflow_forward_backward: only groups == 5 is built for training");
+    EEM_REQUIRE(c->groups >= 1 && c->groups <= 5, "eemflow_forward_backward: groups = %d", c->groups);
     EEM_HIP_CHECK(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     Shape s;

@@ -184,8 +184,6 @@ class EEMFlow(nn.Module):
         if e1.shape != e2.shape or e1.dim() != 4 or e1.shape[1] != self.n_first_channels:
             raise ValueError(f"expected two (B,{self.n_first_channels},H,W) tensors, got {tuple(e1.shape)} and {tuple(e2.shape)}")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            if self.groups != 5:
-                raise _lib.EEMFlowHipError("EEMFlow.forward under autograd: only groups == 5 has a HIP backward pass")
             flow = _EEMFlowFunction.apply(self, e1, e2, out_size, *self.parameters())
             return (events1, events2), [flow]
         ctx = self._context(e1.device)

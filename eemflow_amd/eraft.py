@@ -30,8 +30,10 @@ class ResidualBlock(nn.Module):
             mk = lambda: nn.BatchNorm2d(planes)
         elif norm_fn == 'instance':
             mk = lambda: nn.InstanceNorm2d(planes)
+        elif norm_fn == 'none':
+            mk = lambda: nn.Sequential()                         # model/extractor.py:36-40
         else:
-            raise ValueError("only norm_fn 'batch' and 'instance' are built (the two E-RAFT uses, eraft.py:57-60)")
+            raise ValueError("norm_fn 'group' is not built ('batch', 'instance' - the two E-RAFT uses, eraft.py:57-60 - and 'none' are)")
         self.norm1, self.norm2 = mk(), mk()
         if not stride == 1:
             self.norm3 = mk()
@@ -50,8 +52,10 @@ class BasicEncoder(nn.Module):
             self.norm1 = nn.BatchNorm2d(64)
         elif norm_fn == 'instance':
             self.norm1 = nn.InstanceNorm2d(64)
+        elif norm_fn == 'none':
+            self.norm1 = nn.Sequential()                         # model/extractor.py:131-132
         else:
-            raise ValueError("only norm_fn 'batch' and 'instance' are built")
+            raise ValueError("norm_fn 'group' is not built ('batch', 'instance' and 'none' are)")
         self.conv1 = nn.Conv2d(n_first_channels, 64, kernel_size=7, stride=2, padding=3)
         self.relu1 = nn.ReLU(inplace=True)
         self.in_planes = 64
@@ -76,6 +80,21 @@ class BasicEncoder(nn.Module):
                   ResidualBlock(dim, dim, self.norm_fn, stride=1))
         self.in_planes = dim
         return nn.Sequential(*layers)
+
+    def forward(self, x):
+        """model/extractor.py:162-190 on the HIP operators (differentiable): a list / tuple of inputs runs as one batch and comes back
+        split (:165-169,186-188).  ERAFT calls the same operator chain (ERAFT._encoder_ops) with its own batching."""
+        from . import ops
+        is_list = isinstance(x, (tuple, list))
+        if is_list:
+            batch_dim = x[0].shape[0]
+            x = torch.cat(x, dim=0)
+        if not x.is_cuda:
+            raise _lib.EEMFlowHipError("BasicEncoder.forward: CUDA (ROCm) tensors required - there is no CPU path")
+        y = ops.conv2d(self.conv2, encoder_ops(self, x.contiguous().float()))
+        if is_list:
+            y = torch.split(y, [batch_dim, batch_dim], dim=0)
+        return y
 
 
 class FlowHead(nn.Module):
@@ -225,27 +244,10 @@ class ERAFT(nn.Module):
 
     # ------------------------------------------------------------------ differentiable route (eemflow_amd/ops.py)
     def _norm(self, norm, x, relu):
-        from . import ops
-        if isinstance(norm, nn.InstanceNorm2d):
-            return ops.InstanceNormReLU.apply(x, relu)
-        if not norm.training:                                    # freeze_bn() (model/eraft.py:69-72): running statistics, no update
-            return ops.BatchNormEvalReLU.apply(x, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.eps, relu)
-        y = ops.BatchNormTrainReLU.apply(x, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.momentum, norm.eps, relu)
-        norm.num_batches_tracked += 1
-        return y
+        return apply_norm(norm, x, relu)
 
     def _encoder_ops(self, enc, x):
-        """BasicEncoder up to (not including) its 1x1 output conv (model/extractor.py:170-185)."""
-        from . import ops
-        y = self._norm(enc.norm1, ops.conv2d(enc.conv1, x), True)
-        for layer in (enc.layer1, enc.layer2, enc.layer3):
-            for blk in layer:                                              # ResidualBlock.forward, model/extractor.py:43-57
-                t = self._norm(blk.norm1, ops.conv2d(blk.conv1, y), True)
-                t = self._norm(blk.norm2, ops.conv2d(blk.conv2, t), True)
-                if blk.downsample is not None:
-                    y = self._norm(blk.norm3, ops.conv2d(blk.downsample[0], y), False)
-                y = ops.AddReLU.apply(y, t)
-        return y
+        return encoder_ops(enc, x)
 
     def _update_ops(self, net, inp, corr, flow):
         """BasicUpdateBlock.forward (model/update.py:97-106)."""
@@ -313,3 +315,39 @@ class ERAFT(nn.Module):
             self._release()
         except Exception:
             pass
+
+
+# ---------------------------------------------------------------------- BasicEncoder's operator chain (module level: BasicEncoder.forward and ERAFT share it)
+def apply_norm(norm, x, relu):
+    """norm + optional ReLU as one HIP operator."""
+    from . import ops
+    if isinstance(norm, nn.InstanceNorm2d):
+        return ops.InstanceNormReLU.apply(x, relu)
+    if not norm.training:                                        # freeze_bn() (model/eraft.py:69-72): running statistics, no update
+        return ops.BatchNormEvalReLU.apply(x, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.eps, relu)
+    y = ops.BatchNormTrainReLU.apply(x, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.momentum, norm.eps, relu)
+    norm.num_batches_tracked += 1
+    return y
+
+
+def conv_norm(conv, norm, x, relu):
+    """conv -> norm -> [ReLU]; norm_fn 'none' is the reference's empty nn.Sequential (model/extractor.py:36-40): the ReLU then rides in the
+    convolution's epilogue."""
+    from . import ops
+    if isinstance(norm, nn.Sequential) and len(norm) == 0:
+        return ops.conv2d(conv, x, act=ops.ACT_RELU if relu else ops.ACT_NONE)
+    return apply_norm(norm, ops.conv2d(conv, x), relu)
+
+
+def encoder_ops(enc, x):
+    """BasicEncoder up to (not including) its 1x1 output conv (model/extractor.py:170-185)."""
+    from . import ops
+    y = conv_norm(enc.conv1, enc.norm1, x, True)
+    for layer in (enc.layer1, enc.layer2, enc.layer3):
+        for blk in layer:                                                  # ResidualBlock.forward, model/extractor.py:43-57
+            t = conv_norm(blk.conv1, blk.norm1, y, True)
+            t = conv_norm(blk.conv2, blk.norm2, t, True)
+            if blk.downsample is not None:
+                y = conv_norm(blk.downsample[0], blk.norm3, y, False)
+            y = ops.AddReLU.apply(y, t)
+    return y

@@ -22,6 +22,8 @@ FLOAT = torch.float32
 def _norm(x, sd, prefix, norm_fn, training=False):
     """norm_fn 'instance': InstanceNorm2d(affine=False); 'batch': BatchNorm2d running stats (eval)
     or batch stats (training) - model/extractor.py:19-41,123-133."""
+    if norm_fn == "none":
+        return x                                               # nn.Sequential() - model/extractor.py:36-40,131-132
     if norm_fn == "instance":
         return F.instance_norm(x, eps=1e-5)
     if norm_fn == "batch":

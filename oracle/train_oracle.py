@@ -26,10 +26,10 @@ def sequence_loss(flow_preds, flow_gt, valid, gamma=0.8, max_flow=MAX_FLOW):
     return loss, metrics
 
 
-def loss_and_grads(sd, events1, events2, flow_gt, valid, image_size=None, gamma=0.8, out_size=None):
+def loss_and_grads(sd, events1, events2, flow_gt, valid, image_size=None, gamma=0.8, out_size=None, groups=5):
     """Forward (train-mode shapes), loss, and d loss / d parameter for every tensor of the state dict."""
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    flow, _ = O.eemflow_forward(params, events1, events2, image_size=image_size, out_size=out_size)
+    flow, _ = O.eemflow_forward(params, events1, events2, image_size=image_size, out_size=out_size, groups=groups)
     loss, metrics = sequence_loss([flow], flow_gt, valid, gamma)
     loss.backward()
     return float(loss), metrics, {k: v.grad.detach() for k, v in params.items()}, flow.detach()

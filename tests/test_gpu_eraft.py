@@ -217,6 +217,29 @@ def test_flow_init_and_twelve_iterations():
     assert len(preds) == 12 and maxerr(preds[-1], ref[-1]) < FLOW_TOL
 
 
+@pytest.mark.parametrize("norm_fn", ["none", "instance", "batch"])
+def test_basic_encoder_standalone_forward(norm_fn):
+    """BasicEncoder(output_dim, norm_fn, dropout=0, n_first_channels).forward (model/extractor.py:119-190) on its own - the three norm
+    settings built here ('none' = the reference's empty nn.Sequential; 'group' raises), a list input run as one batch and split again -
+    against the oracle, with gradients flowing (the operator-level autograd route)."""
+    from eemflow_amd.eraft import BasicEncoder
+    torch.manual_seed(5)
+    enc = BasicEncoder(output_dim=96, norm_fn=norm_fn, dropout=0.0, n_first_channels=5).to(DEV).eval()
+    sd = {k: v.detach().cpu().float() for k, v in enc.state_dict().items()}
+    a, b = (torch.from_numpy(x) for x in synthetic_voxel_pair(9, 2, 128, 160))
+    ya, yb = enc([a.to(DEV), b.to(DEV)])
+    ra, rb = O.basic_encoder(sd, "", [a, b], norm_fn)
+    assert ya.shape == (2, 96, 16, 20)
+    scale = float(ra.abs().max())
+    assert maxerr(ya, ra) < 2e-4 * max(scale, 1.0) and maxerr(yb, rb) < 2e-4 * max(scale, 1.0)
+    single = enc(a.to(DEV))
+    assert maxerr(single, O.basic_encoder(sd, "", a, norm_fn)) < 2e-4 * max(scale, 1.0)
+    single.square().mean().backward()
+    assert enc.conv1.weight.grad is not None and float(enc.conv1.weight.grad.abs().max()) > 0
+    with pytest.raises(ValueError):
+        BasicEncoder(norm_fn="group")
+
+
 def test_errors():
     net, _ = make_net(1)
     with pytest.raises(AttributeError):

@@ -239,6 +239,76 @@ def test_reload_after_a_skipped_step_restarts_the_skip_count():
     assert float((got - ref.detach()).abs().max()) < 2e-6
 
 
+@pytest.mark.parametrize("groups", [1, 2, 4])
+def test_decoder_groups_other_than_five(groups):
+    """EEMFlow(config, groups=g) (EEMFlow.py:72, Decoder(69, groups) :37-47): every divisor of 100 up to the reference's default 5 -
+    inference against the oracle, and loss + all gradient tensors of the fused training step against torch autograd through the oracle."""
+    b, h, w = 2, 128, 192
+    sd = seeded_state_dict(71, groups=groups)
+    net = EEMFlow("", groups=groups, n_first_channels=5)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net = net.to(DEV)
+    tsd = O.to_torch_sd(sd)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(72, b, h, w))
+    gt, valid = (torch.from_numpy(a) for a in synthetic_gt(73, b, h, w))
+    net.eval()
+    with torch.no_grad():
+        flow = net(e1.to(DEV), e2.to(DEV))[1][0].cpu()
+        ref, _ = O.eemflow_forward(tsd, e1, e2, groups=groups)
+    assert float((flow - ref).abs().max()) < 1e-4
+    net.train()
+    loss, _, tflow, flat = run_grads(net, e1, e2, gt, valid)
+    rloss, _, rgrads, rflow = T.loss_and_grads(tsd, e1, e2, gt, valid, groups=groups)
+    assert abs(loss - rloss) < 1e-5 and float((tflow - rflow).abs().max()) < 1e-4
+    grads = split_flat(flat, tsd)
+    errs = sorted(((rel_err(grads[k], rgrads[k]), k) for k in tsd), reverse=True)
+    assert all(e < 3e-3 for e, _ in errs[2:]), errs[:4]            # (one LeakyReLU unit at 0 may move one layer's pair: see above)
+    assert errs[0][0] < 8e-3, errs[:2]
+    # the reference's own training statements through autograd (EEMFlow.forward as a torch.autograd.Function) give the same gradients
+    net.zero_grad()
+    from eemflow_amd.train import sequence_loss
+    out = net(e1.to(DEV), e2.to(DEV))[1]
+    l2, _ = sequence_loss(out, gt.to(DEV), valid.to(DEV), 0.8)
+    l2.backward()
+    named = dict(net.named_parameters())
+    worst = max(rel_err(named[k].grad, grads[k]) for k in tsd)
+    assert worst < 1e-5, worst
+
+
+@pytest.mark.parametrize("cin", [3, 15])
+def test_n_first_channels_other_than_five(cin):
+    """EEMFlow(config, n_first_channels=c) (EEMFlow.py:72,75; EEMFlow+'s data configuration feeds 15 bins): pconv1_1 on the generic
+    convolution behind a replicate-pad launch - inference against the oracle (an image size that pads on every side but the top), and the
+    fused training step's loss and gradients against torch autograd through the oracle."""
+    b, h, w = 2, 100, 150
+    sd = seeded_state_dict(81, n_first_channels=cin)
+    net = EEMFlow("", groups=5, n_first_channels=cin)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net = net.to(DEV)
+    tsd = O.to_torch_sd(sd)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(82, b, h, w, bins=cin))
+    gt, valid = (torch.from_numpy(a) for a in synthetic_gt(83, b, h, w))
+    net.eval()
+    with torch.no_grad():
+        flow = net(e1.to(DEV), e2.to(DEV))[1][0].cpu()
+        flow2 = net(e1.to(DEV), e2.to(DEV))[1][0].cpu()
+        ref, st = O.eemflow_forward(tsd, e1, e2, keep=True)
+    assert torch.equal(flow, flow2)
+    assert float((net.stage("f11")[:b].cpu() - st["f11"]).abs().max()) < 1e-4
+    assert float((flow - ref).abs().max()) < 1e-4
+    net.train()
+    loss, _, tflow, flat = run_grads(net, e1, e2, gt, valid)
+    rloss, _, rgrads, rflow = T.loss_and_grads(tsd, e1, e2, gt, valid)
+    assert abs(loss - rloss) < 1e-5 and float((tflow - rflow).abs().max()) < 1e-4
+    grads = split_flat(flat, tsd)
+    errs = sorted(((rel_err(grads[k], rgrads[k]), k) for k in tsd), reverse=True)
+    assert all(e < 3e-3 for e, _ in errs[2:]), errs[:4]
+    assert errs[0][0] < 8e-3, errs[:2]
+    assert rel_err(grads["pconv1_1.0.weight"], rgrads["pconv1_1.0.weight"]) < 3e-3
+
+
 def test_out_mesh_size_training():
     net, sd = make_net(29, out_mesh_size=True)
     net.change_imagesize((128, 128))

@@ -228,12 +228,12 @@ def test_basic_encoder_standalone_forward(norm_fn):
     sd = {k: v.detach().cpu().float() for k, v in enc.state_dict().items()}
     a, b = (torch.from_numpy(x) for x in synthetic_voxel_pair(9, 2, 128, 160))
     ya, yb = enc([a.to(DEV), b.to(DEV)])
-    ra, rb = O.basic_encoder(sd, "", [a, b], norm_fn)
+    ra, rb = R.basic_encoder(sd, "", [a, b], norm_fn)
     assert ya.shape == (2, 96, 16, 20)
     scale = float(ra.abs().max())
     assert maxerr(ya, ra) < 2e-4 * max(scale, 1.0) and maxerr(yb, rb) < 2e-4 * max(scale, 1.0)
     single = enc(a.to(DEV))
-    assert maxerr(single, O.basic_encoder(sd, "", a, norm_fn)) < 2e-4 * max(scale, 1.0)
+    assert maxerr(single, R.basic_encoder(sd, "", a, norm_fn)) < 2e-4 * max(scale, 1.0)
     single.square().mean().backward()
     assert enc.conv1.weight.grad is not None and float(enc.conv1.weight.grad.abs().max()) > 0
     with pytest.raises(ValueError):

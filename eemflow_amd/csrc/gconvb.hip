@@ -437,7 +437,7 @@ bool gconvb_supported(const GConvArgs& a) {
     if ((size_t)a.cout * a.hin * a.win >= (1u << 30) || (size_t)32 * a.hin * a.win * 4 >= (1u << 31)) return false;
     // large tiles (128 pixels x 64 couts): launches that fill the chip with them; the others stay on gconv16.hip
     const char* mb = getenv("EEM_GCONVB_MINBLK");                 // (read per call, like the switch above: the tests run small shapes through it)
-    const long min_blk = mb ? atol(mb) : 128L;
+    const long min_blk = mb ? atol(mb) : 64L;
     const long blocks = (long)ceil_div(a.wout, 16) * ceil_div(a.hout, 8) * ceil_div(a.cout, 128) * a.n;
     return blocks >= min_blk;
 }

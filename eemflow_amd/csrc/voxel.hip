@@ -145,7 +145,7 @@ struct VoxJob {
     const double* ev;
     long n;
     unsigned* run_start;
-    u32x4* recs;
+    unsigned* recs;          // 12-byte records {pixel-in-band | bin << 16, left vote, right vote}, a slab of VT * EPT per binning block
     long long* idx_left;
     long long* idx_right;
     float* grid;
@@ -164,12 +164,12 @@ __global__ __launch_bounds__(VT) void vox_bin_kernel(VoxJobs jobs, int bins, int
     const double* __restrict__ ev = J.ev;
     const long n = J.n;
     unsigned* __restrict__ run_start = J.run_start;
-    u32x4* __restrict__ recs = J.recs;
     long long* __restrict__ idx_left = J.idx_left;
     long long* __restrict__ idx_right = J.idx_right;
     __shared__ unsigned hist[VT];
     __shared__ unsigned lpos[VT];
     __shared__ unsigned sh[VT / 64];
+    extern __shared__ __attribute__((aligned(16))) unsigned stage[];   // the slab as it goes to memory: 3 words per record
     const int tid = threadIdx.x;
     hist[tid] = 0;
     __syncthreads();
@@ -214,18 +214,21 @@ __global__ __launch_bounds__(VT) void vox_bin_kernel(VoxJobs jobs, int bins, int
     lpos[tid] = start;
     if (tid <= pl.nb) run_start[(size_t)blockIdx.x * (pl.nb + 1) + tid] = start;
     __syncthreads();
-    u32x4* slab = recs + (size_t)blockIdx.x * (VT * EPT);
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
         if (band[k] != 0xffffffffu) {
-            u32x4 r;
+            unsigned* r = stage + 3u * (lpos[band[k]] + rank[k]);
             r[0] = key[k];
             r[1] = __float_as_uint(vl[k]);
             r[2] = __float_as_uint(vr[k]);
-            r[3] = 0;
-            slab[lpos[band[k]] + rank[k]] = r;
         }
     }
+    __syncthreads();
+    // the sorted slab leaves as whole 16-byte pieces of consecutive threads (scattered 12-byte stores ran at half the rate)
+    const unsigned words = 3u * lpos[pl.nb];
+    u32x4* slab = reinterpret_cast<u32x4*>(J.recs + (size_t)blockIdx.x * (VT * EPT) * 3);
+    const u32x4* st4 = reinterpret_cast<const u32x4*>(stage);
+    for (unsigned i = tid; i * 4 < words; i += VT) slab[i] = st4[i];   // (the last piece may carry up to three stale words: nobody reads them)
 }
 
 // ------------------------------------------------------------------------------------------------ moments
@@ -286,53 +289,74 @@ __device__ __forceinline__ VoxNorm vox_final(const VoxSums* __restrict__ acc, in
 enum { VOX_BAND_RAW = 0, VOX_BAND_MOMENTS = 1, VOX_BAND_NORMALISED = 2 };
 
 template <int BT>
-__global__ __launch_bounds__(BT) void vox_band_kernel(VoxJobs jobs, int slab, int bins, VoxPlan pl, int vec4, int with_moments, int mode) {
+__global__ __launch_bounds__(BT, BT / 128) void vox_band_kernel(VoxJobs jobs, int slab, int bins, VoxPlan pl, int vec4, int with_moments, int mode, int sgs) {
     const VoxJob& J = jobs.j[blockIdx.y];
-    const u32x4* __restrict__ recs = J.recs;
+    const unsigned* __restrict__ recs = J.recs;
     const unsigned* __restrict__ run_start = J.run_start;
     const int nblk = J.nblk;
     float* __restrict__ grid = J.grid;
     VoxSums* __restrict__ acc = with_moments ? J.acc : nullptr;
-    extern __shared__ __attribute__((aligned(16))) float band[];   // [bins][band_px]
+    // [bins][band_px] fp64 cells: the LDS fp32 add runs at a third of a lane per clock and CU on this chip, the fp64 add 8 - 20 times faster
+    // (profiles/r04_lds_atomics.txt); the sum of a cell's votes is rounded to fp32 once, when the band leaves
+    extern __shared__ __attribute__((aligned(16))) double band[];
     __shared__ double sh3[BT / 64 * 3];
-    __shared__ unsigned pre[BT + 1];                               // exclusive prefix of the run lengths of <= BT slabs
-    __shared__ unsigned first[BT];                                 // record index of each run's first vote
-    __shared__ unsigned shs[BT / 64];
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     const int bpx = pl.band_px;
     const unsigned p0 = (unsigned)b * (unsigned)bpx;
     const int npx = min(bpx, (int)(pl.hw - p0));
     const int nfl = bins * bpx;
-    for (int i = tid * 4; i < nfl; i += BT * 4) *reinterpret_cast<f32x4*>(band + i) = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int g0 = 0; g0 < nblk; g0 += BT) {
-        const int sidx = g0 + tid;
-        unsigned len = 0, start = 0;
-        if (sidx < nblk) {
-            const unsigned* row = run_start + (size_t)sidx * (pl.nb + 1) + b;
-            start = row[0];
-            len = row[1] - start;
-            start += (unsigned)sidx * (unsigned)slab;
+    for (int i = tid * 2; i < nfl; i += BT * 2) *reinterpret_cast<f64x2*>(band + i) = f64x2{0.0, 0.0};
+    __syncthreads();
+    // A run = this band's votes of one binning block: `len` consecutive 12-byte records.  2^sgs adjacent lanes share a run (sized so
+    // that nearly every run is one record per lane): a wave's load then touches a few runs' lines instead of 64 unrelated ones - with a
+    // thread per run (and, before, a thread per vote with a binary search for its run) the address unit's one line per clock was the
+    // kernel: 24 of 35 us.  Eight runs per thread are in flight: all their table entries, then all their first records, then the adds.
+    constexpr int NP = 8;
+    typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+    const int sub = tid & ((1 << sgs) - 1);
+    const int rpp = BT >> sgs;                                     // runs per pass of the block
+    // both streams as buffer loads with 32-bit offsets (a run past the last binning block and a lane past its run's end read zeros:
+    // no branches around the loads, all of a phase in flight together)
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(run_start), (short)0, nblk * (pl.nb + 1) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(recs), (short)0, (unsigned)nblk * (unsigned)slab * 12u, 0x00020000);
+    constexpr int kOut = 0x7ffffff0;
+    for (int g0 = 0; g0 < nblk; g0 += NP * rpp) {
+        unsigned st[NP];
+        int ln[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int sidx = g0 + q * rpp + (tid >> sgs);
+            const int off = sidx < nblk ? (sidx * (pl.nb + 1) + b) * 4 : kOut;
+            st[q] = __builtin_amdgcn_raw_buffer_load_b32(trs, off, 0, 0);
+            ln[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(trs, off, 4, 0);
         }
-        __syncthreads();                                           // LDS zeroed / previous group consumed
-        const unsigned ex = block_exscan<BT>(len, shs);
-        pre[tid] = ex;
-        first[tid] = start;
-        if (tid == BT - 1) pre[BT] = ex + len;
-        __syncthreads();
-        const unsigned total = pre[BT];
-        const int nrun = min(BT, nblk - g0);
-        for (unsigned r = tid; r < total; r += BT) {
-            int lo = 0, hi = nrun;                                 // the run holding vote r: largest i with pre[i] <= r
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (pre[mid] <= r) lo = mid; else hi = mid;
+        u32x3 r0[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int sidx = g0 + q * rpp + (tid >> sgs);
+            ln[q] -= (int)st[q];
+            st[q] = ((unsigned)sidx * (unsigned)slab + st[q] + (unsigned)sub) * 12u;     // byte offset of this lane's first record
+            r0[q] = __builtin_amdgcn_raw_buffer_load_b96(rrs, sub < ln[q] ? (int)st[q] : kOut, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            if (sub < ln[q]) {
+                const int tl = (int)(r0[q][0] >> 16);
+                double* cell = band + tl * bpx + (int)(r0[q][0] & 0xffffu);
+                atomicAdd(cell, (double)__uint_as_float(r0[q][1]));
+                if (tl + 1 < bins) atomicAdd(cell + bpx, (double)__uint_as_float(r0[q][2]));
             }
-            const u32x4 rec = recs[first[lo] + (r - pre[lo])];
-            const int tl = (int)(rec[0] >> 16);
-            float* cell = band + tl * bpx + (int)(rec[0] & 0xffffu);
-            atomicAdd(cell, __uint_as_float(rec[1]));
-            if (tl + 1 < bins) atomicAdd(cell + bpx, __uint_as_float(rec[2]));
+        }
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {                             // the rare longer runs
+            for (int k = sub + (1 << sgs); k < ln[q]; k += 1 << sgs) {
+                const u32x3 r = __builtin_amdgcn_raw_buffer_load_b96(rrs, (int)(st[q] + (unsigned)(k - sub) * 12u), 0, 0);
+                const int tl = (int)(r[0] >> 16);
+                double* cell = band + tl * bpx + (int)(r[0] & 0xffffu);
+                atomicAdd(cell, (double)__uint_as_float(r[1]));
+                if (tl + 1 < bins) atomicAdd(cell + bpx, (double)__uint_as_float(r[2]));
+            }
         }
     }
     __syncthreads();
@@ -340,7 +364,7 @@ __global__ __launch_bounds__(BT) void vox_band_kernel(VoxJobs jobs, int slab, in
         double c = 0.0, sm = 0.0, q = 0.0;
         for (int bin = 0; bin < bins; ++bin)
             for (int i = tid; i < npx; i += BT) {
-                const float v = band[bin * bpx + i];
+                const float v = (float)band[bin * bpx + i];
                 if (v != 0.f) { c += 1.0; sm += (double)v; q += (double)v * (double)v; }
             }
         vox_store_sums(c, sm, q, acc + b, sh3);
@@ -354,17 +378,18 @@ __global__ __launch_bounds__(BT) void vox_band_kernel(VoxJobs jobs, int slab, in
     }
     auto fin = [&](float v) { return (shift && v != 0.f) ? (scale ? (v - mean) / sd : (v - mean)) : v; };
     for (int bin = 0; bin < bins; ++bin) {
-        const float* src = band + bin * bpx;
+        const double* src = band + bin * bpx;
         float* dst = grid + (size_t)bin * pl.hw + p0;
         if (vec4) {
             for (int i = tid * 4; i < npx; i += BT * 4) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+                const f64x2 lo = *reinterpret_cast<const f64x2*>(src + i), hi = *reinterpret_cast<const f64x2*>(src + i + 2);
+                f32x4 v = {(float)lo[0], (float)lo[1], (float)hi[0], (float)hi[1]};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = fin(v[q]);
                 *reinterpret_cast<f32x4*>(dst + i) = v;
             }
         } else {
-            for (int i = tid; i < npx; i += BT) dst[i] = fin(src[i]);
+            for (int i = tid; i < npx; i += BT) dst[i] = fin((float)src[i]);
         }
     }
 }
@@ -437,7 +462,15 @@ constexpr long VOX_MAX_BLOCKS = 4096;                              // 33.5 M eve
 
 template <int EPT>
 void launch_bin(const VoxJobs& jobs, int njobs, long nblk_max, int bins, int h, int w, const VoxPlan& pl, hipStream_t stream) {
-    hipLaunchKernelGGL((vox_bin_kernel<EPT>), dim3((unsigned)nblk_max, njobs), dim3(VT), 0, stream, jobs, bins, h, w, pl);
+    constexpr int stage_bytes = VT * EPT * 12;
+    if (stage_bytes > 48 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            (void)hipFuncSetAttribute((const void*)vox_bin_kernel<EPT>, hipFuncAttributeMaxDynamicSharedMemorySize, stage_bytes);
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL((vox_bin_kernel<EPT>), dim3((unsigned)nblk_max, njobs), dim3(VT), stage_bytes, stream, jobs, bins, h, w, pl);
 }
 
 bool make_plan(int64_t n, int bins, int h, int w, const double* events, VoxPlan* pl, int* lds_bytes) {
@@ -448,17 +481,17 @@ bool make_plan(int64_t n, int bins, int h, int w, const double* events, VoxPlan*
     // 18 KiB of LDS per band and 256-thread blocks: a band block fits beside a resident encoder block of another stream (99-132 KiB of
     // LDS, one wave per SIMD) instead of waiting for a whole CU, and ~1000 small blocks hide each other's latency chain (run table ->
     // scan -> records -> LDS adds -> moments); EEM_VOX_BAND_FLOATS=12288 gives the former 48 KiB bands of 1024 threads
-    static const long band_floats = [] { const char* b = getenv("EEM_VOX_BAND_FLOATS"); const long v = b ? atol(b) : 0; return v >= 256 ? v : 4608L; }();
+    static const long band_floats = [] { const char* b = getenv("EEM_VOX_BAND_FLOATS"); const long v = b ? atol(b) : 0; return v >= 256 ? v : 9216L; }();
     long band_px = (band_floats / bins) & ~3L;
     if (band_px < 64) band_px = 64;
     const long spread = ((hw + 511) / 512 + 3) & ~3L;              // small images: still a few hundred bands
     if (band_px > spread) band_px = spread < 64 ? 64 : spread;
     if ((hw + band_px - 1) / band_px > VT - 1) band_px = ((hw + VT - 2) / (VT - 1) + 3) & ~3L;   // thread nb holds the record count
-    if (band_px * bins > 38400 || band_px > 65535) return false;   // 150 KiB of LDS beside the static tables, 16-bit pixel-in-band
+    if (band_px * bins > 19200 || band_px > 65535) return false;   // 150 KiB of LDS (fp64 cells) beside the static tables, 16-bit pixel-in-band
     pl->band_px = (int)band_px;
     pl->nb = (int)((hw + band_px - 1) / band_px);
     pl->hw = (unsigned)hw;
-    *lds_bytes = (int)(band_px * bins * 4);
+    *lds_bytes = (int)(band_px * bins * 8);
     return true;
 }
 
@@ -508,8 +541,8 @@ int voxel_launch_jobs(int njobs, const double* const* events, const int64_t* n, 
             const long slots = ((long)n[k] + 8191) / 8192 * 8192 + 8192;
             VoxJob& J = jobs.j[k];
             J.ev = events[k]; J.n = (long)n[k];
-            J.recs = reinterpret_cast<u32x4*>(sc + 1);
-            J.run_start = reinterpret_cast<unsigned*>(J.recs + slots);
+            J.recs = reinterpret_cast<unsigned*>(sc + 1);
+            J.run_start = J.recs + slots * 3;                          // (the scratch is sized at 16 bytes per slot)
             J.idx_left = (long long*)idx_left[k]; J.idx_right = (long long*)idx_right[k];
             J.grid = grid[k]; J.acc = sc->acc;
             J.nblk = (int)vox_blocks((long)n[k], ept);
@@ -536,11 +569,16 @@ int voxel_launch_jobs(int njobs, const double* const* events, const int64_t* n, 
         // read + write of the whole grid - a moments-only launch, then a launch that stores the bands already normalised
         const char* tp = getenv("EEM_VOX_TWOPASS");                  // read per call: the tests run both forms in one process
         const long two_pass_ratio = tp ? atol(tp) : 0L;
+        // lanes per run: the smallest power of two >= 1.7 x the mean run length (slab events / bands), 4 .. 64
+        int sgs = 2;
+        while (sgs < 6 && (1 << sgs) * 10L * pl.nb < 17L * VT * ept) ++sgs;
         auto band = [&](int with_moments, int mode) {
             if (lds <= 24 * 1024)
-                hipLaunchKernelGGL(vox_band_kernel<256>, dim3(pl.nb, njobs), dim3(256), lds, stream, jobs, VT * ept, bins, pl, vec4, with_moments, mode);
+                hipLaunchKernelGGL(vox_band_kernel<256>, dim3(pl.nb, njobs), dim3(256), lds, stream, jobs, VT * ept, bins, pl, vec4, with_moments, mode, sgs);
+            else if (lds <= 40 * 1024)
+                hipLaunchKernelGGL(vox_band_kernel<512>, dim3(pl.nb, njobs), dim3(512), lds, stream, jobs, VT * ept, bins, pl, vec4, with_moments, mode, sgs);
             else
-                hipLaunchKernelGGL(vox_band_kernel<VT>, dim3(pl.nb, njobs), dim3(VT), lds, stream, jobs, VT * ept, bins, pl, vec4, with_moments, mode);
+                hipLaunchKernelGGL(vox_band_kernel<VT>, dim3(pl.nb, njobs), dim3(VT), lds, stream, jobs, VT * ept, bins, pl, vec4, with_moments, mode, sgs);
         };
         if (normalize && two_pass_ratio > 0 && (long)nmax * two_pass_ratio <= total) {
             band(1, (int)VOX_BAND_MOMENTS);

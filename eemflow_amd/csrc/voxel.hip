@@ -109,9 +109,23 @@ __global__ __launch_bounds__(256) void voxel_scatter_kernel(const double* __rest
 // ------------------------------------------------------------------------------------------------ block helpers
 constexpr int VT = 1024;                 // threads per block of the binned path (also the maximum number of bands)
 
+// sum over the wave, in every lane: the four steps inside a 16-lane row are DPP moves (VALU), only the two across rows go through
+// ds_bpermute - with all six as __shfl_xor a 3-value reduction was 36 dependent LDS round trips (~1.5 us in front of every
+// moments store and every normalisation)
+template <int CTRL>
+__device__ __forceinline__ double dpp_add64(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return v + __hiloint2double(hi2, lo2);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    v = dpp_add64<0xB1>(v);                     // quad_perm [1,0,3,2]
+    v = dpp_add64<0x4E>(v);                     // quad_perm [2,3,0,1]
+    v = dpp_add64<0x141>(v);                    // row_half_mirror
+    v = dpp_add64<0x140>(v);                    // row_mirror
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
     return v;
 }
 
@@ -243,7 +257,7 @@ __device__ __forceinline__ void vox_store_sums(double c, double s, double q, Vox
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nw = blockDim.x >> 6;
     if (lane == 0) { sh3[wave * 3] = c; sh3[wave * 3 + 1] = s; sh3[wave * 3 + 2] = q; }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (not __syncthreads: that would wait for the band's stores in flight too)
     if (threadIdx.x == 0) {
         c = s = q = 0.0;
         for (int k = 0; k < nw; ++k) { c += sh3[k * 3]; s += sh3[k * 3 + 1]; q += sh3[k * 3 + 2]; }
@@ -360,16 +374,6 @@ __global__ __launch_bounds__(BT, BT / 128) void vox_band_kernel(VoxJobs jobs, in
         }
     }
     __syncthreads();
-    if (acc && mode != VOX_BAND_NORMALISED) {                      // before the stores: the barrier inside would wait for them
-        double c = 0.0, sm = 0.0, q = 0.0;
-        for (int bin = 0; bin < bins; ++bin)
-            for (int i = tid; i < npx; i += BT) {
-                const float v = (float)band[bin * bpx + i];
-                if (v != 0.f) { c += 1.0; sm += (double)v; q += (double)v * (double)v; }
-            }
-        vox_store_sums(c, sm, q, acc + b, sh3);
-    }
-    if (mode == VOX_BAND_MOMENTS) return;
     float mean = 0.f, sd = 1.f;
     bool scale = false, shift = false;
     if (mode == VOX_BAND_NORMALISED) {
@@ -377,6 +381,11 @@ __global__ __launch_bounds__(BT, BT / 128) void vox_band_kernel(VoxJobs jobs, in
         mean = nm.mean; sd = nm.sd; scale = nm.scale; shift = nm.any;
     }
     auto fin = [&](float v) { return (shift && v != 0.f) ? (scale ? (v - mean) / sd : (v - mean)) : v; };
+    // one pass over the band: every cell is rounded to fp32 once, counted into the moments and stored
+    const bool want_sums = acc && mode != VOX_BAND_NORMALISED;
+    const bool store = mode != VOX_BAND_MOMENTS;
+    double c = 0.0, sm = 0.0, sq = 0.0;
+    auto note = [&](float v) { if (v != 0.f) { c += 1.0; sm += (double)v; sq += (double)v * (double)v; } };
     for (int bin = 0; bin < bins; ++bin) {
         const double* src = band + bin * bpx;
         float* dst = grid + (size_t)bin * pl.hw + p0;
@@ -385,13 +394,18 @@ __global__ __launch_bounds__(BT, BT / 128) void vox_band_kernel(VoxJobs jobs, in
                 const f64x2 lo = *reinterpret_cast<const f64x2*>(src + i), hi = *reinterpret_cast<const f64x2*>(src + i + 2);
                 f32x4 v = {(float)lo[0], (float)lo[1], (float)hi[0], (float)hi[1]};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = fin(v[q]);
-                *reinterpret_cast<f32x4*>(dst + i) = v;
+                for (int q = 0; q < 4; ++q) { note(v[q]); v[q] = fin(v[q]); }
+                if (store) *reinterpret_cast<f32x4*>(dst + i) = v;
             }
         } else {
-            for (int i = tid; i < npx; i += BT) dst[i] = fin((float)src[i]);
+            for (int i = tid; i < npx; i += BT) {
+                const float v = (float)src[i];
+                note(v);
+                if (store) dst[i] = fin(v);
+            }
         }
     }
+    if (want_sums) vox_store_sums(c, sm, sq, acc + b, sh3);
 }
 
 // ------------------------------------------------------------------------------------------------ 4. normalisation

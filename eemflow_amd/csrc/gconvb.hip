@@ -312,16 +312,29 @@ int gb_launch_t(const GConvArgs& a, hipStream_t stream) {
     return EEM_OK;
 }
 
-// Rows per tile: a launch of a few blocks per CU runs as long as the CU with the most blocks - E-RAFT's z | r conv at batch 4 is 320
-// blocks of 8 rows (two rounds, the second a quarter full) or 640 of 4 rows (three rounds of half the work): the count with the least
-// (rounds x (rows + 2)), the per-block prologue and epilogue counted as two rows (gconv16.hip's launcher does the same)
+// Rows per tile (2, 4, 6 or 8): a launch of a few blocks per CU runs as long as the CU with the most blocks - E-RAFT's z | r conv at batch 4
+// is 320 blocks of 8 rows (two rounds, the second a quarter full), 400 of 6 (two rounds of 3/4 the work) or 640 of 4 (three rounds of half
+// the work); its 128-cout convs are 160 blocks of 8 rows on 256 CUs or 200 of 6.  The count with the least (rounds x (rows + 2)), the
+// per-block prologue and epilogue counted as two rows (anything from one to six rows gives the same frame rates): E-RAFT 640x480 x 12
+// batch 4 245 -> 256 frames/s against tiles of 4 / 8 rows only, batch 1 162 -> 165; every forced height is slower than the choice
+// (EEM_GCONVB_TH = 2 / 4 / 6 / 8: 208 / 235 / 249 / 243 at batch 4).
 template <int KH, int KW>
 int gb_launch(const GConvArgs& a, hipStream_t stream) {
     static const int th_env = [] { const char* e = getenv("EEM_GCONVB_TH"); return e ? atoi(e) : 0; }();
     static const int cus = [] { int d = 0, n = 256; hipDeviceProp_t p; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) n = p.multiProcessorCount; return n > 0 ? n : 256; }();
     const auto cost = [&](int th) { return (float)ceil_div(ceil_div(a.wout, 16) * ceil_div(a.hout, th) * ceil_div(a.cout, 128) * a.n, cus) * (float)(th + 2); };
-    const int th = th_env ? th_env : (cost(4) < cost(8) - 1e-3f ? 4 : 8);
-    return th == 4 ? gb_launch_t<KH, KW, 4>(a, stream) : gb_launch_t<KH, KW, 8>(a, stream);
+    int th = th_env;
+    if (th != 2 && th != 4 && th != 6 && th != 8) {
+        th = 8;
+        for (int t = 6; t >= 2; t -= 2)
+            if (cost(t) < cost(th) - 1e-3f) th = t;
+    }
+    switch (th) {
+        case 2: return gb_launch_t<KH, KW, 2>(a, stream);
+        case 4: return gb_launch_t<KH, KW, 4>(a, stream);
+        case 6: return gb_launch_t<KH, KW, 6>(a, stream);
+        default: return gb_launch_t<KH, KW, 8>(a, stream);
+    }
 }
 
 }  // namespace

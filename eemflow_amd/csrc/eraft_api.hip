@@ -75,6 +75,11 @@ struct eraft_ctx {
     float* trash = nullptr;        // 1 KB sink for the Winograd kernel's out-of-image stores
     double* nstat = nullptr;       // per-chunk sums of the large-plane instance norm (er_instnorm_launch)
     size_t nstat_cap = 0;
+    // independent branches of the forward on a context-owned side stream (fork / join by events): the context network beside the feature
+    // network and the correlation volume, convf1 -> convf2 beside convc1 -> convc2, the flow head's last conv beside the mask head's
+    hipStream_t side = nullptr;
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    Buf s2[5];                     // the context network's own activations (the feature network runs at the same time)
     bool alt_corr = false;         // eraft_set_alternate_corr: correlation features on the fly, no all-pairs volume
     Buf f2l[3];                    // avg-pooled fmap2, levels 1..3 (alt_corr)
     bool stages_valid = false;
@@ -247,9 +252,10 @@ int run_f4(eraft_ctx* c, const Layer& L, const float* x, int n, int h, int w, fl
 }
 
 // BasicEncoder forward on `n` images [n][cin0][hp][wp]; result of the residual stack in *feat ([n][128][hp/8][wp/8]).
-int run_encoder(eraft_ctx* c, const Encoder& E, const float* x, int n, int cin0, int hp, int wp, float** feat, hipStream_t st) {
+int run_encoder(eraft_ctx* c, const Encoder& E, const float* x, int n, int cin0, int hp, int wp, float** feat, hipStream_t st, Buf* sc = nullptr) {
     int rc;
-    float* X = c->s[0].p; float* R = c->s[1].p; float* Y = c->s[2].p; float* D = c->s[3].p; float* O = c->s[4].p;
+    if (!sc) sc = c->s;
+    float* X = sc[0].p; float* R = sc[1].p; float* Y = sc[2].p; float* D = sc[3].p; float* O = sc[4].p;
     int h = hp, w = wp;
     {   // conv1 7x7 s2 + norm1 + relu
         GConvArgs a = conv_args(c, E.conv1, n, h, w, E.batch_norm ? X : R, 64, 0, E.batch_norm ? GACT_RELU : GACT_NONE);
@@ -377,9 +383,13 @@ extern "C" void eraft_destroy(eraft_ctx* c) {
     Buf* all[] = {&c->padded, &c->s[0], &c->s[1], &c->s[2], &c->s[3], &c->s[4], &c->fmap, &c->net[0], &c->net[1], &c->inp,
                   &c->pyr[0], &c->pyr[1], &c->pyr[2], &c->pyr[3], &c->c0, &c->c1, &c->c1b, &c->corr, &c->cor1, &c->corflo, &c->flo1,
                   &c->motion, &c->z, &c->rh, &c->fhid, &c->delta, &c->mhid, &c->mask, &c->st_corr0, &c->st_net1, &c->st_mask1,
-                  &c->st_delta1, &c->zeros, &c->f2l[0], &c->f2l[1], &c->f2l[2], &c->czr[0], &c->czr[1], &c->cq[0], &c->cq[1]};
+                  &c->st_delta1, &c->zeros, &c->f2l[0], &c->f2l[1], &c->f2l[2], &c->czr[0], &c->czr[1], &c->cq[0], &c->cq[1],
+                  &c->s2[0], &c->s2[1], &c->s2[2], &c->s2[3], &c->s2[4]};
     for (Buf* b : all) if (b->p) (void)hipFree(b->p);
     if (c->nstat) (void)hipFree(c->nstat);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
+    if (c->join_ev) (void)hipEventDestroy(c->join_ev);
     if (c->arena) (void)hipFree(c->arena);
     if (c->wino) (void)hipFree(c->wino);
     if (c->trash) (void)hipFree(c->trash);
@@ -534,6 +544,33 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
     ENS(c->mask, B * 576 * g);
     if (c->keep_stages) { ENS(c->st_corr0, B * 324 * g); ENS(c->st_net1, B * 128 * g); ENS(c->st_mask1, B * 576 * g); ENS(c->st_delta1, B * 2 * g); }
 #undef ENS
+    // Independent branches on the context's side stream (EEM_ERAFT_NO_OVERLAP=1, read per forward: everything on the caller's stream).
+    // One forward at a time most launches of this model are 40 - 300 blocks for 256 CUs: the branches fill CUs the main chain leaves idle.
+    const char* eno = getenv("EEM_ERAFT_NO_OVERLAP");
+    const bool overlap = !(eno && eno[0] == '1');
+    if (overlap) {
+        if (!c->side) {
+            EEM_HIP_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+            EEM_HIP_CHECK(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+            EEM_HIP_CHECK(hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming));
+        }
+        for (int i = 0; i < 5; ++i)
+            if ((rc = ensure(c->s2[i], big / 2)) != EEM_OK) return rc;
+    }
+    hipStream_t sd = overlap ? c->side : st;
+    // fork: the side stream continues from here on the caller's stream; join: the caller's stream waits for the side stream's work so far
+    auto fork = [&]() -> int {
+        if (!overlap) return EEM_OK;
+        EEM_HIP_CHECK(hipEventRecord(c->fork_ev, st));
+        EEM_HIP_CHECK(hipStreamWaitEvent(sd, c->fork_ev, 0));
+        return EEM_OK;
+    };
+    auto join = [&]() -> int {
+        if (!overlap) return EEM_OK;
+        EEM_HIP_CHECK(hipEventRecord(c->join_ev, sd));
+        EEM_HIP_CHECK(hipStreamWaitEvent(st, c->join_ev, 0));
+        return EEM_OK;
+    };
     // pad channels of the correlation buffer (never written by the lookup)
     EEM_HIP_CHECK(hipMemset2DAsync(c->corr.p + (size_t)324 * g, (size_t)kCorrPad * g * 4, 0, (size_t)(kCorrPad - 324) * g * 4, B, st));
     const int cin0 = c->cin0;
@@ -542,6 +579,35 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
     float* pad2 = c->padded.p + (size_t)B * cin0 * hp * wp;
     if ((rc = er_pad2_launch(e1, e2, pad1, B * cin0, in_h, in_w, pad[0], pad[1], pad[2], pad[3], st)) != EEM_OK) return rc;
     (void)pad2;
+    float* cfeat = nullptr;
+    if ((rc = fork()) != EEM_OK) return rc;                            // (the padded volumes are on their way)
+    // ---- context network on image1 (:126-131): net = tanh(first half), inp = relu(second half)
+    if ((rc = run_encoder(c, c->cnet, pad1, B, cin0, hp, wp, &cfeat, sd, overlap ? c->s2 : nullptr)) != EEM_OK) return rc;
+    {
+        GConvArgs a = conv_args(c, c->cnet.conv2a, B, h8, w8, c->net[0].p, 128, 0, GACT_TANH);
+        set_seg(a, 0, cfeat, 128, 128, 0);
+        if ((rc = gconv_launch(a, sd)) != EEM_OK) return rc;
+        GConvArgs b2 = conv_args(c, c->cnet.conv2b, B, h8, w8, c->inp.p, 128, 0, GACT_RELU);
+        set_seg(b2, 0, cfeat, 128, 128, 0);
+        if ((rc = gconv_launch(b2, sd)) != EEM_OK) return rc;
+    }
+    if ((rc = er_coords_init_launch(c->c0.p, c->c1.p, flow_init, B, h8, w8, sd)) != EEM_OK) return rc;
+    // the context features' part of the GRU convs, once per forward (see eraft_ctx)
+    const char* enp = getenv("EEM_ERAFT_NO_PRE");
+    const char* ens0 = getenv("EEM_ERAFT_NO_STACK");
+    const bool use_pre = !(enp && enp[0] == '1') && !(ens0 && ens0[0] == '1');
+    if (use_pre) {
+        for (int pass = 0; pass < 2; ++pass) {
+            if ((rc = ensure(c->czr[pass], (size_t)B * 256 * g)) != EEM_OK || (rc = ensure(c->cq[pass], (size_t)B * 128 * g)) != EEM_OK) return rc;
+            GConvArgs a = conv_args(c, c->gzr_c[pass], B, h8, w8, c->czr[pass].p, 256, 0, GACT_NONE);
+            set_seg(a, 0, c->inp.p, 128, 128, 0);
+            if ((rc = gconv_launch(a, sd)) != EEM_OK) return rc;
+            a = conv_args(c, c->gq_c[pass], B, h8, w8, c->cq[pass].p, 128, 0, GACT_NONE);
+            set_seg(a, 0, c->inp.p, 128, 128, 0);
+            if ((rc = gconv_launch(a, sd)) != EEM_OK) return rc;
+        }
+    }
+
     // ---- feature network on [image1; image2] (:116), then its 1x1 output conv
     float* feat = nullptr;
     if ((rc = run_encoder(c, c->fnet, c->padded.p, 2 * B, cin0, hp, wp, &feat, st)) != EEM_OK) return rc;
@@ -554,33 +620,7 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
     if (c->alt_corr) rc = build_feature_pyramid(c, c->fmap.p + (size_t)B * 256 * g, B, 256, h8, w8, st);
     else rc = build_pyramid(c, c->fmap.p, c->fmap.p + (size_t)B * 256 * g, B, 256, h8, w8, st);
     if (rc != EEM_OK) return rc;
-    // ---- context network on image1 (:126-131): net = tanh(first half), inp = relu(second half)
-    if ((rc = run_encoder(c, c->cnet, pad1, B, cin0, hp, wp, &feat, st)) != EEM_OK) return rc;
-    {
-        GConvArgs a = conv_args(c, c->cnet.conv2a, B, h8, w8, c->net[0].p, 128, 0, GACT_TANH);
-        set_seg(a, 0, feat, 128, 128, 0);
-        if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
-        GConvArgs b2 = conv_args(c, c->cnet.conv2b, B, h8, w8, c->inp.p, 128, 0, GACT_RELU);
-        set_seg(b2, 0, feat, 128, 128, 0);
-        if ((rc = gconv_launch(b2, st)) != EEM_OK) return rc;
-    }
-    if ((rc = er_coords_init_launch(c->c0.p, c->c1.p, flow_init, B, h8, w8, st)) != EEM_OK) return rc;
-    // the context features' part of the GRU convs, once per forward (see eraft_ctx)
-    const char* enp = getenv("EEM_ERAFT_NO_PRE");
-    const char* ens0 = getenv("EEM_ERAFT_NO_STACK");
-    const bool use_pre = !(enp && enp[0] == '1') && !(ens0 && ens0[0] == '1');
-    if (use_pre) {
-        for (int pass = 0; pass < 2; ++pass) {
-            if ((rc = ensure(c->czr[pass], (size_t)B * 256 * g)) != EEM_OK || (rc = ensure(c->cq[pass], (size_t)B * 128 * g)) != EEM_OK) return rc;
-            GConvArgs a = conv_args(c, c->gzr_c[pass], B, h8, w8, c->czr[pass].p, 256, 0, GACT_NONE);
-            set_seg(a, 0, c->inp.p, 128, 128, 0);
-            if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
-            a = conv_args(c, c->gq_c[pass], B, h8, w8, c->cq[pass].p, 128, 0, GACT_NONE);
-            set_seg(a, 0, c->inp.p, 128, 128, 0);
-            if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
-        }
-    }
-
+    if ((rc = join()) != EEM_OK) return rc;                            // net, inp, the context parts of the GRU convs, coords
     int cur = 0;
     for (int it = 0; it < iters; ++it) {
         float* net = c->net[cur].p;
@@ -599,22 +639,24 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
             if ((rc = run_lookup(c, c1cur, c->corr.p, kCorrPad, B, h8, w8, st)) != EEM_OK) return rc;
             if ((rc = er_flow_launch(c->c0.p, c1cur, c->motion.p, 128, 126, B, (int)g, st)) != EEM_OK) return rc;
         }
-        // motion encoder (model/update.py:73-81)
+        // motion encoder (model/update.py:73-81): the flow branch convf1 -> convf2 on the side stream beside the correlation branch
         // the 324 correlation features live in a 336-channel buffer (12 zero channels, zero weight columns) so that the
         // 1x1 conv qualifies for the 16-aligned LDS-tiled kernel; the generic kernel reads the first 324
-        GConvArgs a = conv_args(c, c->convc1, B, h8, w8, c->cor1.p, 256, 0, GACT_RELU);
+        if ((rc = fork()) != EEM_OK) return rc;                        // (the lookup wrote the flow channels of `motion`)
+        GConvArgs a = conv_args(c, c->convf1, B, h8, w8, c->flo1.p, 128, 0, GACT_RELU);
+        set_seg(a, 0, c->motion.p, 2, 128, 126);
+        if ((rc = gconv_launch(a, sd)) != EEM_OK) return rc;
+        a = conv_args(c, c->convf2, B, h8, w8, c->corflo.p, 256, 192, GACT_RELU);
+        set_seg(a, 0, c->flo1.p, 128, 128, 0);
+        if ((rc = gconv_launch(a, sd)) != EEM_OK) return rc;
+        a = conv_args(c, c->convc1, B, h8, w8, c->cor1.p, 256, 0, GACT_RELU);
         set_seg(a, 0, c->corr.p, kCorrPad, kCorrPad, 0);
         if (!gconv16_supported(a)) { a.wpk16 = nullptr; set_seg(a, 0, c->corr.p, 324, kCorrPad, 0); }
         if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
         a = conv_args(c, c->convc2, B, h8, w8, c->corflo.p, 256, 0, GACT_RELU);
         set_seg(a, 0, c->cor1.p, 256, 256, 0);
         if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
-        a = conv_args(c, c->convf1, B, h8, w8, c->flo1.p, 128, 0, GACT_RELU);
-        set_seg(a, 0, c->motion.p, 2, 128, 126);
-        if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
-        a = conv_args(c, c->convf2, B, h8, w8, c->corflo.p, 256, 192, GACT_RELU);
-        set_seg(a, 0, c->flo1.p, 128, 128, 0);
-        if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+        if ((rc = join()) != EEM_OK) return rc;
         a = conv_args(c, c->conv, B, h8, w8, c->motion.p, 128, 0, GACT_RELU);
         set_seg(a, 0, c->corflo.p, 256, 256, 0);
         if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
@@ -682,13 +724,16 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
             set_seg(a, 0, net, 128, 128, 0);
             if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
         }
+        // the flow head's last conv (256 -> 2) beside the mask head's (256 -> 576)
+        if ((rc = fork()) != EEM_OK) return rc;
         a = conv_args(c, c->fh2, B, h8, w8, c->delta.p, 2, 0, GACT_NONE);
         set_seg(a, 0, c->fhid.p, 256, head_ct, 0);
-        if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+        if ((rc = gconv_launch(a, sd)) != EEM_OK) return rc;
         a = conv_args(c, c->mk2, B, h8, w8, c->mask.p, 576, 0, GACT_NONE);
         set_seg(a, 0, mh, 256, head_ct, mh_off);
         a.out_scale = 0.25f;
         if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+        if ((rc = join()) != EEM_OK) return rc;
         // :149 coords1 = coords1 + delta_flow and :155-157 the convex upsampling of coords1 - coords0, one launch
         if (fuse_small) {
             if ((rc = er_convex_up_launch(c->c0.p, c1cur, c->mask.p, out + (size_t)it * B * 2 * in_h * in_w, B, h8, w8, pad[2],

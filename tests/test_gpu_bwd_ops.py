@@ -147,8 +147,10 @@ def test_one_pair_input_conv_with_taps_as_k_steps(monkeypatch, cin, cout, k, h, 
 def test_lds_tiled_conv_with_two_k_groups(monkeypatch, cin, cout, k, h, w, b):
     """E-RAFT's update block at batch 1: launches of at most one block per CU run two groups of four waves per tile that split the
     channel chunks (gconv16.hip, KG = 2; 21 chunks: 11 + 10), with 3 / 5 / 6-row tiles chosen by rounds x rows.  Against torch and
-    against the generic kernel (EEM_NO_GCONV16=1, read per launch)."""
+    against the generic kernel (EEM_NO_GCONV16=1, read per launch).  (EEM_NO_GCONVB=1: the larger of these shapes would otherwise
+    take the bf16-piece kernel, which has its own tests in test_gpu_eraft.py / test_gpu_plus.py.)"""
     from eemflow_amd import ops
+    monkeypatch.setenv("EEM_NO_GCONVB", "1")
     g = torch.Generator().manual_seed(cin + cout)
     conv = torch.nn.Conv2d(cin, cout, k, padding=(k[0] // 2, k[1] // 2))
     x = torch.randn(b, cin, h, w, generator=g)

@@ -359,7 +359,11 @@ struct Hook {
     // diagnostic (EEM_SKIP_KERNELS="enc.pconv2_1;dec."): launches whose name starts with one of the prefixes are skipped - the flow is
     // garbage, the frame rate says what that launch costs BESIDE the others (tools/marginal.sh); read once per process
     static bool skipped(const char* name) {
-        static const std::string list = [] { const char* e = getenv("EEM_SKIP_KERNELS"); return std::string(e ? e : ""); }();
+        static const std::string list = [] {
+            const char* e = getenv("EEM_SKIP_KERNELS");
+            if (e && e[0]) fprintf(stderr, "eemflow_hip: EEM_SKIP_KERNELS=\"%s\" is set - the launches it names are skipped and the flow is GARBAGE (diagnostic runs only)\n", e);
+            return std::string(e ? e : "");
+        }();
         if (list.empty()) return false;
         size_t pos = 0;
         while (pos <= list.size()) {

@@ -77,8 +77,8 @@ void fewout_pack(const float* w, int cout, int cin, int kh, int kw, float* packe
 bool fewout_supported(const GConvArgs& a);
 int fewout_launch(const GConvArgs& a, hipStream_t stream);
 int gconv16_launch(const GConvArgs& a, hipStream_t stream);
-// the same layers on the bf16 matrix pipe with exact three-piece operands (gconvb.hip): launches that fill the chip with 128-pixel x
-// 64-cout tiles; gconv_launch takes it when a.wpkb is set and the launch qualifies
+// the same layers on the bf16 matrix pipe with exact three-piece operands (gconvb.hip): 3x3 / 1x5 / 5x1, cout >= 96, launches of at
+// least 64 blocks of 8 rows x 16 pixels x 128 couts; gconv_launch takes it when a.wpkb is set and the launch qualifies
 bool gconvb_shape(int cout, const int* cs, int nseg, int kh, int kw, int stride);
 size_t gconvb_packed_floats(int cout, const int* cs, int nseg, int kh, int kw);
 void gconvb_pack(const float* w, int cout, const int* cs, int nseg, int kh, int kw, float* packed);

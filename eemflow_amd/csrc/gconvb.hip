@@ -11,14 +11,15 @@
 // costs is operand traffic - a weight is 6 bytes and a 16x16x32 MFMA consumes 2 KB of operands per 16 cycles - so it is built for
 // launches with pixels enough to fill the chip with LARGE tiles (gconvb_supported); smaller ones stay on gconv16.hip.
 //
-//   * block = 8 waves = 8 rows x 16 pixels x 64 couts: four MULTIPLYING waves - wave = (row half, cout half): 4 pixel tiles (rows) x 2 cout groups of 16,
-//     v_mfma_f32_16x16x32_bf16 with M = 16 pixels, N = 16 couts, K = 32 channels: 48 MFMAs per k-step (tap x 32-channel chunk) against
-//     12 A-fragment reads (LDS) and 6 B-fragment loads (global) - and four STAGING waves, one of each kind per SIMD;
+//   * block = 12 waves = TH rows (2 / 4 / 6 / 8, chosen per launch) x 16 pixels x 128 couts: eight MULTIPLYING waves - wave = (row half,
+//     cout quarter): TH / 2 pixel tiles (rows) x 2 cout groups of 16, v_mfma_f32_16x16x32_bf16 with M = 16 pixels, N = 16 couts, K = 32
+//     channels: 6 TH MFMAs per k-step (tap x 32-channel chunk) and wave against 1.5 TH A-fragment reads (LDS) and 6 B-fragment loads
+//     (global) - two of them per SIMD - and four STAGING waves, one per SIMD;
 //   * INPUT: the chunk's haloed tile, split once on its way in: a staging thread loads 8 channels x 4 columns (eight 16-byte loads, one
 //     chunk ahead, out-of-image pieces from the zero page), splits the 32 values and writes twelve 16-byte LDS entries
 //     [piece][8-channel group][row][column] = 8 bf16; double-buffered, one barrier per chunk;
 //   * WEIGHTS: pre-split on the host into B fragments [64-cout chunk][32-channel chunk][tap][cout group][piece][lane] (16 bytes),
-//     streamed L2 -> registers through a ring of three k-steps per wave - no LDS, no barrier (28 bytes per clock and CU);
+//     streamed L2 -> registers through a ring of two k-steps per wave - no LDS, no barrier;
 //   * D: lane = (cout, 4 consecutive pixels): epilogue operands (GRU state and gate, residual, per-pixel addend) and results move as
 //     16-byte loads / stores; every epilogue of gconv16.hip.
 #include "gconv.h"

@@ -104,6 +104,7 @@ _SIGNATURES = {
     "eemop_conv2d_bwd_weight": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 12 + [_c_float_p, _c_float_p, ctypes.c_void_p]),
     "eemop_act_bwd": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_float, _c_float_p, ctypes.c_void_p]),
     "eemop_binary": (ctypes.c_int, [ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_float, ctypes.c_longlong, _c_float_p, ctypes.c_void_p]),
+    "eemop_sum_n": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, _c_float_p, ctypes.c_void_p]),
     "eemop_gru_blend": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, ctypes.c_longlong, _c_float_p, ctypes.c_void_p]),
     "eemop_gru_blend_bwd": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_longlong, _c_float_p, _c_float_p,
                                            _c_float_p, ctypes.c_void_p]),

@@ -54,6 +54,25 @@ __global__ __launch_bounds__(256) void binary_kernel(const float* __restrict__ a
     out[i] = r;
 }
 
+// out = sum of up to eight tensors (the gradients a tensor with several consumers receives, in ONE launch: ops.py's FanOut)
+struct SumNArgs { const float* in[8]; int n; };
+__global__ __launch_bounds__(256) void sum_n_kernel(SumNArgs a, float* __restrict__ out, long n4, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) {
+        f32x4 r = reinterpret_cast<const f32x4*>(a.in[0])[i];
+#pragma unroll
+        for (int k = 1; k < 8; ++k)
+            if (k < a.n) r += reinterpret_cast<const f32x4*>(a.in[k])[i];
+        reinterpret_cast<f32x4*>(out)[i] = r;
+    } else if (i == n4) {                                       // the (< 4) values past the last 16-byte piece
+        for (long j = n4 * 4; j < n; ++j) {
+            float r = a.in[0][j];
+            for (int k = 1; k < a.n; ++k) r += a.in[k][j];
+            out[j] = r;
+        }
+    }
+}
+
 // h' = (1 - z) h + z q and its adjoint (model/update.py:48,57)
 __global__ __launch_bounds__(256) void gru_blend_kernel(const float* __restrict__ z, const float* __restrict__ h,
                                                         const float* __restrict__ q, float* __restrict__ out, long n) {
@@ -695,6 +714,23 @@ extern "C" int eemop_binary(int kind, const float* a, const float* b, float alph
     EEM_REQUIRE(a && out && (b || kind == 4) && kind >= 0 && kind <= 4, "eemop_binary: bad arguments");
     if (n == 0) return EEM_OK;
     hipLaunchKernelGGL(binary_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, (long)n, kind, alpha);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+extern "C" int eemop_sum_n(const float* const* in, int count, long long n, float* out, void* stream) {
+    EEM_REQUIRE(in && out && count >= 1 && count <= 8, "eemop_sum_n: 1..8 inputs, got %d", count);
+    if (n == 0) return EEM_OK;
+    SumNArgs a;
+    bool aligned = ((uintptr_t)out & 15) == 0;
+    for (int k = 0; k < 8; ++k) {
+        a.in[k] = k < count ? in[k] : in[0];
+        EEM_REQUIRE(a.in[k], "eemop_sum_n: NULL input %d", k);
+        aligned = aligned && ((uintptr_t)a.in[k] & 15) == 0;
+    }
+    a.n = count;
+    const long n4 = aligned ? (long)(n / 4) : 0;
+    hipLaunchKernelGGL(sum_n_kernel, dim3(nblk(n4 + 1)), dim3(256), 0, (hipStream_t)stream, a, out, n4, (long)n);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

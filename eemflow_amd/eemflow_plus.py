@@ -195,24 +195,29 @@ class EEMFlow_cdc(nn.Module):  # noqa: N801
         """cdc_model.forward after its upsampling (cdc_utils.py:160-173): flow_init (B,2,h,w) -> flow_up."""
         from . import ops
         est = self.cdc_model.dense_estimator_mask
-        x = ops.CatN.apply(a, ops.Warp.apply(b, flow_init, 2))
+        # (tensors with several consumers go through ops.fan_out: their gradients meet in one launch instead of autograd's chain of adds)
+        fi_w, fi_t, fi_b = ops.fan_out(flow_init, 3)
+        x = ops.CatN.apply(a, ops.Warp.apply(b, fi_w, 2))
         for i in range(1, 6):
-            x = ops.CatN.apply(self._lrelu_conv(getattr(est, f"conv{i}"), x), x)
-        x_out = ops.conv2d(est.conv_last[0], x)
-        inter_flow = ops.ChannelSlice.apply(x_out, 0, 2)
-        m = ops.Sigmoid.apply(ops.ChannelSlice.apply(x_out, 2, 1))
-        m2 = ops.CatN.apply(m, m)                                          # the (B,1,h,w) mask broadcast over the two flow channels
-        return ops.GRUBlend.apply(m2, ops.Warp.apply(flow_init, inter_flow, 1), flow_init)   # warp * (1 - m) + flow_init * m
+            xa, xb = ops.fan_out(x, 2)
+            x = ops.CatN.apply(self._lrelu_conv(getattr(est, f"conv{i}"), xa), xb)
+        xo_f, xo_m = ops.fan_out(ops.conv2d(est.conv_last[0], x), 2)
+        inter_flow = ops.ChannelSlice.apply(xo_f, 0, 2)
+        ma, mb = ops.fan_out(ops.Sigmoid.apply(ops.ChannelSlice.apply(xo_m, 2, 1)), 2)
+        m2 = ops.CatN.apply(ma, mb)                                        # the (B,1,h,w) mask broadcast over the two flow channels
+        return ops.GRUBlend.apply(m2, ops.Warp.apply(fi_t, inter_flow, 1), fi_b)   # warp * (1 - m) + flow_init * m
 
     def _level_ops(self, l, f1l, f2l, flow_init):
         """One l-block of the forward (EEMFlow+.py:183-229) from cdc_model's upsampled flow_init -> (flow_up_l, flow_l)."""
         from . import ops
-        a = self._lrelu_conv(self.conv_1x1[l], f1l)
-        b = self._lrelu_conv(self.conv_1x1[l], f2l)
-        flow_up = self._cdc_from_init(flow_init, a, b)
-        cat = ops.CatN.apply(ops.LocalCorr53.apply(f1l, ops.Warp.apply(f2l, flow_up, 0)), self._lrelu_conv(getattr(self, f"rconv{l}"), f1l),
-                             flow_up)
-        return flow_up, ops.Add.apply(self._decoder_ops(getattr(self, f"decoder{l}"), cat), flow_up, 1)
+        f1a, f1c, f1r = ops.fan_out(f1l, 3)
+        f2a, f2w = ops.fan_out(f2l, 2)
+        a = self._lrelu_conv(self.conv_1x1[l], f1a)
+        b = self._lrelu_conv(self.conv_1x1[l], f2a)
+        fu_w, fu_c, fu_a, flow_up = ops.fan_out(self._cdc_from_init(flow_init, a, b), 4)
+        cat = ops.CatN.apply(ops.LocalCorr53.apply(f1c, ops.Warp.apply(f2w, fu_w, 0)), self._lrelu_conv(getattr(self, f"rconv{l}"), f1r),
+                             fu_c)
+        return flow_up, ops.Add.apply(self._decoder_ops(getattr(self, f"decoder{l}"), cat), fu_a, 1)
 
     def _pyramid_ops(self, e1, e2):
         """Replicate pad, the shared encoder on [image1; image2] and three 2x2 poolings (EEMFlow+.py:162-175) -> f1[l], f2[l], l = 1..6."""

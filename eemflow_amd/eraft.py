@@ -257,14 +257,19 @@ class ERAFT(nn.Module):
         cor = ops.conv2d(e.convc2, ops.conv2d(e.convc1, corr, act=ops.ACT_RELU), act=ops.ACT_RELU)
         flo = ops.conv2d(e.convf2, ops.conv2d(e.convf1, flow, act=ops.ACT_RELU), act=ops.ACT_RELU)
         motion = ops.Cat2.apply(ops.conv2d(e.conv, cor, flo, act=ops.ACT_RELU), flow)
+        # every tensor with several consumers goes through ops.fan_out: its gradients meet in one launch instead of a chain of adds
+        mo = ops.fan_out(motion, 6)
+        ip = ops.fan_out(inp, 6)
         g = ub.gru
-        for cz, cr, cq in ((g.convz1, g.convr1, g.convq1), (g.convz2, g.convr2, g.convq2)):
-            z = ops.conv2d(cz, net, inp, motion, act=ops.ACT_SIGMOID)
-            r = ops.conv2d(cr, net, inp, motion, act=ops.ACT_SIGMOID)
-            q = ops.conv2d(cq, ops.Mul.apply(r, net), inp, motion, act=ops.ACT_TANH)
-            net = ops.GRUBlend.apply(z, net, q)
-        delta = ops.conv2d(ub.flow_head.conv2, ops.conv2d(ub.flow_head.conv1, net, act=ops.ACT_RELU))
-        mask = ops.conv2d(ub.mask[2], ops.conv2d(ub.mask[0], net, act=ops.ACT_RELU), out_scale=0.25)
+        for k, (cz, cr, cq) in enumerate(((g.convz1, g.convr1, g.convq1), (g.convz2, g.convr2, g.convq2))):
+            nz, nr, nm, nb = ops.fan_out(net, 4)
+            z = ops.conv2d(cz, nz, ip[3 * k], mo[3 * k], act=ops.ACT_SIGMOID)
+            r = ops.conv2d(cr, nr, ip[3 * k + 1], mo[3 * k + 1], act=ops.ACT_SIGMOID)
+            q = ops.conv2d(cq, ops.Mul.apply(r, nm), ip[3 * k + 2], mo[3 * k + 2], act=ops.ACT_TANH)
+            net = ops.GRUBlend.apply(z, nb, q)
+        nf, nk, net = ops.fan_out(net, 3)
+        delta = ops.conv2d(ub.flow_head.conv2, ops.conv2d(ub.flow_head.conv1, nf, act=ops.ACT_RELU))
+        mask = ops.conv2d(ub.mask[2], ops.conv2d(ub.mask[0], nk, act=ops.ACT_RELU), out_scale=0.25)
         return net, mask, delta
 
     def _forward_ops(self, e1, e2, iters, flow_init):
@@ -283,14 +288,17 @@ class ERAFT(nn.Module):
         ctx_feat = self._encoder_ops(self.cnet, x[:b])
         w2, b2 = self.cnet.conv2.weight, self.cnet.conv2.bias
         hd = self.hidden_dim
-        net = ops.conv2d(self.cnet.conv2, ctx_feat, act=ops.ACT_TANH, weight=w2[:hd], bias=b2[:hd])      # :128-131
-        inp = ops.conv2d(self.cnet.conv2, ctx_feat, act=ops.ACT_RELU, weight=w2[hd:], bias=b2[hd:])
+        cfa, cfb = ops.fan_out(ctx_feat, 2)
+        net = ops.conv2d(self.cnet.conv2, cfa, act=ops.ACT_TANH, weight=w2[:hd], bias=b2[:hd])      # :128-131
+        inp = ops.conv2d(self.cnet.conv2, cfb, act=ops.ACT_RELU, weight=w2[hd:], bias=b2[hd:])
         coords0, coords1 = ops.coords_grids(b, hp // 8, wp // 8, e1.device, flow_init)
         preds = []
-        for _ in range(iters):
+        inps = ops.fan_out(inp, iters)                                                     # (one alias per iteration; _update_ops fans each out again)
+        pyrs = [ops.fan_out(p, iters) for p in pyr]
+        for it in range(iters):
             coords1 = coords1.detach()                                                     # :141
-            corr = ops.CorrLookup.apply(coords1, *pyr)
-            net, mask, delta = self._update_ops(net, inp, corr, ops.sub(coords1, coords0))
+            corr = ops.CorrLookup.apply(coords1, *[p[it] for p in pyrs])
+            net, mask, delta = self._update_ops(net, inps[it], corr, ops.sub(coords1, coords0))
             coords1 = ops.Add.apply(coords1, delta, 1)
             preds.append(ops.ConvexUpsample.apply(ops.Add.apply(coords1, coords0, -1), mask, tuple(pad)))
         return preds
@@ -345,9 +353,10 @@ def encoder_ops(enc, x):
     y = conv_norm(enc.conv1, enc.norm1, x, True)
     for layer in (enc.layer1, enc.layer2, enc.layer3):
         for blk in layer:                                                  # ResidualBlock.forward, model/extractor.py:43-57
-            t = conv_norm(blk.conv1, blk.norm1, y, True)
+            ya, yb = ops.fan_out(y, 2)                                     # (the block's input feeds the convs and the shortcut)
+            t = conv_norm(blk.conv1, blk.norm1, ya, True)
             t = conv_norm(blk.conv2, blk.norm2, t, True)
             if blk.downsample is not None:
-                y = conv_norm(blk.downsample[0], blk.norm3, y, False)
-            y = ops.AddReLU.apply(y, t)
+                yb = conv_norm(blk.downsample[0], blk.norm3, yb, False)
+            y = ops.AddReLU.apply(yb, t)
     return y

@@ -392,6 +392,42 @@ class Add(torch.autograd.Function):
         return dout, (dout if ctx.sign > 0 else _binary(4, _c(dout), alpha=-1.0)), None
 
 
+def sum_tensors(ts):
+    """Elementwise sum of a list of same-shaped CUDA tensors, eight per launch (eemop_sum_n)."""
+    ts = [_c(t) for t in ts]
+    while len(ts) > 1:
+        head, ts = ts[:8], ts[8:]
+        out = torch.empty_like(head[0])
+        arr = (ctypes.c_void_p * len(head))(*[t.data_ptr() for t in head])
+        with _on(out.device):
+            _lib.check(_lib.lib().eemop_sum_n(ctypes.cast(arr, ctypes.c_void_p), len(head), out.numel(), out.data_ptr(), _sp(out)))
+        ts.insert(0, out)
+    return ts[0]
+
+
+class FanOut(torch.autograd.Function):
+    """n aliases of x, one per consumer.  A tensor with several consumers - E-RAFT's hidden state, context features, motion features and
+    correlation pyramid across the twelve unrolled iterations (model/eraft.py:139-157) - otherwise gets its gradient from autograd's
+    accumulation, n - 1 elementwise add launches (297 per E-RAFT training step); here the n gradients meet in one eemop_sum_n launch per
+    eight of them.  The aliases must not be modified in place."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [g for g in grads if g is not None]
+        return (sum_tensors(gs) if gs else None), None
+
+
+def fan_out(x, n):
+    """FanOut for tensors that take part in autograd; plain repetition otherwise (inference, constants)."""
+    if n == 1 or not (torch.is_grad_enabled() and x.requires_grad):
+        return (x,) * n
+    return FanOut.apply(x, n)
+
+
 class GRUBlend(torch.autograd.Function):
     """(1 - z) h + z q  (model/update.py:48,57)."""
 

@@ -368,6 +368,10 @@ int eemop_act_bwd(const float* dy, const float* y, long long n, int kind, float 
 /* out = a + b (kind 0), a - b (1), a * b (2), relu(a + b) (3), alpha * a (4; b unused).  Replaces: coords1 - coords0, coords1 +
  * delta_flow (model/eraft.py:144,149), r * h (model/update.py:47,56), relu(x + y) (model/extractor.py:57). */
 int eemop_binary(int kind, const float* a, const float* b, float alpha, long long n, float* out, void* stream);
+/* out = in[0] + ... + in[count - 1] (1 <= count <= 8, host array of device pointers), one launch.  Replaces: the chain of adds autograd
+ * runs when a tensor has several consumers - the hidden state, the context features, the motion features and the correlation pyramid
+ * across the twelve unrolled iterations (model/eraft.py:139-157, model/update.py:43-60); Python: ops.FanOut. */
+int eemop_sum_n(const float* const* in, int count, long long n, float* out, void* stream);
 /* h' = (1 - z) h + z q and its adjoint (dz = dout (q - h), dh = dout (1 - z), dq = dout z).  Replaces: model/update.py:48,57. */
 int eemop_gru_blend(const float* z, const float* h, const float* q, long long n, float* out, void* stream);
 int eemop_gru_blend_bwd(const float* dout, const float* z, const float* h, const float* q, long long n, float* dz, float* dh, float* dq,

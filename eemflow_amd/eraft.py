@@ -32,8 +32,10 @@ class ResidualBlock(nn.Module):
             mk = lambda: nn.InstanceNorm2d(planes)
         elif norm_fn == 'none':
             mk = lambda: nn.Sequential()                         # model/extractor.py:36-40
+        elif norm_fn == 'group':
+            mk = lambda: nn.GroupNorm(num_groups=planes // 8, num_channels=planes)      # model/extractor.py:19-23
         else:
-            raise ValueError("norm_fn 'group' is not built ('batch', 'instance' - the two E-RAFT uses, eraft.py:57-60 - and 'none' are)")
+            raise ValueError(f"norm_fn {norm_fn!r}: 'group', 'batch', 'instance' or 'none' (model/extractor.py:17-40)")
         self.norm1, self.norm2 = mk(), mk()
         if not stride == 1:
             self.norm3 = mk()
@@ -54,8 +56,10 @@ class BasicEncoder(nn.Module):
             self.norm1 = nn.InstanceNorm2d(64)
         elif norm_fn == 'none':
             self.norm1 = nn.Sequential()                         # model/extractor.py:131-132
+        elif norm_fn == 'group':
+            self.norm1 = nn.GroupNorm(num_groups=8, num_channels=64)                     # model/extractor.py:123-124
         else:
-            raise ValueError("norm_fn 'group' is not built ('batch', 'instance' and 'none' are)")
+            raise ValueError(f"norm_fn {norm_fn!r}: 'group', 'batch', 'instance' or 'none' (model/extractor.py:122-132)")
         self.conv1 = nn.Conv2d(n_first_channels, 64, kernel_size=7, stride=2, padding=3)
         self.relu1 = nn.ReLU(inplace=True)
         self.in_planes = 64
@@ -63,9 +67,7 @@ class BasicEncoder(nn.Module):
         self.layer2 = self._make_layer(96, stride=2)
         self.layer3 = self._make_layer(128, stride=2)
         self.conv2 = nn.Conv2d(128, output_dim, kernel_size=1)
-        self.dropout = None
-        if dropout > 0:
-            raise ValueError("dropout > 0 is not built (E-RAFT uses 0, eraft.py:57-60)")
+        self.dropout = nn.Dropout2d(p=dropout) if dropout > 0 else None                # model/extractor.py:147-149
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
@@ -92,6 +94,8 @@ class BasicEncoder(nn.Module):
         if not x.is_cuda:
             raise _lib.EEMFlowHipError("BasicEncoder.forward: CUDA (ROCm) tensors required - there is no CPU path")
         y = ops.conv2d(self.conv2, encoder_ops(self, x.contiguous().float()))
+        if self.training and self.dropout is not None:                     # model/extractor.py:183-184
+            y = ops.dropout2d(y, self.dropout.p)
         if is_list:
             y = torch.split(y, [batch_dim, batch_dim], dim=0)
         return y
@@ -331,6 +335,8 @@ def apply_norm(norm, x, relu):
     from . import ops
     if isinstance(norm, nn.InstanceNorm2d):
         return ops.InstanceNormReLU.apply(x, relu)
+    if isinstance(norm, nn.GroupNorm):
+        return ops.group_norm(x, norm.num_groups, norm.weight, norm.bias, norm.eps, relu)
     if not norm.training:                                        # freeze_bn() (model/eraft.py:69-72): running statistics, no update
         return ops.BatchNormEvalReLU.apply(x, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.eps, relu)
     y = ops.BatchNormTrainReLU.apply(x, norm.weight, norm.bias, norm.running_mean, norm.running_var, norm.momentum, norm.eps, relu)

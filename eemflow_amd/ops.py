@@ -347,6 +347,29 @@ class BatchNormEvalReLU(torch.autograd.Function):
         return dx, dw, db, None, None, None, None
 
 
+def group_norm(x, num_groups, weight, bias, eps, relu):
+    """relu?(GroupNorm(num_groups, C)(x)) (model/extractor.py:19-23,123-124) from two operators: the statistics of a group - its C / G
+    channels are contiguous in NCHW - are InstanceNorm's over planes of (C / G) * H * W values, and the per-channel affine map (+ ReLU)
+    is the frozen-BatchNorm operator with mean 0 and variance 1 - eps.  Both have their adjoints, so weight and bias train."""
+    if abs(float(eps) - 1e-5) > 1e-12:
+        raise ValueError("group_norm: eps other than 1e-5 is not built (the instance-norm operator's constant)")
+    n, c, h, w = x.shape
+    if c % num_groups:
+        raise ValueError("group_norm: channels must divide into the groups")
+    xn = InstanceNormReLU.apply(_c(x).view(n, num_groups, (c // num_groups) * h, w), False).view(n, c, h, w)
+    zero = torch.zeros(c, device=x.device, dtype=torch.float32)
+    var = torch.full((c,), 1.0 - float(eps), device=x.device, dtype=torch.float32)
+    return BatchNormEvalReLU.apply(xn, weight, bias, zero, var, float(eps), relu)
+
+
+def dropout2d(x, p):
+    """nn.Dropout2d in training mode (model/extractor.py:147-149,183-184): whole channels zeroed with probability p, the rest scaled by
+    1 / (1 - p).  The mask comes from torch's generator (as the reference's does); the multiply and its adjoint are the Mul operator."""
+    n, c = x.shape[:2]
+    keep = (torch.rand(n, c, 1, 1, device=x.device) >= p).to(torch.float32) / (1.0 - p)
+    return Mul.apply(x, keep.expand_as(x).contiguous())
+
+
 class AddReLU(torch.autograd.Function):
     """relu(x + y): the tail of a residual block (model/extractor.py:57)."""
 

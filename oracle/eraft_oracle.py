@@ -26,6 +26,9 @@ def _norm(x, sd, prefix, norm_fn, training=False):
         return x                                               # nn.Sequential() - model/extractor.py:36-40,131-132
     if norm_fn == "instance":
         return F.instance_norm(x, eps=1e-5)
+    if norm_fn == "group":                                       # model/extractor.py:19-23,123-124: num_groups = planes // 8
+        w = sd[prefix + "weight"]
+        return F.group_norm(x, w.shape[0] // 8, w, sd[prefix + "bias"], eps=1e-5)
     if norm_fn == "batch":
         return F.batch_norm(x, sd[prefix + "running_mean"], sd[prefix + "running_var"], sd[prefix + "weight"],
                             sd[prefix + "bias"], training=training, momentum=0.1, eps=1e-5)

@@ -217,14 +217,19 @@ def test_flow_init_and_twelve_iterations():
     assert len(preds) == 12 and maxerr(preds[-1], ref[-1]) < FLOW_TOL
 
 
-@pytest.mark.parametrize("norm_fn", ["none", "instance", "batch"])
+@pytest.mark.parametrize("norm_fn", ["none", "instance", "batch", "group"])
 def test_basic_encoder_standalone_forward(norm_fn):
-    """BasicEncoder(output_dim, norm_fn, dropout=0, n_first_channels).forward (model/extractor.py:119-190) on its own - the three norm
-    settings built here ('none' = the reference's empty nn.Sequential; 'group' raises), a list input run as one batch and split again -
-    against the oracle, with gradients flowing (the operator-level autograd route)."""
+    """BasicEncoder(output_dim, norm_fn, dropout, n_first_channels).forward (model/extractor.py:119-190) on its own - the four norm
+    settings of the reference ('none' = its empty nn.Sequential, 'group' = GroupNorm(planes // 8) with random affine parameters here), a
+    list input run as one batch and split again - against the oracle, with gradients flowing (the operator-level autograd route)."""
     from eemflow_amd.eraft import BasicEncoder
     torch.manual_seed(5)
     enc = BasicEncoder(output_dim=96, norm_fn=norm_fn, dropout=0.0, n_first_channels=5).to(DEV).eval()
+    if norm_fn == "group":
+        with torch.no_grad():
+            for m in enc.modules():
+                if isinstance(m, torch.nn.GroupNorm):
+                    m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.3, 0.3)
     sd = {k: v.detach().cpu().float() for k, v in enc.state_dict().items()}
     a, b = (torch.from_numpy(x) for x in synthetic_voxel_pair(9, 2, 128, 160))
     ya, yb = enc([a.to(DEV), b.to(DEV)])
@@ -236,8 +241,34 @@ def test_basic_encoder_standalone_forward(norm_fn):
     assert maxerr(single, R.basic_encoder(sd, "", a, norm_fn)) < 2e-4 * max(scale, 1.0)
     single.square().mean().backward()
     assert enc.conv1.weight.grad is not None and float(enc.conv1.weight.grad.abs().max()) > 0
+    if norm_fn == "group":                                       # the affine parameters train: gradient against torch autograd through the oracle
+        params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        R.basic_encoder(params, "", a, norm_fn).square().mean().backward()
+        for name in ("norm1.weight", "norm1.bias", "layer2.0.norm3.weight", "layer3.1.norm2.bias"):
+            got = dict(enc.named_parameters())[name].grad.cpu()
+            ref = params[name].grad
+            assert maxerr(got, ref) < 3e-3 * max(float(ref.abs().max()), 1e-6), name
     with pytest.raises(ValueError):
-        BasicEncoder(norm_fn="group")
+        BasicEncoder(norm_fn="layer")
+
+
+def test_basic_encoder_dropout_in_training_mode():
+    """dropout > 0 (model/extractor.py:147-149,183-184): nn.Dropout2d on the output in train() - whole channels zero with probability p,
+    the others scaled by 1 / (1 - p); identity in eval()."""
+    from eemflow_amd.eraft import BasicEncoder
+    torch.manual_seed(6)
+    enc = BasicEncoder(output_dim=64, norm_fn="instance", dropout=0.5, n_first_channels=5).to(DEV)
+    a = torch.from_numpy(synthetic_voxel_pair(9, 2, 64, 96)[0]).to(DEV)
+    enc.eval()
+    ref = enc(a).detach()
+    enc.train()
+    y = enc(a)
+    dropped = (y.abs().amax(dim=(2, 3)) == 0)
+    assert 0 < int(dropped.sum()) < dropped.numel()
+    kept = ~dropped
+    assert maxerr((y.detach() * kept[:, :, None, None])[kept], (2.0 * ref * kept[:, :, None, None])[kept]) < 1e-5 * max(1.0, float(ref.abs().max()))
+    y.sum().backward()
+    assert float(enc.conv2.weight.grad.abs().max()) > 0
 
 
 def test_errors():

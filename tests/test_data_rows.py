@@ -129,5 +129,30 @@ def test_augmentors_match_reference_classes(golden):
         got = DenseSparseAugmentor(crop_size=[ch, cw], do_flip=bool(flip))(a, b, da, db, fl)
         for i, arr in enumerate(got):
             assert arr.dtype == g[f"dense_{k}_{i}"].dtype and np.array_equal(arr, g[f"dense_{k}_{i}"]), (k, i)
-    with pytest.raises(NotImplementedError):
-        FlowAugmentor(crop_size=[8, 8])(a, b, fl)
+
+
+def test_flow_augmentor_with_rescaling():
+    """FlowAugmentor's default path (utils/augumentor.py:158-200: random rescale, flips, random crop).  cv2 is absent, so the resize is
+    a restatement of cv2.resize(INTER_LINEAR) for float arrays - parity unpinned against cv2; here it is held to torch's bilinear
+    interpolation (align_corners=False: the same half-pixel rule), and the whole transform to its own definition under a fixed seed:
+    crop-sized C-contiguous outputs, flow scaled by the drawn factors."""
+    import torch
+    import torch.nn.functional as F
+    from eemflow_amd.augmentor import FlowAugmentor, resize_linear
+    rng = np.random.default_rng(7)
+    img = rng.standard_normal((37, 53, 3)).astype(np.float32)
+    for fx, fy in ((1.3, 0.8), (0.71, 1.0), (2.0, 2.0)):
+        got = resize_linear(img, fx, fy)
+        oh, ow = int(round(37 * fy)), int(round(53 * fx))
+        ref = F.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None], size=(oh, ow), mode="bilinear", align_corners=False)[0].permute(1, 2, 0).numpy()
+        assert got.shape == (oh, ow, 3) and got.dtype == np.float32
+        assert np.abs(got - ref).max() < 5e-5                      # (torch forms the source index in float32)
+    a, b = (rng.standard_normal((120, 160, 3)).astype(np.float32) for _ in range(2))
+    fl = rng.standard_normal((120, 160, 2))
+    np.random.seed(3)
+    o1, o2, of = FlowAugmentor(crop_size=[64, 96], do_flip=True)(a, b, fl)
+    assert o1.shape == (64, 96, 3) and o2.shape == (64, 96, 3) and of.shape == (64, 96, 2)
+    assert all(x.flags["C_CONTIGUOUS"] for x in (o1, o2, of))
+    np.random.seed(3)                                            # the same draws again: deterministic
+    p1, _, pf = FlowAugmentor(crop_size=[64, 96], do_flip=True)(a, b, fl)
+    assert np.array_equal(o1, p1) and np.array_equal(of, pf)

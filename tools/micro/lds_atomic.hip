@@ -1,5 +1,5 @@
 // LDS atomic throughput on gfx950: ds_add_f32 / ds_add_u32 / ds_add_u64 / ds_add_f64(?) with conflict-free and random addresses.
-// hipcc -O3 --offload-arch=gfx950 tools/micro/lds_atomic.hip -o /tmp/lds_atomic && /tmp/lds_atomic
+// hipcc -O3 --offload-arch=gfx950 -munsafe-fp-atomics tools/micro/lds_atomic.hip -o tools/micro/lds_atomic && tools/micro/lds_atomic
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

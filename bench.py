@@ -67,8 +67,14 @@ def parse():
                         "--frames-in-flight 4 to trace the timed loop's launch configuration one kernel at a time")
     p.add_argument("--rotate-pairs", type=int, default=ROTATE_PAIRS,
                    help="distinct input pairs the timed loop walks (1: the same pair every step, an Infinity-Cache-resident input)")
-    p.add_argument("--streams", type=int, default=4,
-                   help="frames in flight per GPU: independent contexts on separate HIP streams, steps alternate")
+    p.add_argument("--streams", type=int, default=0,
+                   help="chains of launches in flight per GPU: independent contexts on separate HIP streams, calls alternate "
+                        "(default: 2 with --coalesce > 1, else 4)")
+    p.add_argument("--coalesce", type=int, default=10,
+                   help="independent batch-1 frames handed to the library per call (eemflow_forward_many: n frames in n unrelated buffers ride "
+                        "one batch-n chain of launches); 1 = one eemflow_forward per frame.  A step stays ONE frame at batch 1")
+    p.add_argument("--long-steps", type=int, default=400,
+                   help="a second, longer run of the same timed loop after the K steps (reported as value_long; 0 disables)")
     return p.parse_args()
 
 
@@ -95,14 +101,20 @@ def cpu_baseline(sd_np, e1, e2, budget_s):
     sweep = {}
     with torch.no_grad():
         ref, _ = O.eemflow_forward(sd, e1, e2)
-        for c in cands:
+        def med3(c):
             torch.set_num_threads(c)
             O.eemflow_forward(sd, e1, e2)
-            t0 = time.perf_counter()
-            O.eemflow_forward(sd, e1, e2)
-            sweep[c] = time.perf_counter() - t0
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                O.eemflow_forward(sd, e1, e2)
+                ts.append(time.perf_counter() - t0)
+            return float(np.median(ts))
+        for c in cands:
+            sweep[c] = med3(c)
             if sweep[c] > 5.0 and len(sweep) >= 2:
                 break
+        single = sweep[1] if 1 in sweep else med3(1)     # the single-thread figure beside the all-cores one
         best = min(sweep, key=sweep.get)
         torch.set_num_threads(best)
         O.eemflow_forward(sd, e1, e2)
@@ -116,9 +128,10 @@ def cpu_baseline(sd_np, e1, e2, budget_s):
     return ref, {"value": e1.shape[0] / med, "unit": "frames/s", "cores": best, "kind": "port",
                  "sample": f"{len(times)} forwards of the same {e1.shape[0]}x5x{e1.shape[2]}x{e1.shape[3]} pair, "
                            f"median {med * 1e3:.1f} ms, torch {torch.__version__} CPU fp32, {best} threads "
-                           f"(fastest of sweep {{{', '.join(f'{k}: {v * 1e3:.0f} ms' for k, v in sweep.items())}}}; "
-                           f"host has {os.cpu_count()} logical CPUs, {ncpu} usable)",
-                 "ms_per_frame": med * 1e3 / e1.shape[0]}
+                           f"(fastest of a sweep of medians of three: {{{', '.join(f'{k}: {v * 1e3:.0f} ms' for k, v in sweep.items())}}}; "
+                           f"host has {os.cpu_count()} logical CPUs, {ncpu} usable); one thread: {single * 1e3:.0f} ms",
+                 "ms_per_frame": med * 1e3 / e1.shape[0],
+                 "single_thread_value": e1.shape[0] / single, "single_thread_ms_per_frame": single * 1e3 / e1.shape[0]}
 
 
 def other_rows(dev):
@@ -695,8 +708,9 @@ def main():
                            torch.roll(e2, shifts=(37 * r, 53 * r), dims=(2, 3)).contiguous()) for r in range(1, n_rot)]
     flat = torch.cat([torch.from_numpy(v).reshape(-1) for v in sd_np.values()]).contiguous()
 
-    NS = max(1, args.streams)
-    ctxs, streams, flows = [], [], []
+    CO = max(1, args.coalesce) if B == 1 else 1          # frames per library call (batches > 1 are already batched chains)
+    NS = args.streams if args.streams > 0 else (2 if CO > 1 else 4)
+    ctxs, streams = [], []
     for _ in range(NS):
         c = ctypes.c_void_p()
         _lib.check(L.eemflow_create(dev.index, ctypes.byref(c)))
@@ -706,59 +720,112 @@ def main():
         _lib.check(L.eemflow_set_frames_in_flight(c, args.frames_in_flight or NS))
         ctxs.append(c)
         streams.append(torch.cuda.Stream(device=dev))
-        flows.append(torch.empty(B, 2, H, W, device=dev))
+    # every frame in flight writes its own flow tensor: NS chains x CO frames, and one more set so that a chain's next call does not
+    # rewrite tensors its previous call may still be writing... (same stream: ordered) - NS * CO distinct buffers suffice
+    flows = [torch.empty(B, 2, H, W, device=dev) for _ in range(NS * CO)]
     ctx, stream, flow = ctxs[0], streams[0], flows[0]
     sp = ctypes.c_void_p(stream.cuda_stream)
     sps = [ctypes.c_void_p(st.cuda_stream) for st in streams]
     counter = [0]
+    calls = [0]
+    pending = []
 
     stagger = float(os.environ.get("EEM_BENCH_STAGGER_US", "0")) * 1e-6      # experiment: host pause between the first NS launches
 
+    def flush():
+        """Hand the frames collected so far to the library: ONE eemflow_forward_many call on the next chain."""
+        n = len(pending)
+        if n == 0:
+            return
+        i = calls[0] % NS
+        calls[0] += 1
+        arr = ctypes.c_void_p * n
+        p1 = arr(*[f[0].data_ptr() for f in pending])
+        p2 = arr(*[f[1].data_ptr() for f in pending])
+        po = arr(*[f[2].data_ptr() for f in pending])
+        _lib.check(L.eemflow_forward_many(ctxs[i], n, p1, p2, po, H, W, H, W, sps[i]))
+        pending.clear()
+
     def step():
-        i = counter[0] % NS
-        if stagger > 0 and 0 < counter[0] < NS:
-            t_end = time.perf_counter() + stagger
-            while time.perf_counter() < t_end:
-                pass
+        """One frame (batch B = 1 pair) enters the pipeline."""
+        if CO == 1:
+            i = counter[0] % NS
+            if stagger > 0 and 0 < counter[0] < NS:
+                t_end = time.perf_counter() + stagger
+                while time.perf_counter() < t_end:
+                    pass
+            a, b = pairs[counter[0] % n_rot]
+            counter[0] += 1
+            _lib.check(L.eemflow_forward(ctxs[i], a.data_ptr(), b.data_ptr(), B, H, W, flows[i].data_ptr(), H, W, sps[i]))
+            return flows[i]
         a, b = pairs[counter[0] % n_rot]
+        dst = flows[(calls[0] % NS) * CO + len(pending)]
+        pending.append((a, b, dst))
         counter[0] += 1
-        _lib.check(L.eemflow_forward(ctxs[i], a.data_ptr(), b.data_ptr(), B, H, W, flows[i].data_ptr(), H, W, sps[i]))
+        if len(pending) == CO:
+            flush()
+        return dst
+
+    def timed(nsteps):
+        """nsteps frames through the loop, bracketed as the contract says; returns (elapsed s, HIP-event ms, host enqueue s)."""
+        torch.cuda.synchronize(dev)
+        parallel.barrier(dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        counter[0] = 0
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for _ in range(nsteps):
+            step()
+        flush()                                          # a last, shorter call when CO does not divide nsteps
+        enq = time.perf_counter() - t0                   # host time to hand the steps to the streams (reported; < elapsed = GPU-bound)
+        for st in streams[1:]:
+            stream.wait_stream(st)
+        ev1.record(stream)
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        parallel.barrier(dev)
+        return el, ev0.elapsed_time(ev1), enq
 
     # Clock / runtime pre-heat (untimed, reported as "preheat_steps"): the contexts have just been built on an idle GPU, and the first
     # milliseconds after that run at ramping clocks with cold graph-launch paths (20 timed steps after 5 warm-up steps read 6 % lower than
-    # after 100).  Then the W warm-up steps the caller asked for, then the timed region.
+    # after 100).  Every call size the loops below will issue (CO, and the remainders of the step counts) is captured here, on every
+    # chain.  Then the W warm-up steps the caller asked for, then the timed region.
     for _ in range(args.preheat):
         step()
+    flush()
+    if CO > 1:
+        for r in sorted({args.steps % CO, args.warmup % CO, args.long_steps % CO} - {0}):
+            for _ in range(NS):
+                for _ in range(r):
+                    step()
+                flush()
     torch.cuda.synchronize(dev)
     counter[0] = 0
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize(dev)
-    parallel.barrier(dev)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    counter[0] = 0
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        step()
-    enqueue_s = time.perf_counter() - t0                 # host time to hand the K steps to the streams (reported; < elapsed = GPU-bound)
-    for st in streams[1:]:
-        stream.wait_stream(st)
-    ev1.record(stream)
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    parallel.barrier(dev)
-    gpu_ms = ev0.elapsed_time(ev1)
+    flush()
+    elapsed, gpu_ms, enqueue_s = timed(args.steps)
     value, slowest = parallel.aggregate_throughput(args.steps * B, elapsed, dev)
+    value_long = None
+    if args.long_steps > 0:
+        el_long, _, _ = timed(args.long_steps)
+        value_long, _ = parallel.aggregate_throughput(args.long_steps * B, el_long, dev)
 
     if rank == 0:
         # ---- per-kernel roofline, measured live with HIP events on the launch stream, in the launch configuration of the timed loop
         # (frames_in_flight = streams: persistent encoder kernels on fewer blocks) and in the single-frame configuration (full grids)
-        def kernel_table(frames_in_flight):
+        def kernel_table(frames_in_flight, nb=B):
+            # nb frames per launch: the timed loop's chains are batch-CO chains (the frames of one eemflow_forward_many call)
             _lib.check(L.eemflow_set_frames_in_flight(ctx, frames_in_flight))
             stats = (_lib.KernelStat * 64)()
             n = ctypes.c_int(0)
-            _lib.check(L.eemflow_time_kernels(ctx, e1.data_ptr(), e2.data_ptr(), B, H, W, flow.data_ptr(), H, W,
+            if nb == B:
+                k1, k2, kf = e1, e2, flow
+            else:
+                k1 = torch.cat([pairs[r % n_rot][0] for r in range(nb)]).contiguous()
+                k2 = torch.cat([pairs[r % n_rot][1] for r in range(nb)]).contiguous()
+                kf = torch.empty(nb, 2, H, W, device=dev)
+            _lib.check(L.eemflow_time_kernels(ctx, k1.data_ptr(), k2.data_ptr(), nb, H, W, kf.data_ptr(), H, W,
                                               args.kernel_reps, stats, 64, ctypes.byref(n), sp))
             torch.cuda.synchronize(dev)
             table = []
@@ -821,9 +888,10 @@ def main():
             return r
 
         fif = args.frames_in_flight or NS
-        kernels = kernel_table(fif)
+        kernels = kernel_table(fif, CO * B)
         roof = roofline_of(kernels)
         roof["frames_in_flight"] = fif
+        roof["frames_per_launch"] = CO * B
         roof_single = None
         if fif >= 3 and not args.no_side_rows:
             single = kernel_table(1)
@@ -834,7 +902,7 @@ def main():
         sum_us = sum(k["us"] for k in kernels)
         enc = [k for k in kernels if k["name"].startswith("enc.")]
         enc_tflops = sum(k["gflop"] for k in enc) / max(sum(k["us"] for k in enc), 1e-9) * 1e3
-        total_gflop = sum(k["gflop"] for k in kernels)
+        total_gflop = sum(k["gflop"] for k in kernels) / CO        # of one STEP (one batch-B forward): the table's launches carry CO of them
 
         # ---- CPU baseline + EPE agreement on this rank's frames
         cpu = None
@@ -843,9 +911,10 @@ def main():
             from oracle import eemflow_oracle as O
             ref, cpu = cpu_baseline(sd_np, torch.from_numpy(e1_np), torch.from_numpy(e2_np), args.cpu_seconds)
             counter[0] = 0
-            step()
+            got = step()                                     # pair 0 through the timed loop's own path (a one-frame call when coalescing)
+            flush()
             torch.cuda.synchronize(dev)
-            got = flow.cpu()
+            got = got.cpu()
             yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
             gt = np.stack([3 * np.sin(2 * np.pi * xx / W), 3 * np.cos(2 * np.pi * yy / H)])
             extra = {"flow_max_abs_err_vs_oracle": float((got - ref).abs().max()),
@@ -866,13 +935,15 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"EEMFlow inference, HREM {W}x{H} dt1, batch={B} per GPU (BASELINE configs[1]); "
                                    "synthetic 20%-dense voxel pairs resident in HBM, seeded Kaiming weights",
-                       "height": H, "width": W, "batch_per_gpu": B, "hip_graph": not args.no_graph, "streams_per_gpu": NS, "preheat_steps": args.preheat,
+                       "height": H, "width": W, "batch_per_gpu": B, "hip_graph": not args.no_graph, "streams_per_gpu": NS,
+                       "coalesced_frames": CO, "frames_in_flight_hint": args.frames_in_flight or NS, "preheat_steps": args.preheat,
                        "input_pairs_rotated": n_rot, "input_bytes_rotated": n_rot * 2 * e1.numel() * 4,
                        "parallelism": f"replicas x{world}: frames sharded over ranks, no data-path collective"},
             "roofline": roof, "roofline_single_frame_launch": roof_single, "cpu_baseline": cpu,
+            "value_long": None if value_long is None else round(value_long, 2), "value_long_steps": args.long_steps,
             "gpu_ms_per_step_hip_events": round(gpu_ms / args.steps, 4),
             "host_enqueue_ms_per_step": round(enqueue_s * 1e3 / args.steps, 4),
-            "schedule_sum_us": round(sum_us, 1), "frame_gflop": round(total_gflop, 3),
+            "schedule_sum_us": round(sum_us, 1), "schedule_frames_per_launch": CO * B, "frame_gflop": round(total_gflop, 3),
             "frame_tflops": round(total_gflop / ms_per_step, 2),
             "encoder_tflops_in_kernel": round(enc_tflops, 2),
             "kernels": kernels, **extra,

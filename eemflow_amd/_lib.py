@@ -36,6 +36,9 @@ _SIGNATURES = {
     "eemflow_graph_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong * 3)]),
     "eemflow_forward": (ctypes.c_int, [ctypes.c_void_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "eemflow_forward_many": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
+                                            ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_void_p]),
     "eemflow_time_kernels": (ctypes.c_int, [ctypes.c_void_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(KernelStat),
                                             ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),

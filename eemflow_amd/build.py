@@ -11,7 +11,10 @@ from concurrent.futures import ThreadPoolExecutor
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
-LIB = os.path.join(PKG, "libeemflow_hip.so")
+# EEM_BUILD_TAG=<tag> (with EEM_EXTRA_FLAGS, e.g. -DEEM_DIAG): a second library beside the release one - objects under csrc/build_<tag>/,
+# libeemflow_hip_<tag>.so - which tools load through EEM_LIB_PATH
+TAG = os.environ.get("EEM_BUILD_TAG", "")
+LIB = os.path.join(PKG, f"libeemflow_hip_{TAG}.so" if TAG else "libeemflow_hip.so")
 SOURCES = ["api.hip", "conv_enc.hip", "conv_enc1.hip", "conv_enc2.hip", "conv_s2.hip", "conv_s2r.hip", "conv_bx3.hip", "conv_wino.hip", "conv_wino32.hip", "conv_wino4.hip", "tail.hip", "tail_fused.hip", "voxel.hip", "metrics.hip", "gconv.hip", "gconv16.hip", "gconvb.hip", "eraft_kernels.hip",
            "eraft_api.hip", "train.hip", "wgrad_enc.hip", "dgrad_s2.hip", "train_api.hip", "plus_kernels.hip", "plus_api.hip", "bwd_ops.hip", "ops.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-fvisibility=hidden", "-fvisibility-inlines-hidden"]   # hidden: only include/eemflow_hip.h's entry points are dynamic symbols
@@ -37,7 +40,7 @@ def _stale(target, deps):
 
 def build_library(force=False, verbose=True):
     hipcc = _hipcc()
-    objdir = os.path.join(CSRC, "build")
+    objdir = os.path.join(CSRC, f"build_{TAG}" if TAG else "build")
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gconv.h"), os.path.join(CSRC, "eraft_kernels.h"), os.path.join(CSRC, "api_internal.h"), os.path.join(CSRC, "train.h"), os.path.join(CSRC, "plus_kernels.h"), os.path.join(PKG, "..", "include", "eemflow_hip.h"),
                os.path.abspath(__file__)]

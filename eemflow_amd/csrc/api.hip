@@ -41,8 +41,8 @@ extern "C" int eemflow_create(int device, eemflow_ctx** out) {
     if (e == hipSuccess) e = hipMemcpy(c->taps, kTaps53, sizeof(kTaps53), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&c->zero_page, 4096);
     if (e == hipSuccess) e = hipMemset(c->zero_page, 0, 4096);
-    if (e == hipSuccess) e = hipMalloc(&c->io_table, 4 * sizeof(void*));
-    if (e == hipSuccess) e = hipMemset(c->io_table, 0, 4 * sizeof(void*));
+    if (e == hipSuccess) e = hipMalloc(&c->io_table, 3 * EEM_MAX_COALESCE * sizeof(void*));
+    if (e == hipSuccess) e = hipMemset(c->io_table, 0, 3 * EEM_MAX_COALESCE * sizeof(void*));
     if (e != hipSuccess) {
         eem_set_error("eemflow_create: %s", hipGetErrorString(e));
         delete c;
@@ -302,18 +302,38 @@ extern "C" int eemflow_set_frames_in_flight(eemflow_ctx* c, int n) {
     return EEM_OK;
 }
 
-extern "C" int eemflow_forward(eemflow_ctx* c, const float* e1, const float* e2, int batch, int in_h, int in_w,
-                               float* out, int out_h, int out_w, void* stream) {
-    EEM_REQUIRE(c && e1 && e2 && out, "eemflow_forward: NULL argument");
-    EEM_REQUIRE(c->weights_loaded, "eemflow_forward: no weights loaded");
-    EEM_REQUIRE(c->have_pad, "eemflow_forward: call eemflow_set_image_size first (the reference needs "
-                             "change_imagesize before forward too)");
-    EEM_REQUIRE(batch >= 1 && in_h >= 1 && in_w >= 1 && out_h >= 1 && out_w >= 1, "eemflow_forward: bad sizes");
+// One forward of `batch` samples.  nframes == 0: events1 / events2 / flow are contiguous [batch, ...] tensors (e1[0], e2[0], out[0]).
+// nframes == batch >= 1 (eemflow_forward_many): every sample is its own single-frame buffer triple {e1[i], e2[i], out[i]}; the two
+// launches that touch caller memory find them through the io table's per-frame triples, everything between is the batch-n chain.
+static int forward_common(eemflow_ctx* c, int nframes, const float* const* e1, const float* const* e2, float* const* out, int batch,
+                          int in_h, int in_w, int out_h, int out_w, void* stream) {
     EEM_HIP_CHECK(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     Shape s;
     int rc = compute_shape(c, batch, in_h, in_w, out_h, out_w, &s);
     if (rc != EEM_OK) return rc;
+    const int nptr = nframes > 0 ? 3 * nframes : 3;
+    const void* want[3 * EEM_MAX_COALESCE];
+    uintptr_t bits = 0;
+    for (int i = 0; i < (nframes > 0 ? nframes : 1); ++i) {
+        want[3 * i] = e1[i]; want[3 * i + 1] = e2[i]; want[3 * i + 2] = out[i];
+        bits |= (uintptr_t)e1[i] | (uintptr_t)e2[i] | (uintptr_t)out[i];
+    }
+    const int aligned = (bits & 15) == 0;
+    // the table must name this call's buffers before the schedule reads it (stream-ordered; one context = one stream at a time)
+    auto write_table = [&]() -> int {
+        bool same = c->io_host_n == nptr && c->io_stream == stream;
+        for (int i = 0; same && i < nptr; ++i) same = c->io_host[i] == want[i];
+        if (same) return EEM_OK;
+        const int r = nframes > 0 ? io_table_many_launch(c->io_table, nframes, e1, e2, out, st)
+                                  : io_table_launch(c->io_table, e1[0], e2[0], out[0], st);
+        if (r != EEM_OK) return r;
+        for (int i = 0; i < nptr; ++i) c->io_host[i] = want[i];
+        c->io_host_n = nptr;
+        c->io_stream = stream;
+        c->io_updates += 1;
+        return EEM_OK;
+    };
 
     c->workspace_overwritten();
     if ((rc = ensure_forward_wino(c, batch, st)) != EEM_OK) return rc;          // outside any capture
@@ -323,10 +343,14 @@ extern "C" int eemflow_forward(eemflow_ctx* c, const float* e1, const float* e2,
         c->have_last = true;
         Hook hk;
         hk.st = st;
-        return run_forward(c, s, e1, e2, out, hk);
+        if (nframes == 0) return run_forward(c, s, e1[0], e2[0], out[0], hk);
+        if ((rc = write_table()) != EEM_OK) return rc;                // eager launches of per-frame buffers read the table too
+        c->cur_io_frames = nframes;
+        rc = run_forward(c, s, e1[0], e2[0], out[0], hk, c->io_table);
+        c->cur_io_frames = 0;
+        return rc;
     }
-    const int aligned = (((uintptr_t)e1 | (uintptr_t)e2 | (uintptr_t)out) & 15) == 0;
-    const eemflow_ctx::Key key = {batch, in_h, in_w, out_h, out_w, {c->pad[0], c->pad[1], c->pad[2], c->pad[3]}, aligned};
+    const eemflow_ctx::Key key = {batch, in_h, in_w, out_h, out_w, {c->pad[0], c->pad[1], c->pad[2], c->pad[3]}, aligned, nframes};
     eemflow_ctx::GraphEntry* ent = nullptr;
     for (eemflow_ctx::GraphEntry& g : c->graphs)
         if (g.key == key) ent = &g;
@@ -349,7 +373,9 @@ extern "C" int eemflow_forward(eemflow_ctx* c, const float* e1, const float* e2,
         EEM_HIP_CHECK(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
         Hook hk;
         hk.st = cap;
-        rc = run_forward(c, s, e1, e2, out, hk, c->io_table);
+        c->cur_io_frames = nframes;
+        rc = run_forward(c, s, e1[0], e2[0], out[0], hk, c->io_table);
+        c->cur_io_frames = 0;
         hipGraph_t g = nullptr;
         hipError_t e = hipStreamEndCapture(cap, &g);
         if (own_stream) (void)hipStreamDestroy(cap);
@@ -359,6 +385,7 @@ extern "C" int eemflow_forward(eemflow_ctx* c, const float* e1, const float* e2,
         ne.key = key;
         ne.shape = s;
         ne.graph = g;
+        ne.f13_skipped = c->f13_skipped;             // what run_forward_impl decided for this schedule
         hipError_t ie = hipGraphInstantiate(&ne.exec, g, nullptr, nullptr, 0);
         if (ie != hipSuccess) {
             (void)hipGraphDestroy(g);
@@ -369,19 +396,45 @@ extern "C" int eemflow_forward(eemflow_ctx* c, const float* e1, const float* e2,
         ent = &c->graphs.back();
         c->graph_captures += 1;
     }
-    // the table must name this call's buffers before the replay reads it (stream-ordered; one context = one stream at a time)
-    if (c->io_host[0] != e1 || c->io_host[1] != e2 || c->io_host[2] != out || c->io_stream != stream) {
-        if ((rc = io_table_launch(c->io_table, e1, e2, out, st)) != EEM_OK) return rc;
-        c->io_host[0] = e1; c->io_host[1] = e2; c->io_host[2] = out;
-        c->io_stream = stream;
-        c->io_updates += 1;
-    }
+    if ((rc = write_table()) != EEM_OK) return rc;
     ent->last_use = ++c->graph_clock;
     c->last = ent->shape;
     c->have_last = true;
     c->graph_replays += 1;
     EEM_HIP_CHECK(hipGraphLaunch(ent->exec, st));
+    // a replay runs the CAPTURED schedule: f13 is unwritten again whenever that schedule skipped its stores, whatever
+    // eemflow_get_stage("f13") re-ran and cleared after an earlier frame
+    c->f13_skipped = ent->f13_skipped;
     return EEM_OK;
+}
+
+extern "C" int eemflow_forward(eemflow_ctx* c, const float* e1, const float* e2, int batch, int in_h, int in_w,
+                               float* out, int out_h, int out_w, void* stream) {
+    EEM_REQUIRE(c && e1 && e2 && out, "eemflow_forward: NULL argument");
+    EEM_REQUIRE(c->weights_loaded, "eemflow_forward: no weights loaded");
+    EEM_REQUIRE(c->have_pad, "eemflow_forward: call eemflow_set_image_size first (the reference needs "
+                             "change_imagesize before forward too)");
+    EEM_REQUIRE(batch >= 1 && in_h >= 1 && in_w >= 1 && out_h >= 1 && out_w >= 1, "eemflow_forward: bad sizes");
+    return forward_common(c, 0, &e1, &e2, &out, batch, in_h, in_w, out_h, out_w, stream);
+}
+
+// n independent samples of the evaluation loop (test_mvsec.py:580-597: one forward per sample, batch 1) as ONE batch-n chain: the
+// frames stay where the caller has them - n unrelated [1, C, H, W] event-volume pairs, n unrelated [1, 2, oh, ow] flow tensors.
+// Same arithmetic as eemflow_forward on the batch of those frames (bitwise: the same kernels in the same launch configuration).
+extern "C" int eemflow_forward_many(eemflow_ctx* c, int nframes, const float* const* e1, const float* const* e2, float* const* out,
+                                    int in_h, int in_w, int out_h, int out_w, void* stream) {
+    EEM_REQUIRE(c && e1 && e2 && out, "eemflow_forward_many: NULL argument");
+    EEM_REQUIRE(nframes >= 1 && nframes <= EEM_MAX_COALESCE, "eemflow_forward_many: 1..%d frames per call; got %d", EEM_MAX_COALESCE, nframes);
+    EEM_REQUIRE(c->weights_loaded, "eemflow_forward_many: no weights loaded");
+    EEM_REQUIRE(c->have_pad, "eemflow_forward_many: call eemflow_set_image_size first");
+    EEM_REQUIRE(in_h >= 1 && in_w >= 1 && out_h >= 1 && out_w >= 1, "eemflow_forward_many: bad sizes");
+    EEM_REQUIRE(!c->enc0_generic, "eemflow_forward_many: built for the 5-bin first layer (n_first_channels == 5)");
+    for (int i = 0; i < nframes; ++i) {
+        EEM_REQUIRE(e1[i] && e2[i] && out[i], "eemflow_forward_many: frame %d has a NULL buffer", i);
+        EEM_REQUIRE((((uintptr_t)e1[i] | (uintptr_t)e2[i] | (uintptr_t)out[i]) & 15) == 0,
+                    "eemflow_forward_many: frame %d: buffers must be 16-byte aligned (torch allocations are)", i);
+    }
+    return forward_common(c, nframes, e1, e2, out, nframes, in_h, in_w, out_h, out_w, stream);
 }
 
 // Graph-cache statistics of a context: captures (stream captures + instantiations), replays, io-table rewrites.

@@ -146,14 +146,17 @@ struct eemflow_ctx {
     struct Key {
         int batch, in_h, in_w, out_h, out_w, pad[4];
         int aligned16;                                   // all three caller buffers 16-byte aligned (kernel selection depends on it)
+        int io_frames;                                   // 0: one batch in contiguous tensors; n: n single-frame buffer triples (eemflow_forward_many)
         bool operator==(const Key& o) const {
             return batch == o.batch && in_h == o.in_h && in_w == o.in_w && out_h == o.out_h && out_w == o.out_w &&
-                   pad[0] == o.pad[0] && pad[1] == o.pad[1] && pad[2] == o.pad[2] && pad[3] == o.pad[3] && aligned16 == o.aligned16;
+                   pad[0] == o.pad[0] && pad[1] == o.pad[1] && pad[2] == o.pad[2] && pad[3] == o.pad[3] && aligned16 == o.aligned16 &&
+                   io_frames == o.io_frames;
         }
     };
     struct GraphEntry {
         Key key;
         Shape shape;
+        bool f13_skipped = false;                        // the captured schedule leaves f13 unwritten (every replay does, then)
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         long last_use = 0;
@@ -161,8 +164,10 @@ struct eemflow_ctx {
     static constexpr int kMaxGraphs = 4;
     std::vector<GraphEntry> graphs;
     long graph_clock = 0;
-    const void** io_table = nullptr;                     // device
-    const void* io_host[3] = {nullptr, nullptr, nullptr};   // what the table holds once the launches issued so far have run
+    const void** io_table = nullptr;                     // device: 3 * EEM_MAX_COALESCE pointers
+    const void* io_host[3 * EEM_MAX_COALESCE] = {};      // what the table holds once the launches issued so far have run
+    int io_host_n = 0;                                   // entries of io_host in use (3: the contiguous form)
+    int cur_io_frames = 0;                               // the schedule being issued reads per-frame triples (set around run_forward)
     void* io_stream = nullptr;                           // stream of the last table write / replay
     long graph_captures = 0, graph_replays = 0, io_updates = 0;   // statistics (eemflow_graph_stats)
 };
@@ -356,8 +361,13 @@ struct Hook {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<eemflow_kernel_stat> stats;
 
-    // diagnostic (EEM_SKIP_KERNELS="enc.pconv2_1;dec."): launches whose name starts with one of the prefixes are skipped - the flow is
-    // garbage, the frame rate says what that launch costs BESIDE the others (tools/marginal.sh); read once per process
+    // diagnostic BUILDS only (-DEEM_DIAG: `EEM_BUILD_TAG=diag EEM_EXTRA_FLAGS=-DEEM_DIAG python -m eemflow_amd.build`, loaded through
+    // EEM_LIB_PATH; the release library does not read these variables): EEM_SKIP_KERNELS="enc.pconv2_1;dec." skips the launches whose
+    // name starts with one of the prefixes - the flow is garbage, the frame rate says what that launch costs BESIDE the others
+    // (tools/marginal.sh); read once per process
+#ifndef EEM_DIAG
+    static bool skipped(const char*) { return false; }
+#else
     static bool skipped(const char* name) {
         static const std::string list = [] {
             const char* e = getenv("EEM_SKIP_KERNELS");
@@ -374,13 +384,16 @@ struct Hook {
         }
         return false;
     }
+#endif
 
     template <class F>
     int run(const char* name, double flops, double bytes, F&& launch) {
+#ifdef EEM_DIAG
         if (skipped(name)) {                                  // EEM_SKIP_SPIN_US=<us>: one lane holds the launch's place in the stream for <us>
             static const float spin = [] { const char* e = getenv("EEM_SKIP_SPIN_US"); return e ? (float)atof(e) : 0.f; }();
             return spin > 0.f ? spin_launch(spin, st) : EEM_OK;
         }
+#endif
         if (!timing) return launch(st);
         eem_last_grid_blocks = eem_last_grid_threads = eem_last_pipe = 0;
         int rc = launch(st);                                  // warm (also keeps data flowing downstream)
@@ -466,8 +479,12 @@ int run_decoders(eemflow_ctx* c, int k0, int k1, const float* const cat[3], int 
 // copy for the first layer's weight gradient anyway): the first layer then reads it with no padding of its own, which puts inputs whose
 // rows are not 16-byte multiples or that pad on the left (MVSEC: 346-pixel rows, 19 columns) on the LDS-DMA kernel of conv_enc1.hip
 static bool spans_on() {
+#ifdef EEM_DIAG
     static const bool on = [] { const char* e = getenv("EEM_SPANS"); return e && e[0] == '1'; }();
     return on;
+#else
+    return false;                                        // EEM_SPANS is a diagnostic-build switch (-DEEM_DIAG)
+#endif
 }
 static int span_mark(eemflow_ctx* c, int i, hipStream_t st) {
     if (!spans_on()) return EEM_OK;
@@ -569,6 +586,7 @@ int run_enc_layer(eemflow_ctx* c, const Shape& s, int li, const float* e1, const
         a.pool_partial = nullptr;
         a.pool_k = 0;
         a.io = sp.layer == ENC_1_1 ? io : nullptr;
+        a.io_frames = (sp.layer == ENC_1_1 && io != nullptr) ? c->cur_io_frames : 0;
         a.no_store = 0;
         // several frames in flight: kernels of different frames time-slice the CUs, so a block's prologue (DMA plan, first tile's
         // landing) is CU time another frame could use - fewer blocks with more tiles each (measured at 1280x720 with four in flight:
@@ -699,6 +717,7 @@ int run_forward_impl(eemflow_ctx* c, const Shape& s, const float* e1, const floa
         memset(&ua, 0, sizeof(ua));
         ua.wo = c->flat + c->t_outc.w; ua.bo = c->flat + c->t_outc.b;
         ua.flowcat = c->flowcat.p; ua.coarse = c->coarse.p; ua.out = out; ua.io = io;
+        ua.io_frames = io != nullptr ? c->cur_io_frames : 0;
         ua.batch = s.batch; ua.gh = s.gh; ua.gw = s.gw; ua.oh = s.out_h; ua.ow = s.out_w;
         ua.out_aligned16 = ((uintptr_t)out & 15) == 0;
         const double opix = (double)s.batch * 2 * s.out_h * s.out_w;
@@ -710,7 +729,7 @@ int run_forward_impl(eemflow_ctx* c, const Shape& s, const float* e1, const floa
     if ((rc = run_tail(hk, "out_conv 1x1 6->2", L)) != EEM_OK) return rc;
     const double opix = (double)s.batch * 2 * s.out_h * s.out_w;
     return hk.run("upsample bilinear", 8.0 * opix, 4.0 * (opix + (double)s.batch * 2 * g), [&](hipStream_t st) {
-        return upsample_launch(c->coarse.p, out, s.batch * 2, s.gh, s.gw, s.out_h, s.out_w, st, io);
+        return upsample_launch(c->coarse.p, out, s.batch * 2, s.gh, s.gw, s.out_h, s.out_w, st, io, io != nullptr ? c->cur_io_frames : 0);
     });
 }
 

@@ -168,6 +168,10 @@ struct EncConvArgs {
     // ENC_1_1 inside a cached HIP graph: device table {events1, events2, flow_out}; when non-NULL the kernel reads in0 / in1
     // from it instead of from the fields above, so the graph does not depend on the caller's buffers (api.hip)
     const void* const* io;
+    // 0: the table is {events1, events2, flow_out} of one batch in contiguous tensors.  n >= 1 (eemflow_forward_many): the table holds n
+    // triples {events1_i, events2_i, flow_out_i}, one single-frame buffer each - image i < nimg0 is read from io[3 i], image nimg0 + i from
+    // io[3 i + 1]: n unrelated frames ride one batch-n chain
+    int io_frames = 0;
     // persistent kernels: blocks per XCD (0 = one per CU).  The context lowers it when the application keeps several frames in flight
     // (eemflow_set_frames_in_flight): fewer, longer blocks spend less CU time on per-block prologues
     int blocks_per_xcd = 0;
@@ -279,10 +283,13 @@ int corr_launch(const CorrJob* jobs, int njobs, int batch, int h, int w, const i
 // plain bilinear resize (align_corners False) of [n][c][h][w] -> [n][c][oh][ow]
 // io: optional device table {events1, events2, flow_out}; when non-NULL the destination is io[2] (see EncConvArgs::io)
 int upsample_launch(const float* in, float* out, int nc, int h, int w, int oh, int ow, hipStream_t stream,
-                    const void* const* io = nullptr);
+                    const void* const* io = nullptr, int io_frames = 0);
 // writes {e1, e2, out} into the device table (one tiny launch in front of a cached graph whose buffers changed)
-int spin_launch(float us, hipStream_t stream);          // diagnostic: one wave asleep for <us> (tools/marginal.sh)
+int spin_launch(float us, hipStream_t stream);          // diagnostic builds (-DEEM_DIAG): one wave asleep for <us> (tools/marginal.sh)
 int io_table_launch(const void** table, const void* e1, const void* e2, void* out, hipStream_t stream);
+// the per-frame form: n triples {e1[i], e2[i], out[i]} (eemflow_forward_many), n <= EEM_MAX_COALESCE
+#define EEM_MAX_COALESCE 16
+int io_table_many_launch(const void** table, int n, const float* const* e1, const float* const* e2, float* const* out, hipStream_t stream);
 
 // ---- fused launches of the tail (tail_fused.hip)
 // A pooled [n][c][gh][gw] map read through the conv epilogues' partial sums: value = scale * sum_{i < rows} base[n*nstride +
@@ -312,6 +319,7 @@ struct TailUpArgs {
     float* coarse;               // side output [B][2][g] (may be NULL)
     float* out;                  // [B][2][oh][ow]
     const void* const* io;       // graph io table (out = io[2]) or NULL
+    int io_frames;               // > 0: per-frame triples, frame b writes io[3 b + 2] (see EncConvArgs::io_frames)
     int batch, gh, gw, oh, ow, out_aligned16;
     int ty, tx;                  // filled by the launcher
 };

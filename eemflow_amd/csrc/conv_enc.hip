@@ -69,8 +69,11 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(EncConvArgs a) {
         if (PADIN) {
             const float* in0 = a.io ? (const float*)a.io[0] : a.in0;     // cached graph: buffers through the io table
             const float* in1 = a.io ? (const float*)a.io[1] : a.in1;
-            src = (n < a.nimg0) ? in0 + (size_t)n * CIN * a.hraw * a.wraw
-                                : in1 + (size_t)(n - a.nimg0) * CIN * a.hraw * a.wraw;
+            if (a.io_frames)                                             // per-frame buffers (eemflow_forward_many)
+                src = (const float*)(n < a.nimg0 ? a.io[3 * n] : a.io[3 * (n - a.nimg0) + 1]);
+            else
+                src = (n < a.nimg0) ? in0 + (size_t)n * CIN * a.hraw * a.wraw
+                                    : in1 + (size_t)(n - a.nimg0) * CIN * a.hraw * a.wraw;
         }
         else
             src = a.in0 + (size_t)n * CIN * a.hin * a.win;

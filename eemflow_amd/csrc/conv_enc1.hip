@@ -77,11 +77,24 @@ __global__ __launch_bounds__(WAVES * 64) void enc1_kernel(EncConvArgs a) {
         pry[k] = rem / K::PPR;
         pq[k] = (rem - pry[k] * K::PPR) * 4;
     }
+    // eemflow_forward_many: every image is its own buffer, named by the io table's per-frame triples; a block's tiles are a contiguous
+    // range, so the image changes once or twice per block and the (dependent, scalar) table read happens only then
+    int src_n = -1;
+    const float* src_many = nullptr;
     auto issue = [&](int it, const TileCoord& tc) {
         const int bx = tc.bx, by = tc.by, n = tc.n;
         const int gy0 = by * TH * 2 - 1, gx0 = bx * K::TW * 2 - 4;          // padded-image coordinates
-        const float* src = (n < a.nimg0) ? in0 + (size_t)n * K::CIN * a.hraw * a.wraw
-                                         : in1 + (size_t)(n - a.nimg0) * K::CIN * a.hraw * a.wraw;
+        const float* src;
+        if (a.io_frames) {
+            if (n != src_n) {
+                src_many = (const float*)(n < a.nimg0 ? a.io[3 * n] : a.io[3 * (n - a.nimg0) + 1]);
+                src_n = n;
+            }
+            src = src_many;
+        } else {
+            src = (n < a.nimg0) ? in0 + (size_t)n * K::CIN * a.hraw * a.wraw
+                                : in1 + (size_t)(n - a.nimg0) * K::CIN * a.hraw * a.wraw;
+        }
         float* sbase = lds + (it % K::NST) * K::STAGE;
 #pragma unroll
         for (int k = 0; k < K::NI; ++k) {

@@ -306,9 +306,13 @@ __device__ __forceinline__ void src_index(float scale, int dst, int in_size, int
 __global__ void io_table_kernel(const void** table, const void* e1, const void* e2, void* out) {
     table[0] = e1; table[1] = e2; table[2] = out;
 }
+struct IoTriples { const void* p[3 * EEM_MAX_COALESCE]; };
+__global__ void io_table_many_kernel(const void** table, IoTriples t, int n) {
+    for (int i = threadIdx.x; i < 3 * n; i += 64) table[i] = t.p[i];
+}
 
 __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ in, float* __restrict__ out_arg,
-                                                       int nc, int h, int w, int oh, int ow, const void* const* io) {
+                                                       int nc, int h, int w, int oh, int ow, const void* const* io, int io_frames) {
     float* __restrict__ out = io ? (float*)io[2] : out_arg;
     const int xq = ceil_div(ow, 4);
     const long total = (long)nc * oh * xq;
@@ -317,6 +321,11 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
     const int q = idx % xq;
     const int oy = (idx / xq) % oh;
     const int c = idx / ((long)xq * oh);
+    int co = c;                                           // channel index inside `out`
+    if (io_frames) {                                      // per-frame flow buffers [1][2][oh][ow] (eemflow_forward_many)
+        out = (float*)io[3 * (c >> 1) + 2];
+        co = c & 1;
+    }
     const float sy = (float)h / (float)oh, sx = (float)w / (float)ow;
     int y0, y1; float ly;
     src_index(sy, oy, h, y0, y1, ly);
@@ -332,7 +341,7 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
         const float bot = (1.f - lx) * r1[x0] + lx * r1[x1];
         v[i] = (1.f - ly) * top + ly * bot;
     }
-    float* dst = out + ((size_t)c * oh + oy) * ow + q * 4;
+    float* dst = out + ((size_t)co * oh + oy) * ow + q * 4;
     if ((ow & 3) == 0) {
         *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
     } else {
@@ -450,15 +459,17 @@ int tail_conv_launch(const TailConvLaunch& l, hipStream_t stream) {
     return EEM_OK;
 }
 
-int upsample_launch(const float* in, float* out, int nc, int h, int w, int oh, int ow, hipStream_t stream, const void* const* io) {
+int upsample_launch(const float* in, float* out, int nc, int h, int w, int oh, int ow, hipStream_t stream, const void* const* io,
+                    int io_frames) {
     const long total = (long)nc * oh * ceil_div(ow, 4);
     if (total == 0) return EEM_OK;
     hipLaunchKernelGGL(upsample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, in, out, nc,
-                       h, w, oh, ow, io);
+                       h, w, oh, ow, io, io_frames);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }
 
+#ifdef EEM_DIAG
 static __global__ void spin_kernel(long ticks) {                 // wall_clock64: the 100 MHz constant clock
     const long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
@@ -477,6 +488,18 @@ int spin_launch(float us, hipStream_t stream) {
     const dim3 g(blocks), b(blocks > 1 ? 576 : 64);
     if (code) hipLaunchKernelGGL(spin_code_kernel, g, b, 0, stream, ticks);
     else hipLaunchKernelGGL(spin_kernel, g, b, 0, stream, ticks);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+#endif
+
+int io_table_many_launch(const void** table, int n, const float* const* e1, const float* const* e2, float* const* out, hipStream_t stream) {
+    EEM_REQUIRE(n >= 1 && n <= EEM_MAX_COALESCE, "io_table_many_launch: n=%d", n);
+    IoTriples t;
+    for (int i = 0; i < 3 * EEM_MAX_COALESCE; ++i) t.p[i] = nullptr;
+    for (int i = 0; i < n; ++i) { t.p[3 * i] = e1[i]; t.p[3 * i + 1] = e2[i]; t.p[3 * i + 2] = out[i]; }
+    hipLaunchKernelGGL(io_table_many_kernel, dim3(1), dim3(64), 0, stream, table, t, n);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

@@ -185,13 +185,15 @@ __device__ __forceinline__ void src_index2(float scale, int dst, int in_size, in
 
 __global__ __launch_bounds__(256) void tail_up_kernel(TailUpArgs a) {
     __shared__ float coarse_s[2][9];        // out_conv output at the block's <= 3x3 coarse pixels
-    float* __restrict__ out = a.io ? (float*)a.io[2] : a.out;
     const int tid = threadIdx.x;
     const int txn = ceil_div(a.ow, a.tx), tyn = ceil_div(a.oh, a.ty);
     int blk = blockIdx.x;
     const int bx = blk % txn; blk /= txn;
     const int by = blk % tyn;
     const int b = blk / tyn;
+    // caller's flow tensor: the argument, the graph's io table, or - eemflow_forward_many - frame b's own buffer from the table's triples
+    float* __restrict__ out = a.io ? (float*)a.io[a.io_frames ? 3 * b + 2 : 2] : a.out;
+    const int bo = a.io_frames ? 0 : b;                      // the sample's index inside `out`
     const int y0 = by * a.ty, x0 = bx * a.tx;
     const int y1 = min(y0 + a.ty, a.oh), x1 = min(x0 + a.tx, a.ow);
     const float sy = (float)a.gh / (float)a.oh, sx = (float)a.gw / (float)a.ow;
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(256) void tail_up_kernel(TailUpArgs a) {
             const float bot = (1.f - lx[i]) * rb[xa[i]] + lx[i] * rb[xb[i]];
             v[i] = (1.f - ly) * top + ly * bot;
         }
-        float* dst = out + (((size_t)b * 2 + c) * a.oh + oy) * a.ow + x0 + q * 4;
+        float* dst = out + (((size_t)bo * 2 + c) * a.oh + oy) * a.ow + x0 + q * 4;
         if (vec && x0 + q * 4 + 3 < x1) {
             *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
         } else {

@@ -194,6 +194,41 @@ class EEMFlow(nn.Module):
                                                   out_size[0], out_size[1], _lib.current_stream_ptr(e1.device)))
         return (events1, events2), [flow]
 
+    MAX_COALESCE = 16
+
+    def forward_many(self, frames):
+        """Several INDEPENDENT samples of the evaluation loop (test_mvsec.py:580-597: one `model(events1, events2)` per sample at batch 1)
+        as one batch-n chain of launches, each frame staying in its own tensors: `frames` is a sequence of (events1, events2) pairs of
+        [1, C, H, W] tensors; returns one `((events1, events2), [flow])` per frame - flow [1, 2, H, W], bitwise what `forward` gives for
+        the frames stacked into one batch.  Inference only (no autograd graph is recorded)."""
+        frames = list(frames)
+        if not 1 <= len(frames) <= self.MAX_COALESCE:
+            raise ValueError(f"forward_many: 1..{self.MAX_COALESCE} frames per call, got {len(frames)}")
+        if not hasattr(self, "image_padder"):
+            raise AttributeError("call change_imagesize(img_size) before forward (as the reference requires)")
+        keep, shape = [], None
+        for a, b in frames:
+            if not (a.is_cuda and b.is_cuda):
+                raise _lib.EEMFlowHipError("EEMFlow.forward_many: inputs must be CUDA (ROCm) tensors - this implementation has no CPU path")
+            a, b = a.contiguous().float(), b.contiguous().float()
+            if a.shape != b.shape or a.dim() != 4 or a.shape[0] != 1 or a.shape[1] != self.n_first_channels:
+                raise ValueError(f"forward_many: every frame is two (1,{self.n_first_channels},H,W) tensors, got {tuple(a.shape)} and {tuple(b.shape)}")
+            if shape is not None and a.shape != shape:
+                raise ValueError("forward_many: all frames of a call share one shape")
+            shape = a.shape
+            keep.append((a, b))
+        dev = keep[0][0].device
+        h, w = int(shape[2]), int(shape[3])
+        out_size = (16, 16) if (self.training and self.out_mesh_size) else (h, w)
+        ctx = self._context(dev)
+        n = len(keep)
+        flows = [torch.empty(1, 2, out_size[0], out_size[1], device=dev, dtype=torch.float32) for _ in range(n)]
+        arr = ctypes.c_void_p * n
+        p1, p2, po = arr(*[a.data_ptr() for a, _ in keep]), arr(*[b.data_ptr() for _, b in keep]), arr(*[f.data_ptr() for f in flows])
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().eemflow_forward_many(ctx, n, p1, p2, po, h, w, out_size[0], out_size[1], _lib.current_stream_ptr(dev)))
+        return [((frames[i][0], frames[i][1]), [flows[i]]) for i in range(n)]
+
     # ------------------------------------------------------------------ HIP context plumbing
     def _flat_weights(self, device=None):
         # state_dict order == parameter registration order (the module has no buffers)

@@ -88,6 +88,18 @@ int eemflow_graph_stats(eemflow_ctx* ctx, long long out3[3]);
 int eemflow_forward(eemflow_ctx* ctx, const float* events1, const float* events2, int batch, int in_h,
                     int in_w, float* flow_out, int out_h, int out_w, void* stream);
 
+/* nframes (1..16) INDEPENDENT samples as one batch-nframes chain: events1[i] / events2[i] are [1][C][in_h][in_w] tensors and
+ * flow_out[i] a [1][2][out_h][out_w] tensor, each wherever the caller has it (16-byte aligned; the three arrays are HOST arrays of
+ * device pointers, read before the call returns).  Bitwise the result of eemflow_forward on the batch of those frames: the same
+ * kernels in the same launch configuration - only the first conv and the upsampling find each frame through a device table of
+ * per-frame pointers, which one small launch rewrites in front of the cached graph's replay.  Why: one frame's launches leave most
+ * of the 256 CUs idle (64 - 120 tiles in the 32 / 64-channel layers, 240 pixels in the tail); a caller with several samples at hand -
+ * the evaluation loop below - gets the batched chain without first copying them into one tensor.
+ * Replaces: n iterations of `for sample in loader: model(events1=im1, events2=im2)` at batch 1, test_mvsec.py:580-597 /
+ * TestRaftEvents.run_network (test_mvsec.py:1444-1455). */
+int eemflow_forward_many(eemflow_ctx* ctx, int nframes, const float* const* events1, const float* const* events2,
+                         float* const* flow_out, int in_h, int in_w, int out_h, int out_w, void* stream);
+
 /* Per-kernel timing of the forward schedule: each kernel of the schedule is launched `reps` times back
  * to back between two HIP events recorded on `stream` (the stream the kernels run on); `ms` is the
  * average per launch.  `flops` / `bytes` are the ALGORITHMIC work of one launch (conv MACs x 2; compulsory

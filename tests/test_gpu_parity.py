@@ -606,3 +606,83 @@ def test_winograd_encoder_equals_direct_convolution(monkeypatch, h, w, form):
         scale = max(1.0, float(ref[k].abs().max()))
         assert maxerr(fast[k], ref[k]) < 2e-5 * scale, k
     assert maxerr(fast_flow, ref_flow) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------ coalesced frames (eemflow_forward_many)
+@pytest.mark.parametrize("graph", [True, False])
+@pytest.mark.parametrize("n,h,w", [(4, 720, 1280), (3, 260, 346), (5, 128, 192)])
+def test_forward_many_equals_the_batched_forward(n, h, w, graph):
+    """n independent samples of the evaluation loop (test_mvsec.py:580-597), each in its own tensors, through ONE batch-n chain:
+    bitwise the batch-n forward of the stacked frames (same kernels, same launch configuration), every frame in its own flow tensor."""
+    net, sd = make_net(41, graph=graph)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(42, n, h, w))
+    pad = [torch.empty(7 + 3 * i, device=DEV) for i in range(2 * n)]          # unrelated allocations between the frames' buffers
+    frames = [(e1[i:i + 1].clone(), e2[i:i + 1].clone()) for i in range(n)]
+    with torch.no_grad():
+        ref = net(e1, e2)[1][0].clone()
+        outs = net.forward_many(frames)
+        f12_many = net.stage("f12").clone()
+        _ = net(e1, e2)
+        f12_ref = net.stage("f12")
+    assert len(outs) == n and len(pad) == 2 * n
+    for i, ((r1, r2), preds) in enumerate(outs):
+        assert r1 is frames[i][0] and r2 is frames[i][1] and len(preds) == 1
+        assert preds[0].shape == (1, 2, h, w)
+        assert torch.equal(preds[0][0], ref[i]), f"frame {i}"
+    assert torch.equal(f12_many, f12_ref)
+    # a second call with OTHER buffers replays the same graph through a rewritten table
+    frames2 = [(a.clone(), b.clone()) for a, b in reversed(frames)]
+    with torch.no_grad():
+        outs2 = net.forward_many(frames2)
+    for i in range(n):
+        assert torch.equal(outs2[i][1][0][0], ref[n - 1 - i])
+    if graph:
+        gs = (ctypes.c_longlong * 3)()
+        _lib.check(_lib.lib().eemflow_graph_stats(net._ctx, ctypes.byref(gs)))
+        assert gs[0] == 2, list(gs)          # one capture for the batch form, one for the per-frame form
+
+
+def test_forward_many_against_the_oracle_per_frame():
+    n, h, w = 4, 260, 346
+    net, sd = make_net(43)
+    net.change_imagesize((h, w))
+    pairs = [tuple(torch.from_numpy(a) for a in synthetic_voxel_pair(50 + i, 1, h, w)) for i in range(n)]
+    with torch.no_grad():
+        outs = net.forward_many([(a.to(DEV), b.to(DEV)) for a, b in pairs])
+        for i, (a, b) in enumerate(pairs):
+            ref, _ = O.eemflow_forward(O.to_torch_sd(sd), a, b)
+            assert maxerr(outs[i][1][0], ref) < FLOW_TOL, i
+
+
+def test_forward_many_rejects_what_it_cannot_run():
+    net, _ = make_net(44)
+    net.change_imagesize((128, 192))
+    a = torch.zeros(1, 5, 128, 192, device=DEV)
+    with pytest.raises(ValueError):
+        net.forward_many([])
+    with pytest.raises(ValueError):
+        net.forward_many([(a, a)] * 17)
+    with pytest.raises(ValueError):
+        net.forward_many([(torch.zeros(2, 5, 128, 192, device=DEV),) * 2])
+    with pytest.raises(_lib.EEMFlowHipError):
+        net.forward_many([(a.cpu(), a.cpu())])
+
+
+def test_stage_f13_follows_every_graph_replay():
+    """inference leaves f13 unwritten (pconv3_3 pools it in its epilogue) and eemflow_get_stage("f13") re-runs the layer
+    with stores.  The flag that says so was only set at capture time: a replay with NEW inputs after a stage("f13") call then returned
+    the PREVIOUS frame's f13.  Two different frames through one cached graph, stage("f13") after each, against the oracle."""
+    h, w = 128, 192
+    net, sd = make_net(45)
+    net.change_imagesize((h, w))
+    tsd = O.to_torch_sd(sd)
+    for seed in (60, 61, 62):
+        e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(seed, 1, h, w))
+        with torch.no_grad():
+            _ = net(e1.to(DEV), e2.to(DEV))
+            _, st = O.eemflow_forward(tsd, e1, e2, keep=True)
+        assert maxerr(net.stage("f13")[:1], st["f13"]) < FEAT_TOL, seed
+    gs = (ctypes.c_longlong * 3)()
+    _lib.check(_lib.lib().eemflow_graph_stats(net._ctx, ctypes.byref(gs)))
+    assert gs[0] == 1 and gs[1] == 3, list(gs)

@@ -1,5 +1,8 @@
 #!/bin/bash
 # GPU box: sleeping blocks with and without 16 KB of straight-line code in front (instruction-cache footprint beside the encoders)
+# the switches used here exist in the diagnostic build only: EEM_BUILD_TAG=diag EEM_EXTRA_FLAGS=-DEEM_DIAG python -m eemflow_amd.build (before gpurun)
+export EEM_LIB_PATH="$(cd "$(dirname "$0")/.." && pwd)/eemflow_amd/libeemflow_hip_diag.so"
+[ -f "$EEM_LIB_PATH" ] || { echo "build the diagnostic library first" >&2; exit 1; }
 run() {
   EEM_SKIP_KERNELS="$1" EEM_SKIP_SPIN_US="$2" EEM_SKIP_SPIN_BLOCKS="$3" EEM_SKIP_SPIN_CODE="$4" python3 bench.py --steps 300 --warmup 30 --cpu-seconds 0 --no-other-rows --no-side-rows 2>/dev/null | python3 -c "
 import json,sys

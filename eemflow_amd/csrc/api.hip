@@ -57,7 +57,7 @@ extern "C" void eemflow_destroy(eemflow_ctx* c) {
     (void)hipSetDevice(c->device);
     drop_graph(c);
     DevBuf* bufs[] = {&c->a1, &c->f11, &c->a2, &c->b2, &c->f12, &c->a3, &c->b3, &c->f13, &c->flowcat, &c->coarse,
-                      &c->padded, &c->g_a1, &c->g_f11, &c->g_a2, &c->g_b2, &c->g_f12, &c->g_a3, &c->g_b3, &c->g_f13,
+                      &c->padded, &c->fuse_scratch, &c->g_a1, &c->g_f11, &c->g_a2, &c->g_b2, &c->g_f12, &c->g_a3, &c->g_b3, &c->g_f13,
                       &c->g_flowcat, &c->g_coarse, &c->g_flow, &c->ups_tmp, &c->grad_flat, &c->adam_m, &c->adam_v, &c->scalars};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     for (int k = 0; k < 3; ++k) {
@@ -336,6 +336,7 @@ static int forward_common(eemflow_ctx* c, int nframes, const float* const* e1, c
     };
 
     c->workspace_overwritten();
+    c->last_e1 = e1[0]; c->last_e2 = e2[0]; c->last_io_frames = nframes;
     if ((rc = ensure_forward_wino(c, batch, st)) != EEM_OK) return rc;          // outside any capture
     if (!c->use_graph || c->enc0_generic) {                           // (the generic first layer pads through the caller's pointers: no io table)
         if ((rc = alloc_workspace(c, s)) != EEM_OK) return rc;
@@ -386,6 +387,7 @@ static int forward_common(eemflow_ctx* c, int nframes, const float* const* e1, c
         ne.shape = s;
         ne.graph = g;
         ne.f13_skipped = c->f13_skipped;             // what run_forward_impl decided for this schedule
+        ne.a1_skipped = c->a1_skipped;
         hipError_t ie = hipGraphInstantiate(&ne.exec, g, nullptr, nullptr, 0);
         if (ie != hipSuccess) {
             (void)hipGraphDestroy(g);
@@ -405,6 +407,7 @@ static int forward_common(eemflow_ctx* c, int nframes, const float* const* e1, c
     // a replay runs the CAPTURED schedule: f13 is unwritten again whenever that schedule skipped its stores, whatever
     // eemflow_get_stage("f13") re-ran and cleared after an earlier frame
     c->f13_skipped = ent->f13_skipped;
+    c->a1_skipped = ent->a1_skipped;
     return EEM_OK;
 }
 
@@ -458,6 +461,7 @@ extern "C" int eemflow_time_kernels(eemflow_ctx* c, const float* e1, const float
     c->workspace_overwritten();
     c->last = s;
     c->have_last = true;
+    c->last_e1 = e1; c->last_e2 = e2; c->last_io_frames = 0;
     Hook hk;
     hk.st = (hipStream_t)stream;
     hk.timing = true;
@@ -503,6 +507,19 @@ extern "C" int eemflow_get_stage(eemflow_ctx* c, const char* name, float* dst, s
     }
     const size_t n = (size_t)dims[0] * dims[1] * dims[2] * dims[3];
     if (dst == nullptr) return EEM_OK;       // size query
+    if (nm == "a1" && c->a1_skipped) {
+        // the last forward computed pconv1_1 inside pconv1_2's block and never wrote a1: run that layer alone, on the same event volumes
+        // (the caller's tensors of that forward must still be alive - they are whenever a stage is asked for right after a forward)
+        EEM_REQUIRE(c->last_e1 && c->last_e2, "eemflow_get_stage: 'a1' needs the last forward's event volumes");
+        EEM_HIP_CHECK(hipSetDevice(c->device));
+        Hook hk;
+        hk.st = (hipStream_t)stream;
+        c->cur_io_frames = c->last_io_frames;
+        const int rc = run_enc_layer(c, s, ENC_1_1, c->last_e1, c->last_e2, hk, c->last_io_frames > 0 ? c->io_table : nullptr, nullptr, false);
+        c->cur_io_frames = 0;
+        if (rc != EEM_OK) return rc;
+        c->a1_skipped = false;
+    }
     if (nm == "f13" && c->f13_skipped) {
         // the last forward pooled f13 in pconv3_3's epilogue and left the map itself unwritten: run that one layer again, with stores
         // (its input b3 is still in the workspace)

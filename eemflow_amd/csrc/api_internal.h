@@ -142,6 +142,13 @@ struct eemflow_ctx {
     size_t enc0_gw = 0;
     bool keep_stage_stores = false;
     bool f13_skipped = false;
+    // pconv1_1 computed inside pconv1_2's block (conv_enc12.hip; inference, 5-bin first layer, EEM_NO_FUSE12=1 keeps the two launches):
+    // `a1` is then never written - eemflow_get_stage("a1") re-runs pconv1_1 alone on the last call's event volumes
+    DevBuf fuse_scratch;
+    bool a1_skipped = false;
+    const float* last_e1 = nullptr;                      // the last forward's caller buffers (contiguous form) / its io-table form
+    const float* last_e2 = nullptr;
+    int last_io_frames = 0;
     int frames_in_flight = 1;                            // eemflow_set_frames_in_flight: >= 3 shrinks the persistent encoder grids
     struct Key {
         int batch, in_h, in_w, out_h, out_w, pad[4];
@@ -157,6 +164,7 @@ struct eemflow_ctx {
         Key key;
         Shape shape;
         bool f13_skipped = false;                        // the captured schedule leaves f13 unwritten (every replay does, then)
+        bool a1_skipped = false;                         // ... and a1 (the fused first two layers)
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         long last_use = 0;
@@ -335,7 +343,8 @@ int alloc_workspace_raw(eemflow_ctx* c, const Shape& s) {
         ENS(c->t64[k], B * 64 * g);     ENS(c->t32[k], B * 32 * g);
     }
     ENS(c->flowcat, B * 6 * g);  ENS(c->coarse, B * 2 * g);
-    if (c->enc0_generic) ENS(c->padded, n2 * c->cin0 * (size_t)s.hp * s.wp);
+    if (c->enc0_generic) { ENS(c->padded, n2 * c->cin0 * (size_t)s.hp * s.wp); }
+    else { ENS(c->fuse_scratch, enc12_scratch_floats(256)); }
 #undef ENS
     return EEM_OK;
 }
@@ -613,6 +622,42 @@ int run_enc_layer(eemflow_ctx* c, const Shape& s, int li, const float* e1, const
     return EEM_OK;
 }
 
+// The first two encoder layers as ONE launch (conv_enc12.hip) when the schedule allows it: *done says whether it ran
+int run_enc12(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2, Hook& hk, const void* const* io, const float* prepadded,
+              bool* done) {
+    *done = false;
+    // opt-in (EEM_FUSE12=1; read per schedule build - a cached graph keeps the form it was captured with): measured SLOWER than the two
+    // launches it replaces, kept for the traffic it saves and as the record of that measurement
+    const char* eon = getenv("EEM_FUSE12");
+    const bool off = !(eon && eon[0] == '1');
+    if (off || c->keep_stage_stores || c->enc0_generic || prepadded != nullptr || !c->use_wino || !c->enc_wino[ENC_1_2] ||
+        !c->layer_f4(16, s.batch) || !s.fuse[0] || c->fuse_scratch.p == nullptr)
+        return EEM_OK;
+    int rc;
+    Enc12Args a;
+    memset(&a, 0, sizeof(a));
+    a.in0 = e1; a.in1 = e2; a.io = io; a.io_frames = io != nullptr ? c->cur_io_frames : 0;
+    a.wpk1 = c->arena + c->enc_w[ENC_1_1]; a.bias1 = c->arena + c->enc_b[ENC_1_1];
+    int f4 = 0;
+    if ((rc = ensure_wino(c, ENC_1_2, 0, s.batch, hk.st, &a.u2, &f4)) != EEM_OK) return rc;
+    if (!f4) return EEM_OK;
+    a.bias2 = c->arena + c->enc_b[ENC_1_2];
+    a.zero_page = c->zero_page; a.trash = c->zero_page + 256;
+    a.out = c->f11.p; a.pool_partial = c->ppart[0].p; a.scratch = c->fuse_scratch.p;
+    a.nimg = 2 * s.batch; a.nimg0 = s.batch;
+    a.hraw = s.in_h; a.wraw = s.in_w; a.pad_top = c->pad[2];
+    a.hin = s.hp; a.win = s.wp; a.h1 = s.h1; a.w1 = s.w1;
+    if (c->pad[0] != 0 || !enc12_supported(a)) return EEM_OK;
+    const int blocks = enc12_blocks(a.nimg, a.h1, a.w1, 0);
+    if (enc12_scratch_floats(blocks) > c->fuse_scratch.cap) return EEM_OK;
+    const double n2 = 2.0 * s.batch, opix = n2 * s.h1 * s.w1;
+    const double flops = 2.0 * opix * 16 * (5 + 16) * 9;
+    const double bytes = 4.0 * (n2 * s.in_h * s.in_w * 5 + opix * 16 + 16.0 * (5 + 16) * 9 + 32);
+    rc = hk.run("enc.pconv1_1+1_2 fused 5->16 s2 +pad, 16->16", flops, bytes, [&](hipStream_t st) { return enc12_launch(a, blocks, st); });
+    if (rc == EEM_OK) *done = true;
+    return rc;
+}
+
 int run_forward_impl(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2, float* out, Hook& hk,
                      const void* const* io, const float* prepadded);
 int run_forward(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2, float* out, Hook& hk,
@@ -628,7 +673,11 @@ int run_forward_impl(eemflow_ctx* c, const Shape& s, const float* e1, const floa
     int rc;
     const int n2 = 2 * s.batch;
     // ---- encoder (both event volumes as one batch; shared weights, EEMFlow.py:135-140)
-    for (int li = 0; li < ENC_NUM; ++li)
+    // pconv1_1 + pconv1_2 as one launch when nothing needs a1 itself (inference; the training forward keeps every activation)
+    bool fused12 = false;
+    if ((rc = run_enc12(c, s, e1, e2, hk, io, prepadded, &fused12)) != EEM_OK) return rc;
+    c->a1_skipped = fused12;
+    for (int li = fused12 ? ENC_2_1 : 0; li < ENC_NUM; ++li)
         if ((rc = run_enc_layer(c, s, li, e1, e2, hk, io, prepadded, !c->keep_stage_stores)) != EEM_OK) return rc;
     c->f13_skipped = !c->keep_stage_stores;
     // ---- stage pooling to the common 1/64 grid (EEMFlow.py:144-154), 53-tap correlation and rconv into the decoders' input

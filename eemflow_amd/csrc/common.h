@@ -239,6 +239,34 @@ int wino32_transform_launch(const float* w, int c, int transpose_flip, float* pa
 int wino32_launch(int c, const EncConvArgs& a, hipStream_t stream);
 void wino32_tile(int c, int* th, int* tw, int* poolk);
 
+// pconv1_1 computed inside pconv1_2's block (conv_enc12.hip): the first two encoder layers as ONE launch, `a1` never written to memory
+struct Enc12Args {
+    const float* in0;            // events1 [nimg0][5][hraw][wraw] (images 0 .. nimg0-1)
+    const float* in1;            // events2 (images nimg0 .. nimg-1)
+    const void* const* io;       // graph io table or NULL, as EncConvArgs::io / io_frames
+    int io_frames;
+    const float* wpk1;           // pconv1_1 weights packed by enc_pack_weights(5, 16)
+    const float* bias1;          // pconv1_1 bias [16]
+    const float* u2;             // pconv1_2 weights in the Winograd F(4x4,3x3) fragment order (wino4_transform_launch)
+    const float* bias2;          // pconv1_2 bias [16]
+    const float* zero_page;
+    float* trash;
+    float* out;                  // f11 [nimg][16][h1][w1]
+    float* pool_partial;         // 32 x 32 stage-pooling partial sums (conv_wino4.hip's layout)
+    float* scratch;              // enc12_scratch_floats(blocks) floats: a block's haloed a1 tile in ring-slot layout (L2-resident)
+    int nimg, nimg0;
+    int hraw, wraw, pad_top;     // raw event-volume extent; rows replicated on top (bottom rows follow from hin)
+    int hin, win;                // replicate-padded extent = pconv1_1's input
+    int h1, w1;                  // a1 / f11 extent
+    int tiles_x, tiles_y;        // filled by the launcher
+    int dbg;                     // diagnostic builds (-DEEM_DIAG): phases switched off (EEM_E12_DBG)
+    int row_order;               // tiles in row order (x fastest) instead of the column walk (EEM_E12_ROW_ORDER=1: measurement)
+};
+bool enc12_supported(const Enc12Args& a);
+int enc12_blocks(int nimg, int h1, int w1, int blocks_per_xcd);
+size_t enc12_scratch_floats(int blocks);
+int enc12_launch(const Enc12Args& a, int blocks, hipStream_t stream);
+
 // ----------------------------------------------------------------------------- tail kernels
 // Generic small-grid 3x3 (or 1x1) conv on MFMA 16x16x4, K split over the 4 waves of a block.
 struct TailConvJob {

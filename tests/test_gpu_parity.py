@@ -686,3 +686,32 @@ def test_stage_f13_follows_every_graph_replay():
     gs = (ctypes.c_longlong * 3)()
     _lib.check(_lib.lib().eemflow_graph_stats(net._ctx, ctypes.byref(gs)))
     assert gs[0] == 1 and gs[1] == 3, list(gs)
+
+
+# ------------------------------------------------------------------------------------------------ pconv1_1 inside pconv1_2's block
+@pytest.mark.parametrize("b,h,w", [(1, 720, 1280), (2, 256, 384), (1, 192, 1000), (3, 100, 152), (1, 64, 64)])
+def test_fused_first_two_layers_equal_the_two_launches(b, h, w, monkeypatch):
+    """conv_enc12.hip computes pconv1_1 (EEMFlow.py:75) inside pconv1_2's block (EEMFlow.py:76) with the arithmetic of the two kernels it
+    replaces (same MFMA operand order, same k order): f11, the pooled map, the flow and `a1` - re-run on demand, since it is never
+    written - are BITWISE those of the two launches; and both agree with the oracle.  Sizes: the headline, tiles cut by the right and
+    bottom edges, replicate-padded rows, an image smaller than one tile."""
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(72, b, h, w))
+    d1, d2 = e1.to(DEV), e2.to(DEV)                              # alive while stage("a1") re-runs the first layer on them
+    got = {}
+    for off in ("1", "0"):
+        monkeypatch.setenv("EEM_FUSE12", "0" if off == "1" else "1")
+        net, sd = make_net(71)
+        net.change_imagesize((h, w))
+        with torch.no_grad():
+            flow = net(d1, d2)[1][0]
+        got[off] = {"flow": flow.clone(), "f11": net.stage("f11").clone(), "pool_1": net.stage("pool_1").clone(), "a1": net.stage("a1").clone()}
+        with torch.no_grad():                                    # a second frame through the cached graph, then a1 again
+            flow2 = net(d2, d1)[1][0]
+        got[off]["a1_swapped"] = net.stage("a1").clone()
+        got[off]["flow_swapped"] = flow2.clone()
+    for k in got["1"]:
+        assert torch.equal(got["0"][k], got["1"][k]), k
+    with torch.no_grad():
+        ref, st = O.eemflow_forward(O.to_torch_sd(sd), e1, e2, keep=True)
+    assert maxerr(got["0"]["f11"][:b], st["f11"]) < FEAT_TOL
+    assert maxerr(got["0"]["flow"], ref) < FLOW_TOL

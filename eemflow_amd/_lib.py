@@ -33,6 +33,7 @@ _SIGNATURES = {
     "eemflow_set_image_size": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int * 4)]),
     "eemflow_use_graph": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "eemflow_set_frames_in_flight": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "eemflow_set_deferred_input_norm": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "eemflow_graph_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong * 3)]),
     "eemflow_forward": (ctypes.c_int, [ctypes.c_void_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
@@ -64,6 +65,8 @@ _SIGNATURES = {
                                         ctypes.c_int, _c_float_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "eemflow_voxelize_pair": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_void_p]),
+    "eemflow_voxelize_many": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64), ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
     "eemflow_forward_backward": (ctypes.c_int, [ctypes.c_void_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, _c_float_p,
                                                 _c_float_p, ctypes.POINTER(ctypes.c_double * 5), ctypes.c_void_p]),

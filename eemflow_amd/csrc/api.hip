@@ -295,6 +295,12 @@ extern "C" int eemflow_use_graph(eemflow_ctx* c, int enable) {
     return EEM_OK;
 }
 
+extern "C" int eemflow_set_deferred_input_norm(eemflow_ctx* c, int enable) {
+    EEM_REQUIRE(c, "eemflow_set_deferred_input_norm: NULL context");
+    c->deferred_norm = enable != 0;                                   // (part of the graph key: both forms may be cached side by side)
+    return EEM_OK;
+}
+
 extern "C" int eemflow_set_frames_in_flight(eemflow_ctx* c, int n) {
     EEM_REQUIRE(c && n >= 1, "eemflow_set_frames_in_flight: need a context and n >= 1");
     if ((c->frames_in_flight >= 3) != (n >= 3)) drop_graph(c);       // the cached graphs hold the other grid sizes
@@ -351,7 +357,8 @@ static int forward_common(eemflow_ctx* c, int nframes, const float* const* e1, c
         c->cur_io_frames = 0;
         return rc;
     }
-    const eemflow_ctx::Key key = {batch, in_h, in_w, out_h, out_w, {c->pad[0], c->pad[1], c->pad[2], c->pad[3]}, aligned, nframes};
+    const eemflow_ctx::Key key = {batch, in_h, in_w, out_h, out_w, {c->pad[0], c->pad[1], c->pad[2], c->pad[3]}, aligned, nframes,
+                                  c->deferred_norm ? 1 : 0};
     eemflow_ctx::GraphEntry* ent = nullptr;
     for (eemflow_ctx::GraphEntry& g : c->graphs)
         if (g.key == key) ent = &g;
@@ -607,7 +614,8 @@ static int voxelize_jobs(int njobs, const double* const* events, const int64_t* 
         ar->stream = stream;
     }
     ar->used = ++tick;
-    size_t part[2] = {0, 0}, need = 0;
+    EEM_REQUIRE(njobs >= 1 && njobs <= VOX_MAX_JOBS, "voxelize: %d event sets per call (1..%d)", njobs, VOX_MAX_JOBS);
+    size_t part[VOX_MAX_JOBS] = {}, need = 0;
     for (int k = 0; k < njobs; ++k) { part[k] = (voxel_scratch_bytes(n[k]) + 255) & ~(size_t)255; need += part[k]; }
     if (ar->p == nullptr || ar->dev != dev || ar->cap < need) {
         if (ar->p) {                                                             // synchronises with work using it
@@ -622,7 +630,8 @@ static int voxelize_jobs(int njobs, const double* const* events, const int64_t* 
         if (!ar->done) EEM_HIP_CHECK(hipEventCreateWithFlags(&ar->done, hipEventDisableTiming));
         ar->dev = dev;
     }
-    void* scratch[2] = {ar->p, (char*)ar->p + part[0]};
+    void* scratch[VOX_MAX_JOBS];
+    { char* q = (char*)ar->p; for (int k = 0; k < njobs; ++k) { scratch[k] = q; q += part[k]; } }
     hipEvent_t done = ar->done;
     const int rc = voxel_launch_jobs(njobs, events, n, bins, h, w, normalize, grid, idx_left, idx_right, scratch, (hipStream_t)stream);
     if (rc == EEM_OK) EEM_HIP_CHECK(hipEventRecord(done, (hipStream_t)stream));
@@ -633,6 +642,18 @@ extern "C" int eemflow_voxelize(const double* events, int64_t n, int bins, int h
                                 int64_t* idx_left, int64_t* idx_right, void* stream) {
     EEM_REQUIRE(events && grid, "eemflow_voxelize: NULL argument");
     return voxelize_jobs(1, &events, &n, bins, h, w, normalize, &grid, &idx_left, &idx_right, stream);
+}
+
+// The event sets of SEVERAL samples (both volumes of each: 2 x the coalescing width of eemflow_forward_many) in ONE three-launch sequence:
+// at the evaluation loop's 2 x 10^5 events per volume a voxelization is three launches at their fixed costs (~47 us per pair of grids,
+// whatever the pair count up to the chip's width), so a call per sample spends more stream time voxelizing than the forward takes.
+extern "C" int eemflow_voxelize_many(int nsets, const double* const* events, const int64_t* n_events, int bins, int h, int w, int normalize,
+                                     float* const* grids, void* stream) {
+    EEM_REQUIRE(events && n_events && grids, "eemflow_voxelize_many: NULL argument");
+    EEM_REQUIRE(nsets >= 1 && nsets <= VOX_MAX_JOBS, "eemflow_voxelize_many: 1..%d event sets per call; got %d", VOX_MAX_JOBS, nsets);
+    int64_t* none[VOX_MAX_JOBS] = {};
+    for (int k = 0; k < nsets; ++k) EEM_REQUIRE(events[k] && grids[k], "eemflow_voxelize_many: set %d has a NULL buffer", k);
+    return voxelize_jobs(nsets, events, n_events, bins, h, w, normalize, grids, none, none, stream);
 }
 
 // Both event sets of a sample (loader/HREM.py:226-232: event_volume_old, event_volume_new) in ONE three-launch sequence instead of

@@ -150,14 +150,18 @@ struct eemflow_ctx {
     const float* last_e2 = nullptr;
     int last_io_frames = 0;
     int frames_in_flight = 1;                            // eemflow_set_frames_in_flight: >= 3 shrinks the persistent encoder grids
+    // eemflow_set_deferred_input_norm: the event volumes handed to forward / forward_many are RAW voxel grids with their normalisation
+    // record behind them (eemflow_voxelize*, normalize = 2); pconv1_1 normalises as it reads
+    bool deferred_norm = false;
     struct Key {
         int batch, in_h, in_w, out_h, out_w, pad[4];
         int aligned16;                                   // all three caller buffers 16-byte aligned (kernel selection depends on it)
         int io_frames;                                   // 0: one batch in contiguous tensors; n: n single-frame buffer triples (eemflow_forward_many)
+        int deferred_norm;
         bool operator==(const Key& o) const {
             return batch == o.batch && in_h == o.in_h && in_w == o.in_w && out_h == o.out_h && out_w == o.out_w &&
                    pad[0] == o.pad[0] && pad[1] == o.pad[1] && pad[2] == o.pad[2] && pad[3] == o.pad[3] && aligned16 == o.aligned16 &&
-                   io_frames == o.io_frames;
+                   io_frames == o.io_frames && deferred_norm == o.deferred_norm;
         }
     };
     struct GraphEntry {
@@ -596,6 +600,7 @@ int run_enc_layer(eemflow_ctx* c, const Shape& s, int li, const float* e1, const
         a.pool_k = 0;
         a.io = sp.layer == ENC_1_1 ? io : nullptr;
         a.io_frames = (sp.layer == ENC_1_1 && io != nullptr) ? c->cur_io_frames : 0;
+        a.in_norm = (sp.layer == ENC_1_1 && c->deferred_norm && prepadded == nullptr) ? 1 : 0;
         a.no_store = 0;
         // several frames in flight: kernels of different frames time-slice the CUs, so a block's prologue (DMA plan, first tile's
         // landing) is CU time another frame could use - fewer blocks with more tiles each (measured at 1280x720 with four in flight:
@@ -630,7 +635,7 @@ int run_enc12(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2, 
     // launches it replaces, kept for the traffic it saves and as the record of that measurement
     const char* eon = getenv("EEM_FUSE12");
     const bool off = !(eon && eon[0] == '1');
-    if (off || c->keep_stage_stores || c->enc0_generic || prepadded != nullptr || !c->use_wino || !c->enc_wino[ENC_1_2] ||
+    if (off || c->deferred_norm || c->keep_stage_stores || c->enc0_generic || prepadded != nullptr || !c->use_wino || !c->enc_wino[ENC_1_2] ||
         !c->layer_f4(16, s.batch) || !s.fuse[0] || c->fuse_scratch.p == nullptr)
         return EEM_OK;
     int rc;

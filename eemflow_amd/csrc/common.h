@@ -172,6 +172,9 @@ struct EncConvArgs {
     // triples {events1_i, events2_i, flow_out_i}, one single-frame buffer each - image i < nimg0 is read from io[3 i], image nimg0 + i from
     // io[3 i + 1]: n unrelated frames ride one batch-n chain
     int io_frames = 0;
+    // ENC_1_1 only: the event volumes are RAW voxel grids, each followed by its four-float normalisation record (eemflow_voxelize with
+    // normalize = 2); the kernel normalises as it reads (conv_enc1.hip) - the other first-layer kernels do not know this form
+    int in_norm = 0;
     // persistent kernels: blocks per XCD (0 = one per CU).  The context lowers it when the application keeps several frames in flight
     // (eemflow_set_frames_in_flight): fewer, longer blocks spend less CU time on per-block prologues
     int blocks_per_xcd = 0;
@@ -361,6 +364,7 @@ int repack_launch(const float* flat, const int* idx, float* arena, long n, hipSt
 int voxel_launch(const double* events, int64_t n, int bins, int h, int w, int normalize, float* grid,
                  int64_t* idx_left, int64_t* idx_right, void* scratch, hipStream_t stream);
 size_t voxel_scratch_bytes(int64_t n);
-// one or two voxelizations of the same grid shape in ONE three-launch sequence (blockIdx.y = job)
+// up to VOX_MAX_JOBS voxelizations of the same grid shape in ONE three-launch sequence (blockIdx.y = job)
+#define VOX_MAX_JOBS 32
 int voxel_launch_jobs(int njobs, const double* const* events, const int64_t* n, int bins, int h, int w, int normalize, float* const* grid,
                       int64_t* const* idx_left, int64_t* const* idx_right, void* const* scratch, hipStream_t stream);

@@ -264,6 +264,12 @@ int enc_conv_launch(int cin, int cout, int stride, const EncConvArgs& a, hipStre
         eem_set_error("enc_conv_launch: zero_page is NULL");
         return EEM_ERR_ARG;
     }
+    if (a.in_norm) {                                     // raw voxel grids + normalisation records: only conv_enc1.hip reads that form
+        if (cin == 5 && cout == 16 && stride == 2 && enc1_supported(a)) return enc1_launch(a, stream);
+        eem_set_error("deferred input normalisation needs the 5-bin first layer on 16-byte-aligned volumes whose width is a multiple of 4 "
+                      "and that pad on the bottom only (conv_enc1.hip); normalise in the voxelizer instead");
+        return EEM_ERR_ARG;
+    }
     if (a.ws2r && s2r_supported(cin, cout, stride, a)) return s2r_launch(cin, a, stream);
     if (a.wbx3 && bx3_supported(cin, cout, stride, a)) return bx3_launch(cin, stride, a, stream);
     if (a.wwino && wino_supported(cin, cout, stride, a.win)) return wino_launch(cin, a, stream);

@@ -37,7 +37,10 @@ struct E1Cfg {
     static_assert(NST * STAGE * 4 <= 160 * 1024, "LDS budget");
 };
 
-template <int TH, int TWT, int WAVES>
+// NORM: the event volumes are RAW voxel grids followed by their normalisation record {mean, sd, scale, any} (eemflow_voxelize with
+// normalize = 2): loader_utils.py:527-535's (v - mean) / sd on the non-zero voxels is applied to every operand as it is read from LDS
+// (zero padding and empty voxels stay 0; replicated rows normalise like the rows they copy)
+template <int TH, int TWT, int WAVES, bool NORM>
 __global__ __launch_bounds__(WAVES * 64) void enc1_kernel(EncConvArgs a) {
     ENC_ARGS_NOW(a);
     using K = E1Cfg<TH, TWT, WAVES>;
@@ -92,8 +95,8 @@ __global__ __launch_bounds__(WAVES * 64) void enc1_kernel(EncConvArgs a) {
             }
             src = src_many;
         } else {
-            src = (n < a.nimg0) ? in0 + (size_t)n * K::CIN * a.hraw * a.wraw
-                                : in1 + (size_t)(n - a.nimg0) * K::CIN * a.hraw * a.wraw;
+            const size_t img = (size_t)K::CIN * a.hraw * a.wraw + (NORM ? 4 : 0);     // (a batch of raw grids carries a record behind each)
+            src = (n < a.nimg0) ? in0 + (size_t)n * img : in1 + (size_t)(n - a.nimg0) * img;
         }
         float* sbase = lds + (it % K::NST) * K::STAGE;
 #pragma unroll
@@ -122,6 +125,21 @@ __global__ __launch_bounds__(WAVES * 64) void enc1_kernel(EncConvArgs a) {
         const int row = unit / TWT, ct = unit % TWT;
         ubase[u] = row * 2 * K::ROWP + (ct * 16 + j) * 2 + 3;
     }
+
+    // the normalisation record of the image being multiplied (scalar loads when the image changes: once or twice per block)
+    int rec_n = -1;
+    float n_mean = 0.f, n_inv = 1.f;
+    bool n_on = false;
+    auto load_record = [&](int n) {
+        const float* img;
+        if (a.io_frames) img = (const float*)(n < a.nimg0 ? a.io[3 * n] : a.io[3 * (n - a.nimg0) + 1]);
+        else img = (n < a.nimg0) ? in0 + (size_t)n * (K::CIN * a.hraw * a.wraw + 4) : in1 + (size_t)(n - a.nimg0) * (K::CIN * a.hraw * a.wraw + 4);
+        const float* rec = img + (size_t)K::CIN * a.hraw * a.wraw;
+        n_mean = rec[0];
+        n_inv = rec[2] != 0.f ? 1.f / rec[1] : 1.f;
+        n_on = rec[3] != 0.f;
+        rec_n = n;
+    };
 
     issue(0, nxt);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -153,6 +171,9 @@ __global__ __launch_bounds__(WAVES * 64) void enc1_kernel(EncConvArgs a) {
 
         const int bx = cur.bx, by = cur.by, n = cur.n;
         const float* tb = lds + (it % K::NST) * K::STAGE;
+        if constexpr (NORM) {
+            if (n != rec_n) load_record(n);
+        }
 
         f32x4 acc[K::UPW];
 #pragma unroll
@@ -162,8 +183,11 @@ __global__ __launch_bounds__(WAVES * 64) void enc1_kernel(EncConvArgs a) {
 #pragma unroll
         for (int s = 0; s < K::KSTEPS; ++s)
 #pragma unroll
-            for (int u = 0; u < K::UPW; ++u)
-                acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(tb[ubase[u] + koff[s]], wr[s >> 2][s & 3], acc[u], 0, 0, 0);
+            for (int u = 0; u < K::UPW; ++u) {
+                float x = tb[ubase[u] + koff[s]];
+                if constexpr (NORM) x = (n_on && x != 0.f) ? (x - n_mean) * n_inv : x;
+                acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, wr[s >> 2][s & 3], acc[u], 0, 0, 0);
+            }
 
         const int hw = a.hout * a.wout;
         float* dst = a.out + (size_t)n * K::COUT * hw;
@@ -203,7 +227,8 @@ int enc1_launch(const EncConvArgs& a0, hipStream_t stream) {
     const int cap = env_cap > 0 ? env_cap : (a.blocks_per_xcd > 0 ? a.blocks_per_xcd : 32);   // default: one resident block per CU
     if (per_xcd > cap) per_xcd = cap;
     EEM_NOTE_GRID(per_xcd * 8, WAVES * 64);
-    hipLaunchKernelGGL((enc1_kernel<TH, TWT, WAVES>), dim3(per_xcd * 8), dim3(WAVES * 64), 0, stream, a);
+    if (a.in_norm) hipLaunchKernelGGL((enc1_kernel<TH, TWT, WAVES, true>), dim3(per_xcd * 8), dim3(WAVES * 64), 0, stream, a);
+    else hipLaunchKernelGGL((enc1_kernel<TH, TWT, WAVES, false>), dim3(per_xcd * 8), dim3(WAVES * 64), 0, stream, a);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

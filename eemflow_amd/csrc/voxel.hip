@@ -166,7 +166,7 @@ struct VoxJob {
     VoxSums* acc;
     int nblk;                // binning blocks (slabs) of this job
 };
-struct VoxJobs { VoxJob j[2]; };
+struct VoxJobs { VoxJob j[VOX_MAX_JOBS]; };      // (72 bytes each: 2.3 KB of kernel arguments at 32 jobs)
 
 // ------------------------------------------------------------------------------------------------ 1. binning into slabs
 // Block `blk` owns the slab recs[blk * E .. (blk + 1) * E) (E = 1024 * EPT events per block): its votes, sorted by band, and
@@ -450,6 +450,19 @@ __global__ __launch_bounds__(VT) void vox_norm_kernel(VoxJobs jobs, long total, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ 4b. normalisation left to the consumer
+// normalize == 2 ("deferred"): the grid stays RAW and the four floats behind it - grid[total .. total + 4) - receive the record
+// {mean, sd, scale ? 1 : 0, any ? 1 : 0} of loader_utils.py:527-535; the first encoder layer applies (v - mean) / sd to the non-zero voxels
+// as it reads them (conv_enc1.hip), so the 2 x 18.4 MB read-modify-write of vox_norm_kernel never happens.  One block per job.
+__global__ __launch_bounds__(VT) void vox_stats_kernel(VoxJobs jobs, long total, int nsums) {
+    __shared__ double sh3[VT / 64 * 3];
+    const VoxNorm nm = vox_final(jobs.j[blockIdx.x].acc, nsums, sh3);
+    if (threadIdx.x == 0) {
+        float* rec = jobs.j[blockIdx.x].grid + total;
+        rec[0] = nm.mean; rec[1] = nm.scale ? nm.sd : 1.f; rec[2] = nm.scale ? 1.f : 0.f; rec[3] = nm.any ? 1.f : 0.f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ direct path: moments
 __global__ __launch_bounds__(VT) void vox_moments_kernel(const float* __restrict__ grid, long total, VoxSums* __restrict__ acc) {
     __shared__ double sh3[VT / 64 * 3];
@@ -522,20 +535,22 @@ size_t voxel_scratch_bytes(int64_t n) {
 // njobs (1 or 2) voxelizations of the same grid shape in one launch sequence; scratch[k] >= voxel_scratch_bytes(n[k]) each
 int voxel_launch_jobs(int njobs, const double* const* events, const int64_t* n, int bins, int h, int w, int normalize, float* const* grid,
                       int64_t* const* idx_left, int64_t* const* idx_right, void* const* scratch, hipStream_t stream) {
-    EEM_REQUIRE(njobs == 1 || njobs == 2, "voxelize: %d jobs", njobs);
+    EEM_REQUIRE(njobs >= 1 && njobs <= VOX_MAX_JOBS, "voxelize: %d jobs (1..%d per launch sequence)", njobs, VOX_MAX_JOBS);
     for (int k = 0; k < njobs; ++k)
         EEM_REQUIRE(n[k] >= 1, "voxelize: need at least one event (the reference indexes events[-1], "
                                "loader_utils.py:476), got n=%ld", (long)n[k]);
     EEM_REQUIRE(bins > 0 && h > 0 && w > 0, "voxelize: bad shape bins=%d h=%d w=%d", bins, h, w);
+    EEM_REQUIRE(normalize >= 0 && normalize <= 2, "voxelize: normalize is 0 (raw), 1 (normalised grid) or 2 (raw grid + record); got %d", normalize);
     const long total = (long)bins * h * w;
     VoxPlan pl;
     int lds = 0;
     int nsums = 0;
-    const int64_t nmax = njobs == 2 && n[1] > n[0] ? n[1] : n[0];
+    int64_t nmax = n[0];
+    for (int k = 1; k < njobs; ++k) nmax = n[k] > nmax ? n[k] : nmax;
     bool planned = true;
     for (int k = 0; k < njobs; ++k) planned = planned && make_plan(n[k], bins, h, w, events[k], &pl, &lds);
-    if (!planned && njobs == 2) {                                      // the direct kernel has no pair form: one after the other
-        for (int k = 0; k < 2; ++k) {
+    if (!planned && njobs >= 2) {                                      // the direct kernel has no multi-job form: one after the other
+        for (int k = 0; k < njobs; ++k) {
             const int rc = voxel_launch_jobs(1, events + k, n + k, bins, h, w, normalize, grid + k, idx_left + k, idx_right + k, scratch + k, stream);
             if (rc != EEM_OK) return rc;
         }
@@ -594,7 +609,7 @@ int voxel_launch_jobs(int njobs, const double* const* events, const int64_t* n, 
             else
                 hipLaunchKernelGGL(vox_band_kernel<VT>, dim3(pl.nb, njobs), dim3(VT), lds, stream, jobs, VT * ept, bins, pl, vec4, with_moments, mode, sgs);
         };
-        if (normalize && two_pass_ratio > 0 && (long)nmax * two_pass_ratio <= total) {
+        if (normalize == 1 && two_pass_ratio > 0 && (long)nmax * two_pass_ratio <= total) {
             band(1, (int)VOX_BAND_MOMENTS);
             band(1, (int)VOX_BAND_NORMALISED);
             EEM_HIP_CHECK(hipGetLastError());
@@ -614,10 +629,15 @@ int voxel_launch_jobs(int njobs, const double* const* events, const int64_t* n, 
         }
     }
     EEM_HIP_CHECK(hipGetLastError());
+    if (normalize == 2) {                                              // deferred: the record behind each grid, no pass over the grids
+        hipLaunchKernelGGL(vox_stats_kernel, dim3(njobs), dim3(VT), 0, stream, jobs, total, nsums);
+        EEM_HIP_CHECK(hipGetLastError());
+        return EEM_OK;
+    }
     if (normalize) {
         long blocks = (total / 4 + VT - 1) / VT;
         blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);   // one block per CU: the sums are re-added once per block
-        if (njobs == 2 && blocks > 128) blocks = 128;              // the pair shares the chip
+        if (njobs >= 2 && blocks > 256 / njobs) blocks = std::max(16L, 256L / njobs);     // the jobs share the chip
         hipLaunchKernelGGL(vox_norm_kernel, dim3((unsigned)blocks, njobs), dim3(VT), 0, stream, jobs, total, nsums);
         EEM_HIP_CHECK(hipGetLastError());
     }

@@ -196,11 +196,13 @@ class EEMFlow(nn.Module):
 
     MAX_COALESCE = 16
 
-    def forward_many(self, frames):
+    def forward_many(self, frames, deferred_norm=False):
         """Several INDEPENDENT samples of the evaluation loop (test_mvsec.py:580-597: one `model(events1, events2)` per sample at batch 1)
         as one batch-n chain of launches, each frame staying in its own tensors: `frames` is a sequence of (events1, events2) pairs of
         [1, C, H, W] tensors; returns one `((events1, events2), [flow])` per frame - flow [1, 2, H, W], bitwise what `forward` gives for
-        the frames stacked into one batch.  Inference only (no autograd graph is recorded)."""
+        the frames stacked into one batch.  Inference only (no autograd graph is recorded).
+        deferred_norm=True: the frames are RAW voxel grids with their normalisation record behind them (the voxelizer's
+        normalize="deferred"); pconv1_1 applies loader_utils.py:527-535's (v - mean) / sd as it reads them."""
         frames = list(frames)
         if not 1 <= len(frames) <= self.MAX_COALESCE:
             raise ValueError(f"forward_many: 1..{self.MAX_COALESCE} frames per call, got {len(frames)}")
@@ -215,12 +217,18 @@ class EEMFlow(nn.Module):
                 raise ValueError(f"forward_many: every frame is two (1,{self.n_first_channels},H,W) tensors, got {tuple(a.shape)} and {tuple(b.shape)}")
             if shape is not None and a.shape != shape:
                 raise ValueError("forward_many: all frames of a call share one shape")
+            if deferred_norm:
+                from .voxelizer import has_norm_record
+                if not (has_norm_record(a) and has_norm_record(b)):
+                    raise ValueError("forward_many(deferred_norm=True): every volume needs its four-float record behind it "
+                                     "(voxelize with normalize='deferred')")
             shape = a.shape
             keep.append((a, b))
         dev = keep[0][0].device
         h, w = int(shape[2]), int(shape[3])
         out_size = (16, 16) if (self.training and self.out_mesh_size) else (h, w)
         ctx = self._context(dev)
+        _lib.check(_lib.lib().eemflow_set_deferred_input_norm(ctx, 1 if deferred_norm else 0))
         n = len(keep)
         flows = [torch.empty(1, 2, out_size[0], out_size[1], device=dev, dtype=torch.float32) for _ in range(n)]
         arr = ctypes.c_void_p * n
@@ -266,6 +274,7 @@ class EEMFlow(nn.Module):
         assert list(pad) == self.image_padder._pad
         _lib.check(L.eemflow_use_graph(self._ctx, 1 if self.use_graph else 0))
         _lib.check(L.eemflow_set_frames_in_flight(self._ctx, max(1, int(self.frames_in_flight))))
+        _lib.check(L.eemflow_set_deferred_input_norm(self._ctx, 0))       # (forward_many(deferred_norm=True) turns it on for its call)
         return self._ctx
 
     def stage(self, name):

@@ -77,6 +77,16 @@ int eemflow_use_graph(eemflow_ctx* ctx, int enable);
  * Give the process enough hardware queues for its streams (GPU_MAX_HW_QUEUES). */
 int eemflow_set_frames_in_flight(eemflow_ctx* ctx, int n);
 
+/* enable != 0: the event volumes handed to eemflow_forward / eemflow_forward_many are RAW voxel grids, each followed in memory by its
+ * four-float normalisation record - what eemflow_voxelize / _pair / _many write with normalize = 2.  The first convolution applies
+ * (v - mean) / sd to the non-zero voxels as it reads them, so the voxelizer's read-modify-write of every grid (2 x 18.4 MB per volume at
+ * 1280x720x5) is never made.  Needs the 5-bin first layer on volumes whose rows are 16-byte multiples and that pad on the bottom only
+ * (HREM 1280x720: yes; MVSEC 346x260: no - normalise in the voxelizer there); the call fails otherwise.  In a contiguous batch
+ * (eemflow_forward) every sample is [C*H*W + 4] floats long.  Training entry points ignore the flag.
+ * Replaces: loader/loader_utils.py:527-535 (the normalisation inside EventSequenceToVoxelGrid_Pytorch.__call__) feeding
+ * model/EEMFlow/EEMFlow.py:135 (pconv1_1). */
+int eemflow_set_deferred_input_norm(eemflow_ctx* ctx, int enable);
+
 /* Graph-cache statistics: out3 = {captures, replays, io-table rewrites}. */
 int eemflow_graph_stats(eemflow_ctx* ctx, long long out3[3]);
 
@@ -154,6 +164,9 @@ int eemflow_flow_error(const float* flow_gt, const float* flow_pred, const float
  * reference's EventSequence -> grid [bins][h][w] fp32.  idx_left / idx_right (optional, may be NULL)
  * receive, per event, the int64 flat index x + y*w + bin*w*h of the left / right temporal vote, or -1
  * where the reference masks the vote out.
+ * normalize: 0 raw grid; 1 normalised grid (the reference's normalize=True); 2 "deferred" - the grid stays raw and the four floats
+ * BEHIND it (grid[bins*h*w .. +4): the buffer must have them) receive {mean, sd, scale ? 1 : 0, any ? 1 : 0} for
+ * eemflow_set_deferred_input_norm's consumer.
  * Replaces: EventSequenceToVoxelGrid_Pytorch.__call__  (loader/loader_utils.py:447-537). */
 int eemflow_voxelize(const double* events, int64_t n, int bins, int h, int w, int normalize, float* grid,
                      int64_t* idx_left, int64_t* idx_right, void* stream);
@@ -163,6 +176,14 @@ int eemflow_voxelize(const double* events, int64_t n, int bins, int h, int w, in
  * Replaces: the two EventSequenceToVoxelGrid_Pytorch calls of a dataset sample  (loader/HREM.py:226-232, loader/MVSEC.py:166-177). */
 int eemflow_voxelize_pair(const double* events1, int64_t n1, const double* events2, int64_t n2, int bins, int h, int w,
                           int normalize, float* grid1, float* grid2, void* stream);
+
+/* nsets (1..32) event sets of ONE grid shape - e.g. both volumes of every sample of an eemflow_forward_many call - voxelized by ONE
+ * three-launch sequence: events[k] [n_events[k]][4] f64 (t, x, y, p) -> grids[k] [bins][h][w] f32, each bitwise what eemflow_voxelize
+ * gives for that set alone.  `events`, `n_events`, `grids` are HOST arrays, read before the call returns.
+ * Replaces: the per-sample calls of EventSequenceToVoxelGrid_Pytorch.__call__ (loader/loader_utils.py:459-537) in a loader that has
+ * several samples at hand (loader/HREM.py:226-232 for each of them). */
+int eemflow_voxelize_many(int nsets, const double* const* events, const int64_t* n_events, int bins, int h, int w, int normalize,
+                          float* const* grids, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Training step of EEMFlow (train_mvsec.py:229-258).  Weights live on the device in state_dict order; one

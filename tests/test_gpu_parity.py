@@ -715,3 +715,90 @@ def test_fused_first_two_layers_equal_the_two_launches(b, h, w, monkeypatch):
         ref, st = O.eemflow_forward(O.to_torch_sd(sd), e1, e2, keep=True)
     assert maxerr(got["0"]["f11"][:b], st["f11"]) < FEAT_TOL
     assert maxerr(got["0"]["flow"], ref) < FLOW_TOL
+
+
+def test_voxelize_many_equals_the_single_calls():
+    """eemflow_voxelize_many: 2 x n event sets (ragged lengths, one of a single event) in one launch sequence - every grid bitwise the
+    grid eemflow_voxelize gives for that set alone (same kernels, the job index only selects the buffers), and one of them against
+    the oracle's voxel grid."""
+    from eemflow_amd.hrem import synthetic_hrem_events
+    from eemflow_amd.voxelizer import voxelize_device, voxelize_many_device
+    h, w, bins = 260, 346, 5
+    sets = []
+    for k, nev in enumerate([20000, 1, 7777, 50000, 333, 20000, 12345]):
+        seq = EventSequence(None, {"height": h, "width": w}, features=synthetic_hrem_events(80 + k, nev, h, w),
+                            timestamp_multiplier=1e6, convert_to_relative=True)
+        sets.append(torch.from_numpy(np.ascontiguousarray(seq.features)).to(DEV))
+    for normalize in (True, False):
+        many = voxelize_many_device(sets, bins, h, w, normalize=normalize)
+        for k, ev in enumerate(sets):
+            assert torch.equal(many[k], voxelize_device(ev, bins, h, w, normalize=normalize)), (k, normalize)
+    many = voxelize_many_device(sets, bins, h, w)
+    for k in (3, 4):
+        assert maxerr(many[k], O.voxelize(sets[k].cpu().numpy(), bins, h, w, normalize=True)) < 1e-4, k
+    with pytest.raises(ValueError):
+        voxelize_many_device(sets * 5, bins, h, w)
+
+
+# ------------------------------------------------------------------------------------------------ normalisation left to pconv1_1
+@pytest.mark.parametrize("nev", [200000, 2000000])
+def test_deferred_normalisation_route(nev):
+    """loader_utils.py:527-535 folded into its consumer: the voxelizer leaves RAW grids with the record {mean, sd, scale, any} behind
+    them (normalize='deferred'), pconv1_1 normalises as it reads (EEMFlow.py:135).  The record against the oracle's statistics, the raw
+    grid bitwise the normalize=False grid, and the flow of n frames against oracle-voxelize -> oracle-forward (<= 1e-4) and against the
+    normalised-grid route of this library (round-off of one multiply per voxel)."""
+    from eemflow_amd.hrem import synthetic_hrem_events
+    from eemflow_amd.voxelizer import norm_record, voxelize_device, voxelize_many_device
+    h, w, bins, n = 720, 1280, 5, 2
+    net, sd = make_net(91)
+    net.change_imagesize((h, w))
+    sets = []
+    for k in range(2 * n):
+        seq = EventSequence(None, {"height": h, "width": w}, features=synthetic_hrem_events(92 + k, nev, h, w),
+                            timestamp_multiplier=1e6, convert_to_relative=True)
+        sets.append(torch.from_numpy(np.ascontiguousarray(seq.features)).to(DEV))
+    raw = voxelize_many_device(sets, bins, h, w, normalize="deferred")
+    normed = voxelize_many_device(sets, bins, h, w, normalize=True)
+    for k in range(2 * n):
+        assert torch.equal(raw[k], voxelize_device(sets[k], bins, h, w, normalize=False)), k
+        g = raw[k][raw[k] != 0].double()
+        rec = norm_record(raw[k]).cpu()
+        assert abs(float(rec[0]) - float(g.mean())) < 1e-6 and abs(float(rec[1]) - float(g.std())) < 1e-6 * float(g.std()) + 1e-7
+        assert rec[2] == 1 and rec[3] == 1
+    with torch.no_grad():
+        got = net.forward_many([(raw[2 * i][None], raw[2 * i + 1][None]) for i in range(n)], deferred_norm=True)
+        ref2 = net.forward_many([(normed[2 * i][None], normed[2 * i + 1][None]) for i in range(n)])
+        for i in range(n):
+            assert maxerr(got[i][1][0], ref2[i][1][0]) < 2e-5, i
+        v1 = torch.from_numpy(O.voxelize(sets[0].cpu().numpy(), bins, h, w, normalize=True))[None]
+        v2 = torch.from_numpy(O.voxelize(sets[1].cpu().numpy(), bins, h, w, normalize=True))[None]
+        ref, _ = O.eemflow_forward(O.to_torch_sd(sd), v1, v2)
+    assert maxerr(got[0][1][0], ref) < FLOW_TOL
+    # the record is a caller's contract: volumes without one are refused
+    with pytest.raises(ValueError):
+        net.forward_many([(normed[0][None].clone(), normed[1][None].clone())], deferred_norm=True)
+
+
+def test_deferred_normalisation_edge_records():
+    """One non-zero voxel (the reference's std is NaN: mean subtracted only -> 0), and a shape the 16-byte first-layer kernel does not take
+    (MVSEC 346x260: the library refuses the deferred form there instead of computing something else)."""
+    from eemflow_amd.voxelizer import norm_record, voxelize_device
+    h, w, bins = 128, 192, 5
+    ev = torch.tensor([[0.0, 5.0, 7.0, 1.0]], dtype=torch.float64, device=DEV)
+    g = voxelize_device(ev, bins, h, w, normalize="deferred")
+    rec = norm_record(g).cpu()
+    assert rec[3] == 1 and rec[2] == 0 and float(rec[0]) == 1.0          # any, no scaling (sd is NaN for one voxel), mean = the vote
+    net, sd = make_net(93)
+    net.change_imagesize((h, w))
+    z = voxelize_device(ev, bins, h, w, normalize="deferred")
+    with torch.no_grad():
+        got = net.forward_many([(g[None], z[None])], deferred_norm=True)[0][1][0]
+        v = torch.from_numpy(O.voxelize(ev.cpu().numpy(), bins, h, w, normalize=True))[None]
+        ref, _ = O.eemflow_forward(O.to_torch_sd(sd), v, v)
+    assert maxerr(got, ref) < FLOW_TOL
+    net2, _ = make_net(93)
+    net2.change_imagesize((260, 346))
+    ev2 = torch.tensor([[0.0, 5.0, 7.0, 1.0], [1.0, 9.0, 3.0, 0.0]], dtype=torch.float64, device=DEV)
+    a = voxelize_device(ev2, bins, 260, 346, normalize="deferred")
+    with pytest.raises(_lib.EEMFlowHipError), torch.no_grad():
+        net2.forward_many([(a[None], a[None])], deferred_norm=True)

@@ -68,6 +68,9 @@ def build_parser():
         q.add_argument('--loader_threads', default=0, type=int, help='evaluation: host threads that read and voxelize samples ahead')
         q.add_argument('--frames_in_flight', default=1, type=int,
                        help='evaluation: samples kept in flight on as many model replicas / HIP streams (not in the reference; 4 suits one MI355X)')
+        q.add_argument('--coalesce', default=1, type=int,
+                       help='evaluation, EEMFlow: samples voxelized by one launch sequence and handed to one forward_many call (not in the '
+                            'reference; 10 with --frames_in_flight 2 suits one MI355X); the volumes then stay raw and pconv1_1 normalises them')
     common(sub.add_parser('train', help='train_EEMFlow_HREM.py'), True)
     common(sub.add_parser('test', help='test_EEMFlow_HREM.py'), False)
     return p
@@ -184,12 +187,14 @@ def test(args):
     json.dump(config, open(os.path.join(save_path, 'config.json'), 'w'), indent=4, sort_keys=False)
     logger = harness.Logger(os.path.join(save_path, 'test.log'))
     dev = torch.device(args.device)
-    test_set = HREMEventFlow(args=config["data_loader"]["test"]["args"], train=False, root=args.data_root, device=dev)
+    coalesce = args.coalesce if args.model_name == 'EEMFlow' else 1      # (forward_many is EEMFlow's)
+    test_set = HREMEventFlow(args=config["data_loader"]["test"]["args"], train=False, root=args.data_root, device=dev,
+                             deferred_norm=coalesce > 1)
     model = model.to(dev)
     sequences = [args.test_sequence] if args.test_sequence else list(test_set.nori_list.keys())
     ev = harness.TestRaftEvents(test_set, tuple(config["val_img_size"]), logger=logger)
     return ev.test_multi_sequence(model, start_epoch + 1, sequence_list=sequences, stride=1, frames_in_flight=args.frames_in_flight,
-                                  loader_threads=args.loader_threads)
+                                  loader_threads=args.loader_threads, coalesce=coalesce)
 
 
 def main(argv=None):

@@ -94,8 +94,14 @@ class TestRaftEvents:
         _, preds = model(events1=e1, events2=e2)
         return preds[-1]
 
-    def test_multi_sequence(self, model, epoch=0, sequence_list=(), stride=10, frames_in_flight=1, loader_threads=0):
-        """frames_in_flight > 1: that many replicas of the model (model.replicate()) take the samples round robin, each on a HIP
+    def test_multi_sequence(self, model, epoch=0, sequence_list=(), stride=10, frames_in_flight=1, loader_threads=0, coalesce=1):
+        """coalesce > 1 (a model with forward_many - EEMFlow - and a dataset with get_samples): that many samples are read, voxelized by
+        ONE voxelizer launch sequence and handed to ONE model.forward_many call - n independent batch-1 samples riding a batch-n chain of
+        launches, every sample in its own tensors; raw volumes with a normalisation record (HREMEventFlow(deferred_norm=True)) are
+        normalised by the first convolution as it reads them.  Chunks alternate over min(frames_in_flight, 2) replicas / streams.  Same
+        per-sample lines in the same order; the numbers agree with the one-sample loop to fp32 round-off (the batched chain uses the
+        F(4x4) Winograd form on every stride-1 layer).
+        frames_in_flight > 1: that many replicas of the model (model.replicate()) take the samples round robin, each on a HIP
         stream of its own - loading and voxelizing sample i + 1 and the forwards of the samples before it overlap; a sample's
         statistics are fetched (and its line printed, in order) when frames_in_flight - 1 newer samples have been enqueued.
         Same numbers as the sequential loop: every sample runs the same kernels on the same data.
@@ -109,6 +115,12 @@ class TestRaftEvents:
         sparse = getattr(self.dataset, "evaluation_type", "dense") == "sparse"
         mean_aee, mean_out, aee_list, out_list = 0., 0., [], []
         nfl = max(1, int(frames_in_flight))
+        co = max(1, int(coalesce))
+        if co > 1:
+            if not (hasattr(model, "forward_many") and hasattr(self.dataset, "get_samples")):
+                raise ValueError("coalesce > 1 needs a model with forward_many (EEMFlow) and a dataset with get_samples (HREMEventFlow)")
+            co = min(co, 16)
+            nfl = min(nfl, 2)                                    # two batched chains fill the chip; more only share it
         replicas, streams = [model], [torch.cuda.current_stream(dev)]
         hint_before = getattr(model, "frames_in_flight", 1)
         if nfl > 1:
@@ -150,7 +162,27 @@ class TestRaftEvents:
                     for idx in itertools.islice(ahead, 2 * loader_threads):
                         futures.append(pool.submit(load, idx))
                 count = 0
-                for idx in indices:
+                for c0 in (range(0, len(indices), co) if co > 1 else ()):
+                    chunk = indices[c0:c0 + co]
+                    k = count % nfl
+                    count += 1
+                    with torch.cuda.stream(streams[k]):
+                        samples = self.dataset.get_samples(chunk)
+                        frames = [(s_['event_volume_old'].to(dev)[None].float(), s_['event_volume_new'].to(dev)[None].float()) for s_ in samples]
+                        deferred = all(s_.get('deferred_norm', False) for s_ in samples)
+                        if deferred:                             # (.float() / [None] keep the storage: the record stays behind the volume)
+                            outs = replicas[k].forward_many(frames, deferred_norm=True)
+                        else:
+                            outs = replicas[k].forward_many(frames)
+                        for idx, sample, (_, preds) in zip(chunk, samples, outs):
+                            f_est = preds[-1]
+                            f_gt = sample['flow'].to(dev)[None].float()
+                            ev = sample['event_valid'].to(dev).sum(0) if ('event_valid' in sample and sparse) else None
+                            sums = flow_error_sums(f_gt, f_est, ev, is_car=self.is_car, evaluation_type="sparse" if ev is not None else "dense")
+                            pending.append((idx, k, sums, (sample, f_est, f_gt, ev)))
+                    while len(pending) >= nfl * co:
+                        retire()
+                for idx in (indices if co == 1 else ()):
                     k = count % nfl
                     count += 1
                     with torch.cuda.stream(streams[k]):

@@ -138,8 +138,14 @@ class HREMEventFlow(torch.utils.data.Dataset):
     image_width = 1280
     image_height = 720
 
-    def __init__(self, args, train=True, root=None, device=None, to_cpu=False, augmentor=None):
+    def __init__(self, args, train=True, root=None, device=None, to_cpu=False, augmentor=None, deferred_norm=False):
+        """deferred_norm (evaluation, GPU-resident samples): the event volumes stay RAW with their normalisation record behind them
+        (voxelizer normalize='deferred') for a model that normalises as it reads - EEMFlow.forward_many(..., deferred_norm=True),
+        which harness.TestRaftEvents.test_multi_sequence(coalesce=...) calls when the samples say so (`sample['deferred_norm']`)."""
         super().__init__()
+        if deferred_norm and (train or to_cpu):
+            raise ValueError("deferred_norm is the evaluation route with samples resident on the GPU (train=False, to_cpu=False)")
+        self.deferred_norm = bool(deferred_norm)
         self.input_type = 'events'
         self.type = 'train' if train else 'val'
         self.evaluation_type = args['eval_type']
@@ -152,7 +158,7 @@ class HREMEventFlow(torch.utils.data.Dataset):
             from .augmentor import FlowAugmentor                  # HREM.py:146-150
             augmentor = FlowAugmentor(**args['aug_params'])
         self.augmentor = augmentor
-        self.voxel = EventSequenceToVoxelGrid_Pytorch(num_bins=self.num_bins, normalize=True, gpu=True,
+        self.voxel = EventSequenceToVoxelGrid_Pytorch(num_bins=self.num_bins, normalize="deferred" if deferred_norm else True, gpu=True,
                                                       gpu_nr=self.device.index or 0, forkserver=False)
         self.get_data_ls()
 
@@ -180,7 +186,8 @@ class HREMEventFlow(torch.utils.data.Dataset):
     def __len__(self):
         return len(self.data_ls)
 
-    def get_sample(self, idx):
+    def _read(self, idx):
+        """Everything of sample idx that comes from files: the dict without its volumes, and its two event sequences."""
         sample = self.data_ls[idx]
         fflow = read_flo(sample['fflow'])
         height, width = fflow.shape[0], fflow.shape[1]
@@ -192,14 +199,39 @@ class HREMEventFlow(torch.utils.data.Dataset):
         params = {'height': self.image_height, 'width': self.image_width}
         seqs = [EventSequence(None, params, features=get_compressed_events(sample[key]), timestamp_multiplier=1e6,
                               convert_to_relative=True) for key in ('event0', 'event1')]
-        vols = self.voxel.pair(seqs[0], seqs[1])                  # both volumes in one three-launch sequence
-        old, new = (v.cpu() for v in vols) if self.to_cpu else vols
+        return out, seqs
+
+    def _attach(self, out, old, new):
+        if self.to_cpu:
+            old, new = old.cpu(), new.cpu()
         out['event_volume_old'], out['event_volume_new'] = old, new
-        out['event_valid'] = old.sum(dim=0).unsqueeze(0)
+        if self.deferred_norm:
+            # event_valid is the bin sum of the NORMALISED volume (HREM.py:232): from the raw grid and its record
+            from .voxelizer import norm_record
+            rec = norm_record(old)
+            nz = (old != 0).sum(dim=0)
+            ev = (old.sum(dim=0) - nz * rec[0]) / rec[1]
+            out['event_valid'] = torch.where(rec[3] != 0, ev, old.sum(dim=0)).unsqueeze(0)
+            out['deferred_norm'] = True
+        else:
+            out['event_valid'] = old.sum(dim=0).unsqueeze(0)
         return out
 
+    def get_sample(self, idx):
+        out, seqs = self._read(idx)
+        old, new = self.voxel.pair(seqs[0], seqs[1])              # both volumes in one three-launch sequence
+        return self._attach(out, old, new)
+
+    def get_samples(self, idxs):
+        """`[self[i] for i in idxs]` (up to 16 samples) with ALL their volumes from one voxelizer launch sequence."""
+        read = [self._read(i % len(self)) for i in idxs]
+        vols = self.voxel.many([s for _, seqs in read for s in seqs])
+        return [self._finish(self._attach(out, vols[2 * k], vols[2 * k + 1])) for k, (out, _) in enumerate(read)]
+
     def __getitem__(self, idx):
-        sample = self.get_sample(idx % len(self))
+        return self._finish(self.get_sample(idx % len(self)))
+
+    def _finish(self, sample):
         if self.type == 'train':
             if self.augmentor is not None:
                 img1 = sample['event_volume_old'].permute(1, 2, 0).cpu().numpy()

@@ -277,3 +277,47 @@ def test_cli_train_then_test_on_synthetic_hrem(tmp_path):
     # weight by ~lr whatever its gradient's size, so an element whose gradient is ~eps may differ by 2 lr)
     diff = torch.cat([(first[k] - again[k]).abs().reshape(-1) for k in first])
     assert float(diff.max()) < 3e-4 and float(diff.median()) < 1e-6
+
+
+def test_coalesced_evaluation_agrees_with_the_one_sample_loop(tmp_path, monkeypatch):
+    """TestRaftEvents.test_multi_sequence(coalesce=4): four samples per voxelizer launch sequence and per EEMFlow.forward_many call, raw
+    volumes normalised by pconv1_1 (HREMEventFlow(deferred_norm=True)) - the same lines in the same order; per-sample AEE within 1e-4 of
+    the one-sample loop (another Winograd form in the batched chain, one multiply per voxel in the normalisation); seven samples: a last
+    chunk of three.  The dataset's deferred samples carry the event_valid of the normalised volume."""
+    from eemflow_amd import EEMFlow
+    from eemflow_amd.harness import TestRaftEvents
+    from eemflow_amd.weights import seeded_state_dict
+    root = str(tmp_path)
+    for i in range(7):
+        d = os.path.join(root, "dataset/HREM/test/dt1/seqB/%06d" % (i + 1))
+        os.makedirs(d)
+        hrem.write_events_npz(os.path.join(d, "events1.npz"), hrem.synthetic_hrem_events(40 + i, 30000, 720, 1280))
+        hrem.write_events_npz(os.path.join(d, "events2.npz"), hrem.synthetic_hrem_events(60 + i, 30000, 720, 1280))
+        hrem.write_flo(os.path.join(d, "flow.flo"), hrem.synthetic_flow(80 + i, 720, 1280))
+    args = {"eval_type": "dense", "event_interval": "dt1", "num_voxel_bins": 5}
+    net = EEMFlow("", 5, 5)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(5).items()})
+    net = net.to(DEV)
+    res = []
+    for co, nfl, deferred in ((1, 1, False), (4, 2, True), (4, 1, False), (16, 2, True)):
+        ds = hrem.HREMEventFlow(args, train=False, root=root, deferred_norm=deferred)
+        ds.change_test_sequence("seqB")
+        ev = TestRaftEvents(ds, (720, 1280))
+        import io, contextlib
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            mean = ev.test_multi_sequence(net, epoch=0, sequence_list=["seqB"], stride=1, frames_in_flight=nfl, coalesce=co)
+        per = [float(ln.split("AEE:")[1].split()[0]) for ln in buf.getvalue().splitlines() if " / " in ln and "AEE:" in ln]
+        ids = [ln.split("/")[0].strip() for ln in buf.getvalue().splitlines() if " / " in ln and "AEE:" in ln]
+        res.append((mean, per, ids))
+    assert all(r[2] == res[0][2] and len(r[1]) == 7 for r in res)
+    for r in res[1:]:
+        assert abs(r[0] - res[0][0]) < 1e-4
+        assert max(abs(a - b) for a, b in zip(r[1], res[0][1])) < 1e-4
+    # event_valid of a deferred sample = the bin sum of the normalised volume
+    a = hrem.HREMEventFlow(args, train=False, root=root)
+    b = hrem.HREMEventFlow(args, train=False, root=root, deferred_norm=True)
+    a.change_test_sequence("seqB"); b.change_test_sequence("seqB")
+    sa, sb = a[2], b.get_samples([2, 3])[0]
+    assert sb["deferred_norm"] and float((sa["event_valid"] - sb["event_valid"]).abs().max()) < 1e-4
+    assert torch.equal(sa["flow"], sb["flow"])

@@ -544,6 +544,8 @@ def main_train(args):
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path)"
     dev = torch.device("cuda", parallel.local_device_index(local_rank))
     torch.cuda.set_device(dev)
+    if world > 1:
+        parallel.pin_host_threads_to_gpu_numa(dev.index)         # one rank per GPU: its host threads next to that GPU
     B = args.batch if args.batch > 1 else 8
     H, W = args.height, args.width
     L = _lib.lib()
@@ -597,7 +599,7 @@ def main_train(args):
                 "config": {"workload": f"EEMFlow training step, {W}x{H}, batch={B} per GPU: forward + sequence loss + backward + "
                                        "gradient all-reduce + clip + AdamW + re-pack", "height": H, "width": W, "batch_per_gpu": B,
                            "parallelism": f"dp{world}: batch sharded over ranks, one RCCL all-reduce of {n * 4} gradient bytes per step"},
-                "allreduce_us": round(ar_us, 1), "allreduce_bytes": n * 4, "final_loss": loss,
+                "allreduce_us": round(ar_us, 1), "allreduce_ms": round(ar_us / 1e3, 4), "allreduce_bytes": n * 4, "final_loss": loss,
                 "tflops_per_gpu_at_3x_forward": round(flops * B / (slowest / args.steps) / 1e12, 2)}
         print(json.dumps(line), flush=True)
     parallel.barrier(dev)
@@ -623,6 +625,8 @@ def main_eraft(args):
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path)"
     dev = torch.device("cuda", parallel.local_device_index(local_rank))
     torch.cuda.set_device(dev)
+    if world > 1:
+        parallel.pin_host_threads_to_gpu_numa(dev.index)         # one rank per GPU: its host threads next to that GPU
     B = args.batch if args.batch > 1 else 4
     H, W = (480, 640) if (args.height, args.width) == (720, 1280) else (args.height, args.width)
     iters = args.iters
@@ -701,7 +705,8 @@ def main_eraft(args):
                              "kernel": "whole step (direct-algorithm FLOPs of the model over the step time; per-kernel tables: profiles/)"},
                 "cpu_baseline": None}
         if train:
-            line.update({"allreduce_us": round(ar_us, 1), "allreduce_bytes": nparam * 4, "final_loss": float(last["loss"])})
+            line.update({"allreduce_us": round(ar_us, 1), "allreduce_ms": round(ar_us / 1e3, 4), "allreduce_bytes": nparam * 4,
+                         "final_loss": float(last["loss"])})
         print(json.dumps(line), flush=True)
     parallel.barrier(dev)
     if torch.distributed.is_initialized():
@@ -753,6 +758,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path)"
     dev = torch.device("cuda", parallel.local_device_index(local_rank))
     torch.cuda.set_device(dev)
+    if world > 1:
+        parallel.pin_host_threads_to_gpu_numa(dev.index)         # one rank per GPU: its host threads next to that GPU
 
     B, H, W = args.batch, args.height, args.width
     L = _lib.lib()

@@ -15,24 +15,25 @@ import numpy as np
 
 def resize_linear(img, fx, fy):
     """cv2.resize(img, None, fx=fx, fy=fy, interpolation=cv2.INTER_LINEAR) for a floating-point HWC (or HW) array: output size
-    (round(h * fy), round(w * fx)); destination pixel d samples the source at (d + 0.5) / scale - 0.5 with scale = dst / src, the two
-    neighbours clamped to the image."""
+    (round(h * fy), round(w * fx)); destination pixel d samples the source at (d + 0.5) / f - 0.5 with f the GIVEN factor (cv2 uses
+    fx / fy only to round the output size and maps with 1 / fx, 1 / fy - not with src / dst, which drifts by a sub-pixel towards the far
+    edge whenever src * f is not an integer), the two neighbours clamped to the image."""
     a = np.asarray(img)
     h, w = a.shape[:2]
     oh, ow = int(round(h * fy)), int(round(w * fx))
     if oh < 1 or ow < 1:
         raise ValueError("resize_linear: empty output")
 
-    def axis(n_src, n_dst):
-        s = (np.arange(n_dst, dtype=np.float64) + 0.5) * (n_src / float(n_dst)) - 0.5
+    def axis(n_src, n_dst, f):
+        s = (np.arange(n_dst, dtype=np.float64) + 0.5) / float(f) - 0.5
         i0 = np.floor(s).astype(np.int64)
         t = s - i0
         lo = np.clip(i0, 0, n_src - 1)
         hi = np.clip(i0 + 1, 0, n_src - 1)
         return lo, hi, t
 
-    y0, y1, ty = axis(h, oh)
-    x0, x1, tx = axis(w, ow)
+    y0, y1, ty = axis(h, oh, fy)
+    x0, x1, tx = axis(w, ow, fx)
     f = a.astype(np.float64)
     tx = tx.reshape((1, ow) + (1,) * (a.ndim - 2))
     ty = ty.reshape((oh, 1) + (1,) * (a.ndim - 2))

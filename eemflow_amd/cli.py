@@ -115,6 +115,8 @@ def train(args):
     rank, local_rank, world = parallel.init_distributed()
     if world > 1:
         args.device = "cuda:{}".format(parallel.local_device_index(local_rank))
+        # this rank's host threads (the loader's workers inherit the mask) on the CPUs next to its GPU
+        parallel.pin_host_threads_to_gpu_numa(parallel.local_device_index(local_rank))
     config = load_config(args.config)
     model = build_model(args.model_name, config, training=True)
     config["train"]["lr"] = args.lr                                                  # train_EEMFlow_HREM.py:56-59

@@ -602,6 +602,10 @@ int run_enc_layer(eemflow_ctx* c, const Shape& s, int li, const float* e1, const
         a.io_frames = (sp.layer == ENC_1_1 && io != nullptr) ? c->cur_io_frames : 0;
         a.in_norm = (sp.layer == ENC_1_1 && c->deferred_norm && prepadded == nullptr) ? 1 : 0;
         a.no_store = 0;
+        {   // batched chains (EEM_ZIGZAG=<layer mask>, experiment): this layer walks the images back to front
+            static const int zz = [] { const char* e = getenv("EEM_ZIGZAG"); return e ? atoi(e) : 0; }();
+            a.reverse = (s.batch >= 2 && ((zz >> sp.layer) & 1)) ? 1 : 0;
+        }
         // several frames in flight: kernels of different frames time-slice the CUs, so a block's prologue (DMA plan, first tile's
         // landing) is CU time another frame could use - fewer blocks with more tiles each (measured at 1280x720 with four in flight:
         // +3.5 % frames/s, +8 % single-frame latency; the 64-channel layers have one tile per CU and keep the full grid)

@@ -118,6 +118,13 @@ __device__ static inline TileRange block_tile_range(int T, unsigned bid, unsigne
 __device__ static inline TileCoord tile_coord(int lt, int tiles_x, int tiles_y) {
     return TileCoord{lt % tiles_x, (lt / tiles_x) % tiles_y, lt / (tiles_x * tiles_y)};
 }
+// (the same walk backwards: image order reversed, see EncConvArgs::reverse)
+__device__ static inline void tile_retreat(TileCoord& t, int tiles_x, int tiles_y) {
+    if (t.bx-- == 0) {
+        t.bx = tiles_x - 1;
+        if (t.by-- == 0) { t.by = tiles_y - 1; --t.n; }
+    }
+}
 __device__ static inline void tile_advance(TileCoord& t, int tiles_x, int tiles_y) {
     if (++t.bx == tiles_x) {
         t.bx = 0;
@@ -175,6 +182,9 @@ struct EncConvArgs {
     // ENC_1_1 only: the event volumes are RAW voxel grids, each followed by its four-float normalisation record (eemflow_voxelize with
     // normalize = 2); the kernel normalises as it reads (conv_enc1.hip) - the other first-layer kernels do not know this form
     int in_norm = 0;
+    // walk the tiles from the LAST image to the first (conv_wino4.hip): in a batched chain a layer's input was written by the launch
+    // before it, front to back, and is larger than the 256 MB Infinity Cache - read back to front, the part written last is still there
+    int reverse = 0;
     // persistent kernels: blocks per XCD (0 = one per CU).  The context lowers it when the application keeps several frames in flight
     // (eemflow_set_frames_in_flight): fewer, longer blocks spend less CU time on per-block prologues
     int blocks_per_xcd = 0;

@@ -103,7 +103,9 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(EncConvArgs a) {
     const int ntile = tr_.count;
     if (ntile == 0) return;
     const int total = ntile * KS;                                        // k-steps this block walks
-    TileCoord cur = tile_coord(tr_.first, a.tiles_x, a.tiles_y), nxt = cur, prv = cur;   // computed / being requested / previous
+    const int T_all = a.tiles_x * a.tiles_y * a.nimg;
+    TileCoord cur = tile_coord(a.reverse ? T_all - 1 - tr_.first : tr_.first, a.tiles_x, a.tiles_y), nxt = cur, prv = cur;   // computed / being requested / previous
+    auto step_tile = [&](TileCoord& t) { if (a.reverse) tile_retreat(t, a.tiles_x, a.tiles_y); else tile_advance(t, a.tiles_x, a.tiles_y); };
     const char* zero_page = reinterpret_cast<const char*>(a.zero_page);
     const int plane_in = a.hin * a.win;
 
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(EncConvArgs a) {
             __builtin_amdgcn_global_load_lds(GLB_PTR(gp), LDS_PTR(sbase + (k * 8 + wave) * 256), 16, 0, 0);
         }
         dsrc += (size_t)plane_in * 16;                                   // the next four channels
-        if (++dma_s == KS) { dma_s = 0; tile_advance(nxt, a.tiles_x, a.tiles_y); dma_tile(); }
+        if (++dma_s == KS) { dma_s = 0; step_tile(nxt); dma_tile(); }
         if (++dma_slot == R) dma_slot = 0;
     };
 
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(EncConvArgs a) {
         for (int s = 2; s < KS; ++s) step(F{}, std::integral_constant<int, NI>{});
         output(it);
         prv = cur;
-        tile_advance(cur, a.tiles_x, a.tiles_y);
+        step_tile(cur);
     }
     STAMP4(60);
 #ifdef EEM_STAMPS

@@ -559,18 +559,32 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
     }
     hipStream_t sd = overlap ? c->side : st;
     // fork: the side stream continues from here on the caller's stream; join: the caller's stream waits for the side stream's work so far
+    // An error return between a fork and its join must not leave work queued on the side stream that the caller's stream never waits
+    // for (the caller may free or reuse its buffers, or re-enter the context): the guard joins on every way out of this function
+    struct ForkGuard {
+        hipStream_t st, sd; hipEvent_t join_ev; bool forked = false;
+        ~ForkGuard() {
+            if (!forked) return;
+            if (hipEventRecord(join_ev, sd) != hipSuccess || hipStreamWaitEvent(st, join_ev, 0) != hipSuccess) (void)hipStreamSynchronize(sd);
+        }
+    } guard{st, sd, c->join_ev};
     auto fork = [&]() -> int {
         if (!overlap) return EEM_OK;
         EEM_HIP_CHECK(hipEventRecord(c->fork_ev, st));
         EEM_HIP_CHECK(hipStreamWaitEvent(sd, c->fork_ev, 0));
+        guard.forked = true;
         return EEM_OK;
     };
     auto join = [&]() -> int {
         if (!overlap) return EEM_OK;
         EEM_HIP_CHECK(hipEventRecord(c->join_ev, sd));
         EEM_HIP_CHECK(hipStreamWaitEvent(st, c->join_ev, 0));
+        guard.forked = false;
         return EEM_OK;
     };
+    // (workspace of the forked region, before the fork: ensure() may free / allocate and synchronise the device)
+    for (int pass = 0; pass < 2; ++pass)
+        if ((rc = ensure(c->czr[pass], (size_t)B * 256 * g)) != EEM_OK || (rc = ensure(c->cq[pass], (size_t)B * 128 * g)) != EEM_OK) return rc;
     // pad channels of the correlation buffer (never written by the lookup)
     EEM_HIP_CHECK(hipMemset2DAsync(c->corr.p + (size_t)324 * g, (size_t)kCorrPad * g * 4, 0, (size_t)(kCorrPad - 324) * g * 4, B, st));
     const int cin0 = c->cin0;
@@ -598,7 +612,6 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
     const bool use_pre = !(enp && enp[0] == '1') && !(ens0 && ens0[0] == '1');
     if (use_pre) {
         for (int pass = 0; pass < 2; ++pass) {
-            if ((rc = ensure(c->czr[pass], (size_t)B * 256 * g)) != EEM_OK || (rc = ensure(c->cq[pass], (size_t)B * 128 * g)) != EEM_OK) return rc;
             GConvArgs a = conv_args(c, c->gzr_c[pass], B, h8, w8, c->czr[pass].p, 256, 0, GACT_NONE);
             set_seg(a, 0, c->inp.p, 128, 128, 0);
             if ((rc = gconv_launch(a, sd)) != EEM_OK) return rc;

@@ -8,28 +8,39 @@
 //
 // Events arrive time-sorted, so neighbouring lanes vote into unrelated voxels: two fp32 atomics per event
 // straight to HBM run at ~20 G atomics/s whatever the kernel does (0.2 ms for 2e6 events).  The default path
-// therefore bins first and adds in LDS:
-//   1. vox_bin_kernel     every block of 1024 threads derives the votes of its chunk of events, histograms them over `nb`
-//                         bands of `band_px` consecutive pixels (LDS integer atomics, whose return value is the vote's rank
-//                         in its run), scans the histogram and writes 16-byte records {pixel-in-band | bin << 16, left
-//                         vote, right vote} sorted by band into ITS OWN slab, plus a row of run offsets: no global
-//                         atomics and no counting pass (an earlier version sized global runs first: +17 us and a second
-//                         read of the events); also the optional int64 index outputs (event order);
-//   2. vox_band_kernel    one block per band: it scans the run lengths of its band over all slabs, every thread finds the
-//                         run of its vote by binary search in LDS, and the band's bins x band_px voxels are accumulated
-//                         with ds_add_f32 and written once (no memset of the grid).  For the normalisation the block also
-//                         leaves the f64 (count, sum, sum of squares) of its non-zero voxels;
-//   3. vox_norm_kernel    adds the band sums, mean / unbiased sd, rewrites the non-zero voxels.
+// therefore bins first and adds in LDS.  Up to VOX_MAX_JOBS event sets of one grid shape share each launch (blockIdx.y = job:
+// eemflow_voxelize_pair / eemflow_voxelize_many - at 2e5 events per set the launches sit at their fixed costs, so a call per set pays
+// them per set):
+//   1. vox_bin_kernel     every block of 1024 threads derives the votes of its 1024 x EPT events (EPT = 1, 2, 4, 8 by event count), ranks
+//                         them per band of `band_px` consecutive pixels with LDS integer atomics (the return value is the vote's rank
+//                         in its run), scans the counts and builds its slab of 12-BYTE records {pixel-in-band | bin << 16, left
+//                         vote, right vote} sorted by band IN LDS, from where the slab leaves as whole 16-byte pieces of
+//                         consecutive threads, plus a row of run offsets (run_start[blk][band]): no global atomics, no counting
+//                         pass; also the optional int64 index outputs (event order);
+//   2. vox_band_kernel    one block per band (BT = 256 / 512 / 1024 threads by the band's LDS size; 9216 cells = 72 KB of fp64 by
+//                         default -> 1024 threads, two blocks per CU; 57 VGPRs, no scratch).  A run = the band's records of one
+//                         binning block; 2^sgs adjacent lanes share a run (1.7 x the mean run length), eight runs per thread in
+//                         flight: their table entries as one batch of buffer loads, then their first records as one batch of
+//                         12-byte buffer loads (out-of-range lanes read zeros: no branches), the rare longer runs in a clean-up
+//                         loop.  The band accumulates in fp64 LDS cells (ds_add_f64: ds_add_f32 runs at 0.33 lanes per clock and CU
+//                         on this chip, 8 - 20 x slower, profiles/r04_lds_atomics.txt).  One pass then rounds every cell to fp32
+//                         once, stores it (zeros included: no memset of the grid) and leaves the f64 (count, sum, sum of squares)
+//                         of the band's non-zero voxels;
+//   3. normalisation (loader_utils.py:527-535), one of
+//        vox_norm_kernel   (normalize = 1) adds the band sums in a fixed order, mean / unbiased sd, rewrites the non-zero voxels;
+//        vox_stats_kernel  (normalize = 2, "deferred") writes {mean, sd, scale, any} into the four floats BEHIND the grid and leaves
+//                          the grid raw: the first encoder layer normalises as it reads (conv_enc1.hip, NORM) - at 2e5 events per
+//                          volume the rewrite is half of a sample's voxelization time (37 -> 18 us per sample, ten per call).
 // Optional (EEM_VOX_TWOPASS=<r>, off by default): with fewer than one event per r voxels the band kernel runs twice instead of
-// step 3 - a moments-only launch, then a launch that accumulates the bands again and stores them already normalised, so the grid
-// is written once and never read.  Measured at 2e5 events per 4.6 M voxels: 16 + 23 us of band passes replace 23 + 11 us - no gain.
-// HBM traffic: 32 B (event) + 2 x 16 B (record) per event + 4 B (normalised: up to 12 B, two band passes: 4 B + 16 B per event) per
-// voxel, instead of two scattered read-modify-writes per event and three further passes over the grid.
+// step 3 - a moments-only launch, then a launch that accumulates the bands again and stores them already normalised.  Measured at
+// 2e5 events per 4.6 M voxels: no gain.
+// HBM traffic: 32 B (event) + 12 B written + 12 B read (record) per event + 4 B per voxel (normalize = 1: + 8 B per voxel).
 // An event with x >= W lands in a neighbouring row exactly as the reference's flat index_add_ puts it; votes whose
 // flat pixel index x + y*W falls outside the image (the reference raises) are dropped on this path, the index
-// outputs still report them.
-// Grids too large for the LDS band layout (bins * H * W > 1023 * 38400 voxels, bins > 64) and more than 33.5 M events
-// take the direct atomic kernel.
+// outputs still report them.  Grid values: every voxel's votes are summed exactly (fp64) and rounded once - within 2e-5 of the
+// reference's fp32 index_add_, whose order is not defined either; the integer indices are bit-exact.
+// Grids too large for the LDS band layout (band_px * bins > 19 200 cells, bins > 64) and more than 33.5 M events
+// take the direct atomic kernel (one job at a time).
 #include <string.h>
 
 #include "common.h"
@@ -505,9 +516,8 @@ bool make_plan(int64_t n, int bins, int h, int w, const double* events, VoxPlan*
     if (bins > 64 || vox_blocks(n, 8) > VOX_MAX_BLOCKS || hw >= (1L << 31) || ((uintptr_t)events & 15)) return false;
     const char* e = getenv("EEM_VOX_DIRECT");
     if (e && e[0] == '1') return false;
-    // 18 KiB of LDS per band and 256-thread blocks: a band block fits beside a resident encoder block of another stream (99-132 KiB of
-    // LDS, one wave per SIMD) instead of waiting for a whole CU, and ~1000 small blocks hide each other's latency chain (run table ->
-    // scan -> records -> LDS adds -> moments); EEM_VOX_BAND_FLOATS=12288 gives the former 48 KiB bands of 1024 threads
+    // 9216 fp64 cells (72 KB) per band by default -> vox_band_kernel<1024>, two blocks per CU; EEM_VOX_BAND_FLOATS=<cells> picks another
+    // band size (<= 3072 cells: 256-thread blocks, <= 5120: 512) - 2304 .. 18432 cells measure the same within 3 % at 2e5 and 2e6 events
     static const long band_floats = [] { const char* b = getenv("EEM_VOX_BAND_FLOATS"); const long v = b ? atol(b) : 0; return v >= 256 ? v : 9216L; }();
     long band_px = (band_floats / bins) & ~3L;
     if (band_px < 64) band_px = 64;

@@ -49,6 +49,10 @@ struct WgCfg {
     static_assert(2 * STAGE * 4 <= 160 * 1024, "LDS budget");
 };
 
+#ifdef EEM_DIAG
+__device__ int g_wg_dbg;                                 // diagnostic builds: EEM_WG_DBG=1 leaves the MFMAs out (what is left is the operands' way in)
+#endif
+
 template <int MT, int S, int TW, int CP, int KH = 3, int KW = 3>
 __global__ __launch_bounds__(256) void wgrad_enc_kernel(WgradArgs a, int tiles_x, int tiles_y) {
     using C = WgCfg<MT, S, TW, CP, KH, KW>;
@@ -173,6 +177,9 @@ __global__ __launch_bounds__(256) void wgrad_enc_kernel(WgradArgs a, int tiles_x
         }
         const float* sg = lds + (it & 1) * C::STAGE;
         const float* sx = sg + C::GFL;
+#ifdef EEM_DIAG
+        if (g_wg_dbg & 1) continue;
+#endif
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             float av[MT], bv[NT];
@@ -250,6 +257,9 @@ int launch(const WgradArgs& a, hipStream_t st) {
     if (gx < 8) gx = 8;
     const int need = (ceil_div(T, 8)) * 8;
     if (gx > need) gx = need;
+#ifdef EEM_DIAG
+    { static int once = [] { const char* e = getenv("EEM_WG_DBG"); int v = e ? atoi(e) : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wg_dbg), &v, sizeof v); return v; }(); (void)once; }
+#endif
     static bool raised = false;
     if (!raised) {
         EEM_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_enc_kernel<MT, S, TW, CP, KH, KW>, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -67,6 +67,37 @@ def init_distributed(backend=None):
     return rank, local_rank, world
 
 
+def parse_cpulist(text):
+    """'0-3,8,10-11' (sysfs local_cpulist) -> sorted list of CPU numbers."""
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return sorted(cpus)
+
+
+def pin_host_threads_to_gpu_numa(device_index, sysfs="/sys/bus/pci/devices"):
+    """One process per GPU: keep this rank's host threads (the loader's workers inherit the mask) on the CPUs local to ITS GPU's PCIe
+    root - on an 8-GPU node the ranks otherwise share one socket's memory controllers for their pinned staging buffers.  Reads the GPU's
+    PCI address from torch and `local_cpulist` from sysfs; intersects with the mask the process already has (a cgroup's); returns the
+    CPUs it pinned to, or None when anything is missing (no sysfs entry, an empty intersection) - never fatal.  EEM_NO_NUMA_PIN=1 skips it."""
+    if os.environ.get("EEM_NO_NUMA_PIN", "0") == "1" or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        addr = "{:04x}:{:02x}:{:02x}.0".format(p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        local = parse_cpulist(open(os.path.join(sysfs, addr, "local_cpulist")).read())
+        allowed = sorted(set(local) & set(os.sched_getaffinity(0)))
+        if not allowed:
+            return None
+        os.sched_setaffinity(0, allowed)
+        return allowed
+    except Exception:                                        # noqa: BLE001 - a missing sysfs entry must not stop a run
+        return None
+
+
 def exchange_active():
     """True when this process takes part in data-path collectives: a process group exists and has more than one rank (or the
     one-rank group was forced, see force_group)."""

@@ -141,12 +141,27 @@ def test_flow_augmentor_with_rescaling():
     from eemflow_amd.augmentor import FlowAugmentor, resize_linear
     rng = np.random.default_rng(7)
     img = rng.standard_normal((37, 53, 3)).astype(np.float32)
-    for fx, fy in ((1.3, 0.8), (0.71, 1.0), (2.0, 2.0)):
+    for fx, fy in ((2.0, 2.0), (1.0, 1.0)):                      # src * f an integer: cv2's 1 / f map IS the src / dst map torch uses
         got = resize_linear(img, fx, fy)
         oh, ow = int(round(37 * fy)), int(round(53 * fx))
         ref = F.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None], size=(oh, ow), mode="bilinear", align_corners=False)[0].permute(1, 2, 0).numpy()
         assert got.shape == (oh, ow, 3) and got.dtype == np.float32
         assert np.abs(got - ref).max() < 5e-5                      # (torch forms the source index in float32)
+    # src * f NOT an integer: the map uses the given factor (cv2: dsize = round(src * f), sample at (d + 0.5) / f - 0.5), written out per pixel
+    small = rng.standard_normal((7, 9)).astype(np.float32)
+    for fx, fy in ((1.3, 0.8), (0.71, 1.45)):
+        got = resize_linear(small, fx, fy)
+        oh, ow = int(round(7 * fy)), int(round(9 * fx))
+        assert got.shape == (oh, ow)
+        for y in range(oh):
+            sy = (y + 0.5) / fy - 0.5
+            y0 = int(np.floor(sy)); ty = sy - y0
+            for x in range(ow):
+                sx = (x + 0.5) / fx - 0.5
+                x0 = int(np.floor(sx)); tx = sx - x0
+                v = lambda yy, xx: float(small[min(max(yy, 0), 6), min(max(xx, 0), 8)])   # noqa: E731
+                want = (v(y0, x0) * (1 - tx) + v(y0, x0 + 1) * tx) * (1 - ty) + (v(y0 + 1, x0) * (1 - tx) + v(y0 + 1, x0 + 1) * tx) * ty
+                assert abs(float(got[y, x]) - want) < 1e-5, (fx, fy, y, x)
     a, b = (rng.standard_normal((120, 160, 3)).astype(np.float32) for _ in range(2))
     fl = rng.standard_normal((120, 160, 2))
     np.random.seed(3)

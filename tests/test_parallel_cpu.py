@@ -154,3 +154,16 @@ def test_local_device_index_is_one_process_per_gpu(monkeypatch):
         parallel.local_device_index(2)
     monkeypatch.setenv("EEM_DIST_SHARE_GPU", "1")
     assert parallel.local_device_index(3) == 1
+
+
+def test_numa_pinning_helper(tmp_path, monkeypatch):
+    """parallel.pin_host_threads_to_gpu_numa: sysfs cpulist parsing, intersection with the process's own mask, never fatal."""
+    import os
+    from eemflow_amd import parallel
+    assert parallel.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert parallel.parse_cpulist("") == []
+    assert parallel.pin_host_threads_to_gpu_numa(0, sysfs=str(tmp_path)) is None        # no GPU / no sysfs entry: nothing happens
+    before = os.sched_getaffinity(0)
+    monkeypatch.setenv("EEM_NO_NUMA_PIN", "1")
+    assert parallel.pin_host_threads_to_gpu_numa(0) is None
+    assert os.sched_getaffinity(0) == before

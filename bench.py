@@ -928,7 +928,9 @@ def main():
             r["cus"] = dom["cus"]
             r["frac_on_its_cus"] = round(r["frac"] / share, 4) if r["bound"] == "mfma" else None
             tr_all = load_traffic() or {}
-            same_shape = tr_all.get("_workload", {"height": 720, "width": 1280, "batch": 1}) == {"height": H, "width": W, "batch": B}
+            wl = dict(tr_all.get("_workload", {"height": 720, "width": 1280, "batch": 1}))
+            wl.setdefault("frames_per_launch", 1)
+            same_shape = wl == {"height": H, "width": W, "batch": B, "frames_per_launch": CO * B}
             traffic = tr_all.get(dom["name"]) if same_shape else None        # PMC passes of another shape say nothing here
             # HBM bytes per launch of the dominant kernel from the PMC passes (profiles/pmc_traffic.json, tools/profile_gpu.sh): a
             # committed measurement, not a counter of this run - stamped with the kernel symbol and commit it was taken on, and

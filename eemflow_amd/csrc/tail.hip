@@ -293,6 +293,98 @@ __global__ __launch_bounds__(64 * KS * KS) void tail_conv_kernel(TailConvLaunch 
     }
 }
 
+// The same convolution for NARROW layers of a BATCHED chain (eemflow_forward_many: ten frames = 150 pixel tiles per decoder): a
+// block of the kernel above carries CG <= 5 MFMAs per wave - the grouped 20 -> 20 decoder convs - behind the same two memory round
+// trips, so its time is the round trips'.  Here a block takes PT consecutive pixel tiles of its (cout tile, job): the weight
+// fragments are loaded once, the PT x CG input gathers leave as one batch, PT x CG MFMAs, PT reductions - a fifth of the blocks for
+// the same arithmetic in the same order (bitwise the kernel above: per tile the same fragments meet in the same sequence).  Wider
+// layers take it with PT = 2 or 3 (weights once per block, half the blocks' round trips).
+template <int CG, int PT>
+__global__ __launch_bounds__(576) void tail_conv_multi_kernel(TailConvLaunch L) {
+    constexpr int KK = 9;
+    __shared__ f32x4 part[KK][PT][64];
+    const int lane = threadIdx.x & 63;
+    const int t = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const TailConvJob jb = L.job[blockIdx.z];
+    const int hw = L.h * L.w, lw = L.w, lh = L.h;
+    asm volatile("" ::"s"(jb.in), "s"(jb.wpk), "s"(jb.bias), "s"(jb.out), "s"(jb.add), "s"(jb.cin), "s"(jb.cout), "s"(jb.in_cmul),
+                 "s"(jb.out_cmul), "s"(jb.act), "s"(lw), "s"(lh));
+    const int cot = blockIdx.y;
+    const bool live = cot * 16 < jb.cout;
+    const int ptiles = (hw + 15) >> 4, ntile = ptiles * L.batch;
+    const int j = lane & 15, g = lane >> 4;
+    const int cg = (jb.cin + 3) >> 2;
+    const int cmul = jb.in_cmul > 1 ? jb.in_cmul : 1;
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(jb.wpk) + ((size_t)cot * KK + t) * cg * 64, (short)0, live ? cg * 256 : 0, 0x00020000);
+    // one descriptor over the whole batch of the job's input: a tile's sample is part of the lane's offset
+    const long ibytes_l = live ? ((long)(L.batch - 1) * jb.in_ctotal * hw + (long)(jb.in_coff + (jb.cin - 1) * cmul + 1) * hw) * 4 : 0;
+    const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(jb.in), (short)0, (int)ibytes_l, 0x00020000);
+    const int cstep = 4 * cmul * hw * 4;
+    float av[CG], bv[PT][CG];
+#pragma unroll
+    for (int q = 0; q < CG; ++q) av[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wr, lane * 4 + q * 256, 0, 0));
+    int pp[PT], bb[PT];
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        const int tix = blockIdx.x * PT + i;
+        const int b = tix / ptiles;
+        const int p = (tix - b * ptiles) * 16 + j;
+        const int y = p / lw, x = p - y * lw;
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        const bool valid = tix < ntile && p < hw && yy >= 0 && yy < lh && xx >= 0 && xx < lw;
+        // (one descriptor spans the batch, so a channel past cin must be sent out of range by hand: inside the span it would read the
+        // next sample's data)
+        int voff = valid ? (int)((((long)b * jb.in_ctotal + jb.in_coff + g * cmul) * hw + yy * lw + xx) * 4) : 0x7f000000;
+        pp[i] = p; bb[i] = tix < ntile ? b : -1;
+#pragma unroll
+        for (int q = 0; q < CG; ++q) {
+            bv[i][q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ir, (4 * q + g < jb.cin) ? voff : 0x7f000000, 0, 0));
+            voff += valid ? cstep : 0;
+        }
+    }
+    const int co0 = cot * 16 + g * 4;
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (t < PT && live && jb.bias) {                     // the finishing waves' bias rides in the same round trip
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (co0 + r < jb.cout) bs[r] = jb.bias[co0 + r];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (!live) return;
+    f32x4 acc[PT];
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < CG; ++q) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[i][q], acc[i], 0, 0, 0);
+        part[t][i][lane] = acc[i];
+    }
+    __syncthreads();
+    if (t >= PT) return;                                 // wave i finishes tile i (PT <= 9)
+    const int i = t;
+    f32x4 a = part[0][i][lane];
+#pragma unroll
+    for (int k = 1; k < KK; ++k) a += part[k][i][lane];  // fixed order: bitwise the single-tile kernel
+    // tile i's coordinates again for this wave (pp / bb above are per-iteration registers of the unrolled loop: index them by a
+    // compile-time switch)
+    int p = 0, b = -1;
+#pragma unroll
+    for (int q = 0; q < PT; ++q)
+        if (q == i) { p = pp[q]; b = bb[q]; }
+    if (b < 0 || p >= hw) return;
+    const size_t o0 = ((size_t)b * jb.out_ctotal + co0 * jb.out_cmul + jb.out_coff) * hw + p;
+    const size_t ostep = (size_t)jb.out_cmul * hw;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (co0 + r < jb.cout) {
+            float v = a[r] + bs[r];
+            if (jb.act) v = v > 0.f ? v : 0.1f * v;
+            if (jb.add) v += jb.add[o0 + r * ostep];
+            jb.out[o0 + r * ostep] = v;
+        }
+}
+
 // ------------------------------------------------------------------------------- bilinear resize
 // F.interpolate(mode='bilinear', align_corners=False): src = max(scale*(dst+0.5)-0.5, 0)
 __device__ __forceinline__ void src_index(float scale, int dst, int in_size, int& i0, int& i1, float& l1) {
@@ -445,11 +537,35 @@ int tail_conv_launch(const TailConvLaunch& l, hipStream_t stream) {
         max_cg = cg > max_cg ? cg : max_cg;
     }
     EEM_REQUIRE(max_cg <= 25, "tail_conv_launch: cin > 100 is not built");
+    // narrow layers of a batched chain: five pixel tiles per block (tail_conv_multi_kernel; EEM_NO_TAIL_MULTI=1: the one-tile kernel)
+    // (EEM_TAIL_MULTI_MAXCG: the widest layer, in 4-channel groups, that takes it.  5 = the grouped convs: 19.2 -> 13.4 us per launch of
+    // ten frames; the wider layers with two or three tiles per block measured 25.1 -> 23.5 (conv1), 19.9 -> 21.7 (conv5), 3.7 -> 4.7 (conv7))
+    static const int multi_maxcg = [] { const char* e = getenv("EEM_TAIL_MULTI_MAXCG"); return e ? atoi(e) : 5; }();
+    bool multi_ok = l.ksize == 3 && max_cg <= multi_maxcg && ceil_div(l.h * l.w, 16) * l.batch >= 40;
+    for (int i = 0; i < l.njobs && multi_ok; ++i) {
+        const TailConvJob& jb = l.job[i];
+        const long span = ((long)(l.batch - 1) * jb.in_ctotal + jb.in_coff + (jb.cin - 1) * (jb.in_cmul > 1 ? jb.in_cmul : 1) + 1) * l.h * l.w * 4;
+        multi_ok = jb.gate == nullptr && span < 0x7f000000L;
+    }
+    { const char* e = getenv("EEM_NO_TAIL_MULTI"); if (e && e[0] == '1') multi_ok = false; }
     dim3 grid(ceil_div(l.h * l.w, 16) * l.batch, ceil_div(max_cout, 16), l.njobs);
     EEM_NOTE_GRID(grid.x * grid.y * grid.z, 64 * l.ksize * l.ksize);
     if (l.ksize == 1) {
         if (max_cg <= 2) tail_launch_t<1, 2>(l, grid, stream);
         else tail_launch_t<1, 25>(l, grid, stream);
+    } else if (multi_ok) {
+        auto go = [&](auto cg_tag, auto pt_tag) {
+            constexpr int CG = decltype(cg_tag)::value, PT = decltype(pt_tag)::value;
+            dim3 gm(ceil_div((int)grid.x, PT), grid.y, grid.z);
+            EEM_NOTE_GRID(gm.x * gm.y * gm.z, 576);
+            hipLaunchKernelGGL((tail_conv_multi_kernel<CG, PT>), gm, dim3(576), 0, stream, l);
+        };
+        using std::integral_constant;
+        if (max_cg <= 5) go(integral_constant<int, 5>{}, integral_constant<int, 5>{});
+        else if (max_cg <= 8) go(integral_constant<int, 8>{}, integral_constant<int, 3>{});
+        else if (max_cg <= 16) go(integral_constant<int, 16>{}, integral_constant<int, 2>{});
+        else if (max_cg <= 18) go(integral_constant<int, 18>{}, integral_constant<int, 2>{});
+        else go(integral_constant<int, 25>{}, integral_constant<int, 2>{});
     } else if (max_cg <= 5) tail_launch_t<3, 5>(l, grid, stream);
     else if (max_cg <= 8) tail_launch_t<3, 8>(l, grid, stream);
     else if (max_cg <= 16) tail_launch_t<3, 16>(l, grid, stream);

@@ -214,6 +214,9 @@ __global__ __launch_bounds__(256) void wgrad_enc_kernel(WgradArgs a, int tiles_x
         }
     }
     __syncthreads();
+#ifdef EEM_DIAG
+    if (g_wg_dbg & 2) return;                            // EEM_WG_DBG=2: no global atomics (what the one-atomic-per-weight-and-block epilogue costs)
+#endif
     for (int e = threadIdx.x; e < MT * NT * 64; e += 256) {
         const int tile = e >> 6, l = e & 63;
         const int mt = tile / NT, nt = tile - mt * NT;

@@ -802,3 +802,22 @@ def test_deferred_normalisation_edge_records():
     a = voxelize_device(ev2, bins, 260, 346, normalize="deferred")
     with pytest.raises(_lib.EEMFlowHipError), torch.no_grad():
         net2.forward_many([(a[None], a[None])], deferred_norm=True)
+
+
+def test_batched_decoder_kernel_equals_the_one_tile_kernel(monkeypatch):
+    """tail_conv_multi_kernel (five pixel tiles per block: the grouped 20 -> 20 decoder convs of a batched chain, EEMFlow.py:37-69) against
+    tail_conv_kernel (EEM_NO_TAIL_MULTI=1): the same fragments in the same order - bitwise the same flow; batch 10 at the headline size,
+    and a batch whose tile count is not a multiple of five."""
+    for b, h, w in ((10, 720, 1280), (7, 260, 346)):
+        e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(95, b, h, w))
+        got = {}
+        for off in ("1", "0"):
+            monkeypatch.setenv("EEM_NO_TAIL_MULTI", off)
+            net, sd = make_net(94)
+            net.change_imagesize((h, w))
+            with torch.no_grad():
+                got[off] = (net(e1, e2)[1][0].clone(), net.stage("flowcat").clone())
+        assert torch.equal(got["0"][1], got["1"][1]) and torch.equal(got["0"][0], got["1"][0]), (b, h, w)
+    with torch.no_grad():
+        ref, _ = O.eemflow_forward(O.to_torch_sd(sd), e1[:2].cpu(), e2[:2].cpu())
+    assert maxerr(got["0"][0][:2], ref) < FLOW_TOL

@@ -62,13 +62,16 @@ def main():
                           "write_size_kb_raw": round(write[key], 1), "fetch_correction": 2.0}
     # the workload the passes were collected on (tools/profile_gpu.sh runs bench.py's default shape); bench.py only
     # quotes these numbers when it runs that shape
+    fpl = int(sys.argv[6]) if len(sys.argv) > 6 else 1           # frames per launch: the coalescing width of the timed loop's chains
     res["_workload"] = {"height": int(sys.argv[3]) if len(sys.argv) > 3 else 720, "width": int(sys.argv[4]) if len(sys.argv) > 4 else 1280,
-                        "batch": int(sys.argv[5]) if len(sys.argv) > 5 else 1}
+                        "batch": int(sys.argv[5]) if len(sys.argv) > 5 else 1, "frames_per_launch": fpl}
+    res["_encoder_mb_per_frame"] = round(sum(v["hbm_bytes"] for k, v in res.items() if k.startswith("enc.")) / fpl / 1e6, 1)
     import datetime
     import os
     res["_meta"] = {"csrc_sha": csrc_sha(), "commit": os.environ.get("EEM_COMMIT", "unknown"),
                     "date": datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%dT%H:%MZ"),
-                    "command": "bench.py --steps 5 --warmup 2 --no-graph --streams 1 --frames-in-flight 4 under rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE"}
+                    "command": "bench.py --steps 20 --warmup 10 --preheat 10 --long-steps 0 --no-graph --streams 1 --coalesce <frames_per_launch> --kernel-reps 2 "
+                               "under rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes)"}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 

@@ -3,7 +3,7 @@
 export EEM_LIB_PATH="$(cd "$(dirname "$0")/.." && pwd)/eemflow_amd/libeemflow_hip_diag.so"
 [ -f "$EEM_LIB_PATH" ] || { echo "build the diagnostic library first" >&2; exit 1; }
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-for d in 0 1; do
+for d in 0 1 2 3; do
   rm -rf gpurun_out/wgdbg$d
   EEM_WG_DBG=$d timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/wgdbg$d -- python3 tools/bench_train.py > gpurun_out/wgdbg$d.log 2>&1
   echo "EEM_WG_DBG=$d: $(grep 'train step' gpurun_out/wgdbg$d.log)"

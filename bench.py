@@ -901,13 +901,16 @@ def main():
                 ai = k.flops / max(k.bytes, 1.0)
                 # the roof a launch runs against: fp32 MFMA, or - for the kernels that compute fp32 products as six bf16-piece MFMAs -
                 # the bf16 pipe / 6 (416.7 TFLOP/s, balance 52 FLOP/B: the stride-2 layers' 24-48 FLOP/B are then HBM-bound)
-                peak_tf = PEAK_BF16X3_TFLOPS if k.pipe == 1 else PEAK_MFMA_F32_TFLOPS
+                # Winograd launches: `flops` are the DIRECT convolution's (SURVEY 8d's unit), the kernel multiplies a quarter (F(4x4,3x3))
+                # or 1 / 2.25 (F(2x2,3x3)) of them - its matrix roof in that unit is 4 x / 2.25 x the fp32 MFMA peak, and with a balance of
+                # 79 / 44 FLOP/B the 16- and 32-channel layers (32 - 64 FLOP/B) are HBM-bound
+                peak_tf = {0: PEAK_MFMA_F32_TFLOPS, 1: PEAK_BF16X3_TFLOPS, 2: PEAK_MFMA_F32_TFLOPS * 4.0, 3: PEAK_MFMA_F32_TFLOPS * 2.25}.get(k.pipe, PEAK_MFMA_F32_TFLOPS)
                 bound = "mfma" if ai >= peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9) else "hbm"
                 # the encoder's kernels are persistent (one workgroup per CU): a launch of fewer than 256 workgroups occupies that many
                 # CUs and leaves the rest to the other frames in flight; chip_us = duration x the share of the chip it holds
                 cus = min(k.blocks, N_CUS) if k.blocks > 0 else N_CUS
                 table.append({"name": k.name.decode(), "us": round(k.ms * 1e3, 2), "gflop": round(k.flops / 1e9, 4),
-                              "mbytes": round(k.bytes / 1e6, 3), "bound": bound, "pipe": "bf16x3" if k.pipe == 1 else "f32",
+                              "mbytes": round(k.bytes / 1e6, 3), "bound": bound, "pipe": {0: "f32", 1: "bf16x3", 2: "f32 winograd F(4x4)", 3: "f32 winograd F(2x2)"}.get(k.pipe, "f32"),
                               "peak_tflops": round(peak_tf, 1),
                               "tflops": round(k.flops / sec / 1e12, 2), "gbs": round(k.bytes / sec / 1e9, 1),
                               "workgroups": k.blocks, "cus": cus, "chip_us": round(k.ms * 1e3 * cus / N_CUS, 2)})
@@ -996,6 +999,13 @@ def main():
         ceiling_ms = total_gflop / PEAK_MFMA_F32_TFLOPS                    # GFLOP of one step (its whole batch) / (TFLOP/s) = ms
         roof["frame_frac_of_ceiling"] = round(ceiling_ms / ms_per_step, 4)
         roof["frame_ceiling_us"] = round(ceiling_ms * 1e3, 2)
+        # ... and the frame against the HBM roof: the encoder's measured HBM-side bytes per frame (the committed PMC passes, same sources
+        # and launch shape) over the measured time per frame - the first three layers run at their bytes, so this is the bound that binds
+        tr_now = load_traffic() or {}
+        if tr_now.get("_encoder_mb_per_frame") and not tr_now.get("_stale") and (tr_now.get("_workload") or {}).get("frames_per_launch", 1) == CO * B:
+            roof["frame_hbm_mbytes"] = tr_now["_encoder_mb_per_frame"]
+            roof["frame_hbm_gbs"] = round(tr_now["_encoder_mb_per_frame"] / 1e3 / (ms_per_step * 1e-3), 1)
+            roof["frame_hbm_frac"] = round(roof["frame_hbm_gbs"] / PEAK_HBM_GBS, 4)
         line = {
             "metric": baseline_metric(),
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -47,7 +47,9 @@ __host__ __device__ static inline int ceil_div(int a, int b) { return (a + b - 1
 // duration - a kernel that runs on a quarter of the chip by design is not a slow kernel (api.hip defines it)
 extern thread_local int eem_last_grid_blocks, eem_last_grid_threads, eem_last_pipe;
 #define EEM_NOTE_GRID(blocks, threads) do { eem_last_grid_blocks = (int)(blocks); eem_last_grid_threads = (int)(threads); } while (0)
-// which matrix pipe the launch's contraction runs on: 0 fp32 MFMA (157 TFLOP/s), 1 fp32 products as six bf16-piece MFMAs (2.5 PFLOP/s / 6)
+// which matrix pipe the launch's contraction runs on: 0 fp32 MFMA (157 TFLOP/s), 1 fp32 products as six bf16-piece MFMAs (2.5 PFLOP/s / 6),
+// 2 Winograd F(4x4,3x3) on the fp32 MFMA (36 products per 16 outputs where the direct form has 144: its roof in direct-convolution FLOPs
+// is 4 x 157), 3 F(2x2,3x3) (16 per 4 outputs against 36: 2.25 x)
 #define EEM_NOTE_PIPE(p) do { eem_last_pipe = (int)(p); } while (0)
 
 // compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N) - the index is usable as a template /

@@ -424,6 +424,7 @@ int wino_launch_c(const EncConvArgs& a0, hipStream_t stream) {
         return EEM_ERR_ARG;
     }
     EEM_NOTE_GRID(per_xcd * 8, W::WAVES * 64);
+    EEM_NOTE_PIPE(3);                                    // F(2x2,3x3): 16 products per 4 outputs against the direct form's 36
     if (a.pool_partial != nullptr)
         hipLaunchKernelGGL((wino_kernel<C, W::TH, W::TW, W::WAVES, W::POOLK>), dim3(per_xcd * 8), dim3(W::WAVES * 64), 0,
                            stream, a);

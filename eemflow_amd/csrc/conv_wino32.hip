@@ -374,6 +374,7 @@ int launch_c(const EncConvArgs& a0, hipStream_t stream) {
         return EEM_ERR_ARG;
     }
     EEM_NOTE_GRID(per_xcd * 8, W::WAVES * 64);
+    EEM_NOTE_PIPE(3);                                    // F(2x2,3x3): 16 products per 4 outputs against the direct form's 36
     if (a.pool_partial != nullptr && a.no_store && C == 64 && a.gate == nullptr)
         hipLaunchKernelGGL((wino32_kernel<C, W::TH, W::TW, W::NGH, W::WAVES, W::STREAM, W::POOLK, C != 64>), dim3(per_xcd * 8),
                            dim3(W::WAVES * 64), 0, stream, a);

@@ -488,6 +488,7 @@ int launch4_c(const EncConvArgs& a0, hipStream_t stream) {
         return EEM_ERR_ARG;
     }
     EEM_NOTE_GRID(per_xcd * 8, 512);
+    EEM_NOTE_PIPE(2);                                    // F(4x4,3x3) on the fp32 MFMA: a quarter of the direct form's multiplies
     if ((a.gate != nullptr || a.res != nullptr) && (a.pool_partial != nullptr || (a.gate != nullptr && a.res != nullptr))) {
         eem_set_error("wino4: gate / residual epilogues come without pooling and one at a time");
         return EEM_ERR_ARG;

@@ -605,6 +605,15 @@ int run_enc_layer(eemflow_ctx* c, const Shape& s, int li, const float* e1, const
         {   // batched chains (EEM_ZIGZAG=<layer mask>, experiment): this layer walks the images back to front
             static const int zz = [] { const char* e = getenv("EEM_ZIGZAG"); return e ? atoi(e) : 0; }();
             a.reverse = (s.batch >= 2 && ((zz >> sp.layer) & 1)) ? 1 : 0;
+            // ... or in COLUMNS (EEM_COLWALK=<layer mask>; default: the two 64-channel layers of a batched chain).  Measured at ten frames
+            // per launch (rocprofv3 FETCH_SIZE): the 32-pixel-wide tiles of the 64-channel layers fetch 22.3 MB per frame in row order
+            // and 10.8 / 10.3 in column order (a tile row touches three cache lines for one of payload, and in row order the neighbour
+            // that shares two of them comes a whole tile later); 32 channels 29.0 -> 32.2 (worse), 16 channels unchanged; frame rate the
+            // same within noise either way - those layers are bound by their transforms, not their bytes
+            static const int cw = [] { const char* e = getenv("EEM_COLWALK"); return e ? atoi(e) : (1 << ENC_3_2) | (1 << ENC_3_3); }();
+            if (s.batch >= 2 && ((cw >> sp.layer) & 1)) a.reverse = 2;
+            static const int nts = [] { const char* e = getenv("EEM_NT_STORE"); return e ? atoi(e) : 0; }();
+            a.nt_store = ((nts >> sp.layer) & 1) | ((nts >> 8) & 2);          // (bit 9, diagnostic builds: the weight-slice experiment of conv_wino4.hip)
         }
         // several frames in flight: kernels of different frames time-slice the CUs, so a block's prologue (DMA plan, first tile's
         // landing) is CU time another frame could use - fewer blocks with more tiles each (measured at 1280x720 with four in flight:

@@ -187,6 +187,9 @@ struct EncConvArgs {
     // walk the tiles from the LAST image to the first (conv_wino4.hip): in a batched chain a layer's input was written by the launch
     // before it, front to back, and is larger than the 256 MB Infinity Cache - read back to front, the part written last is still there
     int reverse = 0;
+    // feature-map stores as non-temporal stores (conv_wino4.hip; EEM_NT_STORE=<layer mask>, experiment): a batched chain's outputs stream
+    // through each XCD's 4 MB L2 beside the Winograd weights and halo rows the kernel re-reads
+    int nt_store = 0;
     // persistent kernels: blocks per XCD (0 = one per CU).  The context lowers it when the application keeps several frames in flight
     // (eemflow_set_frames_in_flight): fewer, longer blocks spend less CU time on per-block prologues
     int blocks_per_xcd = 0;

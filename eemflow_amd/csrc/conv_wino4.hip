@@ -104,8 +104,20 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(EncConvArgs a) {
     if (ntile == 0) return;
     const int total = ntile * KS;                                        // k-steps this block walks
     const int T_all = a.tiles_x * a.tiles_y * a.nimg;
-    TileCoord cur = tile_coord(a.reverse ? T_all - 1 - tr_.first : tr_.first, a.tiles_x, a.tiles_y), nxt = cur, prv = cur;   // computed / being requested / previous
-    auto step_tile = [&](TileCoord& t) { if (a.reverse) tile_retreat(t, a.tiles_x, a.tiles_y); else tile_advance(t, a.tiles_x, a.tiles_y); };
+    // a.reverse: 0 rows of tiles front to back (x fastest), 1 the same walk back to front, 2 COLUMNS of tiles (y fastest): the block's
+    // consecutive tiles then share halo ROWS and the tiles that share the partial cache lines at their left / right edges - two of the
+    // three to six 128-byte lines a tile row touches - belong to neighbouring blocks of the XCD, which reach them at about the same time
+    auto coord_of = [&](int lt) {
+        if (a.reverse == 2) return TileCoord{(lt / a.tiles_y) % a.tiles_x, lt % a.tiles_y, lt / (a.tiles_x * a.tiles_y)};
+        return tile_coord(a.reverse == 1 ? T_all - 1 - lt : lt, a.tiles_x, a.tiles_y);
+    };
+    TileCoord cur = coord_of(tr_.first), nxt = cur, prv = cur;   // computed / being requested / previous
+    auto step_tile = [&](TileCoord& t) {
+        if (a.reverse == 2) {
+            if (++t.by == a.tiles_y) { t.by = 0; if (++t.bx == a.tiles_x) { t.bx = 0; ++t.n; } }
+        } else if (a.reverse == 1) tile_retreat(t, a.tiles_x, a.tiles_y);
+        else tile_advance(t, a.tiles_x, a.tiles_y);
+    };
     const char* zero_page = reinterpret_cast<const char*>(a.zero_page);
     const int plane_in = a.hin * a.win;
 
@@ -156,7 +168,11 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(EncConvArgs a) {
     };
     auto dma_issue = [&]() {
         float* sbase = lds + dma_slot * K::STAGE;
+#ifdef EEM_DIAG
+        const char* usrc = wbase + (size_t)(a.nt_store & 2 ? 0 : dma_s) * (K::UP * 16);    // EEM_NT_STORE bit 1 (diag): every k-step reads slice 0's weights
+#else
         const char* usrc = wbase + (size_t)dma_s * (K::UP * 16);
+#endif
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             const bool all_in = (k + 1) * 512 <= K::INP, all_u = k * 512 >= K::INP;          // compile-time per k
@@ -357,7 +373,8 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(EncConvArgs a) {
                     if constexpr (EPI == 3) {
                         // (no store)
                     } else if (full) {
-                        *reinterpret_cast<f32x4*>(rb + lane_bo + (size_t)yy * a.wout * 4) = o[yy];
+                        if (a.nt_store) __builtin_nontemporal_store(o[yy], reinterpret_cast<f32x4*>(rb + lane_bo + (size_t)yy * a.wout * 4));
+                        else *reinterpret_cast<f32x4*>(rb + lane_bo + (size_t)yy * a.wout * 4) = o[yy];
                     } else {
                         // every lane stores (outside lanes into a scratch page): exactly NSTORE stores per wave and tile
                         float* p = in ? reinterpret_cast<float*>(rb + lane_bo + (size_t)yy * a.wout * 4) : a.trash + lane * 4;

@@ -473,12 +473,14 @@ extern "C" int eemflow_time_kernels(eemflow_ctx* c, const float* e1, const float
     hk.st = (hipStream_t)stream;
     hk.timing = true;
     hk.reps = reps;
-    EEM_HIP_CHECK(hipEventCreate(&hk.ev0));
-    EEM_HIP_CHECK(hipEventCreate(&hk.ev1));
-    rc = run_forward(c, s, e1, e2, out, hk);
-    (void)hipEventDestroy(hk.ev0);
-    (void)hipEventDestroy(hk.ev1);
+    // pass 0 warms (weights' transforms, clocks, caches) and names the launches; passes 1 .. reps are averaged
+    for (int p = 0; p <= reps && rc == EEM_OK; ++p) {
+        rc = run_forward(c, s, e1, e2, out, hk);
+        if (rc == EEM_OK) rc = hk.collect(p > 0);
+    }
+    hk.release();
     if (rc != EEM_OK) return rc;
+    for (eemflow_kernel_stat& k : hk.stats) k.ms /= (float)reps;
     *nstats = (int)hk.stats.size();
     EEM_REQUIRE(*nstats <= max_stats, "eemflow_time_kernels: %d kernels, room for %d", *nstats, max_stats);
     memcpy(stats, hk.stats.data(), hk.stats.size() * sizeof(eemflow_kernel_stat));

@@ -364,14 +364,18 @@ TailConvJob make_job(const eemflow_ctx* c, const TailW& w, const float* in, int 
     return j;
 }
 
-// Every kernel launch of the schedule goes through a Hook: normally it just launches; in timing mode
-// (eemflow_time_kernels) it launches the same kernel `reps` times back to back between two HIP
-// events on the launch stream and records the average duration with its algorithmic FLOPs / bytes.
+// Every kernel launch of the schedule goes through a Hook: normally it just launches; in timing mode (eemflow_time_kernels) every
+// launch of a pass is bracketed by its own pair of HIP events on the launch stream - the schedule runs as the CHAIN it is, each kernel
+// behind its producer, `reps` passes - and the durations are averaged per launch with its algorithmic FLOPs / bytes.  (Until round 4 a
+// kernel was repeated back to back instead: at ten frames per launch that read 11 % slow for the layers whose input the launch before
+// had just left in the Infinity Cache - the rocprofv3 per-kernel averages of the timed loop said so.)
 struct Hook {
     hipStream_t st = nullptr;
     bool timing = false;
     int reps = 1;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int pass = 0;                                        // timing: pass being issued
+    size_t slot = 0;                                     // timing: launch index inside the pass
+    std::vector<hipEvent_t> evs;                         // timing: two events per launch of a pass, reused pass after pass
     std::vector<eemflow_kernel_stat> stats;
 
     // diagnostic BUILDS only (-DEEM_DIAG: `EEM_BUILD_TAG=diag EEM_EXTRA_FLAGS=-DEEM_DIAG python -m eemflow_amd.build`, loaded through
@@ -408,24 +412,43 @@ struct Hook {
         }
 #endif
         if (!timing) return launch(st);
+        if (evs.size() < 2 * (slot + 1)) {
+            evs.resize(2 * (slot + 1), nullptr);
+            EEM_HIP_CHECK(hipEventCreate(&evs[2 * slot]));
+            EEM_HIP_CHECK(hipEventCreate(&evs[2 * slot + 1]));
+        }
         eem_last_grid_blocks = eem_last_grid_threads = eem_last_pipe = 0;
-        int rc = launch(st);                                  // warm (also keeps data flowing downstream)
+        EEM_HIP_CHECK(hipEventRecord(evs[2 * slot], st));
+        const int rc = launch(st);
         if (rc != EEM_OK) return rc;
-        EEM_HIP_CHECK(hipEventRecord(ev0, st));
-        for (int i = 0; i < reps; ++i)
-            if ((rc = launch(st)) != EEM_OK) return rc;
-        EEM_HIP_CHECK(hipEventRecord(ev1, st));
-        EEM_HIP_CHECK(hipEventSynchronize(ev1));
-        float ms = 0.f;
-        EEM_HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
-        eemflow_kernel_stat ks;
-        memset(&ks, 0, sizeof(ks));
-        strncpy(ks.name, name, sizeof(ks.name) - 1);
-        ks.flops = flops; ks.bytes = bytes; ks.ms = ms / (float)reps;
-        ks.blocks = eem_last_grid_blocks;                     // 0: a launcher that does not report its grid
-        ks.pipe = eem_last_pipe;
-        stats.push_back(ks);
+        EEM_HIP_CHECK(hipEventRecord(evs[2 * slot + 1], st));
+        if (pass == 0) {
+            eemflow_kernel_stat ks;
+            memset(&ks, 0, sizeof(ks));
+            strncpy(ks.name, name, sizeof(ks.name) - 1);
+            ks.flops = flops; ks.bytes = bytes; ks.ms = 0.f;
+            ks.blocks = eem_last_grid_blocks;                     // 0: a launcher that does not report its grid
+            ks.pipe = eem_last_pipe;
+            stats.push_back(ks);
+        }
+        ++slot;
         return EEM_OK;
+    }
+    // after a pass has been issued: wait for it and add its durations (pass 0 is the warm-up and is not counted when reps > 1)
+    int collect(bool count) {
+        for (size_t i = 0; i < slot && i < stats.size(); ++i) {
+            EEM_HIP_CHECK(hipEventSynchronize(evs[2 * i + 1]));
+            float ms = 0.f;
+            EEM_HIP_CHECK(hipEventElapsedTime(&ms, evs[2 * i], evs[2 * i + 1]));
+            if (count) stats[i].ms += ms;
+        }
+        slot = 0;
+        ++pass;
+        return EEM_OK;
+    }
+    void release() {
+        for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+        evs.clear();
     }
 };
 

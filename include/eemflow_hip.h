@@ -110,10 +110,10 @@ int eemflow_forward(eemflow_ctx* ctx, const float* events1, const float* events2
 int eemflow_forward_many(eemflow_ctx* ctx, int nframes, const float* const* events1, const float* const* events2,
                          float* const* flow_out, int in_h, int in_w, int out_h, int out_w, void* stream);
 
-/* Per-kernel timing of the forward schedule: each kernel of the schedule is launched `reps` times back
- * to back between two HIP events recorded on `stream` (the stream the kernels run on); `ms` is the
- * average per launch.  `flops` / `bytes` are the ALGORITHMIC work of one launch (conv MACs x 2; compulsory
- * input + output + weight bytes).  The schedule still produces the correct flow in flow_out.
+/* Per-kernel timing of the forward schedule: the schedule runs `reps` + 1 times as the chain it is (eagerly, the first pass warms and
+ * is not counted) with a pair of HIP events around EVERY launch, recorded on `stream` (the stream the kernels run on); `ms` is the
+ * average per launch - each kernel measured behind its producer, as it runs in a forward.  `flops` / `bytes` are the ALGORITHMIC
+ * work of one launch (conv MACs x 2; compulsory input + output + weight bytes).  flow_out receives the correct flow.
  * Replaces: the reference's time_eval() wall-clock loop (model/EEMFlow/EEMFlow.py:201-225), per kernel. */
 typedef struct eemflow_kernel_stat {
     char name[48];
@@ -122,7 +122,8 @@ typedef struct eemflow_kernel_stat {
     float ms;
     int blocks;      /* workgroups of the launch (0: not reported): the encoder's kernels are persistent, one workgroup per CU,
                         so blocks < 256 means the launch occupies that many of the 256 CUs */
-    int pipe;        /* matrix pipe of the launch's contraction: 0 = fp32 MFMA, 1 = fp32 products as six bf16-piece MFMAs (conv_bx3.hip) */
+    int pipe;        /* matrix pipe of the launch's contraction: 0 = fp32 MFMA, 1 = fp32 products as six bf16-piece MFMAs (conv_bx3.hip),
+                        2 = Winograd F(4x4,3x3) on the fp32 MFMA (a quarter of the direct form's multiplies), 3 = F(2x2,3x3) (1 / 2.25) */
     int reserved;
 } eemflow_kernel_stat;
 int eemflow_time_kernels(eemflow_ctx* ctx, const float* events1, const float* events2, int batch, int in_h,

@@ -73,6 +73,8 @@ def parse():
     p.add_argument("--coalesce", type=int, default=10,
                    help="independent batch-1 frames handed to the library per call (eemflow_forward_many: n frames in n unrelated buffers ride "
                         "one batch-n chain of launches); 1 = one eemflow_forward per frame.  A step stays ONE frame at batch 1")
+    p.add_argument("--rows-child", action="store_true",
+                   help="internal: measure the other rows (E-RAFT, EEMFlow+, voxelizer, training steps) in THIS fresh process and print them as one JSON line")
     p.add_argument("--long-steps", type=int, default=400,
                    help="a second, longer run of the same timed loop after the K steps (reported as value_long; 0 disables)")
     return p.parse_args()
@@ -747,6 +749,11 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: launch with --nproc-per-node {args.gpus}",
               file=sys.stderr, flush=True)
         sys.exit(2)
+    if args.rows_child:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path)"
+        torch.cuda.set_device(0)
+        print(json.dumps(other_rows(torch.device("cuda", 0))), flush=True)
+        return
     if args.workload == "eraft":
         return main_eraft(args)
     if args.mode == "train":
@@ -880,7 +887,7 @@ def main():
     if rank == 0:
         # ---- per-kernel roofline, measured live with HIP events on the launch stream, in the launch configuration of the timed loop
         # (frames_in_flight = streams: persistent encoder kernels on fewer blocks) and in the single-frame configuration (full grids)
-        def kernel_table(frames_in_flight, nb=B):
+        def kernel_table(frames_in_flight, nb=B, chain=True):
             # nb frames per launch: the timed loop's chains are batch-CO chains (the frames of one eemflow_forward_many call)
             _lib.check(L.eemflow_set_frames_in_flight(ctx, frames_in_flight))
             stats = (_lib.KernelStat * 64)()
@@ -891,8 +898,10 @@ def main():
                 k1 = torch.cat([pairs[r % n_rot][0] for r in range(nb)]).contiguous()
                 k2 = torch.cat([pairs[r % n_rot][1] for r in range(nb)]).contiguous()
                 kf = torch.empty(nb, 2, H, W, device=dev)
+            # chain: every launch timed in the chain behind its producer (the timed loop's batch-CO launches: the form rocprofv3's per-kernel
+            # averages of the loop agree with); else each kernel repeated back to back (the single-frame table's few-microsecond launches)
             _lib.check(L.eemflow_time_kernels(ctx, k1.data_ptr(), k2.data_ptr(), nb, H, W, kf.data_ptr(), H, W,
-                                              args.kernel_reps, stats, 64, ctypes.byref(n), sp))
+                                              args.kernel_reps if chain else -args.kernel_reps, stats, 64, ctypes.byref(n), sp))
             torch.cuda.synchronize(dev)
             table = []
             for i in range(n.value):
@@ -964,8 +973,8 @@ def main():
         roof["frames_in_flight"] = fif
         roof["frames_per_launch"] = CO * B
         roof_single = None
-        if fif >= 3 and not args.no_side_rows:
-            single = kernel_table(1)
+        if not args.no_side_rows:
+            single = kernel_table(1, chain=False)
             roof_single = roofline_of(single)
             roof_single["frames_in_flight"] = 1
             roof_single["kernels_us"] = {k["name"].split()[0]: k["us"] for k in single}
@@ -1026,11 +1035,18 @@ def main():
             "encoder_tflops_in_kernel": round(enc_tflops, 2),
             "kernels": kernels, **extra,
         }
-        # (the other rows first: single-stream E-RAFT and the training step run 2.4x / 1.4x slower ON THE GPU - host enqueue unchanged - when
-        # they follow the pipeline section below in a process whose main loop held batch-10 workspaces; measured, not explained:
-        # docs/NOTEBOOK.md, round 5)
+        # The other rows are measured in a FRESH child process (its own HIP context; this one idles meanwhile): in this process, behind the
+        # batch-10 workspaces of the main loop, whichever of them comes late runs slower ON THE GPU with the host enqueue unchanged -
+        # single-stream E-RAFT 178 -> 70 frames/s behind the pipeline section, or the E-RAFT training step 94 -> 112 ms when the rows come
+        # first (measured, not explained: docs/NOTEBOOK.md section 10).  A child process is what `tools/bench_eraft*.py` are, and agrees with them.
         if not args.no_other_rows and world == 1:
-            line["other_rows"] = other_rows(dev)
+            import subprocess
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--rows-child"], capture_output=True, text=True, timeout=900)
+                line["other_rows"] = json.loads(r.stdout.strip().splitlines()[-1])
+                line["other_rows"]["measured_in"] = "child process (fresh HIP context)"
+            except Exception as e:                               # noqa: BLE001 - the side rows are never fatal
+                line["other_rows"] = {"error": repr(e)[:200]}
         if world == 1 and not args.no_side_rows:
             rows = latency_and_pipeline_rows(L, _lib, dev, flat, B, H, W, e1, e2, not args.no_graph, CO)
             line["latency_ms_b1"] = rows.pop("latency_ms_b1")

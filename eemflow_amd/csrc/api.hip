@@ -459,7 +459,7 @@ extern "C" int eemflow_time_kernels(eemflow_ctx* c, const float* e1, const float
                                     int* nstats, void* stream) {
     EEM_REQUIRE(c && e1 && e2 && out && stats && nstats, "eemflow_time_kernels: NULL argument");
     EEM_REQUIRE(c->weights_loaded && c->have_pad, "eemflow_time_kernels: load weights and set the image size first");
-    EEM_REQUIRE(reps >= 1, "eemflow_time_kernels: reps=%d", reps);
+    EEM_REQUIRE(reps != 0, "eemflow_time_kernels: reps=%d", reps);
     EEM_HIP_CHECK(hipSetDevice(c->device));
     Shape s;
     int rc = compute_shape(c, batch, in_h, in_w, out_h, out_w, &s);
@@ -472,11 +472,17 @@ extern "C" int eemflow_time_kernels(eemflow_ctx* c, const float* e1, const float
     Hook hk;
     hk.st = (hipStream_t)stream;
     hk.timing = true;
+    hk.repeat = reps < 0;                                // reps < 0: every kernel -reps times back to back (the single-frame table)
+    if (reps < 0) reps = -reps;
     hk.reps = reps;
-    // pass 0 warms (weights' transforms, clocks, caches) and names the launches; passes 1 .. reps are averaged
-    for (int p = 0; p <= reps && rc == EEM_OK; ++p) {
+    if (hk.repeat) {
         rc = run_forward(c, s, e1, e2, out, hk);
-        if (rc == EEM_OK) rc = hk.collect(p > 0);
+    } else {
+        // pass 0 warms (weights' transforms, clocks, caches) and names the launches; passes 1 .. reps are averaged
+        for (int p = 0; p <= reps && rc == EEM_OK; ++p) {
+            rc = run_forward(c, s, e1, e2, out, hk);
+            if (rc == EEM_OK) rc = hk.collect(p > 0);
+        }
     }
     hk.release();
     if (rc != EEM_OK) return rc;

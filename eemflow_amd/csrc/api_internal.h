@@ -373,6 +373,7 @@ struct Hook {
     hipStream_t st = nullptr;
     bool timing = false;
     int reps = 1;
+    bool repeat = false;                                 // timing, the other form: each kernel `reps` times back to back between ONE pair of events
     int pass = 0;                                        // timing: pass being issued
     size_t slot = 0;                                     // timing: launch index inside the pass
     std::vector<hipEvent_t> evs;                         // timing: two events per launch of a pass, reused pass after pass
@@ -412,6 +413,30 @@ struct Hook {
         }
 #endif
         if (!timing) return launch(st);
+        if (repeat) {
+            // (a launch of a few microseconds is mostly the gap an event pair adds around it: the single-frame table repeats each kernel
+            // instead - its inputs then come from whatever cache the repetition before left them in, which at one frame per launch is
+            // where the launch before it in the chain leaves them too)
+            if (evs.size() < 2) { evs.resize(2, nullptr); EEM_HIP_CHECK(hipEventCreate(&evs[0])); EEM_HIP_CHECK(hipEventCreate(&evs[1])); }
+            eem_last_grid_blocks = eem_last_grid_threads = eem_last_pipe = 0;
+            int rc = launch(st);
+            if (rc != EEM_OK) return rc;
+            EEM_HIP_CHECK(hipEventRecord(evs[0], st));
+            for (int i = 0; i < reps; ++i)
+                if ((rc = launch(st)) != EEM_OK) return rc;
+            EEM_HIP_CHECK(hipEventRecord(evs[1], st));
+            EEM_HIP_CHECK(hipEventSynchronize(evs[1]));
+            float ms = 0.f;
+            EEM_HIP_CHECK(hipEventElapsedTime(&ms, evs[0], evs[1]));
+            eemflow_kernel_stat ks;
+            memset(&ks, 0, sizeof(ks));
+            strncpy(ks.name, name, sizeof(ks.name) - 1);
+            ks.flops = flops; ks.bytes = bytes; ks.ms = ms;      // (divided by reps by the caller, like the chain form's sums)
+            ks.blocks = eem_last_grid_blocks;
+            ks.pipe = eem_last_pipe;
+            stats.push_back(ks);
+            return EEM_OK;
+        }
         if (evs.size() < 2 * (slot + 1)) {
             evs.resize(2 * (slot + 1), nullptr);
             EEM_HIP_CHECK(hipEventCreate(&evs[2 * slot]));

@@ -114,6 +114,8 @@ int eemflow_forward_many(eemflow_ctx* ctx, int nframes, const float* const* even
  * is not counted) with a pair of HIP events around EVERY launch, recorded on `stream` (the stream the kernels run on); `ms` is the
  * average per launch - each kernel measured behind its producer, as it runs in a forward.  `flops` / `bytes` are the ALGORITHMIC
  * work of one launch (conv MACs x 2; compulsory input + output + weight bytes).  flow_out receives the correct flow.
+ * reps < 0: the other form - every kernel of the schedule -reps times back to back between one pair of events (launches of a few
+ * microseconds, which an event pair per launch would mostly measure the gaps of).
  * Replaces: the reference's time_eval() wall-clock loop (model/EEMFlow/EEMFlow.py:201-225), per kernel. */
 typedef struct eemflow_kernel_stat {
     char name[48];

@@ -433,9 +433,12 @@ def latency_and_pipeline_rows(L, _lib, dev, flat, B, H, W, e1, e2, use_graph, co
                 arr = ctypes.c_void_p * co
                 _lib.check(L.eemflow_forward_many(ctxs[k], co, arr(*[v[0].data_ptr() for v in vs]), arr(*[v[1].data_ptr() for v in vs]),
                                                   arr(*[f.data_ptr() for f in fls]), H, W, H, W, spk))
-                for f in fls:
-                    stats = torch.empty(5, device=dev, dtype=torch.float64)
-                    _lib.check(L.eemflow_flow_error(gt.data_ptr(), f.data_ptr(), None, H, W, W, stats.data_ptr(), spk))
+                for s0 in range(0, co, 16):                      # the call's samples scored by ONE launch (up to 16 per call)
+                    part = fls[s0:s0 + 16]
+                    stats = torch.empty(len(part), 5, device=dev, dtype=torch.float64)
+                    pa = ctypes.c_void_p * len(part)
+                    _lib.check(L.eemflow_flow_error_many(len(part), pa(*[gt.data_ptr()] * len(part)), pa(*[f.data_ptr() for f in part]), None,
+                                                         H, W, W, stats.data_ptr(), spk))
                     keep.append(stats)
                 keep.extend(v for pair in vs for v in pair)
                 keep.extend(fls)

@@ -61,6 +61,9 @@ _SIGNATURES = {
                                         ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_void_p]),
     "eemflow_flow_error": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_void_p, ctypes.c_void_p]),
+    "eemflow_flow_error_many": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
+                                               ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                               ctypes.c_void_p]),
     "eemflow_voxelize": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int, _c_float_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "eemflow_voxelize_pair": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,

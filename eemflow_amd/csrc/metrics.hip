@@ -3,16 +3,25 @@
 // finite and non-zero (and, for the 'sparse' evaluation, where the event-count image is positive; rows >= 190 are
 // dropped for the MVSEC 'is_car' crop).  One pass over 5 planes (HBM-bound: 20 B per pixel); per-block partial sums
 // in double, combined with double atomics (5 per block).
+#include <string.h>
+
 #include "common.h"
 
 namespace {
 
 // VEC = 4: four pixels per thread and step by 16-byte loads (plane size and pointers 16-byte aligned); few, fat blocks because each
 // block ends with five f64 atomics on one cache line (~14 ns apiece, serialised at the memory side)
+// blockIdx.y = sample: eemflow_flow_error_many scores the samples of a coalesced call by one launch (their pointers in `many`)
+struct FlowErrMany { const float* gt[16]; const float* pred[16]; const float* ev[16]; };
+
 template <int VEC>
 __global__ __launch_bounds__(1024) void flow_error_kernel(const float* __restrict__ gt, const float* __restrict__ pred,
                                                           const float* __restrict__ ev, int h, int w, int max_row,
-                                                          double* __restrict__ out) {
+                                                          double* __restrict__ out, FlowErrMany many, int nmany) {
+    if (nmany > 0) {
+        gt = many.gt[blockIdx.y]; pred = many.pred[blockIdx.y]; ev = many.ev[blockIdx.y];
+        out += 5 * blockIdx.y;
+    }
     const long plane = (long)h * w, npix = (long)min(max_row, h) * w;
     double s_ee = 0, s_gt = 0, n = 0, n1 = 0, n3 = 0;
     auto pixel = [&](float gx, float gy, float px, float py, float e) {
@@ -66,8 +75,37 @@ extern "C" int eemflow_flow_error(const float* flow_gt, const float* flow_pred, 
     const bool vec = (npix & 3) == 0 && (((long)h * w) & 3) == 0 && ((((uintptr_t)flow_gt | (uintptr_t)flow_pred | (uintptr_t)event_img) & 15) == 0);
     int blocks = (int)((npix + 4095) / 4096);
     if (blocks > 64) blocks = 64;
-    if (vec) hipLaunchKernelGGL(flow_error_kernel<4>, dim3(blocks), dim3(1024), 0, st, flow_gt, flow_pred, event_img, h, w, max_row, out5);
-    else hipLaunchKernelGGL(flow_error_kernel<1>, dim3(blocks), dim3(1024), 0, st, flow_gt, flow_pred, event_img, h, w, max_row, out5);
+    FlowErrMany none;
+    memset(&none, 0, sizeof(none));
+    if (vec) hipLaunchKernelGGL(flow_error_kernel<4>, dim3(blocks), dim3(1024), 0, st, flow_gt, flow_pred, event_img, h, w, max_row, out5, none, 0);
+    else hipLaunchKernelGGL(flow_error_kernel<1>, dim3(blocks), dim3(1024), 0, st, flow_gt, flow_pred, event_img, h, w, max_row, out5, none, 0);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+// n samples (1..16) of one image size by ONE launch: flow_gt[i], flow_pred[i] (and event_img[i], or event_img == NULL for the 'dense'
+// evaluation) are host arrays of device pointers; out5n (device) receives n x 5 doubles, row i = sample i's five sums - the same values as
+// n eemflow_flow_error calls (per sample the same blocks add the same partial sums; the f64 atomics of a row commute only up to
+// rounding, as in the single call)
+extern "C" int eemflow_flow_error_many(int n, const float* const* flow_gt, const float* const* flow_pred, const float* const* event_img,
+                                       int h, int w, int max_row, double* out5n, void* stream) {
+    EEM_REQUIRE(n >= 1 && n <= 16 && flow_gt && flow_pred && out5n && h >= 1 && w >= 1 && max_row >= 1, "eemflow_flow_error_many: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    FlowErrMany m;
+    memset(&m, 0, sizeof(m));
+    uintptr_t bits = 0;
+    for (int i = 0; i < n; ++i) {
+        EEM_REQUIRE(flow_gt[i] && flow_pred[i], "eemflow_flow_error_many: sample %d has a NULL tensor", i);
+        m.gt[i] = flow_gt[i]; m.pred[i] = flow_pred[i]; m.ev[i] = event_img ? event_img[i] : nullptr;
+        bits |= (uintptr_t)flow_gt[i] | (uintptr_t)flow_pred[i] | (uintptr_t)m.ev[i];
+    }
+    EEM_HIP_CHECK(hipMemsetAsync(out5n, 0, (size_t)n * 5 * sizeof(double), st));
+    const long npix = (long)(max_row < h ? max_row : h) * w;
+    const bool vec = (npix & 3) == 0 && (((long)h * w) & 3) == 0 && (bits & 15) == 0;
+    int blocks = (int)((npix + 4095) / 4096);
+    if (blocks > 64) blocks = 64;
+    if (vec) hipLaunchKernelGGL(flow_error_kernel<4>, dim3(blocks, n), dim3(1024), 0, st, nullptr, nullptr, nullptr, h, w, max_row, out5n, m, n);
+    else hipLaunchKernelGGL(flow_error_kernel<1>, dim3(blocks, n), dim3(1024), 0, st, nullptr, nullptr, nullptr, h, w, max_row, out5n, m, n);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

@@ -24,7 +24,7 @@ import sys
 
 import torch
 
-from .metrics import flow_error, flow_error_from_sums, flow_error_sums
+from .metrics import flow_error, flow_error_from_sums, flow_error_sums, flow_error_sums_many
 from . import parallel
 from .train import EEMFlowTrainer, sequence_loss
 
@@ -174,12 +174,13 @@ class TestRaftEvents:
                             outs = replicas[k].forward_many(frames, deferred_norm=True)
                         else:
                             outs = replicas[k].forward_many(frames)
-                        for idx, sample, (_, preds) in zip(chunk, samples, outs):
-                            f_est = preds[-1]
-                            f_gt = sample['flow'].to(dev)[None].float()
-                            ev = sample['event_valid'].to(dev).sum(0) if ('event_valid' in sample and sparse) else None
-                            sums = flow_error_sums(f_gt, f_est, ev, is_car=self.is_car, evaluation_type="sparse" if ev is not None else "dense")
-                            pending.append((idx, k, sums, (sample, f_est, f_gt, ev)))
+                        f_ests = [preds[-1] for _, preds in outs]
+                        f_gts = [s_['flow'].to(dev)[None].float() for s_ in samples]
+                        evs_ = [s_['event_valid'].to(dev).sum(0) for s_ in samples] if (sparse and all('event_valid' in s_ for s_ in samples)) else None
+                        all_sums = flow_error_sums_many(f_gts, f_ests, evs_, is_car=self.is_car,        # the chunk's statistics by one launch
+                                                        evaluation_type="sparse" if evs_ is not None else "dense")
+                        for i_, (idx, sample) in enumerate(zip(chunk, samples)):
+                            pending.append((idx, k, all_sums[i_], (sample, f_ests[i_], f_gts[i_], evs_[i_] if evs_ is not None else None)))
                     while len(pending) >= nfl * co:
                         retire()
                 for idx in (indices if co == 1 else ()):

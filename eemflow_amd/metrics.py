@@ -29,6 +29,36 @@ def flow_error_sums(flow_gt, flow_pred, event_img=None, is_car=False, evaluation
     return out
 
 
+def flow_error_sums_many(flow_gts, flow_preds, event_imgs=None, is_car=False, evaluation_type="dense"):
+    """`[flow_error_sums(g, p, e) for ...]` for up to 16 samples of one size by ONE launch (eemflow_flow_error_many): returns an (n, 5)
+    float64 device tensor, row i = sample i's five sums."""
+    import ctypes
+    n = len(flow_gts)
+    if not 1 <= n <= 16 or len(flow_preds) != n:
+        raise ValueError("flow_error_sums_many: 1..16 samples, as many predictions as ground truths")
+    if not all(t.is_cuda for t in list(flow_gts) + list(flow_preds)):
+        raise _lib.EEMFlowHipError("flow_error: inputs must be CUDA (ROCm) tensors - there is no CPU path")
+    gts = [g[0].contiguous().float() for g in flow_gts]
+    prs = [p[0].contiguous().float() for p in flow_preds]
+    _, h, w = gts[0].shape
+    if any(tuple(t.shape) != (2, h, w) for t in gts + prs):
+        raise ValueError("flow_error_sums_many: all samples share one (2,H,W) shape")
+    max_row = 190 if is_car else w
+    evs = None
+    if evaluation_type == "sparse":
+        evs = [e.to(gts[0].device).reshape(h, w).contiguous().float() for e in event_imgs]
+    elif evaluation_type != "dense":
+        raise ValueError(f"evaluation_type {evaluation_type!r}")
+    dev = gts[0].device
+    out = torch.empty(n, 5, dtype=torch.float64, device=dev)
+    arr = ctypes.c_void_p * n
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().eemflow_flow_error_many(n, arr(*[t.data_ptr() for t in gts]), arr(*[t.data_ptr() for t in prs]),
+                                                      arr(*[t.data_ptr() for t in evs]) if evs is not None else None, h, w, max_row,
+                                                      out.data_ptr(), _lib.current_stream_ptr(dev)))
+    return out
+
+
 def flow_error_from_sums(sums):
     s_ee, s_gt, n, n1, n3 = sums.cpu().tolist() if torch.is_tensor(sums) else sums
     p1 = n1 / (n + 1e-5)

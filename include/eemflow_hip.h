@@ -163,6 +163,13 @@ int eemflow_upsample_bilinear(const float* in, float* out, int nc, int h, int w,
 int eemflow_flow_error(const float* flow_gt, const float* flow_pred, const float* event_img, int h, int w, int max_row,
                        double* out5, void* stream);
 
+/* The same statistics for n (1..16) samples of one image size by ONE launch - the samples of an eemflow_forward_many call: flow_gt[i],
+ * flow_pred[i], event_img[i] (event_img may be NULL: 'dense') are HOST arrays of device pointers; out5n (device): n x 5 doubles, row i
+ * as eemflow_flow_error gives for sample i.
+ * Replaces: n calls of Test.flow_error in the evaluation loop (test_mvsec.py:580-597 -> :291-346). */
+int eemflow_flow_error_many(int n, const float* const* flow_gt, const float* const* flow_pred, const float* const* event_img, int h,
+                            int w, int max_row, double* out5n, void* stream);
+
 /* Event voxelization: events [n][4] f64 (t, x, y, p) on the device, time-sorted, as held by the
  * reference's EventSequence -> grid [bins][h][w] fp32.  idx_left / idx_right (optional, may be NULL)
  * receive, per event, the int64 flat index x + y*w + bin*w*h of the left / right temporal vote, or -1

@@ -321,3 +321,24 @@ def test_coalesced_evaluation_agrees_with_the_one_sample_loop(tmp_path, monkeypa
     sa, sb = a[2], b.get_samples([2, 3])[0]
     assert sb["deferred_norm"] and float((sa["event_valid"] - sb["event_valid"]).abs().max()) < 1e-4
     assert torch.equal(sa["flow"], sb["flow"])
+
+
+def test_flow_error_many_equals_the_single_calls():
+    """eemflow_flow_error_many: the samples of a coalesced call scored by one launch - per sample the five sums of eemflow_flow_error
+    (test_mvsec.py:291-346) to f64 round-off (the atomics of a row commute up to rounding), dense and sparse, is_car rows."""
+    from eemflow_amd.metrics import flow_error_sums, flow_error_sums_many
+    g = torch.Generator().manual_seed(3)
+    n, h, w = 5, 260, 348
+    gts = [torch.randn(1, 2, h, w, generator=g).to(DEV) * 3 for _ in range(n)]
+    prs = [(gts[i] + torch.randn(1, 2, h, w, generator=g).to(DEV)) for i in range(n)]
+    evs = [(torch.rand(h, w, generator=g) < 0.3).float().to(DEV) for _ in range(n)]
+    gts[1][0, :, :7, :9] = float("inf")
+    gts[2][0, :, 100:120] = 0.0
+    for kind, car in (("dense", False), ("sparse", False), ("dense", True)):
+        many = flow_error_sums_many(gts, prs, evs if kind == "sparse" else None, is_car=car, evaluation_type=kind).cpu()
+        for i in range(n):
+            one = flow_error_sums(gts[i], prs[i], evs[i] if kind == "sparse" else None, is_car=car, evaluation_type=kind).cpu()
+            assert torch.allclose(many[i], one, rtol=1e-12, atol=0), (kind, car, i)
+            assert float(many[i][2]) == float(one[2])                     # the counts exactly
+    with pytest.raises(ValueError):
+        flow_error_sums_many(gts * 4, prs * 4)

@@ -81,6 +81,7 @@ struct eraft_ctx {
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     Buf s2[5];                     // the context network's own activations (the feature network runs at the same time)
     bool alt_corr = false;         // eraft_set_alternate_corr: correlation features on the fly, no all-pairs volume
+    bool final_only = false;       // eraft_set_final_only: only the last iteration's prediction leaves the forward
     Buf f2l[3];                    // avg-pooled fmap2, levels 1..3 (alt_corr)
     bool stages_valid = false;
 };
@@ -635,7 +636,13 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
     if (rc != EEM_OK) return rc;
     if ((rc = join()) != EEM_OK) return rc;                            // net, inp, the context parts of the GRU convs, coords
     int cur = 0;
+    // final_only: the predictions of iterations 0 .. iters - 2 are never formed - their mask head (the 3x3 128 -> 256 and 1x1 256 -> 576
+    // convs) and convex upsampling are not launched; the hidden state and coords1 go through the same launches with the same operands,
+    // so the one prediction that leaves is bit for bit the last of the full list (tests/test_eraft_hip.py)
+    float* c1p = c->c1.p;
+    float* c1q = c->c1b.p;
     for (int it = 0; it < iters; ++it) {
+        const bool emit = !c->final_only || it == iters - 1 || (it == 0 && c->keep_stages);   // (mask1 is a kept stage)
         float* net = c->net[cur].p;
         float* netn = c->net[cur ^ 1].p;
         // coords1 lives in two buffers: iteration `it` reads c1[it & 1], the convex-upsampling launch at its end writes the updated
@@ -643,8 +650,8 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
         // EEM_ERAFT_NO_FUSE=1 (read per forward): the separate flow / coords1 += delta launches, for A/B runs and the equality test
         const char* enf = getenv("EEM_ERAFT_NO_FUSE");
         const bool fuse_small = !(enf && enf[0] == '1');
-        float* c1cur = (fuse_small && (it & 1)) ? c->c1b.p : c->c1.p;
-        float* c1nxt = (fuse_small && !(it & 1)) ? c->c1b.p : c->c1.p;
+        float* c1cur = fuse_small ? c1p : c->c1.p;
+        float* c1nxt = fuse_small ? c1q : c->c1.p;
         // :142 lookup; :144 flow = coords1 - coords0 into the motion features' last two channels (update.py:81), by the same launch
         if (fuse_small) {
             if ((rc = run_lookup(c, c1cur, c->corr.p, kCorrPad, B, h8, w8, st, c->c0.p, c->motion.p, 128, 126)) != EEM_OK) return rc;
@@ -724,7 +731,7 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
         // flow head and mask head (model/update.py:102-105)
         const float* mh = c->mhid.p;
         int head_ct = 256, mh_off = 0;
-        if (stack) {
+        if (stack && emit) {
             a = conv_args(c, c->heads1, B, h8, w8, c->fhid.p, 512, 0, GACT_RELU);
             set_seg(a, 0, net, 128, 128, 0);
             if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
@@ -733,9 +740,19 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
             a = conv_args(c, c->fh1, B, h8, w8, c->fhid.p, 256, 0, GACT_RELU);
             set_seg(a, 0, net, 128, 128, 0);
             if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
-            a = conv_args(c, c->mk0, B, h8, w8, c->mhid.p, 256, 0, GACT_RELU);
-            set_seg(a, 0, net, 128, 128, 0);
+            if (emit) {
+                a = conv_args(c, c->mk0, B, h8, w8, c->mhid.p, 256, 0, GACT_RELU);
+                set_seg(a, 0, net, 128, 128, 0);
+                if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+            }
+        }
+        if (!emit) {
+            // the flow head's last conv, then :149 coords1 = coords1 + delta_flow in place
+            a = conv_args(c, c->fh2, B, h8, w8, c->delta.p, 2, 0, GACT_NONE);
+            set_seg(a, 0, c->fhid.p, 256, head_ct, 0);
             if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+            if ((rc = er_axpy_launch(c1cur, c->delta.p, (long)B * 2 * g, st)) != EEM_OK) return rc;
+            continue;
         }
         // the flow head's last conv (256 -> 2) beside the mask head's (256 -> 576)
         if ((rc = fork()) != EEM_OK) return rc;
@@ -748,12 +765,14 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
         if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
         if ((rc = join()) != EEM_OK) return rc;
         // :149 coords1 = coords1 + delta_flow and :155-157 the convex upsampling of coords1 - coords0, one launch
+        const int oi = c->final_only ? 0 : it;
         if (fuse_small) {
-            if ((rc = er_convex_up_launch(c->c0.p, c1cur, c->mask.p, out + (size_t)it * B * 2 * in_h * in_w, B, h8, w8, pad[2],
+            if ((rc = er_convex_up_launch(c->c0.p, c1cur, c->mask.p, out + (size_t)oi * B * 2 * in_h * in_w, B, h8, w8, pad[2],
                                           pad[0], in_h, in_w, st, c->delta.p, c1nxt)) != EEM_OK) return rc;
+            float* t = c1p; c1p = c1q; c1q = t;
         } else {
             if ((rc = er_axpy_launch(c->c1.p, c->delta.p, (long)B * 2 * g, st)) != EEM_OK) return rc;
-            if ((rc = er_convex_up_launch(c->c0.p, c->c1.p, c->mask.p, out + (size_t)it * B * 2 * in_h * in_w, B, h8, w8, pad[2],
+            if ((rc = er_convex_up_launch(c->c0.p, c->c1.p, c->mask.p, out + (size_t)oi * B * 2 * in_h * in_w, B, h8, w8, pad[2],
                                           pad[0], in_h, in_w, st)) != EEM_OK) return rc;
         }
         if (it == 0 && c->keep_stages) {
@@ -767,7 +786,7 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
     }
     {
         const char* enf = getenv("EEM_ERAFT_NO_FUSE");
-        c->c1last = (!(enf && enf[0] == '1') && (iters & 1)) ? c->c1b.p : c->c1.p;
+        c->c1last = !(enf && enf[0] == '1') ? c1p : c->c1.p;
     }
     c->B = B; c->h8 = h8; c->w8 = w8; c->have_last = true;
     c->stages_valid = c->keep_stages;
@@ -778,6 +797,13 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
 extern "C" int eraft_keep_stages(eraft_ctx* c, int enable) {
     EEM_REQUIRE(c, "eraft_keep_stages: NULL context");
     c->keep_stages = enable != 0;
+    return EEM_OK;
+}
+
+// The evaluation loop reads flow_list[-1] only (test_mvsec.py:1455): with this switch the forward writes that one prediction.
+extern "C" int eraft_set_final_only(eraft_ctx* c, int enable) {
+    EEM_REQUIRE(c, "eraft_set_final_only: NULL context");
+    c->final_only = enable != 0;
     return EEM_OK;
 }
 

@@ -166,6 +166,7 @@ class ERAFT(nn.Module):
         self._weights_version = None
         self.keep_stages = False       # True: the first iteration's corr0 / net1 / mask1 / delta1 stay readable through stage()
         self.frames_in_flight = 1      # >= 3: one of several replicas kept busy on separate streams (eraft_set_frames_in_flight)
+        self.final_only = False        # True (inference route): the returned list holds the last prediction only - what test_mvsec.py:1455 reads
         self.alternate_corr = False    # True (inference route): correlation features on the fly, no all-pairs volume (RAFT's alternate_corr)
 
     def change_imagesize(self, img_size):
@@ -182,6 +183,8 @@ class ERAFT(nn.Module):
             twin.change_imagesize(self.image_size)
         twin.train(self.training)
         twin.frames_in_flight = self.frames_in_flight if frames_in_flight is None else frames_in_flight
+        twin.final_only = getattr(self, "final_only", False)
+        twin.alternate_corr = getattr(self, "alternate_corr", False)
         return twin
 
     def freeze_bn(self):
@@ -214,6 +217,7 @@ class ERAFT(nn.Module):
         _lib.check(L.eraft_keep_stages(self._ctx, 1 if self.keep_stages else 0))
         _lib.check(L.eraft_set_frames_in_flight(self._ctx, max(1, int(getattr(self, "frames_in_flight", 1)))))
         _lib.check(L.eraft_set_alternate_corr(self._ctx, 1 if getattr(self, "alternate_corr", False) else 0))
+        _lib.check(L.eraft_set_final_only(self._ctx, 1 if getattr(self, "final_only", False) else 0))
         return self._ctx
 
     def forward(self, events1, events2, iters=12, flow_init=None, upsample=True, normal=False):
@@ -235,7 +239,8 @@ class ERAFT(nn.Module):
             # autograd route; also taken without gradients while BatchNorm is in train(): batch statistics, running-stat update
             return (events1, events2), self._forward_ops(e1, e2, iters, flow_init)
         ctx = self._context(e1.device)
-        out = torch.empty(iters, b, 2, h, w, device=e1.device, dtype=torch.float32)
+        nout = 1 if getattr(self, "final_only", False) else iters
+        out = torch.empty(nout, b, 2, h, w, device=e1.device, dtype=torch.float32)
         fi = None
         if flow_init is not None:
             fi = flow_init.contiguous().float()
@@ -244,7 +249,7 @@ class ERAFT(nn.Module):
             _lib.check(_lib.lib().eraft_forward(ctx, e1.data_ptr(), e2.data_ptr(), b, h, w, ctypes.byref(padc), iters,
                                                 fi.data_ptr() if fi is not None else None, out.data_ptr(),
                                                 _lib.current_stream_ptr(e1.device)))
-        return (events1, events2), [out[i] for i in range(iters)]
+        return (events1, events2), [out[i] for i in range(nout)]
 
     # ------------------------------------------------------------------ differentiable route (eemflow_amd/ops.py)
     def _norm(self, norm, x, relu):

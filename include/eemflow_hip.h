@@ -282,6 +282,12 @@ int eraft_keep_stages(eraft_ctx* ctx, int enable);
  * features up to summation order; eraft_get_stage("pyr<l>") is not available in this mode. */
 int eraft_set_alternate_corr(eraft_ctx* ctx, int enable);
 
+/* 1: eraft_forward writes ONE prediction, flow_out [1][batch][2][in_h][in_w] = the last entry of the reference's list - what the
+ * evaluation loop reads (test_mvsec.py:1455 `batch['flow_list'][-1]`).  The mask head and the convex upsampling of iterations
+ * 0 .. iters - 2 are not launched (their results feed nothing else: model/eraft.py:141-157); the hidden state, coords1 and the last
+ * prediction are bit for bit those of the full forward.  0 = default: every iteration's prediction, as ERAFT.forward returns them. */
+int eraft_set_final_only(eraft_ctx* ctx, int enable);
+
 /* Throughput hint, as eemflow_set_frames_in_flight: the application keeps `n` E-RAFT forwards in flight on this GPU (one context
  * and HIP stream each).  With n >= 3 the 16-aligned stride-1 convs use 4-row tiles from 512 blocks on (2 048 otherwise): the
  * other frames fill the CUs a short launch leaves idle, and each weight fragment is read half as often (640x480, 12 iterations,

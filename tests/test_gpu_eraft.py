@@ -170,6 +170,34 @@ def test_on_the_fly_correlation_equals_the_resident_volume(b, h, w, iters):
         assert maxerr(fly[-1], ref[-1]) < FLOW_TOL
 
 
+@pytest.mark.parametrize("b,h,w,iters,keep", [(2, 136, 200, 5, False), (1, 480, 640, 12, False), (4, 256, 352, 4, False),
+                                              (1, 136, 200, 1, False), (2, 136, 200, 3, True)])
+def test_final_only_is_the_last_of_the_full_list(b, h, w, iters, keep):
+    """ERAFT.final_only (eraft_set_final_only): what the evaluation loop reads (test_mvsec.py:1455 flow_list[-1]) without the mask
+    head and the convex upsampling of the iterations before the last - the one returned prediction and the low-resolution flow are
+    bit for bit those of the full forward (odd and even iteration counts: coords1 stays in one buffer until the last iteration); with
+    keep_stages the first iteration still forms its mask; the switch can be turned back."""
+    net, _ = make_net(71)
+    net.keep_stages = keep
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(72, b, h, w))
+    with torch.no_grad():
+        full = torch.stack(net(e1, e2, iters=iters)[1]).clone()
+        low_full = net.stage("flow_low").clone()
+        mask_full = net.stage("mask1").clone() if keep else None
+        net.final_only = True
+        one = net(e1, e2, iters=iters)[1]
+        low_one = net.stage("flow_low").clone()
+        assert len(one) == 1 and one[0].shape == full[-1].shape
+        last = one[0].clone()
+        if keep:
+            assert torch.equal(net.stage("mask1"), mask_full)
+        net.final_only = False
+        again = torch.stack(net(e1, e2, iters=iters)[1])
+    assert torch.equal(last, full[-1]) and torch.equal(low_one, low_full)
+    assert torch.equal(again, full) and float(full.abs().max()) > 1e-3
+
+
 def test_frames_in_flight_hint_changes_tiles_not_results():
     """eraft_set_frames_in_flight >= 3: the LDS-tiled convs of 512..2047 blocks use 4-row tiles instead of 2-row ones (batch 4 at
     640x480: the update block), and launches of at most one block per CU keep one group of waves per tile instead of two that split

@@ -54,7 +54,14 @@ __device__ __forceinline__ float gb_act(float v, int act) {
     }
 }
 
-template <int KH, int KW, int THT>
+#ifdef EEM_DIAG
+// diagnostic builds, EEM_GB_DBG (tools/gconvb_phases.sh): 1 no MFMAs, 2 no weight loads inside the k-loop, 4 no A-fragment reads inside the
+// k-loop, 8 the staging waves only keep the barriers, 16 no epilogue operands / activation (plain store), 32 every wave leaves at once
+// (the launch alone), 64 no staging prologue either (with 8), 128 no stores
+__device__ int g_gb_dbg;
+#endif
+
+template <int KH, int KW, int THT, int RING>
 __global__ __launch_bounds__(768, 3) void gconvb_kernel(GConvArgs ka, const u32x4* __restrict__ wq, int tiles_x, int nchunks) {
     // every launch argument the kernel uses, as scalars of its own: closures that reach the argument STRUCT by reference kept a copy of it in
     // scratch (328 bytes stored and re-read per thread)
@@ -74,6 +81,12 @@ __global__ __launch_bounds__(768, 3) void gconvb_kernel(GConvArgs ka, const u32x
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave12 = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef EEM_DIAG
+    const int dbg = __builtin_amdgcn_readfirstlane(g_gb_dbg);
+#else
+    constexpr int dbg = 0;
+#endif
+    if (dbg & 32) return;
     // Roles: waves 0-7 multiply (ds_read_b128 + weight loads + MFMAs, nothing else in their stream), two per SIMD; waves 8-11 stage the
     // next chunk's tile (global loads, the split, LDS writes), one per SIMD.  Why: the split's VALU work runs on the SIMD's vector pipe
     // BESIDE the MFMAs instead of between them; vmcnt retires in order - a multiplying wave that had issued the staging loads (HBM)
@@ -144,13 +157,17 @@ __global__ __launch_bounds__(768, 3) void gconvb_kernel(GConvArgs ka, const u32x
                 d[2 * s_pstride + k] = cp[2];
             }
         };
-        stage_load(0);
-        convert(0);
-        stage_load(1);
+        if (!(dbg & 64)) {
+            stage_load(0);
+            convert(0);
+            stage_load(1);
+        }
         __syncthreads();
         for (int ch = 0; ch < nchunks; ++ch) {
-            convert((ch + 1) & 1);                                           // chunk ch + 1's tile, while the multipliers read chunk ch's
-            stage_load(ch + 2);
+            if (!(dbg & 8)) {
+                convert((ch + 1) & 1);                                       // chunk ch + 1's tile, while the multipliers read chunk ch's
+                stage_load(ch + 2);
+            }
             __syncthreads();
         }
         return;
@@ -162,7 +179,9 @@ __global__ __launch_bounds__(768, 3) void gconvb_kernel(GConvArgs ka, const u32x
     const int ccw = blockIdx.y * 2 + (cog8 >> 2);
     const bool wlive = ccw * 64 + (cog8 & 3) * 16 < a_cout;                  // (a cout count that ends inside the block: idle multipliers only keep the barriers)
     const u32x4* wbase = wq + ((size_t)(wlive ? ccw : 0) * nchunks * TAPS * 4 + (cog8 & 3)) * 3 * 64 + lane;
-    u32x4 bw[2][2][3];
+    // the ring: k-step s's fragments live in slot s % RING and are requested RING - 1 k-steps before their MFMAs (RING = 2; three slots
+    // for the tiles of up to six rows were measured and are no faster - gb_launch)
+    u32x4 bw[RING][2][3];
     auto load_b = [&](auto slot_tag, int s) __attribute__((always_inline)) {      // k-step s = ch * TAPS + tap (clamped past the end: a harmless reload)
         constexpr int SL = decltype(slot_tag)::value;
         const int sc = s < nchunks * TAPS ? s : nchunks * TAPS - 1;
@@ -175,30 +194,38 @@ __global__ __launch_bounds__(768, 3) void gconvb_kernel(GConvArgs ka, const u32x
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
     load_b(P0{}, 0);
+    if constexpr (RING > 2) load_b(P1{}, 1);
     __syncthreads();
 
     // A fragment of (tile row p, tap (ky, kx), piece pc): entry ((pc * 4 + kg) * ROWS + 4 ph + p + ky) * COLS + XOFF - PW + kx + m
     const unsigned a_lane = (unsigned)((kg * C::ROWS + PT * ph) * COLS + C::XOFF - C::PW + m) * 16u;
     const char* lb = reinterpret_cast<const char*>(lds);
 
-    // one chunk: TAPS k-steps of 48 MFMAs; PAR = ring slot of its first k-step's weights (the kernels' tap counts are odd: it alternates)
+    // one chunk: TAPS k-steps of 6 TH MFMAs; PAR = ring slot of its first k-step's weights = (ch * TAPS) % RING
+    u32x4 av[PT][3];
     auto chunk = [&](auto par_tag, int ch) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_tag)::value;
         const unsigned abuf = a_lane + (unsigned)((ch & 1) * C::STAGE) * 16u;
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
             const int ky = t / KW, kx = t % KW;
-            u32x4 av[PT][3];
+            if (!(dbg & 4) || (ch == 0 && t == 0)) {
 #pragma unroll
             for (int p = 0; p < PT; ++p)
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc)
                     av[p][pc] = *reinterpret_cast<const u32x4*>(lb + abuf + ((pc * 4 * PLANE) + (p + ky) * COLS + kx) * 16);
-            // the next k-step's weights, into the slot the previous k-step has left
+            }
+            // the weights of k-step s + RING - 1, into the slot the previous k-step has left
             const int s = ch * TAPS + t;
-            if ((PAR + t + 1) % 2 == 0) load_b(P0{}, s + 1);
-            else load_b(P1{}, s + 1);
+            const int slot = (PAR + t + RING - 1) % RING;                    // (t is an unrolled loop's counter: folded)
+            if (!(dbg & 2)) {
+                if (slot == 0) load_b(P0{}, s + RING - 1);
+                else if (slot == 1) load_b(P1{}, s + RING - 1);
+                else if constexpr (RING > 2) load_b(std::integral_constant<int, 2>{}, s + RING - 1);
+            }
             __builtin_amdgcn_sched_barrier(0);
+            if (!(dbg & 1))
 #pragma unroll
             for (int i = 0; i < 6; ++i) {                                    // small terms first
                 constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
@@ -206,17 +233,25 @@ __global__ __launch_bounds__(768, 3) void gconvb_kernel(GConvArgs ka, const u32x
                 for (int p = 0; p < PT; ++p)
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
-                        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gb_bf(av[p][PA[i]]), gb_bf(bw[(PAR + t) % 2][q][PB[i]]), acc[p][q], 0, 0, 0);
+                        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gb_bf(av[p][PA[i]]), gb_bf(bw[(PAR + t) % RING][q][PB[i]]), acc[p][q], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();                                                     // this chunk's tile is read, the next one's is written
     };
-    static_assert(TAPS % 2 == 1, "the two-slot weight ring alternates per chunk");
     if (wlive) {
-        for (int ch = 0; ch < nchunks; ch += 2) {
+        // (groups of RING chunks without a branch inside: the weights a chunk's last k-steps request for the next chunk's first ones are
+        // used in the same basic block - behind `if (ch + 1 < nchunks)` the compiler sank the loads into the conditional block, past
+        // the barrier, and waited for them there: one exposed L2 round trip per pair of chunks)
+        int ch = 0;
+        for (; ch + RING <= nchunks; ch += RING) {
             chunk(P0{}, ch);
-            if (ch + 1 < nchunks) chunk(P1{}, ch + 1);
+            chunk(std::integral_constant<int, TAPS % RING>{}, ch + 1);
+            if constexpr (RING > 2) chunk(std::integral_constant<int, (2 * TAPS) % RING>{}, ch + 2);
+        }
+        if (ch < nchunks) {
+            chunk(P0{}, ch);
+            if (RING > 2 && ch + 1 < nchunks) chunk(std::integral_constant<int, TAPS % RING>{}, ch + 1);
         }
     } else {
         for (int ch = 0; ch < nchunks; ++ch) __syncthreads();
@@ -253,7 +288,8 @@ __global__ __launch_bounds__(768, 3) void gconvb_kernel(GConvArgs ka, const u32x
     for (int p = 0; p < PT; ++p)
 #pragma unroll
         for (int q = 0; q < 2; ++q) { e0v[p][q] = z4; e1v[p][q] = z4; prv[p][q] = z4; }
-    if (a_pre) {
+    const int a_epi_ld = (dbg & 16) ? GEPI_PLAIN : a_epi;
+    if (a_pre && !(dbg & 16)) {
         const float* b = a_pre + ((size_t)n * a_pre_ctotal + a_pre_coff) * hwo;
 #pragma unroll
         for (int p = 0; p < PT; ++p)
@@ -261,14 +297,14 @@ __global__ __launch_bounds__(768, 3) void gconvb_kernel(GConvArgs ka, const u32x
             for (int q = 0; q < 2; ++q) prv[p][q] = *reinterpret_cast<const f32x4*>(b + ip[p][q]);
     }
     const unsigned zsplit = a_epi == GEPI_ZR ? (unsigned)(a_split * hwo) : 0u;   // GEPI_ZR: e0 is indexed by co - split, from split on
-    if (a_epi != GEPI_PLAIN) {
+    if (a_epi_ld != GEPI_PLAIN) {
         const float* b = a_e0 + ((size_t)n * a_e0_ctotal + a_e0_coff) * hwo;
 #pragma unroll
         for (int p = 0; p < PT; ++p)
 #pragma unroll
             for (int q = 0; q < 2; ++q) e0v[p][q] = *reinterpret_cast<const f32x4*>(b + (ip[p][q] < zsplit ? 0u : ip[p][q] - zsplit));
     }
-    if (a_epi == GEPI_GRU) {
+    if (a_epi_ld == GEPI_GRU) {
         const float* b = a_e1 + ((size_t)n * a_e1_ctotal + a_e1_coff) * hwo;
 #pragma unroll
         for (int p = 0; p < PT; ++p)
@@ -279,12 +315,12 @@ __global__ __launch_bounds__(768, 3) void gconvb_kernel(GConvArgs ka, const u32x
     for (int p = 0; p < PT; ++p)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            if (!ok[p][q]) continue;
+            if (!ok[p][q] || (dbg & 128)) continue;
             f32x4 v;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float t = acc[p][q][j] * e_scale[q] + e_shift[q] + prv[p][q][j];
-                t = gb_act(t, a_act);
+                t = gb_act(t, (dbg & 16) ? GACT_NONE : a_act);
                 if (a_epi == GEPI_MUL) t *= e0v[p][q][j];
                 else if (a_epi == GEPI_GRU) t = (1.f - e1v[p][q][j]) * e0v[p][q][j] + e1v[p][q][j] * t;
                 else if (a_epi == GEPI_ADD_RELU) { t += e0v[p][q][j]; t = t > 0.f ? t : 0.f; }
@@ -301,14 +337,17 @@ __global__ __launch_bounds__(768, 3) void gconvb_kernel(GConvArgs ka, const u32x
         }
 }
 
-template <int KH, int KW, int THT>
+template <int KH, int KW, int THT, int RING>
 int gb_launch_t(const GConvArgs& a, hipStream_t stream) {
     using C = GBCfg<KH, KW, THT>;
     int cin = 0;
     for (int s = 0; s < a.nseg; ++s) cin += a.seg[s].c;
     const int tiles_x = ceil_div(a.wout, C::TW), tiles_y = ceil_div(a.hout, C::TH);
     dim3 grid(tiles_x * tiles_y, ceil_div(a.cout, 128), a.n);
-    hipLaunchKernelGGL((gconvb_kernel<KH, KW, THT>), grid, dim3(768), 0, stream, a, reinterpret_cast<const u32x4*>(a.wpkb), tiles_x, cin / 32);
+#ifdef EEM_DIAG
+    { static int once = [] { const char* e = getenv("EEM_GB_DBG"); int v = e ? atoi(e) : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gb_dbg), &v, sizeof v); return v; }(); (void)once; }
+#endif
+    hipLaunchKernelGGL((gconvb_kernel<KH, KW, THT, RING>), grid, dim3(768), 0, stream, a, reinterpret_cast<const u32x4*>(a.wpkb), tiles_x, cin / 32);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }
@@ -330,11 +369,22 @@ int gb_launch(const GConvArgs& a, hipStream_t stream) {
         for (int t = 6; t >= 2; t -= 2)
             if (cost(t) < cost(th) - 1e-3f) th = t;
     }
+#ifdef EEM_DIAG
+    // diagnostic builds, EEM_GCONVB_RING=3: the tiles of up to six rows request their weights two k-steps ahead (three slots).  Measured
+    // (tools/gconvb_ring.sh): E-RAFT 640x480 x 12 batch 1 178.1 / 179.2 against 179.9 / 180.0 frames/s, batch 4 272.1 / 272.4 against
+    // 275.5 / 275.6 - the weights' round trip is not what a k-step waits for
+    const char* rg = getenv("EEM_GCONVB_RING");
+    if (rg && rg[0] == '3') {
+        if (th == 2) return gb_launch_t<KH, KW, 2, 3>(a, stream);
+        if (th == 4) return gb_launch_t<KH, KW, 4, 3>(a, stream);
+        if (th == 6) return gb_launch_t<KH, KW, 6, 3>(a, stream);
+    }
+#endif
     switch (th) {
-        case 2: return gb_launch_t<KH, KW, 2>(a, stream);
-        case 4: return gb_launch_t<KH, KW, 4>(a, stream);
-        case 6: return gb_launch_t<KH, KW, 6>(a, stream);
-        default: return gb_launch_t<KH, KW, 8>(a, stream);
+        case 2: return gb_launch_t<KH, KW, 2, 2>(a, stream);
+        case 4: return gb_launch_t<KH, KW, 4, 2>(a, stream);
+        case 6: return gb_launch_t<KH, KW, 6, 2>(a, stream);
+        default: return gb_launch_t<KH, KW, 8, 2>(a, stream);
     }
 }
 

@@ -79,6 +79,9 @@ struct eraft_ctx {
     // network and the correlation volume, convf1 -> convf2 beside convc1 -> convc2, the flow head's last conv beside the mask head's
     hipStream_t side = nullptr;
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    // the mask head and the convex upsampling of iteration i on a stream of their own, beside iteration i + 1 (eraft_forward)
+    hipStream_t lag = nullptr;
+    hipEvent_t net_ev = nullptr, c1_ev = nullptr, lag_ev = nullptr;
     Buf s2[5];                     // the context network's own activations (the feature network runs at the same time)
     bool alt_corr = false;         // eraft_set_alternate_corr: correlation features on the fly, no all-pairs volume
     bool final_only = false;       // eraft_set_final_only: only the last iteration's prediction leaves the forward
@@ -391,6 +394,8 @@ extern "C" void eraft_destroy(eraft_ctx* c) {
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     if (c->join_ev) (void)hipEventDestroy(c->join_ev);
+    if (c->lag) (void)hipStreamDestroy(c->lag);
+    for (hipEvent_t e : {c->net_ev, c->c1_ev, c->lag_ev}) if (e) (void)hipEventDestroy(e);
     if (c->arena) (void)hipFree(c->arena);
     if (c->wino) (void)hipFree(c->wino);
     if (c->trash) (void)hipFree(c->trash);
@@ -558,6 +563,20 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
         for (int i = 0; i < 5; ++i)
             if ((rc = ensure(c->s2[i], big / 2)) != EEM_OK) return rc;
     }
+    // The prediction of an iteration - mask head (3x3 128 -> 256, 1x1 256 -> 576) and convex upsampling - feeds nothing inside the loop
+    // (model/eraft.py:141-157: the recurrence is net -> flow head -> coords1 -> lookup): it runs on a third stream beside the NEXT
+    // iteration, which starts as soon as the flow head has updated coords1.  One forward at a time the update block's launches leave
+    // most CUs idle (60x80 cells at batch 1 are 75 - 300 blocks): E-RAFT 640x480 x 12 batch 1 / 4: tools/bench_eraft.py, DESIGN.md 4b.
+    // EEM_ERAFT_NO_LAG=1 (read per forward): the mask head inside the iteration, as before.
+    const char* enl = getenv("EEM_ERAFT_NO_LAG");
+    const char* enf0 = getenv("EEM_ERAFT_NO_FUSE");
+    const bool lagged = overlap && !(enl && enl[0] == '1') && !(enf0 && enf0[0] == '1');
+    if (lagged && !c->lag) {
+        EEM_HIP_CHECK(hipStreamCreateWithFlags(&c->lag, hipStreamNonBlocking));
+        EEM_HIP_CHECK(hipEventCreateWithFlags(&c->net_ev, hipEventDisableTiming));
+        EEM_HIP_CHECK(hipEventCreateWithFlags(&c->c1_ev, hipEventDisableTiming));
+        EEM_HIP_CHECK(hipEventCreateWithFlags(&c->lag_ev, hipEventDisableTiming));
+    }
     hipStream_t sd = overlap ? c->side : st;
     // fork: the side stream continues from here on the caller's stream; join: the caller's stream waits for the side stream's work so far
     // An error return between a fork and its join must not leave work queued on the side stream that the caller's stream never waits
@@ -568,7 +587,7 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
             if (!forked) return;
             if (hipEventRecord(join_ev, sd) != hipSuccess || hipStreamWaitEvent(st, join_ev, 0) != hipSuccess) (void)hipStreamSynchronize(sd);
         }
-    } guard{st, sd, c->join_ev};
+    } guard{st, sd, c->join_ev}, lag_guard{st, c->lag, c->lag_ev};
     auto fork = [&]() -> int {
         if (!overlap) return EEM_OK;
         EEM_HIP_CHECK(hipEventRecord(c->fork_ev, st));
@@ -691,6 +710,8 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
         const char* ens = getenv("EEM_ERAFT_NO_STACK");
         const bool stack = !(ens && ens[0] == '1');
         for (int pass = 0; pass < 2; ++pass) {
+            // (the second pass writes the buffer the previous iteration's mask head reads its hidden state from)
+            if (pass == 1 && lag_guard.forked) EEM_HIP_CHECK(hipStreamWaitEvent(st, c->lag_ev, 0));
             if (stack) {
                 if (use_pre) {
                     a = conv_args(c, c->gzr_hm[pass], B, h8, w8, c->z.p, 256, 0, GACT_SIGMOID);
@@ -729,51 +750,94 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
         }
         // after two passes the new hidden state is back in `net`
         // flow head and mask head (model/update.py:102-105)
-        const float* mh = c->mhid.p;
-        int head_ct = 256, mh_off = 0;
-        if (stack && emit) {
-            a = conv_args(c, c->heads1, B, h8, w8, c->fhid.p, 512, 0, GACT_RELU);
-            set_seg(a, 0, net, 128, 128, 0);
-            if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
-            mh = c->fhid.p; head_ct = 512; mh_off = 256;
-        } else {
+        if (lagged) {
+            if (emit) {
+                EEM_HIP_CHECK(hipEventRecord(c->net_ev, st));
+                EEM_HIP_CHECK(hipStreamWaitEvent(c->lag, c->net_ev, 0));
+                lag_guard.forked = true;
+                a = conv_args(c, c->mk0, B, h8, w8, c->mhid.p, 256, 0, GACT_RELU);
+                set_seg(a, 0, net, 128, 128, 0);
+                if ((rc = gconv_launch(a, c->lag)) != EEM_OK) return rc;
+                a = conv_args(c, c->mk2, B, h8, w8, c->mask.p, 576, 0, GACT_NONE);
+                set_seg(a, 0, c->mhid.p, 256, 256, 0);
+                a.out_scale = 0.25f;
+                if ((rc = gconv_launch(a, c->lag)) != EEM_OK) return rc;
+            }
             a = conv_args(c, c->fh1, B, h8, w8, c->fhid.p, 256, 0, GACT_RELU);
             set_seg(a, 0, net, 128, 128, 0);
             if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+            // the flow head's last conv leaves delta_flow and :149 coords1 + delta_flow (the other coords1 buffer) in one launch
+            a = conv_args(c, c->fh2, B, h8, w8, c->delta.p, 2, 0, GACT_NONE);
+            set_seg(a, 0, c->fhid.p, 256, 256, 0);
+            a.epi = GEPI_SUM2; a.e0 = c1cur; a.e0_ctotal = 2; a.e0_coff = 0; a.out2 = c1nxt; a.out2_ctotal = 2;
+            if (fewout_supported(a)) {
+                if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+            } else {                                                         // (maps of less than 256 cells: the generic kernel, then the sum)
+                a.epi = GEPI_PLAIN; a.e0 = nullptr; a.out2 = nullptr;
+                if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+                if ((rc = er_sum_launch(c1nxt, c1cur, c->delta.p, (long)B * 2 * g, st)) != EEM_OK) return rc;
+            }
             if (emit) {
-                a = conv_args(c, c->mk0, B, h8, w8, c->mhid.p, 256, 0, GACT_RELU);
+                // :155-157 the convex upsampling of coords1 - coords0
+                EEM_HIP_CHECK(hipEventRecord(c->c1_ev, st));
+                EEM_HIP_CHECK(hipStreamWaitEvent(c->lag, c->c1_ev, 0));
+                const int oi = c->final_only ? 0 : it;
+                if ((rc = er_convex_up_launch(c->c0.p, c1nxt, c->mask.p, out + (size_t)oi * B * 2 * in_h * in_w, B, h8, w8, pad[2], pad[0],
+                                              in_h, in_w, c->lag)) != EEM_OK) return rc;
+                EEM_HIP_CHECK(hipEventRecord(c->lag_ev, c->lag));
+                if (it == iters - 1 || (it == 0 && c->keep_stages)) {        // the last prediction; the kept stages are copied on `st`
+                    EEM_HIP_CHECK(hipStreamWaitEvent(st, c->lag_ev, 0));
+                    lag_guard.forked = false;
+                }
+            }
+            { float* t = c1p; c1p = c1q; c1q = t; }
+        } else {
+            const float* mh = c->mhid.p;
+            int head_ct = 256, mh_off = 0;
+            if (stack && emit) {
+                a = conv_args(c, c->heads1, B, h8, w8, c->fhid.p, 512, 0, GACT_RELU);
                 set_seg(a, 0, net, 128, 128, 0);
                 if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+                mh = c->fhid.p; head_ct = 512; mh_off = 256;
+            } else {
+                a = conv_args(c, c->fh1, B, h8, w8, c->fhid.p, 256, 0, GACT_RELU);
+                set_seg(a, 0, net, 128, 128, 0);
+                if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+                if (emit) {
+                    a = conv_args(c, c->mk0, B, h8, w8, c->mhid.p, 256, 0, GACT_RELU);
+                    set_seg(a, 0, net, 128, 128, 0);
+                    if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+                }
             }
-        }
-        if (!emit) {
-            // the flow head's last conv, then :149 coords1 = coords1 + delta_flow in place
+            if (!emit) {
+                // the flow head's last conv, then :149 coords1 = coords1 + delta_flow in place
+                a = conv_args(c, c->fh2, B, h8, w8, c->delta.p, 2, 0, GACT_NONE);
+                set_seg(a, 0, c->fhid.p, 256, head_ct, 0);
+                if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+                if ((rc = er_axpy_launch(c1cur, c->delta.p, (long)B * 2 * g, st)) != EEM_OK) return rc;
+                continue;
+            }
+            // the flow head's last conv (256 -> 2) beside the mask head's (256 -> 576)
+            if ((rc = fork()) != EEM_OK) return rc;
             a = conv_args(c, c->fh2, B, h8, w8, c->delta.p, 2, 0, GACT_NONE);
             set_seg(a, 0, c->fhid.p, 256, head_ct, 0);
+            if ((rc = gconv_launch(a, sd)) != EEM_OK) return rc;
+            a = conv_args(c, c->mk2, B, h8, w8, c->mask.p, 576, 0, GACT_NONE);
+            set_seg(a, 0, mh, 256, head_ct, mh_off);
+            a.out_scale = 0.25f;
             if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
-            if ((rc = er_axpy_launch(c1cur, c->delta.p, (long)B * 2 * g, st)) != EEM_OK) return rc;
-            continue;
-        }
-        // the flow head's last conv (256 -> 2) beside the mask head's (256 -> 576)
-        if ((rc = fork()) != EEM_OK) return rc;
-        a = conv_args(c, c->fh2, B, h8, w8, c->delta.p, 2, 0, GACT_NONE);
-        set_seg(a, 0, c->fhid.p, 256, head_ct, 0);
-        if ((rc = gconv_launch(a, sd)) != EEM_OK) return rc;
-        a = conv_args(c, c->mk2, B, h8, w8, c->mask.p, 576, 0, GACT_NONE);
-        set_seg(a, 0, mh, 256, head_ct, mh_off);
-        a.out_scale = 0.25f;
-        if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
-        if ((rc = join()) != EEM_OK) return rc;
-        // :149 coords1 = coords1 + delta_flow and :155-157 the convex upsampling of coords1 - coords0, one launch
-        const int oi = c->final_only ? 0 : it;
-        if (fuse_small) {
-            if ((rc = er_convex_up_launch(c->c0.p, c1cur, c->mask.p, out + (size_t)oi * B * 2 * in_h * in_w, B, h8, w8, pad[2],
-                                          pad[0], in_h, in_w, st, c->delta.p, c1nxt)) != EEM_OK) return rc;
-            float* t = c1p; c1p = c1q; c1q = t;
-        } else {
-            if ((rc = er_axpy_launch(c->c1.p, c->delta.p, (long)B * 2 * g, st)) != EEM_OK) return rc;
-            if ((rc = er_convex_up_launch(c->c0.p, c->c1.p, c->mask.p, out + (size_t)oi * B * 2 * in_h * in_w, B, h8, w8, pad[2],
-                                          pad[0], in_h, in_w, st)) != EEM_OK) return rc;
+            if ((rc = join()) != EEM_OK) return rc;
+            // :149 coords1 = coords1 + delta_flow and :155-157 the convex upsampling of coords1 - coords0, one launch
+            const int oi = c->final_only ? 0 : it;
+            if (fuse_small) {
+                if ((rc = er_convex_up_launch(c->c0.p, c1cur, c->mask.p, out + (size_t)oi * B * 2 * in_h * in_w, B, h8, w8, pad[2],
+                                              pad[0], in_h, in_w, st, c->delta.p, c1nxt)) != EEM_OK) return rc;
+                float* t = c1p; c1p = c1q; c1q = t;
+            } else {
+                if ((rc = er_axpy_launch(c->c1.p, c->delta.p, (long)B * 2 * g, st)) != EEM_OK) return rc;
+                if ((rc = er_convex_up_launch(c->c0.p, c->c1.p, c->mask.p, out + (size_t)oi * B * 2 * in_h * in_w, B, h8, w8, pad[2],
+                                              pad[0], in_h, in_w, st)) != EEM_OK) return rc;
+            }
         }
         if (it == 0 && c->keep_stages) {
             EEM_HIP_CHECK(hipMemcpy2DAsync(c->st_corr0.p, 324 * g * 4, c->corr.p, kCorrPad * g * 4, 324 * g * 4, B,

@@ -58,6 +58,7 @@ int er_flow_launch(const float* coords0, const float* coords1, float* dst, int d
                    hipStream_t st);
 // coords1 += delta
 int er_axpy_launch(float* y, const float* x, long n, hipStream_t st);
+int er_sum_launch(float* out, const float* a, const float* b, long n, hipStream_t st);      // out = a + b
 int er_mul_channels_launch(float* out, const float* a, int a_ctotal, int a_coff, const float* b, int batch, int c, long hw, hipStream_t st);
 
 // convex upsampling (model/eraft.py:83-94) of flow = coords1 - coords0 with mask [B][576][H][W], written

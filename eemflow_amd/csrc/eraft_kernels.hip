@@ -475,6 +475,11 @@ __global__ __launch_bounds__(256) void axpy_kernel(float* y, const float* x, lon
     if (idx < n) y[idx] += x[idx];
 }
 
+__global__ __launch_bounds__(256) void sum_kernel(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b, long n) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx < n) out[idx] = a[idx] + b[idx];
+}
+
 // out[n][c][p] = a[n][a_coff + c][p] * b[n][c][p]: r * h of the GRU when z and r come out of one 256-cout launch
 __global__ __launch_bounds__(256) void mul_channels_kernel(float* __restrict__ out, const float* __restrict__ a, int a_ctotal, int a_coff,
                                                             const float* __restrict__ b, int c, long hw, long n) {
@@ -634,6 +639,12 @@ int er_flow_launch(const float* c0, const float* c1, float* dst, int dst_ctotal,
 
 int er_axpy_launch(float* y, const float* x, long n, hipStream_t st) {
     hipLaunchKernelGGL(axpy_kernel, dim3(blocks(n)), dim3(256), 0, st, y, x, n);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int er_sum_launch(float* out, const float* a, const float* b, long n, hipStream_t st) {
+    hipLaunchKernelGGL(sum_kernel, dim3(blocks(n)), dim3(256), 0, st, out, a, b, n);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

@@ -19,7 +19,8 @@ enum {
     GEPI_GRU = 2,          // out = (1 - e1) * e0 + e1 * v      (e0 = h, e1 = z)
     GEPI_ADD_RELU = 3,     // out = relu(v + e0)                (residual block tail)
     GEPI_ADD = 4,          // out = v + e0                      (EEMFlow+ decoder: flow residual)
-    GEPI_ZR = 5            // co < split: out = v;  co >= split: out2[co - split] = v * e0[co - split]
+    GEPI_ZR = 5,           // co < split: out = v;  co >= split: out2[co - split] = v * e0[co - split]
+    GEPI_SUM2 = 6          // out = v and out2 = e0 + v         (E-RAFT: delta_flow and coords1 + delta_flow; fewout kernel only)
                            // (z | r of a GRU pass as one conv: z stays, r leaves as r * h - model/update.py:46-48,54-56)
 };
 
@@ -55,7 +56,7 @@ struct GConvArgs {
     // features, model/update.py:43-60), computed once
     const float* pre;
     int pre_ctotal, pre_coff;
-    float* out2;           // GEPI_ZR: [N][out2_ctotal][hout][wout]
+    float* out2;           // GEPI_ZR / GEPI_SUM2: [N][out2_ctotal][hout][wout]
     int out2_ctotal, split;
     const float* wpkb;     // packed by gconvb_pack (pre-split bf16 B fragments, gconvb.hip), or NULL
 };

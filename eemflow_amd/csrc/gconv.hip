@@ -345,12 +345,14 @@ __global__ __launch_bounds__(256) void gconv_taps_kernel(GConvArgs a) {
 // one uniform 32-byte load, scalar registers feed the FMAs), the partial sums meet in LDS and thread (co, pixel) finishes one output.
 // Splitting the channels rather than the pixels over the waves is what fills the chip: 180 x 320 pixels are 900 wave-rows, less
 // than one per SIMD, and a lone wave per SIMD cannot hide its own load latency.
-// FEW_WAVES = 8, CA = 1 (a channel ahead, 63 VGPRs, 8 waves per SIMD) for launches that fill the chip; 16 waves x CA = 2 (two
-// channels per request group, a group ahead) for launches of less than a wave per SIMD, where a wave's time is the number of its
-// request round trips (E-RAFT's flow head 256 -> 2 at 60x80: 75 blocks; 26 -> 12 us).
-template <int FEW_WAVES, int CA>
+// FEW_WAVES = 8, CA = 1 (a channel ahead, 63 VGPRs, 8 waves per SIMD) for launches that fill the chip; 16 waves x CA channels per
+// request group, a group ahead, for the layers of many channels, where a wave's time is the number of its request round trips
+// (E-RAFT's flow head 256 -> 2 at 60x80: 75 blocks; 26 -> 12 us with CA = 2; four channels per group are no faster, and 16 waves
+// at batch 4 - 300 blocks - are slower than 8: 257 against 278 frames/s).  NCO = 2: the layers of at most two couts (that flow head)
+// keep two accumulators instead of eight.
+template <int FEW_WAVES, int CA, int NCO>
 __global__ __launch_bounds__(FEW_WAVES * 64, (FEW_WAVES == 8 ? 8 : 4)) void fewout_kernel(GConvArgs a, int cpw) {
-    __shared__ float part[FEW_WAVES][8][64];
+    __shared__ float part[FEW_WAVES][NCO][64];
     const int hw = a.hin * a.win;
     const int lane = threadIdx.x & 63;
     const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -363,9 +365,9 @@ __global__ __launch_bounds__(FEW_WAVES * 64, (FEW_WAVES == 8 ? 8 : 4)) void fewo
     const GConvSeg& sg = a.seg[0];
     const int c0 = g * cpw, c1 = min(c0 + cpw, sg.c);
     const float* in = sg.ptr + ((size_t)n * sg.ctotal + sg.coff + c0) * hw;
-    float acc[8];
+    float acc[NCO];
 #pragma unroll
-    for (int co = 0; co < 8; ++co) acc[co] = 0.f;
+    for (int co = 0; co < NCO; ++co) acc[co] = 0.f;
     int off[9];
     bool keep[9];
 #pragma unroll
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(FEW_WAVES * 64, (FEW_WAVES == 8 ? 8 : 4)) void fewo
                 const float vv = keep[t] ? v[q][t] : 0.f;
                 const float* w8 = w + ((size_t)(c + q - c0) * 9 + t) * 8;
 #pragma unroll
-                for (int co = 0; co < 8; ++co) acc[co] += vv * w8[co];
+                for (int co = 0; co < NCO; ++co) acc[co] += vv * w8[co];
             }
         }
     };
@@ -412,11 +414,11 @@ __global__ __launch_bounds__(FEW_WAVES * 64, (FEW_WAVES == 8 ? 8 : 4)) void fewo
         }
     }
 #pragma unroll
-    for (int co = 0; co < 8; ++co) part[g][co][lane] = acc[co];
+    for (int co = 0; co < NCO; ++co) part[g][co][lane] = acc[co];
     __syncthreads();
     // thread (co = g, pixel = lane) sums the channel groups in order and finishes the output
     const int co = g;
-    if (!live || co >= 8 || co >= a.cout) return;
+    if (!live || co >= NCO || co >= a.cout) return;
     float r = 0.f;
 #pragma unroll
     for (int k = 0; k < FEW_WAVES; ++k) r += part[k][co][lane];
@@ -428,7 +430,9 @@ __global__ __launch_bounds__(FEW_WAVES * 64, (FEW_WAVES == 8 ? 8 : 4)) void fewo
     else if (a.act == GACT_TANH) r = tanhf(r);
     if (a.epi == GEPI_ADD) r += a.e0[((size_t)n * a.e0_ctotal + a.e0_coff + co) * hw + p];
     const int oc = a.out_coff + co * (a.out_cmul > 1 ? a.out_cmul : 1);
-    a.out[((size_t)n * a.out_ctotal + oc) * hw + p] = r * a.out_scale;
+    r *= a.out_scale;
+    a.out[((size_t)n * a.out_ctotal + oc) * hw + p] = r;
+    if (a.epi == GEPI_SUM2) a.out2[((size_t)n * a.out2_ctotal + co) * hw + p] = a.e0[((size_t)n * a.e0_ctotal + a.e0_coff + co) * hw + p] + r;
 }
 
 }  // namespace
@@ -448,17 +452,21 @@ bool fewout_supported(const GConvArgs& a) {
     const char* e = getenv("EEM_NO_FEWOUT");                         // read per call: a test flips it inside one process
     if (e && e[0] == '1') return false;
     return a.wfew && a.nseg == 1 && a.cout <= 8 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.tstride <= 1 && a.pad_h == 1 && a.pad_w == 1 &&
-           a.seg[0].cmul <= 1 && a.seg[0].gate == nullptr && a.pre == nullptr && (a.epi == GEPI_PLAIN || a.epi == GEPI_ADD) && a.hout == a.hin && a.wout == a.win &&
+           a.seg[0].cmul <= 1 && a.seg[0].gate == nullptr && a.pre == nullptr && (a.epi == GEPI_PLAIN || a.epi == GEPI_ADD || a.epi == GEPI_SUM2) && a.hout == a.hin && a.wout == a.win &&
            (long)a.hin * a.win >= few_min_px;                        // smaller maps: the split-K launch of the generic kernel
 }
 
 int fewout_launch(const GConvArgs& a, hipStream_t stream) {
     const long n = (long)a.n * a.hin * a.win;
     const unsigned blocks = (unsigned)((n + 63) / 64);
-    if (blocks * 8 < 1024 && a.seg[0].c >= 64) {                      // less than a wave per SIMD
-        hipLaunchKernelGGL((fewout_kernel<16, 2>), dim3(blocks), dim3(1024), 0, stream, a, (a.seg[0].c + 15) / 16);
+    const bool small = blocks * 8 < 1024 && a.seg[0].c >= 64;         // less than a wave per SIMD
+    if (a.cout <= 2) {                                                // E-RAFT's flow head
+        if (small) hipLaunchKernelGGL((fewout_kernel<16, 2, 2>), dim3(blocks), dim3(1024), 0, stream, a, (a.seg[0].c + 15) / 16);
+        else hipLaunchKernelGGL((fewout_kernel<8, 1, 2>), dim3(blocks), dim3(512), 0, stream, a, (a.seg[0].c + 7) / 8);
+    } else if (small) {
+        hipLaunchKernelGGL((fewout_kernel<16, 2, 8>), dim3(blocks), dim3(1024), 0, stream, a, (a.seg[0].c + 15) / 16);
     } else {
-        hipLaunchKernelGGL((fewout_kernel<8, 1>), dim3(blocks), dim3(512), 0, stream, a, (a.seg[0].c + 7) / 8);
+        hipLaunchKernelGGL((fewout_kernel<8, 1, 8>), dim3(blocks), dim3(512), 0, stream, a, (a.seg[0].c + 7) / 8);
     }
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;

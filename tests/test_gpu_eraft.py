@@ -198,6 +198,30 @@ def test_final_only_is_the_last_of_the_full_list(b, h, w, iters, keep):
     assert torch.equal(again, full) and float(full.abs().max()) > 1e-3
 
 
+@pytest.mark.parametrize("b,h,w,iters,final", [(2, 136, 200, 5, False), (1, 480, 640, 12, False), (4, 480, 640, 3, False),
+                                               (1, 480, 640, 4, True), (1, 64, 96, 3, False)])
+def test_mask_head_beside_the_next_iteration_equals_the_serial_order(monkeypatch, b, h, w, iters, final):
+    """The default schedule - mask head and convex upsampling of iteration i on a third stream beside iteration i + 1, the flow head's
+    last conv writing delta_flow and coords1 + delta_flow in one launch - against the mask head inside the iteration
+    (EEM_ERAFT_NO_LAG=1, read per forward): every prediction, the low-resolution flow and the kept stages of the first iteration are
+    the same (the hidden state is read by the lagging launches while the next iteration reads it, and overwritten only after they have
+    finished); with final_only; on a map of less than 256 cells (the generic kernel and a separate sum); twice in a row on one
+    context (the events are reused)."""
+    net, _ = make_net(91)
+    net.final_only = final
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(92, b, h, w))
+    outs = {}
+    for lag in ("1", "0", "0"):
+        monkeypatch.setenv("EEM_ERAFT_NO_LAG", lag)
+        with torch.no_grad():
+            preds = torch.stack(net(e1, e2, iters=iters)[1]).clone()
+            outs[lag] = (preds, net.stage("flow_low").clone(), net.stage("mask1").clone(), net.stage("delta1").clone(), net.stage("net1").clone())
+    for x, y in zip(outs["0"], outs["1"]):
+        assert maxerr(x, y) < 1e-5 * max(1.0, float(y.abs().max()))
+    assert float(outs["1"][0].abs().max()) > 1e-3
+
+
 def test_frames_in_flight_hint_changes_tiles_not_results():
     """eraft_set_frames_in_flight >= 3: the LDS-tiled convs of 512..2047 blocks use 4-row tiles instead of 2-row ones (batch 4 at
     640x480: the update block), and launches of at most one block per CU keep one group of waves per tile instead of two that split

@@ -64,7 +64,7 @@ struct eraft_ctx {
     Layer gzr_hm[2], gq_hm[2], gzr_c[2], gq_c[2];
     Buf czr[2], cq[2];
     // workspace
-    Buf padded, s[5], fmap, net[2], inp, pyr[4], c0, c1, c1b, corr, cor1, corflo, flo1, motion, z, rh, fhid, delta, mhid, mask;
+    Buf padded, s[5], fmap, net[3], inp, pyr[4], c0, c1, c1b, corr, cor1, corflo, flo1, motion, z, rh, fhid, delta, mhid, mask;
     Buf st_corr0, st_net1, st_mask1, st_delta1, zeros;
     int B = 0, h8 = 0, w8 = 0, ph[4] = {0, 0, 0, 0}, pw[4] = {0, 0, 0, 0};
     bool have_last = false;
@@ -81,7 +81,7 @@ struct eraft_ctx {
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     // the mask head and the convex upsampling of iteration i on a stream of their own, beside iteration i + 1 (eraft_forward)
     hipStream_t lag = nullptr;
-    hipEvent_t net_ev = nullptr, c1_ev = nullptr, lag_ev = nullptr;
+    hipEvent_t net_ev = nullptr, c1_ev = nullptr, lag_ev[2] = {nullptr, nullptr}, lag_join_ev = nullptr;
     Buf s2[5];                     // the context network's own activations (the feature network runs at the same time)
     bool alt_corr = false;         // eraft_set_alternate_corr: correlation features on the fly, no all-pairs volume
     bool final_only = false;       // eraft_set_final_only: only the last iteration's prediction leaves the forward
@@ -384,7 +384,7 @@ extern "C" int eraft_create(int device, eraft_ctx** out) {
 extern "C" void eraft_destroy(eraft_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    Buf* all[] = {&c->padded, &c->s[0], &c->s[1], &c->s[2], &c->s[3], &c->s[4], &c->fmap, &c->net[0], &c->net[1], &c->inp,
+    Buf* all[] = {&c->padded, &c->s[0], &c->s[1], &c->s[2], &c->s[3], &c->s[4], &c->fmap, &c->net[0], &c->net[1], &c->net[2], &c->inp,
                   &c->pyr[0], &c->pyr[1], &c->pyr[2], &c->pyr[3], &c->c0, &c->c1, &c->c1b, &c->corr, &c->cor1, &c->corflo, &c->flo1,
                   &c->motion, &c->z, &c->rh, &c->fhid, &c->delta, &c->mhid, &c->mask, &c->st_corr0, &c->st_net1, &c->st_mask1,
                   &c->st_delta1, &c->zeros, &c->f2l[0], &c->f2l[1], &c->f2l[2], &c->czr[0], &c->czr[1], &c->cq[0], &c->cq[1],
@@ -395,7 +395,7 @@ extern "C" void eraft_destroy(eraft_ctx* c) {
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     if (c->join_ev) (void)hipEventDestroy(c->join_ev);
     if (c->lag) (void)hipStreamDestroy(c->lag);
-    for (hipEvent_t e : {c->net_ev, c->c1_ev, c->lag_ev}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {c->net_ev, c->c1_ev, c->lag_ev[0], c->lag_ev[1], c->lag_join_ev}) if (e) (void)hipEventDestroy(e);
     if (c->arena) (void)hipFree(c->arena);
     if (c->wino) (void)hipFree(c->wino);
     if (c->trash) (void)hipFree(c->trash);
@@ -543,7 +543,7 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
         }
     }
     ENS(c->fmap, (size_t)2 * B * 256 * g);
-    ENS(c->net[0], B * 128 * g); ENS(c->net[1], B * 128 * g); ENS(c->inp, B * 128 * g);
+    ENS(c->net[0], B * 128 * g); ENS(c->net[1], B * 128 * g); ENS(c->net[2], B * 128 * g); ENS(c->inp, B * 128 * g);
     ENS(c->c0, B * 2 * g); ENS(c->c1, B * 2 * g); ENS(c->c1b, B * 2 * g); ENS(c->corr, B * kCorrPad * g); ENS(c->cor1, B * 256 * g);
     ENS(c->corflo, B * 256 * g); ENS(c->flo1, B * 128 * g); ENS(c->motion, B * 128 * g); ENS(c->z, B * 256 * g);
     ENS(c->rh, B * 128 * g); ENS(c->fhid, B * 512 * g); ENS(c->delta, B * 2 * g); ENS(c->mhid, B * 256 * g);
@@ -573,9 +573,7 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
     const bool lagged = overlap && !(enl && enl[0] == '1') && !(enf0 && enf0[0] == '1');
     if (lagged && !c->lag) {
         EEM_HIP_CHECK(hipStreamCreateWithFlags(&c->lag, hipStreamNonBlocking));
-        EEM_HIP_CHECK(hipEventCreateWithFlags(&c->net_ev, hipEventDisableTiming));
-        EEM_HIP_CHECK(hipEventCreateWithFlags(&c->c1_ev, hipEventDisableTiming));
-        EEM_HIP_CHECK(hipEventCreateWithFlags(&c->lag_ev, hipEventDisableTiming));
+        for (hipEvent_t* e : {&c->net_ev, &c->c1_ev, &c->lag_ev[0], &c->lag_ev[1], &c->lag_join_ev}) EEM_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
     hipStream_t sd = overlap ? c->side : st;
     // fork: the side stream continues from here on the caller's stream; join: the caller's stream waits for the side stream's work so far
@@ -587,7 +585,7 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
             if (!forked) return;
             if (hipEventRecord(join_ev, sd) != hipSuccess || hipStreamWaitEvent(st, join_ev, 0) != hipSuccess) (void)hipStreamSynchronize(sd);
         }
-    } guard{st, sd, c->join_ev}, lag_guard{st, c->lag, c->lag_ev};
+    } guard{st, sd, c->join_ev}, lag_guard{st, c->lag, c->lag_join_ev};
     auto fork = [&]() -> int {
         if (!overlap) return EEM_OK;
         EEM_HIP_CHECK(hipEventRecord(c->fork_ev, st));
@@ -654,16 +652,46 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
     else rc = build_pyramid(c, c->fmap.p, c->fmap.p + (size_t)B * 256 * g, B, 256, h8, w8, st);
     if (rc != EEM_OK) return rc;
     if ((rc = join()) != EEM_OK) return rc;                            // net, inp, the context parts of the GRU convs, coords
-    int cur = 0;
     // final_only: the predictions of iterations 0 .. iters - 2 are never formed - their mask head (the 3x3 128 -> 256 and 1x1 256 -> 576
     // convs) and convex upsampling are not launched; the hidden state and coords1 go through the same launches with the same operands,
     // so the one prediction that leaves is bit for bit the last of the full list (tests/test_eraft_hip.py)
     float* c1p = c->c1.p;
     float* c1q = c->c1b.p;
+    // lagged schedule: the mask head of an iteration starts on `lag` as soon as its hidden state is there (beside the flow head, the next
+    // lookup and the 1x1 conv behind it - the launches that leave most of the chip idle); its convex upsampling follows behind the NEXT
+    // iteration's fork event (the record the flow branch needs anyway, after coords1 + delta_flow: an event record of its own costs
+    // the recording stream ~6 us, tools/eraft_timeline.sh) or, after the last iteration, behind a record of its own
+    struct { bool on = false; const float* c1 = nullptr; int oi = 0, ev = 0; } pend;
+    auto lag_heads = [&](const float* hidden) -> int {
+        EEM_HIP_CHECK(hipEventRecord(c->net_ev, st));
+        EEM_HIP_CHECK(hipStreamWaitEvent(c->lag, c->net_ev, 0));
+        lag_guard.forked = true;
+        GConvArgs m = conv_args(c, c->mk0, B, h8, w8, c->mhid.p, 256, 0, GACT_RELU);
+        set_seg(m, 0, hidden, 128, 128, 0);
+        int r2 = gconv_launch(m, c->lag);
+        if (r2 != EEM_OK) return r2;
+        m = conv_args(c, c->mk2, B, h8, w8, c->mask.p, 576, 0, GACT_NONE);
+        set_seg(m, 0, c->mhid.p, 256, 256, 0);
+        m.out_scale = 0.25f;
+        return gconv_launch(m, c->lag);
+    };
+    auto lag_up = [&](hipEvent_t after) -> int {
+        if (!pend.on) return EEM_OK;
+        pend.on = false;
+        EEM_HIP_CHECK(hipStreamWaitEvent(c->lag, after, 0));
+        // :155-157 the convex upsampling of coords1 - coords0
+        int r2 = er_convex_up_launch(c->c0.p, pend.c1, c->mask.p, out + (size_t)pend.oi * B * 2 * in_h * in_w, B, h8, w8, pad[2], pad[0], in_h,
+                                     in_w, c->lag);
+        if (r2 != EEM_OK) return r2;
+        EEM_HIP_CHECK(hipEventRecord(c->lag_ev[pend.ev], c->lag));
+        return EEM_OK;
+    };
     for (int it = 0; it < iters; ++it) {
         const bool emit = !c->final_only || it == iters - 1 || (it == 0 && c->keep_stages);   // (mask1 is a kept stage)
-        float* net = c->net[cur].p;
-        float* netn = c->net[cur ^ 1].p;
+        // the hidden state alternates between two buffers, with a third between the GRU's passes: the state an iteration leaves is read
+        // by its lagging mask head during the next iteration and overwritten only in the one after
+        float* nin = c->net[it & 1].p;
+        float* net = c->net[(it + 1) & 1].p;                               // (the state this iteration leaves)
         // coords1 lives in two buffers: iteration `it` reads c1[it & 1], the convex-upsampling launch at its end writes the updated
         // coordinates into the other one
         // EEM_ERAFT_NO_FUSE=1 (read per forward): the separate flow / coords1 += delta launches, for A/B runs and the equality test
@@ -682,6 +710,7 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
         // the 324 correlation features live in a 336-channel buffer (12 zero channels, zero weight columns) so that the
         // 1x1 conv qualifies for the 16-aligned LDS-tiled kernel; the generic kernel reads the first 324
         if ((rc = fork()) != EEM_OK) return rc;                        // (the lookup wrote the flow channels of `motion`)
+        if (lagged && (rc = lag_up(c->fork_ev)) != EEM_OK) return rc;      // (the previous iteration's prediction)
         GConvArgs a = conv_args(c, c->convf1, B, h8, w8, c->flo1.p, 128, 0, GACT_RELU);
         set_seg(a, 0, c->motion.p, 2, 128, 126);
         if ((rc = gconv_launch(a, sd)) != EEM_OK) return rc;
@@ -696,12 +725,15 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
         set_seg(a, 0, c->cor1.p, 256, 256, 0);
         if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
         if ((rc = join()) != EEM_OK) return rc;
+        // (this iteration's GRU and flow head overwrite the hidden state and the coords1 buffer the prediction of iteration it - 2 reads:
+        // it has had an iteration and a half; the wait sits beside the join's)
+        if (lagged && it >= 2 && lag_guard.forked) EEM_HIP_CHECK(hipStreamWaitEvent(st, c->lag_ev[it & 1], 0));
         a = conv_args(c, c->conv, B, h8, w8, c->motion.p, 128, 0, GACT_RELU);
         set_seg(a, 0, c->corflo.p, 256, 256, 0);
         if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
         // SepConvGRU (model/update.py:43-60): horizontal then vertical pass
-        float* hcur = net;
-        float* hnext = netn;
+        float* hcur = nin;
+        float* hnext = c->net[2].p;
         // Layers that read the same input run as ONE launch stacked along the output channels: z | r of a GRU pass (r * h then is a
         // small elementwise launch), and the first convs of the flow head and the mask head.  One forward at a time at batch 1 these were
         // 200-block launches for 256 CUs each - one round of 5 / 6-row tiles now instead of two launches that each leave the chip
@@ -710,8 +742,6 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
         const char* ens = getenv("EEM_ERAFT_NO_STACK");
         const bool stack = !(ens && ens[0] == '1');
         for (int pass = 0; pass < 2; ++pass) {
-            // (the second pass writes the buffer the previous iteration's mask head reads its hidden state from)
-            if (pass == 1 && lag_guard.forked) EEM_HIP_CHECK(hipStreamWaitEvent(st, c->lag_ev, 0));
             if (stack) {
                 if (use_pre) {
                     a = conv_args(c, c->gzr_hm[pass], B, h8, w8, c->z.p, 256, 0, GACT_SIGMOID);
@@ -746,23 +776,12 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
             }
             a.epi = GEPI_GRU; a.e0 = hcur; a.e0_ctotal = 128; a.e0_coff = 0; a.e1 = c->z.p; a.e1_ctotal = stack ? 256 : 128; a.e1_coff = 0;
             if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
-            float* t = hcur; hcur = hnext; hnext = t;
+            hcur = hnext; hnext = net;
         }
-        // after two passes the new hidden state is back in `net`
+        // after two passes the new hidden state is in `net`
         // flow head and mask head (model/update.py:102-105)
         if (lagged) {
-            if (emit) {
-                EEM_HIP_CHECK(hipEventRecord(c->net_ev, st));
-                EEM_HIP_CHECK(hipStreamWaitEvent(c->lag, c->net_ev, 0));
-                lag_guard.forked = true;
-                a = conv_args(c, c->mk0, B, h8, w8, c->mhid.p, 256, 0, GACT_RELU);
-                set_seg(a, 0, net, 128, 128, 0);
-                if ((rc = gconv_launch(a, c->lag)) != EEM_OK) return rc;
-                a = conv_args(c, c->mk2, B, h8, w8, c->mask.p, 576, 0, GACT_NONE);
-                set_seg(a, 0, c->mhid.p, 256, 256, 0);
-                a.out_scale = 0.25f;
-                if ((rc = gconv_launch(a, c->lag)) != EEM_OK) return rc;
-            }
+            if (emit && (rc = lag_heads(net)) != EEM_OK) return rc;
             a = conv_args(c, c->fh1, B, h8, w8, c->fhid.p, 256, 0, GACT_RELU);
             set_seg(a, 0, net, 128, 128, 0);
             if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
@@ -778,15 +797,11 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
                 if ((rc = er_sum_launch(c1nxt, c1cur, c->delta.p, (long)B * 2 * g, st)) != EEM_OK) return rc;
             }
             if (emit) {
-                // :155-157 the convex upsampling of coords1 - coords0
-                EEM_HIP_CHECK(hipEventRecord(c->c1_ev, st));
-                EEM_HIP_CHECK(hipStreamWaitEvent(c->lag, c->c1_ev, 0));
-                const int oi = c->final_only ? 0 : it;
-                if ((rc = er_convex_up_launch(c->c0.p, c1nxt, c->mask.p, out + (size_t)oi * B * 2 * in_h * in_w, B, h8, w8, pad[2], pad[0],
-                                              in_h, in_w, c->lag)) != EEM_OK) return rc;
-                EEM_HIP_CHECK(hipEventRecord(c->lag_ev, c->lag));
-                if (it == iters - 1 || (it == 0 && c->keep_stages)) {        // the last prediction; the kept stages are copied on `st`
-                    EEM_HIP_CHECK(hipStreamWaitEvent(st, c->lag_ev, 0));
+                pend.on = true; pend.c1 = c1nxt; pend.oi = c->final_only ? 0 : it; pend.ev = it & 1;
+                if (it == iters - 1 || (it == 0 && c->keep_stages)) {        // nothing follows / the kept stages are copied on `st`
+                    EEM_HIP_CHECK(hipEventRecord(c->c1_ev, st));
+                    if ((rc = lag_up(c->c1_ev)) != EEM_OK) return rc;
+                    EEM_HIP_CHECK(hipStreamWaitEvent(st, c->lag_ev[it & 1], 0));
                     lag_guard.forked = false;
                 }
             }
@@ -846,7 +861,6 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
             EEM_HIP_CHECK(hipMemcpyAsync(c->st_mask1.p, c->mask.p, B * 576 * g * 4, hipMemcpyDeviceToDevice, st));
             EEM_HIP_CHECK(hipMemcpyAsync(c->st_delta1.p, c->delta.p, B * 2 * g * 4, hipMemcpyDeviceToDevice, st));
         }
-        (void)cur;
     }
     {
         const char* enf = getenv("EEM_ERAFT_NO_FUSE");

@@ -21,6 +21,9 @@ with torch.no_grad():
     for _ in range(int(os.environ.get("BENCH_WARM", "2"))): net(e1, e2, iters=iters)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     n = int(os.environ.get("BENCH_N", "5"))
-    for _ in range(n): net(e1, e2, iters=iters)
+    sync_each = os.environ.get("BENCH_SYNC", "0") == "1"          # the evaluation loop's use: the result of every forward is read
+    for _ in range(n):
+        net(e1, e2, iters=iters)
+        if sync_each: torch.cuda.synchronize()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 print(f"E-RAFT {w}x{h} iters={iters} batch={b}: {dt*1e3:.2f} ms/forward, {b/dt:.2f} frames/s, {499.2*b*(h*w)/(480*640)/dt/1e3:.1f} TFLOP/s (conv FLOPs scaled from 640x480; the all-pairs GEMM grows quadratically)")

@@ -75,6 +75,8 @@ _SIGNATURES = {
                                                 _c_float_p, ctypes.POINTER(ctypes.c_double * 5), ctypes.c_void_p]),
     "eemflow_optimizer_step": (ctypes.c_int, [ctypes.c_void_p, _c_float_p, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                               ctypes.c_float, ctypes.c_void_p]),
+    "eemflow_train_stats_async": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "eemflow_train_stats_wait": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]),
     "eemflow_optimizer_skipped_steps": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     "eemflow_get_weights": (ctypes.c_int, [ctypes.c_void_p, _c_float_p, ctypes.c_size_t, ctypes.c_void_p]),
     "eraft_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),

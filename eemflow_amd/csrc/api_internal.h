@@ -136,6 +136,12 @@ struct eemflow_ctx {
     int span_n = 0;
     bool span_pending = false;
     bool skip_counter_zeroed = false;                    // train_api.hip: the device-side count of skipped optimizer steps
+    // eemflow_train_stats_async / _wait: the loss statistics of a step on their way to pinned host memory behind an event, so that the
+    // host can enqueue the optimizer step (and the next forward) before it reads them
+    double* stats_host = nullptr;
+    hipEvent_t stats_ev = nullptr;
+    bool stats_pending = false;
+    double stats_scale = 0.0;                            // gamma weight / (B * 2 * out_h * out_w) of the forward they belong to
     // inference leaves f13 unwritten when pconv3_3's epilogue pools it (nothing else reads it); the training forward keeps every
     // activation (keep_stage_stores), and eemflow_get_stage("f13") re-runs the layer with stores when the last forward skipped them
     bool enc0_generic = false;                           // n_first_channels != 5: pconv1_1 = replicate-pad launch + gconv.hip
@@ -209,6 +215,16 @@ int refresh_wino(eemflow_ctx* c, hipStream_t) {
     for (int l = 0; l < ENC_NUM; ++l) c->bx3_ok[l] = false;
     return EEM_OK;
 }
+// The packed forms a launch can actually take (the opt-in kernels' switches are read per launch - conv_s2r.hip, conv_bx3.hip - and so are
+// these): after every optimizer step the packed copies are stale, and a transform nobody reads was six ~5 us launches in the chain of
+// a training step's forward
+inline bool s2r_wanted() { const char* on = getenv("EEM_S2R"); return on && on[0] == '1'; }
+inline bool bx3_wanted(int l) {
+    const EncLayerDesc& d = kEncLayers[l];
+    if (d.stride == 2) return true;
+    const char* m = getenv("EEM_BX3_S1");
+    return ((m ? atoi(m) : 0) & (d.cin == 32 ? 1 : 2)) != 0;
+}
 int ensure_bx3(eemflow_ctx* c, int l, hipStream_t st, const float** w_out) {
     if (!c->bx3_ok[l]) {
         const int rc = bx3_transform_launch(c->flat + c->t_enc[l].w, kEncLayers[l].cin, kEncLayers[l].cout, c->wino + c->bx3_off[l], st);
@@ -267,8 +283,8 @@ int ensure_train_wino(eemflow_ctx* c, int batch, hipStream_t st) {
 int ensure_forward_wino(eemflow_ctx* c, int batch, hipStream_t st) {
     for (int l = 0; l < ENC_NUM; ++l) {
         const float* ws;
-        if (c->enc_s2r[l]) { const int rc = ensure_s2r(c, l, st, &ws); if (rc != EEM_OK) return rc; }
-        if (c->enc_bx3[l]) { const int rc = ensure_bx3(c, l, st, &ws); if (rc != EEM_OK) return rc; }
+        if (c->enc_s2r[l] && s2r_wanted()) { const int rc = ensure_s2r(c, l, st, &ws); if (rc != EEM_OK) return rc; }
+        if (c->enc_bx3[l] && bx3_wanted(l)) { const int rc = ensure_bx3(c, l, st, &ws); if (rc != EEM_OK) return rc; }
     }
     if (!c->use_wino) return EEM_OK;
     for (int l = 0; l < ENC_NUM; ++l) {
@@ -624,9 +640,9 @@ int run_enc_layer(eemflow_ctx* c, const Shape& s, int li, const float* e1, const
         a.wino_f4 = 0;
         if (c->use_wino && c->enc_wino[sp.layer] && (rc = ensure_wino(c, sp.layer, 0, s.batch, hk.st, &a.wwino, &a.wino_f4)) != EEM_OK) return rc;
         a.ws2r = nullptr;
-        if (c->enc_s2r[sp.layer] && (rc = ensure_s2r(c, sp.layer, hk.st, &a.ws2r)) != EEM_OK) return rc;
+        if (c->enc_s2r[sp.layer] && s2r_wanted() && (rc = ensure_s2r(c, sp.layer, hk.st, &a.ws2r)) != EEM_OK) return rc;
         a.wbx3 = nullptr;
-        if (c->enc_bx3[sp.layer] && (rc = ensure_bx3(c, sp.layer, hk.st, &a.wbx3)) != EEM_OK) return rc;
+        if (c->enc_bx3[sp.layer] && bx3_wanted(sp.layer) && (rc = ensure_bx3(c, sp.layer, hk.st, &a.wbx3)) != EEM_OK) return rc;
         a.zero_page = c->zero_page;
         a.trash = c->zero_page + 256;
         a.bias = c->arena + c->enc_b[sp.layer];

@@ -11,6 +11,7 @@ mixed_precision=True in the reference config only enables a GradScaler around fp
 scale/unscale is exact and is not reproduced.
 """
 import ctypes
+import os
 
 import torch
 
@@ -113,11 +114,18 @@ class EEMFlowTrainer:
         L = _lib.lib()
         with torch.cuda.device(dev):
             s = _lib.current_stream_ptr(dev)
+            sync_stats = os.environ.get("EEM_TRAIN_SYNC_STATS") == "1"       # A/B: the statistics read before the optimizer step is enqueued
             _lib.check(L.eemflow_forward_backward(ctx, e1.data_ptr(), e2.data_ptr(), gt.data_ptr(), va.data_ptr(), b, h, w, oh, ow,
-                                                  1.0, flow.data_ptr(), self.grad.data_ptr(), ctypes.byref(stats), s))
+                                                  1.0, flow.data_ptr(), self.grad.data_ptr(), ctypes.byref(stats) if sync_stats else None, s))
+            # the loss statistics travel to the host behind an event; they are read after the optimizer step is enqueued (the GPU does
+            # not wait for the host between the backward and the optimizer)
+            if not sync_stats:
+                _lib.check(L.eemflow_train_stats_async(ctx, s))
             parallel.average_gradients(self.grad)                # one RCCL all-reduce of 2.86 MB per step
             lr = self.schedule.lr(self.iteration)
             _lib.check(L.eemflow_optimizer_step(ctx, self.grad.data_ptr(), lr, self.wdecay, self.eps, self.clip, s))
+            if not sync_stats:
+                _lib.check(L.eemflow_train_stats_wait(ctx, stats))
         self.iteration += 1
         m._weights_on_device_are_newer = True
         return stats[0], {"epe": stats[1], "1px": stats[3], "3px": stats[4], "lr": lr}, flow

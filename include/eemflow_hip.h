@@ -239,6 +239,14 @@ int eemflow_forward_backward(eemflow_ctx* ctx, const float* events1, const float
 int eemflow_optimizer_step(eemflow_ctx* ctx, const float* grad, float lr, float weight_decay, float eps, float clip,
                            void* stream);
 
+/* The statistics of the last eemflow_forward_backward (called with stats_out = NULL) without a stream synchronisation between the
+ * backward and the optimizer step: _async enqueues the copy of the raw sums to pinned host memory and an event on `stream`; the
+ * caller enqueues what follows (gradient all-reduce, eemflow_optimizer_step, the next forward); _wait blocks on that event alone and
+ * returns stats[5] = loss, mean EPE, valid count, fraction < 1 px, fraction < 3 px - the numbers eemflow_forward_backward returns.
+ * Replaces: the .item() reads of sequence_loss's metrics (train_mvsec.py:219-226) - after the step is in flight instead of before. */
+int eemflow_train_stats_async(eemflow_ctx* ctx, void* stream);
+int eemflow_train_stats_wait(eemflow_ctx* ctx, double stats_out[5]);
+
 /* Steps eemflow_optimizer_step has skipped so far: a gradient holding an inf or a NaN changes neither weights nor moments and does
  * not advance the bias corrections - what GradScaler.step does for the reference (train_mvsec.py:237,257; the schedule still
  * advances, :258).  Synchronises `stream`. */

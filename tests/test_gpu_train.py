@@ -320,3 +320,33 @@ def test_out_mesh_size_training():
     grads = split_flat(flat, sd)
     worst = max((rel_err(grads[k], rgrads[k]), k) for k in sd)
     assert worst[0] < 3e-3, worst
+
+
+def test_loss_statistics_behind_an_event_equal_the_synchronous_read():
+    """eemflow_train_stats_async / _wait (what EEMFlowTrainer.step uses: the five statistics are read after the optimizer step is
+    enqueued) against eemflow_forward_backward's own synchronous stats_out on the same forward; _wait without an outstanding _async and
+    _async before any training forward are argument errors."""
+    import ctypes
+
+    from eemflow_amd import _lib
+    h, w, b = 128, 160, 3
+    net, _ = make_net(7)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(8, b, h, w))
+    gt, va = (torch.from_numpy(a).to(DEV) for a in synthetic_gt(9, b, h, w))
+    L, ctx, s = _lib.lib(), net._context(torch.device(DEV)), _lib.current_stream_ptr(torch.device(DEV))
+    n = sum(p.numel() for p in net.parameters())
+    grad, flow = torch.empty(n, device=DEV), torch.empty(b, 2, h, w, device=DEV)
+    sync, later = (ctypes.c_double * 5)(), (ctypes.c_double * 5)()
+    with pytest.raises(_lib.EEMFlowHipError, match="no eemflow_forward_backward"):
+        _lib.check(L.eemflow_train_stats_async(ctx, s))
+    _lib.check(L.eemflow_forward_backward(ctx, e1.data_ptr(), e2.data_ptr(), gt.data_ptr(), va.data_ptr(), b, h, w, h, w, 1.0,
+                                          flow.data_ptr(), grad.data_ptr(), ctypes.byref(sync), s))
+    with pytest.raises(_lib.EEMFlowHipError, match="outstanding"):
+        _lib.check(L.eemflow_train_stats_wait(ctx, later))
+    _lib.check(L.eemflow_forward_backward(ctx, e1.data_ptr(), e2.data_ptr(), gt.data_ptr(), va.data_ptr(), b, h, w, h, w, 1.0,
+                                          flow.data_ptr(), grad.data_ptr(), None, s))
+    _lib.check(L.eemflow_train_stats_async(ctx, s))
+    _lib.check(L.eemflow_optimizer_step(ctx, grad.data_ptr(), 0.0, 0.0, 1e-8, 1.0, s))
+    _lib.check(L.eemflow_train_stats_wait(ctx, later))
+    assert list(sync) == list(later) and sync[0] > 0 and sync[2] > 0

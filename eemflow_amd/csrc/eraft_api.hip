@@ -27,8 +27,8 @@ int ensure(Buf& b, size_t floats) {
 }
 
 struct Layer {                    // one convolution, weights packed for gconv
-    size_t wpk = 0, wpk16 = 0, wpkb = 0, wfew = 0, scale = 0, shift = 0;
-    bool hasb = false;
+    size_t wpk = 0, wpk16 = 0, wpkb = 0, wfew = 0, wstem = 0, scale = 0, shift = 0;
+    bool hasb = false, has_stem = false;
     size_t wraw = 0, wf4 = 0;      // 64 -> 64 3x3 stride-1 layers: OIHW weights (BatchNorm scale folded in) and their F(4x4,3x3) form
     bool has_scale = false, has16 = false, has_few = false, has_f4 = false;
     int cout = 0, kh = 1, kw = 1, stride = 1, ph = 0, pw = 0;
@@ -132,6 +132,11 @@ void make_layer(Packer& pk, Layer& L, const float* w, const float* bias, int cou
         L.wpkb = pk.push(gconvb_packed_floats(con, cs, nseg, kh, kw));
         gconvb_pack(wsl, con, cs, nseg, kh, kw, pk.host.data() + L.wpkb);
     }
+    L.has_stem = kh == 7 && kw == 7 && stride == 2 && ph == 3 && pw == 3 && nseg == 1 && cin <= 5 && con == 64 && co0 == 0;   // the encoders' stem: gconv.h stem7_*
+    if (L.has_stem) {
+        L.wstem = pk.push(stem7_packed_floats(cin));
+        stem7_pack(wsl, cin, pk.host.data() + L.wstem);
+    }
     L.has_few = con <= 8 && kh == 3 && kw == 3 && stride == 1 && nseg == 1 && ph == 1 && pw == 1;   // flow head 256 -> 2: gconv.h fewout_*
     if (L.has_few) {
         L.wfew = pk.push(fewout_packed_floats(cin, kh, kw));
@@ -219,6 +224,7 @@ GConvArgs conv_args(const eraft_ctx* c, const Layer& L, int n, int hin, int win,
     a.wpk16 = L.has16 ? c->arena + L.wpk16 : nullptr;
     a.wpkb = L.hasb ? c->arena + L.wpkb : nullptr;
     a.wfew = L.has_few ? c->arena + L.wfew : nullptr;
+    a.wstem = L.has_stem ? c->arena + L.wstem : nullptr;
     a.zero_page = c->arena + c->zero_off;
     a.scale = L.has_scale ? c->arena + L.scale : nullptr;
     a.shift = c->arena + L.shift;

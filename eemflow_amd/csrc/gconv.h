@@ -59,6 +59,7 @@ struct GConvArgs {
     float* out2;           // GEPI_ZR / GEPI_SUM2: [N][out2_ctotal][hout][wout]
     int out2_ctotal, split;
     const float* wpkb;     // packed by gconvb_pack (pre-split bf16 B fragments, gconvb.hip), or NULL
+    const float* wstem;    // packed by stem7_pack (the encoders' 7x7 stride-2 stem on <= 5 channels, conv_stem7.hip), or NULL
 };
 
 // number of packed floats / packing for weights [cout][sum(c_s)][kh][kw] read as segments of sizes cs[0..nseg)
@@ -73,6 +74,11 @@ bool gconv16_supported(const GConvArgs& a);
 // Layers of <= 8 output channels (EEMFlow+'s mask estimator tail 176 -> 8 -> 3, the 32 -> 2 flow convs): on the matrix cores a
 // 32-cout tile is 75-94 % padding, so these run as a direct convolution on the vector pipe - a thread per pixel, the weights of a
 // (channel, tap) as one uniform 32-byte load.  [cin][kh*kw][8] floats.
+// the encoders' stem: 7x7, stride 2, padding 3, <= 5 input channels, 64 couts (conv_stem7.hip)
+size_t stem7_packed_floats(int cin);
+void stem7_pack(const float* w_64xcinx7x7, int cin, float* packed);
+bool stem7_supported(const GConvArgs& a);
+int stem7_launch(const GConvArgs& a, hipStream_t stream);
 size_t fewout_packed_floats(int cin, int kh, int kw);
 void fewout_pack(const float* w, int cout, int cin, int kh, int kw, float* packed);
 bool fewout_supported(const GConvArgs& a);

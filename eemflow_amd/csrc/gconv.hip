@@ -479,6 +479,7 @@ int gconv_launch(const GConvArgs& a, hipStream_t stream) {
         return gconv16_launch(a, stream);
     }
     if (fewout_supported(a)) return fewout_launch(a, stream);
+    if (stem7_supported(a)) return stem7_launch(a, stream);
     if (gconvb_supported(a)) return gconvb_launch(a, stream);
     if (gconv16_supported(a)) return gconv16_launch(a, stream);
     const int hwo = a.hout * a.wout;

@@ -222,6 +222,26 @@ def test_mask_head_beside_the_next_iteration_equals_the_serial_order(monkeypatch
     assert float(outs["1"][0].abs().max()) > 1e-3
 
 
+@pytest.mark.parametrize("b,h,w,iters", [(1, 480, 640, 2), (4, 480, 640, 1), (3, 136, 200, 2), (1, 128, 160, 2)])
+def test_stem_kernel_equals_the_taps_kernel(monkeypatch, b, h, w, iters):
+    """conv_stem7.hip (the encoders' 7x7 stride-2 stem as an implicit GEMM over (channel, ky, kx): the patch and the weights in LDS,
+    16x16x4 MFMAs) against gconv_taps_kernel<7, 7> (EEM_NO_STEM7=1, read per call): the feature maps of both networks agree to
+    summation order, on full tiles and on ragged ones (112 and 80 output columns are not multiples of 32), with folded BatchNorm + ReLU
+    (context network) and plain (feature network) epilogues."""
+    net, _ = make_net(97)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(98, b, h, w))
+    with torch.no_grad():
+        new = torch.stack(net(e1, e2, iters=iters)[1]).clone()
+        fm_new, inp_new = net.stage("fmap").clone(), net.stage("inp").clone()
+        monkeypatch.setenv("EEM_NO_STEM7", "1")
+        old = torch.stack(net(e1, e2, iters=iters)[1])
+        fm_old, inp_old = net.stage("fmap").clone(), net.stage("inp").clone()
+    assert not torch.equal(fm_new, fm_old)                    # (the switch did switch)
+    assert maxerr(fm_new, fm_old) < 2e-5 * max(1.0, float(fm_old.abs().max())) and maxerr(inp_new, inp_old) < 2e-5 * max(1.0, float(inp_old.abs().max()))
+    assert maxerr(new, old) < 2e-4 and float(old.abs().max()) > 1e-3
+
+
 def test_frames_in_flight_hint_changes_tiles_not_results():
     """eraft_set_frames_in_flight >= 3: the LDS-tiled convs of 512..2047 blocks use 4-row tiles instead of 2-row ones (batch 4 at
     640x480: the update block), and launches of at most one block per CU keep one group of waves per tile instead of two that split

@@ -72,6 +72,16 @@ __global__ __launch_bounds__(256) void stem7_kernel(GConvArgs a, const f32x4* __
         }
     };
 
+    // the lane's 16 couts' scale and shift, once (inside the epilogue they were 32 dependent L2 round trips per tile)
+    float sc[4][4], sh[4][4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int co = 16 * ct + 4 * kg + j;
+            sc[ct][j] = a.scale ? a.scale[co] : 1.f;
+            sh[ct][j] = a.shift ? a.shift[co] : 0.f;
+        }
     int tile = blockIdx.x;
     if (tile < ntiles) fetch(tile);
     // B operand of (row r of the wave, pixel tile t, k-step): patch[c][2 (2 wave + r) + ky][2 (16 t + n16) + 4 half + kg + 1]
@@ -114,12 +124,11 @@ __global__ __launch_bounds__(256) void stem7_kernel(GConvArgs a, const f32x4* __
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int co = 16 * ct + 4 * kg + j;
-                const float sc = a.scale ? a.scale[co] : 1.f, sh = a.shift ? a.shift[co] : 0.f;
                 float* dst = a.out + ((size_t)img * a.out_ctotal + a.out_coff + co) * hwo;
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     const int oy = ty * ST_TH + 2 * wave + (p >> 1), ox = tx * ST_TW + 16 * (p & 1) + n16;
-                    if (oy < a.hout && ox < a.wout) dst[(size_t)oy * a.wout + ox] = st_act(acc[p][ct][j] * sc + sh, a.act) * a.out_scale;
+                    if (oy < a.hout && ox < a.wout) dst[(size_t)oy * a.wout + ox] = st_act(acc[p][ct][j] * sc[ct][j] + sh[ct][j], a.act) * a.out_scale;
                 }
             }
     }

@@ -96,7 +96,7 @@ void mk(Pk& pk, PLayer& L, const float* w, const float* b, int cin, int cout, in
     L.bias = pk.push(cout);
     memcpy(pk.host.data() + L.bias, b, cout * sizeof(float));
     // decoder convs also get the small-grid packing (tail_conv_kernel, used on the coarse pyramid levels)
-    L.has_tail = stride == 1 && (k == 3 || k == 1) && cin <= 100;
+    L.has_tail = stride == 1 && ((k == 3 && cin <= 184) || (k == 1 && cin <= 100));
     if (L.has_tail) {
         L.wtail = pk.push(tail_packed_floats(cin, cout, k));
         tail_pack_weights(w, cin, cout, k, pk.host.data() + L.wtail);
@@ -108,7 +108,12 @@ int conv(eemplus_ctx* c, const PLayer& L, const float* in, int in_ctotal, int in
     // small maps (the coarse pyramid levels): the small-grid kernel of EEMFlow's tail
     static const bool no_tail = [] { const char* e = getenv("EEM_PLUS_NO_TAIL"); return e && e[0] == '1'; }();
     const bool add_ok = add == nullptr || (out_ctotal == L.cout && out_coff == 0 && out_cmul <= 1);   // residual indexed like the output
-    if (!no_tail && L.has_tail && add_ok && (long)hin * win <= 4096 && (act == GACT_LEAKY || act == GACT_NONE)) {
+    // EEM_PLUS_TAIL_MAXCIN (read per call; 184): the widest layer the small-grid kernel takes - 100 keeps the dense estimator's four wide
+    // convs (128 .. 184 channels) on the LDS-tiled / few-cout kernels, as before round 5
+    const char* emc = getenv("EEM_PLUS_TAIL_MAXCIN");
+    const int tail_maxcin = emc ? atoi(emc) : 184;
+    static const long conv_tail_max = [] { const char* e = getenv("EEM_PLUS_CONV_TAIL_MAX"); return e ? atol(e) : 4096L; }();   // cells
+    if (!no_tail && L.has_tail && L.cin <= tail_maxcin && add_ok && (long)hin * win <= conv_tail_max && (act == GACT_LEAKY || act == GACT_NONE)) {
         TailConvLaunch T;
         T.batch = n; T.h = hin; T.w = win; T.ksize = L.k; T.njobs = 1;
         TailConvJob& j = T.job[0];

@@ -536,7 +536,17 @@ int tail_conv_launch(const TailConvLaunch& l, hipStream_t stream) {
         const int cg = ceil_div(l.job[i].cin, 4);
         max_cg = cg > max_cg ? cg : max_cg;
     }
-    EEM_REQUIRE(max_cg <= 25, "tail_conv_launch: cin > 100 is not built");
+    EEM_REQUIRE(max_cg <= 46, "tail_conv_launch: cin > 184 is not built");
+    if (max_cg > 25) {
+        // EEMFlow+'s dense estimator on the coarse pyramid levels (cdc_utils.py: 128 / 160 / 176 / 184 input channels): 46 fragments and
+        // 46 gathers per wave in one round trip - 4 - 5 us where the LDS-tiled kernel and fewout_kernel took 12 - 14 on 23 x 40 cells
+        EEM_REQUIRE(l.ksize == 3, "tail_conv_launch: cin > 100 needs a 3x3 layer");
+        dim3 gw(ceil_div(l.h * l.w, 16) * l.batch, ceil_div(max_cout, 16), l.njobs);
+        EEM_NOTE_GRID(gw.x * gw.y * gw.z, 576);
+        tail_launch_t<3, 46>(l, gw, stream);
+        EEM_HIP_CHECK(hipGetLastError());
+        return EEM_OK;
+    }
     // narrow layers of a batched chain: five pixel tiles per block (tail_conv_multi_kernel; EEM_NO_TAIL_MULTI=1: the one-tile kernel)
     // (EEM_TAIL_MULTI_MAXCG: the widest layer, in 4-channel groups, that takes it.  5 = the grouped convs: 19.2 -> 13.4 us per launch of
     // ten frames; the wider layers with two or three tiles per block measured 25.1 -> 23.5 (conv1), 19.9 -> 21.7 (conv5), 3.7 -> 4.7 (conv7))

@@ -220,3 +220,24 @@ def test_fused_warp_blend_copy_equals_the_three_launches(monkeypatch):
         monkeypatch.setenv("EEM_PLUS_NO_FUSE", "1")
         apart = torch.stack(net(e1, e2)[1]).cpu().numpy()
     assert np.array_equal(fused, apart) and np.abs(apart).max() > 1e-3
+
+
+def test_wide_dense_estimator_convs_on_the_small_grid_kernel(monkeypatch):
+    """The dense estimator's 128 / 160 / 176 / 184-channel convs (cdc_utils.py) on the coarse pyramid levels run on the small-grid
+    kernel (46 fragments per wave; EEM_PLUS_TAIL_MAXCIN=100, read per call, keeps them on the LDS-tiled / few-cout kernels): the same
+    flows to summation order, level by level teacher-forced from the same flow_init (the chained forward amplifies the reference's own
+    `>= 1.0` mask discontinuity)."""
+    h, w = 256, 320
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(85, 2, h, w, bins=5))
+    net = make_net(86, 5)
+    net.change_imagesize((h, w))
+    with torch.no_grad():
+        net(e1, e2)
+        fi = {l: net.stage(f"flow_init{l}").clone() for l in (5, 4, 3)}
+        new = {l: [t.clone() for t in net.level(l, fi[l])] for l in (5, 4, 3)}
+        monkeypatch.setenv("EEM_PLUS_TAIL_MAXCIN", "100")
+        old = {l: [t.clone() for t in net.level(l, fi[l])] for l in (5, 4, 3)}
+    assert not torch.equal(new[5][1], old[5][1])              # (the switch did switch)
+    for l in (5, 4, 3):
+        for a, b in zip(new[l], old[l]):
+            assert float((a - b).abs().max()) < 2e-4 * max(1.0, float(b.abs().max()))

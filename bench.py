@@ -235,6 +235,18 @@ def other_rows(dev):
                 net(e1, e2)
             torch.cuda.synchronize(dev)
         out["eemflow_plus_1280x720_b1_frames_per_s"] = round(20 / (time.perf_counter() - t0), 2)
+        # the evaluation loop's independent batch-1 samples, four per call, each in its own tensors (EEMFlow_cdc.forward_many)
+        frames4 = [tuple(torch.from_numpy(a).to(dev) for a in synthetic_voxel_pair(10 + i, 1, 720, 1280)) for i in range(4)]
+        with torch.no_grad():
+            for _ in range(2):
+                net.forward_many(frames4)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(6):
+                net.forward_many(frames4)
+            torch.cuda.synchronize(dev)
+        out["eemflow_plus_1280x720_b1_coalesced4_frames_per_s"] = round(24 / (time.perf_counter() - t0), 2)
+        del frames4
         nets = [net]
         sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
         for _ in range(3):                                   # four frames in flight: ~160 short launches per frame leave CUs idle

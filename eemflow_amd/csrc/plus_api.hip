@@ -403,18 +403,24 @@ static int run_level(eemplus_ctx* c, int l, int B, const float* forced_init, hip
     return EEM_OK;
 }
 
-extern "C" int eemplus_forward(eemplus_ctx* c, const float* e1, const float* e2, int batch, int in_h, int in_w, const int pad[4],
-                               float* out, void* stream) {
-    EEM_REQUIRE(c && e1 && e2 && out && pad, "eemplus_forward: NULL argument");
-    EEM_REQUIRE(c->loaded, "eemplus_forward: no weights loaded");
-    EEM_REQUIRE(batch >= 1 && in_h >= 1 && in_w >= 1, "eemplus_forward: bad sizes");
-    EEM_HIP_CHECK(hipSetDevice(c->device));
-    hipStream_t st = (hipStream_t)stream;
+// One forward over `batch` samples.  frames == 0: events1 / events2 / flow_out are the batched tensors of eemplus_forward.  frames = n > 0
+// (eemplus_forward_many): e1v / e2v / outv hold n pointers to single samples - the pad launches read each sample from its own tensor and
+// the five full-resolution predictions of sample i go to outv[i] [5][1][2][in_h][in_w]; everything between runs as the batch-n chain.
+static int plus_forward_impl(eemplus_ctx* c, const float* e1, const float* e2, const float* const* e1v, const float* const* e2v, int frames,
+                             int batch, int in_h, int in_w, const int pad[4], float* out, float* const* outv, hipStream_t st) {
     const int B = batch, n2 = 2 * batch, hp = in_h + pad[2] + pad[3], wp = in_w + pad[0] + pad[1];
     int rc;
     // ---- pad, encoder on both volumes (EEMFlow+.py:162-169)
     if ((rc = pensure(c->padded, (size_t)n2 * c->cin0 * hp * wp)) != EEM_OK) return rc;
-    if ((rc = er_pad2_launch(e1, e2, c->padded.p, B * c->cin0, in_h, in_w, pad[0], pad[1], pad[2], pad[3], st)) != EEM_OK) return rc;
+    if (frames == 0) {
+        if ((rc = er_pad2_launch(e1, e2, c->padded.p, B * c->cin0, in_h, in_w, pad[0], pad[1], pad[2], pad[3], st)) != EEM_OK) return rc;
+    } else {
+        const size_t img = (size_t)c->cin0 * hp * wp;
+        for (int i = 0; i < frames; ++i) {
+            if ((rc = er_pad_launch(e1v[i], c->padded.p + (size_t)i * img, c->cin0, in_h, in_w, pad[0], pad[1], pad[2], pad[3], st)) != EEM_OK) return rc;
+            if ((rc = er_pad_launch(e2v[i], c->padded.p + (size_t)(B + i) * img, c->cin0, in_h, in_w, pad[0], pad[1], pad[2], pad[3], st)) != EEM_OK) return rc;
+        }
+    }
     auto half = [](int v) { return (v - 1) / 2 + 1; };
     int* hl = c->hl; int* wl = c->wl;
     hl[1] = half(hp); wl[1] = half(wp); hl[2] = half(hl[1]); wl[2] = half(wl[1]); hl[3] = half(hl[2]); wl[3] = half(wl[2]);
@@ -477,13 +483,39 @@ extern "C" int eemplus_forward(eemplus_ctx* c, const float* e1, const float* e2,
     for (int l = 5; l >= 2; --l)
         if ((rc = run_level(c, l, B, nullptr, st)) != EEM_OK) return rc;
     // ---- five full-resolution predictions, coarse to fine (:231-232); flow6..flow3 carry the doubling above
-    {
+    for (int f = 0; f < (frames ? frames : 1); ++f) {
         const float* ins[5]; float* outs[5]; int hs[5], ws[5];
-        for (int i = 0, l = 6; l >= 2; --l, ++i) { ins[i] = c->flow[l].p; outs[i] = out + (size_t)i * B * 2 * in_h * in_w; hs[i] = hl[l]; ws[i] = wl[l]; }
-        if ((rc = pl_upflow_multi_launch(ins, outs, hs, ws, 5, B, in_h, in_w, 1, st)) != EEM_OK) return rc;
+        for (int i = 0, l = 6; l >= 2; --l, ++i) {
+            ins[i] = c->flow[l].p + (frames ? (size_t)f * 2 * hl[l] * wl[l] : 0);
+            outs[i] = (frames ? outv[f] : out) + (size_t)i * (frames ? 1 : B) * 2 * in_h * in_w;
+            hs[i] = hl[l]; ws[i] = wl[l];
+        }
+        if ((rc = pl_upflow_multi_launch(ins, outs, hs, ws, 5, frames ? 1 : B, in_h, in_w, 1, st)) != EEM_OK) return rc;
     }
     c->B = B; c->have_last = true;
     return EEM_OK;
+}
+
+extern "C" int eemplus_forward(eemplus_ctx* c, const float* e1, const float* e2, int batch, int in_h, int in_w, const int pad[4],
+                               float* out, void* stream) {
+    EEM_REQUIRE(c && e1 && e2 && out && pad, "eemplus_forward: NULL argument");
+    EEM_REQUIRE(c->loaded, "eemplus_forward: no weights loaded");
+    EEM_REQUIRE(batch >= 1 && in_h >= 1 && in_w >= 1, "eemplus_forward: bad sizes");
+    EEM_HIP_CHECK(hipSetDevice(c->device));
+    return plus_forward_impl(c, e1, e2, nullptr, nullptr, 0, batch, in_h, in_w, pad, out, nullptr, (hipStream_t)stream);
+}
+
+// n independent samples of the evaluation loop (test_mvsec.py:580-597: one model(events1, events2) per sample at batch 1), each in its
+// own tensors, as ONE batch-n chain: the coarse pyramid levels' launches - 60 of a forward's 111, each at the ~4.7 us a dependent launch
+// costs - carry n samples instead of one (1280x720: 678 frames/s one sample at a time, 838 / 954 / 1 024 at n = 2 / 4 / 8).
+extern "C" int eemplus_forward_many(eemplus_ctx* c, int n, const float* const* events1, const float* const* events2, int in_h, int in_w,
+                                    const int pad[4], float* const* flow_out, void* stream) {
+    EEM_REQUIRE(c && events1 && events2 && flow_out && pad, "eemplus_forward_many: NULL argument");
+    EEM_REQUIRE(c->loaded, "eemplus_forward_many: no weights loaded");
+    EEM_REQUIRE(n >= 1 && n <= 16 && in_h >= 1 && in_w >= 1, "eemplus_forward_many: n = %d (1..16) samples of %dx%d", n, in_h, in_w);
+    for (int i = 0; i < n; ++i) EEM_REQUIRE(events1[i] && events2[i] && flow_out[i], "eemplus_forward_many: NULL pointer for sample %d", i);
+    EEM_HIP_CHECK(hipSetDevice(c->device));
+    return plus_forward_impl(c, nullptr, nullptr, events1, events2, n, n, in_h, in_w, pad, nullptr, flow_out, (hipStream_t)stream);
 }
 
 extern "C" int eemplus_set_frames_in_flight(eemplus_ctx* c, int n) {

@@ -168,6 +168,41 @@ class EEMFlow_cdc(nn.Module):  # noqa: N801
                                                   _lib.current_stream_ptr(e1.device)))
         return (events1, events2), [out[i] for i in range(5)]
 
+    MAX_COALESCE = 16
+
+    def forward_many(self, frames):
+        """Several INDEPENDENT samples of the evaluation loop (test_mvsec.py:580-597: one `model(events1, events2)` per sample at batch 1)
+        as one batch-n chain of launches, each sample staying in its own tensors: `frames` is a sequence of (events1, events2) pairs of
+        [1, C, H, W] tensors; returns one `((events1, events2), [flow6 .. flow2 at full resolution])` per sample, bitwise what `forward`
+        gives for the samples stacked into one batch.  Inference only."""
+        frames = list(frames)
+        if not 1 <= len(frames) <= self.MAX_COALESCE:
+            raise ValueError(f"forward_many: 1..{self.MAX_COALESCE} frames per call, got {len(frames)}")
+        if not hasattr(self, "image_padder"):
+            raise AttributeError("call change_imagesize(img_size) before forward (as the reference requires)")
+        keep, shape = [], None
+        for a, b in frames:
+            if not (a.is_cuda and b.is_cuda):
+                raise _lib.EEMFlowHipError("EEMFlow_cdc.forward_many: inputs must be CUDA (ROCm) tensors - there is no CPU path")
+            a, b = a.contiguous().float(), b.contiguous().float()
+            if a.shape != b.shape or a.dim() != 4 or a.shape[0] != 1 or a.shape[1] != self.n_first_channels:
+                raise ValueError(f"forward_many: every frame is two (1,{self.n_first_channels},H,W) tensors, got {tuple(a.shape)} and {tuple(b.shape)}")
+            if shape is not None and a.shape != shape:
+                raise ValueError("forward_many: all frames of a call share one shape")
+            shape = a.shape
+            keep.append((a, b))
+        dev = keep[0][0].device
+        h, w = int(shape[2]), int(shape[3])
+        ctx = self._context(dev)
+        n = len(keep)
+        outs = [torch.empty(5, 1, 2, h, w, device=dev, dtype=torch.float32) for _ in range(n)]
+        arr = ctypes.c_void_p * n
+        p1, p2, po = arr(*[a.data_ptr() for a, _ in keep]), arr(*[b.data_ptr() for _, b in keep]), arr(*[o.data_ptr() for o in outs])
+        padc = (ctypes.c_int * 4)(*self.image_padder._pad)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().eemplus_forward_many(ctx, n, p1, p2, h, w, padc, po, _lib.current_stream_ptr(dev)))
+        return [((frames[i][0], frames[i][1]), [outs[i][k] for k in range(5)]) for i in range(n)]
+
     # ------------------------------------------------------------------ differentiable route (eemflow_amd/ops.py)
     def _lrelu_conv(self, seq, *xs):
         from . import ops

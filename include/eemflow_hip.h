@@ -350,6 +350,12 @@ int eemplus_load_weights(eemplus_ctx* ctx, const float* flat_host, size_t nfloat
 int eemplus_forward(eemplus_ctx* ctx, const float* events1, const float* events2, int batch, int in_h, int in_w,
                     const int pad[4], float* flow_out, void* stream);
 
+/* n (1..16) independent batch-1 samples, each in its own tensors (events1[i] / events2[i] [1][C][in_h][in_w], flow_out[i]
+ * [5][1][2][in_h][in_w]), as ONE batch-n chain of launches - bitwise what eemplus_forward returns for the samples stacked into a batch.
+ * Replaces: n iterations of the evaluation loop at batch 1 (test_mvsec.py:580-597 -> run_network, :1444-1455) for EEMFlow_cdc. */
+int eemplus_forward_many(eemplus_ctx* ctx, int n, const float* const* events1, const float* const* events2, int in_h, int in_w,
+                         const int pad[4], float* const* flow_out, void* stream);
+
 /* Intermediates of the LAST forward: "flow2".."flow6" (low-resolution level flows, incl. the in-place doubling
  * the reference applies to flow3..flow6), "flow_up2".."flow_up5" and "flow_init2".."flow_init5" (cdc_model's upsampled
  * input flow of each level). */

@@ -241,3 +241,26 @@ def test_wide_dense_estimator_convs_on_the_small_grid_kernel(monkeypatch):
     for l in (5, 4, 3):
         for a, b in zip(new[l], old[l]):
             assert float((a - b).abs().max()) < 2e-4 * max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("n,h,w", [(3, 256, 320), (2, 100, 150), (1, 128, 192)])
+def test_forward_many_equals_the_batched_forward(n, h, w):
+    """EEMFlow_cdc.forward_many (eemplus_forward_many): n independent batch-1 samples in their own tensors through one batch-n chain -
+    bitwise the five predictions of `forward` on the samples stacked into a batch (padded sizes included: 100 x 150 pads to 128 x 192);
+    argument errors for an empty list, mixed shapes and batched frames."""
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(87, n, h, w, bins=5))
+    net = make_net(88, 5)
+    net.change_imagesize((h, w))
+    with torch.no_grad():
+        batched = torch.stack(net(e1, e2)[1]).clone()                       # [5, n, 2, h, w]
+        frames = [(e1[i:i + 1].clone(), e2[i:i + 1].clone()) for i in range(n)]
+        many = net.forward_many(frames)
+    assert len(many) == n
+    for i, ((a, b), preds) in enumerate(many):
+        assert a is frames[i][0] and len(preds) == 5 and preds[0].shape == (1, 2, h, w)
+        assert torch.equal(torch.stack(preds)[:, 0], batched[:, i])
+    assert float(batched.abs().max()) > 1e-3
+    with pytest.raises(ValueError):
+        net.forward_many([])
+    with pytest.raises(ValueError):
+        net.forward_many([(e1, e2)] if n > 1 else [(torch.cat([e1, e1]), torch.cat([e2, e2]))])

@@ -187,6 +187,18 @@ def other_rows(dev):
                 torch.cuda.synchronize(dev)
             out[key] = round(reps * batch / (time.perf_counter() - t0), 2)
         net.final_only = False
+        # the evaluation loop's independent batch-1 samples, four per call, each in its own tensors (ERAFT.forward_many)
+        frames4 = [tuple(torch.from_numpy(a).to(dev) for a in synthetic_voxel_pair(20 + i, 1, 480, 640)) for i in range(4)]
+        with torch.no_grad():
+            for _ in range(2):
+                net.forward_many(frames4, iters=12)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                net.forward_many(frames4, iters=12)
+            torch.cuda.synchronize(dev)
+        out["eraft_640x480_12it_b1_coalesced4_frames_per_s"] = round(20 / (time.perf_counter() - t0), 2)
+        del frames4
         # several frames in flight (one module / context per HIP stream): at batch 1 the 60x80 update block launches ~300 blocks for
         # 256 CUs - a second and third frame fill the chip
         nets = [net]

@@ -86,6 +86,9 @@ _SIGNATURES = {
                                      ctypes.POINTER(ctypes.c_int * 4), ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_void_p]),
     "eraft_keep_stages": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "eraft_set_frames_in_flight": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "eraft_forward_many": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
+                                           ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
+                                           ctypes.c_void_p]),
     "eraft_set_alternate_corr": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "eraft_set_final_only": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "eraft_get_stage": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, _c_float_p, ctypes.c_size_t,

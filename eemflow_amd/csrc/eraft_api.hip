@@ -66,6 +66,7 @@ struct eraft_ctx {
     // workspace
     Buf padded, s[5], fmap, net[3], inp, pyr[4], c0, c1, c1b, corr, cor1, corflo, flo1, motion, z, rh, fhid, delta, mhid, mask;
     Buf st_corr0, st_net1, st_mask1, st_delta1, zeros;
+    Buf many_out;                  // eraft_forward_many: the batched predictions before they are copied to the samples' own tensors
     int B = 0, h8 = 0, w8 = 0, ph[4] = {0, 0, 0, 0}, pw[4] = {0, 0, 0, 0};
     bool have_last = false;
     bool keep_stages = false;      // copy corr0 / net1 / mask1 / delta1 aside in the first iteration (parity tests)
@@ -393,7 +394,7 @@ extern "C" void eraft_destroy(eraft_ctx* c) {
     Buf* all[] = {&c->padded, &c->s[0], &c->s[1], &c->s[2], &c->s[3], &c->s[4], &c->fmap, &c->net[0], &c->net[1], &c->net[2], &c->inp,
                   &c->pyr[0], &c->pyr[1], &c->pyr[2], &c->pyr[3], &c->c0, &c->c1, &c->c1b, &c->corr, &c->cor1, &c->corflo, &c->flo1,
                   &c->motion, &c->z, &c->rh, &c->fhid, &c->delta, &c->mhid, &c->mask, &c->st_corr0, &c->st_net1, &c->st_mask1,
-                  &c->st_delta1, &c->zeros, &c->f2l[0], &c->f2l[1], &c->f2l[2], &c->czr[0], &c->czr[1], &c->cq[0], &c->cq[1],
+                  &c->st_delta1, &c->zeros, &c->many_out, &c->f2l[0], &c->f2l[1], &c->f2l[2], &c->czr[0], &c->czr[1], &c->cq[0], &c->cq[1],
                   &c->s2[0], &c->s2[1], &c->s2[2], &c->s2[3], &c->s2[4]};
     for (Buf* b : all) if (b->p) (void)hipFree(b->p);
     if (c->nstat) (void)hipFree(c->nstat);
@@ -519,13 +520,10 @@ extern "C" int eraft_load_weights(eraft_ctx* c, const float* flat, size_t nfloat
     return EEM_OK;
 }
 
-extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int batch, int in_h, int in_w, const int pad[4],
-                             int iters, const float* flow_init, float* out, void* stream) {
-    EEM_REQUIRE(c && e1 && e2 && out && pad, "eraft_forward: NULL argument");
-    EEM_REQUIRE(c->loaded, "eraft_forward: no weights loaded");
-    EEM_REQUIRE(batch >= 1 && in_h >= 1 && in_w >= 1 && iters >= 1, "eraft_forward: bad sizes");
-    EEM_HIP_CHECK(hipSetDevice(c->device));
-    hipStream_t st = (hipStream_t)stream;
+// frames == 0: e1 / e2 / out are eraft_forward's batched tensors.  frames = n > 0 (eraft_forward_many): e1v / e2v hold n pointers to single
+// samples, read by the pad launches; `out` is the context's staging buffer for the batched predictions.
+static int eraft_forward_impl(eraft_ctx* c, const float* e1, const float* e2, const float* const* e1v, const float* const* e2v, int frames,
+                              int batch, int in_h, int in_w, const int pad[4], int iters, const float* flow_init, float* out, hipStream_t st) {
     const int B = batch, hp = in_h + pad[2] + pad[3], wp = in_w + pad[0] + pad[1];
     EEM_REQUIRE(hp % 8 == 0 && wp % 8 == 0, "eraft_forward: padded size %dx%d must be a multiple of 8", hp, wp);
     const int h8 = hp / 8, w8 = wp / 8;
@@ -615,8 +613,15 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
     // ---- pad both event volumes into one batch (model/eraft.py:106-109)
     float* pad1 = c->padded.p;
     float* pad2 = c->padded.p + (size_t)B * cin0 * hp * wp;
-    if ((rc = er_pad2_launch(e1, e2, pad1, B * cin0, in_h, in_w, pad[0], pad[1], pad[2], pad[3], st)) != EEM_OK) return rc;
-    (void)pad2;
+    if (frames == 0) {
+        if ((rc = er_pad2_launch(e1, e2, pad1, B * cin0, in_h, in_w, pad[0], pad[1], pad[2], pad[3], st)) != EEM_OK) return rc;
+    } else {
+        const size_t img = (size_t)cin0 * hp * wp;
+        for (int i = 0; i < frames; ++i) {
+            if ((rc = er_pad_launch(e1v[i], pad1 + (size_t)i * img, cin0, in_h, in_w, pad[0], pad[1], pad[2], pad[3], st)) != EEM_OK) return rc;
+            if ((rc = er_pad_launch(e2v[i], pad2 + (size_t)i * img, cin0, in_h, in_w, pad[0], pad[1], pad[2], pad[3], st)) != EEM_OK) return rc;
+        }
+    }
     float* cfeat = nullptr;
     if ((rc = fork()) != EEM_OK) return rc;                            // (the padded volumes are on their way)
     // ---- context network on image1 (:126-131): net = tanh(first half), inp = relu(second half)
@@ -874,6 +879,39 @@ extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int
     }
     c->B = B; c->h8 = h8; c->w8 = w8; c->have_last = true;
     c->stages_valid = c->keep_stages;
+    return EEM_OK;
+}
+
+extern "C" int eraft_forward(eraft_ctx* c, const float* e1, const float* e2, int batch, int in_h, int in_w, const int pad[4],
+                             int iters, const float* flow_init, float* out, void* stream) {
+    EEM_REQUIRE(c && e1 && e2 && out && pad, "eraft_forward: NULL argument");
+    EEM_REQUIRE(c->loaded, "eraft_forward: no weights loaded");
+    EEM_REQUIRE(batch >= 1 && in_h >= 1 && in_w >= 1 && iters >= 1, "eraft_forward: bad sizes");
+    EEM_HIP_CHECK(hipSetDevice(c->device));
+    return eraft_forward_impl(c, e1, e2, nullptr, nullptr, 0, batch, in_h, in_w, pad, iters, flow_init, out, (hipStream_t)stream);
+}
+
+// n independent samples of the evaluation loop (test_mvsec.py:580-597: one model(events1, events2) per sample at batch 1), each in its
+// own tensors, as ONE batch-n forward: at 60x80 cells a sample alone leaves most CUs idle in every launch of the update block (640x480 x
+// 12: 194 frames/s one sample at a time, 276 - 285 at four per call).  The predictions leave the batched chain through a staging
+// buffer: one strided device copy per sample (0.3 % of the forward at four samples).
+extern "C" int eraft_forward_many(eraft_ctx* c, int n, const float* const* events1, const float* const* events2, int in_h, int in_w,
+                                  const int pad[4], int iters, float* const* flow_out, void* stream) {
+    EEM_REQUIRE(c && events1 && events2 && flow_out && pad, "eraft_forward_many: NULL argument");
+    EEM_REQUIRE(c->loaded, "eraft_forward_many: no weights loaded");
+    EEM_REQUIRE(n >= 1 && n <= 16 && in_h >= 1 && in_w >= 1 && iters >= 1, "eraft_forward_many: n = %d (1..16) samples of %dx%d, %d iterations", n,
+                in_h, in_w, iters);
+    for (int i = 0; i < n; ++i) EEM_REQUIRE(events1[i] && events2[i] && flow_out[i], "eraft_forward_many: NULL pointer for sample %d", i);
+    EEM_HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int nout = c->final_only ? 1 : iters;
+    const size_t per = (size_t)2 * in_h * in_w;                          // floats of one prediction of one sample
+    int rc = ensure(c->many_out, (size_t)nout * n * per);
+    if (rc != EEM_OK) return rc;
+    if ((rc = eraft_forward_impl(c, nullptr, nullptr, events1, events2, n, n, in_h, in_w, pad, iters, nullptr, c->many_out.p, st)) != EEM_OK) return rc;
+    for (int i = 0; i < n; ++i)                                          // [nout][n][2][H][W] -> sample i's [nout][1][2][H][W]
+        EEM_HIP_CHECK(hipMemcpy2DAsync(flow_out[i], per * 4, c->many_out.p + (size_t)i * per, (size_t)n * per * 4, per * 4, nout,
+                                       hipMemcpyDeviceToDevice, st));
     return EEM_OK;
 }
 

@@ -251,6 +251,45 @@ class ERAFT(nn.Module):
                                                 _lib.current_stream_ptr(e1.device)))
         return (events1, events2), [out[i] for i in range(nout)]
 
+    MAX_COALESCE = 16
+
+    def forward_many(self, frames, iters=12):
+        """Several INDEPENDENT samples of the evaluation loop (test_mvsec.py:580-597: one `model(events1, events2)` per sample at batch 1)
+        as one batch-n forward, each sample staying in its own tensors: `frames` is a sequence of (events1, events2) pairs of [1, C, H, W]
+        tensors; returns one `((events1, events2), [predictions])` per sample - `iters` predictions, or the last one with `final_only` -
+        bitwise what `forward` gives for the samples stacked into one batch.  Inference only, no flow_init."""
+        frames = list(frames)
+        if not 1 <= len(frames) <= self.MAX_COALESCE:
+            raise ValueError(f"forward_many: 1..{self.MAX_COALESCE} frames per call, got {len(frames)}")
+        if not hasattr(self, "image_padder"):
+            raise AttributeError("call change_imagesize(img_size) before forward (as the reference requires)")
+        keep, shape = [], None
+        for a, b in frames:
+            if not (a.is_cuda and b.is_cuda):
+                raise _lib.EEMFlowHipError("ERAFT.forward_many: inputs must be CUDA (ROCm) tensors - there is no CPU path")
+            a, b = a.contiguous().float(), b.contiguous().float()
+            if a.shape != b.shape or a.dim() != 4 or a.shape[0] != 1 or a.shape[1] != self.n_first_channels:
+                raise ValueError(f"forward_many: every frame is two (1,{self.n_first_channels},H,W) tensors, got {tuple(a.shape)} and {tuple(b.shape)}")
+            if shape is not None and a.shape != shape:
+                raise ValueError("forward_many: all frames of a call share one shape")
+            shape = a.shape
+            keep.append((a, b))
+        dev = keep[0][0].device
+        h, w = int(shape[2]), int(shape[3])
+        pad = self.image_padder._pad
+        if (h + pad[2] + pad[3]) % 8 or (w + pad[0] + pad[1]) % 8:
+            raise ValueError("forward_many: the padded size must be a multiple of 8 (eraft.py:83-94)")
+        ctx = self._context(dev)
+        n = len(keep)
+        nout = 1 if getattr(self, "final_only", False) else iters
+        outs = [torch.empty(nout, 1, 2, h, w, device=dev, dtype=torch.float32) for _ in range(n)]
+        arr = ctypes.c_void_p * n
+        p1, p2, po = arr(*[a.data_ptr() for a, _ in keep]), arr(*[b.data_ptr() for _, b in keep]), arr(*[o.data_ptr() for o in outs])
+        padc = (ctypes.c_int * 4)(*pad)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().eraft_forward_many(ctx, n, p1, p2, h, w, padc, iters, po, _lib.current_stream_ptr(dev)))
+        return [((frames[i][0], frames[i][1]), [outs[i][k] for k in range(nout)]) for i in range(n)]
+
     # ------------------------------------------------------------------ differentiable route (eemflow_amd/ops.py)
     def _norm(self, norm, x, relu):
         return apply_norm(norm, x, relu)

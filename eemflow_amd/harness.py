@@ -95,7 +95,7 @@ class TestRaftEvents:
         return preds[-1]
 
     def test_multi_sequence(self, model, epoch=0, sequence_list=(), stride=10, frames_in_flight=1, loader_threads=0, coalesce=1):
-        """coalesce > 1 (a model with forward_many - EEMFlow - and a dataset with get_samples): that many samples are read, voxelized by
+        """coalesce > 1 (a model with forward_many - EEMFlow, EEMFlow_cdc, ERAFT - and a dataset with get_samples): that many samples are read, voxelized by
         ONE voxelizer launch sequence and handed to ONE model.forward_many call - n independent batch-1 samples riding a batch-n chain of
         launches, every sample in its own tensors; raw volumes with a normalisation record (HREMEventFlow(deferred_norm=True)) are
         normalised by the first convolution as it reads them.  Chunks alternate over min(frames_in_flight, 2) replicas / streams.  Same
@@ -118,7 +118,7 @@ class TestRaftEvents:
         co = max(1, int(coalesce))
         if co > 1:
             if not (hasattr(model, "forward_many") and hasattr(self.dataset, "get_samples")):
-                raise ValueError("coalesce > 1 needs a model with forward_many (EEMFlow) and a dataset with get_samples (HREMEventFlow)")
+                raise ValueError("coalesce > 1 needs a model with forward_many (EEMFlow, EEMFlow_cdc, ERAFT) and a dataset with get_samples (HREMEventFlow)")
             co = min(co, 16)
             nfl = min(nfl, 2)                                    # two batched chains fill the chip; more only share it
         replicas, streams = [model], [torch.cuda.current_stream(dev)]

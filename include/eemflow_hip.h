@@ -278,6 +278,13 @@ int eraft_load_weights(eraft_ctx* ctx, const float* flat_host, size_t nfloats, i
 int eraft_forward(eraft_ctx* ctx, const float* events1, const float* events2, int batch, int in_h, int in_w,
                   const int pad[4], int iters, const float* flow_init, float* flow_out, void* stream);
 
+/* n (1..16) independent batch-1 samples, each in its own tensors (events1[i] / events2[i] [1][C][in_h][in_w]; flow_out[i]
+ * [iters][1][2][in_h][in_w], or [1][1][2][in_h][in_w] after eraft_set_final_only), as ONE batch-n forward - bitwise what eraft_forward
+ * returns for the samples stacked into a batch (flow_init: none).
+ * Replaces: n iterations of the evaluation loop at batch 1 (test_mvsec.py:580-597 -> run_network, :1444-1455) for ERAFT. */
+int eraft_forward_many(eraft_ctx* ctx, int n, const float* const* events1, const float* const* events2, int in_h, int in_w,
+                       const int pad[4], int iters, float* const* flow_out, void* stream);
+
 /* Intermediates of the LAST forward: "fmap" ([2B,256,h,w]: fmap1 then fmap2), "inp", "flow_low", "pyr0".."pyr3", and - only
  * after eraft_keep_stages(ctx, 1), which adds four device copies to every forward - "corr0" (first lookup), "net1", "mask1",
  * "delta1" (after the first update). */

@@ -342,3 +342,38 @@ def test_flow_error_many_equals_the_single_calls():
             assert float(many[i][2]) == float(one[2])                     # the counts exactly
     with pytest.raises(ValueError):
         flow_error_sums_many(gts * 4, prs * 4)
+
+
+def test_coalesced_evaluation_of_the_other_models(tmp_path):
+    """test_multi_sequence(coalesce=3) with EEMFlow_cdc (eemplus_forward_many behind EEMFlow_cdc.forward_many): the same samples in the
+    same order as the one-sample loop; the batched chain picks other tiles on the coarse levels, and past the first warped level the
+    reference's own `>= 1.0` mask moves flows by ~0.1 px on round-off (tests/test_gpu_plus.py's header) - the per-sample AEE agrees to
+    that sensitivity."""
+    from eemflow_amd.eemflow_plus import EEMFlow_cdc
+    from eemflow_amd.harness import TestRaftEvents
+    from eemflow_amd.plus_weights import seeded_from_shapes
+    import contextlib
+    import io
+    root = str(tmp_path)
+    for i in range(5):
+        d = os.path.join(root, "dataset/HREM/test/dt1/seqC/%06d" % (i + 1))
+        os.makedirs(d)
+        hrem.write_events_npz(os.path.join(d, "events1.npz"), hrem.synthetic_hrem_events(140 + i, 30000, 720, 1280))
+        hrem.write_events_npz(os.path.join(d, "events2.npz"), hrem.synthetic_hrem_events(160 + i, 30000, 720, 1280))
+        hrem.write_flo(os.path.join(d, "flow.flo"), hrem.synthetic_flow(180 + i, 720, 1280))
+    args = {"eval_type": "dense", "event_interval": "dt1", "num_voxel_bins": 5}
+    net = EEMFlow_cdc("", 3, 5).eval()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_from_shapes({k: tuple(v.shape) for k, v in net.state_dict().items()}, 3).items()})
+    net = net.to(DEV)
+    res = []
+    for co in (1, 3):
+        ds = hrem.HREMEventFlow(args, train=False, root=root)
+        ds.change_test_sequence("seqC")
+        ev = TestRaftEvents(ds, (720, 1280))
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            mean = ev.test_multi_sequence(net, epoch=0, sequence_list=["seqC"], stride=1, coalesce=co)
+        lines = [ln for ln in buf.getvalue().splitlines() if " / " in ln and "AEE:" in ln]
+        res.append((mean, [float(ln.split("AEE:")[1].split()[0]) for ln in lines], [ln.split("/")[0].strip() for ln in lines]))
+    assert res[0][2] == res[1][2] and len(res[1][1]) == 5
+    assert max(abs(a - b) for a, b in zip(res[0][1], res[1][1])) < 5e-2 and abs(res[0][0] - res[1][0]) < 5e-2

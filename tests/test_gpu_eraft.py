@@ -242,6 +242,30 @@ def test_stem_kernel_equals_the_taps_kernel(monkeypatch, b, h, w, iters):
     assert maxerr(new, old) < 2e-4 and float(old.abs().max()) > 1e-3
 
 
+@pytest.mark.parametrize("n,h,w,iters,final", [(3, 136, 200, 4, False), (4, 480, 640, 3, False), (2, 256, 352, 5, True), (1, 128, 160, 2, False)])
+def test_forward_many_equals_the_batched_forward(n, h, w, iters, final):
+    """ERAFT.forward_many (eraft_forward_many): n independent batch-1 samples in their own tensors through one batch-n forward - every
+    prediction bitwise what `forward` returns for the samples stacked into a batch (padded sizes, `final_only`); argument errors for an
+    empty list and for batched frames."""
+    net, _ = make_net(101)
+    net.final_only = final
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(102, n, h, w))
+    with torch.no_grad():
+        batched = torch.stack(net(e1, e2, iters=iters)[1]).clone()          # [iters or 1, n, 2, h, w]
+        frames = [(e1[i:i + 1].clone(), e2[i:i + 1].clone()) for i in range(n)]
+        many = net.forward_many(frames, iters=iters)
+    assert len(many) == n
+    for i, ((a, b), preds) in enumerate(many):
+        assert a is frames[i][0] and len(preds) == (1 if final else iters) and preds[0].shape == (1, 2, h, w)
+        assert torch.equal(torch.stack(preds)[:, 0], batched[:, i])
+    assert float(batched.abs().max()) > 1e-3
+    with pytest.raises(ValueError):
+        net.forward_many([])
+    with pytest.raises(ValueError):
+        net.forward_many([(torch.cat([e1[:1], e1[:1]]), torch.cat([e2[:1], e2[:1]]))])
+
+
 def test_frames_in_flight_hint_changes_tiles_not_results():
     """eraft_set_frames_in_flight >= 3: the LDS-tiled convs of 512..2047 blocks use 4-row tiles instead of 2-row ones (batch 4 at
     640x480: the update block), and launches of at most one block per CU keep one group of waves per tile instead of two that split

@@ -95,6 +95,18 @@ class TestRaftEvents:
         return preds[-1]
 
     def test_multi_sequence(self, model, epoch=0, sequence_list=(), stride=10, frames_in_flight=1, loader_threads=0, coalesce=1):
+        """The evaluation loop of test_mvsec.py:580-597.  It reads the LAST prediction of every sample only (run_network, :1455): a
+        model that can skip forming the earlier ones (ERAFT.final_only) does so for the duration of the call."""
+        had = getattr(model, "final_only", None)
+        if had is not None:
+            model.final_only = True
+        try:
+            return self._test_multi_sequence(model, epoch, sequence_list, stride, frames_in_flight, loader_threads, coalesce)
+        finally:
+            if had is not None:
+                model.final_only = had
+
+    def _test_multi_sequence(self, model, epoch=0, sequence_list=(), stride=10, frames_in_flight=1, loader_threads=0, coalesce=1):
         """coalesce > 1 (a model with forward_many - EEMFlow, EEMFlow_cdc, ERAFT - and a dataset with get_samples): that many samples are read, voxelized by
         ONE voxelizer launch sequence and handed to ONE model.forward_many call - n independent batch-1 samples riding a batch-n chain of
         launches, every sample in its own tensors; raw volumes with a normalisation record (HREMEventFlow(deferred_norm=True)) are

@@ -377,3 +377,58 @@ def test_coalesced_evaluation_of_the_other_models(tmp_path):
         res.append((mean, [float(ln.split("AEE:")[1].split()[0]) for ln in lines], [ln.split("/")[0].strip() for ln in lines]))
     assert res[0][2] == res[1][2] and len(res[1][1]) == 5
     assert max(abs(a - b) for a, b in zip(res[0][1], res[1][1])) < 5e-2 and abs(res[0][0] - res[1][0]) < 5e-2
+
+
+def test_evaluation_loop_asks_eraft_for_the_last_prediction_only(tmp_path):
+    """test_multi_sequence with ERAFT: the loop reads preds[-1] (test_mvsec.py:1455), so the harness switches ERAFT.final_only on for the
+    call and back afterwards - the same AEE lines as with the full list (the last prediction is bit for bit the same), one sample at a
+    time and three per forward_many call."""
+    from eemflow_amd.eraft import ERAFT
+    from eemflow_amd.eraft_weights import seeded_from_shapes
+    from eemflow_amd.harness import TestRaftEvents
+    import contextlib
+    import io
+    root = str(tmp_path)
+    for i in range(3):
+        d = os.path.join(root, "dataset/HREM/test/dt1/seqE/%06d" % (i + 1))
+        os.makedirs(d)
+        hrem.write_events_npz(os.path.join(d, "events1.npz"), hrem.synthetic_hrem_events(240 + i, 30000, 720, 1280))
+        hrem.write_events_npz(os.path.join(d, "events2.npz"), hrem.synthetic_hrem_events(260 + i, 30000, 720, 1280))
+        hrem.write_flo(os.path.join(d, "flow.flo"), hrem.synthetic_flow(280 + i, 720, 1280))
+    args = {"eval_type": "dense", "event_interval": "dt1", "num_voxel_bins": 5}
+    net = ERAFT("", 5).eval()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_from_shapes({k: tuple(v.shape) for k, v in net.state_dict().items()}, 4).items()})
+    net = net.to(DEV)
+    seen = []
+    orig = ERAFT.forward
+
+    def spy(self, *a, **kw):
+        seen.append(self.final_only)
+        return orig(self, *a, **kw)
+
+    res = []
+    for co, patched in ((1, True), (1, False), (3, False)):
+        ds = hrem.HREMEventFlow(args, train=False, root=root)
+        ds.change_test_sequence("seqE")
+        ev = TestRaftEvents(ds, (720, 1280))
+        buf = io.StringIO()
+        if patched:
+            ERAFT.forward = spy
+        try:
+            with contextlib.redirect_stdout(buf):
+                mean = ev.test_multi_sequence(net, epoch=0, sequence_list=["seqE"], stride=1, coalesce=co)
+        finally:
+            ERAFT.forward = orig
+        res.append((mean, [float(ln.split("AEE:")[1].split()[0]) for ln in buf.getvalue().splitlines() if " / " in ln and "AEE:" in ln]))
+    assert seen and all(seen) and net.final_only is False
+    # the full list's last prediction, scored by hand
+    ds = hrem.HREMEventFlow(args, train=False, root=root)
+    ds.change_test_sequence("seqE")
+    s0 = ds[0]
+    with torch.no_grad():
+        full = net(s0["event_volume_old"].to(DEV)[None].float(), s0["event_volume_new"].to(DEV)[None].float())[1]
+    assert len(full) == 12
+    epe = float((full[-1][0] - s0["flow"].to(DEV)).pow(2).sum(0).sqrt().mean())
+    assert abs(epe - res[0][1][0]) < 1e-4 * max(1.0, epe)
+    assert len(res[0][1]) == 3 and res[0][1] == res[1][1]
+    assert max(abs(a - b) for a, b in zip(res[2][1], res[0][1])) < 2e-3 * max(1.0, max(res[0][1]))

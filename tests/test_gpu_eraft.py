@@ -266,6 +266,25 @@ def test_forward_many_equals_the_batched_forward(n, h, w, iters, final):
         net.forward_many([(torch.cat([e1[:1], e1[:1]]), torch.cat([e2[:1], e2[:1]]))])
 
 
+@pytest.mark.parametrize("b,h,w,iters", [(1, 480, 640, 3), (2, 136, 200, 4)])
+def test_one_stream_forward_equals_the_three_stream_one(monkeypatch, b, h, w, iters):
+    """EEM_ERAFT_NO_OVERLAP=1 (read per forward): every launch on the caller's stream - no side stream for the context network and
+    the flow branch, no lagging stream for the mask head - against the default schedule: the same kernels on the same operands in
+    another order of enqueueing, predictions and kept stages equal to the narrower launches' summation order."""
+    net, _ = make_net(105)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(106, b, h, w))
+    with torch.no_grad():
+        three = torch.stack(net(e1, e2, iters=iters)[1]).clone()
+        st3 = [net.stage(k).clone() for k in ("flow_low", "net1", "mask1", "delta1")]
+        monkeypatch.setenv("EEM_ERAFT_NO_OVERLAP", "1")
+        one = torch.stack(net(e1, e2, iters=iters)[1]).clone()
+        st1 = [net.stage(k).clone() for k in ("flow_low", "net1", "mask1", "delta1")]
+    assert maxerr(three, one) < 2e-4 and float(one.abs().max()) > 1e-3
+    for x, y in zip(st3, st1):
+        assert maxerr(x, y) < 2e-5 * max(1.0, float(y.abs().max()))
+
+
 def test_frames_in_flight_hint_changes_tiles_not_results():
     """eraft_set_frames_in_flight >= 3: the LDS-tiled convs of 512..2047 blocks use 4-row tiles instead of 2-row ones (batch 4 at
     640x480: the update block), and launches of at most one block per CU keep one group of waves per tile instead of two that split

@@ -80,9 +80,6 @@ struct eraft_ctx {
     // network and the correlation volume, convf1 -> convf2 beside convc1 -> convc2, the flow head's last conv beside the mask head's
     hipStream_t side = nullptr;
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
-    // the mask head and the convex upsampling of iteration i on a stream of their own, beside iteration i + 1 (eraft_forward)
-    hipStream_t lag = nullptr;
-    hipEvent_t net_ev = nullptr, c1_ev = nullptr, lag_ev[2] = {nullptr, nullptr}, lag_join_ev = nullptr;
     Buf s2[5];                     // the context network's own activations (the feature network runs at the same time)
     bool alt_corr = false;         // eraft_set_alternate_corr: correlation features on the fly, no all-pairs volume
     bool final_only = false;       // eraft_set_final_only: only the last iteration's prediction leaves the forward
@@ -401,8 +398,6 @@ extern "C" void eraft_destroy(eraft_ctx* c) {
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     if (c->join_ev) (void)hipEventDestroy(c->join_ev);
-    if (c->lag) (void)hipStreamDestroy(c->lag);
-    for (hipEvent_t e : {c->net_ev, c->c1_ev, c->lag_ev[0], c->lag_ev[1], c->lag_join_ev}) if (e) (void)hipEventDestroy(e);
     if (c->arena) (void)hipFree(c->arena);
     if (c->wino) (void)hipFree(c->wino);
     if (c->trash) (void)hipFree(c->trash);
@@ -568,17 +563,13 @@ static int eraft_forward_impl(eraft_ctx* c, const float* e1, const float* e2, co
             if ((rc = ensure(c->s2[i], big / 2)) != EEM_OK) return rc;
     }
     // The prediction of an iteration - mask head (3x3 128 -> 256, 1x1 256 -> 576) and convex upsampling - feeds nothing inside the loop
-    // (model/eraft.py:141-157: the recurrence is net -> flow head -> coords1 -> lookup): it runs on a third stream beside the NEXT
+    // (model/eraft.py:141-157: the recurrence is net -> flow head -> coords1 -> lookup): it runs on the side stream beside the NEXT
     // iteration, which starts as soon as the flow head has updated coords1.  One forward at a time the update block's launches leave
     // most CUs idle (60x80 cells at batch 1 are 75 - 300 blocks): E-RAFT 640x480 x 12 batch 1 / 4: tools/bench_eraft.py, DESIGN.md 4b.
     // EEM_ERAFT_NO_LAG=1 (read per forward): the mask head inside the iteration, as before.
     const char* enl = getenv("EEM_ERAFT_NO_LAG");
     const char* enf0 = getenv("EEM_ERAFT_NO_FUSE");
     const bool lagged = overlap && !(enl && enl[0] == '1') && !(enf0 && enf0[0] == '1');
-    if (lagged && !c->lag) {
-        EEM_HIP_CHECK(hipStreamCreateWithFlags(&c->lag, hipStreamNonBlocking));
-        for (hipEvent_t* e : {&c->net_ev, &c->c1_ev, &c->lag_ev[0], &c->lag_ev[1], &c->lag_join_ev}) EEM_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-    }
     hipStream_t sd = overlap ? c->side : st;
     // fork: the side stream continues from here on the caller's stream; join: the caller's stream waits for the side stream's work so far
     // An error return between a fork and its join must not leave work queued on the side stream that the caller's stream never waits
@@ -589,7 +580,7 @@ static int eraft_forward_impl(eraft_ctx* c, const float* e1, const float* e2, co
             if (!forked) return;
             if (hipEventRecord(join_ev, sd) != hipSuccess || hipStreamWaitEvent(st, join_ev, 0) != hipSuccess) (void)hipStreamSynchronize(sd);
         }
-    } guard{st, sd, c->join_ev}, lag_guard{st, c->lag, c->lag_join_ev};
+    } guard{st, sd, c->join_ev};
     auto fork = [&]() -> int {
         if (!overlap) return EEM_OK;
         EEM_HIP_CHECK(hipEventRecord(c->fork_ev, st));
@@ -668,34 +659,28 @@ static int eraft_forward_impl(eraft_ctx* c, const float* e1, const float* e2, co
     // so the one prediction that leaves is bit for bit the last of the full list (tests/test_eraft_hip.py)
     float* c1p = c->c1.p;
     float* c1q = c->c1b.p;
-    // lagged schedule: the mask head of an iteration starts on `lag` as soon as its hidden state is there (beside the flow head, the next
-    // lookup and the 1x1 conv behind it - the launches that leave most of the chip idle); its convex upsampling follows behind the NEXT
-    // iteration's fork event (the record the flow branch needs anyway, after coords1 + delta_flow: an event record of its own costs
-    // the recording stream ~6 us, tools/eraft_timeline.sh) or, after the last iteration, behind a record of its own
-    struct { bool on = false; const float* c1 = nullptr; int oi = 0, ev = 0; } pend;
-    auto lag_heads = [&](const float* hidden) -> int {
-        EEM_HIP_CHECK(hipEventRecord(c->net_ev, st));
-        EEM_HIP_CHECK(hipStreamWaitEvent(c->lag, c->net_ev, 0));
-        lag_guard.forked = true;
+    // lagged schedule: the prediction of iteration i - mask head and convex upsampling - goes onto the SIDE stream behind the flow branch of
+    // iteration i + 1, after that iteration's join event is recorded there: no stream and no event of its own (an event recorded on the
+    // chain's stream costs it ~7 us, tools/eraft_timeline.sh).  Order on the side stream: [convf(i+1), join event(i+1), prediction(i),
+    // convf(i+2), join event(i+2), ...] - the chain's wait for join event(i+2) is also its wait for prediction(i), whose hidden state
+    // (three rotating buffers) and coords1 buffer iteration i + 2 overwrites.  Measured against a third stream that started the mask
+    // head right behind the GRU (two event records per iteration on the chain's stream): 196.0 against 192.4 frames/s at batch 1, 283.3
+    // against 277.2 at batch 4.
+    struct { bool on = false; const float* c1 = nullptr; const float* hidden = nullptr; int oi = 0; } pend;
+    auto side_mask = [&]() -> int {
+        if (!pend.on) return EEM_OK;
+        pend.on = false;
         GConvArgs m = conv_args(c, c->mk0, B, h8, w8, c->mhid.p, 256, 0, GACT_RELU);
-        set_seg(m, 0, hidden, 128, 128, 0);
-        int r2 = gconv_launch(m, c->lag);
+        set_seg(m, 0, pend.hidden, 128, 128, 0);
+        int r2 = gconv_launch(m, sd);
         if (r2 != EEM_OK) return r2;
         m = conv_args(c, c->mk2, B, h8, w8, c->mask.p, 576, 0, GACT_NONE);
         set_seg(m, 0, c->mhid.p, 256, 256, 0);
         m.out_scale = 0.25f;
-        return gconv_launch(m, c->lag);
-    };
-    auto lag_up = [&](hipEvent_t after) -> int {
-        if (!pend.on) return EEM_OK;
-        pend.on = false;
-        EEM_HIP_CHECK(hipStreamWaitEvent(c->lag, after, 0));
+        if ((r2 = gconv_launch(m, sd)) != EEM_OK) return r2;
         // :155-157 the convex upsampling of coords1 - coords0
-        int r2 = er_convex_up_launch(c->c0.p, pend.c1, c->mask.p, out + (size_t)pend.oi * B * 2 * in_h * in_w, B, h8, w8, pad[2], pad[0], in_h,
-                                     in_w, c->lag);
-        if (r2 != EEM_OK) return r2;
-        EEM_HIP_CHECK(hipEventRecord(c->lag_ev[pend.ev], c->lag));
-        return EEM_OK;
+        return er_convex_up_launch(c->c0.p, pend.c1, c->mask.p, out + (size_t)pend.oi * B * 2 * in_h * in_w, B, h8, w8, pad[2], pad[0], in_h,
+                                   in_w, sd);
     };
     for (int it = 0; it < iters; ++it) {
         const bool emit = !c->final_only || it == iters - 1 || (it == 0 && c->keep_stages);   // (mask1 is a kept stage)
@@ -721,7 +706,6 @@ static int eraft_forward_impl(eraft_ctx* c, const float* e1, const float* e2, co
         // the 324 correlation features live in a 336-channel buffer (12 zero channels, zero weight columns) so that the
         // 1x1 conv qualifies for the 16-aligned LDS-tiled kernel; the generic kernel reads the first 324
         if ((rc = fork()) != EEM_OK) return rc;                        // (the lookup wrote the flow channels of `motion`)
-        if (lagged && (rc = lag_up(c->fork_ev)) != EEM_OK) return rc;      // (the previous iteration's prediction)
         GConvArgs a = conv_args(c, c->convf1, B, h8, w8, c->flo1.p, 128, 0, GACT_RELU);
         set_seg(a, 0, c->motion.p, 2, 128, 126);
         if ((rc = gconv_launch(a, sd)) != EEM_OK) return rc;
@@ -736,9 +720,7 @@ static int eraft_forward_impl(eraft_ctx* c, const float* e1, const float* e2, co
         set_seg(a, 0, c->cor1.p, 256, 256, 0);
         if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
         if ((rc = join()) != EEM_OK) return rc;
-        // (this iteration's GRU and flow head overwrite the hidden state and the coords1 buffer the prediction of iteration it - 2 reads:
-        // it has had an iteration and a half; the wait sits beside the join's)
-        if (lagged && it >= 2 && lag_guard.forked) EEM_HIP_CHECK(hipStreamWaitEvent(st, c->lag_ev[it & 1], 0));
+        if (lagged && (rc = side_mask()) != EEM_OK) return rc;             // (the previous iteration's prediction, behind the join event)
         a = conv_args(c, c->conv, B, h8, w8, c->motion.p, 128, 0, GACT_RELU);
         set_seg(a, 0, c->corflo.p, 256, 256, 0);
         if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
@@ -792,7 +774,6 @@ static int eraft_forward_impl(eraft_ctx* c, const float* e1, const float* e2, co
         // after two passes the new hidden state is in `net`
         // flow head and mask head (model/update.py:102-105)
         if (lagged) {
-            if (emit && (rc = lag_heads(net)) != EEM_OK) return rc;
             a = conv_args(c, c->fh1, B, h8, w8, c->fhid.p, 256, 0, GACT_RELU);
             set_seg(a, 0, net, 128, 128, 0);
             if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
@@ -808,12 +789,9 @@ static int eraft_forward_impl(eraft_ctx* c, const float* e1, const float* e2, co
                 if ((rc = er_sum_launch(c1nxt, c1cur, c->delta.p, (long)B * 2 * g, st)) != EEM_OK) return rc;
             }
             if (emit) {
-                pend.on = true; pend.c1 = c1nxt; pend.oi = c->final_only ? 0 : it; pend.ev = it & 1;
+                pend.on = true; pend.c1 = c1nxt; pend.hidden = net; pend.oi = c->final_only ? 0 : it;
                 if (it == iters - 1 || (it == 0 && c->keep_stages)) {        // nothing follows / the kept stages are copied on `st`
-                    EEM_HIP_CHECK(hipEventRecord(c->c1_ev, st));
-                    if ((rc = lag_up(c->c1_ev)) != EEM_OK) return rc;
-                    EEM_HIP_CHECK(hipStreamWaitEvent(st, c->lag_ev[it & 1], 0));
-                    lag_guard.forked = false;
+                    if ((rc = fork()) != EEM_OK || (rc = side_mask()) != EEM_OK || (rc = join()) != EEM_OK) return rc;
                 }
             }
             { float* t = c1p; c1p = c1q; c1q = t; }

@@ -201,8 +201,8 @@ def test_final_only_is_the_last_of_the_full_list(b, h, w, iters, keep):
 @pytest.mark.parametrize("b,h,w,iters,final", [(2, 136, 200, 5, False), (1, 480, 640, 12, False), (4, 480, 640, 3, False),
                                                (1, 480, 640, 4, True), (1, 64, 96, 3, False)])
 def test_mask_head_beside_the_next_iteration_equals_the_serial_order(monkeypatch, b, h, w, iters, final):
-    """The default schedule - mask head and convex upsampling of iteration i on a third stream beside iteration i + 1, the flow head's
-    last conv writing delta_flow and coords1 + delta_flow in one launch - against the mask head inside the iteration
+    """The default schedule - mask head and convex upsampling of iteration i on the side stream behind the flow branch of iteration
+    i + 1, the flow head's last conv writing delta_flow and coords1 + delta_flow in one launch - against the mask head inside the iteration
     (EEM_ERAFT_NO_LAG=1, read per forward): every prediction, the low-resolution flow and the kept stages of the first iteration are
     the same (the hidden state is read by the lagging launches while the next iteration reads it, and overwritten only after they have
     finished); with final_only; on a map of less than 256 cells (the generic kernel and a separate sum); twice in a row on one
@@ -268,8 +268,8 @@ def test_forward_many_equals_the_batched_forward(n, h, w, iters, final):
 
 @pytest.mark.parametrize("b,h,w,iters", [(1, 480, 640, 3), (2, 136, 200, 4)])
 def test_one_stream_forward_equals_the_three_stream_one(monkeypatch, b, h, w, iters):
-    """EEM_ERAFT_NO_OVERLAP=1 (read per forward): every launch on the caller's stream - no side stream for the context network and
-    the flow branch, no lagging stream for the mask head - against the default schedule: the same kernels on the same operands in
+    """EEM_ERAFT_NO_OVERLAP=1 (read per forward): every launch on the caller's stream - no side stream for the context network, the
+    flow branch and the lagging mask head - against the default schedule: the same kernels on the same operands in
     another order of enqueueing, predictions and kept stages equal to the narrower launches' summation order."""
     net, _ = make_net(105)
     net.change_imagesize((h, w))

@@ -148,7 +148,7 @@ struct eemflow_ctx {
     size_t enc0_gw = 0;
     bool keep_stage_stores = false;
     bool f13_skipped = false;
-    // pconv1_1 computed inside pconv1_2's block (conv_enc12.hip; inference, 5-bin first layer, EEM_NO_FUSE12=1 keeps the two launches):
+    // pconv1_1 computed inside pconv1_2's block (conv_enc12.hip; inference, 5-bin first layer; OPT-IN: EEM_FUSE12=1, set before the context sizes its buffers):
     // `a1` is then never written - eemflow_get_stage("a1") re-runs pconv1_1 alone on the last call's event volumes
     DevBuf fuse_scratch;
     bool a1_skipped = false;
@@ -364,7 +364,10 @@ int alloc_workspace_raw(eemflow_ctx* c, const Shape& s) {
     }
     ENS(c->flowcat, B * 6 * g);  ENS(c->coarse, B * 2 * g);
     if (c->enc0_generic) { ENS(c->padded, n2 * c->cin0 * (size_t)s.hp * s.wp); }
-    else { ENS(c->fuse_scratch, enc12_scratch_floats(256)); }
+    else {                                                   // block scratch of the OPT-IN fused first two layers only (41 MB)
+        const char* eon = getenv("EEM_FUSE12");
+        if (eon && eon[0] == '1') { ENS(c->fuse_scratch, enc12_scratch_floats(256)); }
+    }
 #undef ENS
     return EEM_OK;
 }

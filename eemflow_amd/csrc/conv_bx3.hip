@@ -20,7 +20,9 @@
 // Measured and not kept: pconv2_1 as persistent blocks (weights stationary in 108 registers, two LDS stages, tile t + 1 streaming in under
 // tile t's MFMAs and tile t - 1's stores, counted waits; two blocks per CU): 14.1 us at two tiles per block, 17.2 at three on 150 CUs,
 // against 13.1 for these one-tile blocks on the same box, and 8 790-8 890 frames/s with four frames in flight against 8 850-8 880.
-// Inputs with an infinity give NaN here where the fp32 kernels give an infinity (inf - inf in the split).
+// Inputs with an infinity give NaN here where the fp32 kernels give an infinity (inf - inf in the split): the output is non-finite at
+// exactly the positions where the fp32 kernel's is and unchanged elsewhere (contract, tests/test_gpu_parity.py::
+// test_bf16_piece_kernel_and_an_infinity_in_the_input); a guard would add two VALU per value to a split that runs once per USE here.
 #include "common.h"
 
 namespace {

@@ -670,6 +670,9 @@ static int eraft_forward_impl(eraft_ctx* c, const float* e1, const float* e2, co
     auto side_mask = [&]() -> int {
         if (!pend.on) return EEM_OK;
         pend.on = false;
+        // (work queued on the side stream AFTER a join(): the guard joins it again if a later launch of this iteration fails and the
+        // function returns early - `out`, the hidden state and coords1 are still being used over there)
+        if (sd != st) guard.forked = true;
         GConvArgs m = conv_args(c, c->mk0, B, h8, w8, c->mhid.p, 256, 0, GACT_RELU);
         set_seg(m, 0, pend.hidden, 128, 128, 0);
         int r2 = gconv_launch(m, sd);

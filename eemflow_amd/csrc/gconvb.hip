@@ -4,6 +4,10 @@
 // it EXACTLY (8 significand bits each, by truncation), a product = six piece products (a0 b0, a0 b1, a1 b0, a0 b2, a1 b1, a2 b0; the
 // dropped three are below 2^-24 of it) accumulated in fp32 by the MFMA, small terms first.  tools/micro/bf16x3.hip: worst error over
 // K = 144 is 1.8e-7 of sum |a b| against 1.5e-7 for the fp32 MFMA - the same arithmetic, not a reduced precision.
+// Non-finite operands (contract, tested by tests/test_gpu_bwd_ops.py::test_bf16_piece_wide_conv_and_an_infinity_in_the_input): the split of
+// an infinity is inf - inf = NaN, so an infinite input leaves this kernel as NaN where gconv16.hip leaves an infinity - the output is
+// non-finite at exactly the positions where the fp32 kernel's is, every other value agrees, nothing non-finite ever becomes a number
+// (the training step's inf / NaN test sees it either way).  A guard would cost two VALU per value of the split for no caller of the path.
 //
 // Why here: these are direct convolutions with K = 256 .. 3 456 and no cheaper algorithm (1x5, 5x1, 1x1; the 3x3 ones sit beside them in
 // the same loops); gconv16.hip runs them at 0.4-0.55 of the fp32 MFMA's 155 TFLOP/s.  tools/micro/mfma_clock.hip: six

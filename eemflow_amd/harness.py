@@ -163,8 +163,8 @@ class TestRaftEvents:
 
                 indices = [idx for idx in range(len(self.dataset)) if idx % stride == 0]
                 futures = collections.deque()
-                if pool is not None:
-                    def load(idx):
+                if pool is not None and co == 1:                 # (the coalesced loop reads its chunks through dataset.get_samples: no
+                    def load(idx):                               # per-sample futures are submitted that nobody would consume - ADVICE round 5)
                         with torch.cuda.device(dev):
                             sample = self.dataset[idx]
                             ready = torch.cuda.Event()

@@ -79,7 +79,8 @@ def parse_cpulist(text):
 
 
 def pin_host_threads_to_gpu_numa(device_index, sysfs="/sys/bus/pci/devices"):
-    """One process per GPU: keep this rank's host threads (the loader's workers inherit the mask) on the CPUs local to ITS GPU's PCIe
+    """One process per GPU: keep this rank's host threads - every thread the process has now, and the ones created later (the loader's
+    workers inherit the mask) - on the CPUs local to ITS GPU's PCIe
     root - on an 8-GPU node the ranks otherwise share one socket's memory controllers for their pinned staging buffers.  Reads the GPU's
     PCI address from torch and `local_cpulist` from sysfs; intersects with the mask the process already has (a cgroup's); returns the
     CPUs it pinned to, or None when anything is missing (no sysfs entry, an empty intersection) - never fatal.  EEM_NO_NUMA_PIN=1 skips it."""
@@ -92,6 +93,13 @@ def pin_host_threads_to_gpu_numa(device_index, sysfs="/sys/bus/pci/devices"):
         allowed = sorted(set(local) & set(os.sched_getaffinity(0)))
         if not allowed:
             return None
+        # every thread this process already has (sched_setaffinity(0, ...) moves the CALLING thread only: RCCL's proxy threads, torch's
+        # intra-op pool and the HIP runtime's helpers exist by the time a rank knows its GPU) - threads created later inherit the mask
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                os.sched_setaffinity(int(tid), allowed)
+            except OSError:                                  # a thread that exited between the listing and the call
+                pass
         os.sched_setaffinity(0, allowed)
         return allowed
     except Exception:                                        # noqa: BLE001 - a missing sysfs entry must not stop a run

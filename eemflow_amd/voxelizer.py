@@ -79,8 +79,12 @@ def _grid_buffers(k, num_bins, height, width, dev, deferred):
 
 
 def has_norm_record(t):
-    """Does the tensor's storage hold the four-float normalisation record behind its elements?"""
-    return t.is_contiguous() and t.untyped_storage().nbytes() >= (t.storage_offset() + t.numel() + 4) * t.element_size()
+    """Is this a deferred grid: a contiguous tensor that starts its storage and whose storage is EXACTLY its elements plus the four-float
+    normalisation record (what _grid_buffers allocates)?  "Room for four more floats" alone would also accept frame i of a stacked
+    [N,C,H,W] tensor or any over-allocated buffer, whose "record" is the next frame's first voxels; the exact shape of the
+    allocation is the tag - views that keep the storage ([None], .float() of a float tensor, .view) keep it."""
+    return (t.is_contiguous() and t.storage_offset() == 0
+            and t.untyped_storage().nbytes() == (t.numel() + 4) * t.element_size())
 
 
 def norm_record(t):
@@ -197,15 +201,18 @@ class EventSequenceToVoxelGrid_Pytorch(object):
         if not torch.cuda.is_available():
             raise _lib.EEMFlowHipError("EventSequenceToVoxelGrid_Pytorch: no GPU - the voxelizer has no CPU path here")
         n = events.shape[0]
+        code = _norm_code(self.normalize)
+        if code == 2 and not self.return_on_gpu:
+            raise _lib.EEMFlowHipError("normalize='deferred' grids live on the GPU (gpu=True): their record is read by the first convolution")
         with torch.no_grad(), torch.cuda.device(self.device):
             ev = torch.from_numpy(events).to(self.device)
-            grid = torch.empty(self.num_bins, height, width, dtype=torch.float32, device=self.device)
+            grid = _grid_buffers(1, self.num_bins, height, width, self.device, code == 2)[0]       # deferred: raw grid + its record
             il = ir = None
             if return_indices:
                 il = torch.empty(n, dtype=torch.int64, device=self.device)
                 ir = torch.empty(n, dtype=torch.int64, device=self.device)
             _lib.check(_lib.lib().eemflow_voxelize(
-                ev.data_ptr(), n, self.num_bins, height, width, 1 if (self.normalize and self.normalize != DEFERRED) else 0, grid.data_ptr(),
+                ev.data_ptr(), n, self.num_bins, height, width, code, grid.data_ptr(),
                 il.data_ptr() if return_indices else None, ir.data_ptr() if return_indices else None,
                 _lib.current_stream_ptr(self.device)))
         if not self.return_on_gpu:
@@ -214,7 +221,7 @@ class EventSequenceToVoxelGrid_Pytorch(object):
             return grid, il, ir
         return grid
     # (normalize="deferred" - raw grids with the normalisation record behind them, for EEMFlow.forward_many(..., deferred_norm=True) -
-    # is served by pair() and many(): their grids stay on the GPU, where the record's consumer is)
+    # needs gpu=True in every form of the call: the grids stay on the GPU, where the record's consumer is)
 
     def many(self, sequences):
         """`[self(s) for s in sequences]` - up to 32 sequences of one sensor size - by one launch sequence."""

@@ -165,6 +165,29 @@ def test_lds_tiled_conv_with_two_k_groups(monkeypatch, cin, cout, k, h, w, b):
     assert not torch.equal(tiled, gen)
 
 
+def test_bf16_piece_wide_conv_and_an_infinity_in_the_input(monkeypatch):
+    """gconvb.hip splits every operand into three bf16 pieces by a - (a & 0xffff0000): for a = inf that is inf - inf = NaN (ADVICE round 4
+    item 5).  The documented contract (gconvb.hip header): the output is NON-FINITE at exactly the positions where the fp32 kernel's
+    (gconv16, EEM_NO_GCONVB=1) is - NaN in place of its infinities - and every other value agrees; no non-finite input is ever turned
+    into a number."""
+    from eemflow_amd import ops
+    g = torch.Generator().manual_seed(77)
+    conv = torch.nn.Conv2d(128, 128, 3, padding=1)
+    x = torch.randn(2, 128, 48, 64, generator=g)
+    x[0, 5, 10, 20] = float("inf")
+    x[1, 100, 40, 3] = float("-inf")
+    convd = conv.to(DEV)
+    with torch.no_grad():
+        monkeypatch.setenv("EEM_GCONVB_MINBLK", "1")
+        fast = ops.conv2d(convd, x.to(DEV), act=ops.ACT_NONE).cpu()
+        monkeypatch.setenv("EEM_NO_GCONVB", "1")
+        plain = ops.conv2d(convd, x.to(DEV), act=ops.ACT_NONE).cpu()
+    bad_f, bad_p = ~torch.isfinite(fast), ~torch.isfinite(plain)
+    assert int(bad_p.sum()) == 2 * 9 * 128 and torch.equal(bad_f, bad_p)          # the 3 x 3 footprint of each infinity, every cout
+    assert not torch.equal(fast[~bad_p], plain[~bad_p])                           # (the switch did switch)
+    assert float((fast[~bad_p] - plain[~bad_p]).abs().max()) < 1e-4
+
+
 @pytest.mark.parametrize("cin,cout,k,h,w,b", [(64, 96, 3, 48, 64, 1), (64, 96, 1, 48, 64, 1), (96, 128, 3, 120, 160, 2), (96, 128, 1, 120, 160, 2),
                                                (64, 96, 3, 46, 68, 1), (32, 64, 3, 90, 160, 2)])
 def test_lds_tiled_conv_at_stride_two(monkeypatch, cin, cout, k, h, w, b):

@@ -46,12 +46,16 @@ def launch_two(args, timeout=600, nproc=2, env=None):
            "--master-port", str(free_port()), WORKER, *[str(a) for a in args]]
     r = subprocess.run(cmd, env=env or child_env(), capture_output=True, text=True, timeout=timeout)
     if r.returncode != 0:
-        # one more try on another port: the port found free above can be taken before torch.distributed.run binds it, and a rendezvous
-        # that loses that race fails before any of the code under test runs (seen once in ~15 runs of the whole suite)
-        first = r.stdout[-1500:] + r.stderr[-1500:]
+        # one more try on another port ONLY when the launcher itself lost the race for the port found free above (torch.distributed.run
+        # binds it later; a rendezvous that fails this way fails before any of the code under test runs).  Anything else - a worker's
+        # assertion, a crash, a numerical difference - fails here with the first attempt's output.
+        first = r.stdout[-3000:] + r.stderr[-3000:]
+        port_race = any(k in first for k in ("EADDRINUSE", "ddress already in use", "errno: 98", "RendezvousConnectionError",
+                                             "DistNetworkError"))
+        assert port_race, "worker failed (no rendezvous / bind error in its output, so no retry):\n" + first
         cmd[cmd.index("--master-port") + 1] = str(free_port())
         r = subprocess.run(cmd, env=env or child_env(), capture_output=True, text=True, timeout=timeout)
-        assert r.returncode == 0, "first attempt:\n" + first + "\nsecond attempt:\n" + r.stdout[-3000:] + r.stderr[-3000:]
+        assert r.returncode == 0, "first attempt (port race):\n" + first + "\nsecond attempt:\n" + r.stdout[-3000:] + r.stderr[-3000:]
     return r
 
 
@@ -214,17 +218,25 @@ def test_cli_train_eraft_two_processes_equals_the_mean_of_per_sample_gradients(t
         loss, _ = sequence_loss(preds, gt, va, 0.8)
         (0.5 * loss).backward()                                      # gradients accumulate: the mean over the two replicas
     torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+    g_ref = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).detach().reshape(-1).float().cpu()
+                       for p in model.parameters()]).numpy()
     opt.step()
     sched.step()
     p1 = torch.cat([p.detach().reshape(-1).float().cpu() for p in model.parameters()]).numpy()
     step_ref, step_dp = p1 - p0, r0["params"] - p0
     assert float(np.abs(step_ref).max()) > 1e-6                      # the step moved the weights
-    # AdamW's first step is lr * sign-like (|m / sqrt(v)| = 1): compare the steps themselves, tolerance in units of that step
-    # (elements whose gradient is ~eps take a step of either sign - the weight gradients' atomics add in another order every run: a few
-    # per thousand of the 5.3 M elements; the bound leaves a factor of four over the runs seen)
+    # AdamW's first step is lr * g / (|g| + eps): sign-like.  An element whose gradient is round-off of an exact zero (a conv bias in front
+    # of an instance norm, a unit no sample activates) takes a step of either sign in ANY two runs - the weight gradients' atomics add
+    # in another order every time.  Those elements are named by the REFERENCE gradient (|g| below 1e-4 of its rms: round-off of the sums
+    # that formed it) and left out; on every other element the original bounds hold (the bounds are not widened).
+    rms = float(np.sqrt(np.mean(g_ref.astype(np.float64) ** 2)))
+    sure = np.abs(g_ref) > 1e-4 * rms
     bad = np.abs(step_dp - step_ref) > 0.05 * np.abs(step_ref).max()
-    assert float(bad.mean()) < 2e-2, float(bad.mean())
-    assert np.linalg.norm(step_dp - step_ref) / np.linalg.norm(step_ref) < 0.1
+    print(f"eraft dp step: {1 - sure.mean():.4f} of the elements at round-off level, bad among the others {bad[sure].mean():.2e} "
+          f"(among all {bad.mean():.2e}), relative step difference {np.linalg.norm((step_dp - step_ref)[sure]) / np.linalg.norm(step_ref[sure]):.3e}")
+    assert float(sure.mean()) > 0.9, float(sure.mean())
+    assert float(bad[sure].mean()) < 5e-3, float(bad[sure].mean())
+    assert np.linalg.norm((step_dp - step_ref)[sure]) / np.linalg.norm(step_ref[sure]) < 0.05
 
 
 def _bench(args, share, timeout=900):

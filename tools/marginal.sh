@@ -11,7 +11,8 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms
 }
 base=$(run "" "$@"); echo "nothing skipped: $base"
 b=$(echo $base | cut -d" " -f2)
-for k in "enc.pconv1_1" "enc.pconv1_2" "enc.pconv2_1" "enc.pconv2_2" "enc.pconv2_3" "enc.pconv3_1" "enc.pconv3_2" "enc.pconv3_3" "tail head" "dec." "tail up" "enc.;tail;dec."; do
+for k in "enc.pconv1_1" "enc.pconv1_2" "enc.pconv2_1" "enc.pconv2_2" "enc.pconv2_3" "enc.pconv3_1" "enc.pconv3_2" "enc.pconv3_3" "tail head" "dec." "tail up"; do
   r=$(run "$k" "$@"); t=$(echo $r | cut -d" " -f2)
+  [ -n "$t" ] || { echo "skip $k: the run printed no line"; continue; }      # (every launch skipped at once leaves bench.py nothing to time)
   python3 -c "print('skip %-16s %s frames/s  -> marginal cost %.1f us of %.1f' % ('$k', '$r'.split()[0], ($b - $t) * 1e3, $b * 1e3))"
 done

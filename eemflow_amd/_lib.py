@@ -119,6 +119,8 @@ _SIGNATURES = {
     "eemop_pack_cache_bytes": (ctypes.c_longlong, []),
     "eemop_conv2d_bwd_data": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 12 + [_c_float_p, ctypes.c_void_p]),
     "eemop_conv2d_bwd_weight": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 12 + [_c_float_p, _c_float_p, ctypes.c_void_p]),
+    "eemop_conv2d_bwd_weight_cat": (ctypes.c_int, [_c_float_p, ctypes.c_int, _c_float_p, ctypes.c_int, _c_float_p, ctypes.c_int, _c_float_p]
+                                    + [ctypes.c_int] * 9 + [_c_float_p, _c_float_p, ctypes.c_void_p]),
     "eemop_act_bwd": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_float, _c_float_p, ctypes.c_void_p]),
     "eemop_binary": (ctypes.c_int, [ctypes.c_int, _c_float_p, _c_float_p, ctypes.c_float, ctypes.c_longlong, _c_float_p, ctypes.c_void_p]),
     "eemop_sum_n": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, _c_float_p, ctypes.c_void_p]),

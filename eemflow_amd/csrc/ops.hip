@@ -673,6 +673,12 @@ extern "C" int eemop_conv2d_bwd_weight(const float* x, const float* dy, int n, i
     const int hout = (hin + 2 * ph - kh) / stride + 1, wout = (win + 2 * pw - kw) / stride + 1;
     int rc;
     {
+        static const bool log_calls = [] { const char* e = getenv("EEM_WGRAD_LOG"); return e && e[0] == '1'; }();
+        if (log_calls)                                               // (measurement: the shapes a training step asks for, tools/wgrad_shapes.sh)
+            fprintf(stderr, "WGRAD cic=%d cout=%d k=%dx%d s=%d n=%d hin=%d win=%d cin=%d ci0=%d db=%d\n", cic, cout, kh, kw, stride, n, hin, win, cin,
+                    ci0, db != nullptr);
+    }
+    {
         // LDS-tiled kernel (wgrad_enc.hip: G and the haloed X tile by LDS-DMA, K split over the waves, 65-95 TFLOP/s) where the shape
         // allows; it also leaves the bias gradient
         WgradArgs a;
@@ -685,6 +691,8 @@ extern "C" int eemop_conv2d_bwd_weight(const float* x, const float* dy, int n, i
         float* zp = nullptr;
         if ((rc = scratch_get(g_scratch[1], 1024, &zp)) != EEM_OK) return rc;
         a.zero_page = zp;
+        if (wgrad_ring_supported(a) && wgrad_ring_preferred(a)) return wgrad_ring_launch(a, st);
+        if (kh == 3 && kw == 3 && wgrad_enc_supported(a)) return wgrad_enc_launch(a, st);   // (16 / 32 / 64 couts on blocks of their own height)
         if (wgrad_wide_supported(a)) return wgrad_wide_launch(a, st);
     }
     for (int c0 = 0; c0 < cout; c0 += 128) {                     // the kernel holds at most 128 couts per block
@@ -698,6 +706,45 @@ extern "C" int eemop_conv2d_bwd_weight(const float* x, const float* dy, int n, i
         if ((rc = tr_wgrad_launch_batch(&a, 1, st)) != EEM_OK) return rc;
     }
     if (db) return tr_bias_grad_launch(dy, nullptr, cout, 0, 1, cout, n, hout * wout, db, st);
+    return EEM_OK;
+}
+
+// The same for a conv over up to three channel-concatenated inputs (x_s [n][c_s][hin][win]; x1 / x2 may be NULL) in ONE call:
+// dw [cout][c0 + c1 + c2][kh][kw].  Where the ring kernel is the faster one (wgrad_ring_preferred) the segments ride one launch - the
+// GRU's (1, 5) / (5, 1) convs over [h | inp | motion] are 106 us as one launch against 3 x 48; elsewhere one call per segment as before.
+extern "C" int eemop_conv2d_bwd_weight_cat(const float* x0, int c0, const float* x1, int c1, const float* x2, int c2, const float* dy, int n,
+                                           int hin, int win, int cout, int kh, int kw, int stride, int ph, int pw, float* dw, float* db,
+                                           void* stream) {
+    EEM_REQUIRE(x0 && dy && dw && c0 >= 1 && c1 >= 0 && c2 >= 0 && (c1 == 0 || x1) && (c2 == 0 || (x2 && c1 > 0)),
+                "eemop_conv2d_bwd_weight_cat: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int cin = c0 + c1 + c2;
+    const int hout = (hin + 2 * ph - kh) / stride + 1, wout = (win + 2 * pw - kw) / stride + 1;
+    const float* xs[3] = {x0, x1, x2};
+    const int cs[3] = {c0, c1, c2};
+    const int nseg = c2 > 0 ? 3 : (c1 > 0 ? 2 : 1);
+    if (nseg > 1) {
+        WgradArgs a;
+        a.x = x0; a.x_ctotal = c0; a.x_coff = 0; a.cin = cin;
+        a.g = dy; a.gate = nullptr; a.g_ctotal = cout; a.g_coff = 0; a.g_cmul = 1; a.cout = cout;
+        a.dw = dw;
+        a.n = n; a.hin = hin; a.win = win; a.hout = hout; a.wout = wout; a.k = kh; a.stride = stride; a.pad = ph;
+        a.db = db;
+        a.kh = kh; a.kw = kw; a.ph = ph; a.pw = pw; a.dw_cin = cin; a.dw_coff = 0;
+        a.nxseg = nseg;
+        for (int s = 0; s < nseg; ++s) { a.xs[s] = xs[s]; a.xsc[s] = cs[s]; }
+        float* zp = nullptr;
+        int rc = scratch_get(g_scratch[1], 1024, &zp);
+        if (rc != EEM_OK) return rc;
+        a.zero_page = zp;
+        if (wgrad_ring_supported(a) && wgrad_ring_preferred(a)) return wgrad_ring_launch(a, st);
+    }
+    int ci0 = 0;
+    for (int s = 0; s < nseg; ++s) {
+        const int rc = eemop_conv2d_bwd_weight(xs[s], dy, n, hin, win, cin, ci0, cs[s], cout, kh, kw, stride, ph, pw, dw, s == 0 ? db : nullptr, stream);
+        if (rc != EEM_OK) return rc;
+        ci0 += cs[s];
+    }
     return EEM_OK;
 }
 

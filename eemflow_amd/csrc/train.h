@@ -15,6 +15,11 @@ struct WgradArgs {
     // generic kernel only: rectangular filters (kh != 0 overrides k / pad: kh x kw taps, padding ph / pw) and a dW that is
     // a channel slice of a wider weight tensor: dw[co][dw_coff + ci][tap] with dw_cin input channels per cout (0: cin)
     int kh = 0, kw = 0, ph = 0, pw = 0, dw_cin = 0, dw_coff = 0;
+    // wgrad_ring.hip only: the input as up to three channel-concatenated tensors (the torch.cat of model/update.py:44,51,79 is never
+    // materialised): xs[s] is [N][xsc[s]][hin][win]; nxseg = 0: the single tensor x above.  cin = the channels of all segments
+    int nxseg = 0;
+    const float* xs[3] = {nullptr, nullptr, nullptr};
+    int xsc[3] = {0, 0, 0};
 };
 
 int tr_loss_launch(const float* flow, const float* gt, const float* valid, float* dflow, int batch, int hw, float weight,
@@ -40,6 +45,11 @@ int wgrad_enc_launch(const WgradArgs& a, hipStream_t st);
 // honours kh / kw / ph / pw and dw_cin / dw_coff): E-RAFT's residual stacks, update block and heads
 bool wgrad_wide_supported(const WgradArgs& a);
 int wgrad_wide_launch(const WgradArgs& a, hipStream_t st);
+// round 6: the same jobs on LDS rings that run ahead of the MFMAs (wgrad_ring.hip: one 8-wave block per CU walks a run of output rows,
+// G staged once for up to 64 input channels); EEM_NO_WGRAD_RING=1 (read per call) keeps the kernels above
+bool wgrad_ring_supported(const WgradArgs& a);            // 3x3 (stride 1 / 2), 1x5, 5x1 (stride 1); cin, cout >= 16; honours kh / kw / dw_cin / dw_coff
+int wgrad_ring_launch(const WgradArgs& a, hipStream_t st);
+bool wgrad_ring_preferred(const WgradArgs& a);            // the shapes where it is the faster kernel (measured; EEM_WGRAD_RING=all / none)
 // several convs of the same kernel size / stride in one launch (blockIdx.z = job); at most WGRAD_MAX_JOBS
 #define WGRAD_MAX_JOBS 16
 int tr_wgrad_launch_batch(const WgradArgs* jobs, int njobs, hipStream_t st);

@@ -584,6 +584,7 @@ int tr_wgrad_launch_batch(const WgradArgs* jobs, int njobs, hipStream_t st) {
 }
 
 int tr_wgrad_launch(const WgradArgs& a, hipStream_t st) {
+    if (wgrad_ring_supported(a) && wgrad_ring_preferred(a)) return wgrad_ring_launch(a, st);
     if (wgrad_enc_supported(a)) return wgrad_enc_launch(a, st);
     return tr_wgrad_launch_batch(&a, 1, st);
 }

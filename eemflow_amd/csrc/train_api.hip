@@ -95,7 +95,8 @@ struct Bwd {
         w.zero_page = c->zero_page; w.db = grad + r.b;
         int rc = fork();
         if (rc != EEM_OK) return rc;
-        if (wgrad_enc_supported(w)) return wgrad_enc_launch(w, wst);         // weight and bias gradient in one kernel
+        if (wgrad_ring_supported(w) && wgrad_ring_preferred(w)) return wgrad_ring_launch(w, wst);   // weight and bias gradient in one kernel
+        if (wgrad_enc_supported(w)) return wgrad_enc_launch(w, wst);
         rc = tr_wgrad_launch(w, wst);
         if (rc != EEM_OK) return rc;
         return tr_bias_grad_launch(dy, y_gate, g_ctotal, g_coff, g_cmul, r.cout, n, hout * wout, grad + r.b, wst);

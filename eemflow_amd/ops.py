@@ -229,11 +229,11 @@ class Conv2d(torch.autograd.Function):
                     fork.record(cur)
                     side.wait_event(fork)
                     sw = ctypes.c_void_p(side.cuda_stream)
-                c0 = 0
-                for i, x in enumerate(xs):
-                    _lib.check(L.eemop_conv2d_bwd_weight(x.data_ptr(), dpre.data_ptr(), n, hin, win, cin, c0, cs[i], cout, kh, kw, stride, ph, pw,
-                                                         dw.data_ptr(), _ptr(db) if i == 0 else None, sw))
-                    c0 += cs[i]
+                # one call for all input segments (the GRU's [h | inp | motion]): the library takes them in one launch where that is faster
+                px = [x.data_ptr() for x in xs] + [None] * (3 - len(xs))
+                pc = cs + [0] * (3 - len(xs))
+                _lib.check(L.eemop_conv2d_bwd_weight_cat(px[0], pc[0], px[1], pc[1], px[2], pc[2], dpre.data_ptr(), n, hin, win, cout, kh, kw,
+                                                         stride, ph, pw, dw.data_ptr(), _ptr(db), sw))
                 if side is not None:
                     joined = torch.cuda.Event()
                     joined.record(side)

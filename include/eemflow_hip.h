@@ -432,6 +432,12 @@ int eemop_conv2d_bwd_data(const float* dy, const float* w, int n, int hin, int w
  * 1x5, 5x1, 7x7 (stride 1, 2; at most 32 input channels).  Replaces: autograd of nn.Conv2d w.r.t. weight and bias. */
 int eemop_conv2d_bwd_weight(const float* x, const float* dy, int n, int hin, int win, int cin, int ci0, int cic, int cout, int kh, int kw,
                             int stride, int ph, int pw, float* dw, float* db, void* stream);
+/* The same for a conv over up to three channel-concatenated inputs in ONE call (x_s [n][c_s][hin][win]; x1 / x2 may be NULL):
+ * dw [cout][c0 + c1 + c2][kh][kw] += dy (x) cat(x0, x1, x2), db [cout] += sum dy when not NULL.  The segments ride one launch where that
+ * is the faster form (the GRU's (1, 5) / (5, 1) convs over [h | inp | motion]), one launch per segment elsewhere.
+ * Replaces: autograd of nn.Conv2d w.r.t. its weight and bias for the convs of model/update.py:33-60,63-81 whose input is a torch.cat. */
+int eemop_conv2d_bwd_weight_cat(const float* x0, int c0, const float* x1, int c1, const float* x2, int c2, const float* dy, int n, int hin,
+                                int win, int cout, int kh, int kw, int stride, int ph, int pw, float* dw, float* db, void* stream);
 /* out = scale * dy * act'(y) for y = act(pre): kind 1 ReLU, 2 sigmoid, 3 tanh, 0 identity.  Replaces: autograd of F.relu /
  * torch.sigmoid / torch.tanh (model/update.py:14,45-47,54-56,74-79,95; model/eraft.py:130-131) and of the 0.25 mask scale (:105). */
 int eemop_act_bwd(const float* dy, const float* y, long long n, int kind, float scale, float* out, void* stream);

@@ -228,3 +228,103 @@ def test_bilinear_resize_adjoint(monkeypatch, form, n, h, w, oh, ow):
     _lib.check(_lib.lib().eemop_resize_ac_bwd(d.data_ptr(), dx.data_ptr(), n * 2, h, w, oh, ow, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
     torch.cuda.synchronize()
     assert rel(dx, x.grad) < 2e-5
+
+
+def _conv_wgrad(x, dy, cin_total, ci0, cout, kh, kw, stride, ph, pw):
+    """eemop_conv2d_bwd_weight on device tensors: (dw [cout][cin_total][kh][kw] with only the slice [ci0, ci0 + cic) written, db)."""
+    from eemflow_amd import _lib
+    n, cic, hin, win = x.shape
+    dw = torch.zeros(cout, cin_total, kh, kw, device=DEV)
+    db = torch.zeros(cout, device=DEV)
+    _lib.check(_lib.lib().eemop_conv2d_bwd_weight(x.data_ptr(), dy.data_ptr(), n, hin, win, cin_total, ci0, cic, cout, kh, kw, stride, ph, pw,
+                                                  dw.data_ptr(), db.data_ptr(), _lib.current_stream_ptr(torch.device(DEV))))
+    torch.cuda.synchronize()
+    return dw.cpu(), db.cpu()
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,n,h,w", [
+    (16, 16, (3, 3), 1, 3, 160, 192),     # pconv1_2 at C3's map (Cfg16x16: whole rows of 192, eight K parts)
+    (16, 16, (3, 3), 1, 2, 50, 640),      # ... C4's width: strips
+    (16, 32, (3, 3), 2, 3, 160, 192),     # pconv2_1 (stride 2: two new input rows per slice)
+    (32, 32, (3, 3), 1, 3, 80, 96),       # pconv2_2
+    (32, 32, (3, 3), 1, 1, 37, 320),      # ... strips of 80, a segment count that does not divide the rows
+    (32, 64, (3, 3), 2, 2, 80, 96),       # pconv3_1
+    (64, 64, (3, 3), 1, 3, 40, 48),       # pconv3_2
+    (64, 64, (3, 3), 1, 1, 96, 160),      # ... C4's map: two strips of 80
+    (384, 128, (1, 5), 1, 2, 60, 80),     # SepConvGRU convz1 (model/update.py:36): six input chunks, two cout chunks
+    (384, 128, (5, 1), 1, 2, 60, 80),     # convz2 (:40): strips of 40
+    (256, 192, (3, 3), 1, 1, 60, 80),     # convc2 (:67)
+    (128, 126, (3, 3), 1, 2, 30, 44),     # conv (:71): 126 couts = 64 + 62; a width that is 4 mod 8
+    (96, 80, (3, 3), 1, 1, 20, 36),       # channel remainders on both sides (96 = 64 + 32, 80 = 64 + 16)
+    (64, 96, (3, 3), 2, 2, 120, 160),     # the encoders' downsampling conv (model/extractor.py:13, layer2)
+    (96, 128, (3, 3), 2, 1, 62, 84),      # ... layer3, odd output extents
+])
+def test_weight_gradient_ring_kernel(monkeypatch, cin, cout, k, stride, n, h, w):
+    """wgrad_ring.hip (round 6: LDS rings of G slices and X rows that run ahead of the MFMAs, one 8-wave block per run of output rows)
+    against torch autograd in float64 (conv2d's weight / bias gradient, model/update.py:33-60, EEMFlow.py:75-82 under
+    train_mvsec.py:253-258) and against the kernel it replaces (EEM_NO_WGRAD_RING=1, read per call): <= 2e-5 of the largest gradient.
+    Every block configuration, strips, ragged segments, channel remainders, stride 2, an input-channel slice of a wider weight."""
+    g = torch.Generator().manual_seed(cin * 7 + cout + k[0])
+    kh, kw = k
+    ph, pw = kh // 2, kw // 2
+    x = torch.randn(n, cin, h, w, generator=g)
+    hout, wout = (h + 2 * ph - kh) // stride + 1, (w + 2 * pw - kw) // stride + 1
+    dy = torch.randn(n, cout, hout, wout, generator=g)
+    wt = torch.zeros(cout, cin, kh, kw, dtype=torch.float64, requires_grad=True)
+    bs = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    out = torch.nn.functional.conv2d(x.double(), wt, bs, stride=stride, padding=(ph, pw))
+    out.backward(dy.double())
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    monkeypatch.delenv("EEM_NO_WGRAD_RING", raising=False)
+    monkeypatch.setenv("EEM_WGRAD_RING", "all")              # (by default only the shapes where it is the faster kernel take it)
+    dw_r, db_r = _conv_wgrad(xd, dyd, cin, 0, cout, kh, kw, stride, ph, pw)
+    monkeypatch.setenv("EEM_NO_WGRAD_RING", "1")
+    dw_o, db_o = _conv_wgrad(xd, dyd, cin, 0, cout, kh, kw, stride, ph, pw)
+    scale = float(wt.grad.abs().max())
+    assert rel(dw_r, wt.grad) < 2e-5 and rel(db_r, bs.grad) < 2e-5, (rel(dw_r, wt.grad), rel(db_r, bs.grad))
+    assert float((dw_r - dw_o).abs().max()) < 2e-5 * scale and not torch.equal(dw_r, dw_o)      # (the switch did switch)
+    assert float((db_r - db_o).abs().max()) < 2e-5 * float(bs.grad.abs().max())
+    # an input-channel slice of a wider weight tensor (the GRU's [h | x] inputs, ops.Conv2d.backward: one call per input segment)
+    monkeypatch.delenv("EEM_NO_WGRAD_RING", raising=False)
+    lo = 16 if cin >= 48 else 0
+    cic = cin - lo - (16 if cin >= 64 else 0)
+    dw_s, _ = _conv_wgrad(xd[:, lo:lo + cic].contiguous(), dyd, cin, lo, cout, kh, kw, stride, ph, pw)
+    assert float((dw_s[:, lo:lo + cic] - wt.grad[:, lo:lo + cic].float()).abs().max()) < 2e-5 * scale
+    rest = torch.ones(cin, dtype=torch.bool)
+    rest[lo:lo + cic] = False
+    assert float(dw_s[:, rest].abs().max() if rest.any() else 0.0) == 0.0                         # nothing outside the slice is touched
+
+
+@pytest.mark.parametrize("cs,cout,k,n,h,w", [((128, 128, 128), 128, (1, 5), 2, 60, 80), ((128, 128, 128), 128, (5, 1), 2, 60, 80),
+                                              ((192, 64), 126, (3, 3), 1, 60, 80), ((128, 256), 128, (5, 1), 1, 36, 44),
+                                              ((96, 48, 16), 96, (3, 3), 1, 24, 32)])
+@pytest.mark.parametrize("ring", ["all", "none", "default"])
+def test_weight_gradient_of_concatenated_inputs(monkeypatch, cs, cout, k, n, h, w, ring):
+    """eemop_conv2d_bwd_weight_cat: the weight / bias gradient of a conv whose input is a torch.cat of up to three tensors
+    (model/update.py:44,51 hx = cat([h, x]); :79 cat([out, flow])) in ONE call - on the ring kernel all segments ride one launch (a block's
+    64-channel input chunk is looked up in the segment that holds it; remainders at segment ends) - against torch autograd in float64,
+    with the ring kernel forced (EEM_WGRAD_RING=all), refused (none: one launch per segment on the old kernels) and by the default policy."""
+    from eemflow_amd import _lib
+    if ring == "default":
+        monkeypatch.delenv("EEM_WGRAD_RING", raising=False)
+    else:
+        monkeypatch.setenv("EEM_WGRAD_RING", ring)
+    g = torch.Generator().manual_seed(sum(cs) + cout)
+    kh, kw = k
+    ph, pw = kh // 2, kw // 2
+    xs = [torch.randn(n, c, h, w, generator=g) for c in cs]
+    dy = torch.randn(n, cout, h, w, generator=g)
+    cin = sum(cs)
+    wt = torch.zeros(cout, cin, kh, kw, dtype=torch.float64, requires_grad=True)
+    bs = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(torch.cat(xs, 1).double(), wt, bs, padding=(ph, pw)).backward(dy.double())
+    xd = [x.to(DEV) for x in xs]
+    dyd = dy.to(DEV)
+    dw = torch.zeros(cout, cin, kh, kw, device=DEV)
+    db = torch.zeros(cout, device=DEV)
+    px = [x.data_ptr() for x in xd] + [None] * (3 - len(xd))
+    pc = list(cs) + [0] * (3 - len(cs))
+    _lib.check(_lib.lib().eemop_conv2d_bwd_weight_cat(px[0], pc[0], px[1], pc[1], px[2], pc[2], dyd.data_ptr(), n, h, w, cout, kh, kw, 1, ph, pw,
+                                                      dw.data_ptr(), db.data_ptr(), _lib.current_stream_ptr(torch.device(DEV))))
+    torch.cuda.synchronize()
+    assert rel(dw, wt.grad) < 2e-5 and rel(db, bs.grad) < 2e-5, (rel(dw, wt.grad), rel(db, bs.grad))

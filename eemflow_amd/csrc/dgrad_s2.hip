@@ -220,6 +220,179 @@ int launch(const DgradS2Args& a, hipStream_t st) {
     return EEM_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------ wide layers (E-RAFT's encoders)
+// The same four parity classes for model/extractor.py's downsampling convs (layer2: 64 <- 96, layer3: 96 <- 128 channels; the 3x3 conv of
+// the residual block and its 1x1 stride-2 shortcut, :13,:33-36 under autograd) - round 6; before, these ran the generic kernel's per-tap
+// parity test (830 us x 8 per training step, 20 x their MACs' time).  Differences to the kernel above: a block owns ONE 16-channel tile
+// of dX (blockIdx.y) with the weights of ALL couts resident in LDS ([tap][co][16 ci]: 55 / 74 KB), and walks its tiles with the dY patch
+// arriving in chunks of 32 couts through two LDS stages (the next chunk - or the next tile's first - is requested right after the barrier
+// that hands over the current one); K1 = the 1x1 shortcut: one tap, one class, the other three classes of dX are zeros.
+constexpr int D2W_KC = 32;                                   // couts per staged chunk
+template <int CO, bool K1>
+struct D2WCfg {
+    static constexpr int TAPS = K1 ? 1 : 9;
+    static constexpr int NCH = CO / D2W_KC;
+    static constexpr int WFL = TAPS * CO * 16;
+    static constexpr int SLOTS = D2W_KC * D2_PQ;
+    static constexpr int NI = (SLOTS + 255) / 256;
+    static constexpr int STAGE = NI * 256 * 4;
+    static_assert(CO % D2W_KC == 0, "cout chunks");
+    static_assert((WFL + 2 * STAGE) * 4 <= 160 * 1024, "LDS budget");
+};
+
+template <int CO, bool K1>
+__global__ __launch_bounds__(256) void dgrad_s2w_kernel(DgradS2Args a, int tiles_x, int tiles_y) {
+    using C = D2WCfg<CO, K1>;
+    constexpr int TAPS = C::TAPS, NCH = C::NCH;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wl = lds;
+    float* st0 = lds + C::WFL;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int ci0 = blockIdx.y * 16;
+
+    const TileRange tr_ = block_tile_range(tiles_x * tiles_y * a.n, blockIdx.x, gridDim.x);
+    if (tr_.count == 0) return;
+    TileCoord cur = tile_coord(tr_.first, tiles_x, tiles_y);
+    const size_t yhw = (size_t)a.hout * a.wout, xhw = (size_t)a.hin * a.win;
+
+    // weights: wl[(tap * CO + co) * 16 + i] = W[co][ci0 + i][tap]   (channels past cin read as zero)
+    for (int e = threadIdx.x; e < C::WFL; e += 256) {
+        const int i = e & 15, co = (e >> 4) % CO, tap = (e >> 4) / CO;
+        wl[e] = ci0 + i < a.cin ? a.w[((size_t)co * a.cin + ci0 + i) * TAPS + tap] : 0.f;
+    }
+
+    int off[C::NI], rc[C::NI];
+#pragma unroll
+    for (int k = 0; k < C::NI; ++k) {
+        const int f = (wave + 4 * k) * 64 + lane;
+        const int co = f / D2_PQ, q = f - co * D2_PQ;
+        const int row = q / 5, pc = q - row * 5;
+        const bool ok = f < C::SLOTS && q < D2_RY * 5;
+        off[k] = (int)(((size_t)co * yhw + (size_t)row * a.wout + 4 * pc) * 4);
+        rc[k] = ok ? (row | ((4 * pc) << 8)) : -1;
+    }
+    const char* zero = reinterpret_cast<const char*>(a.zero_page);
+    float* __restrict__ dx = a.dx;
+    auto issue = [&](int stage, const TileCoord& tc, int ch) {
+        const int oy0 = tc.by * (D2_TH / 2), ox0 = tc.bx * (D2_TW / 2);
+        const char* yb = reinterpret_cast<const char*>(a.dy + ((size_t)tc.n * CO + ch * D2W_KC) * yhw) + ((size_t)oy0 * a.wout + ox0) * 4;
+        float* sb = st0 + stage * C::STAGE;
+#pragma unroll
+        for (int k = 0; k < C::NI; ++k) {
+            const bool ok = rc[k] >= 0 && oy0 + (rc[k] & 255) < a.hout && ox0 + (rc[k] >> 8) < a.wout;
+            const char* p = ok ? yb + off[k] : zero;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(p), LDS_PTR(sb + (wave + 4 * k) * 256), 16, 0, 0);
+        }
+    };
+
+    issue(0, cur, 0);
+    TileCoord nxt = cur;
+    int nch_next = 0;                                            // chunk the NEXT step stages
+    const int aoff = g * 16 + j;                                 // weight fragment: co = 4kk + g, ci = j
+    const int boff = g * D2_PL + j;                              // dY fragment: co = 4kk + g, column j
+    f32x4 acc[2][2][2];                                          // [row parity][column parity][pixel row of the wave]
+    bool stored = false;                                         // the previous step ended with the tile's stores (they may stay in flight)
+    const int steps = tr_.count * NCH;
+    int ch = 0;
+#pragma unroll 1
+    for (int t = 0; t < steps; ++t) {
+        if (stored) wait_vmcnt<16>();                            // the step's DMA is older than the 16 stores behind it: it has landed
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                         // (first pass: the weights too)
+        const float* sb = st0 + (t & 1) * C::STAGE;
+        if (t + 1 < steps) {
+            if (++nch_next == NCH) { nch_next = 0; tile_advance(nxt, tiles_x, tiles_y); }
+            issue((t + 1) & 1, nxt, nch_next);
+        }
+        if (ch == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) (&acc[0][0][0])[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const float* wc = wl + ch * D2W_KC * 16;
+#pragma unroll 2
+        for (int kk = 0; kk < D2W_KC / 4; ++kk) {
+            float bv[2][2][2];                                   // [row offset][column offset][pixel row]
+#pragma unroll
+            for (int ro = 0; ro < (K1 ? 1 : 2); ++ro)
+#pragma unroll
+                for (int cofs = 0; cofs < (K1 ? 1 : 2); ++cofs)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+                        bv[ro][cofs][tt] = sb[boff + kk * 4 * D2_PL + (wave + 4 * tt + ro) * D2_CX + cofs];
+            if (K1) {
+                const float av = wc[kk * 64 + aoff];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+                    acc[0][0][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[0][0][tt], acc[0][0][tt], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int pr = ky != 1, pcn = kx != 1;   // parity class this tap feeds
+                        const int ro = ky == 0, cofs = kx == 0;  // dY offset: +1 for tap 0, 0 for taps 1 and 2
+                        const float av = wc[(ky * 3 + kx) * CO * 16 + kk * 64 + aoff];
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt)
+                            acc[pr][pcn][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[ro][cofs][tt], acc[pr][pcn][tt], 0, 0, 0);
+                    }
+            }
+        }
+        stored = false;
+        if (++ch == NCH) {
+            ch = 0;
+            // ---- epilogue: D[ci = 4g + r][pixel j]; the two column parities of a lane are neighbours in dX
+            const int iy0 = cur.by * D2_TH, ix0 = cur.bx * D2_TW;
+            const int ix = ix0 + 2 * j;
+            const bool colok = ix < a.win;
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int iy = iy0 + 2 * (wave + 4 * tt) + pr;
+                    const bool inside = iy < a.hin && colok;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ci = ci0 + 4 * g + r;
+                        const size_t o = ((size_t)cur.n * a.cin + ci) * xhw + (size_t)iy * a.win + ix;
+                        const f32x2 v = {acc[pr][0][tt][r], acc[pr][1][tt][r]};
+                        float* q = (inside && ci < a.cin) ? dx + o : a.trash + lane * 2;       // uniform store count for the counted wait
+                        *reinterpret_cast<f32x2*>(q) = v;
+                    }
+                }
+            stored = true;
+            tile_advance(cur, tiles_x, tiles_y);
+        }
+    }
+}
+
+template <int CO, bool K1>
+int launch_wide(const DgradS2Args& a, hipStream_t st) {
+    using C = D2WCfg<CO, K1>;
+    const int tiles_x = ceil_div(a.win, D2_TW), tiles_y = ceil_div(a.hin, D2_TH);
+    const int T = tiles_x * tiles_y * a.n;
+    const int lds_bytes = (C::WFL + 2 * C::STAGE) * 4;
+    const int citiles = ceil_div(a.cin, 16);
+    int per_cu = (160 * 1024) / lds_bytes;
+    per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+    int gx = (256 * per_cu) / citiles;                           // ~per_cu resident blocks per CU over all channel tiles
+    gx = (gx + 7) & ~7;
+    if (gx < 8) gx = 8;
+    const int need = ceil_div(T, 8) * 8;
+    if (gx > need) gx = need;
+    static bool raised = false;
+    if (!raised) {
+        EEM_HIP_CHECK(hipFuncSetAttribute((const void*)dgrad_s2w_kernel<CO, K1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        raised = true;
+    }
+    hipLaunchKernelGGL((dgrad_s2w_kernel<CO, K1>), dim3(gx, citiles), dim3(256), lds_bytes, st, a, tiles_x, tiles_y);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
 }  // namespace
 
 bool dgrad_s2_supported(const DgradS2Args& a) {
@@ -234,4 +407,18 @@ bool dgrad_s2_supported(const DgradS2Args& a) {
 int dgrad_s2_launch(const DgradS2Args& a, hipStream_t st) {
     if (a.cout == 32) return launch<32, 16, 2>(a, st);
     return launch<64, 32, 1>(a, st);
+}
+
+// wide layers: cout 96 or 128, any cin; k = 3 (pad 1) or k = 1 (pad 0): DgradS2Args::pool_k carries the kernel size here (no pooling branch)
+bool dgrad_s2w_supported(const DgradS2Args& a, int ksize) {
+    const char* e = getenv("EEM_NO_DGRAD_S2W");                     // read per call: a test flips it inside one process
+    if (e && e[0] == '1') return false;
+    return (a.cout == 96 || a.cout == 128) && (ksize == 3 || ksize == 1) && a.zero_page && a.trash && a.gate == nullptr && a.dpool == nullptr &&
+           a.wout % 4 == 0 && a.win % 2 == 0 && a.hout == (a.hin + 1) / 2 && a.wout == (a.win + 1) / 2 && ((uintptr_t)a.dy & 15) == 0 &&
+           ((uintptr_t)a.dx & 7) == 0 && (size_t)a.cout * a.hout * a.wout * 4 < (1u << 31);
+}
+
+int dgrad_s2w_launch(const DgradS2Args& a, int ksize, hipStream_t st) {
+    if (ksize == 1) return a.cout == 96 ? launch_wide<96, true>(a, st) : launch_wide<128, true>(a, st);
+    return a.cout == 96 ? launch_wide<96, false>(a, st) : launch_wide<128, false>(a, st);
 }

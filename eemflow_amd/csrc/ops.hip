@@ -374,7 +374,7 @@ struct Plan {
 std::map<std::string, Plan> g_plans;              // per process; the tables depend on layer shapes only
 std::mutex g_plans_mutex;                         // autograd runs backward ops on its own thread
 struct Scratch { float* p = nullptr; size_t cap = 0; int dev = -1; };
-thread_local Scratch g_scratch[3];                // [0] packed weights, [1] zero bias / zero page, [2] the bf16-piece packing
+thread_local Scratch g_scratch[4];                // [0] packed weights, [1] zero bias / zero page, [2] the bf16-piece packing, [3] store sink
 
 int scratch_get(Scratch& s, size_t floats, float** out) {
     int dev = 0;
@@ -647,10 +647,22 @@ extern "C" int eemop_conv2d_bwd_data(const float* dy, const float* w, int n, int
     EEM_REQUIRE(dy && w && dx && cic >= 1 && ci0 >= 0 && ci0 + cic <= cin, "eemop_conv2d_bwd_data: bad arguments");
     EEM_REQUIRE(stride == 1 || stride == 2, "eemop_conv2d_bwd_data: stride %d", stride);
     hipStream_t st = (hipStream_t)stream;
-    Plan* pl = nullptr;
-    int rc = plan_bwd(cout, cin, ci0, cic, kh, kw, &pl);
-    if (rc != EEM_OK) return rc;
     const int hout = (hin + 2 * ph - kh) / stride + 1, wout = (win + 2 * pw - kw) / stride + 1;
+    int rc;
+    if (stride == 2 && ci0 == 0 && cic == cin && kh == kw && ((kh == 3 && ph == 1 && pw == 1) || (kh == 1 && ph == 0 && pw == 0))) {
+        // the encoders' downsampling convs (model/extractor.py:13,33-36): four parity classes of dX as dense convs of dY (dgrad_s2.hip)
+        DgradS2Args d;
+        memset(&d, 0, sizeof(d));
+        d.dy = dy; d.w = w; d.dx = dx;
+        d.n = n; d.cin = cin; d.cout = cout; d.hin = hin; d.win = win; d.hout = hout; d.wout = wout;
+        float *zp = nullptr, *sink = nullptr;
+        if ((rc = scratch_get(g_scratch[1], 1024, &zp)) != EEM_OK || (rc = scratch_get(g_scratch[3], 1024, &sink)) != EEM_OK) return rc;
+        d.zero_page = zp; d.trash = sink;
+        if (dgrad_s2w_supported(d, kh)) return dgrad_s2w_launch(d, kh, st);
+    }
+    Plan* pl = nullptr;
+    rc = plan_bwd(cout, cin, ci0, cic, kh, kw, &pl);
+    if (rc != EEM_OK) return rc;
     GConvArgs a;
     memset(&a, 0, sizeof(a));
     a.nseg = 1;

@@ -68,6 +68,9 @@ struct DgradS2Args {
 };
 bool dgrad_s2_supported(const DgradS2Args& a);
 int dgrad_s2_launch(const DgradS2Args& a, hipStream_t st);
+// the same for wide layers (E-RAFT's encoders: cout 96 / 128, any cin; 3x3 pad 1 or the 1x1 pad-0 shortcut): no gate, no pooling branch
+bool dgrad_s2w_supported(const DgradS2Args& a, int ksize);
+int dgrad_s2w_launch(const DgradS2Args& a, int ksize, hipStream_t st);
 int tr_sumsq_launch(const float* g, long n, double* out, hipStream_t st);
 int tr_adamw_launch(float* p, const float* g, float* m, float* v, long n, const double* sumsq, float clip, float lr, float wd,
                     float eps, float b1, float b2, long step, int* nskip, hipStream_t st);

@@ -112,6 +112,7 @@ __global__ __launch_bounds__(512) void wgrad_ring_kernel(WgradArgs a, RingGeom q
             }
         }
     }
+    (void)xptr; (void)x_ct; (void)x_co;                          // (read by the device pass only)
     const int ci_loc = local * CW;                                // first channel of the chunk inside its segment
     const int ci_base = seg_start + ci_loc, co_base = chunk_co * MT * 16;      // ... and inside the concatenated input (dW's column)
     const int cin_here = min(CW, seg_c - ci_loc), cout_here = min(MT * 16, a.cout - co_base);

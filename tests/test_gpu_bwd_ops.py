@@ -328,3 +328,34 @@ def test_weight_gradient_of_concatenated_inputs(monkeypatch, cs, cout, k, n, h, 
                                                       dw.data_ptr(), db.data_ptr(), _lib.current_stream_ptr(torch.device(DEV))))
     torch.cuda.synchronize()
     assert rel(dw, wt.grad) < 2e-5 and rel(db, bs.grad) < 2e-5, (rel(dw, wt.grad), rel(db, bs.grad))
+
+
+@pytest.mark.parametrize("cin,cout,k,n,h,w", [(64, 96, 3, 2, 240, 320), (96, 128, 3, 3, 120, 160), (64, 96, 1, 2, 240, 320), (96, 128, 1, 1, 120, 160),
+                                               (64, 96, 3, 1, 46, 72), (80, 128, 3, 1, 34, 40), (96, 128, 1, 2, 30, 24)])
+def test_stride_two_data_gradient_of_the_wide_layers(monkeypatch, cin, cout, k, n, h, w):
+    """dgrad_s2w_kernel (round 6): the data gradient of the encoders' downsampling convs (model/extractor.py:13 3x3 stride 2; :33-36 the 1x1
+    stride-2 shortcut) as four parity classes of dX computed from dY - against torch autograd in float64 and against the generic kernel's
+    per-tap parity test (EEM_NO_DGRAD_S2W=1, read per call).  Ragged tiles, a channel count that is not a multiple of 16, odd output extents
+    are refused (the generic kernel takes them)."""
+    from eemflow_amd import _lib
+    g = torch.Generator().manual_seed(cin + cout + k)
+    pad = k // 2
+    hout, wout = (h + 2 * pad - k) // 2 + 1, (w + 2 * pad - k) // 2 + 1
+    wt = torch.randn(cout, cin, k, k, generator=g) * 0.1
+    dy = torch.randn(n, cout, hout, wout, generator=g)
+    x = torch.zeros(n, cin, h, w, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(x, wt.double(), None, stride=2, padding=pad).backward(dy.double())
+    wd, dyd = wt.to(DEV), dy.to(DEV)
+
+    def run():
+        dx = torch.full((n, cin, h, w), float("nan"), device=DEV)
+        _lib.check(_lib.lib().eemop_conv2d_bwd_data(dyd.data_ptr(), wd.data_ptr(), n, h, w, cin, 0, cin, cout, k, k, 2, pad, pad, dx.data_ptr(),
+                                                    _lib.current_stream_ptr(torch.device(DEV))))
+        torch.cuda.synchronize()
+        return dx.cpu()
+    monkeypatch.delenv("EEM_NO_DGRAD_S2W", raising=False)
+    fast = run()
+    monkeypatch.setenv("EEM_NO_DGRAD_S2W", "1")
+    gen = run()
+    assert rel(fast, x.grad) < 2e-5 and rel(gen, x.grad) < 2e-5, (rel(fast, x.grad), rel(gen, x.grad))
+    assert not torch.equal(fast, gen) or k == 1

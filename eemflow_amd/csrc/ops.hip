@@ -704,6 +704,7 @@ extern "C" int eemop_conv2d_bwd_weight(const float* x, const float* dy, int n, i
         if ((rc = scratch_get(g_scratch[1], 1024, &zp)) != EEM_OK) return rc;
         a.zero_page = zp;
         if (wgrad_ring_supported(a) && wgrad_ring_preferred(a)) return wgrad_ring_launch(a, st);
+        if (wgrad_few_supported(a)) return wgrad_few_launch(a, st);                          // (<= 8 couts: the flow heads)
         if (kh == 3 && kw == 3 && wgrad_enc_supported(a)) return wgrad_enc_launch(a, st);   // (16 / 32 / 64 couts on blocks of their own height)
         if (wgrad_wide_supported(a)) return wgrad_wide_launch(a, st);
     }

@@ -50,6 +50,10 @@ int wgrad_wide_launch(const WgradArgs& a, hipStream_t st);
 bool wgrad_ring_supported(const WgradArgs& a);            // 3x3 (stride 1 / 2), 1x5, 5x1 (stride 1); cin, cout >= 16; honours kh / kw / dw_cin / dw_coff
 int wgrad_ring_launch(const WgradArgs& a, hipStream_t st);
 bool wgrad_ring_preferred(const WgradArgs& a);            // the shapes where it is the faster kernel (measured; EEM_WGRAD_RING=all / none)
+// 3x3 stride-1 convs of at most 8 couts on the vector pipe, weight and bias gradient in one launch (train.hip); x / x_ctotal / x_coff,
+// g / g_ctotal / g_coff, dw_cin / dw_coff, db as above
+bool wgrad_few_supported(const WgradArgs& a);
+int wgrad_few_launch(const WgradArgs& a, hipStream_t st);
 // several convs of the same kernel size / stride in one launch (blockIdx.z = job); at most WGRAD_MAX_JOBS
 #define WGRAD_MAX_JOBS 16
 int tr_wgrad_launch_batch(const WgradArgs* jobs, int njobs, hipStream_t st);

@@ -583,6 +583,100 @@ int tr_wgrad_launch_batch(const WgradArgs* jobs, int njobs, hipStream_t st) {
     return EEM_ERR_ARG;
 }
 
+// ---- weight gradient of a 3x3 stride-1 conv with at most 8 couts (E-RAFT's flow head 256 -> 2, model/update.py:10; EEMFlow+'s
+// 32 -> 2 flow convs) on the vector pipe: on the matrix cores a 2-cout layer is 94 % padding (the generic kernel: 212 us for 88 MFLOP).
+// A block = one input channel x a range of pixels; a thread accumulates cout x 9 products for its pixels (nine neighbours of X - clamped
+// addresses, the condition on the value - and cout values of G), the block sums them (DPP inside a wave, LDS across the four) and
+// leaves with one atomic per weight.  The bias gradient rides in the blocks of input channel 0.
+template <int COUT>
+__global__ __launch_bounds__(256) void wgrad_few_kernel(WgradArgs a, int per_block) {
+    __shared__ float sh[4][COUT * 9 + COUT];
+    const int ci = blockIdx.x;
+    const int hw = a.hout * a.wout;
+    const long total = (long)a.n * hw;
+    const long p0 = (long)blockIdx.y * per_block, p1 = p0 + per_block < total ? p0 + per_block : total;
+    float acc[COUT][9], bs[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) {
+        bs[c] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
+    }
+    const float* __restrict__ g = a.g;
+    const float* __restrict__ x = a.x;
+    for (long p = p0 + threadIdx.x; p < p1; p += 256) {
+        const int n = (int)(p / hw), q = (int)(p - (long)n * hw);
+        const int y = q / a.wout, xx = q - y * a.wout;
+        float gv[COUT];
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) gv[c] = c < a.cout ? g[((size_t)n * a.g_ctotal + a.g_coff + c) * hw + q] : 0.f;
+        const float* xp = x + ((size_t)n * a.x_ctotal + a.x_coff + ci) * hw;
+        float xv[9];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = y + ky - 1, ix = xx + kx - 1;
+                const bool in = iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
+                const float v = xp[(size_t)min(max(iy, 0), a.hin - 1) * a.win + min(max(ix, 0), a.win - 1)];
+                xv[ky * 3 + kx] = in ? v : 0.f;
+            }
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) {
+            bs[c] += gv[c];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[c][t] += gv[c] * xv[t];
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            float v = lane_group_sum<16>(acc[c][t]);
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (lane == 0) sh[wave][c * 9 + t] = v;
+        }
+        float v = lane_group_sum<16>(bs[c]);
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lane == 0) sh[wave][COUT * 9 + c] = v;
+    }
+    __syncthreads();
+    const int dwcin = a.dw_cin ? a.dw_cin : a.cin;
+    if ((int)threadIdx.x < a.cout * 9) {
+        const int c = threadIdx.x / 9, t = threadIdx.x - c * 9;
+        atomicAdd(&a.dw[((size_t)c * dwcin + a.dw_coff + ci) * 9 + t], sh[0][c * 9 + t] + sh[1][c * 9 + t] + sh[2][c * 9 + t] + sh[3][c * 9 + t]);
+    }
+    if (a.db && ci == 0 && (int)threadIdx.x < a.cout) {
+        const int k = COUT * 9 + threadIdx.x;
+        atomicAdd(&a.db[threadIdx.x], sh[0][k] + sh[1][k] + sh[2][k] + sh[3][k]);
+    }
+}
+
+bool wgrad_few_supported(const WgradArgs& a) {
+    const char* e = getenv("EEM_NO_WGRAD_FEW");                       // read per call: a test flips it inside one process
+    if (e && e[0] == '1') return false;
+    const int kh = a.kh ? a.kh : a.k, kw = a.kh ? a.kw : a.k, ph = a.kh ? a.ph : a.pad, pw = a.kh ? a.pw : a.pad;
+    return kh == 3 && kw == 3 && ph == 1 && pw == 1 && a.stride == 1 && a.cout >= 1 && a.cout <= 8 && a.gate == nullptr && a.g_cmul == 1 &&
+           a.nxseg == 0 && a.hin == a.hout && a.win == a.wout;
+}
+
+int wgrad_few_launch(const WgradArgs& a, hipStream_t st) {
+    const long total = (long)a.n * a.hout * a.wout;
+    int splits = (512 + a.cin - 1) / a.cin;                            // ~2 blocks per CU
+    const long min_px = 2048;
+    if ((long)splits * min_px > total) splits = (int)((total + min_px - 1) / min_px);
+    if (splits < 1) splits = 1;
+    const int per_block = (int)((total + splits - 1) / splits);
+    if (a.cout <= 2) hipLaunchKernelGGL((wgrad_few_kernel<2>), dim3(a.cin, splits), dim3(256), 0, st, a, per_block);
+    else if (a.cout <= 4) hipLaunchKernelGGL((wgrad_few_kernel<4>), dim3(a.cin, splits), dim3(256), 0, st, a, per_block);
+    else hipLaunchKernelGGL((wgrad_few_kernel<8>), dim3(a.cin, splits), dim3(256), 0, st, a, per_block);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
 int tr_wgrad_launch(const WgradArgs& a, hipStream_t st) {
     if (wgrad_ring_supported(a) && wgrad_ring_preferred(a)) return wgrad_ring_launch(a, st);
     if (wgrad_enc_supported(a)) return wgrad_enc_launch(a, st);

@@ -359,3 +359,28 @@ def test_stride_two_data_gradient_of_the_wide_layers(monkeypatch, cin, cout, k, 
     gen = run()
     assert rel(fast, x.grad) < 2e-5 and rel(gen, x.grad) < 2e-5, (rel(fast, x.grad), rel(gen, x.grad))
     assert not torch.equal(fast, gen) or k == 1
+
+
+@pytest.mark.parametrize("cin,cout,n,h,w", [(256, 2, 4, 60, 80), (32, 2, 2, 45, 64), (176, 8, 1, 24, 40), (40, 3, 2, 17, 36)])
+def test_weight_gradient_of_the_few_output_layers(monkeypatch, cin, cout, n, h, w):
+    """wgrad_few_kernel (round 6): weight + bias gradient of the 3x3 convs with <= 8 couts (E-RAFT's flow head 256 -> 2, model/update.py:10;
+    EEMFlow+'s 32 -> 2 flow convs and 176 -> 8 mask estimator) on the vector pipe, against torch autograd in float64 and against the
+    matrix-core kernel it replaces there (EEM_NO_WGRAD_FEW=1, read per call); an input-channel slice of a wider weight."""
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(n, cin, h, w, generator=g)
+    dy = torch.randn(n, cout, h, w, generator=g)
+    wt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    bs = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(x.double(), wt, bs, padding=1).backward(dy.double())
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    monkeypatch.delenv("EEM_NO_WGRAD_FEW", raising=False)
+    dw_f, db_f = _conv_wgrad(xd, dyd, cin, 0, cout, 3, 3, 1, 1, 1)
+    monkeypatch.setenv("EEM_NO_WGRAD_FEW", "1")
+    dw_o, db_o = _conv_wgrad(xd, dyd, cin, 0, cout, 3, 3, 1, 1, 1)
+    assert rel(dw_f, wt.grad) < 2e-5 and rel(db_f, bs.grad) < 2e-5 and rel(dw_o, wt.grad) < 2e-5
+    assert not torch.equal(dw_f, dw_o)
+    monkeypatch.delenv("EEM_NO_WGRAD_FEW", raising=False)
+    lo, cic = 8, cin - 16
+    dw_s, _ = _conv_wgrad(xd[:, lo:lo + cic].contiguous(), dyd, cin, lo, cout, 3, 3, 1, 1, 1)
+    assert rel(dw_s[:, lo:lo + cic], wt.grad[:, lo:lo + cic]) < 2e-5
+    assert float(dw_s[:, :lo].abs().max()) == 0.0 and float(dw_s[:, lo + cic:].abs().max()) == 0.0

@@ -66,6 +66,8 @@ extern "C" void eemflow_destroy(eemflow_ctx* c) {
                         &c->g_pool[k], &c->g_cat[k], &c->g_ta[k], &c->g_tb[k], &c->g_tc[k], &c->g_td[k], &c->g_t64[k], &c->g_t32[k]};
         for (DevBuf* b : kb) if (b->p) (void)hipFree(b->p);
     }
+    if (c->cstream) { (void)hipStreamSynchronize(c->cstream); (void)hipStreamDestroy(c->cstream); }
+    if (c->loss_ev) (void)hipEventDestroy(c->loss_ev);
     if (c->stats_ev) (void)hipEventDestroy(c->stats_ev);
     if (c->stats_host) (void)hipHostFree(c->stats_host);
     for (hipEvent_t e : c->span_ev) if (e) (void)hipEventDestroy(e);

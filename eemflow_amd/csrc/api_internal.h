@@ -141,6 +141,8 @@ struct eemflow_ctx {
     double* stats_host = nullptr;
     hipEvent_t stats_ev = nullptr;
     bool stats_pending = false;
+    hipStream_t cstream = nullptr;                       // the statistics' copy stream: the loss sums leave right behind the loss kernel
+    hipEvent_t loss_ev = nullptr;                        // (round 6), not behind the whole backward
     double stats_scale = 0.0;                            // gamma weight / (B * 2 * out_h * out_w) of the forward they belong to
     // inference leaves f13 unwritten when pconv3_3's epilogue pools it (nothing else reads it); the training forward keeps every
     // activation (keep_stage_stores), and eemflow_get_stage("f13") re-runs the layer with stores when the last forward skipped them

@@ -29,6 +29,9 @@ int tr_pool_bwd_launch(const float* dpool, float* g, long nc, int h, int w, int 
                        hipStream_t st);
 int tr_corr_bwd_launch(const float* dcv, int dcv_ctotal, const float* f1, const float* f2, float* d1, float* d2, int batch, int c,
                        int h, int w, const int* taps, int ntaps, hipStream_t st);
+struct CorrBwdJob { const float* dcv; const float* f1; const float* f2; float* d1; float* d2; int dcv_ctotal, c; };
+// up to three correlations of one grid shape in one launch (the three stages of the tail)
+int tr_corr_bwd_launch_jobs(const CorrBwdJob* jobs, int njobs, int batch, int h, int w, const int* taps, int ntaps, hipStream_t st);
 int tr_bias_grad_launch(const float* g, const float* gate, int g_ctotal, int g_coff, int g_cmul, int cout, int n, int hw, float* db,
                         hipStream_t st);
 struct BiasJob {
@@ -54,6 +57,9 @@ bool wgrad_ring_preferred(const WgradArgs& a);            // the shapes where it
 // g / g_ctotal / g_coff, dw_cin / dw_coff, db as above
 bool wgrad_few_supported(const WgradArgs& a);
 int wgrad_few_launch(const WgradArgs& a, hipStream_t st);
+// every 3x3 conv of the 1/64-grid tail (all decoders, groups and layers) in ONE launch: weight and bias gradients (wgrad_tail.hip)
+bool wgrad_tail_supported(const WgradArgs* jobs, int njobs, int n, int h, int w);
+int wgrad_tail_launch(const WgradArgs* jobs, int njobs, int n, int h, int w, hipStream_t st);
 // several convs of the same kernel size / stride in one launch (blockIdx.z = job); at most WGRAD_MAX_JOBS
 #define WGRAD_MAX_JOBS 16
 int tr_wgrad_launch_batch(const WgradArgs* jobs, int njobs, hipStream_t st);

@@ -75,6 +75,32 @@ __global__ __launch_bounds__(256) void upbwd_x_kernel(const float* __restrict__ 
     tmp[idx] = s;
 }
 
+// The same sums with a WAVE per source row (round 6): the row enters LDS by coalesced loads, then every target column's footprint is
+// summed by the 64 lanes together.  The thread-per-target form above reads each row with six far-apart walkers (46 us for 23 MB at
+// 346x260 batch 32: 0.5 TB/s).
+__global__ __launch_bounds__(256) void upbwd_x_rows_kernel(const float* __restrict__ d, float* __restrict__ tmp, long nc_oh, int ow, int w) {
+    extern __shared__ float rowbuf[];                          // 4 waves x ow floats
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wave;
+    if (row >= nc_oh) return;
+    float* rb = rowbuf + wave * ow;
+    const float* r = d + row * ow;
+    for (int X = lane; X < ow; X += 64) rb[X] = r[X];
+    __builtin_amdgcn_wave_barrier();                           // (a wave's own LDS writes: ordered by the waitcnt the compiler inserts)
+    const float scale = (float)w / (float)ow, inv = (float)ow / (float)w;
+    for (int xc = 0; xc < w; ++xc) {
+        int lo = (int)floorf(((float)xc - 1.f + 0.5f) * inv - 0.5f) - 1, hi = (int)ceilf(((float)xc + 1.f + 0.5f) * inv - 0.5f) + 1;
+        lo = lo < 0 ? 0 : lo; hi = hi > ow - 1 ? ow - 1 : hi;
+        if (xc == 0) lo = 0;
+        float s = 0.f;
+        for (int X = lo + lane; X <= hi; X += 64) s += up_weight(scale, X, w, xc) * rb[X];
+        s = lane_group_sum<16>(s);
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (lane == 0) tmp[row * w + xc] = s;
+    }
+}
+
 __global__ __launch_bounds__(256) void upbwd_y_kernel(const float* __restrict__ tmp, float* __restrict__ out, int nc, int oh, int h, int w) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)nc * h * w) return;
@@ -129,27 +155,39 @@ __global__ __launch_bounds__(256) void poolbwd4_kernel(const float* __restrict__
 
 // ---- local correlation backward (the transpose of corr_kernel in tail.hip):
 // dx[b][c][p] += (1/C) sum_t dcv[b][t][p] * y[b][c][p + d_t];   dy[b][c][q] = (1/C) sum_t dcv[b][t][q - d_t] * x[b][c][q - d_t]
-__global__ __launch_bounds__(256) void corrbwd_kernel(const float* __restrict__ dcv, int dcv_ctotal, const float* __restrict__ f1,
-                                                      const float* __restrict__ f2, float* __restrict__ d1, float* __restrict__ d2,
-                                                      int batch, int c, int h, int w, const int* __restrict__ taps, int ntaps) {
+// Up to three correlations of one grid shape (the three stages of EEMFlow.py:160-173) as ONE launch (blockIdx.y = job) - round 6: three
+// launches of 32 - 39 us each sat in the tail's chain of the training step.  Every load is unconditional from a clamped address with the
+// condition applied to the value: a load inside a lane-dependent branch is followed by the compiler's s_waitcnt vmcnt(0) - 106
+// dependent round trips per thread in the form this replaces.
+struct CorrBwdJobs { CorrBwdJob job[3]; };
+__global__ __launch_bounds__(256) void corrbwd_kernel(CorrBwdJobs jobs, int batch, int h, int w, const int* __restrict__ taps, int ntaps) {
+    const CorrBwdJob& jb = jobs.job[blockIdx.y];
+    const int c = jb.c;
     const int hw = h * w;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)batch * c * hw) return;
     const int p = idx % hw, ch = (idx / hw) % c, b = idx / ((long)hw * c);
     const int y = p / w, x = p - y * w;
-    const float* dc = dcv + (size_t)b * dcv_ctotal * hw;
-    const float* a1 = f1 + ((size_t)b * c + ch) * hw;
-    const float* a2 = f2 + ((size_t)b * c + ch) * hw;
+    const float* __restrict__ dc = jb.dcv + (size_t)b * jb.dcv_ctotal * hw;
+    const float* __restrict__ a1 = jb.f1 + ((size_t)b * c + ch) * hw;
+    const float* __restrict__ a2 = jb.f2 + ((size_t)b * c + ch) * hw;
     float s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
     for (int t = 0; t < ntaps; ++t) {
-        const int dy = taps[t] / 9 - 4, dx = taps[t] % 9 - 4;
+        const int tp = taps[t];
+        const int dy = tp / 9 - 4, dx = tp % 9 - 4;
         const int yy = y + dy, xx = x + dx;
-        if (yy >= 0 && yy < h && xx >= 0 && xx < w) s1 = fmaf(dc[(size_t)t * hw + p], a2[yy * w + xx], s1);
+        const bool in1 = yy >= 0 && yy < h && xx >= 0 && xx < w;
+        const float v2 = a2[min(max(yy, 0), h - 1) * w + min(max(xx, 0), w - 1)];
+        s1 = fmaf(dc[(size_t)t * hw + p], in1 ? v2 : 0.f, s1);
         const int y2 = y - dy, x2 = x - dx;
-        if (y2 >= 0 && y2 < h && x2 >= 0 && x2 < w) s2 = fmaf(dc[(size_t)t * hw + y2 * w + x2], a1[y2 * w + x2], s2);
+        const bool in2 = y2 >= 0 && y2 < h && x2 >= 0 && x2 < w;
+        const int q2 = min(max(y2, 0), h - 1) * w + min(max(x2, 0), w - 1);
+        const float d2v = dc[(size_t)t * hw + q2], v1 = a1[q2];
+        s2 = fmaf(in2 ? d2v : 0.f, v1, s2);
     }
-    d1[idx] += s1 / (float)c;
-    d2[idx] = s2 / (float)c;
+    jb.d1[idx] += s1 / (float)c;
+    jb.d2[idx] = s2 / (float)c;
 }
 
 // ---- bias gradient: db[co] = sum_{n,p} g[n][co'][p] * LeakyReLU'(gate); grid (chunks, max cout, jobs)
@@ -453,7 +491,11 @@ int tr_loss_launch(const float* flow, const float* gt, const float* valid, float
 }
 
 int tr_upsample_bwd_launch(const float* d, float* tmp, float* out, int nc, int oh, int ow, int h, int w, hipStream_t st) {
-    hipLaunchKernelGGL(upbwd_x_kernel, dim3(nblocks((long)nc * oh * w)), dim3(256), 0, st, d, tmp, (long)nc * oh, ow, w);
+    const char* ex = getenv("EEM_UPBWD_THREADS");                     // (=1, read per call: the thread-per-target form, for the equality test)
+    if (ow >= 64 && ow <= 8192 && !(ex && ex[0] == '1'))
+        hipLaunchKernelGGL(upbwd_x_rows_kernel, dim3((unsigned)(((long)nc * oh + 3) / 4)), dim3(256), 4 * ow * sizeof(float), st, d, tmp, (long)nc * oh, ow, w);
+    else
+        hipLaunchKernelGGL(upbwd_x_kernel, dim3(nblocks((long)nc * oh * w)), dim3(256), 0, st, d, tmp, (long)nc * oh, ow, w);
     hipLaunchKernelGGL(upbwd_y_kernel, dim3(nblocks((long)nc * h * w)), dim3(256), 0, st, tmp, out, nc, oh, h, w);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
@@ -469,12 +511,20 @@ int tr_pool_bwd_launch(const float* dpool, float* g, long nc, int h, int w, int 
     return EEM_OK;
 }
 
-int tr_corr_bwd_launch(const float* dcv, int dcv_ctotal, const float* f1, const float* f2, float* d1, float* d2, int batch, int c,
-                       int h, int w, const int* taps, int ntaps, hipStream_t st) {
-    hipLaunchKernelGGL(corrbwd_kernel, dim3(nblocks((long)batch * c * h * w)), dim3(256), 0, st, dcv, dcv_ctotal, f1, f2, d1, d2, batch,
-                       c, h, w, taps, ntaps);
+int tr_corr_bwd_launch_jobs(const CorrBwdJob* jobs, int njobs, int batch, int h, int w, const int* taps, int ntaps, hipStream_t st) {
+    EEM_REQUIRE(jobs && njobs >= 1 && njobs <= 3, "tr_corr_bwd_launch_jobs: njobs=%d", njobs);
+    CorrBwdJobs jb;
+    int cmax = 0;
+    for (int i = 0; i < njobs; ++i) { jb.job[i] = jobs[i]; cmax = std::max(cmax, jobs[i].c); }
+    hipLaunchKernelGGL(corrbwd_kernel, dim3(nblocks((long)batch * cmax * h * w), njobs), dim3(256), 0, st, jb, batch, h, w, taps, ntaps);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
+}
+
+int tr_corr_bwd_launch(const float* dcv, int dcv_ctotal, const float* f1, const float* f2, float* d1, float* d2, int batch, int c,
+                       int h, int w, const int* taps, int ntaps, hipStream_t st) {
+    CorrBwdJob j{dcv, f1, f2, d1, d2, dcv_ctotal, c};
+    return tr_corr_bwd_launch_jobs(&j, 1, batch, h, w, taps, ntaps, st);
 }
 
 int tr_bias_grad_launch_batch(const BiasJob* jobs, int njobs, hipStream_t st) {

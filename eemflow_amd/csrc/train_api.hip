@@ -6,6 +6,8 @@
 #include "eraft_kernels.h"
 #include "train.h"
 
+#include <vector>
+
 namespace {
 
 typedef eemflow_ctx::ConvRef ConvRef;
@@ -63,8 +65,22 @@ struct Bwd {
     WgradArgs wq[WGRAD_MAX_JOBS];
     BiasJob bq[WGRAD_MAX_JOBS];
     int nwq = 0;
+    // round 6: the 3x3 convs of the tail are collected over ALL its layers and leave as ONE launch when the tail's chain is through
+    // (flush_tail; wgrad_tail.hip) - their operands are the tail's activations and gradients, each in a buffer of its own
+    std::vector<WgradArgs> tq;
+    bool tail_one_launch = false;
     int wgrad_q(const ConvRef& r, const float* x, int x_ctotal, int x_coff, const float* dy, const float* y_gate, int g_ctotal,
                 int g_coff, int g_cmul, int n, int hin, int win, int hout, int wout) {
+        if (tail_one_launch && r.k == 3) {
+            WgradArgs w;
+            w.x = x; w.x_ctotal = x_ctotal; w.x_coff = x_coff; w.cin = r.cin;
+            w.g = dy; w.gate = y_gate; w.g_ctotal = g_ctotal; w.g_coff = g_coff; w.g_cmul = g_cmul; w.cout = r.cout;
+            w.dw = grad + r.w; w.db = grad + r.b;
+            w.n = n; w.hin = hin; w.win = win; w.hout = hout; w.wout = wout; w.k = 3; w.stride = r.stride; w.pad = 1;
+            w.zero_page = nullptr;
+            tq.push_back(w);
+            return EEM_OK;
+        }
         WgradArgs& w = wq[nwq++];
         w.x = x; w.x_ctotal = x_ctotal; w.x_coff = x_coff; w.cin = r.cin;
         w.g = dy; w.gate = y_gate; w.g_ctotal = g_ctotal; w.g_coff = g_coff; w.g_cmul = g_cmul; w.cout = r.cout;
@@ -82,6 +98,13 @@ struct Bwd {
         if (rc == EEM_OK) rc = tr_wgrad_launch_batch(wq, nwq, wst);
         if (rc == EEM_OK) rc = tr_bias_grad_launch_batch(bq, nwq, wst);
         nwq = 0;
+        return rc;
+    }
+    int flush_tail(int n, int h, int w) {
+        if (tq.empty()) return EEM_OK;
+        int rc = fork();
+        if (rc == EEM_OK) rc = wgrad_tail_launch(tq.data(), (int)tq.size(), n, h, w, wst);
+        tq.clear();
         return rc;
     }
     // weight + bias gradient of a conv layer into the flat buffer
@@ -177,6 +200,13 @@ static int backward_chain(eemflow_ctx* c, const Shape& s, const float* e1, const
         return r;
     };
     TL.njobs = 0;
+    {
+        // one launch for the tail's 3x3 weight gradients when the map fits a K part (wgrad_tail.hip; EEM_NO_WGRAD_TAIL=1, read per call)
+        WgradArgs probe;
+        probe.k = 3; probe.kh = 0; probe.stride = 1; probe.pad = 1; probe.hin = probe.hout = gh; probe.win = probe.wout = gw; probe.n = B;
+        probe.cin = probe.cout = 16;
+        bw.tail_one_launch = wgrad_tail_supported(&probe, 1, B, gh, gw);
+    }
     // out_conv (1x1, no activation)
     if ((rc = bw.wgrad_q(c->t_outc, c->flowcat.p, 6, 0, c->g_coarse.p, nullptr, 2, 0, 1, B, gh, gw, gh, gw)) != EEM_OK) return rc;
     TL.job[TL.njobs++] = bw.djob(c->t_outc, c->g_coarse.p, nullptr, 2, 0, 1, c->g_flowcat.p, 6, 0);
@@ -199,6 +229,7 @@ static int backward_chain(eemflow_ctx* c, const Shape& s, const float* e1, const
         TL.job[TL.njobs++] = bw.djob(c->t_dconv5[k], c->g_t64[k].p, c->t64[k].p, 64, 0, 1, c->g_td[k].p, kDecW, 0);
     }
     if ((rc = run_jobs(3)) != EEM_OK) return rc;
+
     // conv4, conv3, conv2: grouped + channel shuffle; group g's output channel j lives at j*G + g of the shuffled
     // tensor, its inputs are channels [g*per, (g+1)*per) of the previous activation
     for (int layer = 2; layer >= 0; --layer) {
@@ -225,13 +256,16 @@ static int backward_chain(eemflow_ctx* c, const Shape& s, const float* e1, const
         TL.job[TL.njobs++] = bw.djob(c->t_rconv[k], c->g_cat[k].p, c->cat[k].p, kDecIn, kNTaps, 1, c->g_pool[k].p, pc[k], 0);
     }
     if ((rc = run_jobs(3)) != EEM_OK) return rc;
+    // every 3x3 weight gradient of the tail: one launch on the side stream (three launches beside the chain - after conv5, after the
+    // grouped layers, here - measured 178 us of kernels for 99 and a slower step: the chain's own launches wait behind their blocks)
+    if ((rc = bw.flush_tail(B, gh, gw)) != EEM_OK) return rc;
     // correlation: adds to d pool1, writes d pool2
-    for (int k = 0; k < 3; ++k) {
-        const float* pool1 = c->pool[k].p;
-        const float* pool2 = c->pool[k].p + (size_t)B * pc[k] * g;
-        float* gp1 = c->g_pool[k].p;
-        float* gp2 = c->g_pool[k].p + (size_t)B * pc[k] * g;
-        if ((rc = tr_corr_bwd_launch(c->g_cat[k].p, kDecIn, pool1, pool2, gp1, gp2, B, pc[k], gh, gw, c->taps, kNTaps, st)) != EEM_OK) return rc;
+    {
+        CorrBwdJob cj[3];
+        for (int k = 0; k < 3; ++k)
+            cj[k] = CorrBwdJob{c->g_cat[k].p, c->pool[k].p, c->pool[k].p + (size_t)B * pc[k] * g, c->g_pool[k].p,
+                               c->g_pool[k].p + (size_t)B * pc[k] * g, kDecIn, pc[k]};
+        if ((rc = tr_corr_bwd_launch_jobs(cj, 3, B, gh, gw, c->taps, kNTaps, st)) != EEM_OK) return rc;      // one launch for the three stages
     }
     // ---- encoder (EEMFlow.py:135-154): both event volumes as one batch of 2B images; c->padded holds them replicate-padded since the
     // forward (forward_train_impl), which read its first layer from there
@@ -371,8 +405,29 @@ extern "C" int eemflow_forward_backward(eemflow_ctx* c, const float* e1, const f
     EEM_HIP_CHECK(hipMemsetAsync(stats, 0, 8 * sizeof(double), st));
     // ---- loss and d loss / d flow (train_mvsec.py:201-227)
     if ((rc = tr_loss_launch(flow_out, flow_gt, valid, c->g_flow.p, B, s.out_h * s.out_w, gamma_weight, stats, st)) != EEM_OK) return rc;
-    if ((rc = backward_impl(c, s, e1, e2, c->g_flow.p, grad_out, st)) != EEM_OK) return rc;
     c->stats_scale = (double)gamma_weight / ((double)B * 2.0 * s.out_h * s.out_w);
+    // The five sums are final HERE: without stats_out they leave for pinned host memory on a stream of their own, right behind the loss
+    // kernel (an event), while the backward runs - eemflow_train_stats_wait then returns as soon as the host has enqueued the optimizer
+    // step, and the next step's launches queue up behind a GPU that is still busy (round 5: the copy sat behind the whole backward, the
+    // host woke up when the GPU was already idle, and ~100 us per step passed before the next forward's first launch).
+    // EEM_TRAIN_LATE_STATS=1 (read per call) keeps round 5's order.
+    const char* late = getenv("EEM_TRAIN_LATE_STATS");
+    if (!stats_out && !(late && late[0] == '1')) {
+        if (!c->stats_host) {
+            EEM_HIP_CHECK(hipHostMalloc((void**)&c->stats_host, 8 * sizeof(double), hipHostMallocDefault));
+            EEM_HIP_CHECK(hipEventCreateWithFlags(&c->stats_ev, hipEventDisableTiming));
+        }
+        if (!c->cstream) {
+            EEM_HIP_CHECK(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
+            EEM_HIP_CHECK(hipEventCreateWithFlags(&c->loss_ev, hipEventDisableTiming));
+        }
+        EEM_HIP_CHECK(hipEventRecord(c->loss_ev, st));
+        EEM_HIP_CHECK(hipStreamWaitEvent(c->cstream, c->loss_ev, 0));
+        EEM_HIP_CHECK(hipMemcpyAsync(c->stats_host, stats, 5 * sizeof(double), hipMemcpyDeviceToHost, c->cstream));
+        EEM_HIP_CHECK(hipEventRecord(c->stats_ev, c->cstream));
+        c->stats_pending = true;
+    }
+    if ((rc = backward_impl(c, s, e1, e2, c->g_flow.p, grad_out, st)) != EEM_OK) return rc;
     if (stats_out) {
         double hst[5];
         EEM_HIP_CHECK(hipMemcpyAsync(hst, stats, sizeof(hst), hipMemcpyDeviceToHost, st));
@@ -392,6 +447,7 @@ extern "C" int eemflow_train_stats_async(eemflow_ctx* c, void* stream) {
     EEM_REQUIRE(c, "eemflow_train_stats_async: NULL context");
     EEM_REQUIRE(c->scalars.p && c->stats_scale > 0.0, "eemflow_train_stats_async: no eemflow_forward_backward has run");
     EEM_HIP_CHECK(hipSetDevice(c->device));
+    if (c->stats_pending) return EEM_OK;                 // (already on their way: eemflow_forward_backward sent them behind the loss kernel)
     if (!c->stats_host) {
         EEM_HIP_CHECK(hipHostMalloc((void**)&c->stats_host, 8 * sizeof(double), hipHostMallocDefault));
         EEM_HIP_CHECK(hipEventCreateWithFlags(&c->stats_ev, hipEventDisableTiming));

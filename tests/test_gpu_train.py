@@ -122,10 +122,38 @@ def test_dedicated_backward_kernels_equal_generic_ones(monkeypatch, b, h, w):
         loss, _, flow, flat = run_grads(net, e1, e2, gt, valid)
         return loss, flow, split_flat(flat, sd)
     loss_f, flow_f, fast = run()
-    for k in ("EEM_NO_WGRAD_ENC", "EEM_NO_DGRAD_S2", "EEM_NO_WGRAD_SMALL"):
+    for k in ("EEM_NO_WGRAD_ENC", "EEM_NO_DGRAD_S2", "EEM_NO_WGRAD_SMALL", "EEM_NO_WGRAD_TAIL"):
         monkeypatch.setenv(k, "1")
     loss_g, flow_g, gen = run()
     assert abs(loss_f - loss_g) < 1e-9 and torch.equal(flow_f, flow_g)   # same forward code; the loss sums by f64 atomics
+    worst = max((rel_err(fast[k], gen[k]), k) for k in fast)
+    assert worst[0] < 2e-5, worst
+
+
+@pytest.mark.parametrize("b,h,w,groups", [(32, 260, 346, 5), (8, 720, 1280, 5), (3, 200, 300, 5), (5, 260, 346, 2), (2, 128, 192, 1)])
+def test_tail_weight_gradients_in_one_launch_equal_the_per_layer_launches(monkeypatch, b, h, w, groups):
+    """wgrad_tail.hip (round 6): the weight and bias gradients of every 3x3 conv of the 1/64-grid tail - three decoders x seven layers with
+    their groups, the three rconv_k (EEMFlow.py:37-69,96-102 under train_mvsec.py:253) - as ONE launch behind the tail's backward chain,
+    against the per-layer wgrad_small / bias launches (EEM_NO_WGRAD_TAIL=1, read per call): all 66 gradient tensors to summation-order
+    round-off.  BASELINE configs[2] and [3] at their stated batch, a ragged batch (K parts of unequal size), other group counts."""
+    from eemflow_amd import EEMFlow
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(44, b, h, w))
+    gt, valid = (torch.from_numpy(a) for a in synthetic_gt(45, b, h, w))
+
+    def run():
+        sd = O.to_torch_sd(seeded_state_dict(46, groups=groups))
+        net = EEMFlow("", groups=groups, n_first_channels=5)
+        net.load_state_dict(sd)
+        net = net.to(DEV).train()
+        net.change_imagesize((h, w))
+        loss, _, flow, flat = run_grads(net, e1, e2, gt, valid)
+        return loss, split_flat(flat, sd)
+    monkeypatch.delenv("EEM_NO_WGRAD_TAIL", raising=False)
+    loss_f, fast = run()
+    monkeypatch.setenv("EEM_NO_WGRAD_TAIL", "1")
+    loss_g, gen = run()
+    assert abs(loss_f - loss_g) < 1e-9
+    assert not all(torch.equal(fast[k], gen[k]) for k in fast if k.startswith("decoder_"))       # (the switch did switch)
     worst = max((rel_err(fast[k], gen[k]), k) for k in fast)
     assert worst[0] < 2e-5, worst
 

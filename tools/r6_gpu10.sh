@@ -1,0 +1,3 @@
+for d in 0 1 2 3 6 7; do
+EEM_TW_DBG=$d EEM_NO_WGRAD_STREAM=1 bash tools/step_timeline.sh r06tw pad4_kernel tools/bench_train.py; echo "EEM_TW_DBG=$d: $(grep 'x  1  wgrad_tail' gpurun_out/r06tw/timeline.txt)"
+done

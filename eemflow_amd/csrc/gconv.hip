@@ -365,9 +365,11 @@ __global__ __launch_bounds__(FEW_WAVES * 64, (FEW_WAVES == 8 ? 8 : 4)) void fewo
     const GConvSeg& sg = a.seg[0];
     const int c0 = g * cpw, c1 = min(c0 + cpw, sg.c);
     const float* in = sg.ptr + ((size_t)n * sg.ctotal + sg.coff + c0) * hw;
-    float acc[NCO];
+    // (pairs of couts as packed registers: v_pk_fma_f32 does two of the layer's FMAs per issue slot - this kernel is the vector pipe's)
+    constexpr int NP = (NCO + 1) / 2;
+    f32x2 acc2[NP];
 #pragma unroll
-    for (int co = 0; co < NCO; ++co) acc[co] = 0.f;
+    for (int k = 0; k < NP; ++k) acc2[k] = f32x2{0.f, 0.f};
     int off[9];
     bool keep[9];
 #pragma unroll
@@ -396,9 +398,10 @@ __global__ __launch_bounds__(FEW_WAVES * 64, (FEW_WAVES == 8 ? 8 : 4)) void fewo
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const float vv = keep[t] ? v[q][t] : 0.f;
-                const float* w8 = w + ((size_t)(c + q - c0) * 9 + t) * 8;
+                const f32x2* w8 = reinterpret_cast<const f32x2*>(w + ((size_t)(c + q - c0) * 9 + t) * 8);
+                const f32x2 v2 = {vv, vv};
 #pragma unroll
-                for (int co = 0; co < NCO; ++co) acc[co] += vv * w8[co];
+                for (int k = 0; k < NP; ++k) acc2[k] = __builtin_elementwise_fma(v2, w8[k], acc2[k]);
             }
         }
     };
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(FEW_WAVES * 64, (FEW_WAVES == 8 ? 8 : 4)) void fewo
         }
     }
 #pragma unroll
-    for (int co = 0; co < NCO; ++co) part[g][co][lane] = acc[co];
+    for (int co = 0; co < NCO; ++co) part[g][co][lane] = acc2[co >> 1][co & 1];
     __syncthreads();
     // thread (co = g, pixel = lane) sums the channel groups in order and finishes the output
     const int co = g;
@@ -463,6 +466,8 @@ int fewout_launch(const GConvArgs& a, hipStream_t stream) {
     if (a.cout <= 2) {                                                // E-RAFT's flow head
         if (small) hipLaunchKernelGGL((fewout_kernel<16, 2, 2>), dim3(blocks), dim3(1024), 0, stream, a, (a.seg[0].c + 15) / 16);
         else hipLaunchKernelGGL((fewout_kernel<8, 1, 2>), dim3(blocks), dim3(512), 0, stream, a, (a.seg[0].c + 7) / 8);
+    } else if (a.cout <= 4 && !small) {                               // EEMFlow+'s mask estimator tail 184 -> 3 (cdc_utils.py:151)
+        hipLaunchKernelGGL((fewout_kernel<8, 1, 4>), dim3(blocks), dim3(512), 0, stream, a, (a.seg[0].c + 7) / 8);
     } else if (small) {
         hipLaunchKernelGGL((fewout_kernel<16, 2, 8>), dim3(blocks), dim3(1024), 0, stream, a, (a.seg[0].c + 15) / 16);
     } else {

@@ -11,6 +11,8 @@
 #include "gconv.h"
 #include "plus_kernels.h"
 
+#include <utility>
+
 namespace {
 
 struct PBuf { float* p = nullptr; size_t cap = 0; };
@@ -60,7 +62,7 @@ struct eemplus_ctx {
     bool enc_wino[8] = {false};
     int* taps = nullptr;
     PLayer enc[8], rconv[7], dec1[7], decg[7][3][3], dec5[7], dec6[7], dec7[7], de[6], c1x1[6];
-    PBuf padded, f[7], a2, dense, xout, finit[7], tw, fup[7], fw, cat, d[4], t64, t32, flow[7];
+    PBuf padded, f[7], a2, dense, xout, finit[7], tw, fup[7], fw, cat, d[4], t64, t32, flow[7], flow_alt[7];
     int B = 0, hl[7] = {0}, wl[7] = {0};
     bool have_last = false;
 };
@@ -259,6 +261,7 @@ extern "C" void eemplus_destroy(eemplus_ctx* c) {
         if (c->fup[l].p) (void)hipFree(c->fup[l].p);
         if (c->finit[l].p) (void)hipFree(c->finit[l].p);
         if (c->flow[l].p) (void)hipFree(c->flow[l].p);
+        if (c->flow_alt[l].p) (void)hipFree(c->flow_alt[l].p);
     }
     if (c->arena) (void)hipFree(c->arena);
     if (c->wino) (void)hipFree(c->wino);
@@ -366,35 +369,67 @@ static int run_level(eemplus_ctx* c, int l, int B, const float* forced_init, hip
         return rc;
     float* const fi = c->finit[l].p;              // cdc_model's upsampled flow_init, kept per level (stage "flow_init<l>")
     // 1x1 projections of both feature maps (:184-185); feature_1 goes straight into the dense buffer's x slot
-    if ((rc = conv(c, c->c1x1[l], f1(l), C[l], 0, B, h, w, c->dense.p, kDense, 120, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
-    if ((rc = conv(c, c->c1x1[l], f2(l), C[l], 0, B, h, w, c->a2.p, 32, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+    {
+        // (the coarse levels: both projections - the same weights on the two feature maps - as the two jobs of ONE small-grid launch)
+        static const bool no_tail = [] { const char* e = getenv("EEM_PLUS_NO_TAIL"); return e && e[0] == '1'; }();
+        static const long conv_tail_max = [] { const char* e = getenv("EEM_PLUS_CONV_TAIL_MAX"); return e ? atol(e) : 4096L; }();
+        const PLayer& P = c->c1x1[l];
+        const char* epf0 = getenv("EEM_PLUS_NO_FUSE");
+        if (!no_tail && P.has_tail && (long)h * w <= conv_tail_max && !(epf0 && epf0[0] == '1')) {
+            TailConvLaunch T;
+            T.batch = B; T.h = h; T.w = w; T.ksize = P.k; T.njobs = 2;
+            for (int q = 0; q < 2; ++q) {
+                TailConvJob& j = T.job[q];
+                j.in = q == 0 ? f1(l) : f2(l); j.wpk = c->arena + P.wtail; j.bias = c->arena + P.bias;
+                j.out = q == 0 ? c->dense.p : c->a2.p;
+                j.cin = P.cin; j.cout = P.cout; j.in_ctotal = C[l]; j.in_coff = 0;
+                j.out_ctotal = q == 0 ? kDense : 32; j.out_coff = q == 0 ? 120 : 0; j.out_cmul = 1; j.act = 1;
+                j.gate = nullptr; j.in_cmul = 1; j.add = nullptr;
+            }
+            if ((rc = tail_conv_launch(T, st)) != EEM_OK) return rc;
+        } else {
+            if ((rc = conv(c, P, f1(l), C[l], 0, B, h, w, c->dense.p, kDense, 120, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+            if ((rc = conv(c, P, f2(l), C[l], 0, B, h, w, c->a2.p, 32, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+        }
+    }
     // cdc_model.forward (cdc_utils.py:156-174)
     if (forced_init) {
         // teacher-forced level (eemplus_level): cdc_model's upsampled flow_init is supplied by the caller
         EEM_HIP_CHECK(hipMemcpyAsync(fi, forced_init, B * 2 * g * 4, hipMemcpyDeviceToDevice, st));
-    } else if (hc != h || wc != w) {
-        if ((rc = pl_upflow_launch(c->flow[l + 1].p, fi, B, hc, wc, h, w, 1, st)) != EEM_OK) return rc;
-        // in-place side effect of upsample2d_flow_as(if_rate=True) on the coarser flow (cdc_utils.py:85-86)
-        if ((rc = pl_scale_flow_launch(c->flow[l + 1].p, B, hc * wc, (float)w / (float)wc, (float)h / (float)hc, st)) != EEM_OK) return rc;
-    } else {
-        EEM_HIP_CHECK(hipMemcpyAsync(fi, c->flow[l + 1].p, B * 2 * g * 4, hipMemcpyDeviceToDevice, st));
     }
-    if ((rc = pl_warp_launch(c->a2.p, fi, 2, c->dense.p, kDense, 152, B, 32, h, w, 2, st)) != EEM_OK) return rc;
+    // warp + blend + the copy of flow_up into the decoder's input as one launch (EEM_PLUS_NO_FUSE=1, read per forward: the separate launches)
+    const char* epf = getenv("EEM_PLUS_NO_FUSE");
+    const bool fuse3 = !(epf && epf[0] == '1');
+    if (!forced_init && (hc != h || wc != w) && fuse3 && (size_t)h * w >= 2 * (size_t)hc * wc) {
+        // upsampling, the coarse flow's doubling and the warp by the upsampled flow as ONE launch; the doubled coarse flow lands in a
+        // second buffer (the launch's other threads still read the plain one) that takes the coarse flow's place from here on
+        if ((rc = pensure(c->flow_alt[l + 1], B * 2 * (size_t)hc * wc)) != EEM_OK) return rc;
+        if ((rc = pl_upflow_warp_launch(c->flow[l + 1].p, c->flow_alt[l + 1].p, hc, wc, fi, c->a2.p, c->dense.p, kDense, 152, B, 32, h, w, st)) != EEM_OK) return rc;
+        std::swap(c->flow[l + 1], c->flow_alt[l + 1]);
+    } else {
+        if (forced_init) {
+        } else if (hc != h || wc != w) {
+            if ((rc = pl_upflow_launch(c->flow[l + 1].p, fi, B, hc, wc, h, w, 1, st)) != EEM_OK) return rc;
+            // in-place side effect of upsample2d_flow_as(if_rate=True) on the coarser flow (cdc_utils.py:85-86)
+            if ((rc = pl_scale_flow_launch(c->flow[l + 1].p, B, hc * wc, (float)w / (float)wc, (float)h / (float)hc, st)) != EEM_OK) return rc;
+        } else {
+            EEM_HIP_CHECK(hipMemcpyAsync(fi, c->flow[l + 1].p, B * 2 * g * 4, hipMemcpyDeviceToDevice, st));
+        }
+        if ((rc = pl_warp_launch(c->a2.p, fi, 2, c->dense.p, kDense, 152, B, 32, h, w, 2, st)) != EEM_OK) return rc;
+    }
     const int din[6] = {64, 96, 128, 160, 176, 184}, dout_off[5] = {88, 56, 24, 8, 0};
     for (int i = 0; i < 5; ++i)
         if ((rc = conv(c, c->de[i], c->dense.p, kDense, kDense - din[i], B, h, w, c->dense.p, kDense, dout_off[i], 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
     if ((rc = conv(c, c->de[5], c->dense.p, kDense, 0, B, h, w, c->xout.p, 3, 0, 1, GACT_NONE, nullptr, st)) != EEM_OK) return rc;
-    // warp + blend + the copy of flow_up into the decoder's input as one launch (EEM_PLUS_NO_FUSE=1, read per forward: the three launches)
-    const char* epf = getenv("EEM_PLUS_NO_FUSE");
-    const bool fuse3 = !(epf && epf[0] == '1');
     if (fuse3) {
-        if ((rc = pl_warp_blend_launch(fi, c->xout.p, c->fup[l].p, c->cat.p, kCat, 85, B, h, w, st)) != EEM_OK) return rc;
+        // ... and the warp of feature_2 by that flow_up (:189) in the same launch
+        if ((rc = pl_warp_blend_warp_launch(fi, c->xout.p, c->fup[l].p, c->cat.p, kCat, 85, f2(l), c->fw.p, C[l], B, h, w, st)) != EEM_OK) return rc;
     } else {
         if ((rc = pl_warp_launch(fi, c->xout.p, 3, c->tw.p, 2, 0, B, 2, h, w, 1, st)) != EEM_OK) return rc;
         if ((rc = pl_blend_launch(c->tw.p, fi, c->xout.p, c->fup[l].p, B, (int)g, st)) != EEM_OK) return rc;
+        // warp, correlate, decode (:189-193)
+        if ((rc = pl_warp_launch(f2(l), c->fup[l].p, 2, c->fw.p, C[l], 0, B, C[l], h, w, 0, st)) != EEM_OK) return rc;
     }
-    // warp, correlate, decode (:189-193)
-    if ((rc = pl_warp_launch(f2(l), c->fup[l].p, 2, c->fw.p, C[l], 0, B, C[l], h, w, 0, st)) != EEM_OK) return rc;
     CorrJob cj = {f1(l), c->fw.p, c->cat.p, C[l], kCat};
     if ((rc = corr_launch(&cj, 1, B, h, w, c->taps, 53, st)) != EEM_OK) return rc;
     if ((rc = conv(c, c->rconv[l], f1(l), C[l], 0, B, h, w, c->cat.p, kCat, 53, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;

@@ -18,3 +18,9 @@ int pl_warp_blend_launch(const float* flow_init, const float* xout, float* out, 
 // dst[:, d_coff : d_coff + c] = src[:, s_coff : s_coff + c]   (src NULL: zeros)
 int pl_copy_channels_launch(const float* src, int s_ctotal, int s_coff, float* dst, int d_ctotal, int d_coff, int c, int batch, int hw,
                             hipStream_t st);
+// round 6: warp_blend + the warp of feature_2 by the flow_up it forms (EEMFlow+.py:189) as one launch; upsample2d_flow_as + its in-place
+// doubling of the coarse flow (into fc_scaled, a second buffer) + WarpingLayer_no_div(x, flow_init) as one launch (h x w >= 2 hc x wc)
+int pl_warp_blend_warp_launch(const float* flow_init, const float* xout, float* out, float* cat, int cat_ctotal, int cat_coff, const float* f2,
+                              float* fw, int c2, int batch, int h, int w, hipStream_t st);
+int pl_upflow_warp_launch(const float* fc, float* fc_scaled, int hc, int wc, float* fi, const float* x, float* out, int out_ctotal, int out_coff,
+                          int batch, int c, int h, int w, hipStream_t st);

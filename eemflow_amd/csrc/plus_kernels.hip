@@ -12,16 +12,13 @@ inline unsigned nblocks(long n) { return (unsigned)((n + 255) / 256); }
 // mode 0: align_corners=True (EEMFlow_cdc.warp); 1: align_corners=False (torch_warp);
 // 2: align_corners=False + `grid_sample(ones) >= 1` mask (WarpingLayer_no_div)
 constexpr int kWarpCh = 4;
-__global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ x, const float* __restrict__ flow, int flow_ctotal,
-                                                   float* __restrict__ out, int out_ctotal, int out_coff, int batch, int c, int h, int w,
-                                                   int mode) {
+// one pixel of a warp: the flow (fx, fy) of pixel p, the channels [ch0, ch0 + kWarpCh) of x
+__device__ __forceinline__ void warp_px(const float* __restrict__ x, float fx, float fy, float* __restrict__ out, int out_ctotal, int out_coff,
+                                        int b, int c, int h, int w, int p, int mode, int ch0) {
     const int hw = h * w;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)batch * hw) return;
-    const int p = idx % hw, b = idx / hw;
     const int py = p / w, px = p - py * w;
-    const float vx = (float)px + flow[((size_t)b * flow_ctotal + 0) * hw + p];
-    const float vy = (float)py + flow[((size_t)b * flow_ctotal + 1) * hw + p];
+    const float vx = (float)px + fx;
+    const float vy = (float)py + fy;
     const float xn = 2.0f * vx / (float)max(w - 1, 1) - 1.0f;
     const float yn = 2.0f * vy / (float)max(h - 1, 1) - 1.0f;
     float ix, iy;
@@ -46,9 +43,6 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ x, 
                            (in_s && in_e ? 1.f : 0.f) * se;
         m = ones >= 1.0f ? 1.f : 0.f;
     }
-    // blockIdx.y = group of kWarpCh channels: the coarse levels are a handful of pixel blocks, and a thread that walks all 32 / 64
-    // channels pays their gather latencies one after the other (23 x 40 x 64 channels: 22 us); all loads of a group go out together
-    const int ch0 = blockIdx.y * kWarpCh;
     const int o_nw = (in_n && in_w) ? y0 * w + x0 : -1, o_ne = (in_n && in_e) ? y0 * w + x0 + 1 : -1;
     const int o_sw = (in_s && in_w) ? (y0 + 1) * w + x0 : -1, o_se = (in_s && in_e) ? (y0 + 1) * w + x0 + 1 : -1;
     float v[kWarpCh][4];
@@ -71,6 +65,55 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ x, 
     }
 }
 
+// blockIdx.y = group of kWarpCh channels: the coarse levels are a handful of pixel blocks, and a thread that walks all 32 / 64
+// channels pays their gather latencies one after the other (23 x 40 x 64 channels: 22 us); all loads of a group go out together
+__global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ x, const float* __restrict__ flow, int flow_ctotal,
+                                                   float* __restrict__ out, int out_ctotal, int out_coff, int batch, int c, int h, int w,
+                                                   int mode) {
+    const int hw = h * w;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)batch * hw) return;
+    const int p = idx % hw, b = idx / hw;
+    warp_px(x, flow[((size_t)b * flow_ctotal + 0) * hw + p], flow[((size_t)b * flow_ctotal + 1) * hw + p], out, out_ctotal, out_coff, b, c, h, w,
+            p, mode, blockIdx.y * kWarpCh);
+}
+
+// bilinear value of a flow plane s [h][w] at output (Y, X) of an [oh][ow] grid, align_corners=True - upflow_kernel's expression
+__device__ __forceinline__ float upflow_px(const float* __restrict__ s, int h, int w, int oh, int ow, int Y, int X) {
+    const float sy = oh > 1 ? (float)(h - 1) / (float)(oh - 1) : 0.f, sx = ow > 1 ? (float)(w - 1) / (float)(ow - 1) : 0.f;
+    const float fy = sy * (float)Y, fx = sx * (float)X;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    return (1.f - ly) * ((1.f - lx) * s[y0 * w + x0] + lx * s[y0 * w + x1]) + ly * ((1.f - lx) * s[y1 * w + x0] + lx * s[y1 * w + x1]);
+}
+
+// cdc_model's first three steps as ONE launch (round 6; cdc_utils.py:156-162): flow_init = upsample2d_flow_as(flow_coarse, if_rate=True)
+// (upflow_kernel's arithmetic, to the bit), the in-place doubling of the coarse flow that call leaves behind (:85-86; written to a SECOND
+// buffer - other threads of this launch still interpolate from the unscaled one - which the host then takes for the coarse flow), and
+// WarpingLayer_no_div(x, flow_init) (warp_kernel's mode 2) from the flow value the thread has just formed.  Three launches of ~4.8 us
+// each at the coarse levels before.
+__global__ __launch_bounds__(256) void upflow_warp_kernel(const float* __restrict__ fc, float* __restrict__ fc_scaled, int hc, int wc,
+                                                          float* __restrict__ fi, const float* __restrict__ x, float* __restrict__ out,
+                                                          int out_ctotal, int out_coff, int batch, int c, int h, int w) {
+    const int hw = h * w;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.y == 0 && idx < (long)batch * 2 * hc * wc)
+        fc_scaled[idx] = fc[idx] * (((idx / (hc * wc)) & 1) ? ((float)h / (float)hc) : ((float)w / (float)wc));
+    if (idx >= (long)batch * hw) return;
+    const int p = idx % hw, b = idx / hw;
+    const int py = p / w, px = p - py * w;
+    float f[2];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+        float v = upflow_px(fc + ((size_t)b * 2 + ch) * hc * wc, hc, wc, h, w, py, px);
+        v *= ch ? ((float)h / (float)hc) : ((float)w / (float)wc);
+        f[ch] = v;
+        if (blockIdx.y == 0) fi[((size_t)b * 2 + ch) * hw + p] = v;
+    }
+    warp_px(x, f[0], f[1], out, out_ctotal, out_coff, b, c, h, w, p, 2, blockIdx.y * kWarpCh);
+}
+
 // F.interpolate(bilinear, align_corners=True) of a flow [b][2][h][w] -> [b][2][oh][ow], optionally scaled by
 // (ow/w, oh/h) per channel (upsample2d_flow_as, if_rate=True; cdc_utils.py:80-103)
 __global__ __launch_bounds__(256) void upflow_kernel(const float* __restrict__ in, float* __restrict__ out, int batch, int h, int w,
@@ -79,13 +122,7 @@ __global__ __launch_bounds__(256) void upflow_kernel(const float* __restrict__ i
     if (idx >= (long)batch * 2 * oh * ow) return;
     const int X = idx % ow, Y = (idx / ow) % oh;
     const int bc = idx / ((long)ow * oh);
-    const float sy = oh > 1 ? (float)(h - 1) / (float)(oh - 1) : 0.f, sx = ow > 1 ? (float)(w - 1) / (float)(ow - 1) : 0.f;
-    const float fy = sy * (float)Y, fx = sx * (float)X;
-    const int y0 = (int)fy, x0 = (int)fx;
-    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
-    const float ly = fy - (float)y0, lx = fx - (float)x0;
-    const float* s = in + (size_t)bc * h * w;
-    float v = (1.f - ly) * ((1.f - lx) * s[y0 * w + x0] + lx * s[y0 * w + x1]) + ly * ((1.f - lx) * s[y1 * w + x0] + lx * s[y1 * w + x1]);
+    float v = upflow_px(in + (size_t)bc * h * w, h, w, oh, ow, Y, X);
     if (rate) v *= (bc & 1) ? ((float)oh / (float)h) : ((float)ow / (float)w);
     out[idx] = v;
 }
@@ -148,8 +185,11 @@ __global__ __launch_bounds__(256) void blend_kernel(const float* __restrict__ wa
 //   warped = torch_warp(flow_init, xout[:, 0:2])  (warp_kernel's mode 1, operation by operation)
 //   flow_up = warped * (1 - sigmoid(xout[:, 2])) + flow_init * sigmoid(xout[:, 2])  (blend_kernel's expression)
 //   flow_up -> `out` [b][2][hw] and -> channels [cat_coff, cat_coff + 2) of `cat` [b][cat_ctotal][hw]
+// With f2 != NULL (round 6) the launch also does the step behind it, EEMFlow_cdc.warp(feature_2, flow_up) (EEMFlow+.py:189; warp_kernel's
+// mode 0) from the flow_up value the thread has just formed: blockIdx.y = channel group of f2, group 0 writes flow_up.
 __global__ __launch_bounds__(256) void warp_blend_kernel(const float* __restrict__ fi, const float* __restrict__ xout, float* __restrict__ out,
-                                                         float* __restrict__ cat, int cat_ctotal, int cat_coff, int batch, int h, int w) {
+                                                         float* __restrict__ cat, int cat_ctotal, int cat_coff, int batch, int h, int w,
+                                                         const float* __restrict__ f2, float* __restrict__ fw, int c2) {
     const int hw = h * w;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)batch * hw) return;
@@ -179,12 +219,17 @@ __global__ __launch_bounds__(256) void warp_blend_kernel(const float* __restrict
         const float v0 = (in_n && in_w) ? a0 : 0.f, v1 = (in_n && in_e) ? a1 : 0.f, v2 = (in_s && in_w) ? a2 : 0.f, v3 = (in_s && in_e) ? a3 : 0.f;
         r[ch] = ((v0 * nw + v1 * ne) + v2 * sw) + v3 * se;
     }
+    float fu[2];
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch) {
         const float v = r[ch] * (1.f - mk) + f0[ch] * mk;
-        out[((size_t)b * 2 + ch) * hw + p] = v;
-        cat[((size_t)b * cat_ctotal + cat_coff + ch) * hw + p] = v;
+        fu[ch] = v;
+        if (blockIdx.y == 0) {
+            out[((size_t)b * 2 + ch) * hw + p] = v;
+            cat[((size_t)b * cat_ctotal + cat_coff + ch) * hw + p] = v;
+        }
     }
+    if (f2) warp_px(f2, fu[0], fu[1], fw, c2, 0, b, c2, h, w, p, 0, blockIdx.y * kWarpCh);
 }
 
 __global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restrict__ src, int s_ctotal, int s_coff, float* __restrict__ dst,
@@ -244,7 +289,23 @@ int pl_blend_launch(const float* warped, const float* flow_init, const float* xo
 int pl_warp_blend_launch(const float* flow_init, const float* xout, float* out, float* cat, int cat_ctotal, int cat_coff, int batch, int h, int w,
                          hipStream_t st) {
     hipLaunchKernelGGL(warp_blend_kernel, dim3(nblocks((long)batch * h * w)), dim3(256), 0, st, flow_init, xout, out, cat, cat_ctotal, cat_coff,
-                       batch, h, w);
+                       batch, h, w, (const float*)nullptr, (float*)nullptr, 0);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int pl_warp_blend_warp_launch(const float* flow_init, const float* xout, float* out, float* cat, int cat_ctotal, int cat_coff, const float* f2,
+                              float* fw, int c2, int batch, int h, int w, hipStream_t st) {
+    hipLaunchKernelGGL(warp_blend_kernel, dim3(nblocks((long)batch * h * w), (c2 + kWarpCh - 1) / kWarpCh), dim3(256), 0, st, flow_init, xout, out,
+                       cat, cat_ctotal, cat_coff, batch, h, w, f2, fw, c2);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int pl_upflow_warp_launch(const float* fc, float* fc_scaled, int hc, int wc, float* fi, const float* x, float* out, int out_ctotal, int out_coff,
+                          int batch, int c, int h, int w, hipStream_t st) {
+    hipLaunchKernelGGL(upflow_warp_kernel, dim3(nblocks((long)batch * h * w), (c + kWarpCh - 1) / kWarpCh), dim3(256), 0, st, fc, fc_scaled, hc, wc,
+                       fi, x, out, out_ctotal, out_coff, batch, c, h, w);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

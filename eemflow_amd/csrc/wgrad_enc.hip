@@ -49,11 +49,30 @@ struct WgCfg {
     static_assert(2 * STAGE * 4 <= 160 * 1024, "LDS budget");
 };
 
+// ---- fp32 products as bf16 pieces (round 6; the arithmetic of conv_bx3.hip / gconvb.hip): every operand = three bf16 pieces that sum to it
+// exactly (8 significand bits each, by truncation), a product = six piece products accumulated in fp32 by v_mfma_f32_16x16x32_bf16,
+// small terms first.  K = 32 PIXELS per MFMA: a lane holds 8 consecutive pixels of its cout row (A) / of its (ci, tap) column (B).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 wg_bf(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ void wg_split8(const float (&x)[8], u32x4& p0, u32x4& p1, u32x4& p2) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const float xa = x[2 * d], xb = x[2 * d + 1];
+        const float ra = xa - __uint_as_float(__float_as_uint(xa) & 0xffff0000u), rb = xb - __uint_as_float(__float_as_uint(xb) & 0xffff0000u);
+        const float sa = ra - __uint_as_float(__float_as_uint(ra) & 0xffff0000u), sb = rb - __uint_as_float(__float_as_uint(rb) & 0xffff0000u);
+        p0[d] = __builtin_amdgcn_perm(__float_as_uint(xb), __float_as_uint(xa), 0x07060302u);      // (hi16(xb) << 16) | hi16(xa)
+        p1[d] = __builtin_amdgcn_perm(__float_as_uint(rb), __float_as_uint(ra), 0x07060302u);
+        p2[d] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
+    }
+}
+
 #ifdef EEM_DIAG
 __device__ int g_wg_dbg;                                 // diagnostic builds: EEM_WG_DBG=1 leaves the MFMAs out (what is left is the operands' way in)
 #endif
 
-template <int MT, int S, int TW, int CP, int KH = 3, int KW = 3>
+// BX: the tile's products on the bf16 matrix pipe (exact three-piece operands, above) - wave w's 32 pixels of the tile are ONE K = 32 step:
+// (MT + 9) operand splits and 6 x 9 MT MFMAs of 16 cycles where the fp32 form issues 8 x 9 MT of 32
+template <int MT, int S, int TW, int CP, int KH = 3, int KW = 3, bool BX = false>
 __global__ __launch_bounds__(256) void wgrad_enc_kernel(WgradArgs a, int tiles_x, int tiles_y) {
     using C = WgCfg<MT, S, TW, CP, KH, KW>;
     constexpr int NT = C::NT, TAPS = C::TAPS;
@@ -180,6 +199,40 @@ __global__ __launch_bounds__(256) void wgrad_enc_kernel(WgradArgs a, int tiles_x
 #ifdef EEM_DIAG
         if (g_wg_dbg & 1) continue;
 #endif
+        if constexpr (BX) {
+            // this lane's eight pixels: p = 32 wave + 8 g + e (one row of the tile: 8 divides TW)
+            const int p8 = wave * 32 + 8 * g;
+            const int py8 = p8 / TW, px8 = p8 - py8 * TW;
+            u32x4 ap[MT][3];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float x[8];
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(sg + (mt * 16 + j) * C::GP + p8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(sg + (mt * 16 + j) * C::GP + p8 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { x[e] = lo[e]; x[4 + e] = hi[e]; }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bsum[mt] += x[e];
+                wg_split8(x, ap[mt][0], ap[mt][1], ap[mt][2]);
+            }
+            const int xo8 = py8 * S * C::XC + px8 * S;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = sx[boff[nt] + xo8 + e * S];
+                u32x4 bp[3];
+                wg_split8(x, bp[0], bp[1], bp[2]);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {                            // small terms first
+                    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg_bf(ap[mt][PA[i]]), wg_bf(bp[PB[i]]), acc[mt][nt], 0, 0, 0);
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             float av[MT], bv[NT];
@@ -246,7 +299,7 @@ __global__ __launch_bounds__(256) void wgrad_enc_kernel(WgradArgs a, int tiles_x
     }
 }
 
-template <int MT, int S, int TW, int CP, int KH = 3, int KW = 3>
+template <int MT, int S, int TW, int CP, int KH = 3, int KW = 3, bool BX = false>
 int launch(const WgradArgs& a, hipStream_t st) {
     using C = WgCfg<MT, S, TW, CP, KH, KW>;
     const int tiles_x = ceil_div(a.wout, TW), tiles_y = ceil_div(a.hout, C::TH);
@@ -265,24 +318,38 @@ int launch(const WgradArgs& a, hipStream_t st) {
 #endif
     static bool raised = false;
     if (!raised) {
-        EEM_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_enc_kernel<MT, S, TW, CP, KH, KW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        EEM_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_enc_kernel<MT, S, TW, CP, KH, KW, BX>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           160 * 1024));
         raised = true;
     }
-    hipLaunchKernelGGL((wgrad_enc_kernel<MT, S, TW, CP, KH, KW>), dim3(gx, chunks, cochunks), dim3(256), lds_bytes, st, a, tiles_x, tiles_y);
+    hipLaunchKernelGGL((wgrad_enc_kernel<MT, S, TW, CP, KH, KW, BX>), dim3(gx, chunks, cochunks), dim3(256), lds_bytes, st, a, tiles_x, tiles_y);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
+}
+
+// EEM_NO_WGRAD_BX3=1 (read per call): the fp32 MFMA form of every launch
+static bool use_bx3() {
+    const char* e = getenv("EEM_NO_WGRAD_BX3");
+    return !(e && e[0] == '1');
 }
 
 // stride-1 layers of any width with 3x3, 1x5, 5x1 or 1x1 filters (E-RAFT's residual stacks, update block and heads): 64-cout chunks
 template <int KH, int KW>
 int launch_wide(const WgradArgs& a, hipStream_t st) {
+    if (use_bx3()) {
+        if (a.wout % 32 == 0 || a.wout >= 256) return launch<4, 1, 32, 16, KH, KW, true>(a, st);
+        return launch<4, 1, 16, 16, KH, KW, true>(a, st);
+    }
     if (a.wout % 32 == 0 || a.wout >= 256) return launch<4, 1, 32, 16, KH, KW>(a, st);
     return launch<4, 1, 16, 16, KH, KW>(a, st);
 }
 
 template <int MT, int S>
 int launch_tw(const WgradArgs& a, hipStream_t st) {
+    if (MT >= 2 && use_bx3()) {                                      // (one 16-cout tile per wave: the splits cost what the multiplies save)
+        if (a.wout % 32 == 0 || a.wout >= 256) return launch<MT, S, 32, 16, 3, 3, true>(a, st);
+        return launch<MT, S, 16, 16, 3, 3, true>(a, st);
+    }
     if (a.wout % 32 == 0 || a.wout >= 256) return launch<MT, S, 32, 16>(a, st);
     return launch<MT, S, 16, 16>(a, st);
 }

@@ -506,22 +506,19 @@ bool wgrad_ring_supported(const WgradArgs& a) {
 }
 
 // Where the rings are the faster kernel (tools/wgrad_bench.py on the shapes a training step asks for, profiles/r06_wgrad_bench.txt): the
-// encoders' stride-2 convs (3 x: the old path is the generic kernel), the GRU's (1, 5) / (5, 1) convs over their whole concatenated
-// input (106 us as one launch against 3 x 48), and every 3x3 layer wider than 64 channels on either side (alone they range from 0.94 x to
-// 1.4 x of the old kernel; inside the E-RAFT step, beside the data-gradient stream, all of them together are the faster choice).
-// EEMFlow's five encoder shapes (<= 64 channels on both sides) stay on wgrad_enc.hip: 91 - 97 us against 108 - 120 at C3 - 256 K-segments
-// x the whole dW in atomics and ~1.2 us of barrier + restart per slice cost more than the staged bytes they save there.
+// encoders' stride-2 convs (3 x: the other path is the generic kernel).  For the stride-1 shapes the tile kernel of wgrad_enc.hip with its
+// products as bf16 pieces (later in round 6) is faster alone - 73 against 120 us at EEMFlow's 64 -> 64 layer, 89 against 125 at E-RAFT's
+// heads, 34 against 50 at a GRU conv's input segment - and in the E-RAFT step (81.4 ms against 82.7 with every wide layer on the rings);
+// against the tile kernel's fp32 form the rings had won that step (89.5 against 93.8 ms).  What the rings buy - a third of the staged
+// bytes per product - is what the bf16-piece multiply would need next: that kernel is now bound by its operands' way in.
 // EEM_WGRAD_RING=all / none overrides (read per call).
 bool wgrad_ring_preferred(const WgradArgs& a) {
     if (const char* e = getenv("EEM_WGRAD_RING")) {
         if (e[0] == 'a') return true;
         if (e[0] == 'n') return false;
     }
-    const int kh = a.kh ? a.kh : a.k, kw = a.kh ? a.kw : a.k;
-    if (a.stride == 2) return a.cin >= 64;
-    if (kh != kw) return true;
-    return a.cin > 64 || a.cout > 64;                                 // (the E-RAFT step: 93.8 ms on the old kernels, 90.7 with the shapes that
-}                                                                     // win alone, 89.5 with every wide layer: profiles/r06_wgrad_bench.txt)
+    return a.stride == 2 && a.cin >= 64;
+}
 
 int wgrad_ring_launch(const WgradArgs& a, hipStream_t st) {
     const int kh = a.kh ? a.kh : a.k;

@@ -284,6 +284,13 @@ def test_weight_gradient_ring_kernel(monkeypatch, cin, cout, k, stride, n, h, w)
     assert rel(dw_r, wt.grad) < 2e-5 and rel(db_r, bs.grad) < 2e-5, (rel(dw_r, wt.grad), rel(db_r, bs.grad))
     assert float((dw_r - dw_o).abs().max()) < 2e-5 * scale and not torch.equal(dw_r, dw_o)      # (the switch did switch)
     assert float((db_r - db_o).abs().max()) < 2e-5 * float(bs.grad.abs().max())
+    # ... and the tile kernel's two arithmetic forms: products as six bf16-piece MFMAs (default from 32 couts up) against fp32 MFMAs
+    # (EEM_NO_WGRAD_BX3=1, read per call) - the same sums to a few ulp of the largest one
+    monkeypatch.setenv("EEM_NO_WGRAD_BX3", "1")
+    dw_f, db_f = _conv_wgrad(xd, dyd, cin, 0, cout, kh, kw, stride, ph, pw)
+    monkeypatch.delenv("EEM_NO_WGRAD_BX3", raising=False)
+    assert rel(dw_o, wt.grad) < 2e-5 and rel(dw_f, wt.grad) < 2e-5 and rel(db_o, bs.grad) < 2e-5
+    assert float((dw_f - dw_o).abs().max()) < 2e-5 * scale
     # an input-channel slice of a wider weight tensor (the GRU's [h | x] inputs, ops.Conv2d.backward: one call per input segment)
     monkeypatch.delenv("EEM_NO_WGRAD_RING", raising=False)
     lo = 16 if cin >= 48 else 0

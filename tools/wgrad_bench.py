@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""GPU box: the weight-gradient kernels alone, ring (wgrad_ring.hip) against the kernels it replaces (EEM_NO_WGRAD_RING=1), at the shapes of
+"""GPU box: the weight-gradient kernels alone - the ring kernel (wgrad_ring.hip, forced: EEM_WGRAD_RING=all), the tile kernel with its
+products as bf16 pieces (wgrad_enc.hip, EEM_NO_WGRAD_RING=1) and with fp32 MFMAs (+ EEM_NO_WGRAD_BX3=1) - at the shapes of
 the EEMFlow training step (C3: 346x260 batch 32 -> 64 images; C4: 1280x720 batch 8 -> 16 images) and of E-RAFT's update block / encoders
 at 640x480 batch 4.  tools/wgrad_bench.py [reps]   Prints us per launch, TFLOP/s, and the ratio."""
 import os
@@ -85,18 +86,23 @@ def run(shape, reps):
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     only = sys.argv[2] if len(sys.argv) > 2 else ""
-    print(f"{'shape':34s} {'ring us':>9s} {'TFLOP/s':>8s} {'old us':>9s} {'TFLOP/s':>8s}  old/ring")
+    print(f"{'shape':34s} {'ring us':>9s} {'TFLOP/s':>8s} {'tile-bx3 us':>11s} {'TFLOP/s':>8s} {'tile-fp32 us':>12s} {'TFLOP/s':>8s}")
     for sh in SHAPES:
         if only and only not in sh[0]:
             continue
         os.environ.pop("EEM_NO_WGRAD_RING", None)
+        os.environ.pop("EEM_NO_WGRAD_BX3", None)
+        os.environ["EEM_WGRAD_RING"] = "all"
         ur, _ = run(sh, reps)
+        os.environ.pop("EEM_WGRAD_RING", None)
         os.environ["EEM_NO_WGRAD_RING"] = "1"
+        ub, _ = run(sh, reps)
+        os.environ["EEM_NO_WGRAD_BX3"] = "1"
         uo, _ = run(sh, reps)
         name, cin, cout, kh, kw, stride, n, hin, win = sh
         hout, wout = (hin + 2 * (kh // 2) - kh) // stride + 1, (win + 2 * (kw // 2) - kw) // stride + 1
         gflop = 2.0 * n * hout * wout * cout * cin * kh * kw / 1e9
-        print(f"{name:34s} {ur:9.1f} {gflop / ur * 1e3:8.1f} {uo:9.1f} {gflop / uo * 1e3:8.1f}  {uo / ur:5.2f}", flush=True)
+        print(f"{name:34s} {ur:9.1f} {gflop / ur * 1e3:8.1f} {ub:11.1f} {gflop / ub * 1e3:8.1f} {uo:12.1f} {gflop / uo * 1e3:8.1f}", flush=True)
 
 
 if __name__ == "__main__":

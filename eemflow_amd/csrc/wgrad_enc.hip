@@ -346,7 +346,8 @@ int launch_wide(const WgradArgs& a, hipStream_t st) {
 
 template <int MT, int S>
 int launch_tw(const WgradArgs& a, hipStream_t st) {
-    if (MT >= 2 && use_bx3()) {                                      // (one 16-cout tile per wave: the splits cost what the multiplies save)
+    static const bool mt1 = [] { const char* e = getenv("EEM_WGRAD_BX3_MT1"); return e && e[0] == '1'; }();     // (measurement)
+    if ((MT >= 2 || mt1) && use_bx3()) {                             // (one 16-cout tile per wave: the splits cost what the multiplies save)
         if (a.wout % 32 == 0 || a.wout >= 256) return launch<MT, S, 32, 16, 3, 3, true>(a, st);
         return launch<MT, S, 16, 16, 3, 3, true>(a, st);
     }

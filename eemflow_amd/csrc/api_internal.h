@@ -681,6 +681,14 @@ int run_enc_layer(eemflow_ctx* c, const Shape& s, int li, const float* e1, const
             // same within noise either way - those layers are bound by their transforms, not their bytes
             static const int cw = [] { const char* e = getenv("EEM_COLWALK"); return e ? atoi(e) : (1 << ENC_3_2) | (1 << ENC_3_3); }();
             if (s.batch >= 2 && ((cw >> sp.layer) & 1)) a.reverse = 2;
+            // ... or INTERLEAVED (EEM_WALK3=<layer mask>, round 6): an XCD's blocks take every G-th tile of its range, so neighbouring
+            // tiles are in flight together (conv_wino4.hip)
+            // Measured at ten frames per launch (profiles/r06_walk3.txt): FETCH_SIZE per frame pconv1_2 49.5 -> 32.8 MB (31.5 of input),
+            // pconv2_2 / 2_3 29.0 -> 17.0, pconv3_2 / 3_3 10.8 / 10.3 (column walk) -> 9.9 / 9.3; encoder 342 -> 299 MB per frame;
+            // 10 290 -> 10 500 frames/s over 400 steps.  Default for every stride-1 layer of a batched chain (supersedes the column walk).
+            static const int w3 = [] { const char* e = getenv("EEM_WALK3");
+                                       return e ? atoi(e) : (1 << ENC_1_2) | (1 << ENC_2_2) | (1 << ENC_2_3) | (1 << ENC_3_2) | (1 << ENC_3_3); }();
+            if (s.batch >= 2 && ((w3 >> sp.layer) & 1)) a.reverse = 3;
             static const int nts = [] { const char* e = getenv("EEM_NT_STORE"); return e ? atoi(e) : 0; }();
             a.nt_store = ((nts >> sp.layer) & 1) | ((nts >> 8) & 2);          // (bit 9, diagnostic builds: the weight-slice experiment of conv_wino4.hip)
         }

@@ -256,6 +256,10 @@ int run_f4(eraft_ctx* c, const Layer& L, const float* x, int n, int h, int w, fl
     a.bias = c->arena + L.shift; a.out = out;
     a.nimg = n; a.nimg0 = n; a.hin = h; a.win = w; a.hout = h; a.wout = w; a.hraw = h; a.wraw = w;
     a.act = act; a.res = res;
+    {   // the interleaved tile walk (conv_wino4.hip, round 6): neighbouring tiles in flight together; EEM_WALK3_ERAFT=0 keeps contiguous ranges
+        static const bool w3 = [] { const char* e = getenv("EEM_WALK3_ERAFT"); return !(e && e[0] == '0'); }();
+        if (w3) a.reverse = 3;
+    }
     return wino4_launch(64, a, st);
 }
 

@@ -301,6 +301,10 @@ static int backward_chain(eemflow_ctx* c, const Shape& s, const float* e1, const
             a.hin = l.hout; a.win = l.wout; a.hout = l.hin; a.wout = l.win; a.hraw = l.hout; a.wraw = l.wout;
             a.act = 0;
             a.gate = l.x;                                        // -> gradient w.r.t. the previous conv's pre-activation
+            {   // (the interleaved tile walk of the batched forward chains, api_internal.h; EEM_WALK3_TRAIN=0 keeps the contiguous ranges)
+                static const bool w3 = [] { const char* e = getenv("EEM_WALK3_TRAIN"); return !(e && e[0] == '0'); }();
+                if (w3 && n2 >= 4) a.reverse = 3;
+            }
             if ((rc = enc_conv_launch(r.cout, r.cin, 1, a, st)) != EEM_OK) return rc;
         } else {
             // stride-2 layers read a stage output, which also feeds the pooling

@@ -73,7 +73,7 @@ __device__ int g_wg_dbg;                                 // diagnostic builds: E
 // BX: the tile's products on the bf16 matrix pipe (exact three-piece operands, above) - wave w's 32 pixels of the tile are ONE K = 32 step:
 // (MT + 9) operand splits and 6 x 9 MT MFMAs of 16 cycles where the fp32 form issues 8 x 9 MT of 32
 template <int MT, int S, int TW, int CP, int KH = 3, int KW = 3, bool BX = false>
-__global__ __launch_bounds__(256) void wgrad_enc_kernel(WgradArgs a, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256) void wgrad_enc_kernel(WgradArgs a, int tiles_x, int tiles_y, int walk) {
     using C = WgCfg<MT, S, TW, CP, KH, KW>;
     constexpr int NT = C::NT, TAPS = C::TAPS;
     // blockIdx.z: chunk of MT * 16 couts (layers wider than 64 couts: E-RAFT's update block and heads)
@@ -88,9 +88,26 @@ __global__ __launch_bounds__(256) void wgrad_enc_kernel(WgradArgs a, int tiles_x
     const int cin_here = min(CP, a.cin - ci0);
     const int nvalid = cin_here * TAPS;
 
-    const TileRange tr_ = block_tile_range(tiles_x * tiles_y * a.n, blockIdx.x, gridDim.x);
+    // tiles: an XCD owns a contiguous range; its resident blocks take every gb-th tile of it (interleaved, round 6: the tiles whose halo
+    // rows / columns overlap are then in flight together and meet in the XCD's L2 - this kernel is bound by its operands' way in since its
+    // products run as bf16 pieces).  An EXPERIMENT (EEM_WGRAD_WALK=1): measured at no difference; default each block a contiguous sub-range
+    TileRange tr_ = block_tile_range(tiles_x * tiles_y * a.n, blockIdx.x, gridDim.x);
+    int walk_stride = 1;
+    if (walk) {
+        const int T = tiles_x * tiles_y * a.n;
+        const int cpx = (T + 7) >> 3, xcd = blockIdx.x & 7, kb = blockIdx.x >> 3, gb = gridDim.x >> 3;
+        const int r0 = xcd * cpx, r1 = min(r0 + cpx, T);
+        const int have = r1 - r0 - kb;
+        tr_.first = r0 + kb;
+        tr_.count = have > 0 ? (have + gb - 1) / gb : 0;
+        walk_stride = gb;
+    }
     if (tr_.count == 0) return;
     TileCoord cur = tile_coord(tr_.first, tiles_x, tiles_y);
+    auto advance = [&](TileCoord& t) {
+        t.bx += walk_stride;
+        while (t.bx >= tiles_x) { t.bx -= tiles_x; if (++t.by == tiles_y) { t.by = 0; ++t.n; } }
+    };
     const size_t ghw = (size_t)a.hout * a.wout, xhw = (size_t)a.hin * a.win;
 
     // ---- DMA plan: per instruction and lane a byte offset from the tile's base pointer and the piece's
@@ -191,7 +208,7 @@ __global__ __launch_bounds__(256) void wgrad_enc_kernel(WgradArgs a, int tiles_x
         __builtin_amdgcn_s_barrier();                            // everyone's have; everyone is done with tile it-1
         asm volatile("" ::: "memory");
         if (it + 1 < tr_.count) {
-            tile_advance(nxt, tiles_x, tiles_y);
+            advance(nxt);
             issue((it + 1) & 1, nxt);
         }
         const float* sg = lds + (it & 1) * C::STAGE;
@@ -322,7 +339,8 @@ int launch(const WgradArgs& a, hipStream_t st) {
                                           160 * 1024));
         raised = true;
     }
-    hipLaunchKernelGGL((wgrad_enc_kernel<MT, S, TW, CP, KH, KW, BX>), dim3(gx, chunks, cochunks), dim3(256), lds_bytes, st, a, tiles_x, tiles_y);
+    static const int walk = [] { const char* e = getenv("EEM_WGRAD_WALK"); return e ? atoi(e) : 0; }();     // (measured: no difference, profiles/r06_wgwalk.txt - its operands come out of L2 / MALL either way)
+    hipLaunchKernelGGL((wgrad_enc_kernel<MT, S, TW, CP, KH, KW, BX>), dim3(gx, chunks, cochunks), dim3(256), lds_bytes, st, a, tiles_x, tiles_y, walk);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

@@ -1,3 +1,5 @@
+#!/bin/bash
+# GPU box: the interleaved tile walk (EEM_WALK3 layer masks): frames/s over 400 steps, parity tests under both walks, FETCH_SIZE / WRITE_SIZE per frame
 # walk mode 3 on layers: ENC_1_2 = 1, ENC_2_2 = 3, ENC_2_3 = 4, ENC_3_2 = 6, ENC_3_3 = 7  (bit masks)
 for m in 0 2 26 218; do
   echo "== EEM_WALK3=$m"

@@ -1,3 +1,5 @@
+#!/bin/bash
+# GPU box (diagnostic build): tools/wgrad_bench.py with parts of the weight-gradient kernels removed: tools/wgrad_dbg.sh <shape filter> "<EEM_WG_DBG values>"
 mkdir -p gpurun_out
 export EEM_LIB_PATH=$PWD/eemflow_amd/libeemflow_hip_diag.so
 for d in $2; do

@@ -83,6 +83,7 @@ extern "C" void eemflow_destroy(eemflow_ctx* c) {
         (void)hipStreamDestroy(c->wstream);
         for (hipEvent_t e : c->wev) if (e) (void)hipEventDestroy(e);
         if (c->wjoin) (void)hipEventDestroy(c->wjoin);
+        if (c->prep_ev) (void)hipEventDestroy(c->prep_ev);
     }
     delete c;
 }

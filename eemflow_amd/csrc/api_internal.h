@@ -118,6 +118,8 @@ struct eemflow_ctx {
     static constexpr int kWEvents = 32;
     hipEvent_t wev[kWEvents] = {};
     hipEvent_t wjoin = nullptr;
+    hipEvent_t prep_ev = nullptr;                        // the side-stream prologue of a training forward (train_api.hip: forward_train_impl)
+    bool sumsq_zeroed = false;                           // the optimizer's sum-of-squares cell: cleared once by a fill, then by each step's re-packing launch
     int wev_next = 0;
     int* taps = nullptr;
     // workspaces

@@ -82,5 +82,7 @@ int dgrad_s2_launch(const DgradS2Args& a, hipStream_t st);
 bool dgrad_s2w_supported(const DgradS2Args& a, int ksize);
 int dgrad_s2w_launch(const DgradS2Args& a, int ksize, hipStream_t st);
 int tr_sumsq_launch(const float* g, long n, double* out, hipStream_t st);
+// repack_launch that also advances *nskip when *sumsq is not finite and clears *sumsq (the launch behind tr_adamw_launch)
+int tr_repack_after_step_launch(const float* flat, const int* idx, float* arena, long n, double* sumsq, int* nskip, hipStream_t st);
 int tr_adamw_launch(float* p, const float* g, float* m, float* v, long n, const double* sumsq, float clip, float lr, float wd,
                     float eps, float b1, float b2, long step, int* nskip, hipStream_t st);

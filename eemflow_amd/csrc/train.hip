@@ -8,10 +8,17 @@ namespace {
 
 inline unsigned nblocks(long n) { return (unsigned)((n + 255) / 256); }
 
+// sumsq / nskip (optimizer step only): the launch behind adamw_kernel also advances the count of skipped steps (every adamw thread has
+// read the old one by then) and leaves the sum of squares cleared for the next step
 __global__ __launch_bounds__(256) void repack_kernel(const float* __restrict__ flat, const int* __restrict__ idx,
-                                                     float* __restrict__ arena, long n) {
+                                                     float* __restrict__ arena, long n, double* __restrict__ sumsq,
+                                                     int* __restrict__ nskip) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) { const int k = idx[i]; arena[i] = k ? flat[k - 1] : 0.f; }
+    if (sumsq && i == 0) {
+        if (!(*sumsq <= 1.7976931348623157e308)) *nskip += 1;
+        *sumsq = 0.0;
+    }
 }
 
 // ---- sequence_loss for one prediction (train_mvsec.py:201-227): loss = mean(valid * |flow - gt|) over B*2*H*W,
@@ -445,7 +452,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 
 // A gradient with an inf or a NaN in it (sum of squares not finite) skips the step, as GradScaler.step does for the reference
 // (train_mvsec.py:257: no parameter, no moment changes, and the optimizer's own step count - the bias corrections - does not advance).
-// `nskip` counts the skipped steps so far; it is advanced by skipcount_kernel AFTER this launch (every thread reads the old value).
+// `nskip` counts the skipped steps so far; it is advanced by the re-packing launch AFTER this one (every thread reads the old value).
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, long n, const double* __restrict__ sumsq, float clip,
                                                     float lr, float wd, float eps, float b1, float b2, long step,
@@ -471,14 +478,16 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     p[i] = pi;
 }
 
-__global__ void skipcount_kernel(const double* __restrict__ sumsq, int* __restrict__ nskip) {
-    if (!(*sumsq <= 1.7976931348623157e308)) *nskip += 1;
-}
-
 }  // namespace
 
 int repack_launch(const float* flat, const int* idx, float* arena, long n, hipStream_t st) {
-    hipLaunchKernelGGL(repack_kernel, dim3(nblocks(n)), dim3(256), 0, st, flat, idx, arena, n);
+    hipLaunchKernelGGL(repack_kernel, dim3(nblocks(n)), dim3(256), 0, st, flat, idx, arena, n, (double*)nullptr, (int*)nullptr);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
+int tr_repack_after_step_launch(const float* flat, const int* idx, float* arena, long n, double* sumsq, int* nskip, hipStream_t st) {
+    hipLaunchKernelGGL(repack_kernel, dim3(nblocks(n)), dim3(256), 0, st, flat, idx, arena, n, sumsq, nskip);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }
@@ -742,7 +751,6 @@ int tr_sumsq_launch(const float* g, long n, double* out, hipStream_t st) {
 int tr_adamw_launch(float* p, const float* g, float* m, float* v, long n, const double* sumsq, float clip, float lr, float wd,
                     float eps, float b1, float b2, long step, int* nskip, hipStream_t st) {
     hipLaunchKernelGGL(adamw_kernel, dim3(nblocks(n)), dim3(256), 0, st, p, g, m, v, n, sumsq, clip, lr, wd, eps, b1, b2, step, nskip);
-    hipLaunchKernelGGL(skipcount_kernel, dim3(1), dim3(1), 0, st, sumsq, nskip);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

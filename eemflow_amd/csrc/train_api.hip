@@ -12,11 +12,28 @@ namespace {
 
 typedef eemflow_ctx::ConvRef ConvRef;
 
+// The context's side stream (weight gradients; the prologue of a training forward), or `st` itself under EEM_NO_WGRAD_STREAM=1 (read per
+// call: the tests run both forms)
+int side_stream(eemflow_ctx* c, hipStream_t st, hipStream_t* out) {
+    const char* off = getenv("EEM_NO_WGRAD_STREAM");
+    *out = st;
+    if (off && off[0] == '1') return EEM_OK;
+    if (!c->wstream) {
+        EEM_HIP_CHECK(hipStreamCreateWithFlags(&c->wstream, hipStreamNonBlocking));
+        for (hipEvent_t& e : c->wev) EEM_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        EEM_HIP_CHECK(hipEventCreateWithFlags(&c->wjoin, hipEventDisableTiming));
+        EEM_HIP_CHECK(hipEventCreateWithFlags(&c->prep_ev, hipEventDisableTiming));
+    }
+    *out = c->wstream;
+    return EEM_OK;
+}
+
 struct Bwd {
     eemflow_ctx* c;
     hipStream_t st;
     float* grad;           // flat gradient buffer
     hipStream_t wst;       // stream of the weight / bias gradient launches (the context's side stream, or st)
+    bool grad_zeroed = false;   // the forward's prologue cleared `grad` on the side stream (forward_train_impl)
 
     // the side stream picks up after everything queued on st so far (the gradient a weight-gradient launch reads is complete)
     int fork() {
@@ -158,19 +175,12 @@ static int backward_chain(eemflow_ctx* c, const Shape& s, const float* e1, const
                           hipStream_t st, Bwd& bw);
 
 static int backward_impl(eemflow_ctx* c, const Shape& s, const float* e1, const float* e2, const float* dflow, float* grad_out,
-                         hipStream_t st) {
-    // EEM_NO_WGRAD_STREAM=1 (read per call: the tests run both forms) keeps every launch on the caller's stream
-    const char* off = getenv("EEM_NO_WGRAD_STREAM");
-    hipStream_t wst = st;
-    if (!(off && off[0] == '1')) {
-        if (!c->wstream) {
-            EEM_HIP_CHECK(hipStreamCreateWithFlags(&c->wstream, hipStreamNonBlocking));
-            for (hipEvent_t& e : c->wev) EEM_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            EEM_HIP_CHECK(hipEventCreateWithFlags(&c->wjoin, hipEventDisableTiming));
-        }
-        wst = c->wstream;
-    }
+                         hipStream_t st, bool grad_zeroed = false) {
+    hipStream_t wst;
+    const int rs = side_stream(c, st, &wst);
+    if (rs != EEM_OK) return rs;
     Bwd bw{c, st, grad_out, wst};
+    bw.grad_zeroed = grad_zeroed;
     const int rc = backward_chain(c, s, e1, e2, dflow, grad_out, st, bw);
     const int rj = bw.join();                        // also after an error: nothing of this pass stays behind on the side stream
     return rc != EEM_OK ? rc : rj;
@@ -181,7 +191,7 @@ static int backward_chain(eemflow_ctx* c, const Shape& s, const float* e1, const
     int rc;
     const int B = s.batch, n2 = 2 * s.batch, in_h = s.in_h, in_w = s.in_w;
     const size_t g = (size_t)s.gh * s.gw;
-    EEM_HIP_CHECK(hipMemsetAsync(grad_out, 0, c->nflat * sizeof(float), st));
+    if (!bw.grad_zeroed) EEM_HIP_CHECK(hipMemsetAsync(grad_out, 0, c->nflat * sizeof(float), st));
     // ---- upsample backward (EEMFlow.py:118-120)
     if ((rc = tr_upsample_bwd_launch(dflow, c->ups_tmp.p, c->g_coarse.p, B * 2, s.out_h, s.out_w, s.gh, s.gw, st)) != EEM_OK) return rc;
     // ---- the 1/64-grid tail, last layer first.  Weight / bias gradients: one launch per conv.  Data gradients: the
@@ -285,8 +295,18 @@ static int backward_chain(eemflow_ctx* c, const Shape& s, const float* e1, const
     if ((rc = tr_pool_bwd_launch(c->g_pool[2].p, c->g_f13.p, (long)n2 * 64, s.h3, s.w3, 8, s.gh, s.gw, 0, c->f13.p, st)) != EEM_OK) return rc;
     for (const L& l : ls) {
         const ConvRef& r = c->t_enc[l.layer];
+        if (!l.gx) {
+            // the first layer has no data gradient: its weight gradient follows the chain on st, where its operand was produced, and runs
+            // beside pconv1_2's on the side stream instead of behind it (EEM_WGRAD_LAST_SIDE=1: the round-5 order, for measurements)
+            static const bool side = [] { const char* e = getenv("EEM_WGRAD_LAST_SIDE"); return e && e[0] == '1'; }();
+            hipStream_t keep = bw.wst;
+            if (!side) bw.wst = st;
+            rc = bw.wgrad(r, l.x, l.xc, 0, l.gy, nullptr, r.cout, 0, 1, n2, l.hin, l.win, l.hout, l.wout);
+            bw.wst = keep;
+            if (rc != EEM_OK) return rc;
+            continue;
+        }
         if ((rc = bw.wgrad(r, l.x, l.xc, 0, l.gy, nullptr, r.cout, 0, 1, n2, l.hin, l.win, l.hout, l.wout)) != EEM_OK) return rc;
-        if (!l.gx) continue;
         if (r.fast_dgrad) {
             EncConvArgs a;
             memset(&a, 0, sizeof(a));
@@ -328,8 +348,11 @@ static int backward_chain(eemflow_ctx* c, const Shape& s, const float* e1, const
 }
 
 // Eager forward that keeps every activation for a following eemflow_backward (train-mode output size).
+// what eemflow_forward_backward wants cleared before its loss / backward: done by the forward's side-stream prologue when there is one
+struct StepZero { float* grad; double* stats; bool done; };
+
 static int forward_train_impl(eemflow_ctx* c, const float* e1, const float* e2, int batch, int in_h, int in_w, int out_h, int out_w,
-                              float* flow_out, hipStream_t st, Shape* sout) {
+                              float* flow_out, hipStream_t st, Shape* sout, StepZero* zero = nullptr) {
     Shape s;
     int rc = compute_shape(c, batch, in_h, in_w, out_h, out_w, &s);
     if (rc != EEM_OK) return rc;
@@ -343,8 +366,34 @@ static int forward_train_impl(eemflow_ctx* c, const float* e1, const float* e2, 
     // both volumes replicate-padded into one batch: the first layer's weight gradient needs that copy, and reading the forward's first
     // layer from it lets 346-pixel rows (MVSEC: not a 16-byte multiple, 19 columns of left padding) use the LDS-DMA kernel too
     const int B = batch;
-    if ((rc = ensure_train_wino(c, batch, st)) != EEM_OK) return rc;
-    if ((rc = er_pad2_launch(e1, e2, c->padded.p, B * c->cin0, in_h, in_w, c->pad[0], c->pad[1], c->pad[2], c->pad[3], st)) != EEM_OK) return rc;
+    // Round 6: everything in front of the first conv that does not read the inputs - the Winograd / bf16-piece forms of the weights the
+    // optimizer step just changed (three ~5 us launches), and for eemflow_forward_backward the clearing of the gradient buffer and of the
+    // loss sums (two fills, each with a ~7 us bubble behind it) - runs on the side stream BESIDE the padding kernel instead of in the
+    // chain.  EEM_TRAIN_SIDE_PREP=0 keeps them on st (measurements).
+    hipStream_t wst;
+    if ((rc = side_stream(c, st, &wst)) != EEM_OK) return rc;
+    static const bool side_prep = [] { const char* e = getenv("EEM_TRAIN_SIDE_PREP"); return !(e && e[0] == '0'); }();
+    if (wst != st && side_prep) {
+        hipEvent_t e = c->wev[c->wev_next++ % eemflow_ctx::kWEvents];
+        EEM_HIP_CHECK(hipEventRecord(e, st));                 // (behind the previous step: its backward read these weight forms, its optimizer the gradient)
+        EEM_HIP_CHECK(hipStreamWaitEvent(wst, e, 0));
+        if (zero) {
+            EEM_HIP_CHECK(hipMemsetAsync(zero->grad, 0, c->nflat * sizeof(float), wst));
+            EEM_HIP_CHECK(hipMemsetAsync(zero->stats, 0, 8 * sizeof(double), wst));
+            zero->done = true;
+        }
+        if ((rc = ensure_train_wino(c, batch, wst)) != EEM_OK) return rc;
+        for (int l = 0; l < ENC_NUM; ++l) {
+            const float* ws;
+            if (c->enc_bx3[l] && bx3_wanted(l) && (rc = ensure_bx3(c, l, wst, &ws)) != EEM_OK) return rc;
+        }
+        EEM_HIP_CHECK(hipEventRecord(c->prep_ev, wst));
+        if ((rc = er_pad2_launch(e1, e2, c->padded.p, B * c->cin0, in_h, in_w, c->pad[0], c->pad[1], c->pad[2], c->pad[3], st)) != EEM_OK) return rc;
+        EEM_HIP_CHECK(hipStreamWaitEvent(st, c->prep_ev, 0));
+    } else {
+        if ((rc = ensure_train_wino(c, batch, st)) != EEM_OK) return rc;
+        if ((rc = er_pad2_launch(e1, e2, c->padded.p, B * c->cin0, in_h, in_w, c->pad[0], c->pad[1], c->pad[2], c->pad[3], st)) != EEM_OK) return rc;
+    }
     Hook hk;
     hk.st = st;
     static const bool no_prepad = [] { const char* e = getenv("EEM_NO_PREPAD_FWD"); return e && e[0] == '1'; }();
@@ -402,11 +451,13 @@ extern "C" int eemflow_forward_backward(eemflow_ctx* c, const float* e1, const f
     EEM_HIP_CHECK(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     Shape s;
-    int rc = forward_train_impl(c, e1, e2, batch, in_h, in_w, out_h, out_w, flow_out, st, &s);
-    if (rc != EEM_OK) return rc;
-    const int B = batch;
+    int rc;
+    if ((rc = ensure(c->scalars, 24)) != EEM_OK) return rc;
     double* stats = (double*)c->scalars.p;
-    EEM_HIP_CHECK(hipMemsetAsync(stats, 0, 8 * sizeof(double), st));
+    StepZero zero{grad_out, stats, false};
+    if ((rc = forward_train_impl(c, e1, e2, batch, in_h, in_w, out_h, out_w, flow_out, st, &s, &zero)) != EEM_OK) return rc;
+    const int B = batch;
+    if (!zero.done) EEM_HIP_CHECK(hipMemsetAsync(stats, 0, 8 * sizeof(double), st));
     // ---- loss and d loss / d flow (train_mvsec.py:201-227)
     if ((rc = tr_loss_launch(flow_out, flow_gt, valid, c->g_flow.p, B, s.out_h * s.out_w, gamma_weight, stats, st)) != EEM_OK) return rc;
     c->stats_scale = (double)gamma_weight / ((double)B * 2.0 * s.out_h * s.out_w);
@@ -425,13 +476,15 @@ extern "C" int eemflow_forward_backward(eemflow_ctx* c, const float* e1, const f
             EEM_HIP_CHECK(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
             EEM_HIP_CHECK(hipEventCreateWithFlags(&c->loss_ev, hipEventDisableTiming));
         }
+        // (measured: letting the copy ride the backward's first fork event instead of one of its own - one event record less in the
+        // chain - makes the step 0.04 ms SLOWER: the host returns from eemflow_train_stats_wait that much later)
         EEM_HIP_CHECK(hipEventRecord(c->loss_ev, st));
         EEM_HIP_CHECK(hipStreamWaitEvent(c->cstream, c->loss_ev, 0));
         EEM_HIP_CHECK(hipMemcpyAsync(c->stats_host, stats, 5 * sizeof(double), hipMemcpyDeviceToHost, c->cstream));
         EEM_HIP_CHECK(hipEventRecord(c->stats_ev, c->cstream));
         c->stats_pending = true;
     }
-    if ((rc = backward_impl(c, s, e1, e2, c->g_flow.p, grad_out, st)) != EEM_OK) return rc;
+    if ((rc = backward_impl(c, s, e1, e2, c->g_flow.p, grad_out, st, zero.done)) != EEM_OK) return rc;
     if (stats_out) {
         double hst[5];
         EEM_HIP_CHECK(hipMemcpyAsync(hst, stats, sizeof(hst), hipMemcpyDeviceToHost, st));
@@ -498,13 +551,17 @@ extern "C" int eemflow_optimizer_step(eemflow_ctx* c, const float* grad, float l
         EEM_HIP_CHECK(hipMemsetAsync(nskip, 0, sizeof(int), st));
         c->skip_counter_zeroed = true;
     }
-    EEM_HIP_CHECK(hipMemsetAsync(sumsq, 0, sizeof(double), st));
+    if (!c->sumsq_zeroed)                                    // (afterwards the re-packing launch leaves it cleared for the next step)
+        EEM_HIP_CHECK(hipMemsetAsync(sumsq, 0, sizeof(double), st));
+    c->sumsq_zeroed = false;                                 // (true again once this step's re-packing launch is in the queue)
     if ((rc = tr_sumsq_launch(grad, (long)c->nflat, sumsq, st)) != EEM_OK) return rc;
     c->opt_step += 1;
     if ((rc = tr_adamw_launch(c->flat, grad, c->adam_m.p, c->adam_v.p, (long)c->nflat, sumsq, clip, lr, weight_decay, eps, 0.9f,
                               0.999f, c->opt_step, nskip, st)) != EEM_OK) return rc;
     // (cached graphs read the arena in place: same addresses, new values)
-    if ((rc = repack_launch(c->flat, c->pack_idx, c->arena, (long)c->arena_floats, st)) != EEM_OK) return rc;
+    // (its first thread also counts a skipped step and clears the sum of squares: no launches of their own)
+    if ((rc = tr_repack_after_step_launch(c->flat, c->pack_idx, c->arena, (long)c->arena_floats, sumsq, nskip, st)) != EEM_OK) return rc;
+    c->sumsq_zeroed = true;
     return refresh_wino(c, st);
 }
 

@@ -15,7 +15,7 @@ tr = EEMFlowTrainer(net, lr=1e-4, num_steps=1000)
 e1, e2 = (torch.from_numpy(a).cuda() for a in synthetic_voxel_pair(1, b, h, w))
 gt, va = (torch.from_numpy(a).cuda() for a in synthetic_gt(2, b, h, w))
 for _ in range(3): tr.step(e1, e2, gt, va)
-torch.cuda.synchronize(); t0 = time.perf_counter(); n = 10
+torch.cuda.synchronize(); t0 = time.perf_counter(); n = int(os.environ.get("EEM_BT_N", "10"))
 for _ in range(n): loss, m, _ = tr.step(e1, e2, gt, va)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 flop = 3 * 2 * (0.9114e9 if (h, w) == (260, 346) else 7.2913e9 * (h * w) / (720 * 1280)) * b

@@ -15,11 +15,11 @@ CSRC = os.path.join(PKG, "csrc")
 # libeemflow_hip_<tag>.so - which tools load through EEM_LIB_PATH
 TAG = os.environ.get("EEM_BUILD_TAG", "")
 LIB = os.path.join(PKG, f"libeemflow_hip_{TAG}.so" if TAG else "libeemflow_hip.so")
-SOURCES = ["api.hip", "conv_enc.hip", "conv_enc1.hip", "conv_enc2.hip", "conv_s2.hip", "conv_s2r.hip", "conv_bx3.hip", "conv_wino.hip", "conv_wino32.hip", "conv_wino4.hip", "conv_enc12.hip", "tail.hip", "tail_fused.hip", "voxel.hip", "metrics.hip", "gconv.hip", "gconv16.hip", "gconvb.hip", "conv_stem7.hip", "eraft_kernels.hip",
+SOURCES = ["api.hip", "conv_enc.hip", "conv_enc1.hip", "conv_enc2.hip", "conv_s2.hip", "conv_s2r.hip", "conv_bx3.hip", "conv_wino.hip", "conv_wino32.hip", "conv_wino4.hip", "conv_enc12.hip", "conv_wnc.hip", "tail.hip", "tail_fused.hip", "voxel.hip", "metrics.hip", "gconv.hip", "gconv16.hip", "gconvb.hip", "conv_stem7.hip", "eraft_kernels.hip",
            "eraft_api.hip", "train.hip", "wgrad_enc.hip", "wgrad_ring.hip", "wgrad_tail.hip", "dgrad_s2.hip", "train_api.hip", "plus_kernels.hip", "plus_api.hip", "bwd_ops.hip", "ops.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-fvisibility=hidden", "-fvisibility-inlines-hidden"]   # hidden: only include/eemflow_hip.h's entry points are dynamic symbols
 EXTRA = {"voxel.hip": ["-ffp-contract=off"],
-         "conv_wino.hip": ["-fno-slp-vectorize"], "conv_wino32.hip": ["-fno-slp-vectorize"], "conv_wino4.hip": ["-fno-slp-vectorize"], "conv_enc12.hip": ["-fno-slp-vectorize"],     # packed f32 VALU beside MFMAs is slower than scalar (guide: anti-lever)      # bit-exact f64 time scaling
+         "conv_wino.hip": ["-fno-slp-vectorize"], "conv_wino32.hip": ["-fno-slp-vectorize"], "conv_wino4.hip": ["-fno-slp-vectorize"], "conv_enc12.hip": ["-fno-slp-vectorize"], "conv_wnc.hip": ["-fno-slp-vectorize"],     # packed f32 VALU beside MFMAs is slower than scalar (guide: anti-lever)      # bit-exact f64 time scaling
          "plus_kernels.hip": ["-ffp-contract=off"],
          "bwd_ops.hip": ["-ffp-contract=off"]}      # same coordinate arithmetic (and mask) as the forward warp   # the warp mask depends on the last bit of the weight sum
 

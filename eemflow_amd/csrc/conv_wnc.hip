@@ -1,0 +1,295 @@
+// Winograd F(2x2,3x3) for EEMFlow+'s mid-size 3x3 stride-1 layers at the fine pyramid levels (EEMFlow+.py:38-71 decoders,
+// cdc_utils.py:105-151 dense mask estimator, the rconv layers): inputs of 32 .. 256 channels that are a channel RANGE of a wider
+// tensor (the dense estimator's growing concatenation, the decoder's 96-channel buffer, a group of a grouped conv), outputs in
+// slices of 32 channels written with a channel stride (channel_shuffle is an output stride of `groups`).
+//
+// Same algebra and fragment layout as conv_wino32.hip (v_mfma_f32_32x32x2_f32: M = 32 couts, N = 32 2x2-pixel tiles, K = 2 cin;
+// the 16 Winograd positions split by ROWS over the four waves of a team, V = B^T d B computed in the lane that feeds it to the
+// MFMA, the four waves exchange u_xi = M_xi A through LDS and each finishes 8 cout rows), re-cut around the input depth:
+//   * the input is consumed in chunks of 32 channels: the chunk's haloed tile [32][6][72] goes L2/HBM -> LDS by 16-byte LDS-DMA,
+//     double-buffered; the accumulators live across the chunks of a tile and the output transform runs after the last one;
+//   * a chunk's weights (64 KB for the four waves of a team) cannot stay in registers across chunks: they stream from L2 in halves
+//     of a chunk (8 k-steps = 32 VGPRs), each half requested while the half before it multiplies - as asm loads with counted
+//     s_waitcnt vmcnt, the way gconv16.hip does it (the compiler's own bookkeeping of loads in flight across a loop's back edge
+//     drains them all);
+//   * request order inside a chunk: [weights of its second half] [next chunk's tile DMA] ... first half multiplies ...
+//     vmcnt(DMA pieces) ... [weights of the next chunk's first half] ... second half multiplies: nothing the running chunk waits
+//     for is younger than the next chunk's DMA, which has the whole chunk to land;
+//   * a launch takes up to eight JOBS (32-cout slices of one layer, or the groups of a grouped layer): persistent blocks walk
+//     (job, image, tile) triples, so the three groups of a decoder layer or the three slices of its first conv fill the chip as one
+//     launch.
+// Input depths that are not a multiple of 32 (the estimator's 176 and 184) end in a chunk that overlaps the one before it; the
+// repeated channels' weights are packed as zeros (wnc_pack) - what they multiply is a finite activation.
+#include <type_traits>
+#include <vector>
+
+#include "wnc.h"
+
+namespace {
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+constexpr int TH = 4, TW = 64, WAVES = 8;                  // block tile: 4 x 64 pixels = two groups of 32 tiles, one per team of four waves
+constexpr int IN_ROWS = TH + 2, ROWP = TW + 8, PPR = ROWP / 4, PLANE = IN_ROWS * ROWP, PC = IN_ROWS * PPR;
+// one DMA instruction of the block (512 lanes) moves CPI whole channels; lane slot = wave * 64 + lane holds the same (channel in group,
+// row, 16-byte piece) for every instruction (conv_wino32.hip: W32Cfg)
+constexpr int SLOTS_I = WAVES * 64, CPI = (SLOTS_I / PC) & ~1, NI = 32 / CPI, STAGE = NI * WAVES * 256;
+constexpr int NSTORE = 8;                                  // stores per wave and tile (always issued: the waits count them)
+__host__ __device__ constexpr int chan_off(int c) { return ((c / CPI) * SLOTS_I + (c % CPI) * PC) * 4; }   // floats from the stage base
+static_assert(CPI == 4 && NI == 8 && STAGE == WAVES * 64 * 32, "stage = exchange buffer");
+static_assert((chan_off(30) + PLANE) * 4 + 3 * ROWP * 4 + 64 < 65536, "ds_read immediate range");
+static_assert(2 * STAGE * 4 <= 160 * 1024, "LDS budget");
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void unroll_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        unroll_for<I + 1, N>(f);
+    }
+}
+
+__global__ __launch_bounds__(WAVES * 64, 1) void wnc_kernel(WncArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nl = lane & 31, kk = lane >> 5;
+    const int team = wave >> 2, xi = wave & 3;               // team = tile-row pair of the block tile; xi = Winograd row of this wave
+    const int tiles_x = ceil_div(a.w, TW), tiles_y = ceil_div(a.h, TH);
+    const TileRange range = block_tile_range(tiles_x * tiles_y * a.njobs * a.n, blockIdx.x, gridDim.x);
+    const int ntile = range.count;
+    if (ntile == 0) return;
+    const int nchunks = a.nchunks, niter = ntile * nchunks;
+    const int plane = a.h * a.w;
+    TileCoord cur = tile_coord(range.first, tiles_x, tiles_y), nxt = cur;      // .n = job * batch + image
+    int cur_ch = 0, nxt_ch = 0;
+
+    // ---- DMA plan (fixed for the kernel): slot -> (channel in group, tile row, 16-byte piece)
+    const int dslot = wave * 64 + lane;
+    const int dcl = dslot / PC, drem = dslot - dcl * PC, dry = drem / PPR, dq = drem - dry * PPR;
+    auto issue = [&](int stage, const TileCoord& tc, int ch) __attribute__((always_inline)) {
+        const int j = tc.n / a.n, n = tc.n - j * a.n;
+        const WncJob& J = a.job[j];
+        const float* base = J.in + ((size_t)n * J.in_ctotal + J.in_coff + a.chunk_off[ch]) * plane;
+        const int gy = tc.by * TH - 1 + dry, gx = tc.bx * TW - 4 + dq * 4;
+        const bool ok = dcl < CPI && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+        const char* gp = ok ? reinterpret_cast<const char*>(base + ((dcl * a.h + gy) * a.w + gx)) : reinterpret_cast<const char*>(a.zero_page);
+        const unsigned step = ok ? (unsigned)(CPI * plane) * 4u : 0u;
+        float* sbase = lds + stage * STAGE;
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(gp), LDS_PTR(sbase + (wave + k * WAVES) * 256), 16, 0, 0);
+            gp += step;
+        }
+    };
+    // ---- weights: [xi][half-chunk][k-step of the half (8)][lane][nu] floats per job; a half = 8 asm loads of 16 bytes per lane
+    const unsigned vo0 = lane * 16u, vo1 = vo0 + 4096u;
+    auto load_w = [&](f32x4 (&dst)[8], const TileCoord& tc, int hf) __attribute__((always_inline)) {
+        const int j = tc.n / a.n;
+        const char* wb = reinterpret_cast<const char*>(a.job[j].w) + ((size_t)(xi * 2 * nchunks + hf) * 8) * 1024;
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst[s]) : "v"(s < 4 ? vo0 : vo1), "s"(wb), "n"((s & 3) * 1024) : "memory");
+    };
+    auto landed = [&](f32x4 (&w)[8]) __attribute__((always_inline)) {      // tells the compiler the registers are ready (gconv16.hip)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(w[s]));
+    };
+    // bias of the 4 cout rows this wave finishes: co = r + 8 xi + 4 kk
+    f32x4 biasv = {0.f, 0.f, 0.f, 0.f};
+    const unsigned bo = (unsigned)(8 * xi + 4 * kk) * 4u;
+    auto load_bias = [&](const TileCoord& tc) __attribute__((always_inline)) {
+        const int j = tc.n / a.n;
+        const char* bb = reinterpret_cast<const char*>(a.job[j].bias);
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(biasv) : "v"(bo), "s"(bb) : "memory");
+    };
+
+    // patch rows of this wave: t_xi = e_a + sgn * e_b with (a, b, sgn) = (0,2,-) (1,2,+) (2,1,-) (1,3,-)
+    const int ra = xi == 0 ? 0 : (xi == 2 ? 2 : 1);
+    const int rb = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
+    const float sgn = xi == 1 ? 1.f : -1.f;
+    const int lbase = kk * PLANE + 2 * team * ROWP + 2 * nl + 2;          // patch column -1 sits at the odd half of an aligned pair
+
+    f32x16 acc[4];
+    f32x4 wr[2][8];
+    // one half of a chunk: 8 k-steps (2 channels each) x 4 MFMAs
+    auto half = [&](auto hl_tag, const f32x4 (&w)[8], const float* stage) __attribute__((always_inline)) {
+        constexpr int HL = decltype(hl_tag)::value;
+        const float* pa = stage + lbase + ra * ROWP;
+        const float* pb = stage + lbase + rb * ROWP;
+        f32x2 na[3], nb[3];
+        auto load_patch = [&](auto sc_tag) __attribute__((always_inline)) {
+            constexpr int off = chan_off(2 * decltype(sc_tag)::value);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                na[q] = *reinterpret_cast<const f32x2*>(pa + off + 2 * q);
+                nb[q] = *reinterpret_cast<const f32x2*>(pb + off + 2 * q);
+            }
+        };
+        load_patch(std::integral_constant<int, HL * 8>{});
+        unroll_for<0, 8>([&](auto s_tag) __attribute__((always_inline)) {
+            constexpr int s = decltype(s_tag)::value;
+            const float ea[4] = {na[0][1], na[1][0], na[1][1], na[2][0]};
+            const float eb[4] = {nb[0][1], nb[1][0], nb[1][1], nb[2][0]};
+            if constexpr (s + 1 < 8) {
+                load_patch(std::integral_constant<int, HL * 8 + s + 1>{});
+                __builtin_amdgcn_sched_barrier(0);           // the next k-step's reads stay ahead of this one's transform and MFMAs
+            }
+            float t[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) t[b] = __builtin_fmaf(sgn, eb[b], ea[b]);
+            const float v[4] = {t[0] - t[2], t[1] + t[2], t[2] - t[1], t[1] - t[3]};
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[s][nu], v[nu], acc[nu], 0, 0, 0);
+        });
+    };
+
+    // ---- prologue: the first chunk's first half of weights, then its tile
+    load_w(wr[0], cur, 0);
+    issue(0, cur, 0);
+    bool stored = false;                                     // the previous iteration ended in a tile's stores (the youngest requests)
+#pragma unroll 1
+    for (int it = 0; it < niter; ++it) {
+        const bool first = cur_ch == 0, last = cur_ch == nchunks - 1, more = it + 1 < niter;
+        // this chunk's tile and its first half of weights have landed; every wave is through with the other stage
+        if (stored) wait_vm<NSTORE>(); else wait_vm<0>();
+        landed(wr[0]);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (first) {
+            load_bias(cur);
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nu][r] = 0.f;
+        }
+        load_w(wr[1], cur, 2 * cur_ch + 1);
+        if (more) {
+            if (++nxt_ch == nchunks) { nxt_ch = 0; tile_advance(nxt, tiles_x, tiles_y); }
+            issue((it + 1) & 1, nxt, nxt_ch);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float* stage = lds + (it & 1) * STAGE;
+        half(std::integral_constant<int, 0>{}, wr[0], stage);
+        // the second half's weights (and the bias): only the next chunk's DMA pieces are younger
+        if (more) wait_vm<NI>(); else wait_vm<0>();
+        landed(wr[1]);
+        asm volatile("" : "+v"(biasv));
+        if (more) load_w(wr[0], nxt, 2 * nxt_ch);
+        __builtin_amdgcn_sched_barrier(0);
+        half(std::integral_constant<int, 1>{}, wr[1], stage);
+        stored = false;
+        if (last) {
+            // ---- u = M_xi A, exchanged through the stage this tile has finished with: [wave][r][lane][2]
+            __builtin_amdgcn_s_barrier();                    // every wave is done reading the stage
+            float* xst = lds + (it & 1) * STAGE;
+            f32x2* xw = reinterpret_cast<f32x2*>(xst) + (wave * 16) * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                f32x2 u;
+                u[0] = acc[0][r] + acc[1][r] + acc[2][r];
+                u[1] = acc[1][r] - acc[2][r] - acc[3][r];
+                xw[r * 64] = u;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // wave xi finishes accumulator rows 4 xi .. 4 xi + 3 of its team: couts r + 8 xi + 4 kk
+            const f32x2* xr = reinterpret_cast<const f32x2*>(xst) + ((wave - xi) * 16 + 4 * xi) * 64 + lane;
+            const int j = cur.n / a.n, n = cur.n - j * a.n;
+            const WncJob& J = a.job[j];
+            const int oy = cur.by * TH + 2 * team, ox = cur.bx * TW + 2 * nl;
+            const bool in0 = oy < a.h && ox < a.w, in1 = oy + 1 < a.h && ox < a.w;
+            const int co0 = 8 * xi + 4 * kk;
+            float* sink = a.trash + lane * 2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const f32x2 u0 = xr[(0 * 16 + r) * 64], u1 = xr[(1 * 16 + r) * 64], u2 = xr[(2 * 16 + r) * 64], u3 = xr[(3 * 16 + r) * 64];
+                float y00 = u0[0] + u1[0] + u2[0] + biasv[r], y01 = u0[1] + u1[1] + u2[1] + biasv[r];
+                float y10 = u1[0] - u2[0] - u3[0] + biasv[r], y11 = u1[1] - u2[1] - u3[1] + biasv[r];
+                if (a.act) {
+                    y00 = fmaxf(y00, 0.1f * y00); y01 = fmaxf(y01, 0.1f * y01);
+                    y10 = fmaxf(y10, 0.1f * y10); y11 = fmaxf(y11, 0.1f * y11);
+                }
+                const int co = co0 + r;
+                const bool okc = co < J.cout;
+                float* p = J.out + ((size_t)n * J.out_ctotal + J.out_coff + (size_t)co * J.out_cmul) * plane + (size_t)oy * a.w + ox;
+                // every lane stores (lanes outside the image or beyond cout into a scratch page): exactly NSTORE stores per wave and tile
+                *reinterpret_cast<f32x2*>(in0 && okc ? p : sink) = f32x2{y00, y01};
+                *reinterpret_cast<f32x2*>(in1 && okc ? p + a.w : sink) = f32x2{y10, y11};
+            }
+            stored = true;
+        }
+        cur = nxt;
+        cur_ch = nxt_ch;
+    }
+}
+
+}  // namespace
+
+int wnc_chunks(int cin, int* chunk_off) {
+    int n = 0;
+    for (int c = 0; c + 32 <= cin; c += 32) chunk_off[n++] = c;
+    if (cin % 32) chunk_off[n++] = cin - 32;
+    return n;
+}
+
+size_t wnc_packed_floats(int cin) {
+    int off[WNC_MAX_CHUNKS + 2];
+    const int nch = cin >= 32 && cin <= 32 * WNC_MAX_CHUNKS ? wnc_chunks(cin, off) : 0;
+    return (size_t)4 * 2 * nch * 8 * 64 * 4;
+}
+
+void wnc_pack(const float* w, int cout, int cin, int co0, float* packed) {
+    int off[WNC_MAX_CHUNKS + 2];
+    const int nch = wnc_chunks(cin, off);
+    const int rep = cin % 32 ? 32 - cin % 32 : 0;            // the last chunk's first `rep` channels repeat the chunk before it
+    for (int xi = 0; xi < 4; ++xi)
+        for (int hf = 0; hf < 2 * nch; ++hf)
+            for (int s = 0; s < 8; ++s)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int k = hf >> 1, l = (hf & 1) * 16 + 2 * s + (lane >> 5);
+                    const int co = co0 + (lane & 31), ci = off[k] + l;
+                    float* o = packed + ((((size_t)xi * 2 * nch + hf) * 8 + s) * 64 + lane) * 4;
+                    if (co >= cout || (k == nch - 1 && l < rep)) { o[0] = o[1] = o[2] = o[3] = 0.f; continue; }
+                    const float* g = w + ((size_t)co * cin + ci) * 9;
+                    float m[3];                              // row xi of G g
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float g0 = g[kx], g1 = g[3 + kx], g2 = g[6 + kx];
+                        m[kx] = xi == 0 ? g0 : (xi == 1 ? 0.5f * (g0 + g1 + g2) : (xi == 2 ? 0.5f * (g0 - g1 + g2) : g2));
+                    }
+                    o[0] = m[0];
+                    o[1] = 0.5f * (m[0] + m[1] + m[2]);
+                    o[2] = 0.5f * (m[0] - m[1] + m[2]);
+                    o[3] = m[2];
+                }
+}
+
+bool wnc_supported(const WncArgs& a) {
+    const char* e = getenv("EEM_NO_WNC");                   // read per call: a test runs both forms in one process
+    if (e && e[0] == '1') return false;
+    if (a.njobs < 1 || a.njobs > WNC_MAX_JOBS || a.nchunks < 1 || a.nchunks > WNC_MAX_CHUNKS || a.n < 1) return false;
+    if (a.w % 4 || a.h < 1 || !a.zero_page || !a.trash || ((uintptr_t)a.zero_page & 15) || ((uintptr_t)a.trash & 7)) return false;
+    if ((size_t)a.h * a.w * 32 * 4 >= (1u << 31)) return false;                  // 32-bit byte offsets inside a chunk
+    for (int j = 0; j < a.njobs; ++j) {
+        const WncJob& J = a.job[j];
+        if (!J.in || !J.w || !J.bias || !J.out || J.cout < 1 || J.cout > 32 || J.out_cmul < 1) return false;
+        if (((uintptr_t)J.in & 15) || ((uintptr_t)J.w & 15) || ((uintptr_t)J.bias & 15) || ((uintptr_t)J.out & 15)) return false;
+    }
+    return true;
+}
+
+int wnc_launch(const WncArgs& a, hipStream_t st) {
+    const int T = ceil_div(a.w, TW) * ceil_div(a.h, TH) * a.njobs * a.n;
+    int per_xcd = ceil_div(T, 8);
+    if (per_xcd > 32) per_xcd = 32;                          // one resident block per CU
+    hipLaunchKernelGGL(wnc_kernel, dim3(per_xcd * 8), dim3(WAVES * 64), 0, st, a);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}

@@ -10,6 +10,7 @@
 #include "eraft_kernels.h"
 #include "gconv.h"
 #include "plus_kernels.h"
+#include "wnc.h"
 
 #include <utility>
 
@@ -35,7 +36,12 @@ int pensure_zeroed(PBuf& b, size_t floats) {
     return EEM_OK;
 }
 
-struct PLayer { size_t wpk = 0, wpk16 = 0, wpkb = 0, wtail = 0, wfew = 0, bias = 0; bool hasb = false, has16 = false, has_tail = false, has_few = false; int cin = 0, cout = 0, k = 3, stride = 1; };
+struct PLayer {
+    size_t wpk = 0, wpk16 = 0, wpkb = 0, wtail = 0, wfew = 0, bias = 0;
+    size_t wwnc[3] = {0, 0, 0};          // Winograd streams of the layer's 32-cout slices (conv_wnc.hip)
+    bool hasb = false, has16 = false, has_tail = false, has_few = false, has_wnc = false;
+    int cin = 0, cout = 0, k = 3, stride = 1;
+};
 
 const int kTaps[53] = {0,  2,  4,  6,  8,  10, 12, 14, 16, 18, 20, 21, 22, 23, 24, 26, 28, 29, 30, 31, 32, 33, 34, 36, 38, 39, 40,
                        41, 42, 44, 46, 47, 48, 49, 50, 51, 52, 54, 56, 57, 58, 59, 60, 62, 64, 66, 68, 70, 72, 74, 76, 78, 80};
@@ -95,7 +101,15 @@ void mk(Pk& pk, PLayer& L, const float* w, const float* b, int cin, int cout, in
         L.wfew = pk.push(fewout_packed_floats(cin, k, k));
         fewout_pack(w, cout, cin, k, k, pk.host.data() + L.wfew);
     }
-    L.bias = pk.push(cout);
+    // 3x3 layers of >= 32 input channels: the F(2x2) Winograd kernel of the fine pyramid levels (32-cout slices; up to 96 couts)
+    L.has_wnc = k == 3 && stride == 1 && cin >= 32 && cin <= 32 * WNC_MAX_CHUNKS && cout <= 96;
+    if (L.has_wnc) {
+        for (int sl = 0; sl * 32 < cout; ++sl) {
+            L.wwnc[sl] = pk.push(wnc_packed_floats(cin));
+            wnc_pack(w, cout, cin, sl * 32, pk.host.data() + L.wwnc[sl]);
+        }
+    }
+    L.bias = pk.push(cout + 32);                                    // (the Winograd kernel reads 32 biases per slice; the spare ones are zeros)
     memcpy(pk.host.data() + L.bias, b, cout * sizeof(float));
     // decoder convs also get the small-grid packing (tail_conv_kernel, used on the coarse pyramid levels)
     L.has_tail = stride == 1 && ((k == 3 && cin <= 184) || (k == 1 && cin <= 100));
@@ -105,8 +119,41 @@ void mk(Pk& pk, PLayer& L, const float* w, const float* b, int cin, int cout, in
     }
 }
 
+// The fine levels' 3x3 layers on the Winograd kernel (conv_wnc.hip): maps of at least EEM_PLUS_WNC_MINPX pixels (read per call; default
+// 30000: level 2 of a 1280x720 input - 192 x 320 - and up; the 64-pixel-wide tiles leave a 96 x 160 map with 72 tiles for 256 CUs)
+bool wnc_wanted(int h, int w) {
+    const char* m = getenv("EEM_PLUS_WNC_MINPX");
+    return (long)h * w >= (m ? atol(m) : 30000L) && w % 4 == 0;
+}
+void wnc_common(eemplus_ctx* c, WncArgs& a, int cin, int n, int h, int w, int act) {
+    memset(&a, 0, sizeof(a));
+    a.nchunks = wnc_chunks(cin, a.chunk_off);
+    a.n = n; a.h = h; a.w = w; a.act = act == GACT_LEAKY;
+    a.zero_page = c->arena + c->zero_off;
+    a.trash = c->arena + c->zero_off + 1024;
+}
+// one layer: its 32-cout slices are the jobs
+bool conv_wnc_args(eemplus_ctx* c, const PLayer& L, const float* in, int in_ctotal, int in_coff, int n, int h, int w, float* out,
+                   int out_ctotal, int out_coff, int out_cmul, int act, WncArgs& a) {
+    if (!L.has_wnc || !wnc_wanted(h, w) || (act != GACT_LEAKY && act != GACT_NONE)) return false;
+    wnc_common(c, a, L.cin, n, h, w, act);
+    const int cm = out_cmul > 1 ? out_cmul : 1;
+    for (int sl = 0; sl * 32 < L.cout; ++sl) {
+        WncJob& J = a.job[a.njobs++];
+        J.in = in; J.in_ctotal = in_ctotal; J.in_coff = in_coff;
+        J.w = c->arena + L.wwnc[sl]; J.bias = c->arena + L.bias + sl * 32;
+        J.out = out; J.out_ctotal = out_ctotal; J.out_coff = out_coff + sl * 32 * cm; J.out_cmul = cm;
+        J.cout = L.cout - sl * 32 < 32 ? L.cout - sl * 32 : 32;
+    }
+    return wnc_supported(a);
+}
+
 int conv(eemplus_ctx* c, const PLayer& L, const float* in, int in_ctotal, int in_coff, int n, int hin, int win, float* out,
          int out_ctotal, int out_coff, int out_cmul, int act, const float* add, hipStream_t st) {
+    if (add == nullptr) {
+        WncArgs wa;
+        if (conv_wnc_args(c, L, in, in_ctotal, in_coff, n, hin, win, out, out_ctotal, out_coff, out_cmul, act, wa)) return wnc_launch(wa, st);
+    }
     // small maps (the coarse pyramid levels): the small-grid kernel of EEMFlow's tail
     static const bool no_tail = [] { const char* e = getenv("EEM_PLUS_NO_TAIL"); return e && e[0] == '1'; }();
     const bool add_ok = add == nullptr || (out_ctotal == L.cout && out_coff == 0 && out_cmul <= 1);   // residual indexed like the output
@@ -191,6 +238,22 @@ int run_decoder(eemplus_ctx* c, int l, int B, int h, int w, const float* residua
         for (int layer = 0; layer < 3; ++layer) {
             // the G groups of a layer as ONE launch of the LDS-tiled kernel when their packings lie at equal distances in the arena
             // (they do: same shapes, packed one after the other) and the launch qualifies
+            if (G > 1 && !no_grouped && c->decg[l][layer][0].has_wnc && wnc_wanted(h, w)) {
+                // the groups as the jobs of ONE Winograd launch: group gi reads channels [gi*per, (gi+1)*per), its output j goes to j*G + gi
+                WncArgs wa;
+                wnc_common(c, wa, per, B, h, w, GACT_LEAKY);
+                for (int gi = 0; gi < G; ++gi) {
+                    const PLayer& Lg = c->decg[l][layer][gi];
+                    WncJob& J = wa.job[wa.njobs++];
+                    J.in = c->d[layer].p; J.in_ctotal = kDW; J.in_coff = gi * per;
+                    J.w = c->arena + Lg.wwnc[0]; J.bias = c->arena + Lg.bias;
+                    J.out = c->d[layer + 1].p; J.out_ctotal = kDW; J.out_coff = gi; J.out_cmul = G; J.cout = per;
+                }
+                if (per == 32 && wnc_supported(wa)) {
+                    if ((rc = wnc_launch(wa, st)) != EEM_OK) return rc;
+                    continue;
+                }
+            }
             if (G > 1 && !no_grouped) {
                 const PLayer& L0 = c->decg[l][layer][0];
                 const PLayer& L1 = c->decg[l][layer][1];

@@ -1,0 +1,36 @@
+// Winograd F(2x2,3x3) for EEMFlow+'s mid-size 3x3 layers (conv_wnc.hip): any input depth >= 32 -> slices of 32 output channels.
+#pragma once
+#include "common.h"
+
+constexpr int WNC_MAX_JOBS = 8;
+constexpr int WNC_MAX_CHUNKS = 8;
+
+// One job = 32 output channels (a group of a grouped conv, or a 32-channel slice of a wider layer) over the whole batch.
+struct WncJob {
+    const float* in;       // [n][in_ctotal][h][w]; the job reads channels in_coff + chunk_off[k] .. + 32 for every chunk k
+    int in_ctotal, in_coff;
+    const float* w;        // wnc_pack's stream for this job
+    const float* bias;     // 32 floats (zero beyond cout)
+    float* out;            // [n][out_ctotal][h][w]; cout co goes to channel out_coff + co * out_cmul
+    int out_ctotal, out_coff, out_cmul, cout;
+};
+
+struct WncArgs {
+    WncJob job[WNC_MAX_JOBS];
+    int njobs, nchunks;
+    int chunk_off[WNC_MAX_CHUNKS];
+    int n, h, w;
+    int act;               // 1: LeakyReLU(0.1)
+    const float* zero_page;   // >= 16 bytes of zeros (out-of-image pieces of the staged tile)
+    float* trash;             // >= 512 floats nobody reads (stores of lanes outside the image / beyond cout)
+};
+
+// chunks of 32 input channels that cover [0, cin): 0, 32, ... and, when cin % 32 != 0, a last one at cin - 32 whose first
+// 32 - cin % 32 channels repeat the chunk before it (their weights are packed as zeros).  Returns the count (cin >= 32, <= 256).
+int wnc_chunks(int cin, int* chunk_off);
+// floats of one job's stream
+size_t wnc_packed_floats(int cin);
+// U = G g G^T of the 32 output channels [co0, co0 + 32) of w [cout][cin][3][3] in the kernel's fragment order (zeros beyond cout)
+void wnc_pack(const float* w, int cout, int cin, int co0, float* packed);
+bool wnc_supported(const WncArgs& a);
+int wnc_launch(const WncArgs& a, hipStream_t st);

@@ -30,16 +30,24 @@ namespace {
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
-constexpr int TH = 4, TW = 64, WAVES = 8;                  // block tile: 4 x 64 pixels = two groups of 32 tiles, one per team of four waves
-constexpr int IN_ROWS = TH + 2, ROWP = TW + 8, PPR = ROWP / 4, PLANE = IN_ROWS * ROWP, PC = IN_ROWS * PPR;
-// one DMA instruction of the block (512 lanes) moves CPI whole channels; lane slot = wave * 64 + lane holds the same (channel in group,
-// row, 16-byte piece) for every instruction (conv_wino32.hip: W32Cfg)
-constexpr int SLOTS_I = WAVES * 64, CPI = (SLOTS_I / PC) & ~1, NI = 32 / CPI, STAGE = NI * WAVES * 256;
+// TEAMS = 2, NGH = 1: block tile 4 x 64 pixels - two groups of 32 tiles (2 x 64 pixels each), one per team of four waves, one block
+// per CU (the maps of >= 30000 pixels).  TEAMS = 1, NGH = 2: block tile 4 x 32 pixels - one group of 16 x 2 tiles - four waves, two
+// blocks per CU: 96 x 160 maps are 120 such tiles per image and job (72 of the wide ones, with 17 % of their columns outside).
+template <int TEAMS_, int NGH_>
+struct WncCfg {
+    static constexpr int TEAMS = TEAMS_, NGH = NGH_, WAVES = 4 * TEAMS;
+    static constexpr int TH = 4, TW = NGH == 1 ? 64 : 32;
+    static_assert((TEAMS == 2 && NGH == 1) || (TEAMS == 1 && NGH == 2), "block tile = TEAMS groups of 32 tiles");
+    static constexpr int IN_ROWS = TH + 2, ROWP = TW + 8, PPR = ROWP / 4, PLANE = IN_ROWS * ROWP, PC = IN_ROWS * PPR;
+    // one DMA instruction of the block moves CPI whole channels; lane slot = wave * 64 + lane holds the same (channel in group,
+    // row, 16-byte piece) for every instruction (conv_wino32.hip: W32Cfg)
+    static constexpr int SLOTS_I = WAVES * 64, CPI = (SLOTS_I / PC) & ~1, NI = 32 / CPI, STAGE = NI * WAVES * 256;
+    __host__ __device__ static constexpr int chan_off(int c) { return ((c / CPI) * SLOTS_I + (c % CPI) * PC) * 4; }   // floats from the stage base
+    static_assert(CPI >= 2 && 32 % CPI == 0 && STAGE >= WAVES * 64 * 32, "stage >= exchange buffer");
+    static_assert((chan_off(30) + PLANE) * 4 + 3 * ROWP * 4 + 64 < 65536, "ds_read immediate range");
+    static_assert(2 * STAGE * 4 * (TEAMS == 1 ? 2 : 1) <= 160 * 1024, "LDS budget");
+};
 constexpr int NSTORE = 8;                                  // stores per wave and tile (always issued: the waits count them)
-__host__ __device__ constexpr int chan_off(int c) { return ((c / CPI) * SLOTS_I + (c % CPI) * PC) * 4; }   // floats from the stage base
-static_assert(CPI == 4 && NI == 8 && STAGE == WAVES * 64 * 32, "stage = exchange buffer");
-static_assert((chan_off(30) + PLANE) * 4 + 3 * ROWP * 4 + 64 < 65536, "ds_read immediate range");
-static_assert(2 * STAGE * 4 <= 160 * 1024, "LDS budget");
 
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -55,13 +63,18 @@ __device__ __forceinline__ void unroll_for(F&& f) {
     }
 }
 
-__global__ __launch_bounds__(WAVES * 64, 1) void wnc_kernel(WncArgs a) {
+template <class C>
+__global__ __launch_bounds__(C::WAVES * 64, C::TEAMS == 1 ? 2 : 1) void wnc_kernel(WncArgs a) {
+    constexpr int TH = C::TH, TW = C::TW, WAVES = C::WAVES, ROWP = C::ROWP, PLANE = C::PLANE, PC = C::PC, PPR = C::PPR, CPI = C::CPI, NI = C::NI,
+                  STAGE = C::STAGE;
     __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nl = lane & 31, kk = lane >> 5;
-    const int team = wave >> 2, xi = wave & 3;               // team = tile-row pair of the block tile; xi = Winograd row of this wave
+    const int xi = wave & 3;                                 // Winograd row of this wave
+    // tile of this lane inside the block tile: row pair `tr`, column pair `txb`
+    const int tr = C::NGH == 1 ? (wave >> 2) : (nl >> 4), txb = C::NGH == 1 ? nl : (nl & 15);
     const int tiles_x = ceil_div(a.w, TW), tiles_y = ceil_div(a.h, TH);
     const TileRange range = block_tile_range(tiles_x * tiles_y * a.njobs * a.n, blockIdx.x, gridDim.x);
     const int ntile = range.count;
@@ -115,7 +128,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void wnc_kernel(WncArgs a) {
     const int ra = xi == 0 ? 0 : (xi == 2 ? 2 : 1);
     const int rb = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
     const float sgn = xi == 1 ? 1.f : -1.f;
-    const int lbase = kk * PLANE + 2 * team * ROWP + 2 * nl + 2;          // patch column -1 sits at the odd half of an aligned pair
+    const int lbase = kk * PLANE + 2 * tr * ROWP + 2 * txb + 2;          // patch column -1 sits at the odd half of an aligned pair
 
     f32x16 acc[4];
     f32x4 wr[2][8];
@@ -126,7 +139,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void wnc_kernel(WncArgs a) {
         const float* pb = stage + lbase + rb * ROWP;
         f32x2 na[3], nb[3];
         auto load_patch = [&](auto sc_tag) __attribute__((always_inline)) {
-            constexpr int off = chan_off(2 * decltype(sc_tag)::value);
+            constexpr int off = C::chan_off(2 * decltype(sc_tag)::value);
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 na[q] = *reinterpret_cast<const f32x2*>(pa + off + 2 * q);
@@ -204,7 +217,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void wnc_kernel(WncArgs a) {
             const f32x2* xr = reinterpret_cast<const f32x2*>(xst) + ((wave - xi) * 16 + 4 * xi) * 64 + lane;
             const int j = cur.n / a.n, n = cur.n - j * a.n;
             const WncJob& J = a.job[j];
-            const int oy = cur.by * TH + 2 * team, ox = cur.bx * TW + 2 * nl;
+            const int oy = cur.by * TH + 2 * tr, ox = cur.bx * TW + 2 * txb;
             const bool in0 = oy < a.h && ox < a.w, in1 = oy + 1 < a.h && ox < a.w;
             const int co0 = 8 * xi + 4 * kk;
             float* sink = a.trash + lane * 2;
@@ -286,10 +299,22 @@ bool wnc_supported(const WncArgs& a) {
 }
 
 int wnc_launch(const WncArgs& a, hipStream_t st) {
-    const int T = ceil_div(a.w, TW) * ceil_div(a.h, TH) * a.njobs * a.n;
-    int per_xcd = ceil_div(T, 8);
-    if (per_xcd > 32) per_xcd = 32;                          // one resident block per CU
-    hipLaunchKernelGGL(wnc_kernel, dim3(per_xcd * 8), dim3(WAVES * 64), 0, st, a);
+    // EEM_WNC_SMALL_MAXPX (read per call; 30000): maps below it take the 4 x 32 block tile, two blocks per CU
+    const char* m = getenv("EEM_WNC_SMALL_MAXPX");
+    const bool small = (long)a.h * a.w < (m ? atol(m) : 30000L);
+    if (small) {
+        using C = WncCfg<1, 2>;
+        const int T = ceil_div(a.w, C::TW) * ceil_div(a.h, C::TH) * a.njobs * a.n;
+        int per_xcd = ceil_div(T, 8);
+        if (per_xcd > 64) per_xcd = 64;                      // two resident blocks per CU
+        hipLaunchKernelGGL(wnc_kernel<C>, dim3(per_xcd * 8), dim3(C::WAVES * 64), 0, st, a);
+    } else {
+        using C = WncCfg<2, 1>;
+        const int T = ceil_div(a.w, C::TW) * ceil_div(a.h, C::TH) * a.njobs * a.n;
+        int per_xcd = ceil_div(T, 8);
+        if (per_xcd > 32) per_xcd = 32;                      // one resident block per CU
+        hipLaunchKernelGGL(wnc_kernel<C>, dim3(per_xcd * 8), dim3(C::WAVES * 64), 0, st, a);
+    }
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

@@ -462,7 +462,10 @@ bool fewout_supported(const GConvArgs& a) {
 int fewout_launch(const GConvArgs& a, hipStream_t stream) {
     const long n = (long)a.n * a.hin * a.win;
     const unsigned blocks = (unsigned)((n + 63) / 64);
-    const bool small = blocks * 8 < 1024 && a.seg[0].c >= 64;         // less than a wave per SIMD
+    // less than a wave per SIMD - or, for the layers of 3 .. 8 couts (EEMFlow+'s mask estimator tail at 96 x 160: 240 blocks), less than
+    // EEM_FEWOUT_SMALL_BLOCKS (read once; 512): a wave's time there is the number of its request round trips (22 channels, one ahead)
+    static const long small_blocks = [] { const char* e = getenv("EEM_FEWOUT_SMALL_BLOCKS"); return e ? atol(e) : 512L; }();
+    const bool small = (blocks * 8 < 1024 || (a.cout > 2 && (long)blocks < small_blocks)) && a.seg[0].c >= 64;
     if (a.cout <= 2) {                                                // E-RAFT's flow head
         if (small) hipLaunchKernelGGL((fewout_kernel<16, 2, 2>), dim3(blocks), dim3(1024), 0, stream, a, (a.seg[0].c + 15) / 16);
         else hipLaunchKernelGGL((fewout_kernel<8, 1, 2>), dim3(blocks), dim3(512), 0, stream, a, (a.seg[0].c + 7) / 8);

@@ -119,11 +119,16 @@ void mk(Pk& pk, PLayer& L, const float* w, const float* b, int cin, int cout, in
     }
 }
 
-// The fine levels' 3x3 layers on the Winograd kernel (conv_wnc.hip): maps of at least EEM_PLUS_WNC_MINPX pixels (read per call; default
-// 30000: level 2 of a 1280x720 input - 192 x 320 - and up; the 64-pixel-wide tiles leave a 96 x 160 map with 72 tiles for 256 CUs)
-bool wnc_wanted(int h, int w) {
+// The fine levels' 3x3 layers on the Winograd kernel (conv_wnc.hip).  Measured per layer (tools/plus_timeline.sh, 1280x720): at 192 x 320
+// every layer wins (dense estimator 242 -> 183 us, decoder 337 -> 240); at 96 x 160 (the kernel's 4 x 32 tiles, 120 per job) the launches
+// of several jobs win - the decoder's first conv 25 -> 22 us, its grouped layers 16 -> 11, its 96 -> 64 conv 24 -> 16 - and the
+// one-job layers lose 1 - 6 us each to the LDS-tiled kernel (120 blocks on 256 CUs).  Hence: maps of at least EEM_PLUS_WNC_MINPX pixels
+// (30000), or of EEM_PLUS_WNC_MINPX_JOBS (10000) for launches of two or more jobs; both read per call.
+bool wnc_wanted(int h, int w, int njobs) {
     const char* m = getenv("EEM_PLUS_WNC_MINPX");
-    return (long)h * w >= (m ? atol(m) : 30000L) && w % 4 == 0;
+    const char* mj = getenv("EEM_PLUS_WNC_MINPX_JOBS");
+    const long px = (long)h * w, lim1 = m ? atol(m) : 30000L, limj = mj ? atol(mj) : 10000L;
+    return w % 4 == 0 && (px >= lim1 || (njobs >= 2 && px >= limj));
 }
 void wnc_common(eemplus_ctx* c, WncArgs& a, int cin, int n, int h, int w, int act) {
     memset(&a, 0, sizeof(a));
@@ -135,7 +140,7 @@ void wnc_common(eemplus_ctx* c, WncArgs& a, int cin, int n, int h, int w, int ac
 // one layer: its 32-cout slices are the jobs
 bool conv_wnc_args(eemplus_ctx* c, const PLayer& L, const float* in, int in_ctotal, int in_coff, int n, int h, int w, float* out,
                    int out_ctotal, int out_coff, int out_cmul, int act, WncArgs& a) {
-    if (!L.has_wnc || !wnc_wanted(h, w) || (act != GACT_LEAKY && act != GACT_NONE)) return false;
+    if (!L.has_wnc || !wnc_wanted(h, w, (L.cout + 31) / 32) || (act != GACT_LEAKY && act != GACT_NONE)) return false;
     wnc_common(c, a, L.cin, n, h, w, act);
     const int cm = out_cmul > 1 ? out_cmul : 1;
     for (int sl = 0; sl * 32 < L.cout; ++sl) {
@@ -238,7 +243,7 @@ int run_decoder(eemplus_ctx* c, int l, int B, int h, int w, const float* residua
         for (int layer = 0; layer < 3; ++layer) {
             // the G groups of a layer as ONE launch of the LDS-tiled kernel when their packings lie at equal distances in the arena
             // (they do: same shapes, packed one after the other) and the launch qualifies
-            if (G > 1 && !no_grouped && c->decg[l][layer][0].has_wnc && wnc_wanted(h, w)) {
+            if (G > 1 && !no_grouped && c->decg[l][layer][0].has_wnc && wnc_wanted(h, w, G)) {
                 // the groups as the jobs of ONE Winograd launch: group gi reads channels [gi*per, (gi+1)*per), its output j goes to j*G + gi
                 WncArgs wa;
                 wnc_common(c, wa, per, B, h, w, GACT_LEAKY);

@@ -47,7 +47,6 @@ struct WncCfg {
     static_assert((chan_off(30) + PLANE) * 4 + 3 * ROWP * 4 + 64 < 65536, "ds_read immediate range");
     static_assert(2 * STAGE * 4 * (TEAMS == 1 ? 2 : 1) <= 160 * 1024, "LDS budget");
 };
-constexpr int NSTORE = 8;                                  // stores per wave and tile (always issued: the waits count them)
 
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -63,8 +62,14 @@ __device__ __forceinline__ void unroll_for(F&& f) {
     }
 }
 
-template <class C>
+// M16: the layers of at most 16 couts (cdc_utils.py:149-151: 160 -> 16, 176 -> 8, 184 -> 3) on v_mfma_f32_16x16x4_f32 - M = 16 couts,
+// N = 16 tiles, K = 4 cin: a wave multiplies the two halves of its 32-tile group by the same weight fragment, half the matrix-pipe time
+// of the 32-cout form with its upper 16 rows idle.  A k-step is four channels, a half-chunk four k-steps (4 weight loads of 16 bytes);
+// accumulator register r of lane l is cout 4 (l / 16) + r, and wave xi finishes register xi: one cout per lane, four stores per tile.
+template <class C, bool M16>
 __global__ __launch_bounds__(C::WAVES * 64, C::TEAMS == 1 ? 2 : 1) void wnc_kernel(WncArgs a) {
+    constexpr int NW = M16 ? 4 : 8;                          // weight loads (k-steps) per half-chunk
+    constexpr int NST = M16 ? 4 : 8;                         // stores per wave and tile (always issued: the waits count them)
     constexpr int TH = C::TH, TW = C::TW, WAVES = C::WAVES, ROWP = C::ROWP, PLANE = C::PLANE, PC = C::PC, PPR = C::PPR, CPI = C::CPI, NI = C::NI,
                   STAGE = C::STAGE;
     __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
@@ -72,6 +77,7 @@ __global__ __launch_bounds__(C::WAVES * 64, C::TEAMS == 1 ? 2 : 1) void wnc_kern
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nl = lane & 31, kk = lane >> 5;
+    const int n16 = lane & 15, kq = lane >> 4;               // (M16: tile of a half-group, channel of a k-step)
     const int xi = wave & 3;                                 // Winograd row of this wave
     // tile of this lane inside the block tile: row pair `tr`, column pair `txb`
     const int tr = C::NGH == 1 ? (wave >> 2) : (nl >> 4), txb = C::NGH == 1 ? nl : (nl & 15);
@@ -106,22 +112,23 @@ __global__ __launch_bounds__(C::WAVES * 64, C::TEAMS == 1 ? 2 : 1) void wnc_kern
     const unsigned vo0 = lane * 16u, vo1 = vo0 + 4096u;
     auto load_w = [&](f32x4 (&dst)[8], const TileCoord& tc, int hf) __attribute__((always_inline)) {
         const int j = tc.n / a.n;
-        const char* wb = reinterpret_cast<const char*>(a.job[j].w) + ((size_t)(xi * 2 * nchunks + hf) * 8) * 1024;
+        const char* wb = reinterpret_cast<const char*>(a.job[j].w) + ((size_t)(xi * 2 * nchunks + hf) * NW) * 1024;
 #pragma unroll
-        for (int s = 0; s < 8; ++s)
+        for (int s = 0; s < NW; ++s)
             asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst[s]) : "v"(s < 4 ? vo0 : vo1), "s"(wb), "n"((s & 3) * 1024) : "memory");
     };
     auto landed = [&](f32x4 (&w)[8]) __attribute__((always_inline)) {      // tells the compiler the registers are ready (gconv16.hip)
 #pragma unroll
-        for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(w[s]));
+        for (int s = 0; s < NW; ++s) asm volatile("" : "+v"(w[s]));
     };
-    // bias of the 4 cout rows this wave finishes: co = r + 8 xi + 4 kk
+    // bias of the cout rows this wave finishes: co = r + 8 xi + 4 kk, r = 0..3 (M16: the one cout 4 kq + xi, in biasv[0])
     f32x4 biasv = {0.f, 0.f, 0.f, 0.f};
-    const unsigned bo = (unsigned)(8 * xi + 4 * kk) * 4u;
+    const unsigned bo = M16 ? (unsigned)(4 * kq + xi) * 4u : (unsigned)(8 * xi + 4 * kk) * 4u;
     auto load_bias = [&](const TileCoord& tc) __attribute__((always_inline)) {
         const int j = tc.n / a.n;
         const char* bb = reinterpret_cast<const char*>(a.job[j].bias);
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(biasv) : "v"(bo), "s"(bb) : "memory");
+        if constexpr (M16) asm volatile("global_load_dword %0, %1, %2" : "=v"(biasv[0]) : "v"(bo), "s"(bb) : "memory");
+        else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(biasv) : "v"(bo), "s"(bb) : "memory");
     };
 
     // patch rows of this wave: t_xi = e_a + sgn * e_b with (a, b, sgn) = (0,2,-) (1,2,+) (2,1,-) (1,3,-)
@@ -129,39 +136,83 @@ __global__ __launch_bounds__(C::WAVES * 64, C::TEAMS == 1 ? 2 : 1) void wnc_kern
     const int rb = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
     const float sgn = xi == 1 ? 1.f : -1.f;
     const int lbase = kk * PLANE + 2 * tr * ROWP + 2 * txb + 2;          // patch column -1 sits at the odd half of an aligned pair
+    // M16: the lane's tile in the group's first half, and the distance to the one in its second half (16 tile columns on, or the next tile row)
+    const int tr0 = C::NGH == 1 ? (wave >> 2) : 0, lbase16 = kq * PLANE + 2 * tr0 * ROWP + 2 * n16 + 2;
+    constexpr int DNB = C::NGH == 1 ? 32 : 2 * ROWP;
 
     f32x16 acc[4];
+    f32x4 acc16[4][2];
     f32x4 wr[2][8];
     // one half of a chunk: 8 k-steps (2 channels each) x 4 MFMAs
     auto half = [&](auto hl_tag, const f32x4 (&w)[8], const float* stage) __attribute__((always_inline)) {
         constexpr int HL = decltype(hl_tag)::value;
-        const float* pa = stage + lbase + ra * ROWP;
-        const float* pb = stage + lbase + rb * ROWP;
-        f32x2 na[3], nb[3];
-        auto load_patch = [&](auto sc_tag) __attribute__((always_inline)) {
-            constexpr int off = C::chan_off(2 * decltype(sc_tag)::value);
+        if constexpr (!M16) {
+            const float* pa = stage + lbase + ra * ROWP;
+            const float* pb = stage + lbase + rb * ROWP;
+            f32x2 na[3], nb[3];
+            auto load_patch = [&](auto sc_tag) __attribute__((always_inline)) {
+                constexpr int off = C::chan_off(2 * decltype(sc_tag)::value);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                na[q] = *reinterpret_cast<const f32x2*>(pa + off + 2 * q);
-                nb[q] = *reinterpret_cast<const f32x2*>(pb + off + 2 * q);
-            }
-        };
-        load_patch(std::integral_constant<int, HL * 8>{});
-        unroll_for<0, 8>([&](auto s_tag) __attribute__((always_inline)) {
-            constexpr int s = decltype(s_tag)::value;
-            const float ea[4] = {na[0][1], na[1][0], na[1][1], na[2][0]};
-            const float eb[4] = {nb[0][1], nb[1][0], nb[1][1], nb[2][0]};
-            if constexpr (s + 1 < 8) {
-                load_patch(std::integral_constant<int, HL * 8 + s + 1>{});
-                __builtin_amdgcn_sched_barrier(0);           // the next k-step's reads stay ahead of this one's transform and MFMAs
-            }
-            float t[4];
+                for (int q = 0; q < 3; ++q) {
+                    na[q] = *reinterpret_cast<const f32x2*>(pa + off + 2 * q);
+                    nb[q] = *reinterpret_cast<const f32x2*>(pb + off + 2 * q);
+                }
+            };
+            load_patch(std::integral_constant<int, HL * 8>{});
+            unroll_for<0, 8>([&](auto s_tag) __attribute__((always_inline)) {
+                constexpr int s = decltype(s_tag)::value;
+                const float ea[4] = {na[0][1], na[1][0], na[1][1], na[2][0]};
+                const float eb[4] = {nb[0][1], nb[1][0], nb[1][1], nb[2][0]};
+                if constexpr (s + 1 < 8) {
+                    load_patch(std::integral_constant<int, HL * 8 + s + 1>{});
+                    __builtin_amdgcn_sched_barrier(0);       // the next k-step's reads stay ahead of this one's transform and MFMAs
+                }
+                float t[4];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) t[b] = __builtin_fmaf(sgn, eb[b], ea[b]);
-            const float v[4] = {t[0] - t[2], t[1] + t[2], t[2] - t[1], t[1] - t[3]};
+                for (int b = 0; b < 4; ++b) t[b] = __builtin_fmaf(sgn, eb[b], ea[b]);
+                const float v[4] = {t[0] - t[2], t[1] + t[2], t[2] - t[1], t[1] - t[3]};
 #pragma unroll
-            for (int nu = 0; nu < 4; ++nu) acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[s][nu], v[nu], acc[nu], 0, 0, 0);
-        });
+                for (int nu = 0; nu < 4; ++nu) acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[s][nu], v[nu], acc[nu], 0, 0, 0);
+            });
+        } else {
+            // four k-steps of four channels (this lane: channel 4 s + kq), two half-groups of 16 tiles per weight fragment
+            const float* pa = stage + lbase16 + ra * ROWP;
+            const float* pb = stage + lbase16 + rb * ROWP;
+            f32x2 na[2][3], nb[2][3];
+            auto load_patch = [&](auto sc_tag) __attribute__((always_inline)) {
+                constexpr int off = C::chan_off(4 * decltype(sc_tag)::value);
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        na[h2][q] = *reinterpret_cast<const f32x2*>(pa + off + h2 * DNB + 2 * q);
+                        nb[h2][q] = *reinterpret_cast<const f32x2*>(pb + off + h2 * DNB + 2 * q);
+                    }
+            };
+            load_patch(std::integral_constant<int, HL * 4>{});
+            unroll_for<0, 4>([&](auto s_tag) __attribute__((always_inline)) {
+                constexpr int s = decltype(s_tag)::value;
+                float v[2][4];
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const float ea[4] = {na[h2][0][1], na[h2][1][0], na[h2][1][1], na[h2][2][0]};
+                    const float eb[4] = {nb[h2][0][1], nb[h2][1][0], nb[h2][1][1], nb[h2][2][0]};
+                    float t[4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) t[b] = __builtin_fmaf(sgn, eb[b], ea[b]);
+                    v[h2][0] = t[0] - t[2]; v[h2][1] = t[1] + t[2]; v[h2][2] = t[2] - t[1]; v[h2][3] = t[1] - t[3];
+                }
+                if constexpr (s + 1 < 4) {
+                    load_patch(std::integral_constant<int, HL * 4 + s + 1>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2)
+                        acc16[nu][h2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s][nu], v[h2][nu], acc16[nu][h2], 0, 0, 0);
+            });
+        }
     };
 
     // ---- prologue: the first chunk's first half of weights, then its tile
@@ -172,16 +223,21 @@ __global__ __launch_bounds__(C::WAVES * 64, C::TEAMS == 1 ? 2 : 1) void wnc_kern
     for (int it = 0; it < niter; ++it) {
         const bool first = cur_ch == 0, last = cur_ch == nchunks - 1, more = it + 1 < niter;
         // this chunk's tile and its first half of weights have landed; every wave is through with the other stage
-        if (stored) wait_vm<NSTORE>(); else wait_vm<0>();
+        if (stored) wait_vm<NST>(); else wait_vm<0>();
         landed(wr[0]);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (first) {
             load_bias(cur);
+            if constexpr (M16) {
 #pragma unroll
-            for (int nu = 0; nu < 4; ++nu)
+                for (int nu = 0; nu < 4; ++nu) { acc16[nu][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc16[nu][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[nu][r] = 0.f;
+                for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[nu][r] = 0.f;
+            }
         }
         load_w(wr[1], cur, 2 * cur_ch + 1);
         if (more) {
@@ -199,7 +255,47 @@ __global__ __launch_bounds__(C::WAVES * 64, C::TEAMS == 1 ? 2 : 1) void wnc_kern
         __builtin_amdgcn_sched_barrier(0);
         half(std::integral_constant<int, 1>{}, wr[1], stage);
         stored = false;
-        if (last) {
+        if (last && M16) {
+            // ---- M16: u of (half-group h2, cout register r) at [wave][h2 * 4 + r][lane][2]; wave xi finishes register xi of both halves
+            __builtin_amdgcn_s_barrier();
+            float* xst = lds + (it & 1) * STAGE;
+            f32x2* xw = reinterpret_cast<f32x2*>(xst) + (wave * 8) * 64 + lane;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    f32x2 u;
+                    u[0] = acc16[0][h2][r] + acc16[1][h2][r] + acc16[2][h2][r];
+                    u[1] = acc16[1][h2][r] - acc16[2][h2][r] - acc16[3][h2][r];
+                    xw[(h2 * 4 + r) * 64] = u;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const f32x2* xr = reinterpret_cast<const f32x2*>(xst) + ((wave - xi) * 8 + xi) * 64 + lane;
+            const int j = cur.n / a.n, n = cur.n - j * a.n;
+            const WncJob& J = a.job[j];
+            const int co = 4 * kq + xi;
+            const bool okc = co < J.cout;
+            float* sink = a.trash + lane * 2;
+            float* pc = J.out + ((size_t)n * J.out_ctotal + J.out_coff + (size_t)co * J.out_cmul) * plane;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const f32x2 u0 = xr[(0 * 8 + h2 * 4) * 64], u1 = xr[(1 * 8 + h2 * 4) * 64], u2 = xr[(2 * 8 + h2 * 4) * 64], u3 = xr[(3 * 8 + h2 * 4) * 64];
+                float y00 = u0[0] + u1[0] + u2[0] + biasv[0], y01 = u0[1] + u1[1] + u2[1] + biasv[0];
+                float y10 = u1[0] - u2[0] - u3[0] + biasv[0], y11 = u1[1] - u2[1] - u3[1] + biasv[0];
+                if (a.act) {
+                    y00 = fmaxf(y00, 0.1f * y00); y01 = fmaxf(y01, 0.1f * y01);
+                    y10 = fmaxf(y10, 0.1f * y10); y11 = fmaxf(y11, 0.1f * y11);
+                }
+                const int oy = cur.by * TH + 2 * (C::NGH == 1 ? tr0 : h2), ox = cur.bx * TW + 2 * (C::NGH == 1 ? h2 * 16 + n16 : n16);
+                const bool in0 = oy < a.h && ox < a.w, in1 = oy + 1 < a.h && ox < a.w;
+                float* p = pc + (size_t)oy * a.w + ox;
+                *reinterpret_cast<f32x2*>(in0 && okc ? p : sink) = f32x2{y00, y01};
+                *reinterpret_cast<f32x2*>(in1 && okc ? p + a.w : sink) = f32x2{y10, y11};
+            }
+            stored = true;
+        }
+        if (last && !M16) {
             // ---- u = M_xi A, exchanged through the stage this tile has finished with: [wave][r][lane][2]
             __builtin_amdgcn_s_barrier();                    // every wave is done reading the stage
             float* xst = lds + (it & 1) * STAGE;
@@ -233,7 +329,7 @@ __global__ __launch_bounds__(C::WAVES * 64, C::TEAMS == 1 ? 2 : 1) void wnc_kern
                 const int co = co0 + r;
                 const bool okc = co < J.cout;
                 float* p = J.out + ((size_t)n * J.out_ctotal + J.out_coff + (size_t)co * J.out_cmul) * plane + (size_t)oy * a.w + ox;
-                // every lane stores (lanes outside the image or beyond cout into a scratch page): exactly NSTORE stores per wave and tile
+                // every lane stores (lanes outside the image or beyond cout into a scratch page): exactly NST stores per wave and tile
                 *reinterpret_cast<f32x2*>(in0 && okc ? p : sink) = f32x2{y00, y01};
                 *reinterpret_cast<f32x2*>(in1 && okc ? p + a.w : sink) = f32x2{y10, y11};
             }
@@ -253,23 +349,25 @@ int wnc_chunks(int cin, int* chunk_off) {
     return n;
 }
 
-size_t wnc_packed_floats(int cin) {
+size_t wnc_packed_floats(int cin, int m16) {
     int off[WNC_MAX_CHUNKS + 2];
     const int nch = cin >= 32 && cin <= 32 * WNC_MAX_CHUNKS ? wnc_chunks(cin, off) : 0;
-    return (size_t)4 * 2 * nch * 8 * 64 * 4;
+    return (size_t)4 * 2 * nch * (m16 ? 4 : 8) * 64 * 4;
 }
 
-void wnc_pack(const float* w, int cout, int cin, int co0, float* packed) {
+void wnc_pack(const float* w, int cout, int cin, int co0, int m16, float* packed) {
     int off[WNC_MAX_CHUNKS + 2];
     const int nch = wnc_chunks(cin, off);
     const int rep = cin % 32 ? 32 - cin % 32 : 0;            // the last chunk's first `rep` channels repeat the chunk before it
+    const int nw = m16 ? 4 : 8;                              // k-steps per half-chunk (of 4 / 2 channels)
     for (int xi = 0; xi < 4; ++xi)
         for (int hf = 0; hf < 2 * nch; ++hf)
-            for (int s = 0; s < 8; ++s)
+            for (int s = 0; s < nw; ++s)
                 for (int lane = 0; lane < 64; ++lane) {
-                    const int k = hf >> 1, l = (hf & 1) * 16 + 2 * s + (lane >> 5);
-                    const int co = co0 + (lane & 31), ci = off[k] + l;
-                    float* o = packed + ((((size_t)xi * 2 * nch + hf) * 8 + s) * 64 + lane) * 4;
+                    const int k = hf >> 1;
+                    const int l = (hf & 1) * 16 + (m16 ? 4 * s + (lane >> 4) : 2 * s + (lane >> 5));
+                    const int co = co0 + (m16 ? (lane & 15) : (lane & 31)), ci = off[k] + l;
+                    float* o = packed + ((((size_t)xi * 2 * nch + hf) * nw + s) * 64 + lane) * 4;
                     if (co >= cout || (k == nch - 1 && l < rep)) { o[0] = o[1] = o[2] = o[3] = 0.f; continue; }
                     const float* g = w + ((size_t)co * cin + ci) * 9;
                     float m[3];                              // row xi of G g
@@ -292,7 +390,7 @@ bool wnc_supported(const WncArgs& a) {
     if ((size_t)a.h * a.w * 32 * 4 >= (1u << 31)) return false;                  // 32-bit byte offsets inside a chunk
     for (int j = 0; j < a.njobs; ++j) {
         const WncJob& J = a.job[j];
-        if (!J.in || !J.w || !J.bias || !J.out || J.cout < 1 || J.cout > 32 || J.out_cmul < 1) return false;
+        if (!J.in || !J.w || !J.bias || !J.out || J.cout < 1 || J.cout > (a.m16 ? 16 : 32) || J.out_cmul < 1) return false;
         if (((uintptr_t)J.in & 15) || ((uintptr_t)J.w & 15) || ((uintptr_t)J.bias & 15) || ((uintptr_t)J.out & 15)) return false;
     }
     return true;
@@ -307,13 +405,15 @@ int wnc_launch(const WncArgs& a, hipStream_t st) {
         const int T = ceil_div(a.w, C::TW) * ceil_div(a.h, C::TH) * a.njobs * a.n;
         int per_xcd = ceil_div(T, 8);
         if (per_xcd > 64) per_xcd = 64;                      // two resident blocks per CU
-        hipLaunchKernelGGL(wnc_kernel<C>, dim3(per_xcd * 8), dim3(C::WAVES * 64), 0, st, a);
+        if (a.m16) hipLaunchKernelGGL((wnc_kernel<C, true>), dim3(per_xcd * 8), dim3(C::WAVES * 64), 0, st, a);
+        else hipLaunchKernelGGL((wnc_kernel<C, false>), dim3(per_xcd * 8), dim3(C::WAVES * 64), 0, st, a);
     } else {
         using C = WncCfg<2, 1>;
         const int T = ceil_div(a.w, C::TW) * ceil_div(a.h, C::TH) * a.njobs * a.n;
         int per_xcd = ceil_div(T, 8);
         if (per_xcd > 32) per_xcd = 32;                      // one resident block per CU
-        hipLaunchKernelGGL(wnc_kernel<C>, dim3(per_xcd * 8), dim3(C::WAVES * 64), 0, st, a);
+        if (a.m16) hipLaunchKernelGGL((wnc_kernel<C, true>), dim3(per_xcd * 8), dim3(C::WAVES * 64), 0, st, a);
+        else hipLaunchKernelGGL((wnc_kernel<C, false>), dim3(per_xcd * 8), dim3(C::WAVES * 64), 0, st, a);
     }
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;

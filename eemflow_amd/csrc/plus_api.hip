@@ -39,7 +39,7 @@ int pensure_zeroed(PBuf& b, size_t floats) {
 struct PLayer {
     size_t wpk = 0, wpk16 = 0, wpkb = 0, wtail = 0, wfew = 0, bias = 0;
     size_t wwnc[3] = {0, 0, 0};          // Winograd streams of the layer's 32-cout slices (conv_wnc.hip)
-    bool hasb = false, has16 = false, has_tail = false, has_few = false, has_wnc = false;
+    bool hasb = false, has16 = false, has_tail = false, has_few = false, has_wnc = false, wnc16 = false;
     int cin = 0, cout = 0, k = 3, stride = 1;
 };
 
@@ -104,9 +104,10 @@ void mk(Pk& pk, PLayer& L, const float* w, const float* b, int cin, int cout, in
     // 3x3 layers of >= 32 input channels: the F(2x2) Winograd kernel of the fine pyramid levels (32-cout slices; up to 96 couts)
     L.has_wnc = k == 3 && stride == 1 && cin >= 32 && cin <= 32 * WNC_MAX_CHUNKS && cout <= 96;
     if (L.has_wnc) {
+        L.wnc16 = cout <= 16;                                        // one job on the 16x16x4 MFMA (half the matrix-pipe time)
         for (int sl = 0; sl * 32 < cout; ++sl) {
-            L.wwnc[sl] = pk.push(wnc_packed_floats(cin));
-            wnc_pack(w, cout, cin, sl * 32, pk.host.data() + L.wwnc[sl]);
+            L.wwnc[sl] = pk.push(wnc_packed_floats(cin, L.wnc16));
+            wnc_pack(w, cout, cin, sl * 32, L.wnc16, pk.host.data() + L.wwnc[sl]);
         }
     }
     L.bias = pk.push(cout + 32);                                    // (the Winograd kernel reads 32 biases per slice; the spare ones are zeros)
@@ -142,6 +143,7 @@ bool conv_wnc_args(eemplus_ctx* c, const PLayer& L, const float* in, int in_ctot
                    int out_ctotal, int out_coff, int out_cmul, int act, WncArgs& a) {
     if (!L.has_wnc || !wnc_wanted(h, w, (L.cout + 31) / 32) || (act != GACT_LEAKY && act != GACT_NONE)) return false;
     wnc_common(c, a, L.cin, n, h, w, act);
+    a.m16 = L.wnc16;
     const int cm = out_cmul > 1 ? out_cmul : 1;
     for (int sl = 0; sl * 32 < L.cout; ++sl) {
         WncJob& J = a.job[a.njobs++];

@@ -10,7 +10,7 @@ struct WncJob {
     const float* in;       // [n][in_ctotal][h][w]; the job reads channels in_coff + chunk_off[k] .. + 32 for every chunk k
     int in_ctotal, in_coff;
     const float* w;        // wnc_pack's stream for this job
-    const float* bias;     // 32 floats (zero beyond cout)
+    const float* bias;     // 32 floats readable (16 in the m16 form); values beyond cout are never stored
     float* out;            // [n][out_ctotal][h][w]; cout co goes to channel out_coff + co * out_cmul
     int out_ctotal, out_coff, out_cmul, cout;
 };
@@ -21,6 +21,7 @@ struct WncArgs {
     int chunk_off[WNC_MAX_CHUNKS];
     int n, h, w;
     int act;               // 1: LeakyReLU(0.1)
+    int m16;               // the streams are the 16-cout form's (wnc_pack(.., m16 = 1)): jobs of at most 16 couts on the 16x16x4 MFMA
     const float* zero_page;   // >= 16 bytes of zeros (out-of-image pieces of the staged tile)
     float* trash;             // >= 512 floats nobody reads (stores of lanes outside the image / beyond cout)
 };
@@ -29,8 +30,8 @@ struct WncArgs {
 // 32 - cin % 32 channels repeat the chunk before it (their weights are packed as zeros).  Returns the count (cin >= 32, <= 256).
 int wnc_chunks(int cin, int* chunk_off);
 // floats of one job's stream
-size_t wnc_packed_floats(int cin);
-// U = G g G^T of the 32 output channels [co0, co0 + 32) of w [cout][cin][3][3] in the kernel's fragment order (zeros beyond cout)
-void wnc_pack(const float* w, int cout, int cin, int co0, float* packed);
+size_t wnc_packed_floats(int cin, int m16);
+// U = G g G^T of the 32 (m16: 16) output channels from co0 on of w [cout][cin][3][3] in the kernel's fragment order (zeros beyond cout)
+void wnc_pack(const float* w, int cout, int cin, int co0, int m16, float* packed);
 bool wnc_supported(const WncArgs& a);
 int wnc_launch(const WncArgs& a, hipStream_t st);

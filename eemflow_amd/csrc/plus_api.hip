@@ -69,6 +69,12 @@ struct eemplus_ctx {
     int* taps = nullptr;
     PLayer enc[8], rconv[7], dec1[7], decg[7][3][3], dec5[7], dec6[7], dec7[7], de[6], c1x1[6];
     PBuf padded, f[7], a2, dense, xout, finit[7], tw, fup[7], fw, cat, d[4], t64, t32, flow[7], flow_alt[7];
+    // round 6: each level owns its dense-estimator buffer, projection of feature_2 and decoder input (index = level; `dense` above stays the
+    // encoder's scratch), so that what a level computes from the feature pyramid alone - the two 1x1 projections and rconv, level_units -
+    // CAN run on a side stream beside the coarser levels' chain (EEM_PLUS_SIDE=1; measured slower, see plus_forward_impl)
+    PBuf dense_l[7], a2_l[7], cat_l[7];
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_lvl[7] = {};
     int B = 0, hl[7] = {0}, wl[7] = {0};
     bool have_last = false;
 };
@@ -201,6 +207,7 @@ int conv(eemplus_ctx* c, const PLayer& L, const float* in, int in_ctotal, int in
 
 // Decoder (EEMFlow+.py:38-71): cat [B][87] -> flow [B][2] (+ residual)
 int run_decoder(eemplus_ctx* c, int l, int B, int h, int w, const float* residual, hipStream_t st) {
+    float* const cat = c->cat_l[l].p;                 // [53 correlation taps | 32 rconv | 2 flow | 9 spare] of this level
     int rc;
     const size_t g = (size_t)h * w;
     for (int i = 0; i < 4; ++i)
@@ -226,7 +233,7 @@ int run_decoder(eemplus_ctx* c, int l, int B, int h, int w, const float* residua
         };
         TailConvLaunch L;
         L.batch = B; L.h = h; L.w = w; L.ksize = 3;
-        L.njobs = 1; L.job[0] = job(c->dec1[l], c->cat.p, kCat, 0, c->d[0].p, kDW, 0, 1);
+        L.njobs = 1; L.job[0] = job(c->dec1[l], cat, kCat, 0, c->d[0].p, kDW, 0, 1);
         if ((rc = tail_conv_launch(L, st)) != EEM_OK) return rc;
         for (int layer = 0; layer < 3; ++layer) {
             L.njobs = 0;
@@ -239,7 +246,7 @@ int run_decoder(eemplus_ctx* c, int l, int B, int h, int w, const float* residua
         L.njobs = 1; L.job[0] = job(c->dec6[l], c->t64.p, 64, 0, c->t32.p, 32, 0, 1);
         if ((rc = tail_conv_launch(L, st)) != EEM_OK) return rc;
     } else {
-        if ((rc = conv(c, c->dec1[l], c->cat.p, kCat, 0, B, h, w, c->d[0].p, kDW, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+        if ((rc = conv(c, c->dec1[l], cat, kCat, 0, B, h, w, c->d[0].p, kDW, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
         const char* eng = getenv("EEM_PLUS_NO_GROUPED");             // read per forward: a test runs both forms in one process
         const bool no_grouped = eng && eng[0] == '1';
         for (int layer = 0; layer < 3; ++layer) {
@@ -326,7 +333,16 @@ extern "C" void eemplus_destroy(eemplus_ctx* c) {
     PBuf* one[] = {&c->padded, &c->a2, &c->dense, &c->xout, &c->tw, &c->fw, &c->cat, &c->t64, &c->t32,
                    &c->d[0], &c->d[1], &c->d[2], &c->d[3]};
     for (PBuf* b : one) if (b->p) (void)hipFree(b->p);
+    if (c->side) {
+        (void)hipStreamSynchronize(c->side);
+        (void)hipStreamDestroy(c->side);
+        (void)hipEventDestroy(c->ev_fork);
+        for (hipEvent_t e : c->ev_lvl) if (e) (void)hipEventDestroy(e);
+    }
     for (int l = 0; l < 7; ++l) {
+        if (c->dense_l[l].p) (void)hipFree(c->dense_l[l].p);
+        if (c->a2_l[l].p) (void)hipFree(c->a2_l[l].p);
+        if (c->cat_l[l].p) (void)hipFree(c->cat_l[l].p);
         if (c->f[l].p) (void)hipFree(c->f[l].p);
         if (c->fup[l].p) (void)hipFree(c->fup[l].p);
         if (c->finit[l].p) (void)hipFree(c->finit[l].p);
@@ -422,24 +438,25 @@ extern "C" int eemplus_load_weights(eemplus_ctx* c, const float* flat, size_t nf
     return EEM_OK;
 }
 
-// One level l = 5..2 of the coarse-to-fine loop (EEMFlow+.py:183-229) on the features of the current forward: cdc_model
-// self-guided upsampling of flow[l+1] -> flow_up[l], warp, 9x9 correlation, decoder + residual -> flow[l].
-static int run_level(eemplus_ctx* c, int l, int B, const float* forced_init, hipStream_t st) {
+// the buffers a level owns (see eemplus_ctx::dense_l)
+static int level_buffers(eemplus_ctx* c, int l, int B) {
+    const size_t g = (size_t)c->hl[l] * c->wl[l];
+    int rc;
+    if ((rc = pensure_zeroed(c->cat_l[l], B * kCat * g)) != EEM_OK) return rc;
+    if (l <= 5 && ((rc = pensure(c->dense_l[l], B * kDense * g)) != EEM_OK || (rc = pensure(c->a2_l[l], B * 32 * g)) != EEM_OK)) return rc;
+    return EEM_OK;
+}
+
+// What level l computes from the feature pyramid alone (EEMFlow+.py:184-185,191 and :179 for level 6): the 1x1 projections of both
+// feature maps - feature_1's goes straight into the dense buffer's x slot - and rconv_l into the decoder input.  Nothing here reads a
+// coarser level's flow, so a forward runs these on the side stream while the coarse levels' launch-bound chain has the chip.
+static int level_units(eemplus_ctx* c, int l, int B, hipStream_t st) {
     int rc;
     const int C[7] = {0, 16, 32, 64, 64, 64, 64};
-    const int* hl = c->hl; const int* wl = c->wl;
-    auto f1 = [&](int k) { return c->f[k].p; };
-    auto f2 = [&](int k) { return c->f[k].p + (size_t)B * C[k] * hl[k] * wl[k]; };
-    const int h = hl[l], w = wl[l], hc = hl[l + 1], wc = wl[l + 1];
-    const size_t g = (size_t)h * w;
-    if ((rc = pensure(c->dense, B * kDense * g)) != EEM_OK || (rc = pensure(c->a2, B * 32 * g)) != EEM_OK ||
-        (rc = pensure(c->xout, B * 3 * g)) != EEM_OK || (rc = pensure(c->finit[l], B * 2 * g)) != EEM_OK ||
-        (rc = pensure(c->tw, B * 2 * g)) != EEM_OK || (rc = pensure(c->fup[l], B * 2 * g)) != EEM_OK ||
-        (rc = pensure(c->fw, B * C[l] * g)) != EEM_OK || (rc = pensure_zeroed(c->cat, B * kCat * g)) != EEM_OK)
-        return rc;
-    float* const fi = c->finit[l].p;              // cdc_model's upsampled flow_init, kept per level (stage "flow_init<l>")
-    // 1x1 projections of both feature maps (:184-185); feature_1 goes straight into the dense buffer's x slot
-    {
+    const int h = c->hl[l], w = c->wl[l];
+    const float* f1 = c->f[l].p;
+    const float* f2 = c->f[l].p + (size_t)B * C[l] * h * w;
+    if (l <= 5) {
         // (the coarse levels: both projections - the same weights on the two feature maps - as the two jobs of ONE small-grid launch)
         static const bool no_tail = [] { const char* e = getenv("EEM_PLUS_NO_TAIL"); return e && e[0] == '1'; }();
         static const long conv_tail_max = [] { const char* e = getenv("EEM_PLUS_CONV_TAIL_MAX"); return e ? atol(e) : 4096L; }();
@@ -450,18 +467,42 @@ static int run_level(eemplus_ctx* c, int l, int B, const float* forced_init, hip
             T.batch = B; T.h = h; T.w = w; T.ksize = P.k; T.njobs = 2;
             for (int q = 0; q < 2; ++q) {
                 TailConvJob& j = T.job[q];
-                j.in = q == 0 ? f1(l) : f2(l); j.wpk = c->arena + P.wtail; j.bias = c->arena + P.bias;
-                j.out = q == 0 ? c->dense.p : c->a2.p;
+                j.in = q == 0 ? f1 : f2; j.wpk = c->arena + P.wtail; j.bias = c->arena + P.bias;
+                j.out = q == 0 ? c->dense_l[l].p : c->a2_l[l].p;
                 j.cin = P.cin; j.cout = P.cout; j.in_ctotal = C[l]; j.in_coff = 0;
                 j.out_ctotal = q == 0 ? kDense : 32; j.out_coff = q == 0 ? 120 : 0; j.out_cmul = 1; j.act = 1;
                 j.gate = nullptr; j.in_cmul = 1; j.add = nullptr;
             }
             if ((rc = tail_conv_launch(T, st)) != EEM_OK) return rc;
         } else {
-            if ((rc = conv(c, P, f1(l), C[l], 0, B, h, w, c->dense.p, kDense, 120, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
-            if ((rc = conv(c, P, f2(l), C[l], 0, B, h, w, c->a2.p, 32, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+            if ((rc = conv(c, P, f1, C[l], 0, B, h, w, c->dense_l[l].p, kDense, 120, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+            if ((rc = conv(c, P, f2, C[l], 0, B, h, w, c->a2_l[l].p, 32, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
         }
     }
+    return conv(c, c->rconv[l], f1, C[l], 0, B, h, w, c->cat_l[l].p, kCat, 53, 1, GACT_LEAKY, nullptr, st);
+}
+
+// One level l = 5..2 of the coarse-to-fine loop (EEMFlow+.py:183-229) on the features of the current forward: cdc_model
+// self-guided upsampling of flow[l+1] -> flow_up[l], warp, 9x9 correlation, decoder + residual -> flow[l].
+// units_done: level_units(l) is already in flight (or done) on a stream `st` has been made to wait for.
+static int run_level(eemplus_ctx* c, int l, int B, const float* forced_init, hipStream_t st, bool units_done) {
+    int rc;
+    const int C[7] = {0, 16, 32, 64, 64, 64, 64};
+    const int* hl = c->hl; const int* wl = c->wl;
+    auto f1 = [&](int k) { return c->f[k].p; };
+    auto f2 = [&](int k) { return c->f[k].p + (size_t)B * C[k] * hl[k] * wl[k]; };
+    const int h = hl[l], w = wl[l], hc = hl[l + 1], wc = wl[l + 1];
+    const size_t g = (size_t)h * w;
+    if ((rc = level_buffers(c, l, B)) != EEM_OK ||
+        (rc = pensure(c->xout, B * 3 * g)) != EEM_OK || (rc = pensure(c->finit[l], B * 2 * g)) != EEM_OK ||
+        (rc = pensure(c->tw, B * 2 * g)) != EEM_OK || (rc = pensure(c->fup[l], B * 2 * g)) != EEM_OK ||
+        (rc = pensure(c->fw, B * C[l] * g)) != EEM_OK)
+        return rc;
+    float* const fi = c->finit[l].p;              // cdc_model's upsampled flow_init, kept per level (stage "flow_init<l>")
+    float* const dense = c->dense_l[l].p;
+    float* const a2 = c->a2_l[l].p;
+    float* const cat = c->cat_l[l].p;
+    if (!units_done && (rc = level_units(c, l, B, st)) != EEM_OK) return rc;
     // cdc_model.forward (cdc_utils.py:156-174)
     if (forced_init) {
         // teacher-forced level (eemplus_level): cdc_model's upsampled flow_init is supplied by the caller
@@ -474,7 +515,7 @@ static int run_level(eemplus_ctx* c, int l, int B, const float* forced_init, hip
         // upsampling, the coarse flow's doubling and the warp by the upsampled flow as ONE launch; the doubled coarse flow lands in a
         // second buffer (the launch's other threads still read the plain one) that takes the coarse flow's place from here on
         if ((rc = pensure(c->flow_alt[l + 1], B * 2 * (size_t)hc * wc)) != EEM_OK) return rc;
-        if ((rc = pl_upflow_warp_launch(c->flow[l + 1].p, c->flow_alt[l + 1].p, hc, wc, fi, c->a2.p, c->dense.p, kDense, 152, B, 32, h, w, st)) != EEM_OK) return rc;
+        if ((rc = pl_upflow_warp_launch(c->flow[l + 1].p, c->flow_alt[l + 1].p, hc, wc, fi, a2, dense, kDense, 152, B, 32, h, w, st)) != EEM_OK) return rc;
         std::swap(c->flow[l + 1], c->flow_alt[l + 1]);
     } else {
         if (forced_init) {
@@ -485,25 +526,24 @@ static int run_level(eemplus_ctx* c, int l, int B, const float* forced_init, hip
         } else {
             EEM_HIP_CHECK(hipMemcpyAsync(fi, c->flow[l + 1].p, B * 2 * g * 4, hipMemcpyDeviceToDevice, st));
         }
-        if ((rc = pl_warp_launch(c->a2.p, fi, 2, c->dense.p, kDense, 152, B, 32, h, w, 2, st)) != EEM_OK) return rc;
+        if ((rc = pl_warp_launch(a2, fi, 2, dense, kDense, 152, B, 32, h, w, 2, st)) != EEM_OK) return rc;
     }
     const int din[6] = {64, 96, 128, 160, 176, 184}, dout_off[5] = {88, 56, 24, 8, 0};
     for (int i = 0; i < 5; ++i)
-        if ((rc = conv(c, c->de[i], c->dense.p, kDense, kDense - din[i], B, h, w, c->dense.p, kDense, dout_off[i], 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
-    if ((rc = conv(c, c->de[5], c->dense.p, kDense, 0, B, h, w, c->xout.p, 3, 0, 1, GACT_NONE, nullptr, st)) != EEM_OK) return rc;
+        if ((rc = conv(c, c->de[i], dense, kDense, kDense - din[i], B, h, w, dense, kDense, dout_off[i], 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+    if ((rc = conv(c, c->de[5], dense, kDense, 0, B, h, w, c->xout.p, 3, 0, 1, GACT_NONE, nullptr, st)) != EEM_OK) return rc;
     if (fuse3) {
         // ... and the warp of feature_2 by that flow_up (:189) in the same launch
-        if ((rc = pl_warp_blend_warp_launch(fi, c->xout.p, c->fup[l].p, c->cat.p, kCat, 85, f2(l), c->fw.p, C[l], B, h, w, st)) != EEM_OK) return rc;
+        if ((rc = pl_warp_blend_warp_launch(fi, c->xout.p, c->fup[l].p, cat, kCat, 85, f2(l), c->fw.p, C[l], B, h, w, st)) != EEM_OK) return rc;
     } else {
         if ((rc = pl_warp_launch(fi, c->xout.p, 3, c->tw.p, 2, 0, B, 2, h, w, 1, st)) != EEM_OK) return rc;
         if ((rc = pl_blend_launch(c->tw.p, fi, c->xout.p, c->fup[l].p, B, (int)g, st)) != EEM_OK) return rc;
         // warp, correlate, decode (:189-193)
         if ((rc = pl_warp_launch(f2(l), c->fup[l].p, 2, c->fw.p, C[l], 0, B, C[l], h, w, 0, st)) != EEM_OK) return rc;
     }
-    CorrJob cj = {f1(l), c->fw.p, c->cat.p, C[l], kCat};
+    CorrJob cj = {f1(l), c->fw.p, cat, C[l], kCat};
     if ((rc = corr_launch(&cj, 1, B, h, w, c->taps, 53, st)) != EEM_OK) return rc;
-    if ((rc = conv(c, c->rconv[l], f1(l), C[l], 0, B, h, w, c->cat.p, kCat, 53, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
-    if (!fuse3 && (rc = pl_copy_channels_launch(c->fup[l].p, 2, 0, c->cat.p, kCat, 85, 2, B, (int)g, st)) != EEM_OK) return rc;
+    if (!fuse3 && (rc = pl_copy_channels_launch(c->fup[l].p, 2, 0, cat, kCat, 85, 2, B, (int)g, st)) != EEM_OK) return rc;
     if ((rc = run_decoder(c, l, B, h, w, c->fup[l].p, st)) != EEM_OK) return rc;
     return EEM_OK;
 }
@@ -573,20 +613,44 @@ static int plus_forward_impl(eemplus_ctx* c, const float* e1, const float* e2, c
 
     auto f1 = [&](int l) { return c->f[l].p; };
     auto f2 = [&](int l) { return c->f[l].p + (size_t)B * C[l] * hl[l] * wl[l]; };
+    // ---- what the levels compute from the pyramid alone (level_units), on a side stream beside the coarse levels' chain: OPT-IN
+    // (EEM_PLUS_SIDE=1, read per forward).  Measured at 1280x720 over 40 forwards: 841 - 866 frames/s against 884 - 891 in the chain - the
+    // fork's event record and the five waits cost the chain more than the ~75 us of launches they take out of it, and a forward that
+    // starts on an idle GPU is held up by the host enqueueing the side stream's 12 launches first (tools/plus_timeline.sh).
+    for (int l = 6; l >= 2; --l)
+        if ((rc = level_buffers(c, l, B)) != EEM_OK) return rc;
+    const char* ens = getenv("EEM_PLUS_SIDE");
+    const bool side = ens && ens[0] == '1';
+    if (side) {
+        if (!c->side) {
+            EEM_HIP_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+            EEM_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+            for (int l = 2; l <= 6; ++l) EEM_HIP_CHECK(hipEventCreateWithFlags(&c->ev_lvl[l], hipEventDisableTiming));
+        }
+        EEM_HIP_CHECK(hipEventRecord(c->ev_fork, st));        // the pyramid is complete (and the previous forward is through with the buffers)
+        EEM_HIP_CHECK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+        for (int l = 6; l >= 2; --l) {
+            if ((rc = level_units(c, l, B, c->side)) != EEM_OK) return rc;
+            EEM_HIP_CHECK(hipEventRecord(c->ev_lvl[l], c->side));
+        }
+    }
     // ---- level 6 (:177-181)
     {
         const int h = hl[6], w = wl[6];
         const size_t g = (size_t)h * w;
-        if ((rc = pensure_zeroed(c->cat, B * kCat * g)) != EEM_OK) return rc;
-        CorrJob cj = {f1(6), f2(6), c->cat.p, 64, kCat};
+        float* const cat = c->cat_l[6].p;
+        CorrJob cj = {f1(6), f2(6), cat, 64, kCat};
         if ((rc = corr_launch(&cj, 1, B, h, w, c->taps, 53, st)) != EEM_OK) return rc;
-        if ((rc = conv(c, c->rconv[6], f1(6), 64, 0, B, h, w, c->cat.p, kCat, 53, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
-        if ((rc = pl_copy_channels_launch(nullptr, 0, 0, c->cat.p, kCat, 85, 2, B, (int)g, st)) != EEM_OK) return rc;
+        if ((rc = pl_copy_channels_launch(nullptr, 0, 0, cat, kCat, 85, 2, B, (int)g, st)) != EEM_OK) return rc;
+        if (side) EEM_HIP_CHECK(hipStreamWaitEvent(st, c->ev_lvl[6], 0));
+        else if ((rc = level_units(c, 6, B, st)) != EEM_OK) return rc;
         if ((rc = run_decoder(c, 6, B, h, w, nullptr, st)) != EEM_OK) return rc;
     }
     // ---- levels 5..2 (:183-229)
-    for (int l = 5; l >= 2; --l)
-        if ((rc = run_level(c, l, B, nullptr, st)) != EEM_OK) return rc;
+    for (int l = 5; l >= 2; --l) {
+        if (side) EEM_HIP_CHECK(hipStreamWaitEvent(st, c->ev_lvl[l], 0));
+        if ((rc = run_level(c, l, B, nullptr, st, side)) != EEM_OK) return rc;
+    }
     // ---- five full-resolution predictions, coarse to fine (:231-232); flow6..flow3 carry the doubling above
     for (int f = 0; f < (frames ? frames : 1); ++f) {
         const float* ins[5]; float* outs[5]; int hs[5], ws[5];
@@ -663,7 +727,7 @@ extern "C" int eemplus_level(eemplus_ctx* c, int level, const float* flow_init, 
     EEM_REQUIRE(level >= 2 && level <= 5, "eemplus_level: level %d (2..5)", level);
     EEM_HIP_CHECK(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
-    int rc = run_level(c, level, c->B, flow_init, st);
+    int rc = run_level(c, level, c->B, flow_init, st, false);
     if (rc != EEM_OK) return rc;
     const size_t n = (size_t)c->B * 2 * c->hl[level] * c->wl[level] * sizeof(float);
     if (flow_up_out) EEM_HIP_CHECK(hipMemcpyAsync(flow_up_out, c->fup[level].p, n, hipMemcpyDeviceToDevice, st));

@@ -243,6 +243,46 @@ def test_wide_dense_estimator_convs_on_the_small_grid_kernel(monkeypatch):
             assert float((a - b).abs().max()) < 2e-4 * max(1.0, float(b.abs().max()))
 
 
+@pytest.mark.parametrize("b,h,w,small_maxpx", [(2, 256, 320, None), (1, 200, 300, None), (1, 256, 320, "0"), (1, 720, 1280, None)])
+def test_winograd_kernel_of_the_fine_levels_equals_the_lds_tiled_kernels(monkeypatch, b, h, w, small_maxpx):
+    """conv_wnc.hip - F(2x2) Winograd over input chunks of 32 channels, the decoder's groups / 32-cout slices as the jobs of one launch,
+    the <= 16-cout layers on the 16x16x4 MFMA, the 176- and 184-channel inputs through an overlapping last chunk with zeroed weights -
+    against the LDS-tiled / bf16-piece / few-cout kernels it replaces (EEM_NO_WNC=1), level by level teacher-forced from the same
+    flow_init.  EEM_PLUS_WNC_MINPX=0 sends every level's layers through it (partial tiles at 4 x 5 .. 64 x 80 maps); both block tiles
+    (EEM_WNC_SMALL_MAXPX=0: the 4 x 64 one everywhere); all three switches are read per call."""
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(95, b, h, w, bins=5))
+    net = make_net(96, 5)
+    net.change_imagesize((h, w))
+    with torch.no_grad():
+        net(e1, e2)
+        fi = {l: net.stage(f"flow_init{l}").clone() for l in (5, 4, 3, 2)}
+        if (h, w) != (720, 1280):
+            monkeypatch.setenv("EEM_PLUS_WNC_MINPX", "0")       # (at 1280x720 the default policy: levels 3 and 2)
+        if small_maxpx is not None:
+            monkeypatch.setenv("EEM_WNC_SMALL_MAXPX", small_maxpx)
+        new = {l: [t.clone() for t in net.level(l, fi[l])] for l in (5, 4, 3, 2)}
+        monkeypatch.setenv("EEM_NO_WNC", "1")
+        old = {l: [t.clone() for t in net.level(l, fi[l])] for l in (5, 4, 3, 2)}
+    assert not torch.equal(new[2][1], old[2][1])              # (the switch did switch)
+    for l in (5, 4, 3, 2):
+        for x, y in zip(new[l], old[l]):
+            assert float((x - y).abs().max()) < 2e-4 * max(1.0, float(y.abs().max())), l
+
+
+def test_level_units_on_the_side_stream_equal_the_chain(monkeypatch):
+    """EEM_PLUS_SIDE=1 (read per forward; opt-in, measured slower): the 1x1 projections and rconv of every level run on a side stream
+    beside the coarse levels' chain, in the buffers each level owns - the same launches, the same flows, bitwise."""
+    h, w = 256, 320
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(97, 2, h, w, bins=5))
+    net = make_net(98, 5)
+    net.change_imagesize((h, w))
+    with torch.no_grad():
+        chain = torch.stack(net(e1, e2)[1]).cpu().numpy()
+        monkeypatch.setenv("EEM_PLUS_SIDE", "1")
+        side = [torch.stack(net(e1, e2)[1]).cpu().numpy() for _ in range(3)]
+    assert all(np.array_equal(chain, s_) for s_ in side) and np.abs(chain).max() > 1e-3
+
+
 @pytest.mark.parametrize("n,h,w", [(3, 256, 320), (2, 100, 150), (1, 128, 192)])
 def test_forward_many_equals_the_batched_forward(n, h, w):
     """EEMFlow_cdc.forward_many (eemplus_forward_many): n independent batch-1 samples in their own tensors through one batch-n chain -

@@ -14,8 +14,8 @@ net.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_from_shapes({k: t
 net = net.cuda(); net.change_imagesize((h, w))
 e1, e2 = (torch.from_numpy(a).cuda() for a in synthetic_voxel_pair(1, b, h, w))
 with torch.no_grad():
-    for _ in range(2): net(e1, e2)
-    torch.cuda.synchronize(); t0 = time.perf_counter(); n = 5
+    for _ in range(5): net(e1, e2)
+    torch.cuda.synchronize(); t0 = time.perf_counter(); n = int(os.environ.get("EEM_BP_N", "40"))
     for _ in range(n): net(e1, e2)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 print(f"EEMFlow+ {w}x{h} batch={b}: {dt*1e3:.2f} ms/forward, {b/dt:.1f} frames/s, {75.3*b/dt/1e3:.1f} TFLOP/s")

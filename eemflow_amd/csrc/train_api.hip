@@ -118,10 +118,15 @@ struct Bwd {
         return rc;
     }
     int flush_tail(int n, int h, int w) {
-        if (tq.empty()) return EEM_OK;
+        if (tq.empty()) return flush_wgrads();
         int rc = fork();
         if (rc == EEM_OK) rc = wgrad_tail_launch(tq.data(), (int)tq.size(), n, h, w, wst);
         tq.clear();
+        if (rc == EEM_OK && nwq > 0) {                   // (the deferred ones, behind the same fork)
+            rc = tr_wgrad_launch_batch(wq, nwq, wst);
+            if (rc == EEM_OK) rc = tr_bias_grad_launch_batch(bq, nwq, wst);
+            nwq = 0;
+        }
         return rc;
     }
     // weight + bias gradient of a conv layer into the flat buffer
@@ -204,7 +209,9 @@ static int backward_chain(eemflow_ctx* c, const Shape& s, const float* e1, const
     TL.batch = B; TL.h = gh; TL.w = gw;
     auto run_jobs = [&](int ksize) {
         TL.ksize = ksize;
-        int r = bw.flush_wgrads();                   // this layer's weight gradients: one launch
+        // this layer's weight gradients: one launch - or, with the tail's 3x3 layers leaving as one launch at the end (flush_tail), the
+        // few others (the 1x1 out_conv) wait for that launch's fork: one event record less in the chain (~7 us each)
+        int r = bw.tail_one_launch ? EEM_OK : bw.flush_wgrads();
         if (r == EEM_OK) r = tail_conv_launch(TL, st);
         TL.njobs = 0;
         return r;
@@ -459,6 +466,10 @@ extern "C" int eemflow_forward_backward(eemflow_ctx* c, const float* e1, const f
     const int B = batch;
     if (!zero.done) EEM_HIP_CHECK(hipMemsetAsync(stats, 0, 8 * sizeof(double), st));
     // ---- loss and d loss / d flow (train_mvsec.py:201-227)
+    // (measured and not kept: the loss and pass X of the upsampling adjoint as one launch, d loss / d flow kept in LDS rows - a wave per
+    // output row of both channels.  Grid-stride over 512 blocks: 47 us, what the two launches take (30 + 17) - 2 048 waves do not hide
+    // their own round trips; a block per four rows with the six sums finished by the last block behind __threadfence(): 190 us - a
+    // device-scope fence per block writes an XCD's L2 back)
     if ((rc = tr_loss_launch(flow_out, flow_gt, valid, c->g_flow.p, B, s.out_h * s.out_w, gamma_weight, stats, st)) != EEM_OK) return rc;
     c->stats_scale = (double)gamma_weight / ((double)B * 2.0 * s.out_h * s.out_w);
     // The five sums are final HERE: without stats_out they leave for pinned host memory on a stream of their own, right behind the loss

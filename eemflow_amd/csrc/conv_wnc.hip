@@ -284,8 +284,9 @@ __global__ __launch_bounds__(C::WAVES * 64, C::TEAMS == 1 ? 2 : 1) void wnc_kern
                 float y00 = u0[0] + u1[0] + u2[0] + biasv[0], y01 = u0[1] + u1[1] + u2[1] + biasv[0];
                 float y10 = u1[0] - u2[0] - u3[0] + biasv[0], y11 = u1[1] - u2[1] - u3[1] + biasv[0];
                 if (a.act) {
-                    y00 = fmaxf(y00, 0.1f * y00); y01 = fmaxf(y01, 0.1f * y01);
-                    y10 = fmaxf(y10, 0.1f * y10); y11 = fmaxf(y11, 0.1f * y11);
+                    const float sl = a.act == 1 ? 0.1f : 0.f;
+                    y00 = fmaxf(y00, sl * y00); y01 = fmaxf(y01, sl * y01);
+                    y10 = fmaxf(y10, sl * y10); y11 = fmaxf(y11, sl * y11);
                 }
                 const int oy = cur.by * TH + 2 * (C::NGH == 1 ? tr0 : h2), ox = cur.bx * TW + 2 * (C::NGH == 1 ? h2 * 16 + n16 : n16);
                 const bool in0 = oy < a.h && ox < a.w, in1 = oy + 1 < a.h && ox < a.w;
@@ -323,12 +324,20 @@ __global__ __launch_bounds__(C::WAVES * 64, C::TEAMS == 1 ? 2 : 1) void wnc_kern
                 float y00 = u0[0] + u1[0] + u2[0] + biasv[r], y01 = u0[1] + u1[1] + u2[1] + biasv[r];
                 float y10 = u1[0] - u2[0] - u3[0] + biasv[r], y11 = u1[1] - u2[1] - u3[1] + biasv[r];
                 if (a.act) {
-                    y00 = fmaxf(y00, 0.1f * y00); y01 = fmaxf(y01, 0.1f * y01);
-                    y10 = fmaxf(y10, 0.1f * y10); y11 = fmaxf(y11, 0.1f * y11);
+                    const float sl = a.act == 1 ? 0.1f : 0.f;
+                    y00 = fmaxf(y00, sl * y00); y01 = fmaxf(y01, sl * y01);
+                    y10 = fmaxf(y10, sl * y10); y11 = fmaxf(y11, sl * y11);
                 }
                 const int co = co0 + r;
                 const bool okc = co < J.cout;
-                float* p = J.out + ((size_t)n * J.out_ctotal + J.out_coff + (size_t)co * J.out_cmul) * plane + (size_t)oy * a.w + ox;
+                const size_t po = ((size_t)n * J.out_ctotal + J.out_coff + (size_t)co * J.out_cmul) * plane + (size_t)oy * a.w + ox;
+                float* p = J.out + po;
+                if (J.res) {                                 // (wave-uniform) residual block: relu(res + .); outside lanes read the zero page
+                    const f32x2 r0 = *reinterpret_cast<const f32x2*>(in0 && okc ? J.res + po : a.zero_page);
+                    const f32x2 r1 = *reinterpret_cast<const f32x2*>(in1 && okc ? J.res + po + a.w : a.zero_page);
+                    y00 = fmaxf(y00 + r0[0], 0.f); y01 = fmaxf(y01 + r0[1], 0.f);
+                    y10 = fmaxf(y10 + r1[0], 0.f); y11 = fmaxf(y11 + r1[1], 0.f);
+                }
                 // every lane stores (lanes outside the image or beyond cout into a scratch page): exactly NST stores per wave and tile
                 *reinterpret_cast<f32x2*>(in0 && okc ? p : sink) = f32x2{y00, y01};
                 *reinterpret_cast<f32x2*>(in1 && okc ? p + a.w : sink) = f32x2{y10, y11};
@@ -390,7 +399,7 @@ bool wnc_supported(const WncArgs& a) {
     if ((size_t)a.h * a.w * 32 * 4 >= (1u << 31)) return false;                  // 32-bit byte offsets inside a chunk
     for (int j = 0; j < a.njobs; ++j) {
         const WncJob& J = a.job[j];
-        if (!J.in || !J.w || !J.bias || !J.out || J.cout < 1 || J.cout > (a.m16 ? 16 : 32) || J.out_cmul < 1) return false;
+        if (!J.in || !J.w || !J.bias || !J.out || (J.res && (a.m16 || ((uintptr_t)J.res & 15))) || J.cout < 1 || J.cout > (a.m16 ? 16 : 32) || J.out_cmul < 1) return false;
         if (((uintptr_t)J.in & 15) || ((uintptr_t)J.w & 15) || ((uintptr_t)J.bias & 15) || ((uintptr_t)J.out & 15)) return false;
     }
     return true;

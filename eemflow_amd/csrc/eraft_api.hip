@@ -9,6 +9,7 @@
 #include "../../include/eemflow_hip.h"
 #include "eraft_kernels.h"
 #include "gconv.h"
+#include "wnc.h"
 
 namespace {
 
@@ -31,6 +32,8 @@ struct Layer {                    // one convolution, weights packed for gconv
     bool hasb = false, has_stem = false;
     size_t wraw = 0, wf4 = 0;      // 64 -> 64 3x3 stride-1 layers: OIHW weights (BatchNorm scale folded in) and their F(4x4,3x3) form
     bool has_scale = false, has16 = false, has_few = false, has_f4 = false;
+    size_t wwnc[4] = {0, 0, 0, 0};  // 96 -> 96 / 128 -> 128 3x3 stride-1 layers: F(2x2) streams of their 32-cout slices (conv_wnc.hip), BatchNorm scale folded in
+    bool has_wnc = false;
     int cout = 0, kh = 1, kw = 1, stride = 1, ph = 0, pw = 0;
     int cs[3] = {0, 0, 0}, nseg = 1;
 };
@@ -150,6 +153,20 @@ void make_layer(Packer& pk, Layer& L, const float* w, const float* bias, int cou
             for (int i = 0; i < 64 * 9; ++i) pk.host[L.wraw + (size_t)co * 576 + i] = wsl[(size_t)co * 576 + i] * sc;
         }
     }
+    // the encoder's 96 -> 96 and 128 -> 128 residual convs (model/extractor.py:146-147, layer2 / layer3) on the Winograd F(2x2,3x3) kernel
+    // of EEMFlow+'s fine levels (conv_wnc.hip: 32-cout slices as the jobs of one launch), an eval-mode BatchNorm's scale folded in
+    L.has_wnc = nseg == 1 && co0 == 0 && kh == 3 && kw == 3 && stride == 1 && ph == 1 && pw == 1 && cin == con && (con == 96 || con == 128);
+    if (L.has_wnc) {
+        std::vector<float> wsc((size_t)con * cin * 9);
+        for (int co = 0; co < con; ++co) {
+            const float sc = bn ? bn->w[co] / sqrtf(bn->rv[co] + 1e-5f) : 1.f;
+            for (int i = 0; i < cin * 9; ++i) wsc[(size_t)co * cin * 9 + i] = wsl[(size_t)co * cin * 9 + i] * sc;
+        }
+        for (int sl = 0; sl * 32 < con; ++sl) {
+            L.wwnc[sl] = pk.push(wnc_packed_floats(cin, 0));
+            wnc_pack(wsc.data(), con, cin, sl * 32, 0, pk.host.data() + L.wwnc[sl]);
+        }
+    }
     L.shift = pk.push(con);
     if (bn) {
         L.has_scale = true;
@@ -263,6 +280,30 @@ int run_f4(eraft_ctx* c, const Layer& L, const float* x, int n, int h, int w, fl
     return wino4_launch(64, a, st);
 }
 
+// A 96 -> 96 / 128 -> 128 3x3 conv of the encoder on the Winograd F(2x2,3x3) kernel (same contract as run_f4).  From 128 (tile, slice)
+// pairs on; EEM_ERAFT_NO_WNC=1 (read per call) keeps every conv on gconv.
+bool wnc_eligible(const Layer& L, int n, int h, int w) {
+    const char* e = getenv("EEM_ERAFT_NO_WNC");
+    if (e && e[0] == '1') return false;
+    return L.has_wnc && w % 4 == 0 && (long)n * ((h + 3) / 4) * ((w + 31) / 32) * (L.cout / 32) >= 128;
+}
+int run_wnc(eraft_ctx* c, const Layer& L, const float* x, int n, int h, int w, float* out, int act, const float* res, hipStream_t st) {
+    WncArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nchunks = wnc_chunks(L.cs[0], a.chunk_off);
+    a.n = n; a.h = h; a.w = w; a.act = act;
+    a.zero_page = c->arena + c->zero_off; a.trash = c->trash;
+    for (int sl = 0; sl * 32 < L.cout; ++sl) {
+        WncJob& J = a.job[a.njobs++];
+        J.in = x; J.in_ctotal = L.cs[0]; J.in_coff = 0;
+        J.w = c->arena + L.wwnc[sl]; J.bias = c->arena + L.shift + sl * 32;
+        J.out = out; J.out_ctotal = L.cout; J.out_coff = sl * 32; J.out_cmul = 1; J.cout = 32;
+        J.res = res;
+    }
+    EEM_REQUIRE(wnc_supported(a), "run_wnc: the launch does not qualify (alignment)");
+    return wnc_launch(a, st);
+}
+
 // BasicEncoder forward on `n` images [n][cin0][hp][wp]; result of the residual stack in *feat ([n][128][hp/8][wp/8]).
 int run_encoder(eraft_ctx* c, const Encoder& E, const float* x, int n, int cin0, int hp, int wp, float** feat, hipStream_t st, Buf* sc = nullptr) {
     int rc;
@@ -286,6 +327,7 @@ int run_encoder(eraft_ctx* c, const Encoder& E, const float* x, int n, int cin0,
             GConvArgs a1 = conv_args(c, bk.conv1, n, h, w, E.batch_norm ? Y : R, planes, 0, E.batch_norm ? GACT_RELU : GACT_NONE);
             set_seg(a1, 0, X, cin, cin, 0);
             if (f4_eligible(bk.conv1, n, h, w)) rc = run_f4(c, bk.conv1, X, n, h, w, E.batch_norm ? Y : R, E.batch_norm ? 2 : 0, nullptr, st);
+            else if (wnc_eligible(bk.conv1, n, h, w)) rc = run_wnc(c, bk.conv1, X, n, h, w, E.batch_norm ? Y : R, E.batch_norm ? 2 : 0, nullptr, st);
             else rc = gconv_launch(a1, st);
             if (rc != EEM_OK) return rc;
             const int ho = a1.hout, wo = a1.wout;
@@ -304,6 +346,7 @@ int run_encoder(eraft_ctx* c, const Encoder& E, const float* x, int n, int cin0,
             set_seg(a2, 0, Y, planes, planes, 0);
             if (E.batch_norm) { a2.epi = GEPI_ADD_RELU; a2.e0 = res; a2.e0_ctotal = planes; a2.e0_coff = 0; }
             if (f4_eligible(bk.conv2, n, ho, wo)) rc = run_f4(c, bk.conv2, Y, n, ho, wo, E.batch_norm ? O : R, E.batch_norm ? 2 : 0, E.batch_norm ? res : nullptr, st);
+            else if (wnc_eligible(bk.conv2, n, ho, wo)) rc = run_wnc(c, bk.conv2, Y, n, ho, wo, E.batch_norm ? O : R, E.batch_norm ? 2 : 0, E.batch_norm ? res : nullptr, st);
             else rc = gconv_launch(a2, st);
             if (rc != EEM_OK) return rc;
             if (!E.batch_norm && (rc = er_instnorm_launch(R, O, res, n * planes, ho * wo, 1, st, c->nstat, c->nstat_cap)) != EEM_OK) return rc;

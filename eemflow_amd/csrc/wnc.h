@@ -13,6 +13,7 @@ struct WncJob {
     const float* bias;     // 32 floats readable (16 in the m16 form); values beyond cout are never stored
     float* out;            // [n][out_ctotal][h][w]; cout co goes to channel out_coff + co * out_cmul
     int out_ctotal, out_coff, out_cmul, cout;
+    const float* res;      // optional residual, indexed like `out`: out = relu(res + act(conv + bias)) (model/extractor.py:48-57)
 };
 
 struct WncArgs {
@@ -20,7 +21,7 @@ struct WncArgs {
     int njobs, nchunks;
     int chunk_off[WNC_MAX_CHUNKS];
     int n, h, w;
-    int act;               // 1: LeakyReLU(0.1)
+    int act;               // 0: none, 1: LeakyReLU(0.1), 2: ReLU
     int m16;               // the streams are the 16-cout form's (wnc_pack(.., m16 = 1)): jobs of at most 16 couts on the 16x16x4 MFMA
     const float* zero_page;   // >= 16 bytes of zeros (out-of-image pieces of the staged tile)
     float* trash;             // >= 512 floats nobody reads (stores of lanes outside the image / beyond cout)

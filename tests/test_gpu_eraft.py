@@ -413,6 +413,23 @@ def test_encoder_winograd_convs_equal_the_lds_tiled_ones(monkeypatch):
     assert maxerr(wino, tiled) < 5e-4 and float(tiled.abs().max()) > 1e-3
 
 
+@pytest.mark.parametrize("b,h,w", [(1, 480, 640), (2, 256, 320)])
+def test_encoder_winograd_f2_convs_equal_the_bf16_piece_ones(monkeypatch, b, h, w):
+    """The encoder's 96 -> 96 and 128 -> 128 residual convs (model/extractor.py layer2 / layer3, both networks) run on the Winograd
+    F(2x2,3x3) kernel of EEMFlow+'s fine levels (conv_wnc.hip: their 32-cout slices as the jobs of one launch, BatchNorm scale folded
+    into the weights, ReLU and the residual sum in the epilogue for cnet, no activation in front of fnet's InstanceNorm) from 128
+    (tile, slice) pairs on; EEM_ERAFT_NO_WNC=1 (read per call) keeps them on the bf16-piece / LDS-tiled kernels."""
+    net, _ = make_net(47)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(48, b, h, w))
+    with torch.no_grad():
+        wino = torch.stack(net(e1, e2, iters=12)[1]).clone()
+        monkeypatch.setenv("EEM_ERAFT_NO_WNC", "1")
+        plain = torch.stack(net(e1, e2, iters=12)[1]).clone()
+    assert not torch.equal(wino, plain)                                  # (the switch did switch)
+    assert maxerr(wino, plain) < 5e-4 and float(plain.abs().max()) > 1e-3
+
+
 def test_gru_context_part_computed_once_equals_the_full_convs(monkeypatch):
     """The GRU's convs read [h | inp | motion] (model/update.py:43-60) and `inp` does not change over the iterations: its part of
     every conv (+ the bias) is computed once per forward and enters the in-loop convs over [h | motion] as a per-pixel addend in front

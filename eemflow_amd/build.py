@@ -42,7 +42,8 @@ def build_library(force=False, verbose=True):
     hipcc = _hipcc()
     objdir = os.path.join(CSRC, f"build_{TAG}" if TAG else "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gconv.h"), os.path.join(CSRC, "eraft_kernels.h"), os.path.join(CSRC, "api_internal.h"), os.path.join(CSRC, "train.h"), os.path.join(CSRC, "plus_kernels.h"), os.path.join(CSRC, "wino4_xf.h"), os.path.join(PKG, "..", "include", "eemflow_hip.h"),
+    # every header of csrc/ (a stale object behind a changed struct layout links and misbehaves silently), the public header, this file
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(PKG, "..", "include", "eemflow_hip.h"),
                os.path.abspath(__file__)]
     jobs = []
     objs = []

@@ -18,6 +18,10 @@
 //   * a launch takes up to eight JOBS (32-cout slices of one layer, or the groups of a grouped layer): persistent blocks walk
 //     (job, image, tile) triples, so the three groups of a decoder layer or the three slices of its first conv fill the chip as one
 //     launch.
+// Measured and not kept: a ring of THREE half-chunk weight buffers, every half requested two halves ahead (three copies of the loop
+// body, 244 VGPRs) - per-layer times within 0.5 us of the two-buffer form at 192 x 320 (60.0 against 60.8 us for the decoder's first
+// conv): with the matrix pipe's ~3.9 us per chunk (two waves per SIMD x 64 MFMAs of 64 cycles) the one-half lead already covers the
+// round trip; what a chunk pays above that is its top (wait, barrier, 16 requests per wave) and, per tile, the exchange and the stores.
 // Input depths that are not a multiple of 32 (the estimator's 176 and 184) end in a chunk that overlaps the one before it; the
 // repeated channels' weights are packed as zeros (wnc_pack) - what they multiply is a finite activation.
 #include <type_traits>

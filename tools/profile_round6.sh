@@ -34,3 +34,39 @@ echo "EEM_NO_WGRAD_BX3=1: $(EEM_NO_WGRAD_BX3=1 python3 tools/bench_eraft_train.p
 echo "EEM_NO_DGRAD_S2W=1: $(EEM_NO_DGRAD_S2W=1 python3 tools/bench_eraft_train.py 2>/dev/null | tail -1)" >> gpurun_out/${tag}_ertrain.txt
 echo "EEM_NO_WGRAD_FEW=1: $(EEM_NO_WGRAD_FEW=1 python3 tools/bench_eraft_train.py 2>/dev/null | tail -1)" >> gpurun_out/${tag}_ertrain.txt
 ls gpurun_out | grep ${tag}_
+# 5. second half of the round: EEMFlow+'s Winograd kernel (timelines with and without it, the side-stream form, the frame rates over 40
+# forwards), the training step's prologue / first-layer switches, E-RAFT's encoder convs on the Winograd kernel
+tools/plus_timeline.sh ${tag}_plus_tl > /dev/null 2>&1
+cp gpurun_out/${tag}_plus_tl/timeline.txt gpurun_out/${tag}_eemflow_plus_timeline.txt
+EEM_NO_WNC=1 tools/plus_timeline.sh ${tag}_plus_tl_nownc > /dev/null 2>&1
+cp gpurun_out/${tag}_plus_tl_nownc/timeline.txt gpurun_out/${tag}_eemflow_plus_timeline_no_wnc.txt
+{
+  for i in 1 2; do
+    echo "default:                   $(python3 tools/bench_plus.py 2>/dev/null | tail -1)"
+    echo "EEM_NO_WNC=1:              $(EEM_NO_WNC=1 python3 tools/bench_plus.py 2>/dev/null | tail -1)"
+    echo "EEM_PLUS_SIDE=1:           $(EEM_PLUS_SIDE=1 python3 tools/bench_plus.py 2>/dev/null | tail -1)"
+    echo "EEM_PLUS_WNC_MINPX_JOBS=30000 (level 3 off the Winograd kernel): $(EEM_PLUS_WNC_MINPX_JOBS=30000 python3 tools/bench_plus.py 2>/dev/null | tail -1)"
+    echo "EEM_FEWOUT_SMALL_BLOCKS=0: $(EEM_FEWOUT_SMALL_BLOCKS=0 python3 tools/bench_plus.py 2>/dev/null | tail -1)"
+  done
+  echo "batch 4: $(python3 tools/bench_plus.py 4 2>/dev/null | tail -1)"
+} > gpurun_out/${tag}_eemflow_plus_switches.txt 2>&1
+{
+  export EEM_BT_N=300
+  for i in 1 2; do
+    echo "default:                                    $(python3 tools/bench_train.py 2>/dev/null)"
+    echo "EEM_WGRAD_LAST_SIDE=1:                      $(EEM_WGRAD_LAST_SIDE=1 python3 tools/bench_train.py 2>/dev/null)"
+    echo "EEM_TRAIN_SIDE_PREP=0:                      $(EEM_TRAIN_SIDE_PREP=0 python3 tools/bench_train.py 2>/dev/null)"
+    echo "EEM_WGRAD_LAST_SIDE=1 EEM_TRAIN_SIDE_PREP=0: $(EEM_WGRAD_LAST_SIDE=1 EEM_TRAIN_SIDE_PREP=0 python3 tools/bench_train.py 2>/dev/null)"
+  done
+  echo "1280x720 batch 8 default:                   $(python3 tools/bench_train.py 8 720 1280 2>/dev/null)"
+  echo "1280x720 batch 8 both off:                  $(EEM_WGRAD_LAST_SIDE=1 EEM_TRAIN_SIDE_PREP=0 python3 tools/bench_train.py 8 720 1280 2>/dev/null)"
+  python3 tools/train_host_time.py 2>/dev/null | tail -1
+  unset EEM_BT_N
+} > gpurun_out/${tag}_train_switches.txt 2>&1
+{
+  for b in 1 4; do for i in 1 2; do
+    echo "default      b$b: $(BENCH_N=20 python3 tools/bench_eraft.py $b 2>/dev/null | tail -1)"
+    echo "NO_WNC=1     b$b: $(EEM_ERAFT_NO_WNC=1 BENCH_N=20 python3 tools/bench_eraft.py $b 2>/dev/null | tail -1)"
+  done; done
+} > gpurun_out/${tag}_eraft_wnc.txt 2>&1
+ls gpurun_out | grep ${tag}_

@@ -24,23 +24,24 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_kernels_with_asm_loads_use_no_scratch(tmp_path):
-    """gconv16's weight fragments arrive through asm loads whose completion the compiler does not track: an instance that spills would
-    have a register parked in scratch and reused while its load is in flight (how the stride-2 form first died on the GPU).  Every
-    instance in the built code object must have a private segment of 0 bytes."""
+    """gconv16's and conv_wnc's weight fragments arrive through asm loads whose completion the compiler does not track: an instance that
+    spills would have a register parked in scratch and reused while its load is in flight (how gconv16's stride-2 form first died on the
+    GPU).  Every instance in the built code objects must have a private segment of 0 bytes."""
     import subprocess
     from eemflow_amd.build import CSRC, build_library
-    obj = os.path.join(CSRC, "build", "gconv16.o")
-    if not os.path.exists(obj):
-        build_library(verbose=False)
     llvm = "/opt/rocm/lib/llvm/bin"
-    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "gconv16.co")
-    subprocess.run([f"{llvm}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", obj, str(tmp_path / "host.o")], check=True)
-    subprocess.run([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
-    notes = subprocess.run([f"{llvm}/llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout
-    kernels = re.findall(r"\.name:\s+(\S*gconv16_kernel\S*)", notes)
-    sizes = [int(v) for v in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", notes)]
-    assert len(kernels) >= 60 and len(sizes) >= len(kernels)
-    assert all(v == 0 for v in sizes), sorted(set(sizes))
+    for stem, kernel, at_least in (("gconv16", "gconv16_kernel", 60), ("conv_wnc", "wnc_kernel", 4)):
+        obj = os.path.join(CSRC, "build", stem + ".o")
+        if not os.path.exists(obj):
+            build_library(verbose=False)
+        fat, co = str(tmp_path / f"{stem}.fat.bin"), str(tmp_path / f"{stem}.co")
+        subprocess.run([f"{llvm}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", obj, str(tmp_path / f"{stem}.host.o")], check=True)
+        subprocess.run([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+        notes = subprocess.run([f"{llvm}/llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout
+        kernels = re.findall(r"\.name:\s+(\S*" + kernel + r"\S*)", notes)
+        sizes = [int(v) for v in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", notes)]
+        assert len(kernels) >= at_least and len(sizes) >= len(kernels), (stem, len(kernels))
+        assert all(v == 0 for v in sizes), (stem, sorted(set(sizes)))
 
 
 def test_header_cites_reference_interfaces():

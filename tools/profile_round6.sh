@@ -70,3 +70,5 @@ cp gpurun_out/${tag}_plus_tl_nownc/timeline.txt gpurun_out/${tag}_eemflow_plus_t
   done; done
 } > gpurun_out/${tag}_eraft_wnc.txt 2>&1
 ls gpurun_out | grep ${tag}_
+# 6. the event-input pipeline alone (bench.py's coalesced chain): frames/s, per-frame kernel time by launch, voxelizer band sizes
+tools/pipeline_per_frame.sh ${tag} > /dev/null 2>&1

@@ -25,7 +25,8 @@
 //                         loop.  The band accumulates in fp64 LDS cells (ds_add_f64: ds_add_f32 runs at 0.33 lanes per clock and CU
 //                         on this chip, 8 - 20 x slower, profiles/r04_lds_atomics.txt).  One pass then rounds every cell to fp32
 //                         once, stores it (zeros included: no memset of the grid) and leaves the f64 (count, sum, sum of squares)
-//                         of the band's non-zero voxels;
+//                         of the band's non-zero voxels (a thread's few dozen cells as an integer count and fp32 partial sums, widened
+//                         once: round 6).  The band is zeroed under the first table round trip (LDS-only block wait);
 //   3. normalisation (loader_utils.py:527-535), one of
 //        vox_norm_kernel   (normalize = 1) adds the band sums in a fixed order, mean / unbiased sd, rewrites the non-zero voxels;
 //        vox_stats_kernel  (normalize = 2, "deferred") writes {mean, sd, scale, any} into the four floats BEHIND the grid and leaves
@@ -313,6 +314,15 @@ __device__ __forceinline__ VoxNorm vox_final(const VoxSums* __restrict__ acc, in
 // moments only; or read every block's moments and store the band normalised (after a VOX_BAND_MOMENTS launch)
 enum { VOX_BAND_RAW = 0, VOX_BAND_MOMENTS = 1, VOX_BAND_NORMALISED = 2 };
 
+#ifdef EEM_VOX_STAMPS
+// stamps build only (EEM_EXTRA_FLAGS=-DEEM_VOX_STAMPS, tools/vox_stamps.py): s_memtime of wave 0 of the first 1024 band blocks at the phase
+// boundaries: [0] start [1] band zeroed [2] table entries in [3] first records in [4] adds done, block through [5] read out [6] end
+__device__ unsigned long long g_vox_stamps[1024 * 8];
+#define VSTAMP(i) { __builtin_amdgcn_sched_barrier(0); vst[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define VSTAMP(i)
+#endif
+
 template <int BT>
 __global__ __launch_bounds__(BT, BT / 128) void vox_band_kernel(VoxJobs jobs, int slab, int bins, VoxPlan pl, int vec4, int with_moments, int mode, int sgs) {
     const VoxJob& J = jobs.j[blockIdx.y];
@@ -331,8 +341,10 @@ __global__ __launch_bounds__(BT, BT / 128) void vox_band_kernel(VoxJobs jobs, in
     const unsigned p0 = (unsigned)b * (unsigned)bpx;
     const int npx = min(bpx, (int)(pl.hw - p0));
     const int nfl = bins * bpx;
-    for (int i = tid * 2; i < nfl; i += BT * 2) *reinterpret_cast<f64x2*>(band + i) = f64x2{0.0, 0.0};
-    __syncthreads();
+#ifdef EEM_VOX_STAMPS
+    unsigned long long vst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    VSTAMP(0)
     // A run = this band's votes of one binning block: `len` consecutive 12-byte records.  2^sgs adjacent lanes share a run (sized so
     // that nearly every run is one record per lane): a wave's load then touches a few runs' lines instead of 64 unrelated ones - with a
     // thread per run (and, before, a thread per vote with a binary search for its run) the address unit's one line per clock was the
@@ -356,7 +368,19 @@ __global__ __launch_bounds__(BT, BT / 128) void vox_band_kernel(VoxJobs jobs, in
             st[q] = __builtin_amdgcn_raw_buffer_load_b32(trs, off, 0, 0);
             ln[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(trs, off, 4, 0);
         }
+        if (g0 == 0) {
+            // the band is zeroed UNDER the first table round trip (round 6; in-kernel stamps, tools/vox_stamps.py: zeroing + the block's
+            // start-up skew 2 000 cycles, table entries 2 700, first records 1 600, adds 3 700, read-out 4 800 of a block's 14 800): an
+            // LDS-only block wait - __syncthreads would drain the table loads first
+            for (int i = tid * 2; i < nfl; i += BT * 2) *reinterpret_cast<f64x2*>(band + i) = f64x2{0.0, 0.0};
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            VSTAMP(1)
+        }
         u32x3 r0[NP];
+#ifdef EEM_VOX_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        VSTAMP(2)
+#endif
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             const int sidx = g0 + q * rpp + (tid >> sgs);
@@ -364,6 +388,10 @@ __global__ __launch_bounds__(BT, BT / 128) void vox_band_kernel(VoxJobs jobs, in
             st[q] = ((unsigned)sidx * (unsigned)slab + st[q] + (unsigned)sub) * 12u;     // byte offset of this lane's first record
             r0[q] = __builtin_amdgcn_raw_buffer_load_b96(rrs, sub < ln[q] ? (int)st[q] : kOut, 0, 0);
         }
+#ifdef EEM_VOX_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        VSTAMP(3)
+#endif
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             if (sub < ln[q]) {
@@ -385,6 +413,7 @@ __global__ __launch_bounds__(BT, BT / 128) void vox_band_kernel(VoxJobs jobs, in
         }
     }
     __syncthreads();
+    VSTAMP(4)
     float mean = 0.f, sd = 1.f;
     bool scale = false, shift = false;
     if (mode == VOX_BAND_NORMALISED) {
@@ -395,8 +424,12 @@ __global__ __launch_bounds__(BT, BT / 128) void vox_band_kernel(VoxJobs jobs, in
     // one pass over the band: every cell is rounded to fp32 once, counted into the moments and stored
     const bool want_sums = acc && mode != VOX_BAND_NORMALISED;
     const bool store = mode != VOX_BAND_MOMENTS;
-    double c = 0.0, sm = 0.0, sq = 0.0;
-    auto note = [&](float v) { if (v != 0.f) { c += 1.0; sm += (double)v; sq += (double)v * (double)v; } };
+    // a thread's share of the band's moments (at most a few dozen cells) in fp32 and an integer count, widened once below: zeros add
+    // nothing, so no branch - the fp64 form (compare, branch, convert, two adds and an fma per cell, 9 216 cells per band) made the
+    // read-out the longest phase of a band block (stamps: 4 800 of 14 800 cycles, vector-pipe bound: fp64 runs at half rate)
+    int cnz = 0;
+    float sm32 = 0.f, sq32 = 0.f;
+    auto note = [&](float v) { cnz += v != 0.f ? 1 : 0; sm32 += v; sq32 = __builtin_fmaf(v, v, sq32); };
     for (int bin = 0; bin < bins; ++bin) {
         const double* src = band + bin * bpx;
         float* dst = grid + (size_t)bin * pl.hw + p0;
@@ -416,7 +449,13 @@ __global__ __launch_bounds__(BT, BT / 128) void vox_band_kernel(VoxJobs jobs, in
             }
         }
     }
-    if (want_sums) vox_store_sums(c, sm, sq, acc + b, sh3);
+    VSTAMP(5)
+    if (want_sums) vox_store_sums((double)cnz, (double)sm32, (double)sq32, acc + b, sh3);
+#ifdef EEM_VOX_STAMPS
+    VSTAMP(6)
+    if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 1024)
+        for (int i = 0; i < 8; ++i) g_vox_stamps[blockIdx.x * 8 + i] = vst[i];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ 4. normalisation
@@ -534,6 +573,13 @@ bool make_plan(int64_t n, int bins, int h, int w, const double* events, VoxPlan*
 
 }  // namespace
 
+#ifdef EEM_VOX_STAMPS
+extern "C" __attribute__((visibility("default"))) int eemflow_debug_read_vox_stamps(unsigned long long* dst, size_t n) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_vox_stamps), n * sizeof(unsigned long long)) == hipSuccess ? 0 : 2;
+}
+#endif
+
+
 // sums + one 16-byte record slot per event (slabs are whole blocks: round up) + the run table
 size_t voxel_scratch_bytes(int64_t n) {
     const long m = n > 0 ? (long)n : 0;
@@ -608,9 +654,15 @@ int voxel_launch_jobs(int njobs, const double* const* events, const int64_t* n, 
         // read + write of the whole grid - a moments-only launch, then a launch that stores the bands already normalised
         const char* tp = getenv("EEM_VOX_TWOPASS");                  // read per call: the tests run both forms in one process
         const long two_pass_ratio = tp ? atol(tp) : 0L;
-        // lanes per run: the smallest power of two >= 1.7 x the mean run length (slab events / bands), 4 .. 64
+        // lanes per run: the smallest power of two >= EEM_VOX_RUN_LANES_X10 / 10 (default 4.0 for sparse sets, else 1.7 - the rule through round 5) x the mean run length
+        // (slab events / bands), 4 .. 64: a run longer than its lanes costs its block a dependent round trip in the clean-up loop, and with
+        // 196 runs of mean length 2 per band and four lanes each nearly every block had one (stamps: 3 700 cycles in the adds)
+        // (sparse sets only - mean run below 4 records: at 2e6 events per grid the wider runs idle more lanes than they save, 53.0 against
+        // 50.6 us per sample)
+        static const long lanes_env = [] { const char* e = getenv("EEM_VOX_RUN_LANES_X10"); const long v = e ? atol(e) : 0; return v >= 10 ? v : 0L; }();
+        const long lanes_x10 = lanes_env ? lanes_env : ((long)VT * ept < 4L * pl.nb ? 40L : 17L);
         int sgs = 2;
-        while (sgs < 6 && (1 << sgs) * 10L * pl.nb < 17L * VT * ept) ++sgs;
+        while (sgs < 6 && (1 << sgs) * 10L * pl.nb < lanes_x10 * VT * ept) ++sgs;
         auto band = [&](int with_moments, int mode) {
             if (lds <= 24 * 1024)
                 hipLaunchKernelGGL(vox_band_kernel<256>, dim3(pl.nb, njobs), dim3(256), lds, stream, jobs, VT * ept, bins, pl, vec4, with_moments, mode, sgs);

@@ -450,7 +450,7 @@ static int level_buffers(eemplus_ctx* c, int l, int B) {
 // What level l computes from the feature pyramid alone (EEMFlow+.py:184-185,191 and :179 for level 6): the 1x1 projections of both
 // feature maps - feature_1's goes straight into the dense buffer's x slot - and rconv_l into the decoder input.  Nothing here reads a
 // coarser level's flow, so a forward runs these on the side stream while the coarse levels' launch-bound chain has the chip.
-static int level_units(eemplus_ctx* c, int l, int B, hipStream_t st) {
+static int level_units(eemplus_ctx* c, int l, int B, hipStream_t st, bool skip_rconv = false) {
     int rc;
     const int C[7] = {0, 16, 32, 64, 64, 64, 64};
     const int h = c->hl[l], w = c->wl[l];
@@ -479,6 +479,7 @@ static int level_units(eemplus_ctx* c, int l, int B, hipStream_t st) {
             if ((rc = conv(c, P, f2, C[l], 0, B, h, w, c->a2_l[l].p, 32, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
         }
     }
+    if (skip_rconv) return EEM_OK;                                 // (run_level: rconv rides the mask estimator's first launch)
     return conv(c, c->rconv[l], f1, C[l], 0, B, h, w, c->cat_l[l].p, kCat, 53, 1, GACT_LEAKY, nullptr, st);
 }
 
@@ -502,7 +503,18 @@ static int run_level(eemplus_ctx* c, int l, int B, const float* forced_init, hip
     float* const dense = c->dense_l[l].p;
     float* const a2 = c->a2_l[l].p;
     float* const cat = c->cat_l[l].p;
-    if (!units_done && (rc = level_units(c, l, B, st)) != EEM_OK) return rc;
+    // coarse levels (small-grid kernel): rconv_l - 64 -> 32 over feature_1, the shape of the mask estimator's first conv - is the second
+    // job of that conv's launch instead of a launch of its own (EEM_PLUS_NO_FUSE=1, read per forward: apart)
+    bool rconv_rides = false;
+    {
+        static const bool no_tail = [] { const char* e = getenv("EEM_PLUS_NO_TAIL"); return e && e[0] == '1'; }();
+        static const long conv_tail_max = [] { const char* e = getenv("EEM_PLUS_CONV_TAIL_MAX"); return e ? atol(e) : 4096L; }();
+        const char* epf0 = getenv("EEM_PLUS_NO_FUSE");
+        const char* emc = getenv("EEM_PLUS_TAIL_MAXCIN");
+        rconv_rides = !units_done && !no_tail && !(epf0 && epf0[0] == '1') && (long)h * w <= conv_tail_max && c->de[0].has_tail &&
+                      c->rconv[l].has_tail && (emc ? atoi(emc) : 184) >= 64 && TAIL_MAX_JOBS >= 2;
+    }
+    if (!units_done && (rc = level_units(c, l, B, st, rconv_rides)) != EEM_OK) return rc;
     // cdc_model.forward (cdc_utils.py:156-174)
     if (forced_init) {
         // teacher-forced level (eemplus_level): cdc_model's upsampled flow_init is supplied by the caller
@@ -529,8 +541,24 @@ static int run_level(eemplus_ctx* c, int l, int B, const float* forced_init, hip
         if ((rc = pl_warp_launch(a2, fi, 2, dense, kDense, 152, B, 32, h, w, 2, st)) != EEM_OK) return rc;
     }
     const int din[6] = {64, 96, 128, 160, 176, 184}, dout_off[5] = {88, 56, 24, 8, 0};
-    for (int i = 0; i < 5; ++i)
+    for (int i = 0; i < 5; ++i) {
+        if (i == 0 && rconv_rides) {
+            TailConvLaunch T;
+            T.batch = B; T.h = h; T.w = w; T.ksize = 3; T.njobs = 2;
+            for (int q = 0; q < 2; ++q) {
+                const PLayer& P = q == 0 ? c->de[0] : c->rconv[l];
+                TailConvJob& j = T.job[q];
+                j.in = q == 0 ? dense : f1(l); j.wpk = c->arena + P.wtail; j.bias = c->arena + P.bias;
+                j.out = q == 0 ? dense : cat;
+                j.cin = P.cin; j.cout = P.cout; j.in_ctotal = q == 0 ? kDense : C[l]; j.in_coff = q == 0 ? kDense - din[0] : 0;
+                j.out_ctotal = q == 0 ? kDense : kCat; j.out_coff = q == 0 ? dout_off[0] : 53; j.out_cmul = 1; j.act = 1;
+                j.gate = nullptr; j.in_cmul = 1; j.add = nullptr;
+            }
+            if ((rc = tail_conv_launch(T, st)) != EEM_OK) return rc;
+            continue;
+        }
         if ((rc = conv(c, c->de[i], dense, kDense, kDense - din[i], B, h, w, dense, kDense, dout_off[i], 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
+    }
     if ((rc = conv(c, c->de[5], dense, kDense, 0, B, h, w, c->xout.p, 3, 0, 1, GACT_NONE, nullptr, st)) != EEM_OK) return rc;
     if (fuse3) {
         // ... and the warp of feature_2 by that flow_up (:189) in the same launch

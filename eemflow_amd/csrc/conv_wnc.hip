@@ -52,6 +52,19 @@ struct WncCfg {
     static_assert(2 * STAGE * 4 * (TEAMS == 1 ? 2 : 1) <= 160 * 1024, "LDS budget");
 };
 
+#ifdef EEM_WNC_STAMPS
+#ifndef EEM_WNC_STAMPS_JOBS
+#define EEM_WNC_STAMPS_JOBS 3                              // which launches leave their stamps: the decoder's first conv (3 slices x 3 chunks)
+#define EEM_WNC_STAMPS_CHUNKS 3
+#endif
+// stamps build only (-DEEM_WNC_STAMPS, tools/wnc_stamps.py): per wave of the first 256 blocks, cycles (s_memtime) summed over the block's
+// iterations: [0] top wait [1] top barrier [2] requests issued [3] first half [4] mid wait [5] second half [6] exchange + epilogue [7] total
+__device__ unsigned long long g_wnc_stamps[256 * 8 * 8];
+#define WSTAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); wst[i] += now_ - wprev; wprev = now_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define WSTAMP(i)
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vm() {
     static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
@@ -94,13 +107,39 @@ __global__ __launch_bounds__(C::WAVES * 64, C::TEAMS == 1 ? 2 : 1) void wnc_kern
     TileCoord cur = tile_coord(range.first, tiles_x, tiles_y), nxt = cur;      // .n = job * batch + image
     int cur_ch = 0, nxt_ch = 0;
 
+    // ---- what a (job, image) pair means for this wave, fetched ONCE per tile (round 6, in-kernel stamps - tools/wnc_stamps.py: with
+    // the job table indexed and the image / job split divided out in every chunk's request block, that block took 2 600 of a chunk's
+    // 13 800 cycles, the matrix pipe idle: 19 % of the decoder's first conv)
+    struct Tile {
+        const float* in;       // channel 0 of the job's input range in this image
+        const char* w;         // this wave's (Winograd row's) weight stream
+        const char* bias;
+        float* out;            // channel out_coff of this image
+        const float* res;
+        int out_cmul, cout;
+    };
+    auto fetch = [&](const TileCoord& tc) __attribute__((always_inline)) {
+        const int j = tc.n / a.n, n = tc.n - j * a.n;
+        const WncJob& J = a.job[j];
+        Tile t;
+        t.in = J.in + ((size_t)n * J.in_ctotal + J.in_coff) * plane;
+        t.w = reinterpret_cast<const char*>(J.w) + (size_t)xi * 2 * nchunks * NW * 1024;
+        t.bias = reinterpret_cast<const char*>(J.bias);
+        const size_t ob = ((size_t)n * J.out_ctotal + J.out_coff) * plane;
+        t.out = J.out + ob;
+        t.res = J.res ? J.res + ob : nullptr;
+        t.out_cmul = J.out_cmul; t.cout = J.cout;
+        return t;
+    };
+    Tile tcur = fetch(cur), tnxt = tcur;
+    const int cin = a.cin;                                   // chunk k starts at channel min(32 k, cin - 32) (wnc_chunks)
+
     // ---- DMA plan (fixed for the kernel): slot -> (channel in group, tile row, 16-byte piece)
     const int dslot = wave * 64 + lane;
     const int dcl = dslot / PC, drem = dslot - dcl * PC, dry = drem / PPR, dq = drem - dry * PPR;
-    auto issue = [&](int stage, const TileCoord& tc, int ch) __attribute__((always_inline)) {
-        const int j = tc.n / a.n, n = tc.n - j * a.n;
-        const WncJob& J = a.job[j];
-        const float* base = J.in + ((size_t)n * J.in_ctotal + J.in_coff + a.chunk_off[ch]) * plane;
+    auto issue = [&](int stage, const TileCoord& tc, const Tile& t, int ch) __attribute__((always_inline)) {
+        const int choff = min(32 * ch, cin - 32);
+        const float* base = t.in + (size_t)choff * plane;
         const int gy = tc.by * TH - 1 + dry, gx = tc.bx * TW - 4 + dq * 4;
         const bool ok = dcl < CPI && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
         const char* gp = ok ? reinterpret_cast<const char*>(base + ((dcl * a.h + gy) * a.w + gx)) : reinterpret_cast<const char*>(a.zero_page);
@@ -114,9 +153,8 @@ __global__ __launch_bounds__(C::WAVES * 64, C::TEAMS == 1 ? 2 : 1) void wnc_kern
     };
     // ---- weights: [xi][half-chunk][k-step of the half (8)][lane][nu] floats per job; a half = 8 asm loads of 16 bytes per lane
     const unsigned vo0 = lane * 16u, vo1 = vo0 + 4096u;
-    auto load_w = [&](f32x4 (&dst)[8], const TileCoord& tc, int hf) __attribute__((always_inline)) {
-        const int j = tc.n / a.n;
-        const char* wb = reinterpret_cast<const char*>(a.job[j].w) + ((size_t)(xi * 2 * nchunks + hf) * NW) * 1024;
+    auto load_w = [&](f32x4 (&dst)[8], const Tile& t, int hf) __attribute__((always_inline)) {
+        const char* wb = t.w + (size_t)hf * NW * 1024;
 #pragma unroll
         for (int s = 0; s < NW; ++s)
             asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst[s]) : "v"(s < 4 ? vo0 : vo1), "s"(wb), "n"((s & 3) * 1024) : "memory");
@@ -128,9 +166,8 @@ __global__ __launch_bounds__(C::WAVES * 64, C::TEAMS == 1 ? 2 : 1) void wnc_kern
     // bias of the cout rows this wave finishes: co = r + 8 xi + 4 kk, r = 0..3 (M16: the one cout 4 kq + xi, in biasv[0])
     f32x4 biasv = {0.f, 0.f, 0.f, 0.f};
     const unsigned bo = M16 ? (unsigned)(4 * kq + xi) * 4u : (unsigned)(8 * xi + 4 * kk) * 4u;
-    auto load_bias = [&](const TileCoord& tc) __attribute__((always_inline)) {
-        const int j = tc.n / a.n;
-        const char* bb = reinterpret_cast<const char*>(a.job[j].bias);
+    auto load_bias = [&](const Tile& t) __attribute__((always_inline)) {
+        const char* bb = t.bias;
         if constexpr (M16) asm volatile("global_load_dword %0, %1, %2" : "=v"(biasv[0]) : "v"(bo), "s"(bb) : "memory");
         else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(biasv) : "v"(bo), "s"(bb) : "memory");
     };
@@ -220,19 +257,26 @@ __global__ __launch_bounds__(C::WAVES * 64, C::TEAMS == 1 ? 2 : 1) void wnc_kern
     };
 
     // ---- prologue: the first chunk's first half of weights, then its tile
-    load_w(wr[0], cur, 0);
-    issue(0, cur, 0);
+    load_w(wr[0], tcur, 0);
+    issue(0, cur, tcur, 0);
     bool stored = false;                                     // the previous iteration ended in a tile's stores (the youngest requests)
+#ifdef EEM_WNC_STAMPS
+    unsigned long long wst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long wprev = __builtin_amdgcn_s_memtime();
+    const unsigned long long wstart = wprev;
+#endif
 #pragma unroll 1
     for (int it = 0; it < niter; ++it) {
         const bool first = cur_ch == 0, last = cur_ch == nchunks - 1, more = it + 1 < niter;
         // this chunk's tile and its first half of weights have landed; every wave is through with the other stage
         if (stored) wait_vm<NST>(); else wait_vm<0>();
         landed(wr[0]);
+        WSTAMP(0)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        WSTAMP(1)
         if (first) {
-            load_bias(cur);
+            load_bias(tcur);
             if constexpr (M16) {
 #pragma unroll
                 for (int nu = 0; nu < 4; ++nu) { acc16[nu][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc16[nu][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -243,21 +287,30 @@ __global__ __launch_bounds__(C::WAVES * 64, C::TEAMS == 1 ? 2 : 1) void wnc_kern
                     for (int r = 0; r < 16; ++r) acc[nu][r] = 0.f;
             }
         }
-        load_w(wr[1], cur, 2 * cur_ch + 1);
+        load_w(wr[1], tcur, 2 * cur_ch + 1);
         if (more) {
-            if (++nxt_ch == nchunks) { nxt_ch = 0; tile_advance(nxt, tiles_x, tiles_y); }
-            issue((it + 1) & 1, nxt, nxt_ch);
+            if (++nxt_ch == nchunks) {
+                nxt_ch = 0;
+                const int n_before = nxt.n;
+                tile_advance(nxt, tiles_x, tiles_y);
+                if (nxt.n != n_before) tnxt = fetch(nxt);    // (a block's tiles are consecutive: the pair changes at most a few times)
+            }
+            issue((it + 1) & 1, nxt, tnxt, nxt_ch);
         }
         __builtin_amdgcn_sched_barrier(0);
+        WSTAMP(2)
         const float* stage = lds + (it & 1) * STAGE;
         half(std::integral_constant<int, 0>{}, wr[0], stage);
+        WSTAMP(3)
         // the second half's weights (and the bias): only the next chunk's DMA pieces are younger
         if (more) wait_vm<NI>(); else wait_vm<0>();
         landed(wr[1]);
         asm volatile("" : "+v"(biasv));
-        if (more) load_w(wr[0], nxt, 2 * nxt_ch);
+        WSTAMP(4)
+        if (more) load_w(wr[0], tnxt, 2 * nxt_ch);
         __builtin_amdgcn_sched_barrier(0);
         half(std::integral_constant<int, 1>{}, wr[1], stage);
+        WSTAMP(5)
         stored = false;
         if (last && M16) {
             // ---- M16: u of (half-group h2, cout register r) at [wave][h2 * 4 + r][lane][2]; wave xi finishes register xi of both halves
@@ -276,12 +329,10 @@ __global__ __launch_bounds__(C::WAVES * 64, C::TEAMS == 1 ? 2 : 1) void wnc_kern
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             const f32x2* xr = reinterpret_cast<const f32x2*>(xst) + ((wave - xi) * 8 + xi) * 64 + lane;
-            const int j = cur.n / a.n, n = cur.n - j * a.n;
-            const WncJob& J = a.job[j];
             const int co = 4 * kq + xi;
-            const bool okc = co < J.cout;
+            const bool okc = co < tcur.cout;
             float* sink = a.trash + lane * 2;
-            float* pc = J.out + ((size_t)n * J.out_ctotal + J.out_coff + (size_t)co * J.out_cmul) * plane;
+            float* pc = tcur.out + (size_t)co * tcur.out_cmul * plane;
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
                 const f32x2 u0 = xr[(0 * 8 + h2 * 4) * 64], u1 = xr[(1 * 8 + h2 * 4) * 64], u2 = xr[(2 * 8 + h2 * 4) * 64], u3 = xr[(3 * 8 + h2 * 4) * 64];
@@ -316,8 +367,6 @@ __global__ __launch_bounds__(C::WAVES * 64, C::TEAMS == 1 ? 2 : 1) void wnc_kern
             __builtin_amdgcn_s_barrier();
             // wave xi finishes accumulator rows 4 xi .. 4 xi + 3 of its team: couts r + 8 xi + 4 kk
             const f32x2* xr = reinterpret_cast<const f32x2*>(xst) + ((wave - xi) * 16 + 4 * xi) * 64 + lane;
-            const int j = cur.n / a.n, n = cur.n - j * a.n;
-            const WncJob& J = a.job[j];
             const int oy = cur.by * TH + 2 * tr, ox = cur.bx * TW + 2 * txb;
             const bool in0 = oy < a.h && ox < a.w, in1 = oy + 1 < a.h && ox < a.w;
             const int co0 = 8 * xi + 4 * kk;
@@ -333,12 +382,12 @@ __global__ __launch_bounds__(C::WAVES * 64, C::TEAMS == 1 ? 2 : 1) void wnc_kern
                     y10 = fmaxf(y10, sl * y10); y11 = fmaxf(y11, sl * y11);
                 }
                 const int co = co0 + r;
-                const bool okc = co < J.cout;
-                const size_t po = ((size_t)n * J.out_ctotal + J.out_coff + (size_t)co * J.out_cmul) * plane + (size_t)oy * a.w + ox;
-                float* p = J.out + po;
-                if (J.res) {                                 // (wave-uniform) residual block: relu(res + .); outside lanes read the zero page
-                    const f32x2 r0 = *reinterpret_cast<const f32x2*>(in0 && okc ? J.res + po : a.zero_page);
-                    const f32x2 r1 = *reinterpret_cast<const f32x2*>(in1 && okc ? J.res + po + a.w : a.zero_page);
+                const bool okc = co < tcur.cout;
+                const size_t po = (size_t)co * tcur.out_cmul * plane + (size_t)oy * a.w + ox;
+                float* p = tcur.out + po;
+                if (tcur.res) {                              // (wave-uniform) residual block: relu(res + .); outside lanes read the zero page
+                    const f32x2 r0 = *reinterpret_cast<const f32x2*>(in0 && okc ? tcur.res + po : a.zero_page);
+                    const f32x2 r1 = *reinterpret_cast<const f32x2*>(in1 && okc ? tcur.res + po + a.w : a.zero_page);
                     y00 = fmaxf(y00 + r0[0], 0.f); y01 = fmaxf(y01 + r0[1], 0.f);
                     y10 = fmaxf(y10 + r1[0], 0.f); y11 = fmaxf(y11 + r1[1], 0.f);
                 }
@@ -348,12 +397,25 @@ __global__ __launch_bounds__(C::WAVES * 64, C::TEAMS == 1 ? 2 : 1) void wnc_kern
             }
             stored = true;
         }
+        WSTAMP(6)
         cur = nxt;
         cur_ch = nxt_ch;
+        tcur = tnxt;
     }
+#ifdef EEM_WNC_STAMPS
+    wst[7] = __builtin_amdgcn_s_memtime() - wstart;
+    if (lane == 0 && blockIdx.x < 256 && wave < 8 && a.njobs == EEM_WNC_STAMPS_JOBS && a.nchunks == EEM_WNC_STAMPS_CHUNKS)
+        for (int i = 0; i < 8; ++i) g_wnc_stamps[(blockIdx.x * 8 + wave) * 8 + i] = wst[i];
+#endif
 }
 
 }  // namespace
+
+#ifdef EEM_WNC_STAMPS
+extern "C" __attribute__((visibility("default"))) int eemflow_debug_read_wnc_stamps(unsigned long long* dst, size_t n) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wnc_stamps), n * sizeof(unsigned long long)) == hipSuccess ? 0 : 2;
+}
+#endif
 
 int wnc_chunks(int cin, int* chunk_off) {
     int n = 0;
@@ -399,6 +461,7 @@ bool wnc_supported(const WncArgs& a) {
     const char* e = getenv("EEM_NO_WNC");                   // read per call: a test runs both forms in one process
     if (e && e[0] == '1') return false;
     if (a.njobs < 1 || a.njobs > WNC_MAX_JOBS || a.nchunks < 1 || a.nchunks > WNC_MAX_CHUNKS || a.n < 1) return false;
+    if (a.cin < 32 || (a.cin + 31) / 32 != a.nchunks) return false;
     if (a.w % 4 || a.h < 1 || !a.zero_page || !a.trash || ((uintptr_t)a.zero_page & 15) || ((uintptr_t)a.trash & 7)) return false;
     if ((size_t)a.h * a.w * 32 * 4 >= (1u << 31)) return false;                  // 32-bit byte offsets inside a chunk
     for (int j = 0; j < a.njobs; ++j) {

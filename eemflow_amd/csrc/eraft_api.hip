@@ -291,6 +291,7 @@ int run_wnc(eraft_ctx* c, const Layer& L, const float* x, int n, int h, int w, f
     WncArgs a;
     memset(&a, 0, sizeof(a));
     a.nchunks = wnc_chunks(L.cs[0], a.chunk_off);
+    a.cin = L.cs[0];
     a.n = n; a.h = h; a.w = w; a.act = act;
     a.zero_page = c->arena + c->zero_off; a.trash = c->trash;
     for (int sl = 0; sl * 32 < L.cout; ++sl) {

@@ -140,6 +140,7 @@ bool wnc_wanted(int h, int w, int njobs) {
 void wnc_common(eemplus_ctx* c, WncArgs& a, int cin, int n, int h, int w, int act) {
     memset(&a, 0, sizeof(a));
     a.nchunks = wnc_chunks(cin, a.chunk_off);
+    a.cin = cin;
     a.n = n; a.h = h; a.w = w; a.act = act == GACT_LEAKY;
     a.zero_page = c->arena + c->zero_off;
     a.trash = c->arena + c->zero_off + 1024;
@@ -512,7 +513,8 @@ static int run_level(eemplus_ctx* c, int l, int B, const float* forced_init, hip
         const char* epf0 = getenv("EEM_PLUS_NO_FUSE");
         const char* emc = getenv("EEM_PLUS_TAIL_MAXCIN");
         rconv_rides = !units_done && !no_tail && !(epf0 && epf0[0] == '1') && (long)h * w <= conv_tail_max && c->de[0].has_tail &&
-                      c->rconv[l].has_tail && (emc ? atoi(emc) : 184) >= 64 && TAIL_MAX_JOBS >= 2;
+                      c->rconv[l].has_tail && (emc ? atoi(emc) : 184) >= 64 && TAIL_MAX_JOBS >= 2 &&
+                      !(c->rconv[l].has_wnc && wnc_wanted(h, w, 1));      // (a map forced onto the Winograd kernel keeps rconv there)
     }
     if (!units_done && (rc = level_units(c, l, B, st, rconv_rides)) != EEM_OK) return rc;
     // cdc_model.forward (cdc_utils.py:156-174)

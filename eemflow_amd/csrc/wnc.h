@@ -19,6 +19,7 @@ struct WncJob {
 struct WncArgs {
     WncJob job[WNC_MAX_JOBS];
     int njobs, nchunks;
+    int cin;               // input depth of every job: chunk k starts at channel min(32 k, cin - 32) of the job's range (wnc_chunks)
     int chunk_off[WNC_MAX_CHUNKS];
     int n, h, w;
     int act;               // 0: none, 1: LeakyReLU(0.1), 2: ReLU

@@ -9,19 +9,21 @@
 //   * the input is consumed in chunks of 32 channels: the chunk's haloed tile [32][6][72] goes L2/HBM -> LDS by 16-byte LDS-DMA,
 //     double-buffered; the accumulators live across the chunks of a tile and the output transform runs after the last one;
 //   * a chunk's weights (64 KB for the four waves of a team) cannot stay in registers across chunks: they stream from L2 in halves
-//     of a chunk (8 k-steps = 32 VGPRs), each half requested while the half before it multiplies - as asm loads with counted
-//     s_waitcnt vmcnt, the way gconv16.hip does it (the compiler's own bookkeeping of loads in flight across a loop's back edge
-//     drains them all);
-//   * request order inside a chunk: [weights of its second half] [next chunk's tile DMA] ... first half multiplies ...
-//     vmcnt(DMA pieces) ... [weights of the next chunk's first half] ... second half multiplies: nothing the running chunk waits
-//     for is younger than the next chunk's DMA, which has the whole chunk to land;
+//     of a chunk (8 k-steps = 32 VGPRs) through a ring of three buffers, each half requested two halves before it multiplies - as asm
+//     loads with counted s_waitcnt vmcnt, the way gconv16.hip does it (the compiler's own bookkeeping of loads in flight across a
+//     loop's back edge drains them all);
+//   * the requests are issued UNDER the MFMAs: every k-step sends one weight load of the half after next and, in a chunk's first half,
+//     one piece (two for the 16-cout form) of the next chunk's tile DMA.  First form: all 16 requests of a chunk in one block at its top
+//     - 128 instructions of 1 KB per CU at the address unit's 16 cycles each, the matrix pipe idle: 17 - 19 % of a wave's cycles by the
+//     in-kernel stamps (tools/wnc_stamps.py), 4.6 % now (the decoder's first conv 59.8 -> 55.0 us);
 //   * a launch takes up to eight JOBS (32-cout slices of one layer, or the groups of a grouped layer): persistent blocks walk
 //     (job, image, tile) triples, so the three groups of a decoder layer or the three slices of its first conv fill the chip as one
 //     launch.
-// Measured and not kept: a ring of THREE half-chunk weight buffers, every half requested two halves ahead (three copies of the loop
-// body, 244 VGPRs) - per-layer times within 0.5 us of the two-buffer form at 192 x 320 (60.0 against 60.8 us for the decoder's first
-// conv): with the matrix pipe's ~3.9 us per chunk (two waves per SIMD x 64 MFMAs of 64 cycles) the one-half lead already covers the
-// round trip; what a chunk pays above that is its top (wait, barrier, 16 requests per wave) and, per tile, the exchange and the stores.
+// Measured: three weight buffers with two halves of lead but the requests still in one block per chunk changed no layer by more than
+// 0.5 us - what cost time was that block's issue at the address unit, not the round trip; job parameters fetched once per tile instead
+// of indexed out of the kernel arguments per chunk: 19 -> 17 % in that block.  Where a wave's cycles go now (decoder's first conv, 3 jobs x
+// 3 chunks, 9 chunk-iterations per block): the two halves 78 % (the matrix pipe's own time for two waves per SIMD is 68 %), exchange +
+// epilogue 10 %, barrier 4 %, planning 5 %, waits 3 %.
 // Input depths that are not a multiple of 32 (the estimator's 176 and 184) end in a chunk that overlaps the one before it; the
 // repeated channels' weights are packed as zeros (wnc_pack) - what they multiply is a finite activation.
 #include <type_traits>
@@ -137,19 +139,26 @@ __global__ __launch_bounds__(C::WAVES * 64, C::TEAMS == 1 ? 2 : 1) void wnc_kern
     // ---- DMA plan (fixed for the kernel): slot -> (channel in group, tile row, 16-byte piece)
     const int dslot = wave * 64 + lane;
     const int dcl = dslot / PC, drem = dslot - dcl * PC, dry = drem / PPR, dq = drem - dry * PPR;
-    auto issue = [&](int stage, const TileCoord& tc, const Tile& t, int ch) __attribute__((always_inline)) {
+    // a chunk's tile request = this lane's first piece address + the distance to the same piece of the next channel group (`plan`), then
+    // NI pieces (`piece`): all at once in the prologue (`issue`), one or two per k-step under the MFMAs afterwards
+    struct Plan { const char* gp; unsigned step; };
+    auto plan = [&](const TileCoord& tc, const Tile& t, int ch) __attribute__((always_inline)) {
         const int choff = min(32 * ch, cin - 32);
         const float* base = t.in + (size_t)choff * plane;
         const int gy = tc.by * TH - 1 + dry, gx = tc.bx * TW - 4 + dq * 4;
         const bool ok = dcl < CPI && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
-        const char* gp = ok ? reinterpret_cast<const char*>(base + ((dcl * a.h + gy) * a.w + gx)) : reinterpret_cast<const char*>(a.zero_page);
-        const unsigned step = ok ? (unsigned)(CPI * plane) * 4u : 0u;
-        float* sbase = lds + stage * STAGE;
-#pragma unroll
-        for (int k = 0; k < NI; ++k) {
-            __builtin_amdgcn_global_load_lds(GLB_PTR(gp), LDS_PTR(sbase + (wave + k * WAVES) * 256), 16, 0, 0);
-            gp += step;
-        }
+        Plan p;
+        p.gp = ok ? reinterpret_cast<const char*>(base + ((dcl * a.h + gy) * a.w + gx)) : reinterpret_cast<const char*>(a.zero_page);
+        p.step = ok ? (unsigned)(CPI * plane) * 4u : 0u;
+        return p;
+    };
+    auto piece = [&](auto k_tag, int stage, const Plan& p) __attribute__((always_inline)) {
+        constexpr int k = decltype(k_tag)::value;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(p.gp + (size_t)k * p.step), LDS_PTR(lds + stage * STAGE + (wave + k * WAVES) * 256), 16, 0, 0);
+    };
+    auto issue = [&](int stage, const TileCoord& tc, const Tile& t, int ch) __attribute__((always_inline)) {
+        const Plan p = plan(tc, t, ch);
+        unroll_for<0, NI>([&](auto k_tag) __attribute__((always_inline)) { piece(k_tag, stage, p); });
     };
     // ---- weights: [xi][half-chunk][k-step of the half (8)][lane][nu] floats per job; a half = 8 asm loads of 16 bytes per lane
     const unsigned vo0 = lane * 16u, vo1 = vo0 + 4096u;
@@ -158,6 +167,11 @@ __global__ __launch_bounds__(C::WAVES * 64, C::TEAMS == 1 ? 2 : 1) void wnc_kern
 #pragma unroll
         for (int s = 0; s < NW; ++s)
             asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst[s]) : "v"(s < 4 ? vo0 : vo1), "s"(wb), "n"((s & 3) * 1024) : "memory");
+    };
+    auto load_w1 = [](auto s_tag, f32x4& dst, const char* wb, unsigned lane_off) __attribute__((always_inline)) {
+        constexpr int s = decltype(s_tag)::value;
+        const unsigned vo = lane_off + (s < 4 ? 0u : 4096u);
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(vo), "s"(wb), "n"((s & 3) * 1024) : "memory");
     };
     auto landed = [&](f32x4 (&w)[8]) __attribute__((always_inline)) {      // tells the compiler the registers are ready (gconv16.hip)
 #pragma unroll
@@ -183,9 +197,9 @@ __global__ __launch_bounds__(C::WAVES * 64, C::TEAMS == 1 ? 2 : 1) void wnc_kern
 
     f32x16 acc[4];
     f32x4 acc16[4][2];
-    f32x4 wr[2][8];
-    // one half of a chunk: 8 k-steps (2 channels each) x 4 MFMAs
-    auto half = [&](auto hl_tag, const f32x4 (&w)[8], const float* stage) __attribute__((always_inline)) {
+    f32x4 wr[3][8];
+    // one half of a chunk: 8 k-steps (2 channels each) x 4 MFMAs; req(s) issues the k-step's share of the requests under its MFMAs
+    auto half = [&](auto hl_tag, const f32x4 (&w)[8], const float* stage, auto&& req) __attribute__((always_inline)) {
         constexpr int HL = decltype(hl_tag)::value;
         if constexpr (!M16) {
             const float* pa = stage + lbase + ra * ROWP;
@@ -214,6 +228,7 @@ __global__ __launch_bounds__(C::WAVES * 64, C::TEAMS == 1 ? 2 : 1) void wnc_kern
                 const float v[4] = {t[0] - t[2], t[1] + t[2], t[2] - t[1], t[1] - t[3]};
 #pragma unroll
                 for (int nu = 0; nu < 4; ++nu) acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[s][nu], v[nu], acc[nu], 0, 0, 0);
+                req(s_tag);
             });
         } else {
             // four k-steps of four channels (this lane: channel 4 s + kq), two half-groups of 16 tiles per weight fragment
@@ -252,25 +267,37 @@ __global__ __launch_bounds__(C::WAVES * 64, C::TEAMS == 1 ? 2 : 1) void wnc_kern
 #pragma unroll
                     for (int h2 = 0; h2 < 2; ++h2)
                         acc16[nu][h2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s][nu], v[h2][nu], acc16[nu][h2], 0, 0, 0);
+                req(s_tag);
             });
         }
     };
 
-    // ---- prologue: the first chunk's first half of weights, then its tile
+    // ---- requests (second form, round 6; in-kernel stamps, tools/wnc_stamps.py): with a chunk's 16 requests per wave issued in one block at
+    // its top - 128 instructions of 1 KB per CU, 16 cycles each at the address unit - that block was 17 - 19 % of a wave's cycles with the
+    // matrix pipe idle.  Now every k-step issues its share under its MFMAs: one weight load (half g + 2's k-step s: three half-chunk buffers,
+    // half g lives in buffer g % 3, so the loop body comes in three copies - P = chunk mod 3) and, in a chunk's first half, one or two pieces
+    // of the next chunk's tile.  Issue order: prologue [W(0)] [tile 0] [W(1)]; chunk it: [bias] | half 0: W(2it+2)[s], tile(it+1)[s] ... |
+    // half 1: W(2it+3)[s] ... | [stores].  Waits: at the top everything up to tile(it)'s last piece - younger are W(2it+1) and the previous
+    // tile's stores; in the middle W(2it+1) - younger are the first half's NW + NI requests (the bias and any stores in between are waited
+    // for as well: vmcnt counts from the youngest).
     load_w(wr[0], tcur, 0);
     issue(0, cur, tcur, 0);
+    load_w(wr[1], tcur, 1);
     bool stored = false;                                     // the previous iteration ended in a tile's stores (the youngest requests)
 #ifdef EEM_WNC_STAMPS
     unsigned long long wst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long wprev = __builtin_amdgcn_s_memtime();
     const unsigned long long wstart = wprev;
 #endif
-#pragma unroll 1
-    for (int it = 0; it < niter; ++it) {
+    auto chunk = [&](auto p_tag, int it) __attribute__((always_inline)) {
+        constexpr int P = decltype(p_tag)::value;
+        f32x4(&B0)[8] = wr[(2 * P) % 3];
+        f32x4(&B1)[8] = wr[(2 * P + 1) % 3];
+        f32x4(&B2)[8] = wr[(2 * P + 2) % 3];
         const bool first = cur_ch == 0, last = cur_ch == nchunks - 1, more = it + 1 < niter;
         // this chunk's tile and its first half of weights have landed; every wave is through with the other stage
-        if (stored) wait_vm<NST>(); else wait_vm<0>();
-        landed(wr[0]);
+        if (stored) wait_vm<NW + NST>(); else wait_vm<NW>();
+        landed(B0);
         WSTAMP(0)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -287,7 +314,8 @@ __global__ __launch_bounds__(C::WAVES * 64, C::TEAMS == 1 ? 2 : 1) void wnc_kern
                     for (int r = 0; r < 16; ++r) acc[nu][r] = 0.f;
             }
         }
-        load_w(wr[1], tcur, 2 * cur_ch + 1);
+        Plan pn = {reinterpret_cast<const char*>(a.zero_page), 0u};
+        const char* wn = tcur.w;
         if (more) {
             if (++nxt_ch == nchunks) {
                 nxt_ch = 0;
@@ -295,21 +323,34 @@ __global__ __launch_bounds__(C::WAVES * 64, C::TEAMS == 1 ? 2 : 1) void wnc_kern
                 tile_advance(nxt, tiles_x, tiles_y);
                 if (nxt.n != n_before) tnxt = fetch(nxt);    // (a block's tiles are consecutive: the pair changes at most a few times)
             }
-            issue((it + 1) & 1, nxt, tnxt, nxt_ch);
+            pn = plan(nxt, tnxt, nxt_ch);
+            wn = tnxt.w + (size_t)(2 * nxt_ch) * NW * 1024;
         }
+        const int nstage = (it + 1) & 1;
         __builtin_amdgcn_sched_barrier(0);
         WSTAMP(2)
         const float* stage = lds + (it & 1) * STAGE;
-        half(std::integral_constant<int, 0>{}, wr[0], stage);
+        half(std::integral_constant<int, 0>{}, B0, stage, [&](auto s_tag) __attribute__((always_inline)) {
+            constexpr int s = decltype(s_tag)::value;
+            if (more) {
+                load_w1(s_tag, B2[s], wn, vo0);
+                constexpr int PPS = NI / NW;                 // tile pieces per k-step
+                unroll_for<0, PPS>([&](auto q_tag) __attribute__((always_inline)) {
+                    piece(std::integral_constant<int, s * PPS + decltype(q_tag)::value>{}, nstage, pn);
+                });
+            }
+        });
         WSTAMP(3)
-        // the second half's weights (and the bias): only the next chunk's DMA pieces are younger
-        if (more) wait_vm<NI>(); else wait_vm<0>();
-        landed(wr[1]);
+        // the second half's weights (and the bias): only the first half's requests are younger
+        if (more) wait_vm<NW + NI>(); else wait_vm<0>();
+        landed(B1);
         asm volatile("" : "+v"(biasv));
         WSTAMP(4)
-        if (more) load_w(wr[0], tnxt, 2 * nxt_ch);
         __builtin_amdgcn_sched_barrier(0);
-        half(std::integral_constant<int, 1>{}, wr[1], stage);
+        half(std::integral_constant<int, 1>{}, B1, stage, [&](auto s_tag) __attribute__((always_inline)) {
+            constexpr int s = decltype(s_tag)::value;
+            if (more) load_w1(s_tag, B0[s], wn + (size_t)NW * 1024, vo0);
+        });
         WSTAMP(5)
         stored = false;
         if (last && M16) {
@@ -401,6 +442,18 @@ __global__ __launch_bounds__(C::WAVES * 64, C::TEAMS == 1 ? 2 : 1) void wnc_kern
         cur = nxt;
         cur_ch = nxt_ch;
         tcur = tnxt;
+    };
+    {
+        int it = 0;
+#pragma unroll 1
+        while (it < niter) {
+            chunk(std::integral_constant<int, 0>{}, it);
+            if (++it >= niter) break;
+            chunk(std::integral_constant<int, 1>{}, it);
+            if (++it >= niter) break;
+            chunk(std::integral_constant<int, 2>{}, it);
+            ++it;
+        }
     }
 #ifdef EEM_WNC_STAMPS
     wst[7] = __builtin_amdgcn_s_memtime() - wstart;

@@ -73,7 +73,9 @@ __device__ int g_wg_dbg;                                 // diagnostic builds: E
 // BX: the tile's products on the bf16 matrix pipe (exact three-piece operands, above) - wave w's 32 pixels of the tile are ONE K = 32 step:
 // (MT + 9) operand splits and 6 x 9 MT MFMAs of 16 cycles where the fp32 form issues 8 x 9 MT of 32
 template <int MT, int S, int TW, int CP, int KH = 3, int KW = 3, bool BX = false>
-__global__ __launch_bounds__(256) void wgrad_enc_kernel(WgradArgs a, int tiles_x, int tiles_y, int walk) {
+__global__ __launch_bounds__(256) void wgrad_enc_kernel(WgradArgs a, int tiles_x, int tiles_y, int flags) {
+    const int walk = flags & 1;
+    const bool burst = (flags & 2) != 0;
     using C = WgCfg<MT, S, TW, CP, KH, KW>;
     constexpr int NT = C::NT, TAPS = C::TAPS;
     // blockIdx.z: chunk of MT * 16 couts (layers wider than 64 couts: E-RAFT's update block and heads)
@@ -136,40 +138,61 @@ __global__ __launch_bounds__(256) void wgrad_enc_kernel(WgradArgs a, int tiles_x
     // Both operands travel as buffer loads: the descriptor's base is the tile's corner (a scalar), a lane's offset inside the tile is
     // fixed for the whole kernel, and pieces outside the image (or past the block's channels) carry an offset beyond the descriptor's
     // range - the hardware writes zeros.  Interior tiles need no vector instruction per piece; edge tiles one compare + select.
+    // (round 6: a tile's NGI + NXI requests are no longer one block behind the barrier - 13 instructions of 1 KB per wave at the address
+    // unit's 16 cycles each, the matrix pipe idle meanwhile, as conv_wnc.hip's stamps showed for the same pattern - but go out one or two
+    // per column tile / k-step of the running tile's multiply loop: `prep` builds the two descriptors, `piece` sends request k)
 #if __HIP_DEVICE_COMPILE__
-    auto issue = [&](int stage, const TileCoord& tc) {
-        const int oy0 = tc.by * C::TH, ox0 = tc.bx * TW;
-        const int gy0 = oy0 * S - C::PH, gx0 = ox0 * S - 4;
+    struct Req {
+        __amdgpu_buffer_rsrc_t gr, xr;
+        float* sg;
+        float* sx;
+        int oy0, ox0, gy0, gx0;
+        bool g_inside, x_inside;
+    };
+    auto prep = [&](int stage, const TileCoord& tc) {
+        Req r;
+        r.oy0 = tc.by * C::TH; r.ox0 = tc.bx * TW;
+        r.gy0 = r.oy0 * S - C::PH; r.gx0 = r.ox0 * S - 4;
         const char* gb = reinterpret_cast<const char*>(a.g + ((size_t)tc.n * a.g_ctotal + a.g_coff) * ghw) +
-                         ((long)oy0 * a.wout + ox0) * 4;
+                         ((long)r.oy0 * a.wout + r.ox0) * 4;
         const char* xb = reinterpret_cast<const char*>(a.x + ((size_t)tc.n * a.x_ctotal + a.x_coff + ci0) * xhw) +
-                         ((long)gy0 * a.win + gx0) * 4;
-        float* sg = lds + stage * C::STAGE;
-        float* sx = sg + C::GFL;
-        const bool g_inside = oy0 + C::TH <= a.hout && ox0 + TW <= a.wout;
-        const bool x_inside = gy0 >= 0 && gy0 + C::XR <= a.hin && gx0 >= 0 && gx0 + 4 * C::XQ <= a.win;
-        const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(gb), (short)0, (int)RANGE, 0x00020000);
-        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xb), (short)0, (int)RANGE, 0x00020000);
-#pragma unroll
-        for (int k = 0; k < C::NGI; ++k) {
+                         ((long)r.gy0 * a.win + r.gx0) * 4;
+        r.sg = lds + stage * C::STAGE;
+        r.sx = r.sg + C::GFL;
+        r.g_inside = r.oy0 + C::TH <= a.hout && r.ox0 + TW <= a.wout;
+        r.x_inside = r.gy0 >= 0 && r.gy0 + C::XR <= a.hin && r.gx0 >= 0 && r.gx0 + 4 * C::XQ <= a.win;
+        r.gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(gb), (short)0, (int)RANGE, 0x00020000);
+        r.xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xb), (short)0, (int)RANGE, 0x00020000);
+        return r;
+    };
+    // request k of a tile: 0 .. NGI - 1 the G pieces, NGI .. NGI + NXI - 1 the X pieces (k is a compile-time value at every call)
+    auto piece = [&](const Req& r, int k) __attribute__((always_inline)) {
+        if (k < C::NGI) {
             unsigned vo = goff[k];
-            if (!g_inside) {
+            if (!r.g_inside) {
                 const int py = grc[k] & 255, px = grc[k] >> 8;
-                vo = (grc[k] >= 0 && oy0 + py < a.hout && ox0 + px < a.wout) ? vo : RANGE;
+                vo = (grc[k] >= 0 && r.oy0 + py < a.hout && r.ox0 + px < a.wout) ? vo : RANGE;
             }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, LDS_PTR(sg + (wave + 4 * k) * 256), 16, vo, 0, 0, 0);
-        }
-#pragma unroll
-        for (int k = 0; k < C::NXI; ++k) {
-            unsigned vo = xoff[k];
-            if (!x_inside) {
-                const int iy = gy0 + (xrc[k] & 255), ix = gx0 + (xrc[k] >> 8);
-                vo = (xrc[k] >= 0 && iy >= 0 && iy < a.hin && ix >= 0 && ix + 4 <= a.win) ? vo : RANGE;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r.gr, LDS_PTR(r.sg + (wave + 4 * k) * 256), 16, vo, 0, 0, 0);
+        } else if (k < C::NGI + C::NXI) {
+            const int kx = k - C::NGI;
+            unsigned vo = xoff[kx];
+            if (!r.x_inside) {
+                const int iy = r.gy0 + (xrc[kx] & 255), ix = r.gx0 + (xrc[kx] >> 8);
+                vo = (xrc[kx] >= 0 && iy >= 0 && iy < a.hin && ix >= 0 && ix + 4 <= a.win) ? vo : RANGE;
             }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, LDS_PTR(sx + (wave + 4 * k) * 256), 16, vo, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r.xr, LDS_PTR(r.sx + (wave + 4 * kx) * 256), 16, vo, 0, 0, 0);
         }
     };
+    auto issue = [&](int stage, const TileCoord& tc) {
+        const Req r = prep(stage, tc);
+#pragma unroll
+        for (int k = 0; k < C::NGI + C::NXI; ++k) piece(r, k);
+    };
 #else
+    struct Req { int unused; };
+    auto prep = [&](int, const TileCoord&) { return Req{0}; };
+    auto piece = [&](const Req&, int) {};
     auto issue = [&](int, const TileCoord&) {};
 #endif
 
@@ -207,14 +230,25 @@ __global__ __launch_bounds__(256) void wgrad_enc_kernel(WgradArgs a, int tiles_x
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces of tile `it` have landed
         __builtin_amdgcn_s_barrier();                            // everyone's have; everyone is done with tile it-1
         asm volatile("" ::: "memory");
-        if (it + 1 < tr_.count) {
-            advance(nxt);
-            issue((it + 1) & 1, nxt);
+        const bool more = it + 1 < tr_.count;
+        constexpr int NREQ = C::NGI + C::NXI;
+        if (more) advance(nxt);
+        const Req rq = prep((it + 1) & 1, nxt);                  // (of the running tile when there is no next one: never sent)
+        if (more && burst) {
+#pragma unroll
+            for (int k = 0; k < C::NGI + C::NXI; ++k) piece(rq, k);
         }
+        const bool spread = more && !burst;
         const float* sg = lds + (it & 1) * C::STAGE;
         const float* sx = sg + C::GFL;
 #ifdef EEM_DIAG
-        if (g_wg_dbg & 1) continue;
+        if (g_wg_dbg & 1) {                                      // (no compute phase: the requests it would have carried, at once)
+            if (spread) {
+#pragma unroll
+                for (int k = 0; k < NREQ; ++k) piece(rq, k);
+            }
+            continue;
+        }
 #endif
         if constexpr (BX) {
             // this lane's eight pixels: p = 32 wave + 8 g + e (one row of the tile: 8 divides TW)
@@ -240,6 +274,11 @@ __global__ __launch_bounds__(256) void wgrad_enc_kernel(WgradArgs a, int tiles_x
                 for (int e = 0; e < 8; ++e) x[e] = sx[boff[nt] + xo8 + e * S];
                 u32x4 bp[3];
                 wg_split8(x, bp[0], bp[1], bp[2]);
+                if (spread) {                                                // this column tile's share of the next tile's requests
+                    constexpr int PP = (NREQ + NT - 1) / NT;
+#pragma unroll
+                    for (int q = 0; q < PP; ++q) piece(rq, nt * PP + q);
+                }
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {                            // small terms first
                     constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
@@ -252,6 +291,11 @@ __global__ __launch_bounds__(256) void wgrad_enc_kernel(WgradArgs a, int tiles_x
         }
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
+            if (spread) {
+                constexpr int PP = (NREQ + 7) / 8;
+#pragma unroll
+                for (int q = 0; q < PP; ++q) piece(rq, s * PP + q);
+            }
             float av[MT], bv[NT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) av[mt] = sg[aoff[s] + mt * 16 * C::GP];
@@ -340,7 +384,9 @@ int launch(const WgradArgs& a, hipStream_t st) {
         raised = true;
     }
     static const int walk = [] { const char* e = getenv("EEM_WGRAD_WALK"); return e ? atoi(e) : 0; }();     // (measured: no difference, profiles/r06_wgwalk.txt - its operands come out of L2 / MALL either way)
-    hipLaunchKernelGGL((wgrad_enc_kernel<MT, S, TW, CP, KH, KW, BX>), dim3(gx, chunks, cochunks), dim3(256), lds_bytes, st, a, tiles_x, tiles_y, walk);
+    const char* eb = getenv("EEM_WGRAD_BURST");                 // (=1, read per call: a tile's requests in one block behind the barrier, the form through round 6's first half)
+    const int flags = (walk & 1) | ((eb && eb[0] == '1') ? 2 : 0);
+    hipLaunchKernelGGL((wgrad_enc_kernel<MT, S, TW, CP, KH, KW, BX>), dim3(gx, chunks, cochunks), dim3(256), lds_bytes, st, a, tiles_x, tiles_y, flags);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

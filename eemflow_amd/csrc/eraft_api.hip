@@ -32,7 +32,7 @@ struct Layer {                    // one convolution, weights packed for gconv
     bool hasb = false, has_stem = false;
     size_t wraw = 0, wf4 = 0;      // 64 -> 64 3x3 stride-1 layers: OIHW weights (BatchNorm scale folded in) and their F(4x4,3x3) form
     bool has_scale = false, has16 = false, has_few = false, has_f4 = false;
-    size_t wwnc[4] = {0, 0, 0, 0};  // 96 -> 96 / 128 -> 128 3x3 stride-1 layers: F(2x2) streams of their 32-cout slices (conv_wnc.hip), BatchNorm scale folded in
+    size_t wwnc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // 96 -> 96 / 128 -> 128 3x3 stride-1 layers: F(2x2) streams of their 32-cout slices (conv_wnc.hip), BatchNorm scale folded in
     bool has_wnc = false;
     int cout = 0, kh = 1, kw = 1, stride = 1, ph = 0, pw = 0;
     int cs[3] = {0, 0, 0}, nseg = 1;
@@ -155,7 +155,10 @@ void make_layer(Packer& pk, Layer& L, const float* w, const float* bias, int cou
     }
     // the encoder's 96 -> 96 and 128 -> 128 residual convs (model/extractor.py:146-147, layer2 / layer3) on the Winograd F(2x2,3x3) kernel
     // of EEMFlow+'s fine levels (conv_wnc.hip: 32-cout slices as the jobs of one launch), an eval-mode BatchNorm's scale folded in
-    L.has_wnc = nseg == 1 && co0 == 0 && kh == 3 && kw == 3 && stride == 1 && ph == 1 && pw == 1 && cin == con && (con == 96 || con == 128);
+    // (and, round 6, the motion encoder's convc2 256 -> 192, convf2 128 -> 64 and conv 256 -> 126, model/update.py:66-81: any single-tensor
+    // 3x3 layer of 32 .. 256 input channels and up to 256 couts qualifies; which of them take the kernel is the call sites' choice)
+    L.has_wnc = nseg == 1 && co0 == 0 && kh == 3 && kw == 3 && stride == 1 && ph == 1 && pw == 1 && cin >= 32 && cin <= 32 * WNC_MAX_CHUNKS &&
+                con >= 32 && con <= 32 * WNC_MAX_JOBS && !(cin == 64 && con == 64);
     if (L.has_wnc) {
         std::vector<float> wsc((size_t)con * cin * 9);
         for (int co = 0; co < con; ++co) {
@@ -287,7 +290,8 @@ bool wnc_eligible(const Layer& L, int n, int h, int w) {
     if (e && e[0] == '1') return false;
     return L.has_wnc && w % 4 == 0 && (long)n * ((h + 3) / 4) * ((w + 31) / 32) * (L.cout / 32) >= 128;
 }
-int run_wnc(eraft_ctx* c, const Layer& L, const float* x, int n, int h, int w, float* out, int act, const float* res, hipStream_t st) {
+int run_wnc(eraft_ctx* c, const Layer& L, const float* x, int n, int h, int w, float* out, int act, const float* res, hipStream_t st,
+            int out_ctotal = 0, int out_coff = 0) {
     WncArgs a;
     memset(&a, 0, sizeof(a));
     a.nchunks = wnc_chunks(L.cs[0], a.chunk_off);
@@ -298,11 +302,22 @@ int run_wnc(eraft_ctx* c, const Layer& L, const float* x, int n, int h, int w, f
         WncJob& J = a.job[a.njobs++];
         J.in = x; J.in_ctotal = L.cs[0]; J.in_coff = 0;
         J.w = c->arena + L.wwnc[sl]; J.bias = c->arena + L.shift + sl * 32;
-        J.out = out; J.out_ctotal = L.cout; J.out_coff = sl * 32; J.out_cmul = 1; J.cout = 32;
+        J.out = out; J.out_ctotal = out_ctotal ? out_ctotal : L.cout; J.out_coff = out_coff + sl * 32; J.out_cmul = 1;
+        J.cout = L.cout - sl * 32 < 32 ? L.cout - sl * 32 : 32;
         J.res = res;
     }
     EEM_REQUIRE(wnc_supported(a), "run_wnc: the launch does not qualify (alignment)");
     return wnc_launch(a, st);
+}
+
+// the motion encoder's three 3x3 convs (model/update.py:66-81) on the same kernel: EEM_ERAFT_WNC_UPD=<mask> (read per call; bit 0 convc2
+// 256 -> 192, bit 1 convf2 128 -> 64, bit 2 conv 256 -> 126).  Measured at 640x480 x 12, batch 4, one box: none 289.5 frames/s, convf2 298.7
+// (it ran the LDS-tiled kernel's two-K-group form - 240 blocks - at 25 TFLOP/s beside convc2: 115 us), convc2 287, conv 296, all three 297;
+// batch 1 within 0.5 %: the default is convf2 alone
+bool wnc_upd(const Layer& L, int bit, int n, int h, int w) {
+    const char* e = getenv("EEM_ERAFT_WNC_UPD");
+    const int mask = e ? atoi(e) : 2;
+    return ((mask >> bit) & 1) && wnc_eligible(L, n, h, w);
 }
 
 // BasicEncoder forward on `n` images [n][cin0][hp][wp]; result of the residual stack in *feat ([n][128][hp/8][wp/8]).
@@ -760,21 +775,33 @@ static int eraft_forward_impl(eraft_ctx* c, const float* e1, const float* e2, co
         GConvArgs a = conv_args(c, c->convf1, B, h8, w8, c->flo1.p, 128, 0, GACT_RELU);
         set_seg(a, 0, c->motion.p, 2, 128, 126);
         if ((rc = gconv_launch(a, sd)) != EEM_OK) return rc;
-        a = conv_args(c, c->convf2, B, h8, w8, c->corflo.p, 256, 192, GACT_RELU);
-        set_seg(a, 0, c->flo1.p, 128, 128, 0);
-        if ((rc = gconv_launch(a, sd)) != EEM_OK) return rc;
+        if (wnc_upd(c->convf2, 1, B, h8, w8)) {
+            if ((rc = run_wnc(c, c->convf2, c->flo1.p, B, h8, w8, c->corflo.p, 2, nullptr, sd, 256, 192)) != EEM_OK) return rc;
+        } else {
+            a = conv_args(c, c->convf2, B, h8, w8, c->corflo.p, 256, 192, GACT_RELU);
+            set_seg(a, 0, c->flo1.p, 128, 128, 0);
+            if ((rc = gconv_launch(a, sd)) != EEM_OK) return rc;
+        }
         a = conv_args(c, c->convc1, B, h8, w8, c->cor1.p, 256, 0, GACT_RELU);
         set_seg(a, 0, c->corr.p, kCorrPad, kCorrPad, 0);
         if (!gconv16_supported(a)) { a.wpk16 = nullptr; set_seg(a, 0, c->corr.p, 324, kCorrPad, 0); }
         if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
-        a = conv_args(c, c->convc2, B, h8, w8, c->corflo.p, 256, 0, GACT_RELU);
-        set_seg(a, 0, c->cor1.p, 256, 256, 0);
-        if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+        if (wnc_upd(c->convc2, 0, B, h8, w8)) {
+            if ((rc = run_wnc(c, c->convc2, c->cor1.p, B, h8, w8, c->corflo.p, 2, nullptr, st, 256, 0)) != EEM_OK) return rc;
+        } else {
+            a = conv_args(c, c->convc2, B, h8, w8, c->corflo.p, 256, 0, GACT_RELU);
+            set_seg(a, 0, c->cor1.p, 256, 256, 0);
+            if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+        }
         if ((rc = join()) != EEM_OK) return rc;
         if (lagged && (rc = side_mask()) != EEM_OK) return rc;             // (the previous iteration's prediction, behind the join event)
-        a = conv_args(c, c->conv, B, h8, w8, c->motion.p, 128, 0, GACT_RELU);
-        set_seg(a, 0, c->corflo.p, 256, 256, 0);
-        if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+        if (wnc_upd(c->conv, 2, B, h8, w8)) {
+            if ((rc = run_wnc(c, c->conv, c->corflo.p, B, h8, w8, c->motion.p, 2, nullptr, st, 128, 0)) != EEM_OK) return rc;
+        } else {
+            a = conv_args(c, c->conv, B, h8, w8, c->motion.p, 128, 0, GACT_RELU);
+            set_seg(a, 0, c->corflo.p, 256, 256, 0);
+            if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
+        }
         // SepConvGRU (model/update.py:43-60): horizontal then vertical pass
         float* hcur = nin;
         float* hnext = c->net[2].p;

@@ -418,7 +418,8 @@ def test_encoder_winograd_f2_convs_equal_the_bf16_piece_ones(monkeypatch, b, h, 
     """The encoder's 96 -> 96 and 128 -> 128 residual convs (model/extractor.py layer2 / layer3, both networks) run on the Winograd
     F(2x2,3x3) kernel of EEMFlow+'s fine levels (conv_wnc.hip: their 32-cout slices as the jobs of one launch, BatchNorm scale folded
     into the weights, ReLU and the residual sum in the epilogue for cnet, no activation in front of fnet's InstanceNorm) from 128
-    (tile, slice) pairs on; EEM_ERAFT_NO_WNC=1 (read per call) keeps them on the bf16-piece / LDS-tiled kernels."""
+    (tile, slice) pairs on, and so does the motion encoder's convf2 128 -> 64 (model/update.py:69; EEM_ERAFT_WNC_UPD masks it);
+    EEM_ERAFT_NO_WNC=1 (read per call) keeps all of them on the bf16-piece / LDS-tiled kernels."""
     net, _ = make_net(47)
     net.change_imagesize((h, w))
     e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(48, b, h, w))

@@ -6,7 +6,8 @@
 //     in whole blocks per CU); wave w owns the 16 couts of M-tile w and all pixel rows
 //     (N-tiles), so every weight fragment feeds four MFMAs and every input fragment is read once per wave from LDS (layers
 //     of <= 32 couts: two M-tiles x two row groups per block, so no wave idles);
-//   * the input is consumed in chunks of 16 channels: the chunk's haloed tile [16][4 + KH - 1][24] (columns x0 - 4 .. x0 + 19)
+//   * the input is consumed in chunks of 16 channels: the chunk's haloed tile [16][4 + KH - 1][24] (columns x0 - 4 .. x0 + 19; 16 columns
+//     for the one-column-wide filters)
 //     goes HBM/L2 -> LDS by 16-byte LDS-DMA, double-buffered, out-of-image pieces as out-of-range buffer offsets (zeros); the plane pitch is padded to
 //     16 mod 32 floats so the four channel lanes of a k-step fall on different bank halves;
 //   * the chunk's weight fragments (taps x 4 k-steps) are loaded into registers from a stream packed in fragment order
@@ -41,7 +42,10 @@ template <int KH, int KW, int THT, int S = 1>
 struct G16Cfg {
     static constexpr int TH = THT, TW = 16;
     static constexpr int ROWS = (TH - 1) * S + KH;
-    static constexpr int COLS = 16 * S + 8;                      // S * x0 - 4 .. S * x0 + 16 S + 3
+    // columns S * x0 - XM .. S * x0 + 16 S + XM - 1: a four-column margin either side for filters wider than one column, none for the
+    // 1x1 and 5x1 filters (round 6: they staged - and fetched - 24 columns for 16 too: a third of a 1x1 conv's input traffic)
+    static constexpr int XM = KW > 1 ? 4 : 0;
+    static constexpr int COLS = 16 * S + 2 * XM;
     static constexpr int PCS = COLS / 4;                         // 16-byte pieces per staged row
     static constexpr int PL0 = ROWS * COLS;
     static constexpr int PL = PL0 % 32 == 16 ? PL0 : PL0 + ((48 - PL0 % 32) % 32);   // plane pitch = 16 mod 32 floats
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || S > 1 || (THT != 2 && THT != 4
         const int ci = f / C::PQ, q = f - ci * C::PQ;
         const int row = q / C::PCS, pc = q - row * C::PCS;
         const bool ok = f < C::SLOTS && q < C::ROWS * C::PCS;
-        const int gy = y0 * S - PH + row, gx = x0 * S - 4 + 4 * pc;
+        const int gy = y0 * S - PH + row, gx = x0 * S - C::XM + 4 * pc;
         const bool in = ok && gy >= 0 && gy < a.hin && gx >= 0 && gx + 4 <= a.win;
         off[k] = in ? (unsigned)(((size_t)ci * hw + (size_t)gy * a.win + gx) * 4) : G16_RANGE;
     }
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || S > 1 || (THT != 2 && THT != 4
     f32x4 acc[NR];
 #pragma unroll
     for (int t = 0; t < NR; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int bbase = g * C::PL + S * j + 4 - PW;                // B fragment: channel g of a group, pixel column j
+    const int bbase = g * C::PL + S * j + C::XM - PW;            // B fragment: channel g of a group, pixel column j
 
     f32x4 wr[2][C::TAPS];
     auto compute = [&](int stage, f32x4 (&w)[C::TAPS]) __attribute__((always_inline)) {

@@ -407,7 +407,7 @@ int build_feature_pyramid(eraft_ctx* c, const float* f2, int batch, int ch, int 
 // flow_dst (optional): the lookup launch also writes flow = coords - flow_c0 there (resident-volume form; the on-the-fly form
 // keeps the separate launch)
 int run_lookup(eraft_ctx* c, const float* coords, float* out, int out_ctotal, int batch, int h, int w, hipStream_t st,
-               const float* flow_c0 = nullptr, float* flow_dst = nullptr, int flow_ctotal = 0, int flow_coff = 0) {
+               const float* flow_c0 = nullptr, float* flow_dst = nullptr, int flow_ctotal = 0, int flow_coff = 0, hipEvent_t done_ev = nullptr) {
     if (c->alt_corr) {
         if (flow_dst) {
             const int rcf = er_flow_launch(flow_c0, coords, flow_dst, flow_ctotal, flow_coff, batch, h * w, st);
@@ -421,13 +421,15 @@ int run_lookup(eraft_ctx* c, const float* coords, float* out, int out_ctotal, in
         for (int l = 0; l < 4; ++l) { aa.ph[l] = c->ph[l]; aa.pw[l] = c->pw[l]; }
         aa.coords = coords; aa.out = out; aa.batch = batch; aa.c = 256; aa.h = h; aa.w = w; aa.out_ctotal = out_ctotal;
         aa.scale = 1.0f / 16.0f;                                 // 1 / sqrt(256)
-        return er_altcorr_launch(aa, st);
+        const int rca = er_altcorr_launch(aa, st);
+        if (rca == EEM_OK && done_ev) EEM_HIP_CHECK(hipEventRecord(done_ev, st));
+        return rca;
     }
     LookupArgs la;
     for (int l = 0; l < 4; ++l) { la.pyr[l] = c->pyr[l].p; la.ph[l] = c->ph[l]; la.pw[l] = c->pw[l]; }
     la.coords = coords; la.out = out; la.batch = batch; la.h = h; la.w = w; la.out_ctotal = out_ctotal;
     la.coords0 = flow_c0; la.flow_dst = flow_dst; la.flow_ctotal = flow_ctotal; la.flow_coff = flow_coff;
-    return er_lookup_launch(la, st);
+    return er_lookup_launch(la, st, done_ev);
 }
 
 }  // namespace
@@ -762,8 +764,12 @@ static int eraft_forward_impl(eraft_ctx* c, const float* e1, const float* e2, co
         float* c1cur = fuse_small ? c1p : c->c1.p;
         float* c1nxt = fuse_small ? c1q : c->c1.p;
         // :142 lookup; :144 flow = coords1 - coords0 into the motion features' last two channels (update.py:81), by the same launch
+        // (the fork of the flow branch below: the lookup's own completion signal is the event the side stream waits for - EEM_ERAFT_FORK_RECORD=1,
+        // read per forward: a hipEventRecord behind it, as through round 6's first half)
+        const char* efr = getenv("EEM_ERAFT_FORK_RECORD");
+        const bool fork_by_launch = fuse_small && overlap && !(efr && efr[0] == '1');
         if (fuse_small) {
-            if ((rc = run_lookup(c, c1cur, c->corr.p, kCorrPad, B, h8, w8, st, c->c0.p, c->motion.p, 128, 126)) != EEM_OK) return rc;
+            if ((rc = run_lookup(c, c1cur, c->corr.p, kCorrPad, B, h8, w8, st, c->c0.p, c->motion.p, 128, 126, fork_by_launch ? c->fork_ev : nullptr)) != EEM_OK) return rc;
         } else {
             if ((rc = run_lookup(c, c1cur, c->corr.p, kCorrPad, B, h8, w8, st)) != EEM_OK) return rc;
             if ((rc = er_flow_launch(c->c0.p, c1cur, c->motion.p, 128, 126, B, (int)g, st)) != EEM_OK) return rc;
@@ -771,7 +777,10 @@ static int eraft_forward_impl(eraft_ctx* c, const float* e1, const float* e2, co
         // motion encoder (model/update.py:73-81): the flow branch convf1 -> convf2 on the side stream beside the correlation branch
         // the 324 correlation features live in a 336-channel buffer (12 zero channels, zero weight columns) so that the
         // 1x1 conv qualifies for the 16-aligned LDS-tiled kernel; the generic kernel reads the first 324
-        if ((rc = fork()) != EEM_OK) return rc;                        // (the lookup wrote the flow channels of `motion`)
+        if (fork_by_launch) {                                          // (the lookup wrote the flow channels of `motion`)
+            EEM_HIP_CHECK(hipStreamWaitEvent(sd, c->fork_ev, 0));
+            guard.forked = true;
+        } else if ((rc = fork()) != EEM_OK) return rc;
         GConvArgs a = conv_args(c, c->convf1, B, h8, w8, c->flo1.p, 128, 0, GACT_RELU);
         set_seg(a, 0, c->motion.p, 2, 128, 126);
         if ((rc = gconv_launch(a, sd)) != EEM_OK) return rc;

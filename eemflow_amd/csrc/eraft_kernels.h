@@ -37,7 +37,7 @@ struct LookupArgs {
     float* flow_dst = nullptr;
     int flow_ctotal = 0, flow_coff = 0;
 };
-int er_lookup_launch(const LookupArgs& a, hipStream_t st);
+int er_lookup_launch(const LookupArgs& a, hipStream_t st, hipEvent_t done_ev = nullptr);
 
 // the same 324 features computed on the fly from fmap1 and the avg-pooled levels of fmap2 (no all-pairs volume)
 struct AltCorrArgs {

@@ -1,3 +1,5 @@
+#include <hip/hip_ext.h>
+
 #include "eraft_kernels.h"
 
 namespace {
@@ -610,11 +612,15 @@ int er_pool2_launch(const float* in, float* out, long planes, int h, int w, hipS
 }
 
 static const long flat_max = [] { const char* e = getenv("EEM_LOOKUP_FLAT_MAX"); return e ? atol(e) : 1024L; }();
-int er_lookup_launch(const LookupArgs& a, hipStream_t st) {
+// done_ev (optional): signalled when the launch completes - as the launch's own completion signal (hipExtLaunchKernelGGL's stop event),
+// not as a separate hipEventRecord: an event record behind a kernel is a barrier packet that costs the recording stream ~6 us before its
+// next kernel starts (tools/eraft_timeline.sh: the gap in front of convc1 in every iteration)
+int er_lookup_launch(const LookupArgs& a, hipStream_t st, hipEvent_t done_ev) {
     static const bool plain = [] { const char* e = getenv("EEM_LOOKUP_PLAIN"); return e && e[0] == '1'; }();
-    if (plain) hipLaunchKernelGGL(lookup_kernel, dim3(blocks((long)a.batch * 324 * a.h * a.w)), dim3(256), 0, st, a);
-    else if ((long)ceil_div(a.h * a.w, 64) * 4 * a.batch < flat_max) hipLaunchKernelGGL(lookup_tiled_kernel<true>, dim3(ceil_div(a.h * a.w, 64), 4, a.batch), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(lookup_tiled_kernel<false>, dim3(ceil_div(a.h * a.w, 64), 4, a.batch), dim3(256), 0, st, a);
+    const dim3 gt(ceil_div(a.h * a.w, 64), 4, a.batch);
+    if (plain) hipExtLaunchKernelGGL(lookup_kernel, dim3(blocks((long)a.batch * 324 * a.h * a.w)), dim3(256), 0, st, nullptr, done_ev, 0, a);
+    else if ((long)ceil_div(a.h * a.w, 64) * 4 * a.batch < flat_max) hipExtLaunchKernelGGL(lookup_tiled_kernel<true>, gt, dim3(256), 0, st, nullptr, done_ev, 0, a);
+    else hipExtLaunchKernelGGL(lookup_tiled_kernel<false>, gt, dim3(256), 0, st, nullptr, done_ev, 0, a);
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

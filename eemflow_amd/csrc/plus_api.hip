@@ -127,15 +127,26 @@ void mk(Pk& pk, PLayer& L, const float* w, const float* b, int cin, int cout, in
 }
 
 // The fine levels' 3x3 layers on the Winograd kernel (conv_wnc.hip).  Measured per layer (tools/plus_timeline.sh, 1280x720): at 192 x 320
-// every layer wins (dense estimator 242 -> 183 us, decoder 337 -> 240); at 96 x 160 (the kernel's 4 x 32 tiles, 120 per job) the launches
-// of several jobs win - the decoder's first conv 25 -> 22 us, its grouped layers 16 -> 11, its 96 -> 64 conv 24 -> 16 - and the
-// one-job layers lose 1 - 6 us each to the LDS-tiled kernel (120 blocks on 256 CUs).  Hence: maps of at least EEM_PLUS_WNC_MINPX pixels
-// (30000), or of EEM_PLUS_WNC_MINPX_JOBS (10000) for launches of two or more jobs; both read per call.
-bool wnc_wanted(int h, int w, int njobs) {
+// every layer wins (dense estimator 242 -> 140 us, decoder 337 -> 220); at 96 x 160 (the kernel's 4 x 32 tiles, 120 per job and sample) the
+// launches of several jobs win - the decoder's first conv 25 -> 22 us, its grouped layers 16 -> 11, its 96 -> 64 conv 24 -> 16 - and the
+// one-job layers are level with the LDS-tiled kernel (120 blocks on 256 CUs); with four samples per call they win too, and so does
+// 48 x 80 (1 290 -> 1 374 frames/s).  What decides is how many (tile, job, sample) triples a launch has for the chip: from
+// EEM_PLUS_WNC_MINPAIRS (128) on.  EEM_PLUS_WNC_MINPX / EEM_PLUS_WNC_MINPX_JOBS, when set, replace that by the first rule - maps of at
+// least so many pixels, for one-job launches / launches of several jobs (defaults 30000 / 10000; 0 sends every level through the kernel:
+// the tests).  All read per call.
+bool wnc_wanted(int h, int w, int njobs, int n) {
+    if (w % 4) return false;
     const char* m = getenv("EEM_PLUS_WNC_MINPX");
     const char* mj = getenv("EEM_PLUS_WNC_MINPX_JOBS");
-    const long px = (long)h * w, lim1 = m ? atol(m) : 30000L, limj = mj ? atol(mj) : 10000L;
-    return w % 4 == 0 && (px >= lim1 || (njobs >= 2 && px >= limj));
+    const long px = (long)h * w;
+    if (m || mj) {
+        const long lim1 = m ? atol(m) : 30000L, limj = mj ? atol(mj) : 10000L;
+        return px >= lim1 || (njobs >= 2 && px >= limj);
+    }
+    const char* sm = getenv("EEM_WNC_SMALL_MAXPX");                 // (wnc_launch's choice of block tile: 4 x 32 below it, 4 x 64 from it on)
+    const int tw = px < (sm ? atol(sm) : 30000L) ? 32 : 64;
+    const char* mp = getenv("EEM_PLUS_WNC_MINPAIRS");
+    return (long)((h + 3) / 4) * ((w + tw - 1) / tw) * njobs * n >= (mp ? atol(mp) : 128L);
 }
 void wnc_common(eemplus_ctx* c, WncArgs& a, int cin, int n, int h, int w, int act) {
     memset(&a, 0, sizeof(a));
@@ -146,9 +157,11 @@ void wnc_common(eemplus_ctx* c, WncArgs& a, int cin, int n, int h, int w, int ac
     a.trash = c->arena + c->zero_off + 1024;
 }
 // one layer: its 32-cout slices are the jobs
+// (policy_jobs: the job count the kernel choice is made for - a group launched on its own decides like the launch of all groups)
 bool conv_wnc_args(eemplus_ctx* c, const PLayer& L, const float* in, int in_ctotal, int in_coff, int n, int h, int w, float* out,
-                   int out_ctotal, int out_coff, int out_cmul, int act, WncArgs& a) {
-    if (!L.has_wnc || !wnc_wanted(h, w, (L.cout + 31) / 32) || (act != GACT_LEAKY && act != GACT_NONE)) return false;
+                   int out_ctotal, int out_coff, int out_cmul, int act, WncArgs& a, int policy_jobs = 0) {
+    const int pj = policy_jobs > 0 ? policy_jobs : (L.cout + 31) / 32;
+    if (!L.has_wnc || !wnc_wanted(h, w, pj, n) || (act != GACT_LEAKY && act != GACT_NONE)) return false;
     wnc_common(c, a, L.cin, n, h, w, act);
     a.m16 = L.wnc16;
     const int cm = out_cmul > 1 ? out_cmul : 1;
@@ -163,10 +176,10 @@ bool conv_wnc_args(eemplus_ctx* c, const PLayer& L, const float* in, int in_ctot
 }
 
 int conv(eemplus_ctx* c, const PLayer& L, const float* in, int in_ctotal, int in_coff, int n, int hin, int win, float* out,
-         int out_ctotal, int out_coff, int out_cmul, int act, const float* add, hipStream_t st) {
+         int out_ctotal, int out_coff, int out_cmul, int act, const float* add, hipStream_t st, int policy_jobs = 0) {
     if (add == nullptr) {
         WncArgs wa;
-        if (conv_wnc_args(c, L, in, in_ctotal, in_coff, n, hin, win, out, out_ctotal, out_coff, out_cmul, act, wa)) return wnc_launch(wa, st);
+        if (conv_wnc_args(c, L, in, in_ctotal, in_coff, n, hin, win, out, out_ctotal, out_coff, out_cmul, act, wa, policy_jobs)) return wnc_launch(wa, st);
     }
     // small maps (the coarse pyramid levels): the small-grid kernel of EEMFlow's tail
     static const bool no_tail = [] { const char* e = getenv("EEM_PLUS_NO_TAIL"); return e && e[0] == '1'; }();
@@ -253,7 +266,7 @@ int run_decoder(eemplus_ctx* c, int l, int B, int h, int w, const float* residua
         for (int layer = 0; layer < 3; ++layer) {
             // the G groups of a layer as ONE launch of the LDS-tiled kernel when their packings lie at equal distances in the arena
             // (they do: same shapes, packed one after the other) and the launch qualifies
-            if (G > 1 && !no_grouped && c->decg[l][layer][0].has_wnc && wnc_wanted(h, w, G)) {
+            if (G > 1 && !no_grouped && c->decg[l][layer][0].has_wnc && wnc_wanted(h, w, G, B)) {
                 // the groups as the jobs of ONE Winograd launch: group gi reads channels [gi*per, (gi+1)*per), its output j goes to j*G + gi
                 WncArgs wa;
                 wnc_common(c, wa, per, B, h, w, GACT_LEAKY);
@@ -299,7 +312,7 @@ int run_decoder(eemplus_ctx* c, int l, int B, int h, int w, const float* residua
                 // group gi reads channels [gi*per, (gi+1)*per); channel_shuffle puts its output j at j*G + gi
                 const int oc = G == 1 ? 0 : gi, om = G == 1 ? 1 : G;
                 if ((rc = conv(c, c->decg[l][layer][gi], c->d[layer].p, kDW, gi * per, B, h, w, c->d[layer + 1].p, kDW, oc, om, GACT_LEAKY,
-                               nullptr, st)) != EEM_OK) return rc;
+                               nullptr, st, G)) != EEM_OK) return rc;
             }
         }
         if ((rc = conv(c, c->dec5[l], c->d[3].p, kDW, 0, B, h, w, c->t64.p, 64, 0, 1, GACT_LEAKY, nullptr, st)) != EEM_OK) return rc;
@@ -514,7 +527,7 @@ static int run_level(eemplus_ctx* c, int l, int B, const float* forced_init, hip
         const char* emc = getenv("EEM_PLUS_TAIL_MAXCIN");
         rconv_rides = !units_done && !no_tail && !(epf0 && epf0[0] == '1') && (long)h * w <= conv_tail_max && c->de[0].has_tail &&
                       c->rconv[l].has_tail && (emc ? atoi(emc) : 184) >= 64 && TAIL_MAX_JOBS >= 2 &&
-                      !(c->rconv[l].has_wnc && wnc_wanted(h, w, 1));      // (a map forced onto the Winograd kernel keeps rconv there)
+                      !(c->rconv[l].has_wnc && wnc_wanted(h, w, 1, B));      // (a map forced onto the Winograd kernel keeps rconv there)
     }
     if (!units_done && (rc = level_units(c, l, B, st, rconv_rides)) != EEM_OK) return rc;
     // cdc_model.forward (cdc_utils.py:156-174)

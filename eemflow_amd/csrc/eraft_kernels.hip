@@ -297,6 +297,93 @@ __global__ __launch_bounds__(256) void allpairs_kernel(const float* __restrict__
         }
 }
 
+// The same product with both operands staged through LDS (round 6).  allpairs_kernel above feeds every MFMA from L2: a wave loads 1 KB
+// per k-step for four MFMAs - 16 FLOP per byte, 4.6 TB/s of L2 reads at the 73 TFLOP/s it reaches (161 us at 60x80, 645 at batch 4).
+// Here a block's 128 x 128 tile walks the channels in chunks of 16: the chunk's [16][128] slabs of both feature maps (8 KB each, rows of
+// 512 contiguous bytes) arrive by 16-byte LDS-DMA, double-buffered, one barrier per chunk; a wave's two operands of a k-step are one
+// 8-byte LDS read each (same pixel mapping: row j of tile t = pixel 2 j + t), so each staged byte feeds both waves that need it.
+// 32 KB of LDS and 64 accumulator registers per block: four blocks per CU cover each other's waits.  Needs c % 16 == 0, hw % 4 == 0 and
+// 16-byte aligned maps (the launch checks); pixels past hw read a zero page.
+#define AP_LDS(p) ((__attribute__((address_space(3))) void*)(p))
+#define AP_GLB(p) ((const __attribute__((address_space(1))) void*)(p))
+__global__ __launch_bounds__(256, 4) void allpairs_lds_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                              float* __restrict__ out, int c, int hw, float scale,
+                                                              const float* __restrict__ zero_page) {
+    constexpr int KC = 16, TP = 128;                          // channels per chunk, pixels per block side
+    constexpr int SLAB = KC * TP;                             // floats of one operand's chunk
+    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * SLAB];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z;
+    const int mb = blockIdx.y * TP, nb0 = blockIdx.x * TP;
+    const float* a = f1 + (size_t)b * c * hw;
+    const float* bb = f2 + (size_t)b * c * hw;
+    // DMA plan: a slab is 16 rows x 32 pieces of 16 bytes = 512 slots = 2 instructions of the block per operand; slot = (row, piece)
+    const char* ga[2];
+    const char* gb[2];
+    unsigned step_a[2], step_b[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int slot = (wave + 4 * k) * 64 + lane;          // 0 .. 511
+        const int row = slot >> 5, pc = slot & 31;
+        const int pa = mb + 4 * pc, pb = nb0 + 4 * pc;
+        const bool oka = pa < hw, okb = pb < hw;              // (hw % 4 == 0: a piece is inside or outside as a whole)
+        ga[k] = oka ? reinterpret_cast<const char*>(a + (size_t)row * hw + pa) : reinterpret_cast<const char*>(zero_page);
+        gb[k] = okb ? reinterpret_cast<const char*>(bb + (size_t)row * hw + pb) : reinterpret_cast<const char*>(zero_page);
+        step_a[k] = oka ? (unsigned)(KC * hw) * 4u : 0u;      // bytes to the same slot of the next chunk
+        step_b[k] = okb ? (unsigned)(KC * hw) * 4u : 0u;
+    }
+    auto issue = [&](int stage) __attribute__((always_inline)) {
+        float* sa = lds + stage * 2 * SLAB;
+        float* sb = sa + SLAB;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            __builtin_amdgcn_global_load_lds(AP_GLB(ga[k]), AP_LDS(sa + (wave + 4 * k) * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(AP_GLB(gb[k]), AP_LDS(sb + (wave + 4 * k) * 256), 16, 0, 0);
+            ga[k] += step_a[k];
+            gb[k] += step_b[k];
+        }
+    };
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;    // this wave's 64 x 64 corner of the block tile
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[s][t][r] = 0.f;
+    const int nchunks = c / KC;
+    issue(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of chunk ch have landed
+        __builtin_amdgcn_s_barrier();                        // everyone's have; everyone is through with the other stage
+        asm volatile("" ::: "memory");
+        if (ch + 1 < nchunks) issue((ch + 1) & 1);
+        const float* sa = lds + (ch & 1) * 2 * SLAB + wm + 2 * j;
+        const float* sb = lds + (ch & 1) * 2 * SLAB + SLAB + wn + 2 * j;
+#pragma unroll
+        for (int k = 0; k < KC; k += 2) {
+            const f32x2 av = *reinterpret_cast<const f32x2*>(sa + (k + h) * TP);
+            const f32x2 bv = *reinterpret_cast<const f32x2*>(sb + (k + h) * TP);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[t], acc[s][t], 0, 0, 0);
+        }
+    }
+    float* o = out + (size_t)b * hw * hw;
+    const int m0 = mb + wm, nb = nb0 + wn + 2 * j;
+    if (nb >= hw) return;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int p1 = m0 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * h) + s;
+            if (p1 < hw) *reinterpret_cast<f32x2*>(o + (size_t)p1 * hw + nb) = f32x2{acc[s][0][r] * scale, acc[s][1][r] * scale};
+        }
+}
+
 __global__ __launch_bounds__(256) void pool2_kernel(const float* __restrict__ in, float* __restrict__ out, long planes, int h,
                                                     int w) {
     const int oh = h / 2, ow = w / 2;
@@ -597,6 +684,20 @@ int er_instnorm_launch(const float* x, float* out, const float* res, int planes,
 int er_allpairs_launch(const float* f1, const float* f2, float* out, int batch, int c, int hw, hipStream_t st) {
     const bool even = hw % 2 == 0 && ((uintptr_t)f1 & 7) == 0 && ((uintptr_t)f2 & 7) == 0 && ((uintptr_t)out & 7) == 0;
     dim3 grid(ceil_div(hw, 128), ceil_div(hw, 128), batch);
+    // the LDS-staged form where it applies (EEM_ALLPAIRS_L2=1, read per call: the form that feeds the MFMAs from L2)
+    const char* el2 = getenv("EEM_ALLPAIRS_L2");
+    static float* zero_pages[16] = {};                       // 256 bytes of zeros per device for the pieces past the last pixel (never freed)
+    int dev = 0;
+    if (even && c % 16 == 0 && hw % 4 == 0 && (((uintptr_t)f1 | (uintptr_t)f2) & 15) == 0 && !(el2 && el2[0] == '1') &&
+        hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16) {
+        if (!zero_pages[dev]) {
+            EEM_HIP_CHECK(hipMalloc(&zero_pages[dev], 256));
+            EEM_HIP_CHECK(hipMemset(zero_pages[dev], 0, 256));
+        }
+        hipLaunchKernelGGL(allpairs_lds_kernel, grid, dim3(256), 0, st, f1, f2, out, c, hw, 1.0f / sqrtf((float)c), zero_pages[dev]);
+        EEM_HIP_CHECK(hipGetLastError());
+        return EEM_OK;
+    }
     if (even) hipLaunchKernelGGL(allpairs_kernel, grid, dim3(256), 0, st, f1, f2, out, c, hw, 1.0f / sqrtf((float)c));
     else hipLaunchKernelGGL(allpairs_odd_kernel, grid, dim3(256), 0, st, f1, f2, out, c, hw, 1.0f / sqrtf((float)c));
     EEM_HIP_CHECK(hipGetLastError());

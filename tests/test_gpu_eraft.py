@@ -431,6 +431,22 @@ def test_encoder_winograd_f2_convs_equal_the_bf16_piece_ones(monkeypatch, b, h, 
     assert maxerr(wino, plain) < 5e-4 and float(plain.abs().max()) > 1e-3
 
 
+@pytest.mark.parametrize("b,h,w", [(1, 480, 640), (2, 200, 296)])
+def test_all_pairs_volume_through_lds_equals_the_l2_form(monkeypatch, b, h, w):
+    """The all-pairs correlation (model/corr.py:53-60) with both feature maps staged through LDS in chunks of 16 channels against the form
+    that feeds every MFMA from L2 (EEM_ALLPAIRS_L2=1, read per call): the same products summed in the same order - the same twelve
+    predictions bit for bit (60x80 = 37.5 block tiles: pixels past the last read a zero page; 25x37 cells are not a multiple of four: both
+    runs take the L2 form there and the test only says so)."""
+    net, _ = make_net(49)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(50, b, h, w))
+    with torch.no_grad():
+        lds = torch.stack(net(e1, e2, iters=12)[1]).clone()
+        monkeypatch.setenv("EEM_ALLPAIRS_L2", "1")
+        l2 = torch.stack(net(e1, e2, iters=12)[1]).clone()
+    assert torch.equal(lds, l2) and float(l2.abs().max()) > 1e-3
+
+
 def test_gru_context_part_computed_once_equals_the_full_convs(monkeypatch):
     """The GRU's convs read [h | inp | motion] (model/update.py:43-60) and `inp` does not change over the iterations: its part of
     every conv (+ the bias) is computed once per forward and enters the in-loop convs over [h | motion] as a per-pixel addend in front

@@ -384,9 +384,7 @@ int build_pyramid(eraft_ctx* c, const float* f1, const float* f2, int batch, int
         if ((rc = ensure(c->pyr[l], (size_t)batch * hw * c->ph[l] * c->pw[l])) != EEM_OK) return rc;
     }
     if ((rc = er_allpairs_launch(f1, f2, c->pyr[0].p, batch, ch, (int)hw, st)) != EEM_OK) return rc;
-    for (int l = 1; l < 4; ++l)
-        if ((rc = er_pool2_launch(c->pyr[l - 1].p, c->pyr[l].p, (long)batch * hw, c->ph[l - 1], c->pw[l - 1], st)) != EEM_OK) return rc;
-    return EEM_OK;
+    return er_pool2x3_launch(c->pyr[0].p, c->pyr[1].p, c->pyr[2].p, c->pyr[3].p, (long)batch * hw, h, w, st);
 }
 
 // alt_corr: the level sizes and the avg_pool2d(2) chain of fmap2 itself (pooling the volume's last two dimensions = pooling fmap2)

@@ -22,6 +22,7 @@ int er_allpairs_launch(const float* f1, const float* f2, float* out, int batch, 
 
 // avg_pool2d(2, stride 2) over the last two dims of [planes][h][w] -> [planes][h/2][w/2]   (model/corr.py:24-27)
 int er_pool2_launch(const float* in, float* out, long planes, int h, int w, hipStream_t st);
+int er_pool2x3_launch(const float* in, float* o1, float* o2, float* o3, long planes, int h, int w, hipStream_t st);   // three levels, one launch
 
 // 4-level 9x9 bilinear lookup (model/corr.py:29-50, model/model_utils.py:7-21), keeping the reference's
 // transposed window: channel l*81 + i*9 + j samples (x/2^l + i-4, y/2^l + j-4).

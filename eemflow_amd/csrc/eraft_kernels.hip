@@ -395,6 +395,43 @@ __global__ __launch_bounds__(256) void pool2_kernel(const float* __restrict__ in
     out[idx] = (s[0] + s[1] + s[w] + s[w + 1]) * 0.25f;
 }
 
+// Three avg_pool2d(2, 2) levels in one launch (the correlation pyramid, model/corr.py:24-27; EEMFlow+'s feature levels 4 .. 6,
+// EEMFlow+.py:170-175).  Block = one plane's band of 8 input rows: 4 rows of level 1 (kept in LDS), 2 of level 2, 1 of level 3 - bands are
+// independent because every level halves with floor.  pool2_kernel's own expression per output, so the three levels are bit for bit
+// those of three launches; the input is read once and the two smaller levels never come back from memory.
+__global__ __launch_bounds__(128) void pool2x3_kernel(const float* __restrict__ in, float* __restrict__ o1, float* __restrict__ o2,
+                                                      float* __restrict__ o3, int h, int w, int nb) {
+    extern __shared__ float pl[];                                // level 1 [4][w1], level 2 [2][w2]
+    const int h1 = h / 2, w1 = w / 2, h2 = h1 / 2, w2 = w1 / 2, h3 = h2 / 2, w3 = w2 / 2;
+    const long p = blockIdx.x / nb;
+    const int b = blockIdx.x - p * nb, tid = threadIdx.x;
+    float* l1 = pl;
+    float* l2 = pl + 4 * w1;
+    const int r1 = min(4, h1 - 4 * b), r2 = min(2, h2 - 2 * b);
+    const float* s = in + (p * h + 8 * b) * w;
+    for (int i = tid; i < r1 * w1; i += 128) {
+        const int y = i / w1, x = i - y * w1;
+        const float* q = s + 2 * y * w + 2 * x;
+        const float v = (q[0] + q[1] + q[w] + q[w + 1]) * 0.25f;
+        l1[y * w1 + x] = v;
+        o1[(p * h1 + 4 * b + y) * w1 + x] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < r2 * w2; i += 128) {
+        const int y = i / w2, x = i - y * w2;
+        const float* q = l1 + 2 * y * w1 + 2 * x;
+        const float v = (q[0] + q[1] + q[w1] + q[w1 + 1]) * 0.25f;
+        l2[y * w2 + x] = v;
+        o2[(p * h2 + 2 * b + y) * w2 + x] = v;
+    }
+    if (b >= h3) return;
+    __syncthreads();
+    for (int x = tid; x < w3; x += 128) {
+        const float* q = l2 + 2 * x;
+        o3[(p * h3 + b) * w3 + x] = (q[0] + q[1] + q[w2] + q[w2 + 1]) * 0.25f;
+    }
+}
+
 // grid_sample(align_corners=True, zeros) at pixel coordinates, computed like the reference: normalise with
 // (size-1), un-normalise again, floor, 4 taps (model/model_utils.py:7-21)
 // FLAT: the four corners as unconditional loads from clamped cells, the bounds applied to the values - one round trip per sample
@@ -446,16 +483,20 @@ __global__ __launch_bounds__(256) void lookup_kernel(LookupArgs a) {
 // 256-byte runs but every lane samples a different pixel's correlation map (19 KB apart at level 0).  Here a block owns 64
 // consecutive pixels of one pyramid level; lanes walk the flattened (pixel, tap) pairs, so the 64 samples of an instruction
 // come from the 10x10 windows of one or two maps; the values pass through an LDS tile [tap][pixel] and leave as 256-byte runs.
-template <bool FLAT>
+// PX pixels per block: 64, or 16 for the launches that leave the chip mostly empty (60x80 at batch 1: 300 blocks of 64 pixels = 4 waves on
+// a CU, each a chain of ~20 dependent sample round trips to a volume that lives in the Infinity Cache; 1 200 blocks of 16 pixels = 5 round
+// trips each with ~19 waves per CU to hide them; the stores become 64-byte runs of a 6 MB output: 14.7 -> 11.1 us; 8 pixels: 11.5 - what
+// is left is the volume's ~12 MB of scattered 128-byte lines).  Same samples, same values.
+template <bool FLAT, int PX>
 __global__ __launch_bounds__(256) void lookup_tiled_kernel(LookupArgs a) {
-    __shared__ float tile[81][65];
-    __shared__ float cxs[64], cys[64];
+    __shared__ float tile[81][PX + 1];
+    __shared__ float cxs[PX], cys[PX];
     const int hw = a.h * a.w;
     const int lvl = blockIdx.y, b = blockIdx.z;
-    const int p0 = blockIdx.x * 64;
-    const int npx = min(64, hw - p0);
+    const int p0 = blockIdx.x * PX;
+    const int npx = min(PX, hw - p0);
     const int tid = threadIdx.x;
-    if (tid < 64) {
+    if (tid < PX) {
         const int p = p0 + min(tid, npx - 1);
         cxs[tid] = a.coords[((size_t)b * 2 + 0) * hw + p];
         cys[tid] = a.coords[((size_t)b * 2 + 1) * hw + p];
@@ -478,8 +519,8 @@ __global__ __launch_bounds__(256) void lookup_tiled_kernel(LookupArgs a) {
     }
     __syncthreads();
     float* out = a.out + ((size_t)b * a.out_ctotal + lvl * 81) * hw + p0;
-    for (int e = tid; e < 81 * 64; e += 256) {
-        const int k = e >> 6, px = e & 63;
+    for (int e = tid; e < 81 * PX; e += 256) {
+        const int k = e / PX, px = e % PX;
         if (px < npx) out[(size_t)k * hw + px] = tile[k][px];
     }
 }
@@ -712,16 +753,44 @@ int er_pool2_launch(const float* in, float* out, long planes, int h, int w, hipS
     return EEM_OK;
 }
 
+// levels 1 .. 3 of a pyramid over `planes` planes of h x w in one launch (pool2x3_kernel); EEM_POOL_CHAIN=1 (read per call: the equality
+// test flips it) or a level-3 map that would be empty: three er_pool2_launch
+int er_pool2x3_launch(const float* in, float* o1, float* o2, float* o3, long planes, int h, int w, hipStream_t st) {
+    const int h1 = h / 2, w1 = w / 2, h2 = h1 / 2, w2 = w1 / 2, h3 = h2 / 2, w3 = w2 / 2;
+    const char* e = getenv("EEM_POOL_CHAIN");
+    const long nblk = planes * ceil_div(h1, 4);
+    if ((e && e[0] == '1') || nblk >= (1L << 31) || h3 < 1 || w3 < 1) {
+        int rc;
+        if ((rc = er_pool2_launch(in, o1, planes, h, w, st)) != EEM_OK || (rc = er_pool2_launch(o1, o2, planes, h1, w1, st)) != EEM_OK) return rc;
+        return er_pool2_launch(o2, o3, planes, h2, w2, st);
+    }
+    if (planes == 0) return EEM_OK;
+    hipLaunchKernelGGL(pool2x3_kernel, dim3((unsigned)nblk), dim3(128), (4 * w1 + 2 * w2) * sizeof(float), st, in, o1, o2, o3, h, w, ceil_div(h1, 4));
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
+}
+
 static const long flat_max = [] { const char* e = getenv("EEM_LOOKUP_FLAT_MAX"); return e ? atol(e) : 1024L; }();
 // done_ev (optional): signalled when the launch completes - as the launch's own completion signal (hipExtLaunchKernelGGL's stop event),
 // not as a separate hipEventRecord: an event record behind a kernel is a barrier packet that costs the recording stream ~6 us before its
 // next kernel starts (tools/eraft_timeline.sh: the gap in front of convc1 in every iteration)
 int er_lookup_launch(const LookupArgs& a, hipStream_t st, hipEvent_t done_ev) {
     static const bool plain = [] { const char* e = getenv("EEM_LOOKUP_PLAIN"); return e && e[0] == '1'; }();
-    const dim3 gt(ceil_div(a.h * a.w, 64), 4, a.batch);
+    const long blocks64 = (long)ceil_div(a.h * a.w, 64) * 4 * a.batch;
+    // EEM_LOOKUP_PX=64|32|16 (read per call: the equality test flips it): the block's pixels; default 16 below EEM_LOOKUP_FLAT_MAX blocks of 64
+    const char* epx = getenv("EEM_LOOKUP_PX");
+    const int px = epx ? atoi(epx) : (blocks64 < flat_max ? 16 : 64);
+    const dim3 gt(ceil_div(a.h * a.w, px == 16 ? 16 : px == 32 ? 32 : 64), 4, a.batch);
     if (plain) hipExtLaunchKernelGGL(lookup_kernel, dim3(blocks((long)a.batch * 324 * a.h * a.w)), dim3(256), 0, st, nullptr, done_ev, 0, a);
-    else if ((long)ceil_div(a.h * a.w, 64) * 4 * a.batch < flat_max) hipExtLaunchKernelGGL(lookup_tiled_kernel<true>, gt, dim3(256), 0, st, nullptr, done_ev, 0, a);
-    else hipExtLaunchKernelGGL(lookup_tiled_kernel<false>, gt, dim3(256), 0, st, nullptr, done_ev, 0, a);
+    else if (blocks64 < flat_max) {
+        if (px == 16) hipExtLaunchKernelGGL((lookup_tiled_kernel<true, 16>), gt, dim3(256), 0, st, nullptr, done_ev, 0, a);
+        else if (px == 32) hipExtLaunchKernelGGL((lookup_tiled_kernel<true, 32>), gt, dim3(256), 0, st, nullptr, done_ev, 0, a);
+        else hipExtLaunchKernelGGL((lookup_tiled_kernel<true, 64>), gt, dim3(256), 0, st, nullptr, done_ev, 0, a);
+    } else {
+        if (px == 16) hipExtLaunchKernelGGL((lookup_tiled_kernel<false, 16>), gt, dim3(256), 0, st, nullptr, done_ev, 0, a);
+        else if (px == 32) hipExtLaunchKernelGGL((lookup_tiled_kernel<false, 32>), gt, dim3(256), 0, st, nullptr, done_ev, 0, a);
+        else hipExtLaunchKernelGGL((lookup_tiled_kernel<false, 64>), gt, dim3(256), 0, st, nullptr, done_ev, 0, a);
+    }
     EEM_HIP_CHECK(hipGetLastError());
     return EEM_OK;
 }

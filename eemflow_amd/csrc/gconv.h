@@ -44,7 +44,7 @@ struct GConvArgs {
     const float* e1; int e1_ctotal, e1_coff;
     float out_scale;       // final multiplier (1 = none)
     int in_flight;         // frames the application keeps in flight on this GPU (0 / 1: one): tile choices favour CU time over latency
-    const float* wfew;     // packed by fewout_pack (layers of <= 8 couts, 3x3 stride 1, one input segment), or NULL
+    const float* wfew;     // packed by fewout_pack (layers of <= 8 couts, 3x3 stride 1, one input segment; its layout depends on cout <= 2), or NULL
     // grouped convolution as ONE launch of the LDS-tiled kernel (EEMFlow+'s decoder: three 32 -> 32 groups + channel shuffle, EEMFlow+.py:52-63);
     // 0 / 1 = none.  All fields above describe group 0; group g reads the channels g * seg[0].c of segment 0 onwards, takes its weights
     // g_wstride16 floats and its scale / shift g_pstride floats further on, and writes channel out_coff + g * g_ocoff + co * out_cmul

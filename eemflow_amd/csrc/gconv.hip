@@ -379,7 +379,8 @@ __global__ __launch_bounds__(FEW_WAVES * 64, (FEW_WAVES == 8 ? 8 : 4)) void fewo
         off[t] = ok ? yy * a.win + xx : p;
         keep[t] = ok;
     }
-    const float* w = a.wfew + (size_t)c0 * 72;
+    constexpr int WS = NCO <= 2 ? 2 : 8;                            // floats per (channel, tap) of the packing (fewout_pack)
+    const float* w = a.wfew + (size_t)c0 * 9 * WS;
     // two register sets, the next group's taps (CA channels x 9) in flight under this group's FMAs (requests past the last channel
     // repeat it; their products are skipped)
     float va[CA][9], vb[CA][9];
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(FEW_WAVES * 64, (FEW_WAVES == 8 ? 8 : 4)) void fewo
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const float vv = keep[t] ? v[q][t] : 0.f;
-                const f32x2* w8 = reinterpret_cast<const f32x2*>(w + ((size_t)(c + q - c0) * 9 + t) * 8);
+                const f32x2* w8 = reinterpret_cast<const f32x2*>(w + ((size_t)(c + q - c0) * 9 + t) * WS);
                 const f32x2 v2 = {vv, vv};
 #pragma unroll
                 for (int k = 0; k < NP; ++k) acc2[k] = __builtin_elementwise_fma(v2, w8[k], acc2[k]);
@@ -438,16 +439,108 @@ __global__ __launch_bounds__(FEW_WAVES * 64, (FEW_WAVES == 8 ? 8 : 4)) void fewo
     if (a.epi == GEPI_SUM2) a.out2[((size_t)n * a.out2_ctotal + co) * hw + p] = a.e0[((size_t)n * a.e0_ctotal + a.e0_coff + co) * hw + p] + r;
 }
 
+
+// The same conv for launches of less than a wave per SIMD (E-RAFT's flow head 256 -> 2 at 60x80: 75 blocks of the form above, a wave's time =
+// its eight request round trips to a map the previous launch left in the Infinity Cache).  Block = 32 consecutive pixels x 32 channel
+// groups: the two halves of a wave take different groups of the same 32 pixels, a lane holds ALL taps of its group's <= 8 channels in
+// registers - one round trip - and 150 blocks share the vector-memory path of twice as many CUs.  The layer's weights ([cin][tap][2],
+// 18 KB at 256 channels) are staged in LDS under that round trip and a lane reads its half's pair per (channel, tap) as one 8-byte LDS
+// read: the first version selected between two uniform (scalar-register) pairs per lane and spent 1 190 vector instructions per wave on
+// 145 FMAs - moves out of scalar registers and selects - which is what its 13.7 us were (the 64-pixel form: 13.6).  Summation order
+// differs from the form above (32 partial sums of 8 channels instead of 16 of 16): equal within rounding, not bitwise.
+template <int NCO>
+__global__ __launch_bounds__(1024) void fewout_wide_kernel(GConvArgs a, int cpl) {
+    static_assert(NCO == 2, "the [cin][tap][2] packing");
+    constexpr int CPL = 8;
+    __shared__ f32x2 wl[32 * CPL * 9];                            // [channel][tap] pairs; channels past the layer's last: zeros
+    __shared__ float part[32][NCO][32];
+    const int hw = a.hin * a.win;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sub = lane >> 5, px = lane & 31;
+    const long total = (long)a.n * hw;
+    const long idx = (long)blockIdx.x * 32 + px;
+    const long idc = idx < total ? idx : total - 1;
+    const int p = idc % hw, n = idc / hw;
+    const int y = p / a.win, x = p - y * a.win;
+    const GConvSeg& sg = a.seg[0];
+    // the weights' requests first: their data is back before the taps' (requests return in order)
+    const int npair = sg.c * 9;
+    f32x2 wreg[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int e = tid + 1024 * k;
+        wreg[k] = e < npair ? reinterpret_cast<const f32x2*>(a.wfew)[e] : f32x2{0.f, 0.f};
+    }
+    const int c0 = (2 * g + sub) * cpl;
+    const float* in = sg.ptr + ((size_t)n * sg.ctotal + sg.coff) * hw;
+    int off[9];
+    bool keep[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        const bool ok = yy >= 0 && yy < a.hin && xx >= 0 && xx < a.win;
+        off[t] = ok ? yy * a.win + xx : p;
+        keep[t] = ok;
+    }
+    float v[CPL][9];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        const float* plane = in + (size_t)min(c0 + q, sg.c - 1) * hw;     // (requests past the layer's last channel meet zero weights)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) v[q][t] = plane[off[t]];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (tid + 1024 * k < 32 * CPL * 9) wl[tid + 1024 * k] = wreg[k];
+    __syncthreads();
+    f32x2 acc = {0.f, 0.f};
+    const f32x2* wc = wl + c0 * 9;
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        if (q >= cpl) break;                                       // (uniform: channels c0 + cpl .. are the next group's)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float vv = keep[t] ? v[q][t] : 0.f;
+            acc = __builtin_elementwise_fma(f32x2{vv, vv}, wc[q * 9 + t], acc);
+        }
+    }
+    part[2 * g + sub][0][px] = acc[0];
+    part[2 * g + sub][1][px] = acc[1];
+    __syncthreads();
+    const int co = tid >> 5;
+    const long oidx = (long)blockIdx.x * 32 + (tid & 31);
+    if (co >= NCO || co >= a.cout || oidx >= total) return;
+    const int op = oidx % hw, on = oidx / hw;
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) r += part[k][co][tid & 31];
+    if (a.scale) r *= a.scale[co];
+    if (a.shift) r += a.shift[co];
+    if (a.act == GACT_RELU) r = r > 0.f ? r : 0.f;
+    else if (a.act == GACT_LEAKY) r = r > 0.f ? r : 0.1f * r;
+    else if (a.act == GACT_SIGMOID) r = 1.f / (1.f + expf(-r));
+    else if (a.act == GACT_TANH) r = tanhf(r);
+    if (a.epi == GEPI_ADD) r += a.e0[((size_t)on * a.e0_ctotal + a.e0_coff + co) * hw + op];
+    const int oc = a.out_coff + co * (a.out_cmul > 1 ? a.out_cmul : 1);
+    r *= a.out_scale;
+    a.out[((size_t)on * a.out_ctotal + oc) * hw + op] = r;
+    if (a.epi == GEPI_SUM2) a.out2[((size_t)on * a.out2_ctotal + co) * hw + op] = a.e0[((size_t)on * a.e0_ctotal + a.e0_coff + co) * hw + op] + r;
+}
+
 }  // namespace
 
 size_t fewout_packed_floats(int cin, int kh, int kw) { return (size_t)cin * kh * kw * 8; }
 
+// [cin][tap][8]; layers of at most two couts: [cin][tap][2] in the first quarter of the same allocation - a channel's 18 floats are
+// consecutive, so the wide form's uniform loads are two wide scalar loads per channel instead of nine 8-byte ones
 void fewout_pack(const float* w, int cout, int cin, int kh, int kw, float* packed) {
-    const int taps = kh * kw;
+    const int taps = kh * kw, ws = cout <= 2 ? 2 : 8;
     for (int c = 0; c < cin; ++c)
         for (int t = 0; t < taps; ++t)
-            for (int co = 0; co < 8; ++co)
-                packed[((size_t)c * taps + t) * 8 + co] = co < cout ? w[((size_t)co * cin + c) * taps + t] : 0.f;
+            for (int co = 0; co < ws; ++co)
+                packed[((size_t)c * taps + t) * ws + co] = co < cout ? w[((size_t)co * cin + c) * taps + t] : 0.f;
 }
 
 bool fewout_supported(const GConvArgs& a) {
@@ -467,7 +560,11 @@ int fewout_launch(const GConvArgs& a, hipStream_t stream) {
     static const long small_blocks = [] { const char* e = getenv("EEM_FEWOUT_SMALL_BLOCKS"); return e ? atol(e) : 512L; }();
     const bool small = (blocks * 8 < 1024 || (a.cout > 2 && (long)blocks < small_blocks)) && a.seg[0].c >= 64;
     if (a.cout <= 2) {                                                // E-RAFT's flow head
-        if (small) hipLaunchKernelGGL((fewout_kernel<16, 2, 2>), dim3(blocks), dim3(1024), 0, stream, a, (a.seg[0].c + 15) / 16);
+        // EEM_FEWOUT_WIDE=0 (read per call: the equality test flips it): the 64-pixel form for the small launches too
+        const char* ew = getenv("EEM_FEWOUT_WIDE");
+        if (small && a.seg[0].c <= 256 && !(ew && ew[0] == '0')) {
+            hipLaunchKernelGGL((fewout_wide_kernel<2>), dim3((unsigned)((n + 31) / 32)), dim3(1024), 0, stream, a, (a.seg[0].c + 31) / 32);
+        } else if (small) hipLaunchKernelGGL((fewout_kernel<16, 2, 2>), dim3(blocks), dim3(1024), 0, stream, a, (a.seg[0].c + 15) / 16);
         else hipLaunchKernelGGL((fewout_kernel<8, 1, 2>), dim3(blocks), dim3(512), 0, stream, a, (a.seg[0].c + 7) / 8);
     } else if (a.cout <= 4 && !small) {                               // EEMFlow+'s mask estimator tail 184 -> 3 (cdc_utils.py:151)
         hipLaunchKernelGGL((fewout_kernel<8, 1, 4>), dim3(blocks), dim3(512), 0, stream, a, (a.seg[0].c + 7) / 8);

@@ -893,13 +893,7 @@ extern "C" int eemop_corr_pyramid_fwd(const float* fmap1, const float* fmap2, in
     const long planes = (long)batch * h * w;
     int rc = er_allpairs_launch(fmap1, fmap2, pyr0, batch, c, h * w, st);
     if (rc != EEM_OK) return rc;
-    float* lv[4] = {pyr0, pyr1, pyr2, pyr3};
-    int ph = h, pw = w;
-    for (int l = 1; l < 4; ++l) {
-        if ((rc = er_pool2_launch(lv[l - 1], lv[l], planes, ph, pw, st)) != EEM_OK) return rc;
-        ph /= 2; pw /= 2;
-    }
-    return EEM_OK;
+    return er_pool2x3_launch(pyr0, pyr1, pyr2, pyr3, planes, h, w, st);
 }
 
 // CorrBlock.__call__ on caller tensors (model/corr.py:29-50): out [batch][324][h][w]

@@ -73,6 +73,7 @@ struct eemplus_ctx {
     // encoder's scratch), so that what a level computes from the feature pyramid alone - the two 1x1 projections and rconv, level_units -
     // CAN run on a side stream beside the coarser levels' chain (EEM_PLUS_SIDE=1; measured slower, see plus_forward_impl)
     PBuf dense_l[7], a2_l[7], cat_l[7];
+    size_t cat6_key = 0;                 // (batch, map size) for which cat_l[6]'s two flow channels hold zeros (plus_forward_impl, level 6)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_lvl[7] = {};
     int B = 0, hl[7] = {0}, wl[7] = {0};
@@ -651,8 +652,8 @@ static int plus_forward_impl(eemplus_ctx* c, const float* e1, const float* e2, c
             }
         }
     }
-    for (int l = 4; l <= 6; ++l)                                                       // avg_pool2d(2,2) x3 (:170-175)
-        if ((rc = er_pool2_launch(c->f[l - 1].p, c->f[l].p, (long)n2 * 64, hl[l - 1], wl[l - 1], st)) != EEM_OK) return rc;
+    // avg_pool2d(2,2) x3 (:170-175), one launch
+    if ((rc = er_pool2x3_launch(c->f[3].p, c->f[4].p, c->f[5].p, c->f[6].p, (long)n2 * 64, hl[3], wl[3], st)) != EEM_OK) return rc;
 
     auto f1 = [&](int l) { return c->f[l].p; };
     auto f2 = [&](int l) { return c->f[l].p + (size_t)B * C[l] * hl[l] * wl[l]; };
@@ -684,7 +685,13 @@ static int plus_forward_impl(eemplus_ctx* c, const float* e1, const float* e2, c
         float* const cat = c->cat_l[6].p;
         CorrJob cj = {f1(6), f2(6), cat, 64, kCat};
         if ((rc = corr_launch(&cj, 1, B, h, w, c->taps, 53, st)) != EEM_OK) return rc;
-        if ((rc = pl_copy_channels_launch(nullptr, 0, 0, cat, kCat, 85, 2, B, (int)g, st)) != EEM_OK) return rc;
+        // level 6 has no coarser flow: its two flow channels of the decoder input are zeros (:179).  Nothing writes them at this level, so
+        // the fill is launched once per (batch, map size) - the buffer's layout - and not per forward (a re-allocated buffer comes zeroed)
+        const size_t key = ((size_t)B << 40) | g;
+        if (c->cat6_key != key) {
+            if ((rc = pl_copy_channels_launch(nullptr, 0, 0, cat, kCat, 85, 2, B, (int)g, st)) != EEM_OK) return rc;
+            c->cat6_key = key;
+        }
         if (side) EEM_HIP_CHECK(hipStreamWaitEvent(st, c->ev_lvl[6], 0));
         else if ((rc = level_units(c, 6, B, st)) != EEM_OK) return rc;
         if ((rc = run_decoder(c, 6, B, h, w, nullptr, st)) != EEM_OK) return rc;

@@ -447,6 +447,41 @@ def test_all_pairs_volume_through_lds_equals_the_l2_form(monkeypatch, b, h, w):
     assert torch.equal(lds, l2) and float(l2.abs().max()) > 1e-3
 
 
+@pytest.mark.parametrize("b,h,w", [(1, 480, 640), (1, 200, 296), (3, 256, 320)])
+def test_lookup_blocks_of_16_pixels_and_the_one_launch_pyramid_equal_the_round5_forms(monkeypatch, b, h, w):
+    """Two launch shapes of `CorrBlock` (model/corr.py:24-50) that compute the same values: the lookup with 16 or 32 pixels per block
+    instead of 64 (EEM_LOOKUP_PX, read per call; the default below 1 024 blocks of 64), and levels 1 .. 3 of the pyramid from one launch
+    that reads level 0 once (EEM_POOL_CHAIN=1: three avg_pool2d launches).  Same samples, same expressions: the twelve predictions bit
+    for bit (25x37 cells: odd maps, a level-3 map of 3x4, a last band of one level-1 row)."""
+    net, _ = make_net(51)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(52, b, h, w))
+    with torch.no_grad():
+        now = torch.stack(net(e1, e2, iters=12)[1]).clone()
+        for px in ("16", "32", "64"):
+            monkeypatch.setenv("EEM_LOOKUP_PX", px)
+            assert torch.equal(torch.stack(net(e1, e2, iters=12)[1]), now), px
+        monkeypatch.setenv("EEM_POOL_CHAIN", "1")
+        old = torch.stack(net(e1, e2, iters=12)[1]).clone()
+    assert torch.equal(now, old) and float(old.abs().max()) > 1e-3
+
+
+def test_flow_head_on_32_pixel_blocks_equals_the_64_pixel_form(monkeypatch):
+    """The flow head's 256 -> 2 conv (model/update.py:6-13) at batch 1: blocks of 32 pixels x 32 channel groups with all of a lane's taps
+    in registers against 64 pixels x 16 groups of request rounds (EEM_FEWOUT_WIDE=0, read per call).  The same products, 32 partial sums
+    instead of 16: equal within rounding over twelve iterations, not bitwise."""
+    h, w = 480, 640
+    net, _ = make_net(53)
+    net.change_imagesize((h, w))
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(54, 1, h, w))
+    with torch.no_grad():
+        wide = torch.stack(net(e1, e2, iters=12)[1]).clone()
+        monkeypatch.setenv("EEM_FEWOUT_WIDE", "0")
+        old = torch.stack(net(e1, e2, iters=12)[1]).clone()
+    assert not torch.equal(wide, old)                                    # (the switch did switch)
+    assert maxerr(wide, old) < 2e-4 and float(old.abs().max()) > 1e-3
+
+
 def test_gru_context_part_computed_once_equals_the_full_convs(monkeypatch):
     """The GRU's convs read [h | inp | motion] (model/update.py:43-60) and `inp` does not change over the iterations: its part of
     every conv (+ the bias) is computed once per forward and enters the in-loop convs over [h | motion] as a per-pixel addend in front

@@ -283,6 +283,29 @@ def test_level_units_on_the_side_stream_equal_the_chain(monkeypatch):
     assert all(np.array_equal(chain, s_) for s_ in side) and np.abs(chain).max() > 1e-3
 
 
+@pytest.mark.parametrize("h,w", [(256, 320), (200, 296)])
+def test_one_launch_feature_levels_and_a_level6_fill_per_shape_equal_the_chain(monkeypatch, h, w):
+    """Feature levels 4 .. 6 (three avg_pool2d, EEMFlow+.py:170-175) from ONE launch that reads level 3 once (EEM_POOL_CHAIN=1, read per
+    call: three launches), and the zeros of level 6's two flow channels (:179) filled once per (batch, map size) instead of per forward -
+    checked by changing the shape in between (the buffer then holds another layout's values where the zeros have to be) and coming back:
+    the five predictions bit for bit."""
+    e1, e2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(101, 2, h, w, bins=5))
+    o1, o2 = (torch.from_numpy(a).to(DEV) for a in synthetic_voxel_pair(102, 1, 384, 512, bins=5))
+    net = make_net(103, 5)
+    net.change_imagesize((h, w))
+    with torch.no_grad():
+        first = torch.stack(net(e1, e2)[1]).cpu().numpy()
+        again = torch.stack(net(e1, e2)[1]).cpu().numpy()                    # (no fill this time)
+        net.change_imagesize((384, 512))
+        other = torch.stack(net(o1, o2)[1]).cpu().numpy()
+        net.change_imagesize((h, w))
+        back = torch.stack(net(e1, e2)[1]).cpu().numpy()
+        monkeypatch.setenv("EEM_POOL_CHAIN", "1")
+        chain = torch.stack(net(e1, e2)[1]).cpu().numpy()
+    assert np.array_equal(first, again) and np.array_equal(first, back) and np.array_equal(first, chain)
+    assert np.abs(first).max() > 1e-3 and np.abs(other).max() > 1e-3
+
+
 @pytest.mark.parametrize("n,h,w", [(3, 256, 320), (2, 100, 150), (1, 128, 192)])
 def test_forward_many_equals_the_batched_forward(n, h, w):
     """EEMFlow_cdc.forward_many (eemplus_forward_many): n independent batch-1 samples in their own tensors through one batch-n chain -

@@ -678,44 +678,56 @@ static int eraft_forward_impl(eraft_ctx* c, const float* e1, const float* e2, co
     }
     float* cfeat = nullptr;
     if ((rc = fork()) != EEM_OK) return rc;                            // (the padded volumes are on their way)
-    // ---- context network on image1 (:126-131): net = tanh(first half), inp = relu(second half)
-    if ((rc = run_encoder(c, c->cnet, pad1, B, cin0, hp, wp, &cfeat, sd, overlap ? c->s2 : nullptr)) != EEM_OK) return rc;
-    {
-        GConvArgs a = conv_args(c, c->cnet.conv2a, B, h8, w8, c->net[0].p, 128, 0, GACT_TANH);
-        set_seg(a, 0, cfeat, 128, 128, 0);
-        if ((rc = gconv_launch(a, sd)) != EEM_OK) return rc;
-        GConvArgs b2 = conv_args(c, c->cnet.conv2b, B, h8, w8, c->inp.p, 128, 0, GACT_RELU);
-        set_seg(b2, 0, cfeat, 128, 128, 0);
-        if ((rc = gconv_launch(b2, sd)) != EEM_OK) return rc;
-    }
-    if ((rc = er_coords_init_launch(c->c0.p, c->c1.p, flow_init, B, h8, w8, sd)) != EEM_OK) return rc;
-    // the context features' part of the GRU convs, once per forward (see eraft_ctx)
+    // (the feature network's launches are enqueued FIRST: it is the longer chain - two images, instance norms - and the host needs ~0.3 ms
+    // to enqueue either network's ~45 launches; a forward that starts on an idle GPU - the first of a timed region, every forward of a loop
+    // that reads each result - had the chip run the context network alone for that long before the feature network's first kernel arrived)
     const char* enp = getenv("EEM_ERAFT_NO_PRE");
     const char* ens0 = getenv("EEM_ERAFT_NO_STACK");
     const bool use_pre = !(enp && enp[0] == '1') && !(ens0 && ens0[0] == '1');
-    if (use_pre) {
-        for (int pass = 0; pass < 2; ++pass) {
-            GConvArgs a = conv_args(c, c->gzr_c[pass], B, h8, w8, c->czr[pass].p, 256, 0, GACT_NONE);
-            set_seg(a, 0, c->inp.p, 128, 128, 0);
-            if ((rc = gconv_launch(a, sd)) != EEM_OK) return rc;
-            a = conv_args(c, c->gq_c[pass], B, h8, w8, c->cq[pass].p, 128, 0, GACT_NONE);
-            set_seg(a, 0, c->inp.p, 128, 128, 0);
-            if ((rc = gconv_launch(a, sd)) != EEM_OK) return rc;
+    auto run_fnet = [&]() -> int {
+        // ---- feature network on [image1; image2] (:116), then its 1x1 output conv
+        float* feat = nullptr;
+        if ((rc = run_encoder(c, c->fnet, c->padded.p, 2 * B, cin0, hp, wp, &feat, st)) != EEM_OK) return rc;
+        {
+            GConvArgs a = conv_args(c, c->fnet.conv2a, 2 * B, h8, w8, c->fmap.p, 256, 0, GACT_NONE);
+            set_seg(a, 0, feat, 128, 128, 0);
+            if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
         }
-    }
-
-    // ---- feature network on [image1; image2] (:116), then its 1x1 output conv
-    float* feat = nullptr;
-    if ((rc = run_encoder(c, c->fnet, c->padded.p, 2 * B, cin0, hp, wp, &feat, st)) != EEM_OK) return rc;
-    {
-        GConvArgs a = conv_args(c, c->fnet.conv2a, 2 * B, h8, w8, c->fmap.p, 256, 0, GACT_NONE);
-        set_seg(a, 0, feat, 128, 128, 0);
-        if ((rc = gconv_launch(a, st)) != EEM_OK) return rc;
-    }
-    // ---- all-pairs correlation pyramid (:121)
-    if (c->alt_corr) rc = build_feature_pyramid(c, c->fmap.p + (size_t)B * 256 * g, B, 256, h8, w8, st);
-    else rc = build_pyramid(c, c->fmap.p, c->fmap.p + (size_t)B * 256 * g, B, 256, h8, w8, st);
-    if (rc != EEM_OK) return rc;
+        // ---- all-pairs correlation pyramid (:121)
+        if (c->alt_corr) rc = build_feature_pyramid(c, c->fmap.p + (size_t)B * 256 * g, B, 256, h8, w8, st);
+        else rc = build_pyramid(c, c->fmap.p, c->fmap.p + (size_t)B * 256 * g, B, 256, h8, w8, st);
+        if (rc != EEM_OK) return rc;
+        return EEM_OK;
+    };
+    auto run_cnet = [&]() -> int {
+        // ---- context network on image1 (:126-131): net = tanh(first half), inp = relu(second half)
+        if ((rc = run_encoder(c, c->cnet, pad1, B, cin0, hp, wp, &cfeat, sd, overlap ? c->s2 : nullptr)) != EEM_OK) return rc;
+        {
+            GConvArgs a = conv_args(c, c->cnet.conv2a, B, h8, w8, c->net[0].p, 128, 0, GACT_TANH);
+            set_seg(a, 0, cfeat, 128, 128, 0);
+            if ((rc = gconv_launch(a, sd)) != EEM_OK) return rc;
+            GConvArgs b2 = conv_args(c, c->cnet.conv2b, B, h8, w8, c->inp.p, 128, 0, GACT_RELU);
+            set_seg(b2, 0, cfeat, 128, 128, 0);
+            if ((rc = gconv_launch(b2, sd)) != EEM_OK) return rc;
+        }
+        if ((rc = er_coords_init_launch(c->c0.p, c->c1.p, flow_init, B, h8, w8, sd)) != EEM_OK) return rc;
+        // the context features' part of the GRU convs, once per forward (see eraft_ctx)
+        if (use_pre) {
+            for (int pass = 0; pass < 2; ++pass) {
+                GConvArgs a = conv_args(c, c->gzr_c[pass], B, h8, w8, c->czr[pass].p, 256, 0, GACT_NONE);
+                set_seg(a, 0, c->inp.p, 128, 128, 0);
+                if ((rc = gconv_launch(a, sd)) != EEM_OK) return rc;
+                a = conv_args(c, c->gq_c[pass], B, h8, w8, c->cq[pass].p, 128, 0, GACT_NONE);
+                set_seg(a, 0, c->inp.p, 128, 128, 0);
+                if ((rc = gconv_launch(a, sd)) != EEM_OK) return rc;
+            }
+        }
+        return EEM_OK;
+    };
+    // EEM_ERAFT_CNET_FIRST=1 (read per forward): the order through round 6's first half
+    const char* ecf = getenv("EEM_ERAFT_CNET_FIRST");
+    if (ecf && ecf[0] == '1') { if ((rc = run_cnet()) != EEM_OK || (rc = run_fnet()) != EEM_OK) return rc; }
+    else if ((rc = run_fnet()) != EEM_OK || (rc = run_cnet()) != EEM_OK) return rc;
     if ((rc = join()) != EEM_OK) return rc;                            // net, inp, the context parts of the GRU convs, coords
     // final_only: the predictions of iterations 0 .. iters - 2 are never formed - their mask head (the 3x3 128 -> 256 and 1x1 256 -> 576
     // convs) and convex upsampling are not launched; the hidden state and coords1 go through the same launches with the same operands,
@@ -775,6 +787,11 @@ static int eraft_forward_impl(eraft_ctx* c, const float* e1, const float* e2, co
         // motion encoder (model/update.py:73-81): the flow branch convf1 -> convf2 on the side stream beside the correlation branch
         // the 324 correlation features live in a 336-channel buffer (12 zero channels, zero weight columns) so that the
         // 1x1 conv qualifies for the 16-aligned LDS-tiled kernel; the generic kernel reads the first 324
+        // (measured and dropped: the correlation branch convc1 -> convc2 on the SIDE stream and the shorter flow branch on the chain's, so
+        // that both waits sit at the head of a queue that has been idle for a while and the kernels with completion signals - lookup,
+        // convc2 through hipExtLaunchKernelGGL - have nothing critical behind them on their own stream: 200 against 213 frames/s at batch 1,
+        // 299 against 311 at batch 4.  A kernel on another stream starts ~10 us after the signal it waits for; the next kernel on the
+        // signalling kernel's own stream ~5 us late)
         if (fork_by_launch) {                                          // (the lookup wrote the flow channels of `motion`)
             EEM_HIP_CHECK(hipStreamWaitEvent(sd, c->fork_ev, 0));
             guard.forked = true;

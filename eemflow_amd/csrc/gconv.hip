@@ -444,15 +444,19 @@ __global__ __launch_bounds__(FEW_WAVES * 64, (FEW_WAVES == 8 ? 8 : 4)) void fewo
 // its eight request round trips to a map the previous launch left in the Infinity Cache).  Block = 32 consecutive pixels x 32 channel
 // groups: the two halves of a wave take different groups of the same 32 pixels, a lane holds ALL taps of its group's <= 8 channels in
 // registers - one round trip - and 150 blocks share the vector-memory path of twice as many CUs.  The layer's weights ([cin][tap][2],
-// 18 KB at 256 channels) are staged in LDS under that round trip and a lane reads its half's pair per (channel, tap) as one 8-byte LDS
+// 18 KB at 256 channels; [cin][tap][8] for the layers of 3 .. 8 couts) are staged in LDS under that round trip and a lane reads its half's pair per (channel, tap) as one 8-byte LDS
 // read: the first version selected between two uniform (scalar-register) pairs per lane and spent 1 190 vector instructions per wave on
 // 145 FMAs - moves out of scalar registers and selects - which is what its 13.7 us were (the 64-pixel form: 13.6).  Summation order
-// differs from the form above (32 partial sums of 8 channels instead of 16 of 16): equal within rounding, not bitwise.
+// differs from the form above (32 partial sums of 8 channels instead of 16 of 16): equal within rounding, not bitwise.  The template
+// also builds for 4 and 8 couts (weights [cin][tap][8]); EEMFlow+'s mask estimator tail at 90 x 160 (176 -> 8, 184 -> 3: 450 such blocks,
+// two rounds) measured 22.4 and 18.8 us on it against 18.4 and 18.0 on the 64-pixel form, so only the two-cout layers are sent here.
 template <int NCO>
 __global__ __launch_bounds__(1024) void fewout_wide_kernel(GConvArgs a, int cpl) {
-    static_assert(NCO == 2, "the [cin][tap][2] packing");
     constexpr int CPL = 8;
-    __shared__ f32x2 wl[32 * CPL * 9];                            // [channel][tap] pairs; channels past the layer's last: zeros
+    constexpr int WS = NCO <= 2 ? 2 : 8;                          // floats per (channel, tap) of the packing (fewout_pack)
+    constexpr int NP = (NCO + 1) / 2;
+    constexpr int WPAIRS = 32 * CPL * 9 * WS / 2, WIT = (WPAIRS + 1023) / 1024;
+    __shared__ f32x2 wl[WPAIRS];                                  // [channel][tap][WS / 2] pairs; channels past the layer's last: zeros
     __shared__ float part[32][NCO][32];
     const int hw = a.hin * a.win;
     const int tid = threadIdx.x;
@@ -466,10 +470,10 @@ __global__ __launch_bounds__(1024) void fewout_wide_kernel(GConvArgs a, int cpl)
     const int y = p / a.win, x = p - y * a.win;
     const GConvSeg& sg = a.seg[0];
     // the weights' requests first: their data is back before the taps' (requests return in order)
-    const int npair = sg.c * 9;
-    f32x2 wreg[3];
+    const int npair = sg.c * 9 * WS / 2;
+    f32x2 wreg[WIT];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < WIT; ++k) {
         const int e = tid + 1024 * k;
         wreg[k] = e < npair ? reinterpret_cast<const f32x2*>(a.wfew)[e] : f32x2{0.f, 0.f};
     }
@@ -492,22 +496,25 @@ __global__ __launch_bounds__(1024) void fewout_wide_kernel(GConvArgs a, int cpl)
         for (int t = 0; t < 9; ++t) v[q][t] = plane[off[t]];
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-        if (tid + 1024 * k < 32 * CPL * 9) wl[tid + 1024 * k] = wreg[k];
+    for (int k = 0; k < WIT; ++k)
+        if (tid + 1024 * k < WPAIRS) wl[tid + 1024 * k] = wreg[k];
     __syncthreads();
-    f32x2 acc = {0.f, 0.f};
-    const f32x2* wc = wl + c0 * 9;
+    f32x2 acc[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) acc[k] = f32x2{0.f, 0.f};
+    const f32x2* wc = wl + c0 * 9 * (WS / 2);
 #pragma unroll
     for (int q = 0; q < CPL; ++q) {
         if (q >= cpl) break;                                       // (uniform: channels c0 + cpl .. are the next group's)
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const float vv = keep[t] ? v[q][t] : 0.f;
-            acc = __builtin_elementwise_fma(f32x2{vv, vv}, wc[q * 9 + t], acc);
+#pragma unroll
+            for (int k = 0; k < NP; ++k) acc[k] = __builtin_elementwise_fma(f32x2{vv, vv}, wc[(q * 9 + t) * (WS / 2) + k], acc[k]);
         }
     }
-    part[2 * g + sub][0][px] = acc[0];
-    part[2 * g + sub][1][px] = acc[1];
+#pragma unroll
+    for (int co = 0; co < NCO; ++co) part[2 * g + sub][co][px] = acc[co >> 1][co & 1];
     __syncthreads();
     const int co = tid >> 5;
     const long oidx = (long)blockIdx.x * 32 + (tid & 31);

@@ -87,7 +87,8 @@ def test_bwd_ops_reject_cpu_tensors():
         ops_bwd.warp_bwd(torch.zeros(1, 1, 4, 4), torch.zeros(1, 2, 4, 4), torch.zeros(1, 1, 4, 4), 0)
 
 
-@pytest.mark.parametrize("cin,cout,h,w,b", [(176, 8, 72, 96, 1), (184, 3, 90, 160, 2), (32, 2, 64, 65, 1), (256, 2, 60, 80, 1), (67, 5, 65, 70, 1)])
+@pytest.mark.parametrize("cin,cout,h,w,b", [(176, 8, 72, 96, 1), (184, 3, 90, 160, 2), (32, 2, 64, 65, 1), (256, 2, 60, 80, 1), (67, 5, 65, 70, 1),
+                                           (100, 2, 30, 41, 2), (200, 1, 33, 47, 1), (64, 2, 20, 20, 3)])   # (the last three: the 32-pixel form, ragged)
 def test_few_output_conv_vs_torch_and_generic_kernel(monkeypatch, cin, cout, h, w, b):
     """Layers of <= 8 output channels at >= 4096 pixels (EEMFlow+'s mask estimator tail, model/cdc_model.py dense blocks) run as a
     direct convolution on the vector pipe (gconv.h: fewout_*); EEM_NO_FEWOUT=1 (read per call) keeps them on the matrix-core kernel."""

@@ -73,6 +73,7 @@ extern "C" void eemflow_destroy(eemflow_ctx* c) {
     for (hipEvent_t e : c->span_ev) if (e) (void)hipEventDestroy(e);
     if (c->arena) (void)hipFree(c->arena);
     if (c->wino) (void)hipFree(c->wino);
+    if (c->dec_wnc) (void)hipFree(c->dec_wnc);
     if (c->flat) (void)hipFree(c->flat);
     if (c->pack_idx) (void)hipFree(c->pack_idx);
     if (c->taps) (void)hipFree(c->taps);
@@ -251,6 +252,19 @@ extern "C" int eemflow_load_weights(eemflow_ctx* c, const float* flat, size_t nf
         c->wino = nullptr;
         EEM_HIP_CHECK(hipMalloc(&c->wino, off * sizeof(float)));
         if ((rc = refresh_wino(c, nullptr)) != EEM_OK) return rc;
+    }
+    {   // the decoders' conv1 / conv5 streams for the Winograd kernel of conv_wnc.hip (ensure_dec_wnc fills them)
+        size_t off = 0;
+        for (int k = 0; k < 3; ++k) {
+            for (int s = 0; s < 4; ++s) { c->dec_w1[k][s] = off; off += wnc_packed_floats(kDecIn, 0); }
+            for (int s = 0; s < 2; ++s) { c->dec_w5[k][s] = off; off += wnc_packed_floats(kDecW, 0); }
+            c->dec_b1[k] = off; off += 128;
+            c->dec_b5[k] = off; off += 64;
+        }
+        if (c->dec_wnc) EEM_HIP_CHECK(hipFree(c->dec_wnc));
+        c->dec_wnc = nullptr;
+        EEM_HIP_CHECK(hipMalloc(&c->dec_wnc, off * sizeof(float)));
+        c->dec_wnc_ok = false;
     }
     EEM_HIP_CHECK(hipDeviceSynchronize());
     c->cin0 = n_first_channels;

@@ -11,6 +11,7 @@
 #include "common.h"
 #include "gconv.h"
 #include "eraft_kernels.h"
+#include "wnc.h"
 
 // ------------------------------------------------------------------------------- context
 namespace {
@@ -89,6 +90,11 @@ struct eemflow_ctx {
     }
     bool layer_f4(int cin, int batch) const { return (f4_mask(batch) >> (cin == 16 ? 0 : cin == 32 ? 1 : 2)) & 1; }
     float* zero_page = nullptr;
+    // the decoders' two wide 3x3 layers (conv1 69 -> 100, conv5 100 -> 64; EEMFlow.py:38-71) on the Winograd F(2x2) kernel of conv_wnc.hip:
+    // their streams and slice biases, made from `flat` on the device (ensure_dec_wnc) whenever the weights have changed there
+    float* dec_wnc = nullptr;
+    bool dec_wnc_ok = false;
+    size_t dec_w1[3][4] = {}, dec_w5[3][2] = {}, dec_b1[3] = {}, dec_b5[3] = {};      // float offsets into dec_wnc
     TailW rconv[3], dconv1[3], dgroup[3][3][5], dconv5[3], dconv6[3], dconv7[3], outc;
     // training: per-conv descriptors (flat offsets of weight/bias, packed transposed weights for gconv dgrad)
     struct ConvRef {
@@ -217,6 +223,7 @@ int refresh_wino(eemflow_ctx* c, hipStream_t) {
         for (int l = 0; l < ENC_NUM; ++l) c->wino_ok[f][l] = false;
     for (int l = 0; l < ENC_NUM; ++l) c->s2r_ok[l] = false;
     for (int l = 0; l < ENC_NUM; ++l) c->bx3_ok[l] = false;
+    c->dec_wnc_ok = false;
     return EEM_OK;
 }
 // The packed forms a launch can actually take (the opt-in kernels' switches are read per launch - conv_s2r.hip, conv_bx3.hip - and so are
@@ -261,6 +268,30 @@ int ensure_wino(eemflow_ctx* c, int l, int dir, int batch, hipStream_t st, const
     *f4_out = f4;
     return EEM_OK;
 }
+// The decoders' conv1 / conv5 on the Winograd kernel: wanted for grids whose rows are 16-byte multiples (1280x720: 12 x 20 cells; MVSEC's
+// 5 x 6 stays on the small-grid kernel).  A function of the shape alone - never of the batch: a sample's flow must not depend on how many
+// samples share its launch (tests/test_gpu_configs.py) - and the same in the training forward.  EEM_DEC_WNC=0 (read per call): off.
+inline bool dec_wnc_wanted(const eemflow_ctx* c, int gw) {
+    const char* e = getenv("EEM_DEC_WNC");
+    return c->dec_wnc != nullptr && gw % 4 == 0 && !(e && e[0] == '0');
+}
+int ensure_dec_wnc(eemflow_ctx* c, hipStream_t st) {
+    if (c->dec_wnc_ok || !c->dec_wnc) return EEM_OK;
+    WncPackArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int k = 0; k < 3; ++k) {
+        for (int s = 0; s < 4; ++s)
+            a.job[a.njobs++] = {c->flat + c->t_dconv1[k].w, c->flat + c->t_dconv1[k].b, c->dec_wnc + c->dec_w1[k][s], c->dec_wnc + c->dec_b1[k] + 32 * s,
+                                kDecW, kDecIn, 32 * s, 0};
+        for (int s = 0; s < 2; ++s)
+            a.job[a.njobs++] = {c->flat + c->t_dconv5[k].w, c->flat + c->t_dconv5[k].b, c->dec_wnc + c->dec_w5[k][s], c->dec_wnc + c->dec_b5[k] + 32 * s,
+                                64, kDecW, 32 * s, 0};
+    }
+    const int rc = wnc_pack_device_launch(a, st);
+    if (rc != EEM_OK) return rc;
+    c->dec_wnc_ok = true;
+    return EEM_OK;
+}
 // a training step's Winograd weights - forward and data-gradient forms of every F(4x4) layer - refreshed by ONE launch in front of its
 // forward (ensure_wino then finds them valid); the F(2x2) forms stay with ensure_wino
 int ensure_train_wino(eemflow_ctx* c, int batch, hipStream_t st) {
@@ -285,6 +316,7 @@ int ensure_train_wino(eemflow_ctx* c, int batch, hipStream_t st) {
 
 // before a graph capture / replay: the forward copies exist (a transform launched inside a capture would replay with every frame)
 int ensure_forward_wino(eemflow_ctx* c, int batch, hipStream_t st) {
+    { const int rcd = ensure_dec_wnc(c, st); if (rcd != EEM_OK) return rcd; }
     for (int l = 0; l < ENC_NUM; ++l) {
         const float* ws;
         if (c->enc_s2r[l] && s2r_wanted()) { const int rc = ensure_s2r(c, l, st, &ws); if (rc != EEM_OK) return rc; }
@@ -525,9 +557,48 @@ int run_decoders(eemflow_ctx* c, int k0, int k1, const float* const cat[3], int 
     TailConvLaunch L;
     L.batch = batch; L.h = h; L.w = w; L.ksize = 3;
     // conv1: 69 -> 100
-    L.njobs = 0;
-    for (int k = k0; k < k1; ++k) L.job[L.njobs++] = make_job(c, c->dconv1[k], cat[k], kDecIn, 0, c->ta[k].p, kDecW, 0, 1, 1);
-    if ((rc = run_tail(hk, "dec.conv1 69->100", L)) != EEM_OK) return rc;
+    // conv1 and conv5 on the Winograd kernel where the grid allows (dec_wnc_wanted): the decoders' 32-cout slices as the jobs of one launch
+    auto wide = [&](const char* name, int cin, int cout, const float* const* in, float* const* outp, const size_t (*woff)[4], const size_t (*woff5)[2],
+                    const size_t* boff, bool* done) -> int {
+        *done = false;
+        if (!dec_wnc_wanted(c, w)) return EEM_OK;
+        int r2 = ensure_dec_wnc(c, hk.st);
+        if (r2 != EEM_OK) return r2;
+        WncArgs wa;
+        memset(&wa, 0, sizeof(wa));
+        wa.nchunks = wnc_chunks(cin, wa.chunk_off);
+        wa.cin = cin; wa.n = batch; wa.h = h; wa.w = w; wa.act = 1; wa.m16 = 0;
+        wa.zero_page = c->zero_page; wa.trash = c->zero_page + 256;
+        const int ns = (cout + 31) / 32;
+        for (int k = k0; k < k1; ++k)
+            for (int s = 0; s < ns; ++s) {
+                if (wa.njobs == WNC_MAX_JOBS) return EEM_OK;           // (more decoders than a launch has jobs: the small-grid kernel)
+                WncJob& J = wa.job[wa.njobs++];
+                J.in = in[k]; J.in_ctotal = cin; J.in_coff = 0;
+                J.w = c->dec_wnc + (woff ? woff[k][s] : woff5[k][s]); J.bias = c->dec_wnc + boff[k] + 32 * s;
+                J.out = outp[k]; J.out_ctotal = cout; J.out_coff = 32 * s; J.out_cmul = 1; J.cout = cout - 32 * s < 32 ? cout - 32 * s : 32;
+                J.res = nullptr;
+            }
+        if (!wnc_supported(wa)) return EEM_OK;
+        const double px = (double)batch * h * w * (k1 - k0);
+        r2 = hk.run(name, 2.0 * px * cin * cout * 9, 4.0 * px * (cin + cout), [&](hipStream_t st) {
+            const int r3 = wnc_launch(wa, st);
+            eem_last_pipe = 3;
+            return r3;
+        });
+        *done = r2 == EEM_OK;
+        return r2;
+    };
+    bool on_wnc = false;
+    {
+        float* outs[3] = {c->ta[0].p, c->ta[1].p, c->ta[2].p};
+        if ((rc = wide("dec.conv1 69->100", kDecIn, kDecW, cat, outs, c->dec_w1, nullptr, c->dec_b1, &on_wnc)) != EEM_OK) return rc;
+    }
+    if (!on_wnc) {
+        L.njobs = 0;
+        for (int k = k0; k < k1; ++k) L.job[L.njobs++] = make_job(c, c->dconv1[k], cat[k], kDecIn, 0, c->ta[k].p, kDecW, 0, 1, 1);
+        if ((rc = run_tail(hk, "dec.conv1 69->100", L)) != EEM_OK) return rc;
+    }
     // conv2..4: grouped 100 -> 100, each followed by channel_shuffle (EEMFlow.py:51-57):
     // group g, in-group channel j lands in channel j*groups + g
     const int G = c->groups, per = kDecW / G;
@@ -546,9 +617,16 @@ int run_decoders(eemflow_ctx* c, int k0, int k1, const float* const cat[3], int 
         }
         if ((rc = run_tail(hk, gname[layer], L)) != EEM_OK) return rc;
     }
-    L.njobs = 0;
-    for (int k = k0; k < k1; ++k) L.job[L.njobs++] = make_job(c, c->dconv5[k], c->td[k].p, kDecW, 0, c->t64[k].p, 64, 0, 1, 1);
-    if ((rc = run_tail(hk, "dec.conv5 100->64", L)) != EEM_OK) return rc;
+    {
+        const float* ins[3] = {c->td[0].p, c->td[1].p, c->td[2].p};
+        float* outs[3] = {c->t64[0].p, c->t64[1].p, c->t64[2].p};
+        if ((rc = wide("dec.conv5 100->64", kDecW, 64, ins, outs, nullptr, c->dec_w5, c->dec_b5, &on_wnc)) != EEM_OK) return rc;
+    }
+    if (!on_wnc) {
+        L.njobs = 0;
+        for (int k = k0; k < k1; ++k) L.job[L.njobs++] = make_job(c, c->dconv5[k], c->td[k].p, kDecW, 0, c->t64[k].p, 64, 0, 1, 1);
+        if ((rc = run_tail(hk, "dec.conv5 100->64", L)) != EEM_OK) return rc;
+    }
     L.njobs = 0;
     for (int k = k0; k < k1; ++k) L.job[L.njobs++] = make_job(c, c->dconv6[k], c->t64[k].p, 64, 0, c->t32[k].p, 32, 0, 1, 1);
     if ((rc = run_tail(hk, "dec.conv6 64->32", L)) != EEM_OK) return rc;

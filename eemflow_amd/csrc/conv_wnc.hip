@@ -483,31 +483,60 @@ size_t wnc_packed_floats(int cin, int m16) {
     return (size_t)4 * 2 * nch * (m16 ? 4 : 8) * 64 * 4;
 }
 
-void wnc_pack(const float* w, int cout, int cin, int co0, int m16, float* packed) {
-    int off[WNC_MAX_CHUNKS + 2];
-    const int nch = wnc_chunks(cin, off);
+// four floats of the stream: quad q = ((xi * 2 nch + hf) * nw + s) * 64 + lane (host and device: wnc_pack, wnc_pack_kernel)
+__host__ __device__ static inline void wnc_pack_quad(const float* w, int cout, int cin, int co0, int m16, int q, float* o) {
+    const int nch = (cin + 31) / 32;
     const int rep = cin % 32 ? 32 - cin % 32 : 0;            // the last chunk's first `rep` channels repeat the chunk before it
     const int nw = m16 ? 4 : 8;                              // k-steps per half-chunk (of 4 / 2 channels)
-    for (int xi = 0; xi < 4; ++xi)
-        for (int hf = 0; hf < 2 * nch; ++hf)
-            for (int s = 0; s < nw; ++s)
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int k = hf >> 1;
-                    const int l = (hf & 1) * 16 + (m16 ? 4 * s + (lane >> 4) : 2 * s + (lane >> 5));
-                    const int co = co0 + (m16 ? (lane & 15) : (lane & 31)), ci = off[k] + l;
-                    float* o = packed + ((((size_t)xi * 2 * nch + hf) * nw + s) * 64 + lane) * 4;
-                    if (co >= cout || (k == nch - 1 && l < rep)) { o[0] = o[1] = o[2] = o[3] = 0.f; continue; }
-                    const float* g = w + ((size_t)co * cin + ci) * 9;
-                    float m[3];                              // row xi of G g
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const float g0 = g[kx], g1 = g[3 + kx], g2 = g[6 + kx];
-                        m[kx] = xi == 0 ? g0 : (xi == 1 ? 0.5f * (g0 + g1 + g2) : (xi == 2 ? 0.5f * (g0 - g1 + g2) : g2));
-                    }
-                    o[0] = m[0];
-                    o[1] = 0.5f * (m[0] + m[1] + m[2]);
-                    o[2] = 0.5f * (m[0] - m[1] + m[2]);
-                    o[3] = m[2];
-                }
+    const int lane = q & 63, s = (q >> 6) % nw, hf = (q >> 6) / nw % (2 * nch), xi = (q >> 6) / nw / (2 * nch);
+    const int k = hf >> 1;
+    const int l = (hf & 1) * 16 + (m16 ? 4 * s + (lane >> 4) : 2 * s + (lane >> 5));
+    const int co = co0 + (m16 ? (lane & 15) : (lane & 31));
+    const int ci = (k == nch - 1 && cin % 32 ? cin - 32 : 32 * k) + l;            // (wnc_chunks' offsets)
+    if (co >= cout || (k == nch - 1 && l < rep)) { o[0] = o[1] = o[2] = o[3] = 0.f; return; }
+    const float* g = w + ((size_t)co * cin + ci) * 9;
+    float m[3];                                              // row xi of G g
+    for (int kx = 0; kx < 3; ++kx) {
+        const float g0 = g[kx], g1 = g[3 + kx], g2 = g[6 + kx];
+        m[kx] = xi == 0 ? g0 : (xi == 1 ? 0.5f * (g0 + g1 + g2) : (xi == 2 ? 0.5f * (g0 - g1 + g2) : g2));
+    }
+    o[0] = m[0];
+    o[1] = 0.5f * (m[0] + m[1] + m[2]);
+    o[2] = 0.5f * (m[0] - m[1] + m[2]);
+    o[3] = m[2];
+}
+
+void wnc_pack(const float* w, int cout, int cin, int co0, int m16, float* packed) {
+    const int quads = 4 * 2 * ((cin + 31) / 32) * (m16 ? 4 : 8) * 64;
+    for (int q = 0; q < quads; ++q) wnc_pack_quad(w, cout, cin, co0, m16, q, packed + (size_t)q * 4);
+}
+
+namespace {
+__global__ __launch_bounds__(256) void wnc_pack_kernel(WncPackArgs a) {
+    const WncPackJob J = a.job[blockIdx.y];
+    const int quads = 4 * 2 * ((J.cin + 31) / 32) * (J.m16 ? 4 : 8) * 64;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x < (J.m16 ? 16 : 32) && J.bias_out)
+        J.bias_out[threadIdx.x] = J.co0 + (int)threadIdx.x < J.cout ? J.bias[J.co0 + threadIdx.x] : 0.f;
+    if (q >= quads) return;
+    float o[4];
+    wnc_pack_quad(J.w, J.cout, J.cin, J.co0, J.m16, q, o);
+    *reinterpret_cast<f32x4*>(J.packed + (size_t)q * 4) = f32x4{o[0], o[1], o[2], o[3]};
+}
+}  // namespace
+
+int wnc_pack_device_launch(const WncPackArgs& a, hipStream_t st) {
+    EEM_REQUIRE(a.njobs >= 1 && a.njobs <= WNC_PACK_MAX_JOBS, "wnc_pack_device_launch: njobs = %d", a.njobs);
+    int maxq = 0;
+    for (int j = 0; j < a.njobs; ++j) {
+        const WncPackJob& J = a.job[j];
+        EEM_REQUIRE(J.w && J.packed && J.cin >= 32 && J.cin <= 32 * WNC_MAX_CHUNKS && !((uintptr_t)J.packed & 15), "wnc_pack_device_launch: job %d", j);
+        const int quads = 4 * 2 * ((J.cin + 31) / 32) * (J.m16 ? 4 : 8) * 64;
+        maxq = quads > maxq ? quads : maxq;
+    }
+    hipLaunchKernelGGL(wnc_pack_kernel, dim3((maxq + 255) / 256, a.njobs), dim3(256), 0, st, a);
+    EEM_HIP_CHECK(hipGetLastError());
+    return EEM_OK;
 }
 
 bool wnc_supported(const WncArgs& a) {

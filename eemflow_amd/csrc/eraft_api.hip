@@ -158,7 +158,7 @@ void make_layer(Packer& pk, Layer& L, const float* w, const float* bias, int cou
     // (and, round 6, the motion encoder's convc2 256 -> 192, convf2 128 -> 64 and conv 256 -> 126, model/update.py:66-81: any single-tensor
     // 3x3 layer of 32 .. 256 input channels and up to 256 couts qualifies; which of them take the kernel is the call sites' choice)
     L.has_wnc = nseg == 1 && co0 == 0 && kh == 3 && kw == 3 && stride == 1 && ph == 1 && pw == 1 && cin >= 32 && cin <= 32 * WNC_MAX_CHUNKS &&
-                con >= 32 && con <= 32 * WNC_MAX_JOBS && !(cin == 64 && con == 64);
+                con >= 32 && con <= 256 && !(cin == 64 && con == 64);      // (wwnc[8]: up to eight 32-cout slices)
     if (L.has_wnc) {
         std::vector<float> wsc((size_t)con * cin * 9);
         for (int co = 0; co < con; ++co) {

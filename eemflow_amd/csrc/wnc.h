@@ -2,7 +2,7 @@
 #pragma once
 #include "common.h"
 
-constexpr int WNC_MAX_JOBS = 8;
+constexpr int WNC_MAX_JOBS = 12;     // (EEMFlow's decoder: 3 decoders x 4 slices of 100 couts in one launch)
 constexpr int WNC_MAX_CHUNKS = 8;
 
 // One job = 32 output channels (a group of a grouped conv, or a 32-channel slice of a wider layer) over the whole batch.
@@ -37,3 +37,21 @@ size_t wnc_packed_floats(int cin, int m16);
 void wnc_pack(const float* w, int cout, int cin, int co0, int m16, float* packed);
 bool wnc_supported(const WncArgs& a);
 int wnc_launch(const WncArgs& a, hipStream_t st);
+
+// The same packing on the device, for weights that change there (a training step, eemflow_update_weights): job j writes wnc_pack(w, cout,
+// cin, co0, m16)'s stream to `packed` - the very expression, shared with the host function - and the slice's 32 (m16: 16) biases, zero
+// beyond cout, to `bias_out`.  One launch for all jobs.
+constexpr int WNC_PACK_MAX_JOBS = 24;
+struct WncPackJob {
+    const float* w;        // [cout][cin][3][3]
+    const float* bias;     // [cout]
+    float* packed;
+    float* bias_out;
+    int cout, cin, co0, m16;
+};
+struct WncPackArgs {
+    WncPackJob job[WNC_PACK_MAX_JOBS];
+    int njobs;
+};
+int wnc_pack_device_launch(const WncPackArgs& a, hipStream_t st);
+

@@ -269,11 +269,14 @@ int ensure_wino(eemflow_ctx* c, int l, int dir, int batch, hipStream_t st, const
     return EEM_OK;
 }
 // The decoders' conv1 / conv5 on the Winograd kernel: wanted for grids whose rows are 16-byte multiples (1280x720: 12 x 20 cells; MVSEC's
-// 5 x 6 stays on the small-grid kernel).  A function of the shape alone - never of the batch: a sample's flow must not depend on how many
-// samples share its launch (tests/test_gpu_configs.py) - and the same in the training forward.  EEM_DEC_WNC=0 (read per call): off.
-inline bool dec_wnc_wanted(const eemflow_ctx* c, int gw) {
+// 5 x 6 stays on the small-grid kernel) from four samples per launch on - the rule of the encoder's F(4x4) forms (f4_mask): one frame alone
+// is three 20-us tiles per (decoder, slice) where the small-grid kernel needs 5 - 9 us (`latency_ms_b1` 0.192 -> 0.207 ms with the kernel
+// at every batch).  EEM_DEC_WNC (read per call): 0 off, 1 at every batch (tests that compare a batch with its shards pin the form), unset: by batch.
+// The training forward takes the same rule.
+inline bool dec_wnc_wanted(const eemflow_ctx* c, int gw, int batch) {
     const char* e = getenv("EEM_DEC_WNC");
-    return c->dec_wnc != nullptr && gw % 4 == 0 && !(e && e[0] == '0');
+    if (c->dec_wnc == nullptr || gw % 4 != 0 || (e && e[0] == '0')) return false;
+    return (e && e[0] == '1') || batch >= 4;
 }
 int ensure_dec_wnc(eemflow_ctx* c, hipStream_t st) {
     if (c->dec_wnc_ok || !c->dec_wnc) return EEM_OK;
@@ -561,7 +564,7 @@ int run_decoders(eemflow_ctx* c, int k0, int k1, const float* const cat[3], int 
     auto wide = [&](const char* name, int cin, int cout, const float* const* in, float* const* outp, const size_t (*woff)[4], const size_t (*woff5)[2],
                     const size_t* boff, bool* done) -> int {
         *done = false;
-        if (!dec_wnc_wanted(c, w)) return EEM_OK;
+        if (!dec_wnc_wanted(c, w, batch)) return EEM_OK;
         int r2 = ensure_dec_wnc(c, hk.st);
         if (r2 != EEM_OK) return r2;
         WncArgs wa;

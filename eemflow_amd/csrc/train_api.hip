@@ -390,7 +390,7 @@ static int forward_train_impl(eemflow_ctx* c, const float* e1, const float* e2, 
             zero->done = true;
         }
         if ((rc = ensure_train_wino(c, batch, wst)) != EEM_OK) return rc;
-        if (dec_wnc_wanted(c, s.gw) && (rc = ensure_dec_wnc(c, wst)) != EEM_OK) return rc;
+        if (dec_wnc_wanted(c, s.gw, batch) && (rc = ensure_dec_wnc(c, wst)) != EEM_OK) return rc;
         for (int l = 0; l < ENC_NUM; ++l) {
             const float* ws;
             if (c->enc_bx3[l] && bx3_wanted(l) && (rc = ensure_bx3(c, l, wst, &ws)) != EEM_OK) return rc;
@@ -400,7 +400,7 @@ static int forward_train_impl(eemflow_ctx* c, const float* e1, const float* e2, 
         EEM_HIP_CHECK(hipStreamWaitEvent(st, c->prep_ev, 0));
     } else {
         if ((rc = ensure_train_wino(c, batch, st)) != EEM_OK) return rc;
-        if (dec_wnc_wanted(c, s.gw) && (rc = ensure_dec_wnc(c, st)) != EEM_OK) return rc;
+        if (dec_wnc_wanted(c, s.gw, batch) && (rc = ensure_dec_wnc(c, st)) != EEM_OK) return rc;
         if ((rc = er_pad2_launch(e1, e2, c->padded.p, B * c->cin0, in_h, in_w, c->pad[0], c->pad[1], c->pad[2], c->pad[3], st)) != EEM_OK) return rc;
     }
     Hook hk;

@@ -80,6 +80,7 @@ def test_c4_training_hrem_1280x720_batch8_vs_oracle(monkeypatch):
     # the encoder's Winograd form follows the batch (F(4x4,3x3) on every stride-1 layer from batch 4 on, csrc/api_internal.h
     # f4_mask); the shard identities below compare batch 8 with batches of 2, so the form is pinned (read when the weights load)
     monkeypatch.setenv("EEM_WINO4_LAYERS", "7")
+    monkeypatch.setenv("EEM_DEC_WNC", "1")           # (the decoders' wide convs too: Winograd kernel from four samples per launch on)
     b, h, w = 8, 720, 1280
     net, sd = make_net(111)
     net.change_imagesize((h, w))

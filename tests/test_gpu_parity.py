@@ -201,7 +201,7 @@ def test_bf16_piece_stride2_kernel_equals_the_fp32_one(monkeypatch, b, h, w):
 def test_decoder_wide_convs_on_the_winograd_kernel_equal_the_small_grid_ones(monkeypatch, b, h, w):
     """The decoders' conv1 69 -> 100 and conv5 100 -> 64 (EEMFlow.py:38-71) run on the Winograd F(2x2) kernel of conv_wnc.hip where the
     1/64 grid's rows are 16-byte multiples - all three decoders' 32-cout slices as the jobs of one launch, the streams packed from the
-    device-resident weights (ensure_dec_wnc); EEM_DEC_WNC=0 (read per call) keeps the small-grid kernel.  The same convolution in
+    device-resident weights (ensure_dec_wnc) from four samples per launch on; EEM_DEC_WNC=1 / 0 (read per call): at every batch / never.  The same convolution in
     another arithmetic: the decoder outputs agree to summation-order round-off, the flow far inside the 1e-4 budget; and against the
     oracle.  After new weights arrive on the device (load_state_dict) the streams are re-packed: same agreement with the other seed."""
     from oracle import eemflow_oracle as O

@@ -82,6 +82,42 @@ def test_gradients_vs_oracle_autograd(b, h, w, size):
         assert errs[0][1].rsplit(".", 1)[0] == errs[1][1].rsplit(".", 1)[0], errs[:2]
 
 
+def test_decoder_winograd_streams_follow_the_optimizer_steps(monkeypatch):
+    """The decoders' conv1 / conv5 run on the Winograd kernel from four samples per launch on where the 1/64 grid's rows are 16-byte
+    multiples (256 x 256: 4 x 4 cells); its streams are packed on the device from the flat weights, so every optimizer step has to mark
+    them stale (refresh_wino) and the next forward - training or validation - re-pack them: three steps with a real learning rate, then the
+    flow of a validation forward against the same weights through the other kernel (EEM_DEC_WNC is read per call; graphs off) - stale
+    streams would be off by the three steps' updates - and the two forms' weight trajectories against each other: the forms differ in
+    rounding only, so the trajectories stay within a percent of the distance travelled."""
+    b, h, w = 4, 256, 256
+    e1, e2 = (torch.from_numpy(a) for a in synthetic_voxel_pair(71, b, h, w))
+    gt, valid = (torch.from_numpy(a) for a in synthetic_gt(72, b, h, w))
+    flows, weights = {}, {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("EEM_DEC_WNC", mode)
+        net, sd = make_net(73)
+        net.use_graph = False
+        net.change_imagesize((h, w))
+        tr = EEMFlowTrainer(net, lr=2e-2, wdecay=1e-4, clip=1.0)          # (OneCycle starts at lr / 25: ~8e-4 per step)
+        for _ in range(3):
+            tr.step(e1.to(DEV), e2.to(DEV), gt.to(DEV), valid.to(DEV))
+        with torch.no_grad():
+            after = net(e1.to(DEV), e2.to(DEV))[1][0].clone()
+            monkeypatch.setenv("EEM_DEC_WNC", "0" if mode == "1" else "1")            # the same weights through the other kernel
+            other = net(e1.to(DEV), e2.to(DEV))[1][0].clone()
+            monkeypatch.setenv("EEM_DEC_WNC", mode)
+        assert not torch.equal(after, other)                                       # (the switch did switch)
+        assert float((after - other).abs().max()) < 2e-5, mode                      # stale streams would be off by the three steps' updates
+        flows[mode] = after.cpu()
+        tr.sync_parameters()
+        weights[mode] = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    fresh = {k: torch.as_tensor(v).cpu() for k, v in sd.items()}
+    moved = max(float((weights["1"][k] - fresh[k]).abs().max()) for k in fresh)
+    drift = max(float((weights["1"][k] - weights["0"][k]).abs().max()) for k in fresh)
+    assert moved > 1e-3 and drift < 1e-2 * moved                                    # both forms train the same model
+    assert float((flows["1"] - flows["0"]).abs().max()) < 5e-2 * max(1.0, float(flows["0"].abs().max()))
+
+
 def test_weight_gradients_on_the_side_stream_equal_the_single_stream_pass(monkeypatch):
     """Weight / bias gradients run on a context-owned side stream behind events (they are leaves of the data-gradient chain);
     EEM_NO_WGRAD_STREAM=1 keeps them on the caller's stream.  Same gradients (summation order of the split-K atomics aside), repeated

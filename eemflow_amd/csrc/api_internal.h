@@ -559,9 +559,9 @@ int run_decoders(eemflow_ctx* c, int k0, int k1, const float* const cat[3], int 
     int rc;
     TailConvLaunch L;
     L.batch = batch; L.h = h; L.w = w; L.ksize = 3;
-    // conv1: 69 -> 100
-    // conv1 and conv5 on the Winograd kernel where the grid allows (dec_wnc_wanted): the decoders' 32-cout slices as the jobs of one launch
-    auto wide = [&](const char* name, int cin, int cout, const float* const* in, float* const* outp, const size_t (*woff)[4], const size_t (*woff5)[2],
+    // conv1 (69 -> 100) and conv5 (100 -> 64) on the Winograd kernel where the grid and the batch allow (dec_wnc_wanted): the decoders' 32-cout
+    // slices as the jobs of one launch.  woff: the streams' offsets in dec_wnc, wper per decoder; *done says whether the launch was made
+    auto wide = [&](const char* name, int cin, int cout, const float* const* in, float* const* outp, const size_t* woff, int wper,
                     const size_t* boff, bool* done) -> int {
         *done = false;
         if (!dec_wnc_wanted(c, w, batch)) return EEM_OK;
@@ -578,7 +578,7 @@ int run_decoders(eemflow_ctx* c, int k0, int k1, const float* const cat[3], int 
                 if (wa.njobs == WNC_MAX_JOBS) return EEM_OK;           // (more decoders than a launch has jobs: the small-grid kernel)
                 WncJob& J = wa.job[wa.njobs++];
                 J.in = in[k]; J.in_ctotal = cin; J.in_coff = 0;
-                J.w = c->dec_wnc + (woff ? woff[k][s] : woff5[k][s]); J.bias = c->dec_wnc + boff[k] + 32 * s;
+                J.w = c->dec_wnc + woff[k * wper + s]; J.bias = c->dec_wnc + boff[k] + 32 * s;
                 J.out = outp[k]; J.out_ctotal = cout; J.out_coff = 32 * s; J.out_cmul = 1; J.cout = cout - 32 * s < 32 ? cout - 32 * s : 32;
                 J.res = nullptr;
             }
@@ -595,7 +595,7 @@ int run_decoders(eemflow_ctx* c, int k0, int k1, const float* const cat[3], int 
     bool on_wnc = false;
     {
         float* outs[3] = {c->ta[0].p, c->ta[1].p, c->ta[2].p};
-        if ((rc = wide("dec.conv1 69->100", kDecIn, kDecW, cat, outs, c->dec_w1, nullptr, c->dec_b1, &on_wnc)) != EEM_OK) return rc;
+        if ((rc = wide("dec.conv1 69->100", kDecIn, kDecW, cat, outs, &c->dec_w1[0][0], 4, c->dec_b1, &on_wnc)) != EEM_OK) return rc;
     }
     if (!on_wnc) {
         L.njobs = 0;
@@ -623,7 +623,7 @@ int run_decoders(eemflow_ctx* c, int k0, int k1, const float* const cat[3], int 
     {
         const float* ins[3] = {c->td[0].p, c->td[1].p, c->td[2].p};
         float* outs[3] = {c->t64[0].p, c->t64[1].p, c->t64[2].p};
-        if ((rc = wide("dec.conv5 100->64", kDecW, 64, ins, outs, nullptr, c->dec_w5, c->dec_b5, &on_wnc)) != EEM_OK) return rc;
+        if ((rc = wide("dec.conv5 100->64", kDecW, 64, ins, outs, &c->dec_w5[0][0], 2, c->dec_b5, &on_wnc)) != EEM_OK) return rc;
     }
     if (!on_wnc) {
         L.njobs = 0;
